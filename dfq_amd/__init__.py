@@ -1,0 +1,8 @@
+"""dfq_amd -- MI355X-native DFQ calibration engine (weight equalization, bias correction, fake-quant).
+
+Drop-in for the calibration hot path of jakc4103/DFQ: the module layout mirrors the reference
+(``dfq``, ``improve_dfq``, ``utils.quantize``, ``utils.layer_transform``, ``utils.relation``) so that
+``main_cls.py`` only has to change its import prefix.  All arithmetic runs in hand-written HIP
+kernels (gfx950) behind the C ABI declared in ``include/dfq_hip.h``.
+"""
+__version__ = '0.1.0'

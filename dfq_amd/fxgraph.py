@@ -1,0 +1,127 @@
+"""torch.fx tracer that emits the reference's (graph, bottoms) dict pair.
+
+The reference obtains these dicts from the third-party ``PyTransformer`` tracer
+(main_cls.py:132-135; the submodule is not vendored, .gitmodules:1-3).  Only the *format* matters
+to the calibration passes, and it is fixed by their call sites:
+
+  * ``graph``   : OrderedDict key -> nn.Module | str, in forward order, first entry
+                  ``graph['Data'] = 'Data'`` (relation.py:52, dfq.py:197);
+  * ``bottoms`` : OrderedDict key -> list[key] | None (None only for 'Data');
+  * tensor ops are string-valued entries whose key *contains* 'add', 'cat', 'F.pad',
+    'torch.mean', 'F.interpolate' (layer_transform.py:316-326, relation.py:42-43).
+
+Shape-only ops (view/size/flatten/getitem/contiguous/dropout-in-eval...) are transparent: their
+consumers are wired to their producer, which is how the reference graphs look
+(images/graph_cls.png ends ... ReLU -> torch.mean -> Linear).
+"""
+from __future__ import annotations
+
+import operator
+from collections import OrderedDict
+
+import torch
+import torch.fx
+import torch.nn as nn
+import torch.nn.functional as F
+
+_FUNC_NAMES = {
+    operator.add: 'add', torch.add: 'add', operator.iadd: 'add',
+    torch.cat: 'torch.cat', torch.mean: 'torch.mean',
+    F.interpolate: 'F.interpolate', F.pad: 'F.pad', F.softmax: 'F.softmax',
+}
+_METHOD_NAMES = {'add': 'add', 'add_': 'add', 'mean': 'torch.mean'}
+_TRANSPARENT_FUNCS = {torch.flatten, operator.getitem, getattr}
+_TRANSPARENT_METHODS = {'view', 'reshape', 'flatten', 'contiguous', 'size', 'squeeze', 'unsqueeze',
+                        'float', 'detach', 'clone'}
+
+
+class _LeafTracer(torch.fx.Tracer):
+    """Every module that owns no sub-modules (or lives in torch.nn) is a leaf."""
+
+    def is_leaf_module(self, m, qualname):
+        if isinstance(m, (nn.Sequential, nn.ModuleList, nn.ModuleDict)):
+            return False
+        if m.__module__.startswith('torch.nn') or len(list(m.children())) == 0:
+            return True
+        return False
+
+
+def _tensor_inputs(node):
+    out = []
+
+    def visit(a):
+        if isinstance(a, torch.fx.Node):
+            out.append(a)
+        elif isinstance(a, (list, tuple)):
+            for x in a:
+                visit(x)
+    for a in node.args:
+        visit(a)
+    for a in node.kwargs.values():
+        visit(a)
+    return out
+
+
+def trace(model, key_style='name'):
+    """Return (graph, bottoms) for ``model``.
+
+    key_style 'name' keys module nodes as '<ClassName>_<index>' strings; 'module' keys them by
+    the module object itself (any hashable works for the calibration passes).
+    """
+    tracer = _LeafTracer()
+    fx_graph = tracer.trace(model)
+    modules = dict(model.named_modules())
+
+    graph = OrderedDict()
+    bottoms = OrderedDict()
+    graph['Data'] = 'Data'
+    bottoms['Data'] = None
+    alias = {}                    # fx node -> key (or the key of the producer it is transparent to)
+    counter = 1
+
+    def key_of(n):
+        return alias[n]
+
+    for n in fx_graph.nodes:
+        if n.op == 'placeholder':
+            alias[n] = 'Data'
+            continue
+        if n.op == 'output':
+            continue
+        ins = [i for i in _tensor_inputs(n) if i in alias]
+        if n.op == 'call_module':
+            m = modules[n.target]
+            if isinstance(m, (nn.Dropout, nn.Dropout2d, nn.Identity)):
+                alias[n] = key_of(ins[0])
+                continue
+            key = '{}_{}'.format(type(m).__name__, counter) if key_style == 'name' else m
+            graph[key] = m
+        elif n.op == 'call_function':
+            if n.target in _FUNC_NAMES:
+                key = '{}_{}'.format(_FUNC_NAMES[n.target], counter)
+                graph[key] = key
+            else:
+                if not ins:
+                    continue
+                alias[n] = key_of(ins[0])
+                continue
+        elif n.op == 'call_method':
+            if n.target in _METHOD_NAMES and n.target not in _TRANSPARENT_METHODS:
+                key = '{}_{}'.format(_METHOD_NAMES[n.target], counter)
+                graph[key] = key
+            else:
+                if not ins:
+                    continue
+                alias[n] = key_of(ins[0])
+                continue
+        else:                      # get_attr etc.
+            continue
+        bots = []
+        for i in ins:
+            k = key_of(i)
+            if k not in bots or n.op != 'call_module':
+                bots.append(k)
+        bottoms[key] = bots
+        alias[n] = key
+        counter += 1
+    return graph, bottoms

@@ -1,0 +1,395 @@
+"""Pin the oracle against the UNMODIFIED reference and write the golden fixtures.
+
+Runs only in the build container (needs /root/reference, which does not exist on the GPU box):
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/make_golden.py [--full]
+
+For every case it runs the reference implementation (dfq.py, utils/quantize.py,
+utils/layer_transform.py, utils/relation.py imported from /root/reference) and this repo's oracle
+on the same seeded inputs, ASSERTS agreement (bit-exact where the contract is bit-exact, 1e-5
+otherwise) and stores the reference's outputs under tests/golden/ so the CPU test-suite and the
+GPU parity tests can check against them without the reference being present.
+
+  tests/golden/kat_fake_quant.npz     UniformQuantize known-answer vectors (bit-exact contract)
+  tests/golden/kat_le_pairs.npz       _layer_equalization on every pairing case (incl. dead channels)
+  tests/golden/net_<name>_s<seed>.npz full pipeline on the tiny nets: inputs + per-stage outputs
+  tests/golden/full_<name>.npz        (--full) MobileNetV2 / ResNet-18 / DeepLab summaries
+"""
+from __future__ import annotations
+
+import argparse
+import copy
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = '/root/reference'
+sys.path.insert(0, ROOT)
+sys.path.insert(1, REF)
+sys.dont_write_bytecode = True
+
+import torch                                   # noqa: E402
+import torch.nn as nn                          # noqa: E402
+
+import dfq as ref_dfq                          # noqa: E402  (reference)
+from utils import quantize as ref_q            # noqa: E402  (reference)
+from utils import layer_transform as ref_lt    # noqa: E402  (reference)
+from utils import relation as ref_rel          # noqa: E402  (reference)
+
+from oracle import dfq_oracle as orc           # noqa: E402
+from oracle import graphspec                   # noqa: E402
+from dfq_amd import synthetic                  # noqa: E402
+
+GOLD = os.path.join(ROOT, 'tests', 'golden')
+TARG = [nn.Conv2d, nn.Linear]
+F32 = np.float32
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=F32).view(np.int32)
+
+
+def assert_bitexact(a, b, what):
+    a = np.asarray(a, dtype=F32)
+    b = np.asarray(b, dtype=F32)
+    same = (bits(a) == bits(b)) | (np.isnan(a) & np.isnan(b))
+    assert same.all(), '{}: {} of {} elements differ (max abs {})'.format(
+        what, int((~same).sum()), a.size, float(np.nanmax(np.abs(a - b))))
+
+
+def assert_close(a, b, what, tol=1e-5):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    err = np.abs(a - b) / np.maximum(1.0, np.abs(b))
+    assert np.nanmax(err) <= tol, '{}: max err {}'.format(what, np.nanmax(err))
+    return float(np.nanmax(err)) if err.size else 0.0
+
+
+# ------------------------------------------------------------------------------------------
+def kat_fake_quant():
+    rng = np.random.default_rng(1234)
+    out = {}
+    cases = []
+    i = 0
+    for n, bits_, sym, dist in [
+        (4096, 8, False, 'normal'), (4096, 8, True, 'normal'), (1000, 16, False, 'normal'),
+        (1000, 16, True, 'uniform'), (777, 4, False, 'uniform'), (777, 2, True, 'normal'),
+        (64, 8, False, 'const'), (64, 8, True, 'zeros'), (513, 8, False, 'ties'),
+        (300, 8, False, 'wide'), (300, 8, True, 'tinyrange'),
+    ]:
+        if dist == 'normal':
+            x = rng.standard_normal(n).astype(F32)
+        elif dist == 'uniform':
+            x = rng.uniform(-3, 5, n).astype(F32)
+        elif dist == 'const':
+            x = np.full(n, 0.37, dtype=F32)
+        elif dist == 'zeros':
+            x = np.zeros(n, dtype=F32)
+        elif dist == 'ties':                     # values that land exactly on .5 code boundaries
+            x = (np.arange(n, dtype=F32) * F32(0.5)).astype(F32)
+        elif dist == 'wide':
+            x = (rng.standard_normal(n) * 1e4).astype(F32)
+        else:
+            x = (rng.standard_normal(n) * 1e-9).astype(F32)
+        mn, mx = float(x.min()), float(x.max())
+        if dist == 'ties':
+            mn, mx = 0.0, 255.0
+        t = torch.from_numpy(x.copy())
+        y_ref = ref_q.UniformQuantize().apply(t, bits_, mn, mx, False, sym).numpy()
+        y_orc = orc.uniform_quantize(x, bits_, mn, mx, sym)
+        assert_bitexact(y_orc, y_ref, 'fake_quant case {}'.format(i))
+        out['x{}'.format(i)] = x
+        out['y{}'.format(i)] = y_ref
+        cases.append((bits_, int(sym), mn, mx))
+        i += 1
+    # tensor-path (min/max None): bias fake-quant call sites quantize.py:198,226,311,335
+    for n, bits_ in [(32, 16), (960, 16), (5, 8)]:
+        x = rng.standard_normal(n).astype(F32)
+        y_ref = ref_q.quantize(torch.from_numpy(x.copy()), num_bits=bits_).numpy()
+        y_orc = orc.uniform_quantize(x, bits_)
+        assert_bitexact(y_orc, y_ref, 'fake_quant tensor-path n={}'.format(n))
+        out['x{}'.format(i)] = x
+        out['y{}'.format(i)] = y_ref
+        cases.append((bits_, 0, float('nan'), float('nan')))
+        i += 1
+    out['cases'] = np.array(cases, dtype=np.float64)
+    np.savez_compressed(os.path.join(GOLD, 'kat_fake_quant.npz'), **out)
+    print('kat_fake_quant: {} cases bit-exact'.format(i))
+
+
+# ------------------------------------------------------------------------------------------
+LE_CASES = [
+    # name, W1 shape, W2 shape, signed, eps, tweak
+    ('pw_dw', (24, 6, 1, 1), (24, 1, 3, 3), False, 0, None),
+    ('dw_pw', (24, 1, 3, 3), (10, 24, 1, 1), False, 0, None),
+    ('pw_pw', (20, 12, 1, 1), (9, 20, 1, 1), False, 0, None),
+    ('c3_c3', (16, 8, 3, 3), (12, 16, 3, 3), False, 0, None),
+    ('c3_c3_signed', (16, 8, 3, 3), (12, 16, 3, 3), True, 0, None),
+    ('stem_dw', (32, 3, 3, 3), (32, 1, 3, 3), False, 0, None),
+    ('pw_fc', (40, 12, 1, 1), (10, 40), False, 0, None),
+    ('grouped', (16, 4, 3, 3), (32, 4, 3, 3), False, 0, None),          # second layer groups=4
+    ('dw_mult', (8, 4, 1, 1), (16, 1, 3, 3), False, 0, None),           # depthwise, multiplier 2
+    ('dead_first', (12, 5, 1, 1), (7, 12, 1, 1), False, 0, 'dead_first'),
+    ('dead_second', (12, 5, 1, 1), (7, 12, 1, 1), False, 0, 'dead_second'),
+    ('eps', (12, 5, 1, 1), (7, 12, 1, 1), False, 1e-6, None),
+    ('signed_eps', (12, 5, 1, 1), (7, 12, 1, 1), True, 1e-6, 'dead_first'),
+    ('no_bn_no_bias', (12, 5, 1, 1), (7, 12, 1, 1), False, 0, 'nobn'),
+]
+
+
+def kat_le_pairs():
+    rng = np.random.default_rng(99)
+    out = {}
+    names = []
+    worst = 0.0
+    nexact = 0
+    for name, s1, s2, signed, eps, tweak in LE_CASES:
+        w1 = rng.standard_normal(s1).astype(F32)
+        w2 = (rng.standard_normal(s2) * 0.3).astype(F32)
+        b1 = rng.standard_normal(s1[0]).astype(F32)
+        bw = np.abs(rng.standard_normal(s1[0])).astype(F32)
+        bb = rng.standard_normal(s1[0]).astype(F32)
+        if tweak == 'dead_first':
+            w1[3] = 0
+        if tweak == 'dead_second':
+            w2.reshape(s2[0], s2[1], -1)[:, 5] = 0
+        use_bn = tweak != 'nobn'
+        t = [torch.from_numpy(a.copy()) for a in (w1, w2, b1, bw, bb)]
+        with torch.no_grad():
+            _, _, _, S_ref = ref_dfq._layer_equalization(
+                t[0], t[1], t[2] if use_bn else None, t[3] if use_bn else None,
+                t[4] if use_bn else None, signed=signed, eps=eps)
+        o = [a.copy() for a in (w1, w2, b1, bw, bb)]
+        S_orc = orc.layer_equalization(o[0], o[1], o[2] if use_bn else None,
+                                       o[3] if use_bn else None, o[4] if use_bn else None,
+                                       signed=signed, eps=eps)
+        exact = np.array_equal(bits(S_orc), bits(S_ref.numpy()))
+        nexact += int(exact)
+        for a, b, w in zip(o, t, ('w1', 'w2', 'b1', 'bnw', 'bnb')):
+            if exact:
+                assert_bitexact(a, b.numpy(), '{} {}'.format(name, w))
+            else:
+                worst = max(worst, assert_close(a, b.numpy(), '{} {}'.format(name, w)))
+        assert_close(S_orc, S_ref.numpy(), name + ' S')
+        for a, w in zip((w1, w2, b1, bw, bb), ('w1', 'w2', 'b1', 'bnw', 'bnb')):
+            out['{}.in.{}'.format(name, w)] = a
+        for b, w in zip(t, ('w1', 'w2', 'b1', 'bnw', 'bnb')):
+            out['{}.out.{}'.format(name, w)] = b.numpy()
+        out['{}.out.S'.format(name)] = S_ref.numpy()
+        out['{}.cfg'.format(name)] = np.array([int(signed), eps, int(use_bn)], dtype=np.float64)
+        names.append(name)
+    out['names'] = np.array(names)
+    np.savez_compressed(os.path.join(GOLD, 'kat_le_pairs.npz'), **out)
+    print('kat_le_pairs: {} cases, {} bit-exact, worst err of the rest {:.2e}'.format(
+        len(names), nexact, worst))
+
+
+# ------------------------------------------------------------------------------------------
+def snapshot(graph):
+    snap = {}
+    for i, k in enumerate(graph):
+        m = graph[k]
+        if type(m) in TARG:
+            snap['L{}.w'.format(i)] = m.weight.detach().numpy().copy()
+            if m.bias is not None:
+                snap['L{}.b'.format(i)] = m.bias.detach().numpy().copy()
+        elif type(m) == nn.BatchNorm2d and hasattr(m, 'fake_weight'):
+            snap['L{}.fw'.format(i)] = m.fake_weight.numpy().copy()
+            snap['L{}.fb'.format(i)] = m.fake_bias.numpy().copy()
+    return snap
+
+
+def spec_snapshot(spec):
+    snap = {}
+    for i, k in enumerate(spec.order):
+        n = spec.nodes[k]
+        if n.kind == 'targ':
+            snap['L{}.w'.format(i)] = n.weight.copy()
+            if n.bias is not None:
+                snap['L{}.b'.format(i)] = n.bias.copy()
+        elif n.kind == 'bn' and n.fake_weight is not None:
+            snap['L{}.fw'.format(i)] = n.fake_weight.copy()
+            snap['L{}.fb'.format(i)] = n.fake_bias.copy()
+    return snap
+
+
+def compare_snap(a, b, what, exact=False, tol=1e-5):
+    assert set(a) == set(b), '{}: key sets differ: {}'.format(what, set(a) ^ set(b))
+    worst = 0.0
+    for k in a:
+        if exact:
+            assert_bitexact(a[k], b[k], '{} {}'.format(what, k))
+        else:
+            worst = max(worst, assert_close(a[k], b[k], '{} {}'.format(what, k), tol))
+    return worst
+
+
+def ref_le_fixed_sweeps(graph, relations, n_sweeps, signed=False):
+    """Drive dfq._layer_equalization over the relations exactly as dfq.py:85-101 does, for a
+    fixed number of sweeps (the reference loop has no sweep cap)."""
+    with torch.no_grad():
+        for _ in range(n_sweeps):
+            for rr in relations:
+                lf, ls, bn = rr.get_idxs()
+                if graph[lf].bias is None:
+                    graph[lf].bias = nn.Parameter(torch.zeros(graph[lf].weight.size(0)), requires_grad=False)
+                graph[lf].weight, graph[ls].weight, graph[lf].bias, S = ref_dfq._layer_equalization(
+                    graph[lf].weight, graph[ls].weight, graph[lf].bias,
+                    graph[bn].fake_weight, graph[bn].fake_bias, signed=signed)
+                rr.set_scale_vec(S)
+
+
+def count_ref_sweeps():
+    """Wrap the reference's per-sweep deepcopy to count sweeps without touching its code."""
+    counter = {'n': 0}
+    orig = copy.deepcopy
+
+    def counting(x, *a, **k):
+        if isinstance(x, dict) and 'Data' in x:
+            counter['n'] += 1
+        return orig(x, *a, **k)
+    return counter, counting, orig
+
+
+def run_net(name, seed, absorption=False, signed=False, fixed_sweeps=None, save_inputs=True,
+            prefix='net'):
+    t0 = time.time()
+    model, graph, bottoms = synthetic.build(name, seed=seed)
+    spec0 = graphspec.from_torch(graph, bottoms, TARG)
+    out = {}
+    if save_inputs:
+        for i, k in enumerate(spec0.order):
+            n = spec0.nodes[k]
+            if n.kind == 'targ':
+                out['in.L{}.w'.format(i)] = n.weight
+                if n.bias is not None:
+                    out['in.L{}.b'.format(i)] = n.bias
+            elif n.kind == 'bn':
+                out['in.L{}.bn'.format(i)] = np.stack([n.gamma, n.beta, n.mean, n.var])
+
+    # ---- reference pipeline (main_cls.py:149-181) ----
+    ref_lt.merge_batchnorm(model, graph, bottoms, TARG)
+    s_merge = snapshot(graph)
+    rels = ref_rel.create_relation(graph, bottoms, TARG, delete_single=False)
+    keys = list(graph.keys())
+    rel_idx = [(keys.index(r.get_idxs()[0]), keys.index(r.get_idxs()[1]), keys.index(r.get_idxs()[2]))
+               for r in rels]
+    if fixed_sweeps is None:
+        counter, counting, orig = count_ref_sweeps()
+        copy.deepcopy = counting
+        try:
+            ref_dfq.cross_layer_equalization(graph, rels, TARG, converge_thres=2e-7, signed=signed)
+        finally:
+            copy.deepcopy = orig
+        n_sweeps = counter['n']
+    else:
+        ref_le_fixed_sweeps(graph, rels, fixed_sweeps, signed=signed)
+        n_sweeps = fixed_sweeps
+    t_le = time.time() - t0
+    s_le = snapshot(graph)
+    S_ref = [r.get_scale_vec().numpy().copy() for r in rels]
+    if absorption:
+        ref_dfq.bias_absorption(graph, rels, bottoms, 3)
+    s_abs = snapshot(graph)
+    t1 = time.time()
+    ref_dfq.bias_correction(graph, bottoms, TARG, signed=signed)
+    t_bc = time.time() - t1
+    s_bc = snapshot(graph)
+    ref_lt.quantize_targ_layer(graph, 8, 16, TARG)
+    s_q = snapshot(graph)
+
+    # ---- oracle pipeline on the same inputs ----
+    spec = spec0.clone()
+    orc.merge_batchnorm(spec)
+    w = compare_snap(spec_snapshot(spec), s_merge, name + ' merge_bn', tol=1e-6)
+    orels = orc.create_relation(spec)
+    assert [(spec.order.index(a), spec.order.index(b), spec.order.index(c)) for a, b, c in orels] == rel_idx, \
+        'create_relation mismatch'
+    n_orc, S_orc = orc.cross_layer_equalization(spec, orels, signed=signed, max_sweeps=fixed_sweeps)
+    # force the same sweep count when the data-dependent exit differs by a sweep or two
+    if n_orc != n_sweeps:
+        print('  note: oracle stopped after {} sweeps, reference after {}; re-running oracle pinned'.format(
+            n_orc, n_sweeps))
+        spec = spec0.clone()
+        orc.merge_batchnorm(spec)
+        n_orc2, S_orc = orc.cross_layer_equalization(spec, orels, signed=signed, max_sweeps=n_sweeps,
+                                                     converge_thres=-1.0, converge_count=10 ** 9)
+        assert n_orc2 == n_sweeps
+    w_le = compare_snap(spec_snapshot(spec), s_le, name + ' LE')
+    for a, b in zip(S_orc, S_ref):
+        assert_close(a, b, name + ' S_cum')
+    if absorption:
+        orc.bias_absorption(spec, orels, 3)
+        compare_snap(spec_snapshot(spec), s_abs, name + ' absorption')
+    # BC and quantisation are checked from the REFERENCE's post-LE state so that each stage is
+    # compared on identical inputs.
+    spec_bc = spec_from_snapshot(spec, s_abs)
+    orc.bias_correction(spec_bc, signed=signed)
+    w_bc = compare_snap(spec_snapshot(spec_bc), s_bc, name + ' BC')
+    spec_q = spec_from_snapshot(spec, s_bc)
+    orc.quantize_targ_layer(spec_q, 8, 16)
+    compare_snap(spec_snapshot(spec_q), s_q, name + ' quantize_targ_layer', exact=True)
+
+    out['n_sweeps'] = np.array(n_sweeps)
+    out['oracle_sweeps'] = np.array(n_orc)
+    out['relations'] = np.array(rel_idx, dtype=np.int64)
+    out['cfg'] = np.array([int(absorption), int(signed)])
+    for i, s in enumerate(S_ref):
+        out['S{}'.format(i)] = s
+    if save_inputs:
+        for stage, snap in (('merge', s_merge), ('le', s_le), ('abs', s_abs), ('bc', s_bc), ('q', s_q)):
+            for k, v in snap.items():
+                out['{}.{}'.format(stage, k)] = v
+    else:
+        for stage, snap in (('le', s_le), ('bc', s_bc), ('q', s_q)):
+            for k, v in snap.items():
+                if k.endswith('.w'):
+                    v64 = v.astype(np.float64)
+                    out['{}.{}.stats'.format(stage, k)] = np.array(
+                        [v64.min(), v64.max(), v64.sum(), np.abs(v64).sum(), (v64 * v64).sum()])
+                else:
+                    out['{}.{}'.format(stage, k)] = v
+    tag = '{}_{}_s{}{}{}'.format(prefix, name, seed, '_abs' if absorption else '', '_signed' if signed else '')
+    np.savez_compressed(os.path.join(GOLD, tag + '.npz'), **out)
+    print('{}: {} sweeps (oracle {}), {} relations; LE err {:.1e}, BC err {:.1e}; ref LE {:.1f}s BC {:.2f}s'.format(
+        tag, n_sweeps, n_orc, len(rels), w_le, w_bc, t_le, t_bc))
+
+
+def spec_from_snapshot(spec, snap):
+    s = spec.clone()
+    for i, k in enumerate(s.order):
+        n = s.nodes[k]
+        if n.kind == 'targ':
+            n.weight = snap['L{}.w'.format(i)].copy()
+            n.bias = snap['L{}.b'.format(i)].copy() if 'L{}.b'.format(i) in snap else None
+        elif n.kind == 'bn' and 'L{}.fw'.format(i) in snap:
+            n.fake_weight = snap['L{}.fw'.format(i)].copy()
+            n.fake_bias = snap['L{}.fb'.format(i)].copy()
+    return s
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--full', action='store_true', help='also MobileNetV2 / ResNet-18 / DeepLab (minutes)')
+    args = ap.parse_args()
+    os.makedirs(GOLD, exist_ok=True)
+    torch.set_num_threads(os.cpu_count())
+    kat_fake_quant()
+    kat_le_pairs()
+    run_net('tiny_mobile', 0)
+    run_net('tiny_mobile', 1, absorption=True)
+    run_net('tiny_mobile', 2, signed=True)
+    run_net('tiny_res', 0)
+    run_net('tiny_cat', 0)
+    run_net('tiny_cat', 3, absorption=True)
+    if args.full:
+        run_net('resnet18', 0, save_inputs=False, prefix='full')
+        run_net('mobilenet_v2', 0, save_inputs=False, prefix='full')
+        run_net('deeplab_mnv2', 0, fixed_sweeps=12, save_inputs=False, prefix='full')
+
+
+if __name__ == '__main__':
+    main()
