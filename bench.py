@@ -1,0 +1,224 @@
+#!/usr/bin/env python
+"""Headline benchmark: conv weights calibrated per second by one LE+BC pass over a synthetic
+MobileNetV2 (BASELINE.json configs[1]: `--relu --equalize --correction`, 53 layers).
+
+  python bench.py --gpus 1 --steps 20 --warmup 3
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = one complete pass of the hot path over one network whose folded weights are already
+resident in HBM: cross_layer_equalization for exactly the number of sweeps the reference's
+convergence test needs on this input (measured once, untimed, by the device-side loop) followed by
+bias_correction.  Every step runs on its own replica of the network (in-place algorithm, so a used
+replica is "calibrated"; 288 GB of HBM hold hundreds of replicas), nothing is restored or skipped
+inside the timed region and the host never synchronises between launches.
+
+Multi-GPU: the unit of work is a network; rank r calibrates its own replicas (independent
+objects, no data-path collective), `value` = weights calibrated by all ranks / max-over-ranks time
+-> "scaling": "weak".  The sharded single-network mode with its RCCL exchange lives in
+dfq_amd/sharded.py and is covered by tests, not by this line.
+
+One JSON line on rank 0, with `roofline` (dominant kernel le_level_kernel: algorithmic bytes per
+launch / HIP-event duration per launch) and `cpu_baseline` (the numpy oracle, i.e. a vectorised
+CPU port of the reference's algorithm, timed on this host).
+"""
+from __future__ import annotations
+
+import argparse
+import copy
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch                      # noqa: E402
+import torch.nn as nn             # noqa: E402
+
+TARG = [nn.Conv2d, nn.Linear]
+HBM_PEAK_GBS = 8000.0             # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--net', default='mobilenet_v2', choices=['mobilenet_v2', 'resnet18', 'deeplab_mnv2', 'tiny_mobile'])
+    ap.add_argument('--sweeps', type=int, default=0, help='pin the LE sweep count (0 = what the convergence test needs)')
+    ap.add_argument('--cpu-seconds', type=float, default=10.0, help='CPU-baseline budget (0 disables)')
+    ap.add_argument('--no-roofline', action='store_true')
+    return ap.parse_args()
+
+
+def prepare(net, seed, dev):
+    """Random-init network -> device -> BN folded -> relation list (untimed set-up)."""
+    from dfq_amd import synthetic
+    from dfq_amd.utils import layer_transform as lt
+    from dfq_amd.utils import relation as rel
+    model, graph, bottoms = synthetic.build(net, seed=seed)
+    model.to(dev)
+    lt.merge_batchnorm(model, graph, bottoms, TARG)
+    rels = rel.create_relation(graph, bottoms, TARG, delete_single=False)
+    return model, graph, bottoms, rels
+
+
+def make_replica(proto):
+    from dfq_amd import dfq
+    model, graph, bottoms, rels = copy.deepcopy(proto)
+    le = dfq.build_le_plan(graph, rels, TARG)
+    bc, _ = dfq.build_bc_plan(graph, bottoms, TARG)
+    return dict(model=model, graph=graph, bottoms=bottoms, rels=rels, le=le, bc=bc)
+
+
+def cpu_baseline(net, seed, budget_s):
+    """The numpy oracle (port of dfq.py's LE + BC, vectorised over channels) on this host."""
+    from dfq_amd import synthetic
+    from oracle import dfq_oracle as orc
+    from oracle import graphspec
+    torch.set_num_threads(1)
+    model, graph, bottoms = synthetic.build(net, seed=seed)
+    spec0 = graphspec.from_torch(graph, bottoms, TARG)
+    orc.merge_batchnorm(spec0)
+    rels = orc.create_relation(spec0)
+    n_w = spec0.n_weights()
+    reps, spent, sweeps = 0, 0.0, 0
+    while reps == 0 or (spent < budget_s and reps < 64):
+        spec = spec0.clone()
+        t0 = time.perf_counter()
+        sweeps, _ = orc.cross_layer_equalization(spec, rels)
+        orc.bias_correction(spec)
+        spent += time.perf_counter() - t0
+        reps += 1
+    return dict(value=n_w * reps / spent, unit='weights/s', cores=1, kind='port',
+                sample='{} full LE({} sweeps)+BC passes of the numpy oracle over the same synthetic {} '
+                       '({} weights), {:.1f} s of CPU time'.format(reps, sweeps, net, n_w, spent)), sweeps
+
+
+def _device(local_rank):
+    assert torch.cuda.is_available(), 'bench.py needs a ROCm GPU'
+    torch.cuda.set_device(local_rank)
+    return torch.device('cuda', local_rank)
+
+
+def _sync():
+    torch.cuda.synchronize()
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('launch with torch.distributed.run --nproc-per-node {}'.format(args.gpus))
+    dev = _device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', device_id=dev)
+
+    from dfq_amd import _ffi
+    _ffi.lib()
+
+    proto = prepare(args.net, seed=rank, dev=dev)
+    n_w = sum(m.weight.numel() for m in proto[1].values() if type(m) in TARG)
+    n_layers = sum(1 for m in proto[1].values() if type(m) in TARG)
+
+    # sweep count of the reference's convergence loop on this input (device-side loop, untimed)
+    probe = make_replica(proto)
+    if args.sweeps > 0:
+        sweeps = args.sweeps
+    else:
+        sweeps = probe['le'].run()['sweeps']
+        if dist is not None:           # every rank times the same amount of work per step
+            t = torch.tensor([sweeps], device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            sweeps = int(t.item())
+    levels = probe['le'].levels
+    paired, snap = probe['le'].paired_elements, probe['le'].snapshot_elements
+
+    replicas = [make_replica(proto) for _ in range(args.steps + args.warmup)]
+
+    def step(r):
+        r['le'].enqueue(sweeps, restart=True, max_sweeps=sweeps)
+        r['bc'].run()
+
+    def fence():
+        _sync()
+        if dist is not None:
+            dist.barrier()
+        _sync()
+
+    for r in replicas[:args.warmup]:
+        step(r)
+    fence()
+    t0 = time.perf_counter()
+    for r in replicas[args.warmup:]:
+        step(r)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    done_sweeps = replicas[-1]['le'].query()['sweeps']
+    assert done_sweeps == sweeps, 'timed steps ran {} sweeps, expected {}'.format(done_sweeps, sweeps)
+    ms_per_step = elapsed * 1e3 / args.steps
+
+    out = {
+        'metric': 'conv weights calibrated/sec (LE+BC pass, MobileNetV2)' if args.net == 'mobilenet_v2'
+                  else 'conv weights calibrated/sec (LE+BC pass, {})'.format(args.net),
+        'value': n_w * world / (ms_per_step * 1e-3),
+        'unit': 'weights/s',
+        'n_gpus': world,
+        'steps': args.steps,
+        'warmup': args.warmup,
+        'ms_per_step': ms_per_step,
+        'higher_is_better': True,
+        'scaling': 'weak',
+        'vs_baseline': None,
+        'dtype': 'f32',
+        'data': 'synthetic',
+        'config': {
+            'workload': '{} --relu --equalize --correction: {} layers, {} weights, {} relations in {} launch levels, '
+                        '{} LE sweeps (reference convergence test, thres 2e-7) + bias correction; one network per '
+                        'GPU per step, weights resident in HBM'.format(args.net, n_layers, n_w, len(proto[3]), levels, sweeps),
+            'le_sweeps': sweeps,
+            'networks_per_step': world,
+        },
+    }
+
+    if rank == 0 and not args.no_roofline:
+        # dominant kernel: le_level_kernel.  Algorithmic bytes per sweep = 8 B per paired element (read
+        # + write; the ranges come from the same read) + 4 B per snapshot-arena element touched.
+        prof = make_replica(proto)['le'].profile(sweeps, max_sweeps=sweeps)
+        level_ms = sum(prof['level_ms'])
+        launches = prof['level_launches']
+        bytes_per_sweep = 8 * paired + 4 * snap
+        avg_bytes = bytes_per_sweep * sweeps / launches
+        avg_ms = level_ms / launches
+        achieved = avg_bytes / max(avg_ms * 1e-3, 1e-12) / 1e9
+        out['roofline'] = {
+            'bound': 'hbm', 'kernel': 'le_level_kernel', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+            'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+            'bytes_per_launch': avg_bytes, 'us_per_launch': avg_ms * 1e3, 'launches_timed': launches,
+            'control_us_per_sweep': prof['control_ms'] * 1e3 / sweeps,
+        }
+    if rank == 0 and world == 1 and args.cpu_seconds > 0:
+        out['cpu_baseline'], _ = cpu_baseline(args.net, 0, args.cpu_seconds)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

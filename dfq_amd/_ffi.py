@@ -1,0 +1,210 @@
+"""ctypes binding of ``libdfq_hip.so`` (C ABI: ``include/dfq_hip.h``) and the device-buffer staging
+used by every engine call.
+
+There is no CPU path: if the library or a ROCm GPU is missing, the first call raises.  PyTorch is
+used only to own device memory and the HIP stream the kernels are enqueued on.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import (POINTER, Structure, byref, c_char_p, c_double, c_float, c_int32, c_int64,
+                    c_size_t, c_void_p)
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libdfq_hip.so')
+
+c_float_p = c_void_p      # device pointers travel as opaque addresses
+c_int32_dp = c_void_p
+c_uint32_dp = c_void_p
+
+
+# ---- structs of include/dfq_hip.h ---------------------------------------------------------------
+class DfqLayer(Structure):
+    _fields_ = [('weight', c_void_p), ('bias', c_void_p), ('out_ch', c_int32),
+                ('in_per_group', c_int32), ('khkw', c_int32), ('groups', c_int32)]
+
+
+class DfqRelation(Structure):
+    _fields_ = [('first', c_int32), ('second', c_int32), ('bn_weight', c_void_p),
+                ('bn_bias', c_void_p), ('scale_cum', c_void_p)]
+
+
+class DfqLeConfig(Structure):
+    _fields_ = [('s_lo', c_float), ('s_hi', c_float), ('inv_lo', c_float), ('inv_hi', c_float),
+                ('hi_gt_lo', c_int32), ('eps', c_float), ('signed_range', c_int32),
+                ('converge_thres', c_double), ('converge_count', c_int32), ('max_sweeps', c_int32)]
+
+
+class DfqLeResult(Structure):
+    _fields_ = [('sweeps', c_int32), ('stall_count', c_int32), ('diff', c_double),
+                ('last_diff_tmp', c_double)]
+
+
+class DfqSegment(Structure):
+    _fields_ = [('data', c_void_p), ('n', c_int64), ('num_bits', c_int32), ('symmetric', c_int32),
+                ('codes', c_void_p)]
+
+
+class DfqBcSource(Structure):
+    _fields_ = [('fake_weight', c_void_p), ('fake_bias', c_void_p), ('channels', c_int32),
+                ('relu', c_int32), ('concat', c_int32)]
+
+
+class DfqBcStep(Structure):
+    _fields_ = [('layer', c_int32), ('source_begin', c_int32), ('source_count', c_int32),
+                ('next_bn_bias', c_void_p)]
+
+
+# every exported symbol: name -> (restype, argtypes).  tests/test_abi.py checks this table against
+# include/dfq_hip.h and against the symbols the shared object really exports.
+SIGNATURES = {
+    'dfq_version': (c_int32, []),
+    'dfq_last_error': (c_char_p, []),
+    'dfq_device_count': (c_int32, []),
+    'dfq_le_plan_create': (c_int32, [POINTER(DfqLayer), c_int32, POINTER(DfqRelation), c_int32, POINTER(c_void_p)]),
+    'dfq_le_plan_destroy': (None, [c_void_p]),
+    'dfq_le_plan_levels': (c_int32, [c_void_p]),
+    'dfq_le_plan_paired_elements': (c_int64, [c_void_p]),
+    'dfq_le_plan_snapshot_elements': (c_int64, [c_void_p]),
+    'dfq_le_plan_level_launches': (c_int32, [c_void_p, c_int32, POINTER(c_int64), POINTER(c_int64), POINTER(c_int32)]),
+    'dfq_le_enqueue': (c_int32, [c_void_p, POINTER(DfqLeConfig), c_int32, c_int32, c_void_p]),
+    'dfq_le_query': (c_int32, [c_void_p, c_void_p, POINTER(DfqLeResult), POINTER(c_int32)]),
+    'dfq_le_run': (c_int32, [c_void_p, POINTER(DfqLeConfig), c_void_p, POINTER(DfqLeResult)]),
+    'dfq_le_profile': (c_int32, [c_void_p, POINTER(DfqLeConfig), c_int32, c_void_p, POINTER(c_double), POINTER(c_double),
+                                 POINTER(c_int32)]),
+    'dfq_tensor_minmax': (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    'dfq_fake_quant': (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_double, c_double,
+                                 c_void_p, c_void_p, c_void_p]),
+    'dfq_sample_minmax_mean': (c_int32, [c_void_p, c_int32, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'dfq_quant_plan_create': (c_int32, [POINTER(DfqSegment), c_int32, POINTER(c_void_p)]),
+    'dfq_quant_plan_destroy': (None, [c_void_p]),
+    'dfq_quant_plan_run': (c_int32, [c_void_p, c_void_p]),
+    'dfq_quant_plan_minmax': (c_void_p, [c_void_p]),
+    'dfq_bc_plan_create': (c_int32, [POINTER(DfqLayer), c_int32, POINTER(DfqBcStep), c_int32,
+                                     POINTER(DfqBcSource), c_int32, POINTER(c_void_p)]),
+    'dfq_bc_plan_destroy': (None, [c_void_p]),
+    'dfq_bc_plan_run': (c_int32, [c_void_p, c_int32, c_void_p]),
+    'dfq_bc_plan_eps': (c_void_p, [c_void_p, c_int32]),
+    'dfq_bc_plan_correction': (c_void_p, [c_void_p, c_int32]),
+    'dfq_bc_plan_weight_elements': (c_int64, [c_void_p]),
+    'dfq_bc_plan_eps_elements': (c_int64, [c_void_p]),
+    'dfq_quant_error_scratch_bytes': (c_size_t, [c_int64, c_int64]),
+    'dfq_quant_error': (c_int32, [c_void_p, c_int64, c_int64, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
+    'dfq_scale_rows': (c_int32, [c_void_p, c_int32, c_int64, c_void_p, c_int32, c_void_p]),
+    'dfq_scale_cols': (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p]),
+    'dfq_vec_op': (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
+    'dfq_clamp': (c_int32, [c_void_p, c_int64, c_float, c_float, c_void_p]),
+    'dfq_fold_batchnorm': (c_int32, [c_void_p, c_void_p, c_int32, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_float, c_void_p, c_void_p, c_void_p]),
+    'dfq_bias_absorb': (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
+                                  c_void_p, c_float, c_void_p]),
+}
+
+
+def bind(cdll):
+    """Attach restype/argtypes of every C-ABI symbol; raises AttributeError if one is missing."""
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(cdll, name)
+        fn.restype = res
+        fn.argtypes = args
+    return cdll
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                'dfq_amd: {} is missing -- build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                '(or `make -C dfq_amd/csrc`).  There is no CPU implementation to fall back to.'.format(LIB_PATH))
+        _lib = bind(ctypes.CDLL(LIB_PATH))
+    return _lib
+
+
+class DfqError(RuntimeError):
+    pass
+
+
+def check(rc):
+    if rc != 0:
+        msg = lib().dfq_last_error()
+        raise DfqError('libdfq_hip error {}: {}'.format(rc, msg.decode() if msg else '?'))
+
+
+def target_device():
+    """The HIP device the engine runs on.  No GPU -> error (never a CPU fallback)."""
+    if not torch.cuda.is_available():
+        raise RuntimeError('dfq_amd: no ROCm GPU visible; the calibration engine has no CPU path')
+    return torch.device('cuda', torch.cuda.current_device())
+
+
+def current_stream():
+    """hipStream_t of torch's current stream, as an integer address."""
+    return torch.cuda.current_stream().cuda_stream
+
+
+def stream_arg():
+    return c_void_p(current_stream())
+
+
+def ptr(t):
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+class Stage:
+    """Binds torch tensors to float32 contiguous device buffers for one engine call.
+
+    A tensor already resident on the target device is used in place (the kernels then mutate the
+    caller's storage directly, like the reference's ``mul_``/``add_``).  Anything else (the
+    reference's default: a CPU model) is shadowed by a device copy and written back by
+    ``writeback()`` -- the PCIe-inclusive way of calling the engine.
+    """
+
+    def __init__(self):
+        self.device = target_device()
+        self._bound = {}
+        self._shadow = []
+
+    def bind(self, t):
+        if t is None:
+            return None
+        key = id(t)
+        hit = self._bound.get(key)
+        if hit is not None:
+            return hit[1]
+        d = t.detach()
+        if d.device == self.device and d.dtype == torch.float32 and d.is_contiguous():
+            buf = d
+        else:
+            buf = d.to(device=self.device, dtype=torch.float32).contiguous()
+            if buf.data_ptr() == d.data_ptr():      # .to() was a no-op view
+                buf = buf.clone()
+            self._shadow.append((t, buf))
+        self._bound[key] = (t, buf)     # keep `t` alive so id() stays unique
+        return buf
+
+    def new(self, shape, fill=None, dtype=torch.float32):
+        if fill is None:
+            return torch.empty(shape, dtype=dtype, device=self.device)
+        return torch.full(shape, fill, dtype=dtype, device=self.device)
+
+    def writeback(self):
+        with torch.no_grad():
+            for t, buf in self._shadow:
+                t.data.copy_(buf.to(t.device, t.dtype) if (buf.device != t.device or buf.dtype != t.dtype) else buf)
+
+    def out_like(self, t, buf):
+        """Return `buf` on the device/dtype the caller's tensor `t` lives on."""
+        if buf.device == t.device:
+            return buf
+        return buf.to(t.device)
+
+
+def synchronize():
+    torch.cuda.current_stream().synchronize()

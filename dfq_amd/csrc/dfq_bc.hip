@@ -1,0 +1,320 @@
+// Analytic bias correction (dfq.py:173-293) for gfx950.
+//
+// Three stages on one stream:
+//   1. per-tensor min/max of every corrected layer            (one launch, all layers)
+//   2. quant-error row sums  eps[o, i] = sum_k (Q(W)-W)[o,i,k] (one launch, all layers; dfq.py:216-219)
+//   3. the sequential chain, one small launch per layer in graph order:
+//        E[x] from the BN proxies (ReLU moment matching dfq.py:182-184,238-242; add/cat merge
+//        :244-270)  ->  bias[g] = eps[g] . E[g] (:281-287)  ->  b -= bias (:290-292)  ->
+//        next BN's beta~ += -bias (:204-206, 293).
+// Stage 3 is inherently serial across layers (each correction feeds the next expectation); the
+// stream order carries that dependency, no host synchronisation is involved.
+#include <vector>
+
+#include "dfq_common.hpp"
+
+namespace dfq {
+
+constexpr int kQChunk = kBlock * 16;
+constexpr int kExpectMax = 8192;       // floats of E[x] kept in LDS (32 KiB)
+constexpr int kRowsPerBlock = 16;      // output rows of the matvec per workgroup (4 per wave)
+
+struct BcLayerDev {
+    const float* w;
+    float* eps;              // [O * I/g]
+    int64_t n;               // O * I/g * khkw
+    int64_t pairs;           // O * I/g
+    int32_t khkw;
+    int32_t pad;
+};
+
+struct BcSourceDev {
+    const float* fw;
+    const float* fb;
+    int32_t channels, relu, concat, pad;
+};
+
+struct BcStepDev {
+    const float* eps;
+    float* bias;             // layer bias [O], in/out
+    float* next_bn_bias;     // [O] or null
+    float* corr;             // [O] out: the correction `bias` of dfq.py:285-287
+    int32_t out_ch, in_per_group, source_begin, source_count, expect_len, pad;
+};
+
+__device__ __forceinline__ int bc_find(const int32_t* __restrict__ begin, int n, int block) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (begin[mid] <= block) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(kBlock) void bc_minmax_kernel(const BcLayerDev* __restrict__ layers,
+                                                           const int32_t* __restrict__ block_begin, int n_layers,
+                                                           uint32_t* __restrict__ slots) {
+    __shared__ float sh_mn[kBlock / kWave];
+    __shared__ float sh_mx[kBlock / kWave];
+    const int l = bc_find(block_begin, n_layers, blockIdx.x);
+    const BcLayerDev L = layers[l];
+    const int64_t b = (int64_t)(blockIdx.x - block_begin[l]) * kQChunk;
+    const int64_t e = (b + kQChunk < L.n) ? b + kQChunk : L.n;
+    float mn = INFINITY, mx = -INFINITY;
+    for (int64_t i = b + threadIdx.x; i < e; i += kBlock) {
+        const float v = L.w[i];
+        mn = fminf(mn, v);
+        mx = fmaxf(mx, v);
+    }
+    mn = wave_min(mn);
+    mx = wave_max(mx);
+    if ((threadIdx.x % kWave) == 0) { sh_mn[threadIdx.x / kWave] = mn; sh_mx[threadIdx.x / kWave] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float a = sh_mn[0], c = sh_mx[0];
+        for (int w = 1; w < kBlock / kWave; ++w) { a = fminf(a, sh_mn[w]); c = fmaxf(c, sh_mx[w]); }
+        if (a <= c) {
+            atomicMax(slots + 2 * l + 0, ~enc_ord(a));
+            atomicMax(slots + 2 * l + 1, enc_ord(c));
+        }
+    }
+}
+
+// one thread per (o, i) pair: sequential float32 sum over kH*kW of (Q(w) - w)
+__global__ __launch_bounds__(kBlock) void bc_quant_error_kernel(const BcLayerDev* __restrict__ layers,
+                                                                const int32_t* __restrict__ block_begin,
+                                                                int n_layers, const uint32_t* __restrict__ slots,
+                                                                int num_bits, int symmetric) {
+    const int l = bc_find(block_begin, n_layers, blockIdx.x);
+    const BcLayerDev L = layers[l];
+    const QParams p = qparams_double((double)slot_min(slots[2 * l + 0]), (double)slot_max(slots[2 * l + 1]),
+                                     num_bits, symmetric);
+    const int64_t pair = (int64_t)(blockIdx.x - block_begin[l]) * kBlock + threadIdx.x;
+    if (pair >= L.pairs) return;
+    const float* w = L.w + pair * L.khkw;
+    float acc = 0.0f;
+    for (int k = 0; k < L.khkw; ++k) {
+        float code;
+        const float v = w[k];
+        const float d = fake_quant_one(v, p, &code) - v;
+        acc = acc + d;
+    }
+    L.eps[pair] = acc;
+}
+
+// scipy.stats.norm.pdf / cdf in float64 on the float32 ratio, rounded to float32 (dfq.py:182-184)
+__device__ __forceinline__ float relu_mean(float w, float b) {
+    const float t = (-b) / w;
+    const double x = (double)t;
+    const double pdf_d = exp(-(x * x) / 2.0) / 2.5066282746310002;   // sqrt(2*pi)
+    // cephes ndtr
+    const double z = x * 0.70710678118654752440;
+    const double az = fabs(z);
+    double cdf_d;
+    if (az < 0.70710678118654752440) {
+        cdf_d = 0.5 + 0.5 * erf(z);
+    } else {
+        cdf_d = 0.5 * erfc(az);
+        if (z > 0) cdf_d = 1.0 - cdf_d;
+    }
+    const float pdf = (float)pdf_d;
+    const float cdf = (float)cdf_d;
+    const float a = w * pdf;
+    const float one_m = 1.0f - cdf;
+    const float c = b * one_m;
+    float e = a + c;
+    if (e < 0.0f) e = 0.0f;        // expect[expect < 0] = 0; NaN stays NaN
+    return e;
+}
+
+__global__ __launch_bounds__(kBlock) void bc_step_kernel(BcStepDev st, const BcSourceDev* __restrict__ sources) {
+    __shared__ float sh_E[kExpectMax];
+    const int tid = threadIdx.x;
+    // ---- E[x]: first source assigns, 'cat' appends, anything else adds (dfq.py:229-270) ----
+    int cur_len = 0;
+    for (int m = 0; m < st.source_count; ++m) {
+        const BcSourceDev s = sources[st.source_begin + m];
+        const bool assign = (m == 0) || (s.concat != 0);
+        const int base = (m == 0) ? 0 : (s.concat ? cur_len : 0);
+        for (int i = tid; i < s.channels; i += kBlock) {
+            const float fb = s.fb[i];
+            const float e = s.relu ? relu_mean(s.fw[i], fb) : fb;
+            if (assign) sh_E[base + i] = e;
+            else sh_E[i] = sh_E[i] + e;
+        }
+        cur_len = (m == 0) ? s.channels : (s.concat ? cur_len + s.channels : cur_len);
+        __syncthreads();
+    }
+    // ---- grouped matvec, one wave per output row, float64 accumulation rounded once ----
+    const int num_group = st.expect_len / st.in_per_group;
+    const int step_o = st.out_ch / num_group;
+    const int step_i = st.expect_len / num_group;
+    const int lane = tid % kWave;
+    const int wave = tid / kWave;
+    const int row_end = min(st.out_ch, (int)(blockIdx.x + 1) * kRowsPerBlock);
+    for (int o = blockIdx.x * kRowsPerBlock + wave; o < row_end; o += kBlock / kWave) {
+        const int g = o / step_o;
+        const float* er = st.eps + (int64_t)o * st.in_per_group;
+        const float* ex = sh_E + g * step_i;
+        double acc = 0.0;
+        for (int i = lane; i < st.in_per_group; i += kWave) acc += (double)er[i] * (double)ex[i];
+        acc = wave_sum(acc);
+        if (lane == 0) {
+            const float corr = (float)acc;
+            const float neg = -corr;
+            st.corr[o] = corr;
+            st.bias[o] = st.bias[o] + neg;                            // dfq.py:292
+            if (st.next_bn_bias) st.next_bn_bias[o] = st.next_bn_bias[o] + neg;   // dfq.py:204-206, 293
+        }
+    }
+}
+
+}  // namespace dfq
+
+using namespace dfq;
+
+struct dfq_bc_plan {
+    int n_steps = 0;
+    int minmax_blocks = 0, qerr_blocks = 0;
+    int64_t weight_elems = 0, eps_elems = 0;
+    std::vector<BcStepDev> steps;          // host copies (kernel args by value)
+    std::vector<const float*> eps_ptr;
+    BcLayerDev* d_layers = nullptr;
+    int32_t* d_mm_begin = nullptr;
+    int32_t* d_qe_begin = nullptr;
+    BcSourceDev* d_sources = nullptr;
+    uint32_t* d_slots = nullptr;
+    float* d_eps = nullptr;                // all eps matrices, back to back
+    float* d_corr = nullptr;               // all correction vectors, back to back
+};
+
+extern "C" {
+
+void dfq_bc_plan_destroy(dfq_bc_plan* p) {
+    if (!p) return;
+    if (p->d_layers) (void)hipFree(p->d_layers);
+    if (p->d_mm_begin) (void)hipFree(p->d_mm_begin);
+    if (p->d_qe_begin) (void)hipFree(p->d_qe_begin);
+    if (p->d_sources) (void)hipFree(p->d_sources);
+    if (p->d_slots) (void)hipFree(p->d_slots);
+    if (p->d_eps) (void)hipFree(p->d_eps);
+    if (p->d_corr) (void)hipFree(p->d_corr);
+    delete p;
+}
+
+int dfq_bc_plan_create(const dfq_layer* layers, int32_t n_layers, const dfq_bc_step* steps, int32_t n_steps,
+                       const dfq_bc_source* sources, int32_t n_sources, dfq_bc_plan** out_plan) {
+    if (!layers || n_layers <= 0 || !steps || n_steps <= 0 || !sources || n_sources <= 0 || !out_plan)
+        return fail_arg("dfq_bc_plan_create: bad argument");
+    // ---- validate & size ----
+    int64_t eps_total = 0, corr_total = 0, mm_blocks = 0, qe_blocks = 0;
+    std::vector<int> expect_len(n_steps, 0);
+    for (int s = 0; s < n_steps; ++s) {
+        const dfq_bc_step& st = steps[s];
+        if (st.layer < 0 || st.layer >= n_layers) return fail_arg("dfq_bc_plan_create: step %d: bad layer index", s);
+        const dfq_layer& L = layers[st.layer];
+        if (!L.weight || !L.bias) return fail_arg("dfq_bc_plan_create: step %d: layer needs weight and bias", s);
+        if (st.source_count <= 0 || st.source_begin < 0 || st.source_begin + st.source_count > n_sources)
+            return fail_arg("dfq_bc_plan_create: step %d: bad source range", s);
+        int len = 0;
+        for (int m = 0; m < st.source_count; ++m) {
+            const dfq_bc_source& src = sources[st.source_begin + m];
+            if (!src.fake_bias || (src.relu && !src.fake_weight) || src.channels <= 0)
+                return fail_arg("dfq_bc_plan_create: step %d source %d: null BN proxy", s, m);
+            if (m == 0) len = src.channels;
+            else if (src.concat) len += src.channels;
+            else if (src.channels != len)
+                return fail_arg("dfq_bc_plan_create: step %d source %d: add of %d channels onto %d", s, m, src.channels, len);
+        }
+        if (len > kExpectMax) return fail_arg("dfq_bc_plan_create: step %d: expectation of %d channels > %d", s, len, kExpectMax);
+        if (len % L.in_per_group != 0 || L.out_ch % (len / L.in_per_group) != 0)
+            return fail_arg("dfq_bc_plan_create: step %d: expectation length %d does not fit I/g=%d, O=%d", s, len,
+                            L.in_per_group, L.out_ch);
+        expect_len[s] = len;
+        const int64_t pairs = (int64_t)L.out_ch * L.in_per_group;
+        eps_total += pairs;
+        corr_total += L.out_ch;
+        mm_blocks += (pairs * L.khkw + kQChunk - 1) / kQChunk;
+        qe_blocks += (pairs + kBlock - 1) / kBlock;
+    }
+    if (mm_blocks > 0x7fffffff || qe_blocks > 0x7fffffff) return fail_arg("dfq_bc_plan_create: too large");
+
+    dfq_bc_plan* p = new dfq_bc_plan();
+    p->n_steps = n_steps;
+    p->eps_elems = eps_total;
+    hipError_t e;
+    auto fail_alloc = [&](hipError_t err) { dfq_bc_plan_destroy(p); return fail_hip(err, "bc plan allocation", __FILE__, __LINE__); };
+    if ((e = hipMalloc((void**)&p->d_eps, sizeof(float) * eps_total)) != hipSuccess) return fail_alloc(e);
+    if ((e = hipMalloc((void**)&p->d_corr, sizeof(float) * corr_total)) != hipSuccess) return fail_alloc(e);
+    if ((e = hipMalloc((void**)&p->d_layers, sizeof(BcLayerDev) * n_steps)) != hipSuccess) return fail_alloc(e);
+    if ((e = hipMalloc((void**)&p->d_mm_begin, sizeof(int32_t) * (n_steps + 1))) != hipSuccess) return fail_alloc(e);
+    if ((e = hipMalloc((void**)&p->d_qe_begin, sizeof(int32_t) * (n_steps + 1))) != hipSuccess) return fail_alloc(e);
+    if ((e = hipMalloc((void**)&p->d_sources, sizeof(BcSourceDev) * n_sources)) != hipSuccess) return fail_alloc(e);
+    if ((e = hipMalloc((void**)&p->d_slots, sizeof(uint32_t) * 2 * n_steps)) != hipSuccess) return fail_alloc(e);
+
+    std::vector<BcLayerDev> hl(n_steps);
+    std::vector<int32_t> mmb(n_steps + 1), qeb(n_steps + 1);
+    std::vector<BcSourceDev> hs(n_sources);
+    for (int i = 0; i < n_sources; ++i) {
+        hs[i].fw = sources[i].fake_weight; hs[i].fb = sources[i].fake_bias;
+        hs[i].channels = sources[i].channels; hs[i].relu = sources[i].relu; hs[i].concat = sources[i].concat; hs[i].pad = 0;
+    }
+    p->steps.resize(n_steps);
+    p->eps_ptr.resize(n_steps);
+    int64_t eps_off = 0, corr_off = 0, mb = 0, qb = 0;
+    for (int s = 0; s < n_steps; ++s) {
+        const dfq_layer& L = layers[steps[s].layer];
+        const int64_t pairs = (int64_t)L.out_ch * L.in_per_group;
+        hl[s].w = L.weight; hl[s].eps = p->d_eps + eps_off; hl[s].n = pairs * L.khkw; hl[s].pairs = pairs;
+        hl[s].khkw = L.khkw; hl[s].pad = 0;
+        mmb[s] = (int32_t)mb; qeb[s] = (int32_t)qb;
+        mb += (hl[s].n + kQChunk - 1) / kQChunk;
+        qb += (pairs + kBlock - 1) / kBlock;
+        BcStepDev& d = p->steps[s];
+        d.eps = p->d_eps + eps_off; d.bias = L.bias; d.next_bn_bias = steps[s].next_bn_bias; d.corr = p->d_corr + corr_off;
+        d.out_ch = L.out_ch; d.in_per_group = L.in_per_group; d.source_begin = steps[s].source_begin;
+        d.source_count = steps[s].source_count; d.expect_len = expect_len[s]; d.pad = 0;
+        p->eps_ptr[s] = d.eps;
+        p->weight_elems += hl[s].n;
+        eps_off += pairs; corr_off += L.out_ch;
+    }
+    mmb[n_steps] = (int32_t)mb; qeb[n_steps] = (int32_t)qb;
+    p->minmax_blocks = (int)mb; p->qerr_blocks = (int)qb;
+    if ((e = hipMemcpy(p->d_layers, hl.data(), sizeof(BcLayerDev) * n_steps, hipMemcpyHostToDevice)) != hipSuccess) return fail_alloc(e);
+    if ((e = hipMemcpy(p->d_mm_begin, mmb.data(), sizeof(int32_t) * (n_steps + 1), hipMemcpyHostToDevice)) != hipSuccess) return fail_alloc(e);
+    if ((e = hipMemcpy(p->d_qe_begin, qeb.data(), sizeof(int32_t) * (n_steps + 1), hipMemcpyHostToDevice)) != hipSuccess) return fail_alloc(e);
+    if ((e = hipMemcpy(p->d_sources, hs.data(), sizeof(BcSourceDev) * n_sources, hipMemcpyHostToDevice)) != hipSuccess) return fail_alloc(e);
+    if ((e = hipDeviceSynchronize()) != hipSuccess) return fail_alloc(e);
+    *out_plan = p;
+    return DFQ_OK;
+}
+
+int dfq_bc_plan_run(dfq_bc_plan* p, int32_t symmetric, void* stream) {
+    if (!p) return fail_arg("dfq_bc_plan_run: null plan");
+    hipStream_t st = as_stream(stream);
+    DFQ_HIP_TRY(hipMemsetAsync(p->d_slots, 0, sizeof(uint32_t) * 2 * p->n_steps, st));
+    hipLaunchKernelGGL(bc_minmax_kernel, dim3(p->minmax_blocks), dim3(kBlock), 0, st, (const BcLayerDev*)p->d_layers,
+                       (const int32_t*)p->d_mm_begin, p->n_steps, p->d_slots);
+    DFQ_CHECK_LAUNCH();
+    hipLaunchKernelGGL(bc_quant_error_kernel, dim3(p->qerr_blocks), dim3(kBlock), 0, st, (const BcLayerDev*)p->d_layers,
+                       (const int32_t*)p->d_qe_begin, p->n_steps, (const uint32_t*)p->d_slots, 8, (int)symmetric);
+    DFQ_CHECK_LAUNCH();
+    for (int s = 0; s < p->n_steps; ++s) {
+        const BcStepDev& d = p->steps[s];
+        const int grid = (d.out_ch + kRowsPerBlock - 1) / kRowsPerBlock;
+        hipLaunchKernelGGL(bc_step_kernel, dim3(grid), dim3(kBlock), 0, st, d, (const BcSourceDev*)p->d_sources);
+        DFQ_CHECK_LAUNCH();
+    }
+    return DFQ_OK;
+}
+
+const float* dfq_bc_plan_eps(const dfq_bc_plan* p, int32_t step) {
+    return (p && step >= 0 && step < p->n_steps) ? p->eps_ptr[step] : nullptr;
+}
+const float* dfq_bc_plan_correction(const dfq_bc_plan* p, int32_t step) {
+    return (p && step >= 0 && step < p->n_steps) ? p->steps[step].corr : nullptr;
+}
+int64_t dfq_bc_plan_weight_elements(const dfq_bc_plan* p) { return p ? p->weight_elems : 0; }
+int64_t dfq_bc_plan_eps_elements(const dfq_bc_plan* p) { return p ? p->eps_elems : 0; }
+
+}  // extern "C"

@@ -1,0 +1,157 @@
+// Shared device/host helpers of libdfq_hip (gfx950, wave64).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/dfq_hip.h"
+
+namespace dfq {
+
+constexpr int kBlock = 256;   // 4 wavefronts of 64 lanes
+constexpr int kWave = 64;
+
+// ---- error plumbing -----------------------------------------------------------------------
+void set_error(const std::string& msg);
+int fail_arg(const char* fmt, ...);
+int fail_hip(hipError_t e, const char* what, const char* file, int line);
+
+#define DFQ_HIP_TRY(expr)                                                       \
+    do {                                                                        \
+        hipError_t _e = (expr);                                                 \
+        if (_e != hipSuccess) return ::dfq::fail_hip(_e, #expr, __FILE__, __LINE__); \
+    } while (0)
+
+#define DFQ_CHECK_LAUNCH()                                                      \
+    do {                                                                        \
+        hipError_t _e = hipGetLastError();                                      \
+        if (_e != hipSuccess) return ::dfq::fail_hip(_e, "kernel launch", __FILE__, __LINE__); \
+    } while (0)
+
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+// ---- order-preserving float <-> uint32 encoding for atomic min/max ----------------------------
+// enc is monotone in the float order (-inf < ... < -0 < +0 < ... < +inf).  A "max slot" holds
+// atomicMax(enc(x)), a "min slot" holds atomicMax(~enc(x)); both have identity 0, so one memset
+// initialises any number of slots.
+__device__ __forceinline__ uint32_t enc_ord(float f) {
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float dec_ord(uint32_t e) {
+    const uint32_t u = (e & 0x80000000u) ? (e & 0x7fffffffu) : ~e;
+    return __uint_as_float(u);
+}
+__device__ __forceinline__ float slot_max(uint32_t slot) { return dec_ord(slot); }
+__device__ __forceinline__ float slot_min(uint32_t slot) { return dec_ord(~slot); }
+
+// ---- wavefront (64-lane) butterflies: every lane ends with the result ------------------------
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fminf(v, __shfl_xor(v, m));
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m));
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+
+// Deterministic block-wide sum of doubles (fixed butterfly + fixed wave order).  `sh` is a
+// __shared__ double[kBlock / kWave].  Result valid in every thread.
+__device__ __forceinline__ double block_sum(double v, double* sh) {
+    v = wave_sum(v);
+    const int wave = threadIdx.x / kWave;
+    __syncthreads();   // protect `sh` against a previous use
+    if ((threadIdx.x % kWave) == 0) sh[wave] = v;
+    __syncthreads();
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < kBlock / kWave; ++w) t += sh[w];
+    return t;
+}
+
+// ---- fake-quant parameters (utils/quantize.py:49-66) -------------------------------------------
+struct QParams {
+    float qmin, qmax, neg_min, scale, min_value;
+};
+
+// Recipe A: min/max are Python floats in the reference -> all scalar arithmetic in double, each
+// operand cast to float32 where torch casts a Python scalar to the tensor dtype.
+__host__ __device__ inline QParams qparams_double(double mn, double mx, int num_bits, int symmetric) {
+    double qmin, qmax, scale;
+    if (symmetric) {
+        qmin = -(double)(1ll << (num_bits - 1));
+        qmax = (double)((1ll << (num_bits - 1)) - 1);
+        mx = mx < 0 ? -mx : mx;
+        mn = mn < 0 ? -mn : mn;
+        if (mx < mn) mx = mn;
+        scale = mx / qmax;
+        mn = 0.0;
+    } else {
+        qmin = 0.0;
+        qmax = (double)(1ll << num_bits) - 1.0;
+        scale = (mx - mn) / (qmax - qmin);
+    }
+    if (1e-8 > scale) scale = 1e-8;   // Python max(scale, 1e-8): NaN is kept
+    QParams p;
+    p.qmin = (float)qmin;
+    p.qmax = (float)qmax;
+    p.neg_min = (float)(-mn);
+    p.scale = (float)scale;
+    p.min_value = (float)mn;
+    return p;
+}
+
+// Recipe B: min/max are 0-dim float32 tensors in the reference (min_value=None path,
+// quantize.py:24-35) -> the whole recipe stays in float32.
+__host__ __device__ inline QParams qparams_float(float mn, float mx, int num_bits, int symmetric) {
+    float qmin, qmax, scale, mn_used;
+    if (symmetric) {
+        qmin = -(float)(1ll << (num_bits - 1));
+        qmax = (float)((1ll << (num_bits - 1)) - 1);
+        mx = mx < 0 ? -mx : mx;
+        mn = mn < 0 ? -mn : mn;
+        if (mx < mn) mx = mn;
+        scale = mx / qmax;
+        mn_used = 0.0f;
+    } else {
+        qmin = 0.0f;
+        qmax = (float)((double)(1ll << num_bits) - 1.0);
+        const float span = mx - mn;
+        scale = span / (qmax - qmin);
+        mn_used = mn;
+    }
+    if (scale < 1e-8f) scale = 1e-8f;
+    QParams p;
+    p.qmin = qmin;
+    p.qmax = qmax;
+    p.neg_min = -mn_used;
+    p.scale = scale;
+    p.min_value = mn_used;
+    return p;
+}
+
+// quantize.py:70-74 -- five separately rounded float32 operations (the build uses
+// -ffp-contract=off so the last two never fuse into an FMA).  Returns the dequantised value and
+// the integer code (as float).
+__device__ __forceinline__ float fake_quant_one(float x, const QParams& p, float* code) {
+    float q = x + p.neg_min;
+    q = q / p.scale;
+    q = (q < p.qmin) ? p.qmin : q;   // NaN-propagating clamp, like torch.clamp_
+    q = (q > p.qmax) ? p.qmax : q;
+    q = rintf(q);                    // round half to even == torch.round_
+    *code = q;
+    float y = q * p.scale;
+    y = y + p.min_value;
+    return y;
+}
+
+}  // namespace dfq

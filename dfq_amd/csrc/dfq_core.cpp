@@ -1,0 +1,45 @@
+// Error plumbing and version entry points of libdfq_hip.
+#include <stdarg.h>
+
+#include "dfq_common.hpp"
+
+namespace dfq {
+
+static thread_local std::string g_last_error;
+
+void set_error(const std::string& msg) { g_last_error = msg; }
+
+int fail_arg(const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return DFQ_ERR_ARG;
+}
+
+int fail_hip(hipError_t e, const char* what, const char* file, int line) {
+    char buf[640];
+    snprintf(buf, sizeof(buf), "HIP error %d (%s) in `%s` at %s:%d", (int)e, hipGetErrorString(e), what,
+             file, line);
+    g_last_error = buf;
+    return DFQ_ERR_HIP;
+}
+
+}  // namespace dfq
+
+extern "C" {
+
+int dfq_version(void) { return DFQ_HIP_VERSION; }
+
+const char* dfq_last_error(void) { return dfq::g_last_error.c_str(); }
+
+int dfq_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return dfq::fail_hip(e, "hipGetDeviceCount", __FILE__, __LINE__);
+    return n;
+}
+
+}  // extern "C"

@@ -1,0 +1,434 @@
+// Per-tensor range reductions and the fake-quant round trip (utils/quantize.py:23-76, :102-119;
+// utils/layer_transform.py:279-296; dfq.py:8-25) as HIP kernels for gfx950.
+//
+// All kernels here are streaming, HBM/L2-bound: one pass for min/max, one read+write pass for the
+// quantiser.  Reductions use 64-lane butterflies, one LDS hop across the 4 waves of a workgroup
+// and one order-preserving atomicMax per workgroup (min/max are order independent, so the result
+// is deterministic).
+#include <vector>
+
+#include "dfq_common.hpp"
+
+namespace dfq {
+
+constexpr int kChunk = kBlock * 16;   // elements one workgroup owns in the multi-tensor kernels
+
+// ---------------------------------------------------------------------------------------------
+// device bodies
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void thread_minmax_range(const float* __restrict__ x, int64_t begin,
+                                                    int64_t end, float& mn, float& mx) {
+    const int tid = threadIdx.x;
+    const float* p = x + begin;
+    const int64_t len = end - begin;
+    if ((reinterpret_cast<uintptr_t>(p) & 15u) == 0) {
+        const int64_t n4 = len >> 2;
+        const float4* p4 = reinterpret_cast<const float4*>(p);
+        for (int64_t i = tid; i < n4; i += kBlock) {
+            const float4 v = p4[i];
+            mn = fminf(fminf(mn, v.x), fminf(v.y, fminf(v.z, v.w)));
+            mx = fmaxf(fmaxf(mx, v.x), fmaxf(v.y, fmaxf(v.z, v.w)));
+        }
+        for (int64_t i = (n4 << 2) + tid; i < len; i += kBlock) {
+            const float v = p[i];
+            mn = fminf(mn, v);
+            mx = fmaxf(mx, v);
+        }
+    } else {
+        for (int64_t i = tid; i < len; i += kBlock) {
+            const float v = p[i];
+            mn = fminf(mn, v);
+            mx = fmaxf(mx, v);
+        }
+    }
+}
+
+// block-wide min/max -> one pair of atomics on the (max slot, min slot) pair
+__device__ __forceinline__ void block_publish_minmax(float mn, float mx, uint32_t* slot_pair) {
+    __shared__ float sh_mn[kBlock / kWave];
+    __shared__ float sh_mx[kBlock / kWave];
+    mn = wave_min(mn);
+    mx = wave_max(mx);
+    const int wave = threadIdx.x / kWave;
+    if ((threadIdx.x % kWave) == 0) {
+        sh_mn[wave] = mn;
+        sh_mx[wave] = mx;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float a = sh_mn[0], b = sh_mx[0];
+#pragma unroll
+        for (int w = 1; w < kBlock / kWave; ++w) {
+            a = fminf(a, sh_mn[w]);
+            b = fmaxf(b, sh_mx[w]);
+        }
+        if (a <= b) {   // false only if the range was empty
+            atomicMax(slot_pair + 0, ~enc_ord(a));   // min slot
+            atomicMax(slot_pair + 1, enc_ord(b));    // max slot
+        }
+    }
+}
+
+__device__ __forceinline__ int find_segment(const int32_t* __restrict__ block_begin, int n_segs, int block) {
+    int lo = 0, hi = n_segs - 1;   // largest s with block_begin[s] <= block
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (block_begin[mid] <= block) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+struct SegDev {
+    float* data;
+    int32_t* codes;
+    int64_t n;
+    int32_t num_bits;
+    int32_t symmetric;
+};
+
+// ---------------------------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void minmax_kernel(const float* __restrict__ x, int64_t n,
+                                                        uint32_t* __restrict__ slot_pair) {
+    float mn = INFINITY, mx = -INFINITY;
+    for (int64_t c = blockIdx.x; c * kChunk < n; c += gridDim.x) {
+        const int64_t b = c * kChunk;
+        const int64_t e = (b + kChunk < n) ? b + kChunk : n;
+        thread_minmax_range(x, b, e, mn, mx);
+    }
+    block_publish_minmax(mn, mx, slot_pair);
+}
+
+__global__ void slots_decode_kernel(const uint32_t* __restrict__ slots, float* __restrict__ out, int n_pairs) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_pairs) {
+        out[2 * i + 0] = slot_min(slots[2 * i + 0]);
+        out[2 * i + 1] = slot_max(slots[2 * i + 1]);
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void seg_minmax_kernel(const SegDev* __restrict__ segs,
+                                                            const int32_t* __restrict__ block_begin,
+                                                            int n_segs, uint32_t* __restrict__ slots) {
+    const int s = find_segment(block_begin, n_segs, blockIdx.x);
+    const SegDev sg = segs[s];
+    const int64_t b = (int64_t)(blockIdx.x - block_begin[s]) * kChunk;
+    const int64_t e = (b + kChunk < sg.n) ? b + kChunk : sg.n;
+    float mn = INFINITY, mx = -INFINITY;
+    thread_minmax_range(sg.data, b, e, mn, mx);
+    block_publish_minmax(mn, mx, slots + 2 * s);
+}
+
+// x may alias y (in-place), so no __restrict__ here
+__device__ __forceinline__ void thread_fake_quant_range(const float* x, float* y,
+                                                        int32_t* __restrict__ codes, int64_t begin,
+                                                        int64_t end, const QParams& p) {
+    for (int64_t i = begin + threadIdx.x; i < end; i += kBlock) {
+        float code;
+        const float v = fake_quant_one(x[i], p, &code);
+        y[i] = v;
+        if (codes) codes[i] = (int32_t)code;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void seg_fake_quant_kernel(const SegDev* __restrict__ segs,
+                                                                const int32_t* __restrict__ block_begin,
+                                                                int n_segs,
+                                                                const uint32_t* __restrict__ slots,
+                                                                float* __restrict__ minmax_out) {
+    const int s = find_segment(block_begin, n_segs, blockIdx.x);
+    const SegDev sg = segs[s];
+    const int chunk = blockIdx.x - block_begin[s];
+    const float mn = slot_min(slots[2 * s + 0]);
+    const float mx = slot_max(slots[2 * s + 1]);
+    if (chunk == 0 && threadIdx.x == 0) {
+        minmax_out[2 * s + 0] = mn;
+        minmax_out[2 * s + 1] = mx;
+    }
+    const QParams p = qparams_double((double)mn, (double)mx, sg.num_bits, sg.symmetric);
+    const int64_t b = (int64_t)chunk * kChunk;
+    const int64_t e = (b + kChunk < sg.n) ? b + kChunk : sg.n;
+    thread_fake_quant_range(sg.data, sg.data, sg.codes, b, e, p);
+}
+
+// range_mode 0: `p0` is final.  1: double recipe from minmax_dev.  2: float32 recipe from minmax_dev.
+__global__ __launch_bounds__(kBlock) void fake_quant_kernel(const float* x, float* y,
+                                                            int64_t n, QParams p0, int num_bits, int symmetric,
+                                                            int range_mode, const float* __restrict__ minmax_dev,
+                                                            int32_t* __restrict__ codes) {
+    QParams p = p0;
+    if (range_mode == 1) p = qparams_double((double)minmax_dev[0], (double)minmax_dev[1], num_bits, symmetric);
+    else if (range_mode == 2) p = qparams_float(minmax_dev[0], minmax_dev[1], num_bits, symmetric);
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        float code;
+        const float v = fake_quant_one(x[i], p, &code);
+        y[i] = v;
+        if (codes) codes[i] = (int32_t)code;
+    }
+}
+
+// per-sample min/max: grid (chunks, samples)
+__global__ __launch_bounds__(kBlock) void sample_minmax_kernel(const float* __restrict__ x, int64_t sample_len,
+                                                               uint32_t* __restrict__ slots) {
+    const int smp = blockIdx.y;
+    const float* xs = x + (int64_t)smp * sample_len;
+    float mn = INFINITY, mx = -INFINITY;
+    for (int64_t c = blockIdx.x; c * kChunk < sample_len; c += gridDim.x) {
+        const int64_t b = c * kChunk;
+        const int64_t e = (b + kChunk < sample_len) ? b + kChunk : sample_len;
+        thread_minmax_range(xs, b, e, mn, mx);
+    }
+    block_publish_minmax(mn, mx, slots + 2 * smp);
+}
+
+// mean over samples (float64 accumulation, rounded once) + running_min/max update (quantize.py:106-107)
+__global__ __launch_bounds__(kBlock) void sample_mean_kernel(const uint32_t* __restrict__ slots, int n_samples,
+                                                             float* __restrict__ out2, float* __restrict__ running2) {
+    __shared__ double sh[kBlock / kWave];
+    double smn = 0.0, smx = 0.0;
+    for (int i = threadIdx.x; i < n_samples; i += kBlock) {
+        smn += (double)slot_min(slots[2 * i + 0]);
+        smx += (double)slot_max(slots[2 * i + 1]);
+    }
+    smn = block_sum(smn, sh);
+    smx = block_sum(smx, sh);
+    if (threadIdx.x == 0) {
+        // one sample: the mean of one element is the element itself
+        const float mn = (n_samples == 1) ? slot_min(slots[0]) : (float)(smn / (double)n_samples);
+        const float mx = (n_samples == 1) ? slot_max(slots[1]) : (float)(smx / (double)n_samples);
+        out2[0] = mn;
+        out2[1] = mx;
+        if (running2) {
+            // Python min(running_min, v) keeps running_min unless v < running_min (NaN keeps it)
+            if (mn < running2[0]) running2[0] = mn;
+            if (mx > running2[1]) running2[1] = mx;
+        }
+    }
+}
+
+// ---- _quantize_error (dfq.py:8-25) ----------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void quant_error_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                             int64_t n, int num_bits, int symmetric,
+                                                             const uint32_t* __restrict__ slot_pair) {
+    const QParams p = qparams_double((double)slot_min(slot_pair[0]), (double)slot_max(slot_pair[1]), num_bits, symmetric);
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        float code;
+        const float v = x[i];
+        out[i] = fake_quant_one(v, p, &code) - v;
+    }
+}
+
+// rows of `row_len` elements; one wave per row (round robin); per-row value by `reduction`,
+// accumulated per block into partial[blockIdx.x] (float64, fixed order).
+__global__ __launch_bounds__(kBlock) void quant_error_rows_kernel(const float* __restrict__ x, int64_t n,
+                                                                  int64_t rows, int64_t row_len, int num_bits,
+                                                                  int symmetric, int reduction,
+                                                                  const uint32_t* __restrict__ slot_pair,
+                                                                  double* __restrict__ partial) {
+    __shared__ double sh[kBlock / kWave];
+    const QParams p = qparams_double((double)slot_min(slot_pair[0]), (double)slot_max(slot_pair[1]), num_bits, symmetric);
+    const int lane = threadIdx.x % kWave;
+    const int64_t wave_global = (int64_t)blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
+    const int64_t n_waves = (int64_t)gridDim.x * (kBlock / kWave);
+    double acc = 0.0;
+    for (int64_t r = wave_global; r < rows; r += n_waves) {
+        const int64_t b = r * row_len;
+        const int64_t e = (b + row_len < n) ? b + row_len : n;
+        double s = 0.0;
+        for (int64_t i = b + lane; i < e; i += kWave) {
+            float code;
+            const float v = x[i];
+            const float d = fake_quant_one(v, p, &code) - v;
+            s += (reduction == 1) ? (double)fabsf(d) : (double)d;
+        }
+        s = wave_sum(s);
+        if (reduction >= 3) s = fabs(s);
+        acc += s;
+    }
+    const double t = block_sum((lane == 0) ? acc : 0.0, sh);
+    if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
+
+__global__ void quant_error_final_kernel(const double* __restrict__ partial, int n_partial, double denom,
+                                         float* __restrict__ out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double t = 0.0;
+        for (int i = 0; i < n_partial; ++i) t += partial[i];
+        out[0] = (float)(t / denom);
+    }
+}
+
+static int grid_for(int64_t n, int per_block, int cap) {
+    int64_t g = (n + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}
+
+}  // namespace dfq
+
+using namespace dfq;
+
+// ---------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+
+int dfq_tensor_minmax(const float* x, int64_t n, float* out2, uint32_t* scratch2, void* stream) {
+    if (!x || !out2 || !scratch2 || n <= 0) return fail_arg("dfq_tensor_minmax: bad argument (n=%lld)", (long long)n);
+    hipStream_t st = as_stream(stream);
+    DFQ_HIP_TRY(hipMemsetAsync(scratch2, 0, 2 * sizeof(uint32_t), st));
+    hipLaunchKernelGGL(minmax_kernel, dim3(grid_for(n, kChunk, 2048)), dim3(kBlock), 0, st, x, n, scratch2);
+    DFQ_CHECK_LAUNCH();
+    hipLaunchKernelGGL(slots_decode_kernel, dim3(1), dim3(64), 0, st, (const uint32_t*)scratch2, out2, 1);
+    DFQ_CHECK_LAUNCH();
+    return DFQ_OK;
+}
+
+int dfq_fake_quant(const float* x, float* y, int64_t n, int32_t num_bits, int32_t symmetric,
+                   int32_t range_mode, double min_value, double max_value, const float* minmax_dev,
+                   int32_t* codes, void* stream) {
+    if (!x || !y || n < 0) return fail_arg("dfq_fake_quant: bad argument");
+    if (num_bits < 1 || num_bits > 30) return fail_arg("dfq_fake_quant: num_bits=%d out of range", num_bits);
+    if (range_mode < 0 || range_mode > 2) return fail_arg("dfq_fake_quant: range_mode=%d", range_mode);
+    if (range_mode != 0 && !minmax_dev) return fail_arg("dfq_fake_quant: range_mode %d needs minmax_dev", range_mode);
+    if (n == 0) return DFQ_OK;
+    QParams p0 = qparams_double(min_value, max_value, num_bits, symmetric);
+    hipLaunchKernelGGL(fake_quant_kernel, dim3(grid_for(n, kBlock * 8, 4096)), dim3(kBlock), 0, as_stream(stream),
+                       x, y, n, p0, (int)num_bits, (int)symmetric, (int)range_mode, minmax_dev, codes);
+    DFQ_CHECK_LAUNCH();
+    return DFQ_OK;
+}
+
+int dfq_sample_minmax_mean(const float* x, int32_t n_samples, int64_t sample_len, float* out2,
+                           float* running2, uint32_t* scratch, void* stream) {
+    if (!x || !out2 || !scratch || n_samples <= 0 || sample_len <= 0)
+        return fail_arg("dfq_sample_minmax_mean: bad argument");
+    if (n_samples > 65535) return fail_arg("dfq_sample_minmax_mean: n_samples=%d > 65535", n_samples);
+    hipStream_t st = as_stream(stream);
+    DFQ_HIP_TRY(hipMemsetAsync(scratch, 0, 2 * sizeof(uint32_t) * (size_t)n_samples, st));
+    int gx = grid_for(sample_len, kChunk, 2048);
+    if ((int64_t)gx * n_samples > 16384) {   // keep the launch a few waves per CU deep, not more
+        gx = (int)(16384 / n_samples);
+        if (gx < 1) gx = 1;
+    }
+    hipLaunchKernelGGL(sample_minmax_kernel, dim3(gx, n_samples), dim3(kBlock), 0, st, x, sample_len, scratch);
+    DFQ_CHECK_LAUNCH();
+    hipLaunchKernelGGL(sample_mean_kernel, dim3(1), dim3(kBlock), 0, st, (const uint32_t*)scratch, (int)n_samples,
+                       out2, running2);
+    DFQ_CHECK_LAUNCH();
+    return DFQ_OK;
+}
+
+// ---- multi-tensor plan ------------------------------------------------------------------------
+struct dfq_quant_plan {
+    int n_segs = 0;
+    int n_blocks = 0;
+    SegDev* d_segs = nullptr;
+    int32_t* d_block_begin = nullptr;
+    uint32_t* d_slots = nullptr;
+    float* d_minmax = nullptr;
+};
+
+int dfq_quant_plan_create(const dfq_segment* segs, int32_t n_segs, dfq_quant_plan** out_plan) {
+    if (!segs || n_segs <= 0 || !out_plan) return fail_arg("dfq_quant_plan_create: bad argument");
+    std::vector<SegDev> h(n_segs);
+    std::vector<int32_t> bb(n_segs + 1);
+    int64_t blocks = 0;
+    for (int i = 0; i < n_segs; ++i) {
+        if (!segs[i].data || segs[i].n <= 0) return fail_arg("dfq_quant_plan_create: segment %d is empty", i);
+        if (segs[i].num_bits < 1 || segs[i].num_bits > 30) return fail_arg("dfq_quant_plan_create: segment %d bits", i);
+        h[i].data = segs[i].data;
+        h[i].codes = segs[i].codes;
+        h[i].n = segs[i].n;
+        h[i].num_bits = segs[i].num_bits;
+        h[i].symmetric = segs[i].symmetric;
+        bb[i] = (int32_t)blocks;
+        blocks += (segs[i].n + kChunk - 1) / kChunk;
+        if (blocks > 0x7fffffff) return fail_arg("dfq_quant_plan_create: too many elements");
+    }
+    bb[n_segs] = (int32_t)blocks;
+    dfq_quant_plan* p = new dfq_quant_plan();
+    p->n_segs = n_segs;
+    p->n_blocks = (int)blocks;
+    hipError_t e;
+    if ((e = hipMalloc((void**)&p->d_segs, sizeof(SegDev) * n_segs)) != hipSuccess ||
+        (e = hipMalloc((void**)&p->d_block_begin, sizeof(int32_t) * (n_segs + 1))) != hipSuccess ||
+        (e = hipMalloc((void**)&p->d_slots, sizeof(uint32_t) * 2 * n_segs)) != hipSuccess ||
+        (e = hipMalloc((void**)&p->d_minmax, sizeof(float) * 2 * n_segs)) != hipSuccess ||
+        (e = hipMemcpy(p->d_segs, h.data(), sizeof(SegDev) * n_segs, hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(p->d_block_begin, bb.data(), sizeof(int32_t) * (n_segs + 1), hipMemcpyHostToDevice)) != hipSuccess) {
+        dfq_quant_plan_destroy(p);
+        return fail_hip(e, "quant plan allocation", __FILE__, __LINE__);
+    }
+    *out_plan = p;
+    return DFQ_OK;
+}
+
+void dfq_quant_plan_destroy(dfq_quant_plan* p) {
+    if (!p) return;
+    if (p->d_segs) (void)hipFree(p->d_segs);
+    if (p->d_block_begin) (void)hipFree(p->d_block_begin);
+    if (p->d_slots) (void)hipFree(p->d_slots);
+    if (p->d_minmax) (void)hipFree(p->d_minmax);
+    delete p;
+}
+
+int dfq_quant_plan_run(dfq_quant_plan* p, void* stream) {
+    if (!p) return fail_arg("dfq_quant_plan_run: null plan");
+    hipStream_t st = as_stream(stream);
+    DFQ_HIP_TRY(hipMemsetAsync(p->d_slots, 0, sizeof(uint32_t) * 2 * p->n_segs, st));
+    hipLaunchKernelGGL(seg_minmax_kernel, dim3(p->n_blocks), dim3(kBlock), 0, st, (const SegDev*)p->d_segs,
+                       (const int32_t*)p->d_block_begin, p->n_segs, p->d_slots);
+    DFQ_CHECK_LAUNCH();
+    hipLaunchKernelGGL(seg_fake_quant_kernel, dim3(p->n_blocks), dim3(kBlock), 0, st, (const SegDev*)p->d_segs,
+                       (const int32_t*)p->d_block_begin, p->n_segs, (const uint32_t*)p->d_slots, p->d_minmax);
+    DFQ_CHECK_LAUNCH();
+    return DFQ_OK;
+}
+
+const float* dfq_quant_plan_minmax(const dfq_quant_plan* p) { return p ? p->d_minmax : nullptr; }
+
+// ---- _quantize_error ---------------------------------------------------------------------------
+static const int kQerrPartials = 1024;
+
+size_t dfq_quant_error_scratch_bytes(int64_t, int64_t) { return 16 + sizeof(double) * kQerrPartials; }
+
+int dfq_quant_error(const float* x, int64_t n, int64_t rows, int32_t num_bits, int32_t symmetric,
+                    int32_t reduction, float* out, void* scratch, void* stream) {
+    if (!x || !out || !scratch || n <= 0) return fail_arg("dfq_quant_error: bad argument");
+    if (reduction < 0 || reduction > 4) return fail_arg("dfq_quant_error: reduction=%d", reduction);
+    hipStream_t st = as_stream(stream);
+    uint32_t* slots = reinterpret_cast<uint32_t*>(scratch);
+    double* partial = reinterpret_cast<double*>(reinterpret_cast<char*>(scratch) + 16);
+    DFQ_HIP_TRY(hipMemsetAsync(slots, 0, 2 * sizeof(uint32_t), st));
+    hipLaunchKernelGGL(minmax_kernel, dim3(grid_for(n, kChunk, 2048)), dim3(kBlock), 0, st, x, n, slots);
+    DFQ_CHECK_LAUNCH();
+    if (reduction == 0) {
+        hipLaunchKernelGGL(quant_error_kernel, dim3(grid_for(n, kBlock * 8, 4096)), dim3(kBlock), 0, st, x, out, n,
+                           (int)num_bits, (int)symmetric, (const uint32_t*)slots);
+        DFQ_CHECK_LAUNCH();
+        return DFQ_OK;
+    }
+    int64_t r = rows, row_len;
+    if (reduction <= 2) {   // scalar over the whole tensor: rows are just work units
+        row_len = 4096;
+        r = (n + row_len - 1) / row_len;
+    } else {
+        if (rows <= 0 || n % rows != 0) return fail_arg("dfq_quant_error: rows=%lld does not divide n=%lld", (long long)rows, (long long)n);
+        row_len = n / rows;
+    }
+    const int grid = grid_for(r, kBlock / kWave, kQerrPartials);
+    hipLaunchKernelGGL(quant_error_rows_kernel, dim3(grid), dim3(kBlock), 0, st, x, n, r, row_len, (int)num_bits,
+                       (int)symmetric, (int)reduction, (const uint32_t*)slots, partial);
+    DFQ_CHECK_LAUNCH();
+    hipLaunchKernelGGL(quant_error_final_kernel, dim3(1), dim3(64), 0, st, (const double*)partial, grid,
+                       reduction == 2 ? (double)n : 1.0, out);
+    DFQ_CHECK_LAUNCH();
+    return DFQ_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,444 @@
+"""Data-free quantisation passes on the MI355X engine, with the call surface of the reference's
+``dfq.py``:
+
+  _quantize_error            <- dfq.py:8-25
+  _layer_equalization        <- dfq.py:28-75
+  cross_layer_equalization   <- dfq.py:78-117
+  bias_absorption            <- dfq.py:121-164
+  clip_weight                <- dfq.py:167-170
+  bias_correction            <- dfq.py:173-293
+
+The Python here only walks the (graph, bottoms, relations) dictionaries to build flat work tables
+(pointers + geometry); every per-channel loop of the reference runs inside libdfq_hip.so.  Callers'
+``nn.Parameter`` objects are updated in place, ``Relation.S`` receives the cumulative scale vector,
+missing biases are created as zero Parameters -- all as in the reference.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+import torch.nn as nn
+
+from . import _ffi
+from .utils.layer_transform import _ensure_bias, find_prev_bn
+
+
+# ------------------------------------------------------------------------------------------------
+# helpers
+# ------------------------------------------------------------------------------------------------
+def _layer_entry(stage, weight, bias, groups=1):
+    w = stage.bind(weight)
+    b = stage.bind(bias)
+    khkw = 1
+    for d in w.shape[2:]:
+        khkw *= int(d)
+    return _ffi.DfqLayer(w.data_ptr(), b.data_ptr() if b is not None else None, int(w.shape[0]), int(w.shape[1]),
+                         khkw, int(groups)), (w, b)
+
+
+def _le_config(s_range, converge_thres, converge_count, signed, eps, max_sweeps):
+    lo, hi = float(s_range[0]), float(s_range[1])
+    return _ffi.DfqLeConfig(lo, hi, 1.0 / lo if lo != 0 else float('inf'), 1.0 / hi if hi != 0 else float('inf'),
+                            int(hi > lo), float(eps), int(bool(signed)), float(converge_thres), int(converge_count),
+                            -1 if max_sweeps is None else int(max_sweeps))
+
+
+class LEPlan:
+    """Device-side work list for cross-layer equalisation over a fixed set of layers/relations.
+
+    Build once, then ``run`` (whole dfq.py:83-115 loop, synchronises once) or ``enqueue`` (fixed
+    number of sweeps, asynchronous -- what bench.py times with the weights resident in HBM).
+    """
+
+    def __init__(self, layers, relations, stage=None):
+        """layers: list of (weight, bias|None, groups); relations: list of
+        (first_idx, second_idx, bn_weight|None, bn_bias|None, scale_cum tensor [O1])."""
+        self.stage = stage or _ffi.Stage()
+        self._keep = []
+        entries = []
+        for (w, b, g) in layers:
+            e, keep = _layer_entry(self.stage, w, b, g)
+            entries.append(e)
+            self._keep.append(keep)
+        rels = []
+        self.scale_cum = []
+        for (i1, i2, bnw, bnb, scum) in relations:
+            bw, bb = self.stage.bind(bnw), self.stage.bind(bnb)
+            sc = self.stage.bind(scum)
+            self._keep.append((bw, bb, sc))
+            self.scale_cum.append(sc)
+            rels.append(_ffi.DfqRelation(int(i1), int(i2), bw.data_ptr() if bw is not None else None,
+                                         bb.data_ptr() if bb is not None else None, sc.data_ptr()))
+        self.n_layers, self.n_relations = len(entries), len(rels)
+        larr = (_ffi.DfqLayer * len(entries))(*entries)
+        rarr = (_ffi.DfqRelation * max(1, len(rels)))(*rels)
+        self._plan = ctypes.c_void_p()
+        _ffi.check(_ffi.lib().dfq_le_plan_create(larr, len(entries), rarr, len(rels), ctypes.byref(self._plan)))
+
+    # -- introspection -----------------------------------------------------------------------
+    @property
+    def levels(self):
+        return _ffi.lib().dfq_le_plan_levels(self._plan)
+
+    @property
+    def paired_elements(self):
+        return _ffi.lib().dfq_le_plan_paired_elements(self._plan)
+
+    @property
+    def snapshot_elements(self):
+        return _ffi.lib().dfq_le_plan_snapshot_elements(self._plan)
+
+    def level_info(self, level):
+        a, b, c = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int32()
+        n = _ffi.lib().dfq_le_plan_level_launches(self._plan, level, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c))
+        return dict(relations=n, paired_elements=a.value, snapshot_elements=b.value, workgroups=c.value)
+
+    # -- execution -----------------------------------------------------------------------------
+    def run(self, s_range=(1e-8, 1e8), converge_thres=2e-7, converge_count=20, signed=False, eps=0,
+            max_sweeps=None):
+        cfg = _le_config(s_range, converge_thres, converge_count, signed, eps, max_sweeps)
+        res = _ffi.DfqLeResult()
+        _ffi.check(_ffi.lib().dfq_le_run(self._plan, ctypes.byref(cfg), _ffi.stream_arg(), ctypes.byref(res)))
+        return dict(sweeps=res.sweeps, stall_count=res.stall_count, diff=res.diff, last_diff_tmp=res.last_diff_tmp)
+
+    def enqueue(self, n_sweeps, restart=True, s_range=(1e-8, 1e8), converge_thres=2e-7, converge_count=20,
+                signed=False, eps=0, max_sweeps=None):
+        cfg = _le_config(s_range, converge_thres, converge_count, signed, eps, max_sweeps)
+        _ffi.check(_ffi.lib().dfq_le_enqueue(self._plan, ctypes.byref(cfg), int(n_sweeps), int(bool(restart)),
+                                             _ffi.stream_arg()))
+
+    def profile(self, n_sweeps, **kw):
+        """Per-level kernel time (ms, summed over `n_sweeps` sweeps) from HIP events around each launch."""
+        cfg = _le_config(kw.get('s_range', (1e-8, 1e8)), kw.get('converge_thres', 2e-7), kw.get('converge_count', 20),
+                         kw.get('signed', False), kw.get('eps', 0), kw.get('max_sweeps', None))
+        nl = self.levels
+        level_ms = (ctypes.c_double * max(1, nl))()
+        ctl = ctypes.c_double()
+        nlaunch = ctypes.c_int32()
+        _ffi.check(_ffi.lib().dfq_le_profile(self._plan, ctypes.byref(cfg), int(n_sweeps), _ffi.stream_arg(), level_ms,
+                                             ctypes.byref(ctl), ctypes.byref(nlaunch)))
+        return dict(level_ms=[level_ms[i] for i in range(nl)], control_ms=ctl.value, level_launches=nlaunch.value)
+
+    def query(self):
+        res = _ffi.DfqLeResult()
+        done = ctypes.c_int32()
+        _ffi.check(_ffi.lib().dfq_le_query(self._plan, _ffi.stream_arg(), ctypes.byref(res), ctypes.byref(done)))
+        return dict(sweeps=res.sweeps, stall_count=res.stall_count, diff=res.diff, last_diff_tmp=res.last_diff_tmp,
+                    done=bool(done.value))
+
+    def close(self):
+        if self._plan:
+            _ffi.lib().dfq_le_plan_destroy(self._plan)
+            self._plan = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def build_le_plan(graph, relations, targ_type, stage=None):
+    """Work tables for ``cross_layer_equalization`` on a reference-format graph."""
+    stage = stage or _ffi.Stage()
+    keys = [k for k in graph if type(graph[k]) in targ_type]
+    index = {k: i for i, k in enumerate(keys)}
+    for rr in relations:                                  # dfq.py:91-92
+        _ensure_bias(graph[rr.get_idxs()[0]])
+    layers = [(graph[k].weight, graph[k].bias, getattr(graph[k], 'groups', 1)) for k in keys]
+    rels = []
+    for rr in relations:
+        kf, ks, kb = rr.get_idxs()
+        o1 = graph[kf].weight.size(0)
+        if rr.S is None:
+            scum = torch.ones(o1, dtype=torch.float32, device=stage.device)
+        else:
+            scum = rr.S
+        bn = graph[kb] if kb is not None else None
+        rels.append((index[kf], index[ks], getattr(bn, 'fake_weight', None), getattr(bn, 'fake_bias', None), scum))
+    return LEPlan(layers, rels, stage=stage)
+
+
+# ------------------------------------------------------------------------------------------------
+# dfq.py:8-25
+# ------------------------------------------------------------------------------------------------
+_REDUCTIONS = {None: 0, 'none': 0, 'sum': 1, 'mean': 2, 'channel': 3, 'spatial': 4}
+
+
+def _quantize_error(param, num_bits=8, reduction='sum', signed=False):
+    """Q(param) - param with per-tensor min/max; reduction in {'sum','mean','channel','spatial',None}."""
+    mode = _REDUCTIONS.get(reduction, 0)
+    lib = _ffi.lib()
+    with torch.no_grad():
+        stage = _ffi.Stage()
+        x = stage.bind(param)
+        n = x.numel()
+        rows = 0
+        if mode == 3:
+            rows = x.shape[0]
+        elif mode == 4:
+            rows = x.shape[0] * x.shape[1]
+        out = stage.new(x.shape) if mode == 0 else stage.new((1,))
+        scratch = stage.new((int(lib.dfq_quant_error_scratch_bytes(n, rows)) // 4 + 4,), dtype=torch.int32)
+        _ffi.check(lib.dfq_quant_error(_ffi.ptr(x), n, rows, int(num_bits), int(bool(signed)), mode, _ffi.ptr(out),
+                                       _ffi.ptr(scratch), _ffi.stream_arg()))
+        res = stage.out_like(param, out)
+        return res if mode == 0 else res.reshape(())
+
+
+# ------------------------------------------------------------------------------------------------
+# dfq.py:28-75
+# ------------------------------------------------------------------------------------------------
+def _layer_equalization(weight_first, weight_second, bias_first, bn_weight=None, bn_bias=None,
+                        s_range=(1e-8, 1e8), signed=False, eps=0):
+    """Equalise one pair in place; returns (weight_first, weight_second, bias_first, S)."""
+    with torch.no_grad():
+        stage = _ffi.Stage()
+        o1 = weight_first.shape[0]
+        scum = torch.ones(o1, dtype=torch.float32, device=stage.device)
+        plan = LEPlan([(weight_first, bias_first, 1), (weight_second, None, 1)],
+                      [(0, 1, bn_weight, bn_bias, scum)], stage=stage)
+        try:
+            plan.run(s_range=s_range, signed=signed, eps=eps, max_sweeps=1, converge_thres=-1.0)
+        finally:
+            plan.close()
+        stage.writeback()
+        S = stage.out_like(weight_first, scum)
+    return weight_first, weight_second, bias_first, S
+
+
+# ------------------------------------------------------------------------------------------------
+# dfq.py:78-117
+# ------------------------------------------------------------------------------------------------
+last_equalization = None      # result of the most recent cross_layer_equalization call
+
+
+def cross_layer_equalization(graph, relations, targ_type, s_range=[1e-8, 1e8], range_thres=0,
+                             converge_thres=2e-7, converge_count=20, signed=False, eps=0,
+                             visualize_state=False, max_sweeps=None):
+    """Sweep the relation list until the reference's convergence test fires (dfq.py:83-115).
+
+    ``range_thres`` and ``visualize_state`` are accepted and unused (the reference ignores
+    ``range_thres`` too).  ``max_sweeps`` is an extension: an upper bound on the sweep count
+    (``None`` = the reference's unbounded loop).  Returns None; see ``last_equalization``.
+    """
+    global last_equalization
+    print("Start cross layer equalization")
+    with torch.no_grad():
+        stage = _ffi.Stage()
+        plan = build_le_plan(graph, relations, targ_type, stage=stage)
+        try:
+            res = plan.run(s_range=s_range, converge_thres=converge_thres, converge_count=converge_count,
+                           signed=signed, eps=eps, max_sweeps=max_sweeps)
+        finally:
+            plan.close()
+        stage.writeback()
+        for rr, sc in zip(relations, plan.scale_cum):
+            first = graph[rr.get_idxs()[0]].weight
+            rr.S = stage.out_like(first, sc)              # Relation.set_scale_vec, cumulative
+    last_equalization = res
+
+
+# ------------------------------------------------------------------------------------------------
+# dfq.py:121-164
+# ------------------------------------------------------------------------------------------------
+def _relu_between(graph, bottoms, layer_second, layer_first):
+    key = layer_second
+    while key != layer_first:
+        assert len(bottoms[key]) == 1, 'graph in equalization relations should be 1-to-1 input-output'
+        if type(graph[bottoms[key][0]]) == torch.nn.ReLU:
+            return True
+        key = bottoms[key][0]
+    return False
+
+
+def bias_absorption(graph, relations, bottoms, N=3):
+    """Move the part of each first layer's bias that a following ReLU never clips into the second
+    layer: c = max(0, beta~ - N*gamma~); b1 -= c; beta~ -= c; b2 += W2.sum(kh,kw) @ c."""
+    print("Absorbing bias")
+    lib = _ffi.lib()
+    with torch.no_grad():
+        stage = _ffi.Stage()
+        for rr in relations:
+            kf, ks, kb = rr.get_idxs()
+            if not _relu_between(graph, bottoms, ks, kf):
+                continue
+            first, second, bn = graph[kf], graph[ks], graph[kb]
+            _ensure_bias(first)
+            _ensure_bias(second)
+            w2 = stage.bind(second.weight)
+            b1, b2 = stage.bind(first.bias), stage.bind(second.bias)
+            fw, fb = stage.bind(bn.fake_weight), stage.bind(bn.fake_bias)
+            khkw = w2[0, 0].numel() if w2.dim() > 2 else 1
+            _ffi.check(lib.dfq_bias_absorb(_ffi.ptr(w2), w2.shape[0], w2.shape[1], khkw, first.weight.size(0),
+                                           _ffi.ptr(b1), _ffi.ptr(b2), _ffi.ptr(fw), _ffi.ptr(fb),
+                                           ctypes.c_float(N), _ffi.stream_arg()))
+        stage.writeback()
+
+
+# ------------------------------------------------------------------------------------------------
+# dfq.py:167-170
+# ------------------------------------------------------------------------------------------------
+def clip_weight(graph, range_clip=[-15, 15], targ_type=[nn.Conv2d, nn.Linear]):
+    lib = _ffi.lib()
+    with torch.no_grad():
+        stage = _ffi.Stage()
+        for key in graph:
+            if type(graph[key]) in targ_type:
+                w = stage.bind(graph[key].weight)
+                _ffi.check(lib.dfq_clamp(_ffi.ptr(w), w.numel(), ctypes.c_float(range_clip[0]),
+                                         ctypes.c_float(range_clip[1]), _ffi.stream_arg()))
+        stage.writeback()
+
+
+# ------------------------------------------------------------------------------------------------
+# dfq.py:173-293
+# ------------------------------------------------------------------------------------------------
+class BCPlan:
+    """Flat tables for the bias-correction chain of one graph (see build_bc_plan)."""
+
+    def __init__(self, layers, steps, stage=None):
+        """layers: list of (weight, bias, groups); steps: list of (layer_idx, [source,...],
+        next_bn_bias|None); source = (fake_weight, fake_bias, relu, concat)."""
+        self.stage = stage or _ffi.Stage()
+        self._keep = []
+        entries = []
+        for (w, b, g) in layers:
+            e, keep = _layer_entry(self.stage, w, b, g)
+            entries.append(e)
+            self._keep.append(keep)
+        src_arr, step_arr = [], []
+        for (li, srcs, nxt) in steps:
+            begin = len(src_arr)
+            for (fw, fb, relu, concat) in srcs:
+                dfw, dfb = self.stage.bind(fw), self.stage.bind(fb)
+                self._keep.append((dfw, dfb))
+                src_arr.append(_ffi.DfqBcSource(dfw.data_ptr() if dfw is not None else None, dfb.data_ptr(),
+                                                int(dfb.numel()), int(bool(relu)), int(bool(concat))))
+            dn = self.stage.bind(nxt)
+            self._keep.append(dn)
+            step_arr.append(_ffi.DfqBcStep(int(li), begin, len(srcs), dn.data_ptr() if dn is not None else None))
+        self.n_steps = len(step_arr)
+        self.step_out_ch = [int(layers[li][0].shape[0]) for (li, _, _) in steps]
+        self.step_in = [int(layers[li][0].shape[1]) for (li, _, _) in steps]
+        larr = (_ffi.DfqLayer * len(entries))(*entries)
+        sarr = (_ffi.DfqBcStep * len(step_arr))(*step_arr)
+        carr = (_ffi.DfqBcSource * len(src_arr))(*src_arr)
+        self._plan = ctypes.c_void_p()
+        _ffi.check(_ffi.lib().dfq_bc_plan_create(larr, len(entries), sarr, len(step_arr), carr, len(src_arr),
+                                                 ctypes.byref(self._plan)))
+
+    @property
+    def weight_elements(self):
+        return _ffi.lib().dfq_bc_plan_weight_elements(self._plan)
+
+    @property
+    def eps_elements(self):
+        return _ffi.lib().dfq_bc_plan_eps_elements(self._plan)
+
+    def run(self, signed=False):
+        _ffi.check(_ffi.lib().dfq_bc_plan_run(self._plan, int(bool(signed)), _ffi.stream_arg()))
+
+    def _view(self, addr, n):
+        """Copy n floats out of the plan's device scratch (tests / debugging)."""
+        out = self.stage.new((n,))
+        out.copy_(_RawDeviceBuffer(addr, n, self.stage.device).tensor())
+        return out
+
+    def eps(self, step):
+        _ffi.synchronize()
+        addr = _ffi.lib().dfq_bc_plan_eps(self._plan, step)
+        return self._view(addr, self.step_out_ch[step] * self.step_in[step]).reshape(self.step_out_ch[step], -1)
+
+    def correction(self, step):
+        _ffi.synchronize()
+        addr = _ffi.lib().dfq_bc_plan_correction(self._plan, step)
+        return self._view(addr, self.step_out_ch[step])
+
+    def close(self):
+        if self._plan:
+            _ffi.lib().dfq_bc_plan_destroy(self._plan)
+            self._plan = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class _RawDeviceBuffer:
+    """Wrap a raw float32 address of the engine's scratch as a torch tensor (read-only use)."""
+
+    def __init__(self, addr, n, device):
+        self.addr, self.n, self.device = addr, n, device
+
+    def tensor(self):
+        if self.device.type == 'cuda':
+            iface = {'shape': (self.n,), 'typestr': '<f4', 'data': (self.addr, True), 'version': 2, 'strides': None}
+            holder = type('_Holder', (), {'__cuda_array_interface__': iface})()
+            return torch.as_tensor(holder, device=self.device)
+        import numpy as np
+        buf = (ctypes.c_float * self.n).from_address(self.addr)
+        return torch.from_numpy(np.ctypeslib.as_array(buf).copy())
+
+
+def build_bc_plan(graph, bottoms, targ_type, bn_type=torch.nn.BatchNorm2d, stage=None):
+    """Walk the graph like dfq.py:194-293 and flatten what each layer's correction needs."""
+    stage = stage or _ffi.Stage()
+    keys = [k for k in graph if type(graph[k]) in targ_type]
+    index = {k: i for i, k in enumerate(keys)}
+    bn_module, relu_attached = {}, {}
+    steps = []
+    pending = None                       # step whose -bias still waits for "the next BN" (bias_prev)
+    for key in graph:
+        bot = bottoms[key]
+        if bot is None or bot[0] == 'Data':
+            continue
+        node = graph[key]
+        if type(node) == bn_type:
+            bn_module[key] = node
+            relu_attached[key] = False
+            if pending is not None:
+                assert node.fake_bias.numel() == graph[keys[pending[0]]].weight.size(0), \
+                    'bias correction: BN after layer has a different channel count'
+                pending[2] = node.fake_bias
+                pending = None
+            continue
+        if type(node) == torch.nn.ReLU:
+            if bot[0] in bn_module:
+                relu_attached[bot[0]] = True
+        if type(node) in targ_type:
+            bn_list, relu_list, connect_list, _ = find_prev_bn(bn_module, relu_attached, graph, bottoms, bot[:])
+            branches = {}
+            for i, (bn, bid) in enumerate(bn_list):
+                branches.setdefault(bid[0], []).append((bn, bid, relu_list[i], connect_list[i]))
+            assert len(branches) == 1, "Error while calculating expectation for bias correction"
+            ordered = sorted(list(branches.values())[0], key=lambda e: len(e[1]), reverse=True)   # stable
+            srcs = []
+            for j, (bn, _, relu, ctype) in enumerate(ordered):
+                srcs.append((bn.fake_weight, bn.fake_bias, relu, j > 0 and ctype == 'cat'))
+            _ensure_bias(node)
+            step = [index[key], srcs, None]
+            steps.append(step)
+            pending = step
+    layers = [(graph[k].weight, graph[k].bias, getattr(graph[k], 'groups', 1)) for k in keys]
+    return BCPlan(layers, [tuple(s) for s in steps], stage=stage), [keys[s[0]] for s in steps]
+
+
+def bias_correction(graph, bottoms, targ_type, bits_weight=8, bn_type=torch.nn.BatchNorm2d, signed=False):
+    """Analytic bias correction: b -= eps . E[x], propagated into the next BN's beta~.
+
+    ``bits_weight`` is accepted and ignored -- the reference hard-codes 8 bits (dfq.py:218).
+    """
+    print("Start bias correction")
+    with torch.no_grad():
+        stage = _ffi.Stage()
+        plan, _ = build_bc_plan(graph, bottoms, targ_type, bn_type, stage=stage)
+        try:
+            plan.run(signed=signed)
+            _ffi.synchronize()
+        finally:
+            plan.close()
+        stage.writeback()

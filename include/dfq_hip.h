@@ -1,0 +1,267 @@
+/*
+ * dfq_hip.h -- C ABI of libdfq_hip.so, the MI355X (gfx950) engine behind the DFQ calibration
+ * hot path of jakc4103/DFQ.
+ *
+ * This is the drop-in boundary.  The reference is a pure-Python program whose calibration passes
+ * are Python loops over channels issuing eager torch-CPU ops; it has no FFI of its own.  Each
+ * entry point below replaces one such Python function body (cited as file:line of the reference)
+ * and is what a maintainer of the reference would bind from Python with ctypes (see
+ * INTEGRATION.md).  The Python package `dfq_amd` is exactly such a binding, keeping the
+ * reference's call surface (`cross_layer_equalization`, `bias_correction`,
+ * `transform_quant_layer`, `quantize`/`UniformQuantize`, ...).
+ *
+ * Conventions
+ *   - every pointer marked "device" is a HIP device pointer to contiguous float32 (or the stated
+ *     type) owned by the caller (in practice: torch-ROCm tensors);
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); calls are
+ *     asynchronous on that stream unless the comment says "synchronises";
+ *   - return value: 0 on success, a negative code on failure; dfq_last_error() gives the
+ *     thread-local message.  Nothing aborts, nothing falls back to the CPU;
+ *   - weights are OIHW contiguous ([O, I/g, kH, kW]; Linear is [O, I] with kH*kW = 1), float32,
+ *     exactly the layout torch gives `nn.Conv2d.weight` / `nn.Linear.weight`.
+ *
+ * Arithmetic contract (DESIGN.md "Numerics"): all float32 operations are IEEE-754 correctly
+ * rounded single operations (no FMA contraction, no fast-math, round-half-even for the
+ * quantiser), scalars that the reference computes as Python doubles are computed in float64 on
+ * the device.  Integer codes of the fake-quant round trip are bit-exact against the reference.
+ */
+#ifndef DFQ_HIP_H
+#define DFQ_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DFQ_HIP_VERSION 100 /* 0.1.0 */
+
+/* error codes */
+#define DFQ_OK 0
+#define DFQ_ERR_ARG (-1)     /* invalid argument / unsupported geometry            */
+#define DFQ_ERR_HIP (-2)     /* a HIP runtime call failed (message has the details) */
+#define DFQ_ERR_STATE (-3)   /* object used in the wrong state                      */
+
+int dfq_version(void);
+const char* dfq_last_error(void);
+/* number of visible HIP devices, or a negative error */
+int dfq_device_count(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Layer / relation tables shared by the plans
+ * ---------------------------------------------------------------------------------------- */
+
+/* One "targ layer" (Conv2d / Linear family; dfq.py:106, main_cls.py:137-145). */
+typedef struct dfq_layer {
+    float* weight;         /* device [out_ch, in_per_group, khkw]                       */
+    float* bias;           /* device [out_ch] or NULL                                    */
+    int32_t out_ch;        /* O                                                          */
+    int32_t in_per_group;  /* I / groups                                                 */
+    int32_t khkw;          /* kH * kW (1 for Linear)                                     */
+    int32_t groups;        /* conv groups (1 for Linear); informational                  */
+} dfq_layer;
+
+/* One equalisation pair (utils/relation.py:5-27): layers[first] -> (BN, ReLU...) -> layers[second]. */
+typedef struct dfq_relation {
+    int32_t first;         /* index into the dfq_layer table                             */
+    int32_t second;
+    float* bn_weight;      /* device [O1]  BN proxy fake_weight (dfq.py:64-65) or NULL   */
+    float* bn_bias;        /* device [O1]  BN proxy fake_bias   (dfq.py:67-68) or NULL   */
+    float* scale_cum;      /* device [O1]  cumulative S of Relation.set_scale_vec
+                              (relation.py:20-24); must hold 1.0f before the first sweep */
+} dfq_relation;
+
+/* ------------------------------------------------------------------------------------------
+ * Cross-layer equalisation -- replaces dfq.py:28-75 (_layer_equalization) and the sweep loop
+ * dfq.py:78-117 (cross_layer_equalization)
+ * ---------------------------------------------------------------------------------------- */
+typedef struct dfq_le_plan dfq_le_plan;   /* opaque */
+
+typedef struct dfq_le_config {
+    float s_lo, s_hi;          /* s_range (dfq.py:78 default [1e-8, 1e8]) rounded to float32  */
+    float inv_lo, inv_hi;      /* float32(1.0 / s_range[k]) computed in double by the caller  */
+    int32_t hi_gt_lo;          /* Python `s_range[1] > s_range[0]` (double compare)           */
+    float eps;                 /* dfq.py:58 eps                                               */
+    int32_t signed_range;      /* 0: max-min (dfq.py:54-55), 1: max|.| (dfq.py:50-51)         */
+    double converge_thres;     /* dfq.py:83                                                   */
+    int32_t converge_count;    /* dfq.py:83                                                   */
+    int32_t max_sweeps;        /* extension: stop after this many sweeps; <0 = reference loop */
+} dfq_le_config;
+
+typedef struct dfq_le_result {
+    int32_t sweeps;            /* sweeps executed                                             */
+    int32_t stall_count;       /* `count` of dfq.py:110-115 at exit                           */
+    double diff;               /* `diff` of dfq.py:110-115 at exit                            */
+    double last_diff_tmp;      /* diff_tmp of the last sweep                                  */
+} dfq_le_result;
+
+/* Builds the device-side work list: dependency levels of the relation list (Gauss-Seidel order of
+ * dfq.py:85 is preserved: two relations sharing a layer are never in the same launch), channel
+ * tiles, the per-layer convergence-diff bookkeeping.  `layers` / `relations` are host arrays and
+ * are copied.  Allocates a few small device buffers plus a snapshot arena for layers that are
+ * rescaled twice per sweep.  Synchronises. */
+int dfq_le_plan_create(const dfq_layer* layers, int32_t n_layers,
+                       const dfq_relation* relations, int32_t n_relations,
+                       dfq_le_plan** out_plan);
+void dfq_le_plan_destroy(dfq_le_plan* plan);
+
+/* introspection (tests, bench byte accounting) */
+int32_t dfq_le_plan_levels(const dfq_le_plan* plan);
+int64_t dfq_le_plan_paired_elements(const dfq_le_plan* plan);   /* sum over relations of n1+n2  */
+int64_t dfq_le_plan_snapshot_elements(const dfq_le_plan* plan); /* elements of twice-touched layers */
+int32_t dfq_le_plan_level_launches(const dfq_le_plan* plan, int32_t level, int64_t* paired_elems,
+                                   int64_t* snapshot_elems, int32_t* n_workgroups);
+
+/* Enqueue exactly `n_sweeps` sweeps plus their convergence bookkeeping on `stream`; never
+ * synchronises.  The device-side loop state decides whether a sweep still executes (after the
+ * reference's exit condition fires the remaining launches are no-ops).  `restart` != 0 resets the
+ * loop state (diff = 10, count = 0) first. */
+int dfq_le_enqueue(dfq_le_plan* plan, const dfq_le_config* cfg, int32_t n_sweeps, int32_t restart,
+                   void* stream);
+/* Copy the loop state back (synchronises `stream`). */
+int dfq_le_query(dfq_le_plan* plan, void* stream, dfq_le_result* out, int32_t* done);
+/* The whole dfq.py:83-115 loop: enqueue in chunks, poll, stop when the device says so.
+ * Synchronises. */
+int dfq_le_run(dfq_le_plan* plan, const dfq_le_config* cfg, void* stream, dfq_le_result* out);
+/* Measurement aid (bench.py roofline): like dfq_le_enqueue(restart=1) for `n_sweeps` sweeps, but every
+ * launch is bracketed by a pair of HIP events recorded on `stream`.  level_ms[l] receives the summed
+ * duration of the launches of level l (array of dfq_le_plan_levels() doubles), *control_ms the summed
+ * duration of the convergence kernel, *n_level_launches the number of level launches timed.
+ * Synchronises. */
+int dfq_le_profile(dfq_le_plan* plan, const dfq_le_config* cfg, int32_t n_sweeps, void* stream,
+                   double* level_ms, double* control_ms, int32_t* n_level_launches);
+
+/* ------------------------------------------------------------------------------------------
+ * Tensor primitives -- utils/quantize.py:23-76 (UniformQuantize.forward), :102-119 (QuantMeasure)
+ * ---------------------------------------------------------------------------------------- */
+
+/* out2[0] = min(x), out2[1] = max(x) as float32 (device).  `scratch2` is a device uint32[2] that
+ * the call zeroes and uses for the order-preserving atomic reduction. */
+int dfq_tensor_minmax(const float* x, int64_t n, float* out2, uint32_t* scratch2, void* stream);
+
+/* Fake-quant round trip y = rint(clip((x + (-min)) / scale, qmin, qmax)) * scale + min
+ * (quantize.py:70-74), five separately rounded float32 operations.
+ *   range_mode 0: min/max are host doubles (the reference's `float(...)` call sites); the scale
+ *                 recipe of quantize.py:49-66 runs in float64.
+ *   range_mode 1: min/max are read from the device float32 pair `minmax_dev` and the recipe runs
+ *                 in float64 on the device (same values as mode 0 without a host round trip).
+ *   range_mode 2: min/max from `minmax_dev`, recipe entirely in float32 -- the `min_value=None`
+ *                 tensor path of quantize.py:24-35 (bias fake-quant call sites :198,:226,:311,:335).
+ * `codes` (device int32[n]) receives the integer codes when not NULL.  x == y (in place) is allowed. */
+int dfq_fake_quant(const float* x, float* y, int64_t n, int32_t num_bits, int32_t symmetric,
+                   int32_t range_mode, double min_value, double max_value,
+                   const float* minmax_dev, int32_t* codes, void* stream);
+
+/* QuantMeasure statistics (quantize.py:103-107): out2[0] = mean_n(min over chw of x[n]),
+ * out2[1] = mean_n(max over chw of x[n]).  If `running2` (device float[2] = {running_min,
+ * running_max}) is not NULL it is updated in place: running_min = min(running_min, out2[0]),
+ * running_max = max(running_max, out2[1]).  `scratch` is a device uint32[2*n_samples]. */
+int dfq_sample_minmax_mean(const float* x, int32_t n_samples, int64_t sample_len, float* out2,
+                           float* running2, uint32_t* scratch, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Multi-layer weight quantisation -- utils/layer_transform.py:279-296 (quantize_targ_layer)
+ * ---------------------------------------------------------------------------------------- */
+typedef struct dfq_quant_plan dfq_quant_plan;
+
+/* One plan over a table of tensors ("segments"): per-tensor min/max in one launch, fake-quant of
+ * all tensors in a second launch. */
+typedef struct dfq_segment {
+    float* data;            /* device                                                    */
+    int64_t n;
+    int32_t num_bits;       /* per segment (weights 8, biases 16 in main_cls.py:181)      */
+    int32_t symmetric;
+    int32_t* codes;         /* device int32[n] or NULL                                    */
+} dfq_segment;
+
+int dfq_quant_plan_create(const dfq_segment* segs, int32_t n_segs, dfq_quant_plan** out_plan);
+void dfq_quant_plan_destroy(dfq_quant_plan* plan);
+/* min/max of every segment -> quantise every segment in place (range_mode 1 recipe). */
+int dfq_quant_plan_run(dfq_quant_plan* plan, void* stream);
+/* device float32[2*n_segs] min/max pairs of the last run (valid after the stream reaches it) */
+const float* dfq_quant_plan_minmax(const dfq_quant_plan* plan);
+
+/* ------------------------------------------------------------------------------------------
+ * Bias correction -- dfq.py:173-293 (bias_correction), :8-25 (_quantize_error)
+ * ---------------------------------------------------------------------------------------- */
+typedef struct dfq_bc_plan dfq_bc_plan;
+
+/* One BatchNorm contributing to E[x] of a layer (dfq.py:229-270), in the order the reference
+ * merges them (depth-sorted, stable). */
+typedef struct dfq_bc_source {
+    const float* fake_weight;  /* device [channels]  (gamma~)                               */
+    const float* fake_bias;    /* device [channels]  (beta~) -- read at the layer's turn    */
+    int32_t channels;
+    int32_t relu;              /* 1: E = gamma*pdf(-b/g) + b*(1-cdf(-b/g)), clipped at 0    */
+    int32_t concat;            /* 1: torch.cat onto the running expectation, 0: add (first
+                                  source: ignored)                                          */
+} dfq_bc_source;
+
+typedef struct dfq_bc_step {
+    int32_t layer;             /* index into the dfq_layer table; bias must be non-NULL     */
+    int32_t source_begin;      /* range in the dfq_bc_source table                          */
+    int32_t source_count;
+    float* next_bn_bias;       /* device [out_ch]: fake_bias of the next BN in graph order,
+                                  receives += (-bias) (dfq.py:204-206,293); NULL if none    */
+} dfq_bc_step;
+
+int dfq_bc_plan_create(const dfq_layer* layers, int32_t n_layers,
+                       const dfq_bc_step* steps, int32_t n_steps,
+                       const dfq_bc_source* sources, int32_t n_sources,
+                       dfq_bc_plan** out_plan);
+void dfq_bc_plan_destroy(dfq_bc_plan* plan);
+/* per-tensor min/max of all step layers -> quant-error row sums eps[O, I/g] of all step layers
+ * (8 bit, dfq.py:218-219) -> the sequential per-layer chain.  Asynchronous. */
+int dfq_bc_plan_run(dfq_bc_plan* plan, int32_t symmetric, void* stream);
+/* device pointers into the plan's scratch (tests): eps[O*I/g], expect[len], bias[O] of a step */
+const float* dfq_bc_plan_eps(const dfq_bc_plan* plan, int32_t step);
+const float* dfq_bc_plan_correction(const dfq_bc_plan* plan, int32_t step);
+int64_t dfq_bc_plan_weight_elements(const dfq_bc_plan* plan);
+int64_t dfq_bc_plan_eps_elements(const dfq_bc_plan* plan);
+
+/* _quantize_error (dfq.py:8-25) on one tensor: q(x) - x with per-tensor min/max, 5 reductions:
+ *   reduction 0: none   -> out[n]
+ *   reduction 1: 'sum'  -> out[0] = sum |eps|
+ *   reduction 2: 'mean' -> out[0] = mean eps
+ *   reduction 3: 'channel' -> out[0] = sum_o | sum_rest eps |      (rows = shape[0])
+ *   reduction 4: 'spatial' -> out[0] = sum_{o,i} | sum_khkw eps |  (rows = shape[0]*shape[1])
+ * `rows` is the number of leading-dimension groups for reductions 3/4 (ignored otherwise).
+ * `scratch` is device memory of dfq_quant_error_scratch_bytes(n, rows) bytes. */
+size_t dfq_quant_error_scratch_bytes(int64_t n, int64_t rows);
+int dfq_quant_error(const float* x, int64_t n, int64_t rows, int32_t num_bits, int32_t symmetric,
+                    int32_t reduction, float* out, void* scratch, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Row / column rescale helpers -- utils/layer_transform.py:231-276 (merge_batchnorm),
+ * utils/quantize.py:145-174,:269-289 (merge_scale*), dfq.py:121-170 (bias_absorption, clip_weight)
+ * ---------------------------------------------------------------------------------------- */
+
+/* w[o, :] = w[o, :] * s[o]   (op 0)   or   w[o, :] / s[o]   (op 1);  row_len = I/g * khkw */
+int dfq_scale_rows(float* w, int32_t rows, int64_t row_len, const float* s, int32_t op, void* stream);
+/* Input-channel rescale of a grouped conv weight [O, I/g, khkw]: input channel of element
+ * (o, i, k) is  (o / (O/groups)) * I/g + i;  w = w * s[ch] (op 0) or w / s[ch] (op 1). */
+int dfq_scale_cols(float* w, int32_t out_ch, int32_t in_per_group, int32_t khkw, int32_t groups,
+                   const float* s, int32_t op, void* stream);
+/* vector helpers on [n]: y = y * s (op 0), y / s (op 1), y + s (op 2), y - s (op 3) */
+int dfq_vec_op(float* y, const float* s, int64_t n, int32_t op, void* stream);
+/* x = clamp(x, lo, hi) (dfq.py:170) */
+int dfq_clamp(float* x, int64_t n, float lo, float hi, void* stream);
+
+/* BatchNorm folding (layer_transform.py:246-272) for one (conv, bn) pair.  In place:
+ *   k = gamma / sqrt(var + bn_eps);  W[o,:] *= k[o];  b = b*k + (beta - gamma*mean/sqrt(var+bn_eps));
+ *   fake_weight = |gamma|; fake_bias = beta;  then gamma=1, var=1, beta=0, mean=0. */
+int dfq_fold_batchnorm(float* w, float* b, int32_t out_ch, int64_t row_len, float* gamma,
+                       float* beta, float* mean, float* var, float bn_eps, float* fake_weight,
+                       float* fake_bias, void* stream);
+
+/* Bias absorption for one relation (dfq.py:138-164):  c = max(0, beta~ - N*gamma~);
+ * wc[g] = (sum_khkw W2)[g] . c[g];  b1 -= c;  beta~ -= c;  b2 += wc. */
+int dfq_bias_absorb(const float* w2, int32_t o2, int32_t in_per_group, int32_t khkw, int32_t o1,
+                    float* b1, float* b2, const float* bn_weight, float* bn_bias, float n_sigma,
+                    void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DFQ_HIP_H */

@@ -1,0 +1,120 @@
+"""Shared helpers of the parity tests (numpy side: oracle; torch side: engine under test)."""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+TARG = [nn.Conv2d, nn.Linear]
+F32 = np.float32
+
+
+def bits(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=F32)).view(np.int32)
+
+
+def assert_bitexact(a, b, what=''):
+    a = np.asarray(a, dtype=F32)
+    b = np.asarray(b, dtype=F32)
+    assert a.shape == b.shape, '{}: shape {} vs {}'.format(what, a.shape, b.shape)
+    same = (bits(a) == bits(b)) | (np.isnan(a) & np.isnan(b))
+    assert same.all(), '{}: {} of {} elements differ, max abs diff {}'.format(
+        what, int((~same).sum()), a.size, float(np.nanmax(np.abs(a.astype(np.float64) - b))))
+
+
+def assert_close(a, b, what='', tol=1e-5):
+    """|a-b| <= tol * max(1, |b|): the float32 contract of BASELINE.json (1e-5)."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, '{}: shape {} vs {}'.format(what, a.shape, b.shape)
+    if a.size == 0:
+        return 0.0
+    err = np.abs(a - b) / np.maximum(1.0, np.abs(b))
+    worst = float(np.nanmax(err))
+    assert worst <= tol, '{}: max err {:.3e} > {:.1e}'.format(what, worst, tol)
+    return worst
+
+
+def npy(t):
+    return t.detach().cpu().numpy().astype(F32)
+
+
+def load_inputs(graph, gold, device):
+    """Overwrite the random-init parameters of a synthetic net with the fixture's inputs."""
+    with torch.no_grad():
+        for i, k in enumerate(graph):
+            m = graph[k]
+            if type(m) in TARG:
+                m.weight.copy_(torch.from_numpy(gold['in.L{}.w'.format(i)]))
+                if 'in.L{}.b'.format(i) in gold:
+                    m.bias.copy_(torch.from_numpy(gold['in.L{}.b'.format(i)]))
+            elif type(m) == nn.BatchNorm2d:
+                g, b, mu, var = gold['in.L{}.bn'.format(i)]
+                m.weight.copy_(torch.from_numpy(g))
+                m.bias.copy_(torch.from_numpy(b))
+                m.running_mean.copy_(torch.from_numpy(mu))
+                m.running_var.copy_(torch.from_numpy(var))
+
+
+def snapshot(graph):
+    snap = {}
+    for i, k in enumerate(graph):
+        m = graph[k]
+        if type(m) in TARG:
+            snap['L{}.w'.format(i)] = npy(m.weight)
+            if m.bias is not None:
+                snap['L{}.b'.format(i)] = npy(m.bias)
+        elif type(m) == nn.BatchNorm2d and hasattr(m, 'fake_weight'):
+            snap['L{}.fw'.format(i)] = npy(m.fake_weight)
+            snap['L{}.fb'.format(i)] = npy(m.fake_bias)
+    return snap
+
+
+def load_stage(graph, gold, stage):
+    """Put the reference's state after `stage` ('merge','le','abs','bc') into the modules."""
+    with torch.no_grad():
+        for i, k in enumerate(graph):
+            m = graph[k]
+            if type(m) in TARG:
+                m.weight.copy_(torch.from_numpy(gold['{}.L{}.w'.format(stage, i)]).to(m.weight.device))
+                kb = '{}.L{}.b'.format(stage, i)
+                if kb in gold:
+                    if m.bias is None:
+                        m.bias = nn.Parameter(torch.zeros(m.weight.size(0), device=m.weight.device), requires_grad=False)
+                    m.bias.copy_(torch.from_numpy(gold[kb]).to(m.weight.device))
+                else:
+                    m.bias = None
+            elif type(m) == nn.BatchNorm2d and '{}.L{}.fw'.format(stage, i) in gold:
+                fw = torch.from_numpy(gold['{}.L{}.fw'.format(stage, i)]).to(m.weight.device)
+                fb = torch.from_numpy(gold['{}.L{}.fb'.format(stage, i)]).to(m.weight.device)
+                if hasattr(m, 'fake_weight'):
+                    m.fake_weight.copy_(fw)
+                    m.fake_bias.copy_(fb)
+                else:
+                    m.register_buffer('fake_weight', fw.clone())
+                    m.register_buffer('fake_bias', fb.clone())
+
+
+def compare_stage(snap, gold, stage, exact=False, tol=1e-5, what=''):
+    keys = [k[len(stage) + 1:] for k in gold.files if k.startswith(stage + '.')]
+    assert set(keys) == set(snap), '{} {}: key sets differ: {}'.format(what, stage, set(keys) ^ set(snap))
+    worst = 0.0
+    for k in keys:
+        if exact:
+            assert_bitexact(snap[k], gold[stage + '.' + k], '{} {} {}'.format(what, stage, k))
+        else:
+            worst = max(worst, assert_close(snap[k], gold[stage + '.' + k], '{} {} {}'.format(what, stage, k), tol))
+    return worst
+
+
+NET_FIXTURES = [
+    ('tiny_mobile', 0, ''), ('tiny_mobile', 1, '_abs'), ('tiny_mobile', 2, '_signed'),
+    ('tiny_res', 0, ''), ('tiny_cat', 0, ''), ('tiny_cat', 3, '_abs'),
+]
+
+
+def net_fixture(name, seed, suffix):
+    return np.load(os.path.join(GOLD, 'net_{}_s{}{}.npz'.format(name, seed, suffix)))

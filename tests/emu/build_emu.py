@@ -1,0 +1,47 @@
+"""TEST INFRASTRUCTURE ONLY: compile the unmodified kernel sources of dfq_amd/csrc with g++ against
+the fiber-based HIP emulation in tests/emu/include, producing tests/emu/_build/libdfq_emu.so with the
+same C ABI as the product library.  Used by the `-m "not gpu"` tests to run every kernel's logic on
+the CPU of the build container.  The product package never loads this library."""
+from __future__ import annotations
+
+import glob
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+OUT = os.path.join(HERE, '_build', 'libdfq_emu.so')
+
+
+def sources():
+    src = sorted(glob.glob(os.path.join(ROOT, 'dfq_amd', 'csrc', '*.hip')))
+    src += sorted(glob.glob(os.path.join(ROOT, 'dfq_amd', 'csrc', '*.cpp')))
+    src.append(os.path.join(HERE, 'emu_runtime.cpp'))
+    return src
+
+
+def deps():
+    d = sources()
+    d += glob.glob(os.path.join(ROOT, 'dfq_amd', 'csrc', '*.hpp'))
+    d += glob.glob(os.path.join(ROOT, 'include', '*.h'))
+    d += glob.glob(os.path.join(HERE, 'include', 'hip', '*.h'))
+    return d
+
+
+def build(force=False):
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    if not force and os.path.exists(OUT):
+        t = os.path.getmtime(OUT)
+        if all(os.path.getmtime(f) <= t for f in deps()):
+            return OUT
+    cmd = ['g++', '-O2', '-g', '-std=c++17', '-fPIC', '-shared', '-ffp-contract=off', '-fno-fast-math',
+           '-Wall', '-Wno-unknown-pragmas', '-Wno-unused-function', '-Wno-unused-variable',
+           '-I', os.path.join(HERE, 'include'), '-I', os.path.join(ROOT, 'include'), '-o', OUT]
+    for s in sources():
+        cmd += ['-x', 'c++', s]
+    subprocess.run(cmd, check=True)
+    return OUT
+
+
+if __name__ == '__main__':
+    print(build(force=True))

@@ -1,0 +1,37 @@
+"""TEST INFRASTRUCTURE: run bench.py / __graft_entry__.smoke() logic on the CPU emulation (tiny net) to
+catch Python-level mistakes before spending GPU minutes.   python tests/emu/dryrun.py"""
+import ctypes
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import torch
+import build_emu
+from dfq_amd import _ffi
+
+_ffi._lib = _ffi.bind(ctypes.CDLL(build_emu.build()))
+_ffi.target_device = lambda: torch.device('cpu')
+_ffi.current_stream = lambda: 0
+_ffi.synchronize = lambda: None
+
+import bench
+bench._device = lambda lr: torch.device('cpu')
+bench._sync = lambda: None
+sys.argv = ['bench.py', '--net', 'tiny_mobile', '--steps', '2', '--warmup', '1', '--cpu-seconds', '0.2']
+bench.main()
+
+# smoke() with cuda patched out
+import __graft_entry__ as ge
+torch.cuda.is_available = lambda: True
+torch.cuda.synchronize = lambda *a, **k: None
+_real_device = torch.device
+class _Dev:
+    def __call__(self, *a, **k):
+        return _real_device('cpu')
+import unittest.mock as mock
+with mock.patch('torch.device', _Dev()):
+    ge.smoke()

@@ -1,0 +1,123 @@
+// TEST INFRASTRUCTURE ONLY -- a tiny single-threaded emulation of the HIP constructs used by
+// dfq_amd/csrc/*.hip so that the *unmodified* kernel sources can be compiled with g++ and executed
+// on the CPU of the build container (which has no GPU).  Every GPU thread of a workgroup is a
+// ucontext fiber; __syncthreads() and the wave shuffles are real rendezvous points, so divergent
+// barriers and indexing bugs show up here instead of costing GPU minutes.  Workgroups run one after
+// another (no inter-workgroup races can be observed -- those are only testable on the GPU).
+//
+// Nothing under dfq_amd/ knows about this directory; it is reached only through
+// `-I tests/emu/include` in tests/emu/build_emu.py, and the resulting library is loaded only by
+// tests.  The product library is always built by hipcc against the real <hip/hip_runtime.h>.
+#pragma once
+
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <cmath>
+#include <functional>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __launch_bounds__(...)
+#define __shared__ static
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+
+struct float4 {
+    float x, y, z, w;
+};
+
+typedef int hipError_t;
+#define hipSuccess 0
+#define hipErrorUnknown 999
+typedef struct emu_stream* hipStream_t;
+enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 };
+
+namespace emu {
+
+struct ThreadCtx {
+    dim3 tid, bid, bdim, gdim;
+    uint64_t slot;
+};
+extern ThreadCtx* cur;
+
+void launch(dim3 grid, dim3 block, const std::function<void()>& body);
+void sync_block();
+void sync_wave();
+uint64_t peer_slot(int lane_xor_mask, bool* valid);
+uint64_t peer_slot_abs(int src_lane, bool* valid);
+
+template <typename T>
+inline T shfl_xor(T v, int mask) {
+    static_assert(sizeof(T) <= 8, "shuffle payload");
+    uint64_t bits = 0;
+    memcpy(&bits, &v, sizeof(T));
+    cur->slot = bits;
+    sync_wave();
+    bool ok = false;
+    uint64_t got = peer_slot(mask, &ok);
+    sync_wave();
+    if (!ok) return v;
+    T out;
+    memcpy(&out, &got, sizeof(T));
+    return out;
+}
+
+}  // namespace emu
+
+#define threadIdx (emu::cur->tid)
+#define blockIdx (emu::cur->bid)
+#define blockDim (emu::cur->bdim)
+#define gridDim (emu::cur->gdim)
+
+inline void __syncthreads() { emu::sync_block(); }
+template <typename T>
+inline T __shfl_xor(T v, int mask) { return emu::shfl_xor(v, mask); }
+
+inline uint32_t __float_as_uint(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+inline float __uint_as_float(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+inline unsigned atomicMax(unsigned* p, unsigned v) { unsigned o = *p; if (v > o) *p = v; return o; }
+inline unsigned atomicMin(unsigned* p, unsigned v) { unsigned o = *p; if (v < o) *p = v; return o; }
+inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
+inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
+inline double atomicAdd(double* p, double v) { double o = *p; *p = o + v; return o; }
+
+using std::max;
+using std::min;
+
+// ---- runtime API subset -------------------------------------------------------------------------
+inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "success" : "emulated error"; }
+inline hipError_t hipGetLastError() { return hipSuccess; }
+inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+inline hipError_t hipMalloc(void** p, size_t n) {
+    *p = aligned_alloc(256, (n + 255) / 256 * 256 + 256);
+    if (*p) memset(*p, 0xA5, n);   // poison: kernels must not rely on zeroed allocations
+    return *p ? hipSuccess : hipErrorUnknown;
+}
+inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
+inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
+inline hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
+inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
+
+typedef struct emu_event* hipEvent_t;
+inline hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return hipSuccess; }
+inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.0f; return hipSuccess; }
+
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
+    emu::launch((grid), (block), [=]() { kernel(__VA_ARGS__); })

@@ -1,0 +1,253 @@
+"""Parity of the HIP engine with the CPU oracle and with the reference's golden outputs.
+
+Every test runs on both backends of conftest.engine: 'emu' (kernel sources under the CPU emulation,
+`-m "not gpu"`) and 'gpu' (libdfq_hip.so on a real MI355X, `-m gpu` -- the parity tests proper).
+
+Contract (BASELINE.json north_star / DESIGN.md):
+  * fake-quant round trip: bit-exact float32 outputs and integer codes;
+  * LE / BC float32 weights, biases, BN proxies, S: |err| <= 1e-5 against the reference; against the
+    oracle (same IEEE single operations in the same order) LE is bit-exact.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from oracle import dfq_oracle as orc
+from oracle import graphspec
+from dfq_amd import dfq, synthetic
+from dfq_amd.utils import layer_transform as lt
+from dfq_amd.utils import quantize as q
+from dfq_amd.utils import relation as rel
+
+from common import (GOLD, NET_FIXTURES, TARG, F32, assert_bitexact, assert_close, compare_stage, load_inputs,
+                    load_stage, net_fixture, npy, snapshot)
+
+
+# ---------------------------------------------------------------------------------------------
+# fake-quant (a4)
+# ---------------------------------------------------------------------------------------------
+def test_fake_quant_known_answers(engine):
+    g = np.load(os.path.join(GOLD, 'kat_fake_quant.npz'))
+    for i, (nbits, sym, mn, mx) in enumerate(g['cases']):
+        x = engine.to(torch.from_numpy(g['x{}'.format(i)].copy()))
+        if np.isnan(mn):
+            y = q.quantize(x, num_bits=int(nbits))
+        else:
+            y = q.UniformQuantize().apply(x, int(nbits), float(mn), float(mx), False, bool(sym))
+        assert_bitexact(npy(y), g['y{}'.format(i)], 'fake-quant case {}'.format(i))
+
+
+@pytest.mark.parametrize('n,nbits,sym', [(1, 8, False), (63, 8, True), (4097, 8, False), (70001, 4, True),
+                                         (12345, 16, False)])
+def test_fake_quant_codes_vs_oracle(engine, n, nbits, sym):
+    rng = np.random.default_rng(n)
+    x = (rng.standard_normal(n) * 3).astype(F32)
+    mn, mx = float(x.min()), float(x.max())
+    y_o, c_o = orc.uniform_quantize(x, nbits, mn, mx, sym, return_codes=True)
+    y, c = q.uniform_quantize(engine.to(torch.from_numpy(x.copy())), nbits, mn, mx, False, sym, return_codes=True)
+    assert_bitexact(npy(y), y_o, 'values')
+    assert np.array_equal(c.cpu().numpy(), c_o.astype(np.int32)), 'integer codes differ'
+
+
+def test_fake_quant_inplace_and_ste(engine):
+    x = engine.to(torch.linspace(-2, 2, 1000))
+    ref = orc.uniform_quantize(npy(x), 8, -2.0, 2.0)
+    xin = x.clone()
+    out = q.quantize(xin, 8, -2.0, 2.0, inplace=True)
+    assert out.data_ptr() == xin.data_ptr()
+    assert_bitexact(npy(xin), ref)
+    xg = x.clone().requires_grad_(True)
+    q.quantize(xg, 8, -2.0, 2.0).sum().backward()
+    assert torch.equal(xg.grad, torch.ones_like(xg))          # straight-through estimator
+
+
+def test_tensor_minmax_and_sample_stats(engine):
+    rng = np.random.default_rng(5)
+    for shape in [(1,), (7, 3), (16, 5, 9, 9), (3, 100003)]:
+        x = rng.standard_normal(shape).astype(F32)
+        xd = engine.to(torch.from_numpy(x.copy()))
+        mm = npy(q.tensor_minmax(xd))
+        assert mm[0] == x.min() and mm[1] == x.max()
+        n = shape[0]
+        got = npy(q.sample_minmax_mean(xd, n))
+        want = orc.sample_minmax_mean(x)
+        assert_bitexact(got, np.array(want, dtype=F32), 'sample stats {}'.format(shape))
+
+
+def test_quant_measure(engine):
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((8, 4, 6, 6)).astype(F32)
+    m = q.QuantMeasure(update_stat=True).to(engine.device).eval()
+    y = m(engine.to(torch.from_numpy(x.copy())))
+    y_o, rmin, rmax = orc.quant_measure_forward(x, 0.0, 0.0, update_stat=True)
+    assert_bitexact(npy(m.running_min), np.array([rmin], dtype=F32))
+    assert_bitexact(npy(m.running_max), np.array([rmax], dtype=F32))
+    assert_bitexact(npy(y), y_o, 'QuantMeasure output')
+    m.set_update_stat(False)
+    y2 = m(engine.to(torch.from_numpy((x * 0.5).astype(F32))))
+    y2_o, _, _ = orc.quant_measure_forward((x * 0.5).astype(F32), rmin, rmax, update_stat=False)
+    assert_bitexact(npy(y2), y2_o)
+
+
+@pytest.mark.parametrize('reduction', ['sum', 'mean', 'channel', 'spatial', None])
+def test_quantize_error(engine, reduction):
+    rng = np.random.default_rng(3)
+    w = rng.standard_normal((12, 5, 3, 3)).astype(F32)
+    got = npy(dfq._quantize_error(engine.to(torch.from_numpy(w.copy())), 8, reduction))
+    want = orc.quantize_error(w, 8, reduction)
+    if reduction is None:
+        assert_bitexact(got, want)
+    else:
+        assert_close(got, np.asarray(want, dtype=F32), 'reduction {}'.format(reduction), tol=1e-6)
+
+
+# ---------------------------------------------------------------------------------------------
+# _layer_equalization (a1): every pairing geometry, dead channels, eps, signed
+# ---------------------------------------------------------------------------------------------
+def _kat_names():
+    return [str(n) for n in np.load(os.path.join(GOLD, 'kat_le_pairs.npz'))['names']]
+
+
+@pytest.mark.parametrize('name', _kat_names())
+def test_layer_equalization_pairs(engine, name):
+    g = np.load(os.path.join(GOLD, 'kat_le_pairs.npz'))
+    signed, eps, use_bn = g['{}.cfg'.format(name)]
+    use_bn = bool(use_bn)
+    arrs = {w: g['{}.in.{}'.format(name, w)].copy() for w in ('w1', 'w2', 'b1', 'bnw', 'bnb')}
+    t = {k: engine.to(torch.from_numpy(v.copy())) for k, v in arrs.items()}
+    W1, W2, B1, S = dfq._layer_equalization(t['w1'], t['w2'], t['b1'] if use_bn else None,
+                                            t['bnw'] if use_bn else None, t['bnb'] if use_bn else None,
+                                            signed=bool(signed), eps=eps)
+    assert W1 is t['w1'] and W2 is t['w2']                     # in place, like the reference
+    # oracle on the same inputs: identical IEEE operations -> bit-exact
+    o = {k: v.copy() for k, v in arrs.items()}
+    S_o = orc.layer_equalization(o['w1'], o['w2'], o['b1'] if use_bn else None, o['bnw'] if use_bn else None,
+                                 o['bnb'] if use_bn else None, signed=bool(signed), eps=eps)
+    assert_bitexact(npy(S), S_o, name + ' S vs oracle')
+    for k in ('w1', 'w2') + (('b1', 'bnw', 'bnb') if use_bn else ()):
+        assert_bitexact(npy(t[k]), o[k], '{} {} vs oracle'.format(name, k))
+        assert_close(npy(t[k]), g['{}.out.{}'.format(name, k)], '{} {} vs reference'.format(name, k))
+    assert_close(npy(S), g['{}.out.S'.format(name)], name + ' S vs reference')
+
+
+def test_layer_equalization_large_rows(engine):
+    """Rows longer than a workgroup, tiles of one channel, 3x3 second layer (ResNet-like)."""
+    rng = np.random.default_rng(21)
+    w1 = rng.standard_normal((70, 33, 3, 3)).astype(F32)
+    w2 = (rng.standard_normal((90, 70, 3, 3)) * 0.1).astype(F32)
+    b1 = rng.standard_normal(70).astype(F32)
+    t = [engine.to(torch.from_numpy(a.copy())) for a in (w1, w2, b1)]
+    _, _, _, S = dfq._layer_equalization(t[0], t[1], t[2])
+    S_o = orc.layer_equalization(w1, w2, b1)
+    assert_bitexact(npy(S), S_o)
+    assert_bitexact(npy(t[0]), w1)
+    assert_bitexact(npy(t[1]), w2)
+    assert_bitexact(npy(t[2]), b1)
+
+
+# ---------------------------------------------------------------------------------------------
+# whole pipeline on the tiny nets, stage by stage against the reference's outputs
+# ---------------------------------------------------------------------------------------------
+def _build(name, seed, gold, engine):
+    model, graph, bottoms = synthetic.build(name, seed=seed)
+    load_inputs(graph, gold, 'cpu')
+    model.to(engine.device)
+    return model, graph, bottoms
+
+
+@pytest.mark.parametrize('name,seed,suffix', NET_FIXTURES)
+def test_pipeline_stages(engine, name, seed, suffix):
+    gold = net_fixture(name, seed, suffix)
+    absorption, signed = [bool(v) for v in gold['cfg']]
+    model, graph, bottoms = _build(name, seed, gold, engine)
+    spec = graphspec.from_torch(graph, bottoms, TARG)          # oracle twin of the inputs
+    keys = list(graph.keys())
+
+    lt.merge_batchnorm(model, graph, bottoms, TARG)
+    compare_stage(snapshot(graph), gold, 'merge', tol=1e-6, what=name)
+    orc.merge_batchnorm(spec)
+
+    rels = rel.create_relation(graph, bottoms, TARG, delete_single=False)
+    assert [[keys.index(k) for k in r.get_idxs()] for r in rels] == gold['relations'].tolist()
+
+    dfq.cross_layer_equalization(graph, rels, TARG, converge_thres=2e-7, signed=signed)
+    res = dfq.last_equalization
+    orels = orc.create_relation(spec)
+    n_o, S_o = orc.cross_layer_equalization(spec, orels, signed=signed)
+    assert res['sweeps'] == n_o == int(gold['oracle_sweeps'])
+    # engine == oracle bit for bit (same IEEE operations, same order)
+    osnap = _spec_snapshot(spec)
+    esnap = snapshot(graph)
+    for k in osnap:
+        assert_bitexact(esnap[k], osnap[k], '{} LE {} vs oracle'.format(name, k))
+    for r, s in zip(rels, S_o):
+        assert_bitexact(npy(r.get_scale_vec()), s, 'S_cum vs oracle')
+    if res['sweeps'] == int(gold['n_sweeps']):
+        compare_stage(esnap, gold, 'le', what=name)
+        for i, r in enumerate(rels):
+            assert_close(npy(r.get_scale_vec()), gold['S{}'.format(i)], 'S{} vs reference'.format(i))
+
+    # the later stages start from the REFERENCE's state so every stage is compared on equal inputs
+    load_stage(graph, gold, 'le')
+    if absorption:
+        dfq.bias_absorption(graph, rels, bottoms, 3)
+    compare_stage(snapshot(graph), gold, 'abs', what=name)
+
+    load_stage(graph, gold, 'abs')
+    dfq.bias_correction(graph, bottoms, TARG, signed=signed)
+    compare_stage(snapshot(graph), gold, 'bc', what=name)
+
+    load_stage(graph, gold, 'bc')
+    lt.quantize_targ_layer(graph, 8, 16, TARG)
+    compare_stage(snapshot(graph), gold, 'q', exact=True, what=name)
+
+
+def test_max_sweeps_and_restart(engine):
+    gold = net_fixture('tiny_mobile', 0, '')
+    model, graph, bottoms = _build('tiny_mobile', 0, gold, engine)
+    lt.merge_batchnorm(model, graph, bottoms, TARG)
+    rels = rel.create_relation(graph, bottoms, TARG)
+    spec = graphspec.from_torch(graph, bottoms, TARG)
+    dfq.cross_layer_equalization(graph, rels, TARG, max_sweeps=3)
+    assert dfq.last_equalization['sweeps'] == 3
+    orels = orc.create_relation(spec)
+    n, S = orc.cross_layer_equalization(spec, orels, max_sweeps=3)
+    osnap, esnap = _spec_snapshot(spec), snapshot(graph)
+    for k in osnap:
+        assert_bitexact(esnap[k], osnap[k], k)
+    # a second call continues from the current weights and accumulates S (relation.py:20-24)
+    dfq.cross_layer_equalization(graph, rels, TARG, max_sweeps=2)
+    n, S2 = orc.cross_layer_equalization(spec, orels, max_sweeps=2)
+    for r, a, b in zip(rels, S, S2):      # ((s1*s2*s3)*s4)*s5 vs (s1*s2*s3)*(s4*s5): equal up to rounding
+        assert_close(npy(r.get_scale_vec()), (a * b).astype(F32), tol=1e-6)
+    osnap, esnap = _spec_snapshot(spec), snapshot(graph)
+    for k in osnap:
+        assert_bitexact(esnap[k], osnap[k], k)
+
+
+def test_clip_weight(engine):
+    gold = net_fixture('tiny_cat', 0, '')
+    model, graph, bottoms = _build('tiny_cat', 0, gold, engine)
+    before = snapshot(graph)
+    dfq.clip_weight(graph, [-0.05, 0.07], TARG)
+    after = snapshot(graph)
+    for k in before:
+        if k.endswith('.w'):
+            assert_bitexact(after[k], np.clip(before[k], F32(-0.05), F32(0.07)))
+
+
+def _spec_snapshot(spec):
+    snap = {}
+    for i, k in enumerate(spec.order):
+        n = spec.nodes[k]
+        if n.kind == 'targ':
+            snap['L{}.w'.format(i)] = n.weight
+            if n.bias is not None:
+                snap['L{}.b'.format(i)] = n.bias
+        elif n.kind == 'bn' and n.fake_weight is not None:
+            snap['L{}.fw'.format(i)] = n.fake_weight
+            snap['L{}.fb'.format(i)] = n.fake_bias
+    return snap
