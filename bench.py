@@ -198,7 +198,15 @@ def main():
     if rank == 0 and not args.no_roofline:
         # dominant kernel: le_level_kernel.  Algorithmic bytes per sweep = 8 B per paired element (read
         # + write; the ranges come from the same read) + 4 B per snapshot-arena element touched.
-        prof = make_replica(proto)['le'].profile(sweeps, max_sweeps=sweeps)
+        prof_rep = make_replica(proto)
+        prof = prof_rep['le'].profile(sweeps, max_sweeps=sweeps)
+        per_level = []
+        for l in range(levels):
+            info = prof_rep['le'].level_info(l)
+            us = prof['level_ms'][l] * 1e3 / sweeps
+            nbytes = 8 * info['paired_elements'] + 4 * info['snapshot_elements']
+            per_level.append({'level': l, 'relations': info['relations'], 'workgroups': info['workgroups'],
+                              'bytes': nbytes, 'us': us, 'GBps': nbytes / max(us, 1e-9) / 1e3})
         level_ms = sum(prof['level_ms'])
         launches = prof['level_launches']
         bytes_per_sweep = 8 * paired + 4 * snap
@@ -209,7 +217,7 @@ def main():
             'bound': 'hbm', 'kernel': 'le_level_kernel', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
             'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
             'bytes_per_launch': avg_bytes, 'us_per_launch': avg_ms * 1e3, 'launches_timed': launches,
-            'control_us_per_sweep': prof['control_ms'] * 1e3 / sweeps,
+            'control_us_per_sweep': prof['control_ms'] * 1e3 / sweeps, 'levels': per_level,
         }
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         out['cpu_baseline'], _ = cpu_baseline(args.net, 0, args.cpu_seconds)

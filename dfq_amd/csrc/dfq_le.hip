@@ -1,29 +1,39 @@
 // Cross-layer weight equalisation (dfq.py:28-75 _layer_equalization, dfq.py:78-117 sweep loop)
 // for gfx950.
 //
-// Work decomposition
-//   relation  = (first layer W1 [O1, row_len], second layer W2 [O2, I2/g, khkw]);  channel c of
-//               W1 pairs with input channel ii = c % gi of group g = c / gi of W2 (dfq.py:29-46).
-//   tile      = `tc` consecutive paired channels of one relation = one 256-thread workgroup.
-//               The W1 side of a tile is ONE contiguous run of tc*row_len floats, the W2 side is
-//               `go` runs of tc*khkw floats (contiguous across consecutive channels of a group),
-//               so both sides are read with unit-stride lanes.
-//   level     = set of relations that share no layer (Gauss-Seidel order of dfq.py:85 kept
-//               between levels) = one kernel launch.
-// A tile does everything for its channels in one launch: ranges of the rows and of the strided
-// columns (order-preserving LDS atomics), the scale solve with the reference's Python clamp
-// semantics, the in-place rescale of W1 rows / b1 / BN proxies / W2 columns, the cumulative S, and
-// the convergence statistic sum|W - W_prev| as a per-tile float64 partial.  Each paired element is
-// read twice (second read is an L1/L2 hit) and written once.
+// The reference visits every paired channel c of a relation (W1 = first layer [O1, row_len],
+// W2 = second layer [O2, I2/g, khkw]) and does: r1 = range(W1[c]), r2 = range(W2[:, c]),
+// s = solve(r1, r2), W1[c] *= s, W2[:, c] *= 1/s.  Computing a range needs a full row / a full
+// strided column, scaling needs the scale: two dependent passes over the data per relation.
 //
-// Convergence bookkeeping (dfq.py:105-115): a layer touched once per sweep needs no snapshot
-// (|new - old| is known in registers); a layer touched twice (second of one relation, first of the
-// next) stores its pre-sweep value into a snapshot arena at the first touch and reads it back at
-// the last.  Untouched layers contribute exactly 0.  A single-workgroup control kernel reduces the
-// partials per layer in a fixed order, forms mean -> float32 -> float64 sum in graph order and
-// advances the reference's (diff, count) state machine on the device; every level kernel starts
-// with a uniform load of `done` and exits if the loop has ended, so the host can enqueue sweeps
-// ahead without synchronising.
+// Stat forwarding.  fl(v * s) is monotone in v for s > 0, and every write of a layer is done by
+// exactly one of these kernels, so the ranges a relation will need are produced as a by-product of
+// the PREVIOUS write of that layer:
+//   * the column rescale of W2 (which is the first layer of the next relation in its chain) emits
+//     the new per-row min/max of W2                       -> row stats R1 of the next relation;
+//   * the row rescale of W1 (second layer of the previous relation in its chain) emits the new
+//     per-input-channel min/max of W1                     -> column stats R2 of the previous
+//     relation, consumed one sweep later;
+//   * a layer that is only ever scaled one way (chain start / chain end) has its stats forwarded
+//     arithmetically: min' = fl(min * s), max' = fl(max * s) -- exact by monotonicity.
+// A sweep level is therefore ONE streaming launch: every element is read once and written once
+// (8 B per paired element), tiles are independent (any number of workgroups, unit-stride lanes),
+// and the scale of a channel is re-derived from four stat words by every tile that needs it
+// (identical IEEE operations -> identical value everywhere).  Results are bit-identical to the
+// two-pass formulation because min/max are exact.
+//
+//   level     = relations that share no layer (Gauss-Seidel order of dfq.py:85 kept between
+//               levels) = one launch of le_level_kernel;
+//   row tile  = [rt_rows x rt_cols] block of W1: lanes along the contiguous row positions, each
+//               thread walks down the rows (column stats accumulate in registers);
+//   col tile  = ct_rows full rows of W2: `lanes` consecutive threads stride along one row (row
+//               stats by butterfly), the 1/s table of the row's input channels sits in LDS.
+//
+// Convergence (dfq.py:105-115): per-tile float64 partials of sum|W - W_prev| (a layer touched
+// twice per sweep saves its pre-sweep value to a snapshot arena at the first touch), reduced in a
+// fixed order by a one-workgroup control kernel that also advances the reference's (diff, count)
+// state machine on the device.  Level kernels start with a uniform load of `done`, so the host
+// enqueues sweeps ahead without synchronising.
 #include <algorithm>
 #include <cstdlib>
 #include <vector>
@@ -32,9 +42,15 @@
 
 namespace dfq {
 
-constexpr int kTcMax = 64;      // max paired channels per tile (LDS arrays below)
+constexpr int kRowTileRowsMax = 256;   // rows of a row tile (one solve per thread)
+constexpr int kRowTileColsMax = 128;   // positions of a row tile
+constexpr int kSlotMax = 1024;         // column-stat slots of a row tile in LDS
+constexpr int kInvMax = 8192;          // 1/s table of a col tile in LDS (floats)
+constexpr int kChunkCh = 2048;         // input channels of W2 handled per pass of a col tile
+constexpr int kColRowsMax = 1024;      // rows of a col tile
+constexpr int kBootTc = 64;            // channels per bootstrap tile
 
-enum DiffMode : int32_t { DIFF_DIRECT = 0, DIFF_SAVE = 1, DIFF_FROM_PREV = 2, DIFF_NONE = 3 };
+enum DiffMode : int32_t { DIFF_DIRECT = 0, DIFF_SAVE = 1, DIFF_FROM_PREV = 2 };
 
 struct LeRelDev {
     float* w1;
@@ -43,14 +59,24 @@ struct LeRelDev {
     float* bnw;
     float* bnb;
     float* s_cum;
-    float* prev1;    // snapshot arena of the first layer (same indexing as w1) or null
-    float* prev2;    // snapshot arena of the second layer or null
-    int32_t o1, row_len;
-    int32_t gi, go, i2g, khkw;
-    int32_t tc, n_tiles;
+    float* prev1;        // snapshot arena of the first layer (same indexing as w1) or null
+    float* prev2;
+    uint32_t* r1;        // parity 0 of the row stats of W1: [o1][2] = (min slot, max slot); parity 1 is
+    uint32_t* r2;        // `stat_stride` words further.  r2: column stats of W2 per paired channel
+    uint32_t* out_cols;  // R2 of the relation whose SECOND layer is our W1 (atomics), or null: forward r1
+    uint32_t* out_rows;  // R1 of the relation whose FIRST layer is our W2 (plain stores), or null: forward r2
+    int32_t o1, row_len, khkw1;
+    int32_t pc_go, pc_gi, pc_n;          // W1 element (o, i) -> channel (o / pc_go) * pc_gi + i of out_cols
+    int32_t o2, gi, go, i2g, khkw;       // W2 geometry; paired channel c = g*gi + ii
+    int32_t rt_rows, rt_cols, rt_slabs, n_row_tiles;
+    int32_t ct_rows, ct_lanes, ct_chunk, n_col_tiles;
+    int32_t boot_tiles;
     int32_t diff1, diff2;
-    int32_t partial_base;   // first tile slot of this relation in the partial array
+    int32_t partial_base;   // first partial slot of this relation (row tiles, then col tiles)
     int32_t tile_begin;     // first workgroup of this relation inside its level launch
+    int32_t boot_begin;     // first workgroup inside the bootstrap launch
+    int32_t pad;
+    int64_t stat_stride;    // words between the two parities of a stat arena
 };
 
 struct LeParams {
@@ -68,10 +94,8 @@ struct LeState {
 };
 
 struct LeLayerDiff {
-    int32_t partial_begin;   // tile slot of the first partial of the diff-producing touch, -1: untouched
+    int32_t partial_begin;   // -1: layer untouched by any relation (contributes exactly 0)
     int32_t n_partials;
-    int32_t side;            // 0: row side of that relation, 1: column side
-    int32_t pad;
     double n_elems;
 };
 
@@ -90,182 +114,347 @@ __device__ __forceinline__ void le_solve(float r1, float r2, const LeParams& p, 
     inv_out = keep_lo ? (keep_hi ? (1.0f / s_out) : p.inv_hi) : p.inv_lo;
 }
 
-__device__ __forceinline__ float range_of(uint32_t mn_slot, uint32_t mx_slot, int signed_range) {
-    const float mn = slot_min(mn_slot);
-    const float mx = slot_max(mx_slot);
+__device__ __forceinline__ float range_of(float mn, float mx, int signed_range) {
     if (signed_range) return fmaxf(fabsf(mn), fabsf(mx));
     return mx - mn;
+}
+
+// scale of paired channel c from the four stat words of the current parity
+__device__ __forceinline__ void channel_scale(const LeRelDev& R, const LeParams& p, int cur, int c, float& s,
+                                              float& inv, float& mn1, float& mx1, float& mn2, float& mx2) {
+    const uint32_t* a = R.r1 + (int64_t)cur * R.stat_stride + 2 * c;
+    const uint32_t* b = R.r2 + (int64_t)cur * R.stat_stride + 2 * c;
+    mn1 = slot_min(a[0]); mx1 = slot_max(a[1]);
+    mn2 = slot_min(b[0]); mx2 = slot_max(b[1]);
+    le_solve(range_of(mn1, mx1, p.signed_range), range_of(mn2, mx2, p.signed_range), p, s, inv);
+}
+
+__device__ __forceinline__ void diff_touch(int mode, float nv, float v, float* prev, int64_t idx, double& acc) {
+    if (mode == DIFF_DIRECT) acc += (double)fabsf(nv - v);
+    else if (mode == DIFF_SAVE) prev[idx] = v;
+    else acc += (double)fabsf(nv - prev[idx]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// row tile: W1[r0:r0+nr, p0:p0+np] *= s[row]   (+ column stats of the new values)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double row_tile(const LeRelDev& R, const LeParams& p, int tile, int cur,
+                                           float* sh_s, uint32_t* sh_slot) {
+    const int tid = threadIdx.x;
+    const int slab = tile % R.rt_slabs;
+    const int r0 = (tile / R.rt_slabs) * R.rt_rows;
+    const int nr = min(R.rt_rows, R.o1 - r0);
+    const int p0 = slab * R.rt_cols;
+    const int np = min(R.rt_cols, R.row_len - p0);
+    const int nxt = cur ^ 1;
+
+    // column-stat slot geometry of this tile
+    const bool emit = R.out_cols != nullptr;
+    int g0 = 0, i0 = 0, nci = 1, n_slots = 0;
+    if (emit) {
+        g0 = r0 / R.pc_go;
+        i0 = p0 / R.khkw1;
+        nci = (p0 + np - 1) / R.khkw1 - i0 + 1;
+        n_slots = ((r0 + nr - 1) / R.pc_go - g0 + 1) * nci;
+        for (int i = tid; i < 2 * n_slots; i += kBlock) sh_slot[i] = 0u;
+    }
+    if (tid < nr) {
+        const int c = r0 + tid;
+        float s, inv, mn1, mx1, mn2, mx2;
+        channel_scale(R, p, cur, c, s, inv, mn1, mx1, mn2, mx2);
+        sh_s[tid] = s;
+        if (slab == 0) {                                   // one tile per row owns the [O1] vectors
+            R.s_cum[c] = R.s_cum[c] * s;                  // relation.py:20-24
+            if (R.bnw) R.bnw[c] = R.bnw[c] * s;           // dfq.py:64-65
+            if (R.bnb) R.bnb[c] = R.bnb[c] * s;           // dfq.py:67-68
+            if (R.b1) R.b1[c] = R.b1[c] * s;              // dfq.py:70-71
+            if (!emit) {                                   // W1 is never column-scaled: forward its row stats
+                uint32_t* f = R.r1 + (int64_t)nxt * R.stat_stride + 2 * c;
+                f[0] = ~enc_ord(mn1 * s);
+                f[1] = enc_ord(mx1 * s);
+            }
+        }
+    }
+    __syncthreads();
+
+    double acc = 0.0;
+    const int JL = kBlock / np;                // np <= 128 -> JL >= 2
+    const int jl = tid / np;
+    const int pp = tid - jl * np;
+    if (jl < JL) {
+        const int pos = p0 + pp;
+        const int ci = emit ? (pos / R.khkw1 - i0) : 0;
+        float cmn = INFINITY, cmx = -INFINITY;
+        int cur_g = -1;
+        for (int rb = jl; rb < nr; rb += 4 * JL) {
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int r = rb + u * JL;
+                v[u] = (r < nr) ? R.w1[(int64_t)(r0 + r) * R.row_len + pos] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int r = rb + u * JL;
+                if (r < nr) {
+                    const int64_t idx = (int64_t)(r0 + r) * R.row_len + pos;
+                    const float nv = v[u] * sh_s[r];          // dfq.py:62
+                    R.w1[idx] = nv;
+                    diff_touch(R.diff1, nv, v[u], R.prev1, idx, acc);
+                    if (emit) {
+                        const int g = (r0 + r) / R.pc_go - g0;
+                        if (g != cur_g) {
+                            if (cur_g >= 0) {
+                                atomicMax(&sh_slot[2 * (cur_g * nci + ci) + 0], ~enc_ord(cmn));
+                                atomicMax(&sh_slot[2 * (cur_g * nci + ci) + 1], enc_ord(cmx));
+                            }
+                            cur_g = g; cmn = INFINITY; cmx = -INFINITY;
+                        }
+                        cmn = fminf(cmn, nv);
+                        cmx = fmaxf(cmx, nv);
+                    }
+                }
+            }
+        }
+        if (emit && cur_g >= 0) {
+            atomicMax(&sh_slot[2 * (cur_g * nci + ci) + 0], ~enc_ord(cmn));
+            atomicMax(&sh_slot[2 * (cur_g * nci + ci) + 1], enc_ord(cmx));
+        }
+    }
+    if (emit) {
+        __syncthreads();
+        for (int sl = tid; sl < n_slots; sl += kBlock) {
+            const uint32_t a = sh_slot[2 * sl + 0], b = sh_slot[2 * sl + 1];
+            if (b != 0u) {
+                const int g = g0 + sl / nci;
+                const int i = i0 + sl % nci;
+                uint32_t* dst = R.out_cols + (int64_t)nxt * R.stat_stride + 2 * ((int64_t)g * R.pc_gi + i);
+                atomicMax(dst + 0, a);
+                atomicMax(dst + 1, b);
+            }
+        }
+    }
+    return acc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// col tile: full rows W2[r0:r0+nr, :] *= 1/s[input channel]   (+ row stats of the new values)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double col_tile(const LeRelDev& R, const LeParams& p, int tile, int cur,
+                                           float* sh_inv, uint32_t* sh_row) {
+    const int tid = threadIdx.x;
+    const int r0 = tile * R.ct_rows;
+    const int nr = min(R.ct_rows, R.o2 - r0);
+    const int nxt = cur ^ 1;
+    const int G = R.ct_lanes;                  // power of two
+    const int n_groups = kBlock / G;
+    const int grp = tid / G;
+    const int ln = tid - grp * G;
+    const int g_lo = r0 / R.go;
+    const int g_n = (r0 + nr - 1) / R.go - g_lo + 1;
+    const int row_len2 = R.i2g * R.khkw;
+    const bool emit = R.out_rows != nullptr;
+
+    if (emit) {
+        for (int i = tid; i < 2 * nr; i += kBlock) sh_row[i] = 0u;
+    }
+    double acc = 0.0;
+    for (int ii0 = 0; ii0 < R.i2g; ii0 += R.ct_chunk) {
+        const int nch = min(R.ct_chunk, R.i2g - ii0);
+        __syncthreads();                        // previous chunk's readers are done with sh_inv
+        for (int idx = tid; idx < g_n * nch; idx += kBlock) {
+            const int gq = idx / nch;
+            const int ii = ii0 + idx - gq * nch;
+            const int g = g_lo + gq;
+            const int c = g * R.gi + ii;
+            float s, inv, mn1, mx1, mn2, mx2;
+            channel_scale(R, p, cur, c, s, inv, mn1, mx1, mn2, mx2);
+            sh_inv[idx] = inv;
+            // W2 is never row-scaled: forward its column stats (the tile holding the group's first row does it)
+            if (!emit && g * R.go >= r0 && g * R.go < r0 + nr) {
+                uint32_t* f = R.r2 + (int64_t)nxt * R.stat_stride + 2 * c;
+                f[0] = ~enc_ord(mn2 * inv);
+                f[1] = enc_ord(mx2 * inv);
+            }
+        }
+        __syncthreads();
+        const int npos = nch * R.khkw;
+        const int dch = G / R.khkw;
+        const int drem = G - dch * R.khkw;
+        const int n_iter = (nr + n_groups - 1) / n_groups;
+        for (int it = 0; it < n_iter; ++it) {          // uniform trip count: every lane reaches the shuffles
+            const int r = grp + it * n_groups;
+            const bool act = r < nr;
+            const int o = r0 + (act ? r : 0);
+            const float* tab = sh_inv + (o / R.go - g_lo) * nch;
+            const int64_t base = (int64_t)o * row_len2 + (int64_t)ii0 * R.khkw;
+            float* prev = R.prev2;
+            float rmn = INFINITY, rmx = -INFINITY;
+            int ch = ln / R.khkw;
+            int rem = ln - ch * R.khkw;
+            for (int pb = ln; act && pb < npos; pb += 4 * G) {
+                float v[4];
+                int chs[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int pos = pb + u * G;
+                    v[u] = (pos < npos) ? R.w2[base + pos] : 0.0f;
+                    chs[u] = ch;
+                    ch += dch; rem += drem;
+                    if (rem >= R.khkw) { rem -= R.khkw; ++ch; }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int pos = pb + u * G;
+                    if (pos < npos) {
+                        const float nv = v[u] * tab[chs[u]];      // dfq.py:73
+                        R.w2[base + pos] = nv;
+                        diff_touch(R.diff2, nv, v[u], prev, base + pos, acc);
+                        rmn = fminf(rmn, nv);
+                        rmx = fmaxf(rmx, nv);
+                    }
+                }
+            }
+            if (emit) {
+                for (int m = G >> 1; m >= 1; m >>= 1) {
+                    rmn = fminf(rmn, __shfl_xor(rmn, m));
+                    rmx = fmaxf(rmx, __shfl_xor(rmx, m));
+                }
+                if (act && ln == 0 && rmn <= rmx) {
+                    atomicMax(&sh_row[2 * r + 0], ~enc_ord(rmn));
+                    atomicMax(&sh_row[2 * r + 1], enc_ord(rmx));
+                }
+            }
+        }
+    }
+    if (emit) {
+        __syncthreads();
+        // complete rows: plain stores into the SAME sweep's parity (consumed by a later level)
+        for (int r = tid; r < nr; r += kBlock) {
+            uint32_t* dst = R.out_rows + (int64_t)cur * R.stat_stride + 2 * (r0 + r);
+            dst[0] = sh_row[2 * r + 0];
+            dst[1] = sh_row[2 * r + 1];
+        }
+    }
+    return acc;
 }
 
 __global__ __launch_bounds__(kBlock) void le_level_kernel(const LeRelDev* __restrict__ rels, int n_rels,
                                                           LeParams p, const LeState* __restrict__ state,
                                                           double* __restrict__ partials) {
     if (state->done) return;   // wave-uniform: the reference loop has already exited
+    const int cur = state->sweeps & 1;
 
-    __shared__ uint32_t sh_mn1[kTcMax], sh_mx1[kTcMax], sh_mn2[kTcMax], sh_mx2[kTcMax];
-    __shared__ float sh_s[kTcMax], sh_inv[kTcMax];
+    __shared__ float sh_f[kInvMax];                 // row tile: scales; col tile: 1/s table
+    __shared__ uint32_t sh_u[2 * kSlotMax];         // row tile: column-stat slots; col tile: row stats
     __shared__ double sh_red[kBlock / kWave];
 
     int r = 0;
     while (r + 1 < n_rels && (int)blockIdx.x >= rels[r + 1].tile_begin) ++r;
     const LeRelDev R = rels[r];
-    const int tid = threadIdx.x;
     const int tile = blockIdx.x - R.tile_begin;
-    const int c0 = tile * R.tc;
-    const int nc = (R.o1 - c0 < R.tc) ? (R.o1 - c0) : R.tc;
+    double acc;
+    if (tile < R.n_row_tiles) acc = row_tile(R, p, tile, cur, sh_f, sh_u);
+    else acc = col_tile(R, p, tile - R.n_row_tiles, cur, sh_f, sh_u);
+    const double t = block_sum(acc, sh_red);
+    if (threadIdx.x == 0) partials[R.partial_base + tile] = t;
+}
 
-    if (tid < nc) {
-        sh_mn1[tid] = 0u; sh_mx1[tid] = 0u; sh_mn2[tid] = 0u; sh_mx2[tid] = 0u;
-    }
+// Stats of the untouched weights, once per run: R1 (rows of W1) for chain-start relations and R2
+// (columns of W2) for every relation, parity 0.  One workgroup per `kBootTc` paired channels.
+__global__ __launch_bounds__(kBlock) void le_bootstrap_kernel(const LeRelDev* __restrict__ rels, int n_rels) {
+    __shared__ uint32_t sh_mn1[kBootTc], sh_mx1[kBootTc], sh_mn2[kBootTc], sh_mx2[kBootTc];
+    int r = 0;
+    while (r + 1 < n_rels && (int)blockIdx.x >= rels[r + 1].boot_begin) ++r;
+    const LeRelDev R = rels[r];
+    const int tid = threadIdx.x;
+    const int c0 = (blockIdx.x - R.boot_begin) * kBootTc;
+    const int nc = min(kBootTc, R.o1 - c0);
+    if (tid < nc) { sh_mn1[tid] = 0u; sh_mx1[tid] = 0u; sh_mn2[tid] = 0u; sh_mx2[tid] = 0u; }
     __syncthreads();
-
-    // ---- W1 side: one contiguous run of nc*row_len floats; lanes unit-stride ---------------------
-    float* const rows = R.w1 + (int64_t)c0 * R.row_len;
-    const int row_total = nc * R.row_len;
-    const int q0 = tid / R.row_len;            // channel (within the tile) of this thread's first element
-    const int rem0 = tid - q0 * R.row_len;
-    const int dq = kBlock / R.row_len;
-    const int dr = kBlock - dq * R.row_len;
-    {
-        int q = q0, rem = rem0, cur = q0;
+    const bool need_rows = R.out_cols == nullptr;      // chain start: nobody else produces R1
+    if (need_rows) {
+        const float* rows = R.w1 + (int64_t)c0 * R.row_len;
+        const int64_t total = (int64_t)nc * R.row_len;
+        int q = tid / R.row_len, rem = tid - q * R.row_len, cq = q;
+        const int dq = kBlock / R.row_len, dr = kBlock - dq * R.row_len;
         float mn = INFINITY, mx = -INFINITY;
-        for (int e = tid; e < row_total; e += kBlock) {
-            if (q != cur) {
-                atomicMax(&sh_mn1[cur], ~enc_ord(mn));
-                atomicMax(&sh_mx1[cur], enc_ord(mx));
-                mn = INFINITY; mx = -INFINITY; cur = q;
+        for (int64_t e = tid; e < total; e += kBlock) {
+            if (q != cq) {
+                atomicMax(&sh_mn1[cq], ~enc_ord(mn)); atomicMax(&sh_mx1[cq], enc_ord(mx));
+                mn = INFINITY; mx = -INFINITY; cq = q;
             }
             const float v = rows[e];
-            mn = fminf(mn, v);
-            mx = fmaxf(mx, v);
+            mn = fminf(mn, v); mx = fmaxf(mx, v);
             q += dq; rem += dr;
             if (rem >= R.row_len) { rem -= R.row_len; ++q; }
         }
-        if (mn <= mx) {
-            atomicMax(&sh_mn1[cur], ~enc_ord(mn));
-            atomicMax(&sh_mx1[cur], enc_ord(mx));
-        }
+        if (mn <= mx) { atomicMax(&sh_mn1[cq], ~enc_ord(mn)); atomicMax(&sh_mx1[cq], enc_ord(mx)); }
     }
-
-    // ---- W2 side: positions p = (channel-in-tile, k) are contiguous in memory within a group;
-    //      thread -> (row lane jl, position p); rows j = jl, jl+JL, ... ------------------------------
-    const int P = nc * R.khkw;
-    const int JL = (P >= kBlock) ? 1 : (kBlock / P);
-    const int jl = (P >= kBlock) ? 0 : (tid / P);
-    const int p_first = (P >= kBlock) ? tid : (tid - jl * P);
-    const bool col_active = jl < JL;
-    const int64_t col_stride = (int64_t)R.i2g * R.khkw;
-    if (col_active) {
-        for (int pp = p_first; pp < P; pp += kBlock) {
-            const int ct = pp / R.khkw;
-            const int k = pp - ct * R.khkw;
-            const int c = c0 + ct;
-            const int g = c / R.gi;
-            const int ii = c - g * R.gi;
-            const float* col = R.w2 + ((int64_t)g * R.go * R.i2g + ii) * R.khkw + k;
-            float mn = INFINITY, mx = -INFINITY;
-            for (int j = jl; j < R.go; j += JL) {
-                const float v = col[(int64_t)j * col_stride];
-                mn = fminf(mn, v);
-                mx = fmaxf(mx, v);
-            }
-            if (mn <= mx) {
-                atomicMax(&sh_mn2[ct], ~enc_ord(mn));
-                atomicMax(&sh_mx2[ct], enc_ord(mx));
-            }
-        }
-    }
-    __syncthreads();
-
-    // ---- solve + per-channel vectors ---------------------------------------------------------------
-    if (tid < nc) {
-        const float r1 = range_of(sh_mn1[tid], sh_mx1[tid], p.signed_range);
-        const float r2 = range_of(sh_mn2[tid], sh_mx2[tid], p.signed_range);
-        float s, inv;
-        le_solve(r1, r2, p, s, inv);
-        sh_s[tid] = s;
-        sh_inv[tid] = inv;
-        const int c = c0 + tid;
-        R.s_cum[c] = R.s_cum[c] * s;                  // Relation.set_scale_vec (relation.py:20-24)
-        if (R.bnw) R.bnw[c] = R.bnw[c] * s;           // dfq.py:64-65
-        if (R.bnb) R.bnb[c] = R.bnb[c] * s;           // dfq.py:67-68
-        if (R.b1) R.b1[c] = R.b1[c] * s;              // dfq.py:70-71
-    }
-    __syncthreads();
-
-    // ---- apply: W1 rows *= s (dfq.py:62) ------------------------------------------------------------
-    double acc1 = 0.0, acc2 = 0.0;
     {
-        float* const prev = R.prev1 ? R.prev1 + (int64_t)c0 * R.row_len : nullptr;
-        int q = q0, rem = rem0;
-        for (int e = tid; e < row_total; e += kBlock) {
-            const float v = rows[e];
-            const float nv = v * sh_s[q];
-            rows[e] = nv;
-            if (R.diff1 == DIFF_DIRECT) acc1 += (double)fabsf(nv - v);
-            else if (R.diff1 == DIFF_SAVE) prev[e] = v;
-            else if (R.diff1 == DIFF_FROM_PREV) acc1 += (double)fabsf(nv - prev[e]);
-            q += dq; rem += dr;
-            if (rem >= R.row_len) { rem -= R.row_len; ++q; }
-        }
-    }
-    // ---- apply: W2 columns *= 1/s (dfq.py:73) ------------------------------------------------------
-    if (col_active) {
-        for (int pp = p_first; pp < P; pp += kBlock) {
-            const int ct = pp / R.khkw;
-            const int k = pp - ct * R.khkw;
-            const int c = c0 + ct;
-            const int g = c / R.gi;
-            const int ii = c - g * R.gi;
-            const int64_t base = ((int64_t)g * R.go * R.i2g + ii) * R.khkw + k;
-            float* const col = R.w2 + base;
-            float* const prev = R.prev2 ? R.prev2 + base : nullptr;
-            const float inv = sh_inv[ct];
-            for (int j = jl; j < R.go; j += JL) {
-                const int64_t off = (int64_t)j * col_stride;
-                const float v = col[off];
-                const float nv = v * inv;
-                col[off] = nv;
-                if (R.diff2 == DIFF_DIRECT) acc2 += (double)fabsf(nv - v);
-                else if (R.diff2 == DIFF_SAVE) prev[off] = v;
-                else if (R.diff2 == DIFF_FROM_PREV) acc2 += (double)fabsf(nv - prev[off]);
+        const int P = nc * R.khkw;
+        const int JL = (P >= kBlock) ? 1 : (kBlock / P);
+        const int jl = (P >= kBlock) ? 0 : (tid / P);
+        const int p_first = (P >= kBlock) ? tid : (tid - jl * P);
+        const int64_t col_stride = (int64_t)R.i2g * R.khkw;
+        if (jl < JL) {
+            for (int pp = p_first; pp < P; pp += kBlock) {
+                const int ct = pp / R.khkw;
+                const int k = pp - ct * R.khkw;
+                const int c = c0 + ct;
+                const int g = c / R.gi;
+                const int ii = c - g * R.gi;
+                const float* col = R.w2 + ((int64_t)g * R.go * R.i2g + ii) * R.khkw + k;
+                float mn = INFINITY, mx = -INFINITY;
+                for (int j = jl; j < R.go; j += JL) {
+                    const float v = col[(int64_t)j * col_stride];
+                    mn = fminf(mn, v); mx = fmaxf(mx, v);
+                }
+                if (mn <= mx) { atomicMax(&sh_mn2[ct], ~enc_ord(mn)); atomicMax(&sh_mx2[ct], enc_ord(mx)); }
             }
         }
     }
-    // ---- per-tile partials of sum|W - W_prev| (fixed reduction order -> deterministic) ---------------
-    const double t1 = block_sum(acc1, sh_red);
-    const double t2 = block_sum(acc2, sh_red);
-    if (tid == 0) {
-        partials[2 * (int64_t)(R.partial_base + tile) + 0] = t1;
-        partials[2 * (int64_t)(R.partial_base + tile) + 1] = t2;
+    __syncthreads();
+    if (tid < nc) {
+        const int c = c0 + tid;
+        if (need_rows) { R.r1[2 * c + 0] = sh_mn1[tid]; R.r1[2 * c + 1] = sh_mx1[tid]; }
+        R.r2[2 * c + 0] = sh_mn2[tid]; R.r2[2 * c + 1] = sh_mx2[tid];
     }
 }
 
-// dfq.py:105-115 on the device.  One workgroup; wave w reduces layers w, w+4, ...
+// dfq.py:105-115 on the device.  One workgroup; wave w reduces layers w, w+4, ...  Also clears the
+// column-stat buffers of the parity that the next sweep accumulates into.
 __global__ __launch_bounds__(kBlock) void le_control_kernel(const LeLayerDiff* __restrict__ layers, int n_layers,
                                                             const double* __restrict__ partials,
                                                             double* __restrict__ layer_mean,
+                                                            uint32_t* __restrict__ r2_arena, int64_t r2_words,
                                                             LeState* __restrict__ state, double converge_thres,
                                                             int converge_count, int max_sweeps) {
     if (state->done) return;
+    __shared__ double sh_mean[1024];
     const int lane = threadIdx.x % kWave;
     const int wave = threadIdx.x / kWave;
+    const int cur = state->sweeps & 1;
+    // parity `cur` was consumed by this sweep; the next sweep produces (atomicMax) into it
+    uint32_t* z = r2_arena + (int64_t)cur * r2_words;
+    for (int64_t i = threadIdx.x; i < r2_words; i += kBlock) z[i] = 0u;
     for (int l = wave; l < n_layers; l += kBlock / kWave) {
         const LeLayerDiff L = layers[l];
         double s = 0.0;
         if (L.partial_begin >= 0) {
-            for (int i = lane; i < L.n_partials; i += kWave) s += partials[2 * (int64_t)(L.partial_begin + i) + L.side];
+            for (int i = lane; i < L.n_partials; i += kWave) s += partials[L.partial_begin + i];
             s = wave_sum(s);
         }
         if (lane == 0) {
             // float(torch.mean(torch.abs(W - W_prev))): float32 mean, widened to double (dfq.py:108)
-            layer_mean[l] = (L.partial_begin >= 0) ? (double)(float)(s / L.n_elems) : 0.0;
+            const double m = (L.partial_begin >= 0) ? (double)(float)(s / L.n_elems) : 0.0;
+            if (l < 1024) sh_mean[l] = m; else layer_mean[l] = m;
         }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         double diff_tmp = 0.0;
-        for (int l = 0; l < n_layers; ++l) diff_tmp += layer_mean[l];   // graph order
+        for (int l = 0; l < n_layers; ++l) diff_tmp += (l < 1024) ? sh_mean[l] : layer_mean[l];   // graph order
         double diff = state->diff;
         int count = state->count;
         if (fabs(diff - diff_tmp) > 1e-9) { count = 0; diff = diff_tmp; }
@@ -311,27 +500,21 @@ struct dfq_le_plan {
     int n_layers = 0, n_rels = 0;
     std::vector<LevelLaunch> levels;
     int64_t paired_total = 0, snapshot_total = 0;
-    int total_tiles = 0;
+    int total_tiles = 0, boot_blocks = 0;
+    int64_t r1_words = 0, r2_words = 0;    // per parity
     LeRelDev* d_rels = nullptr;
     LeLayerDiff* d_layer_diff = nullptr;
     double* d_partials = nullptr;
     double* d_layer_mean = nullptr;
     LeState* d_state = nullptr;
-    std::vector<float*> arenas;   // snapshot arenas (hipMalloc)
+    uint32_t* d_stats = nullptr;           // [2][r2_words] then [2][r1_words]
+    std::vector<float*> arenas;            // snapshot arenas (hipMalloc)
 };
 
-static int pick_tc(int64_t per_channel, int o1, int khkw2) {
-    static const int target = []() {
-        const char* e = getenv("DFQ_LE_TILE_ELEMS");
-        const int v = e ? atoi(e) : 0;
-        return v > 0 ? v : 8192;
-    }();
-    int64_t tc = target / (per_channel > 0 ? per_channel : 1);
-    if (tc < 1) tc = 1;
-    if (khkw2 == 1 && tc < 8) tc = 8;      // 1x1 second layer: keep >= 32 B of each W2 row per tile
-    if (tc > kTcMax) tc = kTcMax;
-    if (tc > o1) tc = o1;
-    return (int)tc;
+static int tile_target() {     // elements per tile; DFQ_LE_TILE_ELEMS overrides (tuning / tests)
+    const char* e = getenv("DFQ_LE_TILE_ELEMS");
+    const int v = e ? atoi(e) : 0;
+    return v > 0 ? v : 4096;
 }
 
 extern "C" {
@@ -343,6 +526,7 @@ void dfq_le_plan_destroy(dfq_le_plan* p) {
     if (p->d_partials) (void)hipFree(p->d_partials);
     if (p->d_layer_mean) (void)hipFree(p->d_layer_mean);
     if (p->d_state) (void)hipFree(p->d_state);
+    if (p->d_stats) (void)hipFree(p->d_stats);
     for (float* a : p->arenas) (void)hipFree(a);
     delete p;
 }
@@ -351,7 +535,8 @@ int dfq_le_plan_create(const dfq_layer* layers, int32_t n_layers, const dfq_rela
                        int32_t n_relations, dfq_le_plan** out_plan) {
     if (!layers || n_layers <= 0 || !out_plan || n_relations < 0 || (n_relations > 0 && !relations))
         return fail_arg("dfq_le_plan_create: bad argument");
-    // ---- validate geometry (dfq.py:29-35) ----
+    // ---- validate geometry (dfq.py:29-35) and the chain structure create_relation guarantees ----
+    std::vector<int> as_first(n_layers, -1), as_second(n_layers, -1);
     for (int r = 0; r < n_relations; ++r) {
         const dfq_relation& rr = relations[r];
         if (rr.first < 0 || rr.first >= n_layers || rr.second < 0 || rr.second >= n_layers || rr.first == rr.second)
@@ -365,20 +550,27 @@ int dfq_le_plan_create(const dfq_layer* layers, int32_t n_layers, const dfq_rela
         const int G = (o1 != i2g) ? (o1 / i2g) : 1;
         if (G < 1 || o1 != G * i2g || B.out_ch % G != 0)
             return fail_arg("dfq_le_plan_create: relation %d: unsupported pairing O1=%d, I2/g=%d, O2=%d", r, o1, i2g, B.out_ch);
-        if ((int64_t)A.in_per_group * A.khkw > 0x7fffffff / kTcMax)
+        if ((int64_t)A.in_per_group * A.khkw > (1 << 24) || (int64_t)B.in_per_group * B.khkw > (1 << 24))
             return fail_arg("dfq_le_plan_create: relation %d: row too long", r);
+        if (as_first[rr.first] >= 0 || as_second[rr.second] >= 0)
+            return fail_arg("dfq_le_plan_create: relation %d: a layer may be first in one relation and second in one "
+                            "relation only (utils/relation.py:57-67)", r);
+        as_first[rr.first] = r;
+        as_second[rr.second] = r;
     }
+    for (int l = 0; l < n_layers; ++l)
+        if (as_first[l] >= 0 && as_second[l] >= 0 && as_second[l] > as_first[l])
+            return fail_arg("dfq_le_plan_create: layer %d is rescaled as a first layer (relation %d) before it is "
+                            "rescaled as a second layer (relation %d); unsupported order", l, as_first[l], as_second[l]);
     dfq_le_plan* p = new dfq_le_plan();
     p->n_layers = n_layers;
     p->n_rels = n_relations;
-
-    // ---- touches per layer, in sweep order -> diff modes ----
-    std::vector<int> touches(n_layers, 0), seen(n_layers, 0);
-    for (int r = 0; r < n_relations; ++r) { touches[relations[r].first]++; touches[relations[r].second]++; }
-    std::vector<float*> arena(n_layers, nullptr);
     auto fail_alloc = [&](hipError_t e) { dfq_le_plan_destroy(p); return fail_hip(e, "le plan allocation", __FILE__, __LINE__); };
+
+    // ---- snapshot arenas for layers touched twice per sweep ----
+    std::vector<float*> arena(n_layers, nullptr);
     for (int l = 0; l < n_layers; ++l) {
-        if (touches[l] >= 2) {
+        if (as_first[l] >= 0 && as_second[l] >= 0) {
             const int64_t n = (int64_t)layers[l].out_ch * layers[l].in_per_group * layers[l].khkw;
             float* a = nullptr;
             hipError_t e = hipMalloc((void**)&a, sizeof(float) * n);
@@ -387,13 +579,6 @@ int dfq_le_plan_create(const dfq_layer* layers, int32_t n_layers, const dfq_rela
             arena[l] = a;
         }
     }
-    auto mode_for = [&](int l) -> int32_t {
-        const int k = ++seen[l];
-        if (touches[l] == 1) return DIFF_DIRECT;
-        if (k == 1) return DIFF_SAVE;
-        if (k == touches[l]) return DIFF_FROM_PREV;
-        return DIFF_NONE;
-    };
 
     // ---- dependency levels: relations sharing a layer keep their list order ----
     std::vector<int> level(n_relations, 0), last_level(n_layers, -1);
@@ -406,42 +591,101 @@ int dfq_le_plan_create(const dfq_layer* layers, int32_t n_layers, const dfq_rela
         n_levels = std::max(n_levels, lv + 1);
     }
 
+    // ---- stat arrays: [2 parity][R2 of every relation] then [2 parity][R1 of every relation] ----
+    std::vector<int64_t> stat_off(n_relations, 0);
+    int64_t words = 0;
+    for (int r = 0; r < n_relations; ++r) { stat_off[r] = words; words += 2 * (int64_t)layers[relations[r].first].out_ch; }
+    p->r2_words = words;
+    p->r1_words = words;
+    hipError_t e;
+    if ((e = hipMalloc((void**)&p->d_stats, sizeof(uint32_t) * std::max<int64_t>(1, 4 * words))) != hipSuccess) return fail_alloc(e);
+    uint32_t* r2_base = p->d_stats;                  // [2][words]: the control kernel clears one parity of R2
+    uint32_t* r1_base = p->d_stats + 2 * words;      // [2][words]
+
     // ---- per-relation device descriptors ----
     std::vector<LeRelDev> h(n_relations);
     std::vector<LeLayerDiff> ld(n_layers);
     for (int l = 0; l < n_layers; ++l) {
-        ld[l].partial_begin = -1; ld[l].n_partials = 0; ld[l].side = 0; ld[l].pad = 0;
+        ld[l].partial_begin = -1; ld[l].n_partials = 0;
         ld[l].n_elems = (double)((int64_t)layers[l].out_ch * layers[l].in_per_group * layers[l].khkw);
     }
-    int tile_slot = 0;
+    const int target = tile_target();
+    int tile_slot = 0, boot = 0;
     for (int r = 0; r < n_relations; ++r) {
         const dfq_relation& rr = relations[r];
         const dfq_layer& A = layers[rr.first];
         const dfq_layer& B = layers[rr.second];
         LeRelDev& d = h[r];
+        d = LeRelDev();
         d.w1 = A.weight; d.w2 = B.weight; d.b1 = A.bias; d.bnw = rr.bn_weight; d.bnb = rr.bn_bias; d.s_cum = rr.scale_cum;
-        d.o1 = A.out_ch; d.row_len = A.in_per_group * A.khkw;
-        d.i2g = B.in_per_group; d.khkw = B.khkw;
+        d.o1 = A.out_ch; d.row_len = A.in_per_group * A.khkw; d.khkw1 = A.khkw;
+        d.o2 = B.out_ch; d.i2g = B.in_per_group; d.khkw = B.khkw;
         const int G = (d.o1 != d.i2g) ? (d.o1 / d.i2g) : 1;
         d.gi = d.o1 / G; d.go = B.out_ch / G;
-        const int64_t per_channel = (int64_t)d.row_len + (int64_t)d.go * d.khkw;
-        d.tc = pick_tc(per_channel, d.o1, d.khkw);
-        d.n_tiles = (d.o1 + d.tc - 1) / d.tc;
-        d.diff1 = mode_for(rr.first);
-        d.diff2 = mode_for(rr.second);
-        d.prev1 = (d.diff1 == DIFF_SAVE || d.diff1 == DIFF_FROM_PREV) ? arena[rr.first] : nullptr;
-        d.prev2 = (d.diff2 == DIFF_SAVE || d.diff2 == DIFF_FROM_PREV) ? arena[rr.second] : nullptr;
+        d.r1 = r1_base + stat_off[r];
+        d.r2 = r2_base + stat_off[r];
+        d.stat_stride = words;
+        // diff modes: a layer in two relations is touched as second (col tile) first, then as first
+        const bool a_twice = as_second[rr.first] >= 0;     // W1 was column-scaled earlier this sweep
+        const bool b_twice = as_first[rr.second] >= 0;     // W2 will be row-scaled later this sweep
+        d.diff1 = a_twice ? DIFF_FROM_PREV : DIFF_DIRECT;
+        d.diff2 = b_twice ? DIFF_SAVE : DIFF_DIRECT;
+        d.prev1 = a_twice ? arena[rr.first] : nullptr;
+        d.prev2 = b_twice ? arena[rr.second] : nullptr;
+        // row tiles
+        d.rt_slabs = (d.row_len + kRowTileColsMax - 1) / kRowTileColsMax;
+        d.rt_cols = (d.row_len + d.rt_slabs - 1) / d.rt_slabs;
+        d.rt_slabs = (d.row_len + d.rt_cols - 1) / d.rt_cols;
+        int rows = std::max(1, target / d.rt_cols);
+        rows = std::min(rows, std::min(kRowTileRowsMax, d.o1));
+        d.rt_rows = rows;
+        // col tiles
+        const int row_len2 = d.i2g * d.khkw;
+        int lanes = 1;
+        while (lanes < kWave && row_len2 > 8 * lanes) lanes *= 2;
+        d.ct_lanes = lanes;
+        d.ct_chunk = std::min(d.i2g, kChunkCh);
+        int crow = std::max(1, target / row_len2);
+        crow = std::min(crow, std::min(kColRowsMax, d.o2));
+        // a tile of `crow` rows spans at most crow/go + 2 groups; the 1/s table holds (#groups) * chunk entries
+        const int64_t max_groups = kInvMax / d.ct_chunk;     // >= 4 because ct_chunk <= kChunkCh
+        crow = (int)std::min<int64_t>(crow, (max_groups - 2) * d.go);
+        if (crow < 1) crow = 1;
+        d.ct_rows = crow;
+        d.n_col_tiles = (d.o2 + d.ct_rows - 1) / d.ct_rows;
+        d.boot_tiles = (d.o1 + kBootTc - 1) / kBootTc;
+    }
+    // producer links + slot limits need every relation's geometry, so a second pass
+    for (int r = 0; r < n_relations; ++r) {
+        const dfq_relation& rr = relations[r];
+        LeRelDev& d = h[r];
+        const int j_prev = as_second[rr.first];     // relation whose second layer is our W1
+        const int j_next = as_first[rr.second];     // relation whose first layer is our W2
+        if (j_prev >= 0) {
+            d.out_cols = h[j_prev].r2;
+            d.pc_go = h[j_prev].go; d.pc_gi = h[j_prev].gi; d.pc_n = h[j_prev].o1;
+            // LDS slots of a row tile: (#groups spanned) * (#channels spanned)
+            const int nci = (d.rt_cols + d.khkw1 - 1) / d.khkw1 + 1;
+            int rows = d.rt_rows;
+            while (rows > 1 && ((rows + d.pc_go - 1) / d.pc_go + 1) * nci > kSlotMax) rows = (rows + 1) / 2;
+            d.rt_rows = rows;
+        } else {
+            d.out_cols = nullptr; d.pc_go = 1; d.pc_gi = 1; d.pc_n = 0;
+        }
+        d.out_rows = (j_next >= 0) ? h[j_next].r1 : nullptr;
+        if (d.out_rows && d.ct_rows > kSlotMax) d.ct_rows = kSlotMax;
+        d.n_col_tiles = (d.o2 + d.ct_rows - 1) / d.ct_rows;
+        d.n_row_tiles = ((d.o1 + d.rt_rows - 1) / d.rt_rows) * d.rt_slabs;
         d.partial_base = tile_slot;
-        d.tile_begin = 0;
-        tile_slot += d.n_tiles;
-        if (d.diff1 == DIFF_DIRECT || d.diff1 == DIFF_FROM_PREV) {
-            ld[rr.first].partial_begin = d.partial_base; ld[rr.first].n_partials = d.n_tiles; ld[rr.first].side = 0;
+        ld[rr.first].partial_begin = d.partial_base;
+        ld[rr.first].n_partials = d.n_row_tiles;                       // last touch of W1 this sweep
+        if (d.diff2 == DIFF_DIRECT) {
+            ld[rr.second].partial_begin = d.partial_base + d.n_row_tiles;
+            ld[rr.second].n_partials = d.n_col_tiles;
         }
-        if (d.diff2 == DIFF_DIRECT || d.diff2 == DIFF_FROM_PREV) {
-            ld[rr.second].partial_begin = d.partial_base; ld[rr.second].n_partials = d.n_tiles; ld[rr.second].side = 1;
-        }
+        tile_slot += d.n_row_tiles + d.n_col_tiles;
         const int64_t n1 = (int64_t)d.o1 * d.row_len;
-        const int64_t n2 = (int64_t)B.out_ch * d.i2g * d.khkw;
+        const int64_t n2 = (int64_t)d.o2 * d.i2g * d.khkw;
         p->paired_total += n1 + n2;
     }
     p->total_tiles = tile_slot;
@@ -458,20 +702,20 @@ int dfq_le_plan_create(const dfq_layer* layers, int32_t n_layers, const dfq_rela
         if (L.n_rels == 0) L.rel_begin = i;
         sorted[i] = h[r];
         sorted[i].tile_begin = L.n_blocks;
-        L.n_blocks += h[r].n_tiles;
+        sorted[i].boot_begin = boot;              // bootstrap launch walks the same (sorted) table
+        boot += h[r].boot_tiles;
+        L.n_blocks += h[r].n_row_tiles + h[r].n_col_tiles;
         L.n_rels += 1;
-        const dfq_layer& A = layers[relations[r].first];
-        const dfq_layer& B = layers[relations[r].second];
-        const int64_t n1 = (int64_t)A.out_ch * A.in_per_group * A.khkw;
-        const int64_t n2 = (int64_t)B.out_ch * B.in_per_group * B.khkw;
+        const int64_t n1 = (int64_t)h[r].o1 * h[r].row_len;
+        const int64_t n2 = (int64_t)h[r].o2 * h[r].i2g * h[r].khkw;
         L.paired += n1 + n2;
         if (h[r].prev1) L.snapshot += n1;
         if (h[r].prev2) L.snapshot += n2;
     }
     for (const LevelLaunch& L : p->levels) p->snapshot_total += L.snapshot;
+    p->boot_blocks = boot;
 
-    hipError_t e;
-    const size_t n_part = (size_t)std::max(1, p->total_tiles) * 2;
+    const size_t n_part = (size_t)std::max(1, p->total_tiles);
     if ((e = hipMalloc((void**)&p->d_rels, sizeof(LeRelDev) * std::max(1, n_relations))) != hipSuccess) return fail_alloc(e);
     if ((e = hipMalloc((void**)&p->d_layer_diff, sizeof(LeLayerDiff) * n_layers)) != hipSuccess) return fail_alloc(e);
     if ((e = hipMalloc((void**)&p->d_partials, sizeof(double) * n_part)) != hipSuccess) return fail_alloc(e);
@@ -501,6 +745,8 @@ int32_t dfq_le_plan_level_launches(const dfq_le_plan* p, int32_t level, int64_t*
     return L.n_rels;
 }
 
+}  // extern "C"
+
 static LeParams make_params(const dfq_le_config* c) {
     LeParams q;
     q.s_lo = c->s_lo; q.s_hi = c->s_hi; q.inv_lo = c->inv_lo; q.inv_hi = c->inv_hi; q.eps = c->eps;
@@ -508,27 +754,48 @@ static LeParams make_params(const dfq_le_config* c) {
     return q;
 }
 
+// reset the loop state, clear every stat word, recompute the stats of the untouched weights
+static int le_restart(dfq_le_plan* p, const dfq_le_config* cfg, hipStream_t st) {
+    hipLaunchKernelGGL(le_reset_kernel, dim3(1), dim3(64), 0, st, p->d_state, cfg->converge_thres,
+                       (int)cfg->converge_count, (int)cfg->max_sweeps);
+    DFQ_CHECK_LAUNCH();
+    if (p->n_rels > 0) {
+        DFQ_HIP_TRY(hipMemsetAsync(p->d_stats, 0, sizeof(uint32_t) * 4 * p->r2_words, st));
+        hipLaunchKernelGGL(le_bootstrap_kernel, dim3(p->boot_blocks), dim3(kBlock), 0, st,
+                           (const LeRelDev*)p->d_rels, p->n_rels);
+        DFQ_CHECK_LAUNCH();
+    }
+    return DFQ_OK;
+}
+
+static int le_launch_level(dfq_le_plan* p, const LevelLaunch& L, const LeParams& q, hipStream_t st) {
+    if (L.n_blocks == 0) return DFQ_OK;
+    hipLaunchKernelGGL(le_level_kernel, dim3(L.n_blocks), dim3(kBlock), 0, st,
+                       (const LeRelDev*)(p->d_rels + L.rel_begin), L.n_rels, q, (const LeState*)p->d_state, p->d_partials);
+    DFQ_CHECK_LAUNCH();
+    return DFQ_OK;
+}
+
+static int le_launch_control(dfq_le_plan* p, const dfq_le_config* cfg, hipStream_t st) {
+    hipLaunchKernelGGL(le_control_kernel, dim3(1), dim3(kBlock), 0, st, (const LeLayerDiff*)p->d_layer_diff,
+                       p->n_layers, (const double*)p->d_partials, p->d_layer_mean, p->d_stats, (int64_t)p->r2_words,
+                       p->d_state, cfg->converge_thres, (int)cfg->converge_count, (int)cfg->max_sweeps);
+    DFQ_CHECK_LAUNCH();
+    return DFQ_OK;
+}
+
+extern "C" {
+
 int dfq_le_enqueue(dfq_le_plan* p, const dfq_le_config* cfg, int32_t n_sweeps, int32_t restart, void* stream) {
     if (!p || !cfg || n_sweeps < 0) return fail_arg("dfq_le_enqueue: bad argument");
     hipStream_t st = as_stream(stream);
     const LeParams q = make_params(cfg);
-    if (restart) {
-        hipLaunchKernelGGL(le_reset_kernel, dim3(1), dim3(64), 0, st, p->d_state, cfg->converge_thres,
-                           (int)cfg->converge_count, (int)cfg->max_sweeps);
-        DFQ_CHECK_LAUNCH();
-    }
+    int rc;
+    if (restart && (rc = le_restart(p, cfg, st))) return rc;
     for (int s = 0; s < n_sweeps; ++s) {
-        for (const LevelLaunch& L : p->levels) {
-            if (L.n_blocks == 0) continue;
-            hipLaunchKernelGGL(le_level_kernel, dim3(L.n_blocks), dim3(kBlock), 0, st,
-                               (const LeRelDev*)(p->d_rels + L.rel_begin), L.n_rels, q,
-                               (const LeState*)p->d_state, p->d_partials);
-            DFQ_CHECK_LAUNCH();
-        }
-        hipLaunchKernelGGL(le_control_kernel, dim3(1), dim3(kBlock), 0, st, (const LeLayerDiff*)p->d_layer_diff,
-                           p->n_layers, (const double*)p->d_partials, p->d_layer_mean, p->d_state,
-                           cfg->converge_thres, (int)cfg->converge_count, (int)cfg->max_sweeps);
-        DFQ_CHECK_LAUNCH();
+        for (const LevelLaunch& L : p->levels)
+            if ((rc = le_launch_level(p, L, q, st))) return rc;
+        if ((rc = le_launch_control(p, cfg, st))) return rc;
     }
     return DFQ_OK;
 }
@@ -542,26 +809,19 @@ int dfq_le_profile(dfq_le_plan* p, const dfq_le_config* cfg, int32_t n_sweeps, v
     const int per_sweep = n_levels + 1;
     std::vector<hipEvent_t> ev((size_t)2 * per_sweep * n_sweeps);
     for (auto& e : ev) DFQ_HIP_TRY(hipEventCreate(&e));
-    hipLaunchKernelGGL(le_reset_kernel, dim3(1), dim3(64), 0, st, p->d_state, cfg->converge_thres,
-                       (int)cfg->converge_count, (int)cfg->max_sweeps);
-    DFQ_CHECK_LAUNCH();
+    int rc = le_restart(p, cfg, st);
+    if (rc) return rc;
     size_t k = 0;
     for (int s = 0; s < n_sweeps; ++s) {
         for (const LevelLaunch& L : p->levels) {
             DFQ_HIP_TRY(hipEventRecord(ev[k++], st));
-            if (L.n_blocks > 0)
-                hipLaunchKernelGGL(le_level_kernel, dim3(L.n_blocks), dim3(kBlock), 0, st,
-                                   (const LeRelDev*)(p->d_rels + L.rel_begin), L.n_rels, q,
-                                   (const LeState*)p->d_state, p->d_partials);
+            if ((rc = le_launch_level(p, L, q, st))) return rc;
             DFQ_HIP_TRY(hipEventRecord(ev[k++], st));
         }
         DFQ_HIP_TRY(hipEventRecord(ev[k++], st));
-        hipLaunchKernelGGL(le_control_kernel, dim3(1), dim3(kBlock), 0, st, (const LeLayerDiff*)p->d_layer_diff,
-                           p->n_layers, (const double*)p->d_partials, p->d_layer_mean, p->d_state,
-                           cfg->converge_thres, (int)cfg->converge_count, (int)cfg->max_sweeps);
+        if ((rc = le_launch_control(p, cfg, st))) return rc;
         DFQ_HIP_TRY(hipEventRecord(ev[k++], st));
     }
-    DFQ_CHECK_LAUNCH();
     DFQ_HIP_TRY(hipStreamSynchronize(st));
     for (int l = 0; l < n_levels; ++l) level_ms[l] = 0.0;
     double ctl = 0.0;

@@ -205,6 +205,29 @@ def test_pipeline_stages(engine, name, seed, suffix):
     compare_stage(snapshot(graph), gold, 'q', exact=True, what=name)
 
 
+@pytest.mark.parametrize('tile_elems', [48, 500])
+@pytest.mark.parametrize('name,seed,suffix', [('tiny_mobile', 2, '_signed'), ('tiny_cat', 0, ''), ('tiny_res', 0, '')])
+def test_equalization_tile_shapes(engine, monkeypatch, name, seed, suffix, tile_elems):
+    """Small tiles force many row slabs / row blocks / col tiles per relation: the result may not
+    depend on the decomposition (min/max and the scale solve are exact)."""
+    monkeypatch.setenv('DFQ_LE_TILE_ELEMS', str(tile_elems))
+    gold = net_fixture(name, seed, suffix)
+    signed = bool(gold['cfg'][1])
+    model, graph, bottoms = _build(name, seed, gold, engine)
+    spec = graphspec.from_torch(graph, bottoms, TARG)
+    lt.merge_batchnorm(model, graph, bottoms, TARG)
+    orc.merge_batchnorm(spec)
+    rels = rel.create_relation(graph, bottoms, TARG)
+    dfq.cross_layer_equalization(graph, rels, TARG, signed=signed)
+    n_o, S_o = orc.cross_layer_equalization(spec, orc.create_relation(spec), signed=signed)
+    assert dfq.last_equalization['sweeps'] == n_o
+    osnap, esnap = _spec_snapshot(spec), snapshot(graph)
+    for k in osnap:
+        assert_bitexact(esnap[k], osnap[k], '{} {}'.format(name, k))
+    for r, s in zip(rels, S_o):
+        assert_bitexact(npy(r.get_scale_vec()), s)
+
+
 def test_max_sweeps_and_restart(engine):
     gold = net_fixture('tiny_mobile', 0, '')
     model, graph, bottoms = _build('tiny_mobile', 0, gold, engine)
