@@ -49,6 +49,10 @@ constexpr int kInvMax = 8192;          // 1/s table of a col tile in LDS (floats
 constexpr int kChunkCh = 2048;         // input channels of W2 handled per pass of a col tile
 constexpr int kColRowsMax = 1024;      // rows of a col tile
 constexpr int kBootTc = 64;            // channels per bootstrap tile
+constexpr int kRegs = 16;              // elements a thread preloads into registers
+constexpr int kLevelRelsMax = 32;      // relations per launch (longer levels are split)
+constexpr int kCtlBlock = 1024;        // threads of the control kernel
+constexpr int kCtlStage = 6144;        // partials staged in LDS by the control kernel
 
 enum DiffMode : int32_t { DIFF_DIRECT = 0, DIFF_SAVE = 1, DIFF_FROM_PREV = 2 };
 
@@ -137,6 +141,10 @@ __device__ __forceinline__ void diff_touch(int mode, float nv, float v, float* p
 
 // ---------------------------------------------------------------------------------------------
 // row tile: W1[r0:r0+nr, p0:p0+np] *= s[row]   (+ column stats of the new values)
+//
+// The plan sizes tiles so that a thread owns at most kRegs elements: all of them are loaded into
+// registers BEFORE the scale solve, so the data fetch and the stat fetch + solve overlap and the
+// tile's critical path is one memory round trip, not two.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ double row_tile(const LeRelDev& R, const LeParams& p, int tile, int cur,
                                            float* sh_s, uint32_t* sh_slot) {
@@ -147,6 +155,18 @@ __device__ __forceinline__ double row_tile(const LeRelDev& R, const LeParams& p,
     const int p0 = slab * R.rt_cols;
     const int np = min(R.rt_cols, R.row_len - p0);
     const int nxt = cur ^ 1;
+    const int JL = kBlock / np;                // np <= 128 -> JL >= 2
+    const int jl = tid / np;
+    const int pos = p0 + (tid - jl * np);
+    const bool lane_on = jl < JL;
+
+    // ---- issue every data load first -----------------------------------------------------------
+    float v[kRegs];
+#pragma unroll
+    for (int u = 0; u < kRegs; ++u) {
+        const int r = jl + u * JL;
+        v[u] = (lane_on && r < nr) ? R.w1[(int64_t)(r0 + r) * R.row_len + pos] : 0.0f;
+    }
 
     // column-stat slot geometry of this tile
     const bool emit = R.out_cols != nullptr;
@@ -178,24 +198,23 @@ __device__ __forceinline__ double row_tile(const LeRelDev& R, const LeParams& p,
     __syncthreads();
 
     double acc = 0.0;
-    const int JL = kBlock / np;                // np <= 128 -> JL >= 2
-    const int jl = tid / np;
-    const int pp = tid - jl * np;
-    if (jl < JL) {
-        const int pos = p0 + pp;
+    if (lane_on) {
         const int ci = emit ? (pos / R.khkw1 - i0) : 0;
         float cmn = INFINITY, cmx = -INFINITY;
         int cur_g = -1;
-        for (int rb = jl; rb < nr; rb += 4 * JL) {
-            float v[4];
+        // rows beyond kRegs*JL (never produced by the plan's tile sizes) are handled by the tail loop
+        const int n_own = (nr - jl + JL - 1) / JL;        // rows this thread owns
+        for (int u0 = 0; u0 < n_own; u0 += kRegs) {
+            if (u0 > 0) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int r = rb + u * JL;
-                v[u] = (r < nr) ? R.w1[(int64_t)(r0 + r) * R.row_len + pos] : 0.0f;
+                for (int u = 0; u < kRegs; ++u) {
+                    const int r = jl + (u0 + u) * JL;
+                    v[u] = (r < nr) ? R.w1[(int64_t)(r0 + r) * R.row_len + pos] : 0.0f;
+                }
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int r = rb + u * JL;
+            for (int u = 0; u < kRegs; ++u) {
+                const int r = jl + (u0 + u) * JL;
                 if (r < nr) {
                     const int64_t idx = (int64_t)(r0 + r) * R.row_len + pos;
                     const float nv = v[u] * sh_s[r];          // dfq.py:62
@@ -239,6 +258,9 @@ __device__ __forceinline__ double row_tile(const LeRelDev& R, const LeParams& p,
 
 // ---------------------------------------------------------------------------------------------
 // col tile: full rows W2[r0:r0+nr, :] *= 1/s[input channel]   (+ row stats of the new values)
+//
+// `G` consecutive lanes stride along one row; a thread owns (row iteration `it`, position slot
+// `u`) pairs, flattened to j = it*ppt + u < kRegs for the register preload.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ double col_tile(const LeRelDev& R, const LeParams& p, int tile, int cur,
                                            float* sh_inv, uint32_t* sh_row) {
@@ -254,7 +276,22 @@ __device__ __forceinline__ double col_tile(const LeRelDev& R, const LeParams& p,
     const int g_n = (r0 + nr - 1) / R.go - g_lo + 1;
     const int row_len2 = R.i2g * R.khkw;
     const bool emit = R.out_rows != nullptr;
+    const int n_iter = (nr + n_groups - 1) / n_groups;     // row iterations, uniform over the block
+    const bool single = R.ct_chunk >= R.i2g;               // the whole row in one pass (always, unless I2/g > kChunkCh)
+    const int ppt = (row_len2 + G - 1) / G;                // positions per thread per row
+    const bool preload = single && n_iter * ppt <= kRegs;
 
+    float v[kRegs];
+    if (preload) {
+        int it = 0, u = 0;
+#pragma unroll
+        for (int j = 0; j < kRegs; ++j) {
+            const int r = grp + it * n_groups;
+            const int ps = ln + u * G;
+            v[j] = (it < n_iter && r < nr && ps < row_len2) ? R.w2[(int64_t)(r0 + r) * row_len2 + ps] : 0.0f;
+            if (++u == ppt) { u = 0; ++it; }
+        }
+    }
     if (emit) {
         for (int i = tid; i < 2 * nr; i += kBlock) sh_row[i] = 0u;
     }
@@ -281,37 +318,56 @@ __device__ __forceinline__ double col_tile(const LeRelDev& R, const LeParams& p,
         const int npos = nch * R.khkw;
         const int dch = G / R.khkw;
         const int drem = G - dch * R.khkw;
-        const int n_iter = (nr + n_groups - 1) / n_groups;
+        const int ch_first = ln / R.khkw;
+        const int rem_first = ln - ch_first * R.khkw;
         for (int it = 0; it < n_iter; ++it) {          // uniform trip count: every lane reaches the shuffles
             const int r = grp + it * n_groups;
             const bool act = r < nr;
             const int o = r0 + (act ? r : 0);
             const float* tab = sh_inv + (o / R.go - g_lo) * nch;
             const int64_t base = (int64_t)o * row_len2 + (int64_t)ii0 * R.khkw;
-            float* prev = R.prev2;
             float rmn = INFINITY, rmx = -INFINITY;
-            int ch = ln / R.khkw;
-            int rem = ln - ch * R.khkw;
-            for (int pb = ln; act && pb < npos; pb += 4 * G) {
-                float v[4];
-                int chs[4];
+            int ch = ch_first, rem = rem_first;
+            if (preload) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int pos = pb + u * G;
-                    v[u] = (pos < npos) ? R.w2[base + pos] : 0.0f;
-                    chs[u] = ch;
-                    ch += dch; rem += drem;
-                    if (rem >= R.khkw) { rem -= R.khkw; ++ch; }
+                for (int j = 0; j < kRegs; ++j) {
+                    // j = it*ppt + u  <=>  u = j - it*ppt in [0, ppt)
+                    const int u = j - it * ppt;
+                    if (u >= 0 && u < ppt) {
+                        const int ps = ln + u * G;
+                        if (act && ps < npos) {
+                            const float nv = v[j] * tab[ch];        // dfq.py:73
+                            R.w2[base + ps] = nv;
+                            diff_touch(R.diff2, nv, v[j], R.prev2, base + ps, acc);
+                            rmn = fminf(rmn, nv);
+                            rmx = fmaxf(rmx, nv);
+                        }
+                        ch += dch; rem += drem;
+                        if (rem >= R.khkw) { rem -= R.khkw; ++ch; }
+                    }
                 }
+            } else {
+                for (int pb = ln; act && pb < npos; pb += 4 * G) {
+                    float w[4];
+                    int chs[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int pos = pb + u * G;
-                    if (pos < npos) {
-                        const float nv = v[u] * tab[chs[u]];      // dfq.py:73
-                        R.w2[base + pos] = nv;
-                        diff_touch(R.diff2, nv, v[u], prev, base + pos, acc);
-                        rmn = fminf(rmn, nv);
-                        rmx = fmaxf(rmx, nv);
+                    for (int u = 0; u < 4; ++u) {
+                        const int ps = pb + u * G;
+                        w[u] = (ps < npos) ? R.w2[base + ps] : 0.0f;
+                        chs[u] = ch;
+                        ch += dch; rem += drem;
+                        if (rem >= R.khkw) { rem -= R.khkw; ++ch; }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int ps = pb + u * G;
+                        if (ps < npos) {
+                            const float nv = w[u] * tab[chs[u]];      // dfq.py:73
+                            R.w2[base + ps] = nv;
+                            diff_touch(R.diff2, nv, w[u], R.prev2, base + ps, acc);
+                            rmn = fminf(rmn, nv);
+                            rmx = fmaxf(rmx, nv);
+                        }
                     }
                 }
             }
@@ -339,7 +395,14 @@ __device__ __forceinline__ double col_tile(const LeRelDev& R, const LeParams& p,
     return acc;
 }
 
-__global__ __launch_bounds__(kBlock) void le_level_kernel(const LeRelDev* __restrict__ rels, int n_rels,
+// first workgroup of each relation of a level, passed BY VALUE (kernarg -> scalar registers) so the
+// workgroup -> relation lookup costs no dependent global loads
+struct LevelTable {
+    int32_t n;
+    int32_t begin[kLevelRelsMax];
+};
+
+__global__ __launch_bounds__(kBlock) void le_level_kernel(const LeRelDev* __restrict__ rels, LevelTable tab,
                                                           LeParams p, const LeState* __restrict__ state,
                                                           double* __restrict__ partials) {
     if (state->done) return;   // wave-uniform: the reference loop has already exited
@@ -350,7 +413,9 @@ __global__ __launch_bounds__(kBlock) void le_level_kernel(const LeRelDev* __rest
     __shared__ double sh_red[kBlock / kWave];
 
     int r = 0;
-    while (r + 1 < n_rels && (int)blockIdx.x >= rels[r + 1].tile_begin) ++r;
+#pragma unroll
+    for (int i = 1; i < kLevelRelsMax; ++i)
+        if (i < tab.n && (int)blockIdx.x >= tab.begin[i]) r = i;
     const LeRelDev R = rels[r];
     const int tile = blockIdx.x - R.tile_begin;
     double acc;
@@ -422,27 +487,36 @@ __global__ __launch_bounds__(kBlock) void le_bootstrap_kernel(const LeRelDev* __
     }
 }
 
-// dfq.py:105-115 on the device.  One workgroup; wave w reduces layers w, w+4, ...  Also clears the
-// column-stat buffers of the parity that the next sweep accumulates into.
-__global__ __launch_bounds__(kBlock) void le_control_kernel(const LeLayerDiff* __restrict__ layers, int n_layers,
-                                                            const double* __restrict__ partials,
-                                                            double* __restrict__ layer_mean,
-                                                            uint32_t* __restrict__ r2_arena, int64_t r2_words,
-                                                            LeState* __restrict__ state, double converge_thres,
-                                                            int converge_count, int max_sweeps) {
+// dfq.py:105-115 on the device.  One workgroup of 16 waves: the per-tile partials are staged into
+// LDS with every load in flight at once, wave w then reduces layers w, w+16, ... in a fixed order.
+// Also clears the column-stat buffers of the parity that the next sweep accumulates into.
+__global__ __launch_bounds__(kCtlBlock) void le_control_kernel(const LeLayerDiff* __restrict__ layers, int n_layers,
+                                                               const double* __restrict__ partials, int n_partials,
+                                                               double* __restrict__ layer_mean,
+                                                               uint32_t* __restrict__ r2_arena, int64_t r2_words,
+                                                               LeState* __restrict__ state, double converge_thres,
+                                                               int converge_count, int max_sweeps) {
     if (state->done) return;
+    __shared__ double sh_part[kCtlStage];
     __shared__ double sh_mean[1024];
-    const int lane = threadIdx.x % kWave;
-    const int wave = threadIdx.x / kWave;
+    const int tid = threadIdx.x;
+    const int lane = tid % kWave;
+    const int wave = tid / kWave;
     const int cur = state->sweeps & 1;
+    const int n_stage = min(n_partials, kCtlStage);
+    for (int i = tid; i < n_stage; i += kCtlBlock) sh_part[i] = partials[i];
     // parity `cur` was consumed by this sweep; the next sweep produces (atomicMax) into it
     uint32_t* z = r2_arena + (int64_t)cur * r2_words;
-    for (int64_t i = threadIdx.x; i < r2_words; i += kBlock) z[i] = 0u;
-    for (int l = wave; l < n_layers; l += kBlock / kWave) {
+    for (int64_t i = tid; i < r2_words; i += kCtlBlock) z[i] = 0u;
+    __syncthreads();
+    for (int l = wave; l < n_layers; l += kCtlBlock / kWave) {
         const LeLayerDiff L = layers[l];
         double s = 0.0;
         if (L.partial_begin >= 0) {
-            for (int i = lane; i < L.n_partials; i += kWave) s += partials[L.partial_begin + i];
+            for (int i = lane; i < L.n_partials; i += kWave) {
+                const int idx = L.partial_begin + i;
+                s += (idx < n_stage) ? sh_part[idx] : partials[idx];
+            }
             s = wave_sum(s);
         }
         if (lane == 0) {
@@ -452,7 +526,7 @@ __global__ __launch_bounds__(kBlock) void le_control_kernel(const LeLayerDiff* _
         }
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (tid == 0) {
         double diff_tmp = 0.0;
         for (int l = 0; l < n_layers; ++l) diff_tmp += (l < 1024) ? sh_mean[l] : layer_mean[l];   // graph order
         double diff = state->diff;
@@ -488,6 +562,7 @@ struct LevelLaunch {
     int rel_begin = 0;      // range in the level-sorted device relation table
     int n_rels = 0;
     int n_blocks = 0;
+    LevelTable table;       // first workgroup of each relation (kernel argument)
     int64_t paired = 0;     // elements n1+n2 of the relations in this level
     int64_t snapshot = 0;   // snapshot-arena elements written or read in this level
 };
@@ -637,6 +712,7 @@ int dfq_le_plan_create(const dfq_layer* layers, int32_t n_layers, const dfq_rela
         d.rt_cols = (d.row_len + d.rt_slabs - 1) / d.rt_slabs;
         d.rt_slabs = (d.row_len + d.rt_cols - 1) / d.rt_cols;
         int rows = std::max(1, target / d.rt_cols);
+        rows = std::min(rows, kRegs * (kBlock / d.rt_cols));         // <= kRegs rows per thread
         rows = std::min(rows, std::min(kRowTileRowsMax, d.o1));
         d.rt_rows = rows;
         // col tiles
@@ -646,6 +722,10 @@ int dfq_le_plan_create(const dfq_layer* layers, int32_t n_layers, const dfq_rela
         d.ct_lanes = lanes;
         d.ct_chunk = std::min(d.i2g, kChunkCh);
         int crow = std::max(1, target / row_len2);
+        {   // <= kRegs elements per thread so the whole tile is preloaded into registers
+            const int ppt = (row_len2 + lanes - 1) / lanes;
+            crow = std::min(crow, (kBlock / lanes) * std::max(1, kRegs / ppt));
+        }
         crow = std::min(crow, std::min(kColRowsMax, d.o2));
         // a tile of `crow` rows spans at most crow/go + 2 groups; the 1/s table holds (#groups) * chunk entries
         const int64_t max_groups = kInvMax / d.ct_chunk;     // >= 4 because ct_chunk <= kChunkCh
@@ -695,17 +775,25 @@ int dfq_le_plan_create(const dfq_layer* layers, int32_t n_layers, const dfq_rela
     for (int r = 0; r < n_relations; ++r) order[r] = r;
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return level[a] < level[b]; });
     std::vector<LeRelDev> sorted(n_relations);
-    p->levels.assign(n_levels, LevelLaunch());
+    p->levels.clear();
+    int prev_level = -1;
     for (int i = 0; i < n_relations; ++i) {
         const int r = order[i];
-        LevelLaunch& L = p->levels[level[r]];
-        if (L.n_rels == 0) L.rel_begin = i;
+        if (level[r] != prev_level || p->levels.back().n_rels == kLevelRelsMax) {   // new launch
+            p->levels.push_back(LevelLaunch());
+            p->levels.back().rel_begin = i;
+            p->levels.back().table.n = 0;
+            prev_level = level[r];
+        }
+        LevelLaunch& L = p->levels.back();
         sorted[i] = h[r];
         sorted[i].tile_begin = L.n_blocks;
         sorted[i].boot_begin = boot;              // bootstrap launch walks the same (sorted) table
         boot += h[r].boot_tiles;
+        L.table.begin[L.n_rels] = L.n_blocks;
         L.n_blocks += h[r].n_row_tiles + h[r].n_col_tiles;
         L.n_rels += 1;
+        L.table.n = L.n_rels;
         const int64_t n1 = (int64_t)h[r].o1 * h[r].row_len;
         const int64_t n2 = (int64_t)h[r].o2 * h[r].i2g * h[r].khkw;
         L.paired += n1 + n2;
@@ -771,14 +859,15 @@ static int le_restart(dfq_le_plan* p, const dfq_le_config* cfg, hipStream_t st) 
 static int le_launch_level(dfq_le_plan* p, const LevelLaunch& L, const LeParams& q, hipStream_t st) {
     if (L.n_blocks == 0) return DFQ_OK;
     hipLaunchKernelGGL(le_level_kernel, dim3(L.n_blocks), dim3(kBlock), 0, st,
-                       (const LeRelDev*)(p->d_rels + L.rel_begin), L.n_rels, q, (const LeState*)p->d_state, p->d_partials);
+                       (const LeRelDev*)(p->d_rels + L.rel_begin), L.table, q, (const LeState*)p->d_state, p->d_partials);
     DFQ_CHECK_LAUNCH();
     return DFQ_OK;
 }
 
 static int le_launch_control(dfq_le_plan* p, const dfq_le_config* cfg, hipStream_t st) {
-    hipLaunchKernelGGL(le_control_kernel, dim3(1), dim3(kBlock), 0, st, (const LeLayerDiff*)p->d_layer_diff,
-                       p->n_layers, (const double*)p->d_partials, p->d_layer_mean, p->d_stats, (int64_t)p->r2_words,
+    hipLaunchKernelGGL(le_control_kernel, dim3(1), dim3(kCtlBlock), 0, st, (const LeLayerDiff*)p->d_layer_diff,
+                       p->n_layers, (const double*)p->d_partials, p->total_tiles, p->d_layer_mean, p->d_stats,
+                       (int64_t)p->r2_words,
                        p->d_state, cfg->converge_thres, (int)cfg->converge_count, (int)cfg->max_sweeps);
     DFQ_CHECK_LAUNCH();
     return DFQ_OK;
