@@ -10,6 +10,16 @@
 
 namespace dfq {
 
+// Pointers fetched from descriptor tables in memory have no address space the compiler can see, so
+// plain dereferences become flat_load/flat_store.  Casting to the global address space gives
+// global_load/global_store (no LDS-aperture check, no lgkmcnt coupling with LDS traffic).  The CPU
+// test emulation builds with -DDFQ_GLOBAL_AS= (an empty qualifier).
+#ifndef DFQ_GLOBAL_AS
+#define DFQ_GLOBAL_AS __attribute__((address_space(1)))
+#endif
+typedef DFQ_GLOBAL_AS float gfloat;
+typedef DFQ_GLOBAL_AS unsigned int guint;
+
 constexpr int kBlock = 256;   // 4 wavefronts of 64 lanes
 constexpr int kWave = 64;
 

@@ -126,11 +126,21 @@ __device__ __forceinline__ float range_of(float mn, float mx, int signed_range) 
 // scale of paired channel c from the four stat words of the current parity
 __device__ __forceinline__ void channel_scale(const LeRelDev& R, const LeParams& p, int cur, int c, float& s,
                                               float& inv, float& mn1, float& mx1, float& mn2, float& mx2) {
-    const uint32_t* a = R.r1 + (int64_t)cur * R.stat_stride + 2 * c;
-    const uint32_t* b = R.r2 + (int64_t)cur * R.stat_stride + 2 * c;
+    const guint* a = (const guint*)R.r1 + (int64_t)cur * R.stat_stride + 2 * c;
+    const guint* b = (const guint*)R.r2 + (int64_t)cur * R.stat_stride + 2 * c;
     mn1 = slot_min(a[0]); mx1 = slot_max(a[1]);
     mn2 = slot_min(b[0]); mx2 = slot_max(b[1]);
     le_solve(range_of(mn1, mx1, p.signed_range), range_of(mn2, mx2, p.signed_range), p, s, inv);
+}
+
+// optional per-phase cycle stamps of one workgroup (dfq_le_trace, tuning aid; null in production)
+struct LeTrace {
+    long long* out;     // device [16] or null
+    int32_t block;
+    int32_t pad;
+};
+__device__ __forceinline__ void stamp(const LeTrace& tr, int slot) {
+    if (tr.out && (int)blockIdx.x == tr.block && threadIdx.x == 0) tr.out[slot] = clock64();
 }
 
 __device__ __forceinline__ void diff_touch(int mode, float nv, float v, float* prev, int64_t idx, double& acc) {
@@ -144,10 +154,12 @@ __device__ __forceinline__ void diff_touch(int mode, float nv, float v, float* p
 //
 // The plan sizes tiles so that a thread owns at most kRegs elements: all of them are loaded into
 // registers BEFORE the scale solve, so the data fetch and the stat fetch + solve overlap and the
-// tile's critical path is one memory round trip, not two.
+// tile's critical path is one memory round trip, not two.  Loads are unconditional (indices are
+// clamped into the tile) so the compiler emits a straight run of global_load_dword with no exec-mask
+// branches; only the stores are predicated.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ double row_tile(const LeRelDev& R, const LeParams& p, int tile, int cur,
-                                           float* sh_s, uint32_t* sh_slot) {
+                                           float* sh_s, uint32_t* sh_slot, int* sh_g, const LeTrace& tr) {
     const int tid = threadIdx.x;
     const int slab = tile % R.rt_slabs;
     const int r0 = (tile / R.rt_slabs) * R.rt_rows;
@@ -156,16 +168,28 @@ __device__ __forceinline__ double row_tile(const LeRelDev& R, const LeParams& p,
     const int np = min(R.rt_cols, R.row_len - p0);
     const int nxt = cur ^ 1;
     const int JL = kBlock / np;                // np <= 128 -> JL >= 2
-    const int jl = tid / np;
-    const int pos = p0 + (tid - jl * np);
-    const bool lane_on = jl < JL;
+    const int jl_raw = tid / np;
+    const bool lane_on = jl_raw < JL;
+    const int jl = lane_on ? jl_raw : 0;
+    const int pos = p0 + (lane_on ? (tid - jl_raw * np) : 0);
+    const int n_own = lane_on ? (nr - jl + JL - 1) / JL : 0;     // rows this thread owns (<= kRegs by plan)
+    gfloat* const w = (gfloat*)R.w1 + ((int64_t)r0 * R.row_len + pos);
+    gfloat* const pv = (gfloat*)R.prev1 + ((int64_t)r0 * R.row_len + pos);
+    const int mode = R.diff1;
 
     // ---- issue every data load first -----------------------------------------------------------
-    float v[kRegs];
+    float v[kRegs], q[kRegs];
 #pragma unroll
     for (int u = 0; u < kRegs; ++u) {
-        const int r = jl + u * JL;
-        v[u] = (lane_on && r < nr) ? R.w1[(int64_t)(r0 + r) * R.row_len + pos] : 0.0f;
+        const int r = min(jl + u * JL, nr - 1);
+        v[u] = w[r * R.row_len];
+    }
+    if (mode == DIFF_FROM_PREV) {
+#pragma unroll
+        for (int u = 0; u < kRegs; ++u) {
+            const int r = min(jl + u * JL, nr - 1);
+            q[u] = pv[r * R.row_len];
+        }
     }
 
     // column-stat slot geometry of this tile
@@ -178,68 +202,82 @@ __device__ __forceinline__ double row_tile(const LeRelDev& R, const LeParams& p,
         n_slots = ((r0 + nr - 1) / R.pc_go - g0 + 1) * nci;
         for (int i = tid; i < 2 * n_slots; i += kBlock) sh_slot[i] = 0u;
     }
+    stamp(tr, 2);
     if (tid < nr) {
         const int c = r0 + tid;
         float s, inv, mn1, mx1, mn2, mx2;
         channel_scale(R, p, cur, c, s, inv, mn1, mx1, mn2, mx2);
         sh_s[tid] = s;
+        if (emit) sh_g[tid] = c / R.pc_go - g0;
         if (slab == 0) {                                   // one tile per row owns the [O1] vectors
             R.s_cum[c] = R.s_cum[c] * s;                  // relation.py:20-24
             if (R.bnw) R.bnw[c] = R.bnw[c] * s;           // dfq.py:64-65
             if (R.bnb) R.bnb[c] = R.bnb[c] * s;           // dfq.py:67-68
             if (R.b1) R.b1[c] = R.b1[c] * s;              // dfq.py:70-71
             if (!emit) {                                   // W1 is never column-scaled: forward its row stats
-                uint32_t* f = R.r1 + (int64_t)nxt * R.stat_stride + 2 * c;
+                guint* f = (guint*)R.r1 + (int64_t)nxt * R.stat_stride + 2 * c;
                 f[0] = ~enc_ord(mn1 * s);
                 f[1] = enc_ord(mx1 * s);
             }
         }
     }
+    stamp(tr, 3);
     __syncthreads();
+    stamp(tr, 4);
 
     double acc = 0.0;
-    if (lane_on) {
-        const int ci = emit ? (pos / R.khkw1 - i0) : 0;
-        float cmn = INFINITY, cmx = -INFINITY;
-        int cur_g = -1;
-        // rows beyond kRegs*JL (never produced by the plan's tile sizes) are handled by the tail loop
-        const int n_own = (nr - jl + JL - 1) / JL;        // rows this thread owns
-        for (int u0 = 0; u0 < n_own; u0 += kRegs) {
-            if (u0 > 0) {
+    const int ci = emit ? (pos / R.khkw1 - i0) : 0;
+    float cmn = INFINITY, cmx = -INFINITY;
+    int cur_g = -1;
 #pragma unroll
-                for (int u = 0; u < kRegs; ++u) {
-                    const int r = jl + (u0 + u) * JL;
-                    v[u] = (r < nr) ? R.w1[(int64_t)(r0 + r) * R.row_len + pos] : 0.0f;
+    for (int u = 0; u < kRegs; ++u) {
+        const int r = min(jl + u * JL, nr - 1);
+        const bool ok = u < n_own;
+        const float nv = v[u] * sh_s[r];                  // dfq.py:62
+        if (ok) w[r * R.row_len] = nv;
+        if (mode == DIFF_DIRECT) acc += ok ? (double)fabsf(nv - v[u]) : 0.0;
+        else if (mode == DIFF_SAVE) { if (ok) pv[r * R.row_len] = v[u]; }
+        else acc += ok ? (double)fabsf(nv - q[u]) : 0.0;
+        if (emit && ok) {
+            const int g = sh_g[r];
+            if (g != cur_g) {
+                if (cur_g >= 0) {
+                    atomicMax(&sh_slot[2 * (cur_g * nci + ci) + 0], ~enc_ord(cmn));
+                    atomicMax(&sh_slot[2 * (cur_g * nci + ci) + 1], enc_ord(cmx));
                 }
+                cur_g = g; cmn = INFINITY; cmx = -INFINITY;
             }
-#pragma unroll
-            for (int u = 0; u < kRegs; ++u) {
-                const int r = jl + (u0 + u) * JL;
-                if (r < nr) {
-                    const int64_t idx = (int64_t)(r0 + r) * R.row_len + pos;
-                    const float nv = v[u] * sh_s[r];          // dfq.py:62
-                    R.w1[idx] = nv;
-                    diff_touch(R.diff1, nv, v[u], R.prev1, idx, acc);
-                    if (emit) {
-                        const int g = (r0 + r) / R.pc_go - g0;
-                        if (g != cur_g) {
-                            if (cur_g >= 0) {
-                                atomicMax(&sh_slot[2 * (cur_g * nci + ci) + 0], ~enc_ord(cmn));
-                                atomicMax(&sh_slot[2 * (cur_g * nci + ci) + 1], enc_ord(cmx));
-                            }
-                            cur_g = g; cmn = INFINITY; cmx = -INFINITY;
-                        }
-                        cmn = fminf(cmn, nv);
-                        cmx = fmaxf(cmx, nv);
-                    }
-                }
-            }
-        }
-        if (emit && cur_g >= 0) {
-            atomicMax(&sh_slot[2 * (cur_g * nci + ci) + 0], ~enc_ord(cmn));
-            atomicMax(&sh_slot[2 * (cur_g * nci + ci) + 1], enc_ord(cmx));
+            cmn = fminf(cmn, nv);
+            cmx = fmaxf(cmx, nv);
         }
     }
+    // rows beyond kRegs per thread: never produced by the plan's tile sizes, kept for safety
+    for (int u = kRegs; u < n_own; ++u) {
+        const int r = jl + u * JL;
+        const float x = w[r * R.row_len];
+        const float nv = x * sh_s[r];
+        w[r * R.row_len] = nv;
+        if (mode == DIFF_DIRECT) acc += (double)fabsf(nv - x);
+        else if (mode == DIFF_SAVE) pv[r * R.row_len] = x;
+        else acc += (double)fabsf(nv - pv[r * R.row_len]);
+        if (emit) {
+            const int g = sh_g[r];
+            if (g != cur_g) {
+                if (cur_g >= 0) {
+                    atomicMax(&sh_slot[2 * (cur_g * nci + ci) + 0], ~enc_ord(cmn));
+                    atomicMax(&sh_slot[2 * (cur_g * nci + ci) + 1], enc_ord(cmx));
+                }
+                cur_g = g; cmn = INFINITY; cmx = -INFINITY;
+            }
+            cmn = fminf(cmn, nv);
+            cmx = fmaxf(cmx, nv);
+        }
+    }
+    if (emit && cur_g >= 0) {
+        atomicMax(&sh_slot[2 * (cur_g * nci + ci) + 0], ~enc_ord(cmn));
+        atomicMax(&sh_slot[2 * (cur_g * nci + ci) + 1], enc_ord(cmx));
+    }
+    stamp(tr, 5);
     if (emit) {
         __syncthreads();
         for (int sl = tid; sl < n_slots; sl += kBlock) {
@@ -247,9 +285,9 @@ __device__ __forceinline__ double row_tile(const LeRelDev& R, const LeParams& p,
             if (b != 0u) {
                 const int g = g0 + sl / nci;
                 const int i = i0 + sl % nci;
-                uint32_t* dst = R.out_cols + (int64_t)nxt * R.stat_stride + 2 * ((int64_t)g * R.pc_gi + i);
-                atomicMax(dst + 0, a);
-                atomicMax(dst + 1, b);
+                guint* dst = (guint*)R.out_cols + (int64_t)nxt * R.stat_stride + 2 * ((int64_t)g * R.pc_gi + i);
+                atomicMax((unsigned*)dst + 0, a);
+                atomicMax((unsigned*)dst + 1, b);
             }
         }
     }
@@ -263,7 +301,7 @@ __device__ __forceinline__ double row_tile(const LeRelDev& R, const LeParams& p,
 // `u`) pairs, flattened to j = it*ppt + u < kRegs for the register preload.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ double col_tile(const LeRelDev& R, const LeParams& p, int tile, int cur,
-                                           float* sh_inv, uint32_t* sh_row) {
+                                           float* sh_inv, uint32_t* sh_row, const LeTrace& tr) {
     const int tid = threadIdx.x;
     const int r0 = tile * R.ct_rows;
     const int nr = min(R.ct_rows, R.o2 - r0);
@@ -280,21 +318,26 @@ __device__ __forceinline__ double col_tile(const LeRelDev& R, const LeParams& p,
     const bool single = R.ct_chunk >= R.i2g;               // the whole row in one pass (always, unless I2/g > kChunkCh)
     const int ppt = (row_len2 + G - 1) / G;                // positions per thread per row
     const bool preload = single && n_iter * ppt <= kRegs;
+    const int mode = R.diff2;
+    gfloat* const w = (gfloat*)R.w2 + (int64_t)r0 * row_len2;
+    gfloat* const pv = (gfloat*)R.prev2 + (int64_t)r0 * row_len2;
 
-    float v[kRegs];
+    float v[kRegs], q[kRegs];
     if (preload) {
         int it = 0, u = 0;
 #pragma unroll
         for (int j = 0; j < kRegs; ++j) {
-            const int r = grp + it * n_groups;
-            const int ps = ln + u * G;
-            v[j] = (it < n_iter && r < nr && ps < row_len2) ? R.w2[(int64_t)(r0 + r) * row_len2 + ps] : 0.0f;
+            const int r = min(grp + it * n_groups, nr - 1);
+            const int ps = min(ln + u * G, row_len2 - 1);
+            v[j] = w[r * row_len2 + ps];
+            if (mode == DIFF_FROM_PREV) q[j] = pv[r * row_len2 + ps];
             if (++u == ppt) { u = 0; ++it; }
         }
     }
     if (emit) {
         for (int i = tid; i < 2 * nr; i += kBlock) sh_row[i] = 0u;
     }
+    stamp(tr, 2);
     double acc = 0.0;
     for (int ii0 = 0; ii0 < R.i2g; ii0 += R.ct_chunk) {
         const int nch = min(R.ct_chunk, R.i2g - ii0);
@@ -309,52 +352,71 @@ __device__ __forceinline__ double col_tile(const LeRelDev& R, const LeParams& p,
             sh_inv[idx] = inv;
             // W2 is never row-scaled: forward its column stats (the tile holding the group's first row does it)
             if (!emit && g * R.go >= r0 && g * R.go < r0 + nr) {
-                uint32_t* f = R.r2 + (int64_t)nxt * R.stat_stride + 2 * c;
+                guint* f = (guint*)R.r2 + (int64_t)nxt * R.stat_stride + 2 * c;
                 f[0] = ~enc_ord(mn2 * inv);
                 f[1] = enc_ord(mx2 * inv);
             }
         }
+        stamp(tr, 3);
         __syncthreads();
+        stamp(tr, 4);
         const int npos = nch * R.khkw;
         const int dch = G / R.khkw;
         const int drem = G - dch * R.khkw;
         const int ch_first = ln / R.khkw;
         const int rem_first = ln - ch_first * R.khkw;
-        for (int it = 0; it < n_iter; ++it) {          // uniform trip count: every lane reaches the shuffles
-            const int r = grp + it * n_groups;
-            const bool act = r < nr;
-            const int o = r0 + (act ? r : 0);
-            const float* tab = sh_inv + (o / R.go - g_lo) * nch;
-            const int64_t base = (int64_t)o * row_len2 + (int64_t)ii0 * R.khkw;
+        if (preload) {
+            // j = it*ppt + u: (it, u) advance together with j; channel counters restart with every row
+            int it = 0, u = 0, ch = ch_first, rem = rem_first;
             float rmn = INFINITY, rmx = -INFINITY;
-            int ch = ch_first, rem = rem_first;
-            if (preload) {
+            int tab_off = ((r0 + min(grp, nr - 1)) / R.go - g_lo) * nch;      // 1/s table row of this thread's row
 #pragma unroll
-                for (int j = 0; j < kRegs; ++j) {
-                    // j = it*ppt + u  <=>  u = j - it*ppt in [0, ppt)
-                    const int u = j - it * ppt;
-                    if (u >= 0 && u < ppt) {
-                        const int ps = ln + u * G;
-                        if (act && ps < npos) {
-                            const float nv = v[j] * tab[ch];        // dfq.py:73
-                            R.w2[base + ps] = nv;
-                            diff_touch(R.diff2, nv, v[j], R.prev2, base + ps, acc);
-                            rmn = fminf(rmn, nv);
-                            rmx = fmaxf(rmx, nv);
+            for (int j = 0; j < kRegs; ++j) {
+                const int r_raw = grp + it * n_groups;
+                const int r = min(r_raw, nr - 1);
+                const int ps_raw = ln + u * G;
+                const bool ok = it < n_iter && r_raw < nr && ps_raw < npos;
+                const int ps = min(ps_raw, row_len2 - 1);
+                const float nv = v[j] * sh_inv[tab_off + min(ch, nch - 1)];      // dfq.py:73
+                if (ok) w[r * row_len2 + ps] = nv;
+                if (mode == DIFF_DIRECT) acc += ok ? (double)fabsf(nv - v[j]) : 0.0;
+                else if (mode == DIFF_SAVE) { if (ok) pv[r * row_len2 + ps] = v[j]; }
+                else acc += ok ? (double)fabsf(nv - q[j]) : 0.0;
+                if (ok) { rmn = fminf(rmn, nv); rmx = fmaxf(rmx, nv); }
+                ch += dch; rem += drem;
+                if (rem >= R.khkw) { rem -= R.khkw; ++ch; }
+                if (++u == ppt) {                                   // row finished (uniform over the block)
+                    if (emit && it < n_iter) {
+                        for (int m = G >> 1; m >= 1; m >>= 1) {
+                            rmn = fminf(rmn, __shfl_xor(rmn, m));
+                            rmx = fmaxf(rmx, __shfl_xor(rmx, m));
                         }
-                        ch += dch; rem += drem;
-                        if (rem >= R.khkw) { rem -= R.khkw; ++ch; }
+                        if (r_raw < nr && ln == 0 && rmn <= rmx) {
+                            sh_row[2 * r + 0] = ~enc_ord(rmn);     // one writer per row
+                            sh_row[2 * r + 1] = enc_ord(rmx);
+                        }
                     }
+                    u = 0; ++it; ch = ch_first; rem = rem_first; rmn = INFINITY; rmx = -INFINITY;
+                    if (it < n_iter) tab_off = ((r0 + min(grp + it * n_groups, nr - 1)) / R.go - g_lo) * nch;
                 }
-            } else {
+            }
+        } else {
+            for (int it = 0; it < n_iter; ++it) {          // uniform trip count: every lane reaches the shuffles
+                const int r = grp + it * n_groups;
+                const bool act = r < nr;
+                const int rr = act ? r : 0;
+                const float* tab = sh_inv + ((r0 + rr) / R.go - g_lo) * nch;
+                const int64_t base = (int64_t)rr * row_len2 + (int64_t)ii0 * R.khkw;
+                float rmn = INFINITY, rmx = -INFINITY;
+                int ch = ch_first, rem = rem_first;
                 for (int pb = ln; act && pb < npos; pb += 4 * G) {
-                    float w[4];
+                    float x[4];
                     int chs[4];
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const int ps = pb + u * G;
-                        w[u] = (ps < npos) ? R.w2[base + ps] : 0.0f;
-                        chs[u] = ch;
+                        x[u] = w[base + min(ps, npos - 1)];
+                        chs[u] = min(ch, nch - 1);
                         ch += dch; rem += drem;
                         if (rem >= R.khkw) { rem -= R.khkw; ++ch; }
                     }
@@ -362,35 +424,35 @@ __device__ __forceinline__ double col_tile(const LeRelDev& R, const LeParams& p,
                     for (int u = 0; u < 4; ++u) {
                         const int ps = pb + u * G;
                         if (ps < npos) {
-                            const float nv = w[u] * tab[chs[u]];      // dfq.py:73
-                            R.w2[base + ps] = nv;
-                            diff_touch(R.diff2, nv, w[u], R.prev2, base + ps, acc);
+                            const float nv = x[u] * tab[chs[u]];      // dfq.py:73
+                            w[base + ps] = nv;
+                            if (mode == DIFF_DIRECT) acc += (double)fabsf(nv - x[u]);
+                            else if (mode == DIFF_SAVE) pv[base + ps] = x[u];
+                            else acc += (double)fabsf(nv - pv[base + ps]);
                             rmn = fminf(rmn, nv);
                             rmx = fmaxf(rmx, nv);
                         }
                     }
                 }
-            }
-            if (emit) {
-                for (int m = G >> 1; m >= 1; m >>= 1) {
-                    rmn = fminf(rmn, __shfl_xor(rmn, m));
-                    rmx = fmaxf(rmx, __shfl_xor(rmx, m));
-                }
-                if (act && ln == 0 && rmn <= rmx) {
-                    atomicMax(&sh_row[2 * r + 0], ~enc_ord(rmn));
-                    atomicMax(&sh_row[2 * r + 1], enc_ord(rmx));
+                if (emit) {
+                    for (int m = G >> 1; m >= 1; m >>= 1) {
+                        rmn = fminf(rmn, __shfl_xor(rmn, m));
+                        rmx = fmaxf(rmx, __shfl_xor(rmx, m));
+                    }
+                    if (act && ln == 0 && rmn <= rmx) {
+                        atomicMax(&sh_row[2 * r + 0], ~enc_ord(rmn));
+                        atomicMax(&sh_row[2 * r + 1], enc_ord(rmx));
+                    }
                 }
             }
         }
     }
+    stamp(tr, 5);
     if (emit) {
         __syncthreads();
         // complete rows: plain stores into the SAME sweep's parity (consumed by a later level)
-        for (int r = tid; r < nr; r += kBlock) {
-            uint32_t* dst = R.out_rows + (int64_t)cur * R.stat_stride + 2 * (r0 + r);
-            dst[0] = sh_row[2 * r + 0];
-            dst[1] = sh_row[2 * r + 1];
-        }
+        guint* dst = (guint*)R.out_rows + (int64_t)cur * R.stat_stride + 2 * r0;
+        for (int i = tid; i < 2 * nr; i += kBlock) dst[i] = sh_row[i];
     }
     return acc;
 }
@@ -404,25 +466,32 @@ struct LevelTable {
 
 __global__ __launch_bounds__(kBlock) void le_level_kernel(const LeRelDev* __restrict__ rels, LevelTable tab,
                                                           LeParams p, const LeState* __restrict__ state,
-                                                          double* __restrict__ partials) {
-    if (state->done) return;   // wave-uniform: the reference loop has already exited
-    const int cur = state->sweeps & 1;
-
-    __shared__ float sh_f[kInvMax];                 // row tile: scales; col tile: 1/s table
-    __shared__ uint32_t sh_u[2 * kSlotMax];         // row tile: column-stat slots; col tile: row stats
-    __shared__ double sh_red[kBlock / kWave];
-
+                                                          double* __restrict__ partials, LeTrace tr) {
+    stamp(tr, 0);
+    // the descriptor fetch does not depend on the loop state: issue both, wait once
     int r = 0;
 #pragma unroll
     for (int i = 1; i < kLevelRelsMax; ++i)
         if (i < tab.n && (int)blockIdx.x >= tab.begin[i]) r = i;
     const LeRelDev R = rels[r];
+    const int done = state->done;
+    const int cur = state->sweeps & 1;
+    if (done) return;          // wave-uniform: the reference loop has already exited
+    stamp(tr, 1);
+
+    __shared__ float sh_f[kInvMax];                 // row tile: scales; col tile: 1/s table
+    __shared__ uint32_t sh_u[2 * kSlotMax];         // row tile: column-stat slots; col tile: row stats
+    __shared__ int sh_g[kRowTileRowsMax];           // row tile: group (of the stat consumer) of each row
+    __shared__ double sh_red[kBlock / kWave];
+
     const int tile = blockIdx.x - R.tile_begin;
     double acc;
-    if (tile < R.n_row_tiles) acc = row_tile(R, p, tile, cur, sh_f, sh_u);
-    else acc = col_tile(R, p, tile - R.n_row_tiles, cur, sh_f, sh_u);
+    if (tile < R.n_row_tiles) acc = row_tile(R, p, tile, cur, sh_f, sh_u, sh_g, tr);
+    else acc = col_tile(R, p, tile - R.n_row_tiles, cur, sh_f, sh_u, tr);
+    stamp(tr, 6);
     const double t = block_sum(acc, sh_red);
     if (threadIdx.x == 0) partials[R.partial_base + tile] = t;
+    stamp(tr, 7);
 }
 
 // Stats of the untouched weights, once per run: R1 (rows of W1) for chain-start relations and R2
@@ -856,10 +925,11 @@ static int le_restart(dfq_le_plan* p, const dfq_le_config* cfg, hipStream_t st) 
     return DFQ_OK;
 }
 
-static int le_launch_level(dfq_le_plan* p, const LevelLaunch& L, const LeParams& q, hipStream_t st) {
+static int le_launch_level(dfq_le_plan* p, const LevelLaunch& L, const LeParams& q, hipStream_t st,
+                           LeTrace tr = LeTrace{nullptr, 0, 0}) {
     if (L.n_blocks == 0) return DFQ_OK;
     hipLaunchKernelGGL(le_level_kernel, dim3(L.n_blocks), dim3(kBlock), 0, st,
-                       (const LeRelDev*)(p->d_rels + L.rel_begin), L.table, q, (const LeState*)p->d_state, p->d_partials);
+                       (const LeRelDev*)(p->d_rels + L.rel_begin), L.table, q, (const LeState*)p->d_state, p->d_partials, tr);
     DFQ_CHECK_LAUNCH();
     return DFQ_OK;
 }
@@ -927,6 +997,29 @@ int dfq_le_profile(dfq_le_plan* p, const dfq_le_config* cfg, int32_t n_sweeps, v
     if (n_level_launches) *n_level_launches = n_levels * n_sweeps;
     for (auto& e : ev) (void)hipEventDestroy(e);
     return DFQ_OK;
+}
+
+int dfq_le_trace(dfq_le_plan* p, const dfq_le_config* cfg, int32_t launch, int32_t block, void* stream,
+                 int64_t* stamps16) {
+    if (!p || !cfg || !stamps16 || launch < 0 || launch >= (int)p->levels.size()) return fail_arg("dfq_le_trace: bad argument");
+    hipStream_t st = as_stream(stream);
+    const LeParams q = make_params(cfg);
+    long long* d = nullptr;
+    DFQ_HIP_TRY(hipMalloc((void**)&d, 16 * sizeof(long long)));
+    DFQ_HIP_TRY(hipMemsetAsync(d, 0, 16 * sizeof(long long), st));
+    int rc = le_restart(p, cfg, st);
+    for (int s = 0; s < 2 && !rc; ++s) {          // trace the second sweep (steady-state stat flow)
+        for (int l = 0; l < (int)p->levels.size() && !rc; ++l)
+            rc = le_launch_level(p, p->levels[l], q, st, (s == 1 && l == launch) ? LeTrace{d, block, 0} : LeTrace{nullptr, 0, 0});
+        if (!rc) rc = le_launch_control(p, cfg, st);
+    }
+    if (!rc) {
+        hipError_t e = hipMemcpyAsync(stamps16, d, 16 * sizeof(long long), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) rc = fail_hip(e, "trace copy", __FILE__, __LINE__);
+    }
+    (void)hipFree(d);
+    return rc;
 }
 
 int dfq_le_query(dfq_le_plan* p, void* stream, dfq_le_result* out, int32_t* done) {

@@ -120,6 +120,13 @@ class LEPlan:
                                              ctypes.byref(ctl), ctypes.byref(nlaunch)))
         return dict(level_ms=[level_ms[i] for i in range(nl)], control_ms=ctl.value, level_launches=nlaunch.value)
 
+    def trace(self, launch, block, **kw):
+        """Shader-clock stamps of one workgroup's tile phases (tuning aid, see dfq_le_trace)."""
+        cfg = _le_config(kw.get('s_range', (1e-8, 1e8)), -1.0, 10 ** 6, kw.get('signed', False), kw.get('eps', 0), None)
+        out = (ctypes.c_int64 * 16)()
+        _ffi.check(_ffi.lib().dfq_le_trace(self._plan, ctypes.byref(cfg), int(launch), int(block), _ffi.stream_arg(), out))
+        return [int(v) for v in out]
+
     def query(self):
         res = _ffi.DfqLeResult()
         done = ctypes.c_int32()

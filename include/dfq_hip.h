@@ -132,6 +132,14 @@ int dfq_le_run(dfq_le_plan* plan, const dfq_le_config* cfg, void* stream, dfq_le
 int dfq_le_profile(dfq_le_plan* plan, const dfq_le_config* cfg, int32_t n_sweeps, void* stream,
                    double* level_ms, double* control_ms, int32_t* n_level_launches);
 
+/* Tuning aid: run two sweeps and return the shader-clock stamps (s_memtime) that thread 0 of
+ * workgroup `block` of launch `launch` took at the phase boundaries of its tile during the second
+ * sweep: [0] entry, [1] descriptor+state loaded, [2] data loads issued, [3] scales solved,
+ * [4] barrier passed, [5] elements stored, [6] stats published, [7] partial written.  Synchronises;
+ * modifies the weights like two ordinary sweeps. */
+int dfq_le_trace(dfq_le_plan* plan, const dfq_le_config* cfg, int32_t launch, int32_t block, void* stream,
+                 int64_t* stamps16);
+
 /* ------------------------------------------------------------------------------------------
  * Tensor primitives -- utils/quantize.py:23-76 (UniformQuantize.forward), :102-119 (QuantMeasure)
  * ---------------------------------------------------------------------------------------- */

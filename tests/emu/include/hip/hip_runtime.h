@@ -92,6 +92,8 @@ inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
 inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
 inline double atomicAdd(double* p, double v) { double o = *p; *p = o + v; return o; }
 
+inline long long clock64() { return 0; }
+
 using std::max;
 using std::min;
 
