@@ -19,6 +19,8 @@ namespace dfq {
 #endif
 typedef DFQ_GLOBAL_AS float gfloat;
 typedef DFQ_GLOBAL_AS unsigned int guint;
+typedef float fvec4 __attribute__((vector_size(16)));   // native 16-byte vector (dwordx4 loads/stores)
+typedef DFQ_GLOBAL_AS fvec4 gfvec4;
 
 constexpr int kBlock = 256;   // 4 wavefronts of 64 lanes
 constexpr int kWave = 64;

@@ -43,13 +43,13 @@
 namespace dfq {
 
 constexpr int kRowTileRowsMax = 256;   // rows of a row tile (one solve per thread)
-constexpr int kRowTileColsMax = 128;   // positions of a row tile
+constexpr int kRowTileColsMax = 128;   // positions of a row tile (x2 for float4 tiles)
 constexpr int kSlotMax = 1024;         // column-stat slots of a row tile in LDS
 constexpr int kInvMax = 8192;          // 1/s table of a col tile in LDS (floats)
 constexpr int kChunkCh = 2048;         // input channels of W2 handled per pass of a col tile
 constexpr int kColRowsMax = 1024;      // rows of a col tile
 constexpr int kBootTc = 64;            // channels per bootstrap tile
-constexpr int kRegs = 16;              // elements a thread preloads into registers
+constexpr int kRegs = 32;              // floats a thread can preload into registers
 constexpr int kLevelRelsMax = 32;      // relations per launch (longer levels are split)
 constexpr int kCtlBlock = 1024;        // threads of the control kernel
 constexpr int kCtlStage = 6144;        // partials staged in LDS by the control kernel
@@ -79,6 +79,7 @@ struct LeRelDev {
     int32_t partial_base;   // first partial slot of this relation (row tiles, then col tiles)
     int32_t tile_begin;     // first workgroup of this relation inside its level launch
     int32_t boot_begin;     // first workgroup inside the bootstrap launch
+    int32_t rt_vec, ct_vec; // 4: tiles move float4 (row length % 4 == 0), else 1
     int32_t pad;
     int64_t stat_stride;    // words between the two parities of a stat arena
 };
@@ -150,45 +151,77 @@ __device__ __forceinline__ void diff_touch(int mode, float nv, float v, float* p
 }
 
 // ---------------------------------------------------------------------------------------------
-// row tile: W1[r0:r0+nr, p0:p0+np] *= s[row]   (+ column stats of the new values)
+// Tiles.  Both tile kinds are written once for VEC = 1 (any geometry) and VEC = 4 (rows that are a
+// multiple of 4 floats: every 1x1 / linear / dense conv layer of the benchmark networks): a thread
+// then moves 16-byte vectors, which quarters the number of vector-memory instructions -- the store
+// path of a CU retires roughly one wave-wide store instruction per ~36 cycles regardless of width,
+// so dword stores, not bytes, were the limiter of the scalar version.
 //
-// The plan sizes tiles so that a thread owns at most kRegs elements: all of them are loaded into
-// registers BEFORE the scale solve, so the data fetch and the stat fetch + solve overlap and the
-// tile's critical path is one memory round trip, not two.  Loads are unconditional (indices are
-// clamped into the tile) so the compiler emits a straight run of global_load_dword with no exec-mask
-// branches; only the stores are predicated.
+// A thread owns at most kRegs floats (the plan sizes tiles accordingly): all of them are loaded
+// into registers BEFORE the scale solve, so the data fetch and the stat fetch + solve overlap and
+// the tile's critical path is one memory round trip.  Loads are unconditional (indices clamped
+// into the tile), only stores are predicated.
 // ---------------------------------------------------------------------------------------------
+template <int VEC>
+__device__ __forceinline__ void vload(const gfloat* p, float (&x)[VEC]) {
+    if (VEC == 4) {
+        const fvec4 t = *(const gfvec4*)p;
+        x[0] = t[0]; x[1 % VEC] = t[1]; x[2 % VEC] = t[2]; x[3 % VEC] = t[3];
+    } else {
+        x[0] = *p;
+    }
+}
+template <int VEC>
+__device__ __forceinline__ void vstore(gfloat* p, const float (&x)[VEC]) {
+    if (VEC == 4) {
+        fvec4 t;
+        t[0] = x[0]; t[1] = x[1 % VEC]; t[2] = x[2 % VEC]; t[3] = x[3 % VEC];
+        *(gfvec4*)p = t;
+    } else {
+        *p = x[0];
+    }
+}
+
+// row tile: W1[r0:r0+nr, p0:p0+np] *= s[row]   (+ column stats of the new values)
+template <int VEC>
 __device__ __forceinline__ double row_tile(const LeRelDev& R, const LeParams& p, int tile, int cur,
                                            float* sh_s, uint32_t* sh_slot, int* sh_g, const LeTrace& tr) {
+    constexpr int NV = kRegs / VEC;            // vectors per thread
     const int tid = threadIdx.x;
     const int slab = tile % R.rt_slabs;
     const int r0 = (tile / R.rt_slabs) * R.rt_rows;
     const int nr = min(R.rt_rows, R.o1 - r0);
     const int p0 = slab * R.rt_cols;
     const int np = min(R.rt_cols, R.row_len - p0);
+    const int npv = np / VEC;                  // vector positions (np % VEC == 0 by plan)
     const int nxt = cur ^ 1;
-    const int JL = kBlock / np;                // np <= 128 -> JL >= 2
-    const int jl_raw = tid / np;
+    const int JL = kBlock / npv;
+    const int jl_raw = tid / npv;
     const bool lane_on = jl_raw < JL;
     const int jl = lane_on ? jl_raw : 0;
-    const int pos = p0 + (lane_on ? (tid - jl_raw * np) : 0);
-    const int n_own = lane_on ? (nr - jl + JL - 1) / JL : 0;     // rows this thread owns (<= kRegs by plan)
+    const int pos = p0 + (lane_on ? (tid - jl_raw * npv) * VEC : 0);
+    const int n_own = lane_on ? (nr - jl + JL - 1) / JL : 0;     // rows this thread owns (<= NV by plan)
     gfloat* const w = (gfloat*)R.w1 + ((int64_t)r0 * R.row_len + pos);
     gfloat* const pv = (gfloat*)R.prev1 + ((int64_t)r0 * R.row_len + pos);
     const int mode = R.diff1;
+    const int n_max = min(NV, (nr + JL - 1) / JL);         // register slots in use (uniform over the block)
 
     // ---- issue every data load first -----------------------------------------------------------
-    float v[kRegs], q[kRegs];
+    float v[NV][VEC], q[NV][VEC];
 #pragma unroll
-    for (int u = 0; u < kRegs; ++u) {
-        const int r = min(jl + u * JL, nr - 1);
-        v[u] = w[r * R.row_len];
+    for (int u = 0; u < NV; ++u) {
+        if (u < n_max) {
+            const int r = min(jl + u * JL, nr - 1);
+            vload<VEC>(w + r * R.row_len, v[u]);
+        }
     }
     if (mode == DIFF_FROM_PREV) {
 #pragma unroll
-        for (int u = 0; u < kRegs; ++u) {
-            const int r = min(jl + u * JL, nr - 1);
-            q[u] = pv[r * R.row_len];
+        for (int u = 0; u < NV; ++u) {
+            if (u < n_max) {
+                const int r = min(jl + u * JL, nr - 1);
+                vload<VEC>(pv + r * R.row_len, q[u]);
+            }
         }
     }
 
@@ -205,15 +238,23 @@ __device__ __forceinline__ double row_tile(const LeRelDev& R, const LeParams& p,
     stamp(tr, 2);
     if (tid < nr) {
         const int c = r0 + tid;
+        const bool own = slab == 0;                        // one tile per row owns the [O1] vectors
+        float o_cum = 0.f, o_bnw = 0.f, o_bnb = 0.f, o_b1 = 0.f;
+        if (own) {
+            o_cum = R.s_cum[c];
+            if (R.bnw) o_bnw = R.bnw[c];
+            if (R.bnb) o_bnb = R.bnb[c];
+            if (R.b1) o_b1 = R.b1[c];
+        }
         float s, inv, mn1, mx1, mn2, mx2;
         channel_scale(R, p, cur, c, s, inv, mn1, mx1, mn2, mx2);
         sh_s[tid] = s;
         if (emit) sh_g[tid] = c / R.pc_go - g0;
-        if (slab == 0) {                                   // one tile per row owns the [O1] vectors
-            R.s_cum[c] = R.s_cum[c] * s;                  // relation.py:20-24
-            if (R.bnw) R.bnw[c] = R.bnw[c] * s;           // dfq.py:64-65
-            if (R.bnb) R.bnb[c] = R.bnb[c] * s;           // dfq.py:67-68
-            if (R.b1) R.b1[c] = R.b1[c] * s;              // dfq.py:70-71
+        if (own) {
+            R.s_cum[c] = o_cum * s;                       // relation.py:20-24
+            if (R.bnw) R.bnw[c] = o_bnw * s;              // dfq.py:64-65
+            if (R.bnb) R.bnb[c] = o_bnb * s;              // dfq.py:67-68
+            if (R.b1) R.b1[c] = o_b1 * s;                 // dfq.py:70-71
             if (!emit) {                                   // W1 is never column-scaled: forward its row stats
                 guint* f = (guint*)R.r1 + (int64_t)nxt * R.stat_stride + 2 * c;
                 f[0] = ~enc_ord(mn1 * s);
@@ -226,56 +267,89 @@ __device__ __forceinline__ double row_tile(const LeRelDev& R, const LeParams& p,
     stamp(tr, 4);
 
     double acc = 0.0;
-    const int ci = emit ? (pos / R.khkw1 - i0) : 0;
-    float cmn = INFINITY, cmx = -INFINITY;
+    int ci[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) ci[k] = emit ? ((pos + k) / R.khkw1 - i0) : 0;
+    float cmn[VEC], cmx[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) { cmn[k] = INFINITY; cmx[k] = -INFINITY; }
     int cur_g = -1;
 #pragma unroll
-    for (int u = 0; u < kRegs; ++u) {
+    for (int u = 0; u < NV; ++u) {
+        if (u >= n_max) continue;
         const int r = min(jl + u * JL, nr - 1);
         const bool ok = u < n_own;
-        const float nv = v[u] * sh_s[r];                  // dfq.py:62
-        if (ok) w[r * R.row_len] = nv;
-        if (mode == DIFF_DIRECT) acc += ok ? (double)fabsf(nv - v[u]) : 0.0;
-        else if (mode == DIFF_SAVE) { if (ok) pv[r * R.row_len] = v[u]; }
-        else acc += ok ? (double)fabsf(nv - q[u]) : 0.0;
+        const float s = sh_s[r];
+        float nv[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) nv[k] = v[u][k] * s;                 // dfq.py:62
+        if (ok) vstore<VEC>(w + r * R.row_len, nv);
+        if (mode == DIFF_SAVE) {
+            if (ok) vstore<VEC>(pv + r * R.row_len, v[u]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                const float ref = (mode == DIFF_DIRECT) ? v[u][k] : q[u][k];
+                acc += ok ? (double)fabsf(nv[k] - ref) : 0.0;
+            }
+        }
         if (emit && ok) {
             const int g = sh_g[r];
             if (g != cur_g) {
                 if (cur_g >= 0) {
-                    atomicMax(&sh_slot[2 * (cur_g * nci + ci) + 0], ~enc_ord(cmn));
-                    atomicMax(&sh_slot[2 * (cur_g * nci + ci) + 1], enc_ord(cmx));
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) {
+                        atomicMax(&sh_slot[2 * (cur_g * nci + ci[k]) + 0], ~enc_ord(cmn[k]));
+                        atomicMax(&sh_slot[2 * (cur_g * nci + ci[k]) + 1], enc_ord(cmx[k]));
+                        cmn[k] = INFINITY; cmx[k] = -INFINITY;
+                    }
                 }
-                cur_g = g; cmn = INFINITY; cmx = -INFINITY;
+                cur_g = g;
             }
-            cmn = fminf(cmn, nv);
-            cmx = fmaxf(cmx, nv);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) { cmn[k] = fminf(cmn[k], nv[k]); cmx[k] = fmaxf(cmx[k], nv[k]); }
         }
     }
-    // rows beyond kRegs per thread: never produced by the plan's tile sizes, kept for safety
-    for (int u = kRegs; u < n_own; ++u) {
+    // rows beyond NV per thread: never produced by the plan's tile sizes, kept for safety
+    for (int u = NV; u < n_own; ++u) {
         const int r = jl + u * JL;
-        const float x = w[r * R.row_len];
-        const float nv = x * sh_s[r];
-        w[r * R.row_len] = nv;
-        if (mode == DIFF_DIRECT) acc += (double)fabsf(nv - x);
-        else if (mode == DIFF_SAVE) pv[r * R.row_len] = x;
-        else acc += (double)fabsf(nv - pv[r * R.row_len]);
+        float x[VEC], nv[VEC];
+        vload<VEC>(w + r * R.row_len, x);
+        const float s = sh_s[r];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) nv[k] = x[k] * s;
+        vstore<VEC>(w + r * R.row_len, nv);
+        if (mode == DIFF_SAVE) {
+            vstore<VEC>(pv + r * R.row_len, x);
+        } else {
+            float ref[VEC];
+            if (mode == DIFF_FROM_PREV) vload<VEC>(pv + r * R.row_len, ref);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) acc += (double)fabsf(nv[k] - ((mode == DIFF_DIRECT) ? x[k] : ref[k]));
+        }
         if (emit) {
             const int g = sh_g[r];
             if (g != cur_g) {
                 if (cur_g >= 0) {
-                    atomicMax(&sh_slot[2 * (cur_g * nci + ci) + 0], ~enc_ord(cmn));
-                    atomicMax(&sh_slot[2 * (cur_g * nci + ci) + 1], enc_ord(cmx));
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) {
+                        atomicMax(&sh_slot[2 * (cur_g * nci + ci[k]) + 0], ~enc_ord(cmn[k]));
+                        atomicMax(&sh_slot[2 * (cur_g * nci + ci[k]) + 1], enc_ord(cmx[k]));
+                        cmn[k] = INFINITY; cmx[k] = -INFINITY;
+                    }
                 }
-                cur_g = g; cmn = INFINITY; cmx = -INFINITY;
+                cur_g = g;
             }
-            cmn = fminf(cmn, nv);
-            cmx = fmaxf(cmx, nv);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) { cmn[k] = fminf(cmn[k], nv[k]); cmx[k] = fmaxf(cmx[k], nv[k]); }
         }
     }
     if (emit && cur_g >= 0) {
-        atomicMax(&sh_slot[2 * (cur_g * nci + ci) + 0], ~enc_ord(cmn));
-        atomicMax(&sh_slot[2 * (cur_g * nci + ci) + 1], enc_ord(cmx));
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            atomicMax(&sh_slot[2 * (cur_g * nci + ci[k]) + 0], ~enc_ord(cmn[k]));
+            atomicMax(&sh_slot[2 * (cur_g * nci + ci[k]) + 1], enc_ord(cmx[k]));
+        }
     }
     stamp(tr, 5);
     if (emit) {
@@ -294,14 +368,13 @@ __device__ __forceinline__ double row_tile(const LeRelDev& R, const LeParams& p,
     return acc;
 }
 
-// ---------------------------------------------------------------------------------------------
 // col tile: full rows W2[r0:r0+nr, :] *= 1/s[input channel]   (+ row stats of the new values)
-//
-// `G` consecutive lanes stride along one row; a thread owns (row iteration `it`, position slot
-// `u`) pairs, flattened to j = it*ppt + u < kRegs for the register preload.
-// ---------------------------------------------------------------------------------------------
+// `G` consecutive lanes stride along one row in VEC-wide steps; a thread owns (row iteration `it`,
+// slot `u`) pairs, flattened to j = it*ppt + u < NV for the register preload.
+template <int VEC>
 __device__ __forceinline__ double col_tile(const LeRelDev& R, const LeParams& p, int tile, int cur,
                                            float* sh_inv, uint32_t* sh_row, const LeTrace& tr) {
+    constexpr int NV = kRegs / VEC;
     const int tid = threadIdx.x;
     const int r0 = tile * R.ct_rows;
     const int nr = min(R.ct_rows, R.o2 - r0);
@@ -313,24 +386,27 @@ __device__ __forceinline__ double col_tile(const LeRelDev& R, const LeParams& p,
     const int g_lo = r0 / R.go;
     const int g_n = (r0 + nr - 1) / R.go - g_lo + 1;
     const int row_len2 = R.i2g * R.khkw;
+    const int row_v = row_len2 / VEC;                      // vectors per row (row_len2 % VEC == 0 by plan)
     const bool emit = R.out_rows != nullptr;
     const int n_iter = (nr + n_groups - 1) / n_groups;     // row iterations, uniform over the block
     const bool single = R.ct_chunk >= R.i2g;               // the whole row in one pass (always, unless I2/g > kChunkCh)
-    const int ppt = (row_len2 + G - 1) / G;                // positions per thread per row
-    const bool preload = single && n_iter * ppt <= kRegs;
+    const int ppt = (row_v + G - 1) / G;                   // vectors per thread per row
+    const bool preload = single && n_iter * ppt <= NV;
     const int mode = R.diff2;
     gfloat* const w = (gfloat*)R.w2 + (int64_t)r0 * row_len2;
     gfloat* const pv = (gfloat*)R.prev2 + (int64_t)r0 * row_len2;
 
-    float v[kRegs], q[kRegs];
+    const int n_used = n_iter * ppt;                       // register slots in use (uniform over the block)
+    float v[NV][VEC], q[NV][VEC];
     if (preload) {
         int it = 0, u = 0;
 #pragma unroll
-        for (int j = 0; j < kRegs; ++j) {
+        for (int j = 0; j < NV; ++j) {
+            if (j >= n_used) continue;
             const int r = min(grp + it * n_groups, nr - 1);
-            const int ps = min(ln + u * G, row_len2 - 1);
-            v[j] = w[r * row_len2 + ps];
-            if (mode == DIFF_FROM_PREV) q[j] = pv[r * row_len2 + ps];
+            const int ps = min(ln + u * G, row_v - 1) * VEC;
+            vload<VEC>(w + r * row_len2 + ps, v[j]);
+            if (mode == DIFF_FROM_PREV) vload<VEC>(pv + r * row_len2 + ps, q[j]);
             if (++u == ppt) { u = 0; ++it; }
         }
     }
@@ -360,31 +436,41 @@ __device__ __forceinline__ double col_tile(const LeRelDev& R, const LeParams& p,
         stamp(tr, 3);
         __syncthreads();
         stamp(tr, 4);
-        const int npos = nch * R.khkw;
-        const int dch = G / R.khkw;
-        const int drem = G - dch * R.khkw;
-        const int ch_first = ln / R.khkw;
-        const int rem_first = ln - ch_first * R.khkw;
+        const int npos = nch * R.khkw;                     // floats of this chunk per row
+        const int npos_v = npos / VEC;
         if (preload) {
-            // j = it*ppt + u: (it, u) advance together with j; channel counters restart with every row
-            int it = 0, u = 0, ch = ch_first, rem = rem_first;
+            // j = it*ppt + u: (it, u) advance together with j
+            int it = 0, u = 0;
             float rmn = INFINITY, rmx = -INFINITY;
             int tab_off = ((r0 + min(grp, nr - 1)) / R.go - g_lo) * nch;      // 1/s table row of this thread's row
 #pragma unroll
-            for (int j = 0; j < kRegs; ++j) {
+            for (int j = 0; j < NV; ++j) {
+                if (j >= n_used) continue;
                 const int r_raw = grp + it * n_groups;
                 const int r = min(r_raw, nr - 1);
-                const int ps_raw = ln + u * G;
-                const bool ok = it < n_iter && r_raw < nr && ps_raw < npos;
-                const int ps = min(ps_raw, row_len2 - 1);
-                const float nv = v[j] * sh_inv[tab_off + min(ch, nch - 1)];      // dfq.py:73
-                if (ok) w[r * row_len2 + ps] = nv;
-                if (mode == DIFF_DIRECT) acc += ok ? (double)fabsf(nv - v[j]) : 0.0;
-                else if (mode == DIFF_SAVE) { if (ok) pv[r * row_len2 + ps] = v[j]; }
-                else acc += ok ? (double)fabsf(nv - q[j]) : 0.0;
-                if (ok) { rmn = fminf(rmn, nv); rmx = fmaxf(rmx, nv); }
-                ch += dch; rem += drem;
-                if (rem >= R.khkw) { rem -= R.khkw; ++ch; }
+                const int pv_raw = ln + u * G;
+                const bool ok = it < n_iter && r_raw < nr && pv_raw < npos_v;
+                const int ps = min(pv_raw, row_v - 1) * VEC;
+                float nv[VEC];
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) {
+                    const int ch = (R.khkw == 1) ? (ps + k) : (ps + k) / R.khkw;
+                    nv[k] = v[j][k] * sh_inv[tab_off + ch];                    // dfq.py:73
+                }
+                if (ok) vstore<VEC>(w + r * row_len2 + ps, nv);
+                if (mode == DIFF_SAVE) {
+                    if (ok) vstore<VEC>(pv + r * row_len2 + ps, v[j]);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) {
+                        const float ref = (mode == DIFF_DIRECT) ? v[j][k] : q[j][k];
+                        acc += ok ? (double)fabsf(nv[k] - ref) : 0.0;
+                    }
+                }
+                if (ok) {
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) { rmn = fminf(rmn, nv[k]); rmx = fmaxf(rmx, nv[k]); }
+                }
                 if (++u == ppt) {                                   // row finished (uniform over the block)
                     if (emit && it < n_iter) {
                         for (int m = G >> 1; m >= 1; m >>= 1) {
@@ -396,7 +482,7 @@ __device__ __forceinline__ double col_tile(const LeRelDev& R, const LeParams& p,
                             sh_row[2 * r + 1] = enc_ord(rmx);
                         }
                     }
-                    u = 0; ++it; ch = ch_first; rem = rem_first; rmn = INFINITY; rmx = -INFINITY;
+                    u = 0; ++it; rmn = INFINITY; rmx = -INFINITY;
                     if (it < n_iter) tab_off = ((r0 + min(grp + it * n_groups, nr - 1)) / R.go - g_lo) * nch;
                 }
             }
@@ -408,31 +494,23 @@ __device__ __forceinline__ double col_tile(const LeRelDev& R, const LeParams& p,
                 const float* tab = sh_inv + ((r0 + rr) / R.go - g_lo) * nch;
                 const int64_t base = (int64_t)rr * row_len2 + (int64_t)ii0 * R.khkw;
                 float rmn = INFINITY, rmx = -INFINITY;
-                int ch = ch_first, rem = rem_first;
-                for (int pb = ln; act && pb < npos; pb += 4 * G) {
-                    float x[4];
-                    int chs[4];
+                for (int pb = ln; act && pb < npos_v; pb += G) {
+                    const int ps = pb * VEC;
+                    float x[VEC], nv[VEC];
+                    vload<VEC>(w + base + ps, x);
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int ps = pb + u * G;
-                        x[u] = w[base + min(ps, npos - 1)];
-                        chs[u] = min(ch, nch - 1);
-                        ch += dch; rem += drem;
-                        if (rem >= R.khkw) { rem -= R.khkw; ++ch; }
+                    for (int k = 0; k < VEC; ++k) nv[k] = x[k] * tab[(ps + k) / R.khkw];      // dfq.py:73
+                    vstore<VEC>(w + base + ps, nv);
+                    if (mode == DIFF_SAVE) {
+                        vstore<VEC>(pv + base + ps, x);
+                    } else {
+                        float ref[VEC];
+                        if (mode == DIFF_FROM_PREV) vload<VEC>(pv + base + ps, ref);
+#pragma unroll
+                        for (int k = 0; k < VEC; ++k) acc += (double)fabsf(nv[k] - ((mode == DIFF_DIRECT) ? x[k] : ref[k]));
                     }
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int ps = pb + u * G;
-                        if (ps < npos) {
-                            const float nv = x[u] * tab[chs[u]];      // dfq.py:73
-                            w[base + ps] = nv;
-                            if (mode == DIFF_DIRECT) acc += (double)fabsf(nv - x[u]);
-                            else if (mode == DIFF_SAVE) pv[base + ps] = x[u];
-                            else acc += (double)fabsf(nv - pv[base + ps]);
-                            rmn = fminf(rmn, nv);
-                            rmx = fmaxf(rmx, nv);
-                        }
-                    }
+                    for (int k = 0; k < VEC; ++k) { rmn = fminf(rmn, nv[k]); rmx = fmaxf(rmx, nv[k]); }
                 }
                 if (emit) {
                     for (int m = G >> 1; m >= 1; m >>= 1) {
@@ -468,26 +546,43 @@ __global__ __launch_bounds__(kBlock) void le_level_kernel(const LeRelDev* __rest
                                                           LeParams p, const LeState* __restrict__ state,
                                                           double* __restrict__ partials, LeTrace tr) {
     stamp(tr, 0);
-    // the descriptor fetch does not depend on the loop state: issue both, wait once
-    int r = 0;
-#pragma unroll
-    for (int i = 1; i < kLevelRelsMax; ++i)
-        if (i < tab.n && (int)blockIdx.x >= tab.begin[i]) r = i;
-    const LeRelDev R = rels[r];
-    const int done = state->done;
-    const int cur = state->sweeps & 1;
-    if (done) return;          // wave-uniform: the reference loop has already exited
-    stamp(tr, 1);
-
     __shared__ float sh_f[kInvMax];                 // row tile: scales; col tile: 1/s table
     __shared__ uint32_t sh_u[2 * kSlotMax];         // row tile: column-stat slots; col tile: row stats
     __shared__ int sh_g[kRowTileRowsMax];           // row tile: group (of the stat consumer) of each row
     __shared__ double sh_red[kBlock / kWave];
+    __shared__ uint32_t sh_desc[(sizeof(LeRelDev) + 3) / 4 + 2];
+
+    int r = 0;
+#pragma unroll
+    for (int i = 1; i < kLevelRelsMax; ++i)
+        if (i < tab.n && (int)blockIdx.x >= tab.begin[i]) r = i;
+    // One vector load brings the whole descriptor (scalar loads of a cold line would be issued
+    // piecemeal at their first use: one memory round trip per field group); the loop state rides
+    // in the same round trip.
+    constexpr int kDescWords = (int)(sizeof(LeRelDev) / 4);
+    if (threadIdx.x < kDescWords) sh_desc[threadIdx.x] = ((const guint*)(rels + r))[threadIdx.x];
+    if (threadIdx.x == kDescWords) sh_desc[kDescWords] = (uint32_t)((const DFQ_GLOBAL_AS int*)&state->done)[0];
+    if (threadIdx.x == kDescWords + 1) sh_desc[kDescWords + 1] = (uint32_t)((const DFQ_GLOBAL_AS int*)&state->sweeps)[0];
+    __syncthreads();
+    if (sh_desc[kDescWords]) return;   // uniform: the reference loop has already exited
+    const int cur = (int)(sh_desc[kDescWords + 1] & 1u);
+    LeRelDev R;
+    {
+        uint32_t* dst = reinterpret_cast<uint32_t*>(&R);
+#pragma unroll
+        for (int i = 0; i < kDescWords; ++i) dst[i] = sh_desc[i];
+    }
+    stamp(tr, 1);
 
     const int tile = blockIdx.x - R.tile_begin;
     double acc;
-    if (tile < R.n_row_tiles) acc = row_tile(R, p, tile, cur, sh_f, sh_u, sh_g, tr);
-    else acc = col_tile(R, p, tile - R.n_row_tiles, cur, sh_f, sh_u, tr);
+    if (tile < R.n_row_tiles) {
+        acc = R.rt_vec == 4 ? row_tile<4>(R, p, tile, cur, sh_f, sh_u, sh_g, tr)
+                            : row_tile<1>(R, p, tile, cur, sh_f, sh_u, sh_g, tr);
+    } else {
+        acc = R.ct_vec == 4 ? col_tile<4>(R, p, tile - R.n_row_tiles, cur, sh_f, sh_u, tr)
+                            : col_tile<1>(R, p, tile - R.n_row_tiles, cur, sh_f, sh_u, tr);
+    }
     stamp(tr, 6);
     const double t = block_sum(acc, sh_red);
     if (threadIdx.x == 0) partials[R.partial_base + tile] = t;
@@ -565,21 +660,24 @@ __global__ __launch_bounds__(kCtlBlock) void le_control_kernel(const LeLayerDiff
                                                                uint32_t* __restrict__ r2_arena, int64_t r2_words,
                                                                LeState* __restrict__ state, double converge_thres,
                                                                int converge_count, int max_sweeps) {
-    if (state->done) return;
     __shared__ double sh_part[kCtlStage];
     __shared__ double sh_mean[1024];
+    __shared__ LeLayerDiff sh_layer[1024];
     const int tid = threadIdx.x;
     const int lane = tid % kWave;
     const int wave = tid / kWave;
-    const int cur = state->sweeps & 1;
+    // every global read of the kernel is issued before the first wait: partials, layer table, state
     const int n_stage = min(n_partials, kCtlStage);
     for (int i = tid; i < n_stage; i += kCtlBlock) sh_part[i] = partials[i];
+    for (int i = tid; i < min(n_layers, 1024); i += kCtlBlock) sh_layer[i] = layers[i];
+    if (state->done) return;
+    const int cur = state->sweeps & 1;
     // parity `cur` was consumed by this sweep; the next sweep produces (atomicMax) into it
     uint32_t* z = r2_arena + (int64_t)cur * r2_words;
     for (int64_t i = tid; i < r2_words; i += kCtlBlock) z[i] = 0u;
     __syncthreads();
     for (int l = wave; l < n_layers; l += kCtlBlock / kWave) {
-        const LeLayerDiff L = layers[l];
+        const LeLayerDiff L = (l < 1024) ? sh_layer[l] : layers[l];
         double s = 0.0;
         if (L.partial_begin >= 0) {
             for (int i = lane; i < L.n_partials; i += kWave) {
@@ -777,30 +875,40 @@ int dfq_le_plan_create(const dfq_layer* layers, int32_t n_layers, const dfq_rela
         d.prev1 = a_twice ? arena[rr.first] : nullptr;
         d.prev2 = b_twice ? arena[rr.second] : nullptr;
         // row tiles
-        d.rt_slabs = (d.row_len + kRowTileColsMax - 1) / kRowTileColsMax;
-        d.rt_cols = (d.row_len + d.rt_slabs - 1) / d.rt_slabs;
-        d.rt_slabs = (d.row_len + d.rt_cols - 1) / d.rt_cols;
-        int rows = std::max(1, target / d.rt_cols);
-        rows = std::min(rows, kRegs * (kBlock / d.rt_cols));         // <= kRegs rows per thread
-        rows = std::min(rows, std::min(kRowTileRowsMax, d.o1));
-        d.rt_rows = rows;
+        d.rt_vec = (d.row_len % 4 == 0 && ((uintptr_t)A.weight & 15u) == 0) ? 4 : 1;
+        {
+            const int cols_max = kRowTileColsMax * (d.rt_vec == 4 ? 2 : 1);
+            d.rt_slabs = (d.row_len + cols_max - 1) / cols_max;
+            int cols = (d.row_len + d.rt_slabs - 1) / d.rt_slabs;
+            cols = (cols + d.rt_vec - 1) / d.rt_vec * d.rt_vec;
+            d.rt_cols = cols;
+            d.rt_slabs = (d.row_len + d.rt_cols - 1) / d.rt_cols;
+            const int npv = d.rt_cols / d.rt_vec;                      // vector positions per row of a tile
+            int rows = std::max(1, target / d.rt_cols);
+            rows = std::min(rows, (kRegs / d.rt_vec) * (kBlock / npv));  // register preload capacity
+            rows = std::min(rows, std::min(kRowTileRowsMax, d.o1));
+            d.rt_rows = rows;
+        }
         // col tiles
         const int row_len2 = d.i2g * d.khkw;
-        int lanes = 1;
-        while (lanes < kWave && row_len2 > 8 * lanes) lanes *= 2;
-        d.ct_lanes = lanes;
+        d.ct_vec = (row_len2 % 4 == 0 && ((uintptr_t)B.weight & 15u) == 0) ? 4 : 1;
         d.ct_chunk = std::min(d.i2g, kChunkCh);
-        int crow = std::max(1, target / row_len2);
-        {   // <= kRegs elements per thread so the whole tile is preloaded into registers
-            const int ppt = (row_len2 + lanes - 1) / lanes;
-            crow = std::min(crow, (kBlock / lanes) * std::max(1, kRegs / ppt));
+        {
+            const int nv = kRegs / d.ct_vec;
+            const int row_v = row_len2 / d.ct_vec;
+            int lanes = 1;
+            while (lanes < kWave && lanes * nv < row_v) lanes *= 2;      // whole row in the registers of `lanes` threads
+            d.ct_lanes = lanes;
+            const int ppt = (row_v + lanes - 1) / lanes;
+            int crow = std::max(1, target / row_len2);
+            crow = std::min(crow, (kBlock / lanes) * std::max(1, nv / ppt));
+            crow = std::min(crow, std::min(kColRowsMax, d.o2));
+            // a tile of `crow` rows spans at most crow/go + 2 groups; the 1/s table holds (#groups) * chunk entries
+            const int64_t max_groups = kInvMax / d.ct_chunk;     // >= 4 because ct_chunk <= kChunkCh
+            crow = (int)std::min<int64_t>(crow, (max_groups - 2) * d.go);
+            if (crow < 1) crow = 1;
+            d.ct_rows = crow;
         }
-        crow = std::min(crow, std::min(kColRowsMax, d.o2));
-        // a tile of `crow` rows spans at most crow/go + 2 groups; the 1/s table holds (#groups) * chunk entries
-        const int64_t max_groups = kInvMax / d.ct_chunk;     // >= 4 because ct_chunk <= kChunkCh
-        crow = (int)std::min<int64_t>(crow, (max_groups - 2) * d.go);
-        if (crow < 1) crow = 1;
-        d.ct_rows = crow;
         d.n_col_tiles = (d.o2 + d.ct_rows - 1) / d.ct_rows;
         d.boot_tiles = (d.o1 + kBootTc - 1) / kBootTc;
     }
