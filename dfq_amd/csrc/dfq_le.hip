@@ -17,23 +17,27 @@
 //   * a layer that is only ever scaled one way (chain start / chain end) has its stats forwarded
 //     arithmetically: min' = fl(min * s), max' = fl(max * s) -- exact by monotonicity.
 // A sweep level is therefore ONE streaming launch: every element is read once and written once
-// (8 B per paired element), tiles are independent (any number of workgroups, unit-stride lanes),
-// and the scale of a channel is re-derived from four stat words by every tile that needs it
-// (identical IEEE operations -> identical value everywhere).  Results are bit-identical to the
-// two-pass formulation because min/max are exact.
+// (8 B per paired element), tiles are small independent 2-D blocks (any number of workgroups,
+// unit-stride 16-byte lanes), and the scale of a channel is re-derived from four stat words by
+// every tile that needs it (identical IEEE operations -> identical value everywhere).  Results
+// are bit-identical to the two-pass formulation because min/max are exact.
 //
 //   level     = relations that share no layer (Gauss-Seidel order of dfq.py:85 kept between
 //               levels) = one launch of le_level_kernel;
-//   row tile  = [rt_rows x rt_cols] block of W1: lanes along the contiguous row positions, each
-//               thread walks down the rows (column stats accumulate in registers);
-//   col tile  = ct_rows full rows of W2: `lanes` consecutive threads stride along one row (row
-//               stats by butterfly), the 1/s table of the row's input channels sits in LDS.
+//   row tile  = [rt_rows x rt_cols] block of W1, scaled per row, emits per-input-channel stats;
+//   col tile  = [ct_rows x ct_cols] block of W2, scaled per input channel, emits per-row stats.
+//   In both, lanes run along the contiguous row positions and every thread walks down the rows
+//   with all of its (<= kRegs) elements loaded into registers before the scale solve.
+//
+// Partial stats of a tile are merged with order-preserving atomicMax words (identity 0); the
+// buffers alternate between two parities and the control kernel clears the one that is about to
+// be accumulated into.
 //
 // Convergence (dfq.py:105-115): per-tile float64 partials of sum|W - W_prev| (a layer touched
 // twice per sweep saves its pre-sweep value to a snapshot arena at the first touch), reduced in a
 // fixed order by a one-workgroup control kernel that also advances the reference's (diff, count)
-// state machine on the device.  Level kernels start with a uniform load of `done`, so the host
-// enqueues sweeps ahead without synchronising.
+// state machine on the device.  Level kernels start by reading `done`, so the host enqueues sweeps
+// ahead without synchronising.
 #include <algorithm>
 #include <cstdlib>
 #include <vector>
@@ -42,20 +46,20 @@
 
 namespace dfq {
 
-constexpr int kRowTileRowsMax = 256;   // rows of a row tile (one solve per thread)
+constexpr int kRegs = 32;              // floats a thread can hold for the register preload
+constexpr int kTileRowsMax = 256;      // rows of a tile (one LDS entry per row)
 constexpr int kRowTileColsMax = 128;   // positions of a row tile (x2 for float4 tiles)
-constexpr int kSlotMax = 1024;         // column-stat slots of a row tile in LDS
-constexpr int kInvMax = 8192;          // 1/s table of a col tile in LDS (floats)
-constexpr int kChunkCh = 2048;         // input channels of W2 handled per pass of a col tile
-constexpr int kColRowsMax = 1024;      // rows of a col tile
+constexpr int kColTileLanes = 64;      // vector positions of a col tile (one wave per row at most)
+constexpr int kSlotMax = 1024;         // LDS table entries of a tile (stat slots / 1/s table)
 constexpr int kBootTc = 64;            // channels per bootstrap tile
-constexpr int kRegs = 32;              // floats a thread can preload into registers
 constexpr int kLevelRelsMax = 32;      // relations per launch (longer levels are split)
 constexpr int kCtlBlock = 1024;        // threads of the control kernel
 constexpr int kCtlStage = 6144;        // partials staged in LDS by the control kernel
 
 enum DiffMode : int32_t { DIFF_DIRECT = 0, DIFF_SAVE = 1, DIFF_FROM_PREV = 2 };
 
+// One relation.  At most 62 32-bit words: the descriptor plus two words of loop state are fetched
+// with ONE wave-wide load (lane i loads word i) and broadcast with v_readlane.
 struct LeRelDev {
     float* w1;
     float* w2;
@@ -67,22 +71,22 @@ struct LeRelDev {
     float* prev2;
     uint32_t* r1;        // parity 0 of the row stats of W1: [o1][2] = (min slot, max slot); parity 1 is
     uint32_t* r2;        // `stat_stride` words further.  r2: column stats of W2 per paired channel
-    uint32_t* out_cols;  // R2 of the relation whose SECOND layer is our W1 (atomics), or null: forward r1
-    uint32_t* out_rows;  // R1 of the relation whose FIRST layer is our W2 (plain stores), or null: forward r2
+    uint32_t* out_cols;  // R2 of the relation whose SECOND layer is our W1, or null: forward r1
+    uint32_t* out_rows;  // R1 of the relation whose FIRST layer is our W2, or null: forward r2
+    int64_t stat_stride; // words between the two parities of a stat arena
     int32_t o1, row_len, khkw1;
-    int32_t pc_go, pc_gi, pc_n;          // W1 element (o, i) -> channel (o / pc_go) * pc_gi + i of out_cols
+    int32_t pc_go, pc_gi;                // W1 element (o, i) -> channel (o / pc_go) * pc_gi + i of out_cols
     int32_t o2, gi, go, i2g, khkw;       // W2 geometry; paired channel c = g*gi + ii
-    int32_t rt_rows, rt_cols, rt_slabs, n_row_tiles;
-    int32_t ct_rows, ct_lanes, ct_chunk, n_col_tiles;
-    int32_t boot_tiles;
+    int32_t rt_rows, rt_cols, rt_slabs, rt_vec, n_row_tiles;
+    int32_t ct_rows, ct_cols, ct_slabs, ct_vec, n_col_tiles;
     int32_t diff1, diff2;
     int32_t partial_base;   // first partial slot of this relation (row tiles, then col tiles)
     int32_t tile_begin;     // first workgroup of this relation inside its level launch
     int32_t boot_begin;     // first workgroup inside the bootstrap launch
-    int32_t rt_vec, ct_vec; // 4: tiles move float4 (row length % 4 == 0), else 1
-    int32_t pad;
-    int64_t stat_stride;    // words between the two parities of a stat arena
+    int32_t boot_tiles;
 };
+constexpr int kDescWords = (int)(sizeof(LeRelDev) / 4);
+static_assert(sizeof(LeRelDev) % 4 == 0 && kDescWords + 2 <= kWave, "descriptor must fit one wave-wide load");
 
 struct LeParams {
     float s_lo, s_hi, inv_lo, inv_hi, eps;
@@ -103,6 +107,23 @@ struct LeLayerDiff {
     int32_t n_partials;
     double n_elems;
 };
+
+// first workgroup of each relation of a level, passed BY VALUE (kernarg -> scalar registers) so the
+// workgroup -> relation lookup costs no dependent global loads
+struct LevelTable {
+    int32_t n;
+    int32_t begin[kLevelRelsMax];
+};
+
+// optional per-phase cycle stamps of one workgroup (dfq_le_trace, tuning aid; null in production)
+struct LeTrace {
+    long long* out;     // device [16] or null
+    int32_t block;
+    int32_t pad;
+};
+__device__ __forceinline__ void stamp(const LeTrace& tr, int slot) {
+    if (tr.out && (int)blockIdx.x == tr.block && threadIdx.x == 0) tr.out[slot] = clock64();
+}
 
 // dfq.py:58-59 with Python's max/min semantics on a 0-dim float32 tensor (see oracle.le_solve).
 __device__ __forceinline__ void le_solve(float r1, float r2, const LeParams& p, float& s_out, float& inv_out) {
@@ -129,39 +150,12 @@ __device__ __forceinline__ void channel_scale(const LeRelDev& R, const LeParams&
                                               float& inv, float& mn1, float& mx1, float& mn2, float& mx2) {
     const guint* a = (const guint*)R.r1 + (int64_t)cur * R.stat_stride + 2 * c;
     const guint* b = (const guint*)R.r2 + (int64_t)cur * R.stat_stride + 2 * c;
-    mn1 = slot_min(a[0]); mx1 = slot_max(a[1]);
-    mn2 = slot_min(b[0]); mx2 = slot_max(b[1]);
+    const uint32_t a0 = a[0], a1 = a[1], b0 = b[0], b1 = b[1];
+    mn1 = slot_min(a0); mx1 = slot_max(a1);
+    mn2 = slot_min(b0); mx2 = slot_max(b1);
     le_solve(range_of(mn1, mx1, p.signed_range), range_of(mn2, mx2, p.signed_range), p, s, inv);
 }
 
-// optional per-phase cycle stamps of one workgroup (dfq_le_trace, tuning aid; null in production)
-struct LeTrace {
-    long long* out;     // device [16] or null
-    int32_t block;
-    int32_t pad;
-};
-__device__ __forceinline__ void stamp(const LeTrace& tr, int slot) {
-    if (tr.out && (int)blockIdx.x == tr.block && threadIdx.x == 0) tr.out[slot] = clock64();
-}
-
-__device__ __forceinline__ void diff_touch(int mode, float nv, float v, float* prev, int64_t idx, double& acc) {
-    if (mode == DIFF_DIRECT) acc += (double)fabsf(nv - v);
-    else if (mode == DIFF_SAVE) prev[idx] = v;
-    else acc += (double)fabsf(nv - prev[idx]);
-}
-
-// ---------------------------------------------------------------------------------------------
-// Tiles.  Both tile kinds are written once for VEC = 1 (any geometry) and VEC = 4 (rows that are a
-// multiple of 4 floats: every 1x1 / linear / dense conv layer of the benchmark networks): a thread
-// then moves 16-byte vectors, which quarters the number of vector-memory instructions -- the store
-// path of a CU retires roughly one wave-wide store instruction per ~36 cycles regardless of width,
-// so dword stores, not bytes, were the limiter of the scalar version.
-//
-// A thread owns at most kRegs floats (the plan sizes tiles accordingly): all of them are loaded
-// into registers BEFORE the scale solve, so the data fetch and the stat fetch + solve overlap and
-// the tile's critical path is one memory round trip.  Loads are unconditional (indices clamped
-// into the tile), only stores are predicated.
-// ---------------------------------------------------------------------------------------------
 template <int VEC>
 __device__ __forceinline__ void vload(const gfloat* p, float (&x)[VEC]) {
     if (VEC == 4) {
@@ -182,6 +176,15 @@ __device__ __forceinline__ void vstore(gfloat* p, const float (&x)[VEC]) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Tiles.  Written once for VEC = 1 (any geometry) and VEC = 4 (rows that are a multiple of 4
+// floats: every 1x1 / linear / dense conv layer of the benchmark networks): a thread then moves
+// 16-byte vectors, which quarters the number of vector-memory instructions -- a CU retires roughly
+// one wave-wide store instruction per ~36 cycles regardless of its width, so dword stores, not
+// bytes, limit a scalar version.  Loads are unconditional (indices clamped into the tile), only
+// stores are predicated; unused register slots are skipped with block-uniform branches.
+// ---------------------------------------------------------------------------------------------
+
 // row tile: W1[r0:r0+nr, p0:p0+np] *= s[row]   (+ column stats of the new values)
 template <int VEC>
 __device__ __forceinline__ double row_tile(const LeRelDev& R, const LeParams& p, int tile, int cur,
@@ -201,10 +204,10 @@ __device__ __forceinline__ double row_tile(const LeRelDev& R, const LeParams& p,
     const int jl = lane_on ? jl_raw : 0;
     const int pos = p0 + (lane_on ? (tid - jl_raw * npv) * VEC : 0);
     const int n_own = lane_on ? (nr - jl + JL - 1) / JL : 0;     // rows this thread owns (<= NV by plan)
+    const int n_max = min(NV, (nr + JL - 1) / JL);               // register slots in use (block-uniform)
     gfloat* const w = (gfloat*)R.w1 + ((int64_t)r0 * R.row_len + pos);
     gfloat* const pv = (gfloat*)R.prev1 + ((int64_t)r0 * R.row_len + pos);
     const int mode = R.diff1;
-    const int n_max = min(NV, (nr + JL - 1) / JL);         // register slots in use (uniform over the block)
 
     // ---- issue every data load first -----------------------------------------------------------
     float v[NV][VEC], q[NV][VEC];
@@ -249,7 +252,7 @@ __device__ __forceinline__ double row_tile(const LeRelDev& R, const LeParams& p,
         float s, inv, mn1, mx1, mn2, mx2;
         channel_scale(R, p, cur, c, s, inv, mn1, mx1, mn2, mx2);
         sh_s[tid] = s;
-        if (emit) sh_g[tid] = c / R.pc_go - g0;
+        if (emit) sh_g[tid] = (c / R.pc_go - g0) * nci;
         if (own) {
             R.s_cum[c] = o_cum * s;                       // relation.py:20-24
             if (R.bnw) R.bnw[c] = o_bnw * s;              // dfq.py:64-65
@@ -294,47 +297,13 @@ __device__ __forceinline__ double row_tile(const LeRelDev& R, const LeParams& p,
             }
         }
         if (emit && ok) {
-            const int g = sh_g[r];
+            const int g = sh_g[r];                         // slot row of this row's group
             if (g != cur_g) {
                 if (cur_g >= 0) {
 #pragma unroll
                     for (int k = 0; k < VEC; ++k) {
-                        atomicMax(&sh_slot[2 * (cur_g * nci + ci[k]) + 0], ~enc_ord(cmn[k]));
-                        atomicMax(&sh_slot[2 * (cur_g * nci + ci[k]) + 1], enc_ord(cmx[k]));
-                        cmn[k] = INFINITY; cmx[k] = -INFINITY;
-                    }
-                }
-                cur_g = g;
-            }
-#pragma unroll
-            for (int k = 0; k < VEC; ++k) { cmn[k] = fminf(cmn[k], nv[k]); cmx[k] = fmaxf(cmx[k], nv[k]); }
-        }
-    }
-    // rows beyond NV per thread: never produced by the plan's tile sizes, kept for safety
-    for (int u = NV; u < n_own; ++u) {
-        const int r = jl + u * JL;
-        float x[VEC], nv[VEC];
-        vload<VEC>(w + r * R.row_len, x);
-        const float s = sh_s[r];
-#pragma unroll
-        for (int k = 0; k < VEC; ++k) nv[k] = x[k] * s;
-        vstore<VEC>(w + r * R.row_len, nv);
-        if (mode == DIFF_SAVE) {
-            vstore<VEC>(pv + r * R.row_len, x);
-        } else {
-            float ref[VEC];
-            if (mode == DIFF_FROM_PREV) vload<VEC>(pv + r * R.row_len, ref);
-#pragma unroll
-            for (int k = 0; k < VEC; ++k) acc += (double)fabsf(nv[k] - ((mode == DIFF_DIRECT) ? x[k] : ref[k]));
-        }
-        if (emit) {
-            const int g = sh_g[r];
-            if (g != cur_g) {
-                if (cur_g >= 0) {
-#pragma unroll
-                    for (int k = 0; k < VEC; ++k) {
-                        atomicMax(&sh_slot[2 * (cur_g * nci + ci[k]) + 0], ~enc_ord(cmn[k]));
-                        atomicMax(&sh_slot[2 * (cur_g * nci + ci[k]) + 1], enc_ord(cmx[k]));
+                        atomicMax(&sh_slot[2 * (cur_g + ci[k]) + 0], ~enc_ord(cmn[k]));
+                        atomicMax(&sh_slot[2 * (cur_g + ci[k]) + 1], enc_ord(cmx[k]));
                         cmn[k] = INFINITY; cmx[k] = -INFINITY;
                     }
                 }
@@ -347,8 +316,8 @@ __device__ __forceinline__ double row_tile(const LeRelDev& R, const LeParams& p,
     if (emit && cur_g >= 0) {
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
-            atomicMax(&sh_slot[2 * (cur_g * nci + ci[k]) + 0], ~enc_ord(cmn[k]));
-            atomicMax(&sh_slot[2 * (cur_g * nci + ci[k]) + 1], enc_ord(cmx[k]));
+            atomicMax(&sh_slot[2 * (cur_g + ci[k]) + 0], ~enc_ord(cmn[k]));
+            atomicMax(&sh_slot[2 * (cur_g + ci[k]) + 1], enc_ord(cmx[k]));
         }
     }
     stamp(tr, 5);
@@ -368,210 +337,159 @@ __device__ __forceinline__ double row_tile(const LeRelDev& R, const LeParams& p,
     return acc;
 }
 
-// col tile: full rows W2[r0:r0+nr, :] *= 1/s[input channel]   (+ row stats of the new values)
-// `G` consecutive lanes stride along one row in VEC-wide steps; a thread owns (row iteration `it`,
-// slot `u`) pairs, flattened to j = it*ppt + u < NV for the register preload.
+// col tile: W2[r0:r0+nr, p0:p0+np] *= 1/s[input channel]   (+ row stats of the new values)
+// G = pow2 >= np/VEC lanes share a row; 256/G rows are in flight per register slot.
 template <int VEC>
 __device__ __forceinline__ double col_tile(const LeRelDev& R, const LeParams& p, int tile, int cur,
-                                           float* sh_inv, uint32_t* sh_row, const LeTrace& tr) {
+                                           float* sh_inv, uint32_t* sh_row, int* sh_tab, const LeTrace& tr) {
     constexpr int NV = kRegs / VEC;
     const int tid = threadIdx.x;
-    const int r0 = tile * R.ct_rows;
+    const int slab = tile % R.ct_slabs;
+    const int r0 = (tile / R.ct_slabs) * R.ct_rows;
     const int nr = min(R.ct_rows, R.o2 - r0);
-    const int nxt = cur ^ 1;
-    const int G = R.ct_lanes;                  // power of two
-    const int n_groups = kBlock / G;
+    const int row_len2 = R.i2g * R.khkw;
+    const int p0 = slab * R.ct_cols;
+    const int np = min(R.ct_cols, row_len2 - p0);
+    const int npv = np / VEC;                              // <= kColTileLanes by plan
+    int G = 1;
+    while (G < npv) G <<= 1;
+    const int n_rowslots = kBlock / G;                     // rows in flight
     const int grp = tid / G;
     const int ln = tid - grp * G;
+    const bool lane_on = ln < npv;
+    const int pos = p0 + min(ln, npv - 1) * VEC;
+    const int n_max = min(NV, (nr + n_rowslots - 1) / n_rowslots);   // register slots in use (block-uniform)
+    const int nxt = cur ^ 1;
+    const int mode = R.diff2;
+    const bool emit = R.out_rows != nullptr;
+    gfloat* const w = (gfloat*)R.w2 + ((int64_t)r0 * row_len2 + pos);
+    gfloat* const pv = (gfloat*)R.prev2 + ((int64_t)r0 * row_len2 + pos);
+
+    // ---- issue every data load first -----------------------------------------------------------
+    float v[NV][VEC], q[NV][VEC];
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+        if (u < n_max) {
+            const int r = min(grp + u * n_rowslots, nr - 1);
+            vload<VEC>(w + r * row_len2, v[u]);
+        }
+    }
+    if (mode == DIFF_FROM_PREV) {
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            if (u < n_max) {
+                const int r = min(grp + u * n_rowslots, nr - 1);
+                vload<VEC>(pv + r * row_len2, q[u]);
+            }
+        }
+    }
+
+    // 1/s table of the tile: (groups spanned by the rows) x (input channels spanned by the columns)
+    const int i0 = p0 / R.khkw;
+    const int nci = (p0 + np - 1) / R.khkw - i0 + 1;
     const int g_lo = r0 / R.go;
     const int g_n = (r0 + nr - 1) / R.go - g_lo + 1;
-    const int row_len2 = R.i2g * R.khkw;
-    const int row_v = row_len2 / VEC;                      // vectors per row (row_len2 % VEC == 0 by plan)
-    const bool emit = R.out_rows != nullptr;
-    const int n_iter = (nr + n_groups - 1) / n_groups;     // row iterations, uniform over the block
-    const bool single = R.ct_chunk >= R.i2g;               // the whole row in one pass (always, unless I2/g > kChunkCh)
-    const int ppt = (row_v + G - 1) / G;                   // vectors per thread per row
-    const bool preload = single && n_iter * ppt <= NV;
-    const int mode = R.diff2;
-    gfloat* const w = (gfloat*)R.w2 + (int64_t)r0 * row_len2;
-    gfloat* const pv = (gfloat*)R.prev2 + (int64_t)r0 * row_len2;
-
-    const int n_used = n_iter * ppt;                       // register slots in use (uniform over the block)
-    float v[NV][VEC], q[NV][VEC];
-    if (preload) {
-        int it = 0, u = 0;
-#pragma unroll
-        for (int j = 0; j < NV; ++j) {
-            if (j >= n_used) continue;
-            const int r = min(grp + it * n_groups, nr - 1);
-            const int ps = min(ln + u * G, row_v - 1) * VEC;
-            vload<VEC>(w + r * row_len2 + ps, v[j]);
-            if (mode == DIFF_FROM_PREV) vload<VEC>(pv + r * row_len2 + ps, q[j]);
-            if (++u == ppt) { u = 0; ++it; }
-        }
-    }
-    if (emit) {
-        for (int i = tid; i < 2 * nr; i += kBlock) sh_row[i] = 0u;
-    }
     stamp(tr, 2);
+    for (int idx = tid; idx < g_n * nci; idx += kBlock) {      // one entry per thread for every plan-made tile
+        const int gq = idx / nci;
+        const int g = g_lo + gq;
+        const int c = g * R.gi + i0 + (idx - gq * nci);
+        float s, inv, mn1, mx1, mn2, mx2;
+        channel_scale(R, p, cur, c, s, inv, mn1, mx1, mn2, mx2);
+        sh_inv[idx] = inv;
+        // W2 is never row-scaled: forward its column stats (the tile holding the group's first row does it)
+        if (!emit && g * R.go >= r0 && g * R.go < r0 + nr) {
+            guint* f = (guint*)R.r2 + (int64_t)nxt * R.stat_stride + 2 * c;
+            f[0] = ~enc_ord(mn2 * inv);
+            f[1] = enc_ord(mx2 * inv);
+        }
+    }
+    if (tid < nr) sh_tab[tid] = ((r0 + tid) / R.go - g_lo) * nci;
+    stamp(tr, 3);
+    __syncthreads();
+    stamp(tr, 4);
+
     double acc = 0.0;
-    for (int ii0 = 0; ii0 < R.i2g; ii0 += R.ct_chunk) {
-        const int nch = min(R.ct_chunk, R.i2g - ii0);
-        __syncthreads();                        // previous chunk's readers are done with sh_inv
-        for (int idx = tid; idx < g_n * nch; idx += kBlock) {
-            const int gq = idx / nch;
-            const int ii = ii0 + idx - gq * nch;
-            const int g = g_lo + gq;
-            const int c = g * R.gi + ii;
-            float s, inv, mn1, mx1, mn2, mx2;
-            channel_scale(R, p, cur, c, s, inv, mn1, mx1, mn2, mx2);
-            sh_inv[idx] = inv;
-            // W2 is never row-scaled: forward its column stats (the tile holding the group's first row does it)
-            if (!emit && g * R.go >= r0 && g * R.go < r0 + nr) {
-                guint* f = (guint*)R.r2 + (int64_t)nxt * R.stat_stride + 2 * c;
-                f[0] = ~enc_ord(mn2 * inv);
-                f[1] = enc_ord(mx2 * inv);
+    int ci[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) ci[k] = (pos + k) / R.khkw - i0;
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+        if (u >= n_max) continue;
+        const int r_raw = grp + u * n_rowslots;
+        const int r = min(r_raw, nr - 1);
+        const bool ok = lane_on && r_raw < nr;
+        const int t0 = sh_tab[r];
+        float nv[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) nv[k] = v[u][k] * sh_inv[t0 + ci[k]];      // dfq.py:73
+        if (ok) vstore<VEC>(w + r * row_len2, nv);
+        if (mode == DIFF_SAVE) {
+            if (ok) vstore<VEC>(pv + r * row_len2, v[u]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                const float ref = (mode == DIFF_DIRECT) ? v[u][k] : q[u][k];
+                acc += ok ? (double)fabsf(nv[k] - ref) : 0.0;
             }
         }
-        stamp(tr, 3);
-        __syncthreads();
-        stamp(tr, 4);
-        const int npos = nch * R.khkw;                     // floats of this chunk per row
-        const int npos_v = npos / VEC;
-        if (preload) {
-            // j = it*ppt + u: (it, u) advance together with j
-            int it = 0, u = 0;
+        if (emit) {                                        // block-uniform: every lane reaches the shuffles
             float rmn = INFINITY, rmx = -INFINITY;
-            int tab_off = ((r0 + min(grp, nr - 1)) / R.go - g_lo) * nch;      // 1/s table row of this thread's row
+            if (ok) {
 #pragma unroll
-            for (int j = 0; j < NV; ++j) {
-                if (j >= n_used) continue;
-                const int r_raw = grp + it * n_groups;
-                const int r = min(r_raw, nr - 1);
-                const int pv_raw = ln + u * G;
-                const bool ok = it < n_iter && r_raw < nr && pv_raw < npos_v;
-                const int ps = min(pv_raw, row_v - 1) * VEC;
-                float nv[VEC];
-#pragma unroll
-                for (int k = 0; k < VEC; ++k) {
-                    const int ch = (R.khkw == 1) ? (ps + k) : (ps + k) / R.khkw;
-                    nv[k] = v[j][k] * sh_inv[tab_off + ch];                    // dfq.py:73
-                }
-                if (ok) vstore<VEC>(w + r * row_len2 + ps, nv);
-                if (mode == DIFF_SAVE) {
-                    if (ok) vstore<VEC>(pv + r * row_len2 + ps, v[j]);
-                } else {
-#pragma unroll
-                    for (int k = 0; k < VEC; ++k) {
-                        const float ref = (mode == DIFF_DIRECT) ? v[j][k] : q[j][k];
-                        acc += ok ? (double)fabsf(nv[k] - ref) : 0.0;
-                    }
-                }
-                if (ok) {
-#pragma unroll
-                    for (int k = 0; k < VEC; ++k) { rmn = fminf(rmn, nv[k]); rmx = fmaxf(rmx, nv[k]); }
-                }
-                if (++u == ppt) {                                   // row finished (uniform over the block)
-                    if (emit && it < n_iter) {
-                        for (int m = G >> 1; m >= 1; m >>= 1) {
-                            rmn = fminf(rmn, __shfl_xor(rmn, m));
-                            rmx = fmaxf(rmx, __shfl_xor(rmx, m));
-                        }
-                        if (r_raw < nr && ln == 0 && rmn <= rmx) {
-                            sh_row[2 * r + 0] = ~enc_ord(rmn);     // one writer per row
-                            sh_row[2 * r + 1] = enc_ord(rmx);
-                        }
-                    }
-                    u = 0; ++it; rmn = INFINITY; rmx = -INFINITY;
-                    if (it < n_iter) tab_off = ((r0 + min(grp + it * n_groups, nr - 1)) / R.go - g_lo) * nch;
-                }
+                for (int k = 0; k < VEC; ++k) { rmn = fminf(rmn, nv[k]); rmx = fmaxf(rmx, nv[k]); }
             }
-        } else {
-            for (int it = 0; it < n_iter; ++it) {          // uniform trip count: every lane reaches the shuffles
-                const int r = grp + it * n_groups;
-                const bool act = r < nr;
-                const int rr = act ? r : 0;
-                const float* tab = sh_inv + ((r0 + rr) / R.go - g_lo) * nch;
-                const int64_t base = (int64_t)rr * row_len2 + (int64_t)ii0 * R.khkw;
-                float rmn = INFINITY, rmx = -INFINITY;
-                for (int pb = ln; act && pb < npos_v; pb += G) {
-                    const int ps = pb * VEC;
-                    float x[VEC], nv[VEC];
-                    vload<VEC>(w + base + ps, x);
-#pragma unroll
-                    for (int k = 0; k < VEC; ++k) nv[k] = x[k] * tab[(ps + k) / R.khkw];      // dfq.py:73
-                    vstore<VEC>(w + base + ps, nv);
-                    if (mode == DIFF_SAVE) {
-                        vstore<VEC>(pv + base + ps, x);
-                    } else {
-                        float ref[VEC];
-                        if (mode == DIFF_FROM_PREV) vload<VEC>(pv + base + ps, ref);
-#pragma unroll
-                        for (int k = 0; k < VEC; ++k) acc += (double)fabsf(nv[k] - ((mode == DIFF_DIRECT) ? x[k] : ref[k]));
-                    }
-#pragma unroll
-                    for (int k = 0; k < VEC; ++k) { rmn = fminf(rmn, nv[k]); rmx = fmaxf(rmx, nv[k]); }
-                }
-                if (emit) {
-                    for (int m = G >> 1; m >= 1; m >>= 1) {
-                        rmn = fminf(rmn, __shfl_xor(rmn, m));
-                        rmx = fmaxf(rmx, __shfl_xor(rmx, m));
-                    }
-                    if (act && ln == 0 && rmn <= rmx) {
-                        atomicMax(&sh_row[2 * r + 0], ~enc_ord(rmn));
-                        atomicMax(&sh_row[2 * r + 1], enc_ord(rmx));
-                    }
-                }
+            for (int m = G >> 1; m >= 1; m >>= 1) {
+                rmn = fminf(rmn, __shfl_xor(rmn, m));
+                rmx = fmaxf(rmx, __shfl_xor(rmx, m));
+            }
+            if (ln == 0 && r_raw < nr) {                   // one writer per row of the tile
+                sh_row[2 * r + 0] = ~enc_ord(rmn);
+                sh_row[2 * r + 1] = enc_ord(rmx);
             }
         }
     }
     stamp(tr, 5);
     if (emit) {
         __syncthreads();
-        // complete rows: plain stores into the SAME sweep's parity (consumed by a later level)
+        // row stats go into the SAME sweep's parity (consumed by a later level of this sweep)
         guint* dst = (guint*)R.out_rows + (int64_t)cur * R.stat_stride + 2 * r0;
-        for (int i = tid; i < 2 * nr; i += kBlock) dst[i] = sh_row[i];
+        if (R.ct_slabs == 1) {
+            for (int i = tid; i < 2 * nr; i += kBlock) dst[i] = sh_row[i];           // complete rows
+        } else {
+            for (int i = tid; i < 2 * nr; i += kBlock) atomicMax((unsigned*)dst + i, sh_row[i]);
+        }
     }
     return acc;
 }
-
-// first workgroup of each relation of a level, passed BY VALUE (kernarg -> scalar registers) so the
-// workgroup -> relation lookup costs no dependent global loads
-struct LevelTable {
-    int32_t n;
-    int32_t begin[kLevelRelsMax];
-};
 
 __global__ __launch_bounds__(kBlock) void le_level_kernel(const LeRelDev* __restrict__ rels, LevelTable tab,
                                                           LeParams p, const LeState* __restrict__ state,
                                                           double* __restrict__ partials, LeTrace tr) {
     stamp(tr, 0);
-    __shared__ float sh_f[kInvMax];                 // row tile: scales; col tile: 1/s table
+    __shared__ float sh_f[kSlotMax];                // row tile: scales; col tile: 1/s table
     __shared__ uint32_t sh_u[2 * kSlotMax];         // row tile: column-stat slots; col tile: row stats
-    __shared__ int sh_g[kRowTileRowsMax];           // row tile: group (of the stat consumer) of each row
+    __shared__ int sh_g[kTileRowsMax];              // per-row table offsets
     __shared__ double sh_red[kBlock / kWave];
-    __shared__ uint32_t sh_desc[(sizeof(LeRelDev) + 3) / 4 + 2];
 
     int r = 0;
 #pragma unroll
     for (int i = 1; i < kLevelRelsMax; ++i)
         if (i < tab.n && (int)blockIdx.x >= tab.begin[i]) r = i;
-    // One vector load brings the whole descriptor (scalar loads of a cold line would be issued
-    // piecemeal at their first use: one memory round trip per field group); the loop state rides
-    // in the same round trip.
-    constexpr int kDescWords = (int)(sizeof(LeRelDev) / 4);
-    if (threadIdx.x < kDescWords) sh_desc[threadIdx.x] = ((const guint*)(rels + r))[threadIdx.x];
-    if (threadIdx.x == kDescWords) sh_desc[kDescWords] = (uint32_t)((const DFQ_GLOBAL_AS int*)&state->done)[0];
-    if (threadIdx.x == kDescWords + 1) sh_desc[kDescWords + 1] = (uint32_t)((const DFQ_GLOBAL_AS int*)&state->sweeps)[0];
-    __syncthreads();
-    if (sh_desc[kDescWords]) return;   // uniform: the reference loop has already exited
-    const int cur = (int)(sh_desc[kDescWords + 1] & 1u);
-    LeRelDev R;
-    {
-        uint32_t* dst = reinterpret_cast<uint32_t*>(&R);
+    // One wave-wide load brings the whole descriptor and the loop state (lane i loads word i); scalar
+    // loads of a cold descriptor would be issued piecemeal at first use, one round trip per group.
+    const int lane = threadIdx.x % kWave;
+    uint32_t word = 0u;
+    if (lane < kDescWords) word = ((const guint*)(rels + r))[lane];
+    else if (lane == kDescWords) word = (uint32_t)*(const DFQ_GLOBAL_AS int*)&state->done;
+    else if (lane == kDescWords + 1) word = (uint32_t)*(const DFQ_GLOBAL_AS int*)&state->sweeps;
+    union { LeRelDev R; uint32_t u[kDescWords]; } desc;
 #pragma unroll
-        for (int i = 0; i < kDescWords; ++i) dst[i] = sh_desc[i];
-    }
+    for (int i = 0; i < kDescWords; ++i) desc.u[i] = __builtin_amdgcn_readlane(word, i);
+    const uint32_t done = __builtin_amdgcn_readlane(word, kDescWords);
+    const int cur = (int)(__builtin_amdgcn_readlane(word, kDescWords + 1) & 1u);
+    if (done) return;          // uniform: the reference loop has already exited
+    const LeRelDev& R = desc.R;
     stamp(tr, 1);
 
     const int tile = blockIdx.x - R.tile_begin;
@@ -580,8 +498,8 @@ __global__ __launch_bounds__(kBlock) void le_level_kernel(const LeRelDev* __rest
         acc = R.rt_vec == 4 ? row_tile<4>(R, p, tile, cur, sh_f, sh_u, sh_g, tr)
                             : row_tile<1>(R, p, tile, cur, sh_f, sh_u, sh_g, tr);
     } else {
-        acc = R.ct_vec == 4 ? col_tile<4>(R, p, tile - R.n_row_tiles, cur, sh_f, sh_u, tr)
-                            : col_tile<1>(R, p, tile - R.n_row_tiles, cur, sh_f, sh_u, tr);
+        acc = R.ct_vec == 4 ? col_tile<4>(R, p, tile - R.n_row_tiles, cur, sh_f, sh_u, sh_g, tr)
+                            : col_tile<1>(R, p, tile - R.n_row_tiles, cur, sh_f, sh_u, sh_g, tr);
     }
     stamp(tr, 6);
     const double t = block_sum(acc, sh_red);
@@ -651,13 +569,16 @@ __global__ __launch_bounds__(kBlock) void le_bootstrap_kernel(const LeRelDev* __
     }
 }
 
-// dfq.py:105-115 on the device.  One workgroup of 16 waves: the per-tile partials are staged into
-// LDS with every load in flight at once, wave w then reduces layers w, w+16, ... in a fixed order.
-// Also clears the column-stat buffers of the parity that the next sweep accumulates into.
+// dfq.py:105-115 on the device.  One workgroup of 16 waves: the per-tile partials and the layer
+// table are staged into LDS with every load in flight at once, wave w then reduces layers w, w+16,
+// ... in a fixed order.  Also clears the stat buffers the next sweep accumulates into: parity `cur`
+// of the column stats (R2) and parity `nxt` of the in-sweep row stats (leading part of the R1 arena).
 __global__ __launch_bounds__(kCtlBlock) void le_control_kernel(const LeLayerDiff* __restrict__ layers, int n_layers,
                                                                const double* __restrict__ partials, int n_partials,
                                                                double* __restrict__ layer_mean,
                                                                uint32_t* __restrict__ r2_arena, int64_t r2_words,
+                                                               uint32_t* __restrict__ r1_arena, int64_t r1_words,
+                                                               int64_t r1_zero_words,
                                                                LeState* __restrict__ state, double converge_thres,
                                                                int converge_count, int max_sweeps) {
     __shared__ double sh_part[kCtlStage];
@@ -672,9 +593,10 @@ __global__ __launch_bounds__(kCtlBlock) void le_control_kernel(const LeLayerDiff
     for (int i = tid; i < min(n_layers, 1024); i += kCtlBlock) sh_layer[i] = layers[i];
     if (state->done) return;
     const int cur = state->sweeps & 1;
-    // parity `cur` was consumed by this sweep; the next sweep produces (atomicMax) into it
-    uint32_t* z = r2_arena + (int64_t)cur * r2_words;
-    for (int64_t i = tid; i < r2_words; i += kCtlBlock) z[i] = 0u;
+    uint32_t* z2 = r2_arena + (int64_t)cur * r2_words;
+    for (int64_t i = tid; i < r2_words; i += kCtlBlock) z2[i] = 0u;
+    uint32_t* z1 = r1_arena + (int64_t)(cur ^ 1) * r1_words;
+    for (int64_t i = tid; i < r1_zero_words; i += kCtlBlock) z1[i] = 0u;
     __syncthreads();
     for (int l = wave; l < n_layers; l += kCtlBlock / kWave) {
         const LeLayerDiff L = (l < 1024) ? sh_layer[l] : layers[l];
@@ -730,8 +652,8 @@ struct LevelLaunch {
     int n_rels = 0;
     int n_blocks = 0;
     LevelTable table;       // first workgroup of each relation (kernel argument)
-    int64_t paired = 0;     // elements n1+n2 of the relations in this level
-    int64_t snapshot = 0;   // snapshot-arena elements written or read in this level
+    int64_t paired = 0;     // elements n1+n2 of the relations in this launch
+    int64_t snapshot = 0;   // snapshot-arena elements written or read in this launch
 };
 
 }  // namespace dfq
@@ -743,13 +665,14 @@ struct dfq_le_plan {
     std::vector<LevelLaunch> levels;
     int64_t paired_total = 0, snapshot_total = 0;
     int total_tiles = 0, boot_blocks = 0;
-    int64_t r1_words = 0, r2_words = 0;    // per parity
+    int64_t stat_words = 0;                // per parity, per arena
+    int64_t r1_zero_words = 0;             // leading part of the R1 arena that is accumulated with atomics
     LeRelDev* d_rels = nullptr;
     LeLayerDiff* d_layer_diff = nullptr;
     double* d_partials = nullptr;
     double* d_layer_mean = nullptr;
     LeState* d_state = nullptr;
-    uint32_t* d_stats = nullptr;           // [2][r2_words] then [2][r1_words]
+    uint32_t* d_stats = nullptr;           // R2 arena [2][stat_words], then R1 arena [2][stat_words]
     std::vector<float*> arenas;            // snapshot arenas (hipMalloc)
 };
 
@@ -757,6 +680,24 @@ static int tile_target() {     // elements per tile; DFQ_LE_TILE_ELEMS overrides
     const char* e = getenv("DFQ_LE_TILE_ELEMS");
     const int v = e ? atoi(e) : 0;
     return v > 0 ? v : 4096;
+}
+
+static int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// [rows x cols] tiling of a [n_rows, row_len] matrix whose tiles move `vec`-wide vectors:
+// cols = slab width (multiple of vec, <= cols_max), rows so that a thread holds <= kRegs floats.
+static void tile_shape(int n_rows, int row_len, int vec, int cols_max, bool pow2_lanes, int target,
+                       int* rows, int* cols, int* slabs) {
+    int s = ceil_div(row_len, cols_max);
+    int c = ceil_div(ceil_div(row_len, s), vec) * vec;
+    s = ceil_div(row_len, c);
+    int lanes = c / vec;                              // threads along a row
+    if (pow2_lanes) { int g = 1; while (g < lanes) g <<= 1; lanes = g; }
+    const int rows_in_flight = kBlock / lanes;
+    int r = std::max(1, target / c);
+    r = std::min(r, (kRegs / vec) * rows_in_flight);  // register preload capacity
+    r = std::min(r, std::min(kTileRowsMax, n_rows));
+    *rows = r; *cols = c; *slabs = s;
 }
 
 extern "C" {
@@ -792,7 +733,7 @@ int dfq_le_plan_create(const dfq_layer* layers, int32_t n_layers, const dfq_rela
         const int G = (o1 != i2g) ? (o1 / i2g) : 1;
         if (G < 1 || o1 != G * i2g || B.out_ch % G != 0)
             return fail_arg("dfq_le_plan_create: relation %d: unsupported pairing O1=%d, I2/g=%d, O2=%d", r, o1, i2g, B.out_ch);
-        if ((int64_t)A.in_per_group * A.khkw > (1 << 24) || (int64_t)B.in_per_group * B.khkw > (1 << 24))
+        if ((int64_t)A.in_per_group * A.khkw > (1 << 22) || (int64_t)B.in_per_group * B.khkw > (1 << 22))
             return fail_arg("dfq_le_plan_create: relation %d: row too long", r);
         if (as_first[rr.first] >= 0 || as_second[rr.second] >= 0)
             return fail_arg("dfq_le_plan_create: relation %d: a layer may be first in one relation and second in one "
@@ -824,25 +765,32 @@ int dfq_le_plan_create(const dfq_layer* layers, int32_t n_layers, const dfq_rela
 
     // ---- dependency levels: relations sharing a layer keep their list order ----
     std::vector<int> level(n_relations, 0), last_level(n_layers, -1);
-    int n_levels = 0;
     for (int r = 0; r < n_relations; ++r) {
         const int lv = std::max(last_level[relations[r].first], last_level[relations[r].second]) + 1;
         level[r] = lv;
         last_level[relations[r].first] = lv;
         last_level[relations[r].second] = lv;
-        n_levels = std::max(n_levels, lv + 1);
     }
 
-    // ---- stat arrays: [2 parity][R2 of every relation] then [2 parity][R1 of every relation] ----
-    std::vector<int64_t> stat_off(n_relations, 0);
+    // ---- stat arenas.  R2 (column stats) of every relation; R1 (row stats) with the relations whose
+    //      R1 is accumulated in-sweep (their first layer is someone's second layer) laid out first so
+    //      the control kernel can clear exactly that part. ----
+    std::vector<int64_t> r2_off(n_relations, 0), r1_off(n_relations, 0);
     int64_t words = 0;
-    for (int r = 0; r < n_relations; ++r) { stat_off[r] = words; words += 2 * (int64_t)layers[relations[r].first].out_ch; }
-    p->r2_words = words;
-    p->r1_words = words;
+    for (int r = 0; r < n_relations; ++r) { r2_off[r] = words; words += 2 * (int64_t)layers[relations[r].first].out_ch; }
+    p->stat_words = words;
+    int64_t w1 = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int r = 0; r < n_relations; ++r) {
+            const bool interior = as_second[relations[r].first] >= 0;
+            if (interior == (pass == 0)) { r1_off[r] = w1; w1 += 2 * (int64_t)layers[relations[r].first].out_ch; }
+        }
+        if (pass == 0) p->r1_zero_words = w1;
+    }
     hipError_t e;
     if ((e = hipMalloc((void**)&p->d_stats, sizeof(uint32_t) * std::max<int64_t>(1, 4 * words))) != hipSuccess) return fail_alloc(e);
-    uint32_t* r2_base = p->d_stats;                  // [2][words]: the control kernel clears one parity of R2
-    uint32_t* r1_base = p->d_stats + 2 * words;      // [2][words]
+    uint32_t* r2_base = p->d_stats;
+    uint32_t* r1_base = p->d_stats + 2 * words;
 
     // ---- per-relation device descriptors ----
     std::vector<LeRelDev> h(n_relations);
@@ -852,7 +800,6 @@ int dfq_le_plan_create(const dfq_layer* layers, int32_t n_layers, const dfq_rela
         ld[l].n_elems = (double)((int64_t)layers[l].out_ch * layers[l].in_per_group * layers[l].khkw);
     }
     const int target = tile_target();
-    int tile_slot = 0, boot = 0;
     for (int r = 0; r < n_relations; ++r) {
         const dfq_relation& rr = relations[r];
         const dfq_layer& A = layers[rr.first];
@@ -864,8 +811,8 @@ int dfq_le_plan_create(const dfq_layer* layers, int32_t n_layers, const dfq_rela
         d.o2 = B.out_ch; d.i2g = B.in_per_group; d.khkw = B.khkw;
         const int G = (d.o1 != d.i2g) ? (d.o1 / d.i2g) : 1;
         d.gi = d.o1 / G; d.go = B.out_ch / G;
-        d.r1 = r1_base + stat_off[r];
-        d.r2 = r2_base + stat_off[r];
+        d.r1 = r1_base + r1_off[r];
+        d.r2 = r2_base + r2_off[r];
         d.stat_stride = words;
         // diff modes: a layer in two relations is touched as second (col tile) first, then as first
         const bool a_twice = as_second[rr.first] >= 0;     // W1 was column-scaled earlier this sweep
@@ -874,45 +821,22 @@ int dfq_le_plan_create(const dfq_layer* layers, int32_t n_layers, const dfq_rela
         d.diff2 = b_twice ? DIFF_SAVE : DIFF_DIRECT;
         d.prev1 = a_twice ? arena[rr.first] : nullptr;
         d.prev2 = b_twice ? arena[rr.second] : nullptr;
-        // row tiles
-        d.rt_vec = (d.row_len % 4 == 0 && ((uintptr_t)A.weight & 15u) == 0) ? 4 : 1;
-        {
-            const int cols_max = kRowTileColsMax * (d.rt_vec == 4 ? 2 : 1);
-            d.rt_slabs = (d.row_len + cols_max - 1) / cols_max;
-            int cols = (d.row_len + d.rt_slabs - 1) / d.rt_slabs;
-            cols = (cols + d.rt_vec - 1) / d.rt_vec * d.rt_vec;
-            d.rt_cols = cols;
-            d.rt_slabs = (d.row_len + d.rt_cols - 1) / d.rt_cols;
-            const int npv = d.rt_cols / d.rt_vec;                      // vector positions per row of a tile
-            int rows = std::max(1, target / d.rt_cols);
-            rows = std::min(rows, (kRegs / d.rt_vec) * (kBlock / npv));  // register preload capacity
-            rows = std::min(rows, std::min(kRowTileRowsMax, d.o1));
-            d.rt_rows = rows;
-        }
-        // col tiles
         const int row_len2 = d.i2g * d.khkw;
+        d.rt_vec = (d.row_len % 4 == 0 && ((uintptr_t)A.weight & 15u) == 0) ? 4 : 1;
         d.ct_vec = (row_len2 % 4 == 0 && ((uintptr_t)B.weight & 15u) == 0) ? 4 : 1;
-        d.ct_chunk = std::min(d.i2g, kChunkCh);
-        {
-            const int nv = kRegs / d.ct_vec;
-            const int row_v = row_len2 / d.ct_vec;
-            int lanes = 1;
-            while (lanes < kWave && lanes * nv < row_v) lanes *= 2;      // whole row in the registers of `lanes` threads
-            d.ct_lanes = lanes;
-            const int ppt = (row_v + lanes - 1) / lanes;
-            int crow = std::max(1, target / row_len2);
-            crow = std::min(crow, (kBlock / lanes) * std::max(1, nv / ppt));
-            crow = std::min(crow, std::min(kColRowsMax, d.o2));
-            // a tile of `crow` rows spans at most crow/go + 2 groups; the 1/s table holds (#groups) * chunk entries
-            const int64_t max_groups = kInvMax / d.ct_chunk;     // >= 4 because ct_chunk <= kChunkCh
-            crow = (int)std::min<int64_t>(crow, (max_groups - 2) * d.go);
-            if (crow < 1) crow = 1;
-            d.ct_rows = crow;
-        }
-        d.n_col_tiles = (d.o2 + d.ct_rows - 1) / d.ct_rows;
-        d.boot_tiles = (d.o1 + kBootTc - 1) / kBootTc;
+        tile_shape(d.o1, d.row_len, d.rt_vec, kRowTileColsMax * (d.rt_vec == 4 ? 2 : 1), false, target,
+                   &d.rt_rows, &d.rt_cols, &d.rt_slabs);
+        tile_shape(d.o2, row_len2, d.ct_vec, kColTileLanes * d.ct_vec, true, target,
+                   &d.ct_rows, &d.ct_cols, &d.ct_slabs);
+        // 1/s table of a col tile: (#groups spanned by its rows) x (#input channels spanned by its columns)
+        const int nci2 = ceil_div(d.ct_cols, d.khkw) + 1;
+        while (d.ct_rows > 1 && (ceil_div(d.ct_rows, d.go) + 1) * nci2 > kSlotMax) d.ct_rows = (d.ct_rows + 1) / 2;
+        if ((ceil_div(d.ct_rows, d.go) + 1) * nci2 > kSlotMax)
+            return (dfq_le_plan_destroy(p), fail_arg("dfq_le_plan_create: relation %d: kernel size too small for its width", r));
+        d.boot_tiles = ceil_div(d.o1, kBootTc);
     }
     // producer links + slot limits need every relation's geometry, so a second pass
+    int tile_slot = 0;
     for (int r = 0; r < n_relations; ++r) {
         const dfq_relation& rr = relations[r];
         LeRelDev& d = h[r];
@@ -920,19 +844,18 @@ int dfq_le_plan_create(const dfq_layer* layers, int32_t n_layers, const dfq_rela
         const int j_next = as_first[rr.second];     // relation whose first layer is our W2
         if (j_prev >= 0) {
             d.out_cols = h[j_prev].r2;
-            d.pc_go = h[j_prev].go; d.pc_gi = h[j_prev].gi; d.pc_n = h[j_prev].o1;
+            d.pc_go = h[j_prev].go; d.pc_gi = h[j_prev].gi;
             // LDS slots of a row tile: (#groups spanned) * (#channels spanned)
-            const int nci = (d.rt_cols + d.khkw1 - 1) / d.khkw1 + 1;
-            int rows = d.rt_rows;
-            while (rows > 1 && ((rows + d.pc_go - 1) / d.pc_go + 1) * nci > kSlotMax) rows = (rows + 1) / 2;
-            d.rt_rows = rows;
+            const int nci = ceil_div(d.rt_cols, d.khkw1) + 1;
+            while (d.rt_rows > 1 && (ceil_div(d.rt_rows, d.pc_go) + 1) * nci > kSlotMax) d.rt_rows = (d.rt_rows + 1) / 2;
+            if ((ceil_div(d.rt_rows, d.pc_go) + 1) * nci > kSlotMax)
+                return (dfq_le_plan_destroy(p), fail_arg("dfq_le_plan_create: relation %d: row tile does not fit", r));
         } else {
-            d.out_cols = nullptr; d.pc_go = 1; d.pc_gi = 1; d.pc_n = 0;
+            d.out_cols = nullptr; d.pc_go = 1; d.pc_gi = 1;
         }
         d.out_rows = (j_next >= 0) ? h[j_next].r1 : nullptr;
-        if (d.out_rows && d.ct_rows > kSlotMax) d.ct_rows = kSlotMax;
-        d.n_col_tiles = (d.o2 + d.ct_rows - 1) / d.ct_rows;
-        d.n_row_tiles = ((d.o1 + d.rt_rows - 1) / d.rt_rows) * d.rt_slabs;
+        d.n_row_tiles = ceil_div(d.o1, d.rt_rows) * d.rt_slabs;
+        d.n_col_tiles = ceil_div(d.o2, d.ct_rows) * d.ct_slabs;
         d.partial_base = tile_slot;
         ld[rr.first].partial_begin = d.partial_base;
         ld[rr.first].n_partials = d.n_row_tiles;                       // last touch of W1 this sweep
@@ -941,9 +864,7 @@ int dfq_le_plan_create(const dfq_layer* layers, int32_t n_layers, const dfq_rela
             ld[rr.second].n_partials = d.n_col_tiles;
         }
         tile_slot += d.n_row_tiles + d.n_col_tiles;
-        const int64_t n1 = (int64_t)d.o1 * d.row_len;
-        const int64_t n2 = (int64_t)d.o2 * d.i2g * d.khkw;
-        p->paired_total += n1 + n2;
+        p->paired_total += (int64_t)d.o1 * d.row_len + (int64_t)d.o2 * d.i2g * d.khkw;
     }
     p->total_tiles = tile_slot;
 
@@ -952,8 +873,7 @@ int dfq_le_plan_create(const dfq_layer* layers, int32_t n_layers, const dfq_rela
     for (int r = 0; r < n_relations; ++r) order[r] = r;
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return level[a] < level[b]; });
     std::vector<LeRelDev> sorted(n_relations);
-    p->levels.clear();
-    int prev_level = -1;
+    int boot = 0, prev_level = -1;
     for (int i = 0; i < n_relations; ++i) {
         const int r = order[i];
         if (level[r] != prev_level || p->levels.back().n_rels == kLevelRelsMax) {   // new launch
@@ -1025,7 +945,7 @@ static int le_restart(dfq_le_plan* p, const dfq_le_config* cfg, hipStream_t st) 
                        (int)cfg->converge_count, (int)cfg->max_sweeps);
     DFQ_CHECK_LAUNCH();
     if (p->n_rels > 0) {
-        DFQ_HIP_TRY(hipMemsetAsync(p->d_stats, 0, sizeof(uint32_t) * 4 * p->r2_words, st));
+        DFQ_HIP_TRY(hipMemsetAsync(p->d_stats, 0, sizeof(uint32_t) * 4 * p->stat_words, st));
         hipLaunchKernelGGL(le_bootstrap_kernel, dim3(p->boot_blocks), dim3(kBlock), 0, st,
                            (const LeRelDev*)p->d_rels, p->n_rels);
         DFQ_CHECK_LAUNCH();
@@ -1045,7 +965,8 @@ static int le_launch_level(dfq_le_plan* p, const LevelLaunch& L, const LeParams&
 static int le_launch_control(dfq_le_plan* p, const dfq_le_config* cfg, hipStream_t st) {
     hipLaunchKernelGGL(le_control_kernel, dim3(1), dim3(kCtlBlock), 0, st, (const LeLayerDiff*)p->d_layer_diff,
                        p->n_layers, (const double*)p->d_partials, p->total_tiles, p->d_layer_mean, p->d_stats,
-                       (int64_t)p->r2_words,
+                       (int64_t)p->stat_words, p->d_stats + 2 * p->stat_words, (int64_t)p->stat_words,
+                       (int64_t)p->r1_zero_words,
                        p->d_state, cfg->converge_thres, (int)cfg->converge_count, (int)cfg->max_sweeps);
     DFQ_CHECK_LAUNCH();
     return DFQ_OK;

@@ -52,6 +52,14 @@ uint64_t peer_slot(int mask, bool* valid) {
     return fibers[src].tc.slot;
 }
 
+uint64_t peer_rl(int src_lane, bool* valid) {
+    const int lane = cur_idx % kWaveSize;
+    const int src = (cur_idx - lane) + src_lane;
+    if (src_lane < 0 || src_lane >= kWaveSize || src >= (int)fibers.size() || !fibers[src].tc.rl_valid) { *valid = false; return 0; }
+    *valid = true;
+    return fibers[src].tc.rl_val;
+}
+
 void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
     const int nthreads = (int)(block.x * block.y * block.z);
     if (nthreads <= 0 || grid.x * grid.y * grid.z == 0) return;
@@ -71,6 +79,7 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
             f.tc.bdim = block;
             f.tc.gdim = grid;
             f.tc.slot = 0;
+            f.tc.rl_valid = false;
             f.state = READY;
             getcontext(&f.ctx);
             f.ctx.uc_stack.ss_sp = f.stack;

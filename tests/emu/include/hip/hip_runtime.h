@@ -47,6 +47,8 @@ namespace emu {
 struct ThreadCtx {
     dim3 tid, bid, bdim, gdim;
     uint64_t slot;
+    uint32_t rl_val = 0;
+    bool rl_valid = false;
 };
 extern ThreadCtx* cur;
 
@@ -82,6 +84,21 @@ inline T shfl_xor(T v, int mask) {
 inline void __syncthreads() { emu::sync_block(); }
 template <typename T>
 inline T __shfl_xor(T v, int mask) { return emu::shfl_xor(v, mask); }
+
+namespace emu { uint64_t peer_rl(int src_lane, bool* valid); }
+// v_readlane broadcast.  A kernel typically reads many lanes of ONE register in a row; after the
+// first rendezvous every lane's value sits in its `rl_val`, so further reads of the same register
+// need no rendezvous (each fiber is fresh per workgroup, rl_valid starts false).
+inline uint32_t __builtin_amdgcn_readlane(uint32_t v, int src_lane) {
+    if (!(emu::cur->rl_valid && emu::cur->rl_val == v)) {
+        emu::cur->rl_val = v;
+        emu::cur->rl_valid = true;
+        emu::sync_wave();
+    }
+    bool ok = false;
+    const uint64_t got = emu::peer_rl(src_lane, &ok);
+    return ok ? (uint32_t)got : v;
+}
 
 inline uint32_t __float_as_uint(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 inline float __uint_as_float(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
