@@ -17,6 +17,9 @@ namespace dfq {
 #ifndef DFQ_GLOBAL_AS
 #define DFQ_GLOBAL_AS __attribute__((address_space(1)))
 #endif
+#ifndef DFQ_CONSTANT_AS
+#define DFQ_CONSTANT_AS __attribute__((address_space(4)))     // kernarg segment / constant memory
+#endif
 typedef DFQ_GLOBAL_AS float gfloat;
 typedef DFQ_GLOBAL_AS unsigned int guint;
 typedef float fvec4 __attribute__((vector_size(16)));   // native 16-byte vector (dwordx4 loads/stores)

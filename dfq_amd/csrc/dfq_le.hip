@@ -52,14 +52,15 @@ constexpr int kRowTileColsMax = 128;   // positions of a row tile (x2 for float4
 constexpr int kColTileLanes = 64;      // vector positions of a col tile (one wave per row at most)
 constexpr int kSlotMax = 1024;         // LDS table entries of a tile (stat slots / 1/s table)
 constexpr int kBootTc = 64;            // channels per bootstrap tile
-constexpr int kLevelRelsMax = 32;      // relations per launch (longer levels are split)
+constexpr int kLevelRelsMax = 16;      // relations per launch (longer levels are split): descriptors ride in the kernarg
 constexpr int kCtlBlock = 1024;        // threads of the control kernel
 constexpr int kCtlStage = 6144;        // partials staged in LDS by the control kernel
 
 enum DiffMode : int32_t { DIFF_DIRECT = 0, DIFF_SAVE = 1, DIFF_FROM_PREV = 2 };
 
-// One relation.  At most 62 32-bit words: the descriptor plus two words of loop state are fetched
-// with ONE wave-wide load (lane i loads word i) and broadcast with v_readlane.
+// One relation.  The descriptors of a launch are passed BY VALUE (kernarg segment) and selected with
+// blockIdx.y, so a workgroup reaches its descriptor with the kernel's very first scalar loads: no
+// table lookup, no dependent fetch.
 struct LeRelDev {
     float* w1;
     float* w2;
@@ -81,12 +82,9 @@ struct LeRelDev {
     int32_t ct_rows, ct_cols, ct_slabs, ct_vec, n_col_tiles;
     int32_t diff1, diff2;
     int32_t partial_base;   // first partial slot of this relation (row tiles, then col tiles)
-    int32_t tile_begin;     // first workgroup of this relation inside its level launch
     int32_t boot_begin;     // first workgroup inside the bootstrap launch
     int32_t boot_tiles;
 };
-constexpr int kDescWords = (int)(sizeof(LeRelDev) / 4);
-static_assert(sizeof(LeRelDev) % 4 == 0 && kDescWords + 2 <= kWave, "descriptor must fit one wave-wide load");
 
 struct LeParams {
     float s_lo, s_hi, inv_lo, inv_hi, eps;
@@ -108,12 +106,11 @@ struct LeLayerDiff {
     double n_elems;
 };
 
-// first workgroup of each relation of a level, passed BY VALUE (kernarg -> scalar registers) so the
-// workgroup -> relation lookup costs no dependent global loads
-struct LevelTable {
-    int32_t n;
-    int32_t begin[kLevelRelsMax];
+// the relations of one launch; grid = (max tiles of a relation, n relations)
+struct LevelArgs {
+    LeRelDev rel[kLevelRelsMax];
 };
+static_assert(sizeof(LevelArgs) <= 3584, "kernarg segment is limited to 4 KiB");
 
 // optional per-phase cycle stamps of one workgroup (dfq_le_trace, tuning aid; null in production)
 struct LeTrace {
@@ -122,7 +119,7 @@ struct LeTrace {
     int32_t pad;
 };
 __device__ __forceinline__ void stamp(const LeTrace& tr, int slot) {
-    if (tr.out && (int)blockIdx.x == tr.block && threadIdx.x == 0) tr.out[slot] = clock64();
+    if (tr.out && (int)(blockIdx.y * gridDim.x + blockIdx.x) == tr.block && threadIdx.x == 0) tr.out[slot] = clock64();
 }
 
 // dfq.py:58-59 with Python's max/min semantics on a 0-dim float32 tensor (see oracle.le_solve).
@@ -463,8 +460,16 @@ __device__ __forceinline__ double col_tile(const LeRelDev& R, const LeParams& p,
     return acc;
 }
 
-__global__ __launch_bounds__(kBlock) void le_level_kernel(const LeRelDev* __restrict__ rels, LevelTable tab,
-                                                          LeParams p, const LeState* __restrict__ state,
+constexpr int kDescWords = (int)(sizeof(LeRelDev) / 4);
+static_assert(sizeof(LeRelDev) % 4 == 0 && kDescWords + 1 <= kWave, "descriptor must fit one wave-wide load");
+
+// `args` MUST stay the first parameter: the kernel reads its descriptor straight out of the kernarg
+// segment (offset blockIdx.y * sizeof(LeRelDev)) with one wave-wide vector load -- lane i fetches
+// word i, v_readlane broadcasts it.  Letting the compiler materialise `args.rel[blockIdx.y]` makes
+// it fetch the fields piecemeal at first use (one dependent round trip per group of fields).
+// `parity` = sweep index & 1, known to the host at enqueue time.
+__global__ __launch_bounds__(kBlock) void le_level_kernel(LevelArgs args, LeParams p, int parity,
+                                                          const LeState* __restrict__ state,
                                                           double* __restrict__ partials, LeTrace tr) {
     stamp(tr, 0);
     __shared__ float sh_f[kSlotMax];                // row tile: scales; col tile: 1/s table
@@ -472,27 +477,21 @@ __global__ __launch_bounds__(kBlock) void le_level_kernel(const LeRelDev* __rest
     __shared__ int sh_g[kTileRowsMax];              // per-row table offsets
     __shared__ double sh_red[kBlock / kWave];
 
-    int r = 0;
-#pragma unroll
-    for (int i = 1; i < kLevelRelsMax; ++i)
-        if (i < tab.n && (int)blockIdx.x >= tab.begin[i]) r = i;
-    // One wave-wide load brings the whole descriptor and the loop state (lane i loads word i); scalar
-    // loads of a cold descriptor would be issued piecemeal at first use, one round trip per group.
     const int lane = threadIdx.x % kWave;
+    const DFQ_CONSTANT_AS uint32_t* ka = (const DFQ_CONSTANT_AS uint32_t*)__builtin_amdgcn_kernarg_segment_ptr();
     uint32_t word = 0u;
-    if (lane < kDescWords) word = ((const guint*)(rels + r))[lane];
+    if (lane < kDescWords) word = ka[blockIdx.y * kDescWords + lane];
     else if (lane == kDescWords) word = (uint32_t)*(const DFQ_GLOBAL_AS int*)&state->done;
-    else if (lane == kDescWords + 1) word = (uint32_t)*(const DFQ_GLOBAL_AS int*)&state->sweeps;
     union { LeRelDev R; uint32_t u[kDescWords]; } desc;
 #pragma unroll
     for (int i = 0; i < kDescWords; ++i) desc.u[i] = __builtin_amdgcn_readlane(word, i);
     const uint32_t done = __builtin_amdgcn_readlane(word, kDescWords);
-    const int cur = (int)(__builtin_amdgcn_readlane(word, kDescWords + 1) & 1u);
-    if (done) return;          // uniform: the reference loop has already exited
     const LeRelDev& R = desc.R;
+    const int tile = blockIdx.x;
+    const int cur = parity;
+    if (done || tile >= R.n_row_tiles + R.n_col_tiles) return;   // uniform
     stamp(tr, 1);
 
-    const int tile = blockIdx.x - R.tile_begin;
     double acc;
     if (tile < R.n_row_tiles) {
         acc = R.rt_vec == 4 ? row_tile<4>(R, p, tile, cur, sh_f, sh_u, sh_g, tr)
@@ -578,7 +577,7 @@ __global__ __launch_bounds__(kCtlBlock) void le_control_kernel(const LeLayerDiff
                                                                double* __restrict__ layer_mean,
                                                                uint32_t* __restrict__ r2_arena, int64_t r2_words,
                                                                uint32_t* __restrict__ r1_arena, int64_t r1_words,
-                                                               int64_t r1_zero_words,
+                                                               int64_t r1_zero_words, int parity,
                                                                LeState* __restrict__ state, double converge_thres,
                                                                int converge_count, int max_sweeps) {
     __shared__ double sh_part[kCtlStage];
@@ -589,14 +588,21 @@ __global__ __launch_bounds__(kCtlBlock) void le_control_kernel(const LeLayerDiff
     const int wave = tid / kWave;
     // every global read of the kernel is issued before the first wait: partials, layer table, state
     const int n_stage = min(n_partials, kCtlStage);
-    for (int i = tid; i < n_stage; i += kCtlBlock) sh_part[i] = partials[i];
-    for (int i = tid; i < min(n_layers, 1024); i += kCtlBlock) sh_layer[i] = layers[i];
+    if (blockIdx.x == 0) {
+        for (int i = tid; i < n_stage; i += kCtlBlock) sh_part[i] = partials[i];
+        for (int i = tid; i < min(n_layers, 1024); i += kCtlBlock) sh_layer[i] = layers[i];
+    }
     if (state->done) return;
-    const int cur = state->sweeps & 1;
-    uint32_t* z2 = r2_arena + (int64_t)cur * r2_words;
-    for (int64_t i = tid; i < r2_words; i += kCtlBlock) z2[i] = 0u;
-    uint32_t* z1 = r1_arena + (int64_t)(cur ^ 1) * r1_words;
-    for (int64_t i = tid; i < r1_zero_words; i += kCtlBlock) z1[i] = 0u;
+    const int cur = parity;          // sweep index & 1, from the host: block 0 updates the state below
+    if (blockIdx.x > 0) {
+        // helper workgroups: clear the stat words the next sweep accumulates into
+        const int64_t nz = gridDim.x - 1, z = blockIdx.x - 1;
+        uint32_t* z2 = r2_arena + (int64_t)cur * r2_words;
+        for (int64_t i = z * kCtlBlock + tid; i < r2_words; i += nz * kCtlBlock) z2[i] = 0u;
+        uint32_t* z1 = r1_arena + (int64_t)(cur ^ 1) * r1_words;
+        for (int64_t i = z * kCtlBlock + tid; i < r1_zero_words; i += nz * kCtlBlock) z1[i] = 0u;
+        return;
+    }
     __syncthreads();
     for (int l = wave; l < n_layers; l += kCtlBlock / kWave) {
         const LeLayerDiff L = (l < 1024) ? sh_layer[l] : layers[l];
@@ -650,8 +656,9 @@ __global__ void le_reset_kernel(LeState* state, double converge_thres, int conve
 struct LevelLaunch {
     int rel_begin = 0;      // range in the level-sorted device relation table
     int n_rels = 0;
-    int n_blocks = 0;
-    LevelTable table;       // first workgroup of each relation (kernel argument)
+    int n_blocks = 0;       // workgroups that do work
+    int max_tiles = 0;      // grid.x
+    LevelArgs args;         // descriptors of the launch (kernel argument, by value)
     int64_t paired = 0;     // elements n1+n2 of the relations in this launch
     int64_t snapshot = 0;   // snapshot-arena elements written or read in this launch
 };
@@ -667,6 +674,7 @@ struct dfq_le_plan {
     int total_tiles = 0, boot_blocks = 0;
     int64_t stat_words = 0;                // per parity, per arena
     int64_t r1_zero_words = 0;             // leading part of the R1 arena that is accumulated with atomics
+    int64_t sweep_index = 0;               // sweeps enqueued since the last restart (parity = & 1)
     LeRelDev* d_rels = nullptr;
     LeLayerDiff* d_layer_diff = nullptr;
     double* d_partials = nullptr;
@@ -694,6 +702,7 @@ static void tile_shape(int n_rows, int row_len, int vec, int cols_max, bool pow2
     int lanes = c / vec;                              // threads along a row
     if (pow2_lanes) { int g = 1; while (g < lanes) g <<= 1; lanes = g; }
     const int rows_in_flight = kBlock / lanes;
+    if (vec == 1) target = std::min(target, 2048);    // scalar tiles: one memory instruction per float
     int r = std::max(1, target / c);
     r = std::min(r, (kRegs / vec) * rows_in_flight);  // register preload capacity
     r = std::min(r, std::min(kTileRowsMax, n_rows));
@@ -879,18 +888,16 @@ int dfq_le_plan_create(const dfq_layer* layers, int32_t n_layers, const dfq_rela
         if (level[r] != prev_level || p->levels.back().n_rels == kLevelRelsMax) {   // new launch
             p->levels.push_back(LevelLaunch());
             p->levels.back().rel_begin = i;
-            p->levels.back().table.n = 0;
             prev_level = level[r];
         }
         LevelLaunch& L = p->levels.back();
         sorted[i] = h[r];
-        sorted[i].tile_begin = L.n_blocks;
         sorted[i].boot_begin = boot;              // bootstrap launch walks the same (sorted) table
         boot += h[r].boot_tiles;
-        L.table.begin[L.n_rels] = L.n_blocks;
+        L.args.rel[L.n_rels] = sorted[i];
         L.n_blocks += h[r].n_row_tiles + h[r].n_col_tiles;
+        L.max_tiles = std::max(L.max_tiles, h[r].n_row_tiles + h[r].n_col_tiles);
         L.n_rels += 1;
-        L.table.n = L.n_rels;
         const int64_t n1 = (int64_t)h[r].o1 * h[r].row_len;
         const int64_t n2 = (int64_t)h[r].o2 * h[r].i2g * h[r].khkw;
         L.paired += n1 + n2;
@@ -920,6 +927,13 @@ int32_t dfq_le_plan_levels(const dfq_le_plan* p) { return p ? (int32_t)p->levels
 int64_t dfq_le_plan_paired_elements(const dfq_le_plan* p) { return p ? p->paired_total : 0; }
 int64_t dfq_le_plan_snapshot_elements(const dfq_le_plan* p) { return p ? p->snapshot_total : 0; }
 
+int dfq_le_plan_level_grid(const dfq_le_plan* p, int32_t level, int32_t* grid_x, int32_t* grid_y) {
+    if (!p || level < 0 || level >= (int32_t)p->levels.size()) return fail_arg("dfq_le_plan_level_grid: bad level");
+    if (grid_x) *grid_x = p->levels[level].max_tiles;
+    if (grid_y) *grid_y = p->levels[level].n_rels;
+    return DFQ_OK;
+}
+
 int32_t dfq_le_plan_level_launches(const dfq_le_plan* p, int32_t level, int64_t* paired_elems,
                                    int64_t* snapshot_elems, int32_t* n_workgroups) {
     if (!p || level < 0 || level >= (int32_t)p->levels.size()) return fail_arg("dfq_le_plan_level_launches: bad level");
@@ -944,6 +958,7 @@ static int le_restart(dfq_le_plan* p, const dfq_le_config* cfg, hipStream_t st) 
     hipLaunchKernelGGL(le_reset_kernel, dim3(1), dim3(64), 0, st, p->d_state, cfg->converge_thres,
                        (int)cfg->converge_count, (int)cfg->max_sweeps);
     DFQ_CHECK_LAUNCH();
+    p->sweep_index = 0;
     if (p->n_rels > 0) {
         DFQ_HIP_TRY(hipMemsetAsync(p->d_stats, 0, sizeof(uint32_t) * 4 * p->stat_words, st));
         hipLaunchKernelGGL(le_bootstrap_kernel, dim3(p->boot_blocks), dim3(kBlock), 0, st,
@@ -956,19 +971,21 @@ static int le_restart(dfq_le_plan* p, const dfq_le_config* cfg, hipStream_t st) 
 static int le_launch_level(dfq_le_plan* p, const LevelLaunch& L, const LeParams& q, hipStream_t st,
                            LeTrace tr = LeTrace{nullptr, 0, 0}) {
     if (L.n_blocks == 0) return DFQ_OK;
-    hipLaunchKernelGGL(le_level_kernel, dim3(L.n_blocks), dim3(kBlock), 0, st,
-                       (const LeRelDev*)(p->d_rels + L.rel_begin), L.table, q, (const LeState*)p->d_state, p->d_partials, tr);
+    hipLaunchKernelGGL(le_level_kernel, dim3(L.max_tiles, L.n_rels), dim3(kBlock), 0, st, L.args, q,
+                       (int)(p->sweep_index & 1), (const LeState*)p->d_state, p->d_partials, tr);
     DFQ_CHECK_LAUNCH();
     return DFQ_OK;
 }
 
 static int le_launch_control(dfq_le_plan* p, const dfq_le_config* cfg, hipStream_t st) {
-    hipLaunchKernelGGL(le_control_kernel, dim3(1), dim3(kCtlBlock), 0, st, (const LeLayerDiff*)p->d_layer_diff,
+    const int n_clear = (int)std::min<int64_t>(32, (p->stat_words + p->r1_zero_words + 4 * kCtlBlock - 1) / (4 * kCtlBlock));
+    hipLaunchKernelGGL(le_control_kernel, dim3(1 + std::max(1, n_clear)), dim3(kCtlBlock), 0, st, (const LeLayerDiff*)p->d_layer_diff,
                        p->n_layers, (const double*)p->d_partials, p->total_tiles, p->d_layer_mean, p->d_stats,
                        (int64_t)p->stat_words, p->d_stats + 2 * p->stat_words, (int64_t)p->stat_words,
-                       (int64_t)p->r1_zero_words,
+                       (int64_t)p->r1_zero_words, (int)(p->sweep_index & 1),
                        p->d_state, cfg->converge_thres, (int)cfg->converge_count, (int)cfg->max_sweeps);
     DFQ_CHECK_LAUNCH();
+    p->sweep_index += 1;             // the control launch closes a sweep
     return DFQ_OK;
 }
 

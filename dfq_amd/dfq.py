@@ -92,7 +92,10 @@ class LEPlan:
     def level_info(self, level):
         a, b, c = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int32()
         n = _ffi.lib().dfq_le_plan_level_launches(self._plan, level, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c))
-        return dict(relations=n, paired_elements=a.value, snapshot_elements=b.value, workgroups=c.value)
+        gx, gy = ctypes.c_int32(), ctypes.c_int32()
+        _ffi.check(_ffi.lib().dfq_le_plan_level_grid(self._plan, level, ctypes.byref(gx), ctypes.byref(gy)))
+        return dict(relations=n, paired_elements=a.value, snapshot_elements=b.value, workgroups=c.value,
+                    grid=(gx.value, gy.value))
 
     # -- execution -----------------------------------------------------------------------------
     def run(self, s_range=(1e-8, 1e8), converge_thres=2e-7, converge_count=20, signed=False, eps=0,

@@ -112,6 +112,8 @@ int64_t dfq_le_plan_paired_elements(const dfq_le_plan* plan);   /* sum over rela
 int64_t dfq_le_plan_snapshot_elements(const dfq_le_plan* plan); /* elements of twice-touched layers */
 int32_t dfq_le_plan_level_launches(const dfq_le_plan* plan, int32_t level, int64_t* paired_elems,
                                    int64_t* snapshot_elems, int32_t* n_workgroups);
+/* launch geometry of a level: grid_x = tiles of its largest relation, grid_y = relations */
+int dfq_le_plan_level_grid(const dfq_le_plan* plan, int32_t level, int32_t* grid_x, int32_t* grid_y);
 
 /* Enqueue exactly `n_sweeps` sweeps plus their convergence bookkeeping on `stream`; never
  * synchronises.  The device-side loop state decides whether a sweep still executes (after the
@@ -133,7 +135,7 @@ int dfq_le_profile(dfq_le_plan* plan, const dfq_le_config* cfg, int32_t n_sweeps
                    double* level_ms, double* control_ms, int32_t* n_level_launches);
 
 /* Tuning aid: run two sweeps and return the shader-clock stamps (s_memtime) that thread 0 of
- * workgroup `block` of launch `launch` took at the phase boundaries of its tile during the second
+ * workgroup `block` (= blockIdx.y * grid_x + blockIdx.x) of launch `launch` took at the phase boundaries of its tile during the second
  * sweep: [0] entry, [1] descriptor+state loaded, [2] data loads issued, [3] scales solved,
  * [4] barrier passed, [5] elements stored, [6] stats published, [7] partial written.  Synchronises;
  * modifies the weights like two ordinary sweeps. */

@@ -35,7 +35,7 @@ def build(force=False):
         if all(os.path.getmtime(f) <= t for f in deps()):
             return OUT
     cmd = ['g++', '-O2', '-g', '-std=c++17', '-fPIC', '-shared', '-ffp-contract=off', '-fno-fast-math',
-           '-DDFQ_GLOBAL_AS=', '-Wall', '-Wno-unknown-pragmas', '-Wno-unused-function', '-Wno-unused-variable',
+           '-DDFQ_GLOBAL_AS=', '-DDFQ_CONSTANT_AS=', '-Wall', '-Wno-unknown-pragmas', '-Wno-unused-function', '-Wno-unused-variable',
            '-I', os.path.join(HERE, 'include'), '-I', os.path.join(ROOT, 'include'), '-o', OUT]
     for s in sources():
         cmd += ['-x', 'c++', s]

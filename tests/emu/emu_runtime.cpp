@@ -8,6 +8,7 @@
 namespace emu {
 
 ThreadCtx* cur = nullptr;
+const void* kernarg_ptr = nullptr;
 
 namespace {
 

@@ -138,5 +138,17 @@ inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
 inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.0f; return hipSuccess; }
 
+namespace emu {
+extern const void* kernarg_ptr;
+template <typename K, typename A0, typename... As>
+inline void launch_k(dim3 grid, dim3 block, K kernel, A0 a0, As... as) {
+    // the argument copies live here for the whole launch; the first one sits at kernarg offset 0
+    kernarg_ptr = &a0;
+    launch(grid, block, [&]() { kernel(a0, as...); });
+    kernarg_ptr = nullptr;
+}
+}  // namespace emu
+inline const void* __builtin_amdgcn_kernarg_segment_ptr() { return emu::kernarg_ptr; }
+
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
-    emu::launch((grid), (block), [=]() { kernel(__VA_ARGS__); })
+    emu::launch_k((grid), (block), kernel, __VA_ARGS__)

@@ -7,8 +7,9 @@ proto = bench.prepare('mobilenet_v2', 0, dev)
 for launch in range(5):
     rep = bench.make_replica(proto)
     info = rep['le'].level_info(launch)
-    for block in sorted(set([0, info['workgroups'] // 2, info['workgroups'] - 1])):
+    gx, gy = info['grid']
+    for block in sorted(set([0, (gy // 2) * gx, (gy - 1) * gx])):
         rep = bench.make_replica(proto)
         st = rep['le'].trace(launch, block)
         d = [st[i] - st[0] for i in range(8)]
-        print('launch', launch, 'block', block, 'of', info['workgroups'], 'cycles since entry', d)
+        print('launch', launch, 'block', block, 'grid', info['grid'], 'working', info['workgroups'], 'cycles since entry', d)
