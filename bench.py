@@ -51,6 +51,7 @@ def parse():
     ap.add_argument('--sweeps', type=int, default=0, help='pin the LE sweep count (0 = what the convergence test needs)')
     ap.add_argument('--cpu-seconds', type=float, default=10.0, help='CPU-baseline budget (0 disables)')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--force-sweeps', action='store_true', help='tuning: run --sweeps sweeps regardless of convergence')
     return ap.parse_args()
 
 
@@ -146,8 +147,10 @@ def main():
 
     replicas = [make_replica(proto) for _ in range(args.steps + args.warmup)]
 
+    force = dict(converge_thres=-1.0, converge_count=10 ** 9) if args.force_sweeps else {}
+
     def step(r):
-        r['le'].enqueue(sweeps, restart=True, max_sweeps=sweeps)
+        r['le'].enqueue(sweeps, restart=True, max_sweeps=sweeps, **force)
         r['bc'].run()
 
     def fence():
@@ -199,7 +202,7 @@ def main():
         # dominant kernel: le_level_kernel.  Algorithmic bytes per sweep = 8 B per paired element (read
         # + write; the ranges come from the same read) + 4 B per snapshot-arena element touched.
         prof_rep = make_replica(proto)
-        prof = prof_rep['le'].profile(sweeps, max_sweeps=sweeps)
+        prof = prof_rep['le'].profile(sweeps, max_sweeps=sweeps, **force)
         per_level = []
         for l in range(levels):
             info = prof_rep['le'].level_info(l)

@@ -27,7 +27,7 @@
 //   row tile  = [rt_rows x rt_cols] block of W1, scaled per row, emits per-input-channel stats;
 //   col tile  = [ct_rows x ct_cols] block of W2, scaled per input channel, emits per-row stats.
 //   In both, lanes run along the contiguous row positions and every thread walks down the rows
-//   with all of its (<= kRegs) elements loaded into registers before the scale solve.
+//   with all of its elements loaded into registers before the scale solve.
 //
 // Partial stats of a tile are merged with order-preserving atomicMax words (identity 0); the
 // buffers alternate between two parities and the control kernel clears the one that is about to
@@ -46,7 +46,10 @@
 
 namespace dfq {
 
-constexpr int kRegs = 32;              // floats a thread can hold for the register preload
+// register slots (vectors) a thread preloads: 4 x float4 or 8 x float.  Kept small on purpose: every
+// slot is unrolled code, and a cold workgroup pays instruction-fetch latency for every line it walks.
+constexpr int kSlotsVec4 = 4;
+constexpr int kSlotsVec1 = 8;
 constexpr int kTileRowsMax = 256;      // rows of a tile (one LDS entry per row)
 constexpr int kRowTileColsMax = 128;   // positions of a row tile (x2 for float4 tiles)
 constexpr int kColTileLanes = 64;      // vector positions of a col tile (one wave per row at most)
@@ -122,6 +125,14 @@ __device__ __forceinline__ void stamp(const LeTrace& tr, int slot) {
     if (tr.out && (int)(blockIdx.y * gridDim.x + blockIdx.x) == tr.block && threadIdx.x == 0) tr.out[slot] = clock64();
 }
 
+// a / b for 0 <= a < 2^20, b >= 1 in four instructions: (a + 0.5) / b is at least 0.5/b away from every
+// integer, while v_rcp_f32 (1 ulp) plus the multiply are off by < 2e-7 * a/b < 0.5/b, so truncating
+// is exact.  (A 32-bit integer division expands to ~40 dependent instructions and a tile needs a
+// dozen of them: they were a visible share of its latency and of the kernel's code size.)
+__device__ __forceinline__ int small_div(int a, int b) {
+    return (int)(((float)a + 0.5f) * __builtin_amdgcn_rcpf((float)b));
+}
+
 // dfq.py:58-59 with Python's max/min semantics on a 0-dim float32 tensor (see oracle.le_solve).
 __device__ __forceinline__ void le_solve(float r1, float r2, const LeParams& p, float& s_out, float& inv_out) {
     const float a = r1 + p.eps;
@@ -186,22 +197,23 @@ __device__ __forceinline__ void vstore(gfloat* p, const float (&x)[VEC]) {
 template <int VEC>
 __device__ __forceinline__ double row_tile(const LeRelDev& R, const LeParams& p, int tile, int cur,
                                            float* sh_s, uint32_t* sh_slot, int* sh_g, const LeTrace& tr) {
-    constexpr int NV = kRegs / VEC;            // vectors per thread
+    constexpr int NV = (VEC == 4) ? kSlotsVec4 : kSlotsVec1;   // vectors per thread
     const int tid = threadIdx.x;
-    const int slab = tile % R.rt_slabs;
-    const int r0 = (tile / R.rt_slabs) * R.rt_rows;
+    const int rblk = small_div(tile, R.rt_slabs);
+    const int slab = tile - rblk * R.rt_slabs;
+    const int r0 = rblk * R.rt_rows;
     const int nr = min(R.rt_rows, R.o1 - r0);
     const int p0 = slab * R.rt_cols;
     const int np = min(R.rt_cols, R.row_len - p0);
     const int npv = np / VEC;                  // vector positions (np % VEC == 0 by plan)
     const int nxt = cur ^ 1;
-    const int JL = kBlock / npv;
-    const int jl_raw = tid / npv;
+    const int JL = small_div(kBlock, npv);
+    const int jl_raw = small_div(tid, npv);
     const bool lane_on = jl_raw < JL;
     const int jl = lane_on ? jl_raw : 0;
     const int pos = p0 + (lane_on ? (tid - jl_raw * npv) * VEC : 0);
-    const int n_own = lane_on ? (nr - jl + JL - 1) / JL : 0;     // rows this thread owns (<= NV by plan)
-    const int n_max = min(NV, (nr + JL - 1) / JL);               // register slots in use (block-uniform)
+    const int n_own = lane_on ? small_div(nr - jl + JL - 1, JL) : 0;   // rows this thread owns (<= NV by plan)
+    const int n_max = min(NV, small_div(nr + JL - 1, JL));             // register slots in use (block-uniform)
     gfloat* const w = (gfloat*)R.w1 + ((int64_t)r0 * R.row_len + pos);
     gfloat* const pv = (gfloat*)R.prev1 + ((int64_t)r0 * R.row_len + pos);
     const int mode = R.diff1;
@@ -229,10 +241,10 @@ __device__ __forceinline__ double row_tile(const LeRelDev& R, const LeParams& p,
     const bool emit = R.out_cols != nullptr;
     int g0 = 0, i0 = 0, nci = 1, n_slots = 0;
     if (emit) {
-        g0 = r0 / R.pc_go;
-        i0 = p0 / R.khkw1;
-        nci = (p0 + np - 1) / R.khkw1 - i0 + 1;
-        n_slots = ((r0 + nr - 1) / R.pc_go - g0 + 1) * nci;
+        g0 = small_div(r0, R.pc_go);
+        i0 = small_div(p0, R.khkw1);
+        nci = small_div(p0 + np - 1, R.khkw1) - i0 + 1;
+        n_slots = (small_div(r0 + nr - 1, R.pc_go) - g0 + 1) * nci;
         for (int i = tid; i < 2 * n_slots; i += kBlock) sh_slot[i] = 0u;
     }
     stamp(tr, 2);
@@ -249,7 +261,7 @@ __device__ __forceinline__ double row_tile(const LeRelDev& R, const LeParams& p,
         float s, inv, mn1, mx1, mn2, mx2;
         channel_scale(R, p, cur, c, s, inv, mn1, mx1, mn2, mx2);
         sh_s[tid] = s;
-        if (emit) sh_g[tid] = (c / R.pc_go - g0) * nci;
+        if (emit) sh_g[tid] = (small_div(c, R.pc_go) - g0) * nci;
         if (own) {
             R.s_cum[c] = o_cum * s;                       // relation.py:20-24
             if (R.bnw) R.bnw[c] = o_bnw * s;              // dfq.py:64-65
@@ -269,7 +281,7 @@ __device__ __forceinline__ double row_tile(const LeRelDev& R, const LeParams& p,
     double acc = 0.0;
     int ci[VEC];
 #pragma unroll
-    for (int k = 0; k < VEC; ++k) ci[k] = emit ? ((pos + k) / R.khkw1 - i0) : 0;
+    for (int k = 0; k < VEC; ++k) ci[k] = emit ? (small_div(pos + k, R.khkw1) - i0) : 0;
     float cmn[VEC], cmx[VEC];
 #pragma unroll
     for (int k = 0; k < VEC; ++k) { cmn[k] = INFINITY; cmx[k] = -INFINITY; }
@@ -323,8 +335,9 @@ __device__ __forceinline__ double row_tile(const LeRelDev& R, const LeParams& p,
         for (int sl = tid; sl < n_slots; sl += kBlock) {
             const uint32_t a = sh_slot[2 * sl + 0], b = sh_slot[2 * sl + 1];
             if (b != 0u) {
-                const int g = g0 + sl / nci;
-                const int i = i0 + sl % nci;
+                const int gq = small_div(sl, nci);
+                const int g = g0 + gq;
+                const int i = i0 + sl - gq * nci;
                 guint* dst = (guint*)R.out_cols + (int64_t)nxt * R.stat_stride + 2 * ((int64_t)g * R.pc_gi + i);
                 atomicMax((unsigned*)dst + 0, a);
                 atomicMax((unsigned*)dst + 1, b);
@@ -339,23 +352,24 @@ __device__ __forceinline__ double row_tile(const LeRelDev& R, const LeParams& p,
 template <int VEC>
 __device__ __forceinline__ double col_tile(const LeRelDev& R, const LeParams& p, int tile, int cur,
                                            float* sh_inv, uint32_t* sh_row, int* sh_tab, const LeTrace& tr) {
-    constexpr int NV = kRegs / VEC;
+    constexpr int NV = (VEC == 4) ? kSlotsVec4 : kSlotsVec1;
     const int tid = threadIdx.x;
-    const int slab = tile % R.ct_slabs;
-    const int r0 = (tile / R.ct_slabs) * R.ct_rows;
+    const int rblk = small_div(tile, R.ct_slabs);
+    const int slab = tile - rblk * R.ct_slabs;
+    const int r0 = rblk * R.ct_rows;
     const int nr = min(R.ct_rows, R.o2 - r0);
     const int row_len2 = R.i2g * R.khkw;
     const int p0 = slab * R.ct_cols;
     const int np = min(R.ct_cols, row_len2 - p0);
     const int npv = np / VEC;                              // <= kColTileLanes by plan
-    int G = 1;
-    while (G < npv) G <<= 1;
-    const int n_rowslots = kBlock / G;                     // rows in flight
-    const int grp = tid / G;
+    int G = 1, lgG = 0;
+    while (G < npv) { G <<= 1; ++lgG; }
+    const int n_rowslots = kBlock >> lgG;                  // rows in flight
+    const int grp = tid >> lgG;
     const int ln = tid - grp * G;
     const bool lane_on = ln < npv;
     const int pos = p0 + min(ln, npv - 1) * VEC;
-    const int n_max = min(NV, (nr + n_rowslots - 1) / n_rowslots);   // register slots in use (block-uniform)
+    const int n_max = min(NV, (nr + n_rowslots - 1) >> (8 - lgG));     // register slots in use (block-uniform)
     const int nxt = cur ^ 1;
     const int mode = R.diff2;
     const bool emit = R.out_rows != nullptr;
@@ -382,13 +396,13 @@ __device__ __forceinline__ double col_tile(const LeRelDev& R, const LeParams& p,
     }
 
     // 1/s table of the tile: (groups spanned by the rows) x (input channels spanned by the columns)
-    const int i0 = p0 / R.khkw;
-    const int nci = (p0 + np - 1) / R.khkw - i0 + 1;
-    const int g_lo = r0 / R.go;
-    const int g_n = (r0 + nr - 1) / R.go - g_lo + 1;
+    const int i0 = small_div(p0, R.khkw);
+    const int nci = small_div(p0 + np - 1, R.khkw) - i0 + 1;
+    const int g_lo = small_div(r0, R.go);
+    const int g_n = small_div(r0 + nr - 1, R.go) - g_lo + 1;
     stamp(tr, 2);
     for (int idx = tid; idx < g_n * nci; idx += kBlock) {      // one entry per thread for every plan-made tile
-        const int gq = idx / nci;
+        const int gq = small_div(idx, nci);
         const int g = g_lo + gq;
         const int c = g * R.gi + i0 + (idx - gq * nci);
         float s, inv, mn1, mx1, mn2, mx2;
@@ -401,7 +415,7 @@ __device__ __forceinline__ double col_tile(const LeRelDev& R, const LeParams& p,
             f[1] = enc_ord(mx2 * inv);
         }
     }
-    if (tid < nr) sh_tab[tid] = ((r0 + tid) / R.go - g_lo) * nci;
+    if (tid < nr) sh_tab[tid] = (small_div(r0 + tid, R.go) - g_lo) * nci;
     stamp(tr, 3);
     __syncthreads();
     stamp(tr, 4);
@@ -409,7 +423,7 @@ __device__ __forceinline__ double col_tile(const LeRelDev& R, const LeParams& p,
     double acc = 0.0;
     int ci[VEC];
 #pragma unroll
-    for (int k = 0; k < VEC; ++k) ci[k] = (pos + k) / R.khkw - i0;
+    for (int k = 0; k < VEC; ++k) ci[k] = small_div(pos + k, R.khkw) - i0;
 #pragma unroll
     for (int u = 0; u < NV; ++u) {
         if (u >= n_max) continue;
@@ -475,8 +489,6 @@ __global__ __launch_bounds__(kBlock) void le_level_kernel(LevelArgs args, LePara
     __shared__ float sh_f[kSlotMax];                // row tile: scales; col tile: 1/s table
     __shared__ uint32_t sh_u[2 * kSlotMax];         // row tile: column-stat slots; col tile: row stats
     __shared__ int sh_g[kTileRowsMax];              // per-row table offsets
-    __shared__ double sh_red[kBlock / kWave];
-
     const int lane = threadIdx.x % kWave;
     const DFQ_CONSTANT_AS uint32_t* ka = (const DFQ_CONSTANT_AS uint32_t*)__builtin_amdgcn_kernarg_segment_ptr();
     uint32_t word = 0u;
@@ -501,8 +513,9 @@ __global__ __launch_bounds__(kBlock) void le_level_kernel(LevelArgs args, LePara
                             : col_tile<1>(R, p, tile - R.n_row_tiles, cur, sh_f, sh_u, sh_g, tr);
     }
     stamp(tr, 6);
-    const double t = block_sum(acc, sh_red);
-    if (threadIdx.x == 0) partials[R.partial_base + tile] = t;
+    // one partial per wave (fixed butterfly order -> deterministic), no workgroup barrier
+    const double t = wave_sum(acc);
+    if (lane == 0) partials[(int64_t)(R.partial_base + tile) * (kBlock / kWave) + threadIdx.x / kWave] = t;
     stamp(tr, 7);
 }
 
@@ -608,8 +621,9 @@ __global__ __launch_bounds__(kCtlBlock) void le_control_kernel(const LeLayerDiff
         const LeLayerDiff L = (l < 1024) ? sh_layer[l] : layers[l];
         double s = 0.0;
         if (L.partial_begin >= 0) {
-            for (int i = lane; i < L.n_partials; i += kWave) {
-                const int idx = L.partial_begin + i;
+            // every tile left one partial per wave
+            for (int i = lane; i < L.n_partials * (kBlock / kWave); i += kWave) {
+                const int idx = L.partial_begin * (kBlock / kWave) + i;
                 s += (idx < n_stage) ? sh_part[idx] : partials[idx];
             }
             s = wave_sum(s);
@@ -693,7 +707,7 @@ static int tile_target() {     // elements per tile; DFQ_LE_TILE_ELEMS overrides
 static int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
 // [rows x cols] tiling of a [n_rows, row_len] matrix whose tiles move `vec`-wide vectors:
-// cols = slab width (multiple of vec, <= cols_max), rows so that a thread holds <= kRegs floats.
+// cols = slab width (multiple of vec, <= cols_max), rows so that a thread holds <= its register slots.
 static void tile_shape(int n_rows, int row_len, int vec, int cols_max, bool pow2_lanes, int target,
                        int* rows, int* cols, int* slabs) {
     int s = ceil_div(row_len, cols_max);
@@ -704,7 +718,7 @@ static void tile_shape(int n_rows, int row_len, int vec, int cols_max, bool pow2
     const int rows_in_flight = kBlock / lanes;
     if (vec == 1) target = std::min(target, 2048);    // scalar tiles: one memory instruction per float
     int r = std::max(1, target / c);
-    r = std::min(r, (kRegs / vec) * rows_in_flight);  // register preload capacity
+    r = std::min(r, (vec == 4 ? kSlotsVec4 : kSlotsVec1) * rows_in_flight);  // register preload capacity
     r = std::min(r, std::min(kTileRowsMax, n_rows));
     *rows = r; *cols = c; *slabs = s;
 }
@@ -742,8 +756,9 @@ int dfq_le_plan_create(const dfq_layer* layers, int32_t n_layers, const dfq_rela
         const int G = (o1 != i2g) ? (o1 / i2g) : 1;
         if (G < 1 || o1 != G * i2g || B.out_ch % G != 0)
             return fail_arg("dfq_le_plan_create: relation %d: unsupported pairing O1=%d, I2/g=%d, O2=%d", r, o1, i2g, B.out_ch);
-        if ((int64_t)A.in_per_group * A.khkw > (1 << 22) || (int64_t)B.in_per_group * B.khkw > (1 << 22))
-            return fail_arg("dfq_le_plan_create: relation %d: row too long", r);
+        if ((int64_t)A.in_per_group * A.khkw >= (1 << 20) || (int64_t)B.in_per_group * B.khkw >= (1 << 20) ||
+            A.out_ch >= (1 << 20) || B.out_ch >= (1 << 20))
+            return fail_arg("dfq_le_plan_create: relation %d: layer dimension >= 2^20", r);
         if (as_first[rr.first] >= 0 || as_second[rr.second] >= 0)
             return fail_arg("dfq_le_plan_create: relation %d: a layer may be first in one relation and second in one "
                             "relation only (utils/relation.py:57-67)", r);
@@ -907,7 +922,7 @@ int dfq_le_plan_create(const dfq_layer* layers, int32_t n_layers, const dfq_rela
     for (const LevelLaunch& L : p->levels) p->snapshot_total += L.snapshot;
     p->boot_blocks = boot;
 
-    const size_t n_part = (size_t)std::max(1, p->total_tiles);
+    const size_t n_part = (size_t)std::max(1, p->total_tiles) * (kBlock / kWave);
     if ((e = hipMalloc((void**)&p->d_rels, sizeof(LeRelDev) * std::max(1, n_relations))) != hipSuccess) return fail_alloc(e);
     if ((e = hipMalloc((void**)&p->d_layer_diff, sizeof(LeLayerDiff) * n_layers)) != hipSuccess) return fail_alloc(e);
     if ((e = hipMalloc((void**)&p->d_partials, sizeof(double) * n_part)) != hipSuccess) return fail_alloc(e);
@@ -980,7 +995,7 @@ static int le_launch_level(dfq_le_plan* p, const LevelLaunch& L, const LeParams&
 static int le_launch_control(dfq_le_plan* p, const dfq_le_config* cfg, hipStream_t st) {
     const int n_clear = (int)std::min<int64_t>(32, (p->stat_words + p->r1_zero_words + 4 * kCtlBlock - 1) / (4 * kCtlBlock));
     hipLaunchKernelGGL(le_control_kernel, dim3(1 + std::max(1, n_clear)), dim3(kCtlBlock), 0, st, (const LeLayerDiff*)p->d_layer_diff,
-                       p->n_layers, (const double*)p->d_partials, p->total_tiles, p->d_layer_mean, p->d_stats,
+                       p->n_layers, (const double*)p->d_partials, p->total_tiles * (kBlock / kWave), p->d_layer_mean, p->d_stats,
                        (int64_t)p->stat_words, p->d_stats + 2 * p->stat_words, (int64_t)p->stat_words,
                        (int64_t)p->r1_zero_words, (int)(p->sweep_index & 1),
                        p->d_state, cfg->converge_thres, (int)cfg->converge_count, (int)cfg->max_sweeps);

@@ -110,6 +110,7 @@ inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v
 inline double atomicAdd(double* p, double v) { double o = *p; *p = o + v; return o; }
 
 inline long long clock64() { return 0; }
+inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
 
 using std::max;
 using std::min;

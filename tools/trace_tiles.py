@@ -4,7 +4,9 @@ import bench
 from dfq_amd import dfq
 dev = torch.device('cuda', 0)
 proto = bench.prepare('mobilenet_v2', 0, dev)
-for launch in range(5):
+import os
+print('ablate', os.environ.get('DFQ_LE_ABLATE'))
+for launch in (1, 4):
     rep = bench.make_replica(proto)
     info = rep['le'].level_info(launch)
     gx, gy = info['grid']
