@@ -81,7 +81,7 @@ struct LeRelDev {
     int32_t o1, row_len, khkw1;
     int32_t pc_go, pc_gi;                // W1 element (o, i) -> channel (o / pc_go) * pc_gi + i of out_cols
     int32_t o2, gi, go, i2g, khkw;       // W2 geometry; paired channel c = g*gi + ii
-    int32_t rt_rows, rt_cols, rt_slabs, rt_vec, n_row_tiles;
+    int32_t rt_rows, rt_cols, rt_slabs, rt_vec, n_row_tiles;   // *_vec: 4 float4 tiles, 1 scalar tiles, 0 thread-per-row
     int32_t ct_rows, ct_cols, ct_slabs, ct_vec, n_col_tiles;
     int32_t diff1, diff2;
     int32_t partial_base;   // first partial slot of this relation (row tiles, then col tiles)
@@ -149,7 +149,9 @@ __device__ __forceinline__ void le_solve(float r1, float r2, const LeParams& p, 
 }
 
 __device__ __forceinline__ float range_of(float mn, float mx, int signed_range) {
-    if (signed_range) return fmaxf(fabsf(mn), fabsf(mx));
+    // max(|mn|, |mx|) == max(mx, -mn) whenever mn <= mx.  (Written without fabsf(): the abs source
+    // modifier folded into the following select trips an instruction-selection bug of this compiler.)
+    if (signed_range) return fmaxf(mx, -mn);
     return mx - mn;
 }
 
@@ -474,6 +476,88 @@ __device__ __forceinline__ double col_tile(const LeRelDev& R, const LeParams& p,
     return acc;
 }
 
+// ---------------------------------------------------------------------------------------------
+// short-row tile: one THREAD per row (depthwise k x k kernels: 9 or 25 floats per row).  The row's
+// scale depends on a single paired channel, its statistics stay in the thread's registers: no LDS,
+// no barrier, no cross-lane traffic.  side 0: W1 rows (scale s, row == paired channel, emits the
+// per-row stats the previous relation needs as its column stats); side 1: W2 rows of a depthwise
+// second layer (scale 1/s of its single input channel, emits row stats for the next relation).
+// ---------------------------------------------------------------------------------------------
+template <int side>
+__device__ __forceinline__ double short_tile(const LeRelDev& R, const LeParams& p, int tile, int cur) {
+    const int tid = threadIdx.x;
+    const int nxt = cur ^ 1;
+    const int n_rows = side == 0 ? R.o1 : R.o2;
+    const int len = side == 0 ? R.row_len : R.khkw;          // side 1: I2/g == 1, row = khkw floats
+    const int o = min(tile * kBlock + tid, n_rows - 1);
+    const bool ok = tile * kBlock + tid < n_rows;
+    gfloat* const w = (gfloat*)(side == 0 ? R.w1 : R.w2) + (int64_t)o * len;
+    gfloat* const pv = (gfloat*)(side == 0 ? R.prev1 : R.prev2) + (int64_t)o * len;
+    const int mode = side == 0 ? R.diff1 : R.diff2;
+    const int c = side == 0 ? o : small_div(o, R.go) * R.gi;  // paired channel that scales this row
+
+    float o_cum = 0.f, o_bnw = 0.f, o_bnb = 0.f, o_b1 = 0.f;
+    if (side == 0) {
+        o_cum = R.s_cum[c];
+        if (R.bnw) o_bnw = R.bnw[c];
+        if (R.bnb) o_bnb = R.bnb[c];
+        if (R.b1) o_b1 = R.b1[c];
+    }
+    float s, inv, mn1, mx1, mn2, mx2;
+    channel_scale(R, p, cur, c, s, inv, mn1, mx1, mn2, mx2);
+    const float f = side == 0 ? s : inv;
+    if (side == 0 && ok) {
+        R.s_cum[c] = o_cum * s;                       // relation.py:20-24
+        if (R.bnw) R.bnw[c] = o_bnw * s;              // dfq.py:64-65
+        if (R.bnb) R.bnb[c] = o_bnb * s;              // dfq.py:67-68
+        if (R.b1) R.b1[c] = o_b1 * s;                 // dfq.py:70-71
+    }
+    double acc = 0.0;
+    float rmn = INFINITY, rmx = -INFINITY;
+    // the whole row sits in one or two cache lines: a plain loop, the first load pays the latency
+#pragma unroll 1
+    for (int k = 0; k < len; ++k) {
+        const float x = w[k];
+        const float nv = x * f;                       // dfq.py:62 / dfq.py:73
+        if (ok) w[k] = nv;
+        if (mode == DIFF_SAVE) {
+            if (ok) pv[k] = x;
+        } else {
+            // |d| taken in float64 (exact widening): fabsf() folded into the select trips an
+            // instruction-selection bug of this compiler in this function
+            const float ref = (mode == DIFF_DIRECT) ? x : pv[k];
+            const double d = (double)(nv - ref);
+            acc += ok ? fabs(d) : 0.0;
+        }
+        rmn = fminf(rmn, nv);
+        rmx = fmaxf(rmx, nv);
+    }
+    if (ok) {
+        if (side == 0) {
+            if (R.out_cols) {      // row o of W1 is channel o * pc_gi of the relation that has W1 as second layer
+                uint32_t* dst = R.out_cols + (int64_t)nxt * R.stat_stride + 2 * ((int64_t)o * R.pc_gi);
+                dst[0] = ~enc_ord(rmn);
+                dst[1] = enc_ord(rmx);
+            } else {               // chain start: forward the row stats
+                uint32_t* fwd = R.r1 + (int64_t)nxt * R.stat_stride + 2 * c;
+                fwd[0] = ~enc_ord(mn1 * s);
+                fwd[1] = enc_ord(mx1 * s);
+            }
+        } else {
+            if (R.out_rows) {
+                uint32_t* dst = R.out_rows + (int64_t)cur * R.stat_stride + 2 * o;
+                dst[0] = ~enc_ord(rmn);
+                dst[1] = enc_ord(rmx);
+            } else if (o == small_div(o, R.go) * R.go) {   // chain end: first row of the group forwards
+                uint32_t* fwd = R.r2 + (int64_t)nxt * R.stat_stride + 2 * c;
+                fwd[0] = ~enc_ord(mn2 * inv);
+                fwd[1] = enc_ord(mx2 * inv);
+            }
+        }
+    }
+    return acc;
+}
+
 constexpr int kDescWords = (int)(sizeof(LeRelDev) / 4);
 static_assert(sizeof(LeRelDev) % 4 == 0 && kDescWords + 1 <= kWave, "descriptor must fit one wave-wide load");
 
@@ -506,11 +590,13 @@ __global__ __launch_bounds__(kBlock) void le_level_kernel(LevelArgs args, LePara
 
     double acc;
     if (tile < R.n_row_tiles) {
-        acc = R.rt_vec == 4 ? row_tile<4>(R, p, tile, cur, sh_f, sh_u, sh_g, tr)
-                            : row_tile<1>(R, p, tile, cur, sh_f, sh_u, sh_g, tr);
+        if (R.rt_vec == 0) acc = short_tile<0>(R, p, tile, cur);
+        else acc = R.rt_vec == 4 ? row_tile<4>(R, p, tile, cur, sh_f, sh_u, sh_g, tr)
+                                 : row_tile<1>(R, p, tile, cur, sh_f, sh_u, sh_g, tr);
     } else {
-        acc = R.ct_vec == 4 ? col_tile<4>(R, p, tile - R.n_row_tiles, cur, sh_f, sh_u, sh_g, tr)
-                            : col_tile<1>(R, p, tile - R.n_row_tiles, cur, sh_f, sh_u, sh_g, tr);
+        if (R.ct_vec == 0) acc = short_tile<1>(R, p, tile - R.n_row_tiles, cur);
+        else acc = R.ct_vec == 4 ? col_tile<4>(R, p, tile - R.n_row_tiles, cur, sh_f, sh_u, sh_g, tr)
+                                 : col_tile<1>(R, p, tile - R.n_row_tiles, cur, sh_f, sh_u, sh_g, tr);
     }
     stamp(tr, 6);
     // one partial per wave (fixed butterfly order -> deterministic), no workgroup barrier
@@ -852,6 +938,9 @@ int dfq_le_plan_create(const dfq_layer* layers, int32_t n_layers, const dfq_rela
                    &d.rt_rows, &d.rt_cols, &d.rt_slabs);
         tile_shape(d.o2, row_len2, d.ct_vec, kColTileLanes * d.ct_vec, true, target,
                    &d.ct_rows, &d.ct_cols, &d.ct_slabs);
+        if (d.i2g == 1 && d.khkw <= 32 && d.khkw != 1) {     // depthwise second layer: one thread per row
+            d.ct_vec = 0; d.ct_rows = kBlock; d.ct_cols = row_len2; d.ct_slabs = 1;
+        }
         // 1/s table of a col tile: (#groups spanned by its rows) x (#input channels spanned by its columns)
         const int nci2 = ceil_div(d.ct_cols, d.khkw) + 1;
         while (d.ct_rows > 1 && (ceil_div(d.ct_rows, d.go) + 1) * nci2 > kSlotMax) d.ct_rows = (d.ct_rows + 1) / 2;
@@ -878,6 +967,11 @@ int dfq_le_plan_create(const dfq_layer* layers, int32_t n_layers, const dfq_rela
             d.out_cols = nullptr; d.pc_go = 1; d.pc_gi = 1;
         }
         d.out_rows = (j_next >= 0) ? h[j_next].r1 : nullptr;
+        // depthwise-like first layer (one input channel per row, k x k kernel): one thread per row, provided
+        // every row is its own channel of the stat consumer
+        if (d.khkw1 == d.row_len && d.row_len <= 32 && d.row_len != 1 && (j_prev < 0 || d.pc_go == 1)) {
+            d.rt_vec = 0; d.rt_rows = kBlock; d.rt_cols = d.row_len; d.rt_slabs = 1;
+        }
         d.n_row_tiles = ceil_div(d.o1, d.rt_rows) * d.rt_slabs;
         d.n_col_tiles = ceil_div(d.o2, d.ct_rows) * d.ct_slabs;
         d.partial_base = tile_slot;
