@@ -166,6 +166,15 @@ __device__ __forceinline__ void channel_scale(const LeRelDev& R, const LeParams&
     le_solve(range_of(mn1, mx1, p.signed_range), range_of(mn2, mx2, p.signed_range), p, s, inv);
 }
 
+// |a - b| if `on`, else 0 -- the contribution of one element to sum|W - W_prev|.  The select is done
+// on the float32 difference and the magnitude taken afterwards by clearing the sign bit: the pattern
+// select(on, (double)fabsf(d), 0.0) made this compiler fold the abs source modifier into one half of
+// the 64-bit select ("Illegal instruction detected: Operand has incorrect register class").
+__device__ __forceinline__ float abs_diff_if(bool on, float a, float b) {
+    const float d = on ? (a - b) : 0.0f;
+    return __uint_as_float(__float_as_uint(d) & 0x7fffffffu);
+}
+
 template <int VEC>
 __device__ __forceinline__ void vload(const gfloat* p, float (&x)[VEC]) {
     if (VEC == 4) {
@@ -304,7 +313,7 @@ __device__ __forceinline__ double row_tile(const LeRelDev& R, const LeParams& p,
 #pragma unroll
             for (int k = 0; k < VEC; ++k) {
                 const float ref = (mode == DIFF_DIRECT) ? v[u][k] : q[u][k];
-                acc += ok ? (double)fabsf(nv[k] - ref) : 0.0;
+                acc += (double)abs_diff_if(ok, nv[k], ref);
             }
         }
         if (emit && ok) {
@@ -443,7 +452,7 @@ __device__ __forceinline__ double col_tile(const LeRelDev& R, const LeParams& p,
 #pragma unroll
             for (int k = 0; k < VEC; ++k) {
                 const float ref = (mode == DIFF_DIRECT) ? v[u][k] : q[u][k];
-                acc += ok ? (double)fabsf(nv[k] - ref) : 0.0;
+                acc += (double)abs_diff_if(ok, nv[k], ref);
             }
         }
         if (emit) {                                        // block-uniform: every lane reaches the shuffles
@@ -523,11 +532,8 @@ __device__ __forceinline__ double short_tile(const LeRelDev& R, const LeParams& 
         if (mode == DIFF_SAVE) {
             if (ok) pv[k] = x;
         } else {
-            // |d| taken in float64 (exact widening): fabsf() folded into the select trips an
-            // instruction-selection bug of this compiler in this function
             const float ref = (mode == DIFF_DIRECT) ? x : pv[k];
-            const double d = (double)(nv - ref);
-            acc += ok ? fabs(d) : 0.0;
+            acc += (double)abs_diff_if(ok, nv, ref);
         }
         rmn = fminf(rmn, nv);
         rmx = fmaxf(rmx, nv);

@@ -133,6 +133,36 @@ def test_layer_equalization_pairs(engine, name):
     assert_close(npy(S), g['{}.out.S'.format(name)], name + ' S vs reference')
 
 
+_SHAPES = [
+    ((96, 16, 1, 1), (96, 1, 3, 3)),        # expand pw -> depthwise 3x3 (thread-per-row col side)
+    ((96, 1, 3, 3), (24, 96, 1, 1)),        # depthwise -> project pw (thread-per-row row side)
+    ((40, 1, 5, 5), (40, 40, 1, 1)),        # depthwise 5x5 (25 floats per row)
+    ((64, 24, 1, 1), (128, 1, 3, 3)),       # depthwise with channel multiplier 2
+    ((300, 160, 1, 1), (77, 300, 1, 1)),    # float4 tiles, several slabs and row blocks
+    ((33, 7, 3, 3), (20, 33, 3, 3)),        # odd sizes: scalar tiles
+    ((48, 6, 3, 3), (96, 12, 3, 3)),        # grouped second layer (groups = 4)
+    ((130, 516), (9, 130)),                 # linear -> linear
+]
+
+
+@pytest.mark.parametrize('s1,s2', _SHAPES)
+@pytest.mark.parametrize('signed', [False, True])
+def test_layer_equalization_shapes(engine, s1, s2, signed):
+    """One sweep of one pair over the tile kinds of the kernel, bit-exact against the oracle."""
+    rng = np.random.default_rng(abs(hash((s1, s2))) % (2 ** 31))
+    w1 = rng.standard_normal(s1).astype(F32)
+    w2 = (rng.standard_normal(s2) * 0.2).astype(F32)
+    b1 = rng.standard_normal(s1[0]).astype(F32)
+    bw = np.abs(rng.standard_normal(s1[0])).astype(F32)
+    bb = rng.standard_normal(s1[0]).astype(F32)
+    t = [engine.to(torch.from_numpy(a.copy())) for a in (w1, w2, b1, bw, bb)]
+    _, _, _, S = dfq._layer_equalization(t[0], t[1], t[2], t[3], t[4], signed=signed)
+    S_o = orc.layer_equalization(w1, w2, b1, bw, bb, signed=signed)
+    assert_bitexact(npy(S), S_o, 'S')
+    for got, want, what in zip(t, (w1, w2, b1, bw, bb), ('w1', 'w2', 'b1', 'bn_weight', 'bn_bias')):
+        assert_bitexact(npy(got), want, what)
+
+
 def test_layer_equalization_large_rows(engine):
     """Rows longer than a workgroup, tiles of one channel, 3x3 second layer (ResNet-like)."""
     rng = np.random.default_rng(21)
