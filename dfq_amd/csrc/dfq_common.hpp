@@ -51,13 +51,18 @@ inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s);
 // enc is monotone in the float order (-inf < ... < -0 < +0 < ... < +inf).  A "max slot" holds
 // atomicMax(enc(x)), a "min slot" holds atomicMax(~enc(x)); both have identity 0, so one memset
 // initialises any number of slots.
+// Both directions are written as one XOR with a mask built from the arithmetic-shifted sign -- no
+// select and no `& 0x7fffffff`: this compiler pattern-matches those into a v_cndmask with an abs
+// source modifier, and that fold produced wrong code in one of the LE tile kernels (the result
+// changed with unrelated edits to the function; see DESIGN.md "toolchain notes").
 __device__ __forceinline__ uint32_t enc_ord(float f) {
     const uint32_t u = __float_as_uint(f);
-    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    const uint32_t sign = (uint32_t)((int32_t)u >> 31);          // all ones for negative floats
+    return u ^ (sign | 0x80000000u);                             // negative: ~u, else: set the top bit
 }
 __device__ __forceinline__ float dec_ord(uint32_t e) {
-    const uint32_t u = (e & 0x80000000u) ? (e & 0x7fffffffu) : ~e;
-    return __uint_as_float(u);
+    const uint32_t top = (uint32_t)((int32_t)e >> 31);           // all ones if the top bit is set
+    return __uint_as_float(e ^ (~top | 0x80000000u));            // top set: clear it, else: ~e
 }
 __device__ __forceinline__ float slot_max(uint32_t slot) { return dec_ord(slot); }
 __device__ __forceinline__ float slot_min(uint32_t slot) { return dec_ord(~slot); }

@@ -944,7 +944,8 @@ int dfq_le_plan_create(const dfq_layer* layers, int32_t n_layers, const dfq_rela
                    &d.rt_rows, &d.rt_cols, &d.rt_slabs);
         tile_shape(d.o2, row_len2, d.ct_vec, kColTileLanes * d.ct_vec, true, target,
                    &d.ct_rows, &d.ct_cols, &d.ct_slabs);
-        if (d.i2g == 1 && d.khkw <= 32 && d.khkw != 1) {     // depthwise second layer: one thread per row
+        const bool allow_short = getenv("DFQ_LE_NO_SHORT") == nullptr;
+        if (allow_short && d.i2g == 1 && d.khkw <= 32 && d.khkw != 1) {     // depthwise second layer: one thread per row
             d.ct_vec = 0; d.ct_rows = kBlock; d.ct_cols = row_len2; d.ct_slabs = 1;
         }
         // 1/s table of a col tile: (#groups spanned by its rows) x (#input channels spanned by its columns)
@@ -975,7 +976,7 @@ int dfq_le_plan_create(const dfq_layer* layers, int32_t n_layers, const dfq_rela
         d.out_rows = (j_next >= 0) ? h[j_next].r1 : nullptr;
         // depthwise-like first layer (one input channel per row, k x k kernel): one thread per row, provided
         // every row is its own channel of the stat consumer
-        if (d.khkw1 == d.row_len && d.row_len <= 32 && d.row_len != 1 && (j_prev < 0 || d.pc_go == 1)) {
+        if (getenv("DFQ_LE_NO_SHORT") == nullptr && d.khkw1 == d.row_len && d.row_len <= 32 && d.row_len != 1 && (j_prev < 0 || d.pc_go == 1)) {
             d.rt_vec = 0; d.rt_rows = kBlock; d.rt_cols = d.row_len; d.rt_slabs = 1;
         }
         d.n_row_tiles = ceil_div(d.o1, d.rt_rows) * d.rt_slabs;
