@@ -7,8 +7,13 @@
 //        E[x] from the BN proxies (ReLU moment matching dfq.py:182-184,238-242; add/cat merge
 //        :244-270)  ->  bias[g] = eps[g] . E[g] (:281-287)  ->  b -= bias (:290-292)  ->
 //        next BN's beta~ += -bias (:204-206, 293).
-// Stage 3 is inherently serial across layers (each correction feeds the next expectation); the
-// stream order carries that dependency, no host synchronisation is involved.
+// Stage 3 is inherently serial across layers (each correction feeds the next expectation, and every
+// output row needs the whole expectation vector); the stream order carries that dependency, no host
+// synchronisation is involved.  The float64 pdf/cdf evaluation of the ReLU moment is done ONCE per
+// BN channel: a BN's beta~ changes exactly once (when the layer in front of it is corrected), so the
+// thread that applies that update also refreshes the channel's cached E[ReLU(.)]; a step then only
+// gathers cached values.
+#include <map>
 #include <vector>
 
 #include "dfq_common.hpp"
@@ -28,9 +33,12 @@ struct BcLayerDev {
     int32_t pad;
 };
 
+constexpr int kStepSources = 6;        // sources of a step carried in the kernarg
+
 struct BcSourceDev {
     const float* fw;
     const float* fb;
+    const float* cache;      // relu_mean(fw, fb) per channel, kept current by the producing step
     int32_t channels, relu, concat, pad;
 };
 
@@ -38,8 +46,18 @@ struct BcStepDev {
     const float* eps;
     float* bias;             // layer bias [O], in/out
     float* next_bn_bias;     // [O] or null
+    const float* next_bn_weight;   // gamma~ of that BN (null if nobody reads its ReLU moment)
+    float* next_cache;       // its relu_mean cache
     float* corr;             // [O] out: the correction `bias` of dfq.py:285-287
-    int32_t out_ch, in_per_group, source_begin, source_count, expect_len, pad;
+    int32_t out_ch, in_per_group, source_begin, source_count, expect_len, inline_sources;
+    BcSourceDev src[kStepSources];   // copy of sources[source_begin ...] when source_count <= kStepSources
+};
+
+struct BcCacheSeg {          // one BN whose ReLU moment is cached
+    const float* fw;
+    const float* fb;
+    float* cache;
+    int32_t channels, begin; // begin: first global channel index of this segment in the init launch
 };
 
 __device__ __forceinline__ int bc_find(const int32_t* __restrict__ begin, int n, int block) {
@@ -127,18 +145,32 @@ __device__ __forceinline__ float relu_mean(float w, float b) {
     return e;
 }
 
+// ReLU moments of every cached BN from the current beta~ (once per run, all BNs in one launch)
+__global__ __launch_bounds__(kBlock) void bc_cache_init_kernel(const BcCacheSeg* __restrict__ segs, int n_segs, int total) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= total) return;
+    int lo = 0, hi = n_segs - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (segs[mid].begin <= i) lo = mid; else hi = mid - 1;
+    }
+    const BcCacheSeg sg = segs[lo];
+    const int c = i - sg.begin;
+    sg.cache[c] = relu_mean(sg.fw[c], sg.fb[c]);
+}
+
 __global__ __launch_bounds__(kBlock) void bc_step_kernel(BcStepDev st, const BcSourceDev* __restrict__ sources) {
     __shared__ float sh_E[kExpectMax];
     const int tid = threadIdx.x;
     // ---- E[x]: first source assigns, 'cat' appends, anything else adds (dfq.py:229-270) ----
     int cur_len = 0;
     for (int m = 0; m < st.source_count; ++m) {
-        const BcSourceDev s = sources[st.source_begin + m];
+        const BcSourceDev s = st.inline_sources ? st.src[m] : sources[st.source_begin + m];
         const bool assign = (m == 0) || (s.concat != 0);
         const int base = (m == 0) ? 0 : (s.concat ? cur_len : 0);
+        const float* val = s.relu ? s.cache : s.fb;      // E[ReLU(N(beta, gamma^2))] or beta
         for (int i = tid; i < s.channels; i += kBlock) {
-            const float fb = s.fb[i];
-            const float e = s.relu ? relu_mean(s.fw[i], fb) : fb;
+            const float e = val[i];
             if (assign) sh_E[base + i] = e;
             else sh_E[i] = sh_E[i] + e;
         }
@@ -164,7 +196,11 @@ __global__ __launch_bounds__(kBlock) void bc_step_kernel(BcStepDev st, const BcS
             const float neg = -corr;
             st.corr[o] = corr;
             st.bias[o] = st.bias[o] + neg;                            // dfq.py:292
-            if (st.next_bn_bias) st.next_bn_bias[o] = st.next_bn_bias[o] + neg;   // dfq.py:204-206, 293
+            if (st.next_bn_bias) {
+                const float nb = st.next_bn_bias[o] + neg;            // dfq.py:204-206, 293
+                st.next_bn_bias[o] = nb;
+                if (st.next_cache) st.next_cache[o] = relu_mean(st.next_bn_weight[o], nb);
+            }
         }
     }
 }
@@ -186,6 +222,9 @@ struct dfq_bc_plan {
     uint32_t* d_slots = nullptr;
     float* d_eps = nullptr;                // all eps matrices, back to back
     float* d_corr = nullptr;               // all correction vectors, back to back
+    float* d_cache = nullptr;              // ReLU moments of the BNs that some step reads through a ReLU
+    BcCacheSeg* d_cache_segs = nullptr;
+    int n_cache_segs = 0, cache_total = 0;
 };
 
 extern "C" {
@@ -199,6 +238,8 @@ void dfq_bc_plan_destroy(dfq_bc_plan* p) {
     if (p->d_slots) (void)hipFree(p->d_slots);
     if (p->d_eps) (void)hipFree(p->d_eps);
     if (p->d_corr) (void)hipFree(p->d_corr);
+    if (p->d_cache) (void)hipFree(p->d_cache);
+    if (p->d_cache_segs) (void)hipFree(p->d_cache_segs);
     delete p;
 }
 
@@ -254,9 +295,31 @@ int dfq_bc_plan_create(const dfq_layer* layers, int32_t n_layers, const dfq_bc_s
 
     std::vector<BcLayerDev> hl(n_steps);
     std::vector<int32_t> mmb(n_steps + 1), qeb(n_steps + 1);
+    // BNs read through a ReLU get a cache of their moment E[ReLU(N(beta~, gamma~^2))], keyed by beta~
+    std::map<const float*, int> cache_of;
+    std::vector<BcCacheSeg> segs;
+    int cache_total = 0;
+    for (int i = 0; i < n_sources; ++i) {
+        if (!sources[i].relu || cache_of.count(sources[i].fake_bias)) continue;
+        BcCacheSeg sg;
+        sg.fw = sources[i].fake_weight; sg.fb = sources[i].fake_bias; sg.cache = nullptr;
+        sg.channels = sources[i].channels; sg.begin = cache_total;
+        cache_of[sources[i].fake_bias] = (int)segs.size();
+        segs.push_back(sg);
+        cache_total += sources[i].channels;
+    }
+    if (cache_total > 0) {
+        if ((e = hipMalloc((void**)&p->d_cache, sizeof(float) * cache_total)) != hipSuccess) return fail_alloc(e);
+        if ((e = hipMalloc((void**)&p->d_cache_segs, sizeof(BcCacheSeg) * segs.size())) != hipSuccess) return fail_alloc(e);
+        for (BcCacheSeg& sg : segs) sg.cache = p->d_cache + sg.begin;
+        if ((e = hipMemcpy(p->d_cache_segs, segs.data(), sizeof(BcCacheSeg) * segs.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail_alloc(e);
+    }
+    p->n_cache_segs = (int)segs.size();
+    p->cache_total = cache_total;
     std::vector<BcSourceDev> hs(n_sources);
     for (int i = 0; i < n_sources; ++i) {
         hs[i].fw = sources[i].fake_weight; hs[i].fb = sources[i].fake_bias;
+        hs[i].cache = sources[i].relu ? segs[cache_of[sources[i].fake_bias]].cache : nullptr;
         hs[i].channels = sources[i].channels; hs[i].relu = sources[i].relu; hs[i].concat = sources[i].concat; hs[i].pad = 0;
     }
     p->steps.resize(n_steps);
@@ -273,7 +336,22 @@ int dfq_bc_plan_create(const dfq_layer* layers, int32_t n_layers, const dfq_bc_s
         BcStepDev& d = p->steps[s];
         d.eps = p->d_eps + eps_off; d.bias = L.bias; d.next_bn_bias = steps[s].next_bn_bias; d.corr = p->d_corr + corr_off;
         d.out_ch = L.out_ch; d.in_per_group = L.in_per_group; d.source_begin = steps[s].source_begin;
-        d.source_count = steps[s].source_count; d.expect_len = expect_len[s]; d.pad = 0;
+        d.source_count = steps[s].source_count; d.expect_len = expect_len[s];
+        d.inline_sources = d.source_count <= kStepSources ? 1 : 0;
+        for (int m = 0; m < kStepSources; ++m)
+            d.src[m] = (d.inline_sources && m < d.source_count) ? hs[d.source_begin + m] : BcSourceDev();
+        d.next_bn_weight = nullptr; d.next_cache = nullptr;
+        if (d.next_bn_bias) {
+            auto it = cache_of.find(d.next_bn_bias);
+            if (it != cache_of.end()) {
+                if (segs[it->second].channels != L.out_ch) {
+                    dfq_bc_plan_destroy(p);
+                    return fail_arg("dfq_bc_plan_create: step %d: next BN has %d channels, layer has %d", s, segs[it->second].channels, L.out_ch);
+                }
+                d.next_bn_weight = segs[it->second].fw;
+                d.next_cache = segs[it->second].cache;
+            }
+        }
         p->eps_ptr[s] = d.eps;
         p->weight_elems += hl[s].n;
         eps_off += pairs; corr_off += L.out_ch;
@@ -299,6 +377,11 @@ int dfq_bc_plan_run(dfq_bc_plan* p, int32_t symmetric, void* stream) {
     hipLaunchKernelGGL(bc_quant_error_kernel, dim3(p->qerr_blocks), dim3(kBlock), 0, st, (const BcLayerDev*)p->d_layers,
                        (const int32_t*)p->d_qe_begin, p->n_steps, (const uint32_t*)p->d_slots, 8, (int)symmetric);
     DFQ_CHECK_LAUNCH();
+    if (p->cache_total > 0) {
+        hipLaunchKernelGGL(bc_cache_init_kernel, dim3((p->cache_total + kBlock - 1) / kBlock), dim3(kBlock), 0, st,
+                           (const BcCacheSeg*)p->d_cache_segs, p->n_cache_segs, p->cache_total);
+        DFQ_CHECK_LAUNCH();
+    }
     for (int s = 0; s < p->n_steps; ++s) {
         const BcStepDev& d = p->steps[s];
         const int grid = (d.out_ch + kRowsPerBlock - 1) / kRowsPerBlock;

@@ -1122,7 +1122,7 @@ int dfq_le_enqueue(dfq_le_plan* p, const dfq_le_config* cfg, int32_t n_sweeps, i
 }
 
 int dfq_le_profile(dfq_le_plan* p, const dfq_le_config* cfg, int32_t n_sweeps, void* stream, double* level_ms,
-                   double* control_ms, int32_t* n_level_launches) {
+                   double* control_ms, int32_t* n_level_launches, double* empty_bracket_ms) {
     if (!p || !cfg || n_sweeps <= 0 || !level_ms) return fail_arg("dfq_le_profile: bad argument");
     hipStream_t st = as_stream(stream);
     const LeParams q = make_params(cfg);
@@ -1132,6 +1132,14 @@ int dfq_le_profile(dfq_le_plan* p, const dfq_le_config* cfg, int32_t n_sweeps, v
     for (auto& e : ev) DFQ_HIP_TRY(hipEventCreate(&e));
     int rc = le_restart(p, cfg, st);
     if (rc) return rc;
+    // what a pair of event records costs with nothing between them (subtracted by the caller)
+    const int n_cal = 32;
+    std::vector<hipEvent_t> cal((size_t)2 * n_cal);
+    for (auto& e : cal) DFQ_HIP_TRY(hipEventCreate(&e));
+    for (int i = 0; i < n_cal; ++i) {
+        DFQ_HIP_TRY(hipEventRecord(cal[2 * i], st));
+        DFQ_HIP_TRY(hipEventRecord(cal[2 * i + 1], st));
+    }
     size_t k = 0;
     for (int s = 0; s < n_sweeps; ++s) {
         for (const LevelLaunch& L : p->levels) {
@@ -1157,6 +1165,14 @@ int dfq_le_profile(dfq_le_plan* p, const dfq_le_config* cfg, int32_t n_sweeps, v
     }
     if (control_ms) *control_ms = ctl;
     if (n_level_launches) *n_level_launches = n_levels * n_sweeps;
+    double cal_ms = 0.0;
+    for (int i = 0; i < n_cal; ++i) {
+        float ms = 0.0f;
+        DFQ_HIP_TRY(hipEventElapsedTime(&ms, cal[2 * i], cal[2 * i + 1]));
+        cal_ms += ms;
+    }
+    if (empty_bracket_ms) *empty_bracket_ms = cal_ms / n_cal;
+    for (auto& e : cal) (void)hipEventDestroy(e);
     for (auto& e : ev) (void)hipEventDestroy(e);
     return DFQ_OK;
 }

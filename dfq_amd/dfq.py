@@ -119,9 +119,11 @@ class LEPlan:
         level_ms = (ctypes.c_double * max(1, nl))()
         ctl = ctypes.c_double()
         nlaunch = ctypes.c_int32()
+        empty = ctypes.c_double()
         _ffi.check(_ffi.lib().dfq_le_profile(self._plan, ctypes.byref(cfg), int(n_sweeps), _ffi.stream_arg(), level_ms,
-                                             ctypes.byref(ctl), ctypes.byref(nlaunch)))
-        return dict(level_ms=[level_ms[i] for i in range(nl)], control_ms=ctl.value, level_launches=nlaunch.value)
+                                             ctypes.byref(ctl), ctypes.byref(nlaunch), ctypes.byref(empty)))
+        return dict(level_ms=[level_ms[i] for i in range(nl)], control_ms=ctl.value, level_launches=nlaunch.value,
+                    empty_bracket_ms=empty.value)
 
     def trace(self, launch, block, **kw):
         """Shader-clock stamps of one workgroup's tile phases (tuning aid, see dfq_le_trace)."""

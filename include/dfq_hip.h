@@ -129,10 +129,12 @@ int dfq_le_run(dfq_le_plan* plan, const dfq_le_config* cfg, void* stream, dfq_le
 /* Measurement aid (bench.py roofline): like dfq_le_enqueue(restart=1) for `n_sweeps` sweeps, but every
  * launch is bracketed by a pair of HIP events recorded on `stream`.  level_ms[l] receives the summed
  * duration of the launches of level l (array of dfq_le_plan_levels() doubles), *control_ms the summed
- * duration of the convergence kernel, *n_level_launches the number of level launches timed.
+ * duration of the convergence kernel, *n_level_launches the number of level launches timed,
+ * *empty_bracket_ms what a pair of event records measures with nothing between them (to subtract).
  * Synchronises. */
 int dfq_le_profile(dfq_le_plan* plan, const dfq_le_config* cfg, int32_t n_sweeps, void* stream,
-                   double* level_ms, double* control_ms, int32_t* n_level_launches);
+                   double* level_ms, double* control_ms, int32_t* n_level_launches,
+                   double* empty_bracket_ms);
 
 /* Tuning aid: run two sweeps and return the shader-clock stamps (s_memtime) that thread 0 of
  * workgroup `block` (= blockIdx.y * grid_x + blockIdx.x) of launch `launch` took at the phase boundaries of its tile during the second
