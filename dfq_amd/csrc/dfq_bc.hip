@@ -22,7 +22,8 @@ namespace dfq {
 
 constexpr int kQChunk = kBlock * 16;
 constexpr int kExpectMax = 8192;       // floats of E[x] kept in LDS (32 KiB)
-constexpr int kRowsPerBlock = 16;      // output rows of the matvec per workgroup (4 per wave)
+constexpr int kRowsPerBlock = kBlock / kWave;   // output rows of the matvec per workgroup: one per wave
+constexpr int kBcRegs = 24;            // eps values a lane preloads (rows up to 1536 inputs per group)
 
 struct BcLayerDev {
     const float* w;
@@ -162,6 +163,17 @@ __global__ __launch_bounds__(kBlock) void bc_cache_init_kernel(const BcCacheSeg*
 __global__ __launch_bounds__(kBlock) void bc_step_kernel(BcStepDev st, const BcSourceDev* __restrict__ sources) {
     __shared__ float sh_E[kExpectMax];
     const int tid = threadIdx.x;
+    const int lane = tid % kWave;
+    const int o_raw = blockIdx.x * kRowsPerBlock + tid / kWave;
+    const bool row_ok = o_raw < st.out_ch;
+    const int o = row_ok ? o_raw : st.out_ch - 1;
+    // this wave's row of eps goes into registers first: the fetch overlaps the expectation build
+    const float* er = st.eps + (int64_t)o * st.in_per_group;
+    float ev[kBcRegs];
+    const int n_pre = min(kBcRegs, (st.in_per_group + kWave - 1) / kWave);
+#pragma unroll
+    for (int u = 0; u < kBcRegs; ++u)
+        if (u < n_pre) ev[u] = er[min(lane + u * kWave, st.in_per_group - 1)];
     // ---- E[x]: first source assigns, 'cat' appends, anything else adds (dfq.py:229-270) ----
     int cur_len = 0;
     for (int m = 0; m < st.source_count; ++m) {
@@ -177,30 +189,30 @@ __global__ __launch_bounds__(kBlock) void bc_step_kernel(BcStepDev st, const BcS
         cur_len = (m == 0) ? s.channels : (s.concat ? cur_len + s.channels : cur_len);
         __syncthreads();
     }
-    // ---- grouped matvec, one wave per output row, float64 accumulation rounded once ----
+    // ---- grouped matvec: ONE output row per wave (rows of a layer are independent, so the layer's
+    //      latency is one row's latency), float64 accumulation rounded once.  The row of eps was
+    //      loaded into registers before the barrier above. ----
     const int num_group = st.expect_len / st.in_per_group;
     const int step_o = st.out_ch / num_group;
     const int step_i = st.expect_len / num_group;
-    const int lane = tid % kWave;
-    const int wave = tid / kWave;
-    const int row_end = min(st.out_ch, (int)(blockIdx.x + 1) * kRowsPerBlock);
-    for (int o = blockIdx.x * kRowsPerBlock + wave; o < row_end; o += kBlock / kWave) {
-        const int g = o / step_o;
-        const float* er = st.eps + (int64_t)o * st.in_per_group;
-        const float* ex = sh_E + g * step_i;
-        double acc = 0.0;
-        for (int i = lane; i < st.in_per_group; i += kWave) acc += (double)er[i] * (double)ex[i];
-        acc = wave_sum(acc);
-        if (lane == 0) {
-            const float corr = (float)acc;
-            const float neg = -corr;
-            st.corr[o] = corr;
-            st.bias[o] = st.bias[o] + neg;                            // dfq.py:292
-            if (st.next_bn_bias) {
-                const float nb = st.next_bn_bias[o] + neg;            // dfq.py:204-206, 293
-                st.next_bn_bias[o] = nb;
-                if (st.next_cache) st.next_cache[o] = relu_mean(st.next_bn_weight[o], nb);
-            }
+    const float* ex = sh_E + (o / step_o) * step_i;
+    double acc = 0.0;
+#pragma unroll
+    for (int u = 0; u < kBcRegs; ++u) {
+        const int i = lane + u * kWave;
+        if (u < n_pre) acc += (i < st.in_per_group) ? (double)ev[u] * (double)ex[i] : 0.0;
+    }
+    for (int i = lane + kBcRegs * kWave; i < st.in_per_group; i += kWave) acc += (double)er[i] * (double)ex[i];
+    acc = wave_sum(acc);
+    if (lane == 0 && row_ok) {
+        const float corr = (float)acc;
+        const float neg = -corr;
+        st.corr[o] = corr;
+        st.bias[o] = st.bias[o] + neg;                            // dfq.py:292
+        if (st.next_bn_bias) {
+            const float nb = st.next_bn_bias[o] + neg;            // dfq.py:204-206, 293
+            st.next_bn_bias[o] = nb;
+            if (st.next_cache) st.next_cache[o] = relu_mean(st.next_bn_weight[o], nb);
         }
     }
 }
