@@ -50,6 +50,7 @@ def parse():
     ap.add_argument('--net', default='mobilenet_v2', choices=['mobilenet_v2', 'resnet18', 'deeplab_mnv2', 'tiny_mobile'])
     ap.add_argument('--sweeps', type=int, default=0, help='pin the LE sweep count (0 = what the convergence test needs)')
     ap.add_argument('--cpu-seconds', type=float, default=10.0, help='CPU-baseline budget (0 disables)')
+    ap.add_argument('--streams', type=int, default=1, help='networks in flight per GPU (independent replicas on separate HIP streams)')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--force-sweeps', action='store_true', help='tuning: run --sweeps sweeps regardless of convergence')
     return ap.parse_args()
@@ -159,12 +160,21 @@ def main():
             dist.barrier()
         _sync()
 
-    for r in replicas[:args.warmup]:
-        step(r)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(args.streams)] if args.streams > 1 else None
+
+    def run(batch):
+        if streams is None:
+            for r in batch:
+                step(r)
+            return
+        for i, r in enumerate(batch):          # independent networks: round-robin over the streams
+            with torch.cuda.stream(streams[i % len(streams)]):
+                step(r)
+
+    run(replicas[:args.warmup])
     fence()
     t0 = time.perf_counter()
-    for r in replicas[args.warmup:]:
-        step(r)
+    run(replicas[args.warmup:])
     fence()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -195,6 +205,7 @@ def main():
                         'GPU per step, weights resident in HBM'.format(args.net, n_layers, n_w, len(proto[3]), levels, sweeps),
             'le_sweeps': sweeps,
             'networks_per_step': world,
+            'networks_in_flight_per_gpu': args.streams,
         },
     }
 

@@ -237,6 +237,8 @@ struct dfq_bc_plan {
     float* d_cache = nullptr;              // ReLU moments of the BNs that some step reads through a ReLU
     BcCacheSeg* d_cache_segs = nullptr;
     int n_cache_segs = 0, cache_total = 0;
+    hipStream_t capture_stream = nullptr;  // private stream used only to record the graph
+    hipGraphExec_t exec[2] = {nullptr, nullptr};   // recorded run, by `symmetric`
 };
 
 extern "C" {
@@ -252,6 +254,8 @@ void dfq_bc_plan_destroy(dfq_bc_plan* p) {
     if (p->d_corr) (void)hipFree(p->d_corr);
     if (p->d_cache) (void)hipFree(p->d_cache);
     if (p->d_cache_segs) (void)hipFree(p->d_cache_segs);
+    for (auto& e : p->exec) if (e) (void)hipGraphExecDestroy(e);
+    if (p->capture_stream) (void)hipStreamDestroy(p->capture_stream);
     delete p;
 }
 
@@ -379,9 +383,31 @@ int dfq_bc_plan_create(const dfq_layer* layers, int32_t n_layers, const dfq_bc_s
     return DFQ_OK;
 }
 
+static int bc_run_direct(dfq_bc_plan* p, int32_t symmetric, hipStream_t st);
+
 int dfq_bc_plan_run(dfq_bc_plan* p, int32_t symmetric, void* stream) {
     if (!p) return fail_arg("dfq_bc_plan_run: null plan");
     hipStream_t st = as_stream(stream);
+    const char* ge = getenv("DFQ_GRAPH");
+    if (ge && ge[0] == '0') return bc_run_direct(p, symmetric, st);
+    // ~(n_layers + 4) dependent launches with fixed arguments: record once, replay as one graph launch
+    hipGraphExec_t& exec = p->exec[symmetric ? 1 : 0];
+    if (!exec) {
+        if (!p->capture_stream) DFQ_HIP_TRY(hipStreamCreate(&p->capture_stream));
+        DFQ_HIP_TRY(hipStreamBeginCapture(p->capture_stream, hipStreamCaptureModeThreadLocal));
+        const int rc = bc_run_direct(p, symmetric, p->capture_stream);
+        hipGraph_t graph = nullptr;
+        const hipError_t ee = hipStreamEndCapture(p->capture_stream, &graph);
+        if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+        if (ee != hipSuccess) return fail_hip(ee, "hipStreamEndCapture", __FILE__, __LINE__);
+        DFQ_HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        (void)hipGraphDestroy(graph);
+    }
+    DFQ_HIP_TRY(hipGraphLaunch(exec, st));
+    return DFQ_OK;
+}
+
+static int bc_run_direct(dfq_bc_plan* p, int32_t symmetric, hipStream_t st) {
     DFQ_HIP_TRY(hipMemsetAsync(p->d_slots, 0, sizeof(uint32_t) * 2 * p->n_steps, st));
     hipLaunchKernelGGL(bc_minmax_kernel, dim3(p->minmax_blocks), dim3(kBlock), 0, st, (const BcLayerDev*)p->d_layers,
                        (const int32_t*)p->d_mm_begin, p->n_steps, p->d_slots);

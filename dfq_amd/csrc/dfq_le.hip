@@ -40,6 +40,7 @@
 // ahead without synchronising.
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "dfq_common.hpp"
@@ -727,9 +728,24 @@ __global__ __launch_bounds__(kCtlBlock) void le_control_kernel(const LeLayerDiff
         }
     }
     __syncthreads();
+    if (wave != 0) return;
+    // diff_tmp = sum of the layer means IN GRAPH ORDER (Python's left-to-right float64 sum).  Lane l
+    // fetches mean[l]; lane order is replayed with v_readlane, so the 64 LDS reads of a chunk are one
+    // instruction instead of a chain of 64 dependent reads.  Adding +0.0 for missing layers is exact.
+    double diff_tmp = 0.0;
+    for (int base = 0; base < n_layers; base += kWave) {
+        const int l = base + lane;
+        const double m = (l < n_layers) ? ((l < 1024) ? sh_mean[l] : layer_mean[l]) : 0.0;
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(m);
+        const uint32_t lo = (uint32_t)bits, hi = (uint32_t)(bits >> 32);
+#pragma unroll
+        for (int j = 0; j < kWave; ++j) {
+            const unsigned long long b = ((unsigned long long)__builtin_amdgcn_readlane(hi, j) << 32) |
+                                         (unsigned long long)__builtin_amdgcn_readlane(lo, j);
+            diff_tmp += __longlong_as_double((long long)b);
+        }
+    }
     if (tid == 0) {
-        double diff_tmp = 0.0;
-        for (int l = 0; l < n_layers; ++l) diff_tmp += (l < 1024) ? sh_mean[l] : layer_mean[l];   // graph order
         double diff = state->diff;
         int count = state->count;
         if (fabs(diff - diff_tmp) > 1e-9) { count = 0; diff = diff_tmp; }
@@ -781,6 +797,12 @@ struct dfq_le_plan {
     int64_t stat_words = 0;                // per parity, per arena
     int64_t r1_zero_words = 0;             // leading part of the R1 arena that is accumulated with atomics
     int64_t sweep_index = 0;               // sweeps enqueued since the last restart (parity = & 1)
+    hipStream_t capture_stream = nullptr;  // private stream used only to record graphs
+    struct CachedGraph {
+        std::vector<unsigned char> key;    // (n_sweeps, restart, start parity, config bytes)
+        hipGraphExec_t exec;
+    };
+    std::vector<CachedGraph> graphs;
     LeRelDev* d_rels = nullptr;
     LeLayerDiff* d_layer_diff = nullptr;
     double* d_partials = nullptr;
@@ -826,6 +848,8 @@ void dfq_le_plan_destroy(dfq_le_plan* p) {
     if (p->d_state) (void)hipFree(p->d_state);
     if (p->d_stats) (void)hipFree(p->d_stats);
     for (float* a : p->arenas) (void)hipFree(a);
+    for (auto& g : p->graphs) (void)hipGraphExecDestroy(g.exec);
+    if (p->capture_stream) (void)hipStreamDestroy(p->capture_stream);
     delete p;
 }
 
@@ -1107,9 +1131,7 @@ static int le_launch_control(dfq_le_plan* p, const dfq_le_config* cfg, hipStream
 
 extern "C" {
 
-int dfq_le_enqueue(dfq_le_plan* p, const dfq_le_config* cfg, int32_t n_sweeps, int32_t restart, void* stream) {
-    if (!p || !cfg || n_sweeps < 0) return fail_arg("dfq_le_enqueue: bad argument");
-    hipStream_t st = as_stream(stream);
+static int le_enqueue_direct(dfq_le_plan* p, const dfq_le_config* cfg, int n_sweeps, int restart, hipStream_t st) {
     const LeParams q = make_params(cfg);
     int rc;
     if (restart && (rc = le_restart(p, cfg, st))) return rc;
@@ -1118,6 +1140,43 @@ int dfq_le_enqueue(dfq_le_plan* p, const dfq_le_config* cfg, int32_t n_sweeps, i
             if ((rc = le_launch_level(p, L, q, st))) return rc;
         if ((rc = le_launch_control(p, cfg, st))) return rc;
     }
+    return DFQ_OK;
+}
+
+static bool graphs_enabled() {
+    const char* e = getenv("DFQ_GRAPH");
+    return !(e && e[0] == '0');
+}
+
+int dfq_le_enqueue(dfq_le_plan* p, const dfq_le_config* cfg, int32_t n_sweeps, int32_t restart, void* stream) {
+    if (!p || !cfg || n_sweeps < 0) return fail_arg("dfq_le_enqueue: bad argument");
+    hipStream_t st = as_stream(stream);
+    if (!graphs_enabled() || n_sweeps < 2) return le_enqueue_direct(p, cfg, n_sweeps, restart, st);
+    // A whole run of sweeps is a few hundred dependent launches with arguments that only depend on
+    // (config, sweep parity): record it once on a private stream, replay it as one graph launch.
+    const int64_t start_index = restart ? 0 : p->sweep_index;
+    std::vector<unsigned char> key(sizeof(int32_t) * 3 + sizeof(dfq_le_config));
+    const int32_t head[3] = {n_sweeps, restart ? 1 : 0, (int32_t)(start_index & 1)};
+    memcpy(key.data(), head, sizeof(head));
+    memcpy(key.data() + sizeof(head), cfg, sizeof(dfq_le_config));
+    hipGraphExec_t exec = nullptr;
+    for (auto& g : p->graphs) if (g.key == key) exec = g.exec;
+    if (!exec) {
+        if (!p->capture_stream) DFQ_HIP_TRY(hipStreamCreate(&p->capture_stream));
+        if (!restart) p->sweep_index = start_index;
+        DFQ_HIP_TRY(hipStreamBeginCapture(p->capture_stream, hipStreamCaptureModeThreadLocal));
+        const int rc = le_enqueue_direct(p, cfg, n_sweeps, restart, p->capture_stream);
+        hipGraph_t graph = nullptr;
+        const hipError_t ee = hipStreamEndCapture(p->capture_stream, &graph);
+        if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+        if (ee != hipSuccess) return fail_hip(ee, "hipStreamEndCapture", __FILE__, __LINE__);
+        DFQ_HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        (void)hipGraphDestroy(graph);
+        if (p->graphs.size() >= 16) { (void)hipGraphExecDestroy(p->graphs.front().exec); p->graphs.erase(p->graphs.begin()); }
+        p->graphs.push_back({key, exec});
+    }
+    p->sweep_index = start_index + n_sweeps;
+    DFQ_HIP_TRY(hipGraphLaunch(exec, st));
     return DFQ_OK;
 }
 

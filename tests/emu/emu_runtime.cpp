@@ -9,6 +9,7 @@ namespace emu {
 
 ThreadCtx* cur = nullptr;
 const void* kernarg_ptr = nullptr;
+std::vector<std::function<void()>>* capture = nullptr;
 
 namespace {
 

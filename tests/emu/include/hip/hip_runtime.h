@@ -19,6 +19,7 @@
 #include <algorithm>
 #include <cmath>
 #include <functional>
+#include <vector>
 
 #define __global__
 #define __device__
@@ -100,6 +101,8 @@ inline uint32_t __builtin_amdgcn_readlane(uint32_t v, int src_lane) {
     return ok ? (uint32_t)got : v;
 }
 
+inline long long __double_as_longlong(double d) { long long v; memcpy(&v, &d, 8); return v; }
+inline double __longlong_as_double(long long v) { double d; memcpy(&d, &v, 8); return d; }
 inline uint32_t __float_as_uint(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 inline float __uint_as_float(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 
@@ -130,7 +133,12 @@ inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
 inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
 inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
 inline hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
-inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
+namespace emu { extern std::vector<std::function<void()>>* capture; }
+inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) {
+    if (emu::capture) { emu::capture->push_back([=]() { memset(d, v, n); }); return hipSuccess; }
+    memset(d, v, n);
+    return hipSuccess;
+}
 
 typedef struct emu_event* hipEvent_t;
 inline hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return hipSuccess; }
@@ -141,15 +149,42 @@ inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms =
 
 namespace emu {
 extern const void* kernarg_ptr;
+extern std::vector<std::function<void()>>* capture;     // non-null while a stream capture is open
 template <typename K, typename A0, typename... As>
-inline void launch_k(dim3 grid, dim3 block, K kernel, A0 a0, As... as) {
-    // the argument copies live here for the whole launch; the first one sits at kernarg offset 0
-    kernarg_ptr = &a0;
+inline void run_k(dim3 grid, dim3 block, K kernel, A0& a0, As&... as) {
+    kernarg_ptr = &a0;                                   // the first argument sits at kernarg offset 0
     launch(grid, block, [&]() { kernel(a0, as...); });
     kernarg_ptr = nullptr;
 }
+template <typename K, typename A0, typename... As>
+inline void launch_k(dim3 grid, dim3 block, K kernel, A0 a0, As... as) {
+    if (capture) {
+        capture->push_back([=]() mutable { run_k(grid, block, kernel, a0, as...); });
+        return;
+    }
+    run_k(grid, block, kernel, a0, as...);
+}
 }  // namespace emu
 inline const void* __builtin_amdgcn_kernarg_segment_ptr() { return emu::kernarg_ptr; }
+
+// ---- stream capture / graphs: a graph is the recorded list of launches ----
+typedef std::vector<std::function<void()>>* hipGraph_t;
+typedef std::vector<std::function<void()>>* hipGraphExec_t;
+enum hipStreamCaptureMode { hipStreamCaptureModeGlobal = 0, hipStreamCaptureModeThreadLocal = 1, hipStreamCaptureModeRelaxed = 2 };
+inline hipError_t hipStreamCreate(hipStream_t* s) { *s = nullptr; return hipSuccess; }
+inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+inline hipError_t hipStreamBeginCapture(hipStream_t, hipStreamCaptureMode) {
+    emu::capture = new std::vector<std::function<void()>>();
+    return hipSuccess;
+}
+inline hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t* g) { *g = emu::capture; emu::capture = nullptr; return hipSuccess; }
+inline hipError_t hipGraphInstantiate(hipGraphExec_t* e, hipGraph_t g, void*, void*, size_t) {
+    *e = new std::vector<std::function<void()>>(*g);
+    return hipSuccess;
+}
+inline hipError_t hipGraphDestroy(hipGraph_t g) { delete g; return hipSuccess; }
+inline hipError_t hipGraphExecDestroy(hipGraphExec_t e) { delete e; return hipSuccess; }
+inline hipError_t hipGraphLaunch(hipGraphExec_t e, hipStream_t) { for (auto& f : *e) f(); return hipSuccess; }
 
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
     emu::launch_k((grid), (block), kernel, __VA_ARGS__)
