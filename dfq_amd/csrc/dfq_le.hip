@@ -730,20 +730,13 @@ __global__ __launch_bounds__(kCtlBlock) void le_control_kernel(const LeLayerDiff
     __syncthreads();
     if (wave != 0) return;
     // diff_tmp = sum of the layer means IN GRAPH ORDER (Python's left-to-right float64 sum).  Lane l
-    // fetches mean[l]; lane order is replayed with v_readlane, so the 64 LDS reads of a chunk are one
-    // instruction instead of a chain of 64 dependent reads.  Adding +0.0 for missing layers is exact.
+    // fetches mean[l] with one LDS instruction per 64 layers; the values then travel lane by lane
+    // through a shuffle so that lane 0 adds them in order (adding +0.0 for missing layers is exact).
     double diff_tmp = 0.0;
     for (int base = 0; base < n_layers; base += kWave) {
         const int l = base + lane;
         const double m = (l < n_layers) ? ((l < 1024) ? sh_mean[l] : layer_mean[l]) : 0.0;
-        const unsigned long long bits = (unsigned long long)__double_as_longlong(m);
-        const uint32_t lo = (uint32_t)bits, hi = (uint32_t)(bits >> 32);
-#pragma unroll
-        for (int j = 0; j < kWave; ++j) {
-            const unsigned long long b = ((unsigned long long)__builtin_amdgcn_readlane(hi, j) << 32) |
-                                         (unsigned long long)__builtin_amdgcn_readlane(lo, j);
-            diff_tmp += __longlong_as_double((long long)b);
-        }
+        for (int j = 0; j < kWave; ++j) diff_tmp += __shfl(m, j);
     }
     if (tid == 0) {
         double diff = state->diff;

@@ -54,6 +54,14 @@ uint64_t peer_slot(int mask, bool* valid) {
     return fibers[src].tc.slot;
 }
 
+uint64_t peer_slot_lane(int src_lane, bool* valid) {
+    const int lane = cur_idx % kWaveSize;
+    const int src = (cur_idx - lane) + src_lane;
+    if (src_lane < 0 || src_lane >= kWaveSize || src >= (int)fibers.size()) { *valid = false; return 0; }
+    *valid = true;
+    return fibers[src].tc.slot;
+}
+
 uint64_t peer_rl(int src_lane, bool* valid) {
     const int lane = cur_idx % kWaveSize;
     const int src = (cur_idx - lane) + src_lane;

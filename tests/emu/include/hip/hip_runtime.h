@@ -83,6 +83,21 @@ inline T shfl_xor(T v, int mask) {
 #define gridDim (emu::cur->gdim)
 
 inline void __syncthreads() { emu::sync_block(); }
+namespace emu { uint64_t peer_slot_lane(int src_lane, bool* valid); }
+template <typename T>
+inline T __shfl(T v, int src_lane) {
+    uint64_t bits = 0;
+    memcpy(&bits, &v, sizeof(T));
+    emu::cur->slot = bits;
+    emu::sync_wave();
+    bool ok = false;
+    const uint64_t got = emu::peer_slot_lane(src_lane, &ok);
+    emu::sync_wave();
+    if (!ok) return v;
+    T out;
+    memcpy(&out, &got, sizeof(T));
+    return out;
+}
 template <typename T>
 inline T __shfl_xor(T v, int mask) { return emu::shfl_xor(v, mask); }
 
@@ -90,7 +105,8 @@ namespace emu { uint64_t peer_rl(int src_lane, bool* valid); }
 // v_readlane broadcast.  A kernel typically reads many lanes of ONE register in a row; after the
 // first rendezvous every lane's value sits in its `rl_val`, so further reads of the same register
 // need no rendezvous (each fiber is fresh per workgroup, rl_valid starts false).
-inline uint32_t __builtin_amdgcn_readlane(uint32_t v, int src_lane) {
+inline int __builtin_amdgcn_readlane(int v0, int src_lane) {      // the real builtin takes and returns int
+    const uint32_t v = (uint32_t)v0;
     if (!(emu::cur->rl_valid && emu::cur->rl_val == v)) {
         emu::cur->rl_val = v;
         emu::cur->rl_valid = true;
@@ -98,7 +114,7 @@ inline uint32_t __builtin_amdgcn_readlane(uint32_t v, int src_lane) {
     }
     bool ok = false;
     const uint64_t got = emu::peer_rl(src_lane, &ok);
-    return ok ? (uint32_t)got : v;
+    return ok ? (int)(uint32_t)got : v0;
 }
 
 inline long long __double_as_longlong(double d) { long long v; memcpy(&v, &d, 8); return v; }
