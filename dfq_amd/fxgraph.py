@@ -30,9 +30,11 @@ _FUNC_NAMES = {
     F.interpolate: 'F.interpolate', F.pad: 'F.pad', F.softmax: 'F.softmax',
 }
 _METHOD_NAMES = {'add': 'add', 'add_': 'add', 'mean': 'torch.mean'}
-_TRANSPARENT_FUNCS = {torch.flatten, operator.getitem, getattr}
-_TRANSPARENT_METHODS = {'view', 'reshape', 'flatten', 'contiguous', 'size', 'squeeze', 'unsqueeze',
+_TRANSPARENT_METHODS = {'view', 'reshape', 'flatten', 'contiguous', 'squeeze', 'unsqueeze',
                         'float', 'detach', 'clone'}
+# results that are shapes / python numbers, not tensors: they must not become graph edges (e.g. the
+# `size=(x.shape[2], x.shape[3])` argument of F.interpolate refers to x only for its shape)
+_SHAPE_METHODS = {'size', 'dim', 'numel'}
 
 
 class _LeafTracer(torch.fx.Tracer):
@@ -96,6 +98,10 @@ def trace(model, key_style='name'):
                 continue
             key = '{}_{}'.format(type(m).__name__, counter) if key_style == 'name' else m
             graph[key] = m
+        elif n.op == 'call_function' and n.target is getattr:
+            continue                                   # x.shape, x.dtype ...: not a tensor
+        elif n.op == 'call_method' and n.target in _SHAPE_METHODS:
+            continue
         elif n.op == 'call_function':
             if n.target in _FUNC_NAMES:
                 key = '{}_{}'.format(_FUNC_NAMES[n.target], counter)

@@ -304,3 +304,57 @@ def _spec_snapshot(spec):
             snap['L{}.fw'.format(i)] = n.fake_weight
             snap['L{}.fb'.format(i)] = n.fake_bias
     return snap
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE.json configurations at full size (GPU only: the emulation would take minutes)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize('net,max_sweeps', [('mobilenet_v2', None), ('resnet18', None), ('deeplab_mnv2', 12)])
+def test_full_size_networks_against_oracle(net, max_sweeps):
+    """configs[1..3] of BASELINE.json: the whole LE + BC + quantise pass on the real layer shapes.
+    LE must be bit-identical to the oracle (sweep count included), BC within 1e-5, int8 codes of the
+    weights bit-identical.  DeepLab runs a pinned number of sweeps: the reference's loop does not
+    terminate on it."""
+    dev = torch.device('cuda', 0)
+    model, graph, bottoms = synthetic.build(net, seed=0)
+    spec = graphspec.from_torch(graph, bottoms, TARG)
+    model.to(dev)
+    lt.merge_batchnorm(model, graph, bottoms, TARG)
+    orc.merge_batchnorm(spec)
+    rels = rel.create_relation(graph, bottoms, TARG)
+    orels = orc.create_relation(spec)
+    keys = list(graph.keys())
+    assert [[keys.index(k) for k in r.get_idxs()] for r in rels] == [[spec.order.index(k) for k in r] for r in orels]
+
+    dfq.cross_layer_equalization(graph, rels, TARG, max_sweeps=max_sweeps)
+    n_o, S_o = orc.cross_layer_equalization(spec, orels, max_sweeps=max_sweeps)
+    assert dfq.last_equalization['sweeps'] == n_o
+    osnap, esnap = _spec_snapshot(spec), snapshot(graph)
+    for k in osnap:
+        assert_bitexact(esnap[k], osnap[k], '{} LE {}'.format(net, k))
+    for r, s in zip(rels, S_o):
+        assert_bitexact(npy(r.get_scale_vec()), s, 'cumulative S')
+    # property of the converged state: paired ranges are equal (README "equalization")
+    if max_sweeps is None:
+        for r in rels:
+            w1 = npy(graph[r.get_idxs()[0]].weight)
+            w2 = npy(graph[r.get_idxs()[1]].weight)
+            g = w1.shape[0] // w2.shape[1] if w1.shape[0] != w2.shape[1] else 1
+            r1 = w1.reshape(w1.shape[0], -1).max(1) - w1.reshape(w1.shape[0], -1).min(1)
+            cols = w2.reshape(g, w2.shape[0] // g, w2.shape[1], -1).transpose(0, 2, 1, 3).reshape(w1.shape[0], -1)
+            r2 = cols.max(1) - cols.min(1)
+            live = (r1 > 1e-6) & (r2 > 1e-6)
+            np.testing.assert_allclose(r1[live], r2[live], rtol=2e-3)
+
+    dfq.bias_correction(graph, bottoms, TARG)
+    orc.bias_correction(spec)
+    osnap, esnap = _spec_snapshot(spec), snapshot(graph)
+    for k in osnap:
+        assert_close(esnap[k], osnap[k], '{} BC {}'.format(net, k))
+
+    _, codes = lt.quantize_targ_layer(graph, 8, 16, TARG, return_codes=True)
+    ocodes = orc.quantize_targ_layer(spec, 8, 16, return_codes=True)
+    for k in codes:
+        assert np.array_equal(codes[k].cpu().numpy(), ocodes[k].astype(np.int32)), 'int8 codes of {}'.format(k)
+        assert len(np.unique(npy(graph[k].weight))) <= 256
