@@ -1,0 +1,165 @@
+"""Cross-layer equalisation of ONE network sharded over several GPUs.
+
+Channels of a relation are independent, relations that share a layer are order-dependent, so the
+shard unit is a connected component of the relation graph (MobileNetV2: 16 components).  Every rank
+holds the whole network, equalises only the components it owns, then one ``all_gather`` (RCCL over
+xGMI when the process group is 'nccl') exchanges the cumulative per-relation scale vectors -- 4 bytes
+per paired channel, 64 KB for MobileNetV2 -- and every rank rebuilds the layers it does not own from
+its pristine copy:  W = diag(S_out) . W0 . diag(1/S_in),  b = b0 . S_out,  BN proxies likewise.  The
+rebuilt tensors equal the sequentially rescaled ones up to float32 rounding (<= 1e-5 relative, the
+contract of BASELINE.json); the owned components are bit-identical to the single-GPU result.
+
+This is a latency-bound exchange on a millisecond-scale job: it exists for configuration 4 of
+BASELINE.json (DeepLab sharded over 8 GPUs) and for networks too large for one pass to be cheap, not
+for the headline MobileNetV2 number (bench.py shards whole networks over ranks instead).
+
+The data-dependent convergence test of dfq.py:83-115 needs the sum of all layers' mean |dW|: with
+``max_sweeps=None`` the ranks run sweep by sweep and all-reduce that one float64 per sweep.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+from . import _ffi
+from . import dfq as _dfq
+
+
+def relation_components(relations):
+    """Connected components of the relation list (relations sharing a layer are connected).
+    Returns a list of lists of relation indices, each in list (= Gauss-Seidel) order."""
+    parent = {}
+
+    def find(x):
+        while parent.setdefault(x, x) != x:
+            parent[x] = parent[parent[x]]
+            x = parent[x]
+        return x
+
+    for rr in relations:
+        a, b, _ = rr.get_idxs()
+        parent[find(('L', a))] = find(('L', b))
+    comps = {}
+    for i, rr in enumerate(relations):
+        comps.setdefault(find(('L', rr.get_idxs()[0])), []).append(i)
+    return list(comps.values())
+
+
+def assign_components(graph, relations, world_size):
+    """Greedy bin packing of components by paired elements.  Deterministic -> identical on every rank."""
+    comps = relation_components(relations)
+
+    def cost(c):
+        return sum(graph[relations[i].get_idxs()[0]].weight.numel() + graph[relations[i].get_idxs()[1]].weight.numel()
+                   for i in c)
+    order = sorted(range(len(comps)), key=lambda k: (-cost(comps[k]), comps[k][0]))
+    load = [0] * world_size
+    owner = [0] * len(relations)
+    for k in order:
+        r = min(range(world_size), key=lambda q: (load[q], q))
+        load[r] += cost(comps[k])
+        for i in comps[k]:
+            owner[i] = r
+    return owner
+
+
+def _engine_rescale(weight, bias, bn, s_out, s_in, groups):
+    """W <- diag(S_out) W diag(1/S_in) (and b, BN proxies *= S_out) with the engine's row/col kernels."""
+    lib = _ffi.lib()
+    stage = _ffi.Stage()
+    w = stage.bind(weight)
+    khkw = w[0, 0].numel() if w.dim() == 4 else 1
+    if s_out is not None:
+        so = stage.bind(s_out)
+        _ffi.check(lib.dfq_scale_rows(_ffi.ptr(w), w.shape[0], w[0].numel(), _ffi.ptr(so), 0, _ffi.stream_arg()))
+        for v in ([bias] if bias is not None else []) + list(bn):
+            vv = stage.bind(v)
+            _ffi.check(lib.dfq_vec_op(_ffi.ptr(vv), _ffi.ptr(so), vv.numel(), 0, _ffi.stream_arg()))
+    if s_in is not None:
+        si = stage.bind(s_in)
+        _ffi.check(lib.dfq_scale_cols(_ffi.ptr(w), w.shape[0], w.shape[1], khkw, groups, _ffi.ptr(si), 1, _ffi.stream_arg()))
+    stage.writeback()
+
+
+def sharded_cross_layer_equalization(graph, relations, targ_type, group=None, s_range=(1e-8, 1e8),
+                                     converge_thres=2e-7, converge_count=20, signed=False, eps=0,
+                                     max_sweeps=None, le_runner=None, rescale=None):
+    """Equalise ``graph`` in place on every rank of ``group``; returns the number of sweeps.
+
+    ``le_runner(graph, relations, targ_type, max_sweeps=..., **kw) -> dict`` and
+    ``rescale(weight, bias, bn_tensors, s_out, s_in, groups)`` default to the HIP engine; tests inject
+    CPU stand-ins to exercise the partition / exchange / rebuild logic over gloo.
+    """
+    rank = dist.get_rank(group)
+    world = dist.get_world_size(group)
+    if le_runner is None:
+        def le_runner(g, rels, tt, **kw):
+            _dfq.cross_layer_equalization(g, rels, tt, **kw)
+            return _dfq.last_equalization
+    rescale = rescale or _engine_rescale
+    owner = assign_components(graph, relations, world)
+    mine = [rr for rr, o in zip(relations, owner) if o == rank]
+    foreign = [(i, rr) for i, (rr, o) in enumerate(zip(relations, owner)) if o != rank]
+    kw = dict(s_range=list(s_range), signed=signed, eps=eps)
+
+    with torch.no_grad():
+        # pristine copies of everything a foreign relation will change
+        for _, rr in foreign:                               # dfq.py:91-92 on every rank
+            first = graph[rr.get_idxs()[0]]
+            if first.bias is None:
+                first.bias = torch.nn.Parameter(torch.zeros(first.weight.size(0), dtype=torch.float32,
+                                                            device=first.weight.device), requires_grad=False)
+        # ---- local sweeps ----
+        if max_sweeps is not None:
+            sweeps = le_runner(graph, mine, targ_type, max_sweeps=max_sweeps, converge_thres=-1.0,
+                               converge_count=10 ** 9, **kw)['sweeps'] if mine else max_sweeps
+            sweeps = max_sweeps
+        else:
+            diff, count, sweeps = 10.0, 0, 0
+            dev = next(iter(graph[k] for k in graph if type(graph[k]) in targ_type)).weight.device
+            while diff > converge_thres and count < converge_count:
+                local = le_runner(graph, mine, targ_type, max_sweeps=1, converge_thres=-1.0, converge_count=10 ** 9,
+                                  **kw)['last_diff_tmp'] if mine else 0.0
+                t = torch.tensor([local], dtype=torch.float64, device=dev if dist.get_backend(group) == 'nccl' else 'cpu')
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+                diff_tmp = float(t.item())
+                if abs(diff - diff_tmp) > 1e-9:
+                    count, diff = 0, diff_tmp
+                else:
+                    count += 1
+                sweeps += 1
+        # ---- exchange: one all_gather of the cumulative scale vectors, padded to a common length ----
+        lens = [graph[rr.get_idxs()[0]].weight.size(0) for rr in relations]
+        total = sum(lens)
+        dev = graph[relations[0].get_idxs()[0]].weight.device if relations else torch.device('cpu')
+        comm_dev = dev if dist.get_backend(group) == 'nccl' else torch.device('cpu')
+        flat = torch.ones(total, dtype=torch.float32, device=comm_dev)
+        off = 0
+        for rr, o, n in zip(relations, owner, lens):
+            if o == rank and rr.S is not None:
+                flat[off:off + n] = rr.S.to(comm_dev)
+            off += n
+        gathered = [torch.empty_like(flat) for _ in range(world)]
+        dist.all_gather(gathered, flat, group=group)
+        off = 0
+        S_all = []
+        for o, n in zip(owner, lens):
+            S_all.append(gathered[o][off:off + n].to(dev))
+            off += n
+        # ---- rebuild what the other ranks equalised ----
+        s_out, s_in = {}, {}
+        for (i, rr) in foreign:
+            a, b, _ = rr.get_idxs()
+            s_out[a] = (S_all[i], rr)
+            s_in[b] = S_all[i]
+            rr.S = S_all[i]
+        for key in set(s_out) | set(s_in):
+            layer = graph[key]
+            so, rr = s_out.get(key, (None, None))
+            bn = []
+            if rr is not None and rr.get_idxs()[2] is not None:
+                bnm = graph[rr.get_idxs()[2]]
+                bn = [t for t in (getattr(bnm, 'fake_weight', None), getattr(bnm, 'fake_bias', None)) if t is not None]
+            rescale(layer.weight, layer.bias if so is not None else None, bn, so, s_in.get(key),
+                    getattr(layer, 'groups', 1))
+    return sweeps

@@ -1,0 +1,179 @@
+"""N > 1 path of row (e): one network sharded over ranks (dfq_amd/sharded.py), world_size 2 over gloo
+on CPU.  The HIP engine cannot run here, so the per-rank compute is the numpy oracle and the rebuild
+uses torch ops -- injected stand-ins; what is under test is the partition, the all_gather exchange of
+the scale vectors and the rebuild, against the single-process result."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+from oracle import dfq_oracle as orc
+from oracle import graphspec
+from dfq_amd import sharded, synthetic
+from dfq_amd.utils import relation as rel
+
+from common import TARG, assert_bitexact, assert_close, load_inputs, net_fixture, npy
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _prepare(name, seed):
+    gold = net_fixture(name, seed, '')
+    model, graph, bottoms = synthetic.build(name, seed=seed)
+    load_inputs(graph, gold, 'cpu')
+    spec = graphspec.from_torch(graph, bottoms, TARG)
+    orc.merge_batchnorm(spec)
+    with torch.no_grad():                      # put the oracle's folded state into the modules
+        for k in graph:
+            n = spec.nodes[k]
+            if n.kind == 'targ':
+                graph[k].weight.copy_(torch.from_numpy(n.weight))
+                if n.bias is not None:
+                    if graph[k].bias is None:
+                        graph[k].bias = nn.Parameter(torch.zeros(n.bias.shape[0]), requires_grad=False)
+                    graph[k].bias.copy_(torch.from_numpy(n.bias))
+            elif n.kind == 'bn' and n.fake_weight is not None:
+                graph[k].register_buffer('fake_weight', torch.from_numpy(n.fake_weight.copy()))
+                graph[k].register_buffer('fake_bias', torch.from_numpy(n.fake_bias.copy()))
+    return model, graph, bottoms, spec
+
+
+def _oracle_runner(graph, relations, targ_type, max_sweeps=None, **kw):
+    """Stand-in for the engine: run the numpy oracle on the given relations and write the result back."""
+    spec = graphspec.GraphSpec()
+    bottoms = {k: [] for k in graph}
+    for k in graph:
+        m = graph[k]
+        if type(m) in targ_type:
+            n = graphspec.Node(k, 'targ')
+            n.weight = npy(m.weight).copy()
+            n.bias = npy(m.bias).copy() if m.bias is not None else None
+        elif type(m) == nn.BatchNorm2d and hasattr(m, 'fake_weight'):
+            n = graphspec.Node(k, 'bn')
+            n.fake_weight = npy(m.fake_weight).copy()
+            n.fake_bias = npy(m.fake_bias).copy()
+        else:
+            n = graphspec.Node(k, 'other')
+        spec.add(n, bottoms[k])
+    rels = [rr.get_idxs() for rr in relations]
+    trace = []
+    n_sw, S = orc.cross_layer_equalization(spec, rels, s_range=kw.get('s_range', (1e-8, 1e8)),
+                                           converge_thres=kw.get('converge_thres', 2e-7),
+                                           converge_count=kw.get('converge_count', 20), signed=kw.get('signed', False),
+                                           eps=kw.get('eps', 0), max_sweeps=max_sweeps, trace=trace)
+    with torch.no_grad():
+        for k in graph:
+            n = spec.nodes[k]
+            if n.kind == 'targ':
+                graph[k].weight.copy_(torch.from_numpy(n.weight))
+                if n.bias is not None:
+                    if graph[k].bias is None:
+                        graph[k].bias = nn.Parameter(torch.zeros(n.bias.shape[0]), requires_grad=False)
+                    graph[k].bias.copy_(torch.from_numpy(n.bias))
+            elif n.kind == 'bn':
+                graph[k].fake_weight.copy_(torch.from_numpy(n.fake_weight))
+                graph[k].fake_bias.copy_(torch.from_numpy(n.fake_bias))
+    for rr, s in zip(relations, S):
+        rr.set_scale_vec(torch.from_numpy(s.copy()))
+    return dict(sweeps=n_sw, last_diff_tmp=trace[-1] if trace else 0.0)
+
+
+def _torch_rescale(weight, bias, bn, s_out, s_in, groups):
+    with torch.no_grad():
+        if s_out is not None:
+            weight.mul_(s_out.view((-1,) + (1,) * (weight.dim() - 1)))
+            for v in ([bias] if bias is not None else []) + list(bn):
+                v.mul_(s_out)
+        if s_in is not None:
+            per_row = s_in.view(groups, -1).repeat_interleave(weight.shape[0] // groups, dim=0)
+            weight.div_(per_row.view((weight.shape[0], -1) + (1,) * (weight.dim() - 2)))
+
+
+def _worker(rank, world, port, name, seed, max_sweeps, out_dir):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(1)
+        model, graph, bottoms, _ = _prepare(name, seed)
+        rels = rel.create_relation(graph, bottoms, TARG)
+        sweeps = sharded.sharded_cross_layer_equalization(graph, rels, TARG, max_sweeps=max_sweeps,
+                                                          le_runner=_oracle_runner, rescale=_torch_rescale)
+        owner = sharded.assign_components(graph, rels, world)
+        snap = {'sweeps': np.array(sweeps), 'owner': np.array(owner)}
+        for i, k in enumerate(graph):
+            m = graph[k]
+            if type(m) in TARG:
+                snap['L{}.w'.format(i)] = npy(m.weight)
+                if m.bias is not None:
+                    snap['L{}.b'.format(i)] = npy(m.bias)
+            elif type(m) == nn.BatchNorm2d and hasattr(m, 'fake_weight'):
+                snap['L{}.fw'.format(i)] = npy(m.fake_weight)
+                snap['L{}.fb'.format(i)] = npy(m.fake_bias)
+        for i, rr in enumerate(rels):
+            snap['S{}'.format(i)] = npy(rr.get_scale_vec())
+        np.savez(os.path.join(out_dir, 'rank{}.npz'.format(rank)), **snap)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('name,seed,max_sweeps', [('tiny_mobile', 0, 5), ('tiny_mobile', 0, None), ('tiny_res', 0, 3)])
+def test_sharded_equalization_two_ranks(tmp_path, name, seed, max_sweeps):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), name, seed, max_sweeps, str(tmp_path)), nprocs=world, join=True)
+    # single-process result of the same algorithm
+    model, graph, bottoms, spec = _prepare(name, seed)
+    orels = orc.create_relation(spec)
+    if max_sweeps is None:
+        n_ref, S_ref = orc.cross_layer_equalization(spec, orels)
+    else:       # the sharded pinned mode runs exactly max_sweeps sweeps
+        n_ref, S_ref = orc.cross_layer_equalization(spec, orels, max_sweeps=max_sweeps, converge_thres=-1.0,
+                                                    converge_count=10 ** 9)
+    r0 = np.load(os.path.join(str(tmp_path), 'rank0.npz'))
+    r1 = np.load(os.path.join(str(tmp_path), 'rank1.npz'))
+    assert int(r0['sweeps']) == int(r1['sweeps']) == n_ref
+    assert len(set(r0['owner'].tolist())) == 2, 'both ranks must own work'
+    keys = list(graph.keys())
+    for res in (r0, r1):
+        for i, k in enumerate(keys):
+            n = spec.nodes[k]
+            if n.kind == 'targ':
+                assert_close(res['L{}.w'.format(i)], n.weight, 'w {}'.format(k))
+                if n.bias is not None and 'L{}.b'.format(i) in res:
+                    assert_close(res['L{}.b'.format(i)], n.bias, 'b {}'.format(k))
+            elif n.kind == 'bn' and n.fake_weight is not None:
+                assert_close(res['L{}.fw'.format(i)], n.fake_weight, 'fw {}'.format(k))
+                assert_close(res['L{}.fb'.format(i)], n.fake_bias, 'fb {}'.format(k))
+        for i, s in enumerate(S_ref):
+            assert_bitexact(res['S{}'.format(i)], s, 'S{}'.format(i))
+    # both ranks end with the same network
+    for k in r0.files:
+        if k.startswith('L'):
+            assert_close(r0[k], r1[k], k)
+
+
+def test_components_and_assignment():
+    model, graph, bottoms, _ = _prepare('tiny_mobile', 0)
+    rels = rel.create_relation(graph, bottoms, TARG)
+    comps = sharded.relation_components(rels)
+    assert sorted(i for c in comps for i in c) == list(range(len(rels)))
+    layers_of = [set(k for i in c for k in rels[i].get_idxs()[:2]) for c in comps]
+    for a in range(len(comps)):
+        for b in range(a + 1, len(comps)):
+            assert not (layers_of[a] & layers_of[b]), 'components must not share layers'
+    for world in (1, 2, 3, 8):
+        owner = sharded.assign_components(graph, rels, world)
+        assert len(owner) == len(rels) and all(0 <= o < world for o in owner)
+        for c in comps:
+            assert len({owner[i] for i in c}) == 1, 'a component stays on one rank'
