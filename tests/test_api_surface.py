@@ -1,0 +1,124 @@
+"""The rest of the reference's call surface on both backends: scale folding
+(transform_quant_layer / merge_scale_to_weight), distilled-range calibration (set_update_stat /
+update_quant_range / QuantMeasure inside the layers), the Q* layer classes, the sharded rebuild."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from oracle import dfq_oracle as orc
+from dfq_amd import improve_dfq, sharded
+from dfq_amd.utils import quantize as q
+from dfq_amd.utils.relation import Relation
+
+from common import F32, assert_bitexact, assert_close, npy
+
+
+def test_merge_scale_to_weight_conv_and_linear(engine):
+    rng = np.random.default_rng(7)
+    conv = q.QConv2d(8, 12, 3, groups=2, bias=True).to(engine.device)
+    lin = q.QLinear(12, 5).to(engine.device)
+    w = rng.standard_normal((12, 4, 3, 3)).astype(F32)
+    b = rng.standard_normal(12).astype(F32)
+    sc = rng.uniform(0.5, 2, 12).astype(F32)
+    sp = rng.uniform(0.5, 2, 8).astype(F32)
+    with torch.no_grad():
+        conv.weight.copy_(torch.from_numpy(w))
+        conv.bias.copy_(torch.from_numpy(b))
+    conv.set_scale(scale=engine.to(torch.from_numpy(sc.copy())), scale_prev=engine.to(torch.from_numpy(sp.copy()).view(-1, 1, 1, 1)))
+    conv.merge_scale_to_weight()
+    w_o, b_o = orc.merge_scale_to_weight(w, b, sc, sp, groups=2)
+    assert_bitexact(npy(conv.weight), w_o, 'conv weight')
+    assert_bitexact(npy(conv.bias), b_o, 'conv bias')
+
+    wl = rng.standard_normal((5, 12)).astype(F32)
+    bl = rng.standard_normal(5).astype(F32)
+    with torch.no_grad():
+        lin.weight.copy_(torch.from_numpy(wl))
+        lin.bias.copy_(torch.from_numpy(bl))
+    sl = rng.uniform(0.5, 2, 5).astype(F32)
+    spl = rng.uniform(0.5, 2, 12).astype(F32)
+    lin.set_scale(scale=engine.to(torch.from_numpy(sl.copy())), scale_prev=engine.to(torch.from_numpy(spl.copy())))
+    lin.merge_scale_to_weight()
+    w_o, b_o = orc.merge_scale_to_weight(wl, bl, sl, spl, linear=True)
+    assert_bitexact(npy(lin.weight), w_o, 'linear weight')
+    assert_bitexact(npy(lin.bias), b_o, 'linear bias')
+
+
+def test_transform_quant_layer_swaps_and_folds(engine):
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = q.QConv2d(3, 6, 3, padding=1)
+            self.bn = nn.BatchNorm2d(6)
+            self.b = q.QConv2d(6, 4, 1)
+            self.fc = q.QLinear(4, 2)
+
+        def forward(self, x):
+            x = self.b(torch.relu(self.bn(self.a(x))))
+            return self.fc(x.mean((2, 3)))
+    net = Net().to(engine.device).eval()
+    graph = {'Data': 'Data', 'a': net.a, 'bn': net.bn, 'b': net.b, 'fc': net.fc}
+    s = torch.rand(6, device=engine.device) + 0.5
+    wa, wb = npy(net.a.weight).copy(), npy(net.b.weight).copy()
+    net.a.set_scale(scale=s.clone())
+    net.b.set_scale(scale_prev=s.clone().view(-1, 1, 1, 1))
+    rels = [Relation('a', 'b', 'bn')]
+    out = improve_dfq.transform_quant_layer(net, graph, rels, trainable=False)
+    assert out is net
+    assert type(net.a) is q.QuantNConv2d and type(net.b) is q.QuantNConv2d and type(net.fc) is q.QuantNLinear
+    assert graph['a'] is net.a and graph['b'] is net.b
+    assert not hasattr(net.a, 'scale') or getattr(net.a, 'scale', None) is None
+    assert_bitexact(npy(net.a.weight), (wa * npy(s).reshape(-1, 1, 1, 1)).astype(F32))
+    assert_bitexact(npy(net.b.weight), (wb / npy(s).reshape(1, -1, 1, 1)).astype(F32))
+    net(torch.randn(2, 3, 8, 8, device=engine.device))          # still runs
+
+
+def test_update_quant_range_records_activation_ranges(engine):
+    net = nn.Sequential(q.QuantNConv2d(3, 4, 3, padding=1), nn.ReLU(), q.QuantNConv2d(4, 4, 1)).to(engine.device).eval()
+    graph = {'Data': 'Data', 'c0': net[0], 'r': net[1], 'c1': net[2]}
+    bottoms = {'Data': None, 'c0': ['Data'], 'r': ['c0'], 'c1': ['r']}
+    improve_dfq.set_update_stat(net, [q.QuantMeasure], True)
+    assert net[0].quant.update_stat and net[2].quant.update_stat
+    rng = np.random.default_rng(0)
+    data = [torch.from_numpy(rng.standard_normal((4, 3, 6, 6)).astype(F32)) for _ in range(2)]
+    # expected running range of the second layer's input = max over batches of the per-batch
+    # mean-of-per-sample extrema (quantize.py:106-107), computed with plain torch on the same activations
+    improve_dfq.update_quant_range(net, data, graph, bottoms)
+    improve_dfq.set_update_stat(net, [q.QuantMeasure], False)
+    assert float(net[0].quant.running_max) == pytest.approx(2.64) and float(net[0].quant.running_min) == pytest.approx(-2.11790393)
+    assert float(net[2].quant.running_max) > 0.0 and float(net[2].quant.running_min) <= 0.0
+    y = net(data[0].to(engine.device))
+    assert y.shape == (4, 4, 6, 6) and torch.isfinite(y).all()
+
+
+def test_qconv_forward_matches_manual_fake_quant(engine):
+    torch.manual_seed(0)
+    layer = q.QuantConv2d(3, 5, 3, padding=1).to(engine.device).eval()
+    x = torch.randn(2, 3, 7, 7, device=engine.device)
+    layer.quant.running_min.fill_(-2.0)
+    layer.quant.running_max.fill_(2.0)
+    y = layer(x)
+    xq = torch.from_numpy(orc.uniform_quantize(npy(x), 8, -2.0, 2.0))
+    w = npy(layer.weight)
+    wq = torch.from_numpy(orc.uniform_quantize(w, 8, float(w.min()), float(w.max())))
+    bq = torch.from_numpy(orc.uniform_quantize(npy(layer.bias), 16))
+    want = torch.nn.functional.conv2d(xq, wq, bq, padding=1)
+    assert_close(npy(y), want.numpy(), 'QuantConv2d forward', tol=1e-5)
+
+
+def test_sharded_rebuild_kernels(engine):
+    """diag(S_out) . W0 . diag(1/S_in) with the engine's row/column kernels (dfq_amd/sharded.py)."""
+    rng = np.random.default_rng(3)
+    for shape, groups in [((12, 6, 3, 3), 1), ((12, 3, 3, 3), 4), ((10, 7), 1)]:
+        w = rng.standard_normal(shape).astype(F32)
+        b = rng.standard_normal(shape[0]).astype(F32)
+        so = rng.uniform(0.5, 2, shape[0]).astype(F32)
+        si = rng.uniform(0.5, 2, shape[1] * groups).astype(F32)
+        tw, tb = engine.to(torch.from_numpy(w.copy())), engine.to(torch.from_numpy(b.copy()))
+        sharded._engine_rescale(tw, tb, [], engine.to(torch.from_numpy(so)), engine.to(torch.from_numpy(si)), groups)
+        want = (w * so.reshape((-1,) + (1,) * (w.ndim - 1))).astype(F32)
+        per_row = si.reshape(groups, -1).repeat(shape[0] // groups, axis=0)
+        want = (want / per_row.reshape((shape[0], shape[1]) + (1,) * (w.ndim - 2))).astype(F32)
+        assert_bitexact(npy(tw), want, 'weight {}'.format(shape))
+        assert_bitexact(npy(tb), (b * so).astype(F32), 'bias')
