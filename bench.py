@@ -50,7 +50,7 @@ def parse():
     ap.add_argument('--net', default='mobilenet_v2', choices=['mobilenet_v2', 'resnet18', 'deeplab_mnv2', 'tiny_mobile'])
     ap.add_argument('--sweeps', type=int, default=0, help='pin the LE sweep count (0 = what the convergence test needs)')
     ap.add_argument('--cpu-seconds', type=float, default=10.0, help='CPU-baseline budget (0 disables)')
-    ap.add_argument('--streams', type=int, default=1, help='networks in flight per GPU (independent replicas on separate HIP streams)')
+    ap.add_argument('--streams', type=int, default=4, help='networks in flight per GPU (independent replicas, one HIP stream + host thread each)')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--force-sweeps', action='store_true', help='tuning: run --sweeps sweeps regardless of convergence')
     return ap.parse_args()
@@ -108,6 +108,14 @@ def _device(local_rank):
 
 def _sync():
     torch.cuda.synchronize()
+
+
+def _new_stream(dev):
+    return torch.cuda.Stream(device=dev)
+
+
+def _stream_ctx(stream):
+    return torch.cuda.stream(stream)
 
 
 def _gpu_elapsed_ms(fn):
@@ -171,16 +179,29 @@ def main():
             dist.barrier()
         _sync()
 
-    streams = [torch.cuda.Stream(device=dev) for _ in range(args.streams)] if args.streams > 1 else None
+    # Networks are independent jobs: `--streams S` keeps S of them in flight, each on its own HIP stream
+    # fed by its own host thread (ctypes releases the GIL; one thread cannot enqueue the ~340 launches of
+    # a pass faster than the GPU retires them).  S = 1 is the latency of one pass.
+    n_streams = max(1, args.streams)
+    streams = [_new_stream(dev) for _ in range(n_streams)]
 
     def run(batch):
-        if streams is None:
-            for r in batch:
-                step(r)
+        if n_streams == 1:
+            with _stream_ctx(streams[0]):
+                for r in batch:
+                    step(r)
             return
-        for i, r in enumerate(batch):          # independent networks: round-robin over the streams
-            with torch.cuda.stream(streams[i % len(streams)]):
-                step(r)
+        import threading
+
+        def worker(i):
+            with _stream_ctx(streams[i]):
+                for r in batch[i::n_streams]:
+                    step(r)
+        threads = [threading.Thread(target=worker, args=(i,)) for i in range(n_streams)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
 
     run(replicas[:args.warmup])
     fence()
@@ -195,6 +216,18 @@ def main():
     done_sweeps = replicas[-1]['le'].query()['sweeps']
     assert done_sweeps == sweeps, 'timed steps ran {} sweeps, expected {}'.format(done_sweeps, sweeps)
     ms_per_step = elapsed * 1e3 / args.steps
+
+    # latency of ONE pass with nothing else in flight (reported next to the throughput figure)
+    lat_reps = [make_replica(proto) for _ in range(6)]
+    with _stream_ctx(streams[0]):
+        for r in lat_reps[:2]:
+            step(r)
+        fence()
+        t0 = time.perf_counter()
+        for r in lat_reps[2:]:
+            step(r)
+        fence()
+        single_ms = (time.perf_counter() - t0) * 1e3 / 4
 
     out = {
         'metric': 'conv weights calibrated/sec (LE+BC pass, MobileNetV2)' if args.net == 'mobilenet_v2'
@@ -216,7 +249,8 @@ def main():
                         'GPU per step, weights resident in HBM'.format(args.net, n_layers, n_w, len(proto[3]), levels, sweeps),
             'le_sweeps': sweeps,
             'networks_per_step': world,
-            'networks_in_flight_per_gpu': args.streams,
+            'networks_in_flight_per_gpu': n_streams,
+            'single_pass_latency_ms': single_ms,
         },
     }
 

@@ -389,7 +389,7 @@ int dfq_bc_plan_run(dfq_bc_plan* p, int32_t symmetric, void* stream) {
     if (!p) return fail_arg("dfq_bc_plan_run: null plan");
     hipStream_t st = as_stream(stream);
     const char* ge = getenv("DFQ_GRAPH");
-    if (ge && ge[0] == '0') return bc_run_direct(p, symmetric, st);
+    if (!(ge && ge[0] == '1')) return bc_run_direct(p, symmetric, st);     // opt-in, see dfq_le.hip
     // ~(n_layers + 4) dependent launches with fixed arguments: record once, replay as one graph launch
     hipGraphExec_t& exec = p->exec[symmetric ? 1 : 0];
     if (!exec) {

@@ -1136,9 +1136,12 @@ static int le_enqueue_direct(dfq_le_plan* p, const dfq_le_config* cfg, int n_swe
     return DFQ_OK;
 }
 
+// hipGraph replay is opt-in (DFQ_GRAPH=1): on ROCm 7.2 replaying these few-microsecond kernels as graph
+// nodes is slower than plain launches on both sides (MobileNetV2: 2.60 ms vs 2.26 ms of GPU time per
+// 47-sweep run, 1.85 vs 2.2 ms of host time), see DESIGN.md section 7.
 static bool graphs_enabled() {
     const char* e = getenv("DFQ_GRAPH");
-    return !(e && e[0] == '0');
+    return e && e[0] == '1';
 }
 
 int dfq_le_enqueue(dfq_le_plan* p, const dfq_le_config* cfg, int32_t n_sweeps, int32_t restart, void* stream) {

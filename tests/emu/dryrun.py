@@ -31,7 +31,10 @@ def _elapsed(fn):
 
 
 bench._gpu_elapsed_ms = _elapsed
-sys.argv = ['bench.py', '--net', 'tiny_mobile', '--steps', '2', '--warmup', '1', '--cpu-seconds', '0.2']
+import contextlib
+bench._new_stream = lambda dev: None
+bench._stream_ctx = lambda s: contextlib.nullcontext()
+sys.argv = ['bench.py', '--net', 'tiny_mobile', '--steps', '2', '--warmup', '1', '--cpu-seconds', '0.2', '--streams', '1']
 bench.main()
 
 # smoke() with cuda patched out

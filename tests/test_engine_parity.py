@@ -258,6 +258,28 @@ def test_equalization_tile_shapes(engine, monkeypatch, name, seed, suffix, tile_
         assert_bitexact(npy(r.get_scale_vec()), s)
 
 
+def test_graph_replay_mode(engine, monkeypatch):
+    """DFQ_GRAPH=1: the sweep run and the BC chain are recorded once and replayed as hipGraphs."""
+    monkeypatch.setenv('DFQ_GRAPH', '1')
+    gold = net_fixture('tiny_cat', 3, '_abs')
+    model, graph, bottoms = _build('tiny_cat', 3, gold, engine)
+    spec = graphspec.from_torch(graph, bottoms, TARG)
+    lt.merge_batchnorm(model, graph, bottoms, TARG)
+    orc.merge_batchnorm(spec)
+    rels = rel.create_relation(graph, bottoms, TARG)
+    dfq.cross_layer_equalization(graph, rels, TARG)
+    n_o, _ = orc.cross_layer_equalization(spec, orc.create_relation(spec))
+    assert dfq.last_equalization['sweeps'] == n_o
+    dfq.bias_correction(graph, bottoms, TARG)
+    orc.bias_correction(spec)
+    osnap, esnap = _spec_snapshot(spec), snapshot(graph)
+    for k in osnap:
+        if k.endswith('.w') or k.endswith('.fw'):
+            assert_bitexact(esnap[k], osnap[k], k)
+        else:
+            assert_close(esnap[k], osnap[k], k)
+
+
 def test_max_sweeps_and_restart(engine):
     gold = net_fixture('tiny_mobile', 0, '')
     model, graph, bottoms = _build('tiny_mobile', 0, gold, engine)
