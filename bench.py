@@ -45,8 +45,8 @@ HBM_PEAK_GBS = 8000.0             # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=40)
+    ap.add_argument('--warmup', type=int, default=8)
     ap.add_argument('--net', default='mobilenet_v2', choices=['mobilenet_v2', 'resnet18', 'deeplab_mnv2', 'tiny_mobile'])
     ap.add_argument('--sweeps', type=int, default=0, help='pin the LE sweep count (0 = what the convergence test needs)')
     ap.add_argument('--cpu-seconds', type=float, default=10.0, help='CPU-baseline budget (0 disables)')
@@ -268,13 +268,13 @@ def main():
         lvl_corr = [max(ms / sweeps - empty, 0.0) for ms in prof['level_ms']]          # per launch, ms
         ctl_corr = max(prof['control_ms'] / sweeps - empty, 0.0)
         share_levels = sum(lvl_corr) / max(sum(lvl_corr) + ctl_corr, 1e-12)
+        # every sweep must do real work here, so the convergence exit is disabled for this run
+        always = dict(converge_thres=-1.0, converge_count=10 ** 9)
         wall_rep = make_replica(proto)
-        wall_rep['le'].enqueue(sweeps, restart=True, max_sweeps=sweeps, **force)       # warm: records the graph
-        wall_rep2 = make_replica(proto)
-        wall_rep2['le'].enqueue(2, restart=True, max_sweeps=sweeps, **force)
+        wall_rep['le'].enqueue(0, restart=True, max_sweeps=sweeps, **always)           # restart outside the bracket
         _sync()
-        wall_rep['le'].enqueue(0, restart=True, max_sweeps=sweeps, **force)            # restart outside the bracket
-        sweep_ms = _gpu_elapsed_ms(lambda: wall_rep['le'].enqueue(sweeps, restart=False, max_sweeps=sweeps, **force)) / sweeps
+        sweep_ms = _gpu_elapsed_ms(lambda: wall_rep['le'].enqueue(sweeps, restart=False, max_sweeps=sweeps, **always)) / sweeps
+        assert wall_rep['le'].query()['sweeps'] == sweeps
         launches = sweeps * levels
         avg_ms = sweep_ms * share_levels / levels
         bytes_per_sweep = 8 * paired + 4 * snap
