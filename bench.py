@@ -45,12 +45,12 @@ HBM_PEAK_GBS = 8000.0             # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=40)
-    ap.add_argument('--warmup', type=int, default=8)
+    ap.add_argument('--steps', type=int, default=80)
+    ap.add_argument('--warmup', type=int, default=16)
     ap.add_argument('--net', default='mobilenet_v2', choices=['mobilenet_v2', 'resnet18', 'deeplab_mnv2', 'tiny_mobile'])
     ap.add_argument('--sweeps', type=int, default=0, help='pin the LE sweep count (0 = what the convergence test needs)')
     ap.add_argument('--cpu-seconds', type=float, default=10.0, help='CPU-baseline budget (0 disables)')
-    ap.add_argument('--streams', type=int, default=4, help='networks in flight per GPU (independent replicas, one HIP stream + host thread each)')
+    ap.add_argument('--streams', type=int, default=8, help='networks in flight per GPU (independent replicas, one HIP stream + host thread each)')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--force-sweeps', action='store_true', help='tuning: run --sweeps sweeps regardless of convergence')
     return ap.parse_args()
