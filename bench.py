@@ -100,6 +100,17 @@ def cpu_baseline(net, seed, budget_s):
                        '({} weights), {:.1f} s of CPU time'.format(reps, sweeps, net, n_w, spent)), sweeps
 
 
+def _pmc_traffic(net):
+    """HBM bytes per launch of le_level_kernel from the committed PMC summary (MobileNetV2 only), else null."""
+    path = os.path.join(ROOT, 'profiles', 'r01_pmc_summary.json')
+    if net != 'mobilenet_v2' or not os.path.exists(path):
+        return None
+    try:
+        return json.load(open(path))['le_level_kernel']['traffic_bytes_per_launch']
+    except Exception:
+        return None
+
+
 def _device(local_rank):
     assert torch.cuda.is_available(), 'bench.py needs a ROCm GPU'
     torch.cuda.set_device(local_rank)
@@ -289,7 +300,9 @@ def main():
                               'bytes': nbytes, 'us': us, 'GBps': nbytes / max(us, 1e-9) / 1e3})
         out['roofline'] = {
             'bound': 'hbm', 'kernel': 'le_level_kernel', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-            'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+            'frac': achieved / HBM_PEAK_GBS, 'traffic': _pmc_traffic(args.net), 'traffic_unit': 'bytes per launch',
+            'traffic_source': 'profiles/r01_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; '
+                              'a profiler pass cannot run inside this process)',
             'bytes_per_launch': avg_bytes, 'us_per_launch': avg_ms * 1e3, 'launches_timed': launches,
             'sweep_wall_us': sweep_ms * 1e3, 'control_us_per_sweep': sweep_ms * 1e3 * (1.0 - share_levels),
             'event_pair_overhead_us': empty * 1e3, 'levels': per_level,
