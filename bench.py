@@ -45,12 +45,13 @@ HBM_PEAK_GBS = 8000.0             # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=80)
-    ap.add_argument('--warmup', type=int, default=16)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=4)
     ap.add_argument('--net', default='mobilenet_v2', choices=['mobilenet_v2', 'resnet18', 'deeplab_mnv2', 'tiny_mobile'])
     ap.add_argument('--sweeps', type=int, default=0, help='pin the LE sweep count (0 = what the convergence test needs)')
     ap.add_argument('--cpu-seconds', type=float, default=10.0, help='CPU-baseline budget (0 disables)')
-    ap.add_argument('--streams', type=int, default=8, help='networks in flight per GPU (independent replicas, one HIP stream + host thread each)')
+    ap.add_argument('--batch', type=int, default=8, help='networks calibrated together in one step (one batched plan)')
+    ap.add_argument('--streams', type=int, default=2, help='steps in flight per GPU (one HIP stream + host thread each)')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--force-sweeps', action='store_true', help='tuning: run --sweeps sweeps regardless of convergence')
     return ap.parse_args()
@@ -68,12 +69,19 @@ def prepare(net, seed, dev):
     return model, graph, bottoms, rels
 
 
-def make_replica(proto):
+def make_unit(protos):
+    """One unit of work = a batch of networks calibrated together: deep copies of the prototypes plus
+    one LE plan and one BC plan over the whole batch (a batch of 1 is an ordinary single-network plan)."""
     from dfq_amd import dfq
-    model, graph, bottoms, rels = copy.deepcopy(proto)
-    le = dfq.build_le_plan(graph, rels, TARG)
-    bc, _ = dfq.build_bc_plan(graph, bottoms, TARG)
-    return dict(model=model, graph=graph, bottoms=bottoms, rels=rels, le=le, bc=bc)
+    nets = [copy.deepcopy(p) for p in protos]
+    if len(nets) == 1:
+        model, graph, bottoms, rels = nets[0]
+        le = dfq.build_le_plan(graph, rels, TARG)
+        bc, _ = dfq.build_bc_plan(graph, bottoms, TARG)
+    else:
+        le = dfq.build_le_plan_batch([(g, r) for (_, g, _, r) in nets], TARG)
+        bc = dfq.build_bc_plan_batch([(g, b) for (_, g, b, _) in nets], TARG)
+    return dict(nets=nets, le=le, bc=bc)
 
 
 def cpu_baseline(net, seed, budget_s):
@@ -100,13 +108,17 @@ def cpu_baseline(net, seed, budget_s):
                        '({} weights), {:.1f} s of CPU time'.format(reps, sweeps, net, n_w, spent)), sweeps
 
 
-def _pmc_traffic(net):
-    """HBM bytes per launch of le_level_kernel from the committed PMC summary (MobileNetV2 only), else null."""
+def _pmc_traffic(net, batch):
+    """HBM bytes per launch of le_level_kernel from the committed PMC summary, when that summary was
+    collected on this workload (MobileNetV2, same batch); else null."""
     path = os.path.join(ROOT, 'profiles', 'r01_pmc_summary.json')
     if net != 'mobilenet_v2' or not os.path.exists(path):
         return None
     try:
-        return json.load(open(path))['le_level_kernel']['traffic_bytes_per_launch']
+        summary = json.load(open(path))
+        if summary.get('batch', 1) != batch:
+            return None
+        return summary['le_level_kernel']['traffic_bytes_per_launch']
     except Exception:
         return None
 
@@ -159,30 +171,32 @@ def main():
     from dfq_amd import _ffi
     _ffi.lib()
 
-    proto = prepare(args.net, seed=rank, dev=dev)
-    n_w = sum(m.weight.numel() for m in proto[1].values() if type(m) in TARG)
-    n_layers = sum(1 for m in proto[1].values() if type(m) in TARG)
+    # `--batch B` distinct networks (different seeds) are calibrated together in every step
+    batch = max(1, args.batch)
+    protos = [prepare(args.net, seed=rank * 1000 + i, dev=dev) for i in range(batch)]
+    n_w = sum(m.weight.numel() for m in protos[0][1].values() if type(m) in TARG)
+    n_layers = sum(1 for m in protos[0][1].values() if type(m) in TARG)
 
-    # sweep count of the reference's convergence loop on this input (device-side loop, untimed)
-    probe = make_replica(proto)
-    if args.sweeps > 0:
-        sweeps = args.sweeps
-    else:
-        sweeps = probe['le'].run()['sweeps']
-        if dist is not None:           # every rank times the same amount of work per step
-            t = torch.tensor([sweeps], device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            sweeps = int(t.item())
+    # sweep counts of the reference's convergence loop on these inputs (device-side loop, untimed); the
+    # timed steps enqueue the largest one, every network still stops at its own count
+    probe = make_unit(protos)
+    probe['le'].run()
+    net_sweeps = [r['sweeps'] for r in probe['le'].query_all()[0]]
+    sweeps = args.sweeps if args.sweeps > 0 else max(net_sweeps)
+    if dist is not None and args.sweeps == 0:          # every rank enqueues the same amount of work per step
+        t = torch.tensor([sweeps], device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        sweeps = int(t.item())
     levels = probe['le'].levels
     paired, snap = probe['le'].paired_elements, probe['le'].snapshot_elements
 
-    replicas = [make_replica(proto) for _ in range(args.steps + args.warmup)]
+    units = [make_unit(protos) for _ in range(args.steps + args.warmup)]
 
     force = dict(converge_thres=-1.0, converge_count=10 ** 9) if args.force_sweeps else {}
 
-    def step(r):
-        r['le'].enqueue(sweeps, restart=True, max_sweeps=sweeps, **force)
-        r['bc'].run()
+    def step(u):
+        u['le'].enqueue(sweeps, restart=True, max_sweeps=sweeps, **force)
+        u['bc'].run()
 
     def fence():
         _sync()
@@ -190,60 +204,62 @@ def main():
             dist.barrier()
         _sync()
 
-    # Networks are independent jobs: `--streams S` keeps S of them in flight, each on its own HIP stream
-    # fed by its own host thread (ctypes releases the GIL; one thread cannot enqueue the ~340 launches of
-    # a pass faster than the GPU retires them).  S = 1 is the latency of one pass.
+    # Units are independent jobs: `--streams S` keeps S of them in flight, each on its own HIP stream fed
+    # by its own host thread (ctypes releases the GIL).
     n_streams = max(1, args.streams)
     streams = [_new_stream(dev) for _ in range(n_streams)]
 
-    def run(batch):
+    def run(work):
         if n_streams == 1:
             with _stream_ctx(streams[0]):
-                for r in batch:
-                    step(r)
+                for u in work:
+                    step(u)
             return
         import threading
 
         def worker(i):
             with _stream_ctx(streams[i]):
-                for r in batch[i::n_streams]:
-                    step(r)
+                for u in work[i::n_streams]:
+                    step(u)
         threads = [threading.Thread(target=worker, args=(i,)) for i in range(n_streams)]
         for t in threads:
             t.start()
         for t in threads:
             t.join()
 
-    run(replicas[:args.warmup])
+    run(units[:args.warmup])
     fence()
     t0 = time.perf_counter()
-    run(replicas[args.warmup:])
+    run(units[args.warmup:])
     fence()
     elapsed = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    done_sweeps = replicas[-1]['le'].query()['sweeps']
-    assert done_sweeps == sweeps, 'timed steps ran {} sweeps, expected {}'.format(done_sweeps, sweeps)
+    if not args.force_sweeps and args.sweeps == 0:
+        done = [r['sweeps'] for r in units[-1]['le'].query_all()[0]]
+        assert done == net_sweeps, 'timed steps ran {} sweeps, the probe {}'.format(done, net_sweeps)
     ms_per_step = elapsed * 1e3 / args.steps
 
-    # latency of ONE pass with nothing else in flight (reported next to the throughput figure)
-    lat_reps = [make_replica(proto) for _ in range(6)]
+    # latency of ONE single-network pass with nothing else in flight (reported next to the throughput)
+    lat_units = [make_unit(protos[:1]) for _ in range(6)]
     with _stream_ctx(streams[0]):
-        for r in lat_reps[:2]:
-            step(r)
+        for u in lat_units[:2]:
+            u['le'].enqueue(net_sweeps[0], restart=True, max_sweeps=net_sweeps[0])
+            u['bc'].run()
         fence()
         t0 = time.perf_counter()
-        for r in lat_reps[2:]:
-            step(r)
+        for u in lat_units[2:]:
+            u['le'].enqueue(net_sweeps[0], restart=True, max_sweeps=net_sweeps[0])
+            u['bc'].run()
         fence()
         single_ms = (time.perf_counter() - t0) * 1e3 / 4
 
     out = {
         'metric': 'conv weights calibrated/sec (LE+BC pass, MobileNetV2)' if args.net == 'mobilenet_v2'
                   else 'conv weights calibrated/sec (LE+BC pass, {})'.format(args.net),
-        'value': n_w * world / (ms_per_step * 1e-3),
+        'value': n_w * batch * world / (ms_per_step * 1e-3),
         'unit': 'weights/s',
         'n_gpus': world,
         'steps': args.steps,
@@ -255,12 +271,14 @@ def main():
         'dtype': 'f32',
         'data': 'synthetic',
         'config': {
-            'workload': '{} --relu --equalize --correction: {} layers, {} weights, {} relations in {} launch levels, '
-                        '{} LE sweeps (reference convergence test, thres 2e-7) + bias correction; one network per '
-                        'GPU per step, weights resident in HBM'.format(args.net, n_layers, n_w, len(proto[3]), levels, sweeps),
-            'le_sweeps': sweeps,
-            'networks_per_step': world,
-            'networks_in_flight_per_gpu': n_streams,
+            'workload': '{} --relu --equalize --correction: {} layers, {} weights, {} relations per network; a step '
+                        'calibrates a batch of {} networks (distinct random seeds) per GPU: LE until each network\'s '
+                        'reference convergence test fires (thres 2e-7; {} sweeps) + bias correction; weights resident '
+                        'in HBM'.format(args.net, n_layers, n_w, len(protos[0][3]), batch, sorted(set(net_sweeps))),
+            'le_sweeps': net_sweeps,
+            'networks_per_step': batch * world,
+            'launches_per_sweep': levels + 1,
+            'units_in_flight_per_gpu': n_streams,
             'single_pass_latency_ms': single_ms,
         },
     }
@@ -273,7 +291,7 @@ def main():
         #   (b) event pairs around every single launch (dfq_le_profile), minus the same pair around
         #       nothing, -> how that wall time splits between the level launches and the convergence
         #       kernel.  (a) x share(b) is what rocprofv3 reports as the kernel's average duration.
-        prof_rep = make_replica(proto)
+        prof_rep = make_unit(protos)
         prof = prof_rep['le'].profile(sweeps, max_sweeps=sweeps, **force)
         empty = prof['empty_bracket_ms']
         lvl_corr = [max(ms / sweeps - empty, 0.0) for ms in prof['level_ms']]          # per launch, ms
@@ -281,7 +299,7 @@ def main():
         share_levels = sum(lvl_corr) / max(sum(lvl_corr) + ctl_corr, 1e-12)
         # every sweep must do real work here, so the convergence exit is disabled for this run
         always = dict(converge_thres=-1.0, converge_count=10 ** 9)
-        wall_rep = make_replica(proto)
+        wall_rep = make_unit(protos)
         wall_rep['le'].enqueue(0, restart=True, max_sweeps=sweeps, **always)           # restart outside the bracket
         _sync()
         sweep_ms = _gpu_elapsed_ms(lambda: wall_rep['le'].enqueue(sweeps, restart=False, max_sweeps=sweeps, **always)) / sweeps
@@ -300,7 +318,7 @@ def main():
                               'bytes': nbytes, 'us': us, 'GBps': nbytes / max(us, 1e-9) / 1e3})
         out['roofline'] = {
             'bound': 'hbm', 'kernel': 'le_level_kernel', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-            'frac': achieved / HBM_PEAK_GBS, 'traffic': _pmc_traffic(args.net), 'traffic_unit': 'bytes per launch',
+            'frac': achieved / HBM_PEAK_GBS, 'traffic': _pmc_traffic(args.net, batch), 'traffic_unit': 'bytes per launch',
             'traffic_source': 'profiles/r01_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; '
                               'a profiler pass cannot run inside this process)',
             'bytes_per_launch': avg_bytes, 'us_per_launch': avg_ms * 1e3, 'launches_timed': launches,
@@ -308,9 +326,9 @@ def main():
             'event_pair_overhead_us': empty * 1e3, 'levels': per_level,
         }
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
-        out['cpu_baseline'], cpu_sweeps = cpu_baseline(args.net, 0, args.cpu_seconds)
+        out['cpu_baseline'], cpu_sweeps = cpu_baseline(args.net, rank * 1000, args.cpu_seconds)
         if args.sweeps == 0:
-            assert cpu_sweeps == sweeps, 'engine needed {} sweeps, the CPU oracle {}'.format(sweeps, cpu_sweeps)
+            assert cpu_sweeps == net_sweeps[0], 'engine needed {} sweeps, the CPU oracle {}'.format(net_sweeps[0], cpu_sweeps)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -55,7 +55,7 @@ class DfqBcSource(Structure):
 
 class DfqBcStep(Structure):
     _fields_ = [('layer', c_int32), ('source_begin', c_int32), ('source_count', c_int32),
-                ('next_bn_bias', c_void_p)]
+                ('next_bn_bias', c_void_p), ('net', c_int32), ('reserved', c_int32)]
 
 
 # every exported symbol: name -> (restype, argtypes).  tests/test_abi.py checks this table against
@@ -65,7 +65,11 @@ SIGNATURES = {
     'dfq_last_error': (c_char_p, []),
     'dfq_device_count': (c_int32, []),
     'dfq_le_plan_create': (c_int32, [POINTER(DfqLayer), c_int32, POINTER(DfqRelation), c_int32, POINTER(c_void_p)]),
+    'dfq_le_plan_create_batch': (c_int32, [POINTER(DfqLayer), c_int32, POINTER(c_int32), c_int32, POINTER(DfqRelation), c_int32,
+                                           POINTER(c_void_p)]),
     'dfq_le_plan_destroy': (None, [c_void_p]),
+    'dfq_le_plan_nets': (c_int32, [c_void_p]),
+    'dfq_le_query_all': (c_int32, [c_void_p, c_void_p, POINTER(DfqLeResult), POINTER(c_int32)]),
     'dfq_le_plan_levels': (c_int32, [c_void_p]),
     'dfq_le_plan_paired_elements': (c_int64, [c_void_p]),
     'dfq_le_plan_snapshot_elements': (c_int64, [c_void_p]),

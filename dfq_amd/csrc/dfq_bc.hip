@@ -13,6 +13,7 @@
 // BN channel: a BN's beta~ changes exactly once (when the layer in front of it is corrected), so the
 // thread that applies that update also refreshes the channel's cached E[ReLU(.)]; a step then only
 // gathers cached values.
+#include <algorithm>
 #include <map>
 #include <vector>
 
@@ -160,10 +161,30 @@ __global__ __launch_bounds__(kBlock) void bc_cache_init_kernel(const BcCacheSeg*
     sg.cache[c] = relu_mean(sg.fw[c], sg.fb[c]);
 }
 
-__global__ __launch_bounds__(kBlock) void bc_step_kernel(BcStepDev st, const BcSourceDev* __restrict__ sources) {
+constexpr int kStepWords = (int)(sizeof(BcStepDev) / 4);
+static_assert(sizeof(BcStepDev) % 4 == 0 && kStepWords <= 2 * kWave, "step descriptor must fit two wave-wide loads");
+
+// One launch = the j-th correction step of every network of the plan (grid.y = networks; a single
+// network passes its descriptor by value).  Batched descriptors live in a table and are fetched with
+// two wave-wide loads + v_readlane, like the equalisation kernel's.
+__global__ __launch_bounds__(kBlock) void bc_step_kernel(BcStepDev st_inline, const BcStepDev* __restrict__ table,
+                                                         const BcSourceDev* __restrict__ sources) {
     __shared__ float sh_E[kExpectMax];
     const int tid = threadIdx.x;
     const int lane = tid % kWave;
+    union { BcStepDev st; uint32_t u[kStepWords]; } desc;
+    if (table) {
+        const guint* src = (const guint*)(table + blockIdx.y);
+        const uint32_t w0 = src[min(lane, kStepWords - 1)];
+        const uint32_t w1 = src[min(kWave + lane, kStepWords - 1)];
+#pragma unroll
+        for (int i = 0; i < kStepWords; ++i)
+            desc.u[i] = (i < kWave) ? __builtin_amdgcn_readlane(w0, i % kWave) : __builtin_amdgcn_readlane(w1, i % kWave);
+    } else {
+        desc.st = st_inline;
+    }
+    const BcStepDev& st = desc.st;
+    if ((int)blockIdx.x * kRowsPerBlock >= st.out_ch) return;      // grid.x is sized for the widest layer of the launch
     const int o_raw = blockIdx.x * kRowsPerBlock + tid / kWave;
     const bool row_ok = o_raw < st.out_ch;
     const int o = row_ok ? o_raw : st.out_ch - 1;
@@ -225,7 +246,11 @@ struct dfq_bc_plan {
     int n_steps = 0;
     int minmax_blocks = 0, qerr_blocks = 0;
     int64_t weight_elems = 0, eps_elems = 0;
-    std::vector<BcStepDev> steps;          // host copies (kernel args by value)
+    std::vector<BcStepDev> steps;          // host copies in the caller's order
+    struct Launch { int begin, n, max_rows; };
+    std::vector<Launch> launches;          // launch j = j-th step of every network
+    std::vector<BcStepDev> launch_steps;   // launch-major copy (kernel argument by value for 1-step launches)
+    BcStepDev* d_steps = nullptr;          // launch_steps on the device (batched launches)
     std::vector<const float*> eps_ptr;
     BcLayerDev* d_layers = nullptr;
     int32_t* d_mm_begin = nullptr;
@@ -254,6 +279,7 @@ void dfq_bc_plan_destroy(dfq_bc_plan* p) {
     if (p->d_corr) (void)hipFree(p->d_corr);
     if (p->d_cache) (void)hipFree(p->d_cache);
     if (p->d_cache_segs) (void)hipFree(p->d_cache_segs);
+    if (p->d_steps) (void)hipFree(p->d_steps);
     for (auto& e : p->exec) if (e) (void)hipGraphExecDestroy(e);
     if (p->capture_stream) (void)hipStreamDestroy(p->capture_stream);
     delete p;
@@ -269,6 +295,8 @@ int dfq_bc_plan_create(const dfq_layer* layers, int32_t n_layers, const dfq_bc_s
     for (int s = 0; s < n_steps; ++s) {
         const dfq_bc_step& st = steps[s];
         if (st.layer < 0 || st.layer >= n_layers) return fail_arg("dfq_bc_plan_create: step %d: bad layer index", s);
+        if (st.net < 0 || (s > 0 && st.net < steps[s - 1].net))
+            return fail_arg("dfq_bc_plan_create: step %d: steps must be listed network by network", s);
         const dfq_layer& L = layers[st.layer];
         if (!L.weight || !L.bias) return fail_arg("dfq_bc_plan_create: step %d: layer needs weight and bias", s);
         if (st.source_count <= 0 || st.source_begin < 0 || st.source_begin + st.source_count > n_sources)
@@ -373,6 +401,28 @@ int dfq_bc_plan_create(const dfq_layer* layers, int32_t n_layers, const dfq_bc_s
         eps_off += pairs; corr_off += L.out_ch;
     }
     mmb[n_steps] = (int32_t)mb; qeb[n_steps] = (int32_t)qb;
+    // launch j = the j-th step of every network (steps arrive network by network, in graph order)
+    {
+        std::vector<int> ordinal(n_steps, 0);
+        int n_launch = 0;
+        for (int s2 = 0, cur_net = -1, k = 0; s2 < n_steps; ++s2) {
+            if (steps[s2].net != cur_net) { cur_net = steps[s2].net; k = 0; }
+            ordinal[s2] = k++;
+            n_launch = std::max(n_launch, k);
+        }
+        p->launches.assign(n_launch, dfq_bc_plan::Launch{0, 0, 0});
+        for (int s2 = 0; s2 < n_steps; ++s2) p->launches[ordinal[s2]].n += 1;
+        int off = 0;
+        for (auto& L : p->launches) { L.begin = off; off += L.n; L.n = 0; }
+        p->launch_steps.resize(n_steps);
+        for (int s2 = 0; s2 < n_steps; ++s2) {
+            auto& L = p->launches[ordinal[s2]];
+            p->launch_steps[L.begin + L.n++] = p->steps[s2];
+            L.max_rows = std::max(L.max_rows, p->steps[s2].out_ch);
+        }
+        if ((e = hipMalloc((void**)&p->d_steps, sizeof(BcStepDev) * n_steps)) != hipSuccess) return fail_alloc(e);
+        if ((e = hipMemcpy(p->d_steps, p->launch_steps.data(), sizeof(BcStepDev) * n_steps, hipMemcpyHostToDevice)) != hipSuccess) return fail_alloc(e);
+    }
     p->minmax_blocks = (int)mb; p->qerr_blocks = (int)qb;
     if ((e = hipMemcpy(p->d_layers, hl.data(), sizeof(BcLayerDev) * n_steps, hipMemcpyHostToDevice)) != hipSuccess) return fail_alloc(e);
     if ((e = hipMemcpy(p->d_mm_begin, mmb.data(), sizeof(int32_t) * (n_steps + 1), hipMemcpyHostToDevice)) != hipSuccess) return fail_alloc(e);
@@ -420,10 +470,11 @@ static int bc_run_direct(dfq_bc_plan* p, int32_t symmetric, hipStream_t st) {
                            (const BcCacheSeg*)p->d_cache_segs, p->n_cache_segs, p->cache_total);
         DFQ_CHECK_LAUNCH();
     }
-    for (int s = 0; s < p->n_steps; ++s) {
-        const BcStepDev& d = p->steps[s];
-        const int grid = (d.out_ch + kRowsPerBlock - 1) / kRowsPerBlock;
-        hipLaunchKernelGGL(bc_step_kernel, dim3(grid), dim3(kBlock), 0, st, d, (const BcSourceDev*)p->d_sources);
+    for (const auto& L : p->launches) {
+        const int grid = (L.max_rows + kRowsPerBlock - 1) / kRowsPerBlock;
+        const BcStepDev* table = (L.n == 1) ? nullptr : p->d_steps + L.begin;
+        hipLaunchKernelGGL(bc_step_kernel, dim3(grid, L.n), dim3(kBlock), 0, st, p->launch_steps[L.begin], table,
+                           (const BcSourceDev*)p->d_sources);
         DFQ_CHECK_LAUNCH();
     }
     return DFQ_OK;

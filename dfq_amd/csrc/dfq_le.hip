@@ -88,6 +88,7 @@ struct LeRelDev {
     int32_t partial_base;   // first partial slot of this relation (row tiles, then col tiles)
     int32_t boot_begin;     // first workgroup inside the bootstrap launch
     int32_t boot_tiles;
+    int32_t net;            // which network of a batched plan (index into the loop-state array)
 };
 
 struct LeParams {
@@ -110,11 +111,15 @@ struct LeLayerDiff {
     double n_elems;
 };
 
-// the relations of one launch; grid = (max tiles of a relation, n relations)
+// the relations of one launch; grid = (max tiles of a relation, n relations).  Up to kLevelRelsMax
+// descriptors ride in the kernarg (single-network plans: the latency-critical case); batched plans
+// put any number of them in a table in global memory (one more dependent fetch, amortised over the
+// networks of the batch).
 struct LevelArgs {
-    LeRelDev rel[kLevelRelsMax];
+    LeRelDev rel[kLevelRelsMax];      // MUST stay first: read straight from the kernarg segment
+    const LeRelDev* table;            // non-null: descriptors are table[blockIdx.y]
 };
-static_assert(sizeof(LevelArgs) <= 3584, "kernarg segment is limited to 4 KiB");
+static_assert(sizeof(LevelArgs) <= 3600, "kernarg segment is limited to 4 KiB");
 
 // optional per-phase cycle stamps of one workgroup (dfq_le_trace, tuning aid; null in production)
 struct LeTrace {
@@ -583,13 +588,18 @@ __global__ __launch_bounds__(kBlock) void le_level_kernel(LevelArgs args, LePara
     const int lane = threadIdx.x % kWave;
     const DFQ_CONSTANT_AS uint32_t* ka = (const DFQ_CONSTANT_AS uint32_t*)__builtin_amdgcn_kernarg_segment_ptr();
     uint32_t word = 0u;
-    if (lane < kDescWords) word = ka[blockIdx.y * kDescWords + lane];
-    else if (lane == kDescWords) word = (uint32_t)*(const DFQ_GLOBAL_AS int*)&state->done;
+    if (args.table) {
+        if (lane < kDescWords) word = ((const guint*)(args.table + blockIdx.y))[lane];
+    } else {
+        if (lane < kDescWords) word = ka[blockIdx.y * kDescWords + lane];
+        else if (lane == kDescWords) word = (uint32_t)*(const DFQ_GLOBAL_AS int*)&state->done;   // single network
+    }
     union { LeRelDev R; uint32_t u[kDescWords]; } desc;
 #pragma unroll
     for (int i = 0; i < kDescWords; ++i) desc.u[i] = __builtin_amdgcn_readlane(word, i);
-    const uint32_t done = __builtin_amdgcn_readlane(word, kDescWords);
+    uint32_t done = __builtin_amdgcn_readlane(word, kDescWords);
     const LeRelDev& R = desc.R;
+    if (args.table) done = (uint32_t)*(const DFQ_GLOBAL_AS int*)&state[R.net].done;   // batched: per-network state
     const int tile = blockIdx.x;
     const int cur = parity;
     if (done || tile >= R.n_row_tiles + R.n_col_tiles) return;   // uniform
@@ -614,11 +624,10 @@ __global__ __launch_bounds__(kBlock) void le_level_kernel(LevelArgs args, LePara
 
 // Stats of the untouched weights, once per run: R1 (rows of W1) for chain-start relations and R2
 // (columns of W2) for every relation, parity 0.  One workgroup per `kBootTc` paired channels.
-__global__ __launch_bounds__(kBlock) void le_bootstrap_kernel(const LeRelDev* __restrict__ rels, int n_rels) {
+__global__ __launch_bounds__(kBlock) void le_bootstrap_kernel(const LeRelDev* __restrict__ rels,
+                                                              const int32_t* __restrict__ rel_of_block) {
     __shared__ uint32_t sh_mn1[kBootTc], sh_mx1[kBootTc], sh_mn2[kBootTc], sh_mx2[kBootTc];
-    int r = 0;
-    while (r + 1 < n_rels && (int)blockIdx.x >= rels[r + 1].boot_begin) ++r;
-    const LeRelDev R = rels[r];
+    const LeRelDev R = rels[rel_of_block[blockIdx.x]];
     const int tid = threadIdx.x;
     const int c0 = (blockIdx.x - R.boot_begin) * kBootTc;
     const int nc = min(kBootTc, R.o1 - c0);
@@ -674,17 +683,24 @@ __global__ __launch_bounds__(kBlock) void le_bootstrap_kernel(const LeRelDev* __
     }
 }
 
-// dfq.py:105-115 on the device.  One workgroup of 16 waves: the per-tile partials and the layer
+struct LeNetDesc {           // one network of a (possibly batched) plan
+    int32_t layer_begin, n_layers;     // its targ layers, in graph order, in the layer table
+    int32_t tile_begin, n_tiles;       // its contiguous range of tile slots in the partial array
+};
+
+// dfq.py:105-115 on the device.  One 16-wave workgroup per network: its per-wave partials and layer
 // table are staged into LDS with every load in flight at once, wave w then reduces layers w, w+16,
-// ... in a fixed order.  Also clears the stat buffers the next sweep accumulates into: parity `cur`
-// of the column stats (R2) and parity `nxt` of the in-sweep row stats (leading part of the R1 arena).
-__global__ __launch_bounds__(kCtlBlock) void le_control_kernel(const LeLayerDiff* __restrict__ layers, int n_layers,
-                                                               const double* __restrict__ partials, int n_partials,
+// ... in a fixed order.  Extra workgroups (blockIdx >= n_nets) clear the stat buffers the next sweep
+// accumulates into: parity `cur` of the column stats (R2) and parity `nxt` of the in-sweep row stats
+// (leading part of the R1 arena).
+__global__ __launch_bounds__(kCtlBlock) void le_control_kernel(const LeLayerDiff* __restrict__ layers,
+                                                               const LeNetDesc* __restrict__ nets, int n_nets,
+                                                               const double* __restrict__ partials,
                                                                double* __restrict__ layer_mean,
                                                                uint32_t* __restrict__ r2_arena, int64_t r2_words,
                                                                uint32_t* __restrict__ r1_arena, int64_t r1_words,
                                                                int64_t r1_zero_words, int parity,
-                                                               LeState* __restrict__ state, double converge_thres,
+                                                               LeState* __restrict__ states, double converge_thres,
                                                                int converge_count, int max_sweeps) {
     __shared__ double sh_part[kCtlStage];
     __shared__ double sh_mean[1024];
@@ -692,32 +708,39 @@ __global__ __launch_bounds__(kCtlBlock) void le_control_kernel(const LeLayerDiff
     const int tid = threadIdx.x;
     const int lane = tid % kWave;
     const int wave = tid / kWave;
-    // every global read of the kernel is issued before the first wait: partials, layer table, state
-    const int n_stage = min(n_partials, kCtlStage);
-    if (blockIdx.x == 0) {
-        for (int i = tid; i < n_stage; i += kCtlBlock) sh_part[i] = partials[i];
-        for (int i = tid; i < min(n_layers, 1024); i += kCtlBlock) sh_layer[i] = layers[i];
-    }
-    if (state->done) return;
-    const int cur = parity;          // sweep index & 1, from the host: block 0 updates the state below
-    if (blockIdx.x > 0) {
-        // helper workgroups: clear the stat words the next sweep accumulates into
-        const int64_t nz = gridDim.x - 1, z = blockIdx.x - 1;
+    const int cur = parity;          // sweep index & 1, from the host
+    if ((int)blockIdx.x >= n_nets) {
+        // helper workgroups: clear the stat words the next sweep accumulates into (harmless once a
+        // network has converged: its stats are never read again)
+        const int64_t nz = gridDim.x - n_nets, z = blockIdx.x - n_nets;
         uint32_t* z2 = r2_arena + (int64_t)cur * r2_words;
         for (int64_t i = z * kCtlBlock + tid; i < r2_words; i += nz * kCtlBlock) z2[i] = 0u;
         uint32_t* z1 = r1_arena + (int64_t)(cur ^ 1) * r1_words;
         for (int64_t i = z * kCtlBlock + tid; i < r1_zero_words; i += nz * kCtlBlock) z1[i] = 0u;
         return;
     }
+    LeState* const state = states + blockIdx.x;
+    const LeNetDesc nd = nets[blockIdx.x];
+    layers += nd.layer_begin;
+    layer_mean += nd.layer_begin;
+    const int n_layers = nd.n_layers;
+    // every global read of the kernel is issued before the first wait: partials, layer table, state
+    const int waves_per_tile = kBlock / kWave;
+    const int64_t part0 = (int64_t)nd.tile_begin * waves_per_tile;
+    const int n_stage = min(nd.n_tiles * waves_per_tile, kCtlStage);
+    for (int i = tid; i < n_stage; i += kCtlBlock) sh_part[i] = partials[part0 + i];
+    for (int i = tid; i < min(n_layers, 1024); i += kCtlBlock) sh_layer[i] = layers[i];
+    if (state->done) return;
     __syncthreads();
     for (int l = wave; l < n_layers; l += kCtlBlock / kWave) {
         const LeLayerDiff L = (l < 1024) ? sh_layer[l] : layers[l];
         double s = 0.0;
         if (L.partial_begin >= 0) {
             // every tile left one partial per wave
-            for (int i = lane; i < L.n_partials * (kBlock / kWave); i += kWave) {
-                const int idx = L.partial_begin * (kBlock / kWave) + i;
-                s += (idx < n_stage) ? sh_part[idx] : partials[idx];
+            const int rel0 = (L.partial_begin - nd.tile_begin) * waves_per_tile;     // offset inside the staged range
+            for (int i = lane; i < L.n_partials * waves_per_tile; i += kWave) {
+                const int idx = rel0 + i;
+                s += (idx < n_stage) ? sh_part[idx] : partials[part0 + idx];
             }
             s = wave_sum(s);
         }
@@ -754,8 +777,10 @@ __global__ __launch_bounds__(kCtlBlock) void le_control_kernel(const LeLayerDiff
     }
 }
 
-__global__ void le_reset_kernel(LeState* state, double converge_thres, int converge_count, int max_sweeps) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
+__global__ void le_reset_kernel(LeState* states, int n_nets, double converge_thres, int converge_count, int max_sweeps) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_nets) {
+        LeState* state = states + i;
         state->diff = 10.0;          // dfq.py:81
         state->count = 0;            // dfq.py:82
         state->sweeps = 0;
@@ -783,7 +808,9 @@ struct LevelLaunch {
 using namespace dfq;
 
 struct dfq_le_plan {
-    int n_layers = 0, n_rels = 0;
+    int n_layers = 0, n_rels = 0, n_nets = 1;
+    LeNetDesc* d_nets = nullptr;
+    int32_t* d_boot_map = nullptr;         // bootstrap workgroup -> relation
     std::vector<LevelLaunch> levels;
     int64_t paired_total = 0, snapshot_total = 0;
     int total_tiles = 0, boot_blocks = 0;
@@ -840,6 +867,8 @@ void dfq_le_plan_destroy(dfq_le_plan* p) {
     if (p->d_layer_mean) (void)hipFree(p->d_layer_mean);
     if (p->d_state) (void)hipFree(p->d_state);
     if (p->d_stats) (void)hipFree(p->d_stats);
+    if (p->d_nets) (void)hipFree(p->d_nets);
+    if (p->d_boot_map) (void)hipFree(p->d_boot_map);
     for (float* a : p->arenas) (void)hipFree(a);
     for (auto& g : p->graphs) (void)hipGraphExecDestroy(g.exec);
     if (p->capture_stream) (void)hipStreamDestroy(p->capture_stream);
@@ -848,8 +877,28 @@ void dfq_le_plan_destroy(dfq_le_plan* p) {
 
 int dfq_le_plan_create(const dfq_layer* layers, int32_t n_layers, const dfq_relation* relations,
                        int32_t n_relations, dfq_le_plan** out_plan) {
-    if (!layers || n_layers <= 0 || !out_plan || n_relations < 0 || (n_relations > 0 && !relations))
+    return dfq_le_plan_create_batch(layers, n_layers, nullptr, 1, relations, n_relations, out_plan);
+}
+
+int dfq_le_plan_create_batch(const dfq_layer* layers, int32_t n_layers, const int32_t* layer_net, int32_t n_nets,
+                             const dfq_relation* relations, int32_t n_relations, dfq_le_plan** out_plan) {
+    if (!layers || n_layers <= 0 || !out_plan || n_relations < 0 || (n_relations > 0 && !relations) || n_nets < 1 ||
+        (n_nets > 1 && !layer_net))
         return fail_arg("dfq_le_plan_create: bad argument");
+    auto net_of = [&](int l) { return layer_net ? layer_net[l] : 0; };
+    for (int l = 0; l < n_layers; ++l) {
+        if (net_of(l) < 0 || net_of(l) >= n_nets || (l > 0 && net_of(l) < net_of(l - 1)))
+            return fail_arg("dfq_le_plan_create: layers must be listed network by network (layer %d)", l);
+    }
+    for (int r = 0; r < n_relations; ++r) {
+        const dfq_relation& rr = relations[r];
+        if (rr.first < 0 || rr.first >= n_layers || rr.second < 0 || rr.second >= n_layers) continue;   // reported below
+        if (net_of(rr.first) != net_of(rr.second))
+            return fail_arg("dfq_le_plan_create: relation %d pairs layers of two networks", r);
+        if (r > 0 && relations[r - 1].first >= 0 && relations[r - 1].first < n_layers &&
+            net_of(rr.first) < net_of(relations[r - 1].first))
+            return fail_arg("dfq_le_plan_create: relations must be listed network by network (relation %d)", r);
+    }
     // ---- validate geometry (dfq.py:29-35) and the chain structure create_relation guarantees ----
     std::vector<int> as_first(n_layers, -1), as_second(n_layers, -1);
     for (int r = 0; r < n_relations; ++r) {
@@ -881,6 +930,7 @@ int dfq_le_plan_create(const dfq_layer* layers, int32_t n_layers, const dfq_rela
     dfq_le_plan* p = new dfq_le_plan();
     p->n_layers = n_layers;
     p->n_rels = n_relations;
+    p->n_nets = n_nets;
     auto fail_alloc = [&](hipError_t e) { dfq_le_plan_destroy(p); return fail_hip(e, "le plan allocation", __FILE__, __LINE__); };
 
     // ---- snapshot arenas for layers touched twice per sweep ----
@@ -971,6 +1021,7 @@ int dfq_le_plan_create(const dfq_layer* layers, int32_t n_layers, const dfq_rela
         if ((ceil_div(d.ct_rows, d.go) + 1) * nci2 > kSlotMax)
             return (dfq_le_plan_destroy(p), fail_arg("dfq_le_plan_create: relation %d: kernel size too small for its width", r));
         d.boot_tiles = ceil_div(d.o1, kBootTc);
+        d.net = net_of(rr.first);
     }
     // producer links + slot limits need every relation's geometry, so a second pass
     int tile_slot = 0;
@@ -1009,6 +1060,14 @@ int dfq_le_plan_create(const dfq_layer* layers, int32_t n_layers, const dfq_rela
         p->paired_total += (int64_t)d.o1 * d.row_len + (int64_t)d.o2 * d.i2g * d.khkw;
     }
     p->total_tiles = tile_slot;
+    std::vector<LeNetDesc> nets(n_nets);
+    for (int n = 0; n < n_nets; ++n) { nets[n].layer_begin = 0; nets[n].n_layers = 0; nets[n].tile_begin = 0; nets[n].n_tiles = 0; }
+    for (int l = n_layers - 1; l >= 0; --l) { nets[net_of(l)].layer_begin = l; nets[net_of(l)].n_layers += 1; }
+    for (int r = n_relations - 1; r >= 0; --r) {
+        LeNetDesc& nd = nets[h[r].net];
+        nd.tile_begin = h[r].partial_base;
+        nd.n_tiles += h[r].n_row_tiles + h[r].n_col_tiles;
+    }
 
     // ---- sort relations by level (stable) and lay out the launches ----
     std::vector<int> order(n_relations);
@@ -1018,7 +1077,8 @@ int dfq_le_plan_create(const dfq_layer* layers, int32_t n_layers, const dfq_rela
     int boot = 0, prev_level = -1;
     for (int i = 0; i < n_relations; ++i) {
         const int r = order[i];
-        if (level[r] != prev_level || p->levels.back().n_rels == kLevelRelsMax) {   // new launch
+        const int launch_cap = (n_nets == 1) ? kLevelRelsMax : 65535;             // grid.y limit in table mode
+        if (level[r] != prev_level || p->levels.back().n_rels == launch_cap) {    // new launch
             p->levels.push_back(LevelLaunch());
             p->levels.back().rel_begin = i;
             prev_level = level[r];
@@ -1027,7 +1087,7 @@ int dfq_le_plan_create(const dfq_layer* layers, int32_t n_layers, const dfq_rela
         sorted[i] = h[r];
         sorted[i].boot_begin = boot;              // bootstrap launch walks the same (sorted) table
         boot += h[r].boot_tiles;
-        L.args.rel[L.n_rels] = sorted[i];
+        if (n_nets == 1) L.args.rel[L.n_rels] = sorted[i];
         L.n_blocks += h[r].n_row_tiles + h[r].n_col_tiles;
         L.max_tiles = std::max(L.max_tiles, h[r].n_row_tiles + h[r].n_col_tiles);
         L.n_rels += 1;
@@ -1039,18 +1099,26 @@ int dfq_le_plan_create(const dfq_layer* layers, int32_t n_layers, const dfq_rela
     }
     for (const LevelLaunch& L : p->levels) p->snapshot_total += L.snapshot;
     p->boot_blocks = boot;
+    std::vector<int32_t> boot_map(std::max(1, boot));
+    for (int i = 0; i < n_relations; ++i)
+        for (int b = 0; b < sorted[i].boot_tiles; ++b) boot_map[sorted[i].boot_begin + b] = i;
 
     const size_t n_part = (size_t)std::max(1, p->total_tiles) * (kBlock / kWave);
     if ((e = hipMalloc((void**)&p->d_rels, sizeof(LeRelDev) * std::max(1, n_relations))) != hipSuccess) return fail_alloc(e);
     if ((e = hipMalloc((void**)&p->d_layer_diff, sizeof(LeLayerDiff) * n_layers)) != hipSuccess) return fail_alloc(e);
     if ((e = hipMalloc((void**)&p->d_partials, sizeof(double) * n_part)) != hipSuccess) return fail_alloc(e);
     if ((e = hipMalloc((void**)&p->d_layer_mean, sizeof(double) * n_layers)) != hipSuccess) return fail_alloc(e);
-    if ((e = hipMalloc((void**)&p->d_state, sizeof(LeState))) != hipSuccess) return fail_alloc(e);
+    if ((e = hipMalloc((void**)&p->d_state, sizeof(LeState) * n_nets)) != hipSuccess) return fail_alloc(e);
+    if ((e = hipMalloc((void**)&p->d_nets, sizeof(LeNetDesc) * n_nets)) != hipSuccess) return fail_alloc(e);
+    if ((e = hipMalloc((void**)&p->d_boot_map, sizeof(int32_t) * boot_map.size())) != hipSuccess) return fail_alloc(e);
+    if ((e = hipMemcpy(p->d_nets, nets.data(), sizeof(LeNetDesc) * n_nets, hipMemcpyHostToDevice)) != hipSuccess) return fail_alloc(e);
+    if ((e = hipMemcpy(p->d_boot_map, boot_map.data(), sizeof(int32_t) * boot_map.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail_alloc(e);
     if (n_relations > 0 &&
         (e = hipMemcpy(p->d_rels, sorted.data(), sizeof(LeRelDev) * n_relations, hipMemcpyHostToDevice)) != hipSuccess) return fail_alloc(e);
     if ((e = hipMemcpy(p->d_layer_diff, ld.data(), sizeof(LeLayerDiff) * n_layers, hipMemcpyHostToDevice)) != hipSuccess) return fail_alloc(e);
     if ((e = hipMemset(p->d_partials, 0, sizeof(double) * n_part)) != hipSuccess) return fail_alloc(e);
-    if ((e = hipMemset(p->d_state, 0, sizeof(LeState))) != hipSuccess) return fail_alloc(e);
+    if ((e = hipMemset(p->d_state, 0, sizeof(LeState) * n_nets)) != hipSuccess) return fail_alloc(e);
+    for (LevelLaunch& L : p->levels) L.args.table = (n_nets == 1) ? nullptr : p->d_rels + L.rel_begin;
     if ((e = hipDeviceSynchronize()) != hipSuccess) return fail_alloc(e);
     *out_plan = p;
     return DFQ_OK;
@@ -1088,14 +1156,14 @@ static LeParams make_params(const dfq_le_config* c) {
 
 // reset the loop state, clear every stat word, recompute the stats of the untouched weights
 static int le_restart(dfq_le_plan* p, const dfq_le_config* cfg, hipStream_t st) {
-    hipLaunchKernelGGL(le_reset_kernel, dim3(1), dim3(64), 0, st, p->d_state, cfg->converge_thres,
+    hipLaunchKernelGGL(le_reset_kernel, dim3((p->n_nets + 63) / 64), dim3(64), 0, st, p->d_state, p->n_nets, cfg->converge_thres,
                        (int)cfg->converge_count, (int)cfg->max_sweeps);
     DFQ_CHECK_LAUNCH();
     p->sweep_index = 0;
     if (p->n_rels > 0) {
         DFQ_HIP_TRY(hipMemsetAsync(p->d_stats, 0, sizeof(uint32_t) * 4 * p->stat_words, st));
         hipLaunchKernelGGL(le_bootstrap_kernel, dim3(p->boot_blocks), dim3(kBlock), 0, st,
-                           (const LeRelDev*)p->d_rels, p->n_rels);
+                           (const LeRelDev*)p->d_rels, (const int32_t*)p->d_boot_map);
         DFQ_CHECK_LAUNCH();
     }
     return DFQ_OK;
@@ -1112,8 +1180,9 @@ static int le_launch_level(dfq_le_plan* p, const LevelLaunch& L, const LeParams&
 
 static int le_launch_control(dfq_le_plan* p, const dfq_le_config* cfg, hipStream_t st) {
     const int n_clear = (int)std::min<int64_t>(32, (p->stat_words + p->r1_zero_words + 4 * kCtlBlock - 1) / (4 * kCtlBlock));
-    hipLaunchKernelGGL(le_control_kernel, dim3(1 + std::max(1, n_clear)), dim3(kCtlBlock), 0, st, (const LeLayerDiff*)p->d_layer_diff,
-                       p->n_layers, (const double*)p->d_partials, p->total_tiles * (kBlock / kWave), p->d_layer_mean, p->d_stats,
+    hipLaunchKernelGGL(le_control_kernel, dim3(p->n_nets + std::max(1, n_clear)), dim3(kCtlBlock), 0, st,
+                       (const LeLayerDiff*)p->d_layer_diff, (const LeNetDesc*)p->d_nets, p->n_nets,
+                       (const double*)p->d_partials, p->d_layer_mean, p->d_stats,
                        (int64_t)p->stat_words, p->d_stats + 2 * p->stat_words, (int64_t)p->stat_words,
                        (int64_t)p->r1_zero_words, (int)(p->sweep_index & 1),
                        p->d_state, cfg->converge_thres, (int)cfg->converge_count, (int)cfg->max_sweeps);
@@ -1255,21 +1324,36 @@ int dfq_le_trace(dfq_le_plan* p, const dfq_le_config* cfg, int32_t launch, int32
     return rc;
 }
 
-int dfq_le_query(dfq_le_plan* p, void* stream, dfq_le_result* out, int32_t* done) {
+int dfq_le_query_all(dfq_le_plan* p, void* stream, dfq_le_result* out, int32_t* all_done) {
     if (!p) return fail_arg("dfq_le_query: null plan");
-    LeState h;
+    std::vector<LeState> h(p->n_nets);
     hipStream_t st = as_stream(stream);
-    DFQ_HIP_TRY(hipMemcpyAsync(&h, p->d_state, sizeof(LeState), hipMemcpyDeviceToHost, st));
+    DFQ_HIP_TRY(hipMemcpyAsync(h.data(), p->d_state, sizeof(LeState) * p->n_nets, hipMemcpyDeviceToHost, st));
     DFQ_HIP_TRY(hipStreamSynchronize(st));
-    if (out) {
-        out->sweeps = h.sweeps;
-        out->stall_count = h.count;
-        out->diff = h.diff;
-        out->last_diff_tmp = h.last_diff_tmp;
+    int32_t done = 1;
+    for (int n = 0; n < p->n_nets; ++n) {
+        if (out) {
+            out[n].sweeps = h[n].sweeps;
+            out[n].stall_count = h[n].count;
+            out[n].diff = h[n].diff;
+            out[n].last_diff_tmp = h[n].last_diff_tmp;
+        }
+        done &= h[n].done ? 1 : 0;
     }
-    if (done) *done = h.done;
+    if (all_done) *all_done = done;
     return DFQ_OK;
 }
+
+int dfq_le_query(dfq_le_plan* p, void* stream, dfq_le_result* out, int32_t* done) {
+    if (!p) return fail_arg("dfq_le_query: null plan");
+    std::vector<dfq_le_result> all(p->n_nets);
+    const int rc = dfq_le_query_all(p, stream, all.data(), done);
+    if (rc) return rc;
+    if (out) *out = all[0];
+    return DFQ_OK;
+}
+
+int32_t dfq_le_plan_nets(const dfq_le_plan* p) { return p ? p->n_nets : 0; }
 
 int dfq_le_run(dfq_le_plan* p, const dfq_le_config* cfg, void* stream, dfq_le_result* out) {
     if (!p || !cfg) return fail_arg("dfq_le_run: bad argument");

@@ -51,9 +51,11 @@ class LEPlan:
     number of sweeps, asynchronous -- what bench.py times with the weights resident in HBM).
     """
 
-    def __init__(self, layers, relations, stage=None):
+    def __init__(self, layers, relations, stage=None, layer_net=None):
         """layers: list of (weight, bias|None, groups); relations: list of
-        (first_idx, second_idx, bn_weight|None, bn_bias|None, scale_cum tensor [O1])."""
+        (first_idx, second_idx, bn_weight|None, bn_bias|None, scale_cum tensor [O1]).
+        ``layer_net`` (optional, list of ints, non-decreasing) makes it a batched plan over several
+        independent networks: every launch then covers all of them, each with its own loop state."""
         self.stage = stage or _ffi.Stage()
         self._keep = []
         entries = []
@@ -74,7 +76,14 @@ class LEPlan:
         larr = (_ffi.DfqLayer * len(entries))(*entries)
         rarr = (_ffi.DfqRelation * max(1, len(rels)))(*rels)
         self._plan = ctypes.c_void_p()
-        _ffi.check(_ffi.lib().dfq_le_plan_create(larr, len(entries), rarr, len(rels), ctypes.byref(self._plan)))
+        if layer_net is None:
+            self.n_nets = 1
+            _ffi.check(_ffi.lib().dfq_le_plan_create(larr, len(entries), rarr, len(rels), ctypes.byref(self._plan)))
+        else:
+            self.n_nets = max(layer_net) + 1
+            narr = (ctypes.c_int32 * len(entries))(*[int(v) for v in layer_net])
+            _ffi.check(_ffi.lib().dfq_le_plan_create_batch(larr, len(entries), narr, self.n_nets, rarr, len(rels),
+                                                           ctypes.byref(self._plan)))
 
     # -- introspection -----------------------------------------------------------------------
     @property
@@ -139,6 +148,14 @@ class LEPlan:
         return dict(sweeps=res.sweeps, stall_count=res.stall_count, diff=res.diff, last_diff_tmp=res.last_diff_tmp,
                     done=bool(done.value))
 
+    def query_all(self):
+        """Loop state of every network of a batched plan."""
+        res = (_ffi.DfqLeResult * self.n_nets)()
+        done = ctypes.c_int32()
+        _ffi.check(_ffi.lib().dfq_le_query_all(self._plan, _ffi.stream_arg(), res, ctypes.byref(done)))
+        return [dict(sweeps=r.sweeps, stall_count=r.stall_count, diff=r.diff, last_diff_tmp=r.last_diff_tmp)
+                for r in res], bool(done.value)
+
     def close(self):
         if self._plan:
             _ffi.lib().dfq_le_plan_destroy(self._plan)
@@ -149,6 +166,29 @@ class LEPlan:
             self.close()
         except Exception:
             pass
+
+
+def build_le_plan_batch(items, targ_type, stage=None):
+    """One plan over several independent networks: ``items`` is a list of (graph, relations).  The
+    launches of a sweep then cover the whole batch (launch and latency costs are shared), while every
+    network keeps the reference's own convergence loop."""
+    stage = stage or _ffi.Stage()
+    layers, rels, layer_net = [], [], []
+    for net, (graph, relations) in enumerate(items):
+        keys = [k for k in graph if type(graph[k]) in targ_type]
+        base = len(layers)
+        index = {k: base + i for i, k in enumerate(keys)}
+        for rr in relations:                                  # dfq.py:91-92
+            _ensure_bias(graph[rr.get_idxs()[0]])
+        layers += [(graph[k].weight, graph[k].bias, getattr(graph[k], 'groups', 1)) for k in keys]
+        layer_net += [net] * len(keys)
+        for rr in relations:
+            kf, ks, kb = rr.get_idxs()
+            if rr.S is None:
+                rr.S = torch.ones(graph[kf].weight.size(0), dtype=torch.float32, device=stage.device)
+            bn = graph[kb] if kb is not None else None
+            rels.append((index[kf], index[ks], getattr(bn, 'fake_weight', None), getattr(bn, 'fake_bias', None), rr.S))
+    return LEPlan(layers, rels, stage=stage, layer_net=layer_net)
 
 
 def build_le_plan(graph, relations, targ_type, stage=None):
@@ -312,7 +352,8 @@ class BCPlan:
 
     def __init__(self, layers, steps, stage=None):
         """layers: list of (weight, bias, groups); steps: list of (layer_idx, [source,...],
-        next_bn_bias|None); source = (fake_weight, fake_bias, relu, concat)."""
+        next_bn_bias|None[, net]); source = (fake_weight, fake_bias, relu, concat).  With `net` ids
+        (network by network) the j-th steps of all networks share one launch."""
         self.stage = stage or _ffi.Stage()
         self._keep = []
         entries = []
@@ -321,7 +362,8 @@ class BCPlan:
             entries.append(e)
             self._keep.append(keep)
         src_arr, step_arr = [], []
-        for (li, srcs, nxt) in steps:
+        steps = [tuple(st) + (0,) if len(st) == 3 else tuple(st) for st in steps]
+        for (li, srcs, nxt, net) in steps:
             begin = len(src_arr)
             for (fw, fb, relu, concat) in srcs:
                 dfw, dfb = self.stage.bind(fw), self.stage.bind(fb)
@@ -330,10 +372,11 @@ class BCPlan:
                                                 int(dfb.numel()), int(bool(relu)), int(bool(concat))))
             dn = self.stage.bind(nxt)
             self._keep.append(dn)
-            step_arr.append(_ffi.DfqBcStep(int(li), begin, len(srcs), dn.data_ptr() if dn is not None else None))
+            step_arr.append(_ffi.DfqBcStep(int(li), begin, len(srcs), dn.data_ptr() if dn is not None else None,
+                                           int(net), 0))
         self.n_steps = len(step_arr)
-        self.step_out_ch = [int(layers[li][0].shape[0]) for (li, _, _) in steps]
-        self.step_in = [int(layers[li][0].shape[1]) for (li, _, _) in steps]
+        self.step_out_ch = [int(layers[li][0].shape[0]) for (li, _, _, _) in steps]
+        self.step_in = [int(layers[li][0].shape[1]) for (li, _, _, _) in steps]
         larr = (_ffi.DfqLayer * len(entries))(*entries)
         sarr = (_ffi.DfqBcStep * len(step_arr))(*step_arr)
         carr = (_ffi.DfqBcSource * len(src_arr))(*src_arr)
@@ -396,11 +439,27 @@ class _RawDeviceBuffer:
         return torch.from_numpy(np.ctypeslib.as_array(buf).copy())
 
 
+def build_bc_plan_batch(items, targ_type, bn_type=torch.nn.BatchNorm2d, stage=None):
+    """One bias-correction plan over several independent networks: ``items`` = [(graph, bottoms), ...]."""
+    stage = stage or _ffi.Stage()
+    layers, steps = [], []
+    for net, (graph, bottoms) in enumerate(items):
+        l, s, _ = _bc_tables(graph, bottoms, targ_type, bn_type, base=len(layers), net=net)
+        layers += l
+        steps += s
+    return BCPlan(layers, steps, stage=stage)
+
+
 def build_bc_plan(graph, bottoms, targ_type, bn_type=torch.nn.BatchNorm2d, stage=None):
     """Walk the graph like dfq.py:194-293 and flatten what each layer's correction needs."""
     stage = stage or _ffi.Stage()
+    layers, steps, keys = _bc_tables(graph, bottoms, targ_type, bn_type)
+    return BCPlan(layers, steps, stage=stage), keys
+
+
+def _bc_tables(graph, bottoms, targ_type, bn_type, base=0, net=0):
     keys = [k for k in graph if type(graph[k]) in targ_type]
-    index = {k: i for i, k in enumerate(keys)}
+    index = {k: base + i for i, k in enumerate(keys)}
     bn_module, relu_attached = {}, {}
     steps = []
     pending = None                       # step whose -bias still waits for "the next BN" (bias_prev)
@@ -413,7 +472,7 @@ def build_bc_plan(graph, bottoms, targ_type, bn_type=torch.nn.BatchNorm2d, stage
             bn_module[key] = node
             relu_attached[key] = False
             if pending is not None:
-                assert node.fake_bias.numel() == graph[keys[pending[0]]].weight.size(0), \
+                assert node.fake_bias.numel() == graph[keys[pending[0] - base]].weight.size(0), \
                     'bias correction: BN after layer has a different channel count'
                 pending[2] = node.fake_bias
                 pending = None
@@ -432,11 +491,11 @@ def build_bc_plan(graph, bottoms, targ_type, bn_type=torch.nn.BatchNorm2d, stage
             for j, (bn, _, relu, ctype) in enumerate(ordered):
                 srcs.append((bn.fake_weight, bn.fake_bias, relu, j > 0 and ctype == 'cat'))
             _ensure_bias(node)
-            step = [index[key], srcs, None]
+            step = [index[key], srcs, None, net]
             steps.append(step)
             pending = step
     layers = [(graph[k].weight, graph[k].bias, getattr(graph[k], 'groups', 1)) for k in keys]
-    return BCPlan(layers, [tuple(s) for s in steps], stage=stage), [keys[s[0]] for s in steps]
+    return layers, [tuple(s) for s in steps], [keys[s[0] - base] for s in steps]
 
 
 def bias_correction(graph, bottoms, targ_type, bits_weight=8, bn_type=torch.nn.BatchNorm2d, signed=False):

@@ -104,7 +104,15 @@ typedef struct dfq_le_result {
 int dfq_le_plan_create(const dfq_layer* layers, int32_t n_layers,
                        const dfq_relation* relations, int32_t n_relations,
                        dfq_le_plan** out_plan);
+/* Batched form: several independent networks in one plan.  `layer_net[l]` in [0, n_nets) is the network
+ * of layer l; layers and relations must be listed network by network.  Every launch then covers all
+ * networks (relation descriptors come from a table in global memory instead of the kernarg), each
+ * network keeps its own loop state, so networks may converge after different sweep counts.  The sweep
+ * loop of the batch runs until every network has stopped. */
+int dfq_le_plan_create_batch(const dfq_layer* layers, int32_t n_layers, const int32_t* layer_net, int32_t n_nets,
+                             const dfq_relation* relations, int32_t n_relations, dfq_le_plan** out_plan);
 void dfq_le_plan_destroy(dfq_le_plan* plan);
+int32_t dfq_le_plan_nets(const dfq_le_plan* plan);
 
 /* introspection (tests, bench byte accounting) */
 int32_t dfq_le_plan_levels(const dfq_le_plan* plan);
@@ -121,8 +129,10 @@ int dfq_le_plan_level_grid(const dfq_le_plan* plan, int32_t level, int32_t* grid
  * loop state (diff = 10, count = 0) first. */
 int dfq_le_enqueue(dfq_le_plan* plan, const dfq_le_config* cfg, int32_t n_sweeps, int32_t restart,
                    void* stream);
-/* Copy the loop state back (synchronises `stream`). */
+/* Copy the loop state back (synchronises `stream`).  dfq_le_query: network 0, *done = every network of the
+ * plan has stopped; dfq_le_query_all: `out` has dfq_le_plan_nets() entries. */
 int dfq_le_query(dfq_le_plan* plan, void* stream, dfq_le_result* out, int32_t* done);
+int dfq_le_query_all(dfq_le_plan* plan, void* stream, dfq_le_result* out, int32_t* all_done);
 /* The whole dfq.py:83-115 loop: enqueue in chunks, poll, stop when the device says so.
  * Synchronises. */
 int dfq_le_run(dfq_le_plan* plan, const dfq_le_config* cfg, void* stream, dfq_le_result* out);
@@ -216,6 +226,10 @@ typedef struct dfq_bc_step {
     int32_t source_count;
     float* next_bn_bias;       /* device [out_ch]: fake_bias of the next BN in graph order,
                                   receives += (-bias) (dfq.py:204-206,293); NULL if none    */
+    int32_t net;               /* network of a batched plan (0 for a single network); steps are
+                                  listed network by network, each network in graph order: the
+                                  j-th steps of all networks share one launch                 */
+    int32_t reserved;
 } dfq_bc_step;
 
 int dfq_bc_plan_create(const dfq_layer* layers, int32_t n_layers,

@@ -34,7 +34,7 @@ bench._gpu_elapsed_ms = _elapsed
 import contextlib
 bench._new_stream = lambda dev: None
 bench._stream_ctx = lambda s: contextlib.nullcontext()
-sys.argv = ['bench.py', '--net', 'tiny_mobile', '--steps', '2', '--warmup', '1', '--cpu-seconds', '0.2', '--streams', '1']
+sys.argv = ['bench.py', '--net', 'tiny_mobile', '--steps', '2', '--warmup', '1', '--cpu-seconds', '0.2', '--streams', '1', '--batch', '2']
 bench.main()
 
 # smoke() with cuda patched out

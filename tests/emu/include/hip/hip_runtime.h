@@ -49,6 +49,7 @@ struct ThreadCtx {
     dim3 tid, bid, bdim, gdim;
     uint64_t slot;
     uint32_t rl_val = 0;
+    const void* rl_where = nullptr;
     bool rl_valid = false;
 };
 extern ThreadCtx* cur;
@@ -56,6 +57,7 @@ extern ThreadCtx* cur;
 void launch(dim3 grid, dim3 block, const std::function<void()>& body);
 void sync_block();
 void sync_wave();
+uint64_t peer_rl(int src_lane, bool* valid);
 uint64_t peer_slot(int lane_xor_mask, bool* valid);
 uint64_t peer_slot_abs(int src_lane, bool* valid);
 
@@ -101,21 +103,30 @@ inline T __shfl(T v, int src_lane) {
 template <typename T>
 inline T __shfl_xor(T v, int mask) { return emu::shfl_xor(v, mask); }
 
-namespace emu { uint64_t peer_rl(int src_lane, bool* valid); }
-// v_readlane broadcast.  A kernel typically reads many lanes of ONE register in a row; after the
-// first rendezvous every lane's value sits in its `rl_val`, so further reads of the same register
-// need no rendezvous (each fiber is fresh per workgroup, rl_valid starts false).
-inline int __builtin_amdgcn_readlane(int v0, int src_lane) {      // the real builtin takes and returns int
+// v_readlane broadcast.  Kernels read many lanes of ONE register in a row; the register is
+// identified by the address of the variable passed in (the macro below), so the wave rendezvous
+// happens once per register instead of once per read.  All lanes execute the same sequence of call
+// sites, hence they agree on when a new register starts.  Limitation (checked): the variable must not
+// change between two reads of the same run.
+namespace emu {
+inline int readlane_ref(const void* where, int v0, int src_lane) {
     const uint32_t v = (uint32_t)v0;
-    if (!(emu::cur->rl_valid && emu::cur->rl_val == v)) {
-        emu::cur->rl_val = v;
-        emu::cur->rl_valid = true;
-        emu::sync_wave();
+    if (!(cur->rl_valid && cur->rl_where == where)) {
+        if (cur->rl_valid) sync_wave();        // every lane has finished reading the previous register
+        cur->rl_val = v;
+        cur->rl_where = where;
+        cur->rl_valid = true;
+        sync_wave();
+    } else if (cur->rl_val != v) {
+        fprintf(stderr, "emu: readlane source changed between reads of one run\n");
+        abort();
     }
     bool ok = false;
-    const uint64_t got = emu::peer_rl(src_lane, &ok);
+    const uint64_t got = peer_rl(src_lane, &ok);
     return ok ? (int)(uint32_t)got : v0;
 }
+}  // namespace emu
+#define __builtin_amdgcn_readlane(v, lane) emu::readlane_ref(&(v), (int)(v), (lane))
 
 inline long long __double_as_longlong(double d) { long long v; memcpy(&v, &d, 8); return v; }
 inline double __longlong_as_double(long long v) { double d; memcpy(&d, &v, 8); return d; }

@@ -258,6 +258,56 @@ def test_equalization_tile_shapes(engine, monkeypatch, name, seed, suffix, tile_
         assert_bitexact(npy(r.get_scale_vec()), s)
 
 
+def test_batched_plan_matches_separate_runs(engine):
+    """Several networks in one plan (every launch covers the batch): each network must end exactly
+    where a plan of its own ends, including its own sweep count."""
+    cases = [('tiny_mobile', 0, ''), ('tiny_cat', 0, ''), ('tiny_mobile', 1, '_abs'), ('tiny_res', 0, '')]
+    items, specs = [], []
+    for name, seed, suffix in cases:
+        gold = net_fixture(name, seed, suffix)
+        model, graph, bottoms = _build(name, seed, gold, engine)
+        spec = graphspec.from_torch(graph, bottoms, TARG)
+        lt.merge_batchnorm(model, graph, bottoms, TARG)
+        orc.merge_batchnorm(spec)
+        items.append((graph, rel.create_relation(graph, bottoms, TARG)))
+        specs.append(spec)
+    plan = dfq.build_le_plan_batch(items, TARG)
+    assert plan.n_nets == len(cases)
+    plan.run()
+    results, all_done = plan.query_all()
+    assert all_done
+    for (graph, rels), spec, res in zip(items, specs, results):
+        n_o, S_o = orc.cross_layer_equalization(spec, orc.create_relation(spec))
+        assert res['sweeps'] == n_o
+        osnap, esnap = _spec_snapshot(spec), snapshot(graph)
+        for k in osnap:
+            assert_bitexact(esnap[k], osnap[k], k)
+        for r, s in zip(rels, S_o):
+            assert_bitexact(npy(r.get_scale_vec()), s)
+
+
+def test_batched_bias_correction_matches_separate_runs(engine):
+    """The j-th correction steps of all networks of a batch share one launch; every network must get
+    exactly what its own plan gives it."""
+    cases = [('tiny_mobile', 0, ''), ('tiny_cat', 0, ''), ('tiny_res', 0, '')]
+    items, singles = [], []
+    for name, seed, suffix in cases:
+        gold = net_fixture(name, seed, suffix)
+        for target in (items, singles):
+            model, graph, bottoms = _build(name, seed, gold, engine)
+            lt.merge_batchnorm(model, graph, bottoms, TARG)
+            load_stage(graph, gold, 'abs')
+            target.append((graph, bottoms))
+    plan = dfq.build_bc_plan_batch(items, TARG)
+    plan.run()
+    for (graph, bottoms), (g1, b1), (name, seed, suffix) in zip(items, singles, cases):
+        dfq.bias_correction(g1, b1, TARG)
+        a, b = snapshot(graph), snapshot(g1)
+        for k in b:
+            assert_bitexact(a[k], b[k], '{} {}'.format(name, k))
+        compare_stage(a, net_fixture(name, seed, suffix), 'bc', what=name)
+
+
 def test_graph_replay_mode(engine, monkeypatch):
     """DFQ_GRAPH=1: the sweep run and the BC chain are recorded once and replayed as hipGraphs."""
     monkeypatch.setenv('DFQ_GRAPH', '1')
