@@ -23,6 +23,7 @@ namespace dfq {
 
 constexpr int kQChunk = kBlock * 16;
 constexpr int kExpectMax = 8192;       // floats of E[x] kept in LDS (32 KiB)
+constexpr int kExpectSmall = 2048;     // ... by the kernel variant used when every step of a launch fits (8 KiB)
 constexpr int kRowsPerBlock = kBlock / kWave;   // output rows of the matvec per workgroup: one per wave
 constexpr int kBcRegs = 24;            // eps values a lane preloads (rows up to 1536 inputs per group)
 
@@ -52,6 +53,7 @@ struct BcStepDev {
     float* next_cache;       // its relu_mean cache
     float* corr;             // [O] out: the correction `bias` of dfq.py:285-287
     int32_t out_ch, in_per_group, source_begin, source_count, expect_len, inline_sources;
+    int32_t lg_lanes, chunks, rows_per_block, pad;     // work split, see bc_step_kernel
     BcSourceDev src[kStepSources];   // copy of sources[source_begin ...] when source_count <= kStepSources
 };
 
@@ -164,14 +166,29 @@ __global__ __launch_bounds__(kBlock) void bc_cache_init_kernel(const BcCacheSeg*
 constexpr int kStepWords = (int)(sizeof(BcStepDev) / 4);
 static_assert(sizeof(BcStepDev) % 4 == 0 && kStepWords <= 2 * kWave, "step descriptor must fit two wave-wide loads");
 
+__device__ __forceinline__ int bc_small_div(int a, int b) {     // exact for 0 <= a < 2^20 (see dfq_le.hip)
+    return (int)(((float)a + 0.5f) * __builtin_amdgcn_rcpf((float)b));
+}
+
 // One launch = the j-th correction step of every network of the plan (grid.y = networks; a single
 // network passes its descriptor by value).  Batched descriptors live in a table and are fetched with
 // two wave-wide loads + v_readlane, like the equalisation kernel's.
+//
+// Work split (chosen by the plan, carried in the descriptor): `lanes` = 2^lg_lanes lanes share an
+// output row (64 for rows of >= 64 inputs, fewer for narrow / depthwise rows, so one wave covers
+// 64/lanes rows per register slot); a row longer than `lanes` takes `chunks` slots; a wave owns
+// rows_per_block/4 consecutive rows, all of whose eps values are in registers (<= kBcRegs slots)
+// before the expectation vector is assembled.  The per-row tail -- bias update, next BN's beta~ and the
+// float64 ReLU moment behind it -- runs one row per THREAD after a barrier, so its long dependent
+// chain is paid once per workgroup instead of once per row.
+template <int kExp>
 __global__ __launch_bounds__(kBlock) void bc_step_kernel(BcStepDev st_inline, const BcStepDev* __restrict__ table,
                                                          const BcSourceDev* __restrict__ sources) {
-    __shared__ float sh_E[kExpectMax];
+    __shared__ float sh_E[kExp];
+    __shared__ float sh_corr[kBlock];
     const int tid = threadIdx.x;
     const int lane = tid % kWave;
+    const int wave = tid / kWave;
     union { BcStepDev st; uint32_t u[kStepWords]; } desc;
     if (table) {
         const guint* src = (const guint*)(table + blockIdx.y);
@@ -184,17 +201,31 @@ __global__ __launch_bounds__(kBlock) void bc_step_kernel(BcStepDev st_inline, co
         desc.st = st_inline;
     }
     const BcStepDev& st = desc.st;
-    if ((int)blockIdx.x * kRowsPerBlock >= st.out_ch) return;      // grid.x is sized for the widest layer of the launch
-    const int o_raw = blockIdx.x * kRowsPerBlock + tid / kWave;
-    const bool row_ok = o_raw < st.out_ch;
-    const int o = row_ok ? o_raw : st.out_ch - 1;
-    // this wave's row of eps goes into registers first: the fetch overlaps the expectation build
-    const float* er = st.eps + (int64_t)o * st.in_per_group;
+    const int rpb = st.rows_per_block;
+    if ((int)blockIdx.x * rpb >= st.out_ch) return;                // grid.x is sized for the largest step of the launch
+    const int in = st.in_per_group;
+    const int lanes = 1 << st.lg_lanes;
+    const int rps = kWave >> st.lg_lanes;                          // rows per register slot
+    const int chunks = st.chunks;
+    const int rw = rpb / kRowsPerBlock;                            // rows of this wave
+    const int sub = lane >> st.lg_lanes;                           // row inside a slot
+    const int ln = lane & (lanes - 1);
+    const int row0 = blockIdx.x * rpb + wave * rw;
+    const int n_slots = min(kBcRegs, ((rw + rps - 1) >> (6 - st.lg_lanes)) * chunks);
+    // ---- this wave's eps values go into registers first: the fetch overlaps the expectation build ----
     float ev[kBcRegs];
-    const int n_pre = min(kBcRegs, (st.in_per_group + kWave - 1) / kWave);
+    {
+        int rg = 0, c = 0;
 #pragma unroll
-    for (int u = 0; u < kBcRegs; ++u)
-        if (u < n_pre) ev[u] = er[min(lane + u * kWave, st.in_per_group - 1)];
+        for (int u = 0; u < kBcRegs; ++u) {
+            if (u < n_slots) {
+                const int row = min(row0 + rg * rps + sub, st.out_ch - 1);
+                const int col = min(c * lanes + ln, in - 1);
+                ev[u] = st.eps[(int64_t)row * in + col];
+                if (++c == chunks) { c = 0; ++rg; }
+            }
+        }
+    }
     // ---- E[x]: first source assigns, 'cat' appends, anything else adds (dfq.py:229-270) ----
     int cur_len = 0;
     for (int m = 0; m < st.source_count; ++m) {
@@ -210,23 +241,49 @@ __global__ __launch_bounds__(kBlock) void bc_step_kernel(BcStepDev st_inline, co
         cur_len = (m == 0) ? s.channels : (s.concat ? cur_len + s.channels : cur_len);
         __syncthreads();
     }
-    // ---- grouped matvec: ONE output row per wave (rows of a layer are independent, so the layer's
-    //      latency is one row's latency), float64 accumulation rounded once.  The row of eps was
-    //      loaded into registers before the barrier above. ----
-    const int num_group = st.expect_len / st.in_per_group;
+    // ---- grouped matvec (dfq.py:281-287), float64 accumulation rounded once per row ----
+    const int num_group = st.expect_len / in;
     const int step_o = st.out_ch / num_group;
-    const int step_i = st.expect_len / num_group;
-    const float* ex = sh_E + (o / step_o) * step_i;
-    double acc = 0.0;
+    if (chunks > kBcRegs) {
+        // very long rows (> 1536 inputs): one row per wave, the tail streams from memory
+        const int o = min(row0, st.out_ch - 1);
+        const float* ex = sh_E + bc_small_div(o, step_o) * in;
+        const float* er = st.eps + (int64_t)o * in;
+        double acc = 0.0;
 #pragma unroll
-    for (int u = 0; u < kBcRegs; ++u) {
-        const int i = lane + u * kWave;
-        if (u < n_pre) acc += (i < st.in_per_group) ? (double)ev[u] * (double)ex[i] : 0.0;
+        for (int u = 0; u < kBcRegs; ++u) {
+            const int i = lane + u * kWave;
+            acc += (i < in) ? (double)ev[u] * (double)ex[i] : 0.0;
+        }
+        for (int i = lane + kBcRegs * kWave; i < in; i += kWave) acc += (double)er[i] * (double)ex[i];
+        acc = wave_sum(acc);
+        if (lane == 0) sh_corr[wave * rw] = (float)acc;
+    } else {
+        int rg = 0, c = 0;
+        double acc = 0.0;
+#pragma unroll
+        for (int u = 0; u < kBcRegs; ++u) {
+            if (u < n_slots) {
+                const int r_local = rg * rps + sub;
+                const int row = row0 + r_local;
+                const int col = c * lanes + ln;
+                const bool ok = r_local < rw && row < st.out_ch && col < in;
+                const int g = bc_small_div(min(row, st.out_ch - 1), step_o);
+                const float e = sh_E[g * in + min(col, in - 1)];
+                acc += ok ? (double)ev[u] * (double)e : 0.0;
+                if (++c == chunks) {                                   // the rows of this slot group are complete
+                    for (int m = lanes >> 1; m >= 1; m >>= 1) acc += __shfl_xor(acc, m);
+                    if (ln == 0 && r_local < rw) sh_corr[wave * rw + r_local] = (float)acc;
+                    acc = 0.0; c = 0; ++rg;
+                }
+            }
+        }
     }
-    for (int i = lane + kBcRegs * kWave; i < st.in_per_group; i += kWave) acc += (double)er[i] * (double)ex[i];
-    acc = wave_sum(acc);
-    if (lane == 0 && row_ok) {
-        const float corr = (float)acc;
+    __syncthreads();
+    // ---- one row per thread: dfq.py:290-293 and the refreshed ReLU moment of the next BN ----
+    const int o = blockIdx.x * rpb + tid;
+    if (tid < rpb && o < st.out_ch) {
+        const float corr = sh_corr[tid];
         const float neg = -corr;
         st.corr[o] = corr;
         st.bias[o] = st.bias[o] + neg;                            // dfq.py:292
@@ -247,7 +304,7 @@ struct dfq_bc_plan {
     int minmax_blocks = 0, qerr_blocks = 0;
     int64_t weight_elems = 0, eps_elems = 0;
     std::vector<BcStepDev> steps;          // host copies in the caller's order
-    struct Launch { int begin, n, max_rows; };
+    struct Launch { int begin, n, max_blocks, max_expect; };
     std::vector<Launch> launches;          // launch j = j-th step of every network
     std::vector<BcStepDev> launch_steps;   // launch-major copy (kernel argument by value for 1-step launches)
     BcStepDev* d_steps = nullptr;          // launch_steps on the device (batched launches)
@@ -299,6 +356,8 @@ int dfq_bc_plan_create(const dfq_layer* layers, int32_t n_layers, const dfq_bc_s
             return fail_arg("dfq_bc_plan_create: step %d: steps must be listed network by network", s);
         const dfq_layer& L = layers[st.layer];
         if (!L.weight || !L.bias) return fail_arg("dfq_bc_plan_create: step %d: layer needs weight and bias", s);
+        if (L.out_ch <= 0 || L.in_per_group <= 0 || L.khkw <= 0 || L.out_ch >= (1 << 20) || L.in_per_group >= (1 << 20))
+            return fail_arg("dfq_bc_plan_create: step %d: layer dimensions must be in [1, 2^20)", s);
         if (st.source_count <= 0 || st.source_begin < 0 || st.source_begin + st.source_count > n_sources)
             return fail_arg("dfq_bc_plan_create: step %d: bad source range", s);
         int len = 0;
@@ -382,6 +441,19 @@ int dfq_bc_plan_create(const dfq_layer* layers, int32_t n_layers, const dfq_bc_s
         d.out_ch = L.out_ch; d.in_per_group = L.in_per_group; d.source_begin = steps[s].source_begin;
         d.source_count = steps[s].source_count; d.expect_len = expect_len[s];
         d.inline_sources = d.source_count <= kStepSources ? 1 : 0;
+        {
+            // work split: lanes per row, slots per row, rows per wave (everything preloaded: <= kBcRegs slots)
+            int lg = 0;
+            while ((1 << lg) < std::min(L.in_per_group, kWave)) ++lg;
+            const int lanes = 1 << lg, rps = kWave / lanes;
+            d.lg_lanes = lg;
+            d.chunks = (L.in_per_group + lanes - 1) / lanes;
+            int rw = (d.chunks > kBcRegs) ? 1 : rps * (kBcRegs / d.chunks);
+            rw = std::min(rw, kBlock / kRowsPerBlock);                       // one tail row per thread
+            rw = std::min(rw, std::max(1, (L.out_ch + kRowsPerBlock - 1) / kRowsPerBlock));
+            d.rows_per_block = rw * kRowsPerBlock;
+            d.pad = 0;
+        }
         for (int m = 0; m < kStepSources; ++m)
             d.src[m] = (d.inline_sources && m < d.source_count) ? hs[d.source_begin + m] : BcSourceDev();
         d.next_bn_weight = nullptr; d.next_cache = nullptr;
@@ -410,7 +482,7 @@ int dfq_bc_plan_create(const dfq_layer* layers, int32_t n_layers, const dfq_bc_s
             ordinal[s2] = k++;
             n_launch = std::max(n_launch, k);
         }
-        p->launches.assign(n_launch, dfq_bc_plan::Launch{0, 0, 0});
+        p->launches.assign(n_launch, dfq_bc_plan::Launch{0, 0, 0, 0});
         for (int s2 = 0; s2 < n_steps; ++s2) p->launches[ordinal[s2]].n += 1;
         int off = 0;
         for (auto& L : p->launches) { L.begin = off; off += L.n; L.n = 0; }
@@ -418,7 +490,8 @@ int dfq_bc_plan_create(const dfq_layer* layers, int32_t n_layers, const dfq_bc_s
         for (int s2 = 0; s2 < n_steps; ++s2) {
             auto& L = p->launches[ordinal[s2]];
             p->launch_steps[L.begin + L.n++] = p->steps[s2];
-            L.max_rows = std::max(L.max_rows, p->steps[s2].out_ch);
+            L.max_blocks = std::max(L.max_blocks, (p->steps[s2].out_ch + p->steps[s2].rows_per_block - 1) / p->steps[s2].rows_per_block);
+            L.max_expect = std::max(L.max_expect, p->steps[s2].expect_len);
         }
         if ((e = hipMalloc((void**)&p->d_steps, sizeof(BcStepDev) * n_steps)) != hipSuccess) return fail_alloc(e);
         if ((e = hipMemcpy(p->d_steps, p->launch_steps.data(), sizeof(BcStepDev) * n_steps, hipMemcpyHostToDevice)) != hipSuccess) return fail_alloc(e);
@@ -471,10 +544,13 @@ static int bc_run_direct(dfq_bc_plan* p, int32_t symmetric, hipStream_t st) {
         DFQ_CHECK_LAUNCH();
     }
     for (const auto& L : p->launches) {
-        const int grid = (L.max_rows + kRowsPerBlock - 1) / kRowsPerBlock;
         const BcStepDev* table = (L.n == 1) ? nullptr : p->d_steps + L.begin;
-        hipLaunchKernelGGL(bc_step_kernel, dim3(grid, L.n), dim3(kBlock), 0, st, p->launch_steps[L.begin], table,
-                           (const BcSourceDev*)p->d_sources);
+        if (L.max_expect <= kExpectSmall)
+            hipLaunchKernelGGL(bc_step_kernel<kExpectSmall>, dim3(L.max_blocks, L.n), dim3(kBlock), 0, st,
+                               p->launch_steps[L.begin], table, (const BcSourceDev*)p->d_sources);
+        else
+            hipLaunchKernelGGL(bc_step_kernel<kExpectMax>, dim3(L.max_blocks, L.n), dim3(kBlock), 0, st,
+                               p->launch_steps[L.begin], table, (const BcSourceDev*)p->d_sources);
         DFQ_CHECK_LAUNCH();
     }
     return DFQ_OK;

@@ -111,13 +111,24 @@ struct LeLayerDiff {
     double n_elems;
 };
 
-// the relations of one launch; grid = (max tiles of a relation, n relations).  Up to kLevelRelsMax
-// descriptors ride in the kernarg (single-network plans: the latency-critical case); batched plans
-// put any number of them in a table in global memory (one more dependent fetch, amortised over the
-// networks of the batch).
+// one working workgroup of a batched launch
+struct LeBlockRef {
+    int32_t rel;      // descriptor index inside the launch's table
+    int32_t tile;     // tile of that relation (row tiles first, then col tiles)
+    int32_t net;      // network (loop-state index)
+    int32_t pad;
+};
+
+// the relations of one launch.  Single-network plans (the latency-critical case): grid = (max tiles
+// of a relation, n relations), up to kLevelRelsMax descriptors ride in the kernarg and surplus
+// workgroups leave after one scalar-cache hit.  Batched plans: a 1-D grid of exactly the working
+// workgroups; workgroup b reads blocks[b] (one scalar load) and then, in parallel, its descriptor
+// table[rel] and the loop state of its network -- a rectangular grid over hundreds of relations of
+// very different sizes would be mostly empty workgroups that each pay a global round trip to find out.
 struct LevelArgs {
     LeRelDev rel[kLevelRelsMax];      // MUST stay first: read straight from the kernarg segment
-    const LeRelDev* table;            // non-null: descriptors are table[blockIdx.y]
+    const LeRelDev* table;            // non-null: batched plan
+    const LeBlockRef* blocks;         // batched plan: one entry per workgroup
 };
 static_assert(sizeof(LevelArgs) <= 3600, "kernarg segment is limited to 4 KiB");
 
@@ -128,7 +139,20 @@ struct LeTrace {
     int32_t pad;
 };
 __device__ __forceinline__ void stamp(const LeTrace& tr, int slot) {
-    if (tr.out && (int)(blockIdx.y * gridDim.x + blockIdx.x) == tr.block && threadIdx.x == 0) tr.out[slot] = clock64();
+    if (!tr.out || threadIdx.x != 0) return;
+    const int flat = (int)(blockIdx.y * gridDim.x + blockIdx.x);
+    if (tr.block == -1) {
+        // every workgroup: [0] entry, [1] exit (100 MHz wall clock), [2] XCC_ID << 32 | HW_ID
+        if (slot == 0) {
+            tr.out[3 * (int64_t)flat + 0] = wall_clock64();
+            tr.out[3 * (int64_t)flat + 2] = ((long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) |
+                                            (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+        } else if (slot == 7) {
+            tr.out[3 * (int64_t)flat + 1] = wall_clock64();
+        }
+    } else if (flat == tr.block) {
+        tr.out[slot] = clock64();
+    }
 }
 
 // a / b for 0 <= a < 2^20, b >= 1 in four instructions: (a + 0.5) / b is at least 0.5/b away from every
@@ -588,8 +612,18 @@ __global__ __launch_bounds__(kBlock) void le_level_kernel(LevelArgs args, LePara
     const int lane = threadIdx.x % kWave;
     const DFQ_CONSTANT_AS uint32_t* ka = (const DFQ_CONSTANT_AS uint32_t*)__builtin_amdgcn_kernarg_segment_ptr();
     uint32_t word = 0u;
+    int tile = blockIdx.x;
     if (args.table) {
-        if (lane < kDescWords) word = ((const guint*)(args.table + blockIdx.y))[lane];
+        // one 16-byte load of the workgroup's entry, then ONE wave-wide load that fetches the descriptor
+        // (lanes 0..kDescWords-1) and the loop state of the network (lane kDescWords) together
+        typedef int ivec4 __attribute__((vector_size(16)));
+        const ivec4 ref = *(const DFQ_GLOBAL_AS ivec4*)(args.blocks + blockIdx.x);
+        const int rel = __builtin_amdgcn_readfirstlane(ref[0]);
+        const int net = __builtin_amdgcn_readfirstlane(ref[2]);
+        tile = __builtin_amdgcn_readfirstlane(ref[1]);
+        const guint* src = (lane < kDescWords) ? (const guint*)(args.table + rel) + lane
+                                               : (const guint*)&state[net].done;
+        if (lane <= kDescWords) word = *src;
     } else {
         if (lane < kDescWords) word = ka[blockIdx.y * kDescWords + lane];
         else if (lane == kDescWords) word = (uint32_t)*(const DFQ_GLOBAL_AS int*)&state->done;   // single network
@@ -597,10 +631,8 @@ __global__ __launch_bounds__(kBlock) void le_level_kernel(LevelArgs args, LePara
     union { LeRelDev R; uint32_t u[kDescWords]; } desc;
 #pragma unroll
     for (int i = 0; i < kDescWords; ++i) desc.u[i] = __builtin_amdgcn_readlane(word, i);
-    uint32_t done = __builtin_amdgcn_readlane(word, kDescWords);
+    const uint32_t done = __builtin_amdgcn_readlane(word, kDescWords);
     const LeRelDev& R = desc.R;
-    if (args.table) done = (uint32_t)*(const DFQ_GLOBAL_AS int*)&state[R.net].done;   // batched: per-network state
-    const int tile = blockIdx.x;
     const int cur = parity;
     if (done || tile >= R.n_row_tiles + R.n_col_tiles) return;   // uniform
     stamp(tr, 1);
@@ -797,7 +829,8 @@ struct LevelLaunch {
     int rel_begin = 0;      // range in the level-sorted device relation table
     int n_rels = 0;
     int n_blocks = 0;       // workgroups that do work
-    int max_tiles = 0;      // grid.x
+    int max_tiles = 0;      // grid.x of a single-network launch
+    int block_begin = 0;    // batched: first entry of this launch in the workgroup table
     LevelArgs args;         // descriptors of the launch (kernel argument, by value)
     int64_t paired = 0;     // elements n1+n2 of the relations in this launch
     int64_t snapshot = 0;   // snapshot-arena elements written or read in this launch
@@ -824,6 +857,7 @@ struct dfq_le_plan {
     };
     std::vector<CachedGraph> graphs;
     LeRelDev* d_rels = nullptr;
+    LeBlockRef* d_blocks = nullptr;        // batched plans: workgroup table of every launch, back to back
     LeLayerDiff* d_layer_diff = nullptr;
     double* d_partials = nullptr;
     double* d_layer_mean = nullptr;
@@ -869,6 +903,7 @@ void dfq_le_plan_destroy(dfq_le_plan* p) {
     if (p->d_stats) (void)hipFree(p->d_stats);
     if (p->d_nets) (void)hipFree(p->d_nets);
     if (p->d_boot_map) (void)hipFree(p->d_boot_map);
+    if (p->d_blocks) (void)hipFree(p->d_blocks);
     for (float* a : p->arenas) (void)hipFree(a);
     for (auto& g : p->graphs) (void)hipGraphExecDestroy(g.exec);
     if (p->capture_stream) (void)hipStreamDestroy(p->capture_stream);
@@ -1077,7 +1112,7 @@ int dfq_le_plan_create_batch(const dfq_layer* layers, int32_t n_layers, const in
     int boot = 0, prev_level = -1;
     for (int i = 0; i < n_relations; ++i) {
         const int r = order[i];
-        const int launch_cap = (n_nets == 1) ? kLevelRelsMax : 65535;             // grid.y limit in table mode
+        const int launch_cap = (n_nets == 1) ? kLevelRelsMax : (1 << 30);
         if (level[r] != prev_level || p->levels.back().n_rels == launch_cap) {    // new launch
             p->levels.push_back(LevelLaunch());
             p->levels.back().rel_begin = i;
@@ -1118,7 +1153,23 @@ int dfq_le_plan_create_batch(const dfq_layer* layers, int32_t n_layers, const in
     if ((e = hipMemcpy(p->d_layer_diff, ld.data(), sizeof(LeLayerDiff) * n_layers, hipMemcpyHostToDevice)) != hipSuccess) return fail_alloc(e);
     if ((e = hipMemset(p->d_partials, 0, sizeof(double) * n_part)) != hipSuccess) return fail_alloc(e);
     if ((e = hipMemset(p->d_state, 0, sizeof(LeState) * n_nets)) != hipSuccess) return fail_alloc(e);
-    for (LevelLaunch& L : p->levels) L.args.table = (n_nets == 1) ? nullptr : p->d_rels + L.rel_begin;
+    for (LevelLaunch& L : p->levels) { L.args.table = nullptr; L.args.blocks = nullptr; }
+    if (n_nets > 1) {
+        // workgroup tables: the tiles of a launch in relation order (a relation's tiles stay adjacent,
+        // so do its rows in memory)
+        std::vector<LeBlockRef> blocks;
+        for (LevelLaunch& L : p->levels) {
+            L.block_begin = (int)blocks.size();
+            for (int i = 0; i < L.n_rels; ++i) {
+                const LeRelDev& d = sorted[L.rel_begin + i];
+                for (int t = 0; t < d.n_row_tiles + d.n_col_tiles; ++t) blocks.push_back(LeBlockRef{i, t, d.net, 0});
+            }
+        }
+        if ((e = hipMalloc((void**)&p->d_blocks, sizeof(LeBlockRef) * std::max<size_t>(1, blocks.size()))) != hipSuccess) return fail_alloc(e);
+        if (!blocks.empty() &&
+            (e = hipMemcpy(p->d_blocks, blocks.data(), sizeof(LeBlockRef) * blocks.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail_alloc(e);
+        for (LevelLaunch& L : p->levels) { L.args.table = p->d_rels + L.rel_begin; L.args.blocks = p->d_blocks + L.block_begin; }
+    }
     if ((e = hipDeviceSynchronize()) != hipSuccess) return fail_alloc(e);
     *out_plan = p;
     return DFQ_OK;
@@ -1130,8 +1181,9 @@ int64_t dfq_le_plan_snapshot_elements(const dfq_le_plan* p) { return p ? p->snap
 
 int dfq_le_plan_level_grid(const dfq_le_plan* p, int32_t level, int32_t* grid_x, int32_t* grid_y) {
     if (!p || level < 0 || level >= (int32_t)p->levels.size()) return fail_arg("dfq_le_plan_level_grid: bad level");
-    if (grid_x) *grid_x = p->levels[level].max_tiles;
-    if (grid_y) *grid_y = p->levels[level].n_rels;
+    const bool flat = p->levels[level].args.table != nullptr;
+    if (grid_x) *grid_x = flat ? p->levels[level].n_blocks : p->levels[level].max_tiles;
+    if (grid_y) *grid_y = flat ? 1 : p->levels[level].n_rels;
     return DFQ_OK;
 }
 
@@ -1172,7 +1224,8 @@ static int le_restart(dfq_le_plan* p, const dfq_le_config* cfg, hipStream_t st) 
 static int le_launch_level(dfq_le_plan* p, const LevelLaunch& L, const LeParams& q, hipStream_t st,
                            LeTrace tr = LeTrace{nullptr, 0, 0}) {
     if (L.n_blocks == 0) return DFQ_OK;
-    hipLaunchKernelGGL(le_level_kernel, dim3(L.max_tiles, L.n_rels), dim3(kBlock), 0, st, L.args, q,
+    const dim3 grid = L.args.table ? dim3(L.n_blocks) : dim3(L.max_tiles, L.n_rels);
+    hipLaunchKernelGGL(le_level_kernel, grid, dim3(kBlock), 0, st, L.args, q,
                        (int)(p->sweep_index & 1), (const LeState*)p->d_state, p->d_partials, tr);
     DFQ_CHECK_LAUNCH();
     return DFQ_OK;
@@ -1317,6 +1370,32 @@ int dfq_le_trace(dfq_le_plan* p, const dfq_le_config* cfg, int32_t launch, int32
     }
     if (!rc) {
         hipError_t e = hipMemcpyAsync(stamps16, d, 16 * sizeof(long long), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) rc = fail_hip(e, "trace copy", __FILE__, __LINE__);
+    }
+    (void)hipFree(d);
+    return rc;
+}
+
+int dfq_le_trace_blocks(dfq_le_plan* p, const dfq_le_config* cfg, int32_t launch, void* stream, int64_t* out,
+                        int64_t capacity_blocks) {
+    if (!p || !cfg || !out || launch < 0 || launch >= (int)p->levels.size()) return fail_arg("dfq_le_trace_blocks: bad argument");
+    const LevelLaunch& T = p->levels[launch];
+    const int64_t n_blocks = T.args.table ? T.n_blocks : (int64_t)T.max_tiles * T.n_rels;
+    if (capacity_blocks < n_blocks) return fail_arg("dfq_le_trace_blocks: need room for %lld workgroups", (long long)n_blocks);
+    hipStream_t st = as_stream(stream);
+    const LeParams q = make_params(cfg);
+    long long* d = nullptr;
+    DFQ_HIP_TRY(hipMalloc((void**)&d, 3 * n_blocks * sizeof(long long)));
+    DFQ_HIP_TRY(hipMemsetAsync(d, 0, 3 * n_blocks * sizeof(long long), st));
+    int rc = le_restart(p, cfg, st);
+    for (int s = 0; s < 3 && !rc; ++s) {          // trace the third sweep (steady state, code and tables warm)
+        for (int l = 0; l < (int)p->levels.size() && !rc; ++l)
+            rc = le_launch_level(p, p->levels[l], q, st, (s == 2 && l == launch) ? LeTrace{d, -1, 0} : LeTrace{nullptr, 0, 0});
+        if (!rc) rc = le_launch_control(p, cfg, st);
+    }
+    if (!rc) {
+        hipError_t e = hipMemcpyAsync(out, d, 3 * n_blocks * sizeof(long long), hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
         if (e != hipSuccess) rc = fail_hip(e, "trace copy", __FILE__, __LINE__);
     }

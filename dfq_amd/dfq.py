@@ -141,6 +141,15 @@ class LEPlan:
         _ffi.check(_ffi.lib().dfq_le_trace(self._plan, ctypes.byref(cfg), int(launch), int(block), _ffi.stream_arg(), out))
         return [int(v) for v in out]
 
+    def trace_blocks(self, launch, **kw):
+        """(entry, exit, hw id) of every workgroup of one launch (tuning aid, see dfq_le_trace_blocks)."""
+        cfg = _le_config(kw.get('s_range', (1e-8, 1e8)), -1.0, 10 ** 6, kw.get('signed', False), kw.get('eps', 0), None)
+        gx, gy = self.level_info(launch)['grid']
+        n = gx * gy
+        out = (ctypes.c_int64 * (3 * n))()
+        _ffi.check(_ffi.lib().dfq_le_trace_blocks(self._plan, ctypes.byref(cfg), int(launch), _ffi.stream_arg(), out, n))
+        return [(int(out[3 * b]), int(out[3 * b + 1]), int(out[3 * b + 2])) for b in range(n)]
+
     def query(self):
         res = _ffi.DfqLeResult()
         done = ctypes.c_int32()

@@ -284,6 +284,25 @@ class TinyCat(nn.Module):
         return self.last(self.grp(self.proj(x)))
 
 
+class TinyWide(nn.Module):
+    """Geometry corner cases of the kernels: 3-input stem, grouped 3x3 (4 groups), depthwise 5x5, a 1x1
+    expansion to 1600 channels (a row of > 1536 inputs for the classifier) and a 70-input 1x1."""
+
+    def __init__(self, n_class=9):
+        super().__init__()
+        self.stem = nn.Sequential(*_conv_bn_relu(3, 40, 3, 2, 1))
+        self.grp = nn.Sequential(*_conv_bn_relu(40, 80, 3, 1, 1, groups=4))
+        self.dw = nn.Sequential(*_conv_bn_relu(80, 80, 5, 1, 2, groups=80))
+        self.pw = nn.Sequential(*_conv_bn_relu(80, 70, 1, 1, 0))
+        self.head = nn.Sequential(*_conv_bn_relu(70, 1600, 1, 1, 0))
+        self.fc = nn.Linear(1600, n_class)
+
+    def forward(self, x):
+        x = self.head(self.pw(self.dw(self.grp(self.stem(x)))))
+        x = torch.mean(x.view(x.size(0), x.size(1), -1), -1)
+        return self.fc(x)
+
+
 # ------------------------------------------------------------------------------------------
 # factory helpers
 # ------------------------------------------------------------------------------------------
@@ -320,7 +339,7 @@ def relu6_to_relu(model):
 
 _FACTORY = {
     'mobilenet_v2': MobileNetV2, 'resnet18': ResNet18, 'deeplab_mnv2': DeepLabMNV2,
-    'tiny_mobile': TinyMobile, 'tiny_res': TinyRes, 'tiny_cat': TinyCat,
+    'tiny_mobile': TinyMobile, 'tiny_res': TinyRes, 'tiny_cat': TinyCat, 'tiny_wide': TinyWide,
 }
 
 

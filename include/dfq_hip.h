@@ -154,6 +154,13 @@ int dfq_le_profile(dfq_le_plan* plan, const dfq_le_config* cfg, int32_t n_sweeps
 int dfq_le_trace(dfq_le_plan* plan, const dfq_le_config* cfg, int32_t launch, int32_t block, void* stream,
                  int64_t* stamps16);
 
+/* Tuning aid: run three sweeps and return, for EVERY workgroup b of launch `launch` during the third one,
+ * out[3b] = entry and out[3b+1] = exit time (100 MHz wall clock; 0 for a workgroup that had no tile) and
+ * out[3b+2] = XCC_ID << 32 | HW_ID of the compute unit it ran on.  `capacity_blocks` >= grid_x * grid_y of
+ * dfq_le_plan_level_grid.  Synchronises; modifies the weights like three ordinary sweeps. */
+int dfq_le_trace_blocks(dfq_le_plan* plan, const dfq_le_config* cfg, int32_t launch, void* stream, int64_t* out,
+                        int64_t capacity_blocks);
+
 /* ------------------------------------------------------------------------------------------
  * Tensor primitives -- utils/quantize.py:23-76 (UniformQuantize.forward), :102-119 (QuantMeasure)
  * ---------------------------------------------------------------------------------------- */

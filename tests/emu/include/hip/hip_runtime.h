@@ -127,6 +127,8 @@ inline int readlane_ref(const void* where, int v0, int src_lane) {
 }
 }  // namespace emu
 #define __builtin_amdgcn_readlane(v, lane) emu::readlane_ref(&(v), (int)(v), (lane))
+// only ever applied to wave-uniform values in these kernels: the lane's own value is the first lane's
+#define __builtin_amdgcn_readfirstlane(v) (v)
 
 inline long long __double_as_longlong(double d) { long long v; memcpy(&v, &d, 8); return v; }
 inline double __longlong_as_double(long long v) { double d; memcpy(&d, &v, 8); return d; }
@@ -140,6 +142,8 @@ inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v
 inline double atomicAdd(double* p, double v) { double o = *p; *p = o + v; return o; }
 
 inline long long clock64() { return 0; }
+inline long long wall_clock64() { return 0; }
+inline unsigned __builtin_amdgcn_s_getreg(int) { return 0u; }
 inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
 
 using std::max;

@@ -378,6 +378,30 @@ def _spec_snapshot(spec):
     return snap
 
 
+def test_geometry_corner_cases_against_oracle(engine):
+    """tiny_wide: 3-input stem, grouped 3x3, depthwise 5x5, a 70-input and a 1600-input row -- every work
+    split of the equalisation tiles and of the bias-correction matvec (narrow rows sharing a wave,
+    multi-slot rows, rows longer than the register preload).  LE bit-exact, BC within 1e-5."""
+    model, graph, bottoms = synthetic.build('tiny_wide', seed=3)
+    spec = graphspec.from_torch(graph, bottoms, TARG)
+    model.to(engine.device)
+    lt.merge_batchnorm(model, graph, bottoms, TARG)
+    orc.merge_batchnorm(spec)
+    rels = rel.create_relation(graph, bottoms, TARG)
+    orels = orc.create_relation(spec)
+    dfq.cross_layer_equalization(graph, rels, TARG, max_sweeps=6)
+    n_o, S_o = orc.cross_layer_equalization(spec, orels, max_sweeps=6)
+    assert dfq.last_equalization['sweeps'] == n_o == 6
+    osnap, esnap = _spec_snapshot(spec), snapshot(graph)
+    for k in osnap:
+        assert_bitexact(esnap[k], osnap[k], 'tiny_wide LE {}'.format(k))
+    dfq.bias_correction(graph, bottoms, TARG)
+    orc.bias_correction(spec)
+    osnap, esnap = _spec_snapshot(spec), snapshot(graph)
+    for k in osnap:
+        assert_close(esnap[k], osnap[k], 'tiny_wide BC {}'.format(k))
+
+
 # ---------------------------------------------------------------------------------------------
 # BASELINE.json configurations at full size (GPU only: the emulation would take minutes)
 # ---------------------------------------------------------------------------------------------

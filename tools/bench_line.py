@@ -1,0 +1,15 @@
+#!/usr/bin/env python3
+"""Print a one-line digest of bench.py JSON files (tuning aid)."""
+import json
+import sys
+for f in sys.argv[1:]:
+    try:
+        d = json.load(open(f))
+        r = d.get('roofline') or {}
+        print('%s value %.3e ms/step %.3f lat %.3f | level us %.2f GB/s %.0f frac %.3f sweep_us %.1f ctl %.1f | %s' % (
+            f.split('/')[-1], d['value'], d['ms_per_step'], d['config']['single_pass_latency_ms'],
+            r.get('us_per_launch', 0), r.get('achieved', 0), r.get('frac', 0), r.get('sweep_wall_us', 0),
+            r.get('control_us_per_sweep', 0),
+            ' '.join('%.1f' % l['us'] for l in r.get('levels', []))))
+    except Exception as e:
+        print(f, 'failed', e)
