@@ -256,6 +256,16 @@ def main():
         fence()
         single_ms = (time.perf_counter() - t0) * 1e3 / 4
 
+    # where a step's time goes: the two halves of one unit on an otherwise idle GPU (one stream)
+    br_units = [make_unit(protos) for _ in range(3)]
+    with _stream_ctx(streams[0]):
+        for u in br_units[:1]:
+            step(u)
+        _sync()
+        le_ms = sum(_gpu_elapsed_ms(lambda u=u: u['le'].enqueue(sweeps, restart=True, max_sweeps=sweeps, **force))
+                    for u in br_units[1:]) / 2
+        bc_ms = sum(_gpu_elapsed_ms(lambda u=u: u['bc'].run()) for u in br_units[1:]) / 2
+
     out = {
         'metric': 'conv weights calibrated/sec (LE+BC pass, MobileNetV2)' if args.net == 'mobilenet_v2'
                   else 'conv weights calibrated/sec (LE+BC pass, {})'.format(args.net),
@@ -280,6 +290,7 @@ def main():
             'launches_per_sweep': levels + 1,
             'units_in_flight_per_gpu': n_streams,
             'single_pass_latency_ms': single_ms,
+            'one_unit_alone_ms': {'equalization': le_ms, 'bias_correction': bc_ms},
         },
     }
 
@@ -316,12 +327,19 @@ def main():
             nbytes = 8 * info['paired_elements'] + 4 * info['snapshot_elements']
             per_level.append({'level': l, 'relations': info['relations'], 'workgroups': info['workgroups'],
                               'bytes': nbytes, 'us': us, 'GBps': nbytes / max(us, 1e-9) / 1e3})
+        # SURVEY.md 8(d) contract figure for the same launches: 8 B per paired element + 12 B per weight for the
+        # convergence diff with a snapshot refresh -- what an eager restatement of dfq.py:84-108 moves.  This
+        # engine takes the diff inside the rescale pass, so it moves less; `achieved` above is priced on the
+        # bytes it actually needs, `achieved_survey_8d` on the contract figure.
+        survey_bytes = (8 * paired + 12 * n_w * batch) / levels
         out['roofline'] = {
             'bound': 'hbm', 'kernel': 'le_level_kernel', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
             'frac': achieved / HBM_PEAK_GBS, 'traffic': _pmc_traffic(args.net, batch), 'traffic_unit': 'bytes per launch',
             'traffic_source': 'profiles/r01_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; '
                               'a profiler pass cannot run inside this process)',
             'bytes_per_launch': avg_bytes, 'us_per_launch': avg_ms * 1e3, 'launches_timed': launches,
+            'achieved_survey_8d': survey_bytes / max(avg_ms * 1e-3, 1e-12) / 1e9,
+            'frac_survey_8d': survey_bytes / max(avg_ms * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBS,
             'sweep_wall_us': sweep_ms * 1e3, 'control_us_per_sweep': sweep_ms * 1e3 * (1.0 - share_levels),
             'event_pair_overhead_us': empty * 1e3, 'levels': per_level,
         }

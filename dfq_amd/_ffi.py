@@ -14,7 +14,8 @@ from ctypes import (POINTER, Structure, byref, c_char_p, c_double, c_float, c_in
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libdfq_hip.so')
+# DFQ_HIP_LIB points at another build of the same library (kernel-tuning experiments); still no fallback
+LIB_PATH = os.environ.get('DFQ_HIP_LIB') or os.path.join(_HERE, 'libdfq_hip.so')
 
 c_float_p = c_void_p      # device pointers travel as opaque addresses
 c_int32_dp = c_void_p
@@ -108,6 +109,18 @@ SIGNATURES = {
                                      c_float, c_void_p, c_void_p, c_void_p]),
     'dfq_bias_absorb': (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
                                   c_void_p, c_float, c_void_p]),
+    'dfq_row_range': (c_int32, [c_void_p, c_int64, c_int64, c_int32, c_void_p, c_void_p]),
+    'dfq_col_range': (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
+    'dfq_le_solve': (c_int32, [c_void_p, c_void_p, c_int64, c_float, c_double, c_double, c_void_p, c_void_p, c_void_p]),
+    'dfq_le_apply': (c_int32, [c_void_p, c_int32, c_int64, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p,
+                               c_void_p, c_void_p, c_void_p, c_void_p]),
+    'dfq_le_pair': (c_int32, [c_void_p, c_int32, c_int64, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p,
+                              c_void_p, c_double, c_double, c_int32, c_float, c_void_p, c_void_p, c_void_p]),
+    'dfq_absdiff_mean_scratch_bytes': (c_size_t, [c_int64]),
+    'dfq_absdiff_mean': (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    'dfq_fake_quant_rows': (c_int32, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int32, c_int32,
+                                      c_void_p, c_void_p, c_void_p]),
+    'dfq_grouped_matvec': (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
 }
 
 

@@ -14,6 +14,7 @@
 // thread that applies that update also refreshes the channel's cached E[ReLU(.)]; a step then only
 // gathers cached values.
 #include <algorithm>
+#include <cstdlib>
 #include <map>
 #include <vector>
 
@@ -451,7 +452,7 @@ int dfq_bc_plan_create(const dfq_layer* layers, int32_t n_layers, const dfq_bc_s
             int rw = (d.chunks > kBcRegs) ? 1 : rps * (kBcRegs / d.chunks);
             rw = std::min(rw, kBlock / kRowsPerBlock);                       // one tail row per thread
             rw = std::min(rw, std::max(1, (L.out_ch + kRowsPerBlock - 1) / kRowsPerBlock));
-            d.rows_per_block = rw * kRowsPerBlock;
+            d.rows_per_block = rw * kRowsPerBlock;                           // upper bound; trimmed per launch below
             d.pad = 0;
         }
         for (int m = 0; m < kStepSources; ++m)
@@ -487,6 +488,23 @@ int dfq_bc_plan_create(const dfq_layer* layers, int32_t n_layers, const dfq_bc_s
         int off = 0;
         for (auto& L : p->launches) { L.begin = off; off += L.n; L.n = 0; }
         p->launch_steps.resize(n_steps);
+        // A launch wants enough workgroups to occupy the chip (a single network is latency-bound: one
+        // row per wave, every row in flight at once) but no more than that (each workgroup rebuilds the
+        // expectation vector and pays the descriptor round trip): rows per wave shrink until the launch
+        // has about `target` workgroups.
+        const char* te = getenv("DFQ_BC_BLOCKS");
+        const int target = (te && atoi(te) > 0) ? atoi(te) : 512;
+        std::vector<int> n_in_launch(n_launch, 0);
+        for (int s2 = 0; s2 < n_steps; ++s2) n_in_launch[ordinal[s2]] += 1;
+        for (int s2 = 0; s2 < n_steps; ++s2) {
+            BcStepDev& d = p->steps[s2];
+            const int rps = kWave >> d.lg_lanes;
+            int rw = d.rows_per_block / kRowsPerBlock;
+            const int64_t rows_launch = (int64_t)d.out_ch * n_in_launch[ordinal[s2]];
+            const int want = (int)std::max<int64_t>(1, rows_launch / ((int64_t)kRowsPerBlock * target));
+            rw = std::min(rw, std::max(want, std::min(rps, rw)));            // never below one full register slot of rows
+            d.rows_per_block = rw * kRowsPerBlock;
+        }
         for (int s2 = 0; s2 < n_steps; ++s2) {
             auto& L = p->launches[ordinal[s2]];
             p->launch_steps[L.begin + L.n++] = p->steps[s2];

@@ -602,7 +602,10 @@ static_assert(sizeof(LeRelDev) % 4 == 0 && kDescWords + 1 <= kWave, "descriptor 
 // word i, v_readlane broadcasts it.  Letting the compiler materialise `args.rel[blockIdx.y]` makes
 // it fetch the fields piecemeal at first use (one dependent round trip per group of fields).
 // `parity` = sweep index & 1, known to the host at enqueue time.
-__global__ __launch_bounds__(kBlock) void le_level_kernel(LevelArgs args, LeParams p, int parity,
+#ifndef DFQ_LE_MIN_WAVES
+#define DFQ_LE_MIN_WAVES 1
+#endif
+__global__ __launch_bounds__(kBlock, DFQ_LE_MIN_WAVES) void le_level_kernel(LevelArgs args, LeParams p, int parity,
                                                           const LeState* __restrict__ state,
                                                           double* __restrict__ partials, LeTrace tr) {
     stamp(tr, 0);

@@ -294,6 +294,47 @@ int dfq_bias_absorb(const float* w2, int32_t o2, int32_t in_per_group, int32_t k
                     float* b1, float* b2, const float* bn_weight, float* bn_bias, float n_sigma,
                     void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Stand-alone steps of one equalisation pair / one correction layer: what the
+ * plans above fuse, exported one by one.  Composing them reproduces dfq.py:28-75 for one pair bit for bit
+ * with the plans (same device arithmetic); they cost two passes over the data and four launches per
+ * pair, so the plans are the fast path.  All pointers are device pointers, all calls asynchronous.
+ * ---------------------------------------------------------------------------------------- */
+/* out[r] = range(W[r, :]): max-min (signed_range 0, dfq.py:54-55) or max|.| (1, dfq.py:50-51) */
+int dfq_row_range(const float* w, int64_t rows, int64_t row_len, int32_t signed_range, float* out, void* stream);
+/* out[g*I/g + ii] = range over the O/groups rows of pairing group g and the khkw taps of input channel ii
+ * of W2 [O, I/g, khkw] (the view of dfq.py:41-46; `groups` = O1 / (I2/g), 1 for an ordinary pair) */
+int dfq_col_range(const float* w2, int32_t out_ch, int32_t in_per_group, int32_t khkw, int32_t groups,
+                  int32_t signed_range, float* out, void* stream);
+/* S[c] = clamp((1/(r1+eps)) * sqrt(r1*r2+eps)) with the Python max/min semantics of dfq.py:58-59 (NaN ->
+ * s_hi); Sinv[c] = the float32 value dfq.py:73 multiplies by (1/S, or float32(1/s_range[k]) where the clamp
+ * replaced S by a Python float).  Sinv may be NULL. */
+int dfq_le_solve(const float* r1, const float* r2, int64_t n, float eps, double s_lo, double s_hi, float* S,
+                 float* Sinv, void* stream);
+/* dfq.py:62-73: W1[c,:] *= S[c]; b1, bn_weight, bn_bias (each may be NULL) *= S; W2[:, c] *= Sinv[c] */
+int dfq_le_apply(float* w1, int32_t o1, int64_t row_len1, float* w2, int32_t o2, int32_t in_per_group2,
+                 int32_t khkw2, float* b1, float* bn_weight, float* bn_bias, const float* S, const float* Sinv,
+                 void* stream);
+/* the four steps above for one pair = _layer_equalization (dfq.py:28-75).  `S` [O1] receives the scale
+ * vector, `workspace` is 3*O1 floats of device scratch. */
+int dfq_le_pair(float* w1, int32_t o1, int64_t row_len1, float* w2, int32_t o2, int32_t in_per_group2,
+                int32_t khkw2, float* b1, float* bn_weight, float* bn_bias, double s_lo, double s_hi,
+                int32_t signed_range, float eps, float* S, float* workspace, void* stream);
+/* out[0] = float(torch.mean(torch.abs(W - W_prev))) (dfq.py:108): float64 sum in a fixed order, divided by
+ * n, rounded once to float32.  `scratch` is dfq_absdiff_mean_scratch_bytes(n) bytes of device memory. */
+size_t dfq_absdiff_mean_scratch_bytes(int64_t n);
+int dfq_absdiff_mean(const float* w, const float* prev, int64_t n, float* out, void* scratch, void* stream);
+/* Per-row (per-output-channel) form of dfq_fake_quant: row r is quantised with its own range -- (mins[r],
+ * maxs[r]) if given, its own min/max otherwise (written to minmax_out[2r], [2r+1] if non-NULL).  Same
+ * recipe per row as utils/quantize.py:49-74; this is the per-channel weight quantiser of the ncnn table
+ * (convert_ncnn.py:178-201: one scale per output channel) and of ZeroQ (quant_utils.py:39-135). */
+int dfq_fake_quant_rows(const float* x, float* y, int64_t rows, int64_t row_len, const float* mins,
+                        const float* maxs, int32_t num_bits, int32_t symmetric, float* codes, float* minmax_out,
+                        void* stream);
+/* out[o] = eps[o, :] . expect[(o / (O/groups)) * I/g ...] (dfq.py:281-287), float64 accumulation */
+int dfq_grouped_matvec(const float* eps, const float* expect, int32_t out_ch, int32_t in_per_group,
+                       int32_t groups, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
