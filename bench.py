@@ -45,12 +45,12 @@ HBM_PEAK_GBS = 8000.0             # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=4)
+    ap.add_argument('--steps', type=int, default=12)
+    ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--net', default='mobilenet_v2', choices=['mobilenet_v2', 'resnet18', 'deeplab_mnv2', 'tiny_mobile'])
     ap.add_argument('--sweeps', type=int, default=0, help='pin the LE sweep count (0 = what the convergence test needs)')
     ap.add_argument('--cpu-seconds', type=float, default=10.0, help='CPU-baseline budget (0 disables)')
-    ap.add_argument('--batch', type=int, default=8, help='networks calibrated together in one step (one batched plan)')
+    ap.add_argument('--batch', type=int, default=32, help='networks calibrated together in one step (one batched plan)')
     ap.add_argument('--streams', type=int, default=2, help='steps in flight per GPU (one HIP stream + host thread each)')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--force-sweeps', action='store_true', help='tuning: run --sweeps sweeps regardless of convergence')
@@ -109,18 +109,17 @@ def cpu_baseline(net, seed, budget_s):
 
 
 def _pmc_traffic(net, batch):
-    """HBM bytes per launch of le_level_kernel from the committed PMC summary, when that summary was
-    collected on this workload (MobileNetV2, same batch); else null."""
+    """HBM bytes per launch of le_level_kernel from the committed PMC summary (MobileNetV2 only), else null.
+    The counters were collected on a batch of `summary['batch']` networks; a launch over `batch` networks runs
+    the same tiles once per network, so the figure scales with the batch (returned with the batch it came from)."""
     path = os.path.join(ROOT, 'profiles', 'r01_pmc_summary.json')
     if net != 'mobilenet_v2' or not os.path.exists(path):
-        return None
+        return None, None
     try:
         summary = json.load(open(path))
-        if summary.get('batch', 1) != batch:
-            return None
-        return summary['le_level_kernel']['traffic_bytes_per_launch']
+        return summary['le_level_kernel']['traffic_bytes_per_launch'] * batch / summary['batch'], summary['batch']
     except Exception:
-        return None
+        return None, None
 
 
 def _device(local_rank):
@@ -332,11 +331,13 @@ def main():
         # engine takes the diff inside the rescale pass, so it moves less; `achieved` above is priced on the
         # bytes it actually needs, `achieved_survey_8d` on the contract figure.
         survey_bytes = (8 * paired + 12 * n_w * batch) / levels
+        traffic, traffic_batch = _pmc_traffic(args.net, batch)
         out['roofline'] = {
             'bound': 'hbm', 'kernel': 'le_level_kernel', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-            'frac': achieved / HBM_PEAK_GBS, 'traffic': _pmc_traffic(args.net, batch), 'traffic_unit': 'bytes per launch',
-            'traffic_source': 'profiles/r01_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; '
-                              'a profiler pass cannot run inside this process)',
+            'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_unit': 'bytes per launch',
+            'traffic_source': 'profiles/r01_pmc_summary.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes on a '
+                              'batch of {} networks, scaled to this batch (same tiles per network); a profiler pass '
+                              'cannot run inside this process'.format(traffic_batch),
             'bytes_per_launch': avg_bytes, 'us_per_launch': avg_ms * 1e3, 'launches_timed': launches,
             'achieved_survey_8d': survey_bytes / max(avg_ms * 1e-3, 1e-12) / 1e9,
             'frac_survey_8d': survey_bytes / max(avg_ms * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBS,

@@ -55,6 +55,7 @@ constexpr int kTileRowsMax = 256;      // rows of a tile (one LDS entry per row)
 constexpr int kRowTileColsMax = 128;   // positions of a row tile (x2 for float4 tiles)
 constexpr int kColTileLanes = 64;      // vector positions of a col tile (one wave per row at most)
 constexpr int kSlotMax = 1024;         // LDS table entries of a tile (stat slots / 1/s table)
+constexpr int kShortChunk = 9;          // taps a thread-per-row tile keeps in flight (one 3x3 kernel)
 constexpr int kBootTc = 64;            // channels per bootstrap tile
 constexpr int kLevelRelsMax = 16;      // relations per launch (longer levels are split): descriptors ride in the kernarg
 constexpr int kCtlBlock = 1024;        // threads of the control kernel
@@ -553,20 +554,30 @@ __device__ __forceinline__ double short_tile(const LeRelDev& R, const LeParams& 
     }
     double acc = 0.0;
     float rmn = INFINITY, rmx = -INFINITY;
-    // the whole row sits in one or two cache lines: a plain loop, the first load pays the latency
-#pragma unroll 1
-    for (int k = 0; k < len; ++k) {
-        const float x = w[k];
-        const float nv = x * f;                       // dfq.py:62 / dfq.py:73
-        if (ok) w[k] = nv;
-        if (mode == DIFF_SAVE) {
-            if (ok) pv[k] = x;
-        } else {
-            const float ref = (mode == DIFF_DIRECT) ? x : pv[k];
-            acc += (double)abs_diff_if(ok, nv, ref);
+    // the row is walked in chunks of kShortChunk floats with every load of a chunk in flight at once (a
+    // plain one-float-at-a-time loop pays one global round trip per tap: ~9 in a row for a 3x3 kernel)
+    for (int k0 = 0; k0 < len; k0 += kShortChunk) {
+        float x[kShortChunk], q[kShortChunk];
+#pragma unroll
+        for (int k = 0; k < kShortChunk; ++k) x[k] = w[min(k0 + k, len - 1)];
+        if (mode == DIFF_FROM_PREV) {
+#pragma unroll
+            for (int k = 0; k < kShortChunk; ++k) q[k] = pv[min(k0 + k, len - 1)];
         }
-        rmn = fminf(rmn, nv);
-        rmx = fmaxf(rmx, nv);
+#pragma unroll
+        for (int k = 0; k < kShortChunk; ++k) {
+            const bool in = k0 + k < len;                          // uniform
+            const float nv = x[k] * f;                             // dfq.py:62 / dfq.py:73
+            if (ok && in) w[k0 + k] = nv;
+            if (mode == DIFF_SAVE) {
+                if (ok && in) pv[k0 + k] = x[k];
+            } else {
+                const float ref = (mode == DIFF_DIRECT) ? x[k] : q[k];
+                acc += (double)abs_diff_if(ok && in, nv, ref);
+            }
+            rmn = fminf(rmn, nv);                                  // clamped duplicates of the last tap are harmless
+            rmx = fmaxf(rmx, nv);
+        }
     }
     if (ok) {
         if (side == 0) {

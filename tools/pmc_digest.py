@@ -1,10 +1,13 @@
 #!/usr/bin/env python3
-"""Digest the two rocprofv3 --pmc passes of tools/pmc_level.sh into profiles/r01_pmc_summary.json.
+"""Digest the two rocprofv3 --pmc passes of tools/pmc_level.sh into a PMC summary (profiles/r01_pmc_summary.json).
+
+usage: tools/pmc_digest.py <dir with pmc_FETCH_SIZE/ pmc_WRITE_SIZE/> <bench.json of the same --batch> <dest.json>
 
 FETCH_SIZE is reported in KB with 128-byte requests tallied as 64 bytes on gfx950 (MI355X_MICROARCH.md,
 HBM section) -> doubled for the wide coalesced reads of these kernels; bc_minmax_kernel (one plain read
-of every weight) is the in-run calibration of that factor.  Launches of le_level_kernel that exit at the
-`done` flag (sweeps enqueued past convergence) move < 64 KB and are excluded from the per-launch mean.
+of every weight of the batch) is the in-run calibration of that factor.  Only the le_level_kernel launches
+of the timed batch are averaged (identified by their grid size: the process also runs one-network plans
+for its latency probe); launches that exit at the `done` flag (< 64 KB moved) are excluded.
 """
 import collections
 import csv
@@ -13,41 +16,58 @@ import json
 import sys
 
 
-def per_kernel(counter, root):
+def load(counter, root):
     files = glob.glob('%s/pmc_%s/**/*counter_collection.csv' % (root, counter), recursive=True)
     if not files:
         raise SystemExit('no counter file for ' + counter)
-    rows = collections.defaultdict(list)
-    for r in csv.DictReader(open(files[0])):
-        if r.get('Counter_Name') == counter:
-            rows[r['Kernel_Name'].split('(')[0]].append(float(r['Counter_Value']))
-    return rows
+    return [r for r in csv.DictReader(open(files[0])) if r.get('Counter_Name') == counter]
 
 
 def main():
-    root = sys.argv[1] if len(sys.argv) > 1 else 'gpurun_out'
-    batch = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-    alg = float(sys.argv[3]) if len(sys.argv) > 3 else None
-    out = {'batch': batch}
-    level = {}
+    root, bench_path, dest = sys.argv[1], sys.argv[2], sys.argv[3]
+    bench = json.load(open(bench_path))
+    levels = bench['roofline']['levels']
+    grid_of = {l['workgroups'] * 256: l for l in levels}
+    batch = bench['config']['networks_per_step']
+    out = {'batch': batch, 'workload': bench['config']['workload']}
+    per_level = {}
     for c in ('FETCH_SIZE', 'WRITE_SIZE'):
-        rows = per_kernel(c, root)
-        out[c] = {'per_kernel_mean_KB': {k: sum(v) / len(v) for k, v in rows.items()},
-                  'per_kernel_dispatches': {k: len(v) for k, v in rows.items()}}
-        lv = rows.get('dfq::le_level_kernel', [])
-        work = [x for x in lv if x > 64.0]
-        level[c] = (sum(work) / max(len(work), 1), len(work), len(lv))
-    fetch = level['FETCH_SIZE'][0] * 1024 * 2.0
-    write = level['WRITE_SIZE'][0] * 1024
+        rows = load(c, root)
+        by_kernel = collections.defaultdict(list)
+        for r in rows:
+            by_kernel[r['Kernel_Name'].split('(')[0]].append(float(r['Counter_Value']))
+        out[c] = {'per_kernel_mean_KB': {k: sum(v) / len(v) for k, v in by_kernel.items() if 'dfq' in k},
+                  'per_kernel_dispatches': {k: len(v) for k, v in by_kernel.items() if 'dfq' in k}}
+        for r in rows:
+            if 'le_level_kernel' in r['Kernel_Name'] and int(r['Grid_Size']) in grid_of and float(r['Counter_Value']) > 64.0:
+                per_level.setdefault(int(r['Grid_Size']), {}).setdefault(c, []).append(float(r['Counter_Value']))
+    table = []
+    tot_fetch = tot_write = tot_alg = 0.0
+    n_levels = 0
+    for grid, l in sorted(grid_of.items(), key=lambda kv: kv[1]['level']):
+        if grid not in per_level or len(per_level[grid]) < 2:
+            continue
+        f = per_level[grid]['FETCH_SIZE']
+        w = per_level[grid]['WRITE_SIZE']
+        fetch = sum(f) / len(f) * 1024 * 2.0
+        write = sum(w) / len(w) * 1024
+        table.append({'level': l['level'], 'workgroups': l['workgroups'], 'launches_counted': len(f),
+                      'fetch_bytes_corrected': fetch, 'write_bytes': write, 'traffic_bytes': fetch + write,
+                      'algorithmic_bytes': l['bytes'], 'traffic_over_algorithmic': (fetch + write) / l['bytes']})
+        tot_fetch += fetch
+        tot_write += write
+        tot_alg += l['bytes']
+        n_levels += 1
     out['le_level_kernel'] = {
-        'working_launches': level['FETCH_SIZE'][1], 'launches': level['FETCH_SIZE'][2],
-        'fetch_bytes_per_launch_corrected': fetch, 'write_bytes_per_launch': write,
-        'traffic_bytes_per_launch': fetch + write, 'algorithmic_bytes_per_launch': alg,
-        'note': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/pmc_level.sh); '
-                'FETCH_SIZE doubled per MI355X_MICROARCH.md; launches that exit at the done flag excluded',
+        'levels': table,
+        'fetch_bytes_per_launch_corrected': tot_fetch / n_levels, 'write_bytes_per_launch': tot_write / n_levels,
+        'traffic_bytes_per_launch': (tot_fetch + tot_write) / n_levels, 'algorithmic_bytes_per_launch': tot_alg / n_levels,
+        'note': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/pmc_level.sh --batch %d); FETCH_SIZE '
+                'doubled per MI355X_MICROARCH.md; per-launch figures are the mean over the %d launch levels of a sweep, like '
+                'bench.py roofline.bytes_per_launch' % (batch, n_levels),
     }
-    json.dump(out, open('profiles/r01_pmc_summary.json', 'w'), indent=1)
-    print(json.dumps(out['le_level_kernel']))
+    json.dump(out, open(dest, 'w'), indent=1)
+    print(json.dumps(out['le_level_kernel'], indent=1))
 
 
 if __name__ == '__main__':

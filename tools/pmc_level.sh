@@ -1,8 +1,10 @@
 #!/bin/bash
 # HBM traffic of le_level_kernel from the TCC counters (separate --pmc passes, MI355X_MICROARCH.md "HBM").
 # usage: tools/pmc_level.sh [bench flags]   (run on the GPU box; digest with tools/pmc_digest.py)
+# Every pass runs under `timeout`: a counter pass that aborts can leave rocprofv3 waiting forever.
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf gpurun_out/pmc_$c
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_$c -o pmc -- python bench.py --streams 1 --steps 2 --warmup 1 --cpu-seconds 0 --no-roofline "$@" > gpurun_out/pmc_$c.log 2>&1
+  timeout ${PMC_TIMEOUT:-150} rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_$c -o pmc -- python bench.py --streams 1 --steps 1 --warmup 1 --cpu-seconds 0 --no-roofline "$@" > gpurun_out/pmc_$c.log 2>&1
+  echo "pmc $c rc=$?"
 done
