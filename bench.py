@@ -187,7 +187,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         sweeps = int(t.item())
     levels = probe['le'].levels
-    paired, snap = probe['le'].paired_elements, probe['le'].snapshot_elements
+    paired = probe['le'].paired_elements                    # sum over relations of n1 + n2
+    rw, ro = probe['le'].rw_elements, probe['le'].ro_elements
 
     units = [make_unit(protos) for _ in range(args.steps + args.warmup)]
 
@@ -295,8 +296,9 @@ def main():
 
     if rank == 0 and not args.no_roofline:
         # Dominant kernel: le_level_kernel (5 launches per sweep).  Algorithmic bytes of a launch = 8 B per
-        # paired element (read once + written once; the ranges are by-products) + 4 B per snapshot-arena
-        # element it touches.  Its duration comes from HIP events on the launch stream:
+        # element it reads and writes (every weight of a paired layer once per sweep; the ranges are
+        # by-products) + 4 B per element of an interior layer it only measures.  Its duration
+        # comes from HIP events on the launch stream:
         #   (a) one event pair around a whole run of `sweeps` sweeps  -> wall time per sweep;
         #   (b) event pairs around every single launch (dfq_le_profile), minus the same pair around
         #       nothing, -> how that wall time splits between the level launches and the convergence
@@ -316,14 +318,14 @@ def main():
         assert wall_rep['le'].query()['sweeps'] == sweeps
         launches = sweeps * levels
         avg_ms = sweep_ms * share_levels / levels
-        bytes_per_sweep = 8 * paired + 4 * snap
+        bytes_per_sweep = 8 * rw + 4 * ro
         avg_bytes = bytes_per_sweep / levels
         achieved = avg_bytes / max(avg_ms * 1e-3, 1e-12) / 1e9
         per_level = []
         for l in range(levels):
             info = prof_rep['le'].level_info(l)
             us = sweep_ms * 1e3 * lvl_corr[l] / max(sum(lvl_corr) + ctl_corr, 1e-12)
-            nbytes = 8 * info['paired_elements'] + 4 * info['snapshot_elements']
+            nbytes = 8 * info['rw_elements'] + 4 * info['ro_elements']
             per_level.append({'level': l, 'relations': info['relations'], 'workgroups': info['workgroups'],
                               'bytes': nbytes, 'us': us, 'GBps': nbytes / max(us, 1e-9) / 1e3})
         # SURVEY.md 8(d) contract figure for the same launches: 8 B per paired element + 12 B per weight for the

@@ -33,10 +33,18 @@
 // buffers alternate between two parities and the control kernel clears the one that is about to
 // be accumulated into.
 //
-// Convergence (dfq.py:105-115): per-tile float64 partials of sum|W - W_prev| (a layer touched
-// twice per sweep saves its pre-sweep value to a snapshot arena at the first touch), reduced in a
-// fixed order by a one-workgroup control kernel that also advances the reference's (diff, count)
-// state machine on the device.  Level kernels start by reading `done`, so the host enqueues sweeps
+// Interior layers.  A layer that is the second layer of relation A and the first layer of relation B
+// (every layer inside a chain) is rescaled twice per sweep: columns by 1/s_A, then rows by s_B, and s_B
+// needs the row ranges of the column-rescaled matrix.  It is NOT written twice: in A's level a
+// read-only pass computes the row statistics of t = fl(w * 1/s_A) (4 B per element), in B's level one
+// pass recomputes t and stores fl(t * s_B) -- the reference's two roundings, in its order -- while
+// emitting the new column statistics (8 B per element).  12 B per interior element and sweep instead
+// of 24 B for two read-write passes plus a pre-sweep snapshot.
+//
+// Convergence (dfq.py:105-115): every element is written exactly once per sweep, by a pass that has
+// its pre-sweep value in a register, so each tile leaves float64 partials of sum|W - W_prev|; they are
+// reduced in a fixed order by a one-workgroup control kernel that also advances the reference's
+// (diff, count) state machine on the device.  Level kernels start by reading `done`, so the host enqueues sweeps
 // ahead without synchronising.
 #include <algorithm>
 #include <cstdlib>
@@ -61,7 +69,6 @@ constexpr int kLevelRelsMax = 16;      // relations per launch (longer levels ar
 constexpr int kCtlBlock = 1024;        // threads of the control kernel
 constexpr int kCtlStage = 6144;        // partials staged in LDS by the control kernel
 
-enum DiffMode : int32_t { DIFF_DIRECT = 0, DIFF_SAVE = 1, DIFF_FROM_PREV = 2 };
 
 // One relation.  The descriptors of a launch are passed BY VALUE (kernarg segment) and selected with
 // blockIdx.y, so a workgroup reaches its descriptor with the kernel's very first scalar loads: no
@@ -73,8 +80,7 @@ struct LeRelDev {
     float* bnw;
     float* bnb;
     float* s_cum;
-    float* prev1;        // snapshot arena of the first layer (same indexing as w1) or null
-    float* prev2;
+    uint32_t* prev_r1;   // W1 is interior: row stats (R1) of the relation whose second layer it is, else null
     uint32_t* r1;        // parity 0 of the row stats of W1: [o1][2] = (min slot, max slot); parity 1 is
     uint32_t* r2;        // `stat_stride` words further.  r2: column stats of W2 per paired channel
     uint32_t* out_cols;  // R2 of the relation whose SECOND layer is our W1, or null: forward r1
@@ -85,7 +91,8 @@ struct LeRelDev {
     int32_t o2, gi, go, i2g, khkw;       // W2 geometry; paired channel c = g*gi + ii
     int32_t rt_rows, rt_cols, rt_slabs, rt_vec, n_row_tiles;   // *_vec: 4 float4 tiles, 1 scalar tiles, 0 thread-per-row
     int32_t ct_rows, ct_cols, ct_slabs, ct_vec, n_col_tiles;
-    int32_t diff1, diff2;
+    int32_t w1_interior;    // W1 is also the second layer of an earlier relation: its row pass applies both rescales
+    int32_t w2_interior;    // W2 is also the first layer of a later relation: its column pass only takes statistics
     int32_t partial_base;   // first partial slot of this relation (row tiles, then col tiles)
     int32_t boot_begin;     // first workgroup inside the bootstrap launch
     int32_t boot_tiles;
@@ -238,7 +245,7 @@ __device__ __forceinline__ void vstore(gfloat* p, const float (&x)[VEC]) {
 // row tile: W1[r0:r0+nr, p0:p0+np] *= s[row]   (+ column stats of the new values)
 template <int VEC>
 __device__ __forceinline__ double row_tile(const LeRelDev& R, const LeParams& p, int tile, int cur,
-                                           float* sh_s, uint32_t* sh_slot, int* sh_g, const LeTrace& tr) {
+                                           float* sh_s, uint32_t* sh_slot, int* sh_g, float* sh_pinv, const LeTrace& tr) {
     constexpr int NV = (VEC == 4) ? kSlotsVec4 : kSlotsVec1;   // vectors per thread
     const int tid = threadIdx.x;
     const int rblk = small_div(tile, R.rt_slabs);
@@ -257,25 +264,15 @@ __device__ __forceinline__ double row_tile(const LeRelDev& R, const LeParams& p,
     const int n_own = lane_on ? small_div(nr - jl + JL - 1, JL) : 0;   // rows this thread owns (<= NV by plan)
     const int n_max = min(NV, small_div(nr + JL - 1, JL));             // register slots in use (block-uniform)
     gfloat* const w = (gfloat*)R.w1 + ((int64_t)r0 * R.row_len + pos);
-    gfloat* const pv = (gfloat*)R.prev1 + ((int64_t)r0 * R.row_len + pos);
-    const int mode = R.diff1;
+    const bool fused = R.w1_interior != 0;     // the column rescale of the previous relation is applied here too
 
     // ---- issue every data load first -----------------------------------------------------------
-    float v[NV][VEC], q[NV][VEC];
+    float v[NV][VEC];
 #pragma unroll
     for (int u = 0; u < NV; ++u) {
         if (u < n_max) {
             const int r = min(jl + u * JL, nr - 1);
             vload<VEC>(w + r * R.row_len, v[u]);
-        }
-    }
-    if (mode == DIFF_FROM_PREV) {
-#pragma unroll
-        for (int u = 0; u < NV; ++u) {
-            if (u < n_max) {
-                const int r = min(jl + u * JL, nr - 1);
-                vload<VEC>(pv + r * R.row_len, q[u]);
-            }
         }
     }
 
@@ -288,6 +285,22 @@ __device__ __forceinline__ double row_tile(const LeRelDev& R, const LeParams& p,
         nci = small_div(p0 + np - 1, R.khkw1) - i0 + 1;
         n_slots = (small_div(r0 + nr - 1, R.pc_go) - g0 + 1) * nci;
         for (int i = tid; i < 2 * n_slots; i += kBlock) sh_slot[i] = 0u;
+    }
+    if (fused) {
+        // 1/s of the previous relation for every (group, input channel) this tile spans: the same slot
+        // geometry as the column statistics; threads from the top of the workgroup so that the row-scale
+        // solves below (threads 0..nr-1) run next to them
+        const guint* a_base = (const guint*)R.prev_r1 + (int64_t)cur * R.stat_stride;
+        const guint* b_base = (const guint*)R.out_cols + (int64_t)cur * R.stat_stride;
+        for (int sl = kBlock - 1 - tid; sl < n_slots; sl += kBlock) {
+            const int gq = small_div(sl, nci);
+            const int c = (g0 + gq) * R.pc_gi + i0 + (sl - gq * nci);
+            const uint32_t a0 = a_base[2 * c], a1 = a_base[2 * c + 1], b0 = b_base[2 * c], b1 = b_base[2 * c + 1];
+            float s, inv;
+            le_solve(range_of(slot_min(a0), slot_max(a1), p.signed_range), range_of(slot_min(b0), slot_max(b1), p.signed_range),
+                     p, s, inv);
+            sh_pinv[sl] = inv;
+        }
     }
     stamp(tr, 2);
     if (tid < nr) {
@@ -334,21 +347,18 @@ __device__ __forceinline__ double row_tile(const LeRelDev& R, const LeParams& p,
         const int r = min(jl + u * JL, nr - 1);
         const bool ok = u < n_own;
         const float s = sh_s[r];
+        const int g = emit ? sh_g[r] : 0;                  // slot row of this row's group
         float nv[VEC];
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) nv[k] = v[u][k] * s;                 // dfq.py:62
-        if (ok) vstore<VEC>(w + r * R.row_len, nv);
-        if (mode == DIFF_SAVE) {
-            if (ok) vstore<VEC>(pv + r * R.row_len, v[u]);
-        } else {
-#pragma unroll
-            for (int k = 0; k < VEC; ++k) {
-                const float ref = (mode == DIFF_DIRECT) ? v[u][k] : q[u][k];
-                acc += (double)abs_diff_if(ok, nv[k], ref);
-            }
+        for (int k = 0; k < VEC; ++k) {
+            float t = v[u][k];
+            if (fused) t = t * sh_pinv[g + ci[k]];          // dfq.py:73 of the previous relation (rounded), then
+            nv[k] = t * s;                                  // dfq.py:62 of this one
         }
+        if (ok) vstore<VEC>(w + r * R.row_len, nv);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc += (double)abs_diff_if(ok, nv[k], v[u][k]);
         if (emit && ok) {
-            const int g = sh_g[r];                         // slot row of this row's group
             if (g != cur_g) {
                 if (cur_g >= 0) {
 #pragma unroll
@@ -413,27 +423,17 @@ __device__ __forceinline__ double col_tile(const LeRelDev& R, const LeParams& p,
     const int pos = p0 + min(ln, npv - 1) * VEC;
     const int n_max = min(NV, (nr + n_rowslots - 1) >> (8 - lgG));     // register slots in use (block-uniform)
     const int nxt = cur ^ 1;
-    const int mode = R.diff2;
+    const bool stat_only = R.w2_interior != 0;              // the write happens in the next relation's row pass
     const bool emit = R.out_rows != nullptr;
     gfloat* const w = (gfloat*)R.w2 + ((int64_t)r0 * row_len2 + pos);
-    gfloat* const pv = (gfloat*)R.prev2 + ((int64_t)r0 * row_len2 + pos);
 
     // ---- issue every data load first -----------------------------------------------------------
-    float v[NV][VEC], q[NV][VEC];
+    float v[NV][VEC];
 #pragma unroll
     for (int u = 0; u < NV; ++u) {
         if (u < n_max) {
             const int r = min(grp + u * n_rowslots, nr - 1);
             vload<VEC>(w + r * row_len2, v[u]);
-        }
-    }
-    if (mode == DIFF_FROM_PREV) {
-#pragma unroll
-        for (int u = 0; u < NV; ++u) {
-            if (u < n_max) {
-                const int r = min(grp + u * n_rowslots, nr - 1);
-                vload<VEC>(pv + r * row_len2, q[u]);
-            }
         }
     }
 
@@ -476,15 +476,10 @@ __device__ __forceinline__ double col_tile(const LeRelDev& R, const LeParams& p,
         float nv[VEC];
 #pragma unroll
         for (int k = 0; k < VEC; ++k) nv[k] = v[u][k] * sh_inv[t0 + ci[k]];      // dfq.py:73
-        if (ok) vstore<VEC>(w + r * row_len2, nv);
-        if (mode == DIFF_SAVE) {
-            if (ok) vstore<VEC>(pv + r * row_len2, v[u]);
-        } else {
+        if (!stat_only) {
+            if (ok) vstore<VEC>(w + r * row_len2, nv);
 #pragma unroll
-            for (int k = 0; k < VEC; ++k) {
-                const float ref = (mode == DIFF_DIRECT) ? v[u][k] : q[u][k];
-                acc += (double)abs_diff_if(ok, nv[k], ref);
-            }
+            for (int k = 0; k < VEC; ++k) acc += (double)abs_diff_if(ok, nv[k], v[u][k]);
         }
         if (emit) {                                        // block-uniform: every lane reaches the shuffles
             float rmn = INFINITY, rmx = -INFINITY;
@@ -532,8 +527,8 @@ __device__ __forceinline__ double short_tile(const LeRelDev& R, const LeParams& 
     const int o = min(tile * kBlock + tid, n_rows - 1);
     const bool ok = tile * kBlock + tid < n_rows;
     gfloat* const w = (gfloat*)(side == 0 ? R.w1 : R.w2) + (int64_t)o * len;
-    gfloat* const pv = (gfloat*)(side == 0 ? R.prev1 : R.prev2) + (int64_t)o * len;
-    const int mode = side == 0 ? R.diff1 : R.diff2;
+    const bool fused = side == 0 && R.w1_interior != 0;       // also apply the previous relation's 1/s (per row here)
+    const bool stat_only = side == 1 && R.w2_interior != 0;   // statistics of the rescaled row only, no store
     const int c = side == 0 ? o : small_div(o, R.go) * R.gi;  // paired channel that scales this row
 
     float o_cum = 0.f, o_bnw = 0.f, o_bnb = 0.f, o_b1 = 0.f;
@@ -542,6 +537,16 @@ __device__ __forceinline__ double short_tile(const LeRelDev& R, const LeParams& 
         if (R.bnw) o_bnw = R.bnw[c];
         if (R.bnb) o_bnb = R.bnb[c];
         if (R.b1) o_b1 = R.b1[c];
+    }
+    float pinv = 1.0f;
+    if (fused) {              // row o of W1 is channel o * pc_gi of the previous relation (pc_go == 1 by plan)
+        const int cp = o * R.pc_gi;
+        const guint* a = (const guint*)R.prev_r1 + (int64_t)cur * R.stat_stride + 2 * cp;
+        const guint* b = (const guint*)R.out_cols + (int64_t)cur * R.stat_stride + 2 * cp;
+        const uint32_t a0 = a[0], a1 = a[1], b0 = b[0], b1 = b[1];
+        float ps;
+        le_solve(range_of(slot_min(a0), slot_max(a1), p.signed_range), range_of(slot_min(b0), slot_max(b1), p.signed_range),
+                 p, ps, pinv);
     }
     float s, inv, mn1, mx1, mn2, mx2;
     channel_scale(R, p, cur, c, s, inv, mn1, mx1, mn2, mx2);
@@ -557,23 +562,18 @@ __device__ __forceinline__ double short_tile(const LeRelDev& R, const LeParams& 
     // the row is walked in chunks of kShortChunk floats with every load of a chunk in flight at once (a
     // plain one-float-at-a-time loop pays one global round trip per tap: ~9 in a row for a 3x3 kernel)
     for (int k0 = 0; k0 < len; k0 += kShortChunk) {
-        float x[kShortChunk], q[kShortChunk];
+        float x[kShortChunk];
 #pragma unroll
         for (int k = 0; k < kShortChunk; ++k) x[k] = w[min(k0 + k, len - 1)];
-        if (mode == DIFF_FROM_PREV) {
-#pragma unroll
-            for (int k = 0; k < kShortChunk; ++k) q[k] = pv[min(k0 + k, len - 1)];
-        }
 #pragma unroll
         for (int k = 0; k < kShortChunk; ++k) {
             const bool in = k0 + k < len;                          // uniform
-            const float nv = x[k] * f;                             // dfq.py:62 / dfq.py:73
-            if (ok && in) w[k0 + k] = nv;
-            if (mode == DIFF_SAVE) {
-                if (ok && in) pv[k0 + k] = x[k];
-            } else {
-                const float ref = (mode == DIFF_DIRECT) ? x[k] : q[k];
-                acc += (double)abs_diff_if(ok && in, nv, ref);
+            float t = x[k];
+            if (fused) t = t * pinv;                               // dfq.py:73 of the previous relation, rounded
+            const float nv = t * f;                                // dfq.py:62 / dfq.py:73
+            if (!stat_only) {
+                if (ok && in) w[k0 + k] = nv;
+                acc += (double)abs_diff_if(ok && in, nv, x[k]);
             }
             rmn = fminf(rmn, nv);                                  // clamped duplicates of the last tap are harmless
             rmx = fmaxf(rmx, nv);
@@ -623,6 +623,7 @@ __global__ __launch_bounds__(kBlock, DFQ_LE_MIN_WAVES) void le_level_kernel(Leve
     __shared__ float sh_f[kSlotMax];                // row tile: scales; col tile: 1/s table
     __shared__ uint32_t sh_u[2 * kSlotMax];         // row tile: column-stat slots; col tile: row stats
     __shared__ int sh_g[kTileRowsMax];              // per-row table offsets
+    __shared__ float sh_p[kSlotMax];                // row tile of an interior layer: 1/s of the previous relation
     const int lane = threadIdx.x % kWave;
     const DFQ_CONSTANT_AS uint32_t* ka = (const DFQ_CONSTANT_AS uint32_t*)__builtin_amdgcn_kernarg_segment_ptr();
     uint32_t word = 0u;
@@ -654,8 +655,8 @@ __global__ __launch_bounds__(kBlock, DFQ_LE_MIN_WAVES) void le_level_kernel(Leve
     double acc;
     if (tile < R.n_row_tiles) {
         if (R.rt_vec == 0) acc = short_tile<0>(R, p, tile, cur);
-        else acc = R.rt_vec == 4 ? row_tile<4>(R, p, tile, cur, sh_f, sh_u, sh_g, tr)
-                                 : row_tile<1>(R, p, tile, cur, sh_f, sh_u, sh_g, tr);
+        else acc = R.rt_vec == 4 ? row_tile<4>(R, p, tile, cur, sh_f, sh_u, sh_g, sh_p, tr)
+                                 : row_tile<1>(R, p, tile, cur, sh_f, sh_u, sh_g, sh_p, tr);
     } else {
         if (R.ct_vec == 0) acc = short_tile<1>(R, p, tile - R.n_row_tiles, cur);
         else acc = R.ct_vec == 4 ? col_tile<4>(R, p, tile - R.n_row_tiles, cur, sh_f, sh_u, sh_g, tr)
@@ -846,8 +847,8 @@ struct LevelLaunch {
     int max_tiles = 0;      // grid.x of a single-network launch
     int block_begin = 0;    // batched: first entry of this launch in the workgroup table
     LevelArgs args;         // descriptors of the launch (kernel argument, by value)
-    int64_t paired = 0;     // elements n1+n2 of the relations in this launch
-    int64_t snapshot = 0;   // snapshot-arena elements written or read in this launch
+    int64_t rw_elems = 0;   // elements read AND written by this launch (8 B each)
+    int64_t ro_elems = 0;   // elements only read by it: statistics pass over interior layers (4 B each)
 };
 
 }  // namespace dfq
@@ -859,7 +860,8 @@ struct dfq_le_plan {
     LeNetDesc* d_nets = nullptr;
     int32_t* d_boot_map = nullptr;         // bootstrap workgroup -> relation
     std::vector<LevelLaunch> levels;
-    int64_t paired_total = 0, snapshot_total = 0;
+    int64_t paired_total = 0;              // sum over relations of n1 + n2 (SURVEY 8d's Sigma_rel)
+    int64_t rw_total = 0, ro_total = 0;    // per sweep: elements read+written / only read
     int total_tiles = 0, boot_blocks = 0;
     int64_t stat_words = 0;                // per parity, per arena
     int64_t r1_zero_words = 0;             // leading part of the R1 arena that is accumulated with atomics
@@ -877,7 +879,6 @@ struct dfq_le_plan {
     double* d_layer_mean = nullptr;
     LeState* d_state = nullptr;
     uint32_t* d_stats = nullptr;           // R2 arena [2][stat_words], then R1 arena [2][stat_words]
-    std::vector<float*> arenas;            // snapshot arenas (hipMalloc)
 };
 
 static int tile_target() {     // elements per tile; DFQ_LE_TILE_ELEMS overrides (tuning / tests)
@@ -918,7 +919,6 @@ void dfq_le_plan_destroy(dfq_le_plan* p) {
     if (p->d_nets) (void)hipFree(p->d_nets);
     if (p->d_boot_map) (void)hipFree(p->d_boot_map);
     if (p->d_blocks) (void)hipFree(p->d_blocks);
-    for (float* a : p->arenas) (void)hipFree(a);
     for (auto& g : p->graphs) (void)hipGraphExecDestroy(g.exec);
     if (p->capture_stream) (void)hipStreamDestroy(p->capture_stream);
     delete p;
@@ -982,19 +982,6 @@ int dfq_le_plan_create_batch(const dfq_layer* layers, int32_t n_layers, const in
     p->n_nets = n_nets;
     auto fail_alloc = [&](hipError_t e) { dfq_le_plan_destroy(p); return fail_hip(e, "le plan allocation", __FILE__, __LINE__); };
 
-    // ---- snapshot arenas for layers touched twice per sweep ----
-    std::vector<float*> arena(n_layers, nullptr);
-    for (int l = 0; l < n_layers; ++l) {
-        if (as_first[l] >= 0 && as_second[l] >= 0) {
-            const int64_t n = (int64_t)layers[l].out_ch * layers[l].in_per_group * layers[l].khkw;
-            float* a = nullptr;
-            hipError_t e = hipMalloc((void**)&a, sizeof(float) * n);
-            if (e != hipSuccess) return fail_alloc(e);
-            p->arenas.push_back(a);
-            arena[l] = a;
-        }
-    }
-
     // ---- dependency levels: relations sharing a layer keep their list order ----
     std::vector<int> level(n_relations, 0), last_level(n_layers, -1);
     for (int r = 0; r < n_relations; ++r) {
@@ -1046,13 +1033,10 @@ int dfq_le_plan_create_batch(const dfq_layer* layers, int32_t n_layers, const in
         d.r1 = r1_base + r1_off[r];
         d.r2 = r2_base + r2_off[r];
         d.stat_stride = words;
-        // diff modes: a layer in two relations is touched as second (col tile) first, then as first
-        const bool a_twice = as_second[rr.first] >= 0;     // W1 was column-scaled earlier this sweep
-        const bool b_twice = as_first[rr.second] >= 0;     // W2 will be row-scaled later this sweep
-        d.diff1 = a_twice ? DIFF_FROM_PREV : DIFF_DIRECT;
-        d.diff2 = b_twice ? DIFF_SAVE : DIFF_DIRECT;
-        d.prev1 = a_twice ? arena[rr.first] : nullptr;
-        d.prev2 = b_twice ? arena[rr.second] : nullptr;
+        // interior layers: W1 that was the second layer of an earlier relation gets both rescales in this
+        // relation's row pass; W2 that is the first layer of a later relation is only measured here
+        d.w1_interior = as_second[rr.first] >= 0 ? 1 : 0;
+        d.w2_interior = as_first[rr.second] >= 0 ? 1 : 0;
         const int row_len2 = d.i2g * d.khkw;
         d.rt_vec = (d.row_len % 4 == 0 && ((uintptr_t)A.weight & 15u) == 0) ? 4 : 1;
         d.ct_vec = (row_len2 % 4 == 0 && ((uintptr_t)B.weight & 15u) == 0) ? 4 : 1;
@@ -1079,6 +1063,7 @@ int dfq_le_plan_create_batch(const dfq_layer* layers, int32_t n_layers, const in
         LeRelDev& d = h[r];
         const int j_prev = as_second[rr.first];     // relation whose second layer is our W1
         const int j_next = as_first[rr.second];     // relation whose first layer is our W2
+        d.prev_r1 = (j_prev >= 0) ? h[j_prev].r1 : nullptr;
         if (j_prev >= 0) {
             d.out_cols = h[j_prev].r2;
             d.pc_go = h[j_prev].go; d.pc_gi = h[j_prev].gi;
@@ -1101,7 +1086,7 @@ int dfq_le_plan_create_batch(const dfq_layer* layers, int32_t n_layers, const in
         d.partial_base = tile_slot;
         ld[rr.first].partial_begin = d.partial_base;
         ld[rr.first].n_partials = d.n_row_tiles;                       // last touch of W1 this sweep
-        if (d.diff2 == DIFF_DIRECT) {
+        if (!d.w2_interior) {
             ld[rr.second].partial_begin = d.partial_base + d.n_row_tiles;
             ld[rr.second].n_partials = d.n_col_tiles;
         }
@@ -1142,11 +1127,10 @@ int dfq_le_plan_create_batch(const dfq_layer* layers, int32_t n_layers, const in
         L.n_rels += 1;
         const int64_t n1 = (int64_t)h[r].o1 * h[r].row_len;
         const int64_t n2 = (int64_t)h[r].o2 * h[r].i2g * h[r].khkw;
-        L.paired += n1 + n2;
-        if (h[r].prev1) L.snapshot += n1;
-        if (h[r].prev2) L.snapshot += n2;
+        L.rw_elems += n1 + (h[r].w2_interior ? 0 : n2);
+        L.ro_elems += h[r].w2_interior ? n2 : 0;
     }
-    for (const LevelLaunch& L : p->levels) p->snapshot_total += L.snapshot;
+    for (const LevelLaunch& L : p->levels) { p->rw_total += L.rw_elems; p->ro_total += L.ro_elems; }
     p->boot_blocks = boot;
     std::vector<int32_t> boot_map(std::max(1, boot));
     for (int i = 0; i < n_relations; ++i)
@@ -1191,7 +1175,8 @@ int dfq_le_plan_create_batch(const dfq_layer* layers, int32_t n_layers, const in
 
 int32_t dfq_le_plan_levels(const dfq_le_plan* p) { return p ? (int32_t)p->levels.size() : 0; }
 int64_t dfq_le_plan_paired_elements(const dfq_le_plan* p) { return p ? p->paired_total : 0; }
-int64_t dfq_le_plan_snapshot_elements(const dfq_le_plan* p) { return p ? p->snapshot_total : 0; }
+int64_t dfq_le_plan_rw_elements(const dfq_le_plan* p) { return p ? p->rw_total : 0; }
+int64_t dfq_le_plan_ro_elements(const dfq_le_plan* p) { return p ? p->ro_total : 0; }
 
 int dfq_le_plan_level_grid(const dfq_le_plan* p, int32_t level, int32_t* grid_x, int32_t* grid_y) {
     if (!p || level < 0 || level >= (int32_t)p->levels.size()) return fail_arg("dfq_le_plan_level_grid: bad level");
@@ -1201,12 +1186,12 @@ int dfq_le_plan_level_grid(const dfq_le_plan* p, int32_t level, int32_t* grid_x,
     return DFQ_OK;
 }
 
-int32_t dfq_le_plan_level_launches(const dfq_le_plan* p, int32_t level, int64_t* paired_elems,
-                                   int64_t* snapshot_elems, int32_t* n_workgroups) {
+int32_t dfq_le_plan_level_launches(const dfq_le_plan* p, int32_t level, int64_t* rw_elems,
+                                   int64_t* ro_elems, int32_t* n_workgroups) {
     if (!p || level < 0 || level >= (int32_t)p->levels.size()) return fail_arg("dfq_le_plan_level_launches: bad level");
     const LevelLaunch& L = p->levels[level];
-    if (paired_elems) *paired_elems = L.paired;
-    if (snapshot_elems) *snapshot_elems = L.snapshot;
+    if (rw_elems) *rw_elems = L.rw_elems;
+    if (ro_elems) *ro_elems = L.ro_elems;
     if (n_workgroups) *n_workgroups = L.n_blocks;
     return L.n_rels;
 }

@@ -95,15 +95,21 @@ class LEPlan:
         return _ffi.lib().dfq_le_plan_paired_elements(self._plan)
 
     @property
-    def snapshot_elements(self):
-        return _ffi.lib().dfq_le_plan_snapshot_elements(self._plan)
+    def rw_elements(self):
+        """elements read and written per sweep (8 B each)"""
+        return _ffi.lib().dfq_le_plan_rw_elements(self._plan)
+
+    @property
+    def ro_elements(self):
+        """elements only read per sweep: the statistics pass over interior layers (4 B each)"""
+        return _ffi.lib().dfq_le_plan_ro_elements(self._plan)
 
     def level_info(self, level):
         a, b, c = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int32()
         n = _ffi.lib().dfq_le_plan_level_launches(self._plan, level, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c))
         gx, gy = ctypes.c_int32(), ctypes.c_int32()
         _ffi.check(_ffi.lib().dfq_le_plan_level_grid(self._plan, level, ctypes.byref(gx), ctypes.byref(gy)))
-        return dict(relations=n, paired_elements=a.value, snapshot_elements=b.value, workgroups=c.value,
+        return dict(relations=n, rw_elements=a.value, ro_elements=b.value, workgroups=c.value,
                     grid=(gx.value, gy.value))
 
     # -- execution -----------------------------------------------------------------------------

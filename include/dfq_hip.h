@@ -99,8 +99,8 @@ typedef struct dfq_le_result {
 /* Builds the device-side work list: dependency levels of the relation list (Gauss-Seidel order of
  * dfq.py:85 is preserved: two relations sharing a layer are never in the same launch), channel
  * tiles, the per-layer convergence-diff bookkeeping.  `layers` / `relations` are host arrays and
- * are copied.  Allocates a few small device buffers plus a snapshot arena for layers that are
- * rescaled twice per sweep.  Synchronises. */
+ * are copied.  Allocates a few small device buffers (statistics words, partial sums, descriptors);
+ * the weights are processed where they are.  Synchronises. */
 int dfq_le_plan_create(const dfq_layer* layers, int32_t n_layers,
                        const dfq_relation* relations, int32_t n_relations,
                        dfq_le_plan** out_plan);
@@ -117,9 +117,13 @@ int32_t dfq_le_plan_nets(const dfq_le_plan* plan);
 /* introspection (tests, bench byte accounting) */
 int32_t dfq_le_plan_levels(const dfq_le_plan* plan);
 int64_t dfq_le_plan_paired_elements(const dfq_le_plan* plan);   /* sum over relations of n1+n2  */
-int64_t dfq_le_plan_snapshot_elements(const dfq_le_plan* plan); /* elements of twice-touched layers */
-int32_t dfq_le_plan_level_launches(const dfq_le_plan* plan, int32_t level, int64_t* paired_elems,
-                                   int64_t* snapshot_elems, int32_t* n_workgroups);
+/* per sweep: elements read AND written (8 B each) / elements only read by the statistics pass over
+ * interior layers (4 B each); algorithmic bytes of a sweep = 8 * rw + 4 * ro */
+int64_t dfq_le_plan_rw_elements(const dfq_le_plan* plan);
+int64_t dfq_le_plan_ro_elements(const dfq_le_plan* plan);
+/* the same two counts for one launch level; returns the number of relations in it */
+int32_t dfq_le_plan_level_launches(const dfq_le_plan* plan, int32_t level, int64_t* rw_elems,
+                                   int64_t* ro_elems, int32_t* n_workgroups);
 /* launch geometry of a level: grid_x = tiles of its largest relation, grid_y = relations */
 int dfq_le_plan_level_grid(const dfq_le_plan* plan, int32_t level, int32_t* grid_x, int32_t* grid_y);
 

@@ -37,7 +37,7 @@ for launch in range(le.levels):
     starts = sorted((r[0] - t0) * 10 for r in rows)
     print('launch %d: %d workgroups, %d bytes | span %.2f us | wg ns mean %.0f p10 %.0f p50 %.0f p90 %.0f max %.0f | '
           'resident mean %.0f peak %d | distinct (xcc,cu,se) %d, wgs per CU min %d max %d | last wg starts at %.2f us' % (
-              launch, len(rows), 8 * info['paired_elements'] + 4 * info['snapshot_elements'], (t1 - t0) / 100.0,
+              launch, len(rows), 8 * info['rw_elements'] + 4 * info['ro_elements'], (t1 - t0) / 100.0,
               sum(dur) / len(dur), dur[len(dur) // 10], dur[len(dur) // 2], dur[len(dur) * 9 // 10], dur[-1],
               area / max(t1 - t0, 1), peak, len(cus), min(cus.values()), max(cus.values()), starts[-1] / 1e3))
     # start-time histogram in 1 us buckets
