@@ -57,7 +57,7 @@ namespace dfq {
 
 // register slots (vectors) a thread preloads: 4 x float4 or 8 x float.  Kept small on purpose: every
 // slot is unrolled code, and a cold workgroup pays instruction-fetch latency for every line it walks.
-constexpr int kSlotsVec4 = 4;
+constexpr int kSlotsVec4 = 8;
 constexpr int kSlotsVec1 = 8;
 constexpr int kTileRowsMax = 256;      // rows of a tile (one LDS entry per row)
 constexpr int kRowTileColsMax = 128;   // positions of a row tile (x2 for float4 tiles)
@@ -98,6 +98,14 @@ struct LeRelDev {
     int32_t boot_tiles;
     int32_t net;            // which network of a batched plan (index into the loop-state array)
 };
+
+// Tuning builds only (tools/ablate.sh): -DDFQ_LE_ABLATE=bits switches parts of the tile kernels off at compile
+// time to see what a launch's time is made of.  1: no data stores, 2: no |dW| accumulation, 4: no statistics
+// emission, 8: no data loads.  The product library is built with 0.
+#ifndef DFQ_LE_ABLATE
+#define DFQ_LE_ABLATE 0
+#endif
+constexpr int kAblate = DFQ_LE_ABLATE;
 
 struct LeParams {
     float s_lo, s_hi, inv_lo, inv_hi, eps;
@@ -215,6 +223,11 @@ __device__ __forceinline__ float abs_diff_if(bool on, float a, float b) {
 
 template <int VEC>
 __device__ __forceinline__ void vload(const gfloat* p, float (&x)[VEC]) {
+    if (kAblate & 8) {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) x[k] = 1.0f + (float)k;
+        return;
+    }
     if (VEC == 4) {
         const fvec4 t = *(const gfvec4*)p;
         x[0] = t[0]; x[1 % VEC] = t[1]; x[2 % VEC] = t[2]; x[3 % VEC] = t[3];
@@ -224,6 +237,7 @@ __device__ __forceinline__ void vload(const gfloat* p, float (&x)[VEC]) {
 }
 template <int VEC>
 __device__ __forceinline__ void vstore(gfloat* p, const float (&x)[VEC]) {
+    if ((kAblate & 1) && x[0] != 12345.678f) return;      // data-dependent so the producers stay alive
     if (VEC == 4) {
         fvec4 t;
         t[0] = x[0]; t[1] = x[1 % VEC]; t[2] = x[2 % VEC]; t[3] = x[3 % VEC];
@@ -277,7 +291,7 @@ __device__ __forceinline__ double row_tile(const LeRelDev& R, const LeParams& p,
     }
 
     // column-stat slot geometry of this tile
-    const bool emit = R.out_cols != nullptr;
+    const bool emit = R.out_cols != nullptr && !(kAblate & 4);
     int g0 = 0, i0 = 0, nci = 1, n_slots = 0;
     if (emit) {
         g0 = small_div(r0, R.pc_go);
@@ -357,7 +371,7 @@ __device__ __forceinline__ double row_tile(const LeRelDev& R, const LeParams& p,
         }
         if (ok) vstore<VEC>(w + r * R.row_len, nv);
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) acc += (double)abs_diff_if(ok, nv[k], v[u][k]);
+        for (int k = 0; k < VEC; ++k) if (!(kAblate & 2)) acc += (double)abs_diff_if(ok, nv[k], v[u][k]);
         if (emit && ok) {
             if (g != cur_g) {
                 if (cur_g >= 0) {
@@ -424,7 +438,7 @@ __device__ __forceinline__ double col_tile(const LeRelDev& R, const LeParams& p,
     const int n_max = min(NV, (nr + n_rowslots - 1) >> (8 - lgG));     // register slots in use (block-uniform)
     const int nxt = cur ^ 1;
     const bool stat_only = R.w2_interior != 0;              // the write happens in the next relation's row pass
-    const bool emit = R.out_rows != nullptr;
+    const bool emit = R.out_rows != nullptr && !(kAblate & 4);
     gfloat* const w = (gfloat*)R.w2 + ((int64_t)r0 * row_len2 + pos);
 
     // ---- issue every data load first -----------------------------------------------------------
@@ -479,7 +493,7 @@ __device__ __forceinline__ double col_tile(const LeRelDev& R, const LeParams& p,
         if (!stat_only) {
             if (ok) vstore<VEC>(w + r * row_len2, nv);
 #pragma unroll
-            for (int k = 0; k < VEC; ++k) acc += (double)abs_diff_if(ok, nv[k], v[u][k]);
+            for (int k = 0; k < VEC; ++k) if (!(kAblate & 2)) acc += (double)abs_diff_if(ok, nv[k], v[u][k]);
         }
         if (emit) {                                        // block-uniform: every lane reaches the shuffles
             float rmn = INFINITY, rmx = -INFINITY;
@@ -881,10 +895,24 @@ struct dfq_le_plan {
     uint32_t* d_stats = nullptr;           // R2 arena [2][stat_words], then R1 arena [2][stat_words]
 };
 
-static int tile_target() {     // elements per tile; DFQ_LE_TILE_ELEMS overrides (tuning / tests)
+// elements per tile; DFQ_LE_TILE_ELEMS overrides (tuning / tests).  A workgroup's fixed cost (workgroup table ->
+// descriptor -> statistics -> solve -> barrier: about four dependent global round trips) is the same for
+// any tile size, and the register budget admits only 5-6 workgroups per CU to hide it: throughput-oriented
+// (batched) plans therefore use the largest tile the register slots hold, a single network keeps smaller
+// tiles because there the number of workgroups in flight, not their cost, bounds a launch.
+static int tile_target(bool batched) {
     const char* e = getenv("DFQ_LE_TILE_ELEMS");
     const int v = e ? atoi(e) : 0;
-    return v > 0 ? v : 4096;
+    return v > 0 ? v : (batched ? 8192 : 4096);
+}
+// columns of a row tile that publishes column statistics.  Every row block of a layer merges its column
+// minima/maxima into the same global words with atomicMax, so the number of atomics per sweep is
+// (rows / tile rows) x columns: tall narrow tiles.  (A 960x960 layer cut into 17-row tiles issued 57
+// atomics per statistics word and sweep, and that, not the data, set the launch's duration.)
+static int emit_cols_max(int vec) {
+    const char* e = getenv("DFQ_LE_EMIT_COLS");
+    const int v = e ? atoi(e) : 0;
+    return v > 0 ? v : (vec == 4 ? 64 : 32);
 }
 
 static int ceil_div(int a, int b) { return (a + b - 1) / b; }
@@ -1018,7 +1046,7 @@ int dfq_le_plan_create_batch(const dfq_layer* layers, int32_t n_layers, const in
         ld[l].partial_begin = -1; ld[l].n_partials = 0;
         ld[l].n_elems = (double)((int64_t)layers[l].out_ch * layers[l].in_per_group * layers[l].khkw);
     }
-    const int target = tile_target();
+    const int target = tile_target(n_nets > 1);
     for (int r = 0; r < n_relations; ++r) {
         const dfq_relation& rr = relations[r];
         const dfq_layer& A = layers[rr.first];
@@ -1040,7 +1068,9 @@ int dfq_le_plan_create_batch(const dfq_layer* layers, int32_t n_layers, const in
         const int row_len2 = d.i2g * d.khkw;
         d.rt_vec = (d.row_len % 4 == 0 && ((uintptr_t)A.weight & 15u) == 0) ? 4 : 1;
         d.ct_vec = (row_len2 % 4 == 0 && ((uintptr_t)B.weight & 15u) == 0) ? 4 : 1;
-        tile_shape(d.o1, d.row_len, d.rt_vec, kRowTileColsMax * (d.rt_vec == 4 ? 2 : 1), false, target,
+        const bool emits_cols = as_second[rr.first] >= 0;
+        tile_shape(d.o1, d.row_len, d.rt_vec,
+                   emits_cols ? emit_cols_max(d.rt_vec) : kRowTileColsMax * (d.rt_vec == 4 ? 2 : 1), false, target,
                    &d.rt_rows, &d.rt_cols, &d.rt_slabs);
         tile_shape(d.o2, row_len2, d.ct_vec, kColTileLanes * d.ct_vec, true, target,
                    &d.ct_rows, &d.ct_cols, &d.ct_slabs);
