@@ -23,6 +23,7 @@
 namespace dfq {
 
 constexpr int kQChunk = kBlock * 16;
+constexpr int kQePairs = 4;            // (o, i) pairs per thread of the quant-error kernel for khkw == 1 layers
 constexpr int kExpectMax = 8192;       // floats of E[x] kept in LDS (32 KiB)
 constexpr int kExpectSmall = 2048;     // ... by the kernel variant used when every step of a launch fits (8 KiB)
 constexpr int kRowsPerBlock = kBlock / kWave;   // output rows of the matvec per workgroup: one per wave
@@ -84,10 +85,25 @@ __global__ __launch_bounds__(kBlock) void bc_minmax_kernel(const BcLayerDev* __r
     const int64_t b = (int64_t)(blockIdx.x - block_begin[l]) * kQChunk;
     const int64_t e = (b + kQChunk < L.n) ? b + kQChunk : L.n;
     float mn = INFINITY, mx = -INFINITY;
-    for (int64_t i = b + threadIdx.x; i < e; i += kBlock) {
-        const float v = L.w[i];
-        mn = fminf(mn, v);
-        mx = fmaxf(mx, v);
+    if ((((uintptr_t)L.w) & 15u) == 0) {
+        // 16-byte vectors over the aligned body of the chunk (chunk starts are multiples of 4 floats)
+        const int64_t e4 = b + ((e - b) & ~(int64_t)3);
+        for (int64_t i = b + 4 * (int64_t)threadIdx.x; i < e4; i += 4 * kBlock) {
+            const fvec4 v = *(const fvec4*)(L.w + i);
+            mn = fminf(fminf(mn, v[0]), fminf(v[1], fminf(v[2], v[3])));
+            mx = fmaxf(fmaxf(mx, v[0]), fmaxf(v[1], fmaxf(v[2], v[3])));
+        }
+        for (int64_t i = e4 + threadIdx.x; i < e; i += kBlock) {
+            const float v = L.w[i];
+            mn = fminf(mn, v);
+            mx = fmaxf(mx, v);
+        }
+    } else {
+        for (int64_t i = b + threadIdx.x; i < e; i += kBlock) {
+            const float v = L.w[i];
+            mn = fminf(mn, v);
+            mx = fmaxf(mx, v);
+        }
     }
     mn = wave_min(mn);
     mx = wave_max(mx);
@@ -112,6 +128,26 @@ __global__ __launch_bounds__(kBlock) void bc_quant_error_kernel(const BcLayerDev
     const BcLayerDev L = layers[l];
     const QParams p = qparams_double((double)slot_min(slots[2 * l + 0]), (double)slot_max(slots[2 * l + 1]),
                                      num_bits, symmetric);
+    if (L.khkw == 1) {
+        // 1x1 / linear layers (most of the weights): eps has the weight's shape, four pairs per thread as one
+        // 16-byte load and one 16-byte store when the pointers allow it
+        const int64_t pair = ((int64_t)(blockIdx.x - block_begin[l]) * kBlock + threadIdx.x) * kQePairs;
+        if (pair >= L.pairs) return;
+        float code;
+        if (pair + kQePairs <= L.pairs && ((((uintptr_t)L.w) | ((uintptr_t)L.eps)) & 15u) == 0) {
+            const fvec4 v = *(const fvec4*)(L.w + pair);
+            fvec4 d;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) d[k] = 0.0f + (fake_quant_one(v[k], p, &code) - v[k]);
+            *(fvec4*)(L.eps + pair) = d;
+        } else {
+            for (int64_t q = pair; q < pair + kQePairs && q < L.pairs; ++q) {
+                const float v = L.w[q];
+                L.eps[q] = 0.0f + (fake_quant_one(v, p, &code) - v);
+            }
+        }
+        return;
+    }
     const int64_t pair = (int64_t)(blockIdx.x - block_begin[l]) * kBlock + threadIdx.x;
     if (pair >= L.pairs) return;
     const float* w = L.w + pair * L.khkw;
@@ -229,8 +265,7 @@ __global__ __launch_bounds__(kBlock) void bc_step_kernel(BcStepDev st_inline, co
     }
     // ---- E[x]: first source assigns, 'cat' appends, anything else adds (dfq.py:229-270) ----
     int cur_len = 0;
-    for (int m = 0; m < st.source_count; ++m) {
-        const BcSourceDev s = st.inline_sources ? st.src[m] : sources[st.source_begin + m];
+    auto merge_source = [&](const BcSourceDev& s, int m) {
         const bool assign = (m == 0) || (s.concat != 0);
         const int base = (m == 0) ? 0 : (s.concat ? cur_len : 0);
         const float* val = s.relu ? s.cache : s.fb;      // E[ReLU(N(beta, gamma^2))] or beta
@@ -241,6 +276,18 @@ __global__ __launch_bounds__(kBlock) void bc_step_kernel(BcStepDev st_inline, co
         }
         cur_len = (m == 0) ? s.channels : (s.concat ? cur_len + s.channels : cur_len);
         __syncthreads();
+    };
+    if (st.inline_sources) {
+        // compile-time indices only: `st.src[m]` with a run-time m would force the whole descriptor into
+        // scratch memory (it did: 336 B of private segment per lane, written by every wave of every workgroup)
+#pragma unroll
+        for (int m = 0; m < kStepSources; ++m)
+            if (m < st.source_count) merge_source(st.src[m], m);
+    } else {
+        for (int m = 0; m < st.source_count; ++m) {
+            const BcSourceDev s = sources[st.source_begin + m];
+            merge_source(s, m);
+        }
     }
     // ---- grouped matvec (dfq.py:281-287), float64 accumulation rounded once per row ----
     const int num_group = st.expect_len / in;
@@ -348,7 +395,7 @@ int dfq_bc_plan_create(const dfq_layer* layers, int32_t n_layers, const dfq_bc_s
     if (!layers || n_layers <= 0 || !steps || n_steps <= 0 || !sources || n_sources <= 0 || !out_plan)
         return fail_arg("dfq_bc_plan_create: bad argument");
     // ---- validate & size ----
-    int64_t eps_total = 0, corr_total = 0, mm_blocks = 0, qe_blocks = 0;
+    int64_t eps_total = 0, eps_true = 0, corr_total = 0, mm_blocks = 0, qe_blocks = 0;
     std::vector<int> expect_len(n_steps, 0);
     for (int s = 0; s < n_steps; ++s) {
         const dfq_bc_step& st = steps[s];
@@ -377,16 +424,17 @@ int dfq_bc_plan_create(const dfq_layer* layers, int32_t n_layers, const dfq_bc_s
                             L.in_per_group, L.out_ch);
         expect_len[s] = len;
         const int64_t pairs = (int64_t)L.out_ch * L.in_per_group;
-        eps_total += pairs;
+        eps_total += (pairs + 3) & ~(int64_t)3;      // every eps matrix starts 16-byte aligned
+        eps_true += pairs;
         corr_total += L.out_ch;
         mm_blocks += (pairs * L.khkw + kQChunk - 1) / kQChunk;
-        qe_blocks += (pairs + kBlock - 1) / kBlock;
+        qe_blocks += (L.khkw == 1) ? (pairs + kBlock * kQePairs - 1) / (kBlock * kQePairs) : (pairs + kBlock - 1) / kBlock;
     }
     if (mm_blocks > 0x7fffffff || qe_blocks > 0x7fffffff) return fail_arg("dfq_bc_plan_create: too large");
 
     dfq_bc_plan* p = new dfq_bc_plan();
     p->n_steps = n_steps;
-    p->eps_elems = eps_total;
+    p->eps_elems = eps_true;
     hipError_t e;
     auto fail_alloc = [&](hipError_t err) { dfq_bc_plan_destroy(p); return fail_hip(err, "bc plan allocation", __FILE__, __LINE__); };
     if ((e = hipMalloc((void**)&p->d_eps, sizeof(float) * eps_total)) != hipSuccess) return fail_alloc(e);
@@ -436,7 +484,7 @@ int dfq_bc_plan_create(const dfq_layer* layers, int32_t n_layers, const dfq_bc_s
         hl[s].khkw = L.khkw; hl[s].pad = 0;
         mmb[s] = (int32_t)mb; qeb[s] = (int32_t)qb;
         mb += (hl[s].n + kQChunk - 1) / kQChunk;
-        qb += (pairs + kBlock - 1) / kBlock;
+        qb += (L.khkw == 1) ? (pairs + kBlock * kQePairs - 1) / (kBlock * kQePairs) : (pairs + kBlock - 1) / kBlock;
         BcStepDev& d = p->steps[s];
         d.eps = p->d_eps + eps_off; d.bias = L.bias; d.next_bn_bias = steps[s].next_bn_bias; d.corr = p->d_corr + corr_off;
         d.out_ch = L.out_ch; d.in_per_group = L.in_per_group; d.source_begin = steps[s].source_begin;
@@ -471,7 +519,7 @@ int dfq_bc_plan_create(const dfq_layer* layers, int32_t n_layers, const dfq_bc_s
         }
         p->eps_ptr[s] = d.eps;
         p->weight_elems += hl[s].n;
-        eps_off += pairs; corr_off += L.out_ch;
+        eps_off += (pairs + 3) & ~(int64_t)3; corr_off += L.out_ch;
     }
     mmb[n_steps] = (int32_t)mb; qeb[n_steps] = (int32_t)qb;
     // launch j = the j-th step of every network (steps arrive network by network, in graph order)
