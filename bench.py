@@ -122,6 +122,9 @@ def _pmc_traffic(net, batch):
         return None, None
 
 
+_BACKEND = 'nccl'
+
+
 def _device(local_rank):
     assert torch.cuda.is_available(), 'bench.py needs a ROCm GPU'
     torch.cuda.set_device(local_rank)
@@ -165,7 +168,10 @@ def main():
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', device_id=dev)
+        if _BACKEND == 'nccl':                             # RCCL over xGMI: one rank per GPU
+            dist.init_process_group('nccl', device_id=dev)
+        else:                                              # CPU dry run of the multi-rank path (tests/emu/dryrun.py)
+            dist.init_process_group(_BACKEND)
 
     from dfq_amd import _ffi
     _ffi.lib()

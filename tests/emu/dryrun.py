@@ -34,7 +34,13 @@ bench._gpu_elapsed_ms = _elapsed
 import contextlib
 bench._new_stream = lambda dev: None
 bench._stream_ctx = lambda s: contextlib.nullcontext()
-sys.argv = ['bench.py', '--net', 'tiny_mobile', '--steps', '2', '--warmup', '1', '--cpu-seconds', '0.2', '--streams', '1', '--batch', '2']
+world = int(os.environ.get('WORLD_SIZE', '1'))
+sys.argv = ['bench.py', '--net', 'tiny_mobile', '--steps', '2', '--warmup', '1', '--cpu-seconds', '0.2', '--streams', '1', '--batch', '2',
+            '--gpus', str(world)]
+if world > 1:                      # the multi-rank path of bench.py over gloo (tests/test_bench_multirank.py)
+    bench._BACKEND = 'gloo'
+    bench.main()
+    sys.exit(0)
 bench.main()
 
 # smoke() with cuda patched out
