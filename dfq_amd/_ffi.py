@@ -61,6 +61,10 @@ class DfqBcStep(Structure):
 
 # every exported symbol: name -> (restype, argtypes).  tests/test_abi.py checks this table against
 # include/dfq_hip.h and against the symbols the shared object really exports.
+class DfqBnRangeReq(Structure):
+    _fields_ = [('fake_weight', c_void_p), ('fake_bias', c_void_p), ('channels', c_int32), ('relu_mode', c_int32)]
+
+
 SIGNATURES = {
     'dfq_version': (c_int32, []),
     'dfq_last_error': (c_char_p, []),
@@ -91,6 +95,7 @@ SIGNATURES = {
     'dfq_quant_plan_create': (c_int32, [POINTER(DfqSegment), c_int32, POINTER(c_void_p)]),
     'dfq_quant_plan_destroy': (None, [c_void_p]),
     'dfq_quant_plan_run': (c_int32, [c_void_p, c_void_p]),
+    'dfq_quant_plan_measure': (c_int32, [c_void_p, c_void_p]),
     'dfq_quant_plan_minmax': (c_void_p, [c_void_p]),
     'dfq_bc_plan_create': (c_int32, [POINTER(DfqLayer), c_int32, POINTER(DfqBcStep), c_int32,
                                      POINTER(DfqBcSource), c_int32, POINTER(c_void_p)]),
@@ -122,6 +127,12 @@ SIGNATURES = {
     'dfq_fake_quant_rows': (c_int32, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int32, c_int32,
                                       c_void_p, c_void_p, c_void_p]),
     'dfq_grouped_matvec': (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
+    'dfq_bn_ranges_scratch_bytes': (c_size_t, [c_int32]),
+    'dfq_bn_ranges': (c_int32, [POINTER(DfqBnRangeReq), c_int32, c_float, c_void_p, c_void_p, c_void_p]),
+    'dfq_relu_moments': (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_int32, c_void_p]),
+    'dfq_moments_after_add': (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_float, c_void_p]),
+    'dfq_moment_range': (c_int32, [c_void_p, c_void_p, c_int64, c_float, c_float, c_void_p, c_void_p]),
+    'dfq_bn_through_layer': (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
 }
 
 

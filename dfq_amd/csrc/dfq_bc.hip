@@ -161,23 +161,11 @@ __global__ __launch_bounds__(kBlock) void bc_quant_error_kernel(const BcLayerDev
     L.eps[pair] = acc;
 }
 
-// scipy.stats.norm.pdf / cdf in float64 on the float32 ratio, rounded to float32 (dfq.py:182-184)
+// dfq.py:182-184: gamma*pdf(-beta/gamma) + beta*(1 - cdf(-beta/gamma)), clipped at 0 (NaN stays NaN)
 __device__ __forceinline__ float relu_mean(float w, float b) {
     const float t = (-b) / w;
-    const double x = (double)t;
-    const double pdf_d = exp(-(x * x) / 2.0) / 2.5066282746310002;   // sqrt(2*pi)
-    // cephes ndtr
-    const double z = x * 0.70710678118654752440;
-    const double az = fabs(z);
-    double cdf_d;
-    if (az < 0.70710678118654752440) {
-        cdf_d = 0.5 + 0.5 * erf(z);
-    } else {
-        cdf_d = 0.5 * erfc(az);
-        if (z > 0) cdf_d = 1.0 - cdf_d;
-    }
-    const float pdf = (float)pdf_d;
-    const float cdf = (float)cdf_d;
+    float pdf, cdf;
+    normal_pdf_cdf(t, pdf, cdf);
     const float a = w * pdf;
     const float one_m = 1.0f - cdf;
     const float c = b * one_m;

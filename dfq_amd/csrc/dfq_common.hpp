@@ -98,6 +98,24 @@ __device__ __forceinline__ double block_sum(double v, double* sh) {
     return t;
 }
 
+// scipy.stats.norm.pdf / cdf (dfq.py:182-183, layer_transform.py:405-406): evaluated in float64 on the
+// float32 argument, each rounded to float32.  cdf follows cephes ndtr (what scipy calls).
+__device__ __forceinline__ void normal_pdf_cdf(float t, float& pdf, float& cdf) {
+    const double x = (double)t;
+    const double pdf_d = exp(-(x * x) / 2.0) / 2.5066282746310002;   // sqrt(2*pi)
+    const double z = x * 0.70710678118654752440;
+    const double az = fabs(z);
+    double cdf_d;
+    if (az < 0.70710678118654752440) {
+        cdf_d = 0.5 + 0.5 * erf(z);
+    } else {
+        cdf_d = 0.5 * erfc(az);
+        if (z > 0) cdf_d = 1.0 - cdf_d;
+    }
+    pdf = (float)pdf_d;
+    cdf = (float)cdf_d;
+}
+
 // ---- fake-quant parameters (utils/quantize.py:49-66) -------------------------------------------
 struct QParams {
     float qmin, qmax, neg_min, scale, min_value;

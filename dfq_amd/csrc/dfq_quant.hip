@@ -268,6 +268,13 @@ static int grid_for(int64_t n, int per_block, int cap) {
     return (int)g;
 }
 
+__global__ void seg_decode_kernel(const uint32_t* __restrict__ slots, int n_segs, float* __restrict__ minmax) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_segs) return;
+    minmax[2 * i + 0] = slot_min(slots[2 * i + 0]);
+    minmax[2 * i + 1] = slot_max(slots[2 * i + 1]);
+}
+
 }  // namespace dfq
 
 using namespace dfq;
@@ -386,6 +393,21 @@ int dfq_quant_plan_run(dfq_quant_plan* p, void* stream) {
     DFQ_CHECK_LAUNCH();
     hipLaunchKernelGGL(seg_fake_quant_kernel, dim3(p->n_blocks), dim3(kBlock), 0, st, (const SegDev*)p->d_segs,
                        (const int32_t*)p->d_block_begin, p->n_segs, (const uint32_t*)p->d_slots, p->d_minmax);
+    DFQ_CHECK_LAUNCH();
+    return DFQ_OK;
+}
+
+// min/max only: the first launch of dfq_quant_plan_run plus a decode of the slots (calibration-table writers need
+// the ranges of the weights, not quantised weights)
+int dfq_quant_plan_measure(dfq_quant_plan* p, void* stream) {
+    if (!p) return fail_arg("dfq_quant_plan_measure: null plan");
+    hipStream_t st = as_stream(stream);
+    DFQ_HIP_TRY(hipMemsetAsync(p->d_slots, 0, sizeof(uint32_t) * 2 * p->n_segs, st));
+    hipLaunchKernelGGL(seg_minmax_kernel, dim3(p->n_blocks), dim3(kBlock), 0, st, (const SegDev*)p->d_segs,
+                       (const int32_t*)p->d_block_begin, p->n_segs, p->d_slots);
+    DFQ_CHECK_LAUNCH();
+    hipLaunchKernelGGL(seg_decode_kernel, dim3((p->n_segs + kBlock - 1) / kBlock), dim3(kBlock), 0, st,
+                       (const uint32_t*)p->d_slots, p->n_segs, p->d_minmax);
     DFQ_CHECK_LAUNCH();
     return DFQ_OK;
 }

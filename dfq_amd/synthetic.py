@@ -303,6 +303,27 @@ class TinyWide(nn.Module):
         return self.fc(x)
 
 
+class TinyHead(nn.Module):
+    """Layers that are fed by a conv / linear WITHOUT batch norm (case d of set_quant_minmax,
+    layer_transform.py:451-466): a plain 3x3 conv, a plain grouped conv and a plain linear layer sit
+    between a BN and the next layer."""
+
+    def __init__(self, n_class=5):
+        super().__init__()
+        self.stem = nn.Sequential(*_conv_bn_relu(3, 8, 3, 2, 1))
+        self.plain = nn.Conv2d(8, 12, 3, 1, 1, bias=True)
+        self.mid = nn.Sequential(*_conv_bn_relu(12, 16, 1, 1, 0))
+        self.plain_g = nn.Conv2d(16, 16, 3, 1, 1, groups=4, bias=True)
+        self.tail = nn.Sequential(*_conv_bn_relu(16, 24, 1, 1, 0))
+        self.fc1 = nn.Linear(24, 20)
+        self.fc2 = nn.Linear(20, n_class)
+
+    def forward(self, x):
+        x = self.tail(self.plain_g(self.mid(self.plain(self.stem(x)))))
+        x = torch.mean(x.view(x.size(0), x.size(1), -1), -1)
+        return self.fc2(self.fc1(x))
+
+
 # ------------------------------------------------------------------------------------------
 # factory helpers
 # ------------------------------------------------------------------------------------------
@@ -339,12 +360,13 @@ def relu6_to_relu(model):
 
 _FACTORY = {
     'mobilenet_v2': MobileNetV2, 'resnet18': ResNet18, 'deeplab_mnv2': DeepLabMNV2,
-    'tiny_mobile': TinyMobile, 'tiny_res': TinyRes, 'tiny_cat': TinyCat, 'tiny_wide': TinyWide,
+    'tiny_mobile': TinyMobile, 'tiny_res': TinyRes, 'tiny_cat': TinyCat, 'tiny_wide': TinyWide, 'tiny_head': TinyHead,
 }
 
 
-def build(name, seed=0, **kw):
-    """Random-init ``name`` on CPU (deterministic for a given torch build), eval mode, ReLU6->ReLU.
+def build(name, seed=0, keep_relu6=False, **kw):
+    """Random-init ``name`` on CPU (deterministic for a given torch build), eval mode, ReLU6->ReLU
+    (unless ``keep_relu6``: main_cls.py without ``--relu``).
 
     Returns (model, graph, bottoms) with the graph dicts in the reference's format.
     """
@@ -354,6 +376,7 @@ def build(name, seed=0, **kw):
         model = _FACTORY[name](**kw)
         init_weights(model, gen)
     model.eval()
-    relu6_to_relu(model)
+    if not keep_relu6:
+        relu6_to_relu(model)
     graph, bottoms = trace(model)
     return model, graph, bottoms

@@ -645,3 +645,241 @@ def merge_scale_to_weight(weight, bias, scale=None, scale_prev=None, groups=1, l
         if bias is not None:
             bias = (np.asarray(bias, dtype=F32) * s).astype(F32)
     return w, bias
+
+
+# --------------------------------------------------------------------------------------------
+# f1  set_quant_minmax (utils/layer_transform.py:347-609): analytic activation ranges from the BN
+#     proxies.  Restated for quant modules that belong to layers (`layer.quant`, the Q*Conv2d /
+#     Q*Linear classes); tensor-op quant modules (replace_op machinery of the absent PyTransformer
+#     submodule) are outside the restatement -- string nodes have no quant module here, which is
+#     what the reference does when replace_op was not run.
+# --------------------------------------------------------------------------------------------
+def _pdf_cdf(x32):
+    """scipy.stats.norm pdf / cdf of a float32 array, evaluated in float64, rounded to float32
+    (standard_normal / standard_cdf of layer_transform.py:405-406)."""
+    from scipy.special import ndtr
+    x = np.asarray(x32, dtype=F32).astype(np.float64)
+    with np.errstate(over='ignore', invalid='ignore'):
+        pdf = (np.exp(-x ** 2 / 2.0) / _SQRT_2PI).astype(F32)
+        cdf = ndtr(x).astype(F32)
+    return pdf, cdf
+
+
+def moments_relu(weight, bias):
+    """calculate_mean / calculate_var of layer_transform.py:407-410 (float32 tensor arithmetic in the
+    reference's operation order).  Returns (mean, var)."""
+    w = np.asarray(weight, dtype=F32)
+    b = np.asarray(bias, dtype=F32)
+    with np.errstate(divide='ignore', invalid='ignore', over='ignore'):
+        t = ((-b) / w).astype(F32)
+        pdf, cdf = _pdf_cdf(t)
+        mean = ((w * pdf).astype(F32) + (b * (F32(1) - cdf).astype(F32)).astype(F32)).astype(F32)
+        # (1-cdf) * (b*b + w*w + mean*mean - 2*mean*b) + w*(b - 2*mean)*pdf + mean*mean*cdf
+        poly = ((((b * b).astype(F32) + (w * w).astype(F32)).astype(F32) + (mean * mean).astype(F32)).astype(F32)
+                - ((F32(2) * mean).astype(F32) * b).astype(F32)).astype(F32)
+        t1 = ((F32(1) - cdf).astype(F32) * poly).astype(F32)
+        t2 = ((w * (b - (F32(2) * mean).astype(F32)).astype(F32)).astype(F32) * pdf).astype(F32)
+        t3 = ((mean * mean).astype(F32) * cdf).astype(F32)
+        var = ((t1 + t2).astype(F32) + t3).astype(F32)
+    return mean, var
+
+
+def moments_relu6(weight, bias):
+    """calculate_mean_6 / calculate_var_6 of layer_transform.py:411-418."""
+    w = np.asarray(weight, dtype=F32)
+    b = np.asarray(bias, dtype=F32)
+    with np.errstate(divide='ignore', invalid='ignore', over='ignore'):
+        lo = ((-b) / w).astype(F32)
+        hi = ((F32(6) - b).astype(F32) / w).astype(F32)
+        pdf_lo, cdf_lo = _pdf_cdf(lo)
+        pdf_hi, cdf_hi = _pdf_cdf(hi)
+        mean = (((w * (pdf_lo - pdf_hi).astype(F32)).astype(F32)
+                 + (b * (cdf_hi - cdf_lo).astype(F32)).astype(F32)).astype(F32)
+                + (F32(6) * (F32(1) - cdf_hi).astype(F32)).astype(F32)).astype(F32)
+        poly = ((((b * b).astype(F32) + (w * w).astype(F32)).astype(F32) + (mean * mean).astype(F32)).astype(F32)
+                - ((F32(2) * mean).astype(F32) * b).astype(F32)).astype(F32)
+        t1 = ((cdf_hi - cdf_lo).astype(F32) * poly).astype(F32)
+        t2 = ((w * F32(-6)).astype(F32) * pdf_hi).astype(F32)
+        t3 = ((w * (b - (F32(2) * mean).astype(F32)).astype(F32)).astype(F32) * (pdf_lo - pdf_hi).astype(F32)).astype(F32)
+        t4 = ((mean * mean).astype(F32) * cdf_lo).astype(F32)
+        t5 = (((F32(6) - mean).astype(F32) ** 2).astype(F32) * (F32(1) - cdf_hi).astype(F32)).astype(F32)
+        var = ((((t1 + t2).astype(F32) + t3).astype(F32) + t4).astype(F32) + t5).astype(F32)
+    return mean, var
+
+
+def bn_value_range(bias, weight, n):
+    """(get_min_value, get_max_value) of layer_transform.py:403-404 as Python floats."""
+    b = np.asarray(bias, dtype=F32)
+    w = np.asarray(weight, dtype=F32)
+    nw = (F32(n) * w).astype(F32)
+    return float((b - nw).astype(F32).min()), float((b + nw).astype(F32).max())
+
+
+def _clamped_range(bias, weight, n, relu):
+    lo, hi = bn_value_range(bias, weight, n)
+    if 'relu' in relu:                 # true for 'relu' and 'relu6'
+        lo = max(0., lo)
+    if 'relu6' in relu:
+        hi = min(6., hi)
+    return lo, hi
+
+
+def set_quant_minmax(spec, is_detection=False, N=6):
+    """Returns OrderedDict targ key -> (running_min, running_max) in graph order."""
+    EPS = 1e-6
+    bn_seen = OrderedDict()
+    relu_attached = {}
+    out = OrderedDict()
+    for key in spec.order:
+        bot = spec.bottoms[key]
+        if bot is None:
+            continue
+        node = spec.nodes[key]
+        if node.kind == 'bn':
+            bn_seen[key] = node
+            relu_attached[key] = 'none'
+            continue
+        if node.kind == 'relu':
+            relu_attached[bot[0]] = 'relu'
+        elif node.kind == 'relu6':
+            relu_attached[bot[0]] = 'relu6'
+        if node.kind != 'targ':            # only layers carry a quant module in this restatement
+            continue
+        if len(bot) == 1 and bot[0] == 'Data':
+            out[key] = (-1.0, 1.0) if is_detection else (-2.11790393, 2.64)
+            continue
+        bn_list, relu_list, connect_list, no_bn = find_prev_bn_full(spec, bn_seen, relu_attached, list(bot))
+        if len(bn_list) == 1:              # 1 to 1 mapping
+            bn_key, bid = bn_list[0]
+            bias = spec.nodes[bn_key].fake_bias.reshape(-1)
+            weight = spec.nodes[bn_key].fake_weight.reshape(-1)
+            if bid[0] in no_bn:             # case (d): a conv/linear between the BN and this layer
+                lay = spec.nodes[no_bn[bid[0]]]
+                wsum = lay.weight.reshape(lay.weight.shape[0], lay.weight.shape[1], -1).astype(np.float64).sum(-1)
+                G = lay.groups
+                O, Ig = wsum.shape
+                go = O // G
+
+                def through(v):
+                    v64 = v.astype(np.float64).reshape(G, Ig)
+                    r = np.einsum('goi,gi->go', wsum.reshape(G, go, Ig), v64).reshape(-1)
+                    return (r + lay.bias.astype(np.float64)).astype(F32)
+                lo, hi = bn_value_range(through(bias), through(weight), N)
+            else:
+                lo, hi = _clamped_range(bias, weight, N, relu_list[0])
+            out[key] = (lo, hi)
+            continue
+        # 1 to many: every entry hangs off bottom 0 of this layer
+        branches = OrderedDict()
+        for ent, relu, ctype in zip(bn_list, relu_list, connect_list):
+            branches.setdefault(ent[1][0], []).append((ent, relu, ctype))
+        assert len(branches) == 1, 'Error occurs when setting min/max, should be 1 to many'
+        lst = sorted(list(branches.values())[0], key=lambda x: len(x[0][1]), reverse=True)
+        (bn_key, bid), use_relu, connect_type = lst.pop(0)
+        depth = len(bid)
+        bias = spec.nodes[bn_key].fake_bias.copy()
+        weight = spec.nodes[bn_key].fake_weight.copy()
+        mean = var = None
+        value_min = value_max = None
+
+        def moments(w, b, relu):
+            if relu == 'relu':
+                return moments_relu(w, b)
+            if relu == 'relu6':
+                return moments_relu6(w, b)
+            return b.copy(), (w * w).astype(F32)
+        if 'add' in connect_type:
+            mean, var = moments(weight, bias, use_relu)
+        else:
+            value_min, value_max = _clamped_range(bias, weight, N, use_relu)
+        while lst:
+            bound = 0
+            while bound < len(lst) and len(lst[bound][0][1]) == depth:
+                bound += 1
+            if bound == 0:
+                depth = len(lst[0][0][1])       # cut depth
+                continue
+            for (bn_key, bid), relu_t, connect_type in lst[:bound]:
+                bias = spec.nodes[bn_key].fake_bias.copy()
+                weight = spec.nodes[bn_key].fake_weight.copy()
+                if 'add' in connect_type:
+                    m_t, v_t = moments(weight, bias, relu_t)
+                    mean = (mean + m_t).astype(F32)
+                    var = (var + v_t).astype(F32)
+                    if 'relu6' in connect_type:
+                        sd = np.sqrt((var + F32(EPS)).astype(F32)).astype(F32)
+                        mean, var = moments_relu6(sd, mean)
+                    elif 'relu' in connect_type:
+                        sd = np.sqrt((var + F32(EPS)).astype(F32)).astype(F32)
+                        mean, var = moments_relu(sd, mean)
+                elif connect_type == 'cat':
+                    lo, hi = _clamped_range(bias, weight, N, relu_t)
+                    value_min = min(value_min, lo)
+                    value_max = max(value_max, hi)
+                else:
+                    lo, hi = bn_value_range(bias, weight, N)
+                    value_min += max(0., lo)        # `if use_relu_tmp` is always true (a non-empty string)
+                    value_max += hi
+            lst = lst[bound:]
+            if connect_type == 'one':
+                value_min /= (bound + 1)
+                value_max /= (bound + 1)
+        if 'add' in connect_type:
+            sd = np.sqrt((var + F32(EPS)).astype(F32)).astype(F32)
+            value_min, value_max = bn_value_range(mean, sd, N)
+        out[key] = (value_min, value_max)
+    return out
+
+
+def find_prev_bn_full(spec, bn_seen, relu_attached, bot):
+    """find_prev_bn (layer_transform.py:299-344) with the fourth return value: branch id ->
+    key of the conv/linear layer found before the first BN (case d of set_quant_minmax)."""
+    frontier = [(b, str(i)) for i, b in enumerate(bot)]
+    type_tmp = {str(i): 'one' for i in range(len(bot))}
+    bn_list, relu_list, connect_list = [], [], []
+    no_bn = {}
+    cat_add_found = False
+    while frontier:
+        idx_bot, bid = frontier.pop(0)
+        node = spec.nodes[idx_bot]
+        if node.kind == 'op':
+            name = str(idx_bot)
+            if 'add' in name:
+                type_tmp[bid] = 'add_{}'.format(relu_attached[idx_bot]) if idx_bot in relu_attached else 'add'
+                cat_add_found = True
+            elif 'cat' in name:
+                type_tmp[bid] = 'cat'
+                cat_add_found = True
+        elif (not cat_add_found) and node.kind == 'targ':
+            assert bid[0] not in no_bn, 'Multiple conv/linear layer without batch_norm is not supported.'
+            no_bn[bid[0]] = idx_bot
+        if idx_bot not in bn_seen:
+            frontier.extend([(u, bid + bid[0]) for u in spec.bottoms[idx_bot]])
+            type_tmp[bid + bid[0]] = type_tmp[bid]
+        else:
+            bn_list.append((idx_bot, bid))
+            relu_list.append(relu_attached[idx_bot])
+            connect_list.append(type_tmp[bid])
+    return bn_list, relu_list, connect_list, no_bn
+
+
+# --------------------------------------------------------------------------------------------
+# f3  the int8 calibration table of convert_ncnn.py:180-201 (weights block, then activations block)
+# --------------------------------------------------------------------------------------------
+def ncnn_table_lines(spec, act_ranges, names=None):
+    """spec: GraphSpec; act_ranges: {targ key: (running_min, running_max)} as float32-representable
+    Python floats.  Returns the lines the reference writes to model_int8_tensor.table."""
+    keys = spec.targ_keys()
+    if names is None:
+        names = ['{}_param_0'.format(k) for k in keys] + [str(k) for k in keys]
+    lines = []
+    for i, k in enumerate(keys):
+        w = spec.nodes[k].weight
+        mi, ma = float(w.min()), float(w.max())
+        scale = 128. / (max(abs(ma), abs(mi)))
+        lines.append(' '.join([names[i]] + [str(scale)] * w.shape[0]))
+    for i, k in enumerate(keys):
+        mi, ma = float(F32(act_ranges[k][0])), float(F32(act_ranges[k][1]))
+        scale = 128. / (max(abs(ma), abs(mi)))
+        lines.append(' '.join([names[len(keys) + i], str(scale)]))
+    return lines

@@ -4,7 +4,7 @@ The reference keeps the traced network as two ``OrderedDict``s (``graph``: key -
 ``bottoms``: key -> list[key] | None; main_cls.py:134-135).  ``GraphSpec`` holds the same
 topology with numpy arrays instead of modules so the oracle needs no torch.
 
-Node kinds: 'data', 'targ' (Conv2d/Linear family), 'bn', 'relu', 'qm' (QuantMeasure), 'avgpool',
+Node kinds: 'data', 'targ' (Conv2d/Linear family), 'bn', 'relu', 'relu6', 'qm' (QuantMeasure), 'avgpool',
 'op' (string-valued tensor op such as 'add_12', 'torch.cat_30', 'F.pad_7', 'torch.mean_150'),
 'other'.
 """
@@ -93,6 +93,8 @@ def from_torch(graph, bottoms, targ_type):
                 node.fake_bias = _np(m.fake_bias)
         elif type(m) == nn.ReLU:
             node = Node(key, 'relu')
+        elif type(m) == nn.ReLU6:
+            node = Node(key, 'relu6')
         elif type(m) == nn.AvgPool2d:
             node = Node(key, 'avgpool')
         elif type(m).__name__ == 'QuantMeasure':

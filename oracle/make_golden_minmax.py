@@ -1,0 +1,122 @@
+"""Pin the oracle's set_quant_minmax against the UNMODIFIED reference and write tests/golden/minmax_*.npz.
+
+Runs only in the build container (needs /root/reference):
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/make_golden_minmax.py
+
+For every case: build the synthetic net, fold BN with the reference's merge_batchnorm, replace every
+conv / linear of the graph dict by the reference's QConv2d / QLinear (what its switch_layers does, without
+the absent PyTransformer), run the reference's set_quant_minmax (utils/layer_transform.py:347-609) with a
+stub for the tensor-op registry it reads through a module global, read back every layer's
+quant.running_min / running_max; run the oracle on the same inputs; assert agreement; store inputs (BN
+proxies, the weights case (d) needs) and the reference's ranges.
+"""
+from __future__ import annotations
+
+import os
+import sys
+from collections import OrderedDict
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = '/root/reference'
+sys.path.insert(0, ROOT)
+sys.path.insert(1, REF)
+sys.dont_write_bytecode = True
+
+import torch                                   # noqa: E402
+import torch.nn as nn                          # noqa: E402
+
+from utils import quantize as ref_q            # noqa: E402  (reference)
+from utils import layer_transform as ref_lt    # noqa: E402  (reference)
+
+from oracle import dfq_oracle as orc           # noqa: E402
+from oracle import graphspec                   # noqa: E402
+from dfq_amd import synthetic                  # noqa: E402
+
+GOLD = os.path.join(ROOT, 'tests', 'golden')
+TARG = [nn.Conv2d, nn.Linear]
+F32 = np.float32
+
+
+class _NoTensorOps:
+    """module_tensor_op of layer_transform.py (set by replace_op in the reference): never matches."""
+
+    def get_graph_name(self):
+        return None
+
+
+def q_graph(graph):
+    """graph dict with every conv / linear replaced by the reference's Q classes (same parameters)."""
+    out = OrderedDict()
+    for k, m in graph.items():
+        if type(m) == nn.Conv2d:
+            q = ref_q.QConv2d(m.in_channels, m.out_channels, m.kernel_size, m.stride, m.padding, m.dilation, m.groups,
+                              m.bias is not None)
+            q.weight.data.copy_(m.weight.data)
+            if m.bias is not None:
+                q.bias.data.copy_(m.bias.data)
+            out[k] = q
+        elif type(m) == nn.Linear:
+            q = ref_q.QLinear(m.in_features, m.out_features, m.bias is not None)
+            q.weight.data.copy_(m.weight.data)
+            if m.bias is not None:
+                q.bias.data.copy_(m.bias.data)
+            out[k] = q
+        else:
+            out[k] = m
+    return out
+
+
+def run(name, seed, keep_relu6=False, is_detection=False, N=6):
+    model, graph, bottoms = synthetic.build(name, seed=seed, keep_relu6=keep_relu6)
+    ref_lt.merge_batchnorm(model, graph, bottoms, TARG)
+    spec = graphspec.from_torch(graph, bottoms, TARG)
+    gq = q_graph(graph)
+    ref_lt.module_tensor_op = _NoTensorOps()
+    ref_lt.set_quant_minmax(gq, bottoms, is_detection=is_detection, N=N, verbose=False)
+    keys = list(graph.keys())
+    want = OrderedDict()
+    for k, m in gq.items():
+        if hasattr(m, 'quant') and bottoms[k] is not None:
+            want[k] = (float(m.quant.running_min), float(m.quant.running_max))
+    got = orc.set_quant_minmax(spec, is_detection=is_detection, N=N)
+    assert list(got.keys()) == list(want.keys()), (list(got.keys()), list(want.keys()))
+    worst = 0.0
+    for k in want:
+        for a, b in zip(got[k], want[k]):
+            err = abs(a - b) / max(1.0, abs(b))
+            worst = max(worst, err)
+            assert err <= 1e-5, '{} {}: oracle {} reference {}'.format(name, k, got[k], want[k])
+    out = {'cfg': np.array([int(keep_relu6), int(is_detection), N]),
+           'ranges': np.array([want[k] for k in want], dtype=np.float64),
+           'layers': np.array([keys.index(k) for k in want])}
+    for i, k in enumerate(spec.order):
+        n = spec.nodes[k]
+        if n.kind == 'bn':
+            out['bn{}'.format(i)] = np.stack([n.fake_weight, n.fake_bias])
+        elif n.kind == 'targ':
+            out['w{}'.format(i)] = n.weight
+            if n.bias is not None:
+                out['b{}'.format(i)] = n.bias
+    tag = 'minmax_{}_s{}{}{}'.format(name, seed, '_relu6' if keep_relu6 else '', '_det' if is_detection else '')
+    np.savez_compressed(os.path.join(GOLD, tag + '.npz'), **out)
+    print('{}: {} layers, oracle vs reference max rel err {:.2e}'.format(tag, len(want), worst))
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    run('tiny_mobile', 0)
+    run('tiny_mobile', 1, keep_relu6=True)
+    run('tiny_res', 0)
+    run('tiny_res', 2, keep_relu6=True)
+    run('tiny_cat', 0, is_detection=True)
+    run('tiny_cat', 1, keep_relu6=True)
+    run('tiny_wide', 3, keep_relu6=True)
+    run('tiny_head', 0)
+    run('tiny_head', 4, keep_relu6=True)
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,152 @@
+"""set_quant_minmax (utils/layer_transform.py:347-609): analytic activation ranges.
+
+  * oracle vs the reference's outputs stored in tests/golden/minmax_*.npz (oracle/make_golden_minmax.py ran the
+    unmodified reference on the same inputs);
+  * engine (CPU emulation of the kernels / MI355X) vs oracle: the one-BN-per-quantiser cases are the same float32
+    operations (bit-exact); branches through add / cat go through float64 pdf / cdf of different libms (1e-5).
+"""
+import glob
+import os
+import re
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from dfq_amd import synthetic
+from dfq_amd.utils import layer_transform as lt
+from dfq_amd.utils.quantize import QConv2d, QLinear
+from oracle import dfq_oracle as orc
+from oracle import graphspec
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+TARG = [nn.Conv2d, nn.Linear]
+CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLD, 'minmax_*.npz')))
+
+
+def _parse(tag):
+    m = re.match(r'minmax_(\w+?)_s(\d+)((?:_relu6)?)((?:_det)?)$', tag)
+    return m.group(1), int(m.group(2)), bool(m.group(3)), bool(m.group(4))
+
+
+def _load_spec(tag):
+    """Topology from the synthetic builder, every number from the fixture (independent of this torch build's RNG)."""
+    name, seed, relu6, det = _parse(tag)
+    gold = np.load(os.path.join(GOLD, tag + '.npz'))
+    model, graph, bottoms = synthetic.build(name, seed=seed, keep_relu6=relu6)
+    spec = graphspec.from_torch(graph, bottoms, TARG)
+    for i, k in enumerate(spec.order):
+        n = spec.nodes[k]
+        if n.kind == 'bn':
+            n.fake_weight, n.fake_bias = gold['bn{}'.format(i)][0].copy(), gold['bn{}'.format(i)][1].copy()
+        elif n.kind == 'targ':
+            n.weight = gold['w{}'.format(i)].copy()
+            n.bias = gold['b{}'.format(i)].copy() if 'b{}'.format(i) in gold.files else None
+    return spec, gold, (model, graph, bottoms), det
+
+
+def test_fixtures_exist():
+    assert len(CASES) >= 9
+
+
+@pytest.mark.parametrize('tag', CASES)
+def test_oracle_matches_reference_fixture(tag):
+    spec, gold, _, det = _load_spec(tag)
+    got = orc.set_quant_minmax(spec, is_detection=det, N=int(gold['cfg'][2]))
+    keys = list(spec.order)
+    assert [keys.index(k) for k in got] == gold['layers'].tolist()
+    for (lo, hi), (rlo, rhi) in zip(got.values(), gold['ranges']):
+        assert abs(lo - rlo) <= 1e-5 * max(1.0, abs(rlo)) and abs(hi - rhi) <= 1e-5 * max(1.0, abs(rhi))
+
+
+def _q_graph(graph, device):
+    out = OrderedDict()
+    for k, m in graph.items():
+        if type(m) == nn.Conv2d:
+            q = QConv2d(m.in_channels, m.out_channels, m.kernel_size, m.stride, m.padding, m.dilation, m.groups,
+                        m.bias is not None)
+        elif type(m) == nn.Linear:
+            q = QLinear(m.in_features, m.out_features, m.bias is not None)
+        else:
+            out[k] = m
+            continue
+        q.weight.data.copy_(m.weight.data)
+        if m.bias is not None:
+            q.bias.data.copy_(m.bias.data)
+        out[k] = q.to(device)
+    return out
+
+
+@pytest.mark.parametrize('tag', CASES)
+def test_engine_matches_oracle(engine, tag):
+    spec, gold, (model, graph, bottoms), det = _load_spec(tag)
+    N = int(gold['cfg'][2])
+    want = orc.set_quant_minmax(spec, is_detection=det, N=N)
+    # the engine's inputs: the fixture's BN proxies / weights written into the torch graph
+    model.to(engine.device)
+    for i, k in enumerate(graph):
+        m = graph[k]
+        if type(m) == nn.BatchNorm2d:
+            m.register_buffer('fake_weight', torch.from_numpy(gold['bn{}'.format(i)][0].copy()).to(engine.device))
+            m.register_buffer('fake_bias', torch.from_numpy(gold['bn{}'.format(i)][1].copy()).to(engine.device))
+        elif type(m) in TARG:
+            m.weight.data.copy_(torch.from_numpy(gold['w{}'.format(i)]))
+            if 'b{}'.format(i) in gold.files:
+                if m.bias is None:
+                    m.bias = nn.Parameter(torch.zeros(m.weight.shape[0], device=engine.device))
+                m.bias.data.copy_(torch.from_numpy(gold['b{}'.format(i)]))
+    gq = _q_graph(graph, engine.device)
+    lt.set_quant_minmax(gq, bottoms, is_detection=det, N=N, verbose=False)
+    got = OrderedDict((k, (float(m.quant.running_min), float(m.quant.running_max)))
+                      for k, m in gq.items() if hasattr(m, 'quant') and bottoms[k] is not None)
+    assert list(got.keys()) == list(want.keys())
+    for k in want:
+        for a, b in zip(got[k], want[k]):
+            assert abs(a - b) <= 1e-5 * max(1.0, abs(b)), '{} {}: engine {} oracle {}'.format(tag, k, got[k], want[k])
+
+
+def test_relu_moments_kernels_against_oracle(engine):
+    """The channel arithmetic on its own, including dead (gamma = 0) channels."""
+    from dfq_amd import _ffi
+    g = torch.Generator().manual_seed(7)
+    w = torch.rand(300, generator=g) * 2 + 0.05
+    b = torch.randn(300, generator=g) * 2
+    w[5] = 0.0
+    stage = _ffi.Stage()
+    wd, bd = engine.to(w), engine.to(b)
+    for mode, fn in ((1, orc.moments_relu), (2, orc.moments_relu6)):
+        mean, var = stage.new((300,)), stage.new((300,))
+        _ffi.check(_ffi.lib().dfq_relu_moments(_ffi.ptr(wd), _ffi.ptr(bd), 300, mode, _ffi.ptr(mean), _ffi.ptr(var), 0,
+                                               _ffi.stream_arg()))
+        om, ov = fn(w.numpy(), b.numpy())
+        np.testing.assert_allclose(mean.cpu().numpy(), om, rtol=1e-5, atol=1e-6, equal_nan=True)
+        np.testing.assert_allclose(var.cpu().numpy(), ov, rtol=1e-4, atol=1e-5, equal_nan=True)
+
+
+def test_ncnn_calibration_table_matches_oracle(engine, tmp_path):
+    """convert_ncnn.py:180-201: weight scales from the whole network's min/max in one launch, activation scales
+    from the analytic ranges; string-identical lines (min/max are exact, the arithmetic is Python's)."""
+    from dfq_amd import ncnn_table
+    spec, gold, (model, graph, bottoms), det = _load_spec('minmax_tiny_mobile_s0')
+    model.to(engine.device)
+    for i, k in enumerate(graph):
+        m = graph[k]
+        if type(m) == nn.BatchNorm2d:
+            m.register_buffer('fake_weight', torch.from_numpy(gold['bn{}'.format(i)][0].copy()).to(engine.device))
+            m.register_buffer('fake_bias', torch.from_numpy(gold['bn{}'.format(i)][1].copy()).to(engine.device))
+        elif type(m) in TARG:
+            m.weight.data.copy_(torch.from_numpy(gold['w{}'.format(i)]))
+    gq = _q_graph(graph, engine.device)
+    lt.set_quant_minmax(gq, bottoms, verbose=False)
+    act = {k: (float(m.quant.running_min), float(m.quant.running_max)) for k, m in gq.items() if hasattr(m, 'quant')}
+    lines = ncnn_table.write_calibration_table(str(tmp_path / 'model_int8_tensor.table'), gq, targ_type=(QConv2d, QLinear))
+    want = orc.ncnn_table_lines(spec, act)
+    assert lines == want
+    assert open(str(tmp_path / 'model_int8_tensor.table')).read().splitlines() == want
+    # per-channel extension: one scale per output channel = 128 / max|row|
+    pc = ncnn_table.calibration_table(gq, targ_type=(QConv2d, QLinear), per_channel=True)
+    k0 = spec.targ_keys()[0]
+    w0 = spec.nodes[k0].weight.reshape(spec.nodes[k0].weight.shape[0], -1)
+    assert pc[0].split(' ')[1:] == [str(128. / float(np.abs(w0[r]).max())) for r in range(w0.shape[0])]
