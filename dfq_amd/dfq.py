@@ -446,7 +446,7 @@ class _RawDeviceBuffer:
 
     def tensor(self):
         if self.device.type == 'cuda':
-            iface = {'shape': (self.n,), 'typestr': '<f4', 'data': (self.addr, True), 'version': 2, 'strides': None}
+            iface = {'shape': (self.n,), 'typestr': '<f4', 'data': (self.addr, False), 'version': 2, 'strides': None}
             holder = type('_Holder', (), {'__cuda_array_interface__': iface})()
             return torch.as_tensor(holder, device=self.device)
         import numpy as np
