@@ -308,6 +308,25 @@ def test_batched_bias_correction_matches_separate_runs(engine):
         compare_stage(a, net_fixture(name, seed, suffix), 'bc', what=name)
 
 
+def test_bias_correction_intermediates_against_oracle(engine):
+    """eps (quant-error row sums, dfq.py:216-219) and the correction vectors (dfq.py:281-287) read back from
+    the plan: eps is float32 elementwise work in the oracle's order (bit-exact), the matvec is 1e-5."""
+    gold = net_fixture('tiny_res', 0, '')
+    model, graph, bottoms = _build('tiny_res', 0, gold, engine)
+    lt.merge_batchnorm(model, graph, bottoms, TARG)
+    load_stage(graph, gold, 'abs')
+    spec = graphspec.from_torch(graph, bottoms, TARG)
+    collect = {}
+    orc.bias_correction(spec, collect=collect)
+    plan, keys = dfq.build_bc_plan(graph, bottoms, TARG)
+    plan.run()
+    assert keys == list(collect.keys())
+    for step, k in enumerate(keys):
+        assert_bitexact(npy(plan.eps(step)), collect[k]['eps'].reshape(npy(plan.eps(step)).shape), 'eps of {}'.format(k))
+        assert_close(npy(plan.correction(step)), collect[k]['bias'].reshape(-1), 'correction of {}'.format(k))
+    assert plan.weight_elements == sum(spec.nodes[k].weight.size for k in keys)
+
+
 def test_graph_replay_mode(engine, monkeypatch):
     """DFQ_GRAPH=1: the sweep run and the BC chain are recorded once and replayed as hipGraphs."""
     monkeypatch.setenv('DFQ_GRAPH', '1')
