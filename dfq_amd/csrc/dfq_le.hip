@@ -212,6 +212,13 @@ __device__ __forceinline__ void channel_scale(const LeRelDev& R, const LeParams&
     le_solve(range_of(mn1, mx1, p.signed_range), range_of(mn2, mx2, p.signed_range), p, s, inv);
 }
 
+__device__ __forceinline__ void scale_from_words(const LeParams& p, uint32_t a0, uint32_t a1, uint32_t b0, uint32_t b1,
+                                                 float& s, float& inv, float& mn1, float& mx1, float& mn2, float& mx2) {
+    mn1 = slot_min(a0); mx1 = slot_max(a1);
+    mn2 = slot_min(b0); mx2 = slot_max(b1);
+    le_solve(range_of(mn1, mx1, p.signed_range), range_of(mn2, mx2, p.signed_range), p, s, inv);
+}
+
 // |a - b| if `on`, else 0 -- the contribution of one element to sum|W - W_prev|.  The select is done
 // on the float32 difference and the magnitude taken afterwards by clearing the sign bit: the pattern
 // select(on, (double)fabsf(d), 0.0) made this compiler fold the abs source modifier into one half of
@@ -280,7 +287,15 @@ __device__ __forceinline__ double row_tile(const LeRelDev& R, const LeParams& p,
     gfloat* const w = (gfloat*)R.w1 + ((int64_t)r0 * R.row_len + pos);
     const bool fused = R.w1_interior != 0;     // the column rescale of the previous relation is applied here too
 
-    // ---- issue every data load first -----------------------------------------------------------
+    // ---- the four statistics words of this thread's row go first: they are back long before the data and the
+    //      scale solve then overlaps the data's flight instead of queueing behind it (memory returns in order) ----
+    uint32_t wa0 = 0u, wa1 = 0u, wb0 = 0u, wb1 = 0u;
+    if (tid < nr) {
+        const guint* a = (const guint*)R.r1 + (int64_t)cur * R.stat_stride + 2 * (r0 + tid);
+        const guint* b = (const guint*)R.r2 + (int64_t)cur * R.stat_stride + 2 * (r0 + tid);
+        wa0 = a[0]; wa1 = a[1]; wb0 = b[0]; wb1 = b[1];
+    }
+    // ---- then every data load ---------------------------------------------------------------------
     float v[NV][VEC];
 #pragma unroll
     for (int u = 0; u < NV; ++u) {
@@ -328,7 +343,7 @@ __device__ __forceinline__ double row_tile(const LeRelDev& R, const LeParams& p,
             if (R.b1) o_b1 = R.b1[c];
         }
         float s, inv, mn1, mx1, mn2, mx2;
-        channel_scale(R, p, cur, c, s, inv, mn1, mx1, mn2, mx2);
+        scale_from_words(p, wa0, wa1, wb0, wb1, s, inv, mn1, mx1, mn2, mx2);
         sh_s[tid] = s;
         if (emit) sh_g[tid] = (small_div(c, R.pc_go) - g0) * nci;
         if (own) {
@@ -441,7 +456,21 @@ __device__ __forceinline__ double col_tile(const LeRelDev& R, const LeParams& p,
     const bool emit = R.out_rows != nullptr && !(kAblate & 4);
     gfloat* const w = (gfloat*)R.w2 + ((int64_t)r0 * row_len2 + pos);
 
-    // ---- issue every data load first -----------------------------------------------------------
+    // 1/s table of the tile: (groups spanned by the rows) x (input channels spanned by the columns)
+    const int i0 = small_div(p0, R.khkw);
+    const int nci = small_div(p0 + np - 1, R.khkw) - i0 + 1;
+    const int g_lo = small_div(r0, R.go);
+    const int g_n = small_div(r0 + nr - 1, R.go) - g_lo + 1;
+    // ---- the statistics words of this thread's table entry go first (see row_tile) ----
+    uint32_t wa0 = 0u, wa1 = 0u, wb0 = 0u, wb1 = 0u;
+    if (tid < g_n * nci) {
+        const int gq = small_div(tid, nci);
+        const int c = (g_lo + gq) * R.gi + i0 + (tid - gq * nci);
+        const guint* a = (const guint*)R.r1 + (int64_t)cur * R.stat_stride + 2 * c;
+        const guint* b = (const guint*)R.r2 + (int64_t)cur * R.stat_stride + 2 * c;
+        wa0 = a[0]; wa1 = a[1]; wb0 = b[0]; wb1 = b[1];
+    }
+    // ---- then every data load ---------------------------------------------------------------------
     float v[NV][VEC];
 #pragma unroll
     for (int u = 0; u < NV; ++u) {
@@ -450,19 +479,14 @@ __device__ __forceinline__ double col_tile(const LeRelDev& R, const LeParams& p,
             vload<VEC>(w + r * row_len2, v[u]);
         }
     }
-
-    // 1/s table of the tile: (groups spanned by the rows) x (input channels spanned by the columns)
-    const int i0 = small_div(p0, R.khkw);
-    const int nci = small_div(p0 + np - 1, R.khkw) - i0 + 1;
-    const int g_lo = small_div(r0, R.go);
-    const int g_n = small_div(r0 + nr - 1, R.go) - g_lo + 1;
     stamp(tr, 2);
     for (int idx = tid; idx < g_n * nci; idx += kBlock) {      // one entry per thread for every plan-made tile
         const int gq = small_div(idx, nci);
         const int g = g_lo + gq;
         const int c = g * R.gi + i0 + (idx - gq * nci);
         float s, inv, mn1, mx1, mn2, mx2;
-        channel_scale(R, p, cur, c, s, inv, mn1, mx1, mn2, mx2);
+        if (idx == tid) scale_from_words(p, wa0, wa1, wb0, wb1, s, inv, mn1, mx1, mn2, mx2);
+        else channel_scale(R, p, cur, c, s, inv, mn1, mx1, mn2, mx2);
         sh_inv[idx] = inv;
         // W2 is never row-scaled: forward its column stats (the tile holding the group's first row does it)
         if (!emit && g * R.go >= r0 && g * R.go < r0 + nr) {
