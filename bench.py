@@ -74,6 +74,7 @@ def make_unit(protos):
     one LE plan and one BC plan over the whole batch (a batch of 1 is an ordinary single-network plan)."""
     from dfq_amd import dfq
     nets = [copy.deepcopy(p) for p in protos]
+    t0 = time.perf_counter()
     if len(nets) == 1:
         model, graph, bottoms, rels = nets[0]
         le = dfq.build_le_plan(graph, rels, TARG)
@@ -81,7 +82,7 @@ def make_unit(protos):
     else:
         le = dfq.build_le_plan_batch([(g, r) for (_, g, _, r) in nets], TARG)
         bc = dfq.build_bc_plan_batch([(g, b) for (_, g, b, _) in nets], TARG)
-    return dict(nets=nets, le=le, bc=bc)
+    return dict(nets=nets, le=le, bc=bc, plan_build_ms=(time.perf_counter() - t0) * 1e3)
 
 
 def cpu_baseline(net, seed, budget_s):
@@ -297,6 +298,9 @@ def main():
             'units_in_flight_per_gpu': n_streams,
             'single_pass_latency_ms': single_ms,
             'one_unit_alone_ms': {'equalization': le_ms, 'bias_correction': bc_ms},
+            # host-side, once per batch, outside the timed region (like graph tracing / BN folding): descriptor and
+            # launch tables of the two plans, small device allocations, one synchronisation
+            'plan_build_ms_per_unit': sum(u['plan_build_ms'] for u in units) / len(units),
         },
     }
 

@@ -752,7 +752,16 @@ __global__ __launch_bounds__(kBlock) void le_bootstrap_kernel(const LeRelDev* __
                 const int ii = c - g * R.gi;
                 const float* col = R.w2 + ((int64_t)g * R.go * R.i2g + ii) * R.khkw + k;
                 float mn = INFINITY, mx = -INFINITY;
-                for (int j = jl; j < R.go; j += JL) {
+                // eight rows per trip: the loads are independent, so eight are in flight instead of one
+                int j = jl;
+                for (; j + 7 * JL < R.go; j += 8 * JL) {
+                    float v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = col[(int64_t)(j + u * JL) * col_stride];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { mn = fminf(mn, v[u]); mx = fmaxf(mx, v[u]); }
+                }
+                for (; j < R.go; j += JL) {
                     const float v = col[(int64_t)j * col_stride];
                     mn = fminf(mn, v); mx = fmaxf(mx, v);
                 }
