@@ -36,7 +36,7 @@ def merge_batchnorm(model, graph, bottoms, targ_type=[QConv2d]):
 
     W <- W * gamma/sqrt(var+eps) per output channel, b <- b*gamma/sqrt(var+eps) + beta -
     gamma*mean/sqrt(var+eps); the BN keeps ``fake_weight = |gamma|`` and ``fake_bias = beta`` for the
-    later passes and becomes an identity (eps = 0).
+    later passes and becomes an identity (gamma = var = 1, beta = mean = 0, eps below float32 resolution).
     """
     lib = _ffi.lib()
     with torch.no_grad():
@@ -65,7 +65,10 @@ def merge_batchnorm(model, graph, bottoms, targ_type=[QConv2d]):
                                                   _ffi.stream_arg()))
                 bn.register_buffer('fake_weight', stage.out_like(bn.weight, fw))
                 bn.register_buffer('fake_bias', stage.out_like(bn.weight, fb))
-                bn.eps = 0
+                # The reference sets eps = 0 (layer_transform.py:272); current PyTorch rejects eps <= 0 in
+                # F.batch_norm.  1e-12 is absorbed by float32 rounding (1 + 1e-12 == 1): the folded BN is still an
+                # exact identity and the model still runs.
+                bn.eps = 1e-12
                 break
         stage.writeback()
     return model

@@ -92,6 +92,30 @@ def test_quant_measure(engine):
     assert_bitexact(npy(y2), y2_o)
 
 
+@pytest.mark.gpu
+def test_quant_measure_at_config5_size():
+    """BASELINE.json config 5 (--distill_range): one of MobileNetV2's largest activation tensors at batch 64
+    ([64, 96, 112, 112] = 7.7e7 floats) through QuantMeasure with update_stat, against the numpy oracle on a
+    slice-wise evaluation: per-sample max/min are exact, their float32 mean and the five-operation fake-quant
+    are the same IEEE operations -> bit-exact; then the size-independent properties (idempotence of the
+    quantiser on its own output, <= 256 distinct levels, range respected)."""
+    dev = torch.device('cuda', 0)
+    g = torch.Generator(device='cpu').manual_seed(1)
+    x = torch.randn(64, 96, 112, 112, generator=g).clamp_(-2.1179, 2.64)
+    m = q.QuantMeasure(update_stat=True).to(dev).eval()
+    y = m(x.to(dev))
+    xn = x.numpy()
+    y_o, rmin, rmax = orc.quant_measure_forward(xn, 0.0, 0.0, update_stat=True)
+    assert_bitexact(npy(m.running_min), np.array([rmin], dtype=F32))
+    assert_bitexact(npy(m.running_max), np.array([rmax], dtype=F32))
+    yn = npy(y)
+    assert_bitexact(yn, y_o, 'QuantMeasure output at full size')
+    m.set_update_stat(False)
+    y2 = m(y)                                                    # same range, already on the grid
+    assert torch.equal(y2, y)
+    assert len(np.unique(yn)) <= 256 and yn.min() >= rmin - 1e-6 and yn.max() <= rmax + 1e-6
+
+
 @pytest.mark.parametrize('reduction', ['sum', 'mean', 'channel', 'spatial', None])
 def test_quantize_error(engine, reduction):
     rng = np.random.default_rng(3)
