@@ -445,6 +445,39 @@ def test_geometry_corner_cases_against_oracle(engine):
         assert_close(esnap[k], osnap[k], 'tiny_wide BC {}'.format(k))
 
 
+@pytest.mark.gpu
+def test_heterogeneous_full_size_batch_matches_single_plans():
+    """One batched plan over DIFFERENT architectures at full size (MobileNetV2, ResNet-18, a second MobileNetV2
+    with other weights): every network must end bit-identical to a plan of its own -- weights, cumulative scales,
+    sweep count -- and its bias correction (batched BC plan, networks with different layer counts per launch)
+    must equal the single-network one."""
+    dev = torch.device('cuda', 0)
+    cases = [('mobilenet_v2', 0), ('resnet18', 0), ('mobilenet_v2', 5)]
+    batch, single = [], []
+    for name, seed in cases:
+        for target in (batch, single):
+            model, graph, bottoms = synthetic.build(name, seed=seed)
+            model.to(dev)
+            lt.merge_batchnorm(model, graph, bottoms, TARG)
+            target.append((model, graph, bottoms, rel.create_relation(graph, bottoms, TARG)))
+    plan = dfq.build_le_plan_batch([(g, r) for (_, g, _, r) in batch], TARG)
+    plan.run()
+    results, _ = plan.query_all()
+    bc = dfq.build_bc_plan_batch([(g, b) for (_, g, b, _) in batch], TARG)
+    bc.run()
+    first_rel = 0
+    for (name, seed), (_, gb, _, rb), (_, gs, bs, rs), res in zip(cases, batch, single, results):
+        dfq.cross_layer_equalization(gs, rs, TARG)
+        assert res['sweeps'] == dfq.last_equalization['sweeps'], name
+        for i, r2 in enumerate(rs):            # the plan keeps the cumulative S of all networks' relations in list order
+            assert_bitexact(npy(plan.scale_cum[first_rel + i]), npy(r2.get_scale_vec()), '{} cumulative S'.format(name))
+        first_rel += len(rs)
+        dfq.bias_correction(gs, bs, TARG)
+        a, b = snapshot(gb), snapshot(gs)
+        for k in b:
+            assert_bitexact(a[k], b[k], '{} s{} {}'.format(name, seed, k))
+
+
 # ---------------------------------------------------------------------------------------------
 # BASELINE.json configurations at full size (GPU only: the emulation would take minutes)
 # ---------------------------------------------------------------------------------------------
