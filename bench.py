@@ -132,6 +132,10 @@ def _device(local_rank):
     return torch.device('cuda', local_rank)
 
 
+def _bind_thread(dev):
+    torch.cuda.set_device(dev)
+
+
 def _sync():
     torch.cuda.synchronize()
 
@@ -225,6 +229,7 @@ def main():
         import threading
 
         def worker(i):
+            _bind_thread(dev)                  # HIP's current device is per host thread; new threads start on device 0
             with _stream_ctx(streams[i]):
                 for u in work[i::n_streams]:
                     step(u)

@@ -33,6 +33,7 @@ def _elapsed(fn):
 bench._gpu_elapsed_ms = _elapsed
 import contextlib
 bench._new_stream = lambda dev: None
+bench._bind_thread = lambda dev: None
 bench._stream_ctx = lambda s: contextlib.nullcontext()
 world = int(os.environ.get('WORLD_SIZE', '1'))
 sys.argv = ['bench.py', '--net', 'tiny_mobile', '--steps', '2', '--warmup', '1', '--cpu-seconds', '0.2', '--streams', '1', '--batch', '2',
