@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import (POINTER, Structure, byref, c_char_p, c_double, c_float, c_int32, c_int64,
+from ctypes import (POINTER, Structure, c_char_p, c_double, c_float, c_int32, c_int64,
                     c_size_t, c_void_p)
 
 import torch

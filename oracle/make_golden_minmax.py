@@ -25,7 +25,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(1, REF)
 sys.dont_write_bytecode = True
 
-import torch                                   # noqa: E402
+import torch                                   # noqa: E402,F401  (the reference modules expect torch to be imported)
 import torch.nn as nn                          # noqa: E402
 
 from utils import quantize as ref_q            # noqa: E402  (reference)
