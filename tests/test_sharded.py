@@ -1,7 +1,8 @@
 """N > 1 path of row (e): one network sharded over ranks (dfq_amd/sharded.py), world_size 2 over gloo
-on CPU.  The HIP engine cannot run here, so the per-rank compute is the numpy oracle and the rebuild
-uses torch ops -- injected stand-ins; what is under test is the partition, the all_gather exchange of
-the scale vectors and the rebuild, against the single-process result."""
+on CPU.  Two flavours: (1) injected stand-ins (numpy oracle per rank, torch ops for the rebuild) isolate the
+partition / all_gather exchange of the scale vectors / rebuild logic; (2) the product code path -- the engine's
+sweeps on every rank and the engine's row/column rescale kernels for the foreign layers -- with the kernels
+running on the CPU emulation.  Both against the single-process oracle result."""
 import os
 import socket
 
@@ -100,7 +101,17 @@ def _torch_rescale(weight, bias, bn, s_out, s_in, groups):
             weight.div_(per_row.view((weight.shape[0], -1) + (1,) * (weight.dim() - 2)))
 
 
-def _worker(rank, world, port, name, seed, max_sweeps, out_dir):
+def _use_emulated_engine(emu_path):
+    """In a spawned rank: route dfq_amd to the CPU emulation build of the kernels (as the `engine` fixture does)."""
+    import ctypes
+    from dfq_amd import _ffi
+    _ffi._lib = _ffi.bind(ctypes.CDLL(emu_path))
+    _ffi.target_device = lambda: torch.device('cpu')
+    _ffi.current_stream = lambda: 0
+    _ffi.synchronize = lambda: None
+
+
+def _worker(rank, world, port, name, seed, max_sweeps, out_dir, emu_path=None):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
@@ -108,8 +119,12 @@ def _worker(rank, world, port, name, seed, max_sweeps, out_dir):
         torch.set_num_threads(1)
         model, graph, bottoms, _ = _prepare(name, seed)
         rels = rel.create_relation(graph, bottoms, TARG)
-        sweeps = sharded.sharded_cross_layer_equalization(graph, rels, TARG, max_sweeps=max_sweeps,
-                                                          le_runner=_oracle_runner, rescale=_torch_rescale)
+        if emu_path:          # the product code path: engine sweeps per rank, engine rescale of the foreign layers
+            _use_emulated_engine(emu_path)
+            sweeps = sharded.sharded_cross_layer_equalization(graph, rels, TARG, max_sweeps=max_sweeps)
+        else:
+            sweeps = sharded.sharded_cross_layer_equalization(graph, rels, TARG, max_sweeps=max_sweeps,
+                                                              le_runner=_oracle_runner, rescale=_torch_rescale)
         owner = sharded.assign_components(graph, rels, world)
         snap = {'sweeps': np.array(sweeps), 'owner': np.array(owner)}
         for i, k in enumerate(graph):
@@ -128,10 +143,12 @@ def _worker(rank, world, port, name, seed, max_sweeps, out_dir):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize('engine_kind', ['stand-in', 'emulated-engine'])
 @pytest.mark.parametrize('name,seed,max_sweeps', [('tiny_mobile', 0, 5), ('tiny_mobile', 0, None), ('tiny_res', 0, 3)])
-def test_sharded_equalization_two_ranks(tmp_path, name, seed, max_sweeps):
+def test_sharded_equalization_two_ranks(tmp_path, emu_lib_path, name, seed, max_sweeps, engine_kind):
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), name, seed, max_sweeps, str(tmp_path)), nprocs=world, join=True)
+    emu = emu_lib_path if engine_kind == 'emulated-engine' else None
+    mp.spawn(_worker, args=(world, _free_port(), name, seed, max_sweeps, str(tmp_path), emu), nprocs=world, join=True)
     # single-process result of the same algorithm
     model, graph, bottoms, spec = _prepare(name, seed)
     orels = orc.create_relation(spec)
