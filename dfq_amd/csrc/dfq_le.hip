@@ -228,6 +228,20 @@ __device__ __forceinline__ float abs_diff_if(bool on, float a, float b) {
     return __uint_as_float(__float_as_uint(d) & 0x7fffffffu);
 }
 
+// sum_k |a[k] - b[k]| of one register slot in float64, or 0 when the slot is a clamped duplicate (`on` false).
+// One select per slot on the float64 sum; the magnitude is taken on the float32 difference by clearing the sign bit
+// (see abs_diff_if for why not fabs()).
+template <int VEC>
+__device__ __forceinline__ double slot_abs_diff(bool on, const float (&a)[VEC], const float (&b)[VEC]) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+        const float d = a[k] - b[k];
+        t += (double)__uint_as_float(__float_as_uint(d) & 0x7fffffffu);
+    }
+    return on ? t : 0.0;
+}
+
 template <int VEC>
 __device__ __forceinline__ void vload(const gfloat* p, float (&x)[VEC]) {
     if (kAblate & 8) {
@@ -377,16 +391,24 @@ __device__ __forceinline__ double row_tile(const LeRelDev& R, const LeParams& p,
         const bool ok = u < n_own;
         const float s = sh_s[r];
         const int g = emit ? sh_g[r] : 0;                  // slot row of this row's group
+        // 1/s of the previous relation for this row's columns: all reads issued before the first use (a
+        // conditional read per element made the compiler wait for every LDS round trip separately); 1.0f when
+        // the layer is not interior -- multiplying by one is exact
+        float pin[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) pin[k] = 1.0f;
+        if (fused) {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) pin[k] = sh_pinv[g + ci[k]];
+        }
         float nv[VEC];
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
-            float t = v[u][k];
-            if (fused) t = t * sh_pinv[g + ci[k]];          // dfq.py:73 of the previous relation (rounded), then
+            const float t = v[u][k] * pin[k];               // dfq.py:73 of the previous relation (rounded), then
             nv[k] = t * s;                                  // dfq.py:62 of this one
         }
         if (ok) vstore<VEC>(w + r * R.row_len, nv);
-#pragma unroll
-        for (int k = 0; k < VEC; ++k) if (!(kAblate & 2)) acc += (double)abs_diff_if(ok, nv[k], v[u][k]);
+        if (!(kAblate & 2)) acc += slot_abs_diff<VEC>(ok, nv, v[u]);
         if (emit && ok) {
             if (g != cur_g) {
                 if (cur_g >= 0) {
@@ -400,7 +422,7 @@ __device__ __forceinline__ double row_tile(const LeRelDev& R, const LeParams& p,
                 cur_g = g;
             }
 #pragma unroll
-            for (int k = 0; k < VEC; ++k) { cmn[k] = fminf(cmn[k], nv[k]); cmx[k] = fmaxf(cmx[k], nv[k]); }
+            for (int k = 0; k < VEC; ++k) { cmn[k] = vmin_raw(cmn[k], nv[k]); cmx[k] = vmax_raw(cmx[k], nv[k]); }
         }
     }
     if (emit && cur_g >= 0) {
@@ -516,18 +538,17 @@ __device__ __forceinline__ double col_tile(const LeRelDev& R, const LeParams& p,
         for (int k = 0; k < VEC; ++k) nv[k] = v[u][k] * sh_inv[t0 + ci[k]];      // dfq.py:73
         if (!stat_only) {
             if (ok) vstore<VEC>(w + r * row_len2, nv);
-#pragma unroll
-            for (int k = 0; k < VEC; ++k) if (!(kAblate & 2)) acc += (double)abs_diff_if(ok, nv[k], v[u][k]);
+            if (!(kAblate & 2)) acc += slot_abs_diff<VEC>(ok, nv, v[u]);
         }
         if (emit) {                                        // block-uniform: every lane reaches the shuffles
             float rmn = INFINITY, rmx = -INFINITY;
             if (ok) {
 #pragma unroll
-                for (int k = 0; k < VEC; ++k) { rmn = fminf(rmn, nv[k]); rmx = fmaxf(rmx, nv[k]); }
+                for (int k = 0; k < VEC; ++k) { rmn = vmin_raw(rmn, nv[k]); rmx = vmax_raw(rmx, nv[k]); }
             }
             for (int m = G >> 1; m >= 1; m >>= 1) {
-                rmn = fminf(rmn, __shfl_xor(rmn, m));
-                rmx = fmaxf(rmx, __shfl_xor(rmx, m));
+                rmn = vmin_raw(rmn, __shfl_xor(rmn, m));
+                rmx = vmax_raw(rmx, __shfl_xor(rmx, m));
             }
             if (ln == 0 && r_raw < nr) {                   // one writer per row of the tile
                 sh_row[2 * r + 0] = ~enc_ord(rmn);
@@ -613,8 +634,8 @@ __device__ __forceinline__ double short_tile(const LeRelDev& R, const LeParams& 
                 if (ok && in) w[k0 + k] = nv;
                 acc += (double)abs_diff_if(ok && in, nv, x[k]);
             }
-            rmn = fminf(rmn, nv);                                  // clamped duplicates of the last tap are harmless
-            rmx = fmaxf(rmx, nv);
+            rmn = vmin_raw(rmn, nv);                               // clamped duplicates of the last tap are harmless
+            rmx = vmax_raw(rmx, nv);
         }
     }
     if (ok) {
