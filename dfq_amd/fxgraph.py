@@ -70,6 +70,11 @@ def trace(model, key_style='name'):
     key_style 'name' keys module nodes as '<ClassName>_<index>' strings; 'module' keys them by
     the module object itself (any hashable works for the calibration passes).
     """
+    graph, bottoms, _, _ = _trace(model, key_style)
+    return graph, bottoms
+
+
+def _trace(model, key_style='name'):
     tracer = _LeafTracer()
     fx_graph = tracer.trace(model)
     modules = dict(model.named_modules())
@@ -130,4 +135,59 @@ def trace(model, key_style='name'):
         bottoms[key] = bots
         alias[n] = key
         counter += 1
-    return graph, bottoms
+    return graph, bottoms, fx_graph, alias
+
+
+def quantize_tensor_ops(model, ops=('add', 'cat', 'mean'), num_bits=8, momentum=0.1, key_style='name'):
+    """Activation quantisers on the inputs of tensor ops -- what the reference's ``switch_layers(quant_op=True)``
+    + ``replace_op`` achieve by monkey-patching ``torch.Tensor.__add__`` / ``torch.cat`` / ``torch.mean`` and
+    routing their inputs through a ``CustomTensorOP`` container (layer_transform.py:16-228) -- done as a torch.fx
+    rewrite: one ``QuantMeasure`` per tensor input of every add / cat node (one for mean) is inserted in front
+    of the op.
+
+    Returns ``(quantised GraphModule, graph, bottoms, tensor_op_quant)``.  ``graph`` / ``bottoms`` are those of
+    ``trace(model)`` (the quantisers live on the edges, they are no graph nodes, as in the reference);
+    ``tensor_op_quant`` maps the graph key of each rewritten op to its quantisers in input order and is what
+    ``set_quant_minmax(..., tensor_op_quant=...)`` fills.  The GraphModule shares all layers with ``model``.
+    """
+    from .utils.quantize import QuantMeasure
+    graph, bottoms, fx_graph, alias = _trace(model, key_style)
+    holder = nn.ModuleList()
+    tensor_op_quant = OrderedDict()
+    root = model
+    if hasattr(root, 'tensor_op_quant'):
+        raise ValueError('model already has a tensor_op_quant container')
+    root.add_module('tensor_op_quant', holder)
+    for n in list(fx_graph.nodes):
+        key = alias.get(n)
+        if n.op not in ('call_function', 'call_method') or not isinstance(key, str) or graph.get(key) != key:
+            continue
+        if not any(tag in key for tag in ops):
+            continue
+        ins = [i for i in _tensor_inputs(n) if i in alias]
+        if 'mean' in key:
+            ins = ins[:1]
+        quants = []
+        replaced = {}
+        for inp in ins:
+            if inp in replaced:                 # x + x: one quantiser per distinct edge
+                continue
+            qm = QuantMeasure(num_bits=num_bits, momentum=momentum)
+            holder.append(qm)
+            with fx_graph.inserting_before(n):
+                qn = fx_graph.call_module('tensor_op_quant.{}'.format(len(holder) - 1), (inp,))
+            replaced[inp] = qn
+            quants.append(qm)
+
+        def swap(a):
+            if isinstance(a, torch.fx.Node):
+                return replaced.get(a, a)
+            if isinstance(a, (list, tuple)):
+                return type(a)(swap(x) for x in a)
+            return a
+        n.args = tuple(swap(a) for a in n.args)
+        n.kwargs = {k: swap(v) for k, v in n.kwargs.items()}
+        tensor_op_quant[key] = quants
+    fx_graph.lint()
+    gm = torch.fx.GraphModule(root, fx_graph)
+    return gm, graph, bottoms, tensor_op_quant

@@ -724,70 +724,32 @@ def _clamped_range(bias, weight, n, relu):
     return lo, hi
 
 
-def set_quant_minmax(spec, is_detection=False, N=6):
-    """Returns OrderedDict targ key -> (running_min, running_max) in graph order."""
+def set_quant_minmax(spec, is_detection=False, N=6, tensor_ops=None):
+    """Returns OrderedDict key -> (running_min, running_max) for every layer (its input quantiser) and, for the
+    tensor-op nodes listed in ``tensor_ops`` ({key: number of quantisers = inputs of the op}, the quantisers
+    the reference keeps in its CustomTensorOP container, layer_transform.py:186-228), key -> [(min, max), ...]."""
     EPS = 1e-6
+    tensor_ops = tensor_ops or {}
     bn_seen = OrderedDict()
     relu_attached = {}
     out = OrderedDict()
-    for key in spec.order:
-        bot = spec.bottoms[key]
-        if bot is None:
-            continue
-        node = spec.nodes[key]
-        if node.kind == 'bn':
-            bn_seen[key] = node
-            relu_attached[key] = 'none'
-            continue
-        if node.kind == 'relu':
-            relu_attached[bot[0]] = 'relu'
-        elif node.kind == 'relu6':
-            relu_attached[bot[0]] = 'relu6'
-        if node.kind != 'targ':            # only layers carry a quant module in this restatement
-            continue
-        if len(bot) == 1 and bot[0] == 'Data':
-            out[key] = (-1.0, 1.0) if is_detection else (-2.11790393, 2.64)
-            continue
-        bn_list, relu_list, connect_list, no_bn = find_prev_bn_full(spec, bn_seen, relu_attached, list(bot))
-        if len(bn_list) == 1:              # 1 to 1 mapping
-            bn_key, bid = bn_list[0]
-            bias = spec.nodes[bn_key].fake_bias.reshape(-1)
-            weight = spec.nodes[bn_key].fake_weight.reshape(-1)
-            if bid[0] in no_bn:             # case (d): a conv/linear between the BN and this layer
-                lay = spec.nodes[no_bn[bid[0]]]
-                wsum = lay.weight.reshape(lay.weight.shape[0], lay.weight.shape[1], -1).astype(np.float64).sum(-1)
-                G = lay.groups
-                O, Ig = wsum.shape
-                go = O // G
 
-                def through(v):
-                    v64 = v.astype(np.float64).reshape(G, Ig)
-                    r = np.einsum('goi,gi->go', wsum.reshape(G, go, Ig), v64).reshape(-1)
-                    return (r + lay.bias.astype(np.float64)).astype(F32)
-                lo, hi = bn_value_range(through(bias), through(weight), N)
-            else:
-                lo, hi = _clamped_range(bias, weight, N, relu_list[0])
-            out[key] = (lo, hi)
-            continue
-        # 1 to many: every entry hangs off bottom 0 of this layer
-        branches = OrderedDict()
-        for ent, relu, ctype in zip(bn_list, relu_list, connect_list):
-            branches.setdefault(ent[1][0], []).append((ent, relu, ctype))
-        assert len(branches) == 1, 'Error occurs when setting min/max, should be 1 to many'
-        lst = sorted(list(branches.values())[0], key=lambda x: len(x[0][1]), reverse=True)
+    def moments(w, b, relu):
+        if relu == 'relu':
+            return moments_relu(w, b)
+        if relu == 'relu6':
+            return moments_relu6(w, b)
+        return b.copy(), (w * w).astype(F32)
+
+    def branch_result(lst):
+        """One branch (all entries hang off the same bottom): layer_transform.py:485-566."""
+        lst = sorted(lst, key=lambda x: len(x[0][1]), reverse=True)
         (bn_key, bid), use_relu, connect_type = lst.pop(0)
         depth = len(bid)
         bias = spec.nodes[bn_key].fake_bias.copy()
         weight = spec.nodes[bn_key].fake_weight.copy()
         mean = var = None
         value_min = value_max = None
-
-        def moments(w, b, relu):
-            if relu == 'relu':
-                return moments_relu(w, b)
-            if relu == 'relu6':
-                return moments_relu6(w, b)
-            return b.copy(), (w * w).astype(F32)
         if 'add' in connect_type:
             mean, var = moments(weight, bias, use_relu)
         else:
@@ -826,8 +788,65 @@ def set_quant_minmax(spec, is_detection=False, N=6):
                 value_max /= (bound + 1)
         if 'add' in connect_type:
             sd = np.sqrt((var + F32(EPS)).astype(F32)).astype(F32)
-            value_min, value_max = bn_value_range(mean, sd, N)
-        out[key] = (value_min, value_max)
+            return bn_value_range(mean, sd, N)
+        return value_min, value_max
+
+    for key in spec.order:
+        bot = spec.bottoms[key]
+        if bot is None:
+            continue
+        node = spec.nodes[key]
+        if node.kind == 'bn':
+            bn_seen[key] = node
+            relu_attached[key] = 'none'
+            continue
+        if node.kind == 'relu':
+            relu_attached[bot[0]] = 'relu'
+        elif node.kind == 'relu6':
+            relu_attached[bot[0]] = 'relu6'
+        if node.kind == 'targ':
+            n_q = 1
+        elif node.kind == 'op' and key in tensor_ops:
+            n_q = int(tensor_ops[key])
+        else:
+            continue
+        if len(bot) == 1 and bot[0] == 'Data':
+            res = [(-1.0, 1.0) if is_detection else (-2.11790393, 2.64)]
+        else:
+            bn_list, relu_list, connect_list, no_bn = find_prev_bn_full(spec, bn_seen, relu_attached, list(bot))
+            if n_q == len(bn_list):             # 1 to 1 mapping, quantiser i <- BN i
+                res = []
+                for (bn_key, bid), relu in zip(bn_list, relu_list):
+                    bias = spec.nodes[bn_key].fake_bias.reshape(-1)
+                    weight = spec.nodes[bn_key].fake_weight.reshape(-1)
+                    if bid[0] in no_bn:         # case (d): a conv/linear between the BN and this node
+                        lay = spec.nodes[no_bn[bid[0]]]
+                        wsum = lay.weight.reshape(lay.weight.shape[0], lay.weight.shape[1], -1).astype(np.float64).sum(-1)
+                        G = lay.groups
+                        O, Ig = wsum.shape
+                        go = O // G
+
+                        def through(v):
+                            v64 = v.astype(np.float64).reshape(G, Ig)
+                            r = np.einsum('goi,gi->go', wsum.reshape(G, go, Ig), v64).reshape(-1)
+                            return (r + lay.bias.astype(np.float64)).astype(F32)
+                        res.append(bn_value_range(through(bias), through(weight), N))
+                    else:
+                        res.append(_clamped_range(bias, weight, N, relu))
+            else:
+                branches = OrderedDict()
+                for ent, relu, ctype in zip(bn_list, relu_list, connect_list):
+                    branches.setdefault(ent[1][0], []).append((ent, relu, ctype))
+                per_branch = OrderedDict((b, branch_result(items)) for b, items in branches.items())
+                if n_q == 1 and n_q < len(bn_list):                 # 1 to many
+                    assert len(per_branch) == 1, 'Error occurs when setting min/max, should be 1 to many'
+                    res = [list(per_branch.values())[0]]
+                elif n_q < len(bn_list):                            # many to many
+                    assert len(per_branch) == n_q, 'LENGTH NOT EQUAL {} vs {}'.format(len(per_branch), n_q)
+                    res = [per_branch[str(i)] for i in range(n_q)]
+                else:
+                    raise AssertionError('Unknown error occured while setting min/max')
+        out[key] = res[0] if node.kind == 'targ' else res
     return out
 
 

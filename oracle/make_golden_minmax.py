@@ -69,40 +69,73 @@ def q_graph(graph):
     return out
 
 
-def run(name, seed, keep_relu6=False, is_detection=False, N=6):
+def tensor_op_nodes(graph, bottoms):
+    """{key: number of quantisers} for the tensor ops the reference quantises (layer_transform.py:10-14):
+    one quantiser per input of an add / cat, one for the input of torch.mean."""
+    out = OrderedDict()
+    for k, m in graph.items():
+        if isinstance(m, str) and k != 'Data':
+            if 'add' in k or 'cat' in k:
+                out[k] = len(bottoms[k])
+            elif 'mean' in k:
+                out[k] = 1
+    return out
+
+
+def run(name, seed, keep_relu6=False, is_detection=False, N=6, tensor_ops=False):
     model, graph, bottoms = synthetic.build(name, seed=seed, keep_relu6=keep_relu6)
     ref_lt.merge_batchnorm(model, graph, bottoms, TARG)
     spec = graphspec.from_torch(graph, bottoms, TARG)
     gq = q_graph(graph)
-    ref_lt.module_tensor_op = _NoTensorOps()
+    ops = tensor_op_nodes(graph, bottoms) if tensor_ops else OrderedDict()
+    if ops:
+        # the reference's own container (layer_transform.py:186-228) with the names switch_layers would give it:
+        # (graph name of the op, '<op>_<line>_<number of quantisers>'), in graph order
+        op_quant = [ref_q.QuantMeasure(num_bits=8, momentum=0.1) for k in ops for _ in range(ops[k])]
+        names = [(k, 'op_{}_{}'.format(i, ops[k])) for i, k in enumerate(ops)]
+        ref_lt.module_tensor_op = ref_lt.CustomTensorOP(op_quant, names)
+    else:
+        ref_lt.module_tensor_op = _NoTensorOps()
     ref_lt.set_quant_minmax(gq, bottoms, is_detection=is_detection, N=N, verbose=False)
     keys = list(graph.keys())
     want = OrderedDict()
+    qi = 0
     for k, m in gq.items():
         if hasattr(m, 'quant') and bottoms[k] is not None:
             want[k] = (float(m.quant.running_min), float(m.quant.running_max))
-    got = orc.set_quant_minmax(spec, is_detection=is_detection, N=N)
+        elif k in ops:
+            want[k] = [(float(op_quant[qi + j].running_min), float(op_quant[qi + j].running_max)) for j in range(ops[k])]
+            qi += ops[k]
+    got = orc.set_quant_minmax(spec, is_detection=is_detection, N=N, tensor_ops=ops)
     assert list(got.keys()) == list(want.keys()), (list(got.keys()), list(want.keys()))
     worst = 0.0
+    flat_want = []
     for k in want:
-        for a, b in zip(got[k], want[k]):
-            err = abs(a - b) / max(1.0, abs(b))
-            worst = max(worst, err)
-            assert err <= 1e-5, '{} {}: oracle {} reference {}'.format(name, k, got[k], want[k])
+        pairs_g = got[k] if isinstance(want[k], list) else [got[k]]
+        pairs_w = want[k] if isinstance(want[k], list) else [want[k]]
+        assert len(pairs_g) == len(pairs_w)
+        for pg, pw in zip(pairs_g, pairs_w):
+            flat_want.append(pw)
+            for a, b in zip(pg, pw):
+                err = abs(a - b) / max(1.0, abs(b))
+                worst = max(worst, err)
+                assert err <= 1e-5, '{} {}: oracle {} reference {}'.format(name, k, got[k], want[k])
     out = {'cfg': np.array([int(keep_relu6), int(is_detection), N]),
-           'ranges': np.array([want[k] for k in want], dtype=np.float64),
-           'layers': np.array([keys.index(k) for k in want])}
+           'ranges': np.array(flat_want, dtype=np.float64),
+           'layers': np.array([keys.index(k) for k in want]),
+           'counts': np.array([len(want[k]) if isinstance(want[k], list) else 0 for k in want])}   # 0: a layer, n: a tensor op
     for i, k in enumerate(spec.order):
         n = spec.nodes[k]
         if n.kind == 'bn':
             out['bn{}'.format(i)] = np.stack([n.fake_weight, n.fake_bias])
-        elif n.kind == 'targ':
+        elif n.kind == 'targ' and name == 'tiny_head':       # only case (d) reads weights; keep the fixtures small
             out['w{}'.format(i)] = n.weight
             if n.bias is not None:
                 out['b{}'.format(i)] = n.bias
-    tag = 'minmax_{}_s{}{}{}'.format(name, seed, '_relu6' if keep_relu6 else '', '_det' if is_detection else '')
+    tag = 'minmax_{}_s{}{}{}{}'.format(name, seed, '_relu6' if keep_relu6 else '', '_det' if is_detection else '',
+                                       '_ops' if tensor_ops else '')
     np.savez_compressed(os.path.join(GOLD, tag + '.npz'), **out)
-    print('{}: {} layers, oracle vs reference max rel err {:.2e}'.format(tag, len(want), worst))
+    print('{}: {} quantised nodes ({} tensor ops), oracle vs reference max rel err {:.2e}'.format(tag, len(want), len(ops), worst))
 
 
 def main():
@@ -116,6 +149,11 @@ def main():
     run('tiny_wide', 3, keep_relu6=True)
     run('tiny_head', 0)
     run('tiny_head', 4, keep_relu6=True)
+    run('tiny_res', 0, tensor_ops=True)
+    run('tiny_res', 2, keep_relu6=True, tensor_ops=True)
+    run('tiny_mobile', 0, tensor_ops=True)
+    run('tiny_cat', 1, keep_relu6=True, tensor_ops=True)
+    run('resnet18', 0, tensor_ops=True)
 
 
 if __name__ == '__main__':

@@ -27,13 +27,32 @@ CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLD, 'm
 
 
 def _parse(tag):
-    m = re.match(r'minmax_(\w+?)_s(\d+)((?:_relu6)?)((?:_det)?)$', tag)
-    return m.group(1), int(m.group(2)), bool(m.group(3)), bool(m.group(4))
+    m = re.match(r'minmax_(\w+?)_s(\d+)((?:_relu6)?)((?:_det)?)((?:_ops)?)$', tag)
+    return m.group(1), int(m.group(2)), bool(m.group(3)), bool(m.group(4)), bool(m.group(5))
+
+
+def _tensor_ops(graph, bottoms):
+    """{key: quantisers} of the tensor ops the reference quantises: one per input of add / cat, one for mean."""
+    out = OrderedDict()
+    for k, m in graph.items():
+        if isinstance(m, str) and k != 'Data':
+            if 'add' in k or 'cat' in k:
+                out[k] = len(bottoms[k])
+            elif 'mean' in k:
+                out[k] = 1
+    return out
+
+
+def _flat(ranges):
+    out = []
+    for v in ranges.values():
+        out.extend(v if isinstance(v, list) else [v])
+    return out
 
 
 def _load_spec(tag):
     """Topology from the synthetic builder, every number from the fixture (independent of this torch build's RNG)."""
-    name, seed, relu6, det = _parse(tag)
+    name, seed, relu6, det, ops = _parse(tag)
     gold = np.load(os.path.join(GOLD, tag + '.npz'))
     model, graph, bottoms = synthetic.build(name, seed=seed, keep_relu6=relu6)
     spec = graphspec.from_torch(graph, bottoms, TARG)
@@ -41,23 +60,25 @@ def _load_spec(tag):
         n = spec.nodes[k]
         if n.kind == 'bn':
             n.fake_weight, n.fake_bias = gold['bn{}'.format(i)][0].copy(), gold['bn{}'.format(i)][1].copy()
-        elif n.kind == 'targ':
+        elif n.kind == 'targ' and 'w{}'.format(i) in gold.files:      # stored only where case (d) reads them
             n.weight = gold['w{}'.format(i)].copy()
             n.bias = gold['b{}'.format(i)].copy() if 'b{}'.format(i) in gold.files else None
-    return spec, gold, (model, graph, bottoms), det
+    return spec, gold, (model, graph, bottoms), det, (_tensor_ops(graph, bottoms) if ops else None)
 
 
 def test_fixtures_exist():
-    assert len(CASES) >= 9
+    assert len(CASES) >= 14
 
 
 @pytest.mark.parametrize('tag', CASES)
 def test_oracle_matches_reference_fixture(tag):
-    spec, gold, _, det = _load_spec(tag)
-    got = orc.set_quant_minmax(spec, is_detection=det, N=int(gold['cfg'][2]))
+    spec, gold, _, det, ops = _load_spec(tag)
+    got = orc.set_quant_minmax(spec, is_detection=det, N=int(gold['cfg'][2]), tensor_ops=ops)
     keys = list(spec.order)
     assert [keys.index(k) for k in got] == gold['layers'].tolist()
-    for (lo, hi), (rlo, rhi) in zip(got.values(), gold['ranges']):
+    flat = _flat(got)
+    assert len(flat) == len(gold['ranges'])
+    for (lo, hi), (rlo, rhi) in zip(flat, gold['ranges']):
         assert abs(lo - rlo) <= 1e-5 * max(1.0, abs(rlo)) and abs(hi - rhi) <= 1e-5 * max(1.0, abs(rhi))
 
 
@@ -81,9 +102,16 @@ def _q_graph(graph, device):
 
 @pytest.mark.parametrize('tag', CASES)
 def test_engine_matches_oracle(engine, tag):
-    spec, gold, (model, graph, bottoms), det = _load_spec(tag)
+    spec, gold, (model, graph, bottoms), det, ops = _load_spec(tag)
     N = int(gold['cfg'][2])
-    want = orc.set_quant_minmax(spec, is_detection=det, N=N)
+    want = orc.set_quant_minmax(spec, is_detection=det, N=N, tensor_ops=ops)
+    tq = None
+    if ops:         # quantisers on the inputs of add / cat / mean through the torch.fx rewrite
+        from dfq_amd import fxgraph
+        name, seed, relu6, _, _ = _parse(tag)
+        model, graph, bottoms = synthetic.build(name, seed=seed, keep_relu6=relu6)
+        qmodel, graph, bottoms, tq = fxgraph.quantize_tensor_ops(model)
+        assert {k: len(v) for k, v in tq.items()} == dict(ops)
     # the engine's inputs: the fixture's BN proxies / weights written into the torch graph
     model.to(engine.device)
     for i, k in enumerate(graph):
@@ -91,20 +119,33 @@ def test_engine_matches_oracle(engine, tag):
         if type(m) == nn.BatchNorm2d:
             m.register_buffer('fake_weight', torch.from_numpy(gold['bn{}'.format(i)][0].copy()).to(engine.device))
             m.register_buffer('fake_bias', torch.from_numpy(gold['bn{}'.format(i)][1].copy()).to(engine.device))
-        elif type(m) in TARG:
+        elif type(m) in TARG and 'w{}'.format(i) in gold.files:
             m.weight.data.copy_(torch.from_numpy(gold['w{}'.format(i)]))
             if 'b{}'.format(i) in gold.files:
                 if m.bias is None:
                     m.bias = nn.Parameter(torch.zeros(m.weight.shape[0], device=engine.device))
                 m.bias.data.copy_(torch.from_numpy(gold['b{}'.format(i)]))
     gq = _q_graph(graph, engine.device)
-    lt.set_quant_minmax(gq, bottoms, is_detection=det, N=N, verbose=False)
-    got = OrderedDict((k, (float(m.quant.running_min), float(m.quant.running_max)))
-                      for k, m in gq.items() if hasattr(m, 'quant') and bottoms[k] is not None)
+    if tq:
+        for qs in tq.values():
+            for qm in qs:
+                qm.to(engine.device)
+    lt.set_quant_minmax(gq, bottoms, is_detection=det, N=N, verbose=False, tensor_op_quant=tq)
+    got = OrderedDict()
+    for k, m in gq.items():
+        if hasattr(m, 'quant') and bottoms[k] is not None:
+            got[k] = (float(m.quant.running_min), float(m.quant.running_max))
+        elif tq and k in tq:
+            got[k] = [(float(qm.running_min), float(qm.running_max)) for qm in tq[k]]
     assert list(got.keys()) == list(want.keys())
-    for k in want:
-        for a, b in zip(got[k], want[k]):
-            assert abs(a - b) <= 1e-5 * max(1.0, abs(b)), '{} {}: engine {} oracle {}'.format(tag, k, got[k], want[k])
+    for a, b in zip(_flat(got), _flat(want)):
+        for x, y in zip(a, b):
+            assert abs(x - y) <= 1e-5 * max(1.0, abs(y)), '{}: engine {} oracle {}'.format(tag, a, b)
+    if tq and engine.kind == 'gpu' or (tq and 'tiny' in tag):
+        # the rewritten module runs: every add / cat / mean input passes through its quantiser
+        qmodel.to(engine.device).eval()
+        y = qmodel(torch.randn(2, 3, 32, 32, device=engine.device))
+        assert torch.isfinite(y).all()
 
 
 def test_relu_moments_kernels_against_oracle(engine):
@@ -129,14 +170,14 @@ def test_ncnn_calibration_table_matches_oracle(engine, tmp_path):
     """convert_ncnn.py:180-201: weight scales from the whole network's min/max in one launch, activation scales
     from the analytic ranges; string-identical lines (min/max are exact, the arithmetic is Python's)."""
     from dfq_amd import ncnn_table
-    spec, gold, (model, graph, bottoms), det = _load_spec('minmax_tiny_mobile_s0')
+    spec, gold, (model, graph, bottoms), det, _ = _load_spec('minmax_tiny_mobile_s0')
     model.to(engine.device)
     for i, k in enumerate(graph):
         m = graph[k]
         if type(m) == nn.BatchNorm2d:
             m.register_buffer('fake_weight', torch.from_numpy(gold['bn{}'.format(i)][0].copy()).to(engine.device))
             m.register_buffer('fake_bias', torch.from_numpy(gold['bn{}'.format(i)][1].copy()).to(engine.device))
-        elif type(m) in TARG:
+        elif type(m) in TARG and 'w{}'.format(i) in gold.files:
             m.weight.data.copy_(torch.from_numpy(gold['w{}'.format(i)]))
     gq = _q_graph(graph, engine.device)
     lt.set_quant_minmax(gq, bottoms, verbose=False)
