@@ -126,6 +126,8 @@ SIGNATURES = {
     'dfq_absdiff_mean': (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     'dfq_fake_quant_rows': (c_int32, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int32, c_int32,
                                       c_void_p, c_void_p, c_void_p]),
+    'dfq_zeroq_quant_rows': (c_int32, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int32, c_void_p, c_void_p,
+                                       c_void_p]),
     'dfq_grouped_matvec': (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     'dfq_bn_ranges_scratch_bytes': (c_size_t, [c_int32]),
     'dfq_bn_ranges': (c_int32, [POINTER(DfqBnRangeReq), c_int32, c_float, c_void_p, c_void_p, c_void_p]),

@@ -168,6 +168,51 @@ __global__ __launch_bounds__(kBlock) void fake_quant_rows_kernel(const float* __
     }
 }
 
+// ZeroQ's per-output-channel asymmetric weight quantiser (ZeroQ/utils/quantization_utils/quant_utils.py:85-135
+// through quant_modules.py:161-171): float32 tensor arithmetic throughout --
+//   scale = (1 / clamp(max - min, 1e-8)) * (2^k - 1);  zp = round(scale * min) + 2^(k-1);
+//   q = clamp(round(scale * x - zp), -2^(k-1), 2^(k-1) - 1);  y = (q + zp) / scale.
+// One wave per row; the row's own min / max unless given.
+__global__ __launch_bounds__(kBlock) void zeroq_quant_rows_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                  int64_t rows, int64_t row_len,
+                                                                  const float* __restrict__ mins,
+                                                                  const float* __restrict__ maxs, int num_bits,
+                                                                  float* __restrict__ codes,
+                                                                  float* __restrict__ minmax_out) {
+    const int64_t r = (int64_t)blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
+    if (r >= rows) return;
+    const int lane = threadIdx.x % kWave;
+    const float* row = x + r * row_len;
+    float mn, mx;
+    if (mins && maxs) {
+        mn = mins[r];
+        mx = maxs[r];
+    } else {
+        mn = INFINITY; mx = -INFINITY;
+        for (int64_t i = lane; i < row_len; i += kWave) {
+            const float v = row[i];
+            mn = fminf(mn, v);
+            mx = fmaxf(mx, v);
+        }
+        mn = wave_min(mn);
+        mx = wave_max(mx);
+    }
+    if (minmax_out && lane == 0) { minmax_out[2 * r] = mn; minmax_out[2 * r + 1] = mx; }
+    const float n = (float)((1ll << num_bits) - 1);
+    const float half = (float)(1ll << (num_bits - 1));
+    float span = mx - mn;
+    span = (span < 1e-8f) ? 1e-8f : span;            // torch.clamp(min=1e-8): NaN stays NaN
+    const float scale = (1.0f / span) * n;           // `n / tensor` in torch is tensor.reciprocal() * n: two roundings
+    const float zp = rintf(scale * mn) + half;       // .round() is half-to-even
+    for (int64_t i = lane; i < row_len; i += kWave) {
+        float q = rintf(scale * row[i] - zp);
+        q = (q < -half) ? -half : q;                 // torch.clamp propagates NaN
+        q = (q > half - 1.0f) ? half - 1.0f : q;
+        if (codes) codes[r * row_len + i] = q;
+        y[r * row_len + i] = (q + zp) / scale;
+    }
+}
+
 // bias[o] = eps[o, :] . expect[group(o) * I/g : ...]   (dfq.py:281-287), float64 accumulation, one wave per row
 __global__ __launch_bounds__(kBlock) void grouped_matvec_kernel(const float* __restrict__ eps,
                                                                 const float* __restrict__ expect, int32_t out_ch,
@@ -281,6 +326,16 @@ int dfq_fake_quant_rows(const float* x, float* y, int64_t rows, int64_t row_len,
         return fail_arg("dfq_fake_quant_rows: bad argument");
     hipLaunchKernelGGL(fake_quant_rows_kernel, grid_for(rows, kBlock / kWave), dim3(kBlock), 0, as_stream(stream), x, y, rows,
                        row_len, mins, maxs, (int)num_bits, (int)symmetric, codes, minmax_out);
+    DFQ_CHECK_LAUNCH();
+    return DFQ_OK;
+}
+
+int dfq_zeroq_quant_rows(const float* x, float* y, int64_t rows, int64_t row_len, const float* mins, const float* maxs,
+                         int32_t num_bits, float* codes, float* minmax_out, void* stream) {
+    if (!x || !y || rows <= 0 || row_len <= 0 || num_bits < 2 || num_bits > 24 || ((mins == nullptr) != (maxs == nullptr)))
+        return fail_arg("dfq_zeroq_quant_rows: bad argument");
+    hipLaunchKernelGGL(zeroq_quant_rows_kernel, grid_for(rows, kBlock / kWave), dim3(kBlock), 0, as_stream(stream), x, y, rows,
+                       row_len, mins, maxs, (int)num_bits, codes, minmax_out);
     DFQ_CHECK_LAUNCH();
     return DFQ_OK;
 }

@@ -122,6 +122,22 @@ def fake_quant_rows(x, num_bits=8, min_values=None, max_values=None, symmetric=F
         return res
 
 
+def zeroq_quant_rows(x, num_bits=8, min_values=None, max_values=None, return_codes=False):
+    """ZeroQ's per-output-channel asymmetric quantiser (quant_utils.py:85-135 via quant_modules.py:161-171)."""
+    lib = _ffi.lib()
+    with torch.no_grad():
+        stage = _ffi.Stage()
+        xx = stage.bind(x)
+        rows, row_len = xx.shape[0], xx[0].numel()
+        y = stage.new(xx.shape)
+        codes = stage.new(xx.shape) if return_codes else None
+        _ffi.check(lib.dfq_zeroq_quant_rows(_ffi.ptr(xx), _ffi.ptr(y), rows, row_len, _ffi.ptr(stage.bind(min_values)),
+                                            _ffi.ptr(stage.bind(max_values)), int(num_bits), _ffi.ptr(codes), None,
+                                            _ffi.stream_arg()))
+        res = stage.out_like(x, y)
+        return (res, stage.out_like(x, codes)) if return_codes else res
+
+
 def grouped_matvec(eps, expect, groups=1):
     """bias[o] = eps[o, :] . expect[group(o)] (dfq.py:281-287) -> float32 [O]."""
     lib = _ffi.lib()

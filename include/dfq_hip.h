@@ -338,6 +338,12 @@ int dfq_absdiff_mean(const float* w, const float* prev, int64_t n, float* out, v
 int dfq_fake_quant_rows(const float* x, float* y, int64_t rows, int64_t row_len, const float* mins,
                         const float* maxs, int32_t num_bits, int32_t symmetric, float* codes, float* minmax_out,
                         void* stream);
+/* ZeroQ's per-output-channel asymmetric weight quantiser (ZeroQ/utils/quantization_utils/quant_utils.py:85-135 as
+ * used by quant_modules.py:161-171): scale = (1/clamp(max-min, 1e-8)) * (2^k-1) (two roundings, as torch evaluates `n / tensor`), zero point = round(scale*min) + 2^(k-1),
+ * q = clamp(round(scale*x - zp), -2^(k-1), 2^(k-1)-1), y = (q + zp)/scale, all in float32.  Row r uses (mins[r],
+ * maxs[r]) if given, its own min/max otherwise; `codes` (float, signed integers) and `minmax_out` may be NULL. */
+int dfq_zeroq_quant_rows(const float* x, float* y, int64_t rows, int64_t row_len, const float* mins, const float* maxs,
+                         int32_t num_bits, float* codes, float* minmax_out, void* stream);
 /* out[o] = eps[o, :] . expect[(o / (O/groups)) * I/g ...] (dfq.py:281-287), float64 accumulation */
 int dfq_grouped_matvec(const float* eps, const float* expect, int32_t out_ch, int32_t in_per_group,
                        int32_t groups, float* out, void* stream);

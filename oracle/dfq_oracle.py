@@ -902,3 +902,28 @@ def ncnn_table_lines(spec, act_ranges, names=None):
         scale = 128. / (max(abs(ma), abs(mi)))
         lines.append(' '.join([names[len(keys) + i], str(scale)]))
     return lines
+
+
+# --------------------------------------------------------------------------------------------
+# f3  ZeroQ's per-output-channel asymmetric weight quantiser
+#     (ZeroQ/utils/quantization_utils/quant_utils.py:85-135 as called by quant_modules.py:161-171)
+# --------------------------------------------------------------------------------------------
+def zeroq_quant_rows(x, num_bits=8, return_codes=False):
+    """x [O, ...]: per-row min/max, float32 tensor arithmetic in the reference's order."""
+    x = np.asarray(x, dtype=F32)
+    flat = x.reshape(x.shape[0], -1)
+    mn = flat.min(1).astype(F32)
+    mx = flat.max(1).astype(F32)
+    n = F32(2 ** num_bits - 1)
+    half = F32(2 ** (num_bits - 1))
+    with np.errstate(divide='ignore', invalid='ignore', over='ignore'):
+        span = np.maximum((mx - mn).astype(F32), F32(1e-8))
+        # `n / tensor` with a Python int n is Tensor.__rtruediv__ = tensor.reciprocal() * n: two roundings
+        scale = ((F32(1) / span).astype(F32) * n).astype(F32)
+        zp = (np.rint((scale * mn).astype(F32)).astype(F32) + half).astype(F32)
+        q = np.rint(((scale[:, None] * flat).astype(F32) - zp[:, None]).astype(F32)).astype(F32)
+        q = np.clip(q, -half, half - F32(1)).astype(F32)
+        y = ((q + zp[:, None]).astype(F32) / scale[:, None]).astype(F32)
+    if return_codes:
+        return y.reshape(x.shape), q.reshape(x.shape)
+    return y.reshape(x.shape)

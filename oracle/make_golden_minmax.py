@@ -138,8 +138,36 @@ def run(name, seed, keep_relu6=False, is_detection=False, N=6, tensor_ops=False)
     print('{}: {} quantised nodes ({} tensor ops), oracle vs reference max rel err {:.2e}'.format(tag, len(want), len(ops), worst))
 
 
+def kat_zeroq_rows():
+    """ZeroQ's per-channel quantiser: the reference's AsymmetricQuantFunction driven the way its Quant_Conv2d /
+    Quant_Linear do (per-row min / max), on weights of several shapes and bit widths."""
+    import importlib.util
+    spec_ = importlib.util.spec_from_file_location('zeroq_quant_utils',
+                                                   os.path.join(REF, 'ZeroQ', 'utils', 'quantization_utils', 'quant_utils.py'))
+    zq = importlib.util.module_from_spec(spec_)
+    spec_.loader.exec_module(zq)
+    gen = torch.Generator().manual_seed(99)
+    out = {}
+    cases = [((12, 5, 3, 3), 8), ((7, 130), 8), ((16, 1, 5, 5), 4), ((9, 40), 6), ((5, 3, 1, 1), 2)]
+    for i, (shape, bits) in enumerate(cases):
+        w = torch.randn(*shape, generator=gen) * (torch.rand(shape[0], *([1] * (len(shape) - 1)), generator=gen) + 0.05)
+        if i == 1:
+            w[2] = 0.25                                   # constant row: span clamps at 1e-8
+        flat = w.contiguous().view(shape[0], -1)
+        ref = zq.AsymmetricQuantFunction.apply(w, bits, flat.min(dim=1).values, flat.max(dim=1).values)
+        got = orc.zeroq_quant_rows(w.numpy(), bits)
+        same = (np.ascontiguousarray(got).view(np.int32) == ref.numpy().view(np.int32)) | (np.isnan(got) & np.isnan(ref.numpy()))
+        assert same.all(), 'zeroq case {}: {} elements differ'.format(i, int((~same).sum()))
+        out['x{}'.format(i)] = w.numpy()
+        out['y{}'.format(i)] = ref.numpy()
+        out['bits{}'.format(i)] = np.array(bits)
+    np.savez_compressed(os.path.join(GOLD, 'kat_zeroq_rows.npz'), **out)
+    print('kat_zeroq_rows: {} cases, oracle bit-exact with the reference'.format(len(cases)))
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
+    kat_zeroq_rows()
     run('tiny_mobile', 0)
     run('tiny_mobile', 1, keep_relu6=True)
     run('tiny_res', 0)

@@ -110,3 +110,21 @@ def test_grouped_matvec(engine, O, Ig, groups):
     want = np.concatenate([orc._matvec_f32(eps.numpy()[k * step:(k + 1) * step], ex.numpy()[k * Ig:(k + 1) * Ig])
                            for k in range(groups)])
     np.testing.assert_allclose(got, want, rtol=2e-7, atol=0)
+
+
+def test_zeroq_per_channel_quantiser(engine):
+    """ZeroQ's per-output-channel asymmetric quantiser: bit-exact against the reference's outputs (fixture written by
+    oracle/make_golden_minmax.py from the unmodified AsymmetricQuantFunction) and against the oracle incl. codes."""
+    import os
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'kat_zeroq_rows.npz'))
+    i = 0
+    while 'x{}'.format(i) in gold.files:
+        x, bits = gold['x{}'.format(i)], int(gold['bits{}'.format(i)])
+        y, codes = prims.zeroq_quant_rows(engine.to(torch.from_numpy(x.copy())), bits, return_codes=True)
+        assert_bitexact(npy(y), gold['y{}'.format(i)], 'zeroq case {} vs reference'.format(i))
+        oy, oq = orc.zeroq_quant_rows(x, bits, return_codes=True)
+        assert_bitexact(oy, gold['y{}'.format(i)], 'oracle vs reference')
+        assert np.array_equal(npy(codes), oq)
+        assert npy(codes).min() >= -2 ** (bits - 1) and npy(codes).max() <= 2 ** (bits - 1) - 1
+        i += 1
+    assert i >= 5
