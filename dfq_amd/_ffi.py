@@ -134,6 +134,11 @@ SIGNATURES = {
     'dfq_relu_moments': (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_int32, c_void_p]),
     'dfq_moments_after_add': (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_float, c_void_p]),
     'dfq_moment_range': (c_int32, [c_void_p, c_void_p, c_int64, c_float, c_float, c_void_p, c_void_p]),
+    'dfq_bn_stat_loss_scratch_bytes': (c_size_t, [c_int64]),
+    'dfq_bn_stat_loss_forward': (c_int32, [c_void_p, c_int64, c_int64, c_int32, c_void_p, c_void_p, c_float, c_float, c_void_p,
+                                           c_void_p, c_void_p, c_void_p, c_void_p]),
+    'dfq_bn_stat_loss_backward': (c_int32, [c_void_p, c_int64, c_int64, c_int32, c_void_p, c_void_p, c_float, c_float, c_void_p,
+                                            c_void_p, c_float, c_float, c_void_p, c_int32, c_void_p]),
     'dfq_bn_through_layer': (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
 }
 

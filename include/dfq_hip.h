@@ -378,6 +378,22 @@ int dfq_moment_range(const float* mean, const float* var, int64_t n, float eps, 
 int dfq_bn_through_layer(const float* weight, int32_t out_ch, int32_t in_per_group, int32_t khkw, int32_t groups,
                          const float* bias, const float* v_in, float* v_out, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * BatchNorm-statistics loss of ZeroQ's data distillation -- ZeroQ/distill_data.py:170-196 (own_loss :40-45):
+ * for a BN input x [N, C, H, W] (rows = N*C rows of hw = H*W floats, channel of row r = r % C),
+ *   loss2[0] = sum_{n,c} (bn_mean[c] - mean_hw x)^2 / denom,   loss2[1] = sum_{n,c} (bn_std[c] - std_hw(x + eps))^2 / denom
+ * (unbiased std; denom = A.size(0) of own_loss: C for the BN terms, N for the input-batch term of :192-196), one read of x; row_mean / row_std [rows] are kept for the backward pass, which writes (or adds
+ * into) grad_x = grad_mean_loss * d loss2[0]/dx + grad_std_loss * d loss2[1]/dx with one read of x.
+ * `scratch`: dfq_bn_stat_loss_scratch_bytes(rows) bytes.  H*W == 1 is rejected (see the message).
+ * ---------------------------------------------------------------------------------------- */
+size_t dfq_bn_stat_loss_scratch_bytes(int64_t rows);
+int dfq_bn_stat_loss_forward(const float* x, int64_t rows, int64_t hw, int32_t channels, const float* bn_mean,
+                             const float* bn_std, float eps, float denom, float* row_mean, float* row_std, float* loss2,
+                             void* scratch, void* stream);
+int dfq_bn_stat_loss_backward(const float* x, int64_t rows, int64_t hw, int32_t channels, const float* bn_mean,
+                              const float* bn_std, float eps, float denom, const float* row_mean, const float* row_std,
+                              float grad_mean_loss, float grad_std_loss, float* grad_x, int32_t accumulate, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -927,3 +927,27 @@ def zeroq_quant_rows(x, num_bits=8, return_codes=False):
     if return_codes:
         return y.reshape(x.shape), q.reshape(x.shape)
     return y.reshape(x.shape)
+
+
+# --------------------------------------------------------------------------------------------
+# f2  BatchNorm-statistics loss of ZeroQ's distillation (ZeroQ/distill_data.py:40-45, :172-196)
+# --------------------------------------------------------------------------------------------
+def bn_stat_losses(x, bn_mean, bn_std, eps=1e-6, denom=None):
+    """x [N, C, H, W] -> (mean_loss, std_loss, dmean_loss/dx, dstd_loss/dx), evaluated in float64 (the reference
+    computes in float32 with an unspecified reduction order; parity is a 1e-5 contract)."""
+    x64 = np.asarray(x, dtype=F32).astype(np.float64)
+    n, c = x64.shape[:2]
+    flat = x64.reshape(n, c, -1)
+    hw = flat.shape[-1]
+    denom = float(c if denom is None else denom)
+    e = (np.asarray(x, dtype=F32).reshape(n, c, -1) + F32(eps)).astype(F32).astype(np.float64)   # x + eps is rounded in float32
+    mean = flat.mean(-1)
+    me = e.mean(-1)
+    std = np.sqrt(((e - me[..., None]) ** 2).sum(-1) / (hw - 1))
+    bm = np.asarray(bn_mean, dtype=np.float64).reshape(1, c)
+    bs = np.asarray(bn_std, dtype=np.float64).reshape(1, c)
+    mean_loss = ((bm - mean) ** 2).sum() / denom
+    std_loss = ((bs - std) ** 2).sum() / denom
+    g_mean = np.broadcast_to((2.0 * (mean - bm) / (denom * hw))[..., None], flat.shape).reshape(x64.shape)
+    g_std = ((2.0 * (std - bs) / denom)[..., None] * (e - me[..., None]) / ((hw - 1) * std[..., None])).reshape(x64.shape)
+    return float(mean_loss), float(std_loss), g_mean, g_std

@@ -1,0 +1,94 @@
+"""Row f2: the BatchNorm-statistics loss of ZeroQ's data distillation (ZeroQ/distill_data.py:40-45, :172-196).
+
+Three-way check: the HIP kernels (CPU emulation / MI355X) against the float64 oracle AND against the reference's own
+arithmetic -- the torch expressions of distill_data.py:172-190 evaluated with autograd on the CPU."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from dfq_amd import zeroq
+from oracle import dfq_oracle as orc
+from tests.common import npy
+
+
+def _reference_losses(tmp_output, bn_mean, bn_std, eps=1e-6):
+    """distill_data.py:172-190 verbatim in meaning (own_loss :40-45)."""
+    own_loss = lambda A, B: (A - B).norm() ** 2 / A.size(0)
+    tmp_mean = torch.mean(tmp_output.view(tmp_output.size(0), tmp_output.size(1), -1), dim=2)
+    tmp_std = torch.std(tmp_output.view(tmp_output.size(0), tmp_output.size(1), -1) + eps, dim=2)
+    return own_loss(bn_mean, tmp_mean), own_loss(bn_std, tmp_std)
+
+
+@pytest.mark.parametrize('shape', [(2, 3, 7, 7), (4, 16, 14, 14), (1, 5, 40, 40), (3, 2, 1, 2)])
+def test_losses_and_gradients(engine, shape):
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(*shape, generator=g) * 1.5 + 0.3
+    bn_mean = torch.randn(shape[1], generator=g)
+    bn_std = torch.rand(shape[1], generator=g) + 0.5
+    # reference arithmetic with autograd (CPU, float32)
+    xr = x.clone().requires_grad_(True)
+    ml_r, sl_r = _reference_losses(xr, bn_mean, bn_std)
+    (ml_r * 0.7 + sl_r * 1.3).backward()
+    # engine
+    xe = engine.to(x.clone()).requires_grad_(True)
+    ml, sl = zeroq.bn_stat_losses(xe, engine.to(bn_mean), engine.to(bn_std))
+    (ml * 0.7 + sl * 1.3).backward()
+    # oracle (float64)
+    ml_o, sl_o, gm_o, gs_o = orc.bn_stat_losses(x.numpy(), bn_mean.numpy(), bn_std.numpy())
+    for got, ref, ora in ((float(ml.detach()), float(ml_r.detach()), ml_o), (float(sl.detach()), float(sl_r.detach()), sl_o)):
+        assert abs(got - ora) <= 1e-5 * max(1.0, abs(ora))
+        assert abs(got - ref) <= 1e-4 * max(1.0, abs(ref))          # the reference's float32 reductions
+    grad_o = 0.7 * gm_o + 1.3 * gs_o
+    np.testing.assert_allclose(npy(xe.grad), grad_o, rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(npy(xe.grad), xr.grad.numpy(), rtol=2e-3, atol=1e-5)
+
+
+def test_input_batch_term_divides_by_batch(engine):
+    """distill_data.py:192-196: own_loss(tmp_mean [N, 3], input_mean) divides by N, and no eps is added."""
+    g = torch.Generator().manual_seed(5)
+    data = torch.randn(4, 3, 16, 16, generator=g)
+    tmp_mean = torch.mean(data.view(4, 3, -1), dim=2)
+    tmp_std = torch.std(data.view(4, 3, -1), dim=2)
+    own_loss = lambda A, B: (A - B).norm() ** 2 / A.size(0)
+    want = (float(own_loss(tmp_mean, torch.zeros(1, 3))), float(own_loss(tmp_std, torch.ones(1, 3))))
+    ml, sl = zeroq.bn_stat_losses(engine.to(data), engine.to(torch.zeros(3)), engine.to(torch.ones(3)), 0.0, denom=4)
+    assert abs(float(ml) - want[0]) <= 1e-4 * max(1, want[0]) and abs(float(sl) - want[1]) <= 1e-4 * max(1, want[1])
+
+
+def test_single_pixel_maps_are_rejected(engine):
+    from dfq_amd import _ffi
+    with pytest.raises(_ffi.DfqError):
+        zeroq.bn_stat_losses(engine.to(torch.randn(2, 4, 1, 1)), engine.to(torch.zeros(4)), engine.to(torch.ones(4)))
+
+
+def test_distillation_loop_reduces_the_loss(engine):
+    """getDistilData (distill_data.py:75-227) on a small conv net: the statistics loss of the distilled batch is far
+    below that of the noise it started from."""
+    torch.manual_seed(0)
+    net = nn.Sequential(nn.Conv2d(3, 8, 3, padding=1), nn.BatchNorm2d(8), nn.ReLU(), nn.Conv2d(8, 8, 3, padding=1, stride=2),
+                        nn.BatchNorm2d(8), nn.ReLU()).to(engine.device).eval()
+    for m in net.modules():
+        if isinstance(m, nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.5)
+            m.running_var.uniform_(0.5, 1.5)
+    gen = torch.Generator().manual_seed(1)
+
+    def total_loss(batch):
+        hooks = []
+        acc = [0.0]
+        def mk(m):
+            def hook(mod, inp, out):
+                a, b = zeroq.bn_stat_losses(inp[0], mod.running_mean, torch.sqrt(mod.running_var + 1e-6))
+                acc[0] += float(a) + float(b)
+            return m.register_forward_hook(hook)
+        hs = [mk(m) for m in net.modules() if isinstance(m, nn.BatchNorm2d)]
+        with torch.no_grad():
+            net(batch)
+        for h in hs:
+            h.remove()
+        return acc[0]
+    start = ((torch.rand(4, 3, 16, 16, generator=torch.Generator().manual_seed(1)) * 2 - 1) * 3.).to(engine.device)
+    out = zeroq.getDistilData(net, (4, 3, 16, 16), num_batch=1, iterations=60, generator=gen, early_break_factor=0.0)
+    assert len(out) == 1 and out[0].shape == (4, 3, 16, 16)
+    assert total_loss(out[0]) < 0.7 * total_loss(start)          # (the default early break stops at loss <= #BN + 1)
