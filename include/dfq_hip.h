@@ -124,7 +124,8 @@ int64_t dfq_le_plan_ro_elements(const dfq_le_plan* plan);
 /* the same two counts for one launch level; returns the number of relations in it */
 int32_t dfq_le_plan_level_launches(const dfq_le_plan* plan, int32_t level, int64_t* rw_elems,
                                    int64_t* ro_elems, int32_t* n_workgroups);
-/* launch geometry of a level: grid_x = tiles of its largest relation, grid_y = relations */
+/* launch geometry of a level.  Single-network plan: grid_x = tiles of its largest relation, grid_y = relations
+ * (descriptors in the kernarg).  Batched plan: grid_x = working workgroups, grid_y = 1 (workgroup table). */
 int dfq_le_plan_level_grid(const dfq_le_plan* plan, int32_t level, int32_t* grid_x, int32_t* grid_y);
 
 /* Enqueue exactly `n_sweeps` sweeps plus their convergence bookkeeping on `stream`; never

@@ -29,6 +29,15 @@ from common import (GOLD, NET_FIXTURES, TARG, F32, assert_bitexact, assert_close
 # ---------------------------------------------------------------------------------------------
 # fake-quant (a4)
 # ---------------------------------------------------------------------------------------------
+class Engine_cpu:
+    """stand-in for the `engine` fixture's object when the caller's tensors must stay on the host"""
+    kind = 'host'
+    device = torch.device('cpu')
+
+    def to(self, t):
+        return t
+
+
 def test_fake_quant_known_answers(engine):
     g = np.load(os.path.join(GOLD, 'kat_fake_quant.npz'))
     for i, (nbits, sym, mn, mx) in enumerate(g['cases']):
@@ -443,6 +452,32 @@ def test_geometry_corner_cases_against_oracle(engine):
     osnap, esnap = _spec_snapshot(spec), snapshot(graph)
     for k in osnap:
         assert_close(esnap[k], osnap[k], 'tiny_wide BC {}'.format(k))
+
+
+def test_host_resident_model_is_staged_and_written_back(engine):
+    """The reference's default flow keeps the model on the CPU: the package shadows every tensor on the device,
+    runs the passes there and writes the results back into the caller's CPU tensors (same objects)."""
+    gold = net_fixture('tiny_mobile', 0, '')
+    model, graph, bottoms = _build('tiny_mobile', 0, gold, Engine_cpu())
+    spec = graphspec.from_torch(graph, bottoms, TARG)
+    ids = {k: id(m.weight) for k, m in graph.items() if type(m) in TARG}
+    lt.merge_batchnorm(model, graph, bottoms, TARG)
+    orc.merge_batchnorm(spec)
+    rels = rel.create_relation(graph, bottoms, TARG)
+    dfq.cross_layer_equalization(graph, rels, TARG)
+    n_o, S_o = orc.cross_layer_equalization(spec, orc.create_relation(spec))
+    assert dfq.last_equalization['sweeps'] == n_o
+    dfq.bias_correction(graph, bottoms, TARG)
+    orc.bias_correction(spec)
+    osnap, esnap = _spec_snapshot(spec), snapshot(graph)
+    for k in osnap:
+        assert_close(esnap[k], osnap[k], 'host-resident {}'.format(k))
+    for k, m in graph.items():
+        if type(m) in TARG:
+            assert m.weight.device.type == 'cpu' and id(m.weight) == ids[k]
+    for r, s in zip(rels, S_o):
+        assert r.get_scale_vec().device.type == 'cpu'
+        assert_bitexact(npy(r.get_scale_vec()), s)
 
 
 @pytest.mark.gpu
