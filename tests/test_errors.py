@@ -1,0 +1,62 @@
+"""Error behaviour of the C ABI (INTEGRATION.md "Error behaviour"): every entry point returns a negative code and leaves a
+message in dfq_last_error(); geometry the reference would mis-handle silently is rejected; nothing aborts."""
+import ctypes
+
+import pytest
+import torch
+
+from dfq_amd import _ffi, dfq, prims
+
+
+def _w(engine, *shape):
+    return engine.to(torch.randn(*shape))
+
+
+def test_null_and_empty_arguments(engine):
+    lib = _ffi.lib()
+    plan = ctypes.c_void_p()
+    assert lib.dfq_le_plan_create(None, 0, None, 0, ctypes.byref(plan)) == -1          # DFQ_ERR_ARG
+    assert b'dfq_le_plan_create' in lib.dfq_last_error()
+    assert lib.dfq_tensor_minmax(None, 0, None, None, None) < 0
+    assert lib.dfq_row_range(None, 4, 4, 0, None, None) == -1
+    with pytest.raises(_ffi.DfqError, match='dfq_fake_quant_rows'):
+        _ffi.check(lib.dfq_fake_quant_rows(None, None, 0, 0, None, None, 8, 0, None, None, None))
+
+
+def test_relation_geometry_is_validated(engine):
+    w1, w2, w3 = _w(engine, 8, 4, 1, 1), _w(engine, 6, 8, 1, 1), _w(engine, 5, 7, 1, 1)
+    ones = lambda n: torch.ones(n, device=engine.device)
+    # O1 = 8 does not pair with I2/g = 7
+    with pytest.raises(_ffi.DfqError, match='unsupported pairing'):
+        dfq.LEPlan([(w1, None, 1), (w3, None, 1)], [(0, 1, None, None, ones(8))])
+    # a layer may be "first" in one relation only (utils/relation.py:57-67)
+    with pytest.raises(_ffi.DfqError, match='first in one relation'):
+        dfq.LEPlan([(w1, None, 1), (w2, None, 1), (_w(engine, 3, 8, 1, 1), None, 1)],
+                   [(0, 1, None, None, ones(8)), (0, 2, None, None, ones(8))])
+    # bad layer index
+    with pytest.raises(_ffi.DfqError, match='bad layer indices'):
+        dfq.LEPlan([(w1, None, 1), (w2, None, 1)], [(0, 5, None, None, ones(8))])
+    # a relation may not pair layers of two networks of a batch
+    with pytest.raises(_ffi.DfqError, match='two networks'):
+        dfq.LEPlan([(w1, None, 1), (w2, None, 1)], [(0, 1, None, None, ones(8))], layer_net=[0, 1])
+    # and after all that the library still works
+    plan = dfq.LEPlan([(w1, None, 1), (w2, None, 1)], [(0, 1, None, None, ones(8))])
+    assert plan.run(max_sweeps=2)['sweeps'] == 2
+
+
+def test_le_pair_rejects_bad_pairing(engine):
+    with pytest.raises(_ffi.DfqError, match='unsupported pairing'):
+        prims.le_pair(_w(engine, 8, 4), _w(engine, 6, 7), None)
+
+
+def test_bias_correction_plan_validation(engine):
+    lib = _ffi.lib()
+    w = _w(engine, 4, 3, 1, 1)
+    b = torch.zeros(4, device=engine.device)
+    fw, fb = torch.ones(5, device=engine.device), torch.zeros(5, device=engine.device)      # 5 channels for I = 3
+    layers = (_ffi.DfqLayer * 1)(_ffi.DfqLayer(w.data_ptr(), b.data_ptr(), 4, 3, 1, 1))
+    sources = (_ffi.DfqBcSource * 1)(_ffi.DfqBcSource(fw.data_ptr(), fb.data_ptr(), 5, 1, 0))
+    steps = (_ffi.DfqBcStep * 1)(_ffi.DfqBcStep(0, 0, 1, None, 0, 0))
+    plan = ctypes.c_void_p()
+    assert lib.dfq_bc_plan_create(layers, 1, steps, 1, sources, 1, ctypes.byref(plan)) == -1
+    assert b'expectation length' in lib.dfq_last_error()
