@@ -24,10 +24,23 @@ __device__ __forceinline__ void thread_minmax_range(const float* __restrict__ x,
     if ((reinterpret_cast<uintptr_t>(p) & 15u) == 0) {
         const int64_t n4 = len >> 2;
         const float4* p4 = reinterpret_cast<const float4*>(p);
-        for (int64_t i = tid; i < n4; i += kBlock) {
+        // four independent 16-byte loads per trip (a read-only pass with one load in flight per lane leaves most of
+        // the memory pipeline idle), raw v_min / v_max (no canonicalisation prologue)
+        int64_t i = tid;
+        for (; i + 3 * kBlock < n4; i += 4 * kBlock) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = p4[i + u * kBlock];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                mn = vmin_raw(vmin_raw(mn, v[u].x), vmin_raw(v[u].y, vmin_raw(v[u].z, v[u].w)));
+                mx = vmax_raw(vmax_raw(mx, v[u].x), vmax_raw(v[u].y, vmax_raw(v[u].z, v[u].w)));
+            }
+        }
+        for (; i < n4; i += kBlock) {
             const float4 v = p4[i];
-            mn = fminf(fminf(mn, v.x), fminf(v.y, fminf(v.z, v.w)));
-            mx = fmaxf(fmaxf(mx, v.x), fmaxf(v.y, fmaxf(v.z, v.w)));
+            mn = vmin_raw(vmin_raw(mn, v.x), vmin_raw(v.y, vmin_raw(v.z, v.w)));
+            mx = vmax_raw(vmax_raw(mx, v.x), vmax_raw(v.y, vmax_raw(v.z, v.w)));
         }
         for (int64_t i = (n4 << 2) + tid; i < len; i += kBlock) {
             const float v = p[i];
@@ -161,6 +174,23 @@ __global__ __launch_bounds__(kBlock) void fake_quant_kernel(const float* x, floa
     if (range_mode == 1) p = qparams_double((double)minmax_dev[0], (double)minmax_dev[1], num_bits, symmetric);
     else if (range_mode == 2) p = qparams_float(minmax_dev[0], minmax_dev[1], num_bits, symmetric);
     const int64_t stride = (int64_t)gridDim.x * kBlock;
+    if (!codes && ((((uintptr_t)x) | ((uintptr_t)y)) & 15u) == 0) {
+        // 16-byte vectors over the body (in place or out of place: every element is read before it is written)
+        const int64_t n4 = n >> 2;
+        for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += stride) {
+            const fvec4 v = *(const fvec4*)(x + 4 * i);
+            fvec4 r;
+            float code;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) r[k] = fake_quant_one(v[k], p, &code);
+            *(fvec4*)(y + 4 * i) = r;
+        }
+        for (int64_t i = 4 * n4 + (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+            float code;
+            y[i] = fake_quant_one(x[i], p, &code);
+        }
+        return;
+    }
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
         float code;
         const float v = fake_quant_one(x[i], p, &code);

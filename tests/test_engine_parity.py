@@ -61,6 +61,19 @@ def test_fake_quant_codes_vs_oracle(engine, n, nbits, sym):
     assert np.array_equal(c.cpu().numpy(), c_o.astype(np.int32)), 'integer codes differ'
 
 
+def test_fake_quant_unaligned_views(engine):
+    """Pointers that are not 16-byte aligned (a view starting at element 1 / 3) take the scalar path; results must not
+    depend on the path."""
+    rng = np.random.default_rng(21)
+    x = rng.standard_normal(5003).astype(F32)
+    xd = engine.to(torch.from_numpy(x.copy()))
+    for off in (1, 3):
+        got = npy(q.quantize(xd[off:], 8, -2.5, 3.0))
+        assert_bitexact(got, orc.uniform_quantize(x[off:], 8, -2.5, 3.0), 'offset {}'.format(off))
+        mm = npy(q.tensor_minmax(xd[off:]))
+        assert mm[0] == x[off:].min() and mm[1] == x[off:].max()
+
+
 def test_fake_quant_inplace_and_ste(engine):
     x = engine.to(torch.linspace(-2, 2, 1000))
     ref = orc.uniform_quantize(npy(x), 8, -2.0, 2.0)
