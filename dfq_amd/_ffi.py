@@ -77,6 +77,7 @@ SIGNATURES = {
     'dfq_le_query_all': (c_int32, [c_void_p, c_void_p, POINTER(DfqLeResult), POINTER(c_int32)]),
     'dfq_le_plan_levels': (c_int32, [c_void_p]),
     'dfq_le_plan_paired_elements': (c_int64, [c_void_p]),
+    'dfq_le_plan_depth': (c_int32, [c_void_p]),
     'dfq_le_plan_rw_elements': (c_int64, [c_void_p]),
     'dfq_le_plan_ro_elements': (c_int64, [c_void_p]),
     'dfq_le_plan_level_launches': (c_int32, [c_void_p, c_int32, POINTER(c_int64), POINTER(c_int64), POINTER(c_int32)]),

@@ -65,7 +65,6 @@ constexpr int kColTileLanes = 64;      // vector positions of a col tile (one wa
 constexpr int kSlotMax = 1024;         // LDS table entries of a tile (stat slots / 1/s table)
 constexpr int kShortChunk = 9;          // taps a thread-per-row tile keeps in flight (one 3x3 kernel)
 constexpr int kBootTc = 64;            // channels per bootstrap tile
-constexpr int kLevelRelsMax = 16;      // relations per launch (longer levels are split): descriptors ride in the kernarg
 constexpr int kCtlBlock = 1024;        // threads of the control kernel
 constexpr int kCtlStage = 6144;        // partials staged in LDS by the control kernel
 
@@ -97,6 +96,11 @@ struct LeRelDev {
     int32_t boot_begin;     // first workgroup inside the bootstrap launch
     int32_t boot_tiles;
     int32_t net;            // which network of a batched plan (index into the loop-state array)
+    // one launch per sweep: the tiles of this relation may start once the column tiles of the relation that
+    // produces its row statistics have finished -- dep_counter >= dep_tiles * (sweep + 1)
+    int32_t dep_idx;        // index of that relation's counter, or -1
+    int32_t dep_tiles;      // its column tiles per sweep
+    int32_t counter_idx;    // own counter (bumped by this relation's column tiles if somebody waits for them), or -1
 };
 
 // Tuning builds only (tools/ablate.sh): -DDFQ_LE_ABLATE=bits switches parts of the tile kernels off at compile
@@ -127,26 +131,18 @@ struct LeLayerDiff {
     double n_elems;
 };
 
-// one working workgroup of a batched launch
+// one working workgroup of a launch: which relation (index into the descriptor table), which tile of it, which
+// network (loop-state index)
 struct LeBlockRef {
-    int32_t rel;      // descriptor index inside the launch's table
-    int32_t tile;     // tile of that relation (row tiles first, then col tiles)
-    int32_t net;      // network (loop-state index)
+    int32_t rel;
+    int32_t tile;     // row tiles first, then col tiles
+    int32_t net;
     int32_t pad;
 };
-
-// the relations of one launch.  Single-network plans (the latency-critical case): grid = (max tiles
-// of a relation, n relations), up to kLevelRelsMax descriptors ride in the kernarg and surplus
-// workgroups leave after one scalar-cache hit.  Batched plans: a 1-D grid of exactly the working
-// workgroups; workgroup b reads blocks[b] (one scalar load) and then, in parallel, its descriptor
-// table[rel] and the loop state of its network -- a rectangular grid over hundreds of relations of
-// very different sizes would be mostly empty workgroups that each pay a global round trip to find out.
-struct LevelArgs {
-    LeRelDev rel[kLevelRelsMax];      // MUST stay first: read straight from the kernarg segment
-    const LeRelDev* table;            // non-null: batched plan
-    const LeBlockRef* blocks;         // batched plan: one entry per workgroup
-};
-static_assert(sizeof(LevelArgs) <= 3600, "kernarg segment is limited to 4 KiB");
+// A launch is a 1-D grid of exactly the working workgroups: workgroup b reads blocks[b] (16 bytes) and then, with
+// ONE wave-wide load, its descriptor table[rel] and the loop state of its network.  (A rectangular grid over
+// hundreds of relations of very different sizes would be mostly empty workgroups that each pay a global round
+// trip to find that out.)
 
 // optional per-phase cycle stamps of one workgroup (dfq_le_trace, tuning aid; null in production)
 struct LeTrace {
@@ -156,7 +152,7 @@ struct LeTrace {
 };
 __device__ __forceinline__ void stamp(const LeTrace& tr, int slot) {
     if (!tr.out || threadIdx.x != 0) return;
-    const int flat = (int)(blockIdx.y * gridDim.x + blockIdx.x);
+    const int flat = (int)blockIdx.x;
     if (tr.block == -1) {
         // every workgroup: [0] entry, [1] exit (100 MHz wall clock), [2] XCC_ID << 32 | HW_ID
         if (slot == 0) {
@@ -201,12 +197,20 @@ __device__ __forceinline__ float range_of(float mn, float mx, int signed_range) 
     return mx - mn;
 }
 
+// Row statistics are produced and consumed inside ONE launch (by workgroups on different XCDs, whose L2s are not
+// coherent for plain accesses within a kernel): they are published with device-scope atomics and read with
+// device-scope loads (tools/litmus/xcd_flag.hip checks exactly this protocol on the hardware).  Column
+// statistics cross a kernel boundary and use plain loads.
+__device__ __forceinline__ uint32_t ld_stat(const guint* p) {
+    return __hip_atomic_load((const uint32_t*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // scale of paired channel c from the four stat words of the current parity
 __device__ __forceinline__ void channel_scale(const LeRelDev& R, const LeParams& p, int cur, int c, float& s,
                                               float& inv, float& mn1, float& mx1, float& mn2, float& mx2) {
     const guint* a = (const guint*)R.r1 + (int64_t)cur * R.stat_stride + 2 * c;
     const guint* b = (const guint*)R.r2 + (int64_t)cur * R.stat_stride + 2 * c;
-    const uint32_t a0 = a[0], a1 = a[1], b0 = b[0], b1 = b[1];
+    const uint32_t a0 = ld_stat(a), a1 = ld_stat(a + 1), b0 = b[0], b1 = b[1];
     mn1 = slot_min(a0); mx1 = slot_max(a1);
     mn2 = slot_min(b0); mx2 = slot_max(b1);
     le_solve(range_of(mn1, mx1, p.signed_range), range_of(mn2, mx2, p.signed_range), p, s, inv);
@@ -307,7 +311,7 @@ __device__ __forceinline__ double row_tile(const LeRelDev& R, const LeParams& p,
     if (tid < nr) {
         const guint* a = (const guint*)R.r1 + (int64_t)cur * R.stat_stride + 2 * (r0 + tid);
         const guint* b = (const guint*)R.r2 + (int64_t)cur * R.stat_stride + 2 * (r0 + tid);
-        wa0 = a[0]; wa1 = a[1]; wb0 = b[0]; wb1 = b[1];
+        wa0 = ld_stat(a); wa1 = ld_stat(a + 1); wb0 = b[0]; wb1 = b[1];
     }
     // ---- then every data load ---------------------------------------------------------------------
     float v[NV][VEC];
@@ -338,7 +342,7 @@ __device__ __forceinline__ double row_tile(const LeRelDev& R, const LeParams& p,
         for (int sl = kBlock - 1 - tid; sl < n_slots; sl += kBlock) {
             const int gq = small_div(sl, nci);
             const int c = (g0 + gq) * R.pc_gi + i0 + (sl - gq * nci);
-            const uint32_t a0 = a_base[2 * c], a1 = a_base[2 * c + 1], b0 = b_base[2 * c], b1 = b_base[2 * c + 1];
+            const uint32_t a0 = ld_stat(a_base + 2 * c), a1 = ld_stat(a_base + 2 * c + 1), b0 = b_base[2 * c], b1 = b_base[2 * c + 1];
             float s, inv;
             le_solve(range_of(slot_min(a0), slot_max(a1), p.signed_range), range_of(slot_min(b0), slot_max(b1), p.signed_range),
                      p, s, inv);
@@ -490,7 +494,7 @@ __device__ __forceinline__ double col_tile(const LeRelDev& R, const LeParams& p,
         const int c = (g_lo + gq) * R.gi + i0 + (tid - gq * nci);
         const guint* a = (const guint*)R.r1 + (int64_t)cur * R.stat_stride + 2 * c;
         const guint* b = (const guint*)R.r2 + (int64_t)cur * R.stat_stride + 2 * c;
-        wa0 = a[0]; wa1 = a[1]; wb0 = b[0]; wb1 = b[1];
+        wa0 = ld_stat(a); wa1 = ld_stat(a + 1); wb0 = b[0]; wb1 = b[1];
     }
     // ---- then every data load ---------------------------------------------------------------------
     float v[NV][VEC];
@@ -560,12 +564,9 @@ __device__ __forceinline__ double col_tile(const LeRelDev& R, const LeParams& p,
     if (emit) {
         __syncthreads();
         // row stats go into the SAME sweep's parity (consumed by a later level of this sweep)
+        // (always atomics, also for complete rows: a consumer on another XCD reads them in this same launch)
         guint* dst = (guint*)R.out_rows + (int64_t)cur * R.stat_stride + 2 * r0;
-        if (R.ct_slabs == 1) {
-            for (int i = tid; i < 2 * nr; i += kBlock) dst[i] = sh_row[i];           // complete rows
-        } else {
-            for (int i = tid; i < 2 * nr; i += kBlock) atomicMax((unsigned*)dst + i, sh_row[i]);
-        }
+        for (int i = tid; i < 2 * nr; i += kBlock) atomicMax((unsigned*)dst + i, sh_row[i]);
     }
     return acc;
 }
@@ -602,7 +603,7 @@ __device__ __forceinline__ double short_tile(const LeRelDev& R, const LeParams& 
         const int cp = o * R.pc_gi;
         const guint* a = (const guint*)R.prev_r1 + (int64_t)cur * R.stat_stride + 2 * cp;
         const guint* b = (const guint*)R.out_cols + (int64_t)cur * R.stat_stride + 2 * cp;
-        const uint32_t a0 = a[0], a1 = a[1], b0 = b[0], b1 = b[1];
+        const uint32_t a0 = ld_stat(a), a1 = ld_stat(a + 1), b0 = b[0], b1 = b[1];
         float ps;
         le_solve(range_of(slot_min(a0), slot_max(a1), p.signed_range), range_of(slot_min(b0), slot_max(b1), p.signed_range),
                  p, ps, pinv);
@@ -650,10 +651,10 @@ __device__ __forceinline__ double short_tile(const LeRelDev& R, const LeParams& 
                 fwd[1] = enc_ord(mx1 * s);
             }
         } else {
-            if (R.out_rows) {
+            if (R.out_rows) {      // consumed in this same launch: atomics (see ld_stat)
                 uint32_t* dst = R.out_rows + (int64_t)cur * R.stat_stride + 2 * o;
-                dst[0] = ~enc_ord(rmn);
-                dst[1] = enc_ord(rmx);
+                atomicMax(dst + 0, ~enc_ord(rmn));
+                atomicMax(dst + 1, enc_ord(rmx));
             } else if (o == small_div(o, R.go) * R.go) {   // chain end: first row of the group forwards
                 uint32_t* fwd = R.r2 + (int64_t)nxt * R.stat_stride + 2 * c;
                 fwd[0] = ~enc_ord(mn2 * inv);
@@ -667,52 +668,70 @@ __device__ __forceinline__ double short_tile(const LeRelDev& R, const LeParams& 
 constexpr int kDescWords = (int)(sizeof(LeRelDev) / 4);
 static_assert(sizeof(LeRelDev) % 4 == 0 && kDescWords + 1 <= kWave, "descriptor must fit one wave-wide load");
 
-// `args` MUST stay the first parameter: the kernel reads its descriptor straight out of the kernarg
-// segment (offset blockIdx.y * sizeof(LeRelDev)) with one wave-wide vector load -- lane i fetches
-// word i, v_readlane broadcasts it.  Letting the compiler materialise `args.rel[blockIdx.y]` makes
-// it fetch the fields piecemeal at first use (one dependent round trip per group of fields).
-// `parity` = sweep index & 1, known to the host at enqueue time.
+// One launch = any contiguous slice of the sweep's workgroup table: the whole sweep (default) or one dependency
+// level (DFQ_LE_MERGED=0).  `sweep` = sweeps since the last restart (parity = sweep & 1).
+//
+// Dependencies inside a launch.  The tiles of a relation whose first layer is interior need the row statistics
+// that the column tiles of ONE earlier relation (its predecessor in the chain) publish, and must not write that
+// layer before those tiles have read it.  The table is in level order, workgroups are dispatched in index
+// order and only ever wait for lower indices, so a spinning workgroup never blocks its producers.  Producer:
+// statistics atomics -> s_waitcnt 0 -> barrier -> one atomicAdd on the relation's counter.  Consumer: one
+// thread spins (device-scope loads, s_sleep) until the counter reaches tiles x (sweep + 1), then a barrier.
+// The spin is bounded: a consumer that gives up raises `err[0]` and carries on, so a logic error shows up as
+// an error code from the query call instead of a hung GPU.
 #ifndef DFQ_LE_MIN_WAVES
 #define DFQ_LE_MIN_WAVES 1
 #endif
-__global__ __launch_bounds__(kBlock, DFQ_LE_MIN_WAVES) void le_level_kernel(LevelArgs args, LeParams p, int parity,
+constexpr long kSpinLimit = 40000000;   // x (sleep + load) ~ several seconds
+__global__ __launch_bounds__(kBlock, DFQ_LE_MIN_WAVES) void le_level_kernel(const LeRelDev* __restrict__ table,
+                                                          const LeBlockRef* __restrict__ blocks, LeParams p, int sweep,
                                                           const LeState* __restrict__ state,
-                                                          double* __restrict__ partials, LeTrace tr) {
+                                                          double* __restrict__ partials, uint32_t* dep_counters,
+                                                          uint32_t* err, LeTrace tr) {
     stamp(tr, 0);
     __shared__ float sh_f[kSlotMax];                // row tile: scales; col tile: 1/s table
     __shared__ uint32_t sh_u[2 * kSlotMax];         // row tile: column-stat slots; col tile: row stats
     __shared__ int sh_g[kTileRowsMax];              // per-row table offsets
     __shared__ float sh_p[kSlotMax];                // row tile of an interior layer: 1/s of the previous relation
     const int lane = threadIdx.x % kWave;
-    const DFQ_CONSTANT_AS uint32_t* ka = (const DFQ_CONSTANT_AS uint32_t*)__builtin_amdgcn_kernarg_segment_ptr();
+    // one 16-byte load of the workgroup's entry, then ONE wave-wide load that fetches the descriptor
+    // (lanes 0..kDescWords-1) and the loop state of the network (lane kDescWords) together; v_readlane
+    // broadcasts the words (letting the compiler index a descriptor struct makes it fetch the fields piecemeal
+    // at first use: one dependent round trip per group of fields)
+    typedef int ivec4 __attribute__((vector_size(16)));
+    const ivec4 ref = *(const DFQ_GLOBAL_AS ivec4*)(blocks + blockIdx.x);
+    const int rel = __builtin_amdgcn_readfirstlane(ref[0]);
+    const int net = __builtin_amdgcn_readfirstlane(ref[2]);
+    const int tile = __builtin_amdgcn_readfirstlane(ref[1]);
     uint32_t word = 0u;
-    int tile = blockIdx.x;
-    if (args.table) {
-        // one 16-byte load of the workgroup's entry, then ONE wave-wide load that fetches the descriptor
-        // (lanes 0..kDescWords-1) and the loop state of the network (lane kDescWords) together
-        typedef int ivec4 __attribute__((vector_size(16)));
-        const ivec4 ref = *(const DFQ_GLOBAL_AS ivec4*)(args.blocks + blockIdx.x);
-        const int rel = __builtin_amdgcn_readfirstlane(ref[0]);
-        const int net = __builtin_amdgcn_readfirstlane(ref[2]);
-        tile = __builtin_amdgcn_readfirstlane(ref[1]);
-        const guint* src = (lane < kDescWords) ? (const guint*)(args.table + rel) + lane
-                                               : (const guint*)&state[net].done;
+    {
+        const guint* src = (lane < kDescWords) ? (const guint*)(table + rel) + lane : (const guint*)&state[net].done;
         if (lane <= kDescWords) word = *src;
-    } else {
-        if (lane < kDescWords) word = ka[blockIdx.y * kDescWords + lane];
-        else if (lane == kDescWords) word = (uint32_t)*(const DFQ_GLOBAL_AS int*)&state->done;   // single network
     }
     union { LeRelDev R; uint32_t u[kDescWords]; } desc;
 #pragma unroll
     for (int i = 0; i < kDescWords; ++i) desc.u[i] = __builtin_amdgcn_readlane(word, i);
     const uint32_t done = __builtin_amdgcn_readlane(word, kDescWords);
     const LeRelDev& R = desc.R;
-    const int cur = parity;
+    const int cur = sweep & 1;
     if (done || tile >= R.n_row_tiles + R.n_col_tiles) return;   // uniform
     stamp(tr, 1);
 
+    if (R.dep_idx >= 0) {
+        if (threadIdx.x == 0) {
+            const uint32_t target = (uint32_t)R.dep_tiles * (uint32_t)(sweep + 1);
+            long spins = 0;
+            while (__hip_atomic_load(dep_counters + R.dep_idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > kSpinLimit) { atomicMax(err, 1u); break; }
+            }
+        }
+        __syncthreads();
+    }
+
     double acc;
-    if (tile < R.n_row_tiles) {
+    const bool col_side = tile >= R.n_row_tiles;
+    if (!col_side) {
         if (R.rt_vec == 0) acc = short_tile<0>(R, p, tile, cur);
         else acc = R.rt_vec == 4 ? row_tile<4>(R, p, tile, cur, sh_f, sh_u, sh_g, sh_p, tr)
                                  : row_tile<1>(R, p, tile, cur, sh_f, sh_u, sh_g, sh_p, tr);
@@ -722,6 +741,12 @@ __global__ __launch_bounds__(kBlock, DFQ_LE_MIN_WAVES) void le_level_kernel(Leve
                                  : col_tile<1>(R, p, tile - R.n_row_tiles, cur, sh_f, sh_u, sh_g, tr);
     }
     stamp(tr, 6);
+    if (col_side && R.counter_idx >= 0) {
+        // every statistics atomic of this workgroup has been performed before the counter moves
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(dep_counters + R.counter_idx, 1u);
+    }
     // one partial per wave (fixed butterfly order -> deterministic), no workgroup barrier
     const double t = wave_sum(acc);
     if (lane == 0) partials[(int64_t)(R.partial_base + tile) * (kBlock / kWave) + threadIdx.x / kWave] = t;
@@ -911,10 +936,8 @@ __global__ void le_reset_kernel(LeState* states, int n_nets, double converge_thr
 struct LevelLaunch {
     int rel_begin = 0;      // range in the level-sorted device relation table
     int n_rels = 0;
-    int n_blocks = 0;       // workgroups that do work
-    int max_tiles = 0;      // grid.x of a single-network launch
-    int block_begin = 0;    // batched: first entry of this launch in the workgroup table
-    LevelArgs args;         // descriptors of the launch (kernel argument, by value)
+    int n_blocks = 0;       // workgroups (all of them do work)
+    int block_begin = 0;    // first entry of this level in the sweep's workgroup table
     int64_t rw_elems = 0;   // elements read AND written by this launch (8 B each)
     int64_t ro_elems = 0;   // elements only read by it: statistics pass over interior layers (4 B each)
 };
@@ -941,7 +964,9 @@ struct dfq_le_plan {
     };
     std::vector<CachedGraph> graphs;
     LeRelDev* d_rels = nullptr;
-    LeBlockRef* d_blocks = nullptr;        // batched plans: workgroup table of every launch, back to back
+    LeBlockRef* d_blocks = nullptr;        // workgroup table of a sweep: level after level
+    uint32_t* d_dep = nullptr;             // per-relation counters of finished column tiles + [n_rels] = error flag
+    bool merged = true;                    // one launch per sweep (false: one per level, DFQ_LE_MERGED=0)
     LeLayerDiff* d_layer_diff = nullptr;
     double* d_partials = nullptr;
     double* d_layer_mean = nullptr;
@@ -1001,6 +1026,7 @@ void dfq_le_plan_destroy(dfq_le_plan* p) {
     if (p->d_nets) (void)hipFree(p->d_nets);
     if (p->d_boot_map) (void)hipFree(p->d_boot_map);
     if (p->d_blocks) (void)hipFree(p->d_blocks);
+    if (p->d_dep) (void)hipFree(p->d_dep);
     for (auto& g : p->graphs) (void)hipGraphExecDestroy(g.exec);
     if (p->capture_stream) (void)hipStreamDestroy(p->capture_stream);
     delete p;
@@ -1195,8 +1221,7 @@ int dfq_le_plan_create_batch(const dfq_layer* layers, int32_t n_layers, const in
     int boot = 0, prev_level = -1;
     for (int i = 0; i < n_relations; ++i) {
         const int r = order[i];
-        const int launch_cap = (n_nets == 1) ? kLevelRelsMax : (1 << 30);
-        if (level[r] != prev_level || p->levels.back().n_rels == launch_cap) {    // new launch
+        if (level[r] != prev_level) {                                             // new level
             p->levels.push_back(LevelLaunch());
             p->levels.back().rel_begin = i;
             prev_level = level[r];
@@ -1205,9 +1230,7 @@ int dfq_le_plan_create_batch(const dfq_layer* layers, int32_t n_layers, const in
         sorted[i] = h[r];
         sorted[i].boot_begin = boot;              // bootstrap launch walks the same (sorted) table
         boot += h[r].boot_tiles;
-        if (n_nets == 1) L.args.rel[L.n_rels] = sorted[i];
         L.n_blocks += h[r].n_row_tiles + h[r].n_col_tiles;
-        L.max_tiles = std::max(L.max_tiles, h[r].n_row_tiles + h[r].n_col_tiles);
         L.n_rels += 1;
         const int64_t n1 = (int64_t)h[r].o1 * h[r].row_len;
         const int64_t n2 = (int64_t)h[r].o2 * h[r].i2g * h[r].khkw;
@@ -1230,54 +1253,83 @@ int dfq_le_plan_create_batch(const dfq_layer* layers, int32_t n_layers, const in
     if ((e = hipMalloc((void**)&p->d_boot_map, sizeof(int32_t) * boot_map.size())) != hipSuccess) return fail_alloc(e);
     if ((e = hipMemcpy(p->d_nets, nets.data(), sizeof(LeNetDesc) * n_nets, hipMemcpyHostToDevice)) != hipSuccess) return fail_alloc(e);
     if ((e = hipMemcpy(p->d_boot_map, boot_map.data(), sizeof(int32_t) * boot_map.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail_alloc(e);
-    if (n_relations > 0 &&
-        (e = hipMemcpy(p->d_rels, sorted.data(), sizeof(LeRelDev) * n_relations, hipMemcpyHostToDevice)) != hipSuccess) return fail_alloc(e);
     if ((e = hipMemcpy(p->d_layer_diff, ld.data(), sizeof(LeLayerDiff) * n_layers, hipMemcpyHostToDevice)) != hipSuccess) return fail_alloc(e);
     if ((e = hipMemset(p->d_partials, 0, sizeof(double) * n_part)) != hipSuccess) return fail_alloc(e);
     if ((e = hipMemset(p->d_state, 0, sizeof(LeState) * n_nets)) != hipSuccess) return fail_alloc(e);
-    for (LevelLaunch& L : p->levels) { L.args.table = nullptr; L.args.blocks = nullptr; }
-    if (n_nets > 1) {
-        // workgroup tables: the tiles of a launch in relation order (a relation's tiles stay adjacent,
-        // so do its rows in memory)
+    {
+        // dependency links (see le_level_kernel): position of every relation in the level-sorted table
+        std::vector<int> pos(n_relations, -1);
+        for (int i = 0; i < n_relations; ++i) pos[order[i]] = i;
+        for (int i = 0; i < n_relations; ++i) {
+            const int r = order[i];
+            const int j_prev = as_second[relations[r].first];
+            const int j_next = as_first[relations[r].second];
+            sorted[i].dep_idx = (j_prev >= 0) ? pos[j_prev] : -1;
+            sorted[i].dep_tiles = (j_prev >= 0) ? h[j_prev].n_col_tiles : 0;
+            sorted[i].counter_idx = (j_next >= 0) ? i : -1;
+            if (j_prev >= 0 && pos[j_prev] >= i)
+                return (dfq_le_plan_destroy(p), fail_arg("dfq_le_plan_create: relation %d precedes the relation it depends on", r));
+        }
+        if (n_relations > 0 &&
+            (e = hipMemcpy(p->d_rels, sorted.data(), sizeof(LeRelDev) * n_relations, hipMemcpyHostToDevice)) != hipSuccess) return fail_alloc(e);
+        // workgroup table of a sweep: the tiles of a level in relation order (a relation's tiles stay adjacent, so do
+        // its rows in memory), level after level
         std::vector<LeBlockRef> blocks;
         for (LevelLaunch& L : p->levels) {
             L.block_begin = (int)blocks.size();
             for (int i = 0; i < L.n_rels; ++i) {
                 const LeRelDev& d = sorted[L.rel_begin + i];
-                for (int t = 0; t < d.n_row_tiles + d.n_col_tiles; ++t) blocks.push_back(LeBlockRef{i, t, d.net, 0});
+                for (int t = 0; t < d.n_row_tiles + d.n_col_tiles; ++t) blocks.push_back(LeBlockRef{L.rel_begin + i, t, d.net, 0});
             }
         }
         if ((e = hipMalloc((void**)&p->d_blocks, sizeof(LeBlockRef) * std::max<size_t>(1, blocks.size()))) != hipSuccess) return fail_alloc(e);
         if (!blocks.empty() &&
             (e = hipMemcpy(p->d_blocks, blocks.data(), sizeof(LeBlockRef) * blocks.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail_alloc(e);
-        for (LevelLaunch& L : p->levels) { L.args.table = p->d_rels + L.rel_begin; L.args.blocks = p->d_blocks + L.block_begin; }
+        if ((e = hipMalloc((void**)&p->d_dep, sizeof(uint32_t) * (n_relations + 1))) != hipSuccess) return fail_alloc(e);
+        if ((e = hipMemset(p->d_dep, 0, sizeof(uint32_t) * (n_relations + 1))) != hipSuccess) return fail_alloc(e);
+        const char* me = getenv("DFQ_LE_MERGED");
+        p->merged = !(me && me[0] == '0');
     }
     if ((e = hipDeviceSynchronize()) != hipSuccess) return fail_alloc(e);
     *out_plan = p;
     return DFQ_OK;
 }
 
-int32_t dfq_le_plan_levels(const dfq_le_plan* p) { return p ? (int32_t)p->levels.size() : 0; }
+// launches of a sweep (the convergence kernel not counted): 1, or the number of dependency levels with DFQ_LE_MERGED=0
+int32_t dfq_le_plan_levels(const dfq_le_plan* p) { return p ? (p->merged ? (p->levels.empty() ? 0 : 1) : (int32_t)p->levels.size()) : 0; }
+int32_t dfq_le_plan_depth(const dfq_le_plan* p) { return p ? (int32_t)p->levels.size() : 0; }
 int64_t dfq_le_plan_paired_elements(const dfq_le_plan* p) { return p ? p->paired_total : 0; }
 int64_t dfq_le_plan_rw_elements(const dfq_le_plan* p) { return p ? p->rw_total : 0; }
 int64_t dfq_le_plan_ro_elements(const dfq_le_plan* p) { return p ? p->ro_total : 0; }
 
+// the slice of the sweep's workgroup table that launch `launch` covers
+static bool launch_slice(const dfq_le_plan* p, int launch, int* begin, int* count, int* n_rels, int64_t* rw, int64_t* ro) {
+    if (!p || launch < 0 || launch >= dfq_le_plan_levels(p)) return false;
+    if (p->merged) {
+        *begin = 0; *count = p->total_tiles; *n_rels = p->n_rels; *rw = p->rw_total; *ro = p->ro_total;
+    } else {
+        const LevelLaunch& L = p->levels[launch];
+        *begin = L.block_begin; *count = L.n_blocks; *n_rels = L.n_rels; *rw = L.rw_elems; *ro = L.ro_elems;
+    }
+    return true;
+}
+
 int dfq_le_plan_level_grid(const dfq_le_plan* p, int32_t level, int32_t* grid_x, int32_t* grid_y) {
-    if (!p || level < 0 || level >= (int32_t)p->levels.size()) return fail_arg("dfq_le_plan_level_grid: bad level");
-    const bool flat = p->levels[level].args.table != nullptr;
-    if (grid_x) *grid_x = flat ? p->levels[level].n_blocks : p->levels[level].max_tiles;
-    if (grid_y) *grid_y = flat ? 1 : p->levels[level].n_rels;
+    int b, c, n; int64_t rw, ro;
+    if (!launch_slice(p, level, &b, &c, &n, &rw, &ro)) return fail_arg("dfq_le_plan_level_grid: bad level");
+    if (grid_x) *grid_x = c;
+    if (grid_y) *grid_y = 1;
     return DFQ_OK;
 }
 
 int32_t dfq_le_plan_level_launches(const dfq_le_plan* p, int32_t level, int64_t* rw_elems,
                                    int64_t* ro_elems, int32_t* n_workgroups) {
-    if (!p || level < 0 || level >= (int32_t)p->levels.size()) return fail_arg("dfq_le_plan_level_launches: bad level");
-    const LevelLaunch& L = p->levels[level];
-    if (rw_elems) *rw_elems = L.rw_elems;
-    if (ro_elems) *ro_elems = L.ro_elems;
-    if (n_workgroups) *n_workgroups = L.n_blocks;
-    return L.n_rels;
+    int b, c, n; int64_t rw, ro;
+    if (!launch_slice(p, level, &b, &c, &n, &rw, &ro)) return fail_arg("dfq_le_plan_level_launches: bad level");
+    if (rw_elems) *rw_elems = rw;
+    if (ro_elems) *ro_elems = ro;
+    if (n_workgroups) *n_workgroups = c;
+    return n;
 }
 
 }  // extern "C"
@@ -1295,6 +1347,7 @@ static int le_restart(dfq_le_plan* p, const dfq_le_config* cfg, hipStream_t st) 
                        (int)cfg->converge_count, (int)cfg->max_sweeps);
     DFQ_CHECK_LAUNCH();
     p->sweep_index = 0;
+    DFQ_HIP_TRY(hipMemsetAsync(p->d_dep, 0, sizeof(uint32_t) * (p->n_rels + 1), st));
     if (p->n_rels > 0) {
         DFQ_HIP_TRY(hipMemsetAsync(p->d_stats, 0, sizeof(uint32_t) * 4 * p->stat_words, st));
         hipLaunchKernelGGL(le_bootstrap_kernel, dim3(p->boot_blocks), dim3(kBlock), 0, st,
@@ -1304,12 +1357,15 @@ static int le_restart(dfq_le_plan* p, const dfq_le_config* cfg, hipStream_t st) 
     return DFQ_OK;
 }
 
-static int le_launch_level(dfq_le_plan* p, const LevelLaunch& L, const LeParams& q, hipStream_t st,
+// launch number `launch` of a sweep (see dfq_le_plan_levels)
+static int le_launch_level(dfq_le_plan* p, int launch, const LeParams& q, hipStream_t st,
                            LeTrace tr = LeTrace{nullptr, 0, 0}) {
-    if (L.n_blocks == 0) return DFQ_OK;
-    const dim3 grid = L.args.table ? dim3(L.n_blocks) : dim3(L.max_tiles, L.n_rels);
-    hipLaunchKernelGGL(le_level_kernel, grid, dim3(kBlock), 0, st, L.args, q,
-                       (int)(p->sweep_index & 1), (const LeState*)p->d_state, p->d_partials, tr);
+    int begin, count, n; int64_t rw, ro;
+    if (!launch_slice(p, launch, &begin, &count, &n, &rw, &ro)) return fail_arg("le_launch_level: bad launch");
+    if (count == 0) return DFQ_OK;
+    hipLaunchKernelGGL(le_level_kernel, dim3(count), dim3(kBlock), 0, st, (const LeRelDev*)p->d_rels,
+                       (const LeBlockRef*)(p->d_blocks + begin), q, (int)p->sweep_index, (const LeState*)p->d_state,
+                       p->d_partials, p->d_dep, p->d_dep + p->n_rels, tr);
     DFQ_CHECK_LAUNCH();
     return DFQ_OK;
 }
@@ -1334,8 +1390,8 @@ static int le_enqueue_direct(dfq_le_plan* p, const dfq_le_config* cfg, int n_swe
     int rc;
     if (restart && (rc = le_restart(p, cfg, st))) return rc;
     for (int s = 0; s < n_sweeps; ++s) {
-        for (const LevelLaunch& L : p->levels)
-            if ((rc = le_launch_level(p, L, q, st))) return rc;
+        for (int l = 0; l < dfq_le_plan_levels(p); ++l)
+            if ((rc = le_launch_level(p, l, q, st))) return rc;
         if ((rc = le_launch_control(p, cfg, st))) return rc;
     }
     return DFQ_OK;
@@ -1386,7 +1442,7 @@ int dfq_le_profile(dfq_le_plan* p, const dfq_le_config* cfg, int32_t n_sweeps, v
     if (!p || !cfg || n_sweeps <= 0 || !level_ms) return fail_arg("dfq_le_profile: bad argument");
     hipStream_t st = as_stream(stream);
     const LeParams q = make_params(cfg);
-    const int n_levels = (int)p->levels.size();
+    const int n_levels = dfq_le_plan_levels(p);
     const int per_sweep = n_levels + 1;
     std::vector<hipEvent_t> ev((size_t)2 * per_sweep * n_sweeps);
     for (auto& e : ev) DFQ_HIP_TRY(hipEventCreate(&e));
@@ -1402,9 +1458,9 @@ int dfq_le_profile(dfq_le_plan* p, const dfq_le_config* cfg, int32_t n_sweeps, v
     }
     size_t k = 0;
     for (int s = 0; s < n_sweeps; ++s) {
-        for (const LevelLaunch& L : p->levels) {
+        for (int l = 0; l < n_levels; ++l) {
             DFQ_HIP_TRY(hipEventRecord(ev[k++], st));
-            if ((rc = le_launch_level(p, L, q, st))) return rc;
+            if ((rc = le_launch_level(p, l, q, st))) return rc;
             DFQ_HIP_TRY(hipEventRecord(ev[k++], st));
         }
         DFQ_HIP_TRY(hipEventRecord(ev[k++], st));
@@ -1439,7 +1495,7 @@ int dfq_le_profile(dfq_le_plan* p, const dfq_le_config* cfg, int32_t n_sweeps, v
 
 int dfq_le_trace(dfq_le_plan* p, const dfq_le_config* cfg, int32_t launch, int32_t block, void* stream,
                  int64_t* stamps16) {
-    if (!p || !cfg || !stamps16 || launch < 0 || launch >= (int)p->levels.size()) return fail_arg("dfq_le_trace: bad argument");
+    if (!p || !cfg || !stamps16 || launch < 0 || launch >= dfq_le_plan_levels(p)) return fail_arg("dfq_le_trace: bad argument");
     hipStream_t st = as_stream(stream);
     const LeParams q = make_params(cfg);
     long long* d = nullptr;
@@ -1447,8 +1503,8 @@ int dfq_le_trace(dfq_le_plan* p, const dfq_le_config* cfg, int32_t launch, int32
     DFQ_HIP_TRY(hipMemsetAsync(d, 0, 16 * sizeof(long long), st));
     int rc = le_restart(p, cfg, st);
     for (int s = 0; s < 2 && !rc; ++s) {          // trace the second sweep (steady-state stat flow)
-        for (int l = 0; l < (int)p->levels.size() && !rc; ++l)
-            rc = le_launch_level(p, p->levels[l], q, st, (s == 1 && l == launch) ? LeTrace{d, block, 0} : LeTrace{nullptr, 0, 0});
+        for (int l = 0; l < dfq_le_plan_levels(p) && !rc; ++l)
+            rc = le_launch_level(p, l, q, st, (s == 1 && l == launch) ? LeTrace{d, block, 0} : LeTrace{nullptr, 0, 0});
         if (!rc) rc = le_launch_control(p, cfg, st);
     }
     if (!rc) {
@@ -1462,9 +1518,9 @@ int dfq_le_trace(dfq_le_plan* p, const dfq_le_config* cfg, int32_t launch, int32
 
 int dfq_le_trace_blocks(dfq_le_plan* p, const dfq_le_config* cfg, int32_t launch, void* stream, int64_t* out,
                         int64_t capacity_blocks) {
-    if (!p || !cfg || !out || launch < 0 || launch >= (int)p->levels.size()) return fail_arg("dfq_le_trace_blocks: bad argument");
-    const LevelLaunch& T = p->levels[launch];
-    const int64_t n_blocks = T.args.table ? T.n_blocks : (int64_t)T.max_tiles * T.n_rels;
+    int tb, tc, tn; int64_t trw, tro;
+    if (!cfg || !out || !launch_slice(p, launch, &tb, &tc, &tn, &trw, &tro)) return fail_arg("dfq_le_trace_blocks: bad argument");
+    const int64_t n_blocks = tc;
     if (capacity_blocks < n_blocks) return fail_arg("dfq_le_trace_blocks: need room for %lld workgroups", (long long)n_blocks);
     hipStream_t st = as_stream(stream);
     const LeParams q = make_params(cfg);
@@ -1473,8 +1529,8 @@ int dfq_le_trace_blocks(dfq_le_plan* p, const dfq_le_config* cfg, int32_t launch
     DFQ_HIP_TRY(hipMemsetAsync(d, 0, 3 * n_blocks * sizeof(long long), st));
     int rc = le_restart(p, cfg, st);
     for (int s = 0; s < 3 && !rc; ++s) {          // trace the third sweep (steady state, code and tables warm)
-        for (int l = 0; l < (int)p->levels.size() && !rc; ++l)
-            rc = le_launch_level(p, p->levels[l], q, st, (s == 2 && l == launch) ? LeTrace{d, -1, 0} : LeTrace{nullptr, 0, 0});
+        for (int l = 0; l < dfq_le_plan_levels(p) && !rc; ++l)
+            rc = le_launch_level(p, l, q, st, (s == 2 && l == launch) ? LeTrace{d, -1, 0} : LeTrace{nullptr, 0, 0});
         if (!rc) rc = le_launch_control(p, cfg, st);
     }
     if (!rc) {
@@ -1490,8 +1546,14 @@ int dfq_le_query_all(dfq_le_plan* p, void* stream, dfq_le_result* out, int32_t* 
     if (!p) return fail_arg("dfq_le_query: null plan");
     std::vector<LeState> h(p->n_nets);
     hipStream_t st = as_stream(stream);
+    uint32_t gave_up = 0;
     DFQ_HIP_TRY(hipMemcpyAsync(h.data(), p->d_state, sizeof(LeState) * p->n_nets, hipMemcpyDeviceToHost, st));
+    DFQ_HIP_TRY(hipMemcpyAsync(&gave_up, p->d_dep + p->n_rels, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     DFQ_HIP_TRY(hipStreamSynchronize(st));
+    if (gave_up) {
+        set_error("dfq_le_query: a workgroup gave up waiting for the tiles it depends on (results are invalid)");
+        return DFQ_ERR_STATE;
+    }
     int32_t done = 1;
     for (int n = 0; n < p->n_nets; ++n) {
         if (out) {

@@ -91,6 +91,11 @@ class LEPlan:
         return _ffi.lib().dfq_le_plan_levels(self._plan)
 
     @property
+    def depth(self):
+        """dependency levels of the relation list (levels = equalisation launches per sweep: 1 unless DFQ_LE_MERGED=0)"""
+        return _ffi.lib().dfq_le_plan_depth(self._plan)
+
+    @property
     def paired_elements(self):
         return _ffi.lib().dfq_le_plan_paired_elements(self._plan)
 

@@ -114,8 +114,11 @@ int dfq_le_plan_create_batch(const dfq_layer* layers, int32_t n_layers, const in
 void dfq_le_plan_destroy(dfq_le_plan* plan);
 int32_t dfq_le_plan_nets(const dfq_le_plan* plan);
 
-/* introspection (tests, bench byte accounting) */
+/* introspection (tests, bench byte accounting).  levels: equalisation launches per sweep -- 1 (the whole sweep is one
+ * launch whose workgroups wait for the tiles they depend on) or, with DFQ_LE_MERGED=0 in the environment at plan
+ * creation, one per dependency level; depth: number of dependency levels of the relation list */
 int32_t dfq_le_plan_levels(const dfq_le_plan* plan);
+int32_t dfq_le_plan_depth(const dfq_le_plan* plan);
 int64_t dfq_le_plan_paired_elements(const dfq_le_plan* plan);   /* sum over relations of n1+n2  */
 /* per sweep: elements read AND written (8 B each) / elements only read by the statistics pass over
  * interior layers (4 B each); algorithmic bytes of a sweep = 8 * rw + 4 * ro */
@@ -124,8 +127,7 @@ int64_t dfq_le_plan_ro_elements(const dfq_le_plan* plan);
 /* the same two counts for one launch level; returns the number of relations in it */
 int32_t dfq_le_plan_level_launches(const dfq_le_plan* plan, int32_t level, int64_t* rw_elems,
                                    int64_t* ro_elems, int32_t* n_workgroups);
-/* launch geometry of a level.  Single-network plan: grid_x = tiles of its largest relation, grid_y = relations
- * (descriptors in the kernarg).  Batched plan: grid_x = working workgroups, grid_y = 1 (workgroup table). */
+/* launch geometry of launch `level` of a sweep: grid_x = its workgroups (all of them work), grid_y = 1 */
 int dfq_le_plan_level_grid(const dfq_le_plan* plan, int32_t level, int32_t* grid_x, int32_t* grid_y);
 
 /* Enqueue exactly `n_sweeps` sweeps plus their convergence bookkeeping on `stream`; never

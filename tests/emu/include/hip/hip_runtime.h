@@ -141,6 +141,10 @@ inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
 inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
 inline double atomicAdd(double* p, double v) { double o = *p; *p = o + v; return o; }
 
+#define __HIP_MEMORY_SCOPE_AGENT 4
+#define __hip_atomic_load(ptr, order, scope) (*(ptr))
+inline void __builtin_amdgcn_s_sleep(int) {}
+inline void __builtin_amdgcn_s_waitcnt(int) {}
 inline long long clock64() { return 0; }
 inline long long wall_clock64() { return 0; }
 inline unsigned __builtin_amdgcn_s_getreg(int) { return 0u; }
