@@ -232,6 +232,27 @@ __device__ __forceinline__ float abs_diff_if(bool on, float a, float b) {
     return __uint_as_float(__float_as_uint(d) & 0x7fffffffu);
 }
 
+// dependency of a workgroup inside a one-launch sweep (see le_level_kernel)
+struct LeDep {
+    const uint32_t* counters;
+    uint32_t* err;
+    int32_t sweep;
+    int32_t pad;
+};
+constexpr long kSpinLimit = 40000000;   // x (sleep + load) ~ several seconds
+__device__ __forceinline__ void dep_wait(const LeRelDev& R, const LeDep& dep) {
+    if (R.dep_idx < 0) return;                       // uniform
+    if (threadIdx.x == 0) {
+        const uint32_t target = (uint32_t)R.dep_tiles * (uint32_t)(dep.sweep + 1);
+        long spins = 0;
+        while (__hip_atomic_load(dep.counters + R.dep_idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > kSpinLimit) { atomicMax(dep.err, 1u); break; }
+        }
+    }
+    __syncthreads();
+}
+
 // sum_k |a[k] - b[k]| of one register slot in float64, or 0 when the slot is a clamped duplicate (`on` false).
 // One select per slot on the float64 sum; the magnitude is taken on the float32 difference by clearing the sign bit
 // (see abs_diff_if for why not fabs()).
@@ -283,7 +304,7 @@ __device__ __forceinline__ void vstore(gfloat* p, const float (&x)[VEC]) {
 
 // row tile: W1[r0:r0+nr, p0:p0+np] *= s[row]   (+ column stats of the new values)
 template <int VEC>
-__device__ __forceinline__ double row_tile(const LeRelDev& R, const LeParams& p, int tile, int cur,
+__device__ __forceinline__ double row_tile(const LeRelDev& R, const LeParams& p, int tile, int cur, const LeDep& dep,
                                            float* sh_s, uint32_t* sh_slot, int* sh_g, float* sh_pinv, const LeTrace& tr) {
     constexpr int NV = (VEC == 4) ? kSlotsVec4 : kSlotsVec1;   // vectors per thread
     const int tid = threadIdx.x;
@@ -305,15 +326,15 @@ __device__ __forceinline__ double row_tile(const LeRelDev& R, const LeParams& p,
     gfloat* const w = (gfloat*)R.w1 + ((int64_t)r0 * R.row_len + pos);
     const bool fused = R.w1_interior != 0;     // the column rescale of the previous relation is applied here too
 
-    // ---- the four statistics words of this thread's row go first: they are back long before the data and the
-    //      scale solve then overlaps the data's flight instead of queueing behind it (memory returns in order) ----
+    // ---- load order.  No dependency: the four statistics words of this thread's row go first -- they are back long
+    //      before the data and the scale solve then overlaps the data's flight instead of queueing behind it (memory
+    //      returns in order).  With a dependency the statistics do not exist yet: the data (which nobody writes before
+    //      this workgroup does) is requested first and arrives while the workgroup waits for its producers. ----
+    const bool waits = R.dep_idx >= 0;
     uint32_t wa0 = 0u, wa1 = 0u, wb0 = 0u, wb1 = 0u;
-    if (tid < nr) {
-        const guint* a = (const guint*)R.r1 + (int64_t)cur * R.stat_stride + 2 * (r0 + tid);
-        const guint* b = (const guint*)R.r2 + (int64_t)cur * R.stat_stride + 2 * (r0 + tid);
-        wa0 = ld_stat(a); wa1 = ld_stat(a + 1); wb0 = b[0]; wb1 = b[1];
-    }
-    // ---- then every data load ---------------------------------------------------------------------
+    const guint* const st_a = (const guint*)R.r1 + (int64_t)cur * R.stat_stride + 2 * (r0 + min(tid, nr - 1));
+    const guint* const st_b = (const guint*)R.r2 + (int64_t)cur * R.stat_stride + 2 * (r0 + min(tid, nr - 1));
+    if (!waits && tid < nr) { wa0 = ld_stat(st_a); wa1 = ld_stat(st_a + 1); wb0 = st_b[0]; wb1 = st_b[1]; }
     float v[NV][VEC];
 #pragma unroll
     for (int u = 0; u < NV; ++u) {
@@ -321,6 +342,10 @@ __device__ __forceinline__ double row_tile(const LeRelDev& R, const LeParams& p,
             const int r = min(jl + u * JL, nr - 1);
             vload<VEC>(w + r * R.row_len, v[u]);
         }
+    }
+    if (waits) {
+        dep_wait(R, dep);
+        if (tid < nr) { wa0 = ld_stat(st_a); wa1 = ld_stat(st_a + 1); wb0 = st_b[0]; wb1 = st_b[1]; }
     }
 
     // column-stat slot geometry of this tile
@@ -457,7 +482,7 @@ __device__ __forceinline__ double row_tile(const LeRelDev& R, const LeParams& p,
 // col tile: W2[r0:r0+nr, p0:p0+np] *= 1/s[input channel]   (+ row stats of the new values)
 // G = pow2 >= np/VEC lanes share a row; 256/G rows are in flight per register slot.
 template <int VEC>
-__device__ __forceinline__ double col_tile(const LeRelDev& R, const LeParams& p, int tile, int cur,
+__device__ __forceinline__ double col_tile(const LeRelDev& R, const LeParams& p, int tile, int cur, const LeDep& dep,
                                            float* sh_inv, uint32_t* sh_row, int* sh_tab, const LeTrace& tr) {
     constexpr int NV = (VEC == 4) ? kSlotsVec4 : kSlotsVec1;
     const int tid = threadIdx.x;
@@ -487,16 +512,16 @@ __device__ __forceinline__ double col_tile(const LeRelDev& R, const LeParams& p,
     const int nci = small_div(p0 + np - 1, R.khkw) - i0 + 1;
     const int g_lo = small_div(r0, R.go);
     const int g_n = small_div(r0 + nr - 1, R.go) - g_lo + 1;
-    // ---- the statistics words of this thread's table entry go first (see row_tile) ----
+    // ---- load order as in row_tile: statistics of this thread's table entry first, unless they are still being
+    //      produced -- then the data first, the wait, the statistics ----
+    const bool waits = R.dep_idx >= 0;
     uint32_t wa0 = 0u, wa1 = 0u, wb0 = 0u, wb1 = 0u;
-    if (tid < g_n * nci) {
-        const int gq = small_div(tid, nci);
-        const int c = (g_lo + gq) * R.gi + i0 + (tid - gq * nci);
-        const guint* a = (const guint*)R.r1 + (int64_t)cur * R.stat_stride + 2 * c;
-        const guint* b = (const guint*)R.r2 + (int64_t)cur * R.stat_stride + 2 * c;
-        wa0 = ld_stat(a); wa1 = ld_stat(a + 1); wb0 = b[0]; wb1 = b[1];
-    }
-    // ---- then every data load ---------------------------------------------------------------------
+    const bool has_entry = tid < g_n * nci;
+    const int e_gq = small_div(min(tid, g_n * nci - 1), nci);
+    const int e_c = (g_lo + e_gq) * R.gi + i0 + (min(tid, g_n * nci - 1) - e_gq * nci);
+    const guint* const st_a = (const guint*)R.r1 + (int64_t)cur * R.stat_stride + 2 * e_c;
+    const guint* const st_b = (const guint*)R.r2 + (int64_t)cur * R.stat_stride + 2 * e_c;
+    if (!waits && has_entry) { wa0 = ld_stat(st_a); wa1 = ld_stat(st_a + 1); wb0 = st_b[0]; wb1 = st_b[1]; }
     float v[NV][VEC];
 #pragma unroll
     for (int u = 0; u < NV; ++u) {
@@ -504,6 +529,10 @@ __device__ __forceinline__ double col_tile(const LeRelDev& R, const LeParams& p,
             const int r = min(grp + u * n_rowslots, nr - 1);
             vload<VEC>(w + r * row_len2, v[u]);
         }
+    }
+    if (waits) {
+        dep_wait(R, dep);
+        if (has_entry) { wa0 = ld_stat(st_a); wa1 = ld_stat(st_a + 1); wb0 = st_b[0]; wb1 = st_b[1]; }
     }
     stamp(tr, 2);
     for (int idx = tid; idx < g_n * nci; idx += kBlock) {      // one entry per thread for every plan-made tile
@@ -682,7 +711,6 @@ static_assert(sizeof(LeRelDev) % 4 == 0 && kDescWords + 1 <= kWave, "descriptor 
 #ifndef DFQ_LE_MIN_WAVES
 #define DFQ_LE_MIN_WAVES 1
 #endif
-constexpr long kSpinLimit = 40000000;   // x (sleep + load) ~ several seconds
 __global__ __launch_bounds__(kBlock, DFQ_LE_MIN_WAVES) void le_level_kernel(const LeRelDev* __restrict__ table,
                                                           const LeBlockRef* __restrict__ blocks, LeParams p, int sweep,
                                                           const LeState* __restrict__ state,
@@ -717,28 +745,18 @@ __global__ __launch_bounds__(kBlock, DFQ_LE_MIN_WAVES) void le_level_kernel(cons
     if (done || tile >= R.n_row_tiles + R.n_col_tiles) return;   // uniform
     stamp(tr, 1);
 
-    if (R.dep_idx >= 0) {
-        if (threadIdx.x == 0) {
-            const uint32_t target = (uint32_t)R.dep_tiles * (uint32_t)(sweep + 1);
-            long spins = 0;
-            while (__hip_atomic_load(dep_counters + R.dep_idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-                __builtin_amdgcn_s_sleep(1);
-                if (++spins > kSpinLimit) { atomicMax(err, 1u); break; }
-            }
-        }
-        __syncthreads();
-    }
+    const LeDep dep{dep_counters, err, sweep, 0};
 
     double acc;
     const bool col_side = tile >= R.n_row_tiles;
     if (!col_side) {
-        if (R.rt_vec == 0) acc = short_tile<0>(R, p, tile, cur);
-        else acc = R.rt_vec == 4 ? row_tile<4>(R, p, tile, cur, sh_f, sh_u, sh_g, sh_p, tr)
-                                 : row_tile<1>(R, p, tile, cur, sh_f, sh_u, sh_g, sh_p, tr);
+        if (R.rt_vec == 0) { dep_wait(R, dep); acc = short_tile<0>(R, p, tile, cur); }
+        else acc = R.rt_vec == 4 ? row_tile<4>(R, p, tile, cur, dep, sh_f, sh_u, sh_g, sh_p, tr)
+                                 : row_tile<1>(R, p, tile, cur, dep, sh_f, sh_u, sh_g, sh_p, tr);
     } else {
-        if (R.ct_vec == 0) acc = short_tile<1>(R, p, tile - R.n_row_tiles, cur);
-        else acc = R.ct_vec == 4 ? col_tile<4>(R, p, tile - R.n_row_tiles, cur, sh_f, sh_u, sh_g, tr)
-                                 : col_tile<1>(R, p, tile - R.n_row_tiles, cur, sh_f, sh_u, sh_g, tr);
+        if (R.ct_vec == 0) { dep_wait(R, dep); acc = short_tile<1>(R, p, tile - R.n_row_tiles, cur); }
+        else acc = R.ct_vec == 4 ? col_tile<4>(R, p, tile - R.n_row_tiles, cur, dep, sh_f, sh_u, sh_g, tr)
+                                 : col_tile<1>(R, p, tile - R.n_row_tiles, cur, dep, sh_f, sh_u, sh_g, tr);
     }
     stamp(tr, 6);
     if (col_side && R.counter_idx >= 0) {
