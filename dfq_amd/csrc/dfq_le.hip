@@ -239,14 +239,15 @@ struct LeDep {
     int32_t sweep;
     int32_t pad;
 };
-constexpr long kSpinLimit = 40000000;   // x (sleep + load) ~ several seconds
+constexpr long kSpinLimit = 4000000;    // x (sleep + load) ~ several seconds
+constexpr int kDepStride = 32;          // one counter per 128-byte line: hundreds of waiting workgroups poll them
 __device__ __forceinline__ void dep_wait(const LeRelDev& R, const LeDep& dep) {
     if (R.dep_idx < 0) return;                       // uniform
     if (threadIdx.x == 0) {
         const uint32_t target = (uint32_t)R.dep_tiles * (uint32_t)(dep.sweep + 1);
         long spins = 0;
-        while (__hip_atomic_load(dep.counters + R.dep_idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            __builtin_amdgcn_s_sleep(1);
+        while (__hip_atomic_load(dep.counters + (int64_t)R.dep_idx * kDepStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(16);                 // ~0.5 us between polls
             if (++spins > kSpinLimit) { atomicMax(dep.err, 1u); break; }
         }
     }
@@ -763,7 +764,7 @@ __global__ __launch_bounds__(kBlock, DFQ_LE_MIN_WAVES) void le_level_kernel(cons
         // every statistics atomic of this workgroup has been performed before the counter moves
         __builtin_amdgcn_s_waitcnt(0);
         __syncthreads();
-        if (threadIdx.x == 0) atomicAdd(dep_counters + R.counter_idx, 1u);
+        if (threadIdx.x == 0) atomicAdd(dep_counters + (int64_t)R.counter_idx * kDepStride, 1u);
     }
     // one partial per wave (fixed butterfly order -> deterministic), no workgroup barrier
     const double t = wave_sum(acc);
@@ -1234,7 +1235,18 @@ int dfq_le_plan_create_batch(const dfq_layer* layers, int32_t n_layers, const in
     // ---- sort relations by level (stable) and lay out the launches ----
     std::vector<int> order(n_relations);
     for (int r = 0; r < n_relations; ++r) order[r] = r;
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return level[a] < level[b]; });
+    // Inside a level the relations of the longest chains come first: in a one-launch sweep the tiles of the next
+    // level wait for exactly those, so the critical chain must not queue behind the independent short ones
+    // (MobileNetV2's five-relation chain sits at the END of the relation list).
+    std::vector<int> height(n_relations, 0);
+    for (int r = n_relations - 1; r >= 0; --r) {
+        const int j_next = as_first[relations[r].second];
+        height[r] = (j_next >= 0) ? height[j_next] + 1 : 0;
+    }
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+        if (level[a] != level[b]) return level[a] < level[b];
+        return height[a] > height[b];
+    });
     std::vector<LeRelDev> sorted(n_relations);
     int boot = 0, prev_level = -1;
     for (int i = 0; i < n_relations; ++i) {
@@ -1303,8 +1315,8 @@ int dfq_le_plan_create_batch(const dfq_layer* layers, int32_t n_layers, const in
         if ((e = hipMalloc((void**)&p->d_blocks, sizeof(LeBlockRef) * std::max<size_t>(1, blocks.size()))) != hipSuccess) return fail_alloc(e);
         if (!blocks.empty() &&
             (e = hipMemcpy(p->d_blocks, blocks.data(), sizeof(LeBlockRef) * blocks.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail_alloc(e);
-        if ((e = hipMalloc((void**)&p->d_dep, sizeof(uint32_t) * (n_relations + 1))) != hipSuccess) return fail_alloc(e);
-        if ((e = hipMemset(p->d_dep, 0, sizeof(uint32_t) * (n_relations + 1))) != hipSuccess) return fail_alloc(e);
+        if ((e = hipMalloc((void**)&p->d_dep, sizeof(uint32_t) * ((size_t)n_relations * kDepStride + 1))) != hipSuccess) return fail_alloc(e);
+        if ((e = hipMemset(p->d_dep, 0, sizeof(uint32_t) * ((size_t)n_relations * kDepStride + 1))) != hipSuccess) return fail_alloc(e);
         const char* me = getenv("DFQ_LE_MERGED");
         p->merged = !(me && me[0] == '0');
     }
@@ -1365,7 +1377,7 @@ static int le_restart(dfq_le_plan* p, const dfq_le_config* cfg, hipStream_t st) 
                        (int)cfg->converge_count, (int)cfg->max_sweeps);
     DFQ_CHECK_LAUNCH();
     p->sweep_index = 0;
-    DFQ_HIP_TRY(hipMemsetAsync(p->d_dep, 0, sizeof(uint32_t) * (p->n_rels + 1), st));
+    DFQ_HIP_TRY(hipMemsetAsync(p->d_dep, 0, sizeof(uint32_t) * ((size_t)p->n_rels * kDepStride + 1), st));
     if (p->n_rels > 0) {
         DFQ_HIP_TRY(hipMemsetAsync(p->d_stats, 0, sizeof(uint32_t) * 4 * p->stat_words, st));
         hipLaunchKernelGGL(le_bootstrap_kernel, dim3(p->boot_blocks), dim3(kBlock), 0, st,
@@ -1383,7 +1395,7 @@ static int le_launch_level(dfq_le_plan* p, int launch, const LeParams& q, hipStr
     if (count == 0) return DFQ_OK;
     hipLaunchKernelGGL(le_level_kernel, dim3(count), dim3(kBlock), 0, st, (const LeRelDev*)p->d_rels,
                        (const LeBlockRef*)(p->d_blocks + begin), q, (int)p->sweep_index, (const LeState*)p->d_state,
-                       p->d_partials, p->d_dep, p->d_dep + p->n_rels, tr);
+                       p->d_partials, p->d_dep, p->d_dep + (size_t)p->n_rels * kDepStride, tr);
     DFQ_CHECK_LAUNCH();
     return DFQ_OK;
 }
@@ -1566,7 +1578,7 @@ int dfq_le_query_all(dfq_le_plan* p, void* stream, dfq_le_result* out, int32_t* 
     hipStream_t st = as_stream(stream);
     uint32_t gave_up = 0;
     DFQ_HIP_TRY(hipMemcpyAsync(h.data(), p->d_state, sizeof(LeState) * p->n_nets, hipMemcpyDeviceToHost, st));
-    DFQ_HIP_TRY(hipMemcpyAsync(&gave_up, p->d_dep + p->n_rels, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    DFQ_HIP_TRY(hipMemcpyAsync(&gave_up, p->d_dep + (size_t)p->n_rels * kDepStride, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     DFQ_HIP_TRY(hipStreamSynchronize(st));
     if (gave_up) {
         set_error("dfq_le_query: a workgroup gave up waiting for the tiles it depends on (results are invalid)");
