@@ -114,6 +114,7 @@ constexpr int kAblate = DFQ_LE_ABLATE;
 struct LeParams {
     float s_lo, s_hi, inv_lo, inv_hi, eps;
     int32_t hi_gt_lo, signed_range;
+    int32_t poll_naps;      // s_sleep(8) units between two polls of a dependency counter
 };
 
 struct LeState {
@@ -241,13 +242,13 @@ struct LeDep {
 };
 constexpr long kSpinLimit = 4000000;    // x (sleep + load) ~ several seconds
 constexpr int kDepStride = 32;          // one counter per 128-byte line: hundreds of waiting workgroups poll them
-__device__ __forceinline__ void dep_wait(const LeRelDev& R, const LeDep& dep) {
+__device__ __forceinline__ void dep_wait(const LeRelDev& R, const LeDep& dep, int naps) {
     if (R.dep_idx < 0) return;                       // uniform
     if (threadIdx.x == 0) {
         const uint32_t target = (uint32_t)R.dep_tiles * (uint32_t)(dep.sweep + 1);
         long spins = 0;
         while (__hip_atomic_load(dep.counters + (int64_t)R.dep_idx * kDepStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            __builtin_amdgcn_s_sleep(16);                 // ~0.5 us between polls
+            for (int k = 0; k < naps; ++k) __builtin_amdgcn_s_sleep(8);   // default 2 naps: ~0.5 us between polls
             if (++spins > kSpinLimit) { atomicMax(dep.err, 1u); break; }
         }
     }
@@ -345,7 +346,7 @@ __device__ __forceinline__ double row_tile(const LeRelDev& R, const LeParams& p,
         }
     }
     if (waits) {
-        dep_wait(R, dep);
+        dep_wait(R, dep, p.poll_naps);
         if (tid < nr) { wa0 = ld_stat(st_a); wa1 = ld_stat(st_a + 1); wb0 = st_b[0]; wb1 = st_b[1]; }
     }
 
@@ -532,7 +533,7 @@ __device__ __forceinline__ double col_tile(const LeRelDev& R, const LeParams& p,
         }
     }
     if (waits) {
-        dep_wait(R, dep);
+        dep_wait(R, dep, p.poll_naps);
         if (has_entry) { wa0 = ld_stat(st_a); wa1 = ld_stat(st_a + 1); wb0 = st_b[0]; wb1 = st_b[1]; }
     }
     stamp(tr, 2);
@@ -751,11 +752,11 @@ __global__ __launch_bounds__(kBlock, DFQ_LE_MIN_WAVES) void le_level_kernel(cons
     double acc;
     const bool col_side = tile >= R.n_row_tiles;
     if (!col_side) {
-        if (R.rt_vec == 0) { dep_wait(R, dep); acc = short_tile<0>(R, p, tile, cur); }
+        if (R.rt_vec == 0) { dep_wait(R, dep, p.poll_naps); acc = short_tile<0>(R, p, tile, cur); }
         else acc = R.rt_vec == 4 ? row_tile<4>(R, p, tile, cur, dep, sh_f, sh_u, sh_g, sh_p, tr)
                                  : row_tile<1>(R, p, tile, cur, dep, sh_f, sh_u, sh_g, sh_p, tr);
     } else {
-        if (R.ct_vec == 0) { dep_wait(R, dep); acc = short_tile<1>(R, p, tile - R.n_row_tiles, cur); }
+        if (R.ct_vec == 0) { dep_wait(R, dep, p.poll_naps); acc = short_tile<1>(R, p, tile - R.n_row_tiles, cur); }
         else acc = R.ct_vec == 4 ? col_tile<4>(R, p, tile - R.n_row_tiles, cur, dep, sh_f, sh_u, sh_g, tr)
                                  : col_tile<1>(R, p, tile - R.n_row_tiles, cur, dep, sh_f, sh_u, sh_g, tr);
     }
@@ -1368,6 +1369,8 @@ static LeParams make_params(const dfq_le_config* c) {
     LeParams q;
     q.s_lo = c->s_lo; q.s_hi = c->s_hi; q.inv_lo = c->inv_lo; q.inv_hi = c->inv_hi; q.eps = c->eps;
     q.hi_gt_lo = c->hi_gt_lo; q.signed_range = c->signed_range;
+    const char* pe = getenv("DFQ_LE_POLL_NAPS");
+    q.poll_naps = (pe && atoi(pe) > 0) ? atoi(pe) : 2;
     return q;
 }
 
