@@ -1244,9 +1244,11 @@ int dfq_le_plan_create_batch(const dfq_layer* layers, int32_t n_layers, const in
         const int j_next = as_first[relations[r].second];
         height[r] = (j_next >= 0) ? height[j_next] + 1 : 0;
     }
+    const char* cf = getenv("DFQ_LE_CHAIN_FIRST");
+    const bool chain_first = !(cf && cf[0] == '0');
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
         if (level[a] != level[b]) return level[a] < level[b];
-        return height[a] > height[b];
+        return chain_first && height[a] > height[b];
     });
     std::vector<LeRelDev> sorted(n_relations);
     int boot = 0, prev_level = -1;
