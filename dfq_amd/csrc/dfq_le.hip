@@ -16,14 +16,15 @@
 //     relation, consumed one sweep later;
 //   * a layer that is only ever scaled one way (chain start / chain end) has its stats forwarded
 //     arithmetically: min' = fl(min * s), max' = fl(max * s) -- exact by monotonicity.
-// A sweep level is therefore ONE streaming launch: every element is read once and written once
-// (8 B per paired element), tiles are small independent 2-D blocks (any number of workgroups,
-// unit-stride 16-byte lanes), and the scale of a channel is re-derived from four stat words by
-// every tile that needs it (identical IEEE operations -> identical value everywhere).  Results
-// are bit-identical to the two-pass formulation because min/max are exact.
+// A sweep is therefore ONE streaming launch: every weight is read and written once (interior layers
+// are read once more, see below), tiles are small 2-D blocks (unit-stride 16-byte lanes), and the
+// scale of a channel is re-derived from four stat words by every tile that needs it (identical IEEE
+// operations -> identical value everywhere).  Results are bit-identical to the two-pass formulation
+// because min/max are exact.
 //
 //   level     = relations that share no layer (Gauss-Seidel order of dfq.py:85 kept between
-//               levels) = one launch of le_level_kernel;
+//               levels); the workgroups of a sweep are listed level after level and a workgroup
+//               waits for the tiles of the earlier relation it depends on (le_level_kernel);
 //   row tile  = [rt_rows x rt_cols] block of W1, scaled per row, emits per-input-channel stats;
 //   col tile  = [ct_rows x ct_cols] block of W2, scaled per input channel, emits per-row stats.
 //   In both, lanes run along the contiguous row positions and every thread walks down the rows

@@ -97,8 +97,9 @@ typedef struct dfq_le_result {
 } dfq_le_result;
 
 /* Builds the device-side work list: dependency levels of the relation list (Gauss-Seidel order of
- * dfq.py:85 is preserved: two relations sharing a layer are never in the same launch), channel
- * tiles, the per-layer convergence-diff bookkeeping.  `layers` / `relations` are host arrays and
+ * dfq.py:85 is preserved: of two relations sharing a layer the later one's tiles wait, inside the sweep's
+ * single launch, for the tiles of the earlier one they depend on), channel tiles, the per-layer
+ * convergence-diff bookkeeping.  `layers` / `relations` are host arrays and
  * are copied.  Allocates a few small device buffers (statistics words, partial sums, descriptors);
  * the weights are processed where they are.  Synchronises. */
 int dfq_le_plan_create(const dfq_layer* layers, int32_t n_layers,
