@@ -304,6 +304,29 @@ def test_equalization_tile_shapes(engine, monkeypatch, name, seed, suffix, tile_
         assert_bitexact(npy(r.get_scale_vec()), s)
 
 
+@pytest.mark.parametrize('merged,chain_first', [('0', '1'), ('1', '0'), ('0', '0')])
+def test_launch_modes_give_identical_results(engine, monkeypatch, merged, chain_first):
+    """One launch per sweep vs one per dependency level, longest-chain-first vs list order inside a level: the same
+    kernel, the same tiles, only the launch slicing / table order differ -- results are bit-identical."""
+    monkeypatch.setenv('DFQ_LE_MERGED', merged)
+    monkeypatch.setenv('DFQ_LE_CHAIN_FIRST', chain_first)
+    for name, seed in (('tiny_mobile', 0), ('tiny_res', 0)):
+        gold = net_fixture(name, seed, '')
+        model, graph, bottoms = _build(name, seed, gold, engine)
+        spec = graphspec.from_torch(graph, bottoms, TARG)
+        lt.merge_batchnorm(model, graph, bottoms, TARG)
+        orc.merge_batchnorm(spec)
+        rels = rel.create_relation(graph, bottoms, TARG)
+        plan = dfq.build_le_plan(graph, rels, TARG)
+        assert plan.levels == (1 if merged == '1' else plan.depth)
+        res = plan.run()
+        n_o, _ = orc.cross_layer_equalization(spec, orc.create_relation(spec))
+        assert res['sweeps'] == n_o
+        osnap, esnap = _spec_snapshot(spec), snapshot(graph)
+        for k in osnap:
+            assert_bitexact(esnap[k], osnap[k], '{} {} (merged={}, chain_first={})'.format(name, k, merged, chain_first))
+
+
 def test_batched_plan_matches_separate_runs(engine):
     """Several networks in one plan (every launch covers the batch): each network must end exactly
     where a plan of its own ends, including its own sweep count."""
