@@ -517,6 +517,34 @@ def test_host_resident_model_is_staged_and_written_back(engine):
 
 
 @pytest.mark.gpu
+def test_one_launch_sweep_is_stable_against_per_level_launches(monkeypatch):
+    """Stress for the in-launch dependency protocol (device-scope atomics + sc1 loads across XCDs): a batch of
+    full-size MobileNetV2 run several times with one launch per sweep must equal, bit for bit and every time, the
+    same batch run with one launch per dependency level (where every dependency is a kernel boundary)."""
+    dev = torch.device('cuda', 0)
+
+    def run(merged):
+        monkeypatch.setenv('DFQ_LE_MERGED', merged)
+        items = []
+        for seed in range(4):
+            model, graph, bottoms = synthetic.build('mobilenet_v2', seed=seed)
+            model.to(dev)
+            lt.merge_batchnorm(model, graph, bottoms, TARG)
+            items.append((graph, rel.create_relation(graph, bottoms, TARG)))
+        plan = dfq.build_le_plan_batch(items, TARG)
+        plan.run()
+        res, _ = plan.query_all()
+        return [r['sweeps'] for r in res], [snapshot(g) for g, _ in items]
+    sweeps_ref, snaps_ref = run('0')
+    for rep in range(3):
+        sweeps, snaps = run('1')
+        assert sweeps == sweeps_ref
+        for a, b in zip(snaps, snaps_ref):
+            for k in b:
+                assert_bitexact(a[k], b[k], 'repetition {} {}'.format(rep, k))
+
+
+@pytest.mark.gpu
 def test_heterogeneous_full_size_batch_matches_single_plans():
     """One batched plan over DIFFERENT architectures at full size (MobileNetV2, ResNet-18, a second MobileNetV2
     with other weights): every network must end bit-identical to a plan of its own -- weights, cumulative scales,
