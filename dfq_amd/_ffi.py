@@ -102,6 +102,7 @@ SIGNATURES = {
                                      POINTER(DfqBcSource), c_int32, POINTER(c_void_p)]),
     'dfq_bc_plan_destroy': (None, [c_void_p]),
     'dfq_bc_plan_run': (c_int32, [c_void_p, c_int32, c_void_p]),
+    'dfq_bc_plan_status': (c_int32, [c_void_p, c_void_p]),
     'dfq_bc_plan_eps': (c_void_p, [c_void_p, c_int32]),
     'dfq_bc_plan_correction': (c_void_p, [c_void_p, c_int32]),
     'dfq_bc_plan_weight_elements': (c_int64, [c_void_p]),

@@ -206,28 +206,40 @@ __device__ __forceinline__ int bc_small_div(int a, int b) {     // exact for 0 <
 // before the expectation vector is assembled.  The per-row tail -- bias update, next BN's beta~ and the
 // float64 ReLU moment behind it -- runs one row per THREAD after a barrier, so its long dependent
 // chain is paid once per workgroup instead of once per row.
+// One workgroup of a chain launch (the whole correction chain of every network in ONE launch): which step, which
+// workgroup of it, which counter to wait for (the previous step of the same network) and which to bump.
+struct BcChainRef {
+    int32_t step;          // index into the launch-major step table
+    int32_t block;         // workgroup inside the step
+    int32_t wait_idx;      // counter of the step this one depends on, or -1
+    int32_t wait_blocks;   // its workgroups
+};
+constexpr int kBcDepStride = 32;        // one counter per 128-byte line
+constexpr long kBcSpinLimit = 4000000;
+
+// values that another workgroup of the SAME launch may have written (a BN's beta~ and its cached ReLU moment):
+// device-scope accesses, see dfq_le.hip / tools/litmus
+__device__ __forceinline__ float ld_shared_f32(const float* p) {
+    return __uint_as_float(__hip_atomic_load((const uint32_t*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void st_shared_f32(float* p, float v) {
+    __hip_atomic_store((uint32_t*)p, __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+struct BcDep {            // null counters: every step is its own launch (dependencies are kernel boundaries)
+    uint32_t* counters;
+    uint32_t* err;
+    int32_t wait_idx, wait_blocks, bump_idx, pad;
+};
+
 template <int kExp>
-__global__ __launch_bounds__(kBlock) void bc_step_kernel(BcStepDev st_inline, const BcStepDev* __restrict__ table,
-                                                         const BcSourceDev* __restrict__ sources) {
-    __shared__ float sh_E[kExp];
-    __shared__ float sh_corr[kBlock];
+__device__ __forceinline__ void bc_step_body(const BcStepDev& st, int blk, const BcSourceDev* __restrict__ sources,
+                                             const BcDep& dep, float* sh_E, float* sh_corr) {
     const int tid = threadIdx.x;
     const int lane = tid % kWave;
     const int wave = tid / kWave;
-    union { BcStepDev st; uint32_t u[kStepWords]; } desc;
-    if (table) {
-        const guint* src = (const guint*)(table + blockIdx.y);
-        const uint32_t w0 = src[min(lane, kStepWords - 1)];
-        const uint32_t w1 = src[min(kWave + lane, kStepWords - 1)];
-#pragma unroll
-        for (int i = 0; i < kStepWords; ++i)
-            desc.u[i] = (i < kWave) ? __builtin_amdgcn_readlane(w0, i % kWave) : __builtin_amdgcn_readlane(w1, i % kWave);
-    } else {
-        desc.st = st_inline;
-    }
-    const BcStepDev& st = desc.st;
+    const bool chained = dep.counters != nullptr;
     const int rpb = st.rows_per_block;
-    if ((int)blockIdx.x * rpb >= st.out_ch) return;                // grid.x is sized for the largest step of the launch
     const int in = st.in_per_group;
     const int lanes = 1 << st.lg_lanes;
     const int rps = kWave >> st.lg_lanes;                          // rows per register slot
@@ -235,7 +247,7 @@ __global__ __launch_bounds__(kBlock) void bc_step_kernel(BcStepDev st_inline, co
     const int rw = rpb / kRowsPerBlock;                            // rows of this wave
     const int sub = lane >> st.lg_lanes;                           // row inside a slot
     const int ln = lane & (lanes - 1);
-    const int row0 = blockIdx.x * rpb + wave * rw;
+    const int row0 = blk * rpb + wave * rw;
     const int n_slots = min(kBcRegs, ((rw + rps - 1) >> (6 - st.lg_lanes)) * chunks);
     // ---- this wave's eps values go into registers first: the fetch overlaps the expectation build ----
     float ev[kBcRegs];
@@ -251,6 +263,20 @@ __global__ __launch_bounds__(kBlock) void bc_step_kernel(BcStepDev st_inline, co
             }
         }
     }
+    if (chained && dep.wait_idx >= 0) {
+        // the previous layer's correction feeds this expectation: wait for all its workgroups (the eps values
+        // requested above arrive meanwhile)
+        if (tid == 0) {
+            long spins = 0;
+            while (__hip_atomic_load(dep.counters + (int64_t)dep.wait_idx * kBcDepStride, __ATOMIC_RELAXED,
+                                     __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)dep.wait_blocks) {
+                __builtin_amdgcn_s_sleep(8);
+                __builtin_amdgcn_s_sleep(8);
+                if (++spins > kBcSpinLimit) { atomicMax(dep.err, 1u); break; }
+            }
+        }
+        __syncthreads();
+    }
     // ---- E[x]: first source assigns, 'cat' appends, anything else adds (dfq.py:229-270) ----
     int cur_len = 0;
     auto merge_source = [&](const BcSourceDev& s, int m) {
@@ -258,7 +284,7 @@ __global__ __launch_bounds__(kBlock) void bc_step_kernel(BcStepDev st_inline, co
         const int base = (m == 0) ? 0 : (s.concat ? cur_len : 0);
         const float* val = s.relu ? s.cache : s.fb;      // E[ReLU(N(beta, gamma^2))] or beta
         for (int i = tid; i < s.channels; i += kBlock) {
-            const float e = val[i];
+            const float e = chained ? ld_shared_f32(val + i) : val[i];
             if (assign) sh_E[base + i] = e;
             else sh_E[i] = sh_E[i] + e;
         }
@@ -317,18 +343,73 @@ __global__ __launch_bounds__(kBlock) void bc_step_kernel(BcStepDev st_inline, co
     }
     __syncthreads();
     // ---- one row per thread: dfq.py:290-293 and the refreshed ReLU moment of the next BN ----
-    const int o = blockIdx.x * rpb + tid;
+    const int o = blk * rpb + tid;
     if (tid < rpb && o < st.out_ch) {
         const float corr = sh_corr[tid];
         const float neg = -corr;
         st.corr[o] = corr;
         st.bias[o] = st.bias[o] + neg;                            // dfq.py:292
         if (st.next_bn_bias) {
-            const float nb = st.next_bn_bias[o] + neg;            // dfq.py:204-206, 293
-            st.next_bn_bias[o] = nb;
-            if (st.next_cache) st.next_cache[o] = relu_mean(st.next_bn_weight[o], nb);
+            const float nb = st.next_bn_bias[o] + neg;            // dfq.py:204-206, 293 (a BN's beta~ changes once)
+            const float moment = st.next_cache ? relu_mean(st.next_bn_weight[o], nb) : 0.0f;
+            if (chained) {
+                st_shared_f32(st.next_bn_bias + o, nb);
+                if (st.next_cache) st_shared_f32(st.next_cache + o, moment);
+            } else {
+                st.next_bn_bias[o] = nb;
+                if (st.next_cache) st.next_cache[o] = moment;
+            }
         }
     }
+    if (chained) {
+        __builtin_amdgcn_s_waitcnt(0);                            // the stores above have been performed
+        __syncthreads();
+        if (tid == 0) atomicAdd(dep.counters + (int64_t)dep.bump_idx * kBcDepStride, 1u);
+    }
+}
+
+// the two wave-wide loads + v_readlane that fetch a step descriptor from the table
+__device__ __forceinline__ void bc_load_step(const BcStepDev* __restrict__ entry, uint32_t (&u)[kStepWords]) {
+    const int lane = threadIdx.x % kWave;
+    const guint* src = (const guint*)entry;
+    const uint32_t w0 = src[min(lane, kStepWords - 1)];
+    const uint32_t w1 = src[min(kWave + lane, kStepWords - 1)];
+#pragma unroll
+    for (int i = 0; i < kStepWords; ++i)
+        u[i] = (i < kWave) ? __builtin_amdgcn_readlane(w0, i % kWave) : __builtin_amdgcn_readlane(w1, i % kWave);
+}
+
+// one launch per chain position (DFQ_BC_MERGED=0): grid (workgroups of the largest step, networks)
+template <int kExp>
+__global__ __launch_bounds__(kBlock) void bc_step_kernel(BcStepDev st_inline, const BcStepDev* __restrict__ table,
+                                                         const BcSourceDev* __restrict__ sources) {
+    __shared__ float sh_E[kExp];
+    __shared__ float sh_corr[kBlock];
+    union { BcStepDev st; uint32_t u[kStepWords]; } desc;
+    if (table) bc_load_step(table + blockIdx.y, desc.u);
+    else desc.st = st_inline;
+    if ((int)blockIdx.x * desc.st.rows_per_block >= desc.st.out_ch) return;     // grid.x is sized for the largest step of the launch
+    bc_step_body<kExp>(desc.st, blockIdx.x, sources, BcDep{nullptr, nullptr, -1, 0, -1, 0}, sh_E, sh_corr);
+}
+
+// the whole chain of every network in one launch: 1-D grid over (step, workgroup) in chain order; a workgroup waits
+// for the previous step of its network (lower indices only -> no deadlock, see dfq_le.hip)
+template <int kExp>
+__global__ __launch_bounds__(kBlock) void bc_chain_kernel(const BcStepDev* __restrict__ table,
+                                                          const BcChainRef* __restrict__ refs,
+                                                          const BcSourceDev* __restrict__ sources, uint32_t* counters,
+                                                          uint32_t* err) {
+    __shared__ float sh_E[kExp];
+    __shared__ float sh_corr[kBlock];
+    typedef int ivec4 __attribute__((vector_size(16)));
+    const ivec4 ref = *(const DFQ_GLOBAL_AS ivec4*)(refs + blockIdx.x);
+    const int step = __builtin_amdgcn_readfirstlane(ref[0]);
+    const int blk = __builtin_amdgcn_readfirstlane(ref[1]);
+    union { BcStepDev st; uint32_t u[kStepWords]; } desc;
+    bc_load_step(table + step, desc.u);
+    bc_step_body<kExp>(desc.st, blk, sources,
+                       BcDep{counters, err, __builtin_amdgcn_readfirstlane(ref[2]), __builtin_amdgcn_readfirstlane(ref[3]), step, 0},
+                       sh_E, sh_corr);
 }
 
 }  // namespace dfq
@@ -343,7 +424,11 @@ struct dfq_bc_plan {
     struct Launch { int begin, n, max_blocks, max_expect; };
     std::vector<Launch> launches;          // launch j = j-th step of every network
     std::vector<BcStepDev> launch_steps;   // launch-major copy (kernel argument by value for 1-step launches)
-    BcStepDev* d_steps = nullptr;          // launch_steps on the device (batched launches)
+    BcStepDev* d_steps = nullptr;          // launch_steps on the device
+    BcChainRef* d_refs = nullptr;          // workgroup table of the one-launch chain
+    uint32_t* d_counters = nullptr;        // per step: finished workgroups (padded), + error flag
+    int chain_blocks = 0, max_expect = 0;
+    bool merged = true;                    // one launch for the whole chain (false: one per chain position, DFQ_BC_MERGED=0)
     std::vector<const float*> eps_ptr;
     BcLayerDev* d_layers = nullptr;
     int32_t* d_mm_begin = nullptr;
@@ -373,6 +458,8 @@ void dfq_bc_plan_destroy(dfq_bc_plan* p) {
     if (p->d_cache) (void)hipFree(p->d_cache);
     if (p->d_cache_segs) (void)hipFree(p->d_cache_segs);
     if (p->d_steps) (void)hipFree(p->d_steps);
+    if (p->d_refs) (void)hipFree(p->d_refs);
+    if (p->d_counters) (void)hipFree(p->d_counters);
     for (auto& e : p->exec) if (e) (void)hipGraphExecDestroy(e);
     if (p->capture_stream) (void)hipStreamDestroy(p->capture_stream);
     delete p;
@@ -549,6 +636,28 @@ int dfq_bc_plan_create(const dfq_layer* layers, int32_t n_layers, const dfq_bc_s
         }
         if ((e = hipMalloc((void**)&p->d_steps, sizeof(BcStepDev) * n_steps)) != hipSuccess) return fail_alloc(e);
         if ((e = hipMemcpy(p->d_steps, p->launch_steps.data(), sizeof(BcStepDev) * n_steps, hipMemcpyHostToDevice)) != hipSuccess) return fail_alloc(e);
+        // workgroup table of the one-launch chain: chain position after chain position; step s2 waits for the previous
+        // step of its network (steps arrive network by network in graph order, so that is s2 - 1)
+        std::vector<int> pos(n_steps, 0), fill(n_launch, 0);
+        for (int s2 = 0; s2 < n_steps; ++s2) pos[s2] = p->launches[ordinal[s2]].begin + fill[ordinal[s2]]++;
+        std::vector<int> wait_of(n_steps, -1), blocks_of(n_steps, 0);
+        for (int s2 = 0; s2 < n_steps; ++s2) {
+            blocks_of[pos[s2]] = (p->steps[s2].out_ch + p->steps[s2].rows_per_block - 1) / p->steps[s2].rows_per_block;
+            if (ordinal[s2] > 0) wait_of[pos[s2]] = pos[s2 - 1];
+        }
+        std::vector<BcChainRef> refs;
+        for (int q = 0; q < n_steps; ++q) {
+            p->max_expect = std::max(p->max_expect, p->launch_steps[q].expect_len);
+            for (int b = 0; b < blocks_of[q]; ++b)
+                refs.push_back(BcChainRef{q, b, wait_of[q], wait_of[q] >= 0 ? blocks_of[wait_of[q]] : 0});
+        }
+        p->chain_blocks = (int)refs.size();
+        if ((e = hipMalloc((void**)&p->d_refs, sizeof(BcChainRef) * std::max<size_t>(1, refs.size()))) != hipSuccess) return fail_alloc(e);
+        if ((e = hipMemcpy(p->d_refs, refs.data(), sizeof(BcChainRef) * refs.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail_alloc(e);
+        if ((e = hipMalloc((void**)&p->d_counters, sizeof(uint32_t) * ((size_t)n_steps * kBcDepStride + 1))) != hipSuccess) return fail_alloc(e);
+        if ((e = hipMemset(p->d_counters, 0, sizeof(uint32_t) * ((size_t)n_steps * kBcDepStride + 1))) != hipSuccess) return fail_alloc(e);
+        const char* me = getenv("DFQ_BC_MERGED");
+        p->merged = !(me && me[0] == '0');
     }
     p->minmax_blocks = (int)mb; p->qerr_blocks = (int)qb;
     if ((e = hipMemcpy(p->d_layers, hl.data(), sizeof(BcLayerDev) * n_steps, hipMemcpyHostToDevice)) != hipSuccess) return fail_alloc(e);
@@ -597,6 +706,18 @@ static int bc_run_direct(dfq_bc_plan* p, int32_t symmetric, hipStream_t st) {
                            (const BcCacheSeg*)p->d_cache_segs, p->n_cache_segs, p->cache_total);
         DFQ_CHECK_LAUNCH();
     }
+    if (p->merged && p->chain_blocks > 0) {
+        DFQ_HIP_TRY(hipMemsetAsync(p->d_counters, 0, sizeof(uint32_t) * ((size_t)p->n_steps * kBcDepStride + 1), st));
+        uint32_t* err = p->d_counters + (size_t)p->n_steps * kBcDepStride;
+        if (p->max_expect <= kExpectSmall)
+            hipLaunchKernelGGL(bc_chain_kernel<kExpectSmall>, dim3(p->chain_blocks), dim3(kBlock), 0, st, (const BcStepDev*)p->d_steps,
+                               (const BcChainRef*)p->d_refs, (const BcSourceDev*)p->d_sources, p->d_counters, err);
+        else
+            hipLaunchKernelGGL(bc_chain_kernel<kExpectMax>, dim3(p->chain_blocks), dim3(kBlock), 0, st, (const BcStepDev*)p->d_steps,
+                               (const BcChainRef*)p->d_refs, (const BcSourceDev*)p->d_sources, p->d_counters, err);
+        DFQ_CHECK_LAUNCH();
+        return DFQ_OK;
+    }
     for (const auto& L : p->launches) {
         const BcStepDev* table = (L.n == 1) ? nullptr : p->d_steps + L.begin;
         if (L.max_expect <= kExpectSmall)
@@ -606,6 +727,21 @@ static int bc_run_direct(dfq_bc_plan* p, int32_t symmetric, hipStream_t st) {
             hipLaunchKernelGGL(bc_step_kernel<kExpectMax>, dim3(L.max_blocks, L.n), dim3(kBlock), 0, st,
                                p->launch_steps[L.begin], table, (const BcSourceDev*)p->d_sources);
         DFQ_CHECK_LAUNCH();
+    }
+    return DFQ_OK;
+}
+
+// Synchronises `stream` and reports whether a workgroup of the one-launch chain gave up waiting for the step it
+// depends on (a logic error surfaces here instead of as a hung GPU)
+int dfq_bc_plan_status(dfq_bc_plan* p, void* stream) {
+    if (!p) return fail_arg("dfq_bc_plan_status: null plan");
+    hipStream_t st = as_stream(stream);
+    uint32_t gave_up = 0;
+    DFQ_HIP_TRY(hipMemcpyAsync(&gave_up, p->d_counters + (size_t)p->n_steps * kBcDepStride, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    DFQ_HIP_TRY(hipStreamSynchronize(st));
+    if (gave_up) {
+        set_error("dfq_bc_plan_status: a workgroup gave up waiting for the previous correction step (results are invalid)");
+        return DFQ_ERR_STATE;
     }
     return DFQ_OK;
 }

@@ -412,8 +412,12 @@ class BCPlan:
     def eps_elements(self):
         return _ffi.lib().dfq_bc_plan_eps_elements(self._plan)
 
-    def run(self, signed=False):
+    def run(self, signed=False, check=False):
+        """Enqueue the whole correction (asynchronous).  ``check`` synchronises and raises if a workgroup of the
+        one-launch chain gave up waiting for the step it depends on."""
         _ffi.check(_ffi.lib().dfq_bc_plan_run(self._plan, int(bool(signed)), _ffi.stream_arg()))
+        if check:
+            _ffi.check(_ffi.lib().dfq_bc_plan_status(self._plan, _ffi.stream_arg()))
 
     def _view(self, addr, n):
         """Copy n floats out of the plan's device scratch (tests / debugging)."""
@@ -528,8 +532,7 @@ def bias_correction(graph, bottoms, targ_type, bits_weight=8, bn_type=torch.nn.B
         stage = _ffi.Stage()
         plan, _ = build_bc_plan(graph, bottoms, targ_type, bn_type, stage=stage)
         try:
-            plan.run(signed=signed)
-            _ffi.synchronize()
+            plan.run(signed=signed, check=True)
         finally:
             plan.close()
         stage.writeback()

@@ -259,6 +259,10 @@ void dfq_bc_plan_destroy(dfq_bc_plan* plan);
  * (8 bit, dfq.py:218-219) -> the sequential per-layer chain.  Asynchronous. */
 int dfq_bc_plan_run(dfq_bc_plan* plan, int32_t symmetric, void* stream);
 /* device pointers into the plan's scratch (tests): eps[O*I/g], expect[len], bias[O] of a step */
+/* Synchronises `stream`; DFQ_ERR_STATE if a workgroup of the last run gave up waiting for the correction step it
+ * depends on (the chain of all layers is ONE launch whose workgroups wait for the previous layer's; the wait is
+ * bounded).  DFQ_BC_MERGED=0 in the environment at plan creation restores one launch per layer. */
+int dfq_bc_plan_status(dfq_bc_plan* plan, void* stream);
 const float* dfq_bc_plan_eps(const dfq_bc_plan* plan, int32_t step);
 const float* dfq_bc_plan_correction(const dfq_bc_plan* plan, int32_t step);
 int64_t dfq_bc_plan_weight_elements(const dfq_bc_plan* plan);

@@ -143,6 +143,7 @@ inline double atomicAdd(double* p, double v) { double o = *p; *p = o + v; return
 
 #define __HIP_MEMORY_SCOPE_AGENT 4
 #define __hip_atomic_load(ptr, order, scope) (*(ptr))
+#define __hip_atomic_store(ptr, val, order, scope) (*(ptr) = (val))
 inline void __builtin_amdgcn_s_sleep(int) {}
 inline void __builtin_amdgcn_s_waitcnt(int) {}
 inline long long clock64() { return 0; }
