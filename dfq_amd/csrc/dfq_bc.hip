@@ -215,7 +215,7 @@ struct BcChainRef {
     int32_t wait_blocks;   // its workgroups
 };
 constexpr int kBcDepStride = 32;        // one counter per 128-byte line
-constexpr long kBcSpinLimit = 4000000;
+constexpr long kBcSpinLimit = 20000000;
 
 // values that another workgroup of the SAME launch may have written (a BN's beta~ and its cached ReLU moment):
 // device-scope accesses, see dfq_le.hip / tools/litmus
@@ -263,6 +263,16 @@ __device__ __forceinline__ void bc_step_body(const BcStepDev& st, int blk, const
             }
         }
     }
+    // the per-row operands of the tail (this layer's bias, the next BN's beta~ and gamma~) do not depend on the previous
+    // step either: requested now, they are back before the matvec is done
+    const int o_tail = blk * rpb + tid;
+    const bool tail_on = tid < rpb && o_tail < st.out_ch;
+    float pre_bias = 0.0f, pre_nb = 0.0f, pre_nw = 0.0f;
+    if (tail_on) {
+        pre_bias = st.bias[o_tail];
+        if (st.next_bn_bias) pre_nb = st.next_bn_bias[o_tail];
+        if (st.next_cache) pre_nw = st.next_bn_weight[o_tail];
+    }
     if (chained && dep.wait_idx >= 0) {
         // the previous layer's correction feeds this expectation: wait for all its workgroups (the eps values
         // requested above arrive meanwhile)
@@ -270,8 +280,7 @@ __device__ __forceinline__ void bc_step_body(const BcStepDev& st, int blk, const
             long spins = 0;
             while (__hip_atomic_load(dep.counters + (int64_t)dep.wait_idx * kBcDepStride, __ATOMIC_RELAXED,
                                      __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)dep.wait_blocks) {
-                __builtin_amdgcn_s_sleep(8);
-                __builtin_amdgcn_s_sleep(8);
+                __builtin_amdgcn_s_sleep(2);               // few waiters here (one step's workgroups): poll briskly
                 if (++spins > kBcSpinLimit) { atomicMax(dep.err, 1u); break; }
             }
         }
@@ -343,15 +352,15 @@ __device__ __forceinline__ void bc_step_body(const BcStepDev& st, int blk, const
     }
     __syncthreads();
     // ---- one row per thread: dfq.py:290-293 and the refreshed ReLU moment of the next BN ----
-    const int o = blk * rpb + tid;
-    if (tid < rpb && o < st.out_ch) {
+    const int o = o_tail;
+    if (tail_on) {
         const float corr = sh_corr[tid];
         const float neg = -corr;
         st.corr[o] = corr;
-        st.bias[o] = st.bias[o] + neg;                            // dfq.py:292
+        st.bias[o] = pre_bias + neg;                              // dfq.py:292
         if (st.next_bn_bias) {
-            const float nb = st.next_bn_bias[o] + neg;            // dfq.py:204-206, 293 (a BN's beta~ changes once)
-            const float moment = st.next_cache ? relu_mean(st.next_bn_weight[o], nb) : 0.0f;
+            const float nb = pre_nb + neg;                        // dfq.py:204-206, 293 (a BN's beta~ changes once)
+            const float moment = st.next_cache ? relu_mean(pre_nw, nb) : 0.0f;
             if (chained) {
                 st_shared_f32(st.next_bn_bias + o, nb);
                 if (st.next_cache) st_shared_f32(st.next_cache + o, moment);
