@@ -530,6 +530,8 @@ def bias_correction(graph, bottoms, targ_type, bits_weight=8, bn_type=torch.nn.B
     print("Start bias correction")
     with torch.no_grad():
         stage = _ffi.Stage()
+        if not _bc_tables(graph, bottoms, targ_type, bn_type)[1]:
+            return                                       # no layer behind a BN: nothing to correct (dfq.py:197-199)
         plan, _ = build_bc_plan(graph, bottoms, targ_type, bn_type, stage=stage)
         try:
             plan.run(signed=signed, check=True)

@@ -60,3 +60,34 @@ def test_bias_correction_plan_validation(engine):
     plan = ctypes.c_void_p()
     assert lib.dfq_bc_plan_create(layers, 1, steps, 1, sources, 1, ctypes.byref(plan)) == -1
     assert b'expectation length' in lib.dfq_last_error()
+
+
+def test_degenerate_inputs_are_handled(engine):
+    """No relations at all (a network whose layers cannot be paired), a single relation of single-channel layers, a
+    correction of a one-layer network: nothing to equalise is not an error."""
+    import torch.nn as nn
+    from dfq_amd.utils import layer_transform as lt
+    from dfq_amd.utils import relation as rel
+    from dfq_amd import fxgraph
+    TARG = [nn.Conv2d, nn.Linear]
+    # (1) empty relation list: the reference's loop runs until its convergence test fires on diff == 0
+    w = _w(engine, 4, 3, 1, 1)
+    plan = dfq.LEPlan([(w, None, 1)], [])
+    before = w.clone()
+    res = plan.run()
+    assert res['sweeps'] >= 1 and torch.equal(w, before)
+    # (2) one pair of 1-channel layers
+    w1, w2 = _w(engine, 1, 1, 1, 1), _w(engine, 1, 1, 1, 1)
+    p1, p2 = float(w1.flatten()[0] * w2.flatten()[0]), None
+    plan = dfq.LEPlan([(w1, None, 1), (w2, None, 1)], [(0, 1, None, None, torch.ones(1, device=engine.device))])
+    plan.run(max_sweeps=3)
+    assert abs(float(w1.flatten()[0] * w2.flatten()[0]) - p1) <= 1e-6 * abs(p1)      # the product is invariant
+    # (3) a network with one conv + BN: no relation, one correction step
+    torch.manual_seed(0)
+    net = nn.Sequential(nn.Conv2d(3, 4, 3, padding=1), nn.BatchNorm2d(4), nn.ReLU()).to(engine.device).eval()
+    graph, bottoms = fxgraph.trace(net)
+    lt.merge_batchnorm(net, graph, bottoms, TARG)
+    rels = rel.create_relation(graph, bottoms, TARG)
+    assert rels == []
+    dfq.cross_layer_equalization(graph, rels, TARG)
+    dfq.bias_correction(graph, bottoms, TARG)          # first layer is fed by 'Data': nothing to correct, must not fail
