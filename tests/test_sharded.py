@@ -194,3 +194,38 @@ def test_components_and_assignment():
         assert len(owner) == len(rels) and all(0 <= o < world for o in owner)
         for c in comps:
             assert len({owner[i] for i in c}) == 1, 'a component stays on one rank'
+
+
+@pytest.mark.gpu
+def test_sharded_path_over_rccl_single_rank():
+    """The RCCL ('nccl') branch of the sharded path on a real GPU: world size 1 (the GPU box has one device) -- the
+    collectives, the device-side scale exchange and the engine's per-rank sweeps run for real; the result must equal
+    the plain single-GPU equalisation bit for bit (one rank owns every component)."""
+    from dfq_amd import dfq
+    from dfq_amd.utils import layer_transform as lt
+    from common import snapshot
+    dev = torch.device('cuda', 0)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(_free_port())
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+    try:
+        out = []
+        for use_sharded in (True, False):
+            model, graph, bottoms = synthetic.build('tiny_mobile', seed=0)
+            model.to(dev)
+            lt.merge_batchnorm(model, graph, bottoms, TARG)
+            rels = rel.create_relation(graph, bottoms, TARG)
+            if use_sharded:
+                sweeps = sharded.sharded_cross_layer_equalization(graph, rels, TARG, max_sweeps=5)
+            else:
+                dfq.cross_layer_equalization(graph, rels, TARG, max_sweeps=5, converge_thres=-1.0, converge_count=10 ** 9)
+                sweeps = dfq.last_equalization['sweeps']
+            out.append((sweeps, snapshot(graph), [npy(r.get_scale_vec()) for r in rels]))
+        assert out[0][0] == out[1][0] == 5
+        for k in out[1][1]:
+            assert_bitexact(out[0][1][k], out[1][1][k], k)
+        for a, b in zip(out[0][2], out[1][2]):
+            assert_bitexact(a, b, 'S')
+    finally:
+        dist.destroy_process_group()
