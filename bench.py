@@ -25,6 +25,7 @@ CPU port of the reference's algorithm, timed on this host).
 from __future__ import annotations
 
 import argparse
+import contextlib
 import copy
 import json
 import os
@@ -126,6 +127,21 @@ def _pmc_traffic(net, batch):
 _BACKEND = 'nccl'
 
 
+@contextlib.contextmanager
+def _stdout_to_stderr():
+    """File-descriptor level: whatever native libraries print to stdout inside the block goes to stderr, so that the
+    one JSON line stays the only thing on rank 0's stdout."""
+    sys.stdout.flush()
+    saved = os.dup(1)
+    try:
+        os.dup2(2, 1)
+        yield
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
+
+
 def _device(local_rank):
     assert torch.cuda.is_available(), 'bench.py needs a ROCm GPU'
     torch.cuda.set_device(local_rank)
@@ -173,10 +189,12 @@ def main():
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        if _BACKEND == 'nccl':                             # RCCL over xGMI: one rank per GPU
-            dist.init_process_group('nccl', device_id=dev)
-        else:                                              # CPU dry run of the multi-rank path (tests/emu/dryrun.py)
-            dist.init_process_group(_BACKEND)
+        with _stdout_to_stderr():                          # RCCL prints a version banner to stdout at start-up
+            if _BACKEND == 'nccl':                         # RCCL over xGMI: one rank per GPU
+                dist.init_process_group('nccl', device_id=dev)
+            else:                                          # CPU dry run of the multi-rank path (tests/emu/dryrun.py)
+                dist.init_process_group(_BACKEND)
+            dist.barrier()                                 # communicators are created lazily: do it here
 
     from dfq_amd import _ffi
     _ffi.lib()
