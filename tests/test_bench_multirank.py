@@ -32,3 +32,31 @@ def test_two_ranks_weak_scaling_line():
     d = json.loads(lines[0])
     assert d['n_gpus'] == 2 and d['scaling'] == 'weak' and d['config']['networks_per_step'] == 4
     assert d['value'] > 0 and d['vs_baseline'] is None and 'cpu_baseline' not in d     # CPU baseline: N=1 only
+
+
+def test_bench_line_contract_single_rank():
+    """The JSON line of bench.py (dry run on the emulator, tiny net): every field the measurement contract names."""
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE'):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'emu', 'dryrun.py')], env=env, cwd=ROOT,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+                'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert key in d, key
+    assert d['unit'] == 'weights/s' and d['higher_is_better'] is True and d['scaling'] == 'weak' and d['vs_baseline'] is None
+    assert d['dtype'] == 'f32' and d['data'] == 'synthetic' and d['n_gpus'] == 1
+    assert 'workload' in d['config'] and 'model' not in d['config']
+    r = d['roofline']
+    for key in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
+        assert key in r, key
+    assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and r['peak'] == 8000.0 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9
+    c = d['cpu_baseline']
+    for key in ('value', 'unit', 'cores', 'kind', 'sample'):
+        assert key in c, key
+    assert c['kind'] == 'port' and c['cores'] == 1 and c['unit'] == 'weights/s'
+    assert abs(d['value'] - d['config']['networks_per_step'] * 5000 / (d['ms_per_step'] * 1e-3)) < 1e-6 * d['value']
