@@ -1446,10 +1446,11 @@ int dfq_le_enqueue(dfq_le_plan* p, const dfq_le_config* cfg, int32_t n_sweeps, i
     hipStream_t st = as_stream(stream);
     if (!graphs_enabled() || n_sweeps < 2) return le_enqueue_direct(p, cfg, n_sweeps, restart, st);
     // A whole run of sweeps is a few hundred dependent launches with arguments that only depend on
-    // (config, sweep parity): record it once on a private stream, replay it as one graph launch.
+    // (config, index of the first sweep -- the dependency counters count up from the last restart): record it
+    // once on a private stream, replay it as one graph launch.
     const int64_t start_index = restart ? 0 : p->sweep_index;
     std::vector<unsigned char> key(sizeof(int32_t) * 3 + sizeof(dfq_le_config));
-    const int32_t head[3] = {n_sweeps, restart ? 1 : 0, (int32_t)(start_index & 1)};
+    const int32_t head[3] = {n_sweeps, restart ? 1 : 0, (int32_t)start_index};
     memcpy(key.data(), head, sizeof(head));
     memcpy(key.data() + sizeof(head), cfg, sizeof(dfq_le_config));
     hipGraphExec_t exec = nullptr;
