@@ -236,21 +236,21 @@ __device__ __forceinline__ float abs_diff_if(bool on, float a, float b) {
 
 // dependency of a workgroup inside a one-launch sweep (see le_level_kernel)
 struct LeDep {
-    const uint32_t* counters;
-    uint32_t* err;
+    const unsigned long long* counters;   // 64-bit: tiles x sweeps outgrows 32 bits on runs with a large sweep cap
+    unsigned long long* err;
     int32_t sweep;
     int32_t pad;
 };
 constexpr long kSpinLimit = 4000000;    // x (sleep + load) ~ several seconds
-constexpr int kDepStride = 32;          // one counter per 128-byte line: hundreds of waiting workgroups poll them
+constexpr int kDepStride = 16;          // one 64-bit counter per 128-byte line: hundreds of waiting workgroups poll them
 __device__ __forceinline__ void dep_wait(const LeRelDev& R, const LeDep& dep, int naps) {
     if (R.dep_idx < 0) return;                       // uniform
     if (threadIdx.x == 0) {
-        const uint32_t target = (uint32_t)R.dep_tiles * (uint32_t)(dep.sweep + 1);
+        const unsigned long long target = (unsigned long long)R.dep_tiles * (unsigned long long)(dep.sweep + 1);
         long spins = 0;
         while (__hip_atomic_load(dep.counters + (int64_t)R.dep_idx * kDepStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
             for (int k = 0; k < naps; ++k) __builtin_amdgcn_s_sleep(8);   // default 2 naps: ~0.5 us between polls
-            if (++spins > kSpinLimit) { atomicMax(dep.err, 1u); break; }
+            if (++spins > kSpinLimit) { atomicMax(dep.err, 1ull); break; }
         }
     }
     __syncthreads();
@@ -717,8 +717,8 @@ static_assert(sizeof(LeRelDev) % 4 == 0 && kDescWords + 1 <= kWave, "descriptor 
 __global__ __launch_bounds__(kBlock, DFQ_LE_MIN_WAVES) void le_level_kernel(const LeRelDev* __restrict__ table,
                                                           const LeBlockRef* __restrict__ blocks, LeParams p, int sweep,
                                                           const LeState* __restrict__ state,
-                                                          double* __restrict__ partials, uint32_t* dep_counters,
-                                                          uint32_t* err, LeTrace tr) {
+                                                          double* __restrict__ partials, unsigned long long* dep_counters,
+                                                          unsigned long long* err, LeTrace tr) {
     stamp(tr, 0);
     __shared__ float sh_f[kSlotMax];                // row tile: scales; col tile: 1/s table
     __shared__ uint32_t sh_u[2 * kSlotMax];         // row tile: column-stat slots; col tile: row stats
@@ -766,7 +766,7 @@ __global__ __launch_bounds__(kBlock, DFQ_LE_MIN_WAVES) void le_level_kernel(cons
         // every statistics atomic of this workgroup has been performed before the counter moves
         __builtin_amdgcn_s_waitcnt(0);
         __syncthreads();
-        if (threadIdx.x == 0) atomicAdd(dep_counters + (int64_t)R.counter_idx * kDepStride, 1u);
+        if (threadIdx.x == 0) atomicAdd(dep_counters + (int64_t)R.counter_idx * kDepStride, 1ull);
     }
     // one partial per wave (fixed butterfly order -> deterministic), no workgroup barrier
     const double t = wave_sum(acc);
@@ -986,7 +986,7 @@ struct dfq_le_plan {
     std::vector<CachedGraph> graphs;
     LeRelDev* d_rels = nullptr;
     LeBlockRef* d_blocks = nullptr;        // workgroup table of a sweep: level after level
-    uint32_t* d_dep = nullptr;             // per-relation counters of finished column tiles + [n_rels] = error flag
+    unsigned long long* d_dep = nullptr;   // per-relation counters of finished column tiles (padded) + error flag
     bool merged = true;                    // one launch per sweep (false: one per level, DFQ_LE_MERGED=0)
     LeLayerDiff* d_layer_diff = nullptr;
     double* d_partials = nullptr;
@@ -1319,8 +1319,8 @@ int dfq_le_plan_create_batch(const dfq_layer* layers, int32_t n_layers, const in
         if ((e = hipMalloc((void**)&p->d_blocks, sizeof(LeBlockRef) * std::max<size_t>(1, blocks.size()))) != hipSuccess) return fail_alloc(e);
         if (!blocks.empty() &&
             (e = hipMemcpy(p->d_blocks, blocks.data(), sizeof(LeBlockRef) * blocks.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail_alloc(e);
-        if ((e = hipMalloc((void**)&p->d_dep, sizeof(uint32_t) * ((size_t)n_relations * kDepStride + 1))) != hipSuccess) return fail_alloc(e);
-        if ((e = hipMemset(p->d_dep, 0, sizeof(uint32_t) * ((size_t)n_relations * kDepStride + 1))) != hipSuccess) return fail_alloc(e);
+        if ((e = hipMalloc((void**)&p->d_dep, sizeof(unsigned long long) * ((size_t)n_relations * kDepStride + 1))) != hipSuccess) return fail_alloc(e);
+        if ((e = hipMemset(p->d_dep, 0, sizeof(unsigned long long) * ((size_t)n_relations * kDepStride + 1))) != hipSuccess) return fail_alloc(e);
         const char* me = getenv("DFQ_LE_MERGED");
         p->merged = !(me && me[0] == '0');
     }
@@ -1383,7 +1383,7 @@ static int le_restart(dfq_le_plan* p, const dfq_le_config* cfg, hipStream_t st) 
                        (int)cfg->converge_count, (int)cfg->max_sweeps);
     DFQ_CHECK_LAUNCH();
     p->sweep_index = 0;
-    DFQ_HIP_TRY(hipMemsetAsync(p->d_dep, 0, sizeof(uint32_t) * ((size_t)p->n_rels * kDepStride + 1), st));
+    DFQ_HIP_TRY(hipMemsetAsync(p->d_dep, 0, sizeof(unsigned long long) * ((size_t)p->n_rels * kDepStride + 1), st));
     if (p->n_rels > 0) {
         DFQ_HIP_TRY(hipMemsetAsync(p->d_stats, 0, sizeof(uint32_t) * 4 * p->stat_words, st));
         hipLaunchKernelGGL(le_bootstrap_kernel, dim3(p->boot_blocks), dim3(kBlock), 0, st,
@@ -1583,9 +1583,9 @@ int dfq_le_query_all(dfq_le_plan* p, void* stream, dfq_le_result* out, int32_t* 
     if (!p) return fail_arg("dfq_le_query: null plan");
     std::vector<LeState> h(p->n_nets);
     hipStream_t st = as_stream(stream);
-    uint32_t gave_up = 0;
+    unsigned long long gave_up = 0;
     DFQ_HIP_TRY(hipMemcpyAsync(h.data(), p->d_state, sizeof(LeState) * p->n_nets, hipMemcpyDeviceToHost, st));
-    DFQ_HIP_TRY(hipMemcpyAsync(&gave_up, p->d_dep + (size_t)p->n_rels * kDepStride, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    DFQ_HIP_TRY(hipMemcpyAsync(&gave_up, p->d_dep + (size_t)p->n_rels * kDepStride, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     DFQ_HIP_TRY(hipStreamSynchronize(st));
     if (gave_up) {
         set_error("dfq_le_query: a workgroup gave up waiting for the tiles it depends on (results are invalid)");

@@ -139,6 +139,8 @@ inline unsigned atomicMax(unsigned* p, unsigned v) { unsigned o = *p; if (v > o)
 inline unsigned atomicMin(unsigned* p, unsigned v) { unsigned o = *p; if (v < o) *p = v; return o; }
 inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
 inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
+inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; *p = o + v; return o; }
+inline unsigned long long atomicMax(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; if (v > o) *p = v; return o; }
 inline double atomicAdd(double* p, double v) { double o = *p; *p = o + v; return o; }
 
 #define __HIP_MEMORY_SCOPE_AGENT 4
