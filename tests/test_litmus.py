@@ -1,0 +1,29 @@
+"""Hardware litmus test of the protocol the one-launch sweep and the one-launch correction chain rely on
+(tools/litmus/xcd_flag.hip, built by __graft_entry__.build()): words published with device-scope atomics and a
+counter bumped after `s_waitcnt 0` are read correctly by workgroups on other XCDs that spin on the counter and load
+with device-scope loads -- without fences; the same exchange with plain stores / loads is NOT coherent."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, 'tools', 'litmus', 'xcd_flag')
+
+
+def _run(mode, launches):
+    out = subprocess.run([BIN, str(mode), str(launches)], capture_output=True, text=True, timeout=120, check=True).stdout
+    m = re.search(r'(\d+) stale words, (\d+) give-ups', out)
+    assert m, out
+    return int(m.group(1)), int(m.group(2))
+
+
+@pytest.mark.gpu
+def test_device_scope_protocol_is_coherent_across_xcds():
+    if not os.path.exists(BIN):
+        pytest.skip('tools/litmus/xcd_flag not built (python -c "import __graft_entry__ as g; g.build()")')
+    stale, gave_up = _run(0, 2000)
+    assert stale == 0 and gave_up == 0
+    stale_plain, _ = _run(1, 200)
+    assert stale_plain > 0, 'plain stores/loads were expected to be incoherent across XCDs within a launch'
