@@ -81,6 +81,55 @@ def _engine_rescale(weight, bias, bn, s_out, s_in, groups):
     stage.writeback()
 
 
+class _EngineSession:
+    """The owned relations of this rank as ONE engine plan that stays alive for the whole run: the statistics are
+    bootstrapped once, sweeps are enqueued one by one (or all at once), the weights are written back once.  The
+    device-side loop state is configured never to stop by itself (threshold -1, no sweep cap): the stopping rule
+    of dfq.py:83-115 needs the sum over ALL ranks and is evaluated by the caller."""
+
+    def __init__(self, graph, relations, targ_type, s_range, signed, eps):
+        self.graph, self.relations = graph, relations
+        self.cfg = dict(s_range=tuple(s_range), signed=signed, eps=eps, converge_thres=-1.0, converge_count=10 ** 9,
+                        max_sweeps=None)
+        self.stage = _ffi.Stage()
+        self.plan = _dfq.build_le_plan(graph, relations, targ_type, stage=self.stage)
+        self.plan.enqueue(0, restart=True, **self.cfg)
+
+    def sweeps(self, n):
+        self.plan.enqueue(int(n), restart=False, **self.cfg)
+
+    def last_diff(self):
+        """sum over the owned layers of mean|W - W_prev| of the latest sweep (one small device-to-host copy)."""
+        return self.plan.query()['last_diff_tmp']
+
+    def close(self):
+        try:
+            self.plan.query()                      # synchronises and surfaces a failed in-launch wait
+            self.stage.writeback()
+            for rr, sc in zip(self.relations, self.plan.scale_cum):
+                rr.S = self.stage.out_like(self.graph[rr.get_idxs()[0]].weight, sc)
+        finally:
+            self.plan.close()
+
+
+class _RunnerSession:
+    """Adapter for an injected ``le_runner`` (tests): every call equalises the relations for n more sweeps."""
+
+    def __init__(self, runner, graph, relations, targ_type, s_range, signed, eps):
+        self.run = lambda n: runner(graph, relations, targ_type, max_sweeps=n, converge_thres=-1.0,
+                                    converge_count=10 ** 9, s_range=list(s_range), signed=signed, eps=eps)
+        self.res = None
+
+    def sweeps(self, n):
+        self.res = self.run(int(n))
+
+    def last_diff(self):
+        return self.res['last_diff_tmp']
+
+    def close(self):
+        pass
+
+
 def sharded_cross_layer_equalization(graph, relations, targ_type, group=None, s_range=(1e-8, 1e8),
                                      converge_thres=2e-7, converge_count=20, signed=False, eps=0,
                                      max_sweeps=None, le_runner=None, rescale=None):
@@ -89,45 +138,54 @@ def sharded_cross_layer_equalization(graph, relations, targ_type, group=None, s_
     ``le_runner(graph, relations, targ_type, max_sweeps=..., **kw) -> dict`` and
     ``rescale(weight, bias, bn_tensors, s_out, s_in, groups)`` default to the HIP engine; tests inject
     CPU stand-ins to exercise the partition / exchange / rebuild logic over gloo.
+
+    ``max_sweeps=N`` pins the sweep count (no exchange before the final all_gather -- the mode for networks
+    whose reference loop does not terminate, SURVEY 7.3 item 4, and the one bench.py --mode sharded times);
+    ``max_sweeps=None`` keeps the reference's data-dependent loop: one 8-byte all_reduce per sweep.
     """
     rank = dist.get_rank(group)
     world = dist.get_world_size(group)
-    if le_runner is None:
-        def le_runner(g, rels, tt, **kw):
-            _dfq.cross_layer_equalization(g, rels, tt, **kw)
-            return _dfq.last_equalization
     rescale = rescale or _engine_rescale
     owner = assign_components(graph, relations, world)
     mine = [rr for rr, o in zip(relations, owner) if o == rank]
     foreign = [(i, rr) for i, (rr, o) in enumerate(zip(relations, owner)) if o != rank]
-    kw = dict(s_range=list(s_range), signed=signed, eps=eps)
 
     with torch.no_grad():
-        # pristine copies of everything a foreign relation will change
         for _, rr in foreign:                               # dfq.py:91-92 on every rank
             first = graph[rr.get_idxs()[0]]
             if first.bias is None:
                 first.bias = torch.nn.Parameter(torch.zeros(first.weight.size(0), dtype=torch.float32,
                                                             device=first.weight.device), requires_grad=False)
-        # ---- local sweeps ----
-        if max_sweeps is not None:
-            sweeps = le_runner(graph, mine, targ_type, max_sweeps=max_sweeps, converge_thres=-1.0,
-                               converge_count=10 ** 9, **kw)['sweeps'] if mine else max_sweeps
-            sweeps = max_sweeps
-        else:
-            diff, count, sweeps = 10.0, 0, 0
-            dev = next(iter(graph[k] for k in graph if type(graph[k]) in targ_type)).weight.device
-            while diff > converge_thres and count < converge_count:
-                local = le_runner(graph, mine, targ_type, max_sweeps=1, converge_thres=-1.0, converge_count=10 ** 9,
-                                  **kw)['last_diff_tmp'] if mine else 0.0
-                t = torch.tensor([local], dtype=torch.float64, device=dev if dist.get_backend(group) == 'nccl' else 'cpu')
-                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-                diff_tmp = float(t.item())
-                if abs(diff - diff_tmp) > 1e-9:
-                    count, diff = 0, diff_tmp
-                else:
-                    count += 1
-                sweeps += 1
+        # ---- local sweeps: one session (= one engine plan) per rank for the whole run ----
+        session = None
+        if mine:
+            session = (_RunnerSession(le_runner, graph, mine, targ_type, s_range, signed, eps) if le_runner is not None
+                       else _EngineSession(graph, mine, targ_type, s_range, signed, eps))
+        try:
+            if max_sweeps is not None:
+                if session is not None and max_sweeps > 0:
+                    session.sweeps(max_sweeps)
+                sweeps = max_sweeps
+            else:
+                diff, count, sweeps = 10.0, 0, 0
+                dev = next(iter(graph[k] for k in graph if type(graph[k]) in targ_type)).weight.device
+                red_dev = dev if dist.get_backend(group) == 'nccl' else 'cpu'
+                while diff > converge_thres and count < converge_count:       # dfq.py:83
+                    local = 0.0
+                    if session is not None:
+                        session.sweeps(1)
+                        local = session.last_diff()
+                    t = torch.tensor([local], dtype=torch.float64, device=red_dev)
+                    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+                    diff_tmp = float(t.item())
+                    if abs(diff - diff_tmp) > 1e-9:                           # dfq.py:110-115
+                        count, diff = 0, diff_tmp
+                    else:
+                        count += 1
+                    sweeps += 1
+        finally:
+            if session is not None:
+                session.close()
         # ---- exchange: one all_gather of the cumulative scale vectors, padded to a common length ----
         lens = [graph[rr.get_idxs()[0]].weight.size(0) for rr in relations]
         total = sum(lens)

@@ -118,3 +118,39 @@ NET_FIXTURES = [
 
 def net_fixture(name, seed, suffix):
     return np.load(os.path.join(GOLD, 'net_{}_s{}{}.npz'.format(name, seed, suffix)))
+
+
+# ---- config 5 (--distill_range): the small network of tests/golden/range_*.npz -------------------------
+RANGE_LAYERS = ('c0', 'c1', 'c2', 'fc')
+
+
+def build_range_net(q, kind):
+    """The same small network from either module namespace (`q` = the reference's utils.quantize, in
+    oracle/make_golden_range.py, or dfq_amd.utils.quantize, in the tests).  'plain': QuantN* layers (what
+    transform_quant_layer(trainable=False) leaves, main_cls.py:184); 'wq': Quant* layers, which also
+    fake-quantise weights and biases in forward."""
+    from collections import OrderedDict
+    conv = q.QuantNConv2d if kind == 'plain' else q.QuantConv2d
+    lin = q.QuantNLinear if kind == 'plain' else q.QuantLinear
+
+    class RangeNet(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.c0 = conv(3, 8, 3, padding=1)
+            self.r0 = nn.ReLU()
+            self.c1 = conv(8, 8, 3, padding=1, groups=8)
+            self.r1 = nn.ReLU6()
+            self.c2 = conv(8, 12, 1)
+            self.fc = lin(12, 5)
+
+        def forward(self, x):
+            x = self.r0(self.c0(x))
+            x = self.r1(self.c1(x))
+            x = self.c2(x)
+            return self.fc(x.mean(3).mean(2))
+    net = RangeNet().eval()
+    graph = OrderedDict([('Data', 'Data'), ('c0', net.c0), ('r0', net.r0), ('c1', net.c1), ('r1', net.r1),
+                         ('c2', net.c2), ('fc', net.fc)])
+    bottoms = OrderedDict([('Data', None), ('c0', ['Data']), ('r0', ['c0']), ('c1', ['r0']), ('r1', ['c1']),
+                           ('c2', ['r1']), ('fc', ['c2'])])
+    return net, graph, bottoms

@@ -82,12 +82,21 @@ def test_update_quant_range_records_activation_ranges(engine):
     assert net[0].quant.update_stat and net[2].quant.update_stat
     rng = np.random.default_rng(0)
     data = [torch.from_numpy(rng.standard_normal((4, 3, 6, 6)).astype(F32)) for _ in range(2)]
-    # expected running range of the second layer's input = max over batches of the per-batch
-    # mean-of-per-sample extrema (quantize.py:106-107), computed with plain torch on the same activations
+    # expected running range of the second layer's input = running max / min over batches of the per-batch
+    # mean-of-per-sample extrema (quantize.py:106-107), from the oracle on the activations the module saw
+    seen = []
+    hook = net[2].quant.register_forward_pre_hook(lambda m, a: seen.append(npy(a[0])))
     improve_dfq.update_quant_range(net, data, graph, bottoms)
+    hook.remove()
     improve_dfq.set_update_stat(net, [q.QuantMeasure], False)
     assert float(net[0].quant.running_max) == pytest.approx(2.64) and float(net[0].quant.running_min) == pytest.approx(-2.11790393)
-    assert float(net[2].quant.running_max) > 0.0 and float(net[2].quant.running_min) <= 0.0
+    rmin, rmax = F32(0.0), F32(0.0)
+    assert len(seen) == 2
+    for a in seen:
+        _, rmin, rmax = orc.quant_measure_forward(a, rmin, rmax, update_stat=True)
+    assert_bitexact(npy(net[2].quant.running_min), np.array([rmin], dtype=F32), 'running_min')
+    assert_bitexact(npy(net[2].quant.running_max), np.array([rmax], dtype=F32), 'running_max')
+    assert rmax > 0.0 and rmin == 0.0        # the input of the second layer comes out of a ReLU
     y = net(data[0].to(engine.device))
     assert y.shape == (4, 4, 6, 6) and torch.isfinite(y).all()
 

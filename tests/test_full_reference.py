@@ -1,0 +1,177 @@
+"""BASELINE.json configs 1-4 at FULL size against the REFERENCE (not the oracle): tests/golden/full_*.npz hold what
+the unmodified reference produced on the synthetic MobileNetV2 / ResNet-18 / DeepLab (oracle/make_golden.py --full,
+run in the build container): the sweep count of its data-dependent loop, every cumulative scale vector, every
+bias and BN proxy after LE / BC / quantisation, and five float64 moments (min, max, sum, sum|.|, sum of squares)
+of every weight tensor per stage (the tensors themselves would be 80 MB).
+
+CPU (`-m "not gpu"`): the oracle against these records.  GPU: the engine against them.  Tolerance 1e-5 (the float32
+contract of BASELINE.json; LE cannot be bit-exact against torch's CPU sqrt)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import dfq_oracle as orc
+from oracle import graphspec
+from dfq_amd import synthetic
+
+from common import F32, GOLD, TARG, assert_close, npy, snapshot
+
+# Bias correction is pinned at 1e-5 STAGE-WISE: from the reference's own post-LE state (oracle/make_golden.py does that at
+# full size when it writes these fixtures -- "BC err 1.2e-07" -- and test_engine_parity on the tiny-net fixtures).  Here it
+# runs END TO END on this implementation's post-LE weights, which differ from the reference's by ulps (sqrt rounding,
+# <= 1.4e-6): wherever such a weight sits on a rounding boundary of the 8-bit grid its quantisation error jumps by a whole
+# step, and the correction (a sum of those errors times E[x]) moves with it -- the discontinuity SURVEY 7.3 item 3
+# describes.  Measured: perturbing the oracle's own post-LE MobileNetV2 weights by +-8 ulp (1e-6 relative) moves corrected
+# biases by up to 2.4e-2; oracle vs reference end to end differ by up to 2.9e-3.  So end to end this is a sanity bound
+# (no NaN, no wrong sign, no missing layer), not the parity bound.
+BC_END_TO_END_TOL = 5e-2
+
+FULL = [('mobilenet_v2', None, 47, 37), ('resnet18', None, 2, 8), ('deeplab_mnv2', 12, 12, 37)]
+
+
+def _moments(w):
+    v = np.asarray(w, dtype=np.float64)
+    return np.array([v.min(), v.max(), v.sum(), np.abs(v).sum(), (v * v).sum()])
+
+
+def _check_stage(snap, gold, stage, what, tol=1e-5):
+    seen = 0
+    for k, v in snap.items():
+        if k.endswith('.w'):
+            ref = gold['{}.{}.stats'.format(stage, k)]
+            got = _moments(v)
+            n = v.size
+            scale = max(1.0, abs(ref[0]), abs(ref[1]))
+            assert abs(got[0] - ref[0]) <= tol * scale and abs(got[1] - ref[1]) <= tol * scale, \
+                '{} {} {}: min/max {} vs {}'.format(what, stage, k, got[:2], ref[:2])
+            # sums of n elements each within tol * max(1, |x|) of the reference
+            assert abs(got[2] - ref[2]) <= tol * (n + ref[3]), '{} {} {}: sum {} vs {}'.format(what, stage, k, got[2], ref[2])
+            assert abs(got[3] - ref[3]) <= tol * (n + ref[3]), '{} {} {}: sum|.| {} vs {}'.format(what, stage, k, got[3], ref[3])
+            assert abs(got[4] - ref[4]) <= 2 * tol * (ref[3] + ref[4]) + tol * n, \
+                '{} {} {}: sum of squares {} vs {}'.format(what, stage, k, got[4], ref[4])
+        else:
+            assert_close(v, gold['{}.{}'.format(stage, k)], '{} {} {}'.format(what, stage, k), tol)
+        seen += 1
+    assert seen == len([k for k in gold.files if k.startswith(stage + '.')]), 'stage {}: tensor sets differ'.format(stage)
+
+
+def _spec_snapshot(spec):
+    snap = {}
+    for i, k in enumerate(spec.order):
+        n = spec.nodes[k]
+        if n.kind == 'targ':
+            snap['L{}.w'.format(i)] = n.weight
+            if n.bias is not None:
+                snap['L{}.b'.format(i)] = n.bias
+        elif n.kind == 'bn' and n.fake_weight is not None:
+            snap['L{}.fw'.format(i)] = n.fake_weight
+            snap['L{}.fb'.format(i)] = n.fake_bias
+    return snap
+
+
+@pytest.mark.parametrize('net,max_sweeps,ref_sweeps,n_rel', FULL)
+def test_oracle_against_reference_at_full_size(net, max_sweeps, ref_sweeps, n_rel):
+    gold = np.load(os.path.join(GOLD, 'full_{}_s0.npz'.format(net)))
+    assert int(gold['n_sweeps']) == ref_sweeps and len(gold['relations']) == n_rel
+    model, graph, bottoms = synthetic.build(net, seed=0)
+    spec = graphspec.from_torch(graph, bottoms, TARG)
+    orc.merge_batchnorm(spec)
+    orels = orc.create_relation(spec)
+    assert [[spec.order.index(k) for k in r] for r in orels] == gold['relations'].tolist()
+    n_o, S_o = orc.cross_layer_equalization(spec, orels, max_sweeps=max_sweeps)
+    assert n_o == ref_sweeps, 'the data-dependent loop must stop where the reference stopped'
+    for i, s in enumerate(S_o):
+        assert_close(s, gold['S{}'.format(i)], 'cumulative S{}'.format(i))
+    _check_stage(_spec_snapshot(spec), gold, 'le', net)
+    orc.bias_correction(spec)
+    _check_stage(_spec_snapshot(spec), gold, 'bc', net, tol=BC_END_TO_END_TOL)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('net,max_sweeps,ref_sweeps,n_rel', FULL)
+def test_engine_against_reference_at_full_size(net, max_sweeps, ref_sweeps, n_rel):
+    """The drop-in call sequence of main_cls.py:149-181 on the GPU vs the reference's records."""
+    import torch.nn as nn
+    from dfq_amd import dfq
+    from dfq_amd.utils import layer_transform as lt
+    from dfq_amd.utils import relation as rel
+    gold = np.load(os.path.join(GOLD, 'full_{}_s0.npz'.format(net)))
+    dev = torch.device('cuda', 0)
+    model, graph, bottoms = synthetic.build(net, seed=0)
+    model.to(dev)
+    lt.merge_batchnorm(model, graph, bottoms, TARG)
+    rels = rel.create_relation(graph, bottoms, TARG)
+    keys = list(graph.keys())
+    assert [[keys.index(k) for k in r.get_idxs()] for r in rels] == gold['relations'].tolist()
+    dfq.cross_layer_equalization(graph, rels, TARG, max_sweeps=max_sweeps)
+    assert dfq.last_equalization['sweeps'] == ref_sweeps == int(gold['n_sweeps'])
+    for i, r in enumerate(rels):
+        assert_close(npy(r.get_scale_vec()), gold['S{}'.format(i)], 'cumulative S{}'.format(i))
+    _check_stage(snapshot(graph), gold, 'le', net)
+    dfq.bias_correction(graph, bottoms, TARG)
+    _check_stage(snapshot(graph), gold, 'bc', net, tol=BC_END_TO_END_TOL)
+    # int8 grid: after quantize_targ_layer every weight tensor sits on <= 256 levels spanning the reference's range;
+    # the codes themselves are compared bit-exactly against the oracle in test_engine_parity (the reference's
+    # post-LE floats differ from any other implementation's by ulps, so single codes may flip at ties: SURVEY 7.3.3)
+    lt.quantize_targ_layer(graph, 8, 16, TARG)
+    snap = snapshot(graph)
+    for k, v in snap.items():
+        if k.endswith('.w'):
+            ref = gold['q.{}.stats'.format(k)]
+            assert len(np.unique(v)) <= 256
+            step = (ref[1] - ref[0]) / 255.0
+            got = _moments(v)
+            assert abs(got[0] - ref[0]) <= 1e-5 * max(1.0, abs(ref[0])) and abs(got[1] - ref[1]) <= 1e-5 * max(1.0, abs(ref[1]))
+            # at most a handful of codes flip by one step
+            assert abs(got[2] - ref[2]) <= 1e-5 * (v.size + ref[3]) + 64 * step, 'q {}: sum {} vs {}'.format(k, got[2], ref[2])
+
+
+@pytest.mark.gpu
+def test_signed_equalization_chain_property():
+    """The reference's only golden artefact (modeling/ncnn/model_quant_relu_equal.table:1-12): after signed LE the
+    per-tensor max|W| of consecutive layers of a chain are equal, because for every paired channel max|W1 row| ==
+    max|W2 column| at the fixed point.  Checked channel-wise (the stronger statement) on MobileNetV2 at full size."""
+    import torch.nn as nn
+    from dfq_amd import dfq
+    from dfq_amd.utils import layer_transform as lt
+    from dfq_amd.utils import relation as rel
+    dev = torch.device('cuda', 0)
+    model, graph, bottoms = synthetic.build('mobilenet_v2', seed=0)
+    model.to(dev)
+    lt.merge_batchnorm(model, graph, bottoms, TARG)
+    rels = rel.create_relation(graph, bottoms, TARG)
+    dfq.cross_layer_equalization(graph, rels, TARG, signed=True, max_sweeps=200)
+    _signed_chain_property(graph, rels)
+
+
+def _signed_chain_property(graph, rels, rtol=2e-3):
+    checked = 0
+    for r in rels:
+        w1 = npy(graph[r.get_idxs()[0]].weight)
+        w2 = npy(graph[r.get_idxs()[1]].weight)
+        g = w1.shape[0] // w2.shape[1] if w1.shape[0] != w2.shape[1] else 1
+        a1 = np.abs(w1.reshape(w1.shape[0], -1)).max(1)
+        cols = w2.reshape(g, w2.shape[0] // g, w2.shape[1], -1).transpose(0, 2, 1, 3).reshape(w1.shape[0], -1)
+        a2 = np.abs(cols).max(1)
+        live = (a1 > 1e-6) & (a2 > 1e-6)
+        np.testing.assert_allclose(a1[live], a2[live], rtol=rtol)
+        # hence the per-tensor maxima the ncnn table records are equal too
+        assert abs(a1[live].max() - a2[live].max()) <= rtol * a1[live].max()
+        checked += int(live.sum())
+    assert checked > 0
+
+
+def test_signed_equalization_chain_property_oracle_and_emulation(engine):
+    """Same property on the tiny network, oracle and engine (CPU emulation / GPU)."""
+    import torch.nn as nn
+    from dfq_amd import dfq
+    from dfq_amd.utils import layer_transform as lt
+    from dfq_amd.utils import relation as rel
+    model, graph, bottoms = synthetic.build('tiny_mobile', seed=2)
+    model.to(engine.device)
+    lt.merge_batchnorm(model, graph, bottoms, TARG)
+    rels = rel.create_relation(graph, bottoms, TARG)
+    dfq.cross_layer_equalization(graph, rels, TARG, signed=True, max_sweeps=200)
+    _signed_chain_property(graph, rels)

@@ -1,0 +1,133 @@
+"""Config 5 (--distill_range) against the reference: set_update_stat -> update_quant_range -> first-layer pin
+(improve_dfq.py:280-309, utils/quantize.py:102-119).  Fixtures: tests/golden/range_*.npz, written by
+oracle/make_golden_range.py from the UNMODIFIED reference (stub-imported).
+
+Contract.  A running range is a float32 quantity -> 1e-5 vs the reference (the reference's float32 sum order
+over the per-sample extrema is unspecified, see the generator); bit-exact vs the oracle on the same inputs."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import dfq_oracle as orc
+from dfq_amd import improve_dfq
+from dfq_amd.utils import quantize as q
+
+from common import F32, GOLD, RANGE_LAYERS, assert_bitexact, assert_close, build_range_net, npy
+
+CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLD, 'range_*.npz')))
+
+
+def test_fixtures_present():
+    assert len(CASES) >= 3
+
+
+def _pin(is_detection):
+    return (F32(-1.0), F32(1.0)) if is_detection else (F32(-2.11790393), F32(2.64))
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_quant_measure_on_reference_activations(engine, case):
+    """Every QuantMeasure of the network, fed the activations the REFERENCE's module saw (bit-identical
+    inputs): the recorded range equals the oracle's bit for bit and the reference's to 1 ulp-ish (1e-6)."""
+    gold = np.load(os.path.join(GOLD, case + '.npz'))
+    n_batches, is_det = int(gold['cfg'][0]), bool(gold['cfg'][1])
+    for k in RANGE_LAYERS:
+        m = q.QuantMeasure(update_stat=True).to(engine.device).eval()
+        rmin, rmax = F32(0.0), F32(0.0)
+        for i in range(n_batches):
+            a = gold['act.{}.{}'.format(k, i)]
+            y = m(engine.to(torch.from_numpy(a.copy())))
+            y_o, rmin, rmax = orc.quant_measure_forward(a, rmin, rmax, update_stat=True)
+            assert_bitexact(npy(y), y_o, '{} {} batch {} output'.format(case, k, i))
+        assert_bitexact(npy(m.running_min), np.array([rmin], dtype=F32), '{} {} running_min'.format(case, k))
+        assert_bitexact(npy(m.running_max), np.array([rmax], dtype=F32), '{} {} running_max'.format(case, k))
+        if k != 'c0':          # the first layer's recorded range is overwritten by the pin
+            ref = gold['range.' + k]
+            assert_close(np.array([rmin, rmax]), ref, '{} {} vs reference'.format(case, k), tol=1e-6)
+            assert_bitexact(np.array([rmin, rmax], dtype=F32), gold['oracle_range.' + k])
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_update_quant_range_end_to_end(engine, case):
+    """The reference's call sequence (main_cls.py:184-186) through the engine's drop-in functions."""
+    gold = np.load(os.path.join(GOLD, case + '.npz'))
+    n_batches, is_det = int(gold['cfg'][0]), bool(gold['cfg'][1])
+    kind = 'wq' if '_wq_' in case else 'plain'
+    net, graph, bottoms = build_range_net(q, kind)
+    sd = {k[len('param.'):]: torch.from_numpy(gold[k]) for k in gold.files if k.startswith('param.')}
+    missing = net.load_state_dict(sd, strict=False)
+    assert not missing.unexpected_keys and all('running_' in k for k in missing.missing_keys)
+    net.to(engine.device)
+    data = [torch.from_numpy(gold['data{}'.format(i)]) for i in range(n_batches)]
+
+    improve_dfq.set_update_stat(net, [q.QuantMeasure], True)
+    assert all(graph[k].quant.update_stat for k in RANGE_LAYERS)
+    out = improve_dfq.update_quant_range(net, data, graph, bottoms, is_detection=is_det)
+    assert out is net
+    improve_dfq.set_update_stat(net, [q.QuantMeasure], False)
+    assert not any(graph[k].quant.update_stat for k in RANGE_LAYERS)
+    for k in RANGE_LAYERS:
+        got = np.array([float(graph[k].quant.running_min), float(graph[k].quant.running_max)], dtype=F32)
+        if k == 'c0':
+            assert_bitexact(got, np.array(_pin(is_det), dtype=F32), case + ' first-layer pin')
+            assert_bitexact(got, gold['range.c0'])
+        else:
+            # the convolutions in front of the quantisers are torch's (CPU here, MIOpen on the GPU): 1e-5
+            assert_close(got, gold['range.' + k], '{} {} range vs reference'.format(case, k), tol=1e-5)
+    with torch.no_grad():
+        y = net(data[0].to(engine.device))
+    # eval forward with the recorded ranges: one activation code may flip where a range differs by an ulp,
+    # which moves an output by a fraction of a quantisation step
+    step = max(float(gold['range.' + k][1] - gold['range.' + k][0]) for k in RANGE_LAYERS) / 255.0
+    err = np.abs(npy(y) - gold['y']).max()
+    assert err <= 2.0 * step, '{}: eval output differs from the reference by {} (> 2 steps of {})'.format(case, err, step)
+
+
+@pytest.mark.gpu
+def test_update_quant_range_mobilenet_v2_vs_oracle():
+    """BASELINE.json config 5 at MobileNetV2 size (batch 16 of 224 x 224 to keep the oracle's numpy pass short):
+    every QuantMeasure of the quantised network records its range over 2 batches; each is compared with the
+    oracle evaluated on the activation the engine's module actually saw (bit-exact), and the first layer is
+    pinned."""
+    import torch.nn as nn
+    from dfq_amd import fxgraph, synthetic
+    from dfq_amd.utils import layer_transform as lt
+    dev = torch.device('cuda', 0)
+    model, graph, bottoms = synthetic.build('mobilenet_v2', seed=0)
+    lt.merge_batchnorm(model, graph, bottoms, [nn.Conv2d, nn.Linear])
+    mapping = {nn.Conv2d: q.QuantNConv2d, nn.Linear: q.QuantNLinear}
+    swapped = improve_dfq._swap_modules(model, mapping)
+    for k in graph:
+        if not isinstance(graph[k], str) and graph[k] in swapped:
+            graph[k] = swapped[graph[k]]
+    model.to(dev).eval()
+    qlayers = [(k, m) for k, m in graph.items() if hasattr(m, 'quant')]
+    assert len(qlayers) == 53
+    g = torch.Generator().manual_seed(1)
+    data = [torch.randn(16, 3, 224, 224, generator=g).clamp_(-2.1179, 2.64) for _ in range(2)]
+    expect = {k: [F32(0.0), F32(0.0)] for k, _ in qlayers}
+
+    def make_hook(k):
+        def hook(m, args):
+            a = args[0].detach().cpu().numpy()
+            mn, mx = orc.sample_minmax_mean(a)
+            expect[k][0] = min(expect[k][0], mn)
+            expect[k][1] = max(expect[k][1], mx)
+        return hook
+    hooks = [m.quant.register_forward_pre_hook(make_hook(k)) for k, m in qlayers]
+    improve_dfq.set_update_stat(model, [q.QuantMeasure], True)
+    improve_dfq.update_quant_range(model, data, graph, bottoms)
+    improve_dfq.set_update_stat(model, [q.QuantMeasure], False)
+    for h in hooks:
+        h.remove()
+    first = [k for k, m in qlayers if bottoms[k][0] == 'Data']
+    assert len(first) == 1
+    for k, m in qlayers:
+        got = np.array([float(m.quant.running_min), float(m.quant.running_max)], dtype=F32)
+        if k in first:
+            assert_bitexact(got, np.array(_pin(False), dtype=F32), 'first-layer pin')
+        else:
+            assert_bitexact(got, np.array(expect[k], dtype=F32), 'range of ' + str(k))

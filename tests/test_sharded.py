@@ -30,9 +30,9 @@ def _free_port():
 
 
 def _prepare(name, seed):
-    gold = net_fixture(name, seed, '')
     model, graph, bottoms = synthetic.build(name, seed=seed)
-    load_inputs(graph, gold, 'cpu')
+    if name.startswith('tiny_'):               # the tiny nets start from the fixture's inputs; full-size ones from their seed
+        load_inputs(graph, net_fixture(name, seed, ''), 'cpu')
     spec = graphspec.from_torch(graph, bottoms, TARG)
     orc.merge_batchnorm(spec)
     with torch.no_grad():                      # put the oracle's folded state into the modules
@@ -175,6 +175,41 @@ def test_sharded_equalization_two_ranks(tmp_path, emu_lib_path, name, seed, max_
         for i, s in enumerate(S_ref):
             assert_bitexact(res['S{}'.format(i)], s, 'S{}'.format(i))
     # both ranks end with the same network
+    for k in r0.files:
+        if k.startswith('L'):
+            assert_close(r0[k], r1[k], k)
+
+
+def test_sharded_deeplab_two_ranks_product_path(tmp_path, emu_lib_path):
+    """BASELINE.json config 4: DeepLab-v3+ (MobileNetV2 backbone, 61 convs, 35 relations) sharded over ranks, pinned to
+    12 sweeps (the reference's loop does not terminate on this network) -- the product code path
+    (per-rank engine plan kept alive over the run, ONE all_gather of the cumulative scale vectors, engine rebuild of
+    the foreign layers) on the CPU emulation of the kernels, world size 2 over gloo, against the single-process oracle:
+    owned layers bit-exact in their cumulative scales, every tensor within 1e-5."""
+    world, name, seed, sweeps = 2, 'deeplab_mnv2', 0, 12
+    mp.spawn(_worker, args=(world, _free_port(), name, seed, sweeps, str(tmp_path), emu_lib_path), nprocs=world, join=True)
+    model, graph, bottoms, spec = _prepare(name, seed)
+    orels = orc.create_relation(spec)
+    assert len(orels) == 37          # this synthetic DeepLab (reference run: tests/golden/full_deeplab_mnv2_s0.npz)
+    n_ref, S_ref = orc.cross_layer_equalization(spec, orels, max_sweeps=sweeps, converge_thres=-1.0, converge_count=10 ** 9)
+    r0 = np.load(os.path.join(str(tmp_path), 'rank0.npz'))
+    r1 = np.load(os.path.join(str(tmp_path), 'rank1.npz'))
+    assert int(r0['sweeps']) == int(r1['sweeps']) == n_ref == sweeps
+    assert sorted(set(r0['owner'].tolist())) == [0, 1]
+    keys = list(graph.keys())
+    worst = 0.0
+    for res in (r0, r1):
+        for i, k in enumerate(keys):
+            n = spec.nodes[k]
+            if n.kind == 'targ':
+                worst = max(worst, assert_close(res['L{}.w'.format(i)], n.weight, 'w {}'.format(k)))
+                if n.bias is not None and 'L{}.b'.format(i) in res:
+                    assert_close(res['L{}.b'.format(i)], n.bias, 'b {}'.format(k))
+            elif n.kind == 'bn' and n.fake_weight is not None:
+                assert_close(res['L{}.fw'.format(i)], n.fake_weight, 'fw {}'.format(k))
+                assert_close(res['L{}.fb'.format(i)], n.fake_bias, 'fb {}'.format(k))
+        for i, s in enumerate(S_ref):
+            assert_bitexact(res['S{}'.format(i)], s, 'S{}'.format(i))
     for k in r0.files:
         if k.startswith('L'):
             assert_close(r0[k], r1[k], k)
