@@ -141,6 +141,8 @@ SIGNATURES = {
                                            c_void_p, c_void_p, c_void_p, c_void_p]),
     'dfq_bn_stat_loss_backward': (c_int32, [c_void_p, c_int64, c_int64, c_int32, c_void_p, c_void_p, c_float, c_float, c_void_p,
                                             c_void_p, c_float, c_float, c_void_p, c_int32, c_void_p]),
+    'dfq_bn_stat_loss_backward_dev': (c_int32, [c_void_p, c_int64, c_int64, c_int32, c_void_p, c_void_p, c_float, c_float, c_void_p,
+                                                c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
     'dfq_bn_through_layer': (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
 }
 

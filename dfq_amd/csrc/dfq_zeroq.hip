@@ -21,7 +21,7 @@ __global__ __launch_bounds__(kBlock) void bn_stat_rows_kernel(const float* __res
                                                               int32_t channels, const float* __restrict__ bn_mean,
                                                               const float* __restrict__ bn_std, float eps,
                                                               float* __restrict__ row_mean, float* __restrict__ row_std,
-                                                              double* __restrict__ row_terms) {
+                                                              double* __restrict__ row_terms, int terms) {
     __shared__ double sh1[kBlock / kWave], sh2[kBlock / kWave];
     const int sub = (kRowsPerBlock == 1) ? 0 : threadIdx.x / kWave;
     const int64_t r = (int64_t)blockIdx.x * kRowsPerBlock + sub;
@@ -55,26 +55,32 @@ __global__ __launch_bounds__(kBlock) void bn_stat_rows_kernel(const float* __res
         (void)sh2;
     }
     if (live && t == 0) {
+        // `terms`: bit 0 = mean term, bit 1 = std term (the H*W == 1 branch takes them from two different row views)
         const double n = (double)hw;
-        const float mean = (float)(s0 / n);
-        const double me = s1 / n;
-        const float sd = (float)sqrt((s2 - s1 * me) / (n - 1.0));      // unbiased, like torch.std
-        row_mean[r] = mean;
-        row_std[r] = sd;
         const int c = (int)(r % channels);
-        const float dm = bn_mean[c] - mean;
-        const float ds = bn_std[c] - sd;
-        row_terms[2 * r + 0] = (double)dm * (double)dm;
-        row_terms[2 * r + 1] = (double)ds * (double)ds;
+        if (terms & 1) {
+            const float mean = (float)(s0 / n);
+            row_mean[r] = mean;
+            const float dm = bn_mean[c] - mean;
+            row_terms[2 * r + 0] = (double)dm * (double)dm;
+        }
+        if (terms & 2) {
+            const double me = s1 / n;
+            const float sd = (float)sqrt((s2 - s1 * me) / (n - 1.0));      // unbiased, like torch.std
+            row_std[r] = sd;
+            const float ds = bn_std[c] - sd;
+            row_terms[2 * r + 1] = (double)ds * (double)ds;
+        }
     }
 }
 
 // loss2[0] = sum_r terms[2r] / denom, loss2[1] = sum_r terms[2r+1] / denom, fixed summation order
 __global__ __launch_bounds__(kBlock) void bn_stat_reduce_kernel(const double* __restrict__ row_terms, int64_t rows,
-                                                                double denom, float* __restrict__ loss2) {
+                                                                int64_t std_rows, double denom, float* __restrict__ loss2) {
     __shared__ double sh[kBlock / kWave];
     double a = 0.0, b = 0.0;
-    for (int64_t r = threadIdx.x; r < rows; r += kBlock) { a += row_terms[2 * r]; b += row_terms[2 * r + 1]; }
+    for (int64_t r = threadIdx.x; r < rows; r += kBlock) a += row_terms[2 * r];
+    for (int64_t r = threadIdx.x; r < std_rows; r += kBlock) b += row_terms[2 * r + 1];
     a = block_sum(a, sh);
     b = block_sum(b, sh);
     if (threadIdx.x == 0) { loss2[0] = (float)(a / denom); loss2[1] = (float)(b / denom); }
@@ -86,12 +92,24 @@ __global__ __launch_bounds__(kBlock) void bn_stat_backward_kernel(const float* _
                                                                   const float* __restrict__ bn_std, float eps,
                                                                   const float* __restrict__ row_mean,
                                                                   const float* __restrict__ row_std, float denom, float g_mean,
-                                                                  float g_std, float* __restrict__ grad, int accumulate) {
+                                                                  float g_std, const float* __restrict__ g_pair,
+                                                                  float* __restrict__ grad, int accumulate, int terms) {
     const int64_t r = blockIdx.x;                          // one workgroup per (sample, channel) row
     const int c = (int)(r % channels);
-    const float mean = row_mean[r], sd = row_std[r];
-    const float a = g_mean * 2.0f * (mean - bn_mean[c]) / (denom * (float)hw);
-    const float b = g_std * 2.0f * (sd - bn_std[c]) / (denom * ((float)hw - 1.0f) * sd);
+    if (g_pair) { g_mean = g_pair[0]; g_std = g_pair[1]; }   // upstream gradients left on the device by autograd
+    // the spatial mean of the row: stored by the forward when it took the mean term over this row view, else recomputed
+    float mean;
+    if (terms & 1) {
+        mean = row_mean[r];
+    } else {
+        __shared__ double shm[kBlock / kWave];
+        double s0 = 0.0;
+        for (int64_t i = threadIdx.x; i < hw; i += kBlock) s0 += (double)x[r * hw + i];
+        mean = (float)(block_sum(s0, shm) / (double)hw);
+    }
+    const float sd = (terms & 2) ? row_std[r] : 1.0f;
+    const float a = (terms & 1) ? g_mean * 2.0f * (mean - bn_mean[c]) / (denom * (float)hw) : 0.0f;
+    const float b = (terms & 2) ? g_std * 2.0f * (sd - bn_std[c]) / (denom * ((float)hw - 1.0f) * sd) : 0.0f;
     const float mean_e = mean + eps;
     for (int64_t i = threadIdx.x; i < hw; i += kBlock) {
         const float g = a + b * ((x[r * hw + i] + eps) - mean_e);
@@ -112,17 +130,55 @@ int dfq_bn_stat_loss_forward(const float* x, int64_t rows, int64_t hw, int32_t c
                              void* scratch, void* stream) {
     if (!x || !bn_mean || !bn_std || !row_mean || !row_std || !loss2 || !scratch || rows <= 0 || channels <= 0 || rows % channels != 0)
         return fail_arg("dfq_bn_stat_loss_forward: bad argument");
-    if (hw < 2) return fail_arg("dfq_bn_stat_loss_forward: H*W must be >= 2 (the reference's H*W == 1 branch, distill_data.py:181-182, "
-                                "reinterprets the [N, C] block as [C, N]; not supported)");
+    if (hw < 1) return fail_arg("dfq_bn_stat_loss_forward: H*W must be >= 1");
     hipStream_t st = as_stream(stream);
-    if (hw >= 1024)
-        hipLaunchKernelGGL(bn_stat_rows_kernel<1>, dim3((unsigned)rows), dim3(kBlock), 0, st, x, rows, hw, channels, bn_mean, bn_std, eps,
-                           row_mean, row_std, (double*)scratch);
-    else
-        hipLaunchKernelGGL(bn_stat_rows_kernel<kBlock / kWave>, dim3((unsigned)((rows + kBlock / kWave - 1) / (kBlock / kWave))), dim3(kBlock),
-                           0, st, x, rows, hw, channels, bn_mean, bn_std, eps, row_mean, row_std, (double*)scratch);
+    auto launch_rows = [&](int64_t n_rows, int64_t len, int terms) {
+        if (len >= 1024)
+            hipLaunchKernelGGL(bn_stat_rows_kernel<1>, dim3((unsigned)n_rows), dim3(kBlock), 0, st, x, n_rows, len, channels, bn_mean, bn_std,
+                               eps, row_mean, row_std, (double*)scratch, terms);
+        else
+            hipLaunchKernelGGL(bn_stat_rows_kernel<kBlock / kWave>, dim3((unsigned)((n_rows + kBlock / kWave - 1) / (kBlock / kWave))),
+                               dim3(kBlock), 0, st, x, n_rows, len, channels, bn_mean, bn_std, eps, row_mean, row_std, (double*)scratch, terms);
+    };
+    int64_t std_rows = rows;
+    if (hw == 1) {
+        // distill_data.py:181-182: one value per (sample, channel).  The mean term compares every x[n, c] with bn_mean[c];
+        // for the std term the reference reinterprets the contiguous [N, C] block as C rows of N values
+        // (`tmp_output.view(C, -1)`) and compares the unbiased std of row r with bn_std[r].
+        const int64_t n_samples = rows / channels;
+        if (n_samples < 2) return fail_arg("dfq_bn_stat_loss_forward: H*W == 1 needs a batch of >= 2 (std over the batch axis)");
+        launch_rows(rows, 1, 1);
+        DFQ_CHECK_LAUNCH();
+        launch_rows(channels, n_samples, 2);
+        std_rows = channels;
+    } else {
+        launch_rows(rows, hw, 3);
+    }
     DFQ_CHECK_LAUNCH();
-    hipLaunchKernelGGL(bn_stat_reduce_kernel, dim3(1), dim3(kBlock), 0, st, (const double*)scratch, rows, (double)denom, loss2);
+    hipLaunchKernelGGL(bn_stat_reduce_kernel, dim3(1), dim3(kBlock), 0, st, (const double*)scratch, rows, std_rows, (double)denom, loss2);
+    DFQ_CHECK_LAUNCH();
+    return DFQ_OK;
+}
+
+static int bn_stat_backward_impl(const float* x, int64_t rows, int64_t hw, int32_t channels, const float* bn_mean,
+                                 const float* bn_std, float eps, float denom, const float* row_mean, const float* row_std,
+                                 float g_mean, float g_std, const float* g_pair, float* grad_x, int32_t accumulate, void* stream) {
+    if (!x || !bn_mean || !bn_std || !row_mean || !row_std || !grad_x || rows <= 0 || hw < 1 || channels <= 0 || rows > 0x7fffffff ||
+        rows % channels != 0)
+        return fail_arg("dfq_bn_stat_loss_backward: bad argument");
+    hipStream_t st = as_stream(stream);
+    if (hw == 1) {
+        const int64_t n_samples = rows / channels;
+        if (n_samples < 2) return fail_arg("dfq_bn_stat_loss_backward: H*W == 1 needs a batch of >= 2");
+        hipLaunchKernelGGL(bn_stat_backward_kernel, dim3((unsigned)rows), dim3(kBlock), 0, st, x, rows, (int64_t)1, channels, bn_mean,
+                           bn_std, eps, row_mean, row_std, denom, g_mean, g_std, g_pair, grad_x, (int)accumulate, 1);
+        DFQ_CHECK_LAUNCH();
+        hipLaunchKernelGGL(bn_stat_backward_kernel, dim3((unsigned)channels), dim3(kBlock), 0, st, x, (int64_t)channels, n_samples,
+                           channels, bn_mean, bn_std, eps, row_mean, row_std, denom, g_mean, g_std, g_pair, grad_x, 1, 2);
+    } else {
+        hipLaunchKernelGGL(bn_stat_backward_kernel, dim3((unsigned)rows), dim3(kBlock), 0, st, x, rows, hw, channels, bn_mean, bn_std,
+                           eps, row_mean, row_std, denom, g_mean, g_std, g_pair, grad_x, (int)accumulate, 3);
+    }
     DFQ_CHECK_LAUNCH();
     return DFQ_OK;
 }
@@ -130,12 +186,16 @@ int dfq_bn_stat_loss_forward(const float* x, int64_t rows, int64_t hw, int32_t c
 int dfq_bn_stat_loss_backward(const float* x, int64_t rows, int64_t hw, int32_t channels, const float* bn_mean,
                               const float* bn_std, float eps, float denom, const float* row_mean, const float* row_std,
                               float grad_mean_loss, float grad_std_loss, float* grad_x, int32_t accumulate, void* stream) {
-    if (!x || !bn_mean || !bn_std || !row_mean || !row_std || !grad_x || rows <= 0 || hw < 2 || channels <= 0 || rows > 0x7fffffff)
-        return fail_arg("dfq_bn_stat_loss_backward: bad argument");
-    hipLaunchKernelGGL(bn_stat_backward_kernel, dim3((unsigned)rows), dim3(kBlock), 0, as_stream(stream), x, rows, hw, channels,
-                       bn_mean, bn_std, eps, row_mean, row_std, denom, grad_mean_loss, grad_std_loss, grad_x, (int)accumulate);
-    DFQ_CHECK_LAUNCH();
-    return DFQ_OK;
+    return bn_stat_backward_impl(x, rows, hw, channels, bn_mean, bn_std, eps, denom, row_mean, row_std, grad_mean_loss,
+                                 grad_std_loss, nullptr, grad_x, accumulate, stream);
+}
+
+int dfq_bn_stat_loss_backward_dev(const float* x, int64_t rows, int64_t hw, int32_t channels, const float* bn_mean,
+                                  const float* bn_std, float eps, float denom, const float* row_mean, const float* row_std,
+                                  const float* grad_pair, float* grad_x, int32_t accumulate, void* stream) {
+    if (!grad_pair) return fail_arg("dfq_bn_stat_loss_backward_dev: null gradient pair");
+    return bn_stat_backward_impl(x, rows, hw, channels, bn_mean, bn_std, eps, denom, row_mean, row_std, 0.0f, 0.0f, grad_pair,
+                                 grad_x, accumulate, stream);
 }
 
 }  // extern "C"

@@ -46,9 +46,14 @@ class _BNStatLoss(torch.autograd.Function):
         n, c = xx.shape[0], xx.shape[1]
         hw = xx[0, 0].numel()
         grad = torch.empty_like(xx)
-        _ffi.check(lib.dfq_bn_stat_loss_backward(_ffi.ptr(xx), n * c, hw, c, _ffi.ptr(m), _ffi.ptr(s), ctx.eps, ctx.denom,
-                                                 _ffi.ptr(row_mean), _ffi.ptr(row_std), float(g_mean), float(g_std), _ffi.ptr(grad), 0,
-                                                 _ffi.stream_arg()))
+        # the upstream gradients stay on the device (no .item() inside backward: ~50 BN layers per iteration would each
+        # stall the stream); an output that took no part in the loss arrives as None = 0
+        zero = torch.zeros((), dtype=torch.float32, device=xx.device)
+        pair = torch.stack([(zero if g is None else g.detach().to(device=xx.device, dtype=torch.float32).reshape(()))
+                            for g in (g_mean, g_std)]).contiguous()
+        _ffi.check(lib.dfq_bn_stat_loss_backward_dev(_ffi.ptr(xx), n * c, hw, c, _ffi.ptr(m), _ffi.ptr(s), ctx.eps, ctx.denom,
+                                                     _ffi.ptr(row_mean), _ffi.ptr(row_std), _ffi.ptr(pair), _ffi.ptr(grad), 0,
+                                                     _ffi.stream_arg()))
         return grad.to(ctx.src_device).reshape(ctx.shape), None, None, None, None
 
 
@@ -71,9 +76,11 @@ class _InputHook:
 
 
 def getDistilData(teacher_model, shape, num_batch=1, bn_merged=False, value_range=(-10, 10), max_value=3.,
-                  early_break_factor=1., iterations=1000, generator=None):
+                  early_break_factor=1., iterations=1000, generator=None, init=None, loss_log=None):
     """The reference's distillation loop (distill_data.py:75-227).  ``shape`` = (batch, 3, H, W) replaces its
-    dataset switch; the start is uniform noise in [-max_value, max_value] like its ``UniformDataset``."""
+    dataset switch; the start is uniform noise in [-max_value, max_value] like its ``UniformDataset``, or the
+    tensors of ``init`` (one per batch: what the reference's data loader would have produced).  ``loss_log`` (a list)
+    receives the total loss of every iteration (the value the reference hands to its LR scheduler)."""
     eps = 1e-6
     dev = next(teacher_model.parameters()).device
     teacher_model = teacher_model.eval()
@@ -89,8 +96,11 @@ def getDistilData(teacher_model, shape, num_batch=1, bn_merged=False, value_rang
                 bn_stats.append((m.fake_bias.detach().clone().flatten(), m.fake_weight.detach().clone().flatten()))
     layers = len(hooks)
     refined = []
-    for _ in range(num_batch):
-        data = ((torch.rand(*shape, generator=generator) * 2 - 1) * max_value).to(dev)
+    for b in range(num_batch):
+        if init is not None:
+            data = init[b].detach().clone().to(dev)
+        else:
+            data = ((torch.rand(*shape, generator=generator) * 2 - 1) * max_value).to(dev)
         data.requires_grad = True
         optimizer = optim.Adam([data], lr=0.1)
         scheduler = optim.lr_scheduler.ReduceLROnPlateau(optimizer, min_lr=1e-7, patience=100)
@@ -111,8 +121,11 @@ def getDistilData(teacher_model, shape, num_batch=1, bn_merged=False, value_rang
             total = mean_loss + ml + std_loss + sl
             total.backward()
             optimizer.step()
-            scheduler.step(total.item())
-            if total <= (layers + 1) * early_break_factor:
+            total_value = total.item()
+            if loss_log is not None:
+                loss_log.append(total_value)
+            scheduler.step(total_value)
+            if total_value <= (layers + 1) * early_break_factor:
                 break
         refined.append(data.detach().clone().clamp(value_range[0], value_range[1]))
     for hd in handles:

@@ -392,7 +392,10 @@ int dfq_bn_through_layer(const float* weight, int32_t out_ch, int32_t in_per_gro
  *   loss2[0] = sum_{n,c} (bn_mean[c] - mean_hw x)^2 / denom,   loss2[1] = sum_{n,c} (bn_std[c] - std_hw(x + eps))^2 / denom
  * (unbiased std; denom = A.size(0) of own_loss: C for the BN terms, N for the input-batch term of :192-196), one read of x; row_mean / row_std [rows] are kept for the backward pass, which writes (or adds
  * into) grad_x = grad_mean_loss * d loss2[0]/dx + grad_std_loss * d loss2[1]/dx with one read of x.
- * `scratch`: dfq_bn_stat_loss_scratch_bytes(rows) bytes.  H*W == 1 is rejected (see the message).
+ * `scratch`: dfq_bn_stat_loss_scratch_bytes(rows) bytes.  H*W == 1 follows distill_data.py:181-182: the mean term per
+ * (n, c) value, the std term over the contiguous [N, C] block REINTERPRETED as C rows of N values (row r against
+ * bn_std[r]); row_std then holds C entries.  The `_dev` backward reads the two upstream gradients from device memory
+ * (grad_pair[0] = d/d loss2[0], grad_pair[1] = d/d loss2[1]): no host synchronisation inside an autograd backward.
  * ---------------------------------------------------------------------------------------- */
 size_t dfq_bn_stat_loss_scratch_bytes(int64_t rows);
 int dfq_bn_stat_loss_forward(const float* x, int64_t rows, int64_t hw, int32_t channels, const float* bn_mean,
@@ -401,6 +404,9 @@ int dfq_bn_stat_loss_forward(const float* x, int64_t rows, int64_t hw, int32_t c
 int dfq_bn_stat_loss_backward(const float* x, int64_t rows, int64_t hw, int32_t channels, const float* bn_mean,
                               const float* bn_std, float eps, float denom, const float* row_mean, const float* row_std,
                               float grad_mean_loss, float grad_std_loss, float* grad_x, int32_t accumulate, void* stream);
+int dfq_bn_stat_loss_backward_dev(const float* x, int64_t rows, int64_t hw, int32_t channels, const float* bn_mean,
+                                  const float* bn_std, float eps, float denom, const float* row_mean, const float* row_std,
+                                  const float* grad_pair, float* grad_x, int32_t accumulate, void* stream);
 
 #ifdef __cplusplus
 }

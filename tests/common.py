@@ -154,3 +154,23 @@ def build_range_net(q, kind):
     bottoms = OrderedDict([('Data', None), ('c0', ['Data']), ('r0', ['c0']), ('c1', ['r0']), ('r1', ['c1']),
                            ('c2', ['r1']), ('fc', ['c2'])])
     return net, graph, bottoms
+
+
+# ---- row f2 (ZeroQ distillation): the small teacher network of tests/golden/zeroq_*.npz ----------------
+def build_distill_net(gen, with_pixel_bn):
+    """conv-BN-ReLU x2 (+ global pool, 1x1 conv, BN on 1x1 feature maps: the H*W == 1 branch of
+    ZeroQ/distill_data.py:181-182), parameters and BN statistics drawn from `gen`."""
+    layers = [nn.Conv2d(3, 8, 3, padding=1), nn.BatchNorm2d(8), nn.ReLU(),
+              nn.Conv2d(8, 8, 3, padding=1, stride=2), nn.BatchNorm2d(8), nn.ReLU()]
+    if with_pixel_bn:
+        layers += [nn.AdaptiveAvgPool2d(1), nn.Conv2d(8, 6, 1), nn.BatchNorm2d(6)]
+    net = nn.Sequential(*layers).eval()
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, nn.Conv2d):
+                m.weight.copy_(torch.randn(m.weight.shape, generator=gen) * 0.3)
+                m.bias.copy_(torch.randn(m.bias.shape, generator=gen) * 0.1)
+            elif isinstance(m, nn.BatchNorm2d):
+                m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=gen) * 0.5)
+                m.running_var.copy_(torch.rand(m.running_var.shape, generator=gen) + 0.5)
+    return net
