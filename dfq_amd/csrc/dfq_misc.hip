@@ -15,24 +15,28 @@ __device__ __forceinline__ float apply_op(float a, float b, int op) {
 }
 
 // one workgroup per row chunk: grid (chunks_per_row, rows)
-__global__ __launch_bounds__(kBlock) void scale_rows_kernel(float* __restrict__ w, int64_t row_len,
+// 1-D grid of rows x chunks workgroups (a 2-D grid would cap the row count at 65535: a large classifier or
+// embedding Linear has more output channels than that)
+__global__ __launch_bounds__(kBlock) void scale_rows_kernel(float* __restrict__ w, int64_t row_len, int chunks,
                                                             const float* __restrict__ s, int op) {
-    const int row = blockIdx.y;
+    const int64_t row = blockIdx.x / (unsigned)chunks;
+    const int chunk = (int)(blockIdx.x - row * chunks);
     const float sv = s[row];
-    float* p = w + (int64_t)row * row_len;
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < row_len; i += (int64_t)gridDim.x * kBlock)
+    float* p = w + row * row_len;
+    for (int64_t i = (int64_t)chunk * kBlock + threadIdx.x; i < row_len; i += (int64_t)chunks * kBlock)
         p[i] = apply_op(p[i], sv, op);
 }
 
 // element (o, i, k) of [O, I/g, khkw] -> input channel (o / (O/groups)) * I/g + i
-__global__ __launch_bounds__(kBlock) void scale_cols_kernel(float* __restrict__ w, int64_t row_len, int in_per_group,
+__global__ __launch_bounds__(kBlock) void scale_cols_kernel(float* __restrict__ w, int64_t row_len, int chunks, int in_per_group,
                                                             int khkw, int out_per_group,
                                                             const float* __restrict__ s, int op) {
-    const int o = blockIdx.y;
-    const int g = o / out_per_group;
+    const int64_t o = blockIdx.x / (unsigned)chunks;
+    const int chunk = (int)(blockIdx.x - o * chunks);
+    const int g = (int)(o / out_per_group);
     const float* sg = s + (int64_t)g * in_per_group;
-    float* p = w + (int64_t)o * row_len;
-    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < row_len; e += (int64_t)gridDim.x * kBlock) {
+    float* p = w + o * row_len;
+    for (int64_t e = (int64_t)chunk * kBlock + threadIdx.x; e < row_len; e += (int64_t)chunks * kBlock) {
         const int i = (int)(e / khkw);
         p[e] = apply_op(p[e], sg[i], op);
     }
@@ -133,8 +137,10 @@ extern "C" {
 
 int dfq_scale_rows(float* w, int32_t rows, int64_t row_len, const float* s, int32_t op, void* stream) {
     if (!w || !s || rows <= 0 || row_len <= 0 || op < 0 || op > 3) return fail_arg("dfq_scale_rows: bad argument");
-    if (rows > 65535) return fail_arg("dfq_scale_rows: rows=%d > 65535", rows);
-    hipLaunchKernelGGL(scale_rows_kernel, dim3(grid1(row_len, 64), rows), dim3(kBlock), 0, as_stream(stream), w, row_len, s, (int)op);
+    const int chunks = grid1(row_len, 64);
+    if ((int64_t)rows * chunks > 0x7fffffff) return fail_arg("dfq_scale_rows: rows=%d too many", rows);
+    hipLaunchKernelGGL(scale_rows_kernel, dim3((unsigned)((int64_t)rows * chunks)), dim3(kBlock), 0, as_stream(stream), w, row_len,
+                       chunks, s, (int)op);
     DFQ_CHECK_LAUNCH();
     return DFQ_OK;
 }
@@ -143,10 +149,11 @@ int dfq_scale_cols(float* w, int32_t out_ch, int32_t in_per_group, int32_t khkw,
                    const float* s, int32_t op, void* stream) {
     if (!w || !s || out_ch <= 0 || in_per_group <= 0 || khkw <= 0 || groups <= 0 || out_ch % groups != 0 || op < 0 || op > 3)
         return fail_arg("dfq_scale_cols: bad argument");
-    if (out_ch > 65535) return fail_arg("dfq_scale_cols: out_ch=%d > 65535", out_ch);
     const int64_t row_len = (int64_t)in_per_group * khkw;
-    hipLaunchKernelGGL(scale_cols_kernel, dim3(grid1(row_len, 64), out_ch), dim3(kBlock), 0, as_stream(stream), w, row_len,
-                       (int)in_per_group, (int)khkw, (int)(out_ch / groups), s, (int)op);
+    const int chunks = grid1(row_len, 64);
+    if ((int64_t)out_ch * chunks > 0x7fffffff) return fail_arg("dfq_scale_cols: out_ch=%d too many", out_ch);
+    hipLaunchKernelGGL(scale_cols_kernel, dim3((unsigned)((int64_t)out_ch * chunks)), dim3(kBlock), 0, as_stream(stream), w, row_len,
+                       chunks, (int)in_per_group, (int)khkw, (int)(out_ch / groups), s, (int)op);
     DFQ_CHECK_LAUNCH();
     return DFQ_OK;
 }

@@ -12,7 +12,12 @@ to the calibration passes, and it is fixed by their call sites:
 
 Shape-only ops (view/size/flatten/getitem/contiguous/dropout-in-eval...) are transparent: their
 consumers are wired to their producer, which is how the reference graphs look
-(images/graph_cls.png ends ... ReLU -> torch.mean -> Linear).
+(images/graph_cls.png ends ... ReLU -> torch.mean -> Linear).  Only a WHITELIST is transparent.  Functional
+activations the passes must see become module nodes (F.relu -> nn.ReLU(), F.relu6 -> nn.ReLU6(): relation.py:36-41
+walks through ReLU but stops at ReLU6, dfq.py:209-211 and layer_transform.py:373-380 look for them behind a BN);
+every other function or method (sigmoid, hardswish, mul, chunk, ...) is kept as an opaque string node, as the
+reference's tracer does, so that `create_relation` / `find_prev_bn` stop there instead of pairing layers across
+an operation that does not commute with a per-channel scale.
 """
 from __future__ import annotations
 
@@ -32,6 +37,11 @@ _FUNC_NAMES = {
 _METHOD_NAMES = {'add': 'add', 'add_': 'add', 'mean': 'torch.mean'}
 _TRANSPARENT_METHODS = {'view', 'reshape', 'flatten', 'contiguous', 'squeeze', 'unsqueeze',
                         'float', 'detach', 'clone'}
+_TRANSPARENT_FUNCS = {torch.flatten, torch.reshape, torch.squeeze, torch.unsqueeze, operator.getitem,
+                      F.dropout, F.dropout2d}          # models are traced in eval mode: dropout is the identity
+# functional activations -> the module type the calibration passes test for
+_FUNC_MODULES = {F.relu: nn.ReLU, torch.relu: nn.ReLU, F.relu6: nn.ReLU6}
+_METHOD_MODULES = {'relu': nn.ReLU, 'relu_': nn.ReLU}
 # results that are shapes / python numbers, not tensors: they must not become graph edges (e.g. the
 # `size=(x.shape[2], x.shape[3])` argument of F.interpolate refers to x only for its shape)
 _SHAPE_METHODS = {'size', 'dim', 'numel'}
@@ -107,24 +117,28 @@ def _trace(model, key_style='name'):
             continue                                   # x.shape, x.dtype ...: not a tensor
         elif n.op == 'call_method' and n.target in _SHAPE_METHODS:
             continue
-        elif n.op == 'call_function':
-            if n.target in _FUNC_NAMES:
-                key = '{}_{}'.format(_FUNC_NAMES[n.target], counter)
-                graph[key] = key
-            else:
-                if not ins:
-                    continue
+        elif n.op in ('call_function', 'call_method'):
+            is_fn = n.op == 'call_function'
+            names = _FUNC_NAMES if is_fn else _METHOD_NAMES
+            mods = _FUNC_MODULES if is_fn else _METHOD_MODULES
+            transparent = _TRANSPARENT_FUNCS if is_fn else _TRANSPARENT_METHODS
+            if not ins:
+                continue                                   # no tensor input: a constant, not a graph node
+            if n.target in transparent:
                 alias[n] = key_of(ins[0])
                 continue
-        elif n.op == 'call_method':
-            if n.target in _METHOD_NAMES and n.target not in _TRANSPARENT_METHODS:
-                key = '{}_{}'.format(_METHOD_NAMES[n.target], counter)
+            if n.target in names:
+                key = '{}_{}'.format(names[n.target], counter)
                 graph[key] = key
+            elif n.target in mods:
+                m = mods[n.target]()
+                key = '{}_{}'.format(type(m).__name__, counter) if key_style == 'name' else m
+                graph[key] = m
             else:
-                if not ins:
-                    continue
-                alias[n] = key_of(ins[0])
-                continue
+                # unknown operation: an opaque node (a string, like the reference's tensor-op entries)
+                name = getattr(n.target, '__name__', None) or str(n.target)
+                key = '{}_{}'.format(name if is_fn else 'Tensor.' + name, counter)
+                graph[key] = key
         else:                      # get_attr etc.
             continue
         bots = []

@@ -131,3 +131,21 @@ def test_sharded_rebuild_kernels(engine):
         want = (want / per_row.reshape((shape[0], shape[1]) + (1,) * (w.ndim - 2))).astype(F32)
         assert_bitexact(npy(tw), want, 'weight {}'.format(shape))
         assert_bitexact(npy(tb), (b * so).astype(F32), 'bias')
+
+
+@pytest.mark.gpu
+def test_scale_rows_and_cols_beyond_65535_output_channels():
+    """A Linear with more than 65535 output channels (a large classifier / embedding): the row and column rescale
+    kernels use a 1-D grid (a 2-D grid capped the row count)."""
+    from dfq_amd import _ffi
+    dev = torch.device('cuda', 0)
+    rows, cols = 70001, 6
+    g = torch.Generator().manual_seed(0)
+    w = torch.randn(rows, cols, generator=g)
+    so, si = torch.rand(rows, generator=g) + 0.5, torch.rand(cols, generator=g) + 0.5
+    tw, tso, tsi = w.to(dev), so.to(dev), si.to(dev)
+    lib = _ffi.lib()
+    _ffi.check(lib.dfq_scale_rows(_ffi.ptr(tw), rows, cols, _ffi.ptr(tso), 0, _ffi.stream_arg()))
+    _ffi.check(lib.dfq_scale_cols(_ffi.ptr(tw), rows, cols, 1, 1, _ffi.ptr(tsi), 1, _ffi.stream_arg()))
+    want = ((w * so.view(-1, 1)) / si.view(1, -1)).numpy()
+    assert_bitexact(npy(tw), want, 'weight of a 70001-row linear')
