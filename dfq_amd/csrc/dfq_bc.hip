@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <map>
+#include <memory>
 #include <vector>
 
 #include "dfq_common.hpp"
@@ -234,7 +235,7 @@ struct BcDep {            // null counters: every step is its own launch (depend
 
 template <int kExp>
 __device__ __forceinline__ void bc_step_body(const BcStepDev& st, int blk, const BcSourceDev* __restrict__ sources,
-                                             const BcDep& dep, float* sh_E, float* sh_corr) {
+                                             const BcDep& dep, float* sh_E, float* sh_corr, int* sh_flag) {
     const int tid = threadIdx.x;
     const int lane = tid % kWave;
     const int wave = tid / kWave;
@@ -278,13 +279,24 @@ __device__ __forceinline__ void bc_step_body(const BcStepDev& st, int blk, const
         // requested above arrive meanwhile)
         if (tid == 0) {
             long spins = 0;
+            int ok = 1;
             while (__hip_atomic_load(dep.counters + (int64_t)dep.wait_idx * kBcDepStride, __ATOMIC_RELAXED,
                                      __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)dep.wait_blocks) {
                 __builtin_amdgcn_s_sleep(2);               // few waiters here (one step's workgroups): poll briskly
-                if (++spins > kBcSpinLimit) { atomicMax(dep.err, 1u); break; }
+                ++spins;
+                if (spins > kBcSpinLimit ||
+                    ((spins & 255) == 0 && __hip_atomic_load(dep.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                    atomicMax(dep.err, 1u);
+                    ok = 0;
+                    break;
+                }
             }
+            *sh_flag = ok;
         }
         __syncthreads();
+        // abandoned wait: leave before anything is stored (no bias is corrected with a stale expectation) and without
+        // bumping this step's counter -- the later steps give up at once through `err`, the status call reports it
+        if (*sh_flag == 0) return;
     }
     // ---- E[x]: first source assigns, 'cat' appends, anything else adds (dfq.py:229-270) ----
     int cur_len = 0;
@@ -394,11 +406,12 @@ __global__ __launch_bounds__(kBlock) void bc_step_kernel(BcStepDev st_inline, co
                                                          const BcSourceDev* __restrict__ sources) {
     __shared__ float sh_E[kExp];
     __shared__ float sh_corr[kBlock];
+    __shared__ int sh_flag;
     union { BcStepDev st; uint32_t u[kStepWords]; } desc;
     if (table) bc_load_step(table + blockIdx.y, desc.u);
     else desc.st = st_inline;
     if ((int)blockIdx.x * desc.st.rows_per_block >= desc.st.out_ch) return;     // grid.x is sized for the largest step of the launch
-    bc_step_body<kExp>(desc.st, blockIdx.x, sources, BcDep{nullptr, nullptr, -1, 0, -1, 0}, sh_E, sh_corr);
+    bc_step_body<kExp>(desc.st, blockIdx.x, sources, BcDep{nullptr, nullptr, -1, 0, -1, 0}, sh_E, sh_corr, &sh_flag);
 }
 
 // the whole chain of every network in one launch: 1-D grid over (step, workgroup) in chain order; a workgroup waits
@@ -410,6 +423,7 @@ __global__ __launch_bounds__(kBlock) void bc_chain_kernel(const BcStepDev* __res
                                                           uint32_t* err) {
     __shared__ float sh_E[kExp];
     __shared__ float sh_corr[kBlock];
+    __shared__ int sh_flag;
     typedef int ivec4 __attribute__((vector_size(16)));
     const ivec4 ref = *(const DFQ_GLOBAL_AS ivec4*)(refs + blockIdx.x);
     const int step = __builtin_amdgcn_readfirstlane(ref[0]);
@@ -418,7 +432,7 @@ __global__ __launch_bounds__(kBlock) void bc_chain_kernel(const BcStepDev* __res
     bc_load_step(table + step, desc.u);
     bc_step_body<kExp>(desc.st, blk, sources,
                        BcDep{counters, err, __builtin_amdgcn_readfirstlane(ref[2]), __builtin_amdgcn_readfirstlane(ref[3]), step, 0},
-                       sh_E, sh_corr);
+                       sh_E, sh_corr, &sh_flag);
 }
 
 }  // namespace dfq
@@ -718,6 +732,9 @@ static int bc_run_direct(dfq_bc_plan* p, int32_t symmetric, hipStream_t st) {
     if (p->merged && p->chain_blocks > 0) {
         DFQ_HIP_TRY(hipMemsetAsync(p->d_counters, 0, sizeof(uint32_t) * ((size_t)p->n_steps * kBcDepStride + 1), st));
         uint32_t* err = p->d_counters + (size_t)p->n_steps * kBcDepStride;
+        // the chain kernel contains in-launch waits: never concurrent with another stream's (dfq_common.hpp)
+        std::unique_ptr<SpinGuard> guard;
+        if (st != p->capture_stream) guard.reset(new SpinGuard(st));
         if (p->max_expect <= kExpectSmall)
             hipLaunchKernelGGL(bc_chain_kernel<kExpectSmall>, dim3(p->chain_blocks), dim3(kBlock), 0, st, (const BcStepDev*)p->d_steps,
                                (const BcChainRef*)p->d_refs, (const BcSourceDev*)p->d_sources, p->d_counters, err);

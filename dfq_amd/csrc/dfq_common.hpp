@@ -47,6 +47,25 @@ int fail_hip(hipError_t e, const char* what, const char* file, int line);
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// ---- kernels with in-launch waits never overlap across streams -------------------------------------
+// The one-launch sweep (le_level_kernel), the resident equalisation kernel and the one-launch bias-correction
+// chain contain workgroups that wait for other workgroups of the SAME launch.  That is deadlock-free as long as
+// the waited-for workgroups are resident or will become resident -- true for a kernel that has the chip to itself
+// or shares it with kernels that finish on their own, NOT for two such kernels from different streams, each
+// holding the slots the other's producers need.  So the library serialises them: SpinGuard's
+// constructor makes `stream` wait for the last waiting-kernel batch enqueued on a DIFFERENT stream, its destructor
+// records the end of this batch.  One event record per enqueue call, nothing per launch; kernels without in-launch
+// waits (per-level launches, bootstrap, quantisers, ...) are not affected.  Process-wide, per device.
+class SpinGuard {
+public:
+    explicit SpinGuard(hipStream_t stream);
+    ~SpinGuard();
+    SpinGuard(const SpinGuard&) = delete;
+    SpinGuard& operator=(const SpinGuard&) = delete;
+private:
+    hipStream_t stream_;
+};
+
 // ---- order-preserving float <-> uint32 encoding for atomic min/max ----------------------------
 // enc is monotone in the float order (-inf < ... < -0 < +0 < ... < +inf).  A "max slot" holds
 // atomicMax(enc(x)), a "min slot" holds atomicMax(~enc(x)); both have identity 0, so one memset

@@ -1,6 +1,8 @@
 // Error plumbing and version entry points of libdfq_hip.
 #include <stdarg.h>
 
+#include <mutex>
+
 #include "dfq_common.hpp"
 
 namespace dfq {
@@ -25,6 +27,32 @@ int fail_hip(hipError_t e, const char* what, const char* file, int line) {
              file, line);
     g_last_error = buf;
     return DFQ_ERR_HIP;
+}
+
+// ---- SpinGuard (see dfq_common.hpp) ----
+namespace {
+std::mutex g_spin_mu;
+hipEvent_t g_spin_event = nullptr;
+hipStream_t g_spin_stream = nullptr;
+bool g_spin_pending = false;
+}  // namespace
+
+SpinGuard::SpinGuard(hipStream_t stream) : stream_(stream) {
+    std::lock_guard<std::mutex> lock(g_spin_mu);
+    if (g_spin_pending && g_spin_stream != stream_ && g_spin_event)
+        (void)hipStreamWaitEvent(stream_, g_spin_event, 0);
+}
+
+SpinGuard::~SpinGuard() {
+    std::lock_guard<std::mutex> lock(g_spin_mu);
+    if (!g_spin_event && hipEventCreateWithFlags(&g_spin_event, hipEventDisableTiming) != hipSuccess) {
+        g_spin_event = nullptr;
+        return;
+    }
+    if (hipEventRecord(g_spin_event, stream_) == hipSuccess) {
+        g_spin_stream = stream_;
+        g_spin_pending = true;
+    }
 }
 
 }  // namespace dfq

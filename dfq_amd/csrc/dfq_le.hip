@@ -50,6 +50,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <vector>
 
 #include "dfq_common.hpp"
@@ -243,18 +244,35 @@ struct LeDep {
 };
 constexpr long kSpinLimit = 4000000;    // x (sleep + load) ~ several seconds
 constexpr int kDepStride = 16;          // one 64-bit counter per 128-byte line: hundreds of waiting workgroups poll them
-__device__ __forceinline__ void dep_wait(const LeRelDev& R, const LeDep& dep, int naps) {
-    if (R.dep_idx < 0) return;                       // uniform
+// Returns false (for the whole workgroup) when the wait was abandoned: the caller then leaves WITHOUT storing anything,
+// so a failed run never rescales weights with stale statistics -- it only stops short, and `err` makes every later
+// waiter of the plan give up at once (they poll it every 256 spins) and the next query / run report DFQ_ERR_STATE.
+// Memory order: the payload a consumer reads after this wait (row statistics) was written with device-scope atomics,
+// which are performed at the coherence point, and is read with device-scope (sc1) loads, so the counter itself can be
+// relaxed; a release on the add would be a `buffer_wbl2` of every dirty weight line of the XCD per tile.  The producer
+// side orders "statistics performed" before "counter incremented" with s_waitcnt(0) + a workgroup barrier.
+__device__ __forceinline__ bool dep_wait(const LeRelDev& R, const LeDep& dep, int naps, int* sh_flag) {
+    if (R.dep_idx < 0) return true;                  // uniform
     if (threadIdx.x == 0) {
         const unsigned long long target = (unsigned long long)R.dep_tiles * (unsigned long long)(dep.sweep + 1);
         long spins = 0;
+        int ok = 1;
         while (__hip_atomic_load(dep.counters + (int64_t)R.dep_idx * kDepStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
             for (int k = 0; k < naps; ++k) __builtin_amdgcn_s_sleep(8);   // default 2 naps: ~0.5 us between polls
-            if (++spins > kSpinLimit) { atomicMax(dep.err, 1ull); break; }
+            ++spins;
+            if (spins > kSpinLimit ||
+                ((spins & 255) == 0 && __hip_atomic_load(dep.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull)) {
+                atomicMax(dep.err, 1ull);
+                ok = 0;
+                break;
+            }
         }
+        *sh_flag = ok;
     }
     __syncthreads();
+    return *sh_flag != 0;
 }
+constexpr double kTileAbandoned = -1.0;   // a tile function's return value after a failed wait (sums of |dW| are >= 0)
 
 // sum_k |a[k] - b[k]| of one register slot in float64, or 0 when the slot is a clamped duplicate (`on` false).
 // One select per slot on the float64 sum; the magnitude is taken on the float32 difference by clearing the sign bit
@@ -308,7 +326,7 @@ __device__ __forceinline__ void vstore(gfloat* p, const float (&x)[VEC]) {
 // row tile: W1[r0:r0+nr, p0:p0+np] *= s[row]   (+ column stats of the new values)
 template <int VEC>
 __device__ __forceinline__ double row_tile(const LeRelDev& R, const LeParams& p, int tile, int cur, const LeDep& dep,
-                                           float* sh_s, uint32_t* sh_slot, int* sh_g, float* sh_pinv, const LeTrace& tr) {
+                                           float* sh_s, uint32_t* sh_slot, int* sh_g, float* sh_pinv, int* sh_flag, const LeTrace& tr) {
     constexpr int NV = (VEC == 4) ? kSlotsVec4 : kSlotsVec1;   // vectors per thread
     const int tid = threadIdx.x;
     const int rblk = small_div(tile, R.rt_slabs);
@@ -347,7 +365,7 @@ __device__ __forceinline__ double row_tile(const LeRelDev& R, const LeParams& p,
         }
     }
     if (waits) {
-        dep_wait(R, dep, p.poll_naps);
+        if (!dep_wait(R, dep, p.poll_naps, sh_flag)) return kTileAbandoned;
         if (tid < nr) { wa0 = ld_stat(st_a); wa1 = ld_stat(st_a + 1); wb0 = st_b[0]; wb1 = st_b[1]; }
     }
 
@@ -486,7 +504,7 @@ __device__ __forceinline__ double row_tile(const LeRelDev& R, const LeParams& p,
 // G = pow2 >= np/VEC lanes share a row; 256/G rows are in flight per register slot.
 template <int VEC>
 __device__ __forceinline__ double col_tile(const LeRelDev& R, const LeParams& p, int tile, int cur, const LeDep& dep,
-                                           float* sh_inv, uint32_t* sh_row, int* sh_tab, const LeTrace& tr) {
+                                           float* sh_inv, uint32_t* sh_row, int* sh_tab, int* sh_flag, const LeTrace& tr) {
     constexpr int NV = (VEC == 4) ? kSlotsVec4 : kSlotsVec1;
     const int tid = threadIdx.x;
     const int rblk = small_div(tile, R.ct_slabs);
@@ -534,7 +552,7 @@ __device__ __forceinline__ double col_tile(const LeRelDev& R, const LeParams& p,
         }
     }
     if (waits) {
-        dep_wait(R, dep, p.poll_naps);
+        if (!dep_wait(R, dep, p.poll_naps, sh_flag)) return kTileAbandoned;
         if (has_entry) { wa0 = ld_stat(st_a); wa1 = ld_stat(st_a + 1); wb0 = st_b[0]; wb1 = st_b[1]; }
     }
     stamp(tr, 2);
@@ -724,6 +742,7 @@ __global__ __launch_bounds__(kBlock, DFQ_LE_MIN_WAVES) void le_level_kernel(cons
     __shared__ uint32_t sh_u[2 * kSlotMax];         // row tile: column-stat slots; col tile: row stats
     __shared__ int sh_g[kTileRowsMax];              // per-row table offsets
     __shared__ float sh_p[kSlotMax];                // row tile of an interior layer: 1/s of the previous relation
+    __shared__ int sh_flag;                         // outcome of the dependency wait
     const int lane = threadIdx.x % kWave;
     // one 16-byte load of the workgroup's entry, then ONE wave-wide load that fetches the descriptor
     // (lanes 0..kDescWords-1) and the loop state of the network (lane kDescWords) together; v_readlane
@@ -753,15 +772,16 @@ __global__ __launch_bounds__(kBlock, DFQ_LE_MIN_WAVES) void le_level_kernel(cons
     double acc;
     const bool col_side = tile >= R.n_row_tiles;
     if (!col_side) {
-        if (R.rt_vec == 0) { dep_wait(R, dep, p.poll_naps); acc = short_tile<0>(R, p, tile, cur); }
-        else acc = R.rt_vec == 4 ? row_tile<4>(R, p, tile, cur, dep, sh_f, sh_u, sh_g, sh_p, tr)
-                                 : row_tile<1>(R, p, tile, cur, dep, sh_f, sh_u, sh_g, sh_p, tr);
+        if (R.rt_vec == 0) acc = dep_wait(R, dep, p.poll_naps, &sh_flag) ? short_tile<0>(R, p, tile, cur) : kTileAbandoned;
+        else acc = R.rt_vec == 4 ? row_tile<4>(R, p, tile, cur, dep, sh_f, sh_u, sh_g, sh_p, &sh_flag, tr)
+                                 : row_tile<1>(R, p, tile, cur, dep, sh_f, sh_u, sh_g, sh_p, &sh_flag, tr);
     } else {
-        if (R.ct_vec == 0) { dep_wait(R, dep, p.poll_naps); acc = short_tile<1>(R, p, tile - R.n_row_tiles, cur); }
-        else acc = R.ct_vec == 4 ? col_tile<4>(R, p, tile - R.n_row_tiles, cur, dep, sh_f, sh_u, sh_g, tr)
-                                 : col_tile<1>(R, p, tile - R.n_row_tiles, cur, dep, sh_f, sh_u, sh_g, tr);
+        if (R.ct_vec == 0) acc = dep_wait(R, dep, p.poll_naps, &sh_flag) ? short_tile<1>(R, p, tile - R.n_row_tiles, cur) : kTileAbandoned;
+        else acc = R.ct_vec == 4 ? col_tile<4>(R, p, tile - R.n_row_tiles, cur, dep, sh_f, sh_u, sh_g, &sh_flag, tr)
+                                 : col_tile<1>(R, p, tile - R.n_row_tiles, cur, dep, sh_f, sh_u, sh_g, &sh_flag, tr);
     }
     stamp(tr, 6);
+    if (acc < 0.0) return;          // abandoned wait (uniform): nothing was stored, the counter is not bumped
     if (col_side && R.counter_idx >= 0) {
         // every statistics atomic of this workgroup has been performed before the counter moves
         __builtin_amdgcn_s_waitcnt(0);
@@ -1425,6 +1445,11 @@ static int le_enqueue_direct(dfq_le_plan* p, const dfq_le_config* cfg, int n_swe
     const LeParams q = make_params(cfg);
     int rc;
     if (restart && (rc = le_restart(p, cfg, st))) return rc;
+    if (n_sweeps <= 0) return DFQ_OK;
+    // one-launch sweeps contain in-launch waits: never concurrent with another stream's (dfq_common.hpp); not while
+    // the stream is being captured (the graph launch is guarded instead)
+    std::unique_ptr<SpinGuard> guard;
+    if (p->merged && st != p->capture_stream) guard.reset(new SpinGuard(st));
     for (int s = 0; s < n_sweeps; ++s) {
         for (int l = 0; l < dfq_le_plan_levels(p); ++l)
             if ((rc = le_launch_level(p, l, q, st))) return rc;
@@ -1470,6 +1495,7 @@ int dfq_le_enqueue(dfq_le_plan* p, const dfq_le_config* cfg, int32_t n_sweeps, i
         p->graphs.push_back({key, exec});
     }
     p->sweep_index = start_index + n_sweeps;
+    SpinGuard guard(st);
     DFQ_HIP_TRY(hipGraphLaunch(exec, st));
     return DFQ_OK;
 }

@@ -180,6 +180,9 @@ inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) {
 
 typedef struct emu_event* hipEvent_t;
 inline hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return hipSuccess; }
+#define hipEventDisableTiming 2
+inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = (hipEvent_t)1; return hipSuccess; }
+inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
 inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
 inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
