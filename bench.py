@@ -1,26 +1,32 @@
 #!/usr/bin/env python
-"""Headline benchmark: conv weights calibrated per second by one LE+BC pass over a synthetic
-MobileNetV2 (BASELINE.json configs[1]: `--relu --equalize --correction`, 53 layers).
+"""Headline benchmark: conv weights calibrated per second by the LE+BC pass over synthetic MobileNetV2 graphs
+(BASELINE.json configs[1]: `--relu --equalize --correction`, 53 layers), plus one measured entry per other
+BASELINE configuration in the same JSON line.
 
   python bench.py --gpus 1 --steps 20 --warmup 3
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
-A step = one complete pass of the hot path over one network whose folded weights are already
-resident in HBM: cross_layer_equalization for exactly the number of sweeps the reference's
-convergence test needs on this input (measured once, untimed, by the device-side loop) followed by
-bias_correction.  Every step runs on its own replica of the network (in-place algorithm, so a used
-replica is "calibrated"; 288 GB of HBM hold hundreds of replicas), nothing is restored or skipped
-inside the timed region and the host never synchronises between launches.
+Headline (`value`).  A step = one complete pass of the hot path over a batch of `--batch` networks (distinct seeds)
+whose folded weights are already resident in HBM: cross_layer_equalization until every network's reference
+convergence test fires (device-side loop; the host enqueues the largest sweep count, every network leaves at its
+own) followed by bias_correction.  Every step runs on its own replicas (in-place algorithm: a used replica is
+"calibrated"; 288 GB of HBM hold hundreds), nothing is restored or skipped inside the timed region and the host
+never synchronises between launches.  Multi-GPU: the unit that shards without any exchange is a network; rank r
+calibrates its own replicas, `value` = weights calibrated by all ranks / max-over-ranks time -> "scaling": "weak".
 
-Multi-GPU: the unit of work is a network; rank r calibrates its own replicas (independent
-objects, no data-path collective), `value` = weights calibrated by all ranks / max-over-ranks time
--> "scaling": "weak".  The sharded single-network mode with its RCCL exchange lives in
-dfq_amd/sharded.py and is covered by tests, not by this line.
-
-One JSON line on rank 0, with `roofline` (dominant kernel le_level_kernel: algorithmic bytes per
-launch / HIP-event duration per launch) and `cpu_baseline` (the numpy oracle, i.e. a vectorised
-CPU port of the reference's algorithm, timed on this host).
+Next to it, measured by the same run and reported in the same line:
+  latency   one single-network pass with nothing else in flight (what main_cls.py would feel), with its own
+            roofline fraction;
+  config.others   configs[2] ResNet-18, configs[3] DeepLab on one GPU (pinned 60 sweeps), configs[4]
+            the activation-range kernels at MobileNetV2's largest activation (12 B per element);
+  sharded   configs[3] as `north_star` splits it: ONE DeepLab network, relation components partitioned over the
+            ranks, pinned sweeps, ONE all_gather of the cumulative scale vectors (RCCL over xGMI), engine rebuild
+            of the foreign layers, replicated bias correction -> strong scaling (total work fixed); runs at every
+            N (at N = 1 it is the degenerate one-rank group), so a driver run at N = 8 puts 8 ranks on the data path;
+  roofline  dominant kernel le_level_kernel: algorithmic bytes per launch / HIP-event duration per launch;
+  cpu_baseline   the numpy oracle (a vectorised CPU port) timed live on this host + the unmodified reference's own
+            CPU path as measured in the build container (the GPU box has no /root/reference).
 """
 from __future__ import annotations
 
@@ -29,6 +35,7 @@ import contextlib
 import copy
 import json
 import os
+import socket
 import sys
 import time
 
@@ -41,6 +48,7 @@ import torch.nn as nn             # noqa: E402
 
 TARG = [nn.Conv2d, nn.Linear]
 HBM_PEAK_GBS = 8000.0             # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+NETS = ['mobilenet_v2', 'resnet18', 'deeplab_mnv2', 'tiny_mobile', 'tiny_res']
 
 
 def parse():
@@ -48,16 +56,26 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=12)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--net', default='mobilenet_v2', choices=['mobilenet_v2', 'resnet18', 'deeplab_mnv2', 'tiny_mobile'])
+    ap.add_argument('--net', default='mobilenet_v2', choices=NETS)
     ap.add_argument('--sweeps', type=int, default=0, help='pin the LE sweep count (0 = what the convergence test needs)')
     ap.add_argument('--cpu-seconds', type=float, default=10.0, help='CPU-baseline budget (0 disables)')
     ap.add_argument('--batch', type=int, default=32, help='networks calibrated together in one step (one batched plan)')
-    ap.add_argument('--streams', type=int, default=2, help='steps in flight per GPU (one HIP stream + host thread each)')
+    ap.add_argument('--streams', type=int, default=1, help='steps in flight per GPU (one HIP stream + host thread each); '
+                    'kernels with in-launch waits are serialised across streams by the library, so > 1 buys little')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--force-sweeps', action='store_true', help='tuning: run --sweeps sweeps regardless of convergence')
+    ap.add_argument('--others', default='resnet18,deeplab_mnv2:60', help='other BASELINE configs measured on one GPU: '
+                    'comma list of net[:pinned sweeps]; "" disables')
+    ap.add_argument('--act-shape', default='64,96,112,112', help='config 5: activation tensor for the range kernels; "" disables')
+    ap.add_argument('--sharded', default='deeplab_mnv2:60', help='config 4: net:pinned sweeps for the sharded single-network '
+                    'pass; "" disables')
+    ap.add_argument('--sharded-steps', type=int, default=6)
     return ap.parse_args()
 
 
+# ---------------------------------------------------------------------------------------------------
+# set-up helpers (untimed)
+# ---------------------------------------------------------------------------------------------------
 def prepare(net, seed, dev):
     """Random-init network -> device -> BN folded -> relation list (untimed set-up)."""
     from dfq_amd import synthetic
@@ -86,6 +104,13 @@ def make_unit(protos):
     return dict(nets=nets, le=le, bc=bc, plan_build_ms=(time.perf_counter() - t0) * 1e3)
 
 
+def pass_bytes(le, bc, sweeps):
+    """Algorithmic bytes of one LE(sweeps)+BC pass as executed: per sweep 8 B per element read and written +
+    4 B per interior element only measured; bootstrap 4 B per paired element; BC 8 B per weight (min/max + quant-error
+    read) + 8 B per (o, i) pair (eps write + read)."""
+    return sweeps * (8 * le.rw_elements + 4 * le.ro_elements) + 4 * le.paired_elements + 8 * bc.weight_elements + 8 * bc.eps_elements
+
+
 def cpu_baseline(net, seed, budget_s):
     """The numpy oracle (port of dfq.py's LE + BC, vectorised over channels) on this host."""
     from dfq_amd import synthetic
@@ -105,23 +130,43 @@ def cpu_baseline(net, seed, budget_s):
         orc.bias_correction(spec)
         spent += time.perf_counter() - t0
         reps += 1
-    return dict(value=n_w * reps / spent, unit='weights/s', cores=1, kind='port',
-                sample='{} full LE({} sweeps)+BC passes of the numpy oracle over the same synthetic {} '
-                       '({} weights), {:.1f} s of CPU time'.format(reps, sweeps, net, n_w, spent)), sweeps
+    out = dict(value=n_w * reps / spent, unit='weights/s', cores=1, kind='port',
+               sample='{} full LE({} sweeps)+BC passes of the numpy oracle over the same synthetic {} '
+                      '({} weights), {:.1f} s of CPU time'.format(reps, sweeps, net, n_w, spent))
+    out['reference'] = reference_cpu_record(net)
+    return out, sweeps
+
+
+def reference_cpu_record(net):
+    """The UNMODIFIED reference's CPU path (dfq.py:78-117 + :173-293) on the same synthetic network.  It can only be
+    timed where /root/reference exists -- the build container (tools/time_reference.py writes
+    profiles/r02_reference_cpu.json) -- never on the GPU box, so the committed record is carried, labelled as such."""
+    path = os.path.join(ROOT, 'profiles', 'r02_reference_cpu.json')
+    try:
+        rec = json.load(open(path)).get(net)
+    except Exception:
+        rec = None
+    if not rec:
+        return None
+    return {'value': rec['value'], 'unit': rec['unit'], 'cores': rec['cores'], 'kind': 'reference',
+            'sweeps': rec['sweeps'], 'equalization_s': rec['equalization_s'], 'bias_correction_s': rec['bias_correction_s'],
+            'what': rec['what'], 'where': rec['where'] + ' -- committed figure (profiles/r02_reference_cpu.json), not measured by this run'}
 
 
 def _pmc_traffic(net, batch):
-    """HBM bytes per launch of le_level_kernel from the committed PMC summary (MobileNetV2 only), else null.
-    The counters were collected on a batch of `summary['batch']` networks; a launch over `batch` networks runs
-    the same tiles once per network, so the figure scales with the batch (returned with the batch it came from)."""
-    path = os.path.join(ROOT, 'profiles', 'r01_pmc_summary.json')
-    if net != 'mobilenet_v2' or not os.path.exists(path):
-        return None, None
-    try:
-        summary = json.load(open(path))
-        return summary['le_level_kernel']['traffic_bytes_per_launch'] * batch / summary['batch'], summary['batch']
-    except Exception:
-        return None, None
+    """HBM bytes per launch of le_level_kernel from the committed PMC summary of a run with exactly this batch
+    (rocprofv3 --pmc cannot run inside this process), else null."""
+    for name in ('r02_pmc_summary.json', 'r01_pmc_summary.json'):
+        path = os.path.join(ROOT, 'profiles', name)
+        if net != 'mobilenet_v2' or not os.path.exists(path):
+            continue
+        try:
+            summary = json.load(open(path))
+            if int(summary['batch']) == int(batch):
+                return summary['le_level_kernel']['traffic_bytes_per_launch'], 'profiles/' + name
+        except Exception:
+            pass
+    return None, None
 
 
 _BACKEND = 'nccl'
@@ -175,6 +220,149 @@ def _gpu_elapsed_ms(fn):
     return ev0.elapsed_time(ev1)
 
 
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+# ---------------------------------------------------------------------------------------------------
+# single-network measurements (latency, the other BASELINE configs)
+# ---------------------------------------------------------------------------------------------------
+def single_network_pass(proto, sweeps, reps=4, warm=2, pinned=False):
+    """Wall time of ONE network's LE(sweeps)+BC pass with nothing else in flight, and its two halves as GPU time.
+    `pinned`: run exactly `sweeps` sweeps (a network whose reference loop does not terminate)."""
+    kw = dict(converge_thres=-1.0, converge_count=10 ** 9) if pinned else {}
+    units = [make_unit([proto]) for _ in range(reps + warm + 2)]
+
+    def one(u):
+        u['le'].enqueue(sweeps, restart=True, max_sweeps=sweeps, **kw)
+        u['bc'].run()
+    for u in units[:warm]:
+        one(u)
+    _sync()
+    t0 = time.perf_counter()
+    for u in units[warm:warm + reps]:
+        one(u)
+    _sync()
+    wall_ms = (time.perf_counter() - t0) * 1e3 / reps
+    le_ms = _gpu_elapsed_ms(lambda: units[-2]['le'].enqueue(sweeps, restart=True, max_sweeps=sweeps, **kw))
+    bc_ms = _gpu_elapsed_ms(lambda: units[-2]['bc'].run())
+    for u in units:                      # a failed in-launch wait would have left the weights short of the result: raise
+        u['le'].query()
+        u['bc'].status()
+    nbytes = pass_bytes(units[0]['le'], units[0]['bc'], sweeps)
+    return dict(pass_ms=wall_ms, equalization_ms=le_ms, bias_correction_ms=bc_ms, algorithmic_bytes=nbytes,
+                achieved_GBps=nbytes / (wall_ms * 1e-3) / 1e9, frac_of_hbm_peak=nbytes / (wall_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                launches_per_sweep=units[0]['le'].levels + 1)
+
+
+def other_configs(spec, dev):
+    """configs[2], configs[3] (single GPU): one network each, its own sweep count (or the pinned one)."""
+    out = []
+    for item in [s for s in spec.split(',') if s]:
+        net, _, pin = item.partition(':')
+        proto = prepare(net, 0, dev)
+        n_w = sum(m.weight.numel() for m in proto[1].values() if type(m) in TARG)
+        if pin:
+            sweeps, pinned = int(pin), True
+        else:
+            probe = make_unit([proto])
+            sweeps, pinned = probe['le'].run()['sweeps'], False
+        m = single_network_pass(proto, sweeps, pinned=pinned)
+        out.append({'net': net, 'weights': n_w, 'relations': len(proto[3]), 'sweeps': sweeps,
+                    'sweeps_pinned': pinned, 'ms': m['pass_ms'], 'weights_per_s': n_w / (m['pass_ms'] * 1e-3),
+                    'equalization_ms': m['equalization_ms'], 'bias_correction_ms': m['bias_correction_ms'],
+                    'algorithmic_bytes': m['algorithmic_bytes'], 'achieved_GBps': m['achieved_GBps'],
+                    'roofline_frac': m['frac_of_hbm_peak']})
+    return out
+
+
+def activation_range_kernels(shape, dev):
+    """configs[4] (--distill_range): the kernels behind QuantMeasure.forward at MobileNetV2's largest activation
+    (utils/quantize.py:102-119): per-sample min/max + running update (4 B per element), fake-quant with the recorded range
+    (8 B per element) -> 12 B per element for the module; plus the weight quantiser of
+    quantize_targ_layer over a whole MobileNetV2 (12 B per weight, two launches)."""
+    from dfq_amd.utils import quantize as q
+    from dfq_amd.utils import layer_transform as lt
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(*shape, generator=g).clamp_(-2.1179, 2.64).to(dev)
+    n = x.numel()
+    out = torch.empty_like(x)
+    running = torch.zeros(2, device=dev)
+    rows = []
+
+    def timed(fn, reps=5):
+        fn()
+        _sync()
+        return min(_gpu_elapsed_ms(fn) for _ in range(reps))
+    ms = timed(lambda: q.sample_minmax_mean(x, shape[0], running=running))
+    rows.append({'kernel': 'sample_minmax_kernel (+ sample_mean_kernel)', 'bytes': 4 * n, 'us': ms * 1e3})
+    ms = timed(lambda: q.fake_quant_device(x, out, 8, False, 1, 0.0, 0.0, running, None))
+    rows.append({'kernel': 'fake_quant_kernel', 'bytes': 8 * n, 'us': ms * 1e3})
+    m = q.QuantMeasure(update_stat=True).to(dev).eval()
+    ms = timed(lambda: m(x))
+    rows.append({'kernel': 'QuantMeasure.forward (update_stat): 3 launches', 'bytes': 12 * n, 'us': ms * 1e3})
+    proto = prepare('mobilenet_v2' if n > 10 ** 6 else 'tiny_mobile', 0, dev)
+    n_w = sum(m_.weight.numel() + (m_.bias.numel() if m_.bias is not None else 0) for m_ in proto[1].values() if type(m_) in TARG)
+    with contextlib.redirect_stdout(sys.stderr):
+        ms = timed(lambda: lt.quantize_targ_layer(proto[1], 8, 16, TARG), reps=3)
+    rows.append({'kernel': 'seg_minmax_kernel + seg_fake_quant_kernel (quantize_targ_layer, one network, host-synchronous call)',
+                 'bytes': 12 * n_w, 'us': ms * 1e3})
+    for r in rows:
+        r['GBps'] = r['bytes'] / max(r['us'], 1e-9) / 1e3
+        r['frac'] = r['GBps'] / HBM_PEAK_GBS
+    return {'config': 'MobileNetV2 --distill_range (configs[4]): activation [{}] float32'.format(', '.join(map(str, shape))),
+            'elements': n, 'kernels': rows}
+
+
+# ---------------------------------------------------------------------------------------------------
+# config 4: one network sharded over the ranks (north_star's split)
+# ---------------------------------------------------------------------------------------------------
+def sharded_single_network(spec, steps, dev, dist, rank, world):
+    from dfq_amd import dfq, sharded
+    net, _, pin = spec.partition(':')
+    sweeps = int(pin or 60)
+    proto = prepare(net, 0, dev)                       # the SAME network on every rank (seed 0)
+    n_w = sum(m.weight.numel() for m in proto[1].values() if type(m) in TARG)
+    reps = []
+    for _ in range(steps + 2):
+        model, graph, bottoms, rels = copy.deepcopy(proto)
+        eq = sharded.ShardedEqualizer(graph, rels, TARG)            # partition + the owned components' plan (untimed)
+        bc, _ = dfq.build_bc_plan(graph, bottoms, TARG)
+        reps.append((eq, bc, graph))
+
+    def one(r):
+        r[0].run(max_sweeps=sweeps)          # local sweeps -> ONE all_gather -> rebuild of the foreign layers
+        r[1].run()                           # the correction chain is sequential over layers: replicated on every rank
+
+    def fence():
+        _sync()
+        dist.barrier()
+        _sync()
+    for r in reps[:2]:
+        one(r)
+    fence()
+    t0 = time.perf_counter()
+    for r in reps[2:]:
+        one(r)
+    fence()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == 'nccl' else 'cpu')
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    ms = float(t.item()) * 1e3 / steps
+    owned = sorted(set(reps[0][0].owner))
+    return {'net': net, 'weights': n_w, 'relations': len(proto[3]), 'sweeps': sweeps, 'sweeps_pinned': True, 'world': world,
+            'ranks_owning_components': len(owned), 'ms_per_pass': ms, 'value': n_w / (ms * 1e-3), 'unit': 'weights/s',
+            'scaling': 'strong', 'collectives_per_pass': 1, 'exchange_bytes_per_rank': reps[0][0].exchange_bytes,
+            'backend': dist.get_backend(),
+            'what': 'ONE {} network per pass: relation components partitioned over the ranks, {} pinned sweeps per rank on the '
+                    'owned components, one all_gather of the cumulative scale vectors, engine rebuild of the foreign layers '
+                    '(W = diag(S_out) W0 diag(1/S_in)), bias correction replicated on every rank; plans prebuilt, weights '
+                    'resident'.format(net, sweeps)}
+
+
+# ---------------------------------------------------------------------------------------------------
 def main():
     args = parse()
     rank = int(os.environ.get('RANK', '0'))
@@ -185,16 +373,24 @@ def main():
             raise SystemExit('launch with torch.distributed.run --nproc-per-node {}'.format(args.gpus))
     dev = _device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.sharded:
         import torch.distributed as dist_mod
-        dist = dist_mod
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        with _stdout_to_stderr():                          # RCCL prints a version banner to stdout at start-up
-            if _BACKEND == 'nccl':                         # RCCL over xGMI: one rank per GPU
-                dist.init_process_group('nccl', device_id=dev)
-            else:                                          # CPU dry run of the multi-rank path (tests/emu/dryrun.py)
-                dist.init_process_group(_BACKEND)
-            dist.barrier()                                 # communicators are created lazily: do it here
+        if world == 1:                                     # the sharded pass needs a (one-rank) group
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            os.environ.setdefault('MASTER_PORT', str(_free_port()))
+        try:
+            with _stdout_to_stderr():                          # RCCL prints a version banner to stdout at start-up
+                if _BACKEND == 'nccl':                         # RCCL over xGMI: one rank per GPU
+                    dist_mod.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+                else:                                          # CPU dry run of the multi-rank path (tests/emu/dryrun.py)
+                    dist_mod.init_process_group(_BACKEND, rank=rank, world_size=world)
+                dist_mod.barrier()                             # communicators are created lazily: do it here
+            dist = dist_mod
+        except Exception as e:                                 # N = 1 only: the headline does not need a group
+            if world > 1:
+                raise
+            print('bench.py: no process group at N=1 ({}); the sharded entry is skipped'.format(e), file=sys.stderr)
 
     from dfq_amd import _ffi
     _ffi.lib()
@@ -211,7 +407,7 @@ def main():
     probe['le'].run()
     net_sweeps = [r['sweeps'] for r in probe['le'].query_all()[0]]
     sweeps = args.sweeps if args.sweeps > 0 else max(net_sweeps)
-    if dist is not None and args.sweeps == 0:          # every rank enqueues the same amount of work per step
+    if world > 1 and args.sweeps == 0:          # every rank enqueues the same amount of work per step
         t = torch.tensor([sweeps], device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         sweeps = int(t.item())
@@ -229,7 +425,7 @@ def main():
 
     def fence():
         _sync()
-        if dist is not None:
+        if world > 1:
             dist.barrier()
         _sync()
 
@@ -263,28 +459,18 @@ def main():
     run(units[args.warmup:])
     fence()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
+    if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     if not args.force_sweeps and args.sweeps == 0:
-        done = [r['sweeps'] for r in units[-1]['le'].query_all()[0]]
-        assert done == net_sweeps, 'timed steps ran {} sweeps, the probe {}'.format(done, net_sweeps)
+        # every network of EVERY timed batch stopped where the probe stopped (query also surfaces a failed in-launch wait)
+        for u in units[args.warmup:]:
+            done = [r['sweeps'] for r in u['le'].query_all()[0]]
+            assert done == net_sweeps, 'timed steps ran {} sweeps, the probe {}'.format(done, net_sweeps)
+    for u in units[args.warmup:]:
+        u['bc'].status()
     ms_per_step = elapsed * 1e3 / args.steps
-
-    # latency of ONE single-network pass with nothing else in flight (reported next to the throughput)
-    lat_units = [make_unit(protos[:1]) for _ in range(6)]
-    with _stream_ctx(streams[0]):
-        for u in lat_units[:2]:
-            u['le'].enqueue(net_sweeps[0], restart=True, max_sweeps=net_sweeps[0])
-            u['bc'].run()
-        fence()
-        t0 = time.perf_counter()
-        for u in lat_units[2:]:
-            u['le'].enqueue(net_sweeps[0], restart=True, max_sweeps=net_sweeps[0])
-            u['bc'].run()
-        fence()
-        single_ms = (time.perf_counter() - t0) * 1e3 / 4
 
     # where a step's time goes: the two halves of one unit on an otherwise idle GPU (one stream)
     br_units = [make_unit(protos) for _ in range(3)]
@@ -319,7 +505,6 @@ def main():
             'networks_per_step': batch * world,
             'launches_per_sweep': levels + 1,
             'units_in_flight_per_gpu': n_streams,
-            'single_pass_latency_ms': single_ms,
             'one_unit_alone_ms': {'equalization': le_ms, 'bias_correction': bc_ms},
             # host-side, once per batch, outside the timed region (like graph tracing / BN folding): descriptor and
             # launch tables of the two plans, small device allocations, one synchronisation
@@ -327,8 +512,22 @@ def main():
         },
     }
 
+    # ---- one network alone: the latency a caller of the drop-in API sees (first-class, with its own roofline fraction) ----
+    if rank == 0:
+        with _stream_ctx(streams[0]):
+            lat = single_network_pass(protos[0], net_sweeps[0] if args.sweeps == 0 else sweeps, pinned=args.sweeps > 0)
+        out['latency'] = {
+            'single_network_pass_ms': lat['pass_ms'], 'sweeps': net_sweeps[0] if args.sweeps == 0 else sweeps,
+            'equalization_gpu_ms': lat['equalization_ms'], 'bias_correction_gpu_ms': lat['bias_correction_ms'],
+            'weights_per_s': n_w / (lat['pass_ms'] * 1e-3), 'algorithmic_bytes_per_pass': lat['algorithmic_bytes'],
+            'achieved_GBps': lat['achieved_GBps'], 'frac_of_hbm_peak': lat['frac_of_hbm_peak'],
+            'launches_per_sweep': lat['launches_per_sweep'],
+            'bound': 'latency of the dependency chain (a network is {:.1f} MB: cache-resident; see DESIGN.md)'.format(n_w * 4 / 1e6),
+        }
+        out['config']['single_pass_latency_ms'] = lat['pass_ms']
+
     if rank == 0 and not args.no_roofline:
-        # Dominant kernel: le_level_kernel (5 launches per sweep).  Algorithmic bytes of a launch = 8 B per
+        # Dominant kernel: le_level_kernel (one launch per sweep).  Algorithmic bytes of a launch = 8 B per
         # element it reads and writes (every weight of a paired layer once per sweep; the ranges are
         # by-products) + 4 B per element of an interior layer it only measures.  Its duration
         # comes from HIP events on the launch stream:
@@ -361,24 +560,40 @@ def main():
             nbytes = 8 * info['rw_elements'] + 4 * info['ro_elements']
             per_level.append({'level': l, 'relations': info['relations'], 'workgroups': info['workgroups'],
                               'bytes': nbytes, 'us': us, 'GBps': nbytes / max(us, 1e-9) / 1e3})
-        # SURVEY.md 8(d) contract figure for the same launches: 8 B per paired element + 12 B per weight for the
-        # convergence diff with a snapshot refresh -- what an eager restatement of dfq.py:84-108 moves.  This
-        # engine takes the diff inside the rescale pass, so it moves less; `achieved` above is priced on the
-        # bytes it actually needs, `achieved_survey_8d` on the contract figure.
+        # SURVEY.md 8(d)'s eager contract for the same launches: 8 B per paired element + 12 B per weight for a separate
+        # convergence pass with a snapshot refresh -- what a restatement of dfq.py:84-108 would move.  This engine takes the
+        # diff inside the rescale pass and writes interior layers once, so it moves 2.4x fewer bytes; `achieved` / `frac` are
+        # priced on the bytes it actually needs.  The eager figure is NOT a roofline fraction of this kernel: it says how fast
+        # an eager implementation would have to stream to finish a sweep in the same time.
         survey_bytes = (8 * paired + 12 * n_w * batch) / levels
-        traffic, traffic_batch = _pmc_traffic(args.net, batch)
+        traffic, traffic_src = _pmc_traffic(args.net, batch)
         out['roofline'] = {
             'bound': 'hbm', 'kernel': 'le_level_kernel', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
             'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_unit': 'bytes per launch',
-            'traffic_source': 'profiles/r01_pmc_summary.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes on a '
-                              'batch of {} networks, scaled to this batch (same tiles per network); a profiler pass '
-                              'cannot run inside this process'.format(traffic_batch),
+            'traffic_source': ('{}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of this command at this batch size; '
+                               'a profiler pass cannot run inside this process'.format(traffic_src)) if traffic_src else None,
             'bytes_per_launch': avg_bytes, 'us_per_launch': avg_ms * 1e3, 'launches_timed': launches,
-            'achieved_survey_8d': survey_bytes / max(avg_ms * 1e-3, 1e-12) / 1e9,
-            'frac_survey_8d': survey_bytes / max(avg_ms * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBS,
+            'eager_formulation_bytes_per_launch': survey_bytes,
+            'eager_formulation_equivalent_GBps': survey_bytes / max(avg_ms * 1e-3, 1e-12) / 1e9,
             'sweep_wall_us': sweep_ms * 1e3, 'control_us_per_sweep': sweep_ms * 1e3 * (1.0 - share_levels),
             'event_pair_overhead_us': empty * 1e3, 'levels': per_level,
         }
+
+    # ---- the other BASELINE configurations, each with ms and roofline fraction ----
+    if rank == 0 and args.others:
+        with _stream_ctx(streams[0]):
+            out['config']['others'] = other_configs(args.others, dev)
+    if rank == 0 and args.act_shape:
+        with _stream_ctx(streams[0]):
+            out['config']['activation_ranges'] = activation_range_kernels([int(v) for v in args.act_shape.split(',')], dev)
+
+    # ---- config 4 as north_star splits it (every rank takes part) ----
+    if args.sharded and dist is not None:
+        with _stream_ctx(streams[0]):
+            sh = sharded_single_network(args.sharded, args.sharded_steps, dev, dist, rank, world)
+        if rank == 0:
+            out['sharded'] = sh
+
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         out['cpu_baseline'], cpu_sweeps = cpu_baseline(args.net, rank * 1000, args.cpu_seconds)
         if args.sweeps == 0:

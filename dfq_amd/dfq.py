@@ -417,7 +417,11 @@ class BCPlan:
         one-launch chain gave up waiting for the step it depends on."""
         _ffi.check(_ffi.lib().dfq_bc_plan_run(self._plan, int(bool(signed)), _ffi.stream_arg()))
         if check:
-            _ffi.check(_ffi.lib().dfq_bc_plan_status(self._plan, _ffi.stream_arg()))
+            self.status()
+
+    def status(self):
+        """Synchronise and raise if a workgroup of the one-launch chain abandoned its wait (nothing was stored by it)."""
+        _ffi.check(_ffi.lib().dfq_bc_plan_status(self._plan, _ffi.stream_arg()))
 
     def _view(self, addr, n):
         """Copy n floats out of the plan's device scratch (tests / debugging)."""

@@ -130,6 +130,96 @@ class _RunnerSession:
         pass
 
 
+class ShardedEqualizer:
+    """One network, one rank's share of it.  Construction (host side, untimed in bench.py) partitions the relation
+    graph, builds the engine plan of the owned components and the flat exchange buffer; ``run`` is the data path:
+    local sweeps -> ONE all_gather of the cumulative scale vectors -> rebuild of the foreign layers."""
+
+    def __init__(self, graph, relations, targ_type, group=None, s_range=(1e-8, 1e8), signed=False, eps=0,
+                 le_runner=None, rescale=None):
+        self.graph, self.relations, self.targ_type, self.group = graph, relations, targ_type, group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self.rescale = rescale or _engine_rescale
+        self.owner = assign_components(graph, relations, self.world)
+        self.mine = [rr for rr, o in zip(relations, self.owner) if o == self.rank]
+        self.foreign = [(i, rr) for i, (rr, o) in enumerate(zip(relations, self.owner)) if o != self.rank]
+        with torch.no_grad():
+            for _, rr in self.foreign:                               # dfq.py:91-92 on every rank
+                first = graph[rr.get_idxs()[0]]
+                if first.bias is None:
+                    first.bias = torch.nn.Parameter(torch.zeros(first.weight.size(0), dtype=torch.float32,
+                                                                device=first.weight.device), requires_grad=False)
+            self.session = None
+            if self.mine:
+                self.session = (_RunnerSession(le_runner, graph, self.mine, targ_type, s_range, signed, eps)
+                                if le_runner is not None else _EngineSession(graph, self.mine, targ_type, s_range, signed, eps))
+        # exchange layout: the cumulative S of every relation, concatenated in list order (4 B per paired channel)
+        self.lens = [graph[rr.get_idxs()[0]].weight.size(0) for rr in relations]
+        self.offsets = [0]
+        for n in self.lens:
+            self.offsets.append(self.offsets[-1] + n)
+        self.dev = graph[relations[0].get_idxs()[0]].weight.device if relations else torch.device('cpu')
+        self.comm_dev = self.dev if dist.get_backend(group) == 'nccl' else torch.device('cpu')
+        self.exchange_bytes = 4 * self.offsets[-1]
+
+    def run(self, max_sweeps=None, converge_thres=2e-7, converge_count=20):
+        """Returns the number of sweeps.  ``max_sweeps=N`` pins the count (no exchange before the final all_gather);
+        ``None`` keeps the reference's data-dependent loop with one 8-byte all_reduce per sweep."""
+        graph, relations, group, session = self.graph, self.relations, self.group, self.session
+        with torch.no_grad():
+            try:
+                if max_sweeps is not None:
+                    if session is not None and max_sweeps > 0:
+                        session.sweeps(max_sweeps)
+                    sweeps = max_sweeps
+                else:
+                    diff, count, sweeps = 10.0, 0, 0
+                    while diff > converge_thres and count < converge_count:       # dfq.py:83
+                        local = 0.0
+                        if session is not None:
+                            session.sweeps(1)
+                            local = session.last_diff()
+                        t = torch.tensor([local], dtype=torch.float64, device=self.comm_dev)
+                        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+                        diff_tmp = float(t.item())
+                        if abs(diff - diff_tmp) > 1e-9:                           # dfq.py:110-115
+                            count, diff = 0, diff_tmp
+                        else:
+                            count += 1
+                        sweeps += 1
+            finally:
+                if session is not None:
+                    session.close()
+                    self.session = None
+            # ---- exchange: ONE all_gather of the cumulative scale vectors (RCCL over xGMI when the group is 'nccl') ----
+            flat = torch.ones(self.offsets[-1], dtype=torch.float32, device=self.comm_dev)
+            for i, (rr, o) in enumerate(zip(relations, self.owner)):
+                if o == self.rank and rr.S is not None:
+                    flat[self.offsets[i]:self.offsets[i + 1]] = rr.S.to(self.comm_dev)
+            gathered = torch.empty(self.world * self.offsets[-1], dtype=torch.float32, device=self.comm_dev)
+            dist.all_gather_into_tensor(gathered, flat, group=group)
+            gathered = gathered.view(self.world, -1)
+            S_all = [gathered[o, self.offsets[i]:self.offsets[i + 1]].to(self.dev) for i, o in enumerate(self.owner)]
+            # ---- rebuild what the other ranks equalised: W = diag(S_out) . W0 . diag(1 / S_in) ----
+            s_out, s_in = {}, {}
+            for (i, rr) in self.foreign:
+                a, b, _ = rr.get_idxs()
+                s_out[a] = (S_all[i], rr)
+                s_in[b] = S_all[i]
+                rr.S = S_all[i]
+            for key in [k for k in graph if k in s_out or k in s_in]:
+                layer = graph[key]
+                so, rr = s_out.get(key, (None, None))
+                bn = []
+                if rr is not None and rr.get_idxs()[2] is not None:
+                    bnm = graph[rr.get_idxs()[2]]
+                    bn = [t for t in (getattr(bnm, 'fake_weight', None), getattr(bnm, 'fake_bias', None)) if t is not None]
+                self.rescale(layer.weight, layer.bias if so is not None else None, bn, so, s_in.get(key),
+                             getattr(layer, 'groups', 1))
+        return sweeps
+
+
 def sharded_cross_layer_equalization(graph, relations, targ_type, group=None, s_range=(1e-8, 1e8),
                                      converge_thres=2e-7, converge_count=20, signed=False, eps=0,
                                      max_sweeps=None, le_runner=None, rescale=None):
@@ -140,84 +230,9 @@ def sharded_cross_layer_equalization(graph, relations, targ_type, group=None, s_
     CPU stand-ins to exercise the partition / exchange / rebuild logic over gloo.
 
     ``max_sweeps=N`` pins the sweep count (no exchange before the final all_gather -- the mode for networks
-    whose reference loop does not terminate, SURVEY 7.3 item 4, and the one bench.py --mode sharded times);
+    whose reference loop does not terminate, SURVEY 7.3 item 4, and the one bench.py times for config 4);
     ``max_sweeps=None`` keeps the reference's data-dependent loop: one 8-byte all_reduce per sweep.
     """
-    rank = dist.get_rank(group)
-    world = dist.get_world_size(group)
-    rescale = rescale or _engine_rescale
-    owner = assign_components(graph, relations, world)
-    mine = [rr for rr, o in zip(relations, owner) if o == rank]
-    foreign = [(i, rr) for i, (rr, o) in enumerate(zip(relations, owner)) if o != rank]
-
-    with torch.no_grad():
-        for _, rr in foreign:                               # dfq.py:91-92 on every rank
-            first = graph[rr.get_idxs()[0]]
-            if first.bias is None:
-                first.bias = torch.nn.Parameter(torch.zeros(first.weight.size(0), dtype=torch.float32,
-                                                            device=first.weight.device), requires_grad=False)
-        # ---- local sweeps: one session (= one engine plan) per rank for the whole run ----
-        session = None
-        if mine:
-            session = (_RunnerSession(le_runner, graph, mine, targ_type, s_range, signed, eps) if le_runner is not None
-                       else _EngineSession(graph, mine, targ_type, s_range, signed, eps))
-        try:
-            if max_sweeps is not None:
-                if session is not None and max_sweeps > 0:
-                    session.sweeps(max_sweeps)
-                sweeps = max_sweeps
-            else:
-                diff, count, sweeps = 10.0, 0, 0
-                dev = next(iter(graph[k] for k in graph if type(graph[k]) in targ_type)).weight.device
-                red_dev = dev if dist.get_backend(group) == 'nccl' else 'cpu'
-                while diff > converge_thres and count < converge_count:       # dfq.py:83
-                    local = 0.0
-                    if session is not None:
-                        session.sweeps(1)
-                        local = session.last_diff()
-                    t = torch.tensor([local], dtype=torch.float64, device=red_dev)
-                    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-                    diff_tmp = float(t.item())
-                    if abs(diff - diff_tmp) > 1e-9:                           # dfq.py:110-115
-                        count, diff = 0, diff_tmp
-                    else:
-                        count += 1
-                    sweeps += 1
-        finally:
-            if session is not None:
-                session.close()
-        # ---- exchange: one all_gather of the cumulative scale vectors, padded to a common length ----
-        lens = [graph[rr.get_idxs()[0]].weight.size(0) for rr in relations]
-        total = sum(lens)
-        dev = graph[relations[0].get_idxs()[0]].weight.device if relations else torch.device('cpu')
-        comm_dev = dev if dist.get_backend(group) == 'nccl' else torch.device('cpu')
-        flat = torch.ones(total, dtype=torch.float32, device=comm_dev)
-        off = 0
-        for rr, o, n in zip(relations, owner, lens):
-            if o == rank and rr.S is not None:
-                flat[off:off + n] = rr.S.to(comm_dev)
-            off += n
-        gathered = [torch.empty_like(flat) for _ in range(world)]
-        dist.all_gather(gathered, flat, group=group)
-        off = 0
-        S_all = []
-        for o, n in zip(owner, lens):
-            S_all.append(gathered[o][off:off + n].to(dev))
-            off += n
-        # ---- rebuild what the other ranks equalised ----
-        s_out, s_in = {}, {}
-        for (i, rr) in foreign:
-            a, b, _ = rr.get_idxs()
-            s_out[a] = (S_all[i], rr)
-            s_in[b] = S_all[i]
-            rr.S = S_all[i]
-        for key in set(s_out) | set(s_in):
-            layer = graph[key]
-            so, rr = s_out.get(key, (None, None))
-            bn = []
-            if rr is not None and rr.get_idxs()[2] is not None:
-                bnm = graph[rr.get_idxs()[2]]
-                bn = [t for t in (getattr(bnm, 'fake_weight', None), getattr(bnm, 'fake_bias', None)) if t is not None]
-            rescale(layer.weight, layer.bias if so is not None else None, bn, so, s_in.get(key),
-                    getattr(layer, 'groups', 1))
-    return sweeps
+    eq = ShardedEqualizer(graph, relations, targ_type, group=group, s_range=s_range, signed=signed, eps=eps,
+                          le_runner=le_runner, rescale=rescale)
+    return eq.run(max_sweeps=max_sweeps, converge_thres=converge_thres, converge_count=converge_count)

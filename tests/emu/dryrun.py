@@ -37,9 +37,10 @@ bench._bind_thread = lambda dev: None
 bench._stream_ctx = lambda s: contextlib.nullcontext()
 world = int(os.environ.get('WORLD_SIZE', '1'))
 sys.argv = ['bench.py', '--net', 'tiny_mobile', '--steps', '2', '--warmup', '1', '--cpu-seconds', '0.2', '--streams', '1', '--batch', '2',
-            '--gpus', str(world)]
-if world > 1:                      # the multi-rank path of bench.py over gloo (tests/test_bench_multirank.py)
-    bench._BACKEND = 'gloo'
+            '--gpus', str(world), '--others', 'tiny_res,tiny_mobile:3', '--act-shape', '4,3,8,8', '--sharded', 'tiny_mobile:4',
+            '--sharded-steps', '2']
+bench._BACKEND = 'gloo'            # the process group of bench.py over gloo (tests/test_bench_multirank.py)
+if world > 1:
     bench.main()
     sys.exit(0)
 bench.main()

@@ -32,6 +32,10 @@ def test_two_ranks_weak_scaling_line():
     d = json.loads(lines[0])
     assert d['n_gpus'] == 2 and d['scaling'] == 'weak' and d['config']['networks_per_step'] == 4
     assert d['value'] > 0 and d['vs_baseline'] is None and 'cpu_baseline' not in d     # CPU baseline: N=1 only
+    # config 4 as north_star splits it: both ranks on the data path, one collective per pass, strong scaling
+    sh = d['sharded']
+    assert sh['world'] == 2 and sh['ranks_owning_components'] == 2 and sh['collectives_per_pass'] == 1
+    assert sh['scaling'] == 'strong' and sh['sweeps_pinned'] and sh['value'] > 0 and sh['exchange_bytes_per_rank'] > 0
 
 
 def test_bench_line_contract_single_rank():
@@ -60,3 +64,13 @@ def test_bench_line_contract_single_rank():
         assert key in c, key
     assert c['kind'] == 'port' and c['cores'] == 1 and c['unit'] == 'weights/s'
     assert abs(d['value'] - d['config']['networks_per_step'] * 5000 / (d['ms_per_step'] * 1e-3)) < 1e-6 * d['value']
+    assert 'frac_survey_8d' not in r and 'eager_formulation_equivalent_GBps' in r     # not a fraction
+    lat = d['latency']
+    assert lat['single_network_pass_ms'] > 0 and 0 < lat['frac_of_hbm_peak'] and lat['sweeps'] == d['config']['le_sweeps'][0]
+    others = d['config']['others']
+    assert [o['net'] for o in others] == ['tiny_res', 'tiny_mobile'] and others[1]['sweeps_pinned'] and others[1]['sweeps'] == 3
+    assert all(o['ms'] > 0 and o['roofline_frac'] > 0 for o in others)
+    act = d['config']['activation_ranges']
+    assert [k['bytes'] for k in act['kernels'][:3]] == [4 * act['elements'], 8 * act['elements'], 12 * act['elements']]
+    assert d['sharded']['world'] == 1 and d['sharded']['scaling'] == 'strong'
+    assert 'reference' in c          # the committed reference-CPU record (null for nets it was not measured on)
