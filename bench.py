@@ -60,8 +60,8 @@ def parse():
     ap.add_argument('--sweeps', type=int, default=0, help='pin the LE sweep count (0 = what the convergence test needs)')
     ap.add_argument('--cpu-seconds', type=float, default=10.0, help='CPU-baseline budget (0 disables)')
     ap.add_argument('--batch', type=int, default=32, help='networks calibrated together in one step (one batched plan)')
-    ap.add_argument('--streams', type=int, default=1, help='steps in flight per GPU (one HIP stream + host thread each); '
-                    'kernels with in-launch waits are serialised across streams by the library, so > 1 buys little')
+    ap.add_argument('--streams', type=int, default=2, help='steps in flight per GPU (one HIP stream + host thread each); '
+                    'kernels with in-launch waits are serialised across streams by the library, the others overlap')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--force-sweeps', action='store_true', help='tuning: run --sweeps sweeps regardless of convergence')
     ap.add_argument('--others', default='resnet18,deeplab_mnv2:60', help='other BASELINE configs measured on one GPU: '
@@ -176,6 +176,7 @@ _BACKEND = 'nccl'
 def _stdout_to_stderr():
     """File-descriptor level: whatever native libraries print to stdout inside the block goes to stderr, so that the
     one JSON line stays the only thing on rank 0's stdout."""
+    import ctypes
     sys.stdout.flush()
     saved = os.dup(1)
     try:
@@ -183,6 +184,10 @@ def _stdout_to_stderr():
         yield
     finally:
         sys.stdout.flush()
+        try:
+            ctypes.CDLL(None).fflush(None)      # C stdio of native libraries (RCCL's banner): drain it while fd 1 is still stderr
+        except Exception:
+            pass
         os.dup2(saved, 1)
         os.close(saved)
 
@@ -284,7 +289,6 @@ def activation_range_kernels(shape, dev):
     (8 B per element) -> 12 B per element for the module; plus the weight quantiser of
     quantize_targ_layer over a whole MobileNetV2 (12 B per weight, two launches)."""
     from dfq_amd.utils import quantize as q
-    from dfq_amd.utils import layer_transform as lt
     g = torch.Generator().manual_seed(1)
     x = torch.randn(*shape, generator=g).clamp_(-2.1179, 2.64).to(dev)
     n = x.numel()
@@ -292,10 +296,15 @@ def activation_range_kernels(shape, dev):
     running = torch.zeros(2, device=dev)
     rows = []
 
-    def timed(fn, reps=5):
+    def timed(fn, reps=10):
+        """GPU time per call with `reps` calls enqueued back to back (the host prepares call i+1 while call i runs)."""
         fn()
         _sync()
-        return min(_gpu_elapsed_ms(fn) for _ in range(reps))
+
+        def many():
+            for _ in range(reps):
+                fn()
+        return min(_gpu_elapsed_ms(many) for _ in range(3)) / reps
     ms = timed(lambda: q.sample_minmax_mean(x, shape[0], running=running))
     rows.append({'kernel': 'sample_minmax_kernel (+ sample_mean_kernel)', 'bytes': 4 * n, 'us': ms * 1e3})
     ms = timed(lambda: q.fake_quant_device(x, out, 8, False, 1, 0.0, 0.0, running, None))
@@ -305,10 +314,16 @@ def activation_range_kernels(shape, dev):
     rows.append({'kernel': 'QuantMeasure.forward (update_stat): 3 launches', 'bytes': 12 * n, 'us': ms * 1e3})
     proto = prepare('mobilenet_v2' if n > 10 ** 6 else 'tiny_mobile', 0, dev)
     n_w = sum(m_.weight.numel() + (m_.bias.numel() if m_.bias is not None else 0) for m_ in proto[1].values() if type(m_) in TARG)
-    with contextlib.redirect_stdout(sys.stderr):
-        ms = timed(lambda: lt.quantize_targ_layer(proto[1], 8, 16, TARG), reps=3)
-    rows.append({'kernel': 'seg_minmax_kernel + seg_fake_quant_kernel (quantize_targ_layer, one network, host-synchronous call)',
-                 'bytes': 12 * n_w, 'us': ms * 1e3})
+    import ctypes
+    from dfq_amd import _ffi
+    tensors = [t for m_ in proto[1].values() if type(m_) in TARG for t in ((m_.weight, 8), (m_.bias, 16)) if t[0] is not None]
+    segs = (_ffi.DfqSegment * len(tensors))(*[_ffi.DfqSegment(t.data_ptr(), t.numel(), bits, 0, None) for t, bits in tensors])
+    plan = ctypes.c_void_p()
+    _ffi.check(_ffi.lib().dfq_quant_plan_create(segs, len(tensors), ctypes.byref(plan)))
+    ms = timed(lambda: _ffi.check(_ffi.lib().dfq_quant_plan_run(plan, _ffi.stream_arg())))
+    _ffi.lib().dfq_quant_plan_destroy(plan)
+    rows.append({'kernel': 'seg_minmax_kernel + seg_fake_quant_kernel (the two launches of quantize_targ_layer over one network: '
+                           '{:.1f} MB, cache-resident)'.format(4 * n_w / 1e6), 'bytes': 12 * n_w, 'us': ms * 1e3})
     for r in rows:
         r['GBps'] = r['bytes'] / max(r['us'], 1e-9) / 1e3
         r['frac'] = r['GBps'] / HBM_PEAK_GBS
