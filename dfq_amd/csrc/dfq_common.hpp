@@ -25,6 +25,16 @@ typedef DFQ_GLOBAL_AS unsigned int guint;
 typedef float fvec4 __attribute__((vector_size(16)));   // native 16-byte vector (dwordx4 loads/stores)
 typedef DFQ_GLOBAL_AS fvec4 gfvec4;
 
+// dynamic shared memory of a kernel and the launch of a kernel whose workgroups must all be alive at once (the CPU test
+// emulation gives every workgroup its own buffer and runs the grid concurrently, tests/emu)
+#ifdef DFQ_EMU
+#define DFQ_DYN_SMEM(name) unsigned char* name = emu::cur->smem
+#define DFQ_LAUNCH_RESIDENT(kernel, grid, block, smem, stream, ...) emu::launch_concurrent_k((grid), (block), (smem), kernel, __VA_ARGS__)
+#else
+#define DFQ_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
+#define DFQ_LAUNCH_RESIDENT(kernel, grid, block, smem, stream, ...) hipLaunchKernelGGL(kernel, grid, block, smem, stream, __VA_ARGS__)
+#endif
+
 constexpr int kBlock = 256;   // 4 wavefronts of 64 lanes
 constexpr int kWave = 64;
 

@@ -54,6 +54,8 @@
 #include <vector>
 
 #include "dfq_common.hpp"
+#include "dfq_le_shared.hpp"
+#include "dfq_le_resident.hpp"
 
 namespace dfq {
 
@@ -113,21 +115,6 @@ struct LeRelDev {
 #endif
 constexpr int kAblate = DFQ_LE_ABLATE;
 
-struct LeParams {
-    float s_lo, s_hi, inv_lo, inv_hi, eps;
-    int32_t hi_gt_lo, signed_range;
-    int32_t poll_naps;      // s_sleep(8) units between two polls of a dependency counter
-};
-
-struct LeState {
-    double diff;
-    double last_diff_tmp;
-    int32_t count;
-    int32_t sweeps;
-    int32_t done;
-    int32_t pad;
-};
-
 struct LeLayerDiff {
     int32_t partial_begin;   // -1: layer untouched by any relation (contributes exactly 0)
     int32_t n_partials;
@@ -168,36 +155,6 @@ __device__ __forceinline__ void stamp(const LeTrace& tr, int slot) {
     } else if (flat == tr.block) {
         tr.out[slot] = clock64();
     }
-}
-
-// a / b for 0 <= a < 2^20, b >= 1 in four instructions: (a + 0.5) / b is at least 0.5/b away from every
-// integer, while v_rcp_f32 (1 ulp) plus the multiply are off by < 2e-7 * a/b < 0.5/b, so truncating
-// is exact.  (A 32-bit integer division expands to ~40 dependent instructions and a tile needs a
-// dozen of them: they were a visible share of its latency and of the kernel's code size.)
-__device__ __forceinline__ int small_div(int a, int b) {
-    return (int)(((float)a + 0.5f) * __builtin_amdgcn_rcpf((float)b));
-}
-
-// dfq.py:58-59 with Python's max/min semantics on a 0-dim float32 tensor (see oracle.le_solve).
-__device__ __forceinline__ void le_solve(float r1, float r2, const LeParams& p, float& s_out, float& inv_out) {
-    const float a = r1 + p.eps;
-    const float recip = 1.0f / a;
-    const float prod = r1 * r2;
-    const float rad = prod + p.eps;
-    const float root = sqrtf(rad);
-    const float s = recip * root;
-    const bool keep_hi = s < p.s_hi;                 // False for NaN -> hi
-    const float t = keep_hi ? s : p.s_hi;
-    const bool keep_lo = keep_hi ? (t > p.s_lo) : (p.hi_gt_lo != 0);
-    s_out = keep_lo ? t : p.s_lo;
-    inv_out = keep_lo ? (keep_hi ? (1.0f / s_out) : p.inv_hi) : p.inv_lo;
-}
-
-__device__ __forceinline__ float range_of(float mn, float mx, int signed_range) {
-    // max(|mn|, |mx|) == max(mx, -mn) whenever mn <= mx.  (Written without fabsf(): the abs source
-    // modifier folded into the following select trips an instruction-selection bug of this compiler.)
-    if (signed_range) return fmaxf(mx, -mn);
-    return mx - mn;
 }
 
 // Row statistics are produced and consumed inside ONE launch (by workgroups on different XCDs, whose L2s are not
@@ -1013,6 +970,10 @@ struct dfq_le_plan {
     double* d_layer_mean = nullptr;
     LeState* d_state = nullptr;
     uint32_t* d_stats = nullptr;           // R2 arena [2][stat_words], then R1 arena [2][stat_words]
+    // single networks that fit the register files run the whole loop as ONE persistent launch (dfq_le_resident.hip);
+    // null: the streaming one-launch-per-sweep kernel above (batched plans, networks too large, DFQ_LE_RESIDENT=0)
+    dfq::LeResident* resident = nullptr;
+    std::string resident_why;
 };
 
 // elements per tile; DFQ_LE_TILE_ELEMS overrides (tuning / tests).  A workgroup's fixed cost (workgroup table ->
@@ -1070,6 +1031,7 @@ void dfq_le_plan_destroy(dfq_le_plan* p) {
     if (p->d_dep) (void)hipFree(p->d_dep);
     for (auto& g : p->graphs) (void)hipGraphExecDestroy(g.exec);
     if (p->capture_stream) (void)hipStreamDestroy(p->capture_stream);
+    if (p->resident) le_resident_destroy(p->resident);
     delete p;
 }
 
@@ -1344,10 +1306,16 @@ int dfq_le_plan_create_batch(const dfq_layer* layers, int32_t n_layers, const in
         const char* me = getenv("DFQ_LE_MERGED");
         p->merged = !(me && me[0] == '0');
     }
+    if (n_nets == 1 && n_relations > 0) p->resident = le_resident_create(layers, n_layers, relations, n_relations, &p->resident_why);
+    else p->resident_why = n_nets > 1 ? "batched plan" : "no relations";
     if ((e = hipDeviceSynchronize()) != hipSuccess) return fail_alloc(e);
     *out_plan = p;
     return DFQ_OK;
 }
+
+// workgroups (= register-resident tiles) of the persistent whole-loop launch, 0 when the plan streams
+int32_t dfq_le_plan_resident_tiles(const dfq_le_plan* p) { return (p && p->resident) ? le_resident_tiles(p->resident) : 0; }
+const char* dfq_le_plan_resident_reason(const dfq_le_plan* p) { return p ? p->resident_why.c_str() : ""; }
 
 // launches of a sweep (the convergence kernel not counted): 1, or the number of dependency levels with DFQ_LE_MERGED=0
 int32_t dfq_le_plan_levels(const dfq_le_plan* p) { return p ? (p->merged ? (p->levels.empty() ? 0 : 1) : (int32_t)p->levels.size()) : 0; }
@@ -1387,15 +1355,6 @@ int32_t dfq_le_plan_level_launches(const dfq_le_plan* p, int32_t level, int64_t*
 }
 
 }  // extern "C"
-
-static LeParams make_params(const dfq_le_config* c) {
-    LeParams q;
-    q.s_lo = c->s_lo; q.s_hi = c->s_hi; q.inv_lo = c->inv_lo; q.inv_hi = c->inv_hi; q.eps = c->eps;
-    q.hi_gt_lo = c->hi_gt_lo; q.signed_range = c->signed_range;
-    const char* pe = getenv("DFQ_LE_POLL_NAPS");
-    q.poll_naps = (pe && atoi(pe) > 0) ? atoi(pe) : 2;
-    return q;
-}
 
 // reset the loop state, clear every stat word, recompute the stats of the untouched weights
 static int le_restart(dfq_le_plan* p, const dfq_le_config* cfg, hipStream_t st) {
@@ -1469,6 +1428,18 @@ static bool graphs_enabled() {
 int dfq_le_enqueue(dfq_le_plan* p, const dfq_le_config* cfg, int32_t n_sweeps, int32_t restart, void* stream) {
     if (!p || !cfg || n_sweeps < 0) return fail_arg("dfq_le_enqueue: bad argument");
     hipStream_t st = as_stream(stream);
+    if (p->resident) {
+        // one persistent launch runs up to n_sweeps sweeps from the state in d_state (it re-derives the statistics from
+        // the weights it loads, so there is nothing to bootstrap and nothing to carry between calls)
+        unsigned long long* err = p->d_dep + (size_t)p->n_rels * kDepStride;
+        if (restart) {
+            hipLaunchKernelGGL(le_reset_kernel, dim3(1), dim3(64), 0, st, p->d_state, 1, cfg->converge_thres,
+                               (int)cfg->converge_count, (int)cfg->max_sweeps);
+            DFQ_CHECK_LAUNCH();
+            DFQ_HIP_TRY(hipMemsetAsync(err, 0, sizeof(unsigned long long), st));
+        }
+        return le_resident_enqueue(p->resident, cfg, p->d_state, err, n_sweeps, st);
+    }
     if (!graphs_enabled() || n_sweeps < 2) return le_enqueue_direct(p, cfg, n_sweeps, restart, st);
     // A whole run of sweeps is a few hundred dependent launches with arguments that only depend on
     // (config, index of the first sweep -- the dependency counters count up from the last restart): record it
@@ -1649,7 +1620,13 @@ int dfq_le_run(dfq_le_plan* p, const dfq_le_config* cfg, void* stream, dfq_le_re
     int32_t done = 0;
     dfq_le_result res;
     int chunk = 8;
-    if (cfg->max_sweeps >= 0) {
+    if (p->resident) {
+        // the kernel stops by itself where the reference's loop stops
+        rc = dfq_le_enqueue(p, cfg, cfg->max_sweeps >= 0 ? cfg->max_sweeps : (1 << 30), 0, stream);
+        if (rc) return rc;
+        rc = dfq_le_query(p, stream, &res, &done);
+        if (rc) return rc;
+    } else if (cfg->max_sweeps >= 0) {
         // the sweep count is known: enqueue all of it, one synchronisation at the end
         rc = dfq_le_enqueue(p, cfg, cfg->max_sweeps, 0, stream);
         if (rc) return rc;

@@ -91,6 +91,15 @@ class LEPlan:
         return _ffi.lib().dfq_le_plan_levels(self._plan)
 
     @property
+    def resident_tiles(self):
+        """workgroups of the persistent whole-loop launch (weights in registers for all sweeps), 0 if the plan streams"""
+        return _ffi.lib().dfq_le_plan_resident_tiles(self._plan)
+
+    @property
+    def resident_reason(self):
+        return (_ffi.lib().dfq_le_plan_resident_reason(self._plan) or b'').decode()
+
+    @property
     def depth(self):
         """dependency levels of the relation list (levels = equalisation launches per sweep: 1 unless DFQ_LE_MERGED=0)"""
         return _ffi.lib().dfq_le_plan_depth(self._plan)

@@ -131,6 +131,14 @@ int32_t dfq_le_plan_level_launches(const dfq_le_plan* plan, int32_t level, int64
 /* launch geometry of launch `level` of a sweep: grid_x = its workgroups (all of them work), grid_y = 1 */
 int dfq_le_plan_level_grid(const dfq_le_plan* plan, int32_t level, int32_t* grid_x, int32_t* grid_y);
 
+/* Single networks whose paired layers fit the register files run the WHOLE loop as one persistent launch (every
+ * workgroup keeps one tile of one layer in registers for all sweeps; dfq_le_resident.hip): the number of its workgroups,
+ * or 0 when the plan uses the streaming one-launch-per-sweep kernel (batched plans, networks too large for the
+ * chip's resident workgroups, DFQ_LE_RESIDENT=0) -- then dfq_le_plan_resident_reason says why.  Results are
+ * bit-identical either way. */
+int32_t dfq_le_plan_resident_tiles(const dfq_le_plan* plan);
+const char* dfq_le_plan_resident_reason(const dfq_le_plan* plan);
+
 /* Enqueue exactly `n_sweeps` sweeps plus their convergence bookkeeping on `stream`; never
  * synchronises.  The device-side loop state decides whether a sweep still executes (after the
  * reference's exit condition fires the remaining launches are no-ops).  `restart` != 0 resets the

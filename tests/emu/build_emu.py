@@ -34,7 +34,7 @@ def build(force=False):
         t = os.path.getmtime(OUT)
         if all(os.path.getmtime(f) <= t for f in deps()):
             return OUT
-    cmd = ['g++', '-O2', '-g', '-std=c++17', '-fPIC', '-shared', '-ffp-contract=off', '-fno-fast-math',
+    cmd = ['g++', '-O2', '-g', '-std=c++17', '-fPIC', '-shared', '-ffp-contract=off', '-fno-fast-math', '-fno-strict-aliasing',
            '-DDFQ_GLOBAL_AS=', '-DDFQ_CONSTANT_AS=', '-Wall', '-Wno-unknown-pragmas', '-Wno-unused-function', '-Wno-unused-variable',
            '-I', os.path.join(HERE, 'include'), '-I', os.path.join(ROOT, 'include'), '-o', OUT]
     for s in sources():

@@ -13,7 +13,7 @@ std::vector<std::function<void()>>* capture = nullptr;
 
 namespace {
 
-enum State { READY = 0, WAIT_BLOCK = 1, WAIT_WAVE = 2, DONE = 3 };
+enum State { READY = 0, WAIT_BLOCK = 1, WAIT_WAVE = 2, DONE = 3, YIELDED = 4 };
 
 struct Fiber {
     ucontext_t ctx;
@@ -26,6 +26,8 @@ constexpr size_t kStack = 96 * 1024;
 constexpr int kWaveSize = 64;
 
 std::vector<Fiber> fibers;
+int base_idx = 0;                 // first fiber of the running block (concurrent launches)
+bool concurrent = false;
 ucontext_t sched_ctx;
 const std::function<void()>* body_ptr = nullptr;
 int cur_idx = -1;
@@ -45,9 +47,10 @@ void yield_with(State s) {
 
 void sync_block() { yield_with(WAIT_BLOCK); }
 void sync_wave() { yield_with(WAIT_WAVE); }
+void poll_yield() { if (concurrent) yield_with(YIELDED); }
 
 uint64_t peer_slot(int mask, bool* valid) {
-    const int lane = cur_idx % kWaveSize;
+    const int lane = (cur_idx - base_idx) % kWaveSize;
     const int src = (cur_idx - lane) + (lane ^ mask);
     if (src < 0 || src >= (int)fibers.size() || (lane ^ mask) >= kWaveSize) { *valid = false; return 0; }
     *valid = true;
@@ -55,7 +58,7 @@ uint64_t peer_slot(int mask, bool* valid) {
 }
 
 uint64_t peer_slot_lane(int src_lane, bool* valid) {
-    const int lane = cur_idx % kWaveSize;
+    const int lane = (cur_idx - base_idx) % kWaveSize;
     const int src = (cur_idx - lane) + src_lane;
     if (src_lane < 0 || src_lane >= kWaveSize || src >= (int)fibers.size()) { *valid = false; return 0; }
     *valid = true;
@@ -63,7 +66,7 @@ uint64_t peer_slot_lane(int src_lane, bool* valid) {
 }
 
 uint64_t peer_rl(int src_lane, bool* valid) {
-    const int lane = cur_idx % kWaveSize;
+    const int lane = (cur_idx - base_idx) % kWaveSize;
     const int src = (cur_idx - lane) + src_lane;
     if (src_lane < 0 || src_lane >= kWaveSize || src >= (int)fibers.size() || !fibers[src].tc.rl_valid) { *valid = false; return 0; }
     *valid = true;
@@ -137,6 +140,128 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
             }
         }
     }
+    cur = nullptr;
+    cur_idx = -1;
+}
+
+// ---- concurrent launch: all workgroups alive, round-robin over blocks ------------------------------------------
+namespace {
+constexpr size_t kSmallStack = 48 * 1024;
+std::vector<Fiber> cfibers;
+std::vector<std::vector<unsigned char>> csmem;
+
+// run block b until every live fiber of it is blocked (barrier with absentees impossible here: a poll-yield of one
+// thread while the others sit at the barrier is the normal shape of a wait) -- returns true if anything happened
+bool run_block(int b, int nthreads) {
+    bool progress = false;
+    const int b0 = b * nthreads;
+    base_idx = b0;
+    for (;;) {
+        bool ran = false;
+        int live = 0;
+        for (int t = 0; t < nthreads; ++t) {
+            Fiber& f = fibers[b0 + t];
+            if (f.state == READY) {
+                cur_idx = b0 + t;
+                cur = &f.tc;
+                swapcontext(&sched_ctx, &f.ctx);
+                ran = true;
+            }
+            if (f.state != DONE) ++live;
+        }
+        if (ran) progress = true;
+        if (live == 0) return progress;
+        bool released = false;
+        for (int w = 0; w * kWaveSize < nthreads; ++w) {
+            int waiting = 0, alive = 0;
+            const int wb = b0 + w * kWaveSize, we = b0 + std::min(nthreads, (w + 1) * kWaveSize);
+            for (int t = wb; t < we; ++t) {
+                if (fibers[t].state != DONE) ++alive;
+                if (fibers[t].state == WAIT_WAVE) ++waiting;
+            }
+            if (alive > 0 && waiting == alive) {
+                for (int t = wb; t < we; ++t) if (fibers[t].state == WAIT_WAVE) fibers[t].state = READY;
+                released = true;
+            }
+        }
+        int wbk = 0;
+        for (int t = 0; t < nthreads; ++t) if (fibers[b0 + t].state == WAIT_BLOCK) ++wbk;
+        if (wbk == live) {
+            for (int t = 0; t < nthreads; ++t) if (fibers[b0 + t].state == WAIT_BLOCK) fibers[b0 + t].state = READY;
+            released = true;
+        }
+        if (released) { progress = true; continue; }
+        if (!ran) return progress;       // only yielded pollers (and threads waiting for them) are left: next block
+    }
+}
+}  // namespace
+
+void launch_concurrent(dim3 grid, dim3 block, size_t smem_bytes, const std::function<void()>& body) {
+    const int nthreads = (int)(block.x * block.y * block.z);
+    const int nblocks = (int)(grid.x * grid.y * grid.z);
+    if (nthreads <= 0 || nblocks <= 0) return;
+    std::vector<Fiber> saved;
+    saved.swap(fibers);                      // the sequential pool is left alone
+    if (cfibers.size() < (size_t)nthreads * nblocks) {
+        const size_t old = cfibers.size();
+        cfibers.resize((size_t)nthreads * nblocks);
+        for (size_t i = old; i < cfibers.size(); ++i) cfibers[i].stack = (char*)malloc(kSmallStack);
+    }
+    fibers.swap(cfibers);
+    csmem.assign(nblocks, std::vector<unsigned char>(smem_bytes + 64, 0xA5));
+    body_ptr = &body;
+    concurrent = true;
+    for (int b = 0; b < nblocks; ++b) {
+        for (int t = 0; t < nthreads; ++t) {
+            Fiber& f = fibers[(size_t)b * nthreads + t];
+            f.tc.tid = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
+            f.tc.bid = dim3(b % grid.x, (b / grid.x) % grid.y, b / (grid.x * grid.y));
+            f.tc.bdim = block;
+            f.tc.gdim = grid;
+            f.tc.smem = csmem[b].data();
+            f.tc.slot = 0;
+            f.tc.rl_valid = false;
+            f.state = READY;
+            getcontext(&f.ctx);
+            f.ctx.uc_stack.ss_sp = f.stack;
+            f.ctx.uc_stack.ss_size = kSmallStack;
+            f.ctx.uc_link = nullptr;
+            makecontext(&f.ctx, trampoline, 0);
+        }
+    }
+    long idle_rounds = 0;
+    for (;;) {
+        bool progress = false;
+        int live_blocks = 0;
+        for (int b = 0; b < nblocks; ++b) {
+            // yielded pollers get another turn every round
+            bool any_live = false;
+            for (int t = 0; t < nthreads; ++t) {
+                Fiber& f = fibers[(size_t)b * nthreads + t];
+                if (f.state == YIELDED) f.state = READY;
+                if (f.state != DONE) any_live = true;
+            }
+            if (!any_live) continue;
+            ++live_blocks;
+            // a round that only re-polls is not progress: run_block reports a poll as progress only via state changes
+            int before = 0;
+            for (int t = 0; t < nthreads; ++t) before += (int)fibers[(size_t)b * nthreads + t].state * (t + 1);
+            run_block(b, nthreads);
+            int after = 0;
+            for (int t = 0; t < nthreads; ++t) after += (int)fibers[(size_t)b * nthreads + t].state * (t + 1);
+            if (before != after) progress = true;
+        }
+        if (live_blocks == 0) break;
+        idle_rounds = progress ? 0 : idle_rounds + 1;
+        if (idle_rounds > 50000000L) {       // the kernels' own spin limits fire long before this
+            fprintf(stderr, "emu: concurrent launch made no progress (deadlock between workgroups)\n");
+            abort();
+        }
+    }
+    concurrent = false;
+    base_idx = 0;
+    fibers.swap(cfibers);
+    fibers.swap(saved);
     cur = nullptr;
     cur_idx = -1;
 }

@@ -21,6 +21,7 @@
 #include <functional>
 #include <vector>
 
+#define DFQ_EMU 1
 #define __global__
 #define __device__
 #define __host__
@@ -47,6 +48,7 @@ namespace emu {
 
 struct ThreadCtx {
     dim3 tid, bid, bdim, gdim;
+    unsigned char* smem = nullptr;      // dynamic shared memory of the block (concurrent launches only)
     uint64_t slot;
     uint32_t rl_val = 0;
     const void* rl_where = nullptr;
@@ -55,6 +57,10 @@ struct ThreadCtx {
 extern ThreadCtx* cur;
 
 void launch(dim3 grid, dim3 block, const std::function<void()>& body);
+// every workgroup of the grid alive at once (kernels whose workgroups wait for each other in cycles over time: the
+// resident equalisation kernel); `smem_bytes` of dynamic shared memory per workgroup; poll loops yield in s_sleep
+void launch_concurrent(dim3 grid, dim3 block, size_t smem_bytes, const std::function<void()>& body);
+void poll_yield();
 void sync_block();
 void sync_wave();
 uint64_t peer_rl(int src_lane, bool* valid);
@@ -146,7 +152,7 @@ inline double atomicAdd(double* p, double v) { double o = *p; *p = o + v; return
 #define __HIP_MEMORY_SCOPE_AGENT 4
 #define __hip_atomic_load(ptr, order, scope) (*(ptr))
 #define __hip_atomic_store(ptr, val, order, scope) (*(ptr) = (val))
-inline void __builtin_amdgcn_s_sleep(int) {}
+inline void __builtin_amdgcn_s_sleep(int) { emu::poll_yield(); }
 inline void __builtin_amdgcn_s_waitcnt(int) {}
 inline long long clock64() { return 0; }
 inline long long wall_clock64() { return 0; }
@@ -229,3 +235,19 @@ inline hipError_t hipGraphLaunch(hipGraphExec_t e, hipStream_t) { for (auto& f :
 
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
     emu::launch_k((grid), (block), kernel, __VA_ARGS__)
+
+namespace emu {
+template <typename K, typename A0, typename... As>
+inline void launch_concurrent_k(dim3 grid, dim3 block, size_t smem, K kernel, A0 a0, As... as) {
+    kernarg_ptr = &a0;
+    launch_concurrent(grid, block, smem, [&]() { kernel(a0, as...); });
+    kernarg_ptr = nullptr;
+}
+}  // namespace emu
+// residency queries: the emulation keeps any grid alive
+inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, const void*, int, size_t) { *n = 8; return hipSuccess; }
+struct hipDeviceProp_t { int multiProcessorCount; };
+inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) { p->multiProcessorCount = 256; return hipSuccess; }
+#define hipFuncAttributeMaxDynamicSharedMemorySize 8
+inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }

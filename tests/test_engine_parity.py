@@ -629,3 +629,62 @@ def test_full_size_networks_against_oracle(net, max_sweeps):
     for k in codes:
         assert np.array_equal(codes[k].cpu().numpy(), ocodes[k].astype(np.int32)), 'int8 codes of {}'.format(k)
         assert len(np.unique(npy(graph[k].weight))) <= 256
+
+
+# ---------------------------------------------------------------------------------------------
+# the two equalisation engines: register-resident whole-loop launch vs streaming one-launch-per-sweep
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('name,seed,signed', [('tiny_mobile', 0, False), ('tiny_res', 0, False), ('tiny_cat', 3, False), ('tiny_mobile', 2, True)])
+def test_resident_and_streaming_engines_agree(engine, monkeypatch, name, seed, signed):
+    """A single network runs the whole loop as ONE persistent launch with its weights in registers
+    (dfq_le_resident.hip); DFQ_LE_RESIDENT=0 forces the streaming kernel.  Same IEEE operations -> the weights, the
+    [O] vectors, the cumulative scales, the sweep count and the loop state must be identical bit for bit, and both
+    equal the oracle."""
+    out = []
+    for resident in (True, False):
+        if resident:
+            monkeypatch.delenv('DFQ_LE_RESIDENT', raising=False)
+        else:
+            monkeypatch.setenv('DFQ_LE_RESIDENT', '0')
+        model, graph, bottoms = synthetic.build(name, seed=seed)
+        model.to(engine.device)
+        lt.merge_batchnorm(model, graph, bottoms, TARG)
+        rels = rel.create_relation(graph, bottoms, TARG)
+        plan = dfq.build_le_plan(graph, rels, TARG)
+        assert (plan.resident_tiles > 0) == resident, plan.resident_reason
+        res = plan.run(signed=signed)
+        plan.stage.writeback()
+        out.append((res, snapshot(graph), [npy(s) for s in plan.scale_cum]))
+        plan.close()
+    (ra, sa, ca), (rb, sb, cb) = out
+    assert ra == rb, 'loop state differs: {} vs {}'.format(ra, rb)
+    for k in sa:
+        assert_bitexact(sa[k], sb[k], '{} {}'.format(name, k))
+    for a, b in zip(ca, cb):
+        assert_bitexact(a, b, 'cumulative S')
+
+
+def test_resident_engine_in_chunks(engine):
+    """enqueue(n) runs at most n sweeps per launch and carries the loop state: 3 + 3 + the rest == one run."""
+    res = []
+    for chunks in (None, (3, 3, 1000)):
+        model, graph, bottoms = synthetic.build('tiny_mobile', seed=0)
+        model.to(engine.device)
+        lt.merge_batchnorm(model, graph, bottoms, TARG)
+        rels = rel.create_relation(graph, bottoms, TARG)
+        plan = dfq.build_le_plan(graph, rels, TARG)
+        assert plan.resident_tiles > 0
+        if chunks is None:
+            r = plan.run()
+        else:
+            plan.enqueue(0, restart=True)
+            for n in chunks:
+                plan.enqueue(n, restart=False)
+            r = plan.query()
+            assert r.pop('done')
+        plan.stage.writeback()
+        res.append((r, snapshot(graph)))
+        plan.close()
+    assert res[0][0] == res[1][0]
+    for k in res[0][1]:
+        assert_bitexact(res[0][1][k], res[1][1][k], k)
