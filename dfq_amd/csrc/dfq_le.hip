@@ -1317,6 +1317,32 @@ int dfq_le_plan_create_batch(const dfq_layer* layers, int32_t n_layers, const in
 int32_t dfq_le_plan_resident_tiles(const dfq_le_plan* p) { return (p && p->resident) ? le_resident_tiles(p->resident) : 0; }
 const char* dfq_le_plan_resident_reason(const dfq_le_plan* p) { return p ? p->resident_why.c_str() : ""; }
 
+// Tuning aid: restart, run `n_sweeps` sweeps of the persistent launch with per-tile phase stamps (100 MHz wall clock;
+// [tile][6 sweeps][8 points]: 0 sweep start, 1 s_A solved, 2 row statistics published, 3 s_B solved, 4 new values +
+// statistics published, 5 ticket taken, 6 decision seen; [7] of sweep 0 = layer << 32 | rows << 16 | columns).  Synchronises.
+int dfq_le_resident_trace(dfq_le_plan* p, const dfq_le_config* cfg, int32_t n_sweeps, void* stream, int64_t* out, int64_t capacity) {
+    if (!p || !cfg || !out || !p->resident) return fail_arg("dfq_le_resident_trace: not a resident plan");
+    const int64_t words = le_resident_trace_words(p->resident);
+    if (capacity < words) return fail_arg("dfq_le_resident_trace: need room for %lld words", (long long)words);
+    hipStream_t st = as_stream(stream);
+    long long* d = nullptr;
+    DFQ_HIP_TRY(hipMalloc((void**)&d, words * sizeof(long long)));
+    DFQ_HIP_TRY(hipMemsetAsync(d, 0, words * sizeof(long long), st));
+    unsigned long long* err = p->d_dep + (size_t)p->n_rels * kDepStride;
+    hipLaunchKernelGGL(le_reset_kernel, dim3(1), dim3(64), 0, st, p->d_state, 1, cfg->converge_thres, (int)cfg->converge_count,
+                       (int)cfg->max_sweeps);
+    DFQ_HIP_TRY(hipMemsetAsync(err, 0, sizeof(unsigned long long), st));
+    int rc = le_resident_enqueue(p->resident, cfg, p->d_state, err, n_sweeps, st, d);
+    if (!rc) {
+        hipError_t e = hipMemcpyAsync(out, d, words * sizeof(long long), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) rc = fail_hip(e, "trace copy", __FILE__, __LINE__);
+    }
+    (void)hipFree(d);
+    return rc;
+}
+int64_t dfq_le_resident_trace_words(const dfq_le_plan* p) { return (p && p->resident) ? le_resident_trace_words(p->resident) : 0; }
+
 // launches of a sweep (the convergence kernel not counted): 1, or the number of dependency levels with DFQ_LE_MERGED=0
 int32_t dfq_le_plan_levels(const dfq_le_plan* p) { return p ? (p->merged ? (p->levels.empty() ? 0 : 1) : (int32_t)p->levels.size()) : 0; }
 int32_t dfq_le_plan_depth(const dfq_le_plan* p) { return p ? (int32_t)p->levels.size() : 0; }

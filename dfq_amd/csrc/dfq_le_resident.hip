@@ -47,8 +47,8 @@ constexpr int kResRows = 1024;       // rows of a tile that needs per-row tables
 constexpr int kResOwn = kResRows / kBlock;
 constexpr int kResStride = 16;       // one 64-bit counter per 128-byte line
 constexpr long kResSpinLimit = 8000000;
-constexpr int kResMaxTiles = 3072;   // partials staged in LDS by the deciding workgroup
-constexpr int kResMaxLayers = 1024;
+constexpr int kResMaxTiles = 1536;   // partials staged in LDS when the sweep's verdict is drawn
+constexpr int kResMaxLayers = 512;
 
 typedef unsigned long long u64;
 
@@ -63,7 +63,7 @@ struct ResTile {                     // one workgroup
     int32_t a_layer, b_layer;        // paired-layer index of A's first layer / B's second layer
     int32_t nt_self, nt_a, nt_b;     // tiles of this layer / of those two
     int32_t owner;                   // holds column block 0: updates the [O] vectors of relation B
-    int32_t pad;
+    int32_t layout;                  // kLayGeneral / kLayFixed / kLayShort
 };
 
 struct ResRel {
@@ -92,7 +92,7 @@ struct ResArgs {
     u64* done_cnt;                   // tiles that finished a sweep
     u64* seq;                        // (sweeps finished in this launch << 1) | stop
     u64* err;
-    double* partials;                // one per tile
+    double* partials;                // [2 parities][tiles]
     LeState* state;
     int32_t n_tiles, n_layers;       // n_layers: targ layers of the network (layer_diff entries)
     int32_t n_sweeps;                // sweeps this launch may run
@@ -100,15 +100,26 @@ struct ResArgs {
     int32_t converge_count;
     int32_t pad;
     double converge_thres;
+    long long* trace;                // tuning aid (null in production): [tile][kTraceSweeps][8] wall-clock stamps
 };
 
+constexpr int kTraceSweeps = 6;
+__device__ __forceinline__ void res_stamp(const ResArgs& a, int k, int point) {
+    if (a.trace && threadIdx.x == 0 && k < kTraceSweeps)
+        a.trace[((int64_t)blockIdx.x * kTraceSweeps + k) * 8 + point] = wall_clock64();
+}
+
 // ---- waits ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool res_wait(const u64* word, u64 target, u64 shift, u64* err, int* sh_flag) {
+// two counters at once (second may be null): one poll loop, both loads in flight
+__device__ __forceinline__ bool res_wait2(const u64* w1, u64 t1, const u64* w2, u64 t2, u64* err, int* sh_flag) {
     if (threadIdx.x == 0) {
         long spins = 0;
         int ok = 1;
-        while ((__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> shift) < target) {
-            __builtin_amdgcn_s_sleep(2);
+        for (;;) {
+            const u64 a1 = __hip_atomic_load(w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const u64 a2 = w2 ? __hip_atomic_load(w2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : t2;
+            if (a1 >= t1 && a2 >= t2) break;
+            __builtin_amdgcn_s_sleep(1);
             ++spins;
             if (spins > kResSpinLimit ||
                 ((spins & 255) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull)) {
@@ -153,84 +164,332 @@ __device__ __forceinline__ void opaque(int& x) {
 #endif
 }
 
-// ---- the tile in registers ------------------------------------------------------------------------------
-// Slot u of thread t holds VEC consecutive floats of tile row `row`, positions `pos .. pos + VEC - 1`:
-//   q = u * 256 + t,  row = q / (nc / VEC),  pos = c0 + (q % (nc / VEC)) * VEC.
-template <int VEC>
-struct Geo {
-    int tcv;                         // vectors per tile row
-    int n_vec;                       // vectors of the tile
-    int g_lo, nci, i0;               // LDS table of phase 1 / column statistics: (group - g_lo) * nci + (ii - i0)
+// ---- the tile in registers: three layouts -----------------------------------------------------------------
+// A layout says which elements of the [nr x nc] tile a thread's register slots hold and provides the four
+// element loops of a sweep: load / store, row statistics (of w or of w * 1/s_A), column statistics, the update.
+//   LayFixed   float4 slots, tile width nc / 4 a power of two <= 256 vectors: a thread keeps ONE column position for
+//              all its slots (slot u = row u * rps + t / tcv), so 1/s_A of its four columns and its column minima /
+//              maxima live in registers and the row reduction is a butterfly over the tcv lanes of a row;
+//   LayShort   rows of <= 32 floats (depthwise k x k kernels, the stem): one THREAD per row, row statistics without
+//              any cross-lane traffic;
+//   LayGeneral anything else: slot u of thread t holds vector q = u * 256 + t of the tile, statistics through LDS
+//              atomics (correct for every geometry, slow for wide rows: the plan avoids it where it can).
+struct TileGeo {
+    int g_lo, g_n, nci, i0;          // LDS table of phase 1 / column statistics: (group - g_lo) * nci + (ii - i0)
+};
+__device__ __forceinline__ TileGeo tile_geo(const ResTile& T) {
+    TileGeo G;
+    G.i0 = small_div(T.c0, T.khkw);
+    G.nci = small_div(T.c0 + T.nc - 1, T.khkw) - G.i0 + 1;
+    G.g_lo = small_div(T.r0, T.go);
+    G.g_n = small_div(T.r0 + T.nr - 1, T.go) - G.g_lo + 1;
+    return G;
+}
+__device__ __forceinline__ float abs_f32(float d) { return __uint_as_float(__float_as_uint(d) & 0x7fffffffu); }
+__device__ __forceinline__ void lds_minmax(uint32_t* pair, float mn, float mx) {
+    atomicMax(pair, ~enc_ord(mn));
+    atomicMax(pair + 1, enc_ord(mx));
+}
+
+template <int VEC_, int NS_>
+struct LayGeneral {
+    static constexpr int VEC = VEC_, NS = NS_;
+    int tcv, n_vec;
+    __device__ __forceinline__ void init(const ResTile& T, const TileGeo&) { tcv = T.nc / VEC; n_vec = T.nr * tcv; }
+    __device__ __forceinline__ void coords(const ResTile& T, int u, int& row, int& pos, bool& on) const {
+        int q = u * kBlock + (int)threadIdx.x;
+        opaque(q);
+        on = q < n_vec;
+        const int qq = on ? q : 0;
+        row = small_div(qq, tcv);
+        pos = T.c0 + (qq - row * tcv) * VEC;
+    }
+    __device__ __forceinline__ int tab(const ResTile& T, const TileGeo& G, int row, int pos_k) const {
+        return (small_div(T.r0 + row, T.go) - G.g_lo) * G.nci + small_div(pos_k, T.khkw) - G.i0;
+    }
+    template <typename F>     // f(u, row, pos, on) for every slot in use (uniform trip count)
+    __device__ __forceinline__ void slots(const ResTile& T, F f) const {
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {
+            if (u * kBlock >= n_vec) continue;
+            int row, pos; bool on;
+            coords(T, u, row, pos, on);
+            f(u, row, pos, on);
+        }
+    }
+    __device__ __forceinline__ void load(const ResTile& T, float (&v)[NS][VEC]) const {
+        const gfloat* wt = (const gfloat*)T.w;
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) v[u][k] = 0.0f;
+        }
+        slots(T, [&](int u, int row, int pos, bool) {
+            const gfloat* src = wt + ((int64_t)(T.r0 + row) * T.row_len + pos);
+            if (VEC == 4) { const fvec4 t4 = *(const gfvec4*)src; v[u][0] = t4[0]; v[u][1 % VEC] = t4[1]; v[u][2 % VEC] = t4[2]; v[u][3 % VEC] = t4[3]; }
+            else v[u][0] = *src;
+        });
+    }
+    __device__ __forceinline__ void store(const ResTile& T, const float (&v)[NS][VEC]) const {
+        gfloat* wt = (gfloat*)T.w;
+        slots(T, [&](int u, int row, int pos, bool on) {
+            gfloat* dst = wt + ((int64_t)(T.r0 + row) * T.row_len + pos);
+            if (!on) return;
+            if (VEC == 4) { fvec4 t4; t4[0] = v[u][0]; t4[1] = v[u][1 % VEC]; t4[2] = v[u][2 % VEC]; t4[3] = v[u][3 % VEC]; *(gfvec4*)dst = t4; }
+            else *dst = v[u][0];
+        });
+    }
+    // row statistics of w (with_inv false) or of fl(w * 1/s_A) into sh_row (zeroed by the caller)
+    __device__ __forceinline__ void row_stats(const ResTile& T, const TileGeo& G, const float (&v)[NS][VEC], bool with_inv,
+                                              const float* sh_inv, uint32_t* sh_row) const {
+        const int lane = threadIdx.x % kWave;
+        slots(T, [&](int u, int row, int pos, bool on) {
+            float mn = INFINITY, mx = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                const float x = with_inv ? v[u][k] * sh_inv[tab(T, G, row, pos + k)] : v[u][k];
+                mn = vmin_raw(mn, on ? x : INFINITY);
+                mx = vmax_raw(mx, on ? x : -INFINITY);
+            }
+            const int r_first = __shfl(row, 0), r_last = __shfl(row, kWave - 1);
+            const int on_all = __shfl((int)on, kWave - 1);             // lanes are ordered: the last one decides
+            if (on_all && r_first == r_last) {
+                mn = wave_min(mn); mx = wave_max(mx);
+                if (lane == 0) lds_minmax(sh_row + 2 * row, mn, mx);
+            } else if (on) {
+                lds_minmax(sh_row + 2 * row, mn, mx);
+            }
+        });
+    }
+    __device__ __forceinline__ void col_stats(const ResTile& T, const TileGeo& G, const float (&v)[NS][VEC], uint32_t* sh_col) const {
+        slots(T, [&](int u, int row, int pos, bool on) {
+            if (!on) return;
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) lds_minmax(sh_col + 2 * tab(T, G, row, pos + k), v[u][k], v[u][k]);
+        });
+    }
+    // w <- fl(fl(w * 1/s_A) * s_B); returns the thread's sum of |new - old| in float64
+    __device__ __forceinline__ double update(const ResTile& T, const TileGeo& G, float (&v)[NS][VEC], bool hasA, bool hasB,
+                                             const float* sh_inv, const float* sh_s) const {
+        double acc = 0.0;
+        slots(T, [&](int u, int row, int pos, bool on) {
+            const float s = hasB ? sh_s[row] : 1.0f;
+            double part = 0.0;
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                const float inv = hasA ? sh_inv[tab(T, G, row, pos + k)] : 1.0f;
+                const float tt = v[u][k] * inv;                   // dfq.py:73 (rounded), then
+                const float nv = tt * s;                          // dfq.py:62
+                part += (double)abs_f32(nv - v[u][k]);
+                v[u][k] = nv;
+            }
+            acc += on ? part : 0.0;
+        });
+        return acc;
+    }
 };
 
-template <int VEC>
-__device__ __forceinline__ void slot_coords(const ResTile& T, const Geo<VEC>& G, int u, int& row, int& pos, bool& on) {
-    int q = u * kBlock + (int)threadIdx.x;
-    // The coordinates of a slot never change, so the compiler would hoist them out of the sweep loop and keep three
-    // integers per slot alive next to the data (it did: 400+ registers, one wave per SIMD).  They cost a handful of
-    // instructions to recompute; the empty asm makes `q` opaque so that they are recomputed where they are used.
-    opaque(q);
-    on = q < G.n_vec;
-    const int qq = on ? q : 0;
-    row = small_div(qq, G.tcv);
-    pos = T.c0 + (qq - row * G.tcv) * VEC;
-}
-
-// table index of (tile row, position + k)
-template <int VEC>
-__device__ __forceinline__ int tab_index(const ResTile& T, const Geo<VEC>& G, int row, int pos_k) {
-    const int g = small_div(T.r0 + row, T.go) - G.g_lo;
-    const int ii = small_div(pos_k, T.khkw) - G.i0;
-    return g * G.nci + ii;
-}
-
-// Row statistics (per tile row) of the values `get(u, k, row, pos)` into sh_row[2 * row + {0: min slot, 1: max slot}]
-// (identity 0).  A wave whose 64 lanes sit in one row reduces with a butterfly and issues one LDS atomic; otherwise
-// every lane issues its own.
-template <int VEC, int NS, typename Get>
-__device__ __forceinline__ void tile_row_stats(const ResTile& T, const Geo<VEC>& G, uint32_t* sh_row, Get get) {
-    const int lane = threadIdx.x % kWave;
+template <int NS_>
+struct LayFixed {
+    static constexpr int VEC = 4, NS = NS_;
+    int lg_tcv, tcv, rps, rsub, pos, n_used;
+    int tabk[4];                       // table offset of the thread's four columns inside a group row
+    bool one_group;
+    __device__ __forceinline__ void init(const ResTile& T, const TileGeo& G) {
+        tcv = T.nc / 4;
+        lg_tcv = 31 - __builtin_clz((unsigned)tcv);
+        rps = kBlock >> lg_tcv;
+        rsub = (int)threadIdx.x >> lg_tcv;
+        pos = T.c0 + ((int)threadIdx.x & (tcv - 1)) * 4;
+        n_used = (T.nr + rps - 1) >> (8 - lg_tcv);
+        one_group = G.g_n == 1;
 #pragma unroll
-    for (int u = 0; u < NS; ++u) {
-        if (u * kBlock >= G.n_vec) continue;                       // uniform
-        int row, pos; bool on;
-        slot_coords<VEC>(T, G, u, row, pos, on);
+        for (int k = 0; k < 4; ++k) tabk[k] = small_div(pos + k, T.khkw) - G.i0;
+    }
+    __device__ __forceinline__ int group_row(const ResTile& T, const TileGeo& G, int row) const {
+        return one_group ? 0 : (small_div(T.r0 + row, T.go) - G.g_lo) * G.nci;
+    }
+    template <typename F>     // f(u, row, on)
+    __device__ __forceinline__ void slots(const ResTile& T, F f) const {
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {
+            if (u >= n_used) continue;
+            int rs = rsub;
+            opaque(rs);                       // see LayGeneral::coords: keep the per-slot coordinates out of registers
+            int row = u * rps + rs;
+            const bool on = row < T.nr;
+            row = on ? row : T.nr - 1;
+            f(u, row, on);
+        }
+    }
+    __device__ __forceinline__ void load(const ResTile& T, float (&v)[NS][VEC]) const {
+        const gfloat* wt = (const gfloat*)T.w;
+#pragma unroll
+        for (int u = 0; u < NS; ++u) { v[u][0] = 0.0f; v[u][1] = 0.0f; v[u][2] = 0.0f; v[u][3] = 0.0f; }
+        slots(T, [&](int u, int row, bool) {
+            const fvec4 t4 = *(const gfvec4*)(wt + ((int64_t)(T.r0 + row) * T.row_len + pos));
+            v[u][0] = t4[0]; v[u][1] = t4[1]; v[u][2] = t4[2]; v[u][3] = t4[3];
+        });
+    }
+    __device__ __forceinline__ void store(const ResTile& T, const float (&v)[NS][VEC]) const {
+        gfloat* wt = (gfloat*)T.w;
+        slots(T, [&](int u, int row, bool on) {
+            if (!on) return;
+            fvec4 t4; t4[0] = v[u][0]; t4[1] = v[u][1]; t4[2] = v[u][2]; t4[3] = v[u][3];
+            *(gfvec4*)(wt + ((int64_t)(T.r0 + row) * T.row_len + pos)) = t4;
+        });
+    }
+    __device__ __forceinline__ void inv4(const ResTile& T, const TileGeo& G, const float* sh_inv, int row, float (&iv)[4]) const {
+        const int gr = group_row(T, G, row);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) iv[k] = sh_inv[gr + tabk[k]];
+    }
+    __device__ __forceinline__ void row_stats(const ResTile& T, const TileGeo& G, const float (&v)[NS][VEC], bool with_inv,
+                                              const float* sh_inv, uint32_t* sh_row) const {
+        const int lane = threadIdx.x % kWave;
+        const int w = tcv < kWave ? tcv : kWave;                    // lanes of a wave that share a row
+        float iv[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+        if (with_inv && one_group) inv4(T, G, sh_inv, 0, iv);
+        slots(T, [&](int u, int row, bool on) {
+            if (with_inv && !one_group) inv4(T, G, sh_inv, row, iv);
+            float mn = INFINITY, mx = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float x = v[u][k] * iv[k];                    // * 1.0f is exact
+                mn = vmin_raw(mn, x); mx = vmax_raw(mx, x);
+            }
+            for (int m = 1; m < w; m <<= 1) {
+                mn = vmin_raw(mn, __shfl_xor(mn, m));
+                mx = vmax_raw(mx, __shfl_xor(mx, m));
+            }
+            if ((lane & (w - 1)) == 0 && on) lds_minmax(sh_row + 2 * row, mn, mx);   // one writer per row and wave
+        });
+    }
+    __device__ __forceinline__ void col_stats(const ResTile& T, const TileGeo& G, const float (&v)[NS][VEC], uint32_t* sh_col) const {
+        const int lane = threadIdx.x % kWave;
+        if (one_group) {
+            float cmn[4], cmx[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { cmn[k] = INFINITY; cmx[k] = -INFINITY; }
+            slots(T, [&](int u, int, bool on) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    cmn[k] = vmin_raw(cmn[k], on ? v[u][k] : INFINITY);
+                    cmx[k] = vmax_raw(cmx[k], on ? v[u][k] : -INFINITY);
+                }
+            });
+            for (int m = tcv; m < kWave; m <<= 1) {                 // lanes of the wave that hold the same columns
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    cmn[k] = vmin_raw(cmn[k], __shfl_xor(cmn[k], m));
+                    cmx[k] = vmax_raw(cmx[k], __shfl_xor(cmx[k], m));
+                }
+            }
+            if (lane < tcv) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) lds_minmax(sh_col + 2 * tabk[k], cmn[k], cmx[k]);
+            }
+        } else {
+            slots(T, [&](int u, int row, bool on) {
+                if (!on) return;
+                const int gr = group_row(T, G, row);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) lds_minmax(sh_col + 2 * (gr + tabk[k]), v[u][k], v[u][k]);
+            });
+        }
+    }
+    __device__ __forceinline__ double update(const ResTile& T, const TileGeo& G, float (&v)[NS][VEC], bool hasA, bool hasB,
+                                             const float* sh_inv, const float* sh_s) const {
+        double acc = 0.0;
+        float iv[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+        if (hasA && one_group) inv4(T, G, sh_inv, 0, iv);
+        slots(T, [&](int u, int row, bool on) {
+            if (hasA && !one_group) inv4(T, G, sh_inv, row, iv);
+            const float s = hasB ? sh_s[row] : 1.0f;
+            double part = 0.0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float tt = v[u][k] * iv[k];                 // dfq.py:73 (rounded), then
+                const float nv = tt * s;                          // dfq.py:62
+                part += (double)abs_f32(nv - v[u][k]);
+                v[u][k] = nv;
+            }
+            acc += on ? part : 0.0;
+        });
+        return acc;
+    }
+};
+
+// thread t holds rows t, t + 256, ... of the tile (complete rows of L = row_len <= PAD floats), row j in slots
+// j * PAD .. j * PAD + L - 1 (PAD = 16: two rows per thread, PAD = 32: one)
+template <int PAD>
+struct LayShort {
+    static constexpr int VEC = 1, NS = 32, RPT = 32 / PAD;
+    int L;
+    __device__ __forceinline__ void init(const ResTile& T, const TileGeo&) { L = T.row_len; }
+    template <typename F>     // f(u, row, e, on): element e of tile row `row`
+    __device__ __forceinline__ void slots(const ResTile& T, F f) const {
+#pragma unroll
+        for (int j = 0; j < RPT; ++j) {
+            if (j * kBlock >= T.nr) continue;                       // uniform
+            int row = j * kBlock + (int)threadIdx.x;
+            opaque(row);
+            const bool on = row < T.nr;
+            row = on ? row : T.nr - 1;
+#pragma unroll
+            for (int e = 0; e < PAD; ++e)
+                if (e < L) f(j * PAD + e, row, e, on);              // uniform
+        }
+    }
+    __device__ __forceinline__ void load(const ResTile& T, float (&v)[NS][VEC]) const {
+        const gfloat* wt = (const gfloat*)T.w;
+#pragma unroll
+        for (int u = 0; u < NS; ++u) v[u][0] = 0.0f;
+        slots(T, [&](int u, int row, int e, bool) { v[u][0] = wt[(int64_t)(T.r0 + row) * L + e]; });
+    }
+    __device__ __forceinline__ void store(const ResTile& T, const float (&v)[NS][VEC]) const {
+        gfloat* wt = (gfloat*)T.w;
+        slots(T, [&](int u, int row, int e, bool on) { if (on) wt[(int64_t)(T.r0 + row) * L + e] = v[u][0]; });
+    }
+    __device__ __forceinline__ int tab(const ResTile& T, const TileGeo& G, int row, int e) const {
+        return (small_div(T.r0 + row, T.go) - G.g_lo) * G.nci + small_div(e, T.khkw);     // complete rows: i0 == 0
+    }
+    __device__ __forceinline__ void row_stats(const ResTile& T, const TileGeo& G, const float (&v)[NS][VEC], bool with_inv,
+                                              const float* sh_inv, uint32_t* sh_row) const {
         float mn = INFINITY, mx = -INFINITY;
-#pragma unroll
-        for (int k = 0; k < VEC; ++k) {
-            const float x = get(u, k, row, pos);
-            mn = vmin_raw(mn, on ? x : INFINITY);
-            mx = vmax_raw(mx, on ? x : -INFINITY);
-        }
-        const int r_first = __shfl(row, 0), r_last = __shfl(row, kWave - 1);
-        const int on_all = __shfl((int)on, kWave - 1);             // lanes are ordered: the last one decides
-        if (on_all && r_first == r_last) {
-            mn = wave_min(mn); mx = wave_max(mx);
-            if (lane == 0) { atomicMax(&sh_row[2 * row], ~enc_ord(mn)); atomicMax(&sh_row[2 * row + 1], enc_ord(mx)); }
-        } else if (on) {
-            atomicMax(&sh_row[2 * row], ~enc_ord(mn));
-            atomicMax(&sh_row[2 * row + 1], enc_ord(mx));
+        slots(T, [&](int u, int row, int e, bool on) {
+            const float x = with_inv ? v[u][0] * sh_inv[tab(T, G, row, e)] : v[u][0];
+            mn = (e == 0) ? x : vmin_raw(mn, x);
+            mx = (e == 0) ? x : vmax_raw(mx, x);
+            if (e == L - 1 && on) { sh_row[2 * row] = ~enc_ord(mn); sh_row[2 * row + 1] = enc_ord(mx); }   // the row's only owner
+        });
+    }
+    __device__ __forceinline__ void col_stats(const ResTile& T, const TileGeo& G, const float (&v)[NS][VEC], uint32_t* sh_col) const {
+        if (G.nci == 1) {            // one input channel per group (depthwise): a row's range goes to its group's channel
+            float mn = INFINITY, mx = -INFINITY;
+            slots(T, [&](int u, int row, int e, bool on) {
+                mn = (e == 0) ? v[u][0] : vmin_raw(mn, v[u][0]);
+                mx = (e == 0) ? v[u][0] : vmax_raw(mx, v[u][0]);
+                if (e == L - 1 && on) lds_minmax(sh_col + 2 * tab(T, G, row, 0), mn, mx);
+            });
+        } else {
+            slots(T, [&](int u, int row, int e, bool on) { if (on) lds_minmax(sh_col + 2 * tab(T, G, row, e), v[u][0], v[u][0]); });
         }
     }
-}
-
-// Column statistics of x into sh_col[2 * table index + {0, 1}] (identity 0)
-template <int VEC, int NS>
-__device__ __forceinline__ void tile_col_stats(const ResTile& T, const Geo<VEC>& G, const float (&x)[NS][VEC], uint32_t* sh_col) {
-#pragma unroll
-    for (int u = 0; u < NS; ++u) {
-        if (u * kBlock >= G.n_vec) continue;
-        int row, pos; bool on;
-        slot_coords<VEC>(T, G, u, row, pos, on);
-        if (!on) continue;
-#pragma unroll
-        for (int k = 0; k < VEC; ++k) {
-            const int idx = tab_index<VEC>(T, G, row, pos + k);
-            atomicMax(&sh_col[2 * idx], ~enc_ord(x[u][k]));
-            atomicMax(&sh_col[2 * idx + 1], enc_ord(x[u][k]));
-        }
+    __device__ __forceinline__ double update(const ResTile& T, const TileGeo& G, float (&v)[NS][VEC], bool hasA, bool hasB,
+                                             const float* sh_inv, const float* sh_s) const {
+        double acc = 0.0;
+        slots(T, [&](int u, int row, int e, bool on) {
+            const float inv = hasA ? sh_inv[tab(T, G, row, e)] : 1.0f;
+            const float s = hasB ? sh_s[row] : 1.0f;
+            const float tt = v[u][0] * inv;                       // dfq.py:73 (rounded), then
+            const float nv = tt * s;                              // dfq.py:62
+            acc += on ? (double)abs_f32(nv - v[u][0]) : 0.0;
+            v[u][0] = nv;
+        });
+        return acc;
     }
-}
+};
 
 // sh_row -> global row statistics of relation B (rows r0 .. r0 + nr), tagged
 __device__ __forceinline__ void publish_rows(const ResArgs& a, const ResTile& T, const ResRel& RB, const uint32_t* sh_row, uint32_t tag) {
@@ -241,11 +500,10 @@ __device__ __forceinline__ void publish_rows(const ResArgs& a, const ResTile& T,
     }
 }
 // sh_col -> global column statistics of relation A, tagged
-template <int VEC>
-__device__ __forceinline__ void publish_cols(const ResArgs& a, const ResTile& T, const Geo<VEC>& G, int g_n, const ResRel& RA,
+__device__ __forceinline__ void publish_cols(const ResArgs& a, const ResTile& T, const TileGeo& G, const ResRel& RA,
                                              const uint32_t* sh_col, uint32_t tag) {
     u64* dst = a.stats + RA.r2_off + (int64_t)(tag & 1u) * a.parity_stride;
-    for (int idx = threadIdx.x; idx < g_n * G.nci; idx += kBlock) {
+    for (int idx = threadIdx.x; idx < G.g_n * G.nci; idx += kBlock) {
         const int gq = small_div(idx, G.nci);
         const int c = (G.g_lo + gq) * T.i2g + G.i0 + (idx - gq * G.nci);
         if (sh_col[2 * idx + 1] != 0u) {              // a channel no element of this tile belongs to stays untouched
@@ -255,11 +513,18 @@ __device__ __forceinline__ void publish_cols(const ResArgs& a, const ResTile& T,
     }
 }
 
-// dfq.py:105-115 by the last tile to arrive.  sh_d: kResMaxTiles doubles (the tile's own LDS tables are dead here)
-__device__ __forceinline__ void decide(const ResArgs& a, int k, double* sh_d, double* sh_mean) {
+// The loop state of dfq.py:81-83,110-115.  EVERY workgroup advances its own copy from the same partial sums in the same
+// order (identical everywhere), so no workgroup has to wait for another one's verdict.
+struct LoopState {
+    double diff, last_diff_tmp;
+    int count, sweeps, done;
+};
+
+// dfq.py:105-115 after sweep k: sum of the layers' mean |dW| from the tiles' partial sums (fixed order), state machine
+__device__ __forceinline__ void decide(const ResArgs& a, int k, LoopState& st, double* sh_d, double* sh_mean) {
     const int tid = threadIdx.x;
-    for (int i = tid; i < a.n_tiles; i += kBlock)
-        sh_d[i] = __longlong_as_double((long long)ld_word((const u64*)a.partials + i));
+    const u64* part = (const u64*)a.partials + (int64_t)(k & 1) * a.n_tiles;
+    for (int i = tid; i < a.n_tiles; i += kBlock) sh_d[i] = __longlong_as_double((long long)ld_word(part + i));
     __syncthreads();
     for (int l = tid; l < a.n_layers; l += kBlock) {
         const ResLayerDiff L = a.layer_diff[l];
@@ -269,67 +534,43 @@ __device__ __forceinline__ void decide(const ResArgs& a, int k, double* sh_d, do
         sh_mean[l] = (L.n_tiles > 0) ? (double)(float)(s / L.n_elems) : 0.0;
     }
     __syncthreads();
-    if (tid == 0) {
-        double diff_tmp = 0.0;
-        for (int l = 0; l < a.n_layers; ++l) diff_tmp += sh_mean[l];               // graph order, like Python's sum
-        // the deciding workgroup changes from sweep to sweep (different XCDs, L2s not coherent): device-scope accesses
-        LeState* st = a.state;
-        double diff = __longlong_as_double((long long)ld_word((const u64*)&st->diff));
-        int count = (int)__hip_atomic_load((const uint32_t*)&st->count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (fabs(diff - diff_tmp) > 1e-9) { count = 0; diff = diff_tmp; }
-        else { count += 1; }
-        const int sweeps = (int)__hip_atomic_load((const uint32_t*)&st->sweeps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
-        const bool go_on = (diff > a.converge_thres) && (count < a.converge_count) && (a.max_sweeps < 0 || sweeps < a.max_sweeps);
-        __hip_atomic_store((u64*)&st->diff, (u64)__double_as_longlong(diff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store((u64*)&st->last_diff_tmp, (u64)__double_as_longlong(diff_tmp), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store((uint32_t*)&st->count, (uint32_t)count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store((uint32_t*)&st->sweeps, (uint32_t)sweeps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store((uint32_t*)&st->done, go_on ? 0u : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_amdgcn_s_waitcnt(0);
-        __hip_atomic_store(a.seq, ((u64)(k + 1) << 1) | (go_on ? 0ull : 1ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    double diff_tmp = 0.0;
+    for (int l = 0; l < a.n_layers; ++l) diff_tmp += sh_mean[l];                   // graph order, like Python's sum (every thread)
+    if (fabs(st.diff - diff_tmp) > 1e-9) { st.count = 0; st.diff = diff_tmp; }
+    else { st.count += 1; }
+    st.sweeps += 1;
+    st.last_diff_tmp = diff_tmp;
+    const bool go_on = (st.diff > a.converge_thres) && (st.count < a.converge_count) && (a.max_sweeps < 0 || st.sweeps < a.max_sweeps);
+    st.done = go_on ? 0 : 1;
+    __syncthreads();                 // sh_d / sh_mean are reused by the next sweep
 }
 
-template <int VEC, int NS>
+template <typename Lay>
 __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& p, const ResTile& T, unsigned char* smem) {
-    // LDS: [inv: kResTab f32][s: kResRows f32][row stats: 2 * kResRows u32][col stats: 2 * kResTab u32][flag]
+    constexpr int VEC = Lay::VEC, NS = Lay::NS;
+    // LDS: [inv: kResTab f32][s: kResRows f32][row stats: 2 * kResRows u32][col stats: 2 * kResTab u32][flag][decision staging]
     float* sh_inv = (float*)smem;
     float* sh_s = sh_inv + kResTab;
     uint32_t* sh_row = (uint32_t*)(sh_s + kResRows);
     uint32_t* sh_col = sh_row + 2 * kResRows;
     int* sh_flag = (int*)(sh_col + 2 * kResTab);
+    double* sh_dec = (double*)(sh_flag + 16);
     const int tid = threadIdx.x;
     const bool hasA = T.relA >= 0, hasB = T.relB >= 0;
+    const bool chain_start = hasB && !hasA;
+    const bool rows_local = T.nc == T.row_len;       // the tile holds complete rows: its row statistics are final
     const ResRel RA = a.rels[hasA ? T.relA : 0];
     const ResRel RB = a.rels[hasB ? T.relB : 0];
-    Geo<VEC> G;
-    G.tcv = T.nc / VEC;
-    G.n_vec = T.nr * G.tcv;
-    G.i0 = small_div(T.c0, T.khkw);
-    G.nci = small_div(T.c0 + T.nc - 1, T.khkw) - G.i0 + 1;
-    G.g_lo = small_div(T.r0, T.go);
-    const int g_n = small_div(T.r0 + T.nr - 1, T.go) - G.g_lo + 1;
-    gfloat* const wt = (gfloat*)T.w;
+    const TileGeo G = tile_geo(T);
+    Lay lay;
+    lay.init(T, G);
+    LoopState st;
+    st.diff = a.state->diff; st.last_diff_tmp = a.state->last_diff_tmp;
+    st.count = a.state->count; st.sweeps = a.state->sweeps; st.done = 0;
 
     // ---- load the tile (once) ----
     float v[NS][VEC];
-#pragma unroll
-    for (int u = 0; u < NS; ++u) {
-        int row, pos; bool on;
-        slot_coords<VEC>(T, G, u, row, pos, on);
-        const gfloat* src = wt + ((int64_t)(T.r0 + row) * T.row_len + pos);
-        if (u * kBlock < G.n_vec) {
-            if (VEC == 4) {
-                const fvec4 t4 = *(const gfvec4*)src;
-                v[u][0] = t4[0]; v[u][1 % VEC] = t4[1]; v[u][2 % VEC] = t4[2]; v[u][3 % VEC] = t4[3];
-            } else {
-                v[u][0] = *src;
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < VEC; ++k) v[u][k] = 0.0f;
-        }
-    }
+    lay.load(T, v);
     // the [O] vectors of relation B for the rows this thread owns
     float o_cum[kResOwn], o_bnw[kResOwn], o_bnb[kResOwn], o_b1[kResOwn];
     const bool owner = hasB && T.owner != 0;
@@ -347,19 +588,18 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
     }
 
     // ---- statistics of the untouched weights: consumption tag 1 (sweep 0) ----
-    const bool chain_start = hasB && !hasA;
     if (hasA) {
-        for (int i = tid; i < 2 * g_n * G.nci; i += kBlock) sh_col[i] = 0u;
+        for (int i = tid; i < 2 * G.g_n * G.nci; i += kBlock) sh_col[i] = 0u;
         __syncthreads();
-        tile_col_stats<VEC, NS>(T, G, v, sh_col);
+        lay.col_stats(T, G, v, sh_col);
         __syncthreads();
-        publish_cols<VEC>(a, T, G, g_n, RA, sh_col, 1u);
+        publish_cols(a, T, G, RA, sh_col, 1u);
         arrive(a.cnt_c + (int64_t)T.layer * kResStride);
     }
     if (chain_start) {
         for (int i = tid; i < 2 * T.nr; i += kBlock) sh_row[i] = 0u;
         __syncthreads();
-        tile_row_stats<VEC, NS>(T, G, sh_row, [&](int u, int kk, int, int) { return v[u][kk]; });
+        lay.row_stats(T, G, v, false, sh_inv, sh_row);
         __syncthreads();
         publish_rows(a, T, RB, sh_row, 1u);
         arrive(a.cnt_r + (int64_t)T.layer * kResStride);
@@ -370,11 +610,12 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
     for (;; ++k) {
         const uint32_t tag = (uint32_t)k + 1u;                  // what this sweep consumes
         const u64 round = (u64)k + 1ull;
+        res_stamp(a, k, 0);
         // ---- phase 1: s_A per (group, input channel) of the tile ----
         if (hasA) {
-            if (!res_wait(a.cnt_r + (int64_t)T.a_layer * kResStride, (u64)T.nt_a * round, 0, a.err, sh_flag) ||
-                !res_wait(a.cnt_c + (int64_t)T.layer * kResStride, (u64)T.nt_self * round, 0, a.err, sh_flag)) { failed = true; break; }
-            for (int idx = tid; idx < g_n * G.nci; idx += kBlock) {
+            if (!res_wait2(a.cnt_r + (int64_t)T.a_layer * kResStride, (u64)T.nt_a * round,
+                           a.cnt_c + (int64_t)T.layer * kResStride, (u64)T.nt_self * round, a.err, sh_flag)) { failed = true; break; }
+            for (int idx = tid; idx < G.g_n * G.nci; idx += kBlock) {
                 const int gq = small_div(idx, G.nci);
                 const int c = (G.g_lo + gq) * T.i2g + G.i0 + (idx - gq * G.nci);
                 float mn1, mx1, mn2, mx2, s, inv;
@@ -383,29 +624,34 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
                 le_solve(range_of(mn1, mx1, p.signed_range), range_of(mn2, mx2, p.signed_range), p, s, inv);
                 sh_inv[idx] = inv;
             }
+            res_stamp(a, k, 1);
             if (hasB) for (int i = tid; i < 2 * T.nr; i += kBlock) sh_row[i] = 0u;
             __syncthreads();
             if (hasB) {
                 // row statistics of t = fl(w * 1/s_A) for relation B of this same sweep (t is not kept: phase 3 recomputes it)
-                tile_row_stats<VEC, NS>(T, G, sh_row, [&](int u, int kk, int row, int pos) {
-                    return v[u][kk] * sh_inv[tab_index<VEC>(T, G, row, pos + kk)];
-                });
+                lay.row_stats(T, G, v, true, sh_inv, sh_row);
                 __syncthreads();
                 publish_rows(a, T, RB, sh_row, tag);
                 arrive(a.cnt_r + (int64_t)T.layer * kResStride);
             }
         }
+        res_stamp(a, k, 2);
         // ---- phase 2: s_B per row ----
         if (hasB) {
-            if (!res_wait(a.cnt_r + (int64_t)T.layer * kResStride, (u64)T.nt_self * round, 0, a.err, sh_flag) ||
-                !res_wait(a.cnt_c + (int64_t)T.b_layer * kResStride, (u64)T.nt_b * round, 0, a.err, sh_flag)) { failed = true; break; }
+            // a tile of complete rows already has its rows' statistics (sh_row: this sweep's phase 1, or the previous
+            // sweep's phase 3 for a chain start); otherwise they are merged over the row block's tiles in global memory
+            const u64* own = rows_local ? nullptr : a.cnt_r + (int64_t)T.layer * kResStride;
+            if (!res_wait2(a.cnt_c + (int64_t)T.b_layer * kResStride, (u64)T.nt_b * round, own, (u64)T.nt_self * round, a.err, sh_flag)) {
+                failed = true; break;
+            }
 #pragma unroll
             for (int j = 0; j < kResOwn; ++j) {
                 const int i = tid + j * kBlock;
                 if (i < T.nr) {
                     const int c = T.r0 + i;
                     float mn1, mx1, mn2, mx2, s, inv;
-                    read_range(a.stats, RB.r1_off, a.parity_stride, tag, c, mn1, mx1);
+                    if (rows_local) { mn1 = slot_min(sh_row[2 * i]); mx1 = slot_max(sh_row[2 * i + 1]); }
+                    else read_range(a.stats, RB.r1_off, a.parity_stride, tag, c, mn1, mx1);
                     read_range(a.stats, RB.r2_off, a.parity_stride, tag, c, mn2, mx2);
                     le_solve(range_of(mn1, mx1, p.signed_range), range_of(mn2, mx2, p.signed_range), p, s, inv);
                     sh_s[i] = s;
@@ -416,77 +662,46 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
                 }
             }
         }
+        res_stamp(a, k, 3);
         // ---- phase 3: the new values, |dW|, statistics for the next sweep ----
-        if (hasA) for (int i = tid; i < 2 * g_n * G.nci; i += kBlock) sh_col[i] = 0u;
+        __syncthreads();                                          // sh_s complete; sh_row / sh_col free
+        if (hasA) for (int i = tid; i < 2 * G.g_n * G.nci; i += kBlock) sh_col[i] = 0u;
         if (chain_start) for (int i = tid; i < 2 * T.nr; i += kBlock) sh_row[i] = 0u;
+        const double acc = lay.update(T, G, v, hasA, hasB, sh_inv, sh_s);
         __syncthreads();
-        double acc = 0.0;
-#pragma unroll
-        for (int u = 0; u < NS; ++u) {
-            if (u * kBlock >= G.n_vec) continue;
-            int row, pos; bool on;
-            slot_coords<VEC>(T, G, u, row, pos, on);
-            const float s = hasB ? sh_s[row] : 1.0f;
-            double part = 0.0;
-#pragma unroll
-            for (int kk = 0; kk < VEC; ++kk) {
-                const float inv = hasA ? sh_inv[tab_index<VEC>(T, G, row, pos + kk)] : 1.0f;
-                const float tt = v[u][kk] * inv;                  // dfq.py:73 (rounded), then
-                const float nv = tt * s;                          // dfq.py:62
-                const float d = nv - v[u][kk];
-                part += (double)__uint_as_float(__float_as_uint(d) & 0x7fffffffu);
-                v[u][kk] = nv;
-            }
-            acc += on ? part : 0.0;
-        }
-        if (hasA) tile_col_stats<VEC, NS>(T, G, v, sh_col);
-        if (chain_start) tile_row_stats<VEC, NS>(T, G, sh_row, [&](int u, int kk, int, int) { return v[u][kk]; });
+        if (hasA) lay.col_stats(T, G, v, sh_col);
+        if (chain_start) lay.row_stats(T, G, v, false, sh_inv, sh_row);
         __syncthreads();
         if (hasA) {
-            publish_cols<VEC>(a, T, G, g_n, RA, sh_col, tag + 1u);
+            publish_cols(a, T, G, RA, sh_col, tag + 1u);
             arrive(a.cnt_c + (int64_t)T.layer * kResStride);
         }
         if (chain_start) {
             publish_rows(a, T, RB, sh_row, tag + 1u);
             arrive(a.cnt_r + (int64_t)T.layer * kResStride);
         }
-        // ---- convergence: one partial per tile (fixed butterfly + fixed wave order), the last arrival decides ----
+        res_stamp(a, k, 4);
+        // ---- convergence: one partial per tile (fixed butterfly + fixed wave order); when all are in, every workgroup
+        //      draws the same conclusion from them ----
         {
-            double* sh_w = (double*)sh_inv;                        // tables are dead until the next sweep
-            __syncthreads();
-            const double tsum = block_sum(acc, sh_w);
+            const double tsum = block_sum(acc, sh_dec);
             if (tid == 0) {
-                __hip_atomic_store((u64*)a.partials + blockIdx.x, (u64)__double_as_longlong(tsum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store((u64*)a.partials + (int64_t)(k & 1) * a.n_tiles + blockIdx.x, (u64)__double_as_longlong(tsum),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __builtin_amdgcn_s_waitcnt(0);
-                const u64 ticket = atomicAdd(a.done_cnt, 1ull);
-                *sh_flag = (ticket == (u64)a.n_tiles * round - 1ull) ? 1 : 0;
+                atomicAdd(a.done_cnt, 1ull);
             }
-            __syncthreads();
-            const bool last = *sh_flag != 0;
-            __syncthreads();
-            if (last) decide(a, k, (double*)smem, (double*)smem + kResMaxTiles);
+            res_stamp(a, k, 5);
+            if (!res_wait2(a.done_cnt, (u64)a.n_tiles * round, nullptr, 0, a.err, sh_flag)) { failed = true; break; }
+            decide(a, k, st, sh_dec, sh_dec + kResMaxTiles);
         }
-        if (!res_wait(a.seq, round, 1, a.err, sh_flag)) { failed = true; break; }
-        const u64 sq = ld_word(a.seq);
-        if ((sq & 1ull) != 0ull || k + 1 >= a.n_sweeps) { ++k; break; }
+        res_stamp(a, k, 6);
+        if (a.trace && tid == 0 && k == 0) a.trace[((int64_t)blockIdx.x * kTraceSweeps) * 8 + 7] = ((long long)T.layer << 32) | (unsigned)T.nr << 16 | (unsigned)(T.nc & 0xffff);
+        if (st.done || k + 1 >= a.n_sweeps) { ++k; break; }
     }
     if (failed) return;                     // nothing is stored: the weights stay as they were before the launch
     // ---- write the tile back (once) ----
-#pragma unroll
-    for (int u = 0; u < NS; ++u) {
-        int row, pos; bool on;
-        slot_coords<VEC>(T, G, u, row, pos, on);
-        gfloat* dst = wt + ((int64_t)(T.r0 + row) * T.row_len + pos);
-        if (on) {
-            if (VEC == 4) {
-                fvec4 t4;
-                t4[0] = v[u][0]; t4[1] = v[u][1 % VEC]; t4[2] = v[u][2 % VEC]; t4[3] = v[u][3 % VEC];
-                *(gfvec4*)dst = t4;
-            } else {
-                *dst = v[u][0];
-            }
-        }
-    }
+    lay.store(T, v);
 #pragma unroll
     for (int j = 0; j < kResOwn; ++j) {
         const int i = tid + j * kBlock;
@@ -498,19 +713,31 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
             if (RB.b1) RB.b1[c] = o_b1[j];
         }
     }
+    if (blockIdx.x == 0 && tid == 0) {
+        LeState* o = a.state;
+        o->diff = st.diff; o->last_diff_tmp = st.last_diff_tmp; o->count = st.count; o->sweeps = st.sweeps; o->done = st.done;
+    }
 }
 
-constexpr size_t kResSmemBytes = sizeof(float) * (kResTab + kResRows) + sizeof(uint32_t) * 2 * (kResRows + kResTab) + 64;
-static_assert(kResSmemBytes >= sizeof(double) * (kResMaxTiles + kResMaxLayers), "the deciding workgroup stages the partials in the tile's LDS");
+constexpr size_t kResSmemBytes = sizeof(float) * (kResTab + kResRows) + sizeof(uint32_t) * 2 * (kResRows + kResTab) + 64 +
+                                 sizeof(double) * (kResMaxTiles + kResMaxLayers);
+
+enum { kLayGeneral = 0, kLayFixed = 1, kLayShort = 2 };
 
 // NS4 float4 slots per thread (tiles of 1024 * NS4 floats); scalar tiles always hold 32 floats per thread
 template <int NS4>
-__global__ __launch_bounds__(kBlock) void le_resident_kernel(ResArgs a, LeParams p) {
+__global__ __launch_bounds__(kBlock, 3) void le_resident_kernel(ResArgs a, LeParams p) {
     DFQ_DYN_SMEM(smem);
     if (a.state->done) return;              // already stopped (uniform over the launch: written before it started)
     const ResTile T = a.tiles[blockIdx.x];
-    if (T.vec == 4) res_tile_body<4, NS4>(a, p, T, smem);
-    else res_tile_body<1, 32>(a, p, T, smem);
+#ifndef DFQ_RES_ONLY
+#define DFQ_RES_ONLY 15
+#endif
+    if ((DFQ_RES_ONLY & 1) && T.layout == kLayFixed) res_tile_body<LayFixed<NS4>>(a, p, T, smem);
+    else if ((DFQ_RES_ONLY & 2) && T.layout == kLayShort && T.row_len <= 16) res_tile_body<LayShort<16>>(a, p, T, smem);
+    else if ((DFQ_RES_ONLY & 2) && T.layout == kLayShort) res_tile_body<LayShort<32>>(a, p, T, smem);
+    else if ((DFQ_RES_ONLY & 4) && T.vec == 4) res_tile_body<LayGeneral<4, NS4>>(a, p, T, smem);
+    else if (DFQ_RES_ONLY & 8) res_tile_body<LayGeneral<1, 32>>(a, p, T, smem);
 }
 
 }  // namespace dfq
@@ -540,12 +767,27 @@ int ceil_div_i(int a, int b) { return (a + b - 1) / b; }
 
 struct Shape { int tr, tc; };
 
-// [tr x tc] tiling of an [R x C] layer holding at most `cap` floats per tile; cost = global statistics atomics per sweep
+bool is_pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }
+int layout_of(int vec, int row_len, int nc) {
+    if (vec == 1 && row_len <= 32 && nc == row_len) return kLayShort;
+    if (vec == 4 && is_pow2(nc / 4) && nc / 4 <= kBlock) return kLayFixed;
+    return kLayGeneral;
+}
+
+// [tr x tc] tiling of an [R x C] layer holding at most `cap` floats per tile.  Cost = global statistics atomics per sweep
+// (row statistics are merged over the column blocks, column statistics over the row blocks), with a heavy penalty for
+// tiles that fall back to the general layout (LDS atomics per element).
 Shape pick_shape(int R, int C, int vec, int khkw, int go, int i2g, bool need_row, bool need_col, int cap) {
+    if (vec == 1 && C <= 32) {               // thread-per-row tiles: complete rows, two rows per thread if they are <= 16 floats
+        int tr = std::min(R, kBlock * (C <= 16 ? 2 : 1));
+        if (need_row) tr = std::min(tr, kResRows);
+        if (need_col) while (tr > 1 && ((tr + go - 1) / go + 1) * std::min((C + khkw - 1) / khkw + 1, i2g) > kResTab) tr = (tr + 1) / 2;
+        return Shape{tr, C};
+    }
     Shape best{0, 0};
     double best_cost = 1e300;
     std::vector<int> cands;
-    for (int tc = vec; tc < C; tc *= 2) cands.push_back(tc);
+    for (int tc = vec; tc < C && tc <= vec * kBlock; tc *= 2) cands.push_back(tc);
     cands.push_back(C);
     for (int tc : cands) {
         if (tc % vec) continue;
@@ -560,8 +802,11 @@ Shape pick_shape(int R, int C, int vec, int khkw, int go, int i2g, bool need_row
         }
         const int n_rb = ceil_div_i(R, tr), n_cb = ceil_div_i(C, tc);
         double cost = (double)n_rb * n_cb * 0.02;                       // a tile is a workgroup: mild pressure for fewer
-        if (need_row) cost += (double)R * n_cb;
+        if (need_row) cost += (double)R * (n_cb > 1 ? n_cb : 0.25);     // complete rows: no merge, no extra hand-off
         if (need_col) cost += (double)(C / khkw) * n_rb;
+        const int rem = C % tc;
+        if (layout_of(vec, C, tc) == kLayGeneral) cost += 1e7;
+        if (rem && layout_of(vec, C, rem) == kLayGeneral) cost += 1e7 * rem / (double)C;
         if (cost < best_cost) { best_cost = cost; best = Shape{tr, tc}; }
     }
     return best;
@@ -583,6 +828,7 @@ void le_resident_destroy(LeResident* r) {
 }
 
 int le_resident_tiles(const LeResident* r) { return r ? r->n_tiles : 0; }
+int le_resident_trace_words(const LeResident* r) { return r ? r->n_tiles * kTraceSweeps * 8 : 0; }
 int64_t le_resident_elements(const LeResident* r) { return r ? r->elements : 0; }
 
 LeResident* le_resident_create(const dfq_layer* layers, int n_layers, const dfq_relation* relations, int n_relations,
@@ -616,9 +862,8 @@ LeResident* le_resident_create(const dfq_layer* layers, int n_layers, const dfq_
             ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)le_resident_kernel<8>, kBlock, kResSmemBytes)
             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)le_resident_kernel<16>, kBlock, kResSmemBytes);
         if (e != hipSuccess || occ < 1) continue;
-        // the hardware may admit one workgroup per CU fewer than the API says (sgpr granularity): stay one below, and
-        // never above 90 % of that
-        const int cap_tiles = (int)(0.9 * (double)std::max(1, occ - 1) * cus);
+        // the hardware may admit one workgroup per CU fewer than the API says (sgpr granularity): stay one below
+        const int cap_tiles = std::max(1, occ - 1) * cus;
         tiles.clear();
         bool ok = true;
         std::string why;
@@ -654,6 +899,7 @@ LeResident* le_resident_create(const dfq_layer* layers, int n_layers, const dfq_
                     T.a_layer = relA >= 0 ? pl_of[relations[relA].first] : -1;
                     T.b_layer = relB >= 0 ? pl_of[relations[relB].second] : -1;
                     T.owner = cb == 0 ? 1 : 0;
+                    T.layout = layout_of(vec, C, T.nc);
                     tiles.push_back(T);
                 }
             tile_count[l] = n_rb * n_cb;
@@ -703,7 +949,7 @@ LeResident* le_resident_create(const dfq_layer* layers, int n_layers, const dfq_
               hipMalloc((void**)&r->d_layer_diff, sizeof(ResLayerDiff) * n_layers) == hipSuccess &&
               hipMalloc((void**)&r->d_stats, sizeof(u64) * (size_t)r->stat_words) == hipSuccess &&
               hipMalloc((void**)&r->d_sync, sizeof(u64) * r->sync_words) == hipSuccess &&
-              hipMalloc((void**)&r->d_partials, sizeof(double) * tiles.size()) == hipSuccess &&
+              hipMalloc((void**)&r->d_partials, sizeof(double) * 2 * tiles.size()) == hipSuccess &&
               hipMemcpy(r->d_tiles, tiles.data(), sizeof(ResTile) * tiles.size(), hipMemcpyHostToDevice) == hipSuccess &&
               hipMemcpy(r->d_rels, hr.data(), sizeof(ResRel) * n_relations, hipMemcpyHostToDevice) == hipSuccess &&
               hipMemcpy(r->d_layer_diff, ld.data(), sizeof(ResLayerDiff) * n_layers, hipMemcpyHostToDevice) == hipSuccess;
@@ -716,7 +962,7 @@ LeResident* le_resident_create(const dfq_layer* layers, int n_layers, const dfq_
 }
 
 int le_resident_enqueue(LeResident* r, const dfq_le_config* cfg, LeState* d_state, unsigned long long* d_err, int n_sweeps,
-                        hipStream_t st) {
+                        hipStream_t st, long long* d_trace) {
     if (!r || !cfg || !d_state || !d_err) return fail_arg("le_resident_enqueue: bad argument");
     if (n_sweeps <= 0) return DFQ_OK;
     // every launch is self-contained: statistics are re-derived from the weights it loads, tags and counters start at zero
@@ -738,6 +984,7 @@ int le_resident_enqueue(LeResident* r, const dfq_le_config* cfg, LeState* d_stat
     a.max_sweeps = cfg->max_sweeps;
     a.converge_count = cfg->converge_count;
     a.converge_thres = cfg->converge_thres;
+    a.trace = d_trace;
     const LeParams q = make_params(cfg);
     SpinGuard guard(st);
     if (r->ns4 == 8) DFQ_LAUNCH_RESIDENT(le_resident_kernel<8>, dim3(r->n_tiles), dim3(kBlock), kResSmemBytes, st, a, q);

@@ -19,6 +19,7 @@ int64_t le_resident_elements(const LeResident* r);
 // ONE launch: load, run up to n_sweeps sweeps of the loop whose state is *d_state (stops early when the reference's
 // exit test fires), store.  Asynchronous on `st`.
 int le_resident_enqueue(LeResident* r, const dfq_le_config* cfg, LeState* d_state, unsigned long long* d_err, int n_sweeps,
-                        hipStream_t st);
+                        hipStream_t st, long long* d_trace = nullptr);
+int le_resident_trace_words(const LeResident* r);   // tuning aid: int64 words of the per-tile phase stamps
 
 }  // namespace dfq

@@ -170,6 +170,21 @@ class LEPlan:
         _ffi.check(_ffi.lib().dfq_le_trace_blocks(self._plan, ctypes.byref(cfg), int(launch), _ffi.stream_arg(), out, n))
         return [(int(out[3 * b]), int(out[3 * b + 1]), int(out[3 * b + 2])) for b in range(n)]
 
+    def resident_trace(self, n_sweeps, **kw):
+        """Per-workgroup phase stamps of the persistent launch (tuning aid, see dfq_le_resident_trace): list over tiles of
+        dict(layer, rows, cols, stamps=[sweep][8])."""
+        cfg = _le_config(kw.get('s_range', (1e-8, 1e8)), -1.0, 10 ** 9, kw.get('signed', False), kw.get('eps', 0), None)
+        n = _ffi.lib().dfq_le_resident_trace_words(self._plan)
+        out = (ctypes.c_int64 * n)()
+        _ffi.check(_ffi.lib().dfq_le_resident_trace(self._plan, ctypes.byref(cfg), int(n_sweeps), _ffi.stream_arg(), out, n))
+        tiles = []
+        for t in range(n // 48):
+            w = [int(out[t * 48 + i]) for i in range(48)]
+            meta = w[7]
+            tiles.append(dict(layer=meta >> 32, rows=(meta >> 16) & 0xffff, cols=meta & 0xffff,
+                              stamps=[w[k * 8:k * 8 + 7] for k in range(6)]))
+        return tiles
+
     def query(self):
         res = _ffi.DfqLeResult()
         done = ctypes.c_int32()

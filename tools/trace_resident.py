@@ -1,0 +1,44 @@
+#!/usr/bin/env python
+"""Where a sweep of the persistent equalisation launch spends its time: per layer, the phase durations of its tiles
+(dfq_le_resident_trace).   python tools/trace_resident.py [net] [sweeps]"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import torch.nn as nn
+
+from dfq_amd import dfq, synthetic
+from dfq_amd.utils import layer_transform as lt
+from dfq_amd.utils import relation as rel
+
+TARG = [nn.Conv2d, nn.Linear]
+net = sys.argv[1] if len(sys.argv) > 1 else 'mobilenet_v2'
+sweeps = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+dev = torch.device('cuda', 0)
+model, graph, bottoms = synthetic.build(net, seed=0)
+model.to(dev)
+lt.merge_batchnorm(model, graph, bottoms, TARG)
+rels = rel.create_relation(graph, bottoms, TARG)
+plan = dfq.build_le_plan(graph, rels, TARG)
+print('tiles', plan.resident_tiles, plan.resident_reason)
+plan.resident_trace(sweeps)                      # warm
+tiles = plan.resident_trace(sweeps)
+t0 = min(t['stamps'][0][0] for t in tiles if t['stamps'][0][0])
+names = ['start', 'sA', 'rowpub', 'sB', 'newvals', 'ticket', 'decision']
+by_layer = {}
+for t in tiles:
+    by_layer.setdefault(t['layer'], []).append(t)
+for k in (1, 3, 5):
+    print('---- sweep', k, '(us since launch start; per layer: max over its tiles) ----')
+    for layer in sorted(by_layer):
+        ts = by_layer[layer]
+        row = []
+        for p in range(7):
+            vals = [t['stamps'][k][p] for t in ts if t['stamps'][k][p]]
+            row.append((max(vals) - t0) / 100.0 if vals else float('nan'))
+        print('layer {:3d} tiles {:3d} [{:4d}x{:4d}] '.format(layer, len(ts), ts[0]['rows'], ts[0]['cols']) +
+              ' '.join('{}={:7.2f}'.format(n, v) for n, v in zip(names, row)))
+dec = sorted(max(t['stamps'][k][6] for t in tiles) for k in range(6))
+print('sweep boundaries (us):', [round((d - t0) / 100.0, 2) for d in dec])
