@@ -167,7 +167,7 @@ __device__ __forceinline__ void opaque(int& x) {
 // ---- the tile in registers: three layouts -----------------------------------------------------------------
 // A layout says which elements of the [nr x nc] tile a thread's register slots hold and provides the four
 // element loops of a sweep: load / store, row statistics (of w or of w * 1/s_A), column statistics, the update.
-//   LayFixed   float4 slots, tile width nc / 4 a power of two <= 256 vectors: a thread keeps ONE column position for
+//   LayFixed   float4 slots, a tile row of nc / 4 <= 256 vectors on the next power of two of lanes: a thread keeps ONE column position for
 //              all its slots (slot u = row u * rps + t / tcv), so 1/s_A of its four columns and its column minima /
 //              maxima live in registers and the row reduction is a butterfly over the tcv lanes of a row;
 //   LayShort   rows of <= 32 floats (depthwise k x k kernels, the stem): one THREAD per row, row statistics without
@@ -294,13 +294,19 @@ struct LayFixed {
     static constexpr int VEC = 4, NS = NS_;
     int lg_tcv, tcv, rps, rsub, pos, n_used;
     int tabk[4];                       // table offset of the thread's four columns inside a group row
-    bool one_group;
+    bool one_group, lane_on;
     __device__ __forceinline__ void init(const ResTile& T, const TileGeo& G) {
-        tcv = T.nc / 4;
-        lg_tcv = 31 - __builtin_clz((unsigned)tcv);
+        // a row of nc / 4 vectors occupies the next power of two of lanes (tcv); the lanes past its end hold duplicates of
+        // its last vector (harmless for min / max, excluded from the stores and from |dW| through `lane_on`)
+        const int real = T.nc / 4;
+        lg_tcv = 32 - __builtin_clz((unsigned)(real - 1) | 0u);
+        if (real == 1) lg_tcv = 0;
+        tcv = 1 << lg_tcv;
         rps = kBlock >> lg_tcv;
         rsub = (int)threadIdx.x >> lg_tcv;
-        pos = T.c0 + ((int)threadIdx.x & (tcv - 1)) * 4;
+        const int colv = (int)threadIdx.x & (tcv - 1);
+        lane_on = colv < real;
+        pos = T.c0 + min(colv, real - 1) * 4;
         n_used = (T.nr + rps - 1) >> (8 - lg_tcv);
         one_group = G.g_n == 1;
 #pragma unroll
@@ -317,8 +323,9 @@ struct LayFixed {
             int rs = rsub;
             opaque(rs);                       // see LayGeneral::coords: keep the per-slot coordinates out of registers
             int row = u * rps + rs;
-            const bool on = row < T.nr;
-            row = on ? row : T.nr - 1;
+            const bool row_ok = row < T.nr;
+            const bool on = row_ok && lane_on;           // padded lanes keep their OWN row (they duplicate its last vector)
+            row = row_ok ? row : T.nr - 1;
             f(u, row, on);
         }
     }
@@ -358,9 +365,14 @@ struct LayFixed {
                 const float x = v[u][k] * iv[k];                    // * 1.0f is exact
                 mn = vmin_raw(mn, x); mx = vmax_raw(mx, x);
             }
-            for (int m = 1; m < w; m <<= 1) {
-                mn = vmin_raw(mn, __shfl_xor(mn, m));
-                mx = vmax_raw(mx, __shfl_xor(mx, m));
+            // compile-time masks (cross-lane moves without an LDS round trip) behind uniform guards: a run-time mask
+            // makes every step a ds_bpermute the next step waits for
+#pragma unroll
+            for (int m = 1; m < kWave; m <<= 1) {
+                if (m < w) {
+                    mn = vmin_raw(mn, __shfl_xor(mn, m));
+                    mx = vmax_raw(mx, __shfl_xor(mx, m));
+                }
             }
             if ((lane & (w - 1)) == 0 && on) lds_minmax(sh_row + 2 * row, mn, mx);   // one writer per row and wave
         });
@@ -378,11 +390,14 @@ struct LayFixed {
                     cmx[k] = vmax_raw(cmx[k], on ? v[u][k] : -INFINITY);
                 }
             });
-            for (int m = tcv; m < kWave; m <<= 1) {                 // lanes of the wave that hold the same columns
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    cmn[k] = vmin_raw(cmn[k], __shfl_xor(cmn[k], m));
-                    cmx[k] = vmax_raw(cmx[k], __shfl_xor(cmx[k], m));
+            for (int m = 1; m < kWave; m <<= 1) {                   // lanes of the wave that hold the same columns
+                if (m >= tcv) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        cmn[k] = vmin_raw(cmn[k], __shfl_xor(cmn[k], m));
+                        cmx[k] = vmax_raw(cmx[k], __shfl_xor(cmx[k], m));
+                    }
                 }
             }
             if (lane < tcv) {
@@ -520,22 +535,34 @@ struct LoopState {
     int count, sweeps, done;
 };
 
-// dfq.py:105-115 after sweep k: sum of the layers' mean |dW| from the tiles' partial sums (fixed order), state machine
-__device__ __forceinline__ void decide(const ResArgs& a, int k, LoopState& st, double* sh_d, double* sh_mean) {
+// sum of x[0 .. n) in index order, eight LDS reads in flight per trip (a plain loop pays one LDS round trip per element)
+__device__ __forceinline__ double ordered_sum(const double* x, int n) {
+    double s = 0.0;
+    for (int i = 0; i < n; i += 8) {
+        double t[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] = x[min(i + j, n - 1)];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += (i + j < n) ? t[j] : 0.0;                 // + 0.0 is exact
+    }
+    return s;
+}
+
+// dfq.py:105-115 after sweep k: sum of the layers' mean |dW| from the tiles' partial sums (fixed order), state machine.
+// `mine` = layer_diff[threadIdx.x], loaded once before the loop.
+__device__ __forceinline__ void decide(const ResArgs& a, int k, LoopState& st, const ResLayerDiff& mine, double* sh_d, double* sh_mean) {
     const int tid = threadIdx.x;
     const u64* part = (const u64*)a.partials + (int64_t)(k & 1) * a.n_tiles;
     for (int i = tid; i < a.n_tiles; i += kBlock) sh_d[i] = __longlong_as_double((long long)ld_word(part + i));
     __syncthreads();
     for (int l = tid; l < a.n_layers; l += kBlock) {
-        const ResLayerDiff L = a.layer_diff[l];
-        double s = 0.0;
-        for (int i = 0; i < L.n_tiles; ++i) s += sh_d[L.tile_begin + i];          // fixed order
+        const ResLayerDiff L = (l == tid) ? mine : a.layer_diff[l];
+        const double s = ordered_sum(sh_d + L.tile_begin, L.n_tiles);              // fixed order
         // float(torch.mean(torch.abs(W - W_prev))): float32 mean, widened to double (dfq.py:108)
         sh_mean[l] = (L.n_tiles > 0) ? (double)(float)(s / L.n_elems) : 0.0;
     }
     __syncthreads();
-    double diff_tmp = 0.0;
-    for (int l = 0; l < a.n_layers; ++l) diff_tmp += sh_mean[l];                   // graph order, like Python's sum (every thread)
+    const double diff_tmp = ordered_sum(sh_mean, a.n_layers);                      // graph order, like Python's sum (every thread)
     if (fabs(st.diff - diff_tmp) > 1e-9) { st.count = 0; st.diff = diff_tmp; }
     else { st.count += 1; }
     st.sweeps += 1;
@@ -567,6 +594,9 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
     LoopState st;
     st.diff = a.state->diff; st.last_diff_tmp = a.state->last_diff_tmp;
     st.count = a.state->count; st.sweeps = a.state->sweeps; st.done = 0;
+    ResLayerDiff my_layer;
+    my_layer.tile_begin = 0; my_layer.n_tiles = 0; my_layer.n_elems = 1.0;
+    if (tid < a.n_layers) my_layer = a.layer_diff[tid];
 
     // ---- load the tile (once) ----
     float v[NS][VEC];
@@ -693,7 +723,7 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
             }
             res_stamp(a, k, 5);
             if (!res_wait2(a.done_cnt, (u64)a.n_tiles * round, nullptr, 0, a.err, sh_flag)) { failed = true; break; }
-            decide(a, k, st, sh_dec, sh_dec + kResMaxTiles);
+            decide(a, k, st, my_layer, sh_dec, sh_dec + kResMaxTiles);
         }
         res_stamp(a, k, 6);
         if (a.trace && tid == 0 && k == 0) a.trace[((int64_t)blockIdx.x * kTraceSweeps) * 8 + 7] = ((long long)T.layer << 32) | (unsigned)T.nr << 16 | (unsigned)(T.nc & 0xffff);
@@ -768,16 +798,18 @@ int ceil_div_i(int a, int b) { return (a + b - 1) / b; }
 struct Shape { int tr, tc; };
 
 bool is_pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }
+int pow2_ceil(int x) { int p = 1; while (p < x) p <<= 1; return p; }
 int layout_of(int vec, int row_len, int nc) {
     if (vec == 1 && row_len <= 32 && nc == row_len) return kLayShort;
-    if (vec == 4 && is_pow2(nc / 4) && nc / 4 <= kBlock) return kLayFixed;
+    if (vec == 4 && nc / 4 <= kBlock) return kLayFixed;
     return kLayGeneral;
 }
 
-// [tr x tc] tiling of an [R x C] layer holding at most `cap` floats per tile.  Cost = global statistics atomics per sweep
-// (row statistics are merged over the column blocks, column statistics over the row blocks), with a heavy penalty for
+// [tr x tc] tiling of an [R x C] layer; ns4 = float4 slots per thread.  Cost = global statistics atomics per sweep (row
+// statistics are merged over the column blocks, column statistics over the row blocks) -- complete rows are favoured
+// for layers with row duty: no merge, and the tile does not wait for its own publication -- with a heavy penalty for
 // tiles that fall back to the general layout (LDS atomics per element).
-Shape pick_shape(int R, int C, int vec, int khkw, int go, int i2g, bool need_row, bool need_col, int cap) {
+Shape pick_shape(int R, int C, int vec, int khkw, int go, int i2g, bool need_row, bool need_col, int ns4) {
     if (vec == 1 && C <= 32) {               // thread-per-row tiles: complete rows, two rows per thread if they are <= 16 floats
         int tr = std::min(R, kBlock * (C <= 16 ? 2 : 1));
         if (need_row) tr = std::min(tr, kResRows);
@@ -791,7 +823,11 @@ Shape pick_shape(int R, int C, int vec, int khkw, int go, int i2g, bool need_row
     cands.push_back(C);
     for (int tc : cands) {
         if (tc % vec) continue;
-        int tr = std::min(R, cap / tc);
+        const int lay = layout_of(vec, C, tc);
+        int tr;
+        if (lay == kLayFixed) tr = ns4 * (kBlock / pow2_ceil(tc / 4));      // rows per slot x slots
+        else tr = (vec == 4 ? 1024 * ns4 : 32 * kBlock) / tc;
+        tr = std::min(R, tr);
         if (tr < 1) continue;
         if (need_row) tr = std::min(tr, kResRows);
         // LDS table of a tile with column duty: (groups spanned by its rows) x (input channels spanned by its columns)
@@ -801,11 +837,11 @@ Shape pick_shape(int R, int C, int vec, int khkw, int go, int i2g, bool need_row
             if (((tr + go - 1) / go + 1) * nci > kResTab) continue;
         }
         const int n_rb = ceil_div_i(R, tr), n_cb = ceil_div_i(C, tc);
-        double cost = (double)n_rb * n_cb * 0.02;                       // a tile is a workgroup: mild pressure for fewer
-        if (need_row) cost += (double)R * (n_cb > 1 ? n_cb : 0.25);     // complete rows: no merge, no extra hand-off
-        if (need_col) cost += (double)(C / khkw) * n_rb;
+        double cost = (double)n_rb * n_cb * 2.0;                        // a tile is a workgroup of a bounded supply
+        if (need_row) cost += (double)R * (n_cb > 1 ? n_cb : 0.25);
+        if (need_col) cost += (double)(C / khkw) * n_rb * 0.5;          // column statistics are consumed a sweep later
         const int rem = C % tc;
-        if (layout_of(vec, C, tc) == kLayGeneral) cost += 1e7;
+        if (lay == kLayGeneral) cost += 1e7;
         if (rem && layout_of(vec, C, rem) == kLayGeneral) cost += 1e7 * rem / (double)C;
         if (cost < best_cost) { best_cost = cost; best = Shape{tr, tc}; }
     }
@@ -881,8 +917,7 @@ LeResident* le_resident_create(const dfq_layer* layers, int n_layers, const dfq_
                 go = R / Gp;
             }
             const int vec = (C % 4 == 0 && ((uintptr_t)L.weight & 15u) == 0) ? 4 : 1;
-            const int cap = (vec == 4) ? 1024 * cand : 32 * kBlock;
-            const Shape sh = pick_shape(R, C, vec, L.khkw, go, i2g, relB >= 0, relA >= 0, cap);
+            const Shape sh = pick_shape(R, C, vec, L.khkw, go, i2g, relB >= 0, relA >= 0, cand);
             if (sh.tr < 1) { ok = false; why = "a layer does not tile"; break; }
             const int n_rb = ceil_div_i(R, sh.tr), n_cb = ceil_div_i(C, sh.tc);
             for (int rb = 0; rb < n_rb; ++rb)
