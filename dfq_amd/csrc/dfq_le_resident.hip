@@ -89,10 +89,10 @@ struct ResArgs {
     int64_t parity_stride;           // u64 words between the parities of an arena
     u64* cnt_r;                      // per paired layer (x kResStride): tiles that published row statistics
     u64* cnt_c;                      //   "   column statistics
-    u64* done_cnt;                   // tiles that finished a sweep
+    u64* done_cnt;                   // [3] (x kResStride): tiles that finished a sweep, by sweep % 3 (see the partial buffers)
     u64* seq;                        // (sweeps finished in this launch << 1) | stop
     u64* err;
-    double* partials;                // [2 parities][tiles]
+    double* partials;                // [3 parities][tiles]
     LeState* state;
     int32_t n_tiles, n_layers;       // n_layers: targ layers of the network (layer_diff entries)
     int32_t n_sweeps;                // sweeps this launch may run
@@ -239,15 +239,21 @@ struct LayGeneral {
             else *dst = v[u][0];
         });
     }
-    // row statistics of w (with_inv false) or of fl(w * 1/s_A) into sh_row (zeroed by the caller)
-    __device__ __forceinline__ void row_stats(const ResTile& T, const TileGeo& G, const float (&v)[NS][VEC], bool with_inv,
-                                              const float* sh_inv, uint32_t* sh_row) const {
+    // the value an element WILL have: fl(fl(w * 1/s_A) * s_B) with the factors in use (dfq.py:73 then :62, both rounded)
+    __device__ __forceinline__ float val(const ResTile& T, const TileGeo& G, float w, bool useA, bool useB, const float* sh_inv,
+                                         const float* sh_s, int row, int pos_k) const {
+        const float tt = useA ? w * sh_inv[tab(T, G, row, pos_k)] : w;
+        return useB ? tt * sh_s[row] : tt;
+    }
+    // row statistics of the (pending) values into sh_row (zeroed by the caller)
+    __device__ __forceinline__ void row_stats(const ResTile& T, const TileGeo& G, const float (&v)[NS][VEC], bool useA, bool useB,
+                                              const float* sh_inv, const float* sh_s, uint32_t* sh_row) const {
         const int lane = threadIdx.x % kWave;
         slots(T, [&](int u, int row, int pos, bool on) {
             float mn = INFINITY, mx = -INFINITY;
 #pragma unroll
             for (int k = 0; k < VEC; ++k) {
-                const float x = with_inv ? v[u][k] * sh_inv[tab(T, G, row, pos + k)] : v[u][k];
+                const float x = val(T, G, v[u][k], useA, useB, sh_inv, sh_s, row, pos + k);
                 mn = vmin_raw(mn, on ? x : INFINITY);
                 mx = vmax_raw(mx, on ? x : -INFINITY);
             }
@@ -261,27 +267,28 @@ struct LayGeneral {
             }
         });
     }
-    __device__ __forceinline__ void col_stats(const ResTile& T, const TileGeo& G, const float (&v)[NS][VEC], uint32_t* sh_col) const {
+    __device__ __forceinline__ void col_stats(const ResTile& T, const TileGeo& G, const float (&v)[NS][VEC], bool useA, bool useB,
+                                              const float* sh_inv, const float* sh_s, uint32_t* sh_col) const {
         slots(T, [&](int u, int row, int pos, bool on) {
             if (!on) return;
 #pragma unroll
-            for (int k = 0; k < VEC; ++k) lds_minmax(sh_col + 2 * tab(T, G, row, pos + k), v[u][k], v[u][k]);
+            for (int k = 0; k < VEC; ++k) {
+                const float x = val(T, G, v[u][k], useA, useB, sh_inv, sh_s, row, pos + k);
+                lds_minmax(sh_col + 2 * tab(T, G, row, pos + k), x, x);
+            }
         });
     }
-    // w <- fl(fl(w * 1/s_A) * s_B); returns the thread's sum of |new - old| in float64
-    __device__ __forceinline__ double update(const ResTile& T, const TileGeo& G, float (&v)[NS][VEC], bool hasA, bool hasB,
-                                             const float* sh_inv, const float* sh_s) const {
+    // the thread's sum of |new - old| in float64; `commit`: w <- new
+    __device__ __forceinline__ double update(const ResTile& T, const TileGeo& G, float (&v)[NS][VEC], bool useA, bool useB,
+                                             const float* sh_inv, const float* sh_s, bool commit) const {
         double acc = 0.0;
         slots(T, [&](int u, int row, int pos, bool on) {
-            const float s = hasB ? sh_s[row] : 1.0f;
             double part = 0.0;
 #pragma unroll
             for (int k = 0; k < VEC; ++k) {
-                const float inv = hasA ? sh_inv[tab(T, G, row, pos + k)] : 1.0f;
-                const float tt = v[u][k] * inv;                   // dfq.py:73 (rounded), then
-                const float nv = tt * s;                          // dfq.py:62
+                const float nv = val(T, G, v[u][k], useA, useB, sh_inv, sh_s, row, pos + k);
                 part += (double)abs_f32(nv - v[u][k]);
-                v[u][k] = nv;
+                if (commit) v[u][k] = nv;
             }
             acc += on ? part : 0.0;
         });
@@ -351,43 +358,56 @@ struct LayFixed {
 #pragma unroll
         for (int k = 0; k < 4; ++k) iv[k] = sh_inv[gr + tabk[k]];
     }
-    __device__ __forceinline__ void row_stats(const ResTile& T, const TileGeo& G, const float (&v)[NS][VEC], bool with_inv,
-                                              const float* sh_inv, uint32_t* sh_row) const {
+    // Row statistics of the (pending) values.  Steps outside, slots inside: the NS butterflies are independent, so
+    // their cross-lane moves overlap (a butterfly per slot, one after the other, is a chain of dependent moves).
+    __device__ __forceinline__ void row_stats(const ResTile& T, const TileGeo& G, const float (&v)[NS][VEC], bool useA, bool useB,
+                                              const float* sh_inv, const float* sh_s, uint32_t* sh_row) const {
         const int lane = threadIdx.x % kWave;
         const int w = tcv < kWave ? tcv : kWave;                    // lanes of a wave that share a row
         float iv[4] = {1.0f, 1.0f, 1.0f, 1.0f};
-        if (with_inv && one_group) inv4(T, G, sh_inv, 0, iv);
-        slots(T, [&](int u, int row, bool on) {
-            if (with_inv && !one_group) inv4(T, G, sh_inv, row, iv);
-            float mn = INFINITY, mx = -INFINITY;
+        if (useA && one_group) inv4(T, G, sh_inv, 0, iv);
+        float mn[NS], mx[NS];
+#pragma unroll
+        for (int u = 0; u < NS; ++u) { mn[u] = INFINITY; mx[u] = -INFINITY; }
+        slots(T, [&](int u, int row, bool) {
+            if (useA && !one_group) inv4(T, G, sh_inv, row, iv);
+            const float sr = useB ? sh_s[row] : 1.0f;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const float x = v[u][k] * iv[k];                    // * 1.0f is exact
-                mn = vmin_raw(mn, x); mx = vmax_raw(mx, x);
+                const float x = (v[u][k] * iv[k]) * sr;              // * 1.0f is exact
+                mn[u] = vmin_raw(mn[u], x); mx[u] = vmax_raw(mx[u], x);
             }
-            // compile-time masks (cross-lane moves without an LDS round trip) behind uniform guards: a run-time mask
-            // makes every step a ds_bpermute the next step waits for
+        });
 #pragma unroll
-            for (int m = 1; m < kWave; m <<= 1) {
-                if (m < w) {
-                    mn = vmin_raw(mn, __shfl_xor(mn, m));
-                    mx = vmax_raw(mx, __shfl_xor(mx, m));
+        for (int m = 1; m < kWave; m <<= 1) {
+            if (m < w) {                                             // uniform
+#pragma unroll
+                for (int u = 0; u < NS; ++u) {
+                    mn[u] = vmin_raw(mn[u], __shfl_xor(mn[u], m));
+                    mx[u] = vmax_raw(mx[u], __shfl_xor(mx[u], m));
                 }
             }
-            if ((lane & (w - 1)) == 0 && on) lds_minmax(sh_row + 2 * row, mn, mx);   // one writer per row and wave
+        }
+        slots(T, [&](int u, int row, bool on) {
+            if ((lane & (w - 1)) == 0 && on) lds_minmax(sh_row + 2 * row, mn[u], mx[u]);   // one writer per row and wave
         });
     }
-    __device__ __forceinline__ void col_stats(const ResTile& T, const TileGeo& G, const float (&v)[NS][VEC], uint32_t* sh_col) const {
+    __device__ __forceinline__ void col_stats(const ResTile& T, const TileGeo& G, const float (&v)[NS][VEC], bool useA, bool useB,
+                                              const float* sh_inv, const float* sh_s, uint32_t* sh_col) const {
         const int lane = threadIdx.x % kWave;
+        float iv[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+        if (useA && one_group) inv4(T, G, sh_inv, 0, iv);
         if (one_group) {
             float cmn[4], cmx[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) { cmn[k] = INFINITY; cmx[k] = -INFINITY; }
-            slots(T, [&](int u, int, bool on) {
+            slots(T, [&](int u, int row, bool on) {
+                const float sr = useB ? sh_s[row] : 1.0f;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    cmn[k] = vmin_raw(cmn[k], on ? v[u][k] : INFINITY);
-                    cmx[k] = vmax_raw(cmx[k], on ? v[u][k] : -INFINITY);
+                    const float x = (v[u][k] * iv[k]) * sr;
+                    cmn[k] = vmin_raw(cmn[k], on ? x : INFINITY);
+                    cmx[k] = vmax_raw(cmx[k], on ? x : -INFINITY);
                 }
             });
 #pragma unroll
@@ -400,7 +420,7 @@ struct LayFixed {
                     }
                 }
             }
-            if (lane < tcv) {
+            if (lane < tcv && lane_on) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) lds_minmax(sh_col + 2 * tabk[k], cmn[k], cmx[k]);
             }
@@ -408,26 +428,31 @@ struct LayFixed {
             slots(T, [&](int u, int row, bool on) {
                 if (!on) return;
                 const int gr = group_row(T, G, row);
+                if (useA) inv4(T, G, sh_inv, row, iv);
+                const float sr = useB ? sh_s[row] : 1.0f;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) lds_minmax(sh_col + 2 * (gr + tabk[k]), v[u][k], v[u][k]);
+                for (int k = 0; k < 4; ++k) {
+                    const float x = (v[u][k] * iv[k]) * sr;
+                    lds_minmax(sh_col + 2 * (gr + tabk[k]), x, x);
+                }
             });
         }
     }
-    __device__ __forceinline__ double update(const ResTile& T, const TileGeo& G, float (&v)[NS][VEC], bool hasA, bool hasB,
-                                             const float* sh_inv, const float* sh_s) const {
+    __device__ __forceinline__ double update(const ResTile& T, const TileGeo& G, float (&v)[NS][VEC], bool useA, bool useB,
+                                             const float* sh_inv, const float* sh_s, bool commit) const {
         double acc = 0.0;
         float iv[4] = {1.0f, 1.0f, 1.0f, 1.0f};
-        if (hasA && one_group) inv4(T, G, sh_inv, 0, iv);
+        if (useA && one_group) inv4(T, G, sh_inv, 0, iv);
         slots(T, [&](int u, int row, bool on) {
-            if (hasA && !one_group) inv4(T, G, sh_inv, row, iv);
-            const float s = hasB ? sh_s[row] : 1.0f;
+            if (useA && !one_group) inv4(T, G, sh_inv, row, iv);
+            const float s = useB ? sh_s[row] : 1.0f;
             double part = 0.0;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const float tt = v[u][k] * iv[k];                 // dfq.py:73 (rounded), then
                 const float nv = tt * s;                          // dfq.py:62
                 part += (double)abs_f32(nv - v[u][k]);
-                v[u][k] = nv;
+                if (commit) v[u][k] = nv;
             }
             acc += on ? part : 0.0;
         });
@@ -469,38 +494,45 @@ struct LayShort {
     __device__ __forceinline__ int tab(const ResTile& T, const TileGeo& G, int row, int e) const {
         return (small_div(T.r0 + row, T.go) - G.g_lo) * G.nci + small_div(e, T.khkw);     // complete rows: i0 == 0
     }
-    __device__ __forceinline__ void row_stats(const ResTile& T, const TileGeo& G, const float (&v)[NS][VEC], bool with_inv,
-                                              const float* sh_inv, uint32_t* sh_row) const {
+    __device__ __forceinline__ float val(const ResTile& T, const TileGeo& G, float w, bool useA, bool useB, const float* sh_inv,
+                                         const float* sh_s, int row, int e) const {
+        const float tt = useA ? w * sh_inv[tab(T, G, row, e)] : w;   // dfq.py:73 (rounded), then
+        return useB ? tt * sh_s[row] : tt;                           // dfq.py:62
+    }
+    __device__ __forceinline__ void row_stats(const ResTile& T, const TileGeo& G, const float (&v)[NS][VEC], bool useA, bool useB,
+                                              const float* sh_inv, const float* sh_s, uint32_t* sh_row) const {
         float mn = INFINITY, mx = -INFINITY;
         slots(T, [&](int u, int row, int e, bool on) {
-            const float x = with_inv ? v[u][0] * sh_inv[tab(T, G, row, e)] : v[u][0];
+            const float x = val(T, G, v[u][0], useA, useB, sh_inv, sh_s, row, e);
             mn = (e == 0) ? x : vmin_raw(mn, x);
             mx = (e == 0) ? x : vmax_raw(mx, x);
             if (e == L - 1 && on) { sh_row[2 * row] = ~enc_ord(mn); sh_row[2 * row + 1] = enc_ord(mx); }   // the row's only owner
         });
     }
-    __device__ __forceinline__ void col_stats(const ResTile& T, const TileGeo& G, const float (&v)[NS][VEC], uint32_t* sh_col) const {
+    __device__ __forceinline__ void col_stats(const ResTile& T, const TileGeo& G, const float (&v)[NS][VEC], bool useA, bool useB,
+                                              const float* sh_inv, const float* sh_s, uint32_t* sh_col) const {
         if (G.nci == 1) {            // one input channel per group (depthwise): a row's range goes to its group's channel
             float mn = INFINITY, mx = -INFINITY;
             slots(T, [&](int u, int row, int e, bool on) {
-                mn = (e == 0) ? v[u][0] : vmin_raw(mn, v[u][0]);
-                mx = (e == 0) ? v[u][0] : vmax_raw(mx, v[u][0]);
+                const float x = val(T, G, v[u][0], useA, useB, sh_inv, sh_s, row, e);
+                mn = (e == 0) ? x : vmin_raw(mn, x);
+                mx = (e == 0) ? x : vmax_raw(mx, x);
                 if (e == L - 1 && on) lds_minmax(sh_col + 2 * tab(T, G, row, 0), mn, mx);
             });
         } else {
-            slots(T, [&](int u, int row, int e, bool on) { if (on) lds_minmax(sh_col + 2 * tab(T, G, row, e), v[u][0], v[u][0]); });
+            slots(T, [&](int u, int row, int e, bool on) {
+                const float x = val(T, G, v[u][0], useA, useB, sh_inv, sh_s, row, e);
+                if (on) lds_minmax(sh_col + 2 * tab(T, G, row, e), x, x);
+            });
         }
     }
-    __device__ __forceinline__ double update(const ResTile& T, const TileGeo& G, float (&v)[NS][VEC], bool hasA, bool hasB,
-                                             const float* sh_inv, const float* sh_s) const {
+    __device__ __forceinline__ double update(const ResTile& T, const TileGeo& G, float (&v)[NS][VEC], bool useA, bool useB,
+                                             const float* sh_inv, const float* sh_s, bool commit) const {
         double acc = 0.0;
         slots(T, [&](int u, int row, int e, bool on) {
-            const float inv = hasA ? sh_inv[tab(T, G, row, e)] : 1.0f;
-            const float s = hasB ? sh_s[row] : 1.0f;
-            const float tt = v[u][0] * inv;                       // dfq.py:73 (rounded), then
-            const float nv = tt * s;                              // dfq.py:62
+            const float nv = val(T, G, v[u][0], useA, useB, sh_inv, sh_s, row, e);
             acc += on ? (double)abs_f32(nv - v[u][0]) : 0.0;
-            v[u][0] = nv;
+            if (commit) v[u][0] = nv;
         });
         return acc;
     }
@@ -552,7 +584,7 @@ __device__ __forceinline__ double ordered_sum(const double* x, int n) {
 // `mine` = layer_diff[threadIdx.x], loaded once before the loop.
 __device__ __forceinline__ void decide(const ResArgs& a, int k, LoopState& st, const ResLayerDiff& mine, double* sh_d, double* sh_mean) {
     const int tid = threadIdx.x;
-    const u64* part = (const u64*)a.partials + (int64_t)(k & 1) * a.n_tiles;
+    const u64* part = (const u64*)a.partials + (int64_t)(k % 3) * a.n_tiles;
     for (int i = tid; i < a.n_tiles; i += kBlock) sh_d[i] = __longlong_as_double((long long)ld_word(part + i));
     __syncthreads();
     for (int l = tid; l < a.n_layers; l += kBlock) {
@@ -602,12 +634,12 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
     float v[NS][VEC];
     lay.load(T, v);
     // the [O] vectors of relation B for the rows this thread owns
-    float o_cum[kResOwn], o_bnw[kResOwn], o_bnb[kResOwn], o_b1[kResOwn];
+    float o_cum[kResOwn], o_bnw[kResOwn], o_bnb[kResOwn], o_b1[kResOwn], o_s[kResOwn];
     const bool owner = hasB && T.owner != 0;
 #pragma unroll
     for (int j = 0; j < kResOwn; ++j) {
         const int i = tid + j * kBlock;
-        o_cum[j] = 1.0f; o_bnw[j] = 0.0f; o_bnb[j] = 0.0f; o_b1[j] = 0.0f;
+        o_cum[j] = 1.0f; o_bnw[j] = 0.0f; o_bnb[j] = 0.0f; o_b1[j] = 0.0f; o_s[j] = 1.0f;
         if (owner && i < T.nr) {
             const int c = T.r0 + i;
             o_cum[j] = RB.s_cum[c];
@@ -621,7 +653,7 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
     if (hasA) {
         for (int i = tid; i < 2 * G.g_n * G.nci; i += kBlock) sh_col[i] = 0u;
         __syncthreads();
-        lay.col_stats(T, G, v, sh_col);
+        lay.col_stats(T, G, v, false, false, sh_inv, sh_s, sh_col);
         __syncthreads();
         publish_cols(a, T, G, RA, sh_col, 1u);
         arrive(a.cnt_c + (int64_t)T.layer * kResStride);
@@ -629,7 +661,7 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
     if (chain_start) {
         for (int i = tid; i < 2 * T.nr; i += kBlock) sh_row[i] = 0u;
         __syncthreads();
-        lay.row_stats(T, G, v, false, sh_inv, sh_row);
+        lay.row_stats(T, G, v, false, false, sh_inv, sh_s, sh_row);
         __syncthreads();
         publish_rows(a, T, RB, sh_row, 1u);
         arrive(a.cnt_r + (int64_t)T.layer * kResStride);
@@ -659,7 +691,7 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
             __syncthreads();
             if (hasB) {
                 // row statistics of t = fl(w * 1/s_A) for relation B of this same sweep (t is not kept: phase 3 recomputes it)
-                lay.row_stats(T, G, v, true, sh_inv, sh_row);
+                lay.row_stats(T, G, v, true, false, sh_inv, sh_s, sh_row);
                 __syncthreads();
                 publish_rows(a, T, RB, sh_row, tag);
                 arrive(a.cnt_r + (int64_t)T.layer * kResStride);
@@ -670,7 +702,9 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
         if (hasB) {
             // a tile of complete rows already has its rows' statistics (sh_row: this sweep's phase 1, or the previous
             // sweep's phase 3 for a chain start); otherwise they are merged over the row block's tiles in global memory
-            const u64* own = rows_local ? nullptr : a.cnt_r + (int64_t)T.layer * kResStride;
+            // (a chain start still paces itself on its layer's counter: its tiles do not otherwise wait for each other, and a
+            // tile two publications ahead of a sibling would make the monotonic counter lie to the layer's consumers)
+            const u64* own = (rows_local && !chain_start) ? nullptr : a.cnt_r + (int64_t)T.layer * kResStride;
             if (!res_wait2(a.cnt_c + (int64_t)T.b_layer * kResStride, (u64)T.nt_b * round, own, (u64)T.nt_self * round, a.err, sh_flag)) {
                 failed = true; break;
             }
@@ -685,22 +719,19 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
                     read_range(a.stats, RB.r2_off, a.parity_stride, tag, c, mn2, mx2);
                     le_solve(range_of(mn1, mx1, p.signed_range), range_of(mn2, mx2, p.signed_range), p, s, inv);
                     sh_s[i] = s;
-                    o_cum[j] = o_cum[j] * s;                      // relation.py:20-24
-                    o_bnw[j] = o_bnw[j] * s;                      // dfq.py:64-65
-                    o_bnb[j] = o_bnb[j] * s;                      // dfq.py:67-68
-                    o_b1[j] = o_b1[j] * s;                        // dfq.py:70-71
+                    o_s[j] = s;                                   // applied to the [O] vectors when the sweep is committed
                 }
             }
         }
         res_stamp(a, k, 3);
-        // ---- phase 3: the new values, |dW|, statistics for the next sweep ----
+        // ---- phase 3: |dW| and the statistics of the values this sweep WILL produce (w itself is not touched yet) ----
         __syncthreads();                                          // sh_s complete; sh_row / sh_col free
         if (hasA) for (int i = tid; i < 2 * G.g_n * G.nci; i += kBlock) sh_col[i] = 0u;
         if (chain_start) for (int i = tid; i < 2 * T.nr; i += kBlock) sh_row[i] = 0u;
-        const double acc = lay.update(T, G, v, hasA, hasB, sh_inv, sh_s);
+        const double acc = lay.update(T, G, v, hasA, hasB, sh_inv, sh_s, false);
         __syncthreads();
-        if (hasA) lay.col_stats(T, G, v, sh_col);
-        if (chain_start) lay.row_stats(T, G, v, false, sh_inv, sh_row);
+        if (hasA) lay.col_stats(T, G, v, hasA, hasB, sh_inv, sh_s, sh_col);
+        if (chain_start) lay.row_stats(T, G, v, hasA, hasB, sh_inv, sh_s, sh_row);
         __syncthreads();
         if (hasA) {
             publish_cols(a, T, G, RA, sh_col, tag + 1u);
@@ -711,23 +742,44 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
             arrive(a.cnt_r + (int64_t)T.layer * kResStride);
         }
         res_stamp(a, k, 4);
-        // ---- convergence: one partial per tile (fixed butterfly + fixed wave order); when all are in, every workgroup
-        //      draws the same conclusion from them ----
+        // ---- convergence.  One partial per tile (fixed butterfly + fixed wave order); when the partials of a sweep are all
+        //      in, every workgroup draws the same verdict from them.  The verdict of sweep k-1 is needed only HERE, a whole
+        //      sweep after its partials were written: sweep k is applied to the registers ("committed") only once sweep k-1 is
+        //      known not to have been the last one, so nobody ever waits for a verdict in the middle of the dependency chain
+        //      and a workgroup of a short chain may already work on sweep k+1 while a long chain finishes sweep k. ----
         {
             const double tsum = block_sum(acc, sh_dec);
             if (tid == 0) {
-                __hip_atomic_store((u64*)a.partials + (int64_t)(k & 1) * a.n_tiles + blockIdx.x, (u64)__double_as_longlong(tsum),
+                __hip_atomic_store((u64*)a.partials + (int64_t)(k % 3) * a.n_tiles + blockIdx.x, (u64)__double_as_longlong(tsum),
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __builtin_amdgcn_s_waitcnt(0);
-                atomicAdd(a.done_cnt, 1ull);
+                atomicAdd(a.done_cnt + (k % 3) * kResStride, 1ull);          // one counter per partial buffer
             }
             res_stamp(a, k, 5);
-            if (!res_wait2(a.done_cnt, (u64)a.n_tiles * round, nullptr, 0, a.err, sh_flag)) { failed = true; break; }
-            decide(a, k, st, my_layer, sh_dec, sh_dec + kResMaxTiles);
+            if (k > 0) {
+                if (!res_wait2(a.done_cnt + ((k - 1) % 3) * kResStride, (u64)a.n_tiles * (u64)((k - 1) / 3 + 1), nullptr, 0, a.err, sh_flag)) {
+                    failed = true; break;
+                }
+                decide(a, k - 1, st, my_layer, sh_dec, sh_dec + kResMaxTiles);
+                if (st.done) break;                               // sweep k-1 was the last one: sweep k is dropped
+            }
         }
         res_stamp(a, k, 6);
         if (a.trace && tid == 0 && k == 0) a.trace[((int64_t)blockIdx.x * kTraceSweeps) * 8 + 7] = ((long long)T.layer << 32) | (unsigned)T.nr << 16 | (unsigned)(T.nc & 0xffff);
-        if (st.done || k + 1 >= a.n_sweeps) { ++k; break; }
+        // ---- commit sweep k ----
+        (void)lay.update(T, G, v, hasA, hasB, sh_inv, sh_s, true);
+#pragma unroll
+        for (int j = 0; j < kResOwn; ++j) {
+            o_cum[j] = o_cum[j] * o_s[j];                         // relation.py:20-24
+            o_bnw[j] = o_bnw[j] * o_s[j];                         // dfq.py:64-65
+            o_bnb[j] = o_bnb[j] * o_s[j];                         // dfq.py:67-68
+            o_b1[j] = o_b1[j] * o_s[j];                           // dfq.py:70-71
+        }
+        if (k + 1 >= a.n_sweeps) {                                // the launch's last sweep: its verdict closes the state
+            if (!res_wait2(a.done_cnt + (k % 3) * kResStride, (u64)a.n_tiles * (u64)(k / 3 + 1), nullptr, 0, a.err, sh_flag)) { failed = true; break; }
+            decide(a, k, st, my_layer, sh_dec, sh_dec + kResMaxTiles);
+            break;
+        }
     }
     if (failed) return;                     // nothing is stored: the weights stay as they were before the launch
     // ---- write the tile back (once) ----
@@ -978,13 +1030,13 @@ LeResident* le_resident_create(const dfq_layer* layers, int n_layers, const dfq_
         ld[l].n_tiles = tile_count[l];
         ld[l].n_elems = (double)((int64_t)layers[l].out_ch * layers[l].in_per_group * layers[l].khkw);
     }
-    r->sync_words = (size_t)(2 * n_pl + 3) * kResStride;
+    r->sync_words = (size_t)(2 * n_pl + 4) * kResStride;
     bool ok = hipMalloc((void**)&r->d_tiles, sizeof(ResTile) * tiles.size()) == hipSuccess &&
               hipMalloc((void**)&r->d_rels, sizeof(ResRel) * n_relations) == hipSuccess &&
               hipMalloc((void**)&r->d_layer_diff, sizeof(ResLayerDiff) * n_layers) == hipSuccess &&
               hipMalloc((void**)&r->d_stats, sizeof(u64) * (size_t)r->stat_words) == hipSuccess &&
               hipMalloc((void**)&r->d_sync, sizeof(u64) * r->sync_words) == hipSuccess &&
-              hipMalloc((void**)&r->d_partials, sizeof(double) * 2 * tiles.size()) == hipSuccess &&
+              hipMalloc((void**)&r->d_partials, sizeof(double) * 3 * tiles.size()) == hipSuccess &&
               hipMemcpy(r->d_tiles, tiles.data(), sizeof(ResTile) * tiles.size(), hipMemcpyHostToDevice) == hipSuccess &&
               hipMemcpy(r->d_rels, hr.data(), sizeof(ResRel) * n_relations, hipMemcpyHostToDevice) == hipSuccess &&
               hipMemcpy(r->d_layer_diff, ld.data(), sizeof(ResLayerDiff) * n_layers, hipMemcpyHostToDevice) == hipSuccess;
@@ -1010,7 +1062,7 @@ int le_resident_enqueue(LeResident* r, const dfq_le_config* cfg, LeState* d_stat
     a.cnt_r = r->d_sync;
     a.cnt_c = r->d_sync + (size_t)r->n_pl * kResStride;
     a.done_cnt = r->d_sync + (size_t)2 * r->n_pl * kResStride;
-    a.seq = a.done_cnt + kResStride;
+    a.seq = a.done_cnt + 3 * kResStride;
     a.err = d_err;
     a.partials = r->d_partials;
     a.state = d_state;
