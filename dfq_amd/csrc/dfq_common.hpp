@@ -120,15 +120,66 @@ __device__ __forceinline__ float vmax_raw(float a, float b) {
 #endif
 }
 
+// ---- butterfly steps that stay out of the LDS ------------------------------------------------------
+// __shfl_xor is a ds_bpermute_b32: every step goes through the LDS crossbar, which all waves of a CU share -- a tile
+// that reduces 16 register slots over 64 lanes issues ~200 of them, and eight waves doing so take microseconds.
+// xor_lane<M>(x) returns lane (id ^ M)'s x with register-file moves only: DPP quad permutes (M = 1, 2), a pair of DPP
+// row shifts with complementary bank masks (M = 4, 8), gfx950's v_permlane16_swap / v_permlane32_swap (M = 16, 32: after
+// the swap of two copies of x, one of them holds the own value and the other the partner's; for the commutative min / max
+// it does not matter which).  tools/litmus/lane_xor.hip checks all six against __shfl_xor on the hardware.
+#if defined(__HIP_DEVICE_COMPILE__)
+template <int CTRL, int BANK_MASK>
+__device__ __forceinline__ uint32_t dpp_move(uint32_t old, uint32_t src) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)src, CTRL, 0xf, BANK_MASK, false);
+}
+#endif
+template <int M>
+__device__ __forceinline__ void xor_lane_minmax(float& mn, float& mx) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t a = __float_as_uint(mn), b = __float_as_uint(mx);
+    uint32_t pa, pb;
+    if (M == 1) { pa = dpp_move<0xB1, 0xf>(a, a); pb = dpp_move<0xB1, 0xf>(b, b); }              // quad_perm [1,0,3,2]
+    else if (M == 2) { pa = dpp_move<0x4E, 0xf>(a, a); pb = dpp_move<0x4E, 0xf>(b, b); }         // quad_perm [2,3,0,1]
+    else if (M == 4) {      // lanes 0-3 / 8-11 of a row take lane + 4 (row_shl:4), lanes 4-7 / 12-15 take lane - 4 (row_shr:4)
+        pa = dpp_move<0x114, 0xA>(dpp_move<0x104, 0x5>(a, a), a);
+        pb = dpp_move<0x114, 0xA>(dpp_move<0x104, 0x5>(b, b), b);
+    } else if (M == 8) {
+        pa = dpp_move<0x118, 0xC>(dpp_move<0x108, 0x3>(a, a), a);
+        pb = dpp_move<0x118, 0xC>(dpp_move<0x108, 0x3>(b, b), b);
+    } else if (M == 16) {
+        const auto ra = __builtin_amdgcn_permlane16_swap(a, a, false, false);
+        const auto rb = __builtin_amdgcn_permlane16_swap(b, b, false, false);
+        mn = vmin_raw(__uint_as_float(ra[0]), __uint_as_float(ra[1]));
+        mx = vmax_raw(__uint_as_float(rb[0]), __uint_as_float(rb[1]));
+        return;
+    } else {
+        const auto ra = __builtin_amdgcn_permlane32_swap(a, a, false, false);
+        const auto rb = __builtin_amdgcn_permlane32_swap(b, b, false, false);
+        mn = vmin_raw(__uint_as_float(ra[0]), __uint_as_float(ra[1]));
+        mx = vmax_raw(__uint_as_float(rb[0]), __uint_as_float(rb[1]));
+        return;
+    }
+    mn = vmin_raw(mn, __uint_as_float(pa));
+    mx = vmax_raw(mx, __uint_as_float(pb));
+#else
+    mn = vmin_raw(mn, __shfl_xor(mn, M));
+    mx = vmax_raw(mx, __shfl_xor(mx, M));
+#endif
+}
+
 // ---- wavefront (64-lane) butterflies: every lane ends with the result ------------------------
+__device__ __forceinline__ void wave_minmax(float& mn, float& mx) {
+    xor_lane_minmax<1>(mn, mx); xor_lane_minmax<2>(mn, mx); xor_lane_minmax<4>(mn, mx);
+    xor_lane_minmax<8>(mn, mx); xor_lane_minmax<16>(mn, mx); xor_lane_minmax<32>(mn, mx);
+}
 __device__ __forceinline__ float wave_min(float v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v = vmin_raw(v, __shfl_xor(v, m));
+    float other = v;
+    wave_minmax(v, other);
     return v;
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v = vmax_raw(v, __shfl_xor(v, m));
+    float other = v;
+    wave_minmax(other, v);
     return v;
 }
 __device__ __forceinline__ double wave_sum(double v) {

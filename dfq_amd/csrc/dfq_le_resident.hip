@@ -104,9 +104,10 @@ struct ResArgs {
 };
 
 constexpr int kTraceSweeps = 6;
+constexpr int kTracePoints = 12;
 __device__ __forceinline__ void res_stamp(const ResArgs& a, int k, int point) {
     if (a.trace && threadIdx.x == 0 && k < kTraceSweeps)
-        a.trace[((int64_t)blockIdx.x * kTraceSweeps + k) * 8 + point] = wall_clock64();
+        a.trace[((int64_t)blockIdx.x * kTraceSweeps + k) * kTracePoints + point] = wall_clock64();
 }
 
 // ---- waits ---------------------------------------------------------------------------------------------
@@ -378,16 +379,10 @@ struct LayFixed {
                 mn[u] = vmin_raw(mn[u], x); mx[u] = vmax_raw(mx[u], x);
             }
         });
-#pragma unroll
-        for (int m = 1; m < kWave; m <<= 1) {
-            if (m < w) {                                             // uniform
-#pragma unroll
-                for (int u = 0; u < NS; ++u) {
-                    mn[u] = vmin_raw(mn[u], __shfl_xor(mn[u], m));
-                    mx[u] = vmax_raw(mx[u], __shfl_xor(mx[u], m));
-                }
-            }
-        }
+        // register-file butterflies (xor_lane_minmax, dfq_common.hpp) behind uniform guards
+#define DFQ_ROW_STEP(M) if ((M) < w) { _Pragma("unroll") for (int u = 0; u < NS; ++u) xor_lane_minmax<M>(mn[u], mx[u]); }
+        DFQ_ROW_STEP(1) DFQ_ROW_STEP(2) DFQ_ROW_STEP(4) DFQ_ROW_STEP(8) DFQ_ROW_STEP(16) DFQ_ROW_STEP(32)
+#undef DFQ_ROW_STEP
         slots(T, [&](int u, int row, bool on) {
             if ((lane & (w - 1)) == 0 && on) lds_minmax(sh_row + 2 * row, mn[u], mx[u]);   // one writer per row and wave
         });
@@ -410,16 +405,10 @@ struct LayFixed {
                     cmx[k] = vmax_raw(cmx[k], on ? x : -INFINITY);
                 }
             });
-#pragma unroll
-            for (int m = 1; m < kWave; m <<= 1) {                   // lanes of the wave that hold the same columns
-                if (m >= tcv) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        cmn[k] = vmin_raw(cmn[k], __shfl_xor(cmn[k], m));
-                        cmx[k] = vmax_raw(cmx[k], __shfl_xor(cmx[k], m));
-                    }
-                }
-            }
+            // lanes of the wave that hold the same columns: ids that differ in bits >= lg(tcv)
+#define DFQ_COL_STEP(M) if ((M) >= tcv) { _Pragma("unroll") for (int k = 0; k < 4; ++k) xor_lane_minmax<M>(cmn[k], cmx[k]); }
+            DFQ_COL_STEP(1) DFQ_COL_STEP(2) DFQ_COL_STEP(4) DFQ_COL_STEP(8) DFQ_COL_STEP(16) DFQ_COL_STEP(32)
+#undef DFQ_COL_STEP
             if (lane < tcv && lane_on) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) lds_minmax(sh_col + 2 * tabk[k], cmn[k], cmx[k]);
@@ -691,9 +680,12 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
             __syncthreads();
             if (hasB) {
                 // row statistics of t = fl(w * 1/s_A) for relation B of this same sweep (t is not kept: phase 3 recomputes it)
+                res_stamp(a, k, 8);
                 lay.row_stats(T, G, v, true, false, sh_inv, sh_s, sh_row);
                 __syncthreads();
+                res_stamp(a, k, 9);
                 publish_rows(a, T, RB, sh_row, tag);
+                res_stamp(a, k, 10);
                 arrive(a.cnt_r + (int64_t)T.layer * kResStride);
             }
         }
@@ -765,7 +757,7 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
             }
         }
         res_stamp(a, k, 6);
-        if (a.trace && tid == 0 && k == 0) a.trace[((int64_t)blockIdx.x * kTraceSweeps) * 8 + 7] = ((long long)T.layer << 32) | (unsigned)T.nr << 16 | (unsigned)(T.nc & 0xffff);
+        if (a.trace && tid == 0 && k == 0) a.trace[((int64_t)blockIdx.x * kTraceSweeps) * kTracePoints + 7] = ((long long)T.layer << 32) | (unsigned)T.nr << 16 | (unsigned)(T.nc & 0xffff);
         // ---- commit sweep k ----
         (void)lay.update(T, G, v, hasA, hasB, sh_inv, sh_s, true);
 #pragma unroll
@@ -808,7 +800,7 @@ enum { kLayGeneral = 0, kLayFixed = 1, kLayShort = 2 };
 
 // NS4 float4 slots per thread (tiles of 1024 * NS4 floats); scalar tiles always hold 32 floats per thread
 template <int NS4>
-__global__ __launch_bounds__(kBlock, 3) void le_resident_kernel(ResArgs a, LeParams p) {
+__global__ __launch_bounds__(kBlock, 2) void le_resident_kernel(ResArgs a, LeParams p) {
     DFQ_DYN_SMEM(smem);
     if (a.state->done) return;              // already stopped (uniform over the launch: written before it started)
     const ResTile T = a.tiles[blockIdx.x];
@@ -849,7 +841,6 @@ int ceil_div_i(int a, int b) { return (a + b - 1) / b; }
 
 struct Shape { int tr, tc; };
 
-bool is_pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }
 int pow2_ceil(int x) { int p = 1; while (p < x) p <<= 1; return p; }
 int layout_of(int vec, int row_len, int nc) {
     if (vec == 1 && row_len <= 32 && nc == row_len) return kLayShort;
@@ -916,7 +907,7 @@ void le_resident_destroy(LeResident* r) {
 }
 
 int le_resident_tiles(const LeResident* r) { return r ? r->n_tiles : 0; }
-int le_resident_trace_words(const LeResident* r) { return r ? r->n_tiles * kTraceSweeps * 8 : 0; }
+int le_resident_trace_words(const LeResident* r) { return r ? r->n_tiles * kTraceSweeps * kTracePoints : 0; }
 int64_t le_resident_elements(const LeResident* r) { return r ? r->elements : 0; }
 
 LeResident* le_resident_create(const dfq_layer* layers, int n_layers, const dfq_relation* relations, int n_relations,
@@ -950,8 +941,9 @@ LeResident* le_resident_create(const dfq_layer* layers, int n_layers, const dfq_
             ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)le_resident_kernel<8>, kBlock, kResSmemBytes)
             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)le_resident_kernel<16>, kBlock, kResSmemBytes);
         if (e != hipSuccess || occ < 1) continue;
-        // the hardware may admit one workgroup per CU fewer than the API says (sgpr granularity): stay one below
-        const int cap_tiles = std::max(1, occ - 1) * cus;
+        // (the API's answer is exact here: residency is bounded by the vector registers, far below the point where the
+        // scalar-register granularity makes the hardware admit one workgroup fewer than the API says)
+        const int cap_tiles = std::min(occ, 4) * cus;
         tiles.clear();
         bool ok = true;
         std::string why;

@@ -178,11 +178,11 @@ class LEPlan:
         out = (ctypes.c_int64 * n)()
         _ffi.check(_ffi.lib().dfq_le_resident_trace(self._plan, ctypes.byref(cfg), int(n_sweeps), _ffi.stream_arg(), out, n))
         tiles = []
-        for t in range(n // 48):
-            w = [int(out[t * 48 + i]) for i in range(48)]
+        for t in range(n // 72):
+            w = [int(out[t * 72 + i]) for i in range(72)]
             meta = w[7]
             tiles.append(dict(layer=meta >> 32, rows=(meta >> 16) & 0xffff, cols=meta & 0xffff,
-                              stamps=[w[k * 8:k * 8 + 7] for k in range(6)]))
+                              stamps=[w[k * 12:k * 12 + 7] + w[k * 12 + 8:k * 12 + 12] for k in range(6)]))
         return tiles
 
     def query(self):

@@ -139,7 +139,7 @@ int dfq_le_plan_level_grid(const dfq_le_plan* plan, int32_t level, int32_t* grid
 int32_t dfq_le_plan_resident_tiles(const dfq_le_plan* plan);
 const char* dfq_le_plan_resident_reason(const dfq_le_plan* plan);
 /* Tuning aid for the persistent launch: restart, run `n_sweeps` sweeps with per-workgroup phase stamps (100 MHz wall
- * clock): out[(tile * 6 + sweep) * 8 + point] for the first 6 sweeps; points: 0 sweep start, 1 s_A solved, 2 row
+ * clock): out[(tile * 6 + sweep) * 12 + point] for the first 6 sweeps; points: 0 sweep start, 1 s_A solved, 2 row
  * statistics published, 3 s_B solved, 4 new values + statistics published, 5 ticket taken, 6 decision seen; point 7
  * of sweep 0 = layer << 32 | tile rows << 16 | tile columns.  `capacity` >= dfq_le_resident_trace_words().
  * Modifies the weights like an ordinary run.  Synchronises. */

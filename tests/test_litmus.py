@@ -27,3 +27,13 @@ def test_device_scope_protocol_is_coherent_across_xcds():
     assert stale == 0 and gave_up == 0
     stale_plain, _ = _run(1, 200)
     assert stale_plain > 0, 'plain stores/loads were expected to be incoherent across XCDs within a launch'
+
+
+@pytest.mark.gpu
+def test_register_file_butterfly_steps_match_shfl_xor():
+    """xor_lane_minmax<1..32> (DPP / v_permlane swaps, dfq_common.hpp) == min / max with __shfl_xor, on the hardware."""
+    binary = os.path.join(ROOT, 'tools', 'litmus', 'lane_xor')
+    if not os.path.exists(binary):
+        pytest.skip('tools/litmus/lane_xor not built (python -c "import __graft_entry__ as g; g.build()")')
+    out = subprocess.run([binary], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and '0 mismatches' in out.stdout, out.stdout + out.stderr

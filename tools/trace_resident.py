@@ -26,7 +26,7 @@ print('tiles', plan.resident_tiles, plan.resident_reason)
 plan.resident_trace(sweeps)                      # warm
 tiles = plan.resident_trace(sweeps)
 t0 = min(t['stamps'][0][0] for t in tiles if t['stamps'][0][0])
-names = ['start', 'sA', 'rowpub', 'sB', 'newvals', 'ticket', 'decision']
+names = ['start', 'sA', 'rowpub', 'sB', 'newvals', 'ticket', 'decision', 'p1a', 'p1b', 'p1c', 'x']
 by_layer = {}
 for t in tiles:
     by_layer.setdefault(t['layer'], []).append(t)
@@ -35,7 +35,7 @@ for k in (1, 3, 5):
     for layer in sorted(by_layer):
         ts = by_layer[layer]
         row = []
-        for p in range(7):
+        for p in range(11):
             vals = [t['stamps'][k][p] for t in ts if t['stamps'][k][p]]
             row.append((max(vals) - t0) / 100.0 if vals else float('nan'))
         print('layer {:3d} tiles {:3d} [{:4d}x{:4d}] '.format(layer, len(ts), ts[0]['rows'], ts[0]['cols']) +
