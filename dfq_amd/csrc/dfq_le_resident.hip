@@ -90,7 +90,7 @@ struct ResArgs {
     u64* cnt_r;                      // per paired layer (x kResStride): tiles that published row statistics
     u64* cnt_c;                      //   "   column statistics
     u64* done_cnt;                   // [3] (x kResStride): tiles that finished a sweep, by sweep % 3 (see the partial buffers)
-    u64* seq;                        // (sweeps finished in this launch << 1) | stop
+    u64* seq;                        // [3] (x kResStride): {sweep + 1, diff_tmp bits} published by tile 0, by sweep % 3
     u64* err;
     double* partials;                // [3 parities][tiles]
     LeState* state;
@@ -240,6 +240,8 @@ struct LayGeneral {
             else *dst = v[u][0];
         });
     }
+    static constexpr bool kFusedCols = false;
+    __device__ __forceinline__ double diff_and_cols(const ResTile&, const TileGeo&, const float (&)[NS][VEC], bool, bool, const float*, const float*, uint32_t*) const { return 0.0; }
     // the value an element WILL have: fl(fl(w * 1/s_A) * s_B) with the factors in use (dfq.py:73 then :62, both rounded)
     __device__ __forceinline__ float val(const ResTile& T, const TileGeo& G, float w, bool useA, bool useB, const float* sh_inv,
                                          const float* sh_s, int row, int pos_k) const {
@@ -427,6 +429,46 @@ struct LayFixed {
             });
         }
     }
+    // |dW| and the column statistics of the pending values in ONE pass over the slots (phase 3 of a tile with column duty)
+    static constexpr bool kFusedCols = true;
+    __device__ __forceinline__ double diff_and_cols(const ResTile& T, const TileGeo& G, const float (&v)[NS][VEC], bool useA, bool useB,
+                                                    const float* sh_inv, const float* sh_s, uint32_t* sh_col) const {
+        const int lane = threadIdx.x % kWave;
+        double acc = 0.0;
+        float iv[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+        if (useA && one_group) inv4(T, G, sh_inv, 0, iv);
+        float cmn[4], cmx[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { cmn[k] = INFINITY; cmx[k] = -INFINITY; }
+        slots(T, [&](int u, int row, bool on) {
+            if (useA && !one_group) inv4(T, G, sh_inv, row, iv);
+            const float sr = useB ? sh_s[row] : 1.0f;
+            const int gr = one_group ? 0 : group_row(T, G, row);
+            double part = 0.0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float nv = (v[u][k] * iv[k]) * sr;          // dfq.py:73 then :62, both rounded
+                part += (double)abs_f32(nv - v[u][k]);
+                if (one_group) {
+                    cmn[k] = vmin_raw(cmn[k], on ? nv : INFINITY);
+                    cmx[k] = vmax_raw(cmx[k], on ? nv : -INFINITY);
+                } else if (on) {
+                    lds_minmax(sh_col + 2 * (gr + tabk[k]), nv, nv);
+                }
+            }
+            acc += on ? part : 0.0;
+        });
+        if (one_group) {
+#define DFQ_COL_STEP(M) if ((M) >= tcv) { _Pragma("unroll") for (int k = 0; k < 4; ++k) xor_lane_minmax<M>(cmn[k], cmx[k]); }
+            DFQ_COL_STEP(1) DFQ_COL_STEP(2) DFQ_COL_STEP(4) DFQ_COL_STEP(8) DFQ_COL_STEP(16) DFQ_COL_STEP(32)
+#undef DFQ_COL_STEP
+            if (lane < tcv && lane_on) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) lds_minmax(sh_col + 2 * tabk[k], cmn[k], cmx[k]);
+            }
+        }
+        return acc;
+    }
     __device__ __forceinline__ double update(const ResTile& T, const TileGeo& G, float (&v)[NS][VEC], bool useA, bool useB,
                                              const float* sh_inv, const float* sh_s, bool commit) const {
         double acc = 0.0;
@@ -483,6 +525,8 @@ struct LayShort {
     __device__ __forceinline__ int tab(const ResTile& T, const TileGeo& G, int row, int e) const {
         return (small_div(T.r0 + row, T.go) - G.g_lo) * G.nci + small_div(e, T.khkw);     // complete rows: i0 == 0
     }
+    static constexpr bool kFusedCols = false;
+    __device__ __forceinline__ double diff_and_cols(const ResTile&, const TileGeo&, const float (&)[NS][VEC], bool, bool, const float*, const float*, uint32_t*) const { return 0.0; }
     __device__ __forceinline__ float val(const ResTile& T, const TileGeo& G, float w, bool useA, bool useB, const float* sh_inv,
                                          const float* sh_s, int row, int e) const {
         const float tt = useA ? w * sh_inv[tab(T, G, row, e)] : w;   // dfq.py:73 (rounded), then
@@ -569,9 +613,11 @@ __device__ __forceinline__ double ordered_sum(const double* x, int n) {
     return s;
 }
 
-// dfq.py:105-115 after sweep k: sum of the layers' mean |dW| from the tiles' partial sums (fixed order), state machine.
+// dfq.py:105-108 after sweep k: sum over the layers (graph order) of mean |dW|, from the tiles' partial sums (fixed order).
+// Done by ONE workgroup (tile 0, a tile of the network's first paired layer: small, early, mostly idle) and published; the
+// others pick the number up a whole sweep later (see the commit logic), so this reduction is on nobody's critical path.
 // `mine` = layer_diff[threadIdx.x], loaded once before the loop.
-__device__ __forceinline__ void decide(const ResArgs& a, int k, LoopState& st, const ResLayerDiff& mine, double* sh_d, double* sh_mean) {
+__device__ __forceinline__ double reduce_diff(const ResArgs& a, int k, const ResLayerDiff& mine, double* sh_d, double* sh_mean) {
     const int tid = threadIdx.x;
     const u64* part = (const u64*)a.partials + (int64_t)(k % 3) * a.n_tiles;
     for (int i = tid; i < a.n_tiles; i += kBlock) sh_d[i] = __longlong_as_double((long long)ld_word(part + i));
@@ -583,14 +629,40 @@ __device__ __forceinline__ void decide(const ResArgs& a, int k, LoopState& st, c
         sh_mean[l] = (L.n_tiles > 0) ? (double)(float)(s / L.n_elems) : 0.0;
     }
     __syncthreads();
-    const double diff_tmp = ordered_sum(sh_mean, a.n_layers);                      // graph order, like Python's sum (every thread)
+    const double diff_tmp = ordered_sum(sh_mean, a.n_layers);                      // graph order, like Python's sum
+    __syncthreads();                 // sh_d / sh_mean are reused
+    return diff_tmp;
+}
+
+// dfq.py:110-115: every workgroup advances its own copy of the loop state with the published diff_tmp
+__device__ __forceinline__ void advance_state(const ResArgs& a, LoopState& st, double diff_tmp) {
     if (fabs(st.diff - diff_tmp) > 1e-9) { st.count = 0; st.diff = diff_tmp; }
     else { st.count += 1; }
     st.sweeps += 1;
     st.last_diff_tmp = diff_tmp;
     const bool go_on = (st.diff > a.converge_thres) && (st.count < a.converge_count) && (a.max_sweeps < 0 || st.sweeps < a.max_sweeps);
     st.done = go_on ? 0 : 1;
-    __syncthreads();                 // sh_d / sh_mean are reused by the next sweep
+}
+
+// The verdict of sweep k: tile 0 waits for all partials, reduces and publishes {diff_tmp, k + 1}; everybody else waits for the
+// publication (normally long there).  Returns false when a wait was abandoned.
+__device__ __forceinline__ bool verdict(const ResArgs& a, int k, LoopState& st, const ResLayerDiff& mine, double* sh_dec, int* sh_flag) {
+    u64* slot = a.seq + (k % 3) * kResStride;                 // [0] tag (k + 1), [1] diff_tmp bits
+    double diff_tmp;
+    if (blockIdx.x == 0) {
+        if (!res_wait2(a.done_cnt + (k % 3) * kResStride, (u64)a.n_tiles * (u64)(k / 3 + 1), nullptr, 0, a.err, sh_flag)) return false;
+        diff_tmp = reduce_diff(a, k, mine, sh_dec, sh_dec + kResMaxTiles);
+        if (threadIdx.x == 0) {
+            __hip_atomic_store(slot + 1, (u64)__double_as_longlong(diff_tmp), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_s_waitcnt(0);
+            __hip_atomic_store(slot, (u64)(k + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    } else {
+        if (!res_wait2(slot, (u64)(k + 1), nullptr, 0, a.err, sh_flag)) return false;
+        diff_tmp = __longlong_as_double((long long)ld_word(slot + 1));
+    }
+    advance_state(a, st, diff_tmp);
+    return true;
 }
 
 template <typename Lay>
@@ -720,9 +792,14 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
         __syncthreads();                                          // sh_s complete; sh_row / sh_col free
         if (hasA) for (int i = tid; i < 2 * G.g_n * G.nci; i += kBlock) sh_col[i] = 0u;
         if (chain_start) for (int i = tid; i < 2 * T.nr; i += kBlock) sh_row[i] = 0u;
-        const double acc = lay.update(T, G, v, hasA, hasB, sh_inv, sh_s, false);
         __syncthreads();
-        if (hasA) lay.col_stats(T, G, v, hasA, hasB, sh_inv, sh_s, sh_col);
+        double acc;
+        if (Lay::kFusedCols && hasA) {
+            acc = lay.diff_and_cols(T, G, v, hasA, hasB, sh_inv, sh_s, sh_col);
+        } else {
+            acc = lay.update(T, G, v, hasA, hasB, sh_inv, sh_s, false);
+            if (hasA) lay.col_stats(T, G, v, hasA, hasB, sh_inv, sh_s, sh_col);
+        }
         if (chain_start) lay.row_stats(T, G, v, hasA, hasB, sh_inv, sh_s, sh_row);
         __syncthreads();
         if (hasA) {
@@ -749,10 +826,7 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
             }
             res_stamp(a, k, 5);
             if (k > 0) {
-                if (!res_wait2(a.done_cnt + ((k - 1) % 3) * kResStride, (u64)a.n_tiles * (u64)((k - 1) / 3 + 1), nullptr, 0, a.err, sh_flag)) {
-                    failed = true; break;
-                }
-                decide(a, k - 1, st, my_layer, sh_dec, sh_dec + kResMaxTiles);
+                if (!verdict(a, k - 1, st, my_layer, sh_dec, sh_flag)) { failed = true; break; }
                 if (st.done) break;                               // sweep k-1 was the last one: sweep k is dropped
             }
         }
@@ -768,8 +842,7 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
             o_b1[j] = o_b1[j] * o_s[j];                           // dfq.py:70-71
         }
         if (k + 1 >= a.n_sweeps) {                                // the launch's last sweep: its verdict closes the state
-            if (!res_wait2(a.done_cnt + (k % 3) * kResStride, (u64)a.n_tiles * (u64)(k / 3 + 1), nullptr, 0, a.err, sh_flag)) { failed = true; break; }
-            decide(a, k, st, my_layer, sh_dec, sh_dec + kResMaxTiles);
+            if (!verdict(a, k, st, my_layer, sh_dec, sh_flag)) failed = true;
             break;
         }
     }
@@ -1022,7 +1095,7 @@ LeResident* le_resident_create(const dfq_layer* layers, int n_layers, const dfq_
         ld[l].n_tiles = tile_count[l];
         ld[l].n_elems = (double)((int64_t)layers[l].out_ch * layers[l].in_per_group * layers[l].khkw);
     }
-    r->sync_words = (size_t)(2 * n_pl + 4) * kResStride;
+    r->sync_words = (size_t)(2 * n_pl + 6) * kResStride;
     bool ok = hipMalloc((void**)&r->d_tiles, sizeof(ResTile) * tiles.size()) == hipSuccess &&
               hipMalloc((void**)&r->d_rels, sizeof(ResRel) * n_relations) == hipSuccess &&
               hipMalloc((void**)&r->d_layer_diff, sizeof(ResLayerDiff) * n_layers) == hipSuccess &&
