@@ -42,8 +42,9 @@
 
 namespace dfq {
 
-constexpr int kResTab = 2048;        // LDS table entries of a tile: (groups x input channels) it spans
-constexpr int kResRows = 1024;       // rows of a tile that needs per-row tables (4 owner rows per thread at most)
+constexpr int kResTileFloats = 8192;  // the tile in LDS (32 KB)
+constexpr int kResTab = 1024;        // LDS table entries of a tile: (groups x input channels) it spans
+constexpr int kResRows = 512;        // rows of a tile that needs per-row tables (2 owner rows per thread at most)
 constexpr int kResOwn = kResRows / kBlock;
 constexpr int kResStride = 16;       // one 64-bit counter per 128-byte line
 constexpr long kResSpinLimit = 8000000;
@@ -95,6 +96,7 @@ struct ResArgs {
     double* partials;                // [3 parities][tiles]
     LeState* state;
     int32_t n_tiles, n_layers;       // n_layers: targ layers of the network (layer_diff entries)
+    int32_t reducer;                 // the tile that sums the partials of a sweep and publishes the result
     int32_t n_sweeps;                // sweeps this launch may run
     int32_t max_sweeps;              // cfg: total cap (< 0: none)
     int32_t converge_count;
@@ -165,12 +167,17 @@ __device__ __forceinline__ void opaque(int& x) {
 #endif
 }
 
-// ---- the tile in registers: three layouts -----------------------------------------------------------------
-// A layout says which elements of the [nr x nc] tile a thread's register slots hold and provides the four
-// element loops of a sweep: load / store, row statistics (of w or of w * 1/s_A), column statistics, the update.
-//   LayFixed   float4 slots, a tile row of nc / 4 <= 256 vectors on the next power of two of lanes: a thread keeps ONE column position for
-//              all its slots (slot u = row u * rps + t / tcv), so 1/s_A of its four columns and its column minima /
-//              maxima live in registers and the row reduction is a butterfly over the tcv lanes of a row;
+// ---- the tile: three layouts ------------------------------------------------------------------------------
+// The tile lives in the workgroup's LDS for the whole launch (kResTileFloats floats; element = vector q * VEC + k with
+// q = slot u * 256 + thread t, so consecutive threads touch consecutive 16-byte words: conflict-free), and every element
+// loop is an ordinary rolled loop over the slots.  (The first version kept the tile in REGISTERS, which needs fully
+// unrolled slot loops: 99 000 instructions for the sweep loop, 20 % of them scalar-register spill moves, far more code than
+// the instruction cache holds -- every phase ran at instruction-fetch speed, 5-7 us for 64 multiplies per thread.  LDS reads
+// cost a fraction of that, the code is a few kilobytes, and the registers are free for the reductions.)
+// A layout says which elements a thread's slots hold and provides the element loops of a sweep:
+//   LayFixed   float4 slots, a tile row of nc / 4 <= 256 vectors on the next power of two of lanes: a thread keeps ONE column
+//              position for all its slots (slot u = row u * rps + t / tcv), so 1/s_A of its four columns and its column
+//              minima / maxima live in registers and the row reduction is a butterfly over the tcv lanes of a row;
 //   LayShort   rows of <= 32 floats (depthwise k x k kernels, the stem): one THREAD per row, row statistics without
 //              any cross-lane traffic;
 //   LayGeneral anything else: slot u of thread t holds vector q = u * 256 + t of the tile, statistics through LDS
@@ -192,56 +199,46 @@ __device__ __forceinline__ void lds_minmax(uint32_t* pair, float mn, float mx) {
     atomicMax(pair + 1, enc_ord(mx));
 }
 
-template <int VEC_, int NS_>
+template <int VEC_>
 struct LayGeneral {
-    static constexpr int VEC = VEC_, NS = NS_;
-    int tcv, n_vec;
-    __device__ __forceinline__ void init(const ResTile& T, const TileGeo&) { tcv = T.nc / VEC; n_vec = T.nr * tcv; }
-    __device__ __forceinline__ void coords(const ResTile& T, int u, int& row, int& pos, bool& on) const {
-        int q = u * kBlock + (int)threadIdx.x;
-        opaque(q);
-        on = q < n_vec;
-        const int qq = on ? q : 0;
-        row = small_div(qq, tcv);
-        pos = T.c0 + (qq - row * tcv) * VEC;
+    static constexpr int VEC = VEC_;
+    static constexpr bool kFusedCols = false;
+    int tcv, n_vec, n_slots;
+    __device__ __forceinline__ void init(const ResTile& T, const TileGeo&) {
+        tcv = T.nc / VEC; n_vec = T.nr * tcv; n_slots = (n_vec + kBlock - 1) / kBlock;
     }
     __device__ __forceinline__ int tab(const ResTile& T, const TileGeo& G, int row, int pos_k) const {
         return (small_div(T.r0 + row, T.go) - G.g_lo) * G.nci + small_div(pos_k, T.khkw) - G.i0;
     }
-    template <typename F>     // f(u, row, pos, on) for every slot in use (uniform trip count)
-    __device__ __forceinline__ void slots(const ResTile& T, F f) const {
-#pragma unroll
-        for (int u = 0; u < NS; ++u) {
-            if (u * kBlock >= n_vec) continue;
-            int row, pos; bool on;
-            coords(T, u, row, pos, on);
-            f(u, row, pos, on);
+    template <typename F>     // f(x, row, pos, on) for every slot in use (uniform trip count); x = pointer to the VEC floats
+    __device__ __forceinline__ void slots(const ResTile& T, float* tile, F f) const {
+        for (int u = 0; u < n_slots; ++u) {
+            const int q = u * kBlock + (int)threadIdx.x;
+            const bool on = q < n_vec;
+            const int qq = on ? q : 0;
+            const int row = small_div(qq, tcv);
+            const int pos = T.c0 + (qq - row * tcv) * VEC;
+            f(tile + (int64_t)qq * VEC, row, pos, on);
         }
     }
-    __device__ __forceinline__ void load(const ResTile& T, float (&v)[NS][VEC]) const {
+    __device__ __forceinline__ void load(const ResTile& T, float* tile) const {
         const gfloat* wt = (const gfloat*)T.w;
-#pragma unroll
-        for (int u = 0; u < NS; ++u) {
-#pragma unroll
-            for (int k = 0; k < VEC; ++k) v[u][k] = 0.0f;
-        }
-        slots(T, [&](int u, int row, int pos, bool) {
-            const gfloat* src = wt + ((int64_t)(T.r0 + row) * T.row_len + pos);
-            if (VEC == 4) { const fvec4 t4 = *(const gfvec4*)src; v[u][0] = t4[0]; v[u][1 % VEC] = t4[1]; v[u][2 % VEC] = t4[2]; v[u][3 % VEC] = t4[3]; }
-            else v[u][0] = *src;
-        });
-    }
-    __device__ __forceinline__ void store(const ResTile& T, const float (&v)[NS][VEC]) const {
-        gfloat* wt = (gfloat*)T.w;
-        slots(T, [&](int u, int row, int pos, bool on) {
-            gfloat* dst = wt + ((int64_t)(T.r0 + row) * T.row_len + pos);
+        slots(T, tile, [&](float* x, int row, int pos, bool on) {
             if (!on) return;
-            if (VEC == 4) { fvec4 t4; t4[0] = v[u][0]; t4[1] = v[u][1 % VEC]; t4[2] = v[u][2 % VEC]; t4[3] = v[u][3 % VEC]; *(gfvec4*)dst = t4; }
-            else *dst = v[u][0];
+            const gfloat* src = wt + ((int64_t)(T.r0 + row) * T.row_len + pos);
+            if (VEC == 4) *(fvec4*)x = *(const gfvec4*)src;
+            else x[0] = *src;
         });
     }
-    static constexpr bool kFusedCols = false;
-    __device__ __forceinline__ double diff_and_cols(const ResTile&, const TileGeo&, const float (&)[NS][VEC], bool, bool, const float*, const float*, uint32_t*) const { return 0.0; }
+    __device__ __forceinline__ void store(const ResTile& T, float* tile) const {
+        gfloat* wt = (gfloat*)T.w;
+        slots(T, tile, [&](float* x, int row, int pos, bool on) {
+            if (!on) return;
+            gfloat* dst = wt + ((int64_t)(T.r0 + row) * T.row_len + pos);
+            if (VEC == 4) *(gfvec4*)dst = *(const fvec4*)x;
+            else *dst = x[0];
+        });
+    }
     // the value an element WILL have: fl(fl(w * 1/s_A) * s_B) with the factors in use (dfq.py:73 then :62, both rounded)
     __device__ __forceinline__ float val(const ResTile& T, const TileGeo& G, float w, bool useA, bool useB, const float* sh_inv,
                                          const float* sh_s, int row, int pos_k) const {
@@ -249,49 +246,50 @@ struct LayGeneral {
         return useB ? tt * sh_s[row] : tt;
     }
     // row statistics of the (pending) values into sh_row (zeroed by the caller)
-    __device__ __forceinline__ void row_stats(const ResTile& T, const TileGeo& G, const float (&v)[NS][VEC], bool useA, bool useB,
+    __device__ __forceinline__ void row_stats(const ResTile& T, const TileGeo& G, float* tile, bool useA, bool useB,
                                               const float* sh_inv, const float* sh_s, uint32_t* sh_row) const {
         const int lane = threadIdx.x % kWave;
-        slots(T, [&](int u, int row, int pos, bool on) {
+        slots(T, tile, [&](float* x, int row, int pos, bool on) {
             float mn = INFINITY, mx = -INFINITY;
 #pragma unroll
             for (int k = 0; k < VEC; ++k) {
-                const float x = val(T, G, v[u][k], useA, useB, sh_inv, sh_s, row, pos + k);
-                mn = vmin_raw(mn, on ? x : INFINITY);
-                mx = vmax_raw(mx, on ? x : -INFINITY);
+                const float y = val(T, G, x[k], useA, useB, sh_inv, sh_s, row, pos + k);
+                mn = vmin_raw(mn, on ? y : INFINITY);
+                mx = vmax_raw(mx, on ? y : -INFINITY);
             }
             const int r_first = __shfl(row, 0), r_last = __shfl(row, kWave - 1);
             const int on_all = __shfl((int)on, kWave - 1);             // lanes are ordered: the last one decides
             if (on_all && r_first == r_last) {
-                mn = wave_min(mn); mx = wave_max(mx);
+                wave_minmax(mn, mx);
                 if (lane == 0) lds_minmax(sh_row + 2 * row, mn, mx);
             } else if (on) {
                 lds_minmax(sh_row + 2 * row, mn, mx);
             }
         });
     }
-    __device__ __forceinline__ void col_stats(const ResTile& T, const TileGeo& G, const float (&v)[NS][VEC], bool useA, bool useB,
+    __device__ __forceinline__ void col_stats(const ResTile& T, const TileGeo& G, float* tile, bool useA, bool useB,
                                               const float* sh_inv, const float* sh_s, uint32_t* sh_col) const {
-        slots(T, [&](int u, int row, int pos, bool on) {
+        slots(T, tile, [&](float* x, int row, int pos, bool on) {
             if (!on) return;
 #pragma unroll
             for (int k = 0; k < VEC; ++k) {
-                const float x = val(T, G, v[u][k], useA, useB, sh_inv, sh_s, row, pos + k);
-                lds_minmax(sh_col + 2 * tab(T, G, row, pos + k), x, x);
+                const float y = val(T, G, x[k], useA, useB, sh_inv, sh_s, row, pos + k);
+                lds_minmax(sh_col + 2 * tab(T, G, row, pos + k), y, y);
             }
         });
     }
+    __device__ __forceinline__ double diff_and_cols(const ResTile&, const TileGeo&, float*, bool, bool, const float*, const float*, uint32_t*) const { return 0.0; }
     // the thread's sum of |new - old| in float64; `commit`: w <- new
-    __device__ __forceinline__ double update(const ResTile& T, const TileGeo& G, float (&v)[NS][VEC], bool useA, bool useB,
+    __device__ __forceinline__ double update(const ResTile& T, const TileGeo& G, float* tile, bool useA, bool useB,
                                              const float* sh_inv, const float* sh_s, bool commit) const {
         double acc = 0.0;
-        slots(T, [&](int u, int row, int pos, bool on) {
+        slots(T, tile, [&](float* x, int row, int pos, bool on) {
             double part = 0.0;
 #pragma unroll
             for (int k = 0; k < VEC; ++k) {
-                const float nv = val(T, G, v[u][k], useA, useB, sh_inv, sh_s, row, pos + k);
-                part += (double)abs_f32(nv - v[u][k]);
-                if (commit) v[u][k] = nv;
+                const float nv = val(T, G, x[k], useA, useB, sh_inv, sh_s, row, pos + k);
+                part += (double)abs_f32(nv - x[k]);
+                if (commit && on) x[k] = nv;
             }
             acc += on ? part : 0.0;
         });
@@ -299,9 +297,9 @@ struct LayGeneral {
     }
 };
 
-template <int NS_>
 struct LayFixed {
-    static constexpr int VEC = 4, NS = NS_;
+    static constexpr int VEC = 4;
+    static constexpr bool kFusedCols = true;
     int lg_tcv, tcv, rps, rsub, pos, n_used;
     int tabk[4];                       // table offset of the thread's four columns inside a group row
     bool one_group, lane_on;
@@ -309,8 +307,7 @@ struct LayFixed {
         // a row of nc / 4 vectors occupies the next power of two of lanes (tcv); the lanes past its end hold duplicates of
         // its last vector (harmless for min / max, excluded from the stores and from |dW| through `lane_on`)
         const int real = T.nc / 4;
-        lg_tcv = 32 - __builtin_clz((unsigned)(real - 1) | 0u);
-        if (real == 1) lg_tcv = 0;
+        lg_tcv = (real == 1) ? 0 : 32 - __builtin_clz((unsigned)(real - 1));
         tcv = 1 << lg_tcv;
         rps = kBlock >> lg_tcv;
         rsub = (int)threadIdx.x >> lg_tcv;
@@ -325,130 +322,86 @@ struct LayFixed {
     __device__ __forceinline__ int group_row(const ResTile& T, const TileGeo& G, int row) const {
         return one_group ? 0 : (small_div(T.r0 + row, T.go) - G.g_lo) * G.nci;
     }
-    template <typename F>     // f(u, row, on)
-    __device__ __forceinline__ void slots(const ResTile& T, F f) const {
-#pragma unroll
-        for (int u = 0; u < NS; ++u) {
-            if (u >= n_used) continue;
-            int rs = rsub;
-            opaque(rs);                       // see LayGeneral::coords: keep the per-slot coordinates out of registers
-            int row = u * rps + rs;
+    template <typename F>     // f(x, row, on): x = pointer to the slot's float4 in the LDS tile
+    __device__ __forceinline__ void slots(const ResTile& T, float* tile, F f) const {
+
+        for (int u = 0; u < n_used; ++u) {
+            int row = u * rps + rsub;
             const bool row_ok = row < T.nr;
             const bool on = row_ok && lane_on;           // padded lanes keep their OWN row (they duplicate its last vector)
             row = row_ok ? row : T.nr - 1;
-            f(u, row, on);
+            f(tile + (u * kBlock + (int)threadIdx.x) * 4, row, on);
         }
     }
-    __device__ __forceinline__ void load(const ResTile& T, float (&v)[NS][VEC]) const {
+    __device__ __forceinline__ void load(const ResTile& T, float* tile) const {
         const gfloat* wt = (const gfloat*)T.w;
-#pragma unroll
-        for (int u = 0; u < NS; ++u) { v[u][0] = 0.0f; v[u][1] = 0.0f; v[u][2] = 0.0f; v[u][3] = 0.0f; }
-        slots(T, [&](int u, int row, bool) {
-            const fvec4 t4 = *(const gfvec4*)(wt + ((int64_t)(T.r0 + row) * T.row_len + pos));
-            v[u][0] = t4[0]; v[u][1] = t4[1]; v[u][2] = t4[2]; v[u][3] = t4[3];
-        });
+        slots(T, tile, [&](float* x, int row, bool) { *(fvec4*)x = *(const gfvec4*)(wt + ((int64_t)(T.r0 + row) * T.row_len + pos)); });
     }
-    __device__ __forceinline__ void store(const ResTile& T, const float (&v)[NS][VEC]) const {
+    __device__ __forceinline__ void store(const ResTile& T, float* tile) const {
         gfloat* wt = (gfloat*)T.w;
-        slots(T, [&](int u, int row, bool on) {
-            if (!on) return;
-            fvec4 t4; t4[0] = v[u][0]; t4[1] = v[u][1]; t4[2] = v[u][2]; t4[3] = v[u][3];
-            *(gfvec4*)(wt + ((int64_t)(T.r0 + row) * T.row_len + pos)) = t4;
-        });
+        slots(T, tile, [&](float* x, int row, bool on) { if (on) *(gfvec4*)(wt + ((int64_t)(T.r0 + row) * T.row_len + pos)) = *(const fvec4*)x; });
     }
     __device__ __forceinline__ void inv4(const ResTile& T, const TileGeo& G, const float* sh_inv, int row, float (&iv)[4]) const {
         const int gr = group_row(T, G, row);
 #pragma unroll
         for (int k = 0; k < 4; ++k) iv[k] = sh_inv[gr + tabk[k]];
     }
-    // Row statistics of the (pending) values.  Steps outside, slots inside: the NS butterflies are independent, so
-    // their cross-lane moves overlap (a butterfly per slot, one after the other, is a chain of dependent moves).
-    __device__ __forceinline__ void row_stats(const ResTile& T, const TileGeo& G, const float (&v)[NS][VEC], bool useA, bool useB,
+    __device__ __forceinline__ void row_stats(const ResTile& T, const TileGeo& G, float* tile, bool useA, bool useB,
                                               const float* sh_inv, const float* sh_s, uint32_t* sh_row) const {
         const int lane = threadIdx.x % kWave;
         const int w = tcv < kWave ? tcv : kWave;                    // lanes of a wave that share a row
         float iv[4] = {1.0f, 1.0f, 1.0f, 1.0f};
         if (useA && one_group) inv4(T, G, sh_inv, 0, iv);
-        float mn[NS], mx[NS];
-#pragma unroll
-        for (int u = 0; u < NS; ++u) { mn[u] = INFINITY; mx[u] = -INFINITY; }
-        slots(T, [&](int u, int row, bool) {
+        slots(T, tile, [&](float* x, int row, bool on) {
             if (useA && !one_group) inv4(T, G, sh_inv, row, iv);
             const float sr = useB ? sh_s[row] : 1.0f;
+            const fvec4 xv = *(const fvec4*)x;
+            float mn = INFINITY, mx = -INFINITY;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const float x = (v[u][k] * iv[k]) * sr;              // * 1.0f is exact
-                mn[u] = vmin_raw(mn[u], x); mx[u] = vmax_raw(mx[u], x);
+                const float y = (xv[k] * iv[k]) * sr;                // * 1.0f is exact
+                mn = vmin_raw(mn, y); mx = vmax_raw(mx, y);
             }
-        });
-        // register-file butterflies (xor_lane_minmax, dfq_common.hpp) behind uniform guards
-#define DFQ_ROW_STEP(M) if ((M) < w) { _Pragma("unroll") for (int u = 0; u < NS; ++u) xor_lane_minmax<M>(mn[u], mx[u]); }
-        DFQ_ROW_STEP(1) DFQ_ROW_STEP(2) DFQ_ROW_STEP(4) DFQ_ROW_STEP(8) DFQ_ROW_STEP(16) DFQ_ROW_STEP(32)
-#undef DFQ_ROW_STEP
-        slots(T, [&](int u, int row, bool on) {
-            if ((lane & (w - 1)) == 0 && on) lds_minmax(sh_row + 2 * row, mn[u], mx[u]);   // one writer per row and wave
+            // register-file butterflies (xor_lane_minmax, dfq_common.hpp) behind uniform guards
+            if (1 < w) xor_lane_minmax<1>(mn, mx);
+            if (2 < w) xor_lane_minmax<2>(mn, mx);
+            if (4 < w) xor_lane_minmax<4>(mn, mx);
+            if (8 < w) xor_lane_minmax<8>(mn, mx);
+            if (16 < w) xor_lane_minmax<16>(mn, mx);
+            if (32 < w) xor_lane_minmax<32>(mn, mx);
+            if ((lane & (w - 1)) == 0 && on) lds_minmax(sh_row + 2 * row, mn, mx);   // one writer per row and wave
         });
     }
-    __device__ __forceinline__ void col_stats(const ResTile& T, const TileGeo& G, const float (&v)[NS][VEC], bool useA, bool useB,
-                                              const float* sh_inv, const float* sh_s, uint32_t* sh_col) const {
+    // cross-lane part of the column statistics: lanes of the wave that hold the same columns (ids differing in bits >= lg tcv)
+    __device__ __forceinline__ void cols_finish(float (&cmn)[4], float (&cmx)[4], uint32_t* sh_col) const {
         const int lane = threadIdx.x % kWave;
-        float iv[4] = {1.0f, 1.0f, 1.0f, 1.0f};
-        if (useA && one_group) inv4(T, G, sh_inv, 0, iv);
-        if (one_group) {
-            float cmn[4], cmx[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { cmn[k] = INFINITY; cmx[k] = -INFINITY; }
-            slots(T, [&](int u, int row, bool on) {
-                const float sr = useB ? sh_s[row] : 1.0f;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float x = (v[u][k] * iv[k]) * sr;
-                    cmn[k] = vmin_raw(cmn[k], on ? x : INFINITY);
-                    cmx[k] = vmax_raw(cmx[k], on ? x : -INFINITY);
-                }
-            });
-            // lanes of the wave that hold the same columns: ids that differ in bits >= lg(tcv)
 #define DFQ_COL_STEP(M) if ((M) >= tcv) { _Pragma("unroll") for (int k = 0; k < 4; ++k) xor_lane_minmax<M>(cmn[k], cmx[k]); }
-            DFQ_COL_STEP(1) DFQ_COL_STEP(2) DFQ_COL_STEP(4) DFQ_COL_STEP(8) DFQ_COL_STEP(16) DFQ_COL_STEP(32)
+        DFQ_COL_STEP(1) DFQ_COL_STEP(2) DFQ_COL_STEP(4) DFQ_COL_STEP(8) DFQ_COL_STEP(16) DFQ_COL_STEP(32)
 #undef DFQ_COL_STEP
-            if (lane < tcv && lane_on) {
+        if (lane < tcv && lane_on) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) lds_minmax(sh_col + 2 * tabk[k], cmn[k], cmx[k]);
-            }
-        } else {
-            slots(T, [&](int u, int row, bool on) {
-                if (!on) return;
-                const int gr = group_row(T, G, row);
-                if (useA) inv4(T, G, sh_inv, row, iv);
-                const float sr = useB ? sh_s[row] : 1.0f;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float x = (v[u][k] * iv[k]) * sr;
-                    lds_minmax(sh_col + 2 * (gr + tabk[k]), x, x);
-                }
-            });
+            for (int k = 0; k < 4; ++k) lds_minmax(sh_col + 2 * tabk[k], cmn[k], cmx[k]);
         }
     }
-    // |dW| and the column statistics of the pending values in ONE pass over the slots (phase 3 of a tile with column duty)
-    static constexpr bool kFusedCols = true;
-    __device__ __forceinline__ double diff_and_cols(const ResTile& T, const TileGeo& G, const float (&v)[NS][VEC], bool useA, bool useB,
+    // one pass: |dW| (if want_diff) and the column statistics of the pending values
+    __device__ __forceinline__ double diff_and_cols(const ResTile& T, const TileGeo& G, float* tile, bool useA, bool useB,
                                                     const float* sh_inv, const float* sh_s, uint32_t* sh_col) const {
-        const int lane = threadIdx.x % kWave;
         double acc = 0.0;
         float iv[4] = {1.0f, 1.0f, 1.0f, 1.0f};
         if (useA && one_group) inv4(T, G, sh_inv, 0, iv);
         float cmn[4], cmx[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) { cmn[k] = INFINITY; cmx[k] = -INFINITY; }
-        slots(T, [&](int u, int row, bool on) {
+        slots(T, tile, [&](float* x, int row, bool on) {
             if (useA && !one_group) inv4(T, G, sh_inv, row, iv);
             const float sr = useB ? sh_s[row] : 1.0f;
             const int gr = one_group ? 0 : group_row(T, G, row);
+            const fvec4 xv = *(const fvec4*)x;
             double part = 0.0;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const float nv = (v[u][k] * iv[k]) * sr;          // dfq.py:73 then :62, both rounded
-                part += (double)abs_f32(nv - v[u][k]);
+                const float nv = (xv[k] * iv[k]) * sr;            // dfq.py:73 then :62, both rounded
+                part += (double)abs_f32(nv - xv[k]);
                 if (one_group) {
                     cmn[k] = vmin_raw(cmn[k], on ? nv : INFINITY);
                     cmx[k] = vmax_raw(cmx[k], on ? nv : -INFINITY);
@@ -458,114 +411,104 @@ struct LayFixed {
             }
             acc += on ? part : 0.0;
         });
-        if (one_group) {
-#define DFQ_COL_STEP(M) if ((M) >= tcv) { _Pragma("unroll") for (int k = 0; k < 4; ++k) xor_lane_minmax<M>(cmn[k], cmx[k]); }
-            DFQ_COL_STEP(1) DFQ_COL_STEP(2) DFQ_COL_STEP(4) DFQ_COL_STEP(8) DFQ_COL_STEP(16) DFQ_COL_STEP(32)
-#undef DFQ_COL_STEP
-            if (lane < tcv && lane_on) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) lds_minmax(sh_col + 2 * tabk[k], cmn[k], cmx[k]);
-            }
-        }
+        if (one_group) cols_finish(cmn, cmx, sh_col);
         return acc;
     }
-    __device__ __forceinline__ double update(const ResTile& T, const TileGeo& G, float (&v)[NS][VEC], bool useA, bool useB,
+    __device__ __forceinline__ void col_stats(const ResTile& T, const TileGeo& G, float* tile, bool useA, bool useB,
+                                              const float* sh_inv, const float* sh_s, uint32_t* sh_col) const {
+        (void)diff_and_cols(T, G, tile, useA, useB, sh_inv, sh_s, sh_col);
+    }
+    __device__ __forceinline__ double update(const ResTile& T, const TileGeo& G, float* tile, bool useA, bool useB,
                                              const float* sh_inv, const float* sh_s, bool commit) const {
         double acc = 0.0;
         float iv[4] = {1.0f, 1.0f, 1.0f, 1.0f};
         if (useA && one_group) inv4(T, G, sh_inv, 0, iv);
-        slots(T, [&](int u, int row, bool on) {
+        slots(T, tile, [&](float* x, int row, bool on) {
             if (useA && !one_group) inv4(T, G, sh_inv, row, iv);
             const float s = useB ? sh_s[row] : 1.0f;
+            const fvec4 xv = *(const fvec4*)x;
+            fvec4 nv;
             double part = 0.0;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const float tt = v[u][k] * iv[k];                 // dfq.py:73 (rounded), then
-                const float nv = tt * s;                          // dfq.py:62
-                part += (double)abs_f32(nv - v[u][k]);
-                if (commit) v[u][k] = nv;
+                nv[k] = (xv[k] * iv[k]) * s;                      // dfq.py:73 (rounded), then dfq.py:62
+                if (!commit) part += (double)abs_f32(nv[k] - xv[k]);
             }
+            if (commit) *(fvec4*)x = nv;                          // the thread's own slot (padded lanes hold private duplicates)
             acc += on ? part : 0.0;
         });
         return acc;
     }
 };
 
-// thread t holds rows t, t + 256, ... of the tile (complete rows of L = row_len <= PAD floats), row j in slots
-// j * PAD .. j * PAD + L - 1 (PAD = 16: two rows per thread, PAD = 32: one)
-template <int PAD>
+// thread t holds rows t, t + 256 of the tile (complete rows of L = row_len <= 32 floats); element e of the thread's row j
+// sits at tile[(j * L + e) * 256 + t]
 struct LayShort {
-    static constexpr int VEC = 1, NS = 32, RPT = 32 / PAD;
-    int L;
-    __device__ __forceinline__ void init(const ResTile& T, const TileGeo&) { L = T.row_len; }
-    template <typename F>     // f(u, row, e, on): element e of tile row `row`
-    __device__ __forceinline__ void slots(const ResTile& T, F f) const {
-#pragma unroll
-        for (int j = 0; j < RPT; ++j) {
-            if (j * kBlock >= T.nr) continue;                       // uniform
-            int row = j * kBlock + (int)threadIdx.x;
-            opaque(row);
-            const bool on = row < T.nr;
-            row = on ? row : T.nr - 1;
-#pragma unroll
-            for (int e = 0; e < PAD; ++e)
-                if (e < L) f(j * PAD + e, row, e, on);              // uniform
-        }
-    }
-    __device__ __forceinline__ void load(const ResTile& T, float (&v)[NS][VEC]) const {
-        const gfloat* wt = (const gfloat*)T.w;
-#pragma unroll
-        for (int u = 0; u < NS; ++u) v[u][0] = 0.0f;
-        slots(T, [&](int u, int row, int e, bool) { v[u][0] = wt[(int64_t)(T.r0 + row) * L + e]; });
-    }
-    __device__ __forceinline__ void store(const ResTile& T, const float (&v)[NS][VEC]) const {
-        gfloat* wt = (gfloat*)T.w;
-        slots(T, [&](int u, int row, int e, bool on) { if (on) wt[(int64_t)(T.r0 + row) * L + e] = v[u][0]; });
-    }
+    static constexpr int VEC = 1;
+    static constexpr bool kFusedCols = false;
+    int L, rpt;
+    __device__ __forceinline__ void init(const ResTile& T, const TileGeo&) { L = T.row_len; rpt = (T.nr + kBlock - 1) / kBlock; }
     __device__ __forceinline__ int tab(const ResTile& T, const TileGeo& G, int row, int e) const {
         return (small_div(T.r0 + row, T.go) - G.g_lo) * G.nci + small_div(e, T.khkw);     // complete rows: i0 == 0
     }
-    static constexpr bool kFusedCols = false;
-    __device__ __forceinline__ double diff_and_cols(const ResTile&, const TileGeo&, const float (&)[NS][VEC], bool, bool, const float*, const float*, uint32_t*) const { return 0.0; }
+    template <typename F>     // f(x, row, e, on, last): element e of tile row `row`
+    __device__ __forceinline__ void slots(const ResTile& T, float* tile, F f) const {
+        for (int j = 0; j < rpt; ++j) {
+            int row = j * kBlock + (int)threadIdx.x;
+            const bool on = row < T.nr;
+            row = on ? row : T.nr - 1;
+            float* base = tile + (int64_t)j * L * kBlock + threadIdx.x;
+            for (int e = 0; e < L; ++e) f(base + e * kBlock, row, e, on);
+        }
+    }
+    __device__ __forceinline__ void load(const ResTile& T, float* tile) const {
+        const gfloat* wt = (const gfloat*)T.w;
+        slots(T, tile, [&](float* x, int row, int e, bool) { *x = wt[(int64_t)(T.r0 + row) * L + e]; });
+    }
+    __device__ __forceinline__ void store(const ResTile& T, float* tile) const {
+        gfloat* wt = (gfloat*)T.w;
+        slots(T, tile, [&](float* x, int row, int e, bool on) { if (on) wt[(int64_t)(T.r0 + row) * L + e] = *x; });
+    }
     __device__ __forceinline__ float val(const ResTile& T, const TileGeo& G, float w, bool useA, bool useB, const float* sh_inv,
                                          const float* sh_s, int row, int e) const {
         const float tt = useA ? w * sh_inv[tab(T, G, row, e)] : w;   // dfq.py:73 (rounded), then
         return useB ? tt * sh_s[row] : tt;                           // dfq.py:62
     }
-    __device__ __forceinline__ void row_stats(const ResTile& T, const TileGeo& G, const float (&v)[NS][VEC], bool useA, bool useB,
+    __device__ __forceinline__ void row_stats(const ResTile& T, const TileGeo& G, float* tile, bool useA, bool useB,
                                               const float* sh_inv, const float* sh_s, uint32_t* sh_row) const {
         float mn = INFINITY, mx = -INFINITY;
-        slots(T, [&](int u, int row, int e, bool on) {
-            const float x = val(T, G, v[u][0], useA, useB, sh_inv, sh_s, row, e);
-            mn = (e == 0) ? x : vmin_raw(mn, x);
-            mx = (e == 0) ? x : vmax_raw(mx, x);
+        slots(T, tile, [&](float* x, int row, int e, bool on) {
+            const float y = val(T, G, *x, useA, useB, sh_inv, sh_s, row, e);
+            mn = (e == 0) ? y : vmin_raw(mn, y);
+            mx = (e == 0) ? y : vmax_raw(mx, y);
             if (e == L - 1 && on) { sh_row[2 * row] = ~enc_ord(mn); sh_row[2 * row + 1] = enc_ord(mx); }   // the row's only owner
         });
     }
-    __device__ __forceinline__ void col_stats(const ResTile& T, const TileGeo& G, const float (&v)[NS][VEC], bool useA, bool useB,
+    __device__ __forceinline__ void col_stats(const ResTile& T, const TileGeo& G, float* tile, bool useA, bool useB,
                                               const float* sh_inv, const float* sh_s, uint32_t* sh_col) const {
         if (G.nci == 1) {            // one input channel per group (depthwise): a row's range goes to its group's channel
             float mn = INFINITY, mx = -INFINITY;
-            slots(T, [&](int u, int row, int e, bool on) {
-                const float x = val(T, G, v[u][0], useA, useB, sh_inv, sh_s, row, e);
-                mn = (e == 0) ? x : vmin_raw(mn, x);
-                mx = (e == 0) ? x : vmax_raw(mx, x);
+            slots(T, tile, [&](float* x, int row, int e, bool on) {
+                const float y = val(T, G, *x, useA, useB, sh_inv, sh_s, row, e);
+                mn = (e == 0) ? y : vmin_raw(mn, y);
+                mx = (e == 0) ? y : vmax_raw(mx, y);
                 if (e == L - 1 && on) lds_minmax(sh_col + 2 * tab(T, G, row, 0), mn, mx);
             });
         } else {
-            slots(T, [&](int u, int row, int e, bool on) {
-                const float x = val(T, G, v[u][0], useA, useB, sh_inv, sh_s, row, e);
-                if (on) lds_minmax(sh_col + 2 * tab(T, G, row, e), x, x);
+            slots(T, tile, [&](float* x, int row, int e, bool on) {
+                const float y = val(T, G, *x, useA, useB, sh_inv, sh_s, row, e);
+                if (on) lds_minmax(sh_col + 2 * tab(T, G, row, e), y, y);
             });
         }
     }
-    __device__ __forceinline__ double update(const ResTile& T, const TileGeo& G, float (&v)[NS][VEC], bool useA, bool useB,
+    __device__ __forceinline__ double diff_and_cols(const ResTile&, const TileGeo&, float*, bool, bool, const float*, const float*, uint32_t*) const { return 0.0; }
+    __device__ __forceinline__ double update(const ResTile& T, const TileGeo& G, float* tile, bool useA, bool useB,
                                              const float* sh_inv, const float* sh_s, bool commit) const {
         double acc = 0.0;
-        slots(T, [&](int u, int row, int e, bool on) {
-            const float nv = val(T, G, v[u][0], useA, useB, sh_inv, sh_s, row, e);
-            acc += on ? (double)abs_f32(nv - v[u][0]) : 0.0;
-            if (commit) v[u][0] = nv;
+        slots(T, tile, [&](float* x, int row, int e, bool on) {
+            const float nv = val(T, G, *x, useA, useB, sh_inv, sh_s, row, e);
+            acc += on ? (double)abs_f32(nv - *x) : 0.0;
+            if (commit) *x = nv;
         });
         return acc;
     }
@@ -649,7 +592,7 @@ __device__ __forceinline__ void advance_state(const ResArgs& a, LoopState& st, d
 __device__ __forceinline__ bool verdict(const ResArgs& a, int k, LoopState& st, const ResLayerDiff& mine, double* sh_dec, int* sh_flag) {
     u64* slot = a.seq + (k % 3) * kResStride;                 // [0] tag (k + 1), [1] diff_tmp bits
     double diff_tmp;
-    if (blockIdx.x == 0) {
+    if ((int)blockIdx.x == a.reducer) {
         if (!res_wait2(a.done_cnt + (k % 3) * kResStride, (u64)a.n_tiles * (u64)(k / 3 + 1), nullptr, 0, a.err, sh_flag)) return false;
         diff_tmp = reduce_diff(a, k, mine, sh_dec, sh_dec + kResMaxTiles);
         if (threadIdx.x == 0) {
@@ -667,14 +610,15 @@ __device__ __forceinline__ bool verdict(const ResArgs& a, int k, LoopState& st, 
 
 template <typename Lay>
 __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& p, const ResTile& T, unsigned char* smem) {
-    constexpr int VEC = Lay::VEC, NS = Lay::NS;
-    // LDS: [inv: kResTab f32][s: kResRows f32][row stats: 2 * kResRows u32][col stats: 2 * kResTab u32][flag][decision staging]
-    float* sh_inv = (float*)smem;
+    // LDS: [tile: kResTileFloats f32][inv: kResTab f32][s: kResRows f32][row stats: 2 * kResRows u32][col stats: 2 * kResTab u32][flag]
+    float* v = (float*)smem;                       // the tile
+    float* sh_inv = v + kResTileFloats;
     float* sh_s = sh_inv + kResTab;
     uint32_t* sh_row = (uint32_t*)(sh_s + kResRows);
     uint32_t* sh_col = sh_row + 2 * kResRows;
     int* sh_flag = (int*)(sh_col + 2 * kResTab);
-    double* sh_dec = (double*)(sh_flag + 16);
+    // the reducing tile (the smallest one) stages the partial sums in the unused tail of its tile
+    double* sh_dec = (double*)(v + kResTileFloats / 2);
     const int tid = threadIdx.x;
     const bool hasA = T.relA >= 0, hasB = T.relB >= 0;
     const bool chain_start = hasB && !hasA;
@@ -692,7 +636,6 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
     if (tid < a.n_layers) my_layer = a.layer_diff[tid];
 
     // ---- load the tile (once) ----
-    float v[NS][VEC];
     lay.load(T, v);
     // the [O] vectors of relation B for the rows this thread owns
     float o_cum[kResOwn], o_bnw[kResOwn], o_bnb[kResOwn], o_b1[kResOwn], o_s[kResOwn];
@@ -752,12 +695,9 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
             __syncthreads();
             if (hasB) {
                 // row statistics of t = fl(w * 1/s_A) for relation B of this same sweep (t is not kept: phase 3 recomputes it)
-                res_stamp(a, k, 8);
                 lay.row_stats(T, G, v, true, false, sh_inv, sh_s, sh_row);
                 __syncthreads();
-                res_stamp(a, k, 9);
                 publish_rows(a, T, RB, sh_row, tag);
-                res_stamp(a, k, 10);
                 arrive(a.cnt_r + (int64_t)T.layer * kResStride);
             }
         }
@@ -793,6 +733,7 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
         if (hasA) for (int i = tid; i < 2 * G.g_n * G.nci; i += kBlock) sh_col[i] = 0u;
         if (chain_start) for (int i = tid; i < 2 * T.nr; i += kBlock) sh_row[i] = 0u;
         __syncthreads();
+        res_stamp(a, k, 8);
         double acc;
         if (Lay::kFusedCols && hasA) {
             acc = lay.diff_and_cols(T, G, v, hasA, hasB, sh_inv, sh_s, sh_col);
@@ -801,7 +742,9 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
             if (hasA) lay.col_stats(T, G, v, hasA, hasB, sh_inv, sh_s, sh_col);
         }
         if (chain_start) lay.row_stats(T, G, v, hasA, hasB, sh_inv, sh_s, sh_row);
+        res_stamp(a, k, 9);
         __syncthreads();
+        res_stamp(a, k, 10);
         if (hasA) {
             publish_cols(a, T, G, RA, sh_col, tag + 1u);
             arrive(a.cnt_c + (int64_t)T.layer * kResStride);
@@ -817,7 +760,7 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
         //      known not to have been the last one, so nobody ever waits for a verdict in the middle of the dependency chain
         //      and a workgroup of a short chain may already work on sweep k+1 while a long chain finishes sweep k. ----
         {
-            const double tsum = block_sum(acc, sh_dec);
+            const double tsum = block_sum(acc, (double*)sh_col);     // sh_col is free again (statistics published)
             if (tid == 0) {
                 __hip_atomic_store((u64*)a.partials + (int64_t)(k % 3) * a.n_tiles + blockIdx.x, (u64)__double_as_longlong(tsum),
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -834,6 +777,7 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
         if (a.trace && tid == 0 && k == 0) a.trace[((int64_t)blockIdx.x * kTraceSweeps) * kTracePoints + 7] = ((long long)T.layer << 32) | (unsigned)T.nr << 16 | (unsigned)(T.nc & 0xffff);
         // ---- commit sweep k ----
         (void)lay.update(T, G, v, hasA, hasB, sh_inv, sh_s, true);
+        res_stamp(a, k, 11);
 #pragma unroll
         for (int j = 0; j < kResOwn; ++j) {
             o_cum[j] = o_cum[j] * o_s[j];                         // relation.py:20-24
@@ -860,31 +804,25 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
             if (RB.b1) RB.b1[c] = o_b1[j];
         }
     }
-    if (blockIdx.x == 0 && tid == 0) {
+    if ((int)blockIdx.x == a.reducer && tid == 0) {
         LeState* o = a.state;
         o->diff = st.diff; o->last_diff_tmp = st.last_diff_tmp; o->count = st.count; o->sweeps = st.sweeps; o->done = st.done;
     }
 }
 
-constexpr size_t kResSmemBytes = sizeof(float) * (kResTab + kResRows) + sizeof(uint32_t) * 2 * (kResRows + kResTab) + 64 +
-                                 sizeof(double) * (kResMaxTiles + kResMaxLayers);
+constexpr size_t kResSmemBytes = sizeof(float) * (kResTileFloats + kResTab + kResRows) + sizeof(uint32_t) * 2 * (kResRows + kResTab) + 64;
+static_assert(sizeof(double) * (kResMaxTiles + kResMaxLayers) <= sizeof(float) * kResTileFloats / 2, "partials are staged in half a tile");
 
 enum { kLayGeneral = 0, kLayFixed = 1, kLayShort = 2 };
 
-// NS4 float4 slots per thread (tiles of 1024 * NS4 floats); scalar tiles always hold 32 floats per thread
-template <int NS4>
-__global__ __launch_bounds__(kBlock, 2) void le_resident_kernel(ResArgs a, LeParams p) {
+__global__ __launch_bounds__(kBlock) void le_resident_kernel(ResArgs a, LeParams p) {
     DFQ_DYN_SMEM(smem);
     if (a.state->done) return;              // already stopped (uniform over the launch: written before it started)
     const ResTile T = a.tiles[blockIdx.x];
-#ifndef DFQ_RES_ONLY
-#define DFQ_RES_ONLY 15
-#endif
-    if ((DFQ_RES_ONLY & 1) && T.layout == kLayFixed) res_tile_body<LayFixed<NS4>>(a, p, T, smem);
-    else if ((DFQ_RES_ONLY & 2) && T.layout == kLayShort && T.row_len <= 16) res_tile_body<LayShort<16>>(a, p, T, smem);
-    else if ((DFQ_RES_ONLY & 2) && T.layout == kLayShort) res_tile_body<LayShort<32>>(a, p, T, smem);
-    else if ((DFQ_RES_ONLY & 4) && T.vec == 4) res_tile_body<LayGeneral<4, NS4>>(a, p, T, smem);
-    else if (DFQ_RES_ONLY & 8) res_tile_body<LayGeneral<1, 32>>(a, p, T, smem);
+    if (T.layout == kLayFixed) res_tile_body<LayFixed>(a, p, T, smem);
+    else if (T.layout == kLayShort) res_tile_body<LayShort>(a, p, T, smem);
+    else if (T.vec == 4) res_tile_body<LayGeneral<4>>(a, p, T, smem);
+    else res_tile_body<LayGeneral<1>>(a, p, T, smem);
 }
 
 }  // namespace dfq
@@ -895,7 +833,7 @@ using namespace dfq;
 // host side
 // ---------------------------------------------------------------------------------------------
 struct dfq::LeResident {
-    int n_tiles = 0, n_pl = 0, n_rels = 0, n_layers = 0, ns4 = 8;
+    int n_tiles = 0, n_pl = 0, n_rels = 0, n_layers = 0, reducer = 0;
     ResTile* d_tiles = nullptr;
     ResRel* d_rels = nullptr;
     ResLayerDiff* d_layer_diff = nullptr;
@@ -921,11 +859,12 @@ int layout_of(int vec, int row_len, int nc) {
     return kLayGeneral;
 }
 
-// [tr x tc] tiling of an [R x C] layer; ns4 = float4 slots per thread.  Cost = global statistics atomics per sweep (row
+// [tr x tc] tiling of an [R x C] layer (a tile holds kResTileFloats floats).  Cost = global statistics atomics per sweep (row
 // statistics are merged over the column blocks, column statistics over the row blocks) -- complete rows are favoured
 // for layers with row duty: no merge, and the tile does not wait for its own publication -- with a heavy penalty for
 // tiles that fall back to the general layout (LDS atomics per element).
-Shape pick_shape(int R, int C, int vec, int khkw, int go, int i2g, bool need_row, bool need_col, int ns4) {
+Shape pick_shape(int R, int C, int vec, int khkw, int go, int i2g, bool need_row, bool need_col) {
+    const int ns4 = kResTileFloats / (4 * kBlock);          // float4 slots per thread
     if (vec == 1 && C <= 32) {               // thread-per-row tiles: complete rows, two rows per thread if they are <= 16 floats
         int tr = std::min(R, kBlock * (C <= 16 ? 2 : 1));
         if (need_row) tr = std::min(tr, kResRows);
@@ -942,7 +881,7 @@ Shape pick_shape(int R, int C, int vec, int khkw, int go, int i2g, bool need_row
         const int lay = layout_of(vec, C, tc);
         int tr;
         if (lay == kLayFixed) tr = ns4 * (kBlock / pow2_ceil(tc / 4));      // rows per slot x slots
-        else tr = (vec == 4 ? 1024 * ns4 : 32 * kBlock) / tc;
+        else tr = kResTileFloats / tc;
         tr = std::min(R, tr);
         if (tr < 1) continue;
         if (need_row) tr = std::min(tr, kResRows);
@@ -1005,64 +944,73 @@ LeResident* le_resident_create(const dfq_layer* layers, int n_layers, const dfq_
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return refuse("no device properties");
     cus = prop.multiProcessorCount;
-    int ns4 = 0, capacity = 0;
     std::vector<ResTile> tiles;
     std::vector<int> tile_begin(n_layers, 0), tile_count(n_layers, 0);
-    for (int cand : {8, 16}) {
-        int occ = 0;
-        hipError_t e = (cand == 8)
-            ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)le_resident_kernel<8>, kBlock, kResSmemBytes)
-            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)le_resident_kernel<16>, kBlock, kResSmemBytes);
-        if (e != hipSuccess || occ < 1) continue;
-        // (the API's answer is exact here: residency is bounded by the vector registers, far below the point where the
-        // scalar-register granularity makes the hardware admit one workgroup fewer than the API says)
-        const int cap_tiles = std::min(occ, 4) * cus;
-        tiles.clear();
-        bool ok = true;
-        std::string why;
-        for (int l = 0; l < n_layers && ok; ++l) {
-            tile_begin[l] = (int)tiles.size();
-            tile_count[l] = 0;
-            if (pl_of[l] < 0) continue;
-            const dfq_layer& L = layers[l];
-            const int R = L.out_ch, C = L.in_per_group * L.khkw;
-            const int relA = as_second[l], relB = as_first[l];
-            int go = R, i2g = L.in_per_group;
-            if (relA >= 0) {
-                const int o1 = layers[relations[relA].first].out_ch;
-                const int Gp = (o1 != i2g) ? (o1 / i2g) : 1;
-                go = R / Gp;
-            }
-            const int vec = (C % 4 == 0 && ((uintptr_t)L.weight & 15u) == 0) ? 4 : 1;
-            const Shape sh = pick_shape(R, C, vec, L.khkw, go, i2g, relB >= 0, relA >= 0, cand);
-            if (sh.tr < 1) { ok = false; why = "a layer does not tile"; break; }
-            const int n_rb = ceil_div_i(R, sh.tr), n_cb = ceil_div_i(C, sh.tc);
-            for (int rb = 0; rb < n_rb; ++rb)
-                for (int cb = 0; cb < n_cb; ++cb) {
-                    ResTile T;
-                    memset(&T, 0, sizeof(T));
-                    T.w = L.weight;
-                    T.n_rows = R; T.row_len = C; T.khkw = L.khkw; T.go = go; T.i2g = i2g;
-                    T.r0 = rb * sh.tr; T.nr = std::min(sh.tr, R - T.r0);
-                    T.c0 = cb * sh.tc; T.nc = std::min(sh.tc, C - T.c0);
-                    T.vec = vec;
-                    T.relA = relA; T.relB = relB;
-                    T.layer = pl_of[l];
-                    T.a_layer = relA >= 0 ? pl_of[relations[relA].first] : -1;
-                    T.b_layer = relB >= 0 ? pl_of[relations[relB].second] : -1;
-                    T.owner = cb == 0 ? 1 : 0;
-                    T.layout = layout_of(vec, C, T.nc);
-                    tiles.push_back(T);
-                }
-            tile_count[l] = n_rb * n_cb;
+    int occ = 0;
+    if (kResSmemBytes > 48 * 1024 &&
+        hipFuncSetAttribute((const void*)le_resident_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kResSmemBytes) != hipSuccess)
+        return refuse("dynamic shared memory size refused");
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)le_resident_kernel, kBlock, kResSmemBytes) != hipSuccess || occ < 1)
+        return refuse("occupancy query failed");
+    // every workgroup must be resident: LDS bounds it (tile + tables), the API's answer is exact for that
+    const int cap_tiles = std::min(occ, 3) * cus;
+    for (int l = 0; l < n_layers; ++l) {
+        tile_begin[l] = (int)tiles.size();
+        tile_count[l] = 0;
+        if (pl_of[l] < 0) continue;
+        const dfq_layer& L = layers[l];
+        const int R = L.out_ch, C = L.in_per_group * L.khkw;
+        const int relA = as_second[l], relB = as_first[l];
+        int go = R, i2g = L.in_per_group;
+        if (relA >= 0) {
+            const int o1 = layers[relations[relA].first].out_ch;
+            const int Gp = (o1 != i2g) ? (o1 / i2g) : 1;
+            go = R / Gp;
         }
-        if (!ok) { if (why_not) *why_not = why; continue; }
-        if ((int)tiles.size() <= cap_tiles && (int)tiles.size() <= kResMaxTiles) { ns4 = cand; capacity = cap_tiles; break; }
-        if (why_not) *why_not = "the network does not fit the register files: " + std::to_string(tiles.size()) + " tiles > " +
-                                std::to_string(cap_tiles) + " resident workgroups";
+        const int vec = (C % 4 == 0 && ((uintptr_t)L.weight & 15u) == 0) ? 4 : 1;
+        const Shape sh = pick_shape(R, C, vec, L.khkw, go, i2g, relB >= 0, relA >= 0);
+        if (sh.tr < 1) return refuse("a layer does not tile");
+        const int n_rb = ceil_div_i(R, sh.tr), n_cb = ceil_div_i(C, sh.tc);
+        for (int rb = 0; rb < n_rb; ++rb)
+            for (int cb = 0; cb < n_cb; ++cb) {
+                ResTile T;
+                memset(&T, 0, sizeof(T));
+                T.w = L.weight;
+                T.n_rows = R; T.row_len = C; T.khkw = L.khkw; T.go = go; T.i2g = i2g;
+                T.r0 = rb * sh.tr; T.nr = std::min(sh.tr, R - T.r0);
+                T.c0 = cb * sh.tc; T.nc = std::min(sh.tc, C - T.c0);
+                T.vec = vec;
+                T.relA = relA; T.relB = relB;
+                T.layer = pl_of[l];
+                T.a_layer = relA >= 0 ? pl_of[relations[relA].first] : -1;
+                T.b_layer = relB >= 0 ? pl_of[relations[relB].second] : -1;
+                T.owner = cb == 0 ? 1 : 0;
+                T.layout = layout_of(vec, C, T.nc);
+                tiles.push_back(T);
+            }
+        tile_count[l] = n_rb * n_cb;
     }
-    if (!ns4) return nullptr;
-    (void)capacity;
+    if ((int)tiles.size() > cap_tiles || (int)tiles.size() > kResMaxTiles)
+        return refuse("the network does not fit the chip's LDS: " + std::to_string(tiles.size()) + " tiles > " +
+                      std::to_string(std::min(cap_tiles, kResMaxTiles)) + " resident workgroups");
+    // the reducing tile stages the partial sums in the upper half of its own tile: the smallest tile, and it must fit
+    int reducer = -1;
+    int64_t best_fp = (int64_t)1 << 60;
+    for (size_t i = 0; i < tiles.size(); ++i) {
+        const ResTile& T = tiles[i];
+        int64_t fp;
+        if (T.layout == kLayFixed) {
+            const int rps = kBlock / pow2_ceil(T.nc / 4);
+            fp = (int64_t)ceil_div_i(T.nr, rps) * kBlock * 4;
+        } else if (T.layout == kLayShort) {
+            fp = (int64_t)ceil_div_i(T.nr, kBlock) * T.row_len * kBlock;
+        } else {
+            fp = (int64_t)ceil_div_i(T.nr * (T.nc / T.vec), kBlock) * kBlock * T.vec;
+        }
+        if (fp > kResTileFloats) return refuse("internal: a tile exceeds the LDS tile");
+        if (fp < best_fp) { best_fp = fp; reducer = (int)i; }
+    }
+    if (reducer < 0 || best_fp > kResTileFloats / 2) return refuse("no tile small enough to stage the partial sums");
     for (ResTile& T : tiles) {
         // tiles per layer (by paired-layer index)
         for (int l = 0; l < n_layers; ++l) {
@@ -1072,7 +1020,7 @@ LeResident* le_resident_create(const dfq_layer* layers, int n_layers, const dfq_
         }
     }
     LeResident* r = new LeResident();
-    r->n_tiles = (int)tiles.size(); r->n_pl = n_pl; r->n_rels = n_relations; r->n_layers = n_layers; r->ns4 = ns4; r->elements = total;
+    r->n_tiles = (int)tiles.size(); r->n_pl = n_pl; r->n_rels = n_relations; r->n_layers = n_layers; r->reducer = reducer; r->elements = total;
     // statistics arenas: per relation `channels` = O1 entries of 2 words, two parities; r1 arena then r2 arena
     std::vector<ResRel> hr(n_relations);
     int64_t ch_total = 0;
@@ -1105,10 +1053,6 @@ LeResident* le_resident_create(const dfq_layer* layers, int n_layers, const dfq_
               hipMemcpy(r->d_tiles, tiles.data(), sizeof(ResTile) * tiles.size(), hipMemcpyHostToDevice) == hipSuccess &&
               hipMemcpy(r->d_rels, hr.data(), sizeof(ResRel) * n_relations, hipMemcpyHostToDevice) == hipSuccess &&
               hipMemcpy(r->d_layer_diff, ld.data(), sizeof(ResLayerDiff) * n_layers, hipMemcpyHostToDevice) == hipSuccess;
-    if (ok && kResSmemBytes > 48 * 1024) {
-        ok = hipFuncSetAttribute((const void*)le_resident_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kResSmemBytes) == hipSuccess &&
-             hipFuncSetAttribute((const void*)le_resident_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kResSmemBytes) == hipSuccess;
-    }
     if (!ok) { le_resident_destroy(r); return refuse("device allocation failed"); }
     return r;
 }
@@ -1132,6 +1076,7 @@ int le_resident_enqueue(LeResident* r, const dfq_le_config* cfg, LeState* d_stat
     a.partials = r->d_partials;
     a.state = d_state;
     a.n_tiles = r->n_tiles; a.n_layers = r->n_layers;
+    a.reducer = r->reducer;
     a.n_sweeps = n_sweeps;
     a.max_sweeps = cfg->max_sweeps;
     a.converge_count = cfg->converge_count;
@@ -1139,8 +1084,7 @@ int le_resident_enqueue(LeResident* r, const dfq_le_config* cfg, LeState* d_stat
     a.trace = d_trace;
     const LeParams q = make_params(cfg);
     SpinGuard guard(st);
-    if (r->ns4 == 8) DFQ_LAUNCH_RESIDENT(le_resident_kernel<8>, dim3(r->n_tiles), dim3(kBlock), kResSmemBytes, st, a, q);
-    else DFQ_LAUNCH_RESIDENT(le_resident_kernel<16>, dim3(r->n_tiles), dim3(kBlock), kResSmemBytes, st, a, q);
+    DFQ_LAUNCH_RESIDENT(le_resident_kernel, dim3(r->n_tiles), dim3(kBlock), kResSmemBytes, st, a, q);
     DFQ_CHECK_LAUNCH();
     return DFQ_OK;
 }

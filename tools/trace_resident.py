@@ -26,7 +26,7 @@ print('tiles', plan.resident_tiles, plan.resident_reason)
 plan.resident_trace(sweeps)                      # warm
 tiles = plan.resident_trace(sweeps)
 t0 = min(t['stamps'][0][0] for t in tiles if t['stamps'][0][0])
-names = ['start', 'sA', 'rowpub', 'sB', 'newvals', 'ticket', 'decision', 'p1a', 'p1b', 'p1c', 'x']
+names = ['start', 'sA', 'rowpub', 'sB', 'newvals', 'ticket', 'decision', 'p3a', 'p3b', 'p3c', 'commit']
 by_layer = {}
 for t in tiles:
     by_layer.setdefault(t['layer'], []).append(t)
