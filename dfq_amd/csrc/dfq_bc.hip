@@ -355,7 +355,13 @@ __device__ __forceinline__ void bc_step_body(const BcStepDev& st, int blk, const
                 const float e = sh_E[g * in + min(col, in - 1)];
                 acc += ok ? (double)ev[u] * (double)e : 0.0;
                 if (++c == chunks) {                                   // the rows of this slot group are complete
-                    for (int m = lanes >> 1; m >= 1; m >>= 1) acc += __shfl_xor(acc, m);
+                    // segmented butterfly over the `lanes` lanes of a row, high mask first (register-file moves, dfq_common.hpp)
+                    if (lanes > 32) xor_lane_add<32>(acc);
+                    if (lanes > 16) xor_lane_add<16>(acc);
+                    if (lanes > 8) xor_lane_add<8>(acc);
+                    if (lanes > 4) xor_lane_add<4>(acc);
+                    if (lanes > 2) xor_lane_add<2>(acc);
+                    if (lanes > 1) xor_lane_add<1>(acc);
                     if (ln == 0 && r_local < rw) sh_corr[wave * rw + r_local] = (float)acc;
                     acc = 0.0; c = 0; ++rg;
                 }

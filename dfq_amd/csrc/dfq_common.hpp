@@ -182,9 +182,42 @@ __device__ __forceinline__ float wave_max(float v) {
     wave_minmax(other, v);
     return v;
 }
+// v += lane (id ^ M)'s v, with the same register-file moves (both 32-bit halves travel the same way)
+template <int M>
+__device__ __forceinline__ void xor_lane_add(double& v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+    const uint32_t lo = (uint32_t)bits, hi = (uint32_t)(bits >> 32);
+    uint32_t plo, phi;
+    if (M == 1) { plo = dpp_move<0xB1, 0xf>(lo, lo); phi = dpp_move<0xB1, 0xf>(hi, hi); }
+    else if (M == 2) { plo = dpp_move<0x4E, 0xf>(lo, lo); phi = dpp_move<0x4E, 0xf>(hi, hi); }
+    else if (M == 4) { plo = dpp_move<0x114, 0xA>(dpp_move<0x104, 0x5>(lo, lo), lo); phi = dpp_move<0x114, 0xA>(dpp_move<0x104, 0x5>(hi, hi), hi); }
+    else if (M == 8) { plo = dpp_move<0x118, 0xC>(dpp_move<0x108, 0x3>(lo, lo), lo); phi = dpp_move<0x118, 0xC>(dpp_move<0x108, 0x3>(hi, hi), hi); }
+    else {
+        // after the swap of two copies, [0] and [1] hold the own and the partner's word (which is which depends on the lane's
+        // row, the same way for both halves); the sum is commutative
+        uint32_t a0, a1, b0, b1;
+        if (M == 16) {
+            const auto r = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+            const auto q = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+            a0 = r[0]; a1 = r[1]; b0 = q[0]; b1 = q[1];
+        } else {
+            const auto r = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+            const auto q = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+            a0 = r[0]; a1 = r[1]; b0 = q[0]; b1 = q[1];
+        }
+        const double x = __longlong_as_double((long long)(((unsigned long long)b0 << 32) | a0));
+        const double y = __longlong_as_double((long long)(((unsigned long long)b1 << 32) | a1));
+        v = x + y;
+        return;
+    }
+    v += __longlong_as_double((long long)(((unsigned long long)phi << 32) | plo));
+#else
+    v += __shfl_xor(v, M);
+#endif
+}
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    xor_lane_add<32>(v); xor_lane_add<16>(v); xor_lane_add<8>(v); xor_lane_add<4>(v); xor_lane_add<2>(v); xor_lane_add<1>(v);
     return v;
 }
 

@@ -557,10 +557,14 @@ __device__ __forceinline__ double col_tile(const LeRelDev& R, const LeParams& p,
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) { rmn = vmin_raw(rmn, nv[k]); rmx = vmax_raw(rmx, nv[k]); }
             }
-            for (int m = G >> 1; m >= 1; m >>= 1) {
-                rmn = vmin_raw(rmn, __shfl_xor(rmn, m));
-                rmx = vmax_raw(rmx, __shfl_xor(rmx, m));
-            }
+            // register-file butterfly steps behind uniform guards (xor_lane_minmax, dfq_common.hpp): a run-time mask makes
+            // every step a ds_bpermute through the LDS crossbar that all waves of the CU share
+            if (G > 1) xor_lane_minmax<1>(rmn, rmx);
+            if (G > 2) xor_lane_minmax<2>(rmn, rmx);
+            if (G > 4) xor_lane_minmax<4>(rmn, rmx);
+            if (G > 8) xor_lane_minmax<8>(rmn, rmx);
+            if (G > 16) xor_lane_minmax<16>(rmn, rmx);
+            if (G > 32) xor_lane_minmax<32>(rmn, rmx);
             if (ln == 0 && r_raw < nr) {                   // one writer per row of the tile
                 sh_row[2 * r + 0] = ~enc_ord(rmn);
                 sh_row[2 * r + 1] = enc_ord(rmx);

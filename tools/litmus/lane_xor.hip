@@ -27,13 +27,24 @@ __global__ void lane_xor_kernel(const float* x, const float* y, unsigned* errors
     float wmn = a, wmx = b;
     for (int m = 32; m >= 1; m >>= 1) { wmn = fminf(wmn, __shfl_xor(wmn, m)); wmx = fmaxf(wmx, __shfl_xor(wmx, m)); }
     if (__float_as_uint(mn) != __float_as_uint(wmn) || __float_as_uint(mx) != __float_as_uint(wmx)) atomicAdd(errors, 1u);
+    // float64 sums: every step and the whole butterfly (same order, so bit-identical)
+    const double d = (double)a * 1.25 + (double)b;
+    double s1 = d; xor_lane_add<1>(s1);   if (s1 != d + __shfl_xor(d, 1)) atomicAdd(errors, 1u);
+    double s2 = d; xor_lane_add<2>(s2);   if (s2 != d + __shfl_xor(d, 2)) atomicAdd(errors, 1u);
+    double s4 = d; xor_lane_add<4>(s4);   if (s4 != d + __shfl_xor(d, 4)) atomicAdd(errors, 1u);
+    double s8 = d; xor_lane_add<8>(s8);   if (s8 != d + __shfl_xor(d, 8)) atomicAdd(errors, 1u);
+    double s16 = d; xor_lane_add<16>(s16); if (s16 != d + __shfl_xor(d, 16)) atomicAdd(errors, 1u);
+    double s32 = d; xor_lane_add<32>(s32); if (s32 != d + __shfl_xor(d, 32)) atomicAdd(errors, 1u);
+    double ws = d;
+    for (int m = 32; m >= 1; m >>= 1) ws += __shfl_xor(ws, m);
+    if (wave_sum(d) != ws) atomicAdd(errors, 1u);
 }
 
 int main() {
     const int n = 256 * 64;
     std::vector<float> hx(n), hy(n);
     srand(7);
-    for (int i = 0; i < n; ++i) { hx[i] = (float)rand() / RAND_MAX * 20.f - 10.f; hy[i] = (float)rand() / RAND_MAX * 20.f - 10.f; }
+    for (int i = 0; i < n; ++i) { hx[i] = (float)((double)rand() / (double)RAND_MAX) * 20.f - 10.f; hy[i] = (float)((double)rand() / (double)RAND_MAX) * 20.f - 10.f; }
     float *x, *y; unsigned* e; unsigned he = 0;
     if (hipMalloc(&x, n * 4) != hipSuccess || hipMalloc(&y, n * 4) != hipSuccess || hipMalloc(&e, 4) != hipSuccess) { printf("no device memory\n"); return 2; }
     hipMemcpy(x, hx.data(), n * 4, hipMemcpyHostToDevice);
