@@ -892,9 +892,12 @@ Shape pick_shape(int R, int C, int vec, int khkw, int go, int i2g, bool need_row
             if (((tr + go - 1) / go + 1) * nci > kResTab) continue;
         }
         const int n_rb = ceil_div_i(R, tr), n_cb = ceil_div_i(C, tc);
+        // Measured (tools/trace_resident.py): a row merge over column blocks puts one more hand-off (publish -> counter ->
+        // re-read, 2-3 us) on the tile's own critical cycle, every sweep; the column statistics are consumed a sweep later and
+        // their atomics (a few per thread) vanish in the publication.
         double cost = (double)n_rb * n_cb * 2.0;                        // a tile is a workgroup of a bounded supply
-        if (need_row) cost += (double)R * (n_cb > 1 ? n_cb : 0.25);
-        if (need_col) cost += (double)(C / khkw) * n_rb * 0.5;          // column statistics are consumed a sweep later
+        if (need_row) cost += (double)R * (n_cb > 1 ? 4.0 * n_cb : 0.25);
+        if (need_col) cost += (double)(C / khkw) * n_rb * 0.05;
         const int rem = C % tc;
         if (lay == kLayGeneral) cost += 1e7;
         if (rem && layout_of(vec, C, rem) == kLayGeneral) cost += 1e7 * rem / (double)C;
