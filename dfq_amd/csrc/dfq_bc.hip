@@ -23,7 +23,7 @@
 
 namespace dfq {
 
-constexpr int kQChunk = kBlock * 16;
+constexpr int kMmChunk = kBlock * 64;   // floats per workgroup of the min/max pass: a read-only stream wants long runs (4 trips of 4 loads)
 constexpr int kQePairs = 4;            // (o, i) pairs per thread of the quant-error kernel for khkw == 1 layers
 constexpr int kExpectMax = 8192;       // floats of E[x] kept in LDS (32 KiB)
 constexpr int kExpectSmall = 2048;     // ... by the kernel variant used when every step of a launch fits (8 KiB)
@@ -83,16 +83,29 @@ __global__ __launch_bounds__(kBlock) void bc_minmax_kernel(const BcLayerDev* __r
     __shared__ float sh_mx[kBlock / kWave];
     const int l = bc_find(block_begin, n_layers, blockIdx.x);
     const BcLayerDev L = layers[l];
-    const int64_t b = (int64_t)(blockIdx.x - block_begin[l]) * kQChunk;
-    const int64_t e = (b + kQChunk < L.n) ? b + kQChunk : L.n;
+    const int64_t b = (int64_t)(blockIdx.x - block_begin[l]) * kMmChunk;
+    const int64_t e = (b + kMmChunk < L.n) ? b + kMmChunk : L.n;
     float mn = INFINITY, mx = -INFINITY;
     if ((((uintptr_t)L.w) & 15u) == 0) {
         // 16-byte vectors over the aligned body of the chunk (chunk starts are multiples of 4 floats)
         const int64_t e4 = b + ((e - b) & ~(int64_t)3);
-        for (int64_t i = b + 4 * (int64_t)threadIdx.x; i < e4; i += 4 * kBlock) {
+        // four independent 16-byte loads per trip (a read-only pass with one load in flight per lane leaves most of the
+        // memory pipeline idle), raw v_min / v_max (no canonicalisation prologue)
+        int64_t i = b + 4 * (int64_t)threadIdx.x;
+        for (; i + 12 * kBlock < e4; i += 16 * kBlock) {
+            fvec4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *(const fvec4*)(L.w + i + u * 4 * kBlock);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                mn = vmin_raw(vmin_raw(mn, v[u][0]), vmin_raw(v[u][1], vmin_raw(v[u][2], v[u][3])));
+                mx = vmax_raw(vmax_raw(mx, v[u][0]), vmax_raw(v[u][1], vmax_raw(v[u][2], v[u][3])));
+            }
+        }
+        for (; i < e4; i += 4 * kBlock) {
             const fvec4 v = *(const fvec4*)(L.w + i);
-            mn = fminf(fminf(mn, v[0]), fminf(v[1], fminf(v[2], v[3])));
-            mx = fmaxf(fmaxf(mx, v[0]), fmaxf(v[1], fmaxf(v[2], v[3])));
+            mn = vmin_raw(vmin_raw(mn, v[0]), vmin_raw(v[1], vmin_raw(v[2], v[3])));
+            mx = vmax_raw(vmax_raw(mx, v[0]), vmax_raw(v[1], vmax_raw(v[2], v[3])));
         }
         for (int64_t i = e4 + threadIdx.x; i < e; i += kBlock) {
             const float v = L.w[i];
@@ -531,7 +544,7 @@ int dfq_bc_plan_create(const dfq_layer* layers, int32_t n_layers, const dfq_bc_s
         eps_total += (pairs + 3) & ~(int64_t)3;      // every eps matrix starts 16-byte aligned
         eps_true += pairs;
         corr_total += L.out_ch;
-        mm_blocks += (pairs * L.khkw + kQChunk - 1) / kQChunk;
+        mm_blocks += (pairs * L.khkw + kMmChunk - 1) / kMmChunk;
         qe_blocks += (L.khkw == 1) ? (pairs + kBlock * kQePairs - 1) / (kBlock * kQePairs) : (pairs + kBlock - 1) / kBlock;
     }
     if (mm_blocks > 0x7fffffff || qe_blocks > 0x7fffffff) return fail_arg("dfq_bc_plan_create: too large");
@@ -587,7 +600,7 @@ int dfq_bc_plan_create(const dfq_layer* layers, int32_t n_layers, const dfq_bc_s
         hl[s].w = L.weight; hl[s].eps = p->d_eps + eps_off; hl[s].n = pairs * L.khkw; hl[s].pairs = pairs;
         hl[s].khkw = L.khkw; hl[s].pad = 0;
         mmb[s] = (int32_t)mb; qeb[s] = (int32_t)qb;
-        mb += (hl[s].n + kQChunk - 1) / kQChunk;
+        mb += (hl[s].n + kMmChunk - 1) / kMmChunk;
         qb += (L.khkw == 1) ? (pairs + kBlock * kQePairs - 1) / (kBlock * kQePairs) : (pairs + kBlock - 1) / kBlock;
         BcStepDev& d = p->steps[s];
         d.eps = p->d_eps + eps_off; d.bias = L.bias; d.next_bn_bias = steps[s].next_bn_bias; d.corr = p->d_corr + corr_off;

@@ -7,6 +7,8 @@
 // is deterministic).
 #include <vector>
 
+#include <algorithm>
+
 #include "dfq_common.hpp"
 
 namespace dfq {
@@ -27,6 +29,16 @@ __device__ __forceinline__ void thread_minmax_range(const float* __restrict__ x,
         // four independent 16-byte loads per trip (a read-only pass with one load in flight per lane leaves most of
         // the memory pipeline idle), raw v_min / v_max (no canonicalisation prologue)
         int64_t i = tid;
+        for (; i + 7 * kBlock < n4; i += 8 * kBlock) {              // eight 16-byte loads in flight per lane
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = p4[i + u * kBlock];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                mn = vmin_raw(vmin_raw(mn, v[u].x), vmin_raw(v[u].y, vmin_raw(v[u].z, v[u].w)));
+                mx = vmax_raw(vmax_raw(mx, v[u].x), vmax_raw(v[u].y, vmax_raw(v[u].z, v[u].w)));
+            }
+        }
         for (; i + 3 * kBlock < n4; i += 4 * kBlock) {
             float4 v[4];
 #pragma unroll
@@ -199,17 +211,17 @@ __global__ __launch_bounds__(kBlock) void fake_quant_kernel(const float* x, floa
     }
 }
 
-// per-sample min/max: grid (chunks, samples)
-__global__ __launch_bounds__(kBlock) void sample_minmax_kernel(const float* __restrict__ x, int64_t sample_len,
+// per-sample min/max: grid (spans, samples); a workgroup streams ONE contiguous span of a sample (tens of KB: a read-only
+// pass needs long runs per workgroup -- with 16 KB chunks the launch was 16 000 workgroups of one load trip each and ran at
+// 1.7 TB/s)
+__global__ __launch_bounds__(kBlock) void sample_minmax_kernel(const float* __restrict__ x, int64_t sample_len, int64_t span,
                                                                uint32_t* __restrict__ slots) {
     const int smp = blockIdx.y;
     const float* xs = x + (int64_t)smp * sample_len;
+    const int64_t b = (int64_t)blockIdx.x * span;
+    const int64_t e = (b + span < sample_len) ? b + span : sample_len;
     float mn = INFINITY, mx = -INFINITY;
-    for (int64_t c = blockIdx.x; c * kChunk < sample_len; c += gridDim.x) {
-        const int64_t b = c * kChunk;
-        const int64_t e = (b + kChunk < sample_len) ? b + kChunk : sample_len;
-        thread_minmax_range(xs, b, e, mn, mx);
-    }
+    if (b < e) thread_minmax_range(xs, b, e, mn, mx);
     block_publish_minmax(mn, mx, slots + 2 * smp);
 }
 
@@ -347,12 +359,12 @@ int dfq_sample_minmax_mean(const float* x, int32_t n_samples, int64_t sample_len
     if (n_samples > 65535) return fail_arg("dfq_sample_minmax_mean: n_samples=%d > 65535", n_samples);
     hipStream_t st = as_stream(stream);
     DFQ_HIP_TRY(hipMemsetAsync(scratch, 0, 2 * sizeof(uint32_t) * (size_t)n_samples, st));
-    int gx = grid_for(sample_len, kChunk, 2048);
-    if ((int64_t)gx * n_samples > 16384) {   // keep the launch a few waves per CU deep, not more
-        gx = (int)(16384 / n_samples);
-        if (gx < 1) gx = 1;
-    }
-    hipLaunchKernelGGL(sample_minmax_kernel, dim3(gx, n_samples), dim3(kBlock), 0, st, x, sample_len, scratch);
+    // ~2048 workgroups in all (8 per CU), each a span that is a multiple of 1024 floats (16-byte vectors stay aligned)
+    int64_t gx = std::max<int64_t>(1, 2048 / n_samples);
+    int64_t span = (sample_len + gx - 1) / gx;
+    span = std::max<int64_t>(4096, (span + 1023) / 1024 * 1024);
+    gx = (sample_len + span - 1) / span;
+    hipLaunchKernelGGL(sample_minmax_kernel, dim3((unsigned)gx, n_samples), dim3(kBlock), 0, st, x, sample_len, span, scratch);
     DFQ_CHECK_LAUNCH();
     hipLaunchKernelGGL(sample_mean_kernel, dim3(1), dim3(kBlock), 0, st, (const uint32_t*)scratch, (int)n_samples,
                        out2, running2);

@@ -149,3 +149,45 @@ def test_scale_rows_and_cols_beyond_65535_output_channels():
     _ffi.check(lib.dfq_scale_cols(_ffi.ptr(tw), rows, cols, 1, 1, _ffi.ptr(tsi), 1, _ffi.stream_arg()))
     want = ((w * so.view(-1, 1)) / si.view(1, -1)).numpy()
     assert_bitexact(npy(tw), want, 'weight of a 70001-row linear')
+
+
+def test_plan_cache_of_the_drop_in_entry_points(engine):
+    """Calling cross_layer_equalization / bias_correction again on the same (device-resident) graph reuses the plans
+    (the drop-in API rebuilt ~12 device allocations per call); results are those of fresh plans."""
+    from dfq_amd import dfq, synthetic
+    from dfq_amd.utils import layer_transform as lt
+    from dfq_amd.utils import relation as rel
+    from common import TARG, snapshot
+    dfq.clear_plan_cache()
+    for k in dfq.plan_cache_stats:
+        dfq.plan_cache_stats[k] = 0
+    model, graph, bottoms = synthetic.build('tiny_mobile', seed=0)
+    model.to(engine.device)
+    lt.merge_batchnorm(model, graph, bottoms, TARG)
+    rels = rel.create_relation(graph, bottoms, TARG)
+    dfq.cross_layer_equalization(graph, rels, TARG, max_sweeps=3)
+    dfq.cross_layer_equalization(graph, rels, TARG, max_sweeps=2)          # same graph again: 5 sweeps in all
+    dfq.bias_correction(graph, bottoms, TARG)
+    dfq.bias_correction(graph, bottoms, TARG)
+    cached = (snapshot(graph), [npy(r.get_scale_vec()) for r in rels])
+    if engine.kind == 'gpu':                                                # CPU tensors are never cached (shadow copies)
+        assert dfq.plan_cache_stats == {'le_hits': 1, 'le_misses': 1, 'bc_hits': 1, 'bc_misses': 1}
+    # reference run without any cache hit
+    dfq.clear_plan_cache()
+    model2, graph2, bottoms2 = synthetic.build('tiny_mobile', seed=0)
+    model2.to(engine.device)
+    lt.merge_batchnorm(model2, graph2, bottoms2, TARG)
+    rels2 = rel.create_relation(graph2, bottoms2, TARG)
+    dfq.cross_layer_equalization(graph2, rels2, TARG, max_sweeps=3)
+    dfq.clear_plan_cache()
+    dfq.cross_layer_equalization(graph2, rels2, TARG, max_sweeps=2)
+    dfq.clear_plan_cache()
+    dfq.bias_correction(graph2, bottoms2, TARG)
+    dfq.clear_plan_cache()
+    dfq.bias_correction(graph2, bottoms2, TARG)
+    fresh = (snapshot(graph2), [npy(r.get_scale_vec()) for r in rels2])
+    for k in fresh[0]:
+        assert_bitexact(cached[0][k], fresh[0][k], k)
+    for a, b in zip(cached[1], fresh[1]):
+        assert_bitexact(a, b, 'cumulative S')
+    dfq.clear_plan_cache()
