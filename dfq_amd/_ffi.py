@@ -225,10 +225,12 @@ class Stage:
         hit = self._bound.get(key)
         if hit is not None:
             return hit[1]
-        d = t.detach()
-        if d.device == self.device and d.dtype == torch.float32 and d.is_contiguous():
-            buf = d
+        if t.device == self.device and t.dtype == torch.float32 and t.is_contiguous():
+            # already where the kernels want it: the engine only takes its address (no torch op ever writes through this
+            # handle), so the tensor itself will do -- no detach(), whose cost adds up over the ~250 tensors of a network
+            buf = t
         else:
+            d = t.detach()
             buf = d.to(device=self.device, dtype=torch.float32).contiguous()
             if buf.data_ptr() == d.data_ptr():      # .to() was a no-op view
                 buf = buf.clone()

@@ -4,7 +4,7 @@ import json
 import sys
 for f in sys.argv[1:]:
     try:
-        d = json.load(open(f))
+        d = json.loads(open(f).read().splitlines()[0])
         r = d.get('roofline') or {}
         alone = d['config'].get('one_unit_alone_ms', {})
         print('%s value %.3e ms/step %.3f lat %.3f le %.3f bc %.3f | level us %.2f GB/s %.0f frac %.3f sweep_us %.1f ctl %.1f | %s' % (

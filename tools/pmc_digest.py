@@ -25,7 +25,7 @@ def load(counter, root):
 
 def main():
     root, bench_path, dest = sys.argv[1], sys.argv[2], sys.argv[3]
-    bench = json.load(open(bench_path))
+    bench = json.loads(open(bench_path).read().splitlines()[0])
     levels = bench['roofline']['levels']
     grid_of = {l['workgroups'] * 256: l for l in levels}
     batch = bench['config']['networks_per_step']

@@ -3,17 +3,27 @@
 #   1. the default bench line;
 #   2. the same workload on ONE stream under rocprofv3 --kernel-trace --stats (with two units in flight the
 #      kernels of the two streams overlap and every per-kernel duration is stretched by the sharing, so the
-#      average the roofline is priced on is checked against the one-stream trace);
-#   3. FETCH_SIZE / WRITE_SIZE counter passes (separate --pmc runs) + their digest.
+#      average the roofline is priced on is checked against the one-stream trace); the run also executes the
+#      single-network latency probe (le_resident_kernel), the other configs and the activation-range kernels;
+#   3. FETCH_SIZE / WRITE_SIZE counter passes (separate --pmc runs) at the bench's own batch size + their digest.
+# Every step runs under `timeout`; nothing here reads stdin.
+R=${ROUND:-r02}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 B=${PROFILE_BATCH:-32}
 if [ -z "$SKIP_BENCH" ]; then
-python bench.py > gpurun_out/r01_bench_default.json 2> gpurun_out/r01_bench_default.err
+timeout 400 python bench.py > gpurun_out/${R}_bench_default.json 2> gpurun_out/${R}_bench_default.err < /dev/null
 fi
-rm -rf gpurun_out/prof_r01
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_r01 -o r01 -- python bench.py --streams 1 --steps 6 --warmup 2 --cpu-seconds 0 > gpurun_out/r01_bench_under_rocprof.json 2> gpurun_out/r01_bench_under_rocprof.err
-bash tools/pmc_level.sh --batch $B
-python tools/bench_line.py gpurun_out/r01_bench_default.json gpurun_out/r01_bench_under_rocprof.json
-head -6 gpurun_out/prof_r01/*kernel_stats.csv | cut -c1-200
+rm -rf gpurun_out/prof_$R
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$R -o $R -- python bench.py --streams 1 --steps 6 --warmup 2 --cpu-seconds 0 --sharded "" > gpurun_out/${R}_bench_under_rocprof.json 2> gpurun_out/${R}_bench_under_rocprof.err < /dev/null
+echo "rocprof rc=$?"
+S=$(find gpurun_out/prof_$R -name "*kernel_stats.csv" | head -1)
+T=$(find gpurun_out/prof_$R -name "*kernel_trace.csv" | head -1)
+D=$(find gpurun_out/prof_$R -name "*domain_stats.csv" | head -1)
+[ -n "$S" ] && cp "$S" gpurun_out/${R}_bench_kernel_stats.csv && head -12 "$S" | cut -c1-180
+[ -n "$D" ] && cp "$D" gpurun_out/${R}_bench_domain_stats.csv
+[ -n "$T" ] && timeout 120 python tools/rocprof_digest.py "$T" gpurun_out/${R}_bench_under_rocprof.json > gpurun_out/${R}_level_kernel_by_launch.csv < /dev/null
+[ -n "$T" ] && rm -f "$T"
+PMC_TIMEOUT=200 bash tools/pmc_level.sh --batch $B --others "" --act-shape "" --sharded "" < /dev/null
+timeout 120 python tools/pmc_digest.py gpurun_out gpurun_out/${R}_bench_under_rocprof.json gpurun_out/${R}_pmc_summary.json < /dev/null | tail -12
+timeout 60 python tools/bench_line.py gpurun_out/${R}_bench_default.json gpurun_out/${R}_bench_under_rocprof.json < /dev/null
 tail -3 gpurun_out/pmc_FETCH_SIZE.log | cut -c1-300
-ls gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE 2>&1 | head

@@ -27,7 +27,7 @@ for (flat, wgs), d in sorted(groups.items(), key=lambda kv: (-kv[0][0], kv[0][1]
     if flat:
         batched += d
 if len(sys.argv) > 2:
-    b = json.load(open(sys.argv[2]))
+    b = json.loads(open(sys.argv[2]).read().splitlines()[0])
     want = {l['workgroups'] for l in b['roofline']['levels']}
     sel = [x for (flat, wgs), d in groups.items() if flat and wgs in want for x in d]
     print('# launches of the timed batch (%s workgroups): %d dispatches, average %.2f us; bench.py roofline.us_per_launch = %.2f us'
