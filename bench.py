@@ -256,10 +256,19 @@ def single_network_pass(proto, sweeps, reps=4, warm=2, pinned=False):
     for u in units:                      # a failed in-launch wait would have left the weights short of the result: raise
         u['le'].query()
         u['bc'].status()
-    nbytes = pass_bytes(units[0]['le'], units[0]['bc'], sweeps)
+    le, bc = units[0]['le'], units[0]['bc']
+    streaming_bytes = pass_bytes(le, bc, sweeps)
+    tiles = le.resident_tiles
+    if tiles > 0:
+        # the whole loop is ONE persistent launch: every paired weight is read once and written once, whatever the sweep count
+        nbytes = 8 * le.rw_elements + 8 * bc.weight_elements + 8 * bc.eps_elements
+        engine = 'resident: one persistent launch of {} workgroups keeps the paired layers in LDS for all sweeps'.format(tiles)
+    else:
+        nbytes = streaming_bytes
+        engine = 'streaming: one launch per sweep + convergence kernel ({})'.format(le.resident_reason)
     return dict(pass_ms=wall_ms, equalization_ms=le_ms, bias_correction_ms=bc_ms, algorithmic_bytes=nbytes,
                 achieved_GBps=nbytes / (wall_ms * 1e-3) / 1e9, frac_of_hbm_peak=nbytes / (wall_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                launches_per_sweep=units[0]['le'].levels + 1)
+                streaming_formulation_bytes=streaming_bytes, engine=engine, resident_tiles=tiles)
 
 
 def other_configs(spec, dev):
@@ -279,7 +288,8 @@ def other_configs(spec, dev):
                     'sweeps_pinned': pinned, 'ms': m['pass_ms'], 'weights_per_s': n_w / (m['pass_ms'] * 1e-3),
                     'equalization_ms': m['equalization_ms'], 'bias_correction_ms': m['bias_correction_ms'],
                     'algorithmic_bytes': m['algorithmic_bytes'], 'achieved_GBps': m['achieved_GBps'],
-                    'roofline_frac': m['frac_of_hbm_peak']})
+                    'roofline_frac': m['frac_of_hbm_peak'], 'engine': m['engine'],
+                    'streaming_formulation_GBps': m['streaming_formulation_bytes'] / (m['pass_ms'] * 1e-3) / 1e9})
     return out
 
 
@@ -536,8 +546,13 @@ def main():
             'equalization_gpu_ms': lat['equalization_ms'], 'bias_correction_gpu_ms': lat['bias_correction_ms'],
             'weights_per_s': n_w / (lat['pass_ms'] * 1e-3), 'algorithmic_bytes_per_pass': lat['algorithmic_bytes'],
             'achieved_GBps': lat['achieved_GBps'], 'frac_of_hbm_peak': lat['frac_of_hbm_peak'],
-            'launches_per_sweep': lat['launches_per_sweep'],
-            'bound': 'latency of the dependency chain (a network is {:.1f} MB: cache-resident; see DESIGN.md)'.format(n_w * 4 / 1e6),
+            'engine': lat['engine'],
+            # what the same pass would move sweep by sweep (the streaming kernel's accounting), for comparison with round 1
+            'streaming_formulation_bytes_per_pass': lat['streaming_formulation_bytes'],
+            'streaming_formulation_GBps': lat['streaming_formulation_bytes'] / (lat['pass_ms'] * 1e-3) / 1e9,
+            'bound': 'latency: a chain of per-sweep statistics hand-offs between workgroups (a network is {:.1f} MB; with the '
+                     'weights resident on-chip HBM sees them once, so the HBM fraction says how far from bandwidth-bound a single '
+                     'network is, not how good the kernel is; DESIGN.md 4.2)'.format(n_w * 4 / 1e6),
         }
         out['config']['single_pass_latency_ms'] = lat['pass_ms']
 
