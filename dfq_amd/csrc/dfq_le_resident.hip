@@ -65,6 +65,9 @@ struct ResTile {                     // one workgroup
     int32_t nt_self, nt_a, nt_b;     // tiles of this layer / of those two
     int32_t owner;                   // holds column block 0: updates the [O] vectors of relation B
     int32_t layout;                  // kLayGeneral / kLayFixed / kLayShort
+    int32_t relay;                   // 0: polls the layers' counters itself; 1: one of its layer's first 8 tiles, polls and relays to its
+                                     // XCD's flag; 2: waits for that flag (layers of many tiles: see relay_wait)
+    int32_t pad2;
 };
 
 struct ResRel {
@@ -93,6 +96,7 @@ struct ResArgs {
     u64* done_cnt;                   // [3] (x kResStride): tiles that finished a sweep, by sweep % 3 (see the partial buffers)
     u64* seq;                        // [3] (x kResStride): {sweep + 1, diff_tmp bits} published by tile 0, by sweep % 3
     u64* err;
+    u64* flags;                      // [paired layer][phase 1 / 2][8 XCDs] (x kResStride): relayed "both counters reached round r"
     double* partials;                // [3 parities][tiles]
     LeState* state;
     int32_t n_tiles, n_layers;       // n_layers: targ layers of the network (layer_diff entries)
@@ -587,18 +591,34 @@ __device__ __forceinline__ void advance_state(const ResArgs& a, LoopState& st, d
     st.done = go_on ? 0 : 1;
 }
 
+// A layer cut into many tiles (the classifier: 160) has that many workgroups polling the same two counter words, and every
+// poll is a device-scope access to ONE address: ~12 ns each, serialised -- 160 pollers stretched a hand-off from 2 to 5.6 us.
+// So only the layer's first eight tiles (one per XCD: consecutive workgroups go to consecutive XCDs) poll the counters; each
+// then raises a flag for its XCD, which the other tiles of the layer on that XCD poll.  Which XCD a workgroup really runs on
+// does not matter for correctness (all eight flags are raised), only for how the load spreads.
+__device__ __forceinline__ bool relay_wait(const ResArgs& a, const ResTile& T, int phase, u64 round, const u64* w1, u64 t1,
+                                           const u64* w2, u64 t2, int* sh_flag) {
+    u64* flag = a.flags + ((int64_t)(T.layer * 2 + phase) * 8 + (blockIdx.x & 7)) * kResStride;
+    if (T.relay == 2) return res_wait2(flag, round, nullptr, 0, a.err, sh_flag);
+    if (!res_wait2(w1, t1, w2, t2, a.err, sh_flag)) return false;
+    if (T.relay == 1 && threadIdx.x == 0) __hip_atomic_store(flag, round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return true;
+}
+
 // The verdict of sweep k: tile 0 waits for all partials, reduces and publishes {diff_tmp, k + 1}; everybody else waits for the
 // publication (normally long there).  Returns false when a wait was abandoned.
 __device__ __forceinline__ bool verdict(const ResArgs& a, int k, LoopState& st, const ResLayerDiff& mine, double* sh_dec, int* sh_flag) {
-    u64* slot = a.seq + (k % 3) * kResStride;                 // [0] tag (k + 1), [1] diff_tmp bits
+    // [0] tag (k + 1), [1] diff_tmp bits; one copy per XCD (every tile of the launch polls it)
+    u64* slot = a.seq + ((k % 3) * 8 + (blockIdx.x & 7)) * kResStride;
     double diff_tmp;
     if ((int)blockIdx.x == a.reducer) {
         if (!res_wait2(a.done_cnt + (k % 3) * kResStride, (u64)a.n_tiles * (u64)(k / 3 + 1), nullptr, 0, a.err, sh_flag)) return false;
         diff_tmp = reduce_diff(a, k, mine, sh_dec, sh_dec + kResMaxTiles);
-        if (threadIdx.x == 0) {
-            __hip_atomic_store(slot + 1, (u64)__double_as_longlong(diff_tmp), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x < 8) {
+            u64* copy = a.seq + ((k % 3) * 8 + threadIdx.x) * kResStride;
+            __hip_atomic_store(copy + 1, (u64)__double_as_longlong(diff_tmp), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __builtin_amdgcn_s_waitcnt(0);
-            __hip_atomic_store(slot, (u64)(k + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(copy, (u64)(k + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     } else {
         if (!res_wait2(slot, (u64)(k + 1), nullptr, 0, a.err, sh_flag)) return false;
@@ -679,8 +699,8 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
         res_stamp(a, k, 0);
         // ---- phase 1: s_A per (group, input channel) of the tile ----
         if (hasA) {
-            if (!res_wait2(a.cnt_r + (int64_t)T.a_layer * kResStride, (u64)T.nt_a * round,
-                           a.cnt_c + (int64_t)T.layer * kResStride, (u64)T.nt_self * round, a.err, sh_flag)) { failed = true; break; }
+            if (!relay_wait(a, T, 0, round, a.cnt_r + (int64_t)T.a_layer * kResStride, (u64)T.nt_a * round,
+                            a.cnt_c + (int64_t)T.layer * kResStride, (u64)T.nt_self * round, sh_flag)) { failed = true; break; }
             for (int idx = tid; idx < G.g_n * G.nci; idx += kBlock) {
                 const int gq = small_div(idx, G.nci);
                 const int c = (G.g_lo + gq) * T.i2g + G.i0 + (idx - gq * G.nci);
@@ -709,7 +729,7 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
             // (a chain start still paces itself on its layer's counter: its tiles do not otherwise wait for each other, and a
             // tile two publications ahead of a sibling would make the monotonic counter lie to the layer's consumers)
             const u64* own = (rows_local && !chain_start) ? nullptr : a.cnt_r + (int64_t)T.layer * kResStride;
-            if (!res_wait2(a.cnt_c + (int64_t)T.b_layer * kResStride, (u64)T.nt_b * round, own, (u64)T.nt_self * round, a.err, sh_flag)) {
+            if (!relay_wait(a, T, 1, round, a.cnt_c + (int64_t)T.b_layer * kResStride, (u64)T.nt_b * round, own, (u64)T.nt_self * round, sh_flag)) {
                 failed = true; break;
             }
 #pragma unroll
@@ -1022,6 +1042,12 @@ LeResident* le_resident_create(const dfq_layer* layers, int n_layers, const dfq_
             if (pl_of[l] >= 0 && pl_of[l] == T.b_layer) T.nt_b = tile_count[l];
         }
     }
+    for (size_t i = 0; i < tiles.size(); ++i) {
+        ResTile& T = tiles[i];
+        int first = (int)i;
+        while (first > 0 && tiles[first - 1].layer == T.layer) --first;     // tiles of a layer are contiguous
+        T.relay = (T.nt_self >= 16) ? (((int)i - first) < 8 ? 1 : 2) : 0;
+    }
     LeResident* r = new LeResident();
     r->n_tiles = (int)tiles.size(); r->n_pl = n_pl; r->n_rels = n_relations; r->n_layers = n_layers; r->reducer = reducer; r->elements = total;
     // statistics arenas: per relation `channels` = O1 entries of 2 words, two parities; r1 arena then r2 arena
@@ -1046,7 +1072,7 @@ LeResident* le_resident_create(const dfq_layer* layers, int n_layers, const dfq_
         ld[l].n_tiles = tile_count[l];
         ld[l].n_elems = (double)((int64_t)layers[l].out_ch * layers[l].in_per_group * layers[l].khkw);
     }
-    r->sync_words = (size_t)(2 * n_pl + 6) * kResStride;
+    r->sync_words = (size_t)(2 * n_pl + 3 + 24 + 16 * n_pl) * kResStride;   // counters | done[3] | verdict[3][8] | flags[n_pl][2][8]
     bool ok = hipMalloc((void**)&r->d_tiles, sizeof(ResTile) * tiles.size()) == hipSuccess &&
               hipMalloc((void**)&r->d_rels, sizeof(ResRel) * n_relations) == hipSuccess &&
               hipMalloc((void**)&r->d_layer_diff, sizeof(ResLayerDiff) * n_layers) == hipSuccess &&
@@ -1075,6 +1101,7 @@ int le_resident_enqueue(LeResident* r, const dfq_le_config* cfg, LeState* d_stat
     a.cnt_c = r->d_sync + (size_t)r->n_pl * kResStride;
     a.done_cnt = r->d_sync + (size_t)2 * r->n_pl * kResStride;
     a.seq = a.done_cnt + 3 * kResStride;
+    a.flags = a.seq + 24 * kResStride;
     a.err = d_err;
     a.partials = r->d_partials;
     a.state = d_state;
