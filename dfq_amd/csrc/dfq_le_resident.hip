@@ -599,7 +599,20 @@ __device__ __forceinline__ void advance_state(const ResArgs& a, LoopState& st, d
 __device__ __forceinline__ bool relay_wait(const ResArgs& a, const ResTile& T, int phase, u64 round, const u64* w1, u64 t1,
                                            const u64* w2, u64 t2, int* sh_flag) {
     u64* flag = a.flags + ((int64_t)(T.layer * 2 + phase) * 8 + (blockIdx.x & 7)) * kResStride;
-    if (T.relay == 2) return res_wait2(flag, round, nullptr, 0, a.err, sh_flag);
+    if (T.relay == 2) {
+        // one direct look first: what a phase waits for is often there already (statistics of the previous sweep), and then
+        // the relay would only add its own hop
+        if (threadIdx.x == 0) {
+            const u64 a1 = __hip_atomic_load(w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const u64 a2 = w2 ? __hip_atomic_load(w2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : t2;
+            *sh_flag = (a1 >= t1 && a2 >= t2) ? 1 : 0;
+        }
+        __syncthreads();
+        const bool there = *sh_flag != 0;
+        __syncthreads();
+        if (there) return true;
+        return res_wait2(flag, round, nullptr, 0, a.err, sh_flag);
+    }
     if (!res_wait2(w1, t1, w2, t2, a.err, sh_flag)) return false;
     if (T.relay == 1 && threadIdx.x == 0) __hip_atomic_store(flag, round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return true;
