@@ -175,3 +175,58 @@ def test_signed_equalization_chain_property_oracle_and_emulation(engine):
     rels = rel.create_relation(graph, bottoms, TARG)
     dfq.cross_layer_equalization(graph, rels, TARG, signed=True, max_sweeps=200)
     _signed_chain_property(graph, rels)
+
+
+@pytest.mark.gpu
+def test_sweep_counts_of_many_seeds_against_oracle():
+    """The data-dependent exit of dfq.py:83-115 sits near a 2e-7 threshold and the engine's mean |dW| is a float64 sum rounded
+    once (the reference's float32 mean has an unspecified order): the decision must agree with the oracle not for one
+    lucky seed but for every network of a batch -- eight MobileNetV2 seeds here (41...47 sweeps), through BOTH engines: the
+    batched streaming plan and, network by network, the resident launch."""
+    import torch.nn as nn
+    from dfq_amd import dfq
+    from dfq_amd.utils import layer_transform as lt
+    from dfq_amd.utils import relation as rel
+    dev = torch.device('cuda', 0)
+    seeds = list(range(8))
+    want, nets = [], []
+    for seed in seeds:
+        model, graph, bottoms = synthetic.build('mobilenet_v2', seed=seed)
+        spec = graphspec.from_torch(graph, bottoms, TARG)
+        orc.merge_batchnorm(spec)
+        want.append(orc.cross_layer_equalization(spec, orc.create_relation(spec))[0])
+        model.to(dev)
+        lt.merge_batchnorm(model, graph, bottoms, TARG)
+        nets.append((model, graph, bottoms, rel.create_relation(graph, bottoms, TARG)))
+    assert len(set(want)) > 1, 'the seeds should not all need the same number of sweeps'
+    import copy
+    batch = [copy.deepcopy(n) for n in nets]
+    plan = dfq.build_le_plan_batch([(g, r) for (_, g, _, r) in batch], TARG)
+    assert plan.resident_tiles == 0
+    plan.run()
+    got = [r['sweeps'] for r in plan.query_all()[0]]
+    assert got == want, 'streaming engine: sweeps {} vs oracle {}'.format(got, want)
+    for (model, graph, bottoms, rels), w in zip(nets, want):
+        single = dfq.build_le_plan(graph, rels, TARG)
+        assert single.resident_tiles > 0, single.resident_reason
+        assert single.run()['sweeps'] == w
+
+
+@pytest.mark.gpu
+def test_engine_choice_by_network_size():
+    """MobileNetV2 and DeepLab fit the chip's LDS (one persistent launch); ResNet-18 (11.7 M paired weights) does not and
+    streams -- and says why."""
+    import torch.nn as nn
+    from dfq_amd import dfq
+    from dfq_amd.utils import layer_transform as lt
+    from dfq_amd.utils import relation as rel
+    dev = torch.device('cuda', 0)
+    for net, resident in (('mobilenet_v2', True), ('deeplab_mnv2', True), ('resnet18', False)):
+        model, graph, bottoms = synthetic.build(net, seed=0)
+        model.to(dev)
+        lt.merge_batchnorm(model, graph, bottoms, TARG)
+        plan = dfq.build_le_plan(graph, rel.create_relation(graph, bottoms, TARG), TARG)
+        assert (plan.resident_tiles > 0) == resident, '{}: {} tiles, {}'.format(net, plan.resident_tiles, plan.resident_reason)
+        if not resident:
+            assert 'does not fit' in plan.resident_reason
+        plan.close()
