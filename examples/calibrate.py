@@ -2,12 +2,14 @@
 """The calibration section of the reference's main_cls.py (lines 116-188) with dfq_amd as the engine.
 
     python examples/calibrate.py [--net mobilenet_v2] [--seed 0] [--bits-weight 8] [--bits-bias 16]
-                                 [--absorption] [--table model_int8_tensor.table]
+                                 [--absorption] [--distill-range] [--table model_int8_tensor.table]
 
 A synthetic, randomly initialised network stands in for the pretrained checkpoint (no network access);
 everything after "model built" is what a user of the reference runs, with only the imports changed
 (INTEGRATION.md): trace -> fold BN -> pair layers -> cross-layer equalisation -> [bias absorption] ->
-bias correction -> weight/bias fake-quant -> analytic activation ranges -> ncnn calibration table.
+bias correction -> weight/bias fake-quant -> analytic activation ranges -> ncnn calibration table; with
+--distill-range (main_cls.py:86-113, :183-186): ZeroQ-distilled batches from the UNFOLDED model's BatchNorm statistics, then
+activation ranges recorded by running them through the quantised model instead of the analytic ranges.
 Needs an MI355X (the engine has no CPU path).
 """
 import argparse
@@ -22,7 +24,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 from dfq_amd import ncnn_table, synthetic                                              # noqa: E402
 from dfq_amd.dfq import bias_absorption, bias_correction, cross_layer_equalization    # noqa: E402
-from dfq_amd.improve_dfq import _swap_modules                                          # noqa: E402
+from dfq_amd.improve_dfq import _swap_modules, set_update_stat, update_quant_range      # noqa: E402
+from dfq_amd.utils.quantize import QuantMeasure                                        # noqa: E402
+from dfq_amd.zeroq import getDistilData                                                # noqa: E402
 from dfq_amd.utils.layer_transform import merge_batchnorm, quantize_targ_layer, set_quant_minmax   # noqa: E402
 from dfq_amd.utils.quantize import QConv2d, QLinear                                    # noqa: E402
 from dfq_amd.utils.relation import create_relation                                     # noqa: E402
@@ -59,12 +63,24 @@ def main(argv=None):
     ap.add_argument('--bits-bias', type=int, default=16)
     ap.add_argument('--absorption', action='store_true')
     ap.add_argument('--max-sweeps', type=int, default=None)
+    ap.add_argument('--distill-range', action='store_true', help='activation ranges from ZeroQ-distilled batches (config 5)')
+    ap.add_argument('--dis-batch-size', type=int, default=8)
+    ap.add_argument('--dis-num-batch', type=int, default=2)
+    ap.add_argument('--dis-iterations', type=int, default=20, help='the reference runs up to 1000 per batch')
+    ap.add_argument('--image-size', type=int, default=32)
     ap.add_argument('--table', default=None, help='write the ncnn int8 calibration table here')
     ap.add_argument('--device', default='cuda')
     args = ap.parse_args(argv)
 
     model, graph, bottoms = synthetic.build(args.net, seed=args.seed)      # main_cls.py:91-135 (model + traced graph)
     model.to(args.device)
+    data_distill = None
+    if args.distill_range:                                                                           # :86-100
+        import copy
+        model_original = copy.deepcopy(model)          # BatchNorm still unfolded: its running statistics are the target
+        data_distill = getDistilData(model_original, (args.dis_batch_size, 3, args.image_size, args.image_size),
+                                     num_batch=args.dis_num_batch, bn_merged=False, iterations=args.dis_iterations,
+                                     generator=torch.Generator().manual_seed(args.seed))
     switch_layers(model, graph)
     targ_layer = [QConv2d, QLinear]
 
@@ -77,13 +93,18 @@ def main(argv=None):
     if args.absorption:
         bias_absorption(graph, res, bottoms, 3)                                                     # :156
     bias_correction(graph, bottoms, targ_layer, bits_weight=args.bits_weight)                       # :175
-    graph = quantize_targ_layer(graph, args.bits_weight, args.bits_bias, targ_layer)                # :181
-    set_quant_minmax(graph, bottoms, verbose=False)                                                 # :188
+    if args.distill_range:                                                                           # :183-186
+        set_update_stat(model, [QuantMeasure], True)
+        model = update_quant_range(model, data_distill, graph, bottoms)
+        set_update_stat(model, [QuantMeasure], False)
+    else:
+        graph = quantize_targ_layer(graph, args.bits_weight, args.bits_bias, targ_layer)            # :181
+        set_quant_minmax(graph, bottoms, verbose=False)                                             # :188
     if args.device == 'cuda':
         torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     n_w = sum(graph[k].weight.numel() for k in graph if type(graph[k]) in targ_layer)
-    levels = max(len(torch.unique(graph[k].weight)) for k in graph if type(graph[k]) in targ_layer)
+    levels = max(len(torch.unique(graph[k].weight)) for k in graph if type(graph[k]) in targ_layer) if not args.distill_range else -1
     print('{}: {} layers, {} weights, {} relations; {} equalisation sweeps; <= {} distinct weight levels per layer; '
           '{:.1f} ms wall for the whole calibration section'.format(args.net, sum(type(graph[k]) in targ_layer for k in graph),
                                                                      n_w, len(res), sweeps, levels, dt * 1e3))
