@@ -519,17 +519,17 @@ struct LayShort {
 };
 
 // sh_row -> global row statistics of relation B (rows r0 .. r0 + nr), tagged
-__device__ __forceinline__ void publish_rows(const ResArgs& a, const ResTile& T, const ResRel& RB, const uint32_t* sh_row, uint32_t tag) {
-    u64* dst = a.stats + RB.r1_off + (int64_t)(tag & 1u) * a.parity_stride;
+__device__ __forceinline__ void publish_rows(const ResArgs& a, const ResTile& T, int64_t r1_off, const uint32_t* sh_row, uint32_t tag) {
+    u64* dst = a.stats + r1_off + (int64_t)(tag & 1u) * a.parity_stride;
     for (int i = threadIdx.x; i < T.nr; i += kBlock) {
         publish_max(dst + 2 * (int64_t)(T.r0 + i), tag, sh_row[2 * i]);
         publish_max(dst + 2 * (int64_t)(T.r0 + i) + 1, tag, sh_row[2 * i + 1]);
     }
 }
 // sh_col -> global column statistics of relation A, tagged
-__device__ __forceinline__ void publish_cols(const ResArgs& a, const ResTile& T, const TileGeo& G, const ResRel& RA,
+__device__ __forceinline__ void publish_cols(const ResArgs& a, const ResTile& T, const TileGeo& G, int64_t r2_off,
                                              const uint32_t* sh_col, uint32_t tag) {
-    u64* dst = a.stats + RA.r2_off + (int64_t)(tag & 1u) * a.parity_stride;
+    u64* dst = a.stats + r2_off + (int64_t)(tag & 1u) * a.parity_stride;
     for (int idx = threadIdx.x; idx < G.g_n * G.nci; idx += kBlock) {
         const int gq = small_div(idx, G.nci);
         const int c = (G.g_lo + gq) * T.i2g + G.i0 + (idx - gq * G.nci);
@@ -656,8 +656,10 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
     const bool hasA = T.relA >= 0, hasB = T.relB >= 0;
     const bool chain_start = hasB && !hasA;
     const bool rows_local = T.nc == T.row_len;       // the tile holds complete rows: its row statistics are final
-    const ResRel RA = a.rels[hasA ? T.relA : 0];
-    const ResRel RB = a.rels[hasB ? T.relB : 0];
+    // only the statistics offsets of the two relations stay live through the loop (scalar registers are the scarce resource
+    // of this kernel); the [O] vector pointers are re-read where the vectors are loaded and stored
+    const int64_t ra_r1 = a.rels[hasA ? T.relA : 0].r1_off, ra_r2 = a.rels[hasA ? T.relA : 0].r2_off;
+    const int64_t rb_r1 = a.rels[hasB ? T.relB : 0].r1_off, rb_r2 = a.rels[hasB ? T.relB : 0].r2_off;
     const TileGeo G = tile_geo(T);
     Lay lay;
     lay.init(T, G);
@@ -678,6 +680,7 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
         const int i = tid + j * kBlock;
         o_cum[j] = 1.0f; o_bnw[j] = 0.0f; o_bnb[j] = 0.0f; o_b1[j] = 0.0f; o_s[j] = 1.0f;
         if (owner && i < T.nr) {
+            const ResRel RB = a.rels[T.relB];
             const int c = T.r0 + i;
             o_cum[j] = RB.s_cum[c];
             if (RB.bnw) o_bnw[j] = RB.bnw[c];
@@ -692,7 +695,7 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
         __syncthreads();
         lay.col_stats(T, G, v, false, false, sh_inv, sh_s, sh_col);
         __syncthreads();
-        publish_cols(a, T, G, RA, sh_col, 1u);
+        publish_cols(a, T, G, ra_r2, sh_col, 1u);
         arrive(a.cnt_c + (int64_t)T.layer * kResStride);
     }
     if (chain_start) {
@@ -700,7 +703,7 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
         __syncthreads();
         lay.row_stats(T, G, v, false, false, sh_inv, sh_s, sh_row);
         __syncthreads();
-        publish_rows(a, T, RB, sh_row, 1u);
+        publish_rows(a, T, rb_r1, sh_row, 1u);
         arrive(a.cnt_r + (int64_t)T.layer * kResStride);
     }
 
@@ -718,8 +721,8 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
                 const int gq = small_div(idx, G.nci);
                 const int c = (G.g_lo + gq) * T.i2g + G.i0 + (idx - gq * G.nci);
                 float mn1, mx1, mn2, mx2, s, inv;
-                read_range(a.stats, RA.r1_off, a.parity_stride, tag, c, mn1, mx1);
-                read_range(a.stats, RA.r2_off, a.parity_stride, tag, c, mn2, mx2);
+                read_range(a.stats, ra_r1, a.parity_stride, tag, c, mn1, mx1);
+                read_range(a.stats, ra_r2, a.parity_stride, tag, c, mn2, mx2);
                 le_solve(range_of(mn1, mx1, p.signed_range), range_of(mn2, mx2, p.signed_range), p, s, inv);
                 sh_inv[idx] = inv;
             }
@@ -730,7 +733,7 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
                 // row statistics of t = fl(w * 1/s_A) for relation B of this same sweep (t is not kept: phase 3 recomputes it)
                 lay.row_stats(T, G, v, true, false, sh_inv, sh_s, sh_row);
                 __syncthreads();
-                publish_rows(a, T, RB, sh_row, tag);
+                publish_rows(a, T, rb_r1, sh_row, tag);
                 arrive(a.cnt_r + (int64_t)T.layer * kResStride);
             }
         }
@@ -752,8 +755,8 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
                     const int c = T.r0 + i;
                     float mn1, mx1, mn2, mx2, s, inv;
                     if (rows_local) { mn1 = slot_min(sh_row[2 * i]); mx1 = slot_max(sh_row[2 * i + 1]); }
-                    else read_range(a.stats, RB.r1_off, a.parity_stride, tag, c, mn1, mx1);
-                    read_range(a.stats, RB.r2_off, a.parity_stride, tag, c, mn2, mx2);
+                    else read_range(a.stats, rb_r1, a.parity_stride, tag, c, mn1, mx1);
+                    read_range(a.stats, rb_r2, a.parity_stride, tag, c, mn2, mx2);
                     le_solve(range_of(mn1, mx1, p.signed_range), range_of(mn2, mx2, p.signed_range), p, s, inv);
                     sh_s[i] = s;
                     o_s[j] = s;                                   // applied to the [O] vectors when the sweep is committed
@@ -779,11 +782,11 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
         __syncthreads();
         res_stamp(a, k, 10);
         if (hasA) {
-            publish_cols(a, T, G, RA, sh_col, tag + 1u);
+            publish_cols(a, T, G, ra_r2, sh_col, tag + 1u);
             arrive(a.cnt_c + (int64_t)T.layer * kResStride);
         }
         if (chain_start) {
-            publish_rows(a, T, RB, sh_row, tag + 1u);
+            publish_rows(a, T, rb_r1, sh_row, tag + 1u);
             arrive(a.cnt_r + (int64_t)T.layer * kResStride);
         }
         res_stamp(a, k, 4);
@@ -830,6 +833,7 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
     for (int j = 0; j < kResOwn; ++j) {
         const int i = tid + j * kBlock;
         if (owner && i < T.nr) {
+            const ResRel RB = a.rels[T.relB];
             const int c = T.r0 + i;
             RB.s_cum[c] = o_cum[j];
             if (RB.bnw) RB.bnw[c] = o_bnw[j];

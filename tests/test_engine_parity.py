@@ -158,7 +158,12 @@ def _kat_names():
 
 
 @pytest.mark.parametrize('name', _kat_names())
-def test_layer_equalization_pairs(engine, name):
+@pytest.mark.parametrize('le_engine', ['resident', 'streaming'])
+def test_layer_equalization_pairs(engine, monkeypatch, name, le_engine):
+    if le_engine == 'streaming':
+        monkeypatch.setenv('DFQ_LE_RESIDENT', '0')
+    else:
+        monkeypatch.delenv('DFQ_LE_RESIDENT', raising=False)
     g = np.load(os.path.join(GOLD, 'kat_le_pairs.npz'))
     signed, eps, use_bn = g['{}.cfg'.format(name)]
     use_bn = bool(use_bn)
@@ -188,13 +193,21 @@ _SHAPES = [
     ((33, 7, 3, 3), (20, 33, 3, 3)),        # odd sizes: scalar tiles
     ((48, 6, 3, 3), (96, 12, 3, 3)),        # grouped second layer (groups = 4)
     ((130, 516), (9, 130)),                 # linear -> linear
+    ((128, 12, 1, 1), (200, 128, 1, 1)),    # 128 paired channels, pointwise second layer: the bootstrap's wide-column path
+    ((320, 16, 1, 1), (37, 320, 1, 1)),     # ... with a partial last channel block (320 = 5 x 64)
 ]
 
 
 @pytest.mark.parametrize('s1,s2', _SHAPES)
 @pytest.mark.parametrize('signed', [False, True])
-def test_layer_equalization_shapes(engine, s1, s2, signed):
-    """One sweep of one pair over the tile kinds of the kernel, bit-exact against the oracle."""
+@pytest.mark.parametrize('le_engine', ['resident', 'streaming'])
+def test_layer_equalization_shapes(engine, monkeypatch, s1, s2, signed, le_engine):
+    """One sweep of one pair over the tile kinds of both equalisation engines (a single pair would always take the
+    resident launch: DFQ_LE_RESIDENT=0 forces the streaming kernel), bit-exact against the oracle."""
+    if le_engine == 'streaming':
+        monkeypatch.setenv('DFQ_LE_RESIDENT', '0')
+    else:
+        monkeypatch.delenv('DFQ_LE_RESIDENT', raising=False)
     rng = np.random.default_rng(abs(hash((s1, s2))) % (2 ** 31))
     w1 = rng.standard_normal(s1).astype(F32)
     w2 = (rng.standard_normal(s2) * 0.2).astype(F32)
@@ -209,8 +222,13 @@ def test_layer_equalization_shapes(engine, s1, s2, signed):
         assert_bitexact(npy(got), want, what)
 
 
-def test_layer_equalization_large_rows(engine):
+@pytest.mark.parametrize('le_engine', ['resident', 'streaming'])
+def test_layer_equalization_large_rows(engine, monkeypatch, le_engine):
     """Rows longer than a workgroup, tiles of one channel, 3x3 second layer (ResNet-like)."""
+    if le_engine == 'streaming':
+        monkeypatch.setenv('DFQ_LE_RESIDENT', '0')
+    else:
+        monkeypatch.delenv('DFQ_LE_RESIDENT', raising=False)
     rng = np.random.default_rng(21)
     w1 = rng.standard_normal((70, 33, 3, 3)).astype(F32)
     w2 = (rng.standard_normal((90, 70, 3, 3)) * 0.1).astype(F32)
