@@ -773,15 +773,23 @@ __global__ __launch_bounds__(kBlock) void le_bootstrap_kernel(const LeRelDev* __
         int q = tid / R.row_len, rem = tid - q * R.row_len, cq = q;
         const int dq = kBlock / R.row_len, dr = kBlock - dq * R.row_len;
         float mn = INFINITY, mx = -INFINITY;
-        for (int64_t e = tid; e < total; e += kBlock) {
-            if (q != cq) {
-                atomicMax(&sh_mn1[cq], ~enc_ord(mn)); atomicMax(&sh_mx1[cq], enc_ord(mx));
-                mn = INFINITY; mx = -INFINITY; cq = q;
+        // eight loads in flight per lane (one at a time, a 64-row block of a wide layer is ~40 dependent round trips)
+        for (int64_t e0 = tid; e0 < total; e0 += 8 * kBlock) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = rows[min(e0 + (int64_t)u * kBlock, total - 1)];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (e0 + (int64_t)u * kBlock < total) {
+                    if (q != cq) {
+                        atomicMax(&sh_mn1[cq], ~enc_ord(mn)); atomicMax(&sh_mx1[cq], enc_ord(mx));
+                        mn = INFINITY; mx = -INFINITY; cq = q;
+                    }
+                    mn = fminf(mn, v[u]); mx = fmaxf(mx, v[u]);
+                    q += dq; rem += dr;
+                    if (rem >= R.row_len) { rem -= R.row_len; ++q; }
+                }
             }
-            const float v = rows[e];
-            mn = fminf(mn, v); mx = fmaxf(mx, v);
-            q += dq; rem += dr;
-            if (rem >= R.row_len) { rem -= R.row_len; ++q; }
         }
         if (mn <= mx) { atomicMax(&sh_mn1[cq], ~enc_ord(mn)); atomicMax(&sh_mx1[cq], enc_ord(mx)); }
     }
