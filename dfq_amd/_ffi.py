@@ -92,6 +92,8 @@ SIGNATURES = {
     'dfq_le_profile': (c_int32, [c_void_p, POINTER(DfqLeConfig), c_int32, c_void_p, POINTER(c_double), POINTER(c_double),
                                  POINTER(c_int32), POINTER(c_double)]),
     'dfq_le_trace': (c_int32, [c_void_p, POINTER(DfqLeConfig), c_int32, c_int32, c_void_p, POINTER(c_int64)]),
+    'dfq_le_plan_sweep_workgroups': (c_int32, [c_void_p]),
+    'dfq_le_plan_block_info': (c_int32, [c_void_p, c_int32, c_int32, POINTER(c_int64)]),
     'dfq_le_trace_blocks': (c_int32, [c_void_p, POINTER(DfqLeConfig), c_int32, c_void_p, POINTER(c_int64), c_int64]),
     'dfq_tensor_minmax': (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     'dfq_fake_quant': (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_double, c_double,

@@ -64,7 +64,7 @@ inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s);
 // or shares it with kernels that finish on their own, NOT for two such kernels from different streams, each
 // holding the slots the other's producers need.  So the library serialises them: SpinGuard's
 // constructor makes `stream` wait for the last waiting-kernel batch enqueued on a DIFFERENT stream, its destructor
-// records the end of this batch.  One event record per enqueue call, nothing per launch; kernels without in-launch
+// records the end of this batch; host threads enqueue such batches one at a time (a process-wide mutex held between the two).  One event record per enqueue call, nothing per launch; kernels without in-launch
 // waits (per-level launches, bootstrap, quantisers, ...) are not affected.  Process-wide, per device.
 class SpinGuard {
 public:

@@ -37,22 +37,21 @@ hipStream_t g_spin_stream = nullptr;
 bool g_spin_pending = false;
 }  // namespace
 
+// The mutex is held from the constructor to the destructor: a second host thread that enqueued its batch between
+// this thread's wait and this thread's record would wait for the batch BEFORE this one and overlap with this one.
 SpinGuard::SpinGuard(hipStream_t stream) : stream_(stream) {
-    std::lock_guard<std::mutex> lock(g_spin_mu);
+    g_spin_mu.lock();
     if (g_spin_pending && g_spin_stream != stream_ && g_spin_event)
         (void)hipStreamWaitEvent(stream_, g_spin_event, 0);
 }
 
 SpinGuard::~SpinGuard() {
-    std::lock_guard<std::mutex> lock(g_spin_mu);
-    if (!g_spin_event && hipEventCreateWithFlags(&g_spin_event, hipEventDisableTiming) != hipSuccess) {
-        g_spin_event = nullptr;
-        return;
-    }
-    if (hipEventRecord(g_spin_event, stream_) == hipSuccess) {
+    if (!g_spin_event && hipEventCreateWithFlags(&g_spin_event, hipEventDisableTiming) != hipSuccess) g_spin_event = nullptr;
+    if (g_spin_event && hipEventRecord(g_spin_event, stream_) == hipSuccess) {
         g_spin_stream = stream_;
         g_spin_pending = true;
     }
+    g_spin_mu.unlock();
 }
 
 }  // namespace dfq

@@ -63,6 +63,7 @@ namespace dfq {
 // slot is unrolled code, and a cold workgroup pays instruction-fetch latency for every line it walks.
 constexpr int kSlotsVec4 = 8;
 constexpr int kSlotsVec1 = 8;
+static_assert(kSlotsVec4 == kSlotsVec1, "the tile functions take one register-array shape");
 constexpr int kTileRowsMax = 256;      // rows of a tile (one LDS entry per row)
 constexpr int kRowTileColsMax = 128;   // positions of a row tile (x2 for float4 tiles)
 constexpr int kColTileLanes = 64;      // vector positions of a col tile (one wave per row at most)
@@ -114,6 +115,11 @@ struct LeRelDev {
 #define DFQ_LE_ABLATE 0
 #endif
 constexpr int kAblate = DFQ_LE_ABLATE;
+// Tuning builds only: 1 = the tiles' 16-byte element loads carry the non-temporal hint, 2 = their stores do, 3 = both.
+#ifndef DFQ_LE_NT
+#define DFQ_LE_NT 0
+#endif
+constexpr int kNonTemporal = DFQ_LE_NT;
 
 struct LeLayerDiff {
     int32_t partial_begin;   // -1: layer untouched by any relation (contributes exactly 0)
@@ -138,11 +144,11 @@ struct LeBlockRef {
 struct LeTrace {
     long long* out;     // device [16] or null
     int32_t block;
-    int32_t pad;
+    int32_t flat;       // index of the running tile in the launch's table (set by the kernel)
 };
 __device__ __forceinline__ void stamp(const LeTrace& tr, int slot) {
     if (!tr.out || threadIdx.x != 0) return;
-    const int flat = (int)blockIdx.x;
+    const int flat = tr.flat;
     if (tr.block == -1) {
         // every workgroup: [0] entry, [1] exit (100 MHz wall clock), [2] XCC_ID << 32 | HW_ID
         if (slot == 0) {
@@ -190,6 +196,15 @@ __device__ __forceinline__ void scale_from_words(const LeParams& p, uint32_t a0,
 __device__ __forceinline__ float abs_diff_if(bool on, float a, float b) {
     const float d = on ? (a - b) : 0.0f;
     return __uint_as_float(__float_as_uint(d) & 0x7fffffffu);
+}
+
+// Make four just-requested words count as "arrived" from here on.  The compiler tracks outstanding vector-memory results
+// per register and, where two paths join, assumes the younger request: a register requested early on one path and late
+// on the other is then waited for as if it were the youngest request of all.  The late path calls this.
+__device__ __forceinline__ void landed(uint32_t& a, uint32_t& b, uint32_t& c, uint32_t& d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+#endif
 }
 
 // dependency of a workgroup inside a one-launch sweep (see le_level_kernel)
@@ -253,7 +268,11 @@ __device__ __forceinline__ void vload(const gfloat* p, float (&x)[VEC]) {
         return;
     }
     if (VEC == 4) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const fvec4 t = (kNonTemporal & 1) ? __builtin_nontemporal_load((const gfvec4*)p) : *(const gfvec4*)p;
+#else
         const fvec4 t = *(const gfvec4*)p;
+#endif
         x[0] = t[0]; x[1 % VEC] = t[1]; x[2 % VEC] = t[2]; x[3 % VEC] = t[3];
     } else {
         x[0] = *p;
@@ -265,7 +284,11 @@ __device__ __forceinline__ void vstore(gfloat* p, const float (&x)[VEC]) {
     if (VEC == 4) {
         fvec4 t;
         t[0] = x[0]; t[1] = x[1 % VEC]; t[2] = x[2 % VEC]; t[3] = x[3 % VEC];
-        *(gfvec4*)p = t;
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (kNonTemporal & 2) __builtin_nontemporal_store(t, (gfvec4*)p);
+        else
+#endif
+            *(gfvec4*)p = t;
     } else {
         *p = x[0];
     }
@@ -281,10 +304,17 @@ __device__ __forceinline__ void vstore(gfloat* p, const float (&x)[VEC]) {
 // ---------------------------------------------------------------------------------------------
 
 // row tile: W1[r0:r0+nr, p0:p0+np] *= s[row]   (+ column stats of the new values)
-template <int VEC>
-__device__ __forceinline__ double row_tile(const LeRelDev& R, const LeParams& p, int tile, int cur, const LeDep& dep,
+// PRE: the tile's elements are already in `v` (le_sweep_kernel requested them one tile ahead); `ready`: the dependency
+// is known to be satisfied; `mid()` is called right after the tile's own statistics requests have been issued -- the
+// sweep kernel requests the NEXT tile's data there, so that waiting for the statistics does not wait for that data
+// (vector memory returns in order).
+template <int VEC, bool PRE, class Mid>
+__device__ __forceinline__ double row_tile(const LeRelDev& R, const LeParams& p, int tile, int cur, const LeDep& dep, bool ready,
+                                           float (&v_in)[kSlotsVec4][VEC], Mid mid,
                                            float* sh_s, uint32_t* sh_slot, int* sh_g, float* sh_pinv, int* sh_flag, const LeTrace& tr) {
     constexpr int NV = (VEC == 4) ? kSlotsVec4 : kSlotsVec1;   // vectors per thread
+    float v_own[NV][VEC];                                      // (an array of the caller used here when !PRE tripled the registers)
+    float (&v)[NV][VEC] = *(PRE ? &v_in : &v_own);
     const int tid = threadIdx.x;
     const int rblk = small_div(tile, R.rt_slabs);
     const int slab = tile - rblk * R.rt_slabs;
@@ -308,24 +338,7 @@ __device__ __forceinline__ double row_tile(const LeRelDev& R, const LeParams& p,
     //      before the data and the scale solve then overlaps the data's flight instead of queueing behind it (memory
     //      returns in order).  With a dependency the statistics do not exist yet: the data (which nobody writes before
     //      this workgroup does) is requested first and arrives while the workgroup waits for its producers. ----
-    const bool waits = R.dep_idx >= 0;
-    uint32_t wa0 = 0u, wa1 = 0u, wb0 = 0u, wb1 = 0u;
-    const guint* const st_a = (const guint*)R.r1 + (int64_t)cur * R.stat_stride + 2 * (r0 + min(tid, nr - 1));
-    const guint* const st_b = (const guint*)R.r2 + (int64_t)cur * R.stat_stride + 2 * (r0 + min(tid, nr - 1));
-    if (!waits && tid < nr) { wa0 = ld_stat(st_a); wa1 = ld_stat(st_a + 1); wb0 = st_b[0]; wb1 = st_b[1]; }
-    float v[NV][VEC];
-#pragma unroll
-    for (int u = 0; u < NV; ++u) {
-        if (u < n_max) {
-            const int r = min(jl + u * JL, nr - 1);
-            vload<VEC>(w + r * R.row_len, v[u]);
-        }
-    }
-    if (waits) {
-        if (!dep_wait(R, dep, p.poll_naps, sh_flag)) return kTileAbandoned;
-        if (tid < nr) { wa0 = ld_stat(st_a); wa1 = ld_stat(st_a + 1); wb0 = st_b[0]; wb1 = st_b[1]; }
-    }
-
+    const bool waits = R.dep_idx >= 0 && !ready;
     // column-stat slot geometry of this tile
     const bool emit = R.out_cols != nullptr && !(kAblate & 4);
     int g0 = 0, i0 = 0, nci = 1, n_slots = 0;
@@ -334,15 +347,51 @@ __device__ __forceinline__ double row_tile(const LeRelDev& R, const LeParams& p,
         i0 = small_div(p0, R.khkw1);
         nci = small_div(p0 + np - 1, R.khkw1) - i0 + 1;
         n_slots = (small_div(r0 + nr - 1, R.pc_go) - g0 + 1) * nci;
-        for (int i = tid; i < 2 * n_slots; i += kBlock) sh_slot[i] = 0u;
     }
+    uint32_t wa0 = 0u, wa1 = 0u, wb0 = 0u, wb1 = 0u;
+    const guint* const st_a = (const guint*)R.r1 + (int64_t)cur * R.stat_stride + 2 * (r0 + min(tid, nr - 1));
+    const guint* const st_b = (const guint*)R.r2 + (int64_t)cur * R.stat_stride + 2 * (r0 + min(tid, nr - 1));
+    // first entry of this thread in the table of 1/s of the previous relation (see below): requested with the row's own
+    // statistics; threads from the top of the workgroup so that the row-scale solves (threads 0..nr-1) run next to them
+    const guint* const a_base = fused ? (const guint*)R.prev_r1 + (int64_t)cur * R.stat_stride : nullptr;
+    const guint* const b_base = fused ? (const guint*)R.out_cols + (int64_t)cur * R.stat_stride : nullptr;
+    const int sl0 = kBlock - 1 - tid;
+    const bool has_sl0 = fused && sl0 < n_slots;
+    int c_sl0 = 0;
+    if (has_sl0) { const int gq = small_div(sl0, nci); c_sl0 = (g0 + gq) * R.pc_gi + i0 + (sl0 - gq * nci); }
+    uint32_t pa0 = 0u, pa1 = 0u, pb0 = 0u, pb1 = 0u;
+    if (!waits) {
+        if (tid < nr) { wa0 = ld_stat(st_a); wa1 = ld_stat(st_a + 1); wb0 = st_b[0]; wb1 = st_b[1]; }
+        if (has_sl0) { pa0 = ld_stat(a_base + 2 * c_sl0); pa1 = ld_stat(a_base + 2 * c_sl0 + 1); pb0 = b_base[2 * c_sl0]; pb1 = b_base[2 * c_sl0 + 1]; }
+    }
+    if (!PRE) {
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            if (u < n_max) {
+                const int r = min(jl + u * JL, nr - 1);
+                vload<VEC>(w + r * R.row_len, v[u]);
+            }
+        }
+    }
+    mid();
+    if (waits) {
+        if (!dep_wait(R, dep, p.poll_naps, sh_flag)) return kTileAbandoned;
+        if (tid < nr) { wa0 = ld_stat(st_a); wa1 = ld_stat(st_a + 1); wb0 = st_b[0]; wb1 = st_b[1]; }
+        if (has_sl0) { pa0 = ld_stat(a_base + 2 * c_sl0); pa1 = ld_stat(a_base + 2 * c_sl0 + 1); pb0 = b_base[2 * c_sl0]; pb1 = b_base[2 * c_sl0 + 1]; }
+        if (PRE) { landed(wa0, wa1, wb0, wb1); landed(pa0, pa1, pb0, pb1); }
+    }
+
+    if (emit) for (int i = tid; i < 2 * n_slots; i += kBlock) sh_slot[i] = 0u;
     if (fused) {
         // 1/s of the previous relation for every (group, input channel) this tile spans: the same slot
-        // geometry as the column statistics; threads from the top of the workgroup so that the row-scale
-        // solves below (threads 0..nr-1) run next to them
-        const guint* a_base = (const guint*)R.prev_r1 + (int64_t)cur * R.stat_stride;
-        const guint* b_base = (const guint*)R.out_cols + (int64_t)cur * R.stat_stride;
-        for (int sl = kBlock - 1 - tid; sl < n_slots; sl += kBlock) {
+        // geometry as the column statistics
+        if (has_sl0) {
+            float s, inv;
+            le_solve(range_of(slot_min(pa0), slot_max(pa1), p.signed_range), range_of(slot_min(pb0), slot_max(pb1), p.signed_range),
+                     p, s, inv);
+            sh_pinv[sl0] = inv;
+        }
+        for (int sl = sl0 + kBlock; sl < n_slots; sl += kBlock) {      // tables of more than 256 entries
             const int gq = small_div(sl, nci);
             const int c = (g0 + gq) * R.pc_gi + i0 + (sl - gq * nci);
             const uint32_t a0 = ld_stat(a_base + 2 * c), a1 = ld_stat(a_base + 2 * c + 1), b0 = b_base[2 * c], b1 = b_base[2 * c + 1];
@@ -459,10 +508,13 @@ __device__ __forceinline__ double row_tile(const LeRelDev& R, const LeParams& p,
 
 // col tile: W2[r0:r0+nr, p0:p0+np] *= 1/s[input channel]   (+ row stats of the new values)
 // G = pow2 >= np/VEC lanes share a row; 256/G rows are in flight per register slot.
-template <int VEC>
-__device__ __forceinline__ double col_tile(const LeRelDev& R, const LeParams& p, int tile, int cur, const LeDep& dep,
+template <int VEC, bool PRE, class Mid>
+__device__ __forceinline__ double col_tile(const LeRelDev& R, const LeParams& p, int tile, int cur, const LeDep& dep, bool ready,
+                                           float (&v_in)[kSlotsVec4][VEC], Mid mid,
                                            float* sh_inv, uint32_t* sh_row, int* sh_tab, int* sh_flag, const LeTrace& tr) {
     constexpr int NV = (VEC == 4) ? kSlotsVec4 : kSlotsVec1;
+    float v_own[NV][VEC];
+    float (&v)[NV][VEC] = *(PRE ? &v_in : &v_own);
     const int tid = threadIdx.x;
     const int rblk = small_div(tile, R.ct_slabs);
     const int slab = tile - rblk * R.ct_slabs;
@@ -492,7 +544,7 @@ __device__ __forceinline__ double col_tile(const LeRelDev& R, const LeParams& p,
     const int g_n = small_div(r0 + nr - 1, R.go) - g_lo + 1;
     // ---- load order as in row_tile: statistics of this thread's table entry first, unless they are still being
     //      produced -- then the data first, the wait, the statistics ----
-    const bool waits = R.dep_idx >= 0;
+    const bool waits = R.dep_idx >= 0 && !ready;
     uint32_t wa0 = 0u, wa1 = 0u, wb0 = 0u, wb1 = 0u;
     const bool has_entry = tid < g_n * nci;
     const int e_gq = small_div(min(tid, g_n * nci - 1), nci);
@@ -500,17 +552,20 @@ __device__ __forceinline__ double col_tile(const LeRelDev& R, const LeParams& p,
     const guint* const st_a = (const guint*)R.r1 + (int64_t)cur * R.stat_stride + 2 * e_c;
     const guint* const st_b = (const guint*)R.r2 + (int64_t)cur * R.stat_stride + 2 * e_c;
     if (!waits && has_entry) { wa0 = ld_stat(st_a); wa1 = ld_stat(st_a + 1); wb0 = st_b[0]; wb1 = st_b[1]; }
-    float v[NV][VEC];
+    if (!PRE) {
 #pragma unroll
-    for (int u = 0; u < NV; ++u) {
-        if (u < n_max) {
-            const int r = min(grp + u * n_rowslots, nr - 1);
-            vload<VEC>(w + r * row_len2, v[u]);
+        for (int u = 0; u < NV; ++u) {
+            if (u < n_max) {
+                const int r = min(grp + u * n_rowslots, nr - 1);
+                vload<VEC>(w + r * row_len2, v[u]);
+            }
         }
     }
+    mid();
     if (waits) {
         if (!dep_wait(R, dep, p.poll_naps, sh_flag)) return kTileAbandoned;
         if (has_entry) { wa0 = ld_stat(st_a); wa1 = ld_stat(st_a + 1); wb0 = st_b[0]; wb1 = st_b[1]; }
+        if (PRE) landed(wa0, wa1, wb0, wb1);
     }
     stamp(tr, 2);
     for (int idx = tid; idx < g_n * nci; idx += kBlock) {      // one entry per thread for every plan-made tile
@@ -698,6 +753,7 @@ __global__ __launch_bounds__(kBlock, DFQ_LE_MIN_WAVES) void le_level_kernel(cons
                                                           const LeState* __restrict__ state,
                                                           double* __restrict__ partials, unsigned long long* dep_counters,
                                                           unsigned long long* err, LeTrace tr) {
+    tr.flat = (int)blockIdx.x;
     stamp(tr, 0);
     __shared__ float sh_f[kSlotMax];                // row tile: scales; col tile: 1/s table
     __shared__ uint32_t sh_u[2 * kSlotMax];         // row tile: column-stat slots; col tile: row stats
@@ -729,17 +785,18 @@ __global__ __launch_bounds__(kBlock, DFQ_LE_MIN_WAVES) void le_level_kernel(cons
     stamp(tr, 1);
 
     const LeDep dep{dep_counters, err, sweep, 0};
+    auto nothing = [] {};
 
     double acc;
     const bool col_side = tile >= R.n_row_tiles;
     if (!col_side) {
         if (R.rt_vec == 0) acc = dep_wait(R, dep, p.poll_naps, &sh_flag) ? short_tile<0>(R, p, tile, cur) : kTileAbandoned;
-        else acc = R.rt_vec == 4 ? row_tile<4>(R, p, tile, cur, dep, sh_f, sh_u, sh_g, sh_p, &sh_flag, tr)
-                                 : row_tile<1>(R, p, tile, cur, dep, sh_f, sh_u, sh_g, sh_p, &sh_flag, tr);
+        else if (R.rt_vec == 4) { float v[kSlotsVec4][4]; acc = row_tile<4, false>(R, p, tile, cur, dep, false, v, nothing, sh_f, sh_u, sh_g, sh_p, &sh_flag, tr); }
+        else { float v[kSlotsVec4][1]; acc = row_tile<1, false>(R, p, tile, cur, dep, false, v, nothing, sh_f, sh_u, sh_g, sh_p, &sh_flag, tr); }
     } else {
         if (R.ct_vec == 0) acc = dep_wait(R, dep, p.poll_naps, &sh_flag) ? short_tile<1>(R, p, tile - R.n_row_tiles, cur) : kTileAbandoned;
-        else acc = R.ct_vec == 4 ? col_tile<4>(R, p, tile - R.n_row_tiles, cur, dep, sh_f, sh_u, sh_g, &sh_flag, tr)
-                                 : col_tile<1>(R, p, tile - R.n_row_tiles, cur, dep, sh_f, sh_u, sh_g, &sh_flag, tr);
+        else if (R.ct_vec == 4) { float v[kSlotsVec4][4]; acc = col_tile<4, false>(R, p, tile - R.n_row_tiles, cur, dep, false, v, nothing, sh_f, sh_u, sh_g, &sh_flag, tr); }
+        else { float v[kSlotsVec4][1]; acc = col_tile<1, false>(R, p, tile - R.n_row_tiles, cur, dep, false, v, nothing, sh_f, sh_u, sh_g, &sh_flag, tr); }
     }
     stamp(tr, 6);
     if (acc < 0.0) return;          // abandoned wait (uniform): nothing was stored, the counter is not bumped
@@ -753,6 +810,201 @@ __global__ __launch_bounds__(kBlock, DFQ_LE_MIN_WAVES) void le_level_kernel(cons
     const double t = wave_sum(acc);
     if (lane == 0) partials[(int64_t)(R.partial_base + tile) * (kBlock / kWave) + threadIdx.x / kWave] = t;
     stamp(tr, 7);
+}
+
+// ---------------------------------------------------------------------------------------------
+// le_sweep_kernel: the same sweep as ONE launch of persistent workgroups.  Workgroup g walks the tiles g, g + G,
+// g + 2G, ... of the sweep's table (G = gridDim.x <= the number of workgroups the chip holds at once) and keeps the
+// NEXT tile's data in flight while it works on the current one: everything needed to request a tile's elements is a
+// 64-byte LeTileRef, fetched two tiles ahead; the relation descriptor and the dependency counter of a tile are fetched
+// one tile ahead together with its elements.  A workgroup of le_level_kernel spends most of its 10-15 us on the chain
+// table entry -> descriptor -> statistics -> solve -> elements -> stores, with its loads in flight for a fraction of that
+// time; here the chain of tile i+1 overlaps the arithmetic and the stores of tile i.
+//
+// Order of the requests inside an iteration (vector memory returns in order): the statistics of tile i first, then the
+// elements of tile i+1 -- all eight slots unconditionally, so that the compiler can count them and the wait for the
+// statistics does not become a wait for everything.
+//
+// Progress: a tile only ever waits for tiles with a lower index; the workgroups hold their tiles in increasing order and
+// are all resident (the host sizes the grid with the occupancy query), so the lowest unfinished tile is always some
+// workgroup's current tile and can finish.  The wait is bounded as in le_level_kernel.
+// ---------------------------------------------------------------------------------------------
+struct alignas(64) LeTileRef {
+    float* w;            // element (first row, first position) of the tile
+    int32_t stride;      // floats between two rows of the layer
+    int32_t nr;          // rows
+    int32_t npv;         // 16-byte vectors per row of the tile; 0: the tile fetches its own elements (scalar / thread-per-row)
+    int32_t lanes;       // threads along a row: npv for row tiles, the next power of two for column tiles
+    int32_t rel;         // relation (index into the level-sorted table)
+    int32_t tile;        // tile of the relation: row tiles first, then column tiles
+    int32_t net;         // network (loop-state index)
+    int32_t dep_idx;     // counter this tile waits for, or -1
+    int32_t dep_tiles;   // column tiles per sweep behind that counter
+};
+static_assert(sizeof(LeTileRef) == 64, "one tile reference per 64-byte line");
+constexpr int kRefWords = 11;
+constexpr int kSweepMaxNets = 4096;     // done flags of a launch's networks, one LDS byte each
+
+// lanes 0..n_words-1 fetch one word each (the others repeat the last one: no predicate, so the request is unconditional
+// for the compiler's bookkeeping of outstanding loads, see le_sweep_kernel)
+__device__ __forceinline__ uint32_t fetch_words(const void* base, int n_words, int lane) {
+    return ((const guint*)base)[min(lane, n_words - 1)];
+}
+__device__ __forceinline__ void ref_from_word(uint32_t word, LeTileRef& T) {
+    const uint64_t lo = (uint32_t)__builtin_amdgcn_readlane(word, 0), hi = (uint32_t)__builtin_amdgcn_readlane(word, 1);
+    T.w = (float*)(uintptr_t)(lo | (hi << 32));
+    T.stride = __builtin_amdgcn_readlane(word, 2);
+    T.nr = __builtin_amdgcn_readlane(word, 3);
+    T.npv = __builtin_amdgcn_readlane(word, 4);
+    T.lanes = __builtin_amdgcn_readlane(word, 5);
+    T.rel = __builtin_amdgcn_readlane(word, 6);
+    T.tile = __builtin_amdgcn_readlane(word, 7);
+    T.net = __builtin_amdgcn_readlane(word, 8);
+    T.dep_idx = __builtin_amdgcn_readlane(word, 9);
+    T.dep_tiles = __builtin_amdgcn_readlane(word, 10);
+}
+// request the elements of a tile made of 16-byte vectors: the same (row, position) per thread and slot as row_tile<4> /
+// col_tile<4> compute for themselves
+__device__ __forceinline__ void request_tile(const LeTileRef& T, float (&x)[kSlotsVec4][4]) {
+    const int tid = threadIdx.x;
+    const int rf = small_div(kBlock, T.lanes);               // rows in flight
+    const int trow = small_div(tid, T.lanes);
+    const bool on = trow < rf;
+    const int row0 = on ? trow : 0;
+    const int ln = on ? min(tid - trow * T.lanes, T.npv - 1) : 0;
+    const gfloat* w = (const gfloat*)T.w + ln * 4;
+#pragma unroll
+    for (int u = 0; u < kSlotsVec4; ++u) {
+        const int r = min(row0 + u * rf, T.nr - 1);          // slots past the tile repeat its last row (a cache hit)
+        vload<4>(w + r * T.stride, x[u]);
+    }
+}
+
+#ifndef DFQ_LE_SWEEP_MIN_WAVES
+#define DFQ_LE_SWEEP_MIN_WAVES 4
+#endif
+__global__ __launch_bounds__(kBlock, DFQ_LE_SWEEP_MIN_WAVES) void le_sweep_kernel(const LeRelDev* __restrict__ table, const LeTileRef* __restrict__ tiles,
+                                                          int n_tiles, LeParams p, int sweep, const LeState* __restrict__ state,
+                                                          int n_nets, double* __restrict__ partials,
+                                                          unsigned long long* dep_counters, unsigned long long* err, LeTrace tr) {
+    __shared__ float sh_f[kSlotMax];
+    __shared__ uint32_t sh_u[2 * kSlotMax];
+    __shared__ int sh_g[kTileRowsMax];
+    __shared__ float sh_p[kSlotMax];
+    __shared__ int sh_flag;
+    __shared__ unsigned char sh_done[kSweepMaxNets];
+    __shared__ int sh_ready[2];                     // is the dependency of the tile of an even / odd iteration satisfied already?
+    const int tid = threadIdx.x;
+    const int lane = tid % kWave;
+    const int G = (int)gridDim.x;
+    const int cur = sweep & 1;
+    const LeDep dep{dep_counters, err, sweep, 0};
+
+    // which networks have stopped (the flags only change between launches)
+    for (int n = tid; n < n_nets; n += kBlock) sh_done[n] = state[n].done != 0;
+    __syncthreads();
+    auto net_done = [&](int net) { return sh_done[net] != 0; };
+
+    int t = (int)blockIdx.x;
+    if (t >= n_tiles) return;
+    // prologue: reference of the first tile, its descriptor / counter / elements, and the reference of the second
+    // (only the fetched words are carried around the loop, the fields are re-broadcast from them every iteration)
+    uint32_t ref_cur = fetch_words(tiles + t, kRefWords, lane);
+    uint32_t ref_next = fetch_words(tiles + min(t + G, n_tiles - 1), kRefWords, lane);
+    uint32_t rel_word;
+    unsigned long long cnt;
+    float v[kSlotsVec4][4];
+    {
+        LeTileRef F;
+        ref_from_word(ref_cur, F);
+        rel_word = fetch_words(table + F.rel, kDescWords, lane);
+        cnt = __hip_atomic_load(dep_counters + (int64_t)max(F.dep_idx, 0) * kDepStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!(F.npv > 0 && !net_done(F.net))) { F.w = (float*)tiles; F.stride = 0; F.nr = 1; F.npv = 1; F.lanes = 1; }
+        request_tile(F, v);
+        // ONE thread's view of the counter decides for the workgroup: the waves read it at different times, and a
+        // workgroup whose waves disagree on whether to wait would disagree on the number of barriers
+        if (tid == 0) sh_ready[0] = F.dep_idx < 0 || cnt >= (unsigned long long)F.dep_tiles * (unsigned long long)(sweep + 1);
+        __syncthreads();
+    }
+
+    for (int iter = 0;; ++iter) {
+        tr.flat = t;
+        stamp(tr, 0);
+        const bool has_next = t + G < n_tiles;                  // uniform
+        LeTileRef T, N;
+        ref_from_word(ref_cur, T);
+        ref_from_word(ref_next, N);                             // (the last reference again when there is no next tile)
+        const bool live = !net_done(T.net);
+        const bool next_live = has_next && !net_done(N.net);
+        float vn[kSlotsVec4][4];
+        uint32_t rel_next = 0u;
+        unsigned long long cnt_next = 0ull;
+        // the requests for the next tile, issued by the current tile right after its own statistics requests
+        // (every request unconditional; with nothing to fetch the eight element requests all hit one 16-byte word)
+        const uint32_t ref_next_old = ref_next;
+        LeTileRef Q = N;
+        if (!(next_live && N.npv > 0)) { Q.w = (float*)tiles; Q.stride = 0; Q.nr = 1; Q.npv = 1; Q.lanes = 1; }
+        auto ahead = [&]() __attribute__((always_inline)) {
+            request_tile(Q, vn);
+            rel_next = fetch_words(table + N.rel, kDescWords, lane);
+            cnt_next = __hip_atomic_load(dep_counters + (int64_t)max(N.dep_idx, 0) * kDepStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ref_next = fetch_words(tiles + min(t + 2 * G, n_tiles - 1), kRefWords, lane);
+        };
+        if (live) {
+            union { LeRelDev R; uint32_t u[kDescWords]; } desc;
+#pragma unroll
+            for (int i = 0; i < kDescWords; ++i) desc.u[i] = __builtin_amdgcn_readlane(rel_word, i);
+            const LeRelDev& R = desc.R;
+            stamp(tr, 1);
+            // the counter was read one tile ago: if it had already reached its target the producers are done
+            const bool ready = sh_ready[iter & 1] != 0;
+            const int tile = T.tile;
+            const bool col_side = tile >= R.n_row_tiles;
+            double acc;
+            if (!col_side) {
+                if (R.rt_vec == 4) acc = row_tile<4, true>(R, p, tile, cur, dep, ready, v, ahead, sh_f, sh_u, sh_g, sh_p, &sh_flag, tr);
+                else {
+                    ahead();
+                    if (!ready && !dep_wait(R, dep, p.poll_naps, &sh_flag)) acc = kTileAbandoned;
+                    else if (R.rt_vec == 0) acc = short_tile<0>(R, p, tile, cur);
+                    else { float v1[kSlotsVec4][1]; acc = row_tile<1, false>(R, p, tile, cur, dep, true, v1, [] {}, sh_f, sh_u, sh_g, sh_p, &sh_flag, tr); }
+                }
+            } else {
+                if (R.ct_vec == 4) acc = col_tile<4, true>(R, p, tile - R.n_row_tiles, cur, dep, ready, v, ahead, sh_f, sh_u, sh_g, &sh_flag, tr);
+                else {
+                    ahead();
+                    if (!ready && !dep_wait(R, dep, p.poll_naps, &sh_flag)) acc = kTileAbandoned;
+                    else if (R.ct_vec == 0) acc = short_tile<1>(R, p, tile - R.n_row_tiles, cur);
+                    else { float v1[kSlotsVec4][1]; acc = col_tile<1, false>(R, p, tile - R.n_row_tiles, cur, dep, true, v1, [] {}, sh_f, sh_u, sh_g, &sh_flag, tr); }
+                }
+            }
+            stamp(tr, 6);
+            if (acc < 0.0) return;      // abandoned wait (uniform): nothing was stored; `err` stops every other workgroup
+            if (col_side && R.counter_idx >= 0) {
+                __builtin_amdgcn_s_waitcnt(0);
+                __syncthreads();
+                if (tid == 0) atomicAdd(dep_counters + (int64_t)R.counter_idx * kDepStride, 1ull);
+            }
+            const double ts = wave_sum(acc);
+            if (lane == 0) partials[(int64_t)(R.partial_base + tile) * (kBlock / kWave) + tid / kWave] = ts;
+            stamp(tr, 7);
+        } else {
+            ahead();
+        }
+        if (!has_next) return;
+        // rotate
+        ref_cur = ref_next_old;
+        rel_word = rel_next;
+        cnt = cnt_next;
+#pragma unroll
+        for (int u = 0; u < kSlotsVec4; ++u) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[u][k] = vn[u][k];
+        }
+        if (tid == 0) sh_ready[(iter + 1) & 1] = N.dep_idx < 0 || cnt >= (unsigned long long)N.dep_tiles * (unsigned long long)(sweep + 1);
+        t += G;
+        __syncthreads();               // the LDS tables of this tile are dead before the next one fills them
+    }
 }
 
 // Stats of the untouched weights, once per run: R1 (rows of W1) for chain-start relations and R2
@@ -1021,6 +1273,12 @@ struct dfq_le_plan {
     // null: the streaming one-launch-per-sweep kernel above (batched plans, networks too large, DFQ_LE_RESIDENT=0)
     dfq::LeResident* resident = nullptr;
     std::string resident_why;
+    std::vector<LeRelDev> h_rels;          // host copies of the two tables (dfq_le_plan_block_info)
+    std::vector<LeBlockRef> h_blocks;
+    // DFQ_LE_PERSIST=1: one-launch sweeps run as persistent workgroups that keep the next tile's data in flight
+    // (le_sweep_kernel; an experiment that measured slower than one workgroup per tile)
+    LeTileRef* d_tiles = nullptr;
+    int sweep_grid = 0;                    // workgroups of le_sweep_kernel; 0: le_level_kernel
 };
 
 // elements per tile; DFQ_LE_TILE_ELEMS overrides (tuning / tests).  A workgroup's fixed cost (workgroup table ->
@@ -1076,6 +1334,7 @@ void dfq_le_plan_destroy(dfq_le_plan* p) {
     if (p->d_boot_map) (void)hipFree(p->d_boot_map);
     if (p->d_blocks) (void)hipFree(p->d_blocks);
     if (p->d_dep) (void)hipFree(p->d_dep);
+    if (p->d_tiles) (void)hipFree(p->d_tiles);
     for (auto& g : p->graphs) (void)hipGraphExecDestroy(g.exec);
     if (p->capture_stream) (void)hipStreamDestroy(p->capture_stream);
     if (p->resident) le_resident_destroy(p->resident);
@@ -1348,10 +1607,52 @@ int dfq_le_plan_create_batch(const dfq_layer* layers, int32_t n_layers, const in
         if ((e = hipMalloc((void**)&p->d_blocks, sizeof(LeBlockRef) * std::max<size_t>(1, blocks.size()))) != hipSuccess) return fail_alloc(e);
         if (!blocks.empty() &&
             (e = hipMemcpy(p->d_blocks, blocks.data(), sizeof(LeBlockRef) * blocks.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail_alloc(e);
+        p->h_rels = sorted;
+        p->h_blocks = blocks;
         if ((e = hipMalloc((void**)&p->d_dep, sizeof(unsigned long long) * ((size_t)n_relations * kDepStride + 1))) != hipSuccess) return fail_alloc(e);
         if ((e = hipMemset(p->d_dep, 0, sizeof(unsigned long long) * ((size_t)n_relations * kDepStride + 1))) != hipSuccess) return fail_alloc(e);
         const char* me = getenv("DFQ_LE_MERGED");
         p->merged = !(me && me[0] == '0');
+        const char* pe = getenv("DFQ_LE_PERSIST");
+        if (p->merged && pe && pe[0] == '1' && n_nets <= kSweepMaxNets && !blocks.empty()) {
+            std::vector<LeTileRef> refs(blocks.size());
+            for (size_t i = 0; i < blocks.size(); ++i) {
+                const LeRelDev& d = sorted[blocks[i].rel];
+                const bool col = blocks[i].tile >= d.n_row_tiles;
+                const int tile = col ? blocks[i].tile - d.n_row_tiles : blocks[i].tile;
+                const int vec = col ? d.ct_vec : d.rt_vec;
+                const int n_rows = col ? d.o2 : d.o1, row_len = col ? d.i2g * d.khkw : d.row_len;
+                const int t_rows = col ? d.ct_rows : d.rt_rows, t_cols = col ? d.ct_cols : d.rt_cols, slabs = col ? d.ct_slabs : d.rt_slabs;
+                const int rblk = tile / slabs, slab = tile - rblk * slabs;
+                const int r0 = rblk * t_rows, p0 = slab * t_cols;
+                LeTileRef& t = refs[i];
+                memset(&t, 0, sizeof(t));
+                t.w = (col ? d.w2 : d.w1) + ((int64_t)r0 * row_len + p0);
+                t.stride = row_len;
+                t.nr = std::min(t_rows, n_rows - r0);
+                t.npv = vec == 4 ? std::min(t_cols, row_len - p0) / 4 : 0;
+                t.lanes = std::max(1, t.npv);
+                if (col) { int g = 1; while (g < t.npv) g <<= 1; t.lanes = g; }
+                t.rel = blocks[i].rel; t.tile = blocks[i].tile; t.net = blocks[i].net;
+                t.dep_idx = d.dep_idx; t.dep_tiles = d.dep_tiles;
+            }
+            if ((e = hipMalloc((void**)&p->d_tiles, sizeof(LeTileRef) * refs.size())) != hipSuccess) return fail_alloc(e);
+            if ((e = hipMemcpy(p->d_tiles, refs.data(), sizeof(LeTileRef) * refs.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail_alloc(e);
+            // every workgroup must be resident at once (a tile may wait for a tile another workgroup holds)
+            int dev = 0, occ = 0;
+            hipDeviceProp_t prop;
+            if ((e = hipGetDevice(&dev)) != hipSuccess || (e = hipGetDeviceProperties(&prop, dev)) != hipSuccess) return fail_alloc(e);
+            if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)le_sweep_kernel, kBlock, 0)) != hipSuccess) return fail_alloc(e);
+            // ... with a quarter of the chip left free: at exactly the occupancy limit the launch never became fully
+            // resident while a second stream kept the chip busy (measured: 1024 of 1024 slots gave up, 768 ran)
+            int64_t cap = std::max<int64_t>(1, (int64_t)std::max(1, occ) * std::max(1, prop.multiProcessorCount) * 3 / 4);
+#ifdef DFQ_EMU
+            cap = 24;                      // the CPU emulation keeps every workgroup of such a launch alive as fibers
+#endif
+            const char* we = getenv("DFQ_LE_SWEEP_WGS");
+            if (we && atoi(we) > 0) cap = std::min<int64_t>(cap, atoi(we));
+            p->sweep_grid = (int)std::min<int64_t>(cap, (int64_t)blocks.size());
+        }
     }
     if (n_nets == 1 && n_relations > 0) p->resident = le_resident_create(layers, n_layers, relations, n_relations, &p->resident_why);
     else p->resident_why = n_nets > 1 ? "batched plan" : "no relations";
@@ -1363,6 +1664,8 @@ int dfq_le_plan_create_batch(const dfq_layer* layers, int32_t n_layers, const in
 // workgroups (= register-resident tiles) of the persistent whole-loop launch, 0 when the plan streams
 int32_t dfq_le_plan_resident_tiles(const dfq_le_plan* p) { return (p && p->resident) ? le_resident_tiles(p->resident) : 0; }
 const char* dfq_le_plan_resident_reason(const dfq_le_plan* p) { return p ? p->resident_why.c_str() : ""; }
+// persistent workgroups of a streaming sweep launch (le_sweep_kernel), 0 when the plan launches one workgroup per tile
+int32_t dfq_le_plan_sweep_workgroups(const dfq_le_plan* p) { return (p && !p->resident) ? p->sweep_grid : 0; }
 
 // Tuning aid: restart, run `n_sweeps` sweeps of the persistent launch with per-tile phase stamps (100 MHz wall clock;
 // [tile][6 sweeps][8 points]: 0 sweep start, 1 s_A solved, 2 row statistics published, 3 s_B solved, 4 new values +
@@ -1417,6 +1720,30 @@ int dfq_le_plan_level_grid(const dfq_le_plan* p, int32_t level, int32_t* grid_x,
     return DFQ_OK;
 }
 
+int dfq_le_plan_block_info(const dfq_le_plan* p, int32_t launch, int32_t block, int64_t* out8) {
+    int b, c, n; int64_t rw, ro;
+    if (!out8 || !launch_slice(p, launch, &b, &c, &n, &rw, &ro) || block < 0 || block >= c) return fail_arg("dfq_le_plan_block_info: bad argument");
+    const LeBlockRef& ref = p->h_blocks[(size_t)b + block];
+    const LeRelDev& R = p->h_rels[ref.rel];
+    const bool col = ref.tile >= R.n_row_tiles;
+    const int tile = col ? ref.tile - R.n_row_tiles : ref.tile;
+    const int vec = col ? R.ct_vec : R.rt_vec;
+    const int n_rows = col ? R.o2 : R.o1, row_len = col ? R.i2g * R.khkw : R.row_len;
+    const int t_rows = col ? R.ct_rows : R.rt_rows, t_cols = col ? R.ct_cols : R.rt_cols, slabs = col ? R.ct_slabs : R.rt_slabs;
+    const int rblk = tile / slabs, slab = tile - rblk * slabs;
+    const int nr = std::min(t_rows, n_rows - rblk * t_rows), nc = std::min(t_cols, row_len - slab * t_cols);
+    const bool stat_only = col && R.w2_interior;
+    out8[0] = (col ? 3 : 0) + (vec == 4 ? 0 : vec == 1 ? 1 : 2);
+    out8[1] = nr;
+    out8[2] = nc;
+    out8[3] = stat_only ? 0 : (int64_t)nr * nc;
+    out8[4] = stat_only ? (int64_t)nr * nc : 0;
+    out8[5] = R.dep_idx >= 0 ? 1 : 0;
+    out8[6] = col ? (R.out_rows != nullptr) : (R.out_cols != nullptr);
+    out8[7] = ref.rel;
+    return DFQ_OK;
+}
+
 int32_t dfq_le_plan_level_launches(const dfq_le_plan* p, int32_t level, int64_t* rw_elems,
                                    int64_t* ro_elems, int32_t* n_workgroups) {
     int b, c, n; int64_t rw, ro;
@@ -1451,6 +1778,13 @@ static int le_launch_level(dfq_le_plan* p, int launch, const LeParams& q, hipStr
     int begin, count, n; int64_t rw, ro;
     if (!launch_slice(p, launch, &begin, &count, &n, &rw, &ro)) return fail_arg("le_launch_level: bad launch");
     if (count == 0) return DFQ_OK;
+    if (p->sweep_grid > 0) {
+        DFQ_LAUNCH_RESIDENT(le_sweep_kernel, dim3(p->sweep_grid), dim3(kBlock), 0, st, (const LeRelDev*)p->d_rels,
+                            (const LeTileRef*)p->d_tiles, count, q, (int)p->sweep_index, (const LeState*)p->d_state, p->n_nets,
+                            p->d_partials, p->d_dep, p->d_dep + (size_t)p->n_rels * kDepStride, tr);
+        DFQ_CHECK_LAUNCH();
+        return DFQ_OK;
+    }
     hipLaunchKernelGGL(le_level_kernel, dim3(count), dim3(kBlock), 0, st, (const LeRelDev*)p->d_rels,
                        (const LeBlockRef*)(p->d_blocks + begin), q, (int)p->sweep_index, (const LeState*)p->d_state,
                        p->d_partials, p->d_dep, p->d_dep + (size_t)p->n_rels * kDepStride, tr);

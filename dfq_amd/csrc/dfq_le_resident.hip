@@ -992,8 +992,10 @@ LeResident* le_resident_create(const dfq_layer* layers, int n_layers, const dfq_
         return refuse("dynamic shared memory size refused");
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)le_resident_kernel, kBlock, kResSmemBytes) != hipSuccess || occ < 1)
         return refuse("occupancy query failed");
-    // every workgroup must be resident: LDS bounds it (tile + tables), the API's answer is exact for that
-    const int cap_tiles = std::min(occ, 3) * cus;
+    // every workgroup must be resident: LDS bounds it (tile + tables), the API's answer is exact for that.  A quarter of
+    // the slots stays free: a launch sized to exactly the occupancy limit (le_sweep_kernel, dfq_le.hip) never became fully
+    // resident while a second stream kept the chip busy.
+    const int cap_tiles = std::min(occ, 3) * cus * 3 / 4;
     for (int l = 0; l < n_layers; ++l) {
         tile_begin[l] = (int)tiles.size();
         tile_count[l] = 0;

@@ -119,6 +119,11 @@ class LEPlan:
         """elements only read per sweep: the statistics pass over interior layers (4 B each)"""
         return _ffi.lib().dfq_le_plan_ro_elements(self._plan)
 
+    @property
+    def sweep_workgroups(self):
+        """Persistent workgroups of a streaming sweep launch; 0: one workgroup per tile, or a resident plan."""
+        return int(_ffi.lib().dfq_le_plan_sweep_workgroups(self._plan))
+
     def level_info(self, level):
         a, b, c = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int32()
         n = _ffi.lib().dfq_le_plan_level_launches(self._plan, level, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c))
@@ -161,6 +166,13 @@ class LEPlan:
         out = (ctypes.c_int64 * 16)()
         _ffi.check(_ffi.lib().dfq_le_trace(self._plan, ctypes.byref(cfg), int(launch), int(block), _ffi.stream_arg(), out))
         return [int(v) for v in out]
+
+    def block_info(self, launch, block):
+        """What one workgroup of a launch does (tuning aid, see dfq_le_plan_block_info)."""
+        out = (ctypes.c_int64 * 8)()
+        _ffi.check(_ffi.lib().dfq_le_plan_block_info(self._plan, int(launch), int(block), out))
+        return dict(kind=int(out[0]), rows=int(out[1]), cols=int(out[2]), rw_elements=int(out[3]), ro_elements=int(out[4]),
+                    waits=bool(out[5]), publishes=bool(out[6]), relation=int(out[7]))
 
     def trace_blocks(self, launch, **kw):
         """(entry, exit, hw id) of every workgroup of one launch (tuning aid, see dfq_le_trace_blocks)."""

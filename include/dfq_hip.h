@@ -138,6 +138,10 @@ int dfq_le_plan_level_grid(const dfq_le_plan* plan, int32_t level, int32_t* grid
  * bit-identical either way. */
 int32_t dfq_le_plan_resident_tiles(const dfq_le_plan* plan);
 const char* dfq_le_plan_resident_reason(const dfq_le_plan* plan);
+/* Streaming plans built with DFQ_LE_PERSIST=1 (an experiment, off by default): persistent workgroups of a sweep launch
+ * (each walks its share of the sweep's tiles with the next tile's data in flight); 0 when a sweep launches one workgroup
+ * per tile or the plan is resident.  DFQ_LE_SWEEP_WGS caps the number. */
+int32_t dfq_le_plan_sweep_workgroups(const dfq_le_plan* plan);
 /* Tuning aid for the persistent launch: restart, run `n_sweeps` sweeps with per-workgroup phase stamps (100 MHz wall
  * clock): out[(tile * 6 + sweep) * 12 + point] for the first 6 sweeps; points: 0 sweep start, 1 s_A solved, 2 row
  * statistics published, 3 s_B solved, 4 new values + statistics published, 5 ticket taken, 6 decision seen; point 7
@@ -177,6 +181,12 @@ int dfq_le_profile(dfq_le_plan* plan, const dfq_le_config* cfg, int32_t n_sweeps
  * modifies the weights like two ordinary sweeps. */
 int dfq_le_trace(dfq_le_plan* plan, const dfq_le_config* cfg, int32_t launch, int32_t block, void* stream,
                  int64_t* stamps16);
+
+/* Tuning aid: what workgroup `block` of launch `launch` does.  out8 = { kind (0/1/2: row tile of 16-byte vectors /
+ * scalars / one thread per row; 3/4/5: the same for column tiles), rows, columns, elements read and written,
+ * elements only read, 1 if it waits for another relation inside the launch, 1 if it publishes statistics,
+ * index of its relation in the level-sorted table }. */
+int dfq_le_plan_block_info(const dfq_le_plan* plan, int32_t launch, int32_t block, int64_t* out8);
 
 /* Tuning aid: run three sweeps and return, for EVERY workgroup b of launch `launch` during the third one,
  * out[3b] = entry and out[3b+1] = exit time (100 MHz wall clock; 0 for a workgroup that had no tile) and

@@ -157,13 +157,27 @@ def _kat_names():
     return [str(n) for n in np.load(os.path.join(GOLD, 'kat_le_pairs.npz'))['names']]
 
 
-@pytest.mark.parametrize('name', _kat_names())
-@pytest.mark.parametrize('le_engine', ['resident', 'streaming'])
-def test_layer_equalization_pairs(engine, monkeypatch, name, le_engine):
-    if le_engine == 'streaming':
+# the equalisation engines a single network can run on: the resident whole-loop launch; the streaming launch of one
+# workgroup per tile (what batched plans use); the opt-in streaming launch of persistent workgroups (DFQ_LE_PERSIST=1;
+# with 3 workgroups every workgroup walks several tiles and tiles wait for tiles of other workgroups)
+LE_ENGINES = ['resident', 'streaming', 'streaming-persistent', 'streaming-persistent-3wg']
+
+
+def _select_le_engine(monkeypatch, le_engine):
+    for k in ('DFQ_LE_RESIDENT', 'DFQ_LE_PERSIST', 'DFQ_LE_SWEEP_WGS'):
+        monkeypatch.delenv(k, raising=False)
+    if le_engine != 'resident':
         monkeypatch.setenv('DFQ_LE_RESIDENT', '0')
-    else:
-        monkeypatch.delenv('DFQ_LE_RESIDENT', raising=False)
+    if le_engine.startswith('streaming-persistent'):
+        monkeypatch.setenv('DFQ_LE_PERSIST', '1')
+    if le_engine == 'streaming-persistent-3wg':
+        monkeypatch.setenv('DFQ_LE_SWEEP_WGS', '3')
+
+
+@pytest.mark.parametrize('name', _kat_names())
+@pytest.mark.parametrize('le_engine', LE_ENGINES)
+def test_layer_equalization_pairs(engine, monkeypatch, name, le_engine):
+    _select_le_engine(monkeypatch, le_engine)
     g = np.load(os.path.join(GOLD, 'kat_le_pairs.npz'))
     signed, eps, use_bn = g['{}.cfg'.format(name)]
     use_bn = bool(use_bn)
@@ -200,14 +214,11 @@ _SHAPES = [
 
 @pytest.mark.parametrize('s1,s2', _SHAPES)
 @pytest.mark.parametrize('signed', [False, True])
-@pytest.mark.parametrize('le_engine', ['resident', 'streaming'])
+@pytest.mark.parametrize('le_engine', LE_ENGINES)
 def test_layer_equalization_shapes(engine, monkeypatch, s1, s2, signed, le_engine):
     """One sweep of one pair over the tile kinds of both equalisation engines (a single pair would always take the
     resident launch: DFQ_LE_RESIDENT=0 forces the streaming kernel), bit-exact against the oracle."""
-    if le_engine == 'streaming':
-        monkeypatch.setenv('DFQ_LE_RESIDENT', '0')
-    else:
-        monkeypatch.delenv('DFQ_LE_RESIDENT', raising=False)
+    _select_le_engine(monkeypatch, le_engine)
     rng = np.random.default_rng(abs(hash((s1, s2))) % (2 ** 31))
     w1 = rng.standard_normal(s1).astype(F32)
     w2 = (rng.standard_normal(s2) * 0.2).astype(F32)
@@ -222,13 +233,10 @@ def test_layer_equalization_shapes(engine, monkeypatch, s1, s2, signed, le_engin
         assert_bitexact(npy(got), want, what)
 
 
-@pytest.mark.parametrize('le_engine', ['resident', 'streaming'])
+@pytest.mark.parametrize('le_engine', LE_ENGINES)
 def test_layer_equalization_large_rows(engine, monkeypatch, le_engine):
     """Rows longer than a workgroup, tiles of one channel, 3x3 second layer (ResNet-like)."""
-    if le_engine == 'streaming':
-        monkeypatch.setenv('DFQ_LE_RESIDENT', '0')
-    else:
-        monkeypatch.delenv('DFQ_LE_RESIDENT', raising=False)
+    _select_le_engine(monkeypatch, le_engine)
     rng = np.random.default_rng(21)
     w1 = rng.standard_normal((70, 33, 3, 3)).astype(F32)
     w2 = (rng.standard_normal((90, 70, 3, 3)) * 0.1).astype(F32)
@@ -659,27 +667,31 @@ def test_resident_and_streaming_engines_agree(engine, monkeypatch, name, seed, s
     [O] vectors, the cumulative scales, the sweep count and the loop state must be identical bit for bit, and both
     equal the oracle."""
     out = []
-    for resident in (True, False):
-        if resident:
-            monkeypatch.delenv('DFQ_LE_RESIDENT', raising=False)
-        else:
-            monkeypatch.setenv('DFQ_LE_RESIDENT', '0')
+    for le_engine in LE_ENGINES:
+        _select_le_engine(monkeypatch, le_engine)
         model, graph, bottoms = synthetic.build(name, seed=seed)
         model.to(engine.device)
         lt.merge_batchnorm(model, graph, bottoms, TARG)
         rels = rel.create_relation(graph, bottoms, TARG)
         plan = dfq.build_le_plan(graph, rels, TARG)
-        assert (plan.resident_tiles > 0) == resident, plan.resident_reason
+        assert (plan.resident_tiles > 0) == (le_engine == 'resident'), plan.resident_reason
+        if le_engine == 'streaming-persistent':
+            assert plan.sweep_workgroups > 3
+        elif le_engine == 'streaming-persistent-3wg':
+            assert plan.sweep_workgroups == 3 and plan.level_info(0)['workgroups'] > 3
+        else:
+            assert plan.sweep_workgroups == 0
         res = plan.run(signed=signed)
         plan.stage.writeback()
         out.append((res, snapshot(graph), [npy(s) for s in plan.scale_cum]))
         plan.close()
-    (ra, sa, ca), (rb, sb, cb) = out
-    assert ra == rb, 'loop state differs: {} vs {}'.format(ra, rb)
-    for k in sa:
-        assert_bitexact(sa[k], sb[k], '{} {}'.format(name, k))
-    for a, b in zip(ca, cb):
-        assert_bitexact(a, b, 'cumulative S')
+    ra, sa, ca = out[0]
+    for le_engine, (rb, sb, cb) in zip(LE_ENGINES[1:], out[1:]):
+        assert ra == rb, '{}: loop state differs: {} vs {}'.format(le_engine, ra, rb)
+        for k in sa:
+            assert_bitexact(sa[k], sb[k], '{} {} {}'.format(le_engine, name, k))
+        for a, b in zip(ca, cb):
+            assert_bitexact(a, b, '{}: cumulative S'.format(le_engine))
 
 
 def test_resident_engine_in_chunks(engine):
