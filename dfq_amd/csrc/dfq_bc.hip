@@ -95,7 +95,7 @@ __global__ __launch_bounds__(kBlock) void bc_minmax_kernel(const BcLayerDev* __r
         for (; i + 12 * kBlock < e4; i += 16 * kBlock) {
             fvec4 v[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = *(const fvec4*)(L.w + i + u * 4 * kBlock);
+            for (int u = 0; u < 4; ++u) v[u] = kReadNt ? DFQ_NT_LOAD((const fvec4*)(L.w + i + u * 4 * kBlock)) : *(const fvec4*)(L.w + i + u * 4 * kBlock);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 mn = vmin_raw(vmin_raw(mn, v[u][0]), vmin_raw(v[u][1], vmin_raw(v[u][2], v[u][3])));
@@ -133,6 +133,13 @@ __global__ __launch_bounds__(kBlock) void bc_minmax_kernel(const BcLayerDev* __r
     }
 }
 
+// non-temporal hint on the 16-byte loads (1) / stores (2) of bc_quant_error_kernel (stores only: -1.5 % of a batch's
+// bias-correction time; both: the same within noise)
+#ifndef DFQ_BC_NT
+#define DFQ_BC_NT 2
+#endif
+constexpr int kBcNt = DFQ_BC_NT;
+
 // one thread per (o, i) pair: sequential float32 sum over kH*kW of (Q(w) - w)
 __global__ __launch_bounds__(kBlock) void bc_quant_error_kernel(const BcLayerDev* __restrict__ layers,
                                                                 const int32_t* __restrict__ block_begin,
@@ -149,11 +156,12 @@ __global__ __launch_bounds__(kBlock) void bc_quant_error_kernel(const BcLayerDev
         if (pair >= L.pairs) return;
         float code;
         if (pair + kQePairs <= L.pairs && ((((uintptr_t)L.w) | ((uintptr_t)L.eps)) & 15u) == 0) {
-            const fvec4 v = *(const fvec4*)(L.w + pair);
+            const fvec4 v = (kBcNt & 1) ? DFQ_NT_LOAD((const fvec4*)(L.w + pair)) : *(const fvec4*)(L.w + pair);
             fvec4 d;
 #pragma unroll
             for (int k = 0; k < 4; ++k) d[k] = 0.0f + (fake_quant_one(v[k], p, &code) - v[k]);
-            *(fvec4*)(L.eps + pair) = d;
+            if (kBcNt & 2) DFQ_NT_STORE(d, (fvec4*)(L.eps + pair));
+            else *(fvec4*)(L.eps + pair) = d;
         } else {
             for (int64_t q = pair; q < pair + kQePairs && q < L.pairs; ++q) {
                 const float v = L.w[q];

@@ -115,9 +115,10 @@ struct LeRelDev {
 #define DFQ_LE_ABLATE 0
 #endif
 constexpr int kAblate = DFQ_LE_ABLATE;
-// Tuning builds only: 1 = the tiles' 16-byte element loads carry the non-temporal hint, 2 = their stores do, 3 = both.
+// 1 = the tiles' 16-byte element loads carry the non-temporal hint, 2 = their stores do, 3 = both (dfq_common.hpp);
+// +4 = not the loads of the read-only passes over interior layers (the row pass of the next relation reads them again)
 #ifndef DFQ_LE_NT
-#define DFQ_LE_NT 0
+#define DFQ_LE_NT 3
 #endif
 constexpr int kNonTemporal = DFQ_LE_NT;
 
@@ -261,18 +262,14 @@ __device__ __forceinline__ double slot_abs_diff(bool on, const float (&a)[VEC], 
 }
 
 template <int VEC>
-__device__ __forceinline__ void vload(const gfloat* p, float (&x)[VEC]) {
+__device__ __forceinline__ void vload(const gfloat* p, float (&x)[VEC], bool keep = false) {
     if (kAblate & 8) {
 #pragma unroll
         for (int k = 0; k < VEC; ++k) x[k] = 1.0f + (float)k;
         return;
     }
     if (VEC == 4) {
-#if defined(__HIP_DEVICE_COMPILE__)
-        const fvec4 t = (kNonTemporal & 1) ? __builtin_nontemporal_load((const gfvec4*)p) : *(const gfvec4*)p;
-#else
-        const fvec4 t = *(const gfvec4*)p;
-#endif
+        const fvec4 t = ((kNonTemporal & 1) && !((kNonTemporal & 4) && keep)) ? DFQ_NT_LOAD((const gfvec4*)p) : *(const gfvec4*)p;
         x[0] = t[0]; x[1 % VEC] = t[1]; x[2 % VEC] = t[2]; x[3 % VEC] = t[3];
     } else {
         x[0] = *p;
@@ -284,11 +281,8 @@ __device__ __forceinline__ void vstore(gfloat* p, const float (&x)[VEC]) {
     if (VEC == 4) {
         fvec4 t;
         t[0] = x[0]; t[1] = x[1 % VEC]; t[2] = x[2 % VEC]; t[3] = x[3 % VEC];
-#if defined(__HIP_DEVICE_COMPILE__)
-        if (kNonTemporal & 2) __builtin_nontemporal_store(t, (gfvec4*)p);
-        else
-#endif
-            *(gfvec4*)p = t;
+        if (kNonTemporal & 2) DFQ_NT_STORE(t, (gfvec4*)p);
+        else *(gfvec4*)p = t;
     } else {
         *p = x[0];
     }
@@ -557,7 +551,7 @@ __device__ __forceinline__ double col_tile(const LeRelDev& R, const LeParams& p,
         for (int u = 0; u < NV; ++u) {
             if (u < n_max) {
                 const int r = min(grp + u * n_rowslots, nr - 1);
-                vload<VEC>(w + r * row_len2, v[u]);
+                vload<VEC>(w + r * row_len2, v[u], stat_only);
             }
         }
     }

@@ -12,5 +12,8 @@ for f in sys.argv[1:]:
             r.get('us_per_launch', 0), r.get('achieved', 0), r.get('frac', 0), r.get('sweep_wall_us', 0),
             r.get('control_us_per_sweep', 0),
             ' '.join('%.1f' % l['us'] for l in r.get('levels', []))))
+        ar = d['config'].get('activation_ranges')
+        if ar:
+            print('    act: ' + ' '.join('%s %.1f us' % (k['kernel'] if isinstance(k, dict) and 'kernel' in k else str(i), k.get('us', 0)) for i, k in enumerate(ar if isinstance(ar, list) else ar.get('kernels', []))))
     except Exception as e:
         print(f, 'failed', e)
