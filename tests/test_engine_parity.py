@@ -571,6 +571,73 @@ def test_one_launch_sweep_is_stable_against_per_level_launches(monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('persist', ['0', '1'])
+def test_two_host_threads_two_streams(monkeypatch, persist):
+    """Two host threads feed two HIP streams with batched equalisation + bias correction at full size, as bench.py does.
+    Launches with in-launch waits from different streams must never overlap (SpinGuard holds its mutex from the stream
+    wait to the event record); with DFQ_LE_PERSIST=1 every sweep launch also needs all its workgroups resident.
+    Every network must end exactly where the same batch ends on one stream."""
+    import threading
+    dev = torch.device('cuda', 0)
+    monkeypatch.setenv('DFQ_LE_PERSIST', persist)
+
+    def make(seed0):
+        items = []
+        for seed in range(seed0, seed0 + 8):
+            model, graph, bottoms = synthetic.build('mobilenet_v2', seed=seed)
+            model.to(dev)
+            lt.merge_batchnorm(model, graph, bottoms, TARG)
+            items.append((graph, bottoms, rel.create_relation(graph, bottoms, TARG)))
+        le = dfq.build_le_plan_batch([(g, r) for g, _, r in items], TARG)
+        bc = dfq.build_bc_plan_batch([(g, b) for g, b, _ in items], TARG)
+        assert (le.sweep_workgroups > 0) == (persist == '1')
+        return items, le, bc
+
+    def work(unit):
+        items, le, bc = unit
+        le.enqueue(0, restart=True)
+        le.enqueue(47, restart=False)
+        bc.run()
+
+    ref_units = [make(0), make(8)]
+    for u in ref_units:
+        work(u)
+    torch.cuda.synchronize()
+    ref = [([r['sweeps'] for r in u[1].query_all()[0]], [snapshot(g) for g, _, _ in u[0]]) for u in ref_units]
+    assert max(ref[0][0]) == 47 and min(ref[0][0]) >= 40
+
+    for rep in range(2):
+        units = [make(0), make(8), make(0), make(8)]
+        streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+        errors = []
+
+        def worker(i):
+            try:
+                torch.cuda.set_device(dev)
+                with torch.cuda.stream(streams[i]):
+                    for u in units[i::2]:
+                        work(u)
+            except Exception as e:      # surfaced below: an exception in a thread would otherwise pass silently
+                errors.append(e)
+        threads = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        torch.cuda.synchronize()
+        assert not errors, errors
+        for j, u in enumerate(units):
+            sweeps_ref, snaps_ref = ref[j % 2]
+            with torch.cuda.stream(streams[j % 2]):
+                assert [r['sweeps'] for r in u[1].query_all()[0]] == sweeps_ref      # also surfaces an abandoned wait
+                u[2].status()
+            for (g, _, _), b in zip(u[0], snaps_ref):
+                a = snapshot(g)
+                for k in b:
+                    assert_bitexact(a[k], b[k], 'repetition {} unit {} {}'.format(rep, j, k))
+
+
+@pytest.mark.gpu
 def test_heterogeneous_full_size_batch_matches_single_plans():
     """One batched plan over DIFFERENT architectures at full size (MobileNetV2, ResNet-18, a second MobileNetV2
     with other weights): every network must end bit-identical to a plan of its own -- weights, cumulative scales,
@@ -692,6 +759,28 @@ def test_resident_and_streaming_engines_agree(engine, monkeypatch, name, seed, s
             assert_bitexact(sa[k], sb[k], '{} {} {}'.format(le_engine, name, k))
         for a, b in zip(ca, cb):
             assert_bitexact(a, b, '{}: cumulative S'.format(le_engine))
+
+
+def test_block_info_accounts_for_every_element(engine, monkeypatch):
+    """dfq_le_plan_block_info (tuning aid): the workgroups of a sweep launch cover every element the plan says a sweep
+    reads and writes / only reads, exactly once."""
+    monkeypatch.setenv('DFQ_LE_RESIDENT', '0')
+    for name in ('tiny_mobile', 'tiny_res', 'tiny_cat'):
+        model, graph, bottoms = synthetic.build(name, seed=0)
+        model.to(engine.device)
+        lt.merge_batchnorm(model, graph, bottoms, TARG)
+        rels = rel.create_relation(graph, bottoms, TARG)
+        plan = dfq.build_le_plan(graph, rels, TARG)
+        rw = ro = 0
+        for launch in range(plan.levels):
+            for b in range(plan.level_info(launch)['workgroups']):
+                info = plan.block_info(launch, b)
+                assert 0 <= info['kind'] <= 5 and info['rows'] > 0 and info['cols'] > 0
+                assert info['rw_elements'] + info['ro_elements'] == info['rows'] * info['cols']
+                rw += info['rw_elements']
+                ro += info['ro_elements']
+        assert (rw, ro) == (plan.rw_elements, plan.ro_elements), name
+        plan.close()
 
 
 def test_resident_engine_in_chunks(engine):
