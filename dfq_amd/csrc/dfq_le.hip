@@ -70,6 +70,7 @@ constexpr int kColTileLanes = 64;      // vector positions of a col tile (one wa
 constexpr int kSlotMax = 1024;         // LDS table entries of a tile (stat slots / 1/s table)
 constexpr int kShortChunk = 9;          // taps a thread-per-row tile keeps in flight (one 3x3 kernel)
 constexpr int kBootTc = 64;            // channels per bootstrap tile
+constexpr int kBootWork = 16384;       // elements per pass a bootstrap workgroup streams at most (larger blocks are split)
 constexpr int kCtlBlock = 1024;        // threads of the control kernel
 constexpr int kCtlStage = 6144;        // partials staged in LDS by the control kernel
 
@@ -99,7 +100,8 @@ struct LeRelDev {
     int32_t w2_interior;    // W2 is also the first layer of a later relation: its column pass only takes statistics
     int32_t partial_base;   // first partial slot of this relation (row tiles, then col tiles)
     int32_t boot_begin;     // first workgroup inside the bootstrap launch
-    int32_t boot_tiles;
+    int32_t boot_tiles;     // channel blocks x boot_split
+    int32_t boot_split;     // workgroups that share one block of kBootTc channels (long rows / tall columns are cut up)
     int32_t net;            // which network of a batched plan (index into the loop-state array)
     // one launch per sweep: the tiles of this relation may start once the column tiles of the relation that
     // produces its row statistics have finished -- dep_counter >= dep_tiles * (sweep + 1)
@@ -1008,7 +1010,11 @@ __global__ __launch_bounds__(kBlock) void le_bootstrap_kernel(const LeRelDev* __
     __shared__ uint32_t sh_mn1[kBootTc], sh_mx1[kBootTc], sh_mn2[kBootTc], sh_mx2[kBootTc];
     const LeRelDev R = rels[rel_of_block[blockIdx.x]];
     const int tid = threadIdx.x;
-    const int c0 = (blockIdx.x - R.boot_begin) * kBootTc;
+    // a block of kBootTc channels is shared by boot_split workgroups: each takes a slice of the rows' elements and a slice of
+    // the second layer's rows, and merges into the (zeroed) statistics words with atomicMax
+    const int local = (int)blockIdx.x - R.boot_begin;
+    const int cb = local / R.boot_split, sp = local - cb * R.boot_split;
+    const int c0 = cb * kBootTc;
     const int nc = min(kBootTc, R.o1 - c0);
     if (tid < nc) { sh_mn1[tid] = 0u; sh_mx1[tid] = 0u; sh_mn2[tid] = 0u; sh_mx2[tid] = 0u; }
     __syncthreads();
@@ -1016,17 +1022,19 @@ __global__ __launch_bounds__(kBlock) void le_bootstrap_kernel(const LeRelDev* __
     if (need_rows) {
         const float* rows = R.w1 + (int64_t)c0 * R.row_len;
         const int64_t total = (int64_t)nc * R.row_len;
-        int q = tid / R.row_len, rem = tid - q * R.row_len, cq = q;
+        const int64_t piece = (total + R.boot_split - 1) / R.boot_split;
+        const int64_t lo = (int64_t)sp * piece, hi = min(total, lo + piece);
+        int q = (int)((lo + tid) / R.row_len), rem = (int)((lo + tid) - (int64_t)q * R.row_len), cq = q;
         const int dq = kBlock / R.row_len, dr = kBlock - dq * R.row_len;
         float mn = INFINITY, mx = -INFINITY;
         // eight loads in flight per lane (one at a time, a 64-row block of a wide layer is ~40 dependent round trips)
-        for (int64_t e0 = tid; e0 < total; e0 += 8 * kBlock) {
+        for (int64_t e0 = lo + tid; e0 < hi; e0 += 8 * kBlock) {
             float v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = rows[min(e0 + (int64_t)u * kBlock, total - 1)];
+            for (int u = 0; u < 8; ++u) v[u] = rows[min(e0 + (int64_t)u * kBlock, hi - 1)];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                if (e0 + (int64_t)u * kBlock < total) {
+                if (e0 + (int64_t)u * kBlock < hi) {
                     if (q != cq) {
                         atomicMax(&sh_mn1[cq], ~enc_ord(mn)); atomicMax(&sh_mx1[cq], enc_ord(mx));
                         mn = INFINITY; mx = -INFINITY; cq = q;
@@ -1039,6 +1047,9 @@ __global__ __launch_bounds__(kBlock) void le_bootstrap_kernel(const LeRelDev* __
         }
         if (mn <= mx) { atomicMax(&sh_mn1[cq], ~enc_ord(mn)); atomicMax(&sh_mx1[cq], enc_ord(mx)); }
     }
+    // this workgroup's rows of the second layer (of every group's go rows)
+    const int j_piece = (R.go + R.boot_split - 1) / R.boot_split;
+    const int j_lo = sp * j_piece, j_hi = min(R.go, j_lo + j_piece);
     const bool wide_cols = R.khkw == 1 && (R.gi % kBootTc) == 0 && (R.i2g % 4) == 0 && (nc % 4) == 0 &&
                            (((uintptr_t)R.w2) & 15u) == 0;
     if (wide_cols) {
@@ -1054,8 +1065,8 @@ __global__ __launch_bounds__(kBlock) void le_bootstrap_kernel(const LeRelDev* __
         float cmn[4], cmx[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) { cmn[k] = INFINITY; cmx[k] = -INFINITY; }
-        int j = rg;
-        for (; j + 7 * 16 < R.go; j += 8 * 16) {
+        int j = j_lo + rg;
+        for (; j + 7 * 16 < j_hi; j += 8 * 16) {
             fvec4 v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) v[u] = *(const fvec4*)(colp + (int64_t)(j + u * 16) * R.i2g);
@@ -1065,12 +1076,12 @@ __global__ __launch_bounds__(kBlock) void le_bootstrap_kernel(const LeRelDev* __
                 for (int k = 0; k < 4; ++k) { cmn[k] = vmin_raw(cmn[k], v[u][k]); cmx[k] = vmax_raw(cmx[k], v[u][k]); }
             }
         }
-        for (; j < R.go; j += 16) {
+        for (; j < j_hi; j += 16) {
             const fvec4 v = *(const fvec4*)(colp + (int64_t)j * R.i2g);
 #pragma unroll
             for (int k = 0; k < 4; ++k) { cmn[k] = vmin_raw(cmn[k], v[k]); cmx[k] = vmax_raw(cmx[k], v[k]); }
         }
-        if (on && rg < R.go) {
+        if (on && j_lo + rg < j_hi) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) { atomicMax(&sh_mn2[4 * lane4 + k], ~enc_ord(cmn[k])); atomicMax(&sh_mx2[4 * lane4 + k], enc_ord(cmx[k])); }
         }
@@ -1090,15 +1101,15 @@ __global__ __launch_bounds__(kBlock) void le_bootstrap_kernel(const LeRelDev* __
                 const float* col = R.w2 + ((int64_t)g * R.go * R.i2g + ii) * R.khkw + k;
                 float mn = INFINITY, mx = -INFINITY;
                 // eight rows per trip: the loads are independent, so eight are in flight instead of one
-                int j = jl;
-                for (; j + 7 * JL < R.go; j += 8 * JL) {
+                int j = j_lo + jl;
+                for (; j + 7 * JL < j_hi; j += 8 * JL) {
                     float v[8];
 #pragma unroll
                     for (int u = 0; u < 8; ++u) v[u] = col[(int64_t)(j + u * JL) * col_stride];
 #pragma unroll
                     for (int u = 0; u < 8; ++u) { mn = fminf(mn, v[u]); mx = fmaxf(mx, v[u]); }
                 }
-                for (; j < R.go; j += JL) {
+                for (; j < j_hi; j += JL) {
                     const float v = col[(int64_t)j * col_stride];
                     mn = fminf(mn, v); mx = fmaxf(mx, v);
                 }
@@ -1109,8 +1120,13 @@ __global__ __launch_bounds__(kBlock) void le_bootstrap_kernel(const LeRelDev* __
     __syncthreads();
     if (tid < nc) {
         const int c = c0 + tid;
-        if (need_rows) { R.r1[2 * c + 0] = sh_mn1[tid]; R.r1[2 * c + 1] = sh_mx1[tid]; }
-        R.r2[2 * c + 0] = sh_mn2[tid]; R.r2[2 * c + 1] = sh_mx2[tid];
+        if (R.boot_split == 1) {
+            if (need_rows) { R.r1[2 * c + 0] = sh_mn1[tid]; R.r1[2 * c + 1] = sh_mx1[tid]; }
+            R.r2[2 * c + 0] = sh_mn2[tid]; R.r2[2 * c + 1] = sh_mx2[tid];
+        } else {
+            if (need_rows) { atomicMax(&R.r1[2 * c + 0], sh_mn1[tid]); atomicMax(&R.r1[2 * c + 1], sh_mx1[tid]); }
+            atomicMax(&R.r2[2 * c + 0], sh_mn2[tid]); atomicMax(&R.r2[2 * c + 1], sh_mx2[tid]);
+        }
     }
 }
 
@@ -1466,7 +1482,18 @@ int dfq_le_plan_create_batch(const dfq_layer* layers, int32_t n_layers, const in
         while (d.ct_rows > 1 && (ceil_div(d.ct_rows, d.go) + 1) * nci2 > kSlotMax) d.ct_rows = (d.ct_rows + 1) / 2;
         if ((ceil_div(d.ct_rows, d.go) + 1) * nci2 > kSlotMax)
             return (dfq_le_plan_destroy(p), fail_arg("dfq_le_plan_create: relation %d: kernel size too small for its width", r));
-        d.boot_tiles = ceil_div(d.o1, kBootTc);
+        {
+            // a workgroup of the bootstrap launch streams ~kBootWork elements at most: a block of 64 channels of a 3x3 layer
+            // with 512 of them is 295 000 elements per pass -- 30 workgroups, 227 us for the whole of ResNet-18 before the split
+            const int nc = std::min(kBootTc, d.o1);
+            const int64_t rows_work = (as_second[rr.first] < 0) ? (int64_t)nc * d.row_len : 0;
+            const int64_t cols_work = (int64_t)nc * d.khkw * d.go;
+            const char* be = getenv("DFQ_LE_BOOT_WORK");          // tests: split small layers too
+            const int64_t unit = (be && atoi(be) > 0) ? atoi(be) : kBootWork;
+            const int64_t want = (std::max(rows_work, cols_work) + unit - 1) / unit;
+            d.boot_split = (int)std::max<int64_t>(1, std::min<int64_t>(want, std::min<int64_t>(64, std::max(1, be ? d.go : d.go / 16))));
+        }
+        d.boot_tiles = ceil_div(d.o1, kBootTc) * d.boot_split;
         d.net = net_of(rr.first);
     }
     // producer links + slot limits need every relation's geometry, so a second pass

@@ -307,12 +307,17 @@ def test_pipeline_stages(engine, name, seed, suffix):
     compare_stage(snapshot(graph), gold, 'q', exact=True, what=name)
 
 
-@pytest.mark.parametrize('tile_elems', [48, 500])
+@pytest.mark.parametrize('tile_elems,boot_work', [(48, None), (500, None), (500, 40), (None, 7)])
 @pytest.mark.parametrize('name,seed,suffix', [('tiny_mobile', 2, '_signed'), ('tiny_cat', 0, ''), ('tiny_res', 0, '')])
-def test_equalization_tile_shapes(engine, monkeypatch, name, seed, suffix, tile_elems):
-    """Small tiles force many row slabs / row blocks / col tiles per relation: the result may not
-    depend on the decomposition (min/max and the scale solve are exact)."""
-    monkeypatch.setenv('DFQ_LE_TILE_ELEMS', str(tile_elems))
+def test_equalization_tile_shapes(engine, monkeypatch, name, seed, suffix, tile_elems, boot_work):
+    """Small tiles force many row slabs / row blocks / col tiles per relation, a small bootstrap work unit makes several
+    workgroups share a block of channels (their statistics merge through atomicMax): the result may not depend on the
+    decomposition (min/max and the scale solve are exact).  Streaming engine (the resident launch has its own tiling)."""
+    monkeypatch.setenv('DFQ_LE_RESIDENT', '0')
+    if tile_elems:
+        monkeypatch.setenv('DFQ_LE_TILE_ELEMS', str(tile_elems))
+    if boot_work:
+        monkeypatch.setenv('DFQ_LE_BOOT_WORK', str(boot_work))
     gold = net_fixture(name, seed, suffix)
     signed = bool(gold['cfg'][1])
     model, graph, bottoms = _build(name, seed, gold, engine)
