@@ -1311,6 +1311,14 @@ static int emit_cols_max(int vec) {
     return v > 0 ? v : (vec == 4 ? 64 : 32);
 }
 
+// columns of a row tile that publishes nothing (a row's scale is all it needs): DFQ_LE_ROW_COLS overrides (tuning; at
+// most 1024 floats = 256 lanes x 16 bytes)
+static int plain_row_cols_max(int vec) {
+    const char* e = getenv("DFQ_LE_ROW_COLS");
+    const int v = e ? atoi(e) : 0;
+    if (v > 0) return std::min(v, vec == 4 ? 1024 : 256);
+    return kRowTileColsMax * (vec == 4 ? 2 : 1);
+}
 static int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
 // [rows x cols] tiling of a [n_rows, row_len] matrix whose tiles move `vec`-wide vectors:
@@ -1469,7 +1477,7 @@ int dfq_le_plan_create_batch(const dfq_layer* layers, int32_t n_layers, const in
         d.ct_vec = (row_len2 % 4 == 0 && ((uintptr_t)B.weight & 15u) == 0) ? 4 : 1;
         const bool emits_cols = as_second[rr.first] >= 0;
         tile_shape(d.o1, d.row_len, d.rt_vec,
-                   emits_cols ? emit_cols_max(d.rt_vec) : kRowTileColsMax * (d.rt_vec == 4 ? 2 : 1), false, target,
+                   emits_cols ? emit_cols_max(d.rt_vec) : plain_row_cols_max(d.rt_vec), false, target,
                    &d.rt_rows, &d.rt_cols, &d.rt_slabs);
         tile_shape(d.o2, row_len2, d.ct_vec, kColTileLanes * d.ct_vec, true, target,
                    &d.ct_rows, &d.ct_cols, &d.ct_slabs);
