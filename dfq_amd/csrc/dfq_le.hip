@@ -69,7 +69,11 @@ constexpr int kRowTileColsMax = 128;   // positions of a row tile (x2 for float4
 constexpr int kColTileLanes = 64;      // vector positions of a col tile (one wave per row at most)
 constexpr int kSlotMax = 1024;         // LDS table entries of a tile (stat slots / 1/s table)
 constexpr int kShortChunk = 9;          // taps a thread-per-row tile keeps in flight (one 3x3 kernel)
-constexpr int kBootTc = 64;            // channels per bootstrap tile
+constexpr int kBootTc = 256;           // channels per bootstrap tile (1 KB of a pointwise second layer's row)
+#ifndef DFQ_BOOT_ABLATE
+#define DFQ_BOOT_ABLATE 0
+#endif
+constexpr int kBootAblate = DFQ_BOOT_ABLATE;   // tuning builds: 1 no row pass, 2 no wide column pass, 4 no generic column pass
 constexpr int kBootWork = 16384;       // elements per pass a bootstrap workgroup streams at most (larger blocks are split)
 constexpr int kCtlBlock = 1024;        // threads of the control kernel
 constexpr int kCtlStage = 6144;        // partials staged in LDS by the control kernel
@@ -1019,64 +1023,122 @@ __global__ __launch_bounds__(kBlock) void le_bootstrap_kernel(const LeRelDev* __
     if (tid < nc) { sh_mn1[tid] = 0u; sh_mx1[tid] = 0u; sh_mn2[tid] = 0u; sh_mx2[tid] = 0u; }
     __syncthreads();
     const bool need_rows = R.out_cols == nullptr;      // chain start: nobody else produces R1
-    if (need_rows) {
+    if (need_rows && !(kBootAblate & 1)) {
+        // Rows of the first layer: G = pow2 >= (vectors per row) lanes, at most one wave, share a row; 256/G rows are in
+        // flight per trip and a row's min/max is reduced inside its lanes with register-file butterflies -- one plain LDS
+        // store per row.  (The first version walked the block's elements linearly and merged into LDS with an atomicMax pair
+        // whenever a lane's row changed: for 16..160-float rows that is every element, and the row pass was 210 of the
+        // launch's 280 us for a batch of 32.)  The boot_split workgroups of a block take disjoint rows.
+        const int r_piece = (nc + R.boot_split - 1) / R.boot_split;
+        const int r_lo = sp * r_piece, r_hi = min(nc, r_lo + r_piece);
+        const bool vec = (R.row_len % 4) == 0 && (((uintptr_t)R.w1) & 15u) == 0;
+        const int npv = vec ? R.row_len / 4 : R.row_len;              // positions of a row
+        int lgG = 0;
+        while ((1 << lgG) < npv && lgG < 6) ++lgG;
+        const int G = 1 << lgG, n_rg = kBlock >> lgG;
+        const int ln = tid & (G - 1), rg = tid >> lgG;
         const float* rows = R.w1 + (int64_t)c0 * R.row_len;
-        const int64_t total = (int64_t)nc * R.row_len;
-        const int64_t piece = (total + R.boot_split - 1) / R.boot_split;
-        const int64_t lo = (int64_t)sp * piece, hi = min(total, lo + piece);
-        int q = (int)((lo + tid) / R.row_len), rem = (int)((lo + tid) - (int64_t)q * R.row_len), cq = q;
-        const int dq = kBlock / R.row_len, dr = kBlock - dq * R.row_len;
-        float mn = INFINITY, mx = -INFINITY;
-        // eight loads in flight per lane (one at a time, a 64-row block of a wide layer is ~40 dependent round trips)
-        for (int64_t e0 = lo + tid; e0 < hi; e0 += 8 * kBlock) {
-            float v[8];
+        if (npv <= G) {
+            // short rows: eight rows per trip
+            const bool on = ln < npv;
+            const int pos = (on ? ln : 0) * (vec ? 4 : 1);
+            for (int rb = r_lo; rb < r_hi; rb += 8 * n_rg) {          // uniform trip count: the butterflies below are wave-wide
+                const int r0 = rb + rg;
+                float mn[8], mx[8];
+                if (vec) {
+                    fvec4 v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = rows[min(e0 + (int64_t)u * kBlock, hi - 1)];
+                    for (int u = 0; u < 8; ++u) v[u] = *(const fvec4*)(rows + (int64_t)min(r0 + u * n_rg, r_hi - 1) * R.row_len + pos);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                if (e0 + (int64_t)u * kBlock < hi) {
-                    if (q != cq) {
-                        atomicMax(&sh_mn1[cq], ~enc_ord(mn)); atomicMax(&sh_mx1[cq], enc_ord(mx));
-                        mn = INFINITY; mx = -INFINITY; cq = q;
+                    for (int u = 0; u < 8; ++u) {
+                        mn[u] = vmin_raw(vmin_raw(v[u][0], v[u][1]), vmin_raw(v[u][2], v[u][3]));
+                        mx[u] = vmax_raw(vmax_raw(v[u][0], v[u][1]), vmax_raw(v[u][2], v[u][3]));
                     }
-                    mn = fminf(mn, v[u]); mx = fmaxf(mx, v[u]);
-                    q += dq; rem += dr;
-                    if (rem >= R.row_len) { rem -= R.row_len; ++q; }
+                } else {
+                    float v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = rows[(int64_t)min(r0 + u * n_rg, r_hi - 1) * R.row_len + pos];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { mn[u] = v[u]; mx[u] = v[u]; }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (!on) { mn[u] = INFINITY; mx[u] = -INFINITY; }
+                    if (G > 1) xor_lane_minmax<1>(mn[u], mx[u]);
+                    if (G > 2) xor_lane_minmax<2>(mn[u], mx[u]);
+                    if (G > 4) xor_lane_minmax<4>(mn[u], mx[u]);
+                    if (G > 8) xor_lane_minmax<8>(mn[u], mx[u]);
+                    if (G > 16) xor_lane_minmax<16>(mn[u], mx[u]);
+                    if (G > 32) xor_lane_minmax<32>(mn[u], mx[u]);
+                    const int r = r0 + u * n_rg;
+                    if (ln == 0 && r < r_hi) { sh_mn1[r] = ~enc_ord(mn[u]); sh_mx1[r] = enc_ord(mx[u]); }
                 }
             }
+        } else {
+            // long rows (more than one wave of positions): a wave per row, eight positions per trip
+            for (int r = r_lo + rg; r < r_hi; r += n_rg) {
+                const float* row = rows + (int64_t)r * R.row_len;
+                float mn = INFINITY, mx = -INFINITY;
+                for (int p0 = ln; p0 < npv; p0 += 8 * G) {
+                    if (vec) {
+                        fvec4 v[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) v[u] = *(const fvec4*)(row + 4 * min(p0 + u * G, npv - 1));
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {          // positions past the row repeat its last vector: harmless
+                            mn = vmin_raw(vmin_raw(mn, v[u][0]), vmin_raw(v[u][1], vmin_raw(v[u][2], v[u][3])));
+                            mx = vmax_raw(vmax_raw(mx, v[u][0]), vmax_raw(v[u][1], vmax_raw(v[u][2], v[u][3])));
+                        }
+                    } else {
+                        float v[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) v[u] = row[min(p0 + u * G, npv - 1)];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) { mn = vmin_raw(mn, v[u]); mx = vmax_raw(mx, v[u]); }
+                    }
+                }
+                xor_lane_minmax<1>(mn, mx); xor_lane_minmax<2>(mn, mx); xor_lane_minmax<4>(mn, mx);
+                xor_lane_minmax<8>(mn, mx); xor_lane_minmax<16>(mn, mx); xor_lane_minmax<32>(mn, mx);
+                if (ln == 0) { sh_mn1[r] = ~enc_ord(mn); sh_mx1[r] = enc_ord(mx); }
+            }
         }
-        if (mn <= mx) { atomicMax(&sh_mn1[cq], ~enc_ord(mn)); atomicMax(&sh_mx1[cq], enc_ord(mx)); }
     }
     // this workgroup's rows of the second layer (of every group's go rows)
     const int j_piece = (R.go + R.boot_split - 1) / R.boot_split;
     const int j_lo = sp * j_piece, j_hi = min(R.go, j_lo + j_piece);
-    const bool wide_cols = R.khkw == 1 && (R.gi % kBootTc) == 0 && (R.i2g % 4) == 0 && (nc % 4) == 0 &&
-                           (((uintptr_t)R.w2) & 15u) == 0;
-    if (wide_cols) {
-        // pointwise / linear second layer: 16 lanes x float4 cover the block's 64 input channels of one row, 16 row groups per
-        // workgroup, eight 16-byte loads in flight per lane (the generic path below reads one float per lane and row: 256-byte
-        // segments, one load in flight per 4 bytes -- it ran at ~1.7 TB/s)
+    // (the block's channels must lie in ONE group of the second layer: always true for an ungrouped layer)
+    const bool wide_cols = R.khkw == 1 && c0 / R.gi == (c0 + nc - 1) / R.gi && (R.i2g % 4) == 0 && (nc % 4) == 0 &&
+                           ((c0 - (c0 / R.gi) * R.gi) % 4) == 0 && (((uintptr_t)R.w2) & 15u) == 0;
+    if (wide_cols && (kBootAblate & 2)) {
+    } else if (wide_cols) {
+        // pointwise / linear second layer: G = pow2 >= nc/4 lanes x float4 cover the block's input channels of one row (up to
+        // 1 KB contiguous; a layer with <= 256 input channels is read front to back), 256/G row groups per workgroup, eight
+        // 16-byte loads in flight per lane.  (One float per lane and row ran at ~1.7 TB/s; 64-channel blocks = 256-byte
+        // pieces at 2.3 TB/s whatever the number of workgroups.)
         const int g = c0 / R.gi;
         const int ii0 = c0 - g * R.gi;
         const float* base = R.w2 + ((int64_t)g * R.go * R.i2g + ii0);
-        const int lane4 = tid & 15, rg = tid >> 4;
+        int lgG = 0;
+        while ((4 << lgG) < nc) ++lgG;
+        const int n_rg = kBlock >> lgG;
+        const int lane4 = tid & ((1 << lgG) - 1), rg = tid >> lgG;
         const bool on = 4 * lane4 < nc;
         const float* colp = base + 4 * (on ? lane4 : 0);
         float cmn[4], cmx[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) { cmn[k] = INFINITY; cmx[k] = -INFINITY; }
         int j = j_lo + rg;
-        for (; j + 7 * 16 < j_hi; j += 8 * 16) {
+        for (; j + 7 * n_rg < j_hi; j += 8 * n_rg) {
             fvec4 v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = *(const fvec4*)(colp + (int64_t)(j + u * 16) * R.i2g);
+            for (int u = 0; u < 8; ++u) v[u] = *(const fvec4*)(colp + (int64_t)(j + u * n_rg) * R.i2g);
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) { cmn[k] = vmin_raw(cmn[k], v[u][k]); cmx[k] = vmax_raw(cmx[k], v[u][k]); }
             }
         }
-        for (; j < j_hi; j += 16) {
+        for (; j < j_hi; j += n_rg) {
             const fvec4 v = *(const fvec4*)(colp + (int64_t)j * R.i2g);
 #pragma unroll
             for (int k = 0; k < 4; ++k) { cmn[k] = vmin_raw(cmn[k], v[k]); cmx[k] = vmax_raw(cmx[k], v[k]); }
@@ -1085,7 +1147,7 @@ __global__ __launch_bounds__(kBlock) void le_bootstrap_kernel(const LeRelDev* __
 #pragma unroll
             for (int k = 0; k < 4; ++k) { atomicMax(&sh_mn2[4 * lane4 + k], ~enc_ord(cmn[k])); atomicMax(&sh_mx2[4 * lane4 + k], enc_ord(cmx[k])); }
         }
-    } else {
+    } else if (!(kBootAblate & 4)) {
         const int P = nc * R.khkw;
         const int JL = (P >= kBlock) ? 1 : (kBlock / P);
         const int jl = (P >= kBlock) ? 0 : (tid / P);
@@ -1499,7 +1561,7 @@ int dfq_le_plan_create_batch(const dfq_layer* layers, int32_t n_layers, const in
             const char* be = getenv("DFQ_LE_BOOT_WORK");          // tests: split small layers too
             const int64_t unit = (be && atoi(be) > 0) ? atoi(be) : kBootWork;
             const int64_t want = (std::max(rows_work, cols_work) + unit - 1) / unit;
-            d.boot_split = (int)std::max<int64_t>(1, std::min<int64_t>(want, std::min<int64_t>(64, std::max(1, be ? d.go : d.go / 16))));
+            d.boot_split = (int)std::max<int64_t>(1, std::min<int64_t>(want, std::min<int64_t>(64, std::max(1, be ? d.go : d.go / 8))));
         }
         d.boot_tiles = ceil_div(d.o1, kBootTc) * d.boot_split;
         d.net = net_of(rr.first);

@@ -209,6 +209,9 @@ _SHAPES = [
     ((130, 516), (9, 130)),                 # linear -> linear
     ((128, 12, 1, 1), (200, 128, 1, 1)),    # 128 paired channels, pointwise second layer: the bootstrap's wide-column path
     ((320, 16, 1, 1), (37, 320, 1, 1)),     # ... with a partial last channel block (320 = 5 x 64)
+    ((144, 24, 1, 1), (24, 144, 1, 1)),     # ... 144 = 64 + 64 + 16 paired channels (not a multiple of the block)
+    ((24, 8, 1, 1), (144, 24, 1, 1)),       # ... fewer channels than one block
+    ((96, 12, 1, 1), (64, 48, 1, 1)),       # grouped pointwise second layer (groups = 2): blocks straddle a group -> generic path
 ]
 
 

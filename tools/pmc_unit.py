@@ -17,6 +17,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--batch', type=int, default=32)
 ap.add_argument('--sweeps', type=int, default=4)
 ap.add_argument('--net', default='mobilenet_v2')
+ap.add_argument('--restarts', type=int, default=1, help='repeat the restart (bootstrap launch) this many times')
 args = ap.parse_args()
 dev = torch.device('cuda', 0)
 protos = [bench.prepare(args.net, seed=i, dev=dev) for i in range(args.batch)]
@@ -27,6 +28,8 @@ if args.batch == 1:
 else:
     le = dfq.build_le_plan_batch([(g, r) for (_, g, _, r) in protos], bench.TARG)
     bc = dfq.build_bc_plan_batch([(g, b) for (_, g, b, _) in protos], bench.TARG)
+for _ in range(args.restarts - 1):
+    le.enqueue(0, restart=True, max_sweeps=args.sweeps, converge_thres=-1.0, converge_count=10 ** 9)
 le.enqueue(args.sweeps, restart=True, max_sweeps=args.sweeps, converge_thres=-1.0, converge_count=10 ** 9)
 bc.run()
 torch.cuda.synchronize()
