@@ -2,7 +2,7 @@
 # A/B of library builds on ONE GPU box: the in-tree library against every variants/libdfq_hip_*.so, two rounds.
 # usage: tools/ab_variants.sh [bench flags]
 mkdir -p gpurun_out
-FLAGS="--steps 6 --warmup 2 --cpu-seconds 0 --others= --sharded= $*"
+FLAGS="--steps 6 --warmup 2 --cpu-seconds 0 --others= --act-shape= --sharded= --streams 1 $*"
 for round in 1 2; do
   for lib in dfq_amd/libdfq_hip.so variants/libdfq_hip_*.so; do
     [ -f $lib ] || continue
