@@ -236,6 +236,61 @@ def test_layer_equalization_shapes(engine, monkeypatch, s1, s2, signed, le_engin
         assert_bitexact(npy(got), want, what)
 
 
+def _random_pair(rng):
+    """A random valid pairing (dfq.py:29-35): first layer [O1, I1/g1, k1, k1] or linear, second layer conv (possibly grouped,
+    depthwise, with channel multiplier) or linear."""
+    kind = rng.integers(0, 5)
+    k1 = int(rng.choice([1, 1, 3]))
+    i1 = int(rng.integers(1, 40))
+    if kind == 0:        # dense -> dense
+        o1 = int(rng.integers(1, 300))
+        o2 = int(rng.integers(1, 120))
+        k2 = int(rng.choice([1, 1, 3]))
+        return (o1, i1, k1, k1), (o2, o1, k2, k2)
+    if kind == 1:        # -> depthwise with channel multiplier m
+        o1 = int(rng.integers(1, 300))
+        m = int(rng.choice([1, 1, 2]))
+        k2 = int(rng.choice([3, 5]))
+        return (o1, i1, k1, k1), (o1 * m, 1, k2, k2)
+    if kind == 2:        # depthwise first layer -> pointwise
+        o1 = int(rng.integers(1, 300))
+        k = int(rng.choice([3, 5]))
+        return (o1, 1, k, k), (int(rng.integers(1, 100)), o1, 1, 1)
+    if kind == 3:        # grouped second layer
+        g = int(rng.choice([2, 3, 4]))
+        per = int(rng.integers(1, 50))
+        o1 = g * per
+        return (o1, i1, k1, k1), (g * int(rng.integers(1, 20)), per, 1, 1)
+    o1 = int(rng.integers(1, 400))      # linear -> linear, rows of any length
+    return (o1, int(rng.integers(1, 1500))), (int(rng.integers(1, 60)), o1)
+
+
+@pytest.mark.parametrize('le_engine,boot_work', [('resident', None), ('streaming', None), ('streaming', 50)])
+def test_layer_equalization_random_geometries(engine, monkeypatch, le_engine, boot_work):
+    """Random pairings (60 per engine on the GPU, 10 on the CPU emulation, which is slow) -- odd sizes, rows shorter than a vector and longer than a wave of vectors, fewer
+    channels than a bootstrap block and several blocks, slices of a block shared by several workgroups -- bit-exact against
+    the oracle, three sweeps each (the second and third use the statistics the first one forwarded)."""
+    _select_le_engine(monkeypatch, le_engine)
+    if boot_work:
+        monkeypatch.setenv('DFQ_LE_BOOT_WORK', str(boot_work))
+    rng = np.random.default_rng(20260926)
+    for case in range(60 if engine.device.type == 'cuda' else 10):
+        s1, s2 = _random_pair(rng)
+        signed = bool(rng.integers(0, 2))
+        w1 = rng.standard_normal(s1).astype(F32)
+        w2 = (rng.standard_normal(s2) * 0.3).astype(F32)
+        b1 = rng.standard_normal(s1[0]).astype(F32)
+        t = [engine.to(torch.from_numpy(a.copy())) for a in (w1, w2, b1)]
+        for sweep in range(3 if engine.device.type == 'cuda' else 2):
+            _, _, _, S = dfq._layer_equalization(t[0], t[1], t[2], signed=signed)
+            S_o = orc.layer_equalization(w1, w2, b1, signed=signed)
+            what = 'case {} {} -> {} signed={} sweep {}'.format(case, s1, s2, signed, sweep)
+            assert_bitexact(npy(S), S_o, what + ' S')
+            assert_bitexact(npy(t[0]), w1, what + ' w1')
+            assert_bitexact(npy(t[1]), w2, what + ' w2')
+            assert_bitexact(npy(t[2]), b1, what + ' b1')
+
+
 @pytest.mark.parametrize('le_engine', LE_ENGINES)
 def test_layer_equalization_large_rows(engine, monkeypatch, le_engine):
     """Rows longer than a workgroup, tiles of one channel, 3x3 second layer (ResNet-like)."""
