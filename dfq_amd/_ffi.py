@@ -112,6 +112,7 @@ SIGNATURES = {
     'dfq_bc_plan_eps': (c_void_p, [c_void_p, c_int32]),
     'dfq_bc_plan_correction': (c_void_p, [c_void_p, c_int32]),
     'dfq_bc_plan_weight_elements': (c_int64, [c_void_p]),
+    'dfq_bc_plan_tagged': (c_int32, [c_void_p]),
     'dfq_bc_plan_eps_elements': (c_int64, [c_void_p]),
     'dfq_quant_error_scratch_bytes': (c_size_t, [c_int64, c_int64]),
     'dfq_quant_error': (c_int32, [c_void_p, c_int64, c_int64, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),

@@ -45,7 +45,8 @@ struct BcSourceDev {
     const float* fw;
     const float* fb;
     const float* cache;      // relu_mean(fw, fb) per channel, kept current by the producing step
-    int32_t channels, relu, concat, pad;
+    int32_t channels, relu, concat;
+    int32_t tag_off;         // first tagged-value slot of this BN when a step of the plan rewrites it, else -1 (see BcDep)
 };
 
 struct BcStepDev {
@@ -56,7 +57,8 @@ struct BcStepDev {
     float* next_cache;       // its relu_mean cache
     float* corr;             // [O] out: the correction `bias` of dfq.py:285-287
     int32_t out_ch, in_per_group, source_begin, source_count, expect_len, inline_sources;
-    int32_t lg_lanes, chunks, rows_per_block, pad;     // work split, see bc_step_kernel
+    int32_t lg_lanes, chunks, rows_per_block;          // work split, see bc_step_kernel
+    int32_t next_tag_off;    // tagged-value slots of the next BN, or -1
     BcSourceDev src[kStepSources];   // copy of sources[source_begin ...] when source_count <= kStepSources
 };
 
@@ -248,11 +250,23 @@ __device__ __forceinline__ void st_shared_f32(float* p, float v) {
     __hip_atomic_store((uint32_t*)p, __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Two hand-over protocols inside the one-launch chain.  Counters (tags == null): a step's workgroups wait until the counter
+// of the previous step of their network has reached its number of workgroups, then read beta~ / the ReLU moment with
+// device-scope loads; a producer makes its stores visible (s_waitcnt 0, barrier) and bumps its counter -- per step: store
+// -> ack -> barrier -> atomic -> poll -> barrier -> load, about five dependent trips through the memory system.
+// Tagged values (tags != null, the default): every BN channel a step of the plan rewrites has two 64-bit slots {run epoch :
+// float bits} for beta~ and for its ReLU moment; the producing thread writes them with ONE 64-bit device-scope store each,
+// a consumer thread polls exactly the slots it needs until they carry this run's epoch -- store -> poll, and no counter,
+// barrier or wait for the acknowledgement on the producing side.  A step then depends on the steps that produce its sources,
+// not on its predecessor in the list.
 struct BcDep {            // null counters: every step is its own launch (dependencies are kernel boundaries)
     uint32_t* counters;
     uint32_t* err;
     int32_t wait_idx, wait_blocks, bump_idx, pad;
+    unsigned long long* tags;
+    uint32_t epoch, pad2;
 };
+constexpr long kBcTagSpinLimit = 20000000;
 
 template <int kExp>
 __device__ __forceinline__ void bc_step_body(const BcStepDev& st, int blk, const BcSourceDev* __restrict__ sources,
@@ -295,7 +309,12 @@ __device__ __forceinline__ void bc_step_body(const BcStepDev& st, int blk, const
         if (st.next_bn_bias) pre_nb = st.next_bn_bias[o_tail];
         if (st.next_cache) pre_nw = st.next_bn_weight[o_tail];
     }
-    if (chained && dep.wait_idx >= 0) {
+    const bool tagged = chained && dep.tags != nullptr;
+    if (tagged) {
+        if (tid == 0) *sh_flag = 1;
+        __syncthreads();
+    }
+    if (chained && !tagged && dep.wait_idx >= 0) {
         // the previous layer's correction feeds this expectation: wait for all its workgroups (the eps values
         // requested above arrive meanwhile)
         if (tid == 0) {
@@ -325,8 +344,28 @@ __device__ __forceinline__ void bc_step_body(const BcStepDev& st, int blk, const
         const bool assign = (m == 0) || (s.concat != 0);
         const int base = (m == 0) ? 0 : (s.concat ? cur_len : 0);
         const float* val = s.relu ? s.cache : s.fb;      // E[ReLU(N(beta, gamma^2))] or beta
+        const bool poll = tagged && s.tag_off >= 0;      // rewritten by an earlier step of this launch: wait for THIS run's value
+        const unsigned long long* slot = poll ? dep.tags + 2 * (int64_t)s.tag_off + (s.relu ? 1 : 0) : nullptr;
         for (int i = tid; i < s.channels; i += kBlock) {
-            const float e = chained ? ld_shared_f32(val + i) : val[i];
+            float e;
+            if (poll) {
+                unsigned long long w = __hip_atomic_load(slot + 2 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                long spins = 0;
+                while ((uint32_t)(w >> 32) != dep.epoch) {
+                    __builtin_amdgcn_s_sleep(1);
+                    ++spins;
+                    if (spins > kBcTagSpinLimit ||
+                        ((spins & 255) == 0 && __hip_atomic_load(dep.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                        atomicMax(dep.err, 1u);
+                        *sh_flag = 0;                      // (every thread that gives up writes the same value)
+                        break;
+                    }
+                    w = __hip_atomic_load(slot + 2 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                e = __uint_as_float((uint32_t)w);
+            } else {
+                e = (chained && !tagged) ? ld_shared_f32(val + i) : val[i];
+            }
             if (assign) sh_E[base + i] = e;
             else sh_E[i] = sh_E[i] + e;
         }
@@ -345,6 +384,8 @@ __device__ __forceinline__ void bc_step_body(const BcStepDev& st, int blk, const
             merge_source(s, m);
         }
     }
+    // (every merge ends with a barrier) an abandoned poll: leave before anything is stored, like an abandoned counter wait
+    if (tagged && *sh_flag == 0) return;
     // ---- grouped matvec (dfq.py:281-287), float64 accumulation rounded once per row ----
     const int num_group = st.expect_len / in;
     const int step_o = st.out_ch / num_group;
@@ -400,7 +441,17 @@ __device__ __forceinline__ void bc_step_body(const BcStepDev& st, int blk, const
         if (st.next_bn_bias) {
             const float nb = pre_nb + neg;                        // dfq.py:204-206, 293 (a BN's beta~ changes once)
             const float moment = st.next_cache ? relu_mean(pre_nw, nb) : 0.0f;
-            if (chained) {
+            if (tagged) {
+                st.next_bn_bias[o] = nb;                          // the final state; consumers inside the launch read the slots
+                if (st.next_cache) st.next_cache[o] = moment;
+                if (st.next_tag_off >= 0) {
+                    unsigned long long* slot = dep.tags + 2 * ((int64_t)st.next_tag_off + o);
+                    const unsigned long long hi = (unsigned long long)dep.epoch << 32;
+                    __hip_atomic_store(slot + 0, hi | __float_as_uint(nb), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (st.next_cache)
+                        __hip_atomic_store(slot + 1, hi | __float_as_uint(moment), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            } else if (chained) {
                 st_shared_f32(st.next_bn_bias + o, nb);
                 if (st.next_cache) st_shared_f32(st.next_cache + o, moment);
             } else {
@@ -409,7 +460,7 @@ __device__ __forceinline__ void bc_step_body(const BcStepDev& st, int blk, const
             }
         }
     }
-    if (chained) {
+    if (chained && !tagged) {
         __builtin_amdgcn_s_waitcnt(0);                            // the stores above have been performed
         __syncthreads();
         if (tid == 0) atomicAdd(dep.counters + (int64_t)dep.bump_idx * kBcDepStride, 1u);
@@ -438,7 +489,7 @@ __global__ __launch_bounds__(kBlock) void bc_step_kernel(BcStepDev st_inline, co
     if (table) bc_load_step(table + blockIdx.y, desc.u);
     else desc.st = st_inline;
     if ((int)blockIdx.x * desc.st.rows_per_block >= desc.st.out_ch) return;     // grid.x is sized for the largest step of the launch
-    bc_step_body<kExp>(desc.st, blockIdx.x, sources, BcDep{nullptr, nullptr, -1, 0, -1, 0}, sh_E, sh_corr, &sh_flag);
+    bc_step_body<kExp>(desc.st, blockIdx.x, sources, BcDep{nullptr, nullptr, -1, 0, -1, 0, nullptr, 0u, 0u}, sh_E, sh_corr, &sh_flag);
 }
 
 // the whole chain of every network in one launch: 1-D grid over (step, workgroup) in chain order; a workgroup waits
@@ -447,7 +498,7 @@ template <int kExp>
 __global__ __launch_bounds__(kBlock) void bc_chain_kernel(const BcStepDev* __restrict__ table,
                                                           const BcChainRef* __restrict__ refs,
                                                           const BcSourceDev* __restrict__ sources, uint32_t* counters,
-                                                          uint32_t* err) {
+                                                          uint32_t* err, unsigned long long* tags, uint32_t epoch) {
     __shared__ float sh_E[kExp];
     __shared__ float sh_corr[kBlock];
     __shared__ int sh_flag;
@@ -458,7 +509,8 @@ __global__ __launch_bounds__(kBlock) void bc_chain_kernel(const BcStepDev* __res
     union { BcStepDev st; uint32_t u[kStepWords]; } desc;
     bc_load_step(table + step, desc.u);
     bc_step_body<kExp>(desc.st, blk, sources,
-                       BcDep{counters, err, __builtin_amdgcn_readfirstlane(ref[2]), __builtin_amdgcn_readfirstlane(ref[3]), step, 0},
+                       BcDep{counters, err, __builtin_amdgcn_readfirstlane(ref[2]), __builtin_amdgcn_readfirstlane(ref[3]), step, 0,
+                             tags, epoch, 0u},
                        sh_E, sh_corr, &sh_flag);
 }
 
@@ -477,6 +529,8 @@ struct dfq_bc_plan {
     BcStepDev* d_steps = nullptr;          // launch_steps on the device
     BcChainRef* d_refs = nullptr;          // workgroup table of the one-launch chain
     uint32_t* d_counters = nullptr;        // per step: finished workgroups (padded), + error flag
+    unsigned long long* d_tags = nullptr;  // tagged-value slots {epoch : float} x 2 per rewritten BN channel; null: counter protocol
+    uint32_t epoch = 0;                    // run counter carried by the slots
     int chain_blocks = 0, max_expect = 0;
     bool merged = true;                    // one launch for the whole chain (false: one per chain position, DFQ_BC_MERGED=0)
     std::vector<const float*> eps_ptr;
@@ -510,6 +564,7 @@ void dfq_bc_plan_destroy(dfq_bc_plan* p) {
     if (p->d_steps) (void)hipFree(p->d_steps);
     if (p->d_refs) (void)hipFree(p->d_refs);
     if (p->d_counters) (void)hipFree(p->d_counters);
+    if (p->d_tags) (void)hipFree(p->d_tags);
     for (auto& e : p->exec) if (e) (void)hipGraphExecDestroy(e);
     if (p->capture_stream) (void)hipStreamDestroy(p->capture_stream);
     delete p;
@@ -593,11 +648,38 @@ int dfq_bc_plan_create(const dfq_layer* layers, int32_t n_layers, const dfq_bc_s
     }
     p->n_cache_segs = (int)segs.size();
     p->cache_total = cache_total;
+    // tagged-value slots (see BcDep): one pair per channel of every BN that a step rewrites.  Only if every source of every step
+    // is either never rewritten or rewritten by an EARLIER step (the reference's sequential loop reads the old value otherwise)
+    // and no BN is rewritten twice; else the counter protocol, which orders whole steps, stays.
+    std::map<const float*, int> tag_of;
+    std::map<const float*, int> writer_of;
+    int tag_total = 0;
+    bool tagged_ok = true;
+    {
+        const char* te = getenv("DFQ_BC_TAGGED");
+        if (te && te[0] == '0') tagged_ok = false;
+    }
+    for (int s2 = 0; s2 < n_steps && tagged_ok; ++s2) {
+        const float* nb = steps[s2].next_bn_bias;
+        if (!nb) continue;
+        if (tag_of.count(nb)) { tagged_ok = false; break; }
+        tag_of[nb] = tag_total;
+        writer_of[nb] = s2;
+        tag_total += layers[steps[s2].layer].out_ch;
+    }
+    for (int s2 = 0; s2 < n_steps && tagged_ok; ++s2)
+        for (int m = 0; m < steps[s2].source_count; ++m) {
+            auto it = writer_of.find(sources[steps[s2].source_begin + m].fake_bias);
+            if (it != writer_of.end() && it->second >= s2) tagged_ok = false;
+            if (it != writer_of.end() && layers[steps[it->second].layer].out_ch != sources[steps[s2].source_begin + m].channels) tagged_ok = false;
+        }
+    if (!tagged_ok) { tag_of.clear(); tag_total = 0; }
     std::vector<BcSourceDev> hs(n_sources);
     for (int i = 0; i < n_sources; ++i) {
         hs[i].fw = sources[i].fake_weight; hs[i].fb = sources[i].fake_bias;
         hs[i].cache = sources[i].relu ? segs[cache_of[sources[i].fake_bias]].cache : nullptr;
-        hs[i].channels = sources[i].channels; hs[i].relu = sources[i].relu; hs[i].concat = sources[i].concat; hs[i].pad = 0;
+        hs[i].channels = sources[i].channels; hs[i].relu = sources[i].relu; hs[i].concat = sources[i].concat;
+        { auto it = tag_of.find(sources[i].fake_bias); hs[i].tag_off = (it != tag_of.end()) ? it->second : -1; }
     }
     p->steps.resize(n_steps);
     p->eps_ptr.resize(n_steps);
@@ -626,7 +708,7 @@ int dfq_bc_plan_create(const dfq_layer* layers, int32_t n_layers, const dfq_bc_s
             rw = std::min(rw, kBlock / kRowsPerBlock);                       // one tail row per thread
             rw = std::min(rw, std::max(1, (L.out_ch + kRowsPerBlock - 1) / kRowsPerBlock));
             d.rows_per_block = rw * kRowsPerBlock;                           // upper bound; trimmed per launch below
-            d.pad = 0;
+            { auto it = steps[s].next_bn_bias ? tag_of.find(steps[s].next_bn_bias) : tag_of.end(); d.next_tag_off = (it != tag_of.end()) ? it->second : -1; }
         }
         for (int m = 0; m < kStepSources; ++m)
             d.src[m] = (d.inline_sources && m < d.source_count) ? hs[d.source_begin + m] : BcSourceDev();
@@ -706,6 +788,10 @@ int dfq_bc_plan_create(const dfq_layer* layers, int32_t n_layers, const dfq_bc_s
         if ((e = hipMemcpy(p->d_refs, refs.data(), sizeof(BcChainRef) * refs.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail_alloc(e);
         if ((e = hipMalloc((void**)&p->d_counters, sizeof(uint32_t) * ((size_t)n_steps * kBcDepStride + 1))) != hipSuccess) return fail_alloc(e);
         if ((e = hipMemset(p->d_counters, 0, sizeof(uint32_t) * ((size_t)n_steps * kBcDepStride + 1))) != hipSuccess) return fail_alloc(e);
+        if (tag_total > 0) {
+            if ((e = hipMalloc((void**)&p->d_tags, sizeof(unsigned long long) * 2 * (size_t)tag_total)) != hipSuccess) return fail_alloc(e);
+            if ((e = hipMemset(p->d_tags, 0, sizeof(unsigned long long) * 2 * (size_t)tag_total)) != hipSuccess) return fail_alloc(e);
+        }
         const char* me = getenv("DFQ_BC_MERGED");
         p->merged = !(me && me[0] == '0');
     }
@@ -762,12 +848,15 @@ static int bc_run_direct(dfq_bc_plan* p, int32_t symmetric, hipStream_t st) {
         // the chain kernel contains in-launch waits: never concurrent with another stream's (dfq_common.hpp)
         std::unique_ptr<SpinGuard> guard;
         if (st != p->capture_stream) guard.reset(new SpinGuard(st));
+        // a recorded graph replays its arguments, so the run epoch of the tagged slots cannot advance: counters there
+        unsigned long long* tags = (st != p->capture_stream) ? p->d_tags : nullptr;
+        if (tags && ++p->epoch == 0u) p->epoch = 1u;
         if (p->max_expect <= kExpectSmall)
             hipLaunchKernelGGL(bc_chain_kernel<kExpectSmall>, dim3(p->chain_blocks), dim3(kBlock), 0, st, (const BcStepDev*)p->d_steps,
-                               (const BcChainRef*)p->d_refs, (const BcSourceDev*)p->d_sources, p->d_counters, err);
+                               (const BcChainRef*)p->d_refs, (const BcSourceDev*)p->d_sources, p->d_counters, err, tags, p->epoch);
         else
             hipLaunchKernelGGL(bc_chain_kernel<kExpectMax>, dim3(p->chain_blocks), dim3(kBlock), 0, st, (const BcStepDev*)p->d_steps,
-                               (const BcChainRef*)p->d_refs, (const BcSourceDev*)p->d_sources, p->d_counters, err);
+                               (const BcChainRef*)p->d_refs, (const BcSourceDev*)p->d_sources, p->d_counters, err, tags, p->epoch);
         DFQ_CHECK_LAUNCH();
         return DFQ_OK;
     }
@@ -806,6 +895,7 @@ const float* dfq_bc_plan_correction(const dfq_bc_plan* p, int32_t step) {
     return (p && step >= 0 && step < p->n_steps) ? p->steps[step].corr : nullptr;
 }
 int64_t dfq_bc_plan_weight_elements(const dfq_bc_plan* p) { return p ? p->weight_elems : 0; }
+int32_t dfq_bc_plan_tagged(const dfq_bc_plan* p) { return (p && p->merged && p->d_tags) ? 1 : 0; }
 int64_t dfq_bc_plan_eps_elements(const dfq_bc_plan* p) { return p ? p->eps_elems : 0; }
 
 }  // extern "C"

@@ -556,6 +556,11 @@ class BCPlan:
         if check:
             self.status()
 
+    @property
+    def tagged(self):
+        """True when the one-launch chain hands values over as tagged 64-bit slots (see dfq_bc_plan_tagged)."""
+        return bool(_ffi.lib().dfq_bc_plan_tagged(self._plan))
+
     def status(self):
         """Synchronise and raise if a workgroup of the one-launch chain abandoned its wait (nothing was stored by it)."""
         _ffi.check(_ffi.lib().dfq_bc_plan_status(self._plan, _ffi.stream_arg()))

@@ -292,6 +292,9 @@ int dfq_bc_plan_status(dfq_bc_plan* plan, void* stream);
 const float* dfq_bc_plan_eps(const dfq_bc_plan* plan, int32_t step);
 const float* dfq_bc_plan_correction(const dfq_bc_plan* plan, int32_t step);
 int64_t dfq_bc_plan_weight_elements(const dfq_bc_plan* plan);
+/* 1 when the one-launch chain hands values from step to step as tagged 64-bit slots (the default), 0 when it uses per-step
+ * counters (DFQ_BC_TAGGED=0, or a graph the tagged scheme does not cover) or one launch per chain position. */
+int32_t dfq_bc_plan_tagged(const dfq_bc_plan* plan);
 int64_t dfq_bc_plan_eps_elements(const dfq_bc_plan* plan);
 
 /* _quantize_error (dfq.py:8-25) on one tensor: q(x) - x with per-tensor min/max, 5 reductions:

@@ -466,6 +466,38 @@ def test_batched_bias_correction_matches_separate_runs(engine):
         compare_stage(a, net_fixture(name, seed, suffix), 'bc', what=name)
 
 
+@pytest.mark.parametrize('mode', ['tagged', 'counters', 'per-position'])
+def test_bias_correction_hand_over_protocols_agree(engine, monkeypatch, mode):
+    """The one-launch chain hands beta~ / the ReLU moment from step to step as tagged 64-bit values (default) or behind
+    per-step counters (DFQ_BC_TAGGED=0); DFQ_BC_MERGED=0 makes every chain position its own launch.  Same arithmetic:
+    identical results, also when the plan is run a second time on fresh inputs (the slots then carry the next epoch)."""
+    for k in ('DFQ_BC_TAGGED', 'DFQ_BC_MERGED'):
+        monkeypatch.delenv(k, raising=False)
+    if mode == 'counters':
+        monkeypatch.setenv('DFQ_BC_TAGGED', '0')
+    if mode == 'per-position':
+        monkeypatch.setenv('DFQ_BC_MERGED', '0')
+    for name, seed, suffix in [('tiny_mobile', 0, ''), ('tiny_cat', 0, ''), ('tiny_res', 0, '')]:
+        gold = net_fixture(name, seed, suffix)
+        model, graph, bottoms = _build(name, seed, gold, engine)
+        lt.merge_batchnorm(model, graph, bottoms, TARG)
+        load_stage(graph, gold, 'abs')
+        start = {k: v.copy() for k, v in snapshot(graph).items()}
+        plan, _ = dfq.build_bc_plan(graph, bottoms, TARG)
+        assert plan.tagged == (mode == 'tagged')
+        plan.run()
+        first = snapshot(graph)
+        compare_stage(first, gold, 'bc', what='{} {}'.format(name, mode))
+        # second run of the SAME plan from the same start: bit-identical to the first
+        load_stage(graph, gold, 'abs')
+        for k, v in snapshot(graph).items():
+            assert_bitexact(v, start[k], 'reload {}'.format(k))
+        plan.run()
+        for k, v in snapshot(graph).items():
+            assert_bitexact(v, first[k], '{} second run {} ({})'.format(name, k, mode))
+        plan.close()
+
+
 def test_bias_correction_intermediates_against_oracle(engine):
     """eps (quant-error row sums, dfq.py:216-219) and the correction vectors (dfq.py:281-287) read back from
     the plan: eps is float32 elementwise work in the oracle's order (bit-exact), the matvec is 1e-5."""
