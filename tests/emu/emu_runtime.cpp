@@ -48,6 +48,17 @@ void yield_with(State s) {
 void sync_block() { yield_with(WAIT_BLOCK); }
 void sync_wave() { yield_with(WAIT_WAVE); }
 void poll_yield() { if (concurrent) yield_with(YIELDED); }
+// Only in launches that keep their LDS state in the per-workgroup dynamic buffer: `__shared__` variables are plain statics
+// here (one copy for all workgroups), which is fine as long as a workgroup is only switched out where none of them is live
+// (the s_sleep of a dependency wait) -- le_sweep_kernel; le_resident_kernel uses the dynamic buffer and can be switched
+// out anywhere.
+bool preempt_at_loads = false;
+void visibility_point() {
+    static uint32_t lcg = 12345u;
+    if (!concurrent || !preempt_at_loads) return;
+    lcg = lcg * 1664525u + 1013904223u;
+    if ((lcg >> 16) % 4u == 0u) yield_with(YIELDED);
+}
 
 uint64_t peer_slot(int mask, bool* valid) {
     const int lane = (cur_idx - base_idx) % kWaveSize;
@@ -211,6 +222,7 @@ void launch_concurrent(dim3 grid, dim3 block, size_t smem_bytes, const std::func
     csmem.assign(nblocks, std::vector<unsigned char>(smem_bytes + 64, 0xA5));
     body_ptr = &body;
     concurrent = true;
+    preempt_at_loads = smem_bytes > 0;
     for (int b = 0; b < nblocks; ++b) {
         for (int t = 0; t < nthreads; ++t) {
             Fiber& f = fibers[(size_t)b * nthreads + t];
@@ -259,6 +271,7 @@ void launch_concurrent(dim3 grid, dim3 block, size_t smem_bytes, const std::func
         }
     }
     concurrent = false;
+    preempt_at_loads = false;
     base_idx = 0;
     fibers.swap(cfibers);
     fibers.swap(saved);

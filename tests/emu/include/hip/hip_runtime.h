@@ -61,6 +61,7 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body);
 // resident equalisation kernel); `smem_bytes` of dynamic shared memory per workgroup; poll loops yield in s_sleep
 void launch_concurrent(dim3 grid, dim3 block, size_t smem_bytes, const std::function<void()>& body);
 void poll_yield();
+void visibility_point();
 void sync_block();
 void sync_wave();
 uint64_t peer_rl(int src_lane, bool* valid);
@@ -150,7 +151,11 @@ inline unsigned long long atomicMax(unsigned long long* p, unsigned long long v)
 inline double atomicAdd(double* p, double v) { double o = *p; *p = o + v; return o; }
 
 #define __HIP_MEMORY_SCOPE_AGENT 4
-#define __hip_atomic_load(ptr, order, scope) (*(ptr))
+// A device-scope load is where another workgroup's progress becomes visible.  In a launch whose workgroups run concurrently
+// the emulation lets OTHER workgroups run at a pseudo-random quarter of these loads, so that the threads of one workgroup
+// can see different values of a word that is changing -- as waves do on the hardware.  (A workgroup that lets every thread
+// decide "is the counter there yet?" for itself passed every emulated test and mismatched its barriers on the GPU.)
+#define __hip_atomic_load(ptr, order, scope) (emu::visibility_point(), *(ptr))
 #define __hip_atomic_store(ptr, val, order, scope) (*(ptr) = (val))
 inline void __builtin_amdgcn_s_sleep(int) { emu::poll_yield(); }
 inline void __builtin_amdgcn_s_waitcnt(int) {}
