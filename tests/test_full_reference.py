@@ -246,22 +246,24 @@ def test_engine_choice_by_network_size():
 ONE_SWEEP_LATER = {2}
 
 
-def _sweep_fixture():
+def _sweep_fixture(net='mobilenet_v2'):
     import json
     path = os.path.join(GOLD, 'full_sweeps.json')
-    rec = json.load(open(path))['mobilenet_v2']
-    return sorted((int(s), int(n) + (1 if int(s) in ONE_SWEEP_LATER else 0)) for s, n in rec.items())
+    rec = json.load(open(path))[net]
+    later = ONE_SWEEP_LATER if net == 'mobilenet_v2' else set()
+    return sorted((int(s), int(n) + (1 if int(s) in later else 0)) for s, n in rec.items())
 
 
 def test_oracle_stops_where_the_reference_stops_on_every_recorded_seed():
     fixture = _sweep_fixture()
     assert len(fixture) >= 8 and len(ONE_SWEEP_LATER) <= 1
-    for seed, expect in fixture:
-        model, graph, bottoms = synthetic.build('mobilenet_v2', seed=seed)
-        spec = graphspec.from_torch(graph, bottoms, TARG)
-        orc.merge_batchnorm(spec)
-        n_o, _ = orc.cross_layer_equalization(spec, orc.create_relation(spec))
-        assert n_o == expect, 'seed {}: oracle {} sweeps, expected {}'.format(seed, n_o, expect)
+    for net, fx in (('mobilenet_v2', fixture), ('resnet18', _sweep_fixture('resnet18'))):
+        for seed, expect in fx:
+            model, graph, bottoms = synthetic.build(net, seed=seed)
+            spec = graphspec.from_torch(graph, bottoms, TARG)
+            orc.merge_batchnorm(spec)
+            n_o, _ = orc.cross_layer_equalization(spec, orc.create_relation(spec))
+            assert n_o == expect, '{} seed {}: oracle {} sweeps, expected {}'.format(net, seed, n_o, expect)
 
 
 @pytest.mark.gpu
@@ -282,6 +284,17 @@ def test_engine_batch_stops_where_the_reference_stops_on_every_recorded_seed():
     plan.run()
     res, _ = plan.query_all()
     assert [r['sweeps'] for r in res] == [n for _, n in fixture]
+    # ResNet-18 (config 3; streams: too large for LDS residency), as a batch of its recorded seeds
+    r18 = _sweep_fixture('resnet18')
+    items18 = []
+    for seed, _ in r18:
+        model, graph, bottoms = synthetic.build('resnet18', seed=seed)
+        model.to(dev)
+        lt.merge_batchnorm(model, graph, bottoms, TARG)
+        items18.append((graph, rel.create_relation(graph, bottoms, TARG)))
+    plan18 = dfq.build_le_plan_batch(items18, TARG)
+    plan18.run()
+    assert [r['sweeps'] for r in plan18.query_all()[0]] == [n for _, n in r18]
     # ... and a network alone (the resident whole-loop launch) stops there too
     for (seed, n), (graph, _) in list(zip(fixture, items))[:3]:
         model, g2, bottoms = synthetic.build('mobilenet_v2', seed=seed)
