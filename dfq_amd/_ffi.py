@@ -61,6 +61,11 @@ class DfqBcStep(Structure):
 
 # every exported symbol: name -> (restype, argtypes).  tests/test_abi.py checks this table against
 # include/dfq_hip.h and against the symbols the shared object really exports.
+class DfqRebuildItem(Structure):
+    _fields_ = [('src', c_void_p), ('dst', c_void_p), ('s_out', c_void_p), ('s_in', c_void_p), ('rows', c_int32),
+                ('cols', c_int32), ('khkw', c_int32), ('groups', c_int32)]
+
+
 class DfqBnRangeReq(Structure):
     _fields_ = [('fake_weight', c_void_p), ('fake_bias', c_void_p), ('channels', c_int32), ('relu_mode', c_int32)]
 
@@ -119,6 +124,10 @@ SIGNATURES = {
     'dfq_scale_rows': (c_int32, [c_void_p, c_int32, c_int64, c_void_p, c_int32, c_void_p]),
     'dfq_scale_cols': (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p]),
     'dfq_vec_op': (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
+    'dfq_rebuild_plan_create': (c_int32, [POINTER(DfqRebuildItem), c_int32, POINTER(c_void_p)]),
+    'dfq_rebuild_plan_destroy': (None, [c_void_p]),
+    'dfq_rebuild_plan_elements': (c_int64, [c_void_p]),
+    'dfq_rebuild_plan_run': (c_int32, [c_void_p, c_void_p]),
     'dfq_clamp': (c_int32, [c_void_p, c_int64, c_float, c_float, c_void_p]),
     'dfq_fold_batchnorm': (c_int32, [c_void_p, c_void_p, c_int32, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_float, c_void_p, c_void_p, c_void_p]),

@@ -2,12 +2,21 @@
 
 Channels of a relation are independent, relations that share a layer are order-dependent, so the
 shard unit is a connected component of the relation graph (MobileNetV2: 16 components).  Every rank
-holds the whole network, equalises only the components it owns, then one ``all_gather`` (RCCL over
-xGMI when the process group is 'nccl') exchanges the cumulative per-relation scale vectors -- 4 bytes
-per paired channel, 64 KB for MobileNetV2 -- and every rank rebuilds the layers it does not own from
-its pristine copy:  W = diag(S_out) . W0 . diag(1/S_in),  b = b0 . S_out,  BN proxies likewise.  The
-rebuilt tensors equal the sequentially rescaled ones up to float32 rounding (<= 1e-5 relative, the
-contract of BASELINE.json); the owned components are bit-identical to the single-GPU result.
+holds the whole network.  A rank runs the sequential sweeps of dfq.py:85-101 on *scratch copies* of
+the components it owns -- all it keeps of that is the cumulative scale vector of every owned relation
+(utils/relation.py:20-24), bit-identical to the single-GPU loop's -- then ONE ``all_gather`` (RCCL
+over xGMI when the process group is 'nccl') exchanges those vectors: 4 bytes per paired channel,
+64 KB for MobileNetV2.  After it EVERY rank, the owner of a component included, rebuilds every paired
+tensor from its pristine value with one batched engine launch,
+
+    W = diag(S_out) . W0 . diag(1 / S_in),    b = b0 . S_out,    BN proxies likewise
+
+(``dfq_rebuild_plan_run``: per element fl(fl(w0 * s_out) / s_in)).  All ranks execute the same launch
+on the same inputs, so they end with **bit-identical networks** -- and the same network for every
+world size, N = 1 included -- which is what lets the bias-correction chain and the int8 quantisation
+that follow be plain replicas.  The result is within 1e-5 (relative) of the sequentially rescaled
+tensors of the reference loop, the contract of BASELINE.json; the scale vectors themselves are
+bit-identical to it.
 
 This is a latency-bound exchange on a millisecond-scale job: it exists for configuration 4 of
 BASELINE.json (DeepLab sharded over 8 GPUs) and for networks too large for one pass to be cheap, not
@@ -18,11 +27,16 @@ The data-dependent convergence test of dfq.py:83-115 needs the sum of all layers
 """
 from __future__ import annotations
 
+import copy
+import ctypes
+from collections import OrderedDict
+
 import torch
 import torch.distributed as dist
 
 from . import _ffi
 from . import dfq as _dfq
+from .utils.layer_transform import _ensure_bias
 
 
 def relation_components(relations):
@@ -63,37 +77,74 @@ def assign_components(graph, relations, world_size):
     return owner
 
 
-def _engine_rescale(weight, bias, bn, s_out, s_in, groups):
-    """W <- diag(S_out) W diag(1/S_in) (and b, BN proxies *= S_out) with the engine's row/col kernels."""
-    lib = _ffi.lib()
-    stage = _ffi.Stage()
-    w = stage.bind(weight)
-    khkw = w[0, 0].numel() if w.dim() == 4 else 1
+def _khkw(w):
+    n = 1
+    for d in w.shape[2:]:
+        n *= int(d)
+    return n
+
+
+class _RebuildPlan:
+    """ONE launch over a table of (src, dst, s_out, s_in) items -- ``dfq_rebuild_plan_*`` of include/dfq_hip.h."""
+
+    def __init__(self, items):
+        """items: list of (src, dst, s_out|None, s_in|None, groups) device tensors; vectors have groups == 1."""
+        self._keep = items
+        arr = (_ffi.DfqRebuildItem * len(items))()
+        for a, (src, dst, so, si, groups) in zip(arr, items):
+            a.src, a.dst = src.data_ptr(), dst.data_ptr()
+            a.s_out = so.data_ptr() if so is not None else None
+            a.s_in = si.data_ptr() if si is not None else None
+            a.rows = int(src.shape[0])
+            a.cols = int(src.shape[1]) if src.dim() > 1 else 1
+            a.khkw = _khkw(src)
+            a.groups = int(groups)
+        self._plan = ctypes.c_void_p()
+        _ffi.check(_ffi.lib().dfq_rebuild_plan_create(arr, len(items), ctypes.byref(self._plan)))
+
+    @property
+    def elements(self):
+        return int(_ffi.lib().dfq_rebuild_plan_elements(self._plan))
+
+    def run(self):
+        _ffi.check(_ffi.lib().dfq_rebuild_plan_run(self._plan, _ffi.stream_arg()))
+
+    def close(self):
+        if self._plan:
+            _ffi.lib().dfq_rebuild_plan_destroy(self._plan)
+            self._plan = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _torch_rebuild(src, dst, s_out, s_in, groups):
+    """The same two roundings with torch ops (stand-in for the engine launch in the CPU-only logic tests)."""
+    t = src
     if s_out is not None:
-        so = stage.bind(s_out)
-        _ffi.check(lib.dfq_scale_rows(_ffi.ptr(w), w.shape[0], w[0].numel(), _ffi.ptr(so), 0, _ffi.stream_arg()))
-        for v in ([bias] if bias is not None else []) + list(bn):
-            vv = stage.bind(v)
-            _ffi.check(lib.dfq_vec_op(_ffi.ptr(vv), _ffi.ptr(so), vv.numel(), 0, _ffi.stream_arg()))
+        t = t * s_out.view((-1,) + (1,) * (t.dim() - 1))
     if s_in is not None:
-        si = stage.bind(s_in)
-        _ffi.check(lib.dfq_scale_cols(_ffi.ptr(w), w.shape[0], w.shape[1], khkw, groups, _ffi.ptr(si), 1, _ffi.stream_arg()))
-    stage.writeback()
+        per_row = s_in.view(groups, -1).repeat_interleave(src.shape[0] // groups, dim=0)
+        t = t / per_row.view((src.shape[0], -1) + (1,) * (src.dim() - 2))
+    dst.copy_(t)
 
 
 class _EngineSession:
-    """The owned relations of this rank as ONE engine plan that stays alive for the whole run: the statistics are
-    bootstrapped once, sweeps are enqueued one by one (or all at once), the weights are written back once.  The
-    device-side loop state is configured never to stop by itself (threshold -1, no sweep cap): the stopping rule
-    of dfq.py:83-115 needs the sum over ALL ranks and is evaluated by the caller."""
+    """The owned relations of this rank as ONE engine plan over scratch copies of the owned tensors.  The plan's
+    cumulative-scale buffers ARE the rank's slice of the exchange buffer.  The device-side loop state is configured
+    never to stop by itself (threshold -1, no sweep cap): the stopping rule of dfq.py:83-115 needs the sum over ALL
+    ranks and is evaluated by the caller."""
 
-    def __init__(self, graph, relations, targ_type, s_range, signed, eps):
-        self.graph, self.relations = graph, relations
+    def __init__(self, layers, rels, s_range, signed, eps):
         self.cfg = dict(s_range=tuple(s_range), signed=signed, eps=eps, converge_thres=-1.0, converge_count=10 ** 9,
                         max_sweeps=None)
-        self.stage = _ffi.Stage()
-        self.plan = _dfq.build_le_plan(graph, relations, targ_type, stage=self.stage)
-        self.plan.enqueue(0, restart=True, **self.cfg)
+        self.plan = _dfq.LEPlan(layers, rels)
+
+    def start(self):
+        self.plan.enqueue(0, restart=True, **self.cfg)       # statistics of the (just snapshotted) scratch tensors
 
     def sweeps(self, n):
         self.plan.enqueue(int(n), restart=False, **self.cfg)
@@ -102,23 +153,28 @@ class _EngineSession:
         """sum over the owned layers of mean|W - W_prev| of the latest sweep (one small device-to-host copy)."""
         return self.plan.query()['last_diff_tmp']
 
+    def finish(self):
+        self.plan.query()                                    # synchronises and surfaces a failed in-launch wait
+
     def close(self):
-        try:
-            self.plan.query()                      # synchronises and surfaces a failed in-launch wait
-            self.stage.writeback()
-            for rr, sc in zip(self.relations, self.plan.scale_cum):
-                rr.S = self.stage.out_like(self.graph[rr.get_idxs()[0]].weight, sc)
-        finally:
-            self.plan.close()
+        self.plan.close()
 
 
 class _RunnerSession:
-    """Adapter for an injected ``le_runner`` (tests): every call equalises the relations for n more sweeps."""
+    """Adapter for an injected ``le_runner`` (tests): every call equalises the scratch graph for n more sweeps; the
+    cumulative scales it leaves in ``Relation.S`` are copied into the exchange buffer."""
 
-    def __init__(self, runner, graph, relations, targ_type, s_range, signed, eps):
+    def __init__(self, runner, graph, relations, targ_type, s_range, signed, eps, scale_slices):
+        self.relations, self.scale_slices = relations, scale_slices
+        self.saved = [rr.S for rr in relations]
+        for rr in relations:
+            rr.S = None
         self.run = lambda n: runner(graph, relations, targ_type, max_sweeps=n, converge_thres=-1.0,
                                     converge_count=10 ** 9, s_range=list(s_range), signed=signed, eps=eps)
         self.res = None
+
+    def start(self):
+        pass
 
     def sweeps(self, n):
         self.res = self.run(int(n))
@@ -126,49 +182,150 @@ class _RunnerSession:
     def last_diff(self):
         return self.res['last_diff_tmp']
 
+    def finish(self):
+        for rr, dst, old in zip(self.relations, self.scale_slices, self.saved):
+            if rr.S is not None:
+                dst.copy_(rr.S)
+            rr.S = old
+
     def close(self):
         pass
 
 
 class ShardedEqualizer:
     """One network, one rank's share of it.  Construction (host side, untimed in bench.py) partitions the relation
-    graph, builds the engine plan of the owned components and the flat exchange buffer; ``run`` is the data path:
-    local sweeps -> ONE all_gather of the cumulative scale vectors -> rebuild of the foreign layers."""
+    graph and builds the tables: the engine plan of the owned components over scratch tensors, the flat exchange
+    buffer the plan accumulates its scales into, the snapshot and rebuild launches.  ``run`` is the data path:
+    snapshot of the owned tensors (1 launch) -> local sweeps -> ONE all_gather -> rebuild of every paired tensor on
+    every rank (1 launch)."""
 
     def __init__(self, graph, relations, targ_type, group=None, s_range=(1e-8, 1e8), signed=False, eps=0,
-                 le_runner=None, rescale=None):
+                 le_runner=None, use_torch_rebuild=False):
         self.graph, self.relations, self.targ_type, self.group = graph, relations, targ_type, group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
-        self.rescale = rescale or _engine_rescale
         self.owner = assign_components(graph, relations, self.world)
-        self.mine = [rr for rr, o in zip(relations, self.owner) if o == self.rank]
-        self.foreign = [(i, rr) for i, (rr, o) in enumerate(zip(relations, self.owner)) if o != self.rank]
+        self.stage = _ffi.Stage()
+        dev = self.dev = self.stage.device
+        self.comm_dev = dev if dist.get_backend(group) == 'nccl' else torch.device('cpu')
+        self._torch_rebuild = use_torch_rebuild
+        first_of, second_of = {}, {}
         with torch.no_grad():
-            for _, rr in self.foreign:                               # dfq.py:91-92 on every rank
-                first = graph[rr.get_idxs()[0]]
-                if first.bias is None:
-                    first.bias = torch.nn.Parameter(torch.zeros(first.weight.size(0), dtype=torch.float32,
-                                                                device=first.weight.device), requires_grad=False)
-            self.session = None
-            if self.mine:
-                self.session = (_RunnerSession(le_runner, graph, self.mine, targ_type, s_range, signed, eps)
-                                if le_runner is not None else _EngineSession(graph, self.mine, targ_type, s_range, signed, eps))
-        # exchange layout: the cumulative S of every relation, concatenated in list order (4 B per paired channel)
-        self.lens = [graph[rr.get_idxs()[0]].weight.size(0) for rr in relations]
-        self.offsets = [0]
-        for n in self.lens:
-            self.offsets.append(self.offsets[-1] + n)
-        self.dev = graph[relations[0].get_idxs()[0]].weight.device if relations else torch.device('cpu')
-        self.comm_dev = self.dev if dist.get_backend(group) == 'nccl' else torch.device('cpu')
-        self.exchange_bytes = 4 * self.offsets[-1]
+            for i, rr in enumerate(relations):
+                a, b, _ = rr.get_idxs()
+                assert a not in first_of and b not in second_of, 'a layer is the first / second layer of one relation at most'
+                first_of[a], second_of[b] = i, i
+                _ensure_bias(graph[a])                                   # dfq.py:91-92, on every rank
+
+            # ---- exchange layout: the cumulative S of every relation in list order (4 B per paired channel) ----
+            self.lens = [graph[rr.get_idxs()[0]].weight.size(0) for rr in relations]
+            self.offsets = [0]
+            for n in self.lens:
+                self.offsets.append(self.offsets[-1] + n)
+            total = self.total = self.offsets[-1]
+            self.exchange_bytes = 4 * total
+            self.flat = torch.ones(max(1, total), dtype=torch.float32, device=dev)
+            self.gathered = torch.ones(self.world * max(1, total), dtype=torch.float32, device=dev)
+            gat = self.gathered.view(self.world, -1)
+            s_of = [gat[o, self.offsets[i]:self.offsets[i + 1]] for i, o in enumerate(self.owner)]   # fixed addresses
+            sel = torch.cat([torch.arange(self.offsets[i], self.offsets[i + 1]) + o * max(1, total)
+                             for i, o in enumerate(self.owner)]) if relations else torch.zeros(0, dtype=torch.int64)
+            self._sel = sel.to(dev)
+
+            # ---- the tensors the rebuild rewrites, bound once (CPU-resident models get device shadows) ----
+            bind = self.stage.bind
+            paired = [k for k in graph if k in first_of or k in second_of]
+            items = []
+            for k in paired:
+                layer = graph[k]
+                w = bind(layer.weight)
+                so = s_of[first_of[k]] if k in first_of else None
+                si = s_of[second_of[k]] if k in second_of else None
+                items.append((w, w, so, si, getattr(layer, 'groups', 1)))
+                if so is not None:
+                    vecs = [layer.bias]
+                    kb = relations[first_of[k]].get_idxs()[2]
+                    if kb is not None:
+                        vecs += [getattr(graph[kb], 'fake_weight', None), getattr(graph[kb], 'fake_bias', None)]
+                    for v in vecs:
+                        if v is not None:
+                            vb = bind(v)
+                            items.append((vb, vb, so, None, 1))
+            self._rebuild_items = items
+            self.rebuild = None if use_torch_rebuild or not items else _RebuildPlan(items)
+
+            # ---- this rank's components: scratch copies + the engine plan over them ----
+            mine = [i for i, o in enumerate(self.owner) if o == self.rank]
+            self.mine = [relations[i] for i in mine]
+            self.session, self.snapshot, self._snap_items, self._sgraph_bind = None, None, [], []
+            if mine:
+                keys = [k for k in graph if any(k in relations[i].get_idxs()[:2] for i in mine)]
+                bn_keys = [relations[i].get_idxs()[2] for i in mine if relations[i].get_idxs()[2] is not None]
+                srcs = []
+                for k in keys:
+                    srcs.append(bind(graph[k].weight))
+                    if k in first_of:
+                        srcs.append(bind(graph[k].bias))
+                for kb in bn_keys:
+                    for name in ('fake_weight', 'fake_bias'):
+                        if getattr(graph[kb], name, None) is not None:
+                            srcs.append(bind(getattr(graph[kb], name)))
+                sizes = [(t.numel() + 63) // 64 * 64 for t in srcs]              # 256-byte aligned carve-outs
+                self.scratch = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
+                clone, off = {}, 0
+                for t, n in zip(srcs, sizes):
+                    clone[t.data_ptr()] = self.scratch[off:off + t.numel()].view(t.shape)
+                    off += n
+                self._snap_items = [(t, clone[t.data_ptr()], None, None, 1) for t in srcs]
+                self.snapshot = None if use_torch_rebuild else _RebuildPlan(self._snap_items)
+                scale_slices = [self.flat[self.offsets[i]:self.offsets[i + 1]] for i in mine]
+                if le_runner is not None:
+                    sgraph = OrderedDict(graph)                                  # the same keys, owned modules replaced by copies
+                    for k in keys + bn_keys:
+                        sgraph[k] = copy.deepcopy(graph[k])
+                    self._sgraph_bind = [(sgraph[k], graph[k]) for k in keys + bn_keys]
+                    self.session = _RunnerSession(le_runner, sgraph, self.mine, targ_type, s_range, signed, eps, scale_slices)
+                else:
+                    index = {k: j for j, k in enumerate(keys)}
+                    layers = [(clone[bind(graph[k].weight).data_ptr()],
+                               clone[bind(graph[k].bias).data_ptr()] if k in first_of else None,
+                               getattr(graph[k], 'groups', 1)) for k in keys]
+                    rels = []
+                    for i, sl in zip(mine, scale_slices):
+                        a, b, kb = relations[i].get_idxs()
+                        bn = graph[kb] if kb is not None else None
+                        fw, fb = getattr(bn, 'fake_weight', None), getattr(bn, 'fake_bias', None)
+                        rels.append((index[a], index[b], clone[bind(fw).data_ptr()] if fw is not None else None,
+                                     clone[bind(fb).data_ptr()] if fb is not None else None, sl))
+                    self.session = _EngineSession(layers, rels, s_range, signed, eps)
+
+    # ---- the two table-driven launches (torch stand-ins in the CPU-only logic tests) ----
+    def _run_snapshot(self):
+        if self._sgraph_bind:                                # runner stand-in: refresh the copied modules instead
+            for dst_m, src_m in self._sgraph_bind:
+                dst_m.load_state_dict(src_m.state_dict())
+        elif self._torch_rebuild:
+            for it in self._snap_items:
+                _torch_rebuild(*it)
+        elif self.snapshot is not None:
+            self.snapshot.run()
+
+    def _run_rebuild(self):
+        if self._torch_rebuild:
+            for it in self._rebuild_items:
+                _torch_rebuild(*it)
+        elif self.rebuild is not None:
+            self.rebuild.run()
 
     def run(self, max_sweeps=None, converge_thres=2e-7, converge_count=20):
         """Returns the number of sweeps.  ``max_sweeps=N`` pins the count (no exchange before the final all_gather);
         ``None`` keeps the reference's data-dependent loop with one 8-byte all_reduce per sweep."""
-        graph, relations, group, session = self.graph, self.relations, self.group, self.session
+        group, session = self.group, self.session
         with torch.no_grad():
             try:
+                if session is not None:
+                    self._run_snapshot()                     # owned tensors -> scratch (the real ones stay pristine)
+                    session.start()
                 if max_sweeps is not None:
                     if session is not None and max_sweeps > 0:
                         session.sweeps(max_sweeps)
@@ -188,51 +345,53 @@ class ShardedEqualizer:
                         else:
                             count += 1
                         sweeps += 1
+                if session is not None:
+                    session.finish()
             finally:
                 if session is not None:
                     session.close()
                     self.session = None
             # ---- exchange: ONE all_gather of the cumulative scale vectors (RCCL over xGMI when the group is 'nccl') ----
-            flat = torch.ones(self.offsets[-1], dtype=torch.float32, device=self.comm_dev)
-            for i, (rr, o) in enumerate(zip(relations, self.owner)):
-                if o == self.rank and rr.S is not None:
-                    flat[self.offsets[i]:self.offsets[i + 1]] = rr.S.to(self.comm_dev)
-            gathered = torch.empty(self.world * self.offsets[-1], dtype=torch.float32, device=self.comm_dev)
-            dist.all_gather_into_tensor(gathered, flat, group=group)
-            gathered = gathered.view(self.world, -1)
-            S_all = [gathered[o, self.offsets[i]:self.offsets[i + 1]].to(self.dev) for i, o in enumerate(self.owner)]
-            # ---- rebuild what the other ranks equalised: W = diag(S_out) . W0 . diag(1 / S_in) ----
-            s_out, s_in = {}, {}
-            for (i, rr) in self.foreign:
-                a, b, _ = rr.get_idxs()
-                s_out[a] = (S_all[i], rr)
-                s_in[b] = S_all[i]
-                rr.S = S_all[i]
-            for key in [k for k in graph if k in s_out or k in s_in]:
-                layer = graph[key]
-                so, rr = s_out.get(key, (None, None))
-                bn = []
-                if rr is not None and rr.get_idxs()[2] is not None:
-                    bnm = graph[rr.get_idxs()[2]]
-                    bn = [t for t in (getattr(bnm, 'fake_weight', None), getattr(bnm, 'fake_bias', None)) if t is not None]
-                self.rescale(layer.weight, layer.bias if so is not None else None, bn, so, s_in.get(key),
-                             getattr(layer, 'groups', 1))
+            if self.comm_dev == self.dev:
+                dist.all_gather_into_tensor(self.gathered, self.flat, group=group)
+            else:
+                g = torch.empty(self.gathered.shape, dtype=torch.float32, device=self.comm_dev)
+                dist.all_gather_into_tensor(g, self.flat.to(self.comm_dev), group=group)
+                self.gathered.copy_(g)
+            # ---- every rank rebuilds every paired tensor from its pristine value: identical launch, identical inputs ----
+            self._run_rebuild()
+            self.stage.writeback()
+            S = self.gathered[self._sel]                    # the owners' segments, relation after relation (one gather)
+            for i, rr in enumerate(self.relations):          # Relation.set_scale_vec, cumulative (relation.py:20-24)
+                s = self.stage.out_like(self.graph[rr.get_idxs()[0]].weight, S[self.offsets[i]:self.offsets[i + 1]])
+                rr.S = s if rr.S is None else rr.S.to(s.device) * s
         return sweeps
+
+    def close(self):
+        for p in (self.rebuild, self.snapshot):
+            if p is not None:
+                p.close()
+        if self.session is not None:
+            self.session.close()
+            self.session = None
 
 
 def sharded_cross_layer_equalization(graph, relations, targ_type, group=None, s_range=(1e-8, 1e8),
                                      converge_thres=2e-7, converge_count=20, signed=False, eps=0,
-                                     max_sweeps=None, le_runner=None, rescale=None):
-    """Equalise ``graph`` in place on every rank of ``group``; returns the number of sweeps.
+                                     max_sweeps=None, le_runner=None, use_torch_rebuild=False):
+    """Equalise ``graph`` in place on every rank of ``group``; returns the number of sweeps.  Every rank ends with
+    the same bits in every tensor (see the module docstring).
 
-    ``le_runner(graph, relations, targ_type, max_sweeps=..., **kw) -> dict`` and
-    ``rescale(weight, bias, bn_tensors, s_out, s_in, groups)`` default to the HIP engine; tests inject
-    CPU stand-ins to exercise the partition / exchange / rebuild logic over gloo.
+    ``le_runner(graph, relations, targ_type, max_sweeps=..., **kw) -> dict`` and ``use_torch_rebuild`` replace the
+    HIP engine's sweeps / batched rebuild launch by CPU stand-ins in the partition / exchange logic tests.
 
     ``max_sweeps=N`` pins the sweep count (no exchange before the final all_gather -- the mode for networks
     whose reference loop does not terminate, SURVEY 7.3 item 4, and the one bench.py times for config 4);
     ``max_sweeps=None`` keeps the reference's data-dependent loop: one 8-byte all_reduce per sweep.
     """
     eq = ShardedEqualizer(graph, relations, targ_type, group=group, s_range=s_range, signed=signed, eps=eps,
-                          le_runner=le_runner, rescale=rescale)
-    return eq.run(max_sweeps=max_sweeps, converge_thres=converge_thres, converge_count=converge_count)
+                          le_runner=le_runner, use_torch_rebuild=use_torch_rebuild)
+    try:
+        return eq.run(max_sweeps=max_sweeps, converge_thres=converge_thres, converge_count=converge_count)
+    finally:
+        eq.close()

@@ -322,6 +322,28 @@ int dfq_scale_cols(float* w, int32_t out_ch, int32_t in_per_group, int32_t khkw,
                    const float* s, int32_t op, void* stream);
 /* vector helpers on [n]: y = y * s (op 0), y / s (op 1), y + s (op 2), y - s (op 3) */
 int dfq_vec_op(float* y, const float* s, int64_t n, int32_t op, void* stream);
+
+/* Batched rebuild from pristine tensors and cumulative scale vectors (utils/relation.py:20-24; the replicated write of
+ * the sharded equalisation):  dst[o,i,k] = fl(fl(src[o,i,k] * s_out[o]) / s_in[ch(o,i)])  with
+ * ch = (o / (rows/groups)) * cols + i  -- two separately rounded float32 operations in this order; a NULL vector
+ * skips its step (both NULL: a copy).  Vectors (bias, BN proxies) are items with cols = khkw = groups = 1.  src may equal
+ * dst.  ONE launch covers all items of a plan (8 B per element); identical inputs give bit-identical outputs on every
+ * rank.  `items` is a host array and is copied.  Synchronises (create only). */
+typedef struct dfq_rebuild_item {
+    const float* src;      /* device [rows, cols, khkw]                                   */
+    float* dst;            /* device, same shape                                          */
+    const float* s_out;    /* device [rows] or NULL                                       */
+    const float* s_in;     /* device [groups * cols] or NULL                              */
+    int32_t rows;          /* O                                                           */
+    int32_t cols;          /* I / groups                                                  */
+    int32_t khkw;
+    int32_t groups;
+} dfq_rebuild_item;
+typedef struct dfq_rebuild_plan dfq_rebuild_plan;   /* opaque */
+int dfq_rebuild_plan_create(const dfq_rebuild_item* items, int32_t n_items, dfq_rebuild_plan** out_plan);
+void dfq_rebuild_plan_destroy(dfq_rebuild_plan* plan);
+int64_t dfq_rebuild_plan_elements(const dfq_rebuild_plan* plan);
+int dfq_rebuild_plan_run(dfq_rebuild_plan* plan, void* stream);
 /* x = clamp(x, lo, hi) (dfq.py:170) */
 int dfq_clamp(float* x, int64_t n, float lo, float hi, void* stream);
 

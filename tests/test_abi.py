@@ -61,8 +61,8 @@ def test_struct_layouts_match_header():
     #include <stdio.h>
     #include "dfq_hip.h"
     int main(void) {
-        printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(dfq_layer), sizeof(dfq_relation), sizeof(dfq_le_config),
-               sizeof(dfq_le_result), sizeof(dfq_segment), sizeof(dfq_bc_source), sizeof(dfq_bc_step));
+        printf("%zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(dfq_layer), sizeof(dfq_relation), sizeof(dfq_le_config),
+               sizeof(dfq_le_result), sizeof(dfq_segment), sizeof(dfq_bc_source), sizeof(dfq_bc_step), sizeof(dfq_rebuild_item));
         return 0;
     }'''
     import tempfile
@@ -73,7 +73,7 @@ def test_struct_layouts_match_header():
         subprocess.run(['gcc', '-I', os.path.join(ROOT, 'include'), c, '-o', exe], check=True)
         sizes = [int(v) for v in subprocess.run([exe], capture_output=True, text=True, check=True).stdout.split()]
     want = [ctypes.sizeof(t) for t in (_ffi.DfqLayer, _ffi.DfqRelation, _ffi.DfqLeConfig, _ffi.DfqLeResult,
-                                       _ffi.DfqSegment, _ffi.DfqBcSource, _ffi.DfqBcStep)]
+                                       _ffi.DfqSegment, _ffi.DfqBcSource, _ffi.DfqBcStep, _ffi.DfqRebuildItem)]
     assert sizes == want
 
 

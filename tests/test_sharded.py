@@ -90,17 +90,6 @@ def _oracle_runner(graph, relations, targ_type, max_sweeps=None, **kw):
     return dict(sweeps=n_sw, last_diff_tmp=trace[-1] if trace else 0.0)
 
 
-def _torch_rescale(weight, bias, bn, s_out, s_in, groups):
-    with torch.no_grad():
-        if s_out is not None:
-            weight.mul_(s_out.view((-1,) + (1,) * (weight.dim() - 1)))
-            for v in ([bias] if bias is not None else []) + list(bn):
-                v.mul_(s_out)
-        if s_in is not None:
-            per_row = s_in.view(groups, -1).repeat_interleave(weight.shape[0] // groups, dim=0)
-            weight.div_(per_row.view((weight.shape[0], -1) + (1,) * (weight.dim() - 2)))
-
-
 def _use_emulated_engine(emu_path):
     """In a spawned rank: route dfq_amd to the CPU emulation build of the kernels (as the `engine` fixture does)."""
     import ctypes
@@ -111,7 +100,7 @@ def _use_emulated_engine(emu_path):
     _ffi.synchronize = lambda: None
 
 
-def _worker(rank, world, port, name, seed, max_sweeps, out_dir, emu_path=None):
+def _worker(rank, world, port, name, seed, max_sweeps, out_dir, emu_path, standin=False, finish=True):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
@@ -119,12 +108,12 @@ def _worker(rank, world, port, name, seed, max_sweeps, out_dir, emu_path=None):
         torch.set_num_threads(1)
         model, graph, bottoms, _ = _prepare(name, seed)
         rels = rel.create_relation(graph, bottoms, TARG)
-        if emu_path:          # the product code path: engine sweeps per rank, engine rescale of the foreign layers
-            _use_emulated_engine(emu_path)
-            sweeps = sharded.sharded_cross_layer_equalization(graph, rels, TARG, max_sweeps=max_sweeps)
-        else:
+        _use_emulated_engine(emu_path)
+        if standin:           # numpy oracle per rank + torch ops for the rebuild: the partition / exchange logic alone
             sweeps = sharded.sharded_cross_layer_equalization(graph, rels, TARG, max_sweeps=max_sweeps,
-                                                              le_runner=_oracle_runner, rescale=_torch_rescale)
+                                                              le_runner=_oracle_runner, use_torch_rebuild=True)
+        else:                 # the product code path: engine sweeps per rank, ONE batched engine rebuild launch
+            sweeps = sharded.sharded_cross_layer_equalization(graph, rels, TARG, max_sweeps=max_sweeps)
         owner = sharded.assign_components(graph, rels, world)
         snap = {'sweeps': np.array(sweeps), 'owner': np.array(owner)}
         for i, k in enumerate(graph):
@@ -138,17 +127,86 @@ def _worker(rank, world, port, name, seed, max_sweeps, out_dir, emu_path=None):
                 snap['L{}.fb'.format(i)] = npy(m.fake_bias)
         for i, rr in enumerate(rels):
             snap['S{}'.format(i)] = npy(rr.get_scale_vec())
+        if finish:            # the replicated tail of the pass: bias correction + int8 weights / 16-bit biases (engine kernels)
+            from dfq_amd import dfq
+            from dfq_amd.utils import layer_transform as lt
+            dfq.bias_correction(graph, bottoms, TARG)
+            for i, k in enumerate(graph):
+                m = graph[k]
+                if type(m) in TARG and m.bias is not None:
+                    snap['C{}.b'.format(i)] = npy(m.bias)
+                elif type(m) == nn.BatchNorm2d and hasattr(m, 'fake_weight'):
+                    snap['C{}.fb'.format(i)] = npy(m.fake_bias)
+            _, codes = lt.quantize_targ_layer(graph, 8, 16, TARG, return_codes=True)
+            for j, k in enumerate(codes):
+                snap['Q{}'.format(j)] = npy(codes[k])
         np.savez(os.path.join(out_dir, 'rank{}.npz'.format(rank)), **snap)
     finally:
         dist.destroy_process_group()
+
+
+def _check_against_oracle(res_list, graph, spec, S_ref):
+    """every tensor within 1e-5 of the sequential (single-process oracle) result, cumulative scales bit-identical"""
+    keys = list(graph.keys())
+    worst = 0.0
+    for res in res_list:
+        for i, k in enumerate(keys):
+            n = spec.nodes[k]
+            if n.kind == 'targ':
+                worst = max(worst, assert_close(res['L{}.w'.format(i)], n.weight, 'w {}'.format(k)))
+                if n.bias is not None and 'L{}.b'.format(i) in res:
+                    assert_close(res['L{}.b'.format(i)], n.bias, 'b {}'.format(k))
+            elif n.kind == 'bn' and n.fake_weight is not None:
+                assert_close(res['L{}.fw'.format(i)], n.fake_weight, 'fw {}'.format(k))
+                assert_close(res['L{}.fb'.format(i)], n.fake_bias, 'fb {}'.format(k))
+        for i, s in enumerate(S_ref):
+            assert_bitexact(res['S{}'.format(i)], s, 'S{}'.format(i))
+    return worst
+
+
+def _check_ranks_identical(r0, r1, need_tail):
+    """All ranks end with the SAME BITS in every tensor -- equalised weights / biases / BN proxies, and then the replicated
+    tail of the pass: corrected biases, BN proxies after bias correction, int8 weight codes."""
+    kinds = set()
+    assert sorted(r0.files) == sorted(r1.files)
+    for k in r0.files:
+        if k[0] in 'LCQS':
+            assert_bitexact(r0[k], r1[k], 'rank 0 vs rank 1: ' + k)
+            kinds.add(k[0])
+    assert kinds >= (set('LCQS') if need_tail else set('LS'))
+
+
+def _canonical(name, seed, S_ref):
+    """diag(S_out) . W0 . diag(1/S_in) with numpy float32 operations, from the pristine tensors and the oracle's cumulative
+    scales: what every rank must hold, bit for bit, for every world size."""
+    model, graph, bottoms, spec = _prepare(name, seed)
+    orels = orc.create_relation(spec)
+    out = {}
+    keys = list(graph.keys())
+    for (a, b, bn), S in zip(orels, S_ref):
+        S = S.astype(np.float32)
+        na, nb = spec.nodes[a], spec.nodes[b]
+        out.setdefault(a, na.weight.copy())
+        out.setdefault(b, nb.weight.copy())
+    for (a, b, bn), S in zip(orels, S_ref):      # rows first (fl(w0 * s_out)) ...
+        S = S.astype(np.float32)
+        out[a] = out[a] * S.reshape((-1,) + (1,) * (out[a].ndim - 1))
+    for (a, b, bn), S in zip(orels, S_ref):      # ... then columns (fl(t / s_in))
+        S = S.astype(np.float32)
+        w = out[b]
+        groups = getattr(graph[b], 'groups', 1)
+        per_row = np.repeat(S.reshape(groups, -1), w.shape[0] // groups, axis=0)
+        out[b] = w / per_row.reshape((w.shape[0], -1) + (1,) * (w.ndim - 2))
+    return {'L{}.w'.format(keys.index(k)): v for k, v in out.items()}
 
 
 @pytest.mark.parametrize('engine_kind', ['stand-in', 'emulated-engine'])
 @pytest.mark.parametrize('name,seed,max_sweeps', [('tiny_mobile', 0, 5), ('tiny_mobile', 0, None), ('tiny_res', 0, 3)])
 def test_sharded_equalization_two_ranks(tmp_path, emu_lib_path, name, seed, max_sweeps, engine_kind):
     world = 2
-    emu = emu_lib_path if engine_kind == 'emulated-engine' else None
-    mp.spawn(_worker, args=(world, _free_port(), name, seed, max_sweeps, str(tmp_path), emu), nprocs=world, join=True)
+    standin = engine_kind == 'stand-in'
+    mp.spawn(_worker, args=(world, _free_port(), name, seed, max_sweeps, str(tmp_path), emu_lib_path, standin),
+             nprocs=world, join=True)
     # single-process result of the same algorithm
     model, graph, bottoms, spec = _prepare(name, seed)
     orels = orc.create_relation(spec)
@@ -161,31 +219,33 @@ def test_sharded_equalization_two_ranks(tmp_path, emu_lib_path, name, seed, max_
     r1 = np.load(os.path.join(str(tmp_path), 'rank1.npz'))
     assert int(r0['sweeps']) == int(r1['sweeps']) == n_ref
     assert len(set(r0['owner'].tolist())) == 2, 'both ranks must own work'
-    keys = list(graph.keys())
-    for res in (r0, r1):
-        for i, k in enumerate(keys):
-            n = spec.nodes[k]
-            if n.kind == 'targ':
-                assert_close(res['L{}.w'.format(i)], n.weight, 'w {}'.format(k))
-                if n.bias is not None and 'L{}.b'.format(i) in res:
-                    assert_close(res['L{}.b'.format(i)], n.bias, 'b {}'.format(k))
-            elif n.kind == 'bn' and n.fake_weight is not None:
-                assert_close(res['L{}.fw'.format(i)], n.fake_weight, 'fw {}'.format(k))
-                assert_close(res['L{}.fb'.format(i)], n.fake_bias, 'fb {}'.format(k))
-        for i, s in enumerate(S_ref):
-            assert_bitexact(res['S{}'.format(i)], s, 'S{}'.format(i))
-    # both ranks end with the same network
-    for k in r0.files:
-        if k.startswith('L'):
-            assert_close(r0[k], r1[k], k)
+    _check_against_oracle((r0, r1), graph, spec, S_ref)
+    _check_ranks_identical(r0, r1, need_tail=True)
+    # ... and it is THE canonical rebuild, whoever computed it (torch stand-in or the engine's batched launch)
+    for k, v in _canonical(name, seed, S_ref).items():
+        assert_bitexact(r0[k], v, 'canonical ' + k)
+
+
+def test_sharded_result_does_not_depend_on_world_size(tmp_path, emu_lib_path):
+    """One rank and two ranks end with the same bits (the rebuild is a function of W0 and the cumulative scales only)."""
+    outs = []
+    for world in (1, 2):
+        d = tmp_path / 'w{}'.format(world)
+        d.mkdir()
+        mp.spawn(_worker, args=(world, _free_port(), 'tiny_mobile', 0, 5, str(d), emu_lib_path), nprocs=world, join=True)
+        outs.append(np.load(os.path.join(str(d), 'rank0.npz')))
+    for k in outs[0].files:
+        if k[0] in 'LCQS':
+            assert_bitexact(outs[0][k], outs[1][k], 'world 1 vs world 2: ' + k)
 
 
 def test_sharded_deeplab_two_ranks_product_path(tmp_path, emu_lib_path):
     """BASELINE.json config 4: DeepLab-v3+ (MobileNetV2 backbone, 61 convs, 35 relations) sharded over ranks, pinned to
     12 sweeps (the reference's loop does not terminate on this network) -- the product code path
-    (per-rank engine plan kept alive over the run, ONE all_gather of the cumulative scale vectors, engine rebuild of
-    the foreign layers) on the CPU emulation of the kernels, world size 2 over gloo, against the single-process oracle:
-    owned layers bit-exact in their cumulative scales, every tensor within 1e-5."""
+    (per-rank engine plan over scratch copies, ONE all_gather of the cumulative scale vectors, ONE batched rebuild launch on
+    every rank, then the replicated bias correction and int8 quantisation) on the CPU emulation of the kernels, world size 2
+    over gloo, against the single-process oracle: cumulative scales bit-exact, every tensor within 1e-5, and the two ranks
+    bit-identical in every tensor, every corrected bias and every int8 code."""
     world, name, seed, sweeps = 2, 'deeplab_mnv2', 0, 12
     mp.spawn(_worker, args=(world, _free_port(), name, seed, sweeps, str(tmp_path), emu_lib_path), nprocs=world, join=True)
     model, graph, bottoms, spec = _prepare(name, seed)
@@ -196,23 +256,10 @@ def test_sharded_deeplab_two_ranks_product_path(tmp_path, emu_lib_path):
     r1 = np.load(os.path.join(str(tmp_path), 'rank1.npz'))
     assert int(r0['sweeps']) == int(r1['sweeps']) == n_ref == sweeps
     assert sorted(set(r0['owner'].tolist())) == [0, 1]
-    keys = list(graph.keys())
-    worst = 0.0
-    for res in (r0, r1):
-        for i, k in enumerate(keys):
-            n = spec.nodes[k]
-            if n.kind == 'targ':
-                worst = max(worst, assert_close(res['L{}.w'.format(i)], n.weight, 'w {}'.format(k)))
-                if n.bias is not None and 'L{}.b'.format(i) in res:
-                    assert_close(res['L{}.b'.format(i)], n.bias, 'b {}'.format(k))
-            elif n.kind == 'bn' and n.fake_weight is not None:
-                assert_close(res['L{}.fw'.format(i)], n.fake_weight, 'fw {}'.format(k))
-                assert_close(res['L{}.fb'.format(i)], n.fake_bias, 'fb {}'.format(k))
-        for i, s in enumerate(S_ref):
-            assert_bitexact(res['S{}'.format(i)], s, 'S{}'.format(i))
-    for k in r0.files:
-        if k.startswith('L'):
-            assert_close(r0[k], r1[k], k)
+    _check_against_oracle((r0, r1), graph, spec, S_ref)
+    _check_ranks_identical(r0, r1, need_tail=True)
+    for k, v in _canonical(name, seed, S_ref).items():
+        assert_bitexact(r0[k], v, 'canonical ' + k)
 
 
 def test_components_and_assignment():
@@ -234,8 +281,10 @@ def test_components_and_assignment():
 @pytest.mark.gpu
 def test_sharded_path_over_rccl_single_rank():
     """The RCCL ('nccl') branch of the sharded path on a real GPU: world size 1 (the GPU box has one device) -- the
-    collectives, the device-side scale exchange and the engine's per-rank sweeps run for real; the result must equal
-    the plain single-GPU equalisation bit for bit (one rank owns every component)."""
+    collectives, the device-side scale exchange, the engine's per-rank sweeps on scratch copies and the batched rebuild
+    launch run for real.  Cumulative scales: bit-identical to the plain single-GPU equalisation; tensors: within 1e-5 of
+    it and bit-identical to the canonical rebuild diag(S_out) . W0 . diag(1/S_in) computed with numpy -- the same bits a
+    rank of a larger group would hold (tests above)."""
     from dfq_amd import dfq
     from dfq_amd.utils import layer_transform as lt
     from common import snapshot
@@ -245,22 +294,46 @@ def test_sharded_path_over_rccl_single_rank():
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
     try:
-        out = []
-        for use_sharded in (True, False):
-            model, graph, bottoms = synthetic.build('tiny_mobile', seed=0)
-            model.to(dev)
-            lt.merge_batchnorm(model, graph, bottoms, TARG)
-            rels = rel.create_relation(graph, bottoms, TARG)
-            if use_sharded:
-                sweeps = sharded.sharded_cross_layer_equalization(graph, rels, TARG, max_sweeps=5)
-            else:
-                dfq.cross_layer_equalization(graph, rels, TARG, max_sweeps=5, converge_thres=-1.0, converge_count=10 ** 9)
-                sweeps = dfq.last_equalization['sweeps']
-            out.append((sweeps, snapshot(graph), [npy(r.get_scale_vec()) for r in rels]))
-        assert out[0][0] == out[1][0] == 5
-        for k in out[1][1]:
-            assert_bitexact(out[0][1][k], out[1][1][k], k)
-        for a, b in zip(out[0][2], out[1][2]):
-            assert_bitexact(a, b, 'S')
+        for name, sweeps_pin in (('tiny_mobile', 5), ('deeplab_mnv2', 12)):
+            out = []
+            for use_sharded in (True, False):
+                model, graph, bottoms = synthetic.build(name, seed=0)
+                model.to(dev)
+                lt.merge_batchnorm(model, graph, bottoms, TARG)
+                rels = rel.create_relation(graph, bottoms, TARG)
+                w0 = snapshot(graph)
+                if use_sharded:
+                    sweeps = sharded.sharded_cross_layer_equalization(graph, rels, TARG, max_sweeps=sweeps_pin)
+                else:
+                    dfq.cross_layer_equalization(graph, rels, TARG, max_sweeps=sweeps_pin, converge_thres=-1.0,
+                                                 converge_count=10 ** 9)
+                    sweeps = dfq.last_equalization['sweeps']
+                out.append((sweeps, snapshot(graph), [npy(r.get_scale_vec()) for r in rels]))
+            assert out[0][0] == out[1][0] == sweeps_pin
+            for a, b in zip(out[0][2], out[1][2]):
+                assert_bitexact(a, b, 'S')
+            for k in out[1][1]:
+                assert_close(out[0][1][k], out[1][1][k], k)
+            # canonical rebuild from the pristine tensors and the cumulative scales (numpy float32: one rounding per operation)
+            keys = list(graph.keys())
+            want = {k: v.copy() for k, v in w0.items()}
+            for rr, S in zip(rels, out[0][2]):
+                a, b, bn = rr.get_idxs()
+                ia = keys.index(a)
+                want['L{}.w'.format(ia)] = want['L{}.w'.format(ia)] * S.reshape((-1,) + (1,) * (want['L{}.w'.format(ia)].ndim - 1))
+                want['L{}.b'.format(ia)] = want.get('L{}.b'.format(ia), np.zeros_like(S)) * S
+                if bn is not None:
+                    ib = keys.index(bn)
+                    want['L{}.fw'.format(ib)] = want['L{}.fw'.format(ib)] * S
+                    want['L{}.fb'.format(ib)] = want['L{}.fb'.format(ib)] * S
+            for rr, S in zip(rels, out[0][2]):
+                a, b, bn = rr.get_idxs()
+                ib = keys.index(b)
+                w = want['L{}.w'.format(ib)]
+                groups = getattr(graph[b], 'groups', 1)
+                per_row = np.repeat(S.reshape(groups, -1), w.shape[0] // groups, axis=0)
+                want['L{}.w'.format(ib)] = w / per_row.reshape((w.shape[0], -1) + (1,) * (w.ndim - 2))
+            for k in want:
+                assert_bitexact(out[0][1][k], want[k], 'canonical ' + k)
     finally:
         dist.destroy_process_group()
