@@ -135,10 +135,13 @@ def _trace(model, key_style='name'):
                 key = '{}_{}'.format(type(m).__name__, counter) if key_style == 'name' else m
                 graph[key] = m
             else:
-                # unknown operation: an opaque node (a string, like the reference's tensor-op entries)
+                # unknown operation: an opaque node (a string, like the reference's tensor-op entries).  The passes
+                # classify string nodes by SUBSTRINGS of the key ('add', 'cat', 'mean', 'pad', 'interpolate': relation.py:42-43,
+                # layer_transform.py:316-326), so the key must not carry the operation's name (addmm, scatter, ...): the name
+                # goes into the value
                 name = getattr(n.target, '__name__', None) or str(n.target)
-                key = '{}_{}'.format(name if is_fn else 'Tensor.' + name, counter)
-                graph[key] = key
+                key = 'opaque_{}'.format(counter)
+                graph[key] = 'opaque:{}'.format(name if is_fn else 'Tensor.' + name)
         else:                      # get_attr etc.
             continue
         bots = []
@@ -152,12 +155,17 @@ def _trace(model, key_style='name'):
     return graph, bottoms, fx_graph, alias
 
 
-def quantize_tensor_ops(model, ops=('add', 'cat', 'mean'), num_bits=8, momentum=0.1, key_style='name'):
+# the reference's list (utils/layer_transform.py:10-14): Tensor.__add__ / add / __iadd__, torch.cat, torch.mean,
+# F.interpolate, F.softmax.  add / cat get one quantiser per input, the others one for their (first) input.
+TENSOR_OPS = ('add', 'cat', 'mean', 'interpolate', 'softmax')
+
+
+def quantize_tensor_ops(model, ops=TENSOR_OPS, num_bits=8, momentum=0.1, key_style='name'):
     """Activation quantisers on the inputs of tensor ops -- what the reference's ``switch_layers(quant_op=True)``
-    + ``replace_op`` achieve by monkey-patching ``torch.Tensor.__add__`` / ``torch.cat`` / ``torch.mean`` and
-    routing their inputs through a ``CustomTensorOP`` container (layer_transform.py:16-228) -- done as a torch.fx
-    rewrite: one ``QuantMeasure`` per tensor input of every add / cat node (one for mean) is inserted in front
-    of the op.
+    + ``replace_op`` achieve by monkey-patching ``torch.Tensor.__add__`` / ``torch.cat`` / ``torch.mean`` /
+    ``F.interpolate`` / ``F.softmax`` and routing their inputs through a ``CustomTensorOP`` container
+    (layer_transform.py:16-228) -- done as a torch.fx rewrite: one ``QuantMeasure`` per tensor input of every add / cat
+    node (one for the input of mean, interpolate, softmax) is inserted in front of the op.
 
     Returns ``(quantised GraphModule, graph, bottoms, tensor_op_quant)``.  ``graph`` / ``bottoms`` are those of
     ``trace(model)`` (the quantisers live on the edges, they are no graph nodes, as in the reference);
@@ -179,7 +187,7 @@ def quantize_tensor_ops(model, ops=('add', 'cat', 'mean'), num_bits=8, momentum=
         if not any(tag in key for tag in ops):
             continue
         ins = [i for i in _tensor_inputs(n) if i in alias]
-        if 'mean' in key:
+        if not ('add' in key or 'cat' in key):      # mean / interpolate / softmax: the data input only
             ins = ins[:1]
         quants = []
         replaced = {}

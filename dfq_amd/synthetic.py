@@ -324,6 +324,37 @@ class TinyHead(nn.Module):
         return self.fc2(self.fc1(x))
 
 
+class TinySeg(nn.Module):
+    """DeepLab in miniature: every functional op the reference quantises on a segmentation graph
+    (utils/layer_transform.py:10-14) -- F.interpolate behind a BN + ReLU (ASPP image pooling, decoder upsampling), behind a
+    plain conv (the logits), torch.cat of branches, a residual add, and F.softmax on the upsampled logits."""
+
+    def __init__(self, n_class=4):
+        super().__init__()
+        self.stem = nn.Sequential(*_conv_bn_relu(3, 8, 3, 2, 1))
+        self.low = InvertedResidual(8, 8, 1, 2)
+        self.high = InvertedResidual(8, 12, 2, 3)
+        self.b0 = nn.Sequential(nn.Conv2d(12, 6, 1, bias=False), nn.BatchNorm2d(6), nn.ReLU())
+        self.b1 = nn.Sequential(nn.Conv2d(12, 6, 3, padding=2, dilation=2, bias=False), nn.BatchNorm2d(6), nn.ReLU())
+        self.gp = nn.Sequential(nn.AdaptiveAvgPool2d((1, 1)), nn.Conv2d(12, 6, 1, bias=False), nn.BatchNorm2d(6), nn.ReLU())
+        self.proj = nn.Sequential(nn.Conv2d(18, 10, 1, bias=False), nn.BatchNorm2d(10), nn.ReLU(), nn.Dropout(0.5))
+        self.lowp = nn.Sequential(nn.Conv2d(8, 4, 1, bias=False), nn.BatchNorm2d(4), nn.ReLU())
+        self.last = nn.Sequential(nn.Conv2d(14, 10, 3, padding=1, bias=False), nn.BatchNorm2d(10), nn.ReLU(),
+                                  nn.Conv2d(10, n_class, 1))
+
+    def forward(self, inp):
+        low = self.low(self.stem(inp))
+        x = self.high(low)
+        x0, x1 = self.b0(x), self.b1(x)
+        x2 = F.interpolate(self.gp(x), size=(x1.shape[2], x1.shape[3]), mode='bilinear', align_corners=True)
+        x = self.proj(torch.cat((x0, x1, x2), dim=1))
+        lowp = self.lowp(low)
+        x = F.interpolate(x, size=(lowp.shape[2], lowp.shape[3]), mode='bilinear', align_corners=True)
+        x = self.last(torch.cat((x, lowp), dim=1))
+        x = F.interpolate(x, size=(inp.shape[2], inp.shape[3]), mode='bilinear', align_corners=True)
+        return F.softmax(x, dim=1)
+
+
 # ------------------------------------------------------------------------------------------
 # factory helpers
 # ------------------------------------------------------------------------------------------
@@ -360,7 +391,7 @@ def relu6_to_relu(model):
 
 _FACTORY = {
     'mobilenet_v2': MobileNetV2, 'resnet18': ResNet18, 'deeplab_mnv2': DeepLabMNV2,
-    'tiny_mobile': TinyMobile, 'tiny_res': TinyRes, 'tiny_cat': TinyCat, 'tiny_wide': TinyWide, 'tiny_head': TinyHead,
+    'tiny_mobile': TinyMobile, 'tiny_res': TinyRes, 'tiny_cat': TinyCat, 'tiny_wide': TinyWide, 'tiny_head': TinyHead, 'tiny_seg': TinySeg,
 }
 
 

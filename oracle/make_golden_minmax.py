@@ -71,13 +71,13 @@ def q_graph(graph):
 
 def tensor_op_nodes(graph, bottoms):
     """{key: number of quantisers} for the tensor ops the reference quantises (layer_transform.py:10-14):
-    one quantiser per input of an add / cat, one for the input of torch.mean."""
+    one quantiser per input of an add / cat, one for the input of torch.mean, F.interpolate and F.softmax."""
     out = OrderedDict()
     for k, m in graph.items():
         if isinstance(m, str) and k != 'Data':
             if 'add' in k or 'cat' in k:
                 out[k] = len(bottoms[k])
-            elif 'mean' in k:
+            elif 'mean' in k or 'interpolate' in k or 'softmax' in k:
                 out[k] = 1
     return out
 
@@ -128,7 +128,7 @@ def run(name, seed, keep_relu6=False, is_detection=False, N=6, tensor_ops=False)
         n = spec.nodes[k]
         if n.kind == 'bn':
             out['bn{}'.format(i)] = np.stack([n.fake_weight, n.fake_bias])
-        elif n.kind == 'targ' and name == 'tiny_head':       # only case (d) reads weights; keep the fixtures small
+        elif n.kind == 'targ' and name in ('tiny_head', 'tiny_seg'):       # only case (d) reads weights; keep the fixtures small
             out['w{}'.format(i)] = n.weight
             if n.bias is not None:
                 out['b{}'.format(i)] = n.bias
@@ -182,6 +182,9 @@ def main():
     run('tiny_mobile', 0, tensor_ops=True)
     run('tiny_cat', 1, keep_relu6=True, tensor_ops=True)
     run('resnet18', 0, tensor_ops=True)
+    run('tiny_seg', 0, tensor_ops=True)
+    run('tiny_seg', 1, keep_relu6=True, tensor_ops=True)
+    run('tiny_seg', 2)
 
 
 if __name__ == '__main__':

@@ -117,20 +117,41 @@ def test_qconv_forward_matches_manual_fake_quant(engine):
 
 
 def test_sharded_rebuild_kernels(engine):
-    """diag(S_out) . W0 . diag(1/S_in) with the engine's row/column kernels (dfq_amd/sharded.py)."""
+    """diag(S_out) . W0 . diag(1/S_in) with the engine's batched rebuild launch (dfq_amd/sharded.py): ONE launch over
+    weights of every geometry (vector and scalar paths, grouped, linear, rows that are no multiple of 4, an out-of-place
+    copy item, an unaligned view) plus the per-channel vectors; two separately rounded float32 operations per element."""
     rng = np.random.default_rng(3)
-    for shape, groups in [((12, 6, 3, 3), 1), ((12, 3, 3, 3), 4), ((10, 7), 1)]:
+    items, want = [], []
+    cases = [((12, 6, 3, 3), 1), ((12, 3, 3, 3), 4), ((10, 7), 1), ((16, 8, 1, 1), 1), ((24, 1, 3, 3), 24), ((9, 4100), 1),
+             ((8, 16, 3, 3), 2)]
+    for shape, groups in cases:
         w = rng.standard_normal(shape).astype(F32)
         b = rng.standard_normal(shape[0]).astype(F32)
         so = rng.uniform(0.5, 2, shape[0]).astype(F32)
         si = rng.uniform(0.5, 2, shape[1] * groups).astype(F32)
         tw, tb = engine.to(torch.from_numpy(w.copy())), engine.to(torch.from_numpy(b.copy()))
-        sharded._engine_rescale(tw, tb, [], engine.to(torch.from_numpy(so)), engine.to(torch.from_numpy(si)), groups)
-        want = (w * so.reshape((-1,) + (1,) * (w.ndim - 1))).astype(F32)
+        tso, tsi = engine.to(torch.from_numpy(so)), engine.to(torch.from_numpy(si))
+        items += [(tw, tw, tso, tsi, groups), (tb, tb, tso, None, 1)]
+        t = (w * so.reshape((-1,) + (1,) * (w.ndim - 1))).astype(F32)
         per_row = si.reshape(groups, -1).repeat(shape[0] // groups, axis=0)
-        want = (want / per_row.reshape((shape[0], shape[1]) + (1,) * (w.ndim - 2))).astype(F32)
-        assert_bitexact(npy(tw), want, 'weight {}'.format(shape))
-        assert_bitexact(npy(tb), (b * so).astype(F32), 'bias')
+        want += [(t / per_row.reshape((shape[0], shape[1]) + (1,) * (w.ndim - 2))).astype(F32), (b * so).astype(F32)]
+    # rows only / columns only / plain copy into another buffer / a view that is not 16-byte aligned
+    w = rng.standard_normal((6, 8)).astype(F32)
+    s6, s8 = rng.uniform(0.5, 2, 6).astype(F32), rng.uniform(0.5, 2, 8).astype(F32)
+    src = engine.to(torch.from_numpy(w.copy()))
+    d0, d1, d2 = (torch.zeros_like(src) for _ in range(3))
+    arena = engine.to(torch.zeros(49 + 3))
+    d3 = arena[3:51].view(6, 8)
+    items += [(src, d0, engine.to(torch.from_numpy(s6)), None, 1), (src, d1, None, engine.to(torch.from_numpy(s8)), 1),
+              (src, d2, None, None, 1), (src, d3, None, None, 1)]
+    want += [(w * s6[:, None]).astype(F32), (w / s8[None, :]).astype(F32), w, w]
+    plan = sharded._RebuildPlan(items)
+    assert plan.elements == sum(int(np.prod(x.shape)) for x in want)
+    plan.run()
+    for (_, dst, _, _, _), ref in zip(items, want):
+        assert_bitexact(npy(dst), ref, 'rebuild item {}'.format(tuple(ref.shape)))
+    assert_bitexact(npy(src), w, 'out-of-place source untouched')
+    plan.close()
 
 
 @pytest.mark.gpu

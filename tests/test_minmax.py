@@ -32,13 +32,14 @@ def _parse(tag):
 
 
 def _tensor_ops(graph, bottoms):
-    """{key: quantisers} of the tensor ops the reference quantises: one per input of add / cat, one for mean."""
+    """{key: quantisers} of the tensor ops the reference quantises (utils/layer_transform.py:10-14): one per input of
+    add / cat, one for mean / F.interpolate / F.softmax."""
     out = OrderedDict()
     for k, m in graph.items():
         if isinstance(m, str) and k != 'Data':
             if 'add' in k or 'cat' in k:
                 out[k] = len(bottoms[k])
-            elif 'mean' in k:
+            elif 'mean' in k or 'interpolate' in k or 'softmax' in k:
                 out[k] = 1
     return out
 
@@ -67,7 +68,7 @@ def _load_spec(tag):
 
 
 def test_fixtures_exist():
-    assert len(CASES) >= 14
+    assert len(CASES) >= 17
 
 
 @pytest.mark.parametrize('tag', CASES)
