@@ -890,6 +890,19 @@ int ceil_div_i(int a, int b) { return (a + b - 1) / b; }
 struct Shape { int tr, tc; };
 
 int pow2_ceil(int x) { int p = 1; while (p < x) p <<= 1; return p; }
+// groups (blocks of `go` rows) the row blocks of height tr of an R-row layer span at most -- exactly, not (tr / go + 1): with
+// one group (go == R), or row blocks that divide a group, a tile never straddles a boundary, and the bound decides whether a
+// tile of complete 960-float rows fits the LDS table at all
+int max_groups(int R, int tr, int go) {
+    static const bool exact = !(getenv("DFQ_RES_EXACT_GROUPS") && getenv("DFQ_RES_EXACT_GROUPS")[0] == '0');   // A/B switch
+    if (!exact) return (tr + go - 1) / go + 1;
+    int worst = 1;
+    for (int r0 = 0; r0 < R; r0 += tr) {
+        const int r1 = std::min(R, r0 + tr) - 1;
+        worst = std::max(worst, r1 / go - r0 / go + 1);
+    }
+    return worst;
+}
 int layout_of(int vec, int row_len, int nc) {
     if (vec == 1 && row_len <= 32 && nc == row_len) return kLayShort;
     if (vec == 4 && nc / 4 <= kBlock) return kLayFixed;
@@ -905,7 +918,7 @@ Shape pick_shape(int R, int C, int vec, int khkw, int go, int i2g, bool need_row
     if (vec == 1 && C <= 32) {               // thread-per-row tiles: complete rows, two rows per thread if they are <= 16 floats
         int tr = std::min(R, kBlock * (C <= 16 ? 2 : 1));
         if (need_row) tr = std::min(tr, kResRows);
-        if (need_col) while (tr > 1 && ((tr + go - 1) / go + 1) * std::min((C + khkw - 1) / khkw + 1, i2g) > kResTab) tr = (tr + 1) / 2;
+        if (need_col) while (tr > 1 && max_groups(R, tr, go) * std::min((C + khkw - 1) / khkw + 1, i2g) > kResTab) tr = (tr + 1) / 2;
         return Shape{tr, C};
     }
     Shape best{0, 0};
@@ -925,8 +938,8 @@ Shape pick_shape(int R, int C, int vec, int khkw, int go, int i2g, bool need_row
         // LDS table of a tile with column duty: (groups spanned by its rows) x (input channels spanned by its columns)
         const int nci = std::min((tc + khkw - 1) / khkw + 1, i2g);
         if (need_col) {
-            while (tr > 1 && ((tr + go - 1) / go + 1) * nci > kResTab) tr = (tr + 1) / 2;
-            if (((tr + go - 1) / go + 1) * nci > kResTab) continue;
+            while (tr > 1 && max_groups(R, tr, go) * nci > kResTab) tr = (tr + 1) / 2;
+            if (max_groups(R, tr, go) * nci > kResTab) continue;
         }
         const int n_rb = ceil_div_i(R, tr), n_cb = ceil_div_i(C, tc);
         // Measured (tools/trace_resident.py): a row merge over column blocks puts one more hand-off (publish -> counter ->
