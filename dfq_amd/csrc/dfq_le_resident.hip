@@ -50,6 +50,13 @@ constexpr int kResStride = 16;       // one 64-bit counter per 128-byte line
 constexpr long kResSpinLimit = 8000000;
 constexpr int kResMaxTiles = 1536;   // partials staged in LDS when the sweep's verdict is drawn
 constexpr int kResMaxLayers = 512;
+#ifndef DFQ_RES_EAGER
+#define DFQ_RES_EAGER 0              // 1: a sweep is applied in phase 3 itself (verdict of the previous sweep taken BEFORE it: measured
+                                     // slower, 24.6 vs 21.6 us per sweep -- the verdict then sits on the chain's critical path); 0: lazily
+#endif
+#ifndef DFQ_RES_TOPWAIT
+#define DFQ_RES_TOPWAIT 0            // 1: the sweep's first poll also WAITS for phase 2's counter (A/B; slower: see the loop)
+#endif
 
 typedef unsigned long long u64;
 
@@ -65,9 +72,8 @@ struct ResTile {                     // one workgroup
     int32_t nt_self, nt_a, nt_b;     // tiles of this layer / of those two
     int32_t owner;                   // holds column block 0: updates the [O] vectors of relation B
     int32_t layout;                  // kLayGeneral / kLayFixed / kLayShort
-    int32_t relay;                   // 0: polls the layers' counters itself; 1: one of its layer's first 8 tiles, polls and relays to its
-                                     // XCD's flag; 2: waits for that flag (layers of many tiles: see relay_wait)
-    int32_t pad2;
+    int32_t relax_r;                 // 1: every row of this layer lives in ONE tile -> its row statistics have a single producer
+    int32_t relax_c;                 // 1: every input channel of this layer lives in ONE tile -> likewise for its column statistics
 };
 
 struct ResRel {
@@ -91,13 +97,11 @@ struct ResArgs {
     const ResLayerDiff* layer_diff;
     u64* stats;                      // r1 arena then r2 arena; each [2 parities][channels][2 words]
     int64_t parity_stride;           // u64 words between the parities of an arena
-    u64* cnt_r;                      // per paired layer (x kResStride): tiles that published row statistics
+    u64* cnt_r;                      // [paired layer][8 copies] (x kResStride): tiles that published row statistics (see arrive)
     u64* cnt_c;                      //   "   column statistics
-    u64* done_cnt;                   // [3] (x kResStride): tiles that finished a sweep, by sweep % 3 (see the partial buffers)
-    u64* seq;                        // [3] (x kResStride): {sweep + 1, diff_tmp bits} published by tile 0, by sweep % 3
+    u64* seq;                        // [3][8 copies] (x kResStride): two words {sweep + 1 : half of diff_tmp}, by sweep % 3
     u64* err;
-    u64* flags;                      // [paired layer][phase 1 / 2][8 XCDs] (x kResStride): relayed "both counters reached round r"
-    double* partials;                // [3 parities][tiles]
+    double* partials;                // [3 parities][tiles][2]: {sweep + 1 : half of the tile's float64 sum of |dW|}
     LeState* state;
     int32_t n_tiles, n_layers;       // n_layers: targ layers of the network (layer_diff entries)
     int32_t reducer;                 // the tile that sums the partials of a sweep and publishes the result
@@ -110,22 +114,39 @@ struct ResArgs {
 };
 
 constexpr int kTraceSweeps = 6;
-constexpr int kTracePoints = 12;
+constexpr int kTracePoints = 16;
+// Cold launch arguments -- everything a sweep touches at most once (the verdict's buffers and thresholds, the trace buffer,
+// tables read in the prologue): read from the kernarg segment WHERE THEY ARE USED, through a pointer the compiler cannot
+// prove loop-invariant, instead of living in scalar registers for the whole loop (the kernel's scarce resource: descriptor
+// fields that stay live across the loop are spilled to vector-register lanes, and every use becomes a v_readlane).
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ const ResArgs DFQ_CONSTANT_AS& cold(const ResArgs&) {
+    auto p = __builtin_amdgcn_kernarg_segment_ptr();      // ResArgs is the kernel's first argument
+    asm volatile("" : "+s"(p));
+    return *(const ResArgs DFQ_CONSTANT_AS*)p;
+}
+#else
+__device__ __forceinline__ const ResArgs& cold(const ResArgs& a) { return a; }
+#endif
+template <bool kTrace>
 __device__ __forceinline__ void res_stamp(const ResArgs& a, int k, int point) {
-    if (a.trace && threadIdx.x == 0 && k < kTraceSweeps)
-        a.trace[((int64_t)blockIdx.x * kTraceSweeps + k) * kTracePoints + point] = wall_clock64();
+    if (kTrace && threadIdx.x == 0 && k < kTraceSweeps)
+        cold(a).trace[((int64_t)blockIdx.x * kTraceSweeps + k) * kTracePoints + point] = wall_clock64();
 }
 
 // ---- waits ---------------------------------------------------------------------------------------------
-// two counters at once (second may be null): one poll loop, both loads in flight
-__device__ __forceinline__ bool res_wait2(const u64* w1, u64 t1, const u64* w2, u64 t2, u64* err, int* sh_flag) {
+// up to three counters at once (null = not needed): one poll loop by one thread, all loads in flight.  The third one is
+// waited for only if `need3`; returns 0: a wait was abandoned, 1: the first two are there, 2: all three are there.
+__device__ __forceinline__ int res_wait3(const u64* w1, u64 t1, const u64* w2, u64 t2, const u64* w3, u64 t3, bool need3, u64* err,
+                                         int* sh_flag) {
     if (threadIdx.x == 0) {
         long spins = 0;
         int ok = 1;
         for (;;) {
-            const u64 a1 = __hip_atomic_load(w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const u64 a1 = w1 ? __hip_atomic_load(w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : t1;
             const u64 a2 = w2 ? __hip_atomic_load(w2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : t2;
-            if (a1 >= t1 && a2 >= t2) break;
+            const u64 a3 = w3 ? __hip_atomic_load(w3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : t3;
+            if (a1 >= t1 && a2 >= t2 && (a3 >= t3 || !need3)) { ok = (a3 >= t3) ? 2 : 1; break; }
             __builtin_amdgcn_s_sleep(1);
             ++spins;
             if (spins > kResSpinLimit ||
@@ -138,9 +159,12 @@ __device__ __forceinline__ bool res_wait2(const u64* w1, u64 t1, const u64* w2, 
         *sh_flag = ok;
     }
     __syncthreads();
-    const bool ok = *sh_flag != 0;
+    const int ok = *sh_flag;
     __syncthreads();                 // sh_flag may be rewritten by the next wait
     return ok;
+}
+__device__ __forceinline__ bool res_wait2(const u64* w1, u64 t1, const u64* w2, u64 t2, u64* err, int* sh_flag) {
+    return res_wait3(w1, t1, w2, t2, nullptr, 0, false, err, sh_flag) != 0;
 }
 
 __device__ __forceinline__ u64 ld_word(const u64* p) {
@@ -158,11 +182,35 @@ __device__ __forceinline__ void read_range(const u64* arena, int64_t off, int64_
     mx = ((uint32_t)(b >> 32) == tag) ? slot_max((uint32_t)b) : -INFINITY;
 }
 
-// everything performed -> one arrival on the counter
-__device__ __forceinline__ void arrive(u64* counter) {
-    __builtin_amdgcn_s_waitcnt(0);
+// the same in two steps: request the two words of a channel, decode them later (several channels in flight)
+struct RangeWords { u64 a, b; };
+__device__ __forceinline__ RangeWords load_range(const u64* arena, int64_t off, int64_t parity_stride, uint32_t tag, int c) {
+    const u64* p = arena + off + (int64_t)(tag & 1u) * parity_stride + 2 * (int64_t)c;
+    RangeWords w;
+    w.a = ld_word(p); w.b = ld_word(p + 1);
+    return w;
+}
+__device__ __forceinline__ bool tagged(const RangeWords& w, uint32_t tag) {
+    return (uint32_t)(w.a >> 32) == tag && (uint32_t)(w.b >> 32) == tag;
+}
+__device__ __forceinline__ void decode_range(const RangeWords& w, uint32_t tag, float& mn, float& mx) {
+    mn = ((uint32_t)(w.a >> 32) == tag) ? slot_min((uint32_t)w.a) : INFINITY;
+    mx = ((uint32_t)(w.b >> 32) == tag) ? slot_max((uint32_t)w.b) : -INFINITY;
+}
+
+// One arrival of this tile on a layer's counter.  The counter exists in eight copies, each on its own 128-byte line (a layer
+// cut into 160 tiles has 160 workgroups polling it, and polls of ONE address are served one after the other, ~12 ns each:
+// a waiter polls copy blockIdx % 8, the arriving tile bumps all eight with one instruction).
+//   strict : statistics merged from several tiles (atomicMax over the row / column blocks of a layer) -- a reader must not
+//            look before ALL contributions have been performed: s_waitcnt 0, barrier, then the arrival.
+//   relaxed: statistics with a single producer tile -- the arrival only says "issued" (barrier, no wait for the atomics:
+//            one trip through the memory system less on the producer's side of every hand-off); the reader checks the
+//            sweep tag every statistics word carries and reads again while a word still shows an older one.
+__device__ __forceinline__ u64* cnt_line(u64* base, int layer, int copy) { return base + ((int64_t)layer * 8 + copy) * kResStride; }
+__device__ __forceinline__ void arrive(u64* base, int layer, bool strict) {
+    if (strict) __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(counter, 1ull);
+    if (threadIdx.x < 8) atomicAdd(cnt_line(base, layer, threadIdx.x), 1ull);
 }
 
 __device__ __forceinline__ void opaque(int& x) {
@@ -282,7 +330,7 @@ struct LayGeneral {
             }
         });
     }
-    __device__ __forceinline__ double diff_and_cols(const ResTile&, const TileGeo&, float*, bool, bool, const float*, const float*, uint32_t*) const { return 0.0; }
+    __device__ __forceinline__ double diff_and_cols(const ResTile&, const TileGeo&, float*, bool, bool, const float*, const float*, uint32_t*, bool = false) const { return 0.0; }
     // the thread's sum of |new - old| in float64; `commit`: w <- new
     __device__ __forceinline__ double update(const ResTile& T, const TileGeo& G, float* tile, bool useA, bool useB,
                                              const float* sh_inv, const float* sh_s, bool commit) const {
@@ -387,9 +435,9 @@ struct LayFixed {
             for (int k = 0; k < 4; ++k) lds_minmax(sh_col + 2 * tabk[k], cmn[k], cmx[k]);
         }
     }
-    // one pass: |dW| (if want_diff) and the column statistics of the pending values
+    // one pass: |dW| and the column statistics of the new values; `commit`: w <- new in the same pass
     __device__ __forceinline__ double diff_and_cols(const ResTile& T, const TileGeo& G, float* tile, bool useA, bool useB,
-                                                    const float* sh_inv, const float* sh_s, uint32_t* sh_col) const {
+                                                    const float* sh_inv, const float* sh_s, uint32_t* sh_col, bool commit = false) const {
         double acc = 0.0;
         float iv[4] = {1.0f, 1.0f, 1.0f, 1.0f};
         if (useA && one_group) inv4(T, G, sh_inv, 0, iv);
@@ -401,10 +449,12 @@ struct LayFixed {
             const float sr = useB ? sh_s[row] : 1.0f;
             const int gr = one_group ? 0 : group_row(T, G, row);
             const fvec4 xv = *(const fvec4*)x;
+            fvec4 nw;
             double part = 0.0;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const float nv = (xv[k] * iv[k]) * sr;            // dfq.py:73 then :62, both rounded
+                nw[k] = nv;
                 part += (double)abs_f32(nv - xv[k]);
                 if (one_group) {
                     cmn[k] = vmin_raw(cmn[k], on ? nv : INFINITY);
@@ -413,6 +463,7 @@ struct LayFixed {
                     lds_minmax(sh_col + 2 * (gr + tabk[k]), nv, nv);
                 }
             }
+            if (commit) *(fvec4*)x = nw;                          // the thread's own slot (padded lanes hold private duplicates)
             acc += on ? part : 0.0;
         });
         if (one_group) cols_finish(cmn, cmx, sh_col);
@@ -436,7 +487,7 @@ struct LayFixed {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 nv[k] = (xv[k] * iv[k]) * s;                      // dfq.py:73 (rounded), then dfq.py:62
-                if (!commit) part += (double)abs_f32(nv[k] - xv[k]);
+                if (!commit || DFQ_RES_EAGER) part += (double)abs_f32(nv[k] - xv[k]);
             }
             if (commit) *(fvec4*)x = nv;                          // the thread's own slot (padded lanes hold private duplicates)
             acc += on ? part : 0.0;
@@ -446,73 +497,110 @@ struct LayFixed {
 };
 
 // thread t holds rows t, t + 256 of the tile (complete rows of L = row_len <= 32 floats); element e of the thread's row j
-// sits at tile[(j * L + e) * 256 + t]
+// sits at tile[(j * L + e) * 256 + t].  Everything that depends on the row only -- its group's table offset, 1/s_A of a
+// depthwise row (one input channel per group: the common case), s_B -- is fetched once per row, so an element costs one LDS
+// access and two multiplications (the first version divided twice per element to find its table entry: 40 instructions per
+// element, 2.2 us to multiply the 18 elements a thread holds).
 struct LayShort {
     static constexpr int VEC = 1;
     static constexpr bool kFusedCols = false;
-    int L, rpt;
-    __device__ __forceinline__ void init(const ResTile& T, const TileGeo&) { L = T.row_len; rpt = (T.nr + kBlock - 1) / kBlock; }
-    __device__ __forceinline__ int tab(const ResTile& T, const TileGeo& G, int row, int e) const {
-        return (small_div(T.r0 + row, T.go) - G.g_lo) * G.nci + small_div(e, T.khkw);     // complete rows: i0 == 0
+    int L, rpt, nci, khkw;
+    int rt[kResOwn];                   // table offset of the row's group: (group - g_lo) * nci
+    __device__ __forceinline__ void init(const ResTile& T, const TileGeo& G) {
+        L = T.row_len; rpt = (T.nr + kBlock - 1) / kBlock; nci = G.nci; khkw = T.khkw;
+#pragma unroll
+        for (int j = 0; j < kResOwn; ++j) {
+            const int row = min(j * kBlock + (int)threadIdx.x, T.nr - 1);
+            rt[j] = (small_div(T.r0 + row, T.go) - G.g_lo) * G.nci;              // complete rows: i0 == 0
+        }
     }
-    template <typename F>     // f(x, row, e, on, last): element e of tile row `row`
-    __device__ __forceinline__ void slots(const ResTile& T, float* tile, F f) const {
-        for (int j = 0; j < rpt; ++j) {
-            int row = j * kBlock + (int)threadIdx.x;
-            const bool on = row < T.nr;
-            row = on ? row : T.nr - 1;
-            float* base = tile + (int64_t)j * L * kBlock + threadIdx.x;
-            for (int e = 0; e < L; ++e) f(base + e * kBlock, row, e, on);
+    // f(j, row, on, base): row j of the thread (base = its first element in the tile; elements are kBlock floats apart)
+    template <typename F>
+    __device__ __forceinline__ void rows(const ResTile& T, float* tile, F f) const {
+#pragma unroll
+        for (int j = 0; j < kResOwn; ++j) {
+            if (j < rpt) {
+                int row = j * kBlock + (int)threadIdx.x;
+                const bool on = row < T.nr;
+                row = on ? row : T.nr - 1;
+                f(j, row, on, tile + (int64_t)j * L * kBlock + threadIdx.x);
+            }
         }
     }
     __device__ __forceinline__ void load(const ResTile& T, float* tile) const {
         const gfloat* wt = (const gfloat*)T.w;
-        slots(T, tile, [&](float* x, int row, int e, bool) { *x = wt[(int64_t)(T.r0 + row) * L + e]; });
+        rows(T, tile, [&](int, int row, bool, float* base) {
+            for (int e = 0; e < L; ++e) base[e * kBlock] = wt[(int64_t)(T.r0 + row) * L + e];
+        });
     }
     __device__ __forceinline__ void store(const ResTile& T, float* tile) const {
         gfloat* wt = (gfloat*)T.w;
-        slots(T, tile, [&](float* x, int row, int e, bool on) { if (on) wt[(int64_t)(T.r0 + row) * L + e] = *x; });
+        rows(T, tile, [&](int, int row, bool on, float* base) {
+            if (on) for (int e = 0; e < L; ++e) wt[(int64_t)(T.r0 + row) * L + e] = base[e * kBlock];
+        });
     }
-    __device__ __forceinline__ float val(const ResTile& T, const TileGeo& G, float w, bool useA, bool useB, const float* sh_inv,
-                                         const float* sh_s, int row, int e) const {
-        const float tt = useA ? w * sh_inv[tab(T, G, row, e)] : w;   // dfq.py:73 (rounded), then
-        return useB ? tt * sh_s[row] : tt;                           // dfq.py:62
+    // g(e, x) for every element of a row, nine LDS reads in flight per trip (a 3 x 3 kernel is one trip; a plain loop pays
+    // one LDS round trip per element)
+    template <typename Gf>
+    __device__ __forceinline__ void elems(const float* base, Gf g) const {
+        for (int e0 = 0; e0 < L; e0 += 9) {
+            float x[9];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) x[i] = base[min(e0 + i, L - 1) * kBlock];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) if (e0 + i < L) g(e0 + i, x[i]);
+        }
+    }
+    // the factors of row j: fa = 1/s_A when the row has ONE input channel (else per element through `inv_at`), fb = s_B
+    __device__ __forceinline__ float fa_of(int j, bool useA, const float* sh_inv) const { return (useA && nci == 1) ? sh_inv[rt[j]] : 1.0f; }
+    __device__ __forceinline__ float val(float w, int j, int e, bool useA, float fa, float fb, const float* sh_inv) const {
+        const float ia = (useA && nci != 1) ? sh_inv[rt[j] + small_div(e, khkw)] : fa;
+        return (w * ia) * fb;                                        // dfq.py:73 (rounded), then dfq.py:62; * 1.0f is exact
     }
     __device__ __forceinline__ void row_stats(const ResTile& T, const TileGeo& G, float* tile, bool useA, bool useB,
                                               const float* sh_inv, const float* sh_s, uint32_t* sh_row) const {
-        float mn = INFINITY, mx = -INFINITY;
-        slots(T, tile, [&](float* x, int row, int e, bool on) {
-            const float y = val(T, G, *x, useA, useB, sh_inv, sh_s, row, e);
-            mn = (e == 0) ? y : vmin_raw(mn, y);
-            mx = (e == 0) ? y : vmax_raw(mx, y);
-            if (e == L - 1 && on) { sh_row[2 * row] = ~enc_ord(mn); sh_row[2 * row + 1] = enc_ord(mx); }   // the row's only owner
+        rows(T, tile, [&](int j, int row, bool on, float* base) {
+            const float fa = fa_of(j, useA, sh_inv), fb = useB ? sh_s[row] : 1.0f;
+            float mn = INFINITY, mx = -INFINITY;
+            elems(base, [&](int e, float x) {
+                const float y = val(x, j, e, useA, fa, fb, sh_inv);
+                mn = vmin_raw(mn, y); mx = vmax_raw(mx, y);
+            });
+            if (on) { sh_row[2 * row] = ~enc_ord(mn); sh_row[2 * row + 1] = enc_ord(mx); }    // the row's only owner
         });
     }
     __device__ __forceinline__ void col_stats(const ResTile& T, const TileGeo& G, float* tile, bool useA, bool useB,
                                               const float* sh_inv, const float* sh_s, uint32_t* sh_col) const {
-        if (G.nci == 1) {            // one input channel per group (depthwise): a row's range goes to its group's channel
-            float mn = INFINITY, mx = -INFINITY;
-            slots(T, tile, [&](float* x, int row, int e, bool on) {
-                const float y = val(T, G, *x, useA, useB, sh_inv, sh_s, row, e);
-                mn = (e == 0) ? y : vmin_raw(mn, y);
-                mx = (e == 0) ? y : vmax_raw(mx, y);
-                if (e == L - 1 && on) lds_minmax(sh_col + 2 * tab(T, G, row, 0), mn, mx);
-            });
-        } else {
-            slots(T, tile, [&](float* x, int row, int e, bool on) {
-                const float y = val(T, G, *x, useA, useB, sh_inv, sh_s, row, e);
-                if (on) lds_minmax(sh_col + 2 * tab(T, G, row, e), y, y);
-            });
-        }
+        rows(T, tile, [&](int j, int row, bool on, float* base) {
+            const float fa = fa_of(j, useA, sh_inv), fb = useB ? sh_s[row] : 1.0f;
+            if (nci == 1) {          // one input channel per group (depthwise): the row's range goes to its group's channel
+                float mn = INFINITY, mx = -INFINITY;
+                elems(base, [&](int e, float x) {
+                    const float y = val(x, j, e, useA, fa, fb, sh_inv);
+                    mn = vmin_raw(mn, y); mx = vmax_raw(mx, y);
+                });
+                if (on) lds_minmax(sh_col + 2 * rt[j], mn, mx);
+            } else {
+                elems(base, [&](int e, float x) {
+                    const float y = val(x, j, e, useA, fa, fb, sh_inv);
+                    if (on) lds_minmax(sh_col + 2 * (rt[j] + small_div(e, khkw)), y, y);
+                });
+            }
+        });
     }
-    __device__ __forceinline__ double diff_and_cols(const ResTile&, const TileGeo&, float*, bool, bool, const float*, const float*, uint32_t*) const { return 0.0; }
+    __device__ __forceinline__ double diff_and_cols(const ResTile&, const TileGeo&, float*, bool, bool, const float*, const float*, uint32_t*, bool = false) const { return 0.0; }
     __device__ __forceinline__ double update(const ResTile& T, const TileGeo& G, float* tile, bool useA, bool useB,
                                              const float* sh_inv, const float* sh_s, bool commit) const {
         double acc = 0.0;
-        slots(T, tile, [&](float* x, int row, int e, bool on) {
-            const float nv = val(T, G, *x, useA, useB, sh_inv, sh_s, row, e);
-            acc += on ? (double)abs_f32(nv - *x) : 0.0;
-            if (commit) *x = nv;
+        rows(T, tile, [&](int j, int row, bool on, float* base) {
+            const float fa = fa_of(j, useA, sh_inv), fb = useB ? sh_s[row] : 1.0f;
+            double part = 0.0;
+            elems(base, [&](int e, float x) {
+                const float nv = val(x, j, e, useA, fa, fb, sh_inv);
+                part += (double)abs_f32(nv - x);
+                if (commit) base[e * kBlock] = nv;
+            });
+            acc += on ? part : 0.0;
         });
         return acc;
     }
@@ -564,19 +652,37 @@ __device__ __forceinline__ double ordered_sum(const double* x, int n) {
 // Done by ONE workgroup (tile 0, a tile of the network's first paired layer: small, early, mostly idle) and published; the
 // others pick the number up a whole sweep later (see the commit logic), so this reduction is on nobody's critical path.
 // `mine` = layer_diff[threadIdx.x], loaded once before the loop.
-__device__ __forceinline__ double reduce_diff(const ResArgs& a, int k, const ResLayerDiff& mine, double* sh_d, double* sh_mean) {
+__device__ __forceinline__ double reduce_diff(const ResArgs& a, int k, const ResLayerDiff& mine, double* sh_d, double* sh_mean, int* sh_bad) {
     const int tid = threadIdx.x;
-    const u64* part = (const u64*)a.partials + (int64_t)(k % 3) * a.n_tiles;
-    for (int i = tid; i < a.n_tiles; i += kBlock) sh_d[i] = __longlong_as_double((long long)ld_word(part + i));
+    const auto& c = cold(a);
+    const int n_tiles = c.n_tiles, n_layers = c.n_layers;
+    // a tile's partial sum is two words {sweep tag : half of the float64}: the reducer reads the words themselves until they
+    // carry this sweep's tag -- no arrival counter between the tile's store and this load
+    const u64* part = (const u64*)c.partials + (int64_t)(k % 3) * 2 * n_tiles;
+    const u64 want = (u64)(k + 1);
+    for (int i = tid; i < n_tiles; i += kBlock) {
+        long tries = 0;
+        u64 hi, lo;
+        for (;;) {
+            hi = ld_word(part + 2 * i); lo = ld_word(part + 2 * i + 1);
+            if ((hi >> 32) == want && (lo >> 32) == want) break;
+            __builtin_amdgcn_s_sleep(1);
+            if (++tries > kResSpinLimit ||
+                ((tries & 255) == 0 && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull)) {
+                atomicMax(a.err, 1ull); *sh_bad = 1; break;
+            }
+        }
+        sh_d[i] = __longlong_as_double((long long)((hi << 32) | (lo & 0xffffffffull)));
+    }
     __syncthreads();
-    for (int l = tid; l < a.n_layers; l += kBlock) {
-        const ResLayerDiff L = (l == tid) ? mine : a.layer_diff[l];
+    for (int l = tid; l < n_layers; l += kBlock) {
+        const ResLayerDiff L = (l == tid) ? mine : c.layer_diff[l];
         const double s = ordered_sum(sh_d + L.tile_begin, L.n_tiles);              // fixed order
         // float(torch.mean(torch.abs(W - W_prev))): float32 mean, widened to double (dfq.py:108)
         sh_mean[l] = (L.n_tiles > 0) ? (double)(float)(s / L.n_elems) : 0.0;
     }
     __syncthreads();
-    const double diff_tmp = ordered_sum(sh_mean, a.n_layers);                      // graph order, like Python's sum
+    const double diff_tmp = ordered_sum(sh_mean, n_layers);                        // graph order, like Python's sum
     __syncthreads();                 // sh_d / sh_mean are reused
     return diff_tmp;
 }
@@ -587,61 +693,57 @@ __device__ __forceinline__ void advance_state(const ResArgs& a, LoopState& st, d
     else { st.count += 1; }
     st.sweeps += 1;
     st.last_diff_tmp = diff_tmp;
-    const bool go_on = (st.diff > a.converge_thres) && (st.count < a.converge_count) && (a.max_sweeps < 0 || st.sweeps < a.max_sweeps);
+    const auto& c = cold(a);
+    const bool go_on = (st.diff > c.converge_thres) && (st.count < c.converge_count) && (c.max_sweeps < 0 || st.sweeps < c.max_sweeps);
     st.done = go_on ? 0 : 1;
 }
 
-// A layer cut into many tiles (the classifier: 160) has that many workgroups polling the same two counter words, and every
-// poll is a device-scope access to ONE address: ~12 ns each, serialised -- 160 pollers stretched a hand-off from 2 to 5.6 us.
-// So only the layer's first eight tiles (one per XCD: consecutive workgroups go to consecutive XCDs) poll the counters; each
-// then raises a flag for its XCD, which the other tiles of the layer on that XCD poll.  Which XCD a workgroup really runs on
-// does not matter for correctness (all eight flags are raised), only for how the load spreads.
-__device__ __forceinline__ bool relay_wait(const ResArgs& a, const ResTile& T, int phase, u64 round, const u64* w1, u64 t1,
-                                           const u64* w2, u64 t2, int* sh_flag) {
-    u64* flag = a.flags + ((int64_t)(T.layer * 2 + phase) * 8 + (blockIdx.x & 7)) * kResStride;
-    if (T.relay == 2) {
-        // one direct look first: what a phase waits for is often there already (statistics of the previous sweep), and then
-        // the relay would only add its own hop
-        if (threadIdx.x == 0) {
-            const u64 a1 = __hip_atomic_load(w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const u64 a2 = w2 ? __hip_atomic_load(w2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : t2;
-            *sh_flag = (a1 >= t1 && a2 >= t2) ? 1 : 0;
-        }
-        __syncthreads();
-        const bool there = *sh_flag != 0;
-        __syncthreads();
-        if (there) return true;
-        return res_wait2(flag, round, nullptr, 0, a.err, sh_flag);
-    }
-    if (!res_wait2(w1, t1, w2, t2, a.err, sh_flag)) return false;
-    if (T.relay == 1 && threadIdx.x == 0) __hip_atomic_store(flag, round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return true;
-}
-
-// The verdict of sweep k: tile 0 waits for all partials, reduces and publishes {diff_tmp, k + 1}; everybody else waits for the
-// publication (normally long there).  Returns false when a wait was abandoned.
-__device__ __forceinline__ bool verdict(const ResArgs& a, int k, LoopState& st, const ResLayerDiff& mine, double* sh_dec, int* sh_flag) {
-    // [0] tag (k + 1), [1] diff_tmp bits; one copy per XCD (every tile of the launch polls it)
-    u64* slot = a.seq + ((k % 3) * 8 + (blockIdx.x & 7)) * kResStride;
+// The verdict of sweep k: the reducing tile collects all partials, reduces and publishes diff_tmp as two words {k + 1 : half of
+// the float64} (one copy per XCD: every tile of the launch polls it); everybody else reads the two words until both carry
+// k + 1 (normally at the first look: the publication is most of a sweep old).  Returns false when a wait was abandoned.
+__device__ __forceinline__ bool verdict(const ResArgs& a, int k, LoopState& st, const ResLayerDiff& mine, double* sh_dec, int* sh_flag, int* sh_bad,
+                                        double* sh_val) {
+    const auto& c = cold(a);
+    const u64 want = (u64)(k + 1);
     double diff_tmp;
-    if ((int)blockIdx.x == a.reducer) {
-        if (!res_wait2(a.done_cnt + (k % 3) * kResStride, (u64)a.n_tiles * (u64)(k / 3 + 1), nullptr, 0, a.err, sh_flag)) return false;
-        diff_tmp = reduce_diff(a, k, mine, sh_dec, sh_dec + kResMaxTiles);
+    if ((int)blockIdx.x == c.reducer) {
+        diff_tmp = reduce_diff(a, k, mine, sh_dec, sh_dec + kResMaxTiles, sh_bad);
+        if (*sh_bad) return false;                                   // (read behind reduce_diff's barriers)
         if (threadIdx.x < 8) {
-            u64* copy = a.seq + ((k % 3) * 8 + threadIdx.x) * kResStride;
-            __hip_atomic_store(copy + 1, (u64)__double_as_longlong(diff_tmp), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __builtin_amdgcn_s_waitcnt(0);
-            __hip_atomic_store(copy, (u64)(k + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            u64* copy = cold(a).seq + ((k % 3) * 8 + threadIdx.x) * kResStride;
+            const u64 bits = (u64)__double_as_longlong(diff_tmp);
+            __hip_atomic_store(copy, (want << 32) | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(copy + 1, (want << 32) | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     } else {
-        if (!res_wait2(slot, (u64)(k + 1), nullptr, 0, a.err, sh_flag)) return false;
-        diff_tmp = __longlong_as_double((long long)ld_word(slot + 1));
+        const u64* slot = c.seq + ((k % 3) * 8 + (blockIdx.x & 7)) * kResStride;
+        if (threadIdx.x == 0) {
+            long spins = 0;
+            int ok = 1;
+            u64 hi, lo;
+            for (;;) {
+                hi = ld_word(slot); lo = ld_word(slot + 1);
+                if ((hi >> 32) == want && (lo >> 32) == want) break;
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > kResSpinLimit ||
+                    ((spins & 255) == 0 && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull)) {
+                    atomicMax(a.err, 1ull); ok = 0; break;
+                }
+            }
+            *sh_val = __longlong_as_double((long long)((hi << 32) | (lo & 0xffffffffull)));
+            *sh_flag = ok;
+        }
+        __syncthreads();
+        const bool ok = *sh_flag != 0;
+        diff_tmp = *sh_val;
+        __syncthreads();
+        if (!ok) return false;
     }
     advance_state(a, st, diff_tmp);
     return true;
 }
 
-template <typename Lay>
+template <typename Lay, bool kTrace>
 __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& p, const ResTile& T, unsigned char* smem) {
     // LDS: [tile: kResTileFloats f32][inv: kResTab f32][s: kResRows f32][row stats: 2 * kResRows u32][col stats: 2 * kResTab u32][flag]
     float* v = (float*)smem;                       // the tile
@@ -650,6 +752,9 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
     uint32_t* sh_row = (uint32_t*)(sh_s + kResRows);
     uint32_t* sh_col = sh_row + 2 * kResRows;
     int* sh_flag = (int*)(sh_col + 2 * kResTab);
+    int* sh_bad = sh_flag + 1;                     // set by a thread whose statistics words never showed this sweep's tag
+    double* sh_val = (double*)(sh_flag + 2);       // the verdict's diff_tmp, broadcast by the polling thread
+    if (threadIdx.x == 0) *sh_bad = 0;
     // the reducing tile (the smallest one) stages the partial sums in the unused tail of its tile
     double* sh_dec = (double*)(v + kResTileFloats / 2);
     const int tid = threadIdx.x;
@@ -658,29 +763,32 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
     const bool rows_local = T.nc == T.row_len;       // the tile holds complete rows: its row statistics are final
     // only the statistics offsets of the two relations stay live through the loop (scalar registers are the scarce resource
     // of this kernel); the [O] vector pointers are re-read where the vectors are loaded and stored
-    const int64_t ra_r1 = a.rels[hasA ? T.relA : 0].r1_off, ra_r2 = a.rels[hasA ? T.relA : 0].r2_off;
-    const int64_t rb_r1 = a.rels[hasB ? T.relB : 0].r1_off, rb_r2 = a.rels[hasB ? T.relB : 0].r2_off;
+    const int64_t ra_r1 = cold(a).rels[hasA ? T.relA : 0].r1_off, ra_r2 = cold(a).rels[hasA ? T.relA : 0].r2_off;
+    const int64_t rb_r1 = cold(a).rels[hasB ? T.relB : 0].r1_off, rb_r2 = cold(a).rels[hasB ? T.relB : 0].r2_off;
     const TileGeo G = tile_geo(T);
     Lay lay;
     lay.init(T, G);
     LoopState st;
-    st.diff = a.state->diff; st.last_diff_tmp = a.state->last_diff_tmp;
-    st.count = a.state->count; st.sweeps = a.state->sweeps; st.done = 0;
+    {
+        const LeState* s0 = cold(a).state;
+        st.diff = s0->diff; st.last_diff_tmp = s0->last_diff_tmp;
+        st.count = s0->count; st.sweeps = s0->sweeps; st.done = 0;
+    }
     ResLayerDiff my_layer;
     my_layer.tile_begin = 0; my_layer.n_tiles = 0; my_layer.n_elems = 1.0;
-    if (tid < a.n_layers) my_layer = a.layer_diff[tid];
+    if (tid < cold(a).n_layers) my_layer = cold(a).layer_diff[tid];
 
     // ---- load the tile (once) ----
     lay.load(T, v);
     // the [O] vectors of relation B for the rows this thread owns
-    float o_cum[kResOwn], o_bnw[kResOwn], o_bnb[kResOwn], o_b1[kResOwn], o_s[kResOwn];
+    float o_cum[kResOwn], o_bnw[kResOwn], o_bnb[kResOwn], o_b1[kResOwn];
     const bool owner = hasB && T.owner != 0;
 #pragma unroll
     for (int j = 0; j < kResOwn; ++j) {
         const int i = tid + j * kBlock;
-        o_cum[j] = 1.0f; o_bnw[j] = 0.0f; o_bnb[j] = 0.0f; o_b1[j] = 0.0f; o_s[j] = 1.0f;
+        o_cum[j] = 1.0f; o_bnw[j] = 0.0f; o_bnb[j] = 0.0f; o_b1[j] = 0.0f;
         if (owner && i < T.nr) {
-            const ResRel RB = a.rels[T.relB];
+            const ResRel RB = cold(a).rels[T.relB];
             const int c = T.r0 + i;
             o_cum[j] = RB.s_cum[c];
             if (RB.bnw) o_bnw[j] = RB.bnw[c];
@@ -696,7 +804,7 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
         lay.col_stats(T, G, v, false, false, sh_inv, sh_s, sh_col);
         __syncthreads();
         publish_cols(a, T, G, ra_r2, sh_col, 1u);
-        arrive(a.cnt_c + (int64_t)T.layer * kResStride);
+        arrive(a.cnt_c, T.layer, !T.relax_c);
     }
     if (chain_start) {
         for (int i = tid; i < 2 * T.nr; i += kBlock) sh_row[i] = 0u;
@@ -704,7 +812,7 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
         lay.row_stats(T, G, v, false, false, sh_inv, sh_s, sh_row);
         __syncthreads();
         publish_rows(a, T, rb_r1, sh_row, 1u);
-        arrive(a.cnt_r + (int64_t)T.layer * kResStride);
+        arrive(a.cnt_r, T.layer, !T.relax_r);
     }
 
     int k = 0;
@@ -712,64 +820,195 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
     for (;; ++k) {
         const uint32_t tag = (uint32_t)k + 1u;                  // what this sweep consumes
         const u64 round = (u64)k + 1ull;
-        res_stamp(a, k, 0);
+        res_stamp<kTrace>(a, k, 0);
+        // ---- what this sweep consumes.  Phase 1 (s_A) needs the row statistics of A's first layer (this sweep: the chain's
+        //      hand-off) and this layer's own column statistics (previous sweep); phase 2 (s_B) needs the column statistics of
+        //      B's second layer (previous sweep).  ONE poll looks at all three counters; it waits only for phase 1's.  If phase
+        //      2's are there as well (the usual case: they are a sweep old), every statistics word of the tile is requested in
+        //      the same trip through the memory system and phase 2 never waits; otherwise phase 2 polls and reads later -- the
+        //      row statistics this tile publishes in phase 1 must not wait for that (the tiles of B's second layer overlap
+        //      their own work with it).  A chain start paces itself on its own layer's row counter (its tiles do not otherwise
+        //      wait for each other, and a tile two publications ahead of a sibling would make the monotonic counter lie to the
+        //      layer's consumers). ----
+        bool have_b = false;
+        {
+            const int copy = blockIdx.x & 7;
+            const u64* c1 = hasA ? cnt_line(a.cnt_r, T.a_layer, copy) : (chain_start ? cnt_line(a.cnt_r, T.layer, copy) : nullptr);
+            const u64 t1 = (u64)(hasA ? T.nt_a : T.nt_self) * round;
+            const u64* c2 = hasA ? cnt_line(a.cnt_c, T.layer, copy) : nullptr;
+            const u64* c3 = hasB ? cnt_line(a.cnt_c, T.b_layer, copy) : nullptr;
+            const int got = res_wait3(c1, t1, c2, (u64)T.nt_self * round, c3, (u64)T.nt_b * round, DFQ_RES_TOPWAIT != 0, a.err, sh_flag);
+            if (!got) { failed = true; break; }
+            have_b = hasB && got == 2;
+        }
+        res_stamp<kTrace>(a, k, 15);
+        const int n_ch = hasA ? G.g_n * G.nci : 0;
+        RangeWords w1[kResTab / kBlock], w2[kResTab / kBlock], v1[kResOwn], v2[kResOwn];
+        {
+            // A word whose producer arrived "relaxed" (see arrive) may still show the previous sweep's tag: read again.  Words
+            // merged from several tiles were complete before their counter moved.  Each thread looks after its own words.
+            long tries = 0;
+            for (;;) {
+                bool ok = true;
+#pragma unroll
+                for (int j = 0; j < kResTab / kBlock; ++j) {
+                    if (j * kBlock < n_ch) {                              // uniform over the workgroup
+                        const int idx = min(tid + j * kBlock, n_ch - 1);
+                        const int gq = small_div(idx, G.nci);
+                        const int c = (G.g_lo + gq) * T.i2g + G.i0 + (idx - gq * G.nci);
+                        w1[j] = load_range(a.stats, ra_r1, a.parity_stride, tag, c);
+                        w2[j] = load_range(a.stats, ra_r2, a.parity_stride, tag, c);
+                    }
+                }
+                if (have_b) {
+#pragma unroll
+                    for (int j = 0; j < kResOwn; ++j) {
+                        const int c = T.r0 + min(tid + j * kBlock, T.nr - 1);
+                        v2[j] = load_range(a.stats, rb_r2, a.parity_stride, tag, c);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < kResTab / kBlock; ++j)
+                    if (j * kBlock < n_ch) ok = ok && tagged(w1[j], tag) && tagged(w2[j], tag);
+                if (have_b) {
+#pragma unroll
+                    for (int j = 0; j < kResOwn; ++j) ok = ok && tagged(v2[j], tag);
+                }
+                if (ok) break;
+                __builtin_amdgcn_s_sleep(1);
+                if (++tries > kResSpinLimit / 16) { atomicMax(a.err, 1ull); *sh_bad = 1; break; }
+            }
+        }
         // ---- phase 1: s_A per (group, input channel) of the tile ----
         if (hasA) {
-            if (!relay_wait(a, T, 0, round, a.cnt_r + (int64_t)T.a_layer * kResStride, (u64)T.nt_a * round,
-                            a.cnt_c + (int64_t)T.layer * kResStride, (u64)T.nt_self * round, sh_flag)) { failed = true; break; }
-            for (int idx = tid; idx < G.g_n * G.nci; idx += kBlock) {
-                const int gq = small_div(idx, G.nci);
-                const int c = (G.g_lo + gq) * T.i2g + G.i0 + (idx - gq * G.nci);
-                float mn1, mx1, mn2, mx2, s, inv;
-                read_range(a.stats, ra_r1, a.parity_stride, tag, c, mn1, mx1);
-                read_range(a.stats, ra_r2, a.parity_stride, tag, c, mn2, mx2);
-                le_solve(range_of(mn1, mx1, p.signed_range), range_of(mn2, mx2, p.signed_range), p, s, inv);
-                sh_inv[idx] = inv;
+#pragma unroll
+            for (int j = 0; j < kResTab / kBlock; ++j) {
+                const int idx = tid + j * kBlock;
+                if (j * kBlock < n_ch) {
+                    float mn1, mx1, mn2, mx2, s, inv;
+                    decode_range(w1[j], tag, mn1, mx1);
+                    decode_range(w2[j], tag, mn2, mx2);
+                    le_solve(range_of(mn1, mx1, p.signed_range), range_of(mn2, mx2, p.signed_range), p, s, inv);
+                    if (idx < n_ch) sh_inv[idx] = inv;
+                }
             }
-            res_stamp(a, k, 1);
+            res_stamp<kTrace>(a, k, 1);
             if (hasB) for (int i = tid; i < 2 * T.nr; i += kBlock) sh_row[i] = 0u;
             __syncthreads();
             if (hasB) {
                 // row statistics of t = fl(w * 1/s_A) for relation B of this same sweep (t is not kept: phase 3 recomputes it)
+                res_stamp<kTrace>(a, k, 12);
                 lay.row_stats(T, G, v, true, false, sh_inv, sh_s, sh_row);
+                res_stamp<kTrace>(a, k, 13);
                 __syncthreads();
                 publish_rows(a, T, rb_r1, sh_row, tag);
-                arrive(a.cnt_r + (int64_t)T.layer * kResStride);
+                res_stamp<kTrace>(a, k, 14);
+                arrive(a.cnt_r, T.layer, !T.relax_r);
             }
         }
-        res_stamp(a, k, 2);
+        if (!hasA) __syncthreads();                               // (phase 1 has its own barriers)
+        if (*sh_bad) { failed = true; break; }
+        res_stamp<kTrace>(a, k, 2);
         // ---- phase 2: s_B per row ----
         if (hasB) {
             // a tile of complete rows already has its rows' statistics (sh_row: this sweep's phase 1, or the previous
             // sweep's phase 3 for a chain start); otherwise they are merged over the row block's tiles in global memory
-            // (a chain start still paces itself on its layer's counter: its tiles do not otherwise wait for each other, and a
-            // tile two publications ahead of a sibling would make the monotonic counter lie to the layer's consumers)
-            const u64* own = (rows_local && !chain_start) ? nullptr : a.cnt_r + (int64_t)T.layer * kResStride;
-            if (!relay_wait(a, T, 1, round, a.cnt_c + (int64_t)T.b_layer * kResStride, (u64)T.nt_b * round, own, (u64)T.nt_self * round, sh_flag)) {
-                failed = true; break;
+            const bool own_wait = !rows_local && !chain_start;
+            if (own_wait || !have_b) {
+                const int copy = blockIdx.x & 7;
+                if (!res_wait2(own_wait ? cnt_line(a.cnt_r, T.layer, copy) : nullptr, (u64)T.nt_self * round,
+                               have_b ? nullptr : cnt_line(a.cnt_c, T.b_layer, copy), (u64)T.nt_b * round, a.err, sh_flag)) { failed = true; break; }
+            }
+            if (!rows_local || !have_b) {
+                long tries = 0;
+                for (;;) {
+                    bool ok = true;
+#pragma unroll
+                    for (int j = 0; j < kResOwn; ++j) {
+                        const int c = T.r0 + min(tid + j * kBlock, T.nr - 1);
+                        if (!rows_local) v1[j] = load_range(a.stats, rb_r1, a.parity_stride, tag, c);
+                        if (!have_b) v2[j] = load_range(a.stats, rb_r2, a.parity_stride, tag, c);
+                    }
+#pragma unroll
+                    for (int j = 0; j < kResOwn; ++j) ok = ok && (rows_local || tagged(v1[j], tag)) && (have_b || tagged(v2[j], tag));
+                    if (ok) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++tries > kResSpinLimit / 16) { atomicMax(a.err, 1ull); *sh_bad = 1; break; }
+                }
             }
 #pragma unroll
             for (int j = 0; j < kResOwn; ++j) {
                 const int i = tid + j * kBlock;
                 if (i < T.nr) {
-                    const int c = T.r0 + i;
                     float mn1, mx1, mn2, mx2, s, inv;
                     if (rows_local) { mn1 = slot_min(sh_row[2 * i]); mx1 = slot_max(sh_row[2 * i + 1]); }
-                    else read_range(a.stats, rb_r1, a.parity_stride, tag, c, mn1, mx1);
-                    read_range(a.stats, rb_r2, a.parity_stride, tag, c, mn2, mx2);
+                    else decode_range(v1[j], tag, mn1, mx1);
+                    decode_range(v2[j], tag, mn2, mx2);
                     le_solve(range_of(mn1, mx1, p.signed_range), range_of(mn2, mx2, p.signed_range), p, s, inv);
-                    sh_s[i] = s;
-                    o_s[j] = s;                                   // applied to the [O] vectors when the sweep is committed
+                    sh_s[i] = s;                                  // also applied to the [O] vectors when the sweep is committed
                 }
             }
         }
-        res_stamp(a, k, 3);
-        // ---- phase 3: |dW| and the statistics of the values this sweep WILL produce (w itself is not touched yet) ----
+        res_stamp<kTrace>(a, k, 3);
+#if DFQ_RES_EAGER
+        // ---- phase 3: w <- fl(fl(w / s_A) * s_B), |dW| and the statistics of the new values in ONE pass over the tile.  It needs
+        //      to know that sweep k-1 was not the last one (then sweep k must not happen): the verdict of sweep k-1 is taken HERE,
+        //      most of a sweep after this tile left its partial sum -- for all but the tiles at the end of the longest chain it
+        //      has long been published.  (Until round 3 the sweep was applied lazily: statistics and |dW| from pending factors in
+        //      one pass, the multiplication again in a second pass after the verdict -- a third of a tile's instructions.) ----
         __syncthreads();                                          // sh_s complete; sh_row / sh_col free
+        if (*sh_bad) { failed = true; break; }                    // a statistics word of phase 2 never showed this sweep's tag
+        if (k > 0) {
+            if (!verdict(a, k - 1, st, my_layer, sh_dec, sh_flag, sh_bad, sh_val)) { failed = true; break; }
+            if (st.done) break;                                   // sweep k-1 was the last one: sweep k is dropped
+        }
+        res_stamp<kTrace>(a, k, 6);
         if (hasA) for (int i = tid; i < 2 * G.g_n * G.nci; i += kBlock) sh_col[i] = 0u;
         if (chain_start) for (int i = tid; i < 2 * T.nr; i += kBlock) sh_row[i] = 0u;
         __syncthreads();
-        res_stamp(a, k, 8);
+        res_stamp<kTrace>(a, k, 8);
+        double acc;
+        if (Lay::kFusedCols && hasA) {
+            acc = lay.diff_and_cols(T, G, v, hasA, hasB, sh_inv, sh_s, sh_col, true);
+        } else {
+            acc = lay.update(T, G, v, hasA, hasB, sh_inv, sh_s, true);
+            if (hasA) lay.col_stats(T, G, v, false, false, sh_inv, sh_s, sh_col);      // of the values just written
+        }
+        if (chain_start) lay.row_stats(T, G, v, false, false, sh_inv, sh_s, sh_row);
+        res_stamp<kTrace>(a, k, 9);
+        __syncthreads();
+        res_stamp<kTrace>(a, k, 10);
+        if (hasA) {
+            publish_cols(a, T, G, ra_r2, sh_col, tag + 1u);
+            arrive(a.cnt_c, T.layer, !T.relax_c);
+        }
+        if (chain_start) {
+            publish_rows(a, T, rb_r1, sh_row, tag + 1u);
+            arrive(a.cnt_r, T.layer, !T.relax_r);
+        }
+        res_stamp<kTrace>(a, k, 4);
+        // ---- convergence: one partial per tile (fixed butterfly + fixed wave order); the reducing tile sums them per layer ----
+        {
+            const double tsum = block_sum(acc, (double*)sh_col);     // sh_col is free again (statistics published)
+            if (tid == 0) {
+                const auto& c = cold(a);            // two tagged words, no counter: the reducer reads them until they carry k + 1
+                u64* dst = (u64*)c.partials + ((int64_t)(k % 3) * c.n_tiles + blockIdx.x) * 2;
+                const u64 bits = (u64)__double_as_longlong(tsum), tg = (u64)(k + 1) << 32;
+                __hip_atomic_store(dst, tg | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(dst + 1, tg | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            res_stamp<kTrace>(a, k, 5);
+        }
+        if (kTrace && tid == 0 && k == 0) cold(a).trace[((int64_t)blockIdx.x * kTraceSweeps) * kTracePoints + 7] = ((long long)T.layer << 32) | (unsigned)T.nr << 16 | (unsigned)(T.nc & 0xffff);
+        res_stamp<kTrace>(a, k, 11);
+#else
+        // ---- phase 3: |dW| and the statistics of the values this sweep WILL produce (w itself is not touched yet) ----
+        __syncthreads();                                          // sh_s complete; sh_row / sh_col free
+        if (*sh_bad) { failed = true; break; }                    // a statistics word of phase 2 never showed this sweep's tag
+        if (hasA) for (int i = tid; i < 2 * G.g_n * G.nci; i += kBlock) sh_col[i] = 0u;
+        if (chain_start) for (int i = tid; i < 2 * T.nr; i += kBlock) sh_row[i] = 0u;
+        __syncthreads();
+        res_stamp<kTrace>(a, k, 8);
         double acc;
         if (Lay::kFusedCols && hasA) {
             acc = lay.diff_and_cols(T, G, v, hasA, hasB, sh_inv, sh_s, sh_col);
@@ -778,18 +1017,18 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
             if (hasA) lay.col_stats(T, G, v, hasA, hasB, sh_inv, sh_s, sh_col);
         }
         if (chain_start) lay.row_stats(T, G, v, hasA, hasB, sh_inv, sh_s, sh_row);
-        res_stamp(a, k, 9);
+        res_stamp<kTrace>(a, k, 9);
         __syncthreads();
-        res_stamp(a, k, 10);
+        res_stamp<kTrace>(a, k, 10);
         if (hasA) {
             publish_cols(a, T, G, ra_r2, sh_col, tag + 1u);
-            arrive(a.cnt_c + (int64_t)T.layer * kResStride);
+            arrive(a.cnt_c, T.layer, !T.relax_c);
         }
         if (chain_start) {
             publish_rows(a, T, rb_r1, sh_row, tag + 1u);
-            arrive(a.cnt_r + (int64_t)T.layer * kResStride);
+            arrive(a.cnt_r, T.layer, !T.relax_r);
         }
-        res_stamp(a, k, 4);
+        res_stamp<kTrace>(a, k, 4);
         // ---- convergence.  One partial per tile (fixed butterfly + fixed wave order); when the partials of a sweep are all
         //      in, every workgroup draws the same verdict from them.  The verdict of sweep k-1 is needed only HERE, a whole
         //      sweep after its partials were written: sweep k is applied to the registers ("committed") only once sweep k-1 is
@@ -798,31 +1037,36 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
         {
             const double tsum = block_sum(acc, (double*)sh_col);     // sh_col is free again (statistics published)
             if (tid == 0) {
-                __hip_atomic_store((u64*)a.partials + (int64_t)(k % 3) * a.n_tiles + blockIdx.x, (u64)__double_as_longlong(tsum),
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __builtin_amdgcn_s_waitcnt(0);
-                atomicAdd(a.done_cnt + (k % 3) * kResStride, 1ull);          // one counter per partial buffer
+                const auto& c = cold(a);            // two tagged words, no counter: the reducer reads them until they carry k + 1
+                u64* dst = (u64*)c.partials + ((int64_t)(k % 3) * c.n_tiles + blockIdx.x) * 2;
+                const u64 bits = (u64)__double_as_longlong(tsum), tg = (u64)(k + 1) << 32;
+                __hip_atomic_store(dst, tg | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(dst + 1, tg | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            res_stamp(a, k, 5);
+            res_stamp<kTrace>(a, k, 5);
             if (k > 0) {
-                if (!verdict(a, k - 1, st, my_layer, sh_dec, sh_flag)) { failed = true; break; }
+                if (!verdict(a, k - 1, st, my_layer, sh_dec, sh_flag, sh_bad, sh_val)) { failed = true; break; }
                 if (st.done) break;                               // sweep k-1 was the last one: sweep k is dropped
             }
         }
-        res_stamp(a, k, 6);
-        if (a.trace && tid == 0 && k == 0) a.trace[((int64_t)blockIdx.x * kTraceSweeps) * kTracePoints + 7] = ((long long)T.layer << 32) | (unsigned)T.nr << 16 | (unsigned)(T.nc & 0xffff);
+        res_stamp<kTrace>(a, k, 6);
+        if (kTrace && tid == 0 && k == 0) cold(a).trace[((int64_t)blockIdx.x * kTraceSweeps) * kTracePoints + 7] = ((long long)T.layer << 32) | (unsigned)T.nr << 16 | (unsigned)(T.nc & 0xffff);
         // ---- commit sweep k ----
         (void)lay.update(T, G, v, hasA, hasB, sh_inv, sh_s, true);
-        res_stamp(a, k, 11);
+        res_stamp<kTrace>(a, k, 11);
+#endif
+        if (hasB) {
 #pragma unroll
-        for (int j = 0; j < kResOwn; ++j) {
-            o_cum[j] = o_cum[j] * o_s[j];                         // relation.py:20-24
-            o_bnw[j] = o_bnw[j] * o_s[j];                         // dfq.py:64-65
-            o_bnb[j] = o_bnb[j] * o_s[j];                         // dfq.py:67-68
-            o_b1[j] = o_b1[j] * o_s[j];                           // dfq.py:70-71
+            for (int j = 0; j < kResOwn; ++j) {
+                const float sj = sh_s[min(tid + j * kBlock, T.nr - 1)];     // this thread's own rows (written by itself in phase 2)
+                o_cum[j] = o_cum[j] * sj;                         // relation.py:20-24
+                o_bnw[j] = o_bnw[j] * sj;                         // dfq.py:64-65
+                o_bnb[j] = o_bnb[j] * sj;                         // dfq.py:67-68
+                o_b1[j] = o_b1[j] * sj;                           // dfq.py:70-71
+            }
         }
-        if (k + 1 >= a.n_sweeps) {                                // the launch's last sweep: its verdict closes the state
-            if (!verdict(a, k, st, my_layer, sh_dec, sh_flag)) failed = true;
+        if (k + 1 >= cold(a).n_sweeps) {                          // the launch's last sweep: its verdict closes the state
+            if (!verdict(a, k, st, my_layer, sh_dec, sh_flag, sh_bad, sh_val)) failed = true;
             break;
         }
     }
@@ -833,7 +1077,7 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
     for (int j = 0; j < kResOwn; ++j) {
         const int i = tid + j * kBlock;
         if (owner && i < T.nr) {
-            const ResRel RB = a.rels[T.relB];
+            const ResRel RB = cold(a).rels[T.relB];
             const int c = T.r0 + i;
             RB.s_cum[c] = o_cum[j];
             if (RB.bnw) RB.bnw[c] = o_bnw[j];
@@ -841,8 +1085,8 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
             if (RB.b1) RB.b1[c] = o_b1[j];
         }
     }
-    if ((int)blockIdx.x == a.reducer && tid == 0) {
-        LeState* o = a.state;
+    if ((int)blockIdx.x == cold(a).reducer && tid == 0) {
+        LeState* o = cold(a).state;
         o->diff = st.diff; o->last_diff_tmp = st.last_diff_tmp; o->count = st.count; o->sweeps = st.sweeps; o->done = st.done;
     }
 }
@@ -852,14 +1096,15 @@ static_assert(sizeof(double) * (kResMaxTiles + kResMaxLayers) <= sizeof(float) *
 
 enum { kLayGeneral = 0, kLayFixed = 1, kLayShort = 2 };
 
-__global__ __launch_bounds__(kBlock) void le_resident_kernel(ResArgs a, LeParams p) {
+template <bool kTrace>      // 3 waves per SIMD: at most 168 registers (three workgroups per CU is what the plan counts on)
+__global__ __launch_bounds__(kBlock, 3) void le_resident_kernel(ResArgs a, LeParams p) {
     DFQ_DYN_SMEM(smem);
     if (a.state->done) return;              // already stopped (uniform over the launch: written before it started)
     const ResTile T = a.tiles[blockIdx.x];
-    if (T.layout == kLayFixed) res_tile_body<LayFixed>(a, p, T, smem);
-    else if (T.layout == kLayShort) res_tile_body<LayShort>(a, p, T, smem);
-    else if (T.vec == 4) res_tile_body<LayGeneral<4>>(a, p, T, smem);
-    else res_tile_body<LayGeneral<1>>(a, p, T, smem);
+    if (T.layout == kLayFixed) res_tile_body<LayFixed, kTrace>(a, p, T, smem);
+    else if (T.layout == kLayShort) res_tile_body<LayShort, kTrace>(a, p, T, smem);
+    else if (T.vec == 4) res_tile_body<LayGeneral<4>, kTrace>(a, p, T, smem);
+    else res_tile_body<LayGeneral<1>, kTrace>(a, p, T, smem);
 }
 
 }  // namespace dfq
@@ -999,11 +1244,12 @@ LeResident* le_resident_create(const dfq_layer* layers, int n_layers, const dfq_
     cus = prop.multiProcessorCount;
     std::vector<ResTile> tiles;
     std::vector<int> tile_begin(n_layers, 0), tile_count(n_layers, 0);
+    const bool relaxed_ok = !(getenv("DFQ_RES_RELAXED") && getenv("DFQ_RES_RELAXED")[0] == '0');   // A/B switch
     int occ = 0;
     if (kResSmemBytes > 48 * 1024 &&
-        hipFuncSetAttribute((const void*)le_resident_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kResSmemBytes) != hipSuccess)
+        hipFuncSetAttribute((const void*)le_resident_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kResSmemBytes) != hipSuccess)
         return refuse("dynamic shared memory size refused");
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)le_resident_kernel, kBlock, kResSmemBytes) != hipSuccess || occ < 1)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)le_resident_kernel<false>, kBlock, kResSmemBytes) != hipSuccess || occ < 1)
         return refuse("occupancy query failed");
     // every workgroup must be resident: LDS bounds it (tile + tables), the API's answer is exact for that.  A quarter of
     // the slots stays free: a launch sized to exactly the occupancy limit (le_sweep_kernel, dfq_le.hip) never became fully
@@ -1041,6 +1287,10 @@ LeResident* le_resident_create(const dfq_layer* layers, int n_layers, const dfq_
                 T.b_layer = relB >= 0 ? pl_of[relations[relB].second] : -1;
                 T.owner = cb == 0 ? 1 : 0;
                 T.layout = layout_of(vec, C, T.nc);
+                // single-producer statistics (see arrive): a row lives in one tile when the layer has one column block; an input
+                // channel (rows of its group x its khkw taps) when no row block cuts a group and no column block cuts the taps
+                T.relax_r = (relaxed_ok && n_cb == 1) ? 1 : 0;
+                T.relax_c = (relaxed_ok && (n_rb == 1 || sh.tr % go == 0) && (n_cb == 1 || sh.tc % L.khkw == 0)) ? 1 : 0;
                 tiles.push_back(T);
             }
         tile_count[l] = n_rb * n_cb;
@@ -1074,12 +1324,6 @@ LeResident* le_resident_create(const dfq_layer* layers, int n_layers, const dfq_
             if (pl_of[l] >= 0 && pl_of[l] == T.b_layer) T.nt_b = tile_count[l];
         }
     }
-    for (size_t i = 0; i < tiles.size(); ++i) {
-        ResTile& T = tiles[i];
-        int first = (int)i;
-        while (first > 0 && tiles[first - 1].layer == T.layer) --first;     // tiles of a layer are contiguous
-        T.relay = (T.nt_self >= 16) ? (((int)i - first) < 8 ? 1 : 2) : 0;
-    }
     LeResident* r = new LeResident();
     r->n_tiles = (int)tiles.size(); r->n_pl = n_pl; r->n_rels = n_relations; r->n_layers = n_layers; r->reducer = reducer; r->elements = total;
     // statistics arenas: per relation `channels` = O1 entries of 2 words, two parities; r1 arena then r2 arena
@@ -1104,13 +1348,13 @@ LeResident* le_resident_create(const dfq_layer* layers, int n_layers, const dfq_
         ld[l].n_tiles = tile_count[l];
         ld[l].n_elems = (double)((int64_t)layers[l].out_ch * layers[l].in_per_group * layers[l].khkw);
     }
-    r->sync_words = (size_t)(2 * n_pl + 3 + 24 + 16 * n_pl) * kResStride;   // counters | done[3] | verdict[3][8] | flags[n_pl][2][8]
+    r->sync_words = (size_t)(16 * n_pl + 24) * kResStride;                  // counters [2][n_pl][8] | verdict[3][8]
     bool ok = hipMalloc((void**)&r->d_tiles, sizeof(ResTile) * tiles.size()) == hipSuccess &&
               hipMalloc((void**)&r->d_rels, sizeof(ResRel) * n_relations) == hipSuccess &&
               hipMalloc((void**)&r->d_layer_diff, sizeof(ResLayerDiff) * n_layers) == hipSuccess &&
               hipMalloc((void**)&r->d_stats, sizeof(u64) * (size_t)r->stat_words) == hipSuccess &&
               hipMalloc((void**)&r->d_sync, sizeof(u64) * r->sync_words) == hipSuccess &&
-              hipMalloc((void**)&r->d_partials, sizeof(double) * 3 * tiles.size()) == hipSuccess &&
+              hipMalloc((void**)&r->d_partials, sizeof(double) * 6 * tiles.size()) == hipSuccess &&
               hipMemcpy(r->d_tiles, tiles.data(), sizeof(ResTile) * tiles.size(), hipMemcpyHostToDevice) == hipSuccess &&
               hipMemcpy(r->d_rels, hr.data(), sizeof(ResRel) * n_relations, hipMemcpyHostToDevice) == hipSuccess &&
               hipMemcpy(r->d_layer_diff, ld.data(), sizeof(ResLayerDiff) * n_layers, hipMemcpyHostToDevice) == hipSuccess;
@@ -1125,15 +1369,14 @@ int le_resident_enqueue(LeResident* r, const dfq_le_config* cfg, LeState* d_stat
     // every launch is self-contained: statistics are re-derived from the weights it loads, tags and counters start at zero
     DFQ_HIP_TRY(hipMemsetAsync(r->d_stats, 0, sizeof(u64) * (size_t)r->stat_words, st));
     DFQ_HIP_TRY(hipMemsetAsync(r->d_sync, 0, sizeof(u64) * r->sync_words, st));
+    DFQ_HIP_TRY(hipMemsetAsync(r->d_partials, 0, sizeof(double) * 6 * (size_t)r->n_tiles, st));
     ResArgs a;
     memset(&a, 0, sizeof(a));
     a.tiles = r->d_tiles; a.rels = r->d_rels; a.layer_diff = r->d_layer_diff;
     a.stats = r->d_stats; a.parity_stride = r->parity_stride;
     a.cnt_r = r->d_sync;
-    a.cnt_c = r->d_sync + (size_t)r->n_pl * kResStride;
-    a.done_cnt = r->d_sync + (size_t)2 * r->n_pl * kResStride;
-    a.seq = a.done_cnt + 3 * kResStride;
-    a.flags = a.seq + 24 * kResStride;
+    a.cnt_c = r->d_sync + (size_t)8 * r->n_pl * kResStride;
+    a.seq = r->d_sync + (size_t)16 * r->n_pl * kResStride;
     a.err = d_err;
     a.partials = r->d_partials;
     a.state = d_state;
@@ -1146,7 +1389,13 @@ int le_resident_enqueue(LeResident* r, const dfq_le_config* cfg, LeState* d_stat
     a.trace = d_trace;
     const LeParams q = make_params(cfg);
     SpinGuard guard(st);
-    DFQ_LAUNCH_RESIDENT(le_resident_kernel, dim3(r->n_tiles), dim3(kBlock), kResSmemBytes, st, a, q);
+    if (d_trace) {
+        if (kResSmemBytes > 48 * 1024)
+            DFQ_HIP_TRY(hipFuncSetAttribute((const void*)le_resident_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kResSmemBytes));
+        DFQ_LAUNCH_RESIDENT(le_resident_kernel<true>, dim3(r->n_tiles), dim3(kBlock), kResSmemBytes, st, a, q);
+    } else {
+        DFQ_LAUNCH_RESIDENT(le_resident_kernel<false>, dim3(r->n_tiles), dim3(kBlock), kResSmemBytes, st, a, q);
+    }
     DFQ_CHECK_LAUNCH();
     return DFQ_OK;
 }

@@ -191,11 +191,12 @@ class LEPlan:
         out = (ctypes.c_int64 * n)()
         _ffi.check(_ffi.lib().dfq_le_resident_trace(self._plan, ctypes.byref(cfg), int(n_sweeps), _ffi.stream_arg(), out, n))
         tiles = []
-        for t in range(n // 72):
-            w = [int(out[t * 72 + i]) for i in range(72)]
+        per = 6 * 16                                         # kTraceSweeps x kTracePoints of dfq_le_resident.hip
+        for t in range(n // per):
+            w = [int(out[t * per + i]) for i in range(per)]
             meta = w[7]
             tiles.append(dict(layer=meta >> 32, rows=(meta >> 16) & 0xffff, cols=meta & 0xffff,
-                              stamps=[w[k * 12:k * 12 + 7] + w[k * 12 + 8:k * 12 + 12] for k in range(6)]))
+                              stamps=[w[k * 16:k * 16 + 7] + w[k * 16 + 8:k * 16 + 16] for k in range(6)]))
         return tiles
 
     def query(self):
