@@ -70,6 +70,9 @@ def parse():
     ap.add_argument('--sharded', default='deeplab_mnv2:60', help='config 4: net:pinned sweeps for the sharded single-network '
                     'pass; "" disables')
     ap.add_argument('--sharded-steps', type=int, default=6)
+    ap.add_argument('--distill', default='mobilenet_v2:8:64,3,224,224', help='config 5 end to end: net:batches:shape of '
+                    'update_quant_range over the distilled batches; "" disables')
+    ap.add_argument('--pcie', default='mobilenet_v2', help='CPU-resident model through the drop-in entry points; "" disables')
     return ap.parse_args()
 
 
@@ -106,9 +109,9 @@ def make_unit(protos):
 
 def pass_bytes(le, bc, sweeps):
     """Algorithmic bytes of one LE(sweeps)+BC pass as executed: per sweep 8 B per element read and written +
-    4 B per interior element only measured; bootstrap 4 B per paired element; BC 8 B per weight (min/max + quant-error
-    read) + 8 B per (o, i) pair (eps write + read)."""
-    return sweeps * (8 * le.rw_elements + 4 * le.ro_elements) + 4 * le.paired_elements + 8 * bc.weight_elements + 8 * bc.eps_elements
+    4 B per interior element only measured; bootstrap 4 B per paired element; BC 8 B per weight (min/max read + the chain's
+    read: the quant-error row sums are formed in registers)."""
+    return sweeps * (8 * le.rw_elements + 4 * le.ro_elements) + 4 * le.paired_elements + 8 * bc.weight_elements
 
 
 def cpu_baseline(net, seed, budget_s):
@@ -261,7 +264,7 @@ def single_network_pass(proto, sweeps, reps=4, warm=2, pinned=False):
     tiles = le.resident_tiles
     if tiles > 0:
         # the whole loop is ONE persistent launch: every paired weight is read once and written once, whatever the sweep count
-        nbytes = 8 * le.rw_elements + 8 * bc.weight_elements + 8 * bc.eps_elements
+        nbytes = 8 * le.rw_elements + 8 * bc.weight_elements
         engine = 'resident: one persistent launch of {} workgroups keeps the paired layers in LDS for all sweeps'.format(tiles)
     else:
         nbytes = streaming_bytes
@@ -339,6 +342,102 @@ def activation_range_kernels(shape, dev):
         r['frac'] = r['GBps'] / HBM_PEAK_GBS
     return {'config': 'MobileNetV2 --distill_range (configs[4]): activation [{}] float32'.format(', '.join(map(str, shape))),
             'elements': n, 'kernels': rows}
+
+
+# ---------------------------------------------------------------------------------------------------
+# config 5 end to end: update_quant_range over the distilled batches through the whole quantised network
+# ---------------------------------------------------------------------------------------------------
+def distill_range_pass(net, shape, n_batches, dev):
+    """configs[4] as improve_dfq.py:280-297 runs it: `n_batches` batches of `shape` through the whole quantised network with
+    every QuantMeasure recording its range (set_update_stat -> update_quant_range), the data resident on the GPU.  The
+    convolutions are MIOpen's (the inference path, out of scope); the QuantMeasure kernels' share is the difference to the same
+    forward passes with the quantisers switched to pass-through, priced at 12 B per element they see."""
+    from dfq_amd import fxgraph, improve_dfq, synthetic
+    from dfq_amd.utils import layer_transform as lt
+    from dfq_amd.utils import quantize as q
+    model, graph, bottoms = synthetic.build(net, seed=0)
+    lt.merge_batchnorm(model, graph, bottoms, TARG)
+    swapped = improve_dfq._swap_modules(model, {nn.Conv2d: q.QuantNConv2d, nn.Linear: q.QuantNLinear})
+    for k in graph:
+        if not isinstance(graph[k], str) and graph[k] in swapped:
+            graph[k] = swapped[graph[k]]
+    qmodel, graph, bottoms, tq = fxgraph.quantize_tensor_ops(model)      # + the quantisers of add / mean (layer_transform.py:10-14)
+    qmodel.to(dev).eval()
+    measures = [m for m in qmodel.modules() if isinstance(m, q.QuantMeasure)]
+    g = torch.Generator().manual_seed(1)
+    data = [torch.randn(*shape, generator=g).clamp_(-2.1179, 2.64).to(dev) for _ in range(n_batches)]
+    seen = [0]
+    hooks = [m.register_forward_pre_hook(lambda mod, args: seen.__setitem__(0, seen[0] + args[0].numel())) for m in measures]
+    improve_dfq.set_update_stat(qmodel, [q.QuantMeasure], True)
+    with torch.no_grad():
+        qmodel(data[0])                                                  # warm-up: MIOpen picks its kernels
+    elements_per_batch = seen[0]
+    for h in hooks:
+        h.remove()
+    _sync()
+
+    def run_all():
+        improve_dfq.update_quant_range(qmodel, data, graph, bottoms)
+    with_q = min(_gpu_elapsed_ms(run_all) for _ in range(2))
+    t0 = time.perf_counter()
+    run_all()
+    _sync()
+    wall = (time.perf_counter() - t0) * 1e3
+    # the same forwards with every quantiser a pass-through: what the convolutions alone cost
+    saved = [m.forward for m in measures]
+    for m in measures:
+        m.forward = lambda x: x
+    without_q = min(_gpu_elapsed_ms(run_all) for _ in range(2))
+    for m, f in zip(measures, saved):
+        m.forward = f
+    improve_dfq.set_update_stat(qmodel, [q.QuantMeasure], False)
+    qm_ms = max(with_q - without_q, 1e-9)
+    nbytes = 12 * elements_per_batch * n_batches
+    return {'net': net, 'batches': n_batches, 'batch_shape': list(shape), 'quant_measures': len(measures),
+            'elements_per_batch': elements_per_batch, 'ms_per_batch': with_q / n_batches, 'ms_total': with_q, 'wall_ms_total': wall,
+            'convolutions_only_ms_per_batch': without_q / n_batches,
+            'quant_measure_ms_per_batch': qm_ms / n_batches, 'quant_measure_share': qm_ms / with_q,
+            'quant_measure_bytes_per_batch': 12 * elements_per_batch, 'quant_measure_GBps': nbytes / (qm_ms * 1e-3) / 1e9,
+            'quant_measure_frac_of_hbm_peak': nbytes / (qm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            'what': 'improve_dfq.update_quant_range over {} batches of {} through the whole quantised {} ({} QuantMeasure modules '
+                    'incl. the tensor-op quantisers; improve_dfq.py:280-297); convolutions are MIOpen\'s, the QuantMeasure share is '
+                    'the difference to the same forwards with pass-through quantisers'.format(n_batches, list(shape), net, len(measures))}
+
+
+# ---------------------------------------------------------------------------------------------------
+# the reference's default flow: a CPU-resident model through the drop-in entry points (PCIe inclusive)
+# ---------------------------------------------------------------------------------------------------
+def pcie_inclusive_pass(net, reps=3):
+    """main_cls.py:149-181 with the model where the reference keeps it -- on the CPU: every entry point shadows the tensors it
+    touches with device copies and writes them back (dfq_amd._ffi.Stage), and builds its plan per call (CPU tensors are not
+    cached).  Wall time of cross_layer_equalization + bias_correction, H2D / D2H and host work included.  Never `value`."""
+    from dfq_amd import dfq, synthetic
+    from dfq_amd.utils import layer_transform as lt
+    from dfq_amd.utils import relation as rel
+    best = None
+    for _ in range(reps):
+        model, graph, bottoms = synthetic.build(net, seed=0)             # stays on the CPU
+        with _stdout_to_stderr():
+            t0 = time.perf_counter()
+            lt.merge_batchnorm(model, graph, bottoms, TARG)
+            t1 = time.perf_counter()
+            rels = rel.create_relation(graph, bottoms, TARG, delete_single=False)
+            t2 = time.perf_counter()
+            dfq.cross_layer_equalization(graph, rels, TARG)
+            _sync()
+            t3 = time.perf_counter()
+            dfq.bias_correction(graph, bottoms, TARG)
+            _sync()
+            t4 = time.perf_counter()
+        rec = {'merge_batchnorm_ms': (t1 - t0) * 1e3, 'create_relation_ms': (t2 - t1) * 1e3, 'equalization_ms': (t3 - t2) * 1e3,
+               'bias_correction_ms': (t4 - t3) * 1e3, 'le_plus_bc_ms': (t4 - t2) * 1e3}
+        if best is None or rec['le_plus_bc_ms'] < best['le_plus_bc_ms']:
+            best = rec
+    n_w = sum(m.weight.numel() for m in graph.values() if type(m) in TARG)
+    best.update({'net': net, 'weights': n_w, 'weights_per_s': n_w / (best['le_plus_bc_ms'] * 1e-3),
+                 'what': 'CPU-resident {}: cross_layer_equalization + bias_correction through the drop-in entry points, wall time '
+                         'incl. H2D / D2H of every tensor, plan building and synchronisation (best of {})'.format(net, reps)})
+    return best
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -555,6 +654,11 @@ def main():
                      'network is, not how good the kernel is; DESIGN.md 4.2)'.format(n_w * 4 / 1e6),
         }
         out['config']['single_pass_latency_ms'] = lat['pass_ms']
+        # like for like with BASELINE.json's metric (ONE network per pass, configs[1]); `value` above is a batch of
+        # independent networks per step -- an API the reference does not have
+        out['value_single_network'] = n_w / (lat['pass_ms'] * 1e-3)
+        out['value_single_network_what'] = ('weights/s of ONE {} through LE + BC with nothing else in flight ({:.3f} ms per pass); '
+                                            'latency-bound, see `latency`'.format(args.net, lat['pass_ms']))
 
     if rank == 0 and not args.no_roofline:
         # Dominant kernel: le_level_kernel (one launch per sweep).  Algorithmic bytes of a launch = 8 B per
@@ -616,6 +720,15 @@ def main():
     if rank == 0 and args.act_shape:
         with _stream_ctx(streams[0]):
             out['config']['activation_ranges'] = activation_range_kernels([int(v) for v in args.act_shape.split(',')], dev)
+
+    if rank == 0 and args.distill:
+        dnet, dn, dshape = args.distill.split(':')
+        with _stream_ctx(streams[0]):
+            out['config']['distill_range'] = distill_range_pass(dnet, [int(v) for v in dshape.split(',')], int(dn), dev)
+    if rank == 0 and world == 1 and args.pcie:
+        rec = pcie_inclusive_pass(args.pcie)
+        out['pcie_inclusive'] = rec
+        out['pcie_inclusive_ms'] = rec['le_plus_bc_ms']
 
     # ---- config 4 as north_star splits it (every rank takes part) ----
     if args.sharded and dist is not None:

@@ -1,9 +1,12 @@
 // Analytic bias correction (dfq.py:173-293) for gfx950.
 //
-// Three stages on one stream:
+// Two stages on one stream:
 //   1. per-tensor min/max of every corrected layer            (one launch, all layers)
-//   2. quant-error row sums  eps[o, i] = sum_k (Q(W)-W)[o,i,k] (one launch, all layers; dfq.py:216-219)
-//   3. the sequential chain, one small launch per layer in graph order:
+//   2. the sequential chain (ONE launch); a step forms the quant-error row sums of its rows,
+//        eps[o, i] = sum_k (Q(W)-W)[o,i,k]  (dfq.py:216-219),  in registers straight from W -- until round 3 a
+//        separate launch wrote eps[O, I/g] for all layers and the chain read it back: for 1x1 layers a buffer the size
+//        of the weights, 8 B per (o, i) pair of traffic; now a pass moves 8 B per weight (min/max read + this read) --
+//        then:
 //        E[x] from the BN proxies (ReLU moment matching dfq.py:182-184,238-242; add/cat merge
 //        :244-270)  ->  bias[g] = eps[g] . E[g] (:281-287)  ->  b -= bias (:290-292)  ->
 //        next BN's beta~ += -bias (:204-206, 293).
@@ -50,7 +53,10 @@ struct BcSourceDev {
 };
 
 struct BcStepDev {
-    const float* eps;
+    const float* w;          // the layer's weights [O, I/g, khkw]
+    const uint32_t* mm;      // its (min, max) slots, filled by bc_minmax_kernel
+    int32_t khkw, pad0;
+    const float* eps;        // debug copy of the row sums (DFQ_BC_EPS=1: written by bc_quant_error_kernel, read by nobody)
     float* bias;             // layer bias [O], in/out
     float* next_bn_bias;     // [O] or null
     const float* next_bn_weight;   // gamma~ of that BN (null if nobody reads its ReLU moment)
@@ -264,7 +270,8 @@ struct BcDep {            // null counters: every step is its own launch (depend
     uint32_t* err;
     int32_t wait_idx, wait_blocks, bump_idx, pad;
     unsigned long long* tags;
-    uint32_t epoch, pad2;
+    uint32_t epoch;
+    int32_t symmetric;    // dfq.py:173 `signed`: the quantiser of the row sums
 };
 constexpr long kBcTagSpinLimit = 20000000;
 
@@ -285,17 +292,47 @@ __device__ __forceinline__ void bc_step_body(const BcStepDev& st, int blk, const
     const int ln = lane & (lanes - 1);
     const int row0 = blk * rpb + wave * rw;
     const int n_slots = min(kBcRegs, ((rw + rps - 1) >> (6 - st.lg_lanes)) * chunks);
-    // ---- this wave's eps values go into registers first: the fetch overlaps the expectation build ----
+    // ---- this wave's quant-error row sums go into registers first: eps[o, i] = sum_k (Q(w) - w) (dfq.py:216-219, 8 bit,
+    //      per-tensor range from the min/max launch; sequential float32 sum over k from 0.0f like the reference's .sum(-1)).
+    //      The weights are requested before anything else and the quantiser runs while the expectation's sources arrive ----
+    const int khkw = st.khkw;
     float ev[kBcRegs];
+    {
+        int rg = 0, c = 0;
+        if (khkw == 1) {
+#pragma unroll
+            for (int u = 0; u < kBcRegs; ++u) {
+                if (u < n_slots) {
+                    const int row = min(row0 + rg * rps + sub, st.out_ch - 1);
+                    const int col = min(c * lanes + ln, in - 1);
+                    ev[u] = st.w[(int64_t)row * in + col];
+                    if (++c == chunks) { c = 0; ++rg; }
+                }
+            }
+        }
+    }
+    const QParams qp = qparams_double((double)slot_min(st.mm[0]), (double)slot_max(st.mm[1]), 8, dep.symmetric);
     {
         int rg = 0, c = 0;
 #pragma unroll
         for (int u = 0; u < kBcRegs; ++u) {
             if (u < n_slots) {
-                const int row = min(row0 + rg * rps + sub, st.out_ch - 1);
-                const int col = min(c * lanes + ln, in - 1);
-                ev[u] = st.eps[(int64_t)row * in + col];
-                if (++c == chunks) { c = 0; ++rg; }
+                float code;
+                if (khkw == 1) {
+                    const float v = ev[u];
+                    ev[u] = 0.0f + (fake_quant_one(v, qp, &code) - v);
+                } else {
+                    const int row = min(row0 + rg * rps + sub, st.out_ch - 1);
+                    const int col = min(c * lanes + ln, in - 1);
+                    const float* wp = st.w + ((int64_t)row * in + col) * khkw;
+                    float acc = 0.0f;
+                    for (int k = 0; k < khkw; ++k) {
+                        const float v = wp[k];
+                        acc = acc + (fake_quant_one(v, qp, &code) - v);
+                    }
+                    ev[u] = acc;
+                    if (++c == chunks) { c = 0; ++rg; }
+                }
             }
         }
     }
@@ -393,14 +430,21 @@ __device__ __forceinline__ void bc_step_body(const BcStepDev& st, int blk, const
         // very long rows (> 1536 inputs): one row per wave, the tail streams from memory
         const int o = min(row0, st.out_ch - 1);
         const float* ex = sh_E + bc_small_div(o, step_o) * in;
-        const float* er = st.eps + (int64_t)o * in;
+        const float* wr = st.w + (int64_t)o * in * khkw;
         double acc = 0.0;
 #pragma unroll
         for (int u = 0; u < kBcRegs; ++u) {
             const int i = lane + u * kWave;
             acc += (i < in) ? (double)ev[u] * (double)ex[i] : 0.0;
         }
-        for (int i = lane + kBcRegs * kWave; i < in; i += kWave) acc += (double)er[i] * (double)ex[i];
+        for (int i = lane + kBcRegs * kWave; i < in; i += kWave) {
+            float er = 0.0f, code;
+            for (int k = 0; k < khkw; ++k) {
+                const float v = wr[(int64_t)i * khkw + k];
+                er = er + (fake_quant_one(v, qp, &code) - v);
+            }
+            acc += (double)er * (double)ex[i];
+        }
         acc = wave_sum(acc);
         if (lane == 0) sh_corr[wave * rw] = (float)acc;
     } else {
@@ -481,7 +525,7 @@ __device__ __forceinline__ void bc_load_step(const BcStepDev* __restrict__ entry
 // one launch per chain position (DFQ_BC_MERGED=0): grid (workgroups of the largest step, networks)
 template <int kExp>
 __global__ __launch_bounds__(kBlock) void bc_step_kernel(BcStepDev st_inline, const BcStepDev* __restrict__ table,
-                                                         const BcSourceDev* __restrict__ sources) {
+                                                         const BcSourceDev* __restrict__ sources, int symmetric) {
     __shared__ float sh_E[kExp];
     __shared__ float sh_corr[kBlock];
     __shared__ int sh_flag;
@@ -489,7 +533,7 @@ __global__ __launch_bounds__(kBlock) void bc_step_kernel(BcStepDev st_inline, co
     if (table) bc_load_step(table + blockIdx.y, desc.u);
     else desc.st = st_inline;
     if ((int)blockIdx.x * desc.st.rows_per_block >= desc.st.out_ch) return;     // grid.x is sized for the largest step of the launch
-    bc_step_body<kExp>(desc.st, blockIdx.x, sources, BcDep{nullptr, nullptr, -1, 0, -1, 0, nullptr, 0u, 0u}, sh_E, sh_corr, &sh_flag);
+    bc_step_body<kExp>(desc.st, blockIdx.x, sources, BcDep{nullptr, nullptr, -1, 0, -1, 0, nullptr, 0u, symmetric}, sh_E, sh_corr, &sh_flag);
 }
 
 // the whole chain of every network in one launch: 1-D grid over (step, workgroup) in chain order; a workgroup waits
@@ -498,7 +542,7 @@ template <int kExp>
 __global__ __launch_bounds__(kBlock) void bc_chain_kernel(const BcStepDev* __restrict__ table,
                                                           const BcChainRef* __restrict__ refs,
                                                           const BcSourceDev* __restrict__ sources, uint32_t* counters,
-                                                          uint32_t* err, unsigned long long* tags, uint32_t epoch) {
+                                                          uint32_t* err, unsigned long long* tags, uint32_t epoch, int symmetric) {
     __shared__ float sh_E[kExp];
     __shared__ float sh_corr[kBlock];
     __shared__ int sh_flag;
@@ -510,7 +554,7 @@ __global__ __launch_bounds__(kBlock) void bc_chain_kernel(const BcStepDev* __res
     bc_load_step(table + step, desc.u);
     bc_step_body<kExp>(desc.st, blk, sources,
                        BcDep{counters, err, __builtin_amdgcn_readfirstlane(ref[2]), __builtin_amdgcn_readfirstlane(ref[3]), step, 0,
-                             tags, epoch, 0u},
+                             tags, epoch, symmetric},
                        sh_E, sh_corr, &sh_flag);
 }
 
@@ -539,7 +583,8 @@ struct dfq_bc_plan {
     int32_t* d_qe_begin = nullptr;
     BcSourceDev* d_sources = nullptr;
     uint32_t* d_slots = nullptr;
-    float* d_eps = nullptr;                // all eps matrices, back to back
+    float* d_eps = nullptr;                // debug (DFQ_BC_EPS=1): all eps matrices, back to back
+    bool keep_eps = false;
     float* d_corr = nullptr;               // all correction vectors, back to back
     float* d_cache = nullptr;              // ReLU moments of the BNs that some step reads through a ReLU
     BcCacheSeg* d_cache_segs = nullptr;
@@ -617,7 +662,11 @@ int dfq_bc_plan_create(const dfq_layer* layers, int32_t n_layers, const dfq_bc_s
     p->eps_elems = eps_true;
     hipError_t e;
     auto fail_alloc = [&](hipError_t err) { dfq_bc_plan_destroy(p); return fail_hip(err, "bc plan allocation", __FILE__, __LINE__); };
-    if ((e = hipMalloc((void**)&p->d_eps, sizeof(float) * eps_total)) != hipSuccess) return fail_alloc(e);
+    {   // debug: also materialise eps[O, I/g] of every layer (dfq_bc_plan_eps); the chain does not read it
+        const char* de = getenv("DFQ_BC_EPS");
+        p->keep_eps = de && de[0] == '1';
+    }
+    if (p->keep_eps && (e = hipMalloc((void**)&p->d_eps, sizeof(float) * eps_total)) != hipSuccess) return fail_alloc(e);
     if ((e = hipMalloc((void**)&p->d_corr, sizeof(float) * corr_total)) != hipSuccess) return fail_alloc(e);
     if ((e = hipMalloc((void**)&p->d_layers, sizeof(BcLayerDev) * n_steps)) != hipSuccess) return fail_alloc(e);
     if ((e = hipMalloc((void**)&p->d_mm_begin, sizeof(int32_t) * (n_steps + 1))) != hipSuccess) return fail_alloc(e);
@@ -687,13 +736,14 @@ int dfq_bc_plan_create(const dfq_layer* layers, int32_t n_layers, const dfq_bc_s
     for (int s = 0; s < n_steps; ++s) {
         const dfq_layer& L = layers[steps[s].layer];
         const int64_t pairs = (int64_t)L.out_ch * L.in_per_group;
-        hl[s].w = L.weight; hl[s].eps = p->d_eps + eps_off; hl[s].n = pairs * L.khkw; hl[s].pairs = pairs;
+        hl[s].w = L.weight; hl[s].eps = p->keep_eps ? p->d_eps + eps_off : nullptr; hl[s].n = pairs * L.khkw; hl[s].pairs = pairs;
         hl[s].khkw = L.khkw; hl[s].pad = 0;
         mmb[s] = (int32_t)mb; qeb[s] = (int32_t)qb;
         mb += (hl[s].n + kMmChunk - 1) / kMmChunk;
         qb += (L.khkw == 1) ? (pairs + kBlock * kQePairs - 1) / (kBlock * kQePairs) : (pairs + kBlock - 1) / kBlock;
         BcStepDev& d = p->steps[s];
-        d.eps = p->d_eps + eps_off; d.bias = L.bias; d.next_bn_bias = steps[s].next_bn_bias; d.corr = p->d_corr + corr_off;
+        d.w = L.weight; d.mm = p->d_slots + 2 * s; d.khkw = L.khkw; d.pad0 = 0;
+        d.eps = p->keep_eps ? p->d_eps + eps_off : nullptr; d.bias = L.bias; d.next_bn_bias = steps[s].next_bn_bias; d.corr = p->d_corr + corr_off;
         d.out_ch = L.out_ch; d.in_per_group = L.in_per_group; d.source_begin = steps[s].source_begin;
         d.source_count = steps[s].source_count; d.expect_len = expect_len[s];
         d.inline_sources = d.source_count <= kStepSources ? 1 : 0;
@@ -834,9 +884,11 @@ static int bc_run_direct(dfq_bc_plan* p, int32_t symmetric, hipStream_t st) {
     hipLaunchKernelGGL(bc_minmax_kernel, dim3(p->minmax_blocks), dim3(kBlock), 0, st, (const BcLayerDev*)p->d_layers,
                        (const int32_t*)p->d_mm_begin, p->n_steps, p->d_slots);
     DFQ_CHECK_LAUNCH();
-    hipLaunchKernelGGL(bc_quant_error_kernel, dim3(p->qerr_blocks), dim3(kBlock), 0, st, (const BcLayerDev*)p->d_layers,
-                       (const int32_t*)p->d_qe_begin, p->n_steps, (const uint32_t*)p->d_slots, 8, (int)symmetric);
-    DFQ_CHECK_LAUNCH();
+    if (p->keep_eps) {
+        hipLaunchKernelGGL(bc_quant_error_kernel, dim3(p->qerr_blocks), dim3(kBlock), 0, st, (const BcLayerDev*)p->d_layers,
+                           (const int32_t*)p->d_qe_begin, p->n_steps, (const uint32_t*)p->d_slots, 8, (int)symmetric);
+        DFQ_CHECK_LAUNCH();
+    }
     if (p->cache_total > 0) {
         hipLaunchKernelGGL(bc_cache_init_kernel, dim3((p->cache_total + kBlock - 1) / kBlock), dim3(kBlock), 0, st,
                            (const BcCacheSeg*)p->d_cache_segs, p->n_cache_segs, p->cache_total);
@@ -853,10 +905,10 @@ static int bc_run_direct(dfq_bc_plan* p, int32_t symmetric, hipStream_t st) {
         if (tags && ++p->epoch == 0u) p->epoch = 1u;
         if (p->max_expect <= kExpectSmall)
             hipLaunchKernelGGL(bc_chain_kernel<kExpectSmall>, dim3(p->chain_blocks), dim3(kBlock), 0, st, (const BcStepDev*)p->d_steps,
-                               (const BcChainRef*)p->d_refs, (const BcSourceDev*)p->d_sources, p->d_counters, err, tags, p->epoch);
+                               (const BcChainRef*)p->d_refs, (const BcSourceDev*)p->d_sources, p->d_counters, err, tags, p->epoch, (int)symmetric);
         else
             hipLaunchKernelGGL(bc_chain_kernel<kExpectMax>, dim3(p->chain_blocks), dim3(kBlock), 0, st, (const BcStepDev*)p->d_steps,
-                               (const BcChainRef*)p->d_refs, (const BcSourceDev*)p->d_sources, p->d_counters, err, tags, p->epoch);
+                               (const BcChainRef*)p->d_refs, (const BcSourceDev*)p->d_sources, p->d_counters, err, tags, p->epoch, (int)symmetric);
         DFQ_CHECK_LAUNCH();
         return DFQ_OK;
     }
@@ -864,10 +916,10 @@ static int bc_run_direct(dfq_bc_plan* p, int32_t symmetric, hipStream_t st) {
         const BcStepDev* table = (L.n == 1) ? nullptr : p->d_steps + L.begin;
         if (L.max_expect <= kExpectSmall)
             hipLaunchKernelGGL(bc_step_kernel<kExpectSmall>, dim3(L.max_blocks, L.n), dim3(kBlock), 0, st,
-                               p->launch_steps[L.begin], table, (const BcSourceDev*)p->d_sources);
+                               p->launch_steps[L.begin], table, (const BcSourceDev*)p->d_sources, (int)symmetric);
         else
             hipLaunchKernelGGL(bc_step_kernel<kExpectMax>, dim3(L.max_blocks, L.n), dim3(kBlock), 0, st,
-                               p->launch_steps[L.begin], table, (const BcSourceDev*)p->d_sources);
+                               p->launch_steps[L.begin], table, (const BcSourceDev*)p->d_sources, (int)symmetric);
         DFQ_CHECK_LAUNCH();
     }
     return DFQ_OK;

@@ -575,6 +575,8 @@ class BCPlan:
     def eps(self, step):
         _ffi.synchronize()
         addr = _ffi.lib().dfq_bc_plan_eps(self._plan, step)
+        if not addr:
+            raise RuntimeError('the quant-error row sums are only materialised by plans created with DFQ_BC_EPS=1 (debug)')
         return self._view(addr, self.step_out_ch[step] * self.step_in[step]).reshape(self.step_out_ch[step], -1)
 
     def correction(self, step):

@@ -281,10 +281,13 @@ int dfq_bc_plan_create(const dfq_layer* layers, int32_t n_layers,
                        const dfq_bc_source* sources, int32_t n_sources,
                        dfq_bc_plan** out_plan);
 void dfq_bc_plan_destroy(dfq_bc_plan* plan);
-/* per-tensor min/max of all step layers -> quant-error row sums eps[O, I/g] of all step layers
- * (8 bit, dfq.py:218-219) -> the sequential per-layer chain.  Asynchronous. */
+/* per-tensor min/max of all step layers (one launch) -> the sequential per-layer chain (one launch); a step forms
+ * the quant-error row sums eps[o, i] = sum_k (Q(w) - w) of its rows (8 bit, dfq.py:216-219) in registers, straight from
+ * the weights: 8 B per weight for the whole pass.  Asynchronous. */
 int dfq_bc_plan_run(dfq_bc_plan* plan, int32_t symmetric, void* stream);
-/* device pointers into the plan's scratch (tests): eps[O*I/g], expect[len], bias[O] of a step */
+/* device pointers into the plan's scratch (tests): the correction vector bias[O] of a step; eps[O*I/g] only for plans
+ * created with DFQ_BC_EPS=1 in the environment (debug: one more launch materialises the row sums the chain computes on the
+ * fly, same arithmetic) -- NULL otherwise */
 /* Synchronises `stream`; DFQ_ERR_STATE if a workgroup of the last run gave up waiting for the correction step it
  * depends on (the chain of all layers is ONE launch whose workgroups wait for the previous layer's; the wait is
  * bounded).  DFQ_BC_MERGED=0 in the environment at plan creation restores one launch per layer. */

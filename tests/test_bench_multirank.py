@@ -73,4 +73,10 @@ def test_bench_line_contract_single_rank():
     act = d['config']['activation_ranges']
     assert [k['bytes'] for k in act['kernels'][:3]] == [4 * act['elements'], 8 * act['elements'], 12 * act['elements']]
     assert d['sharded']['world'] == 1 and d['sharded']['scaling'] == 'strong'
+    # like-for-like figure, config 5 end to end, the PCIe-inclusive drop-in pass
+    assert abs(d['value_single_network'] - lat['weights_per_s']) < 1e-6 * lat['weights_per_s']
+    dr = d['config']['distill_range']
+    assert dr['batches'] == 2 and dr['quant_measures'] > 0 and dr['ms_per_batch'] > 0
+    assert dr['quant_measure_bytes_per_batch'] == 12 * dr['elements_per_batch'] and dr['elements_per_batch'] > 0
+    assert d['pcie_inclusive_ms'] == d['pcie_inclusive']['le_plus_bc_ms'] > 0
     assert 'reference' in c          # the committed reference-CPU record (null for nets it was not measured on)

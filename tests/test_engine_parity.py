@@ -498,9 +498,12 @@ def test_bias_correction_hand_over_protocols_agree(engine, monkeypatch, mode):
         plan.close()
 
 
-def test_bias_correction_intermediates_against_oracle(engine):
+def test_bias_correction_intermediates_against_oracle(engine, monkeypatch):
     """eps (quant-error row sums, dfq.py:216-219) and the correction vectors (dfq.py:281-287) read back from
-    the plan: eps is float32 elementwise work in the oracle's order (bit-exact), the matvec is 1e-5."""
+    the plan: eps is float32 elementwise work in the oracle's order (bit-exact), the matvec is 1e-5.  The chain forms the
+    row sums in registers; DFQ_BC_EPS=1 at plan creation makes one more launch materialise them (same device function)
+    for this inspection, and the corrected biases must not depend on that switch."""
+    monkeypatch.setenv('DFQ_BC_EPS', '1')
     gold = net_fixture('tiny_res', 0, '')
     model, graph, bottoms = _build('tiny_res', 0, gold, engine)
     lt.merge_batchnorm(model, graph, bottoms, TARG)
@@ -515,6 +518,17 @@ def test_bias_correction_intermediates_against_oracle(engine):
         assert_bitexact(npy(plan.eps(step)), collect[k]['eps'].reshape(npy(plan.eps(step)).shape), 'eps of {}'.format(k))
         assert_close(npy(plan.correction(step)), collect[k]['bias'].reshape(-1), 'correction of {}'.format(k))
     assert plan.weight_elements == sum(spec.nodes[k].weight.size for k in keys)
+    with_debug = snapshot(graph)
+    plan.close()
+    monkeypatch.delenv('DFQ_BC_EPS')
+    load_stage(graph, gold, 'abs')
+    plain, _ = dfq.build_bc_plan(graph, bottoms, TARG)
+    plain.run()
+    with pytest.raises(RuntimeError, match='DFQ_BC_EPS'):
+        plain.eps(0)
+    for k, v in snapshot(graph).items():
+        assert_bitexact(v, with_debug[k], 'with / without the materialised row sums: {}'.format(k))
+    plain.close()
 
 
 def test_graph_replay_mode(engine, monkeypatch):
