@@ -457,7 +457,7 @@ def sharded_single_network(spec, steps, dev, dist, rank, world):
         reps.append((eq, bc, graph))
 
     def one(r):
-        r[0].run(max_sweeps=sweeps)          # local sweeps -> ONE all_gather -> rebuild of the foreign layers
+        r[0].run(max_sweeps=sweeps, check=False)   # snapshot -> local sweeps -> ONE all_gather -> rebuild of every paired tensor
         r[1].run()                           # the correction chain is sequential over layers: replicated on every rank
 
     def fence():
@@ -472,6 +472,9 @@ def sharded_single_network(spec, steps, dev, dist, rank, world):
         one(r)
     fence()
     elapsed = time.perf_counter() - t0
+    for r in reps:
+        r[0].check()                         # an abandoned in-launch wait of any pass raises here
+        r[1].status()
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == 'nccl' else 'cpu')
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     ms = float(t.item()) * 1e3 / steps
@@ -481,9 +484,9 @@ def sharded_single_network(spec, steps, dev, dist, rank, world):
             'scaling': 'strong', 'collectives_per_pass': 1, 'exchange_bytes_per_rank': reps[0][0].exchange_bytes,
             'backend': dist.get_backend(),
             'what': 'ONE {} network per pass: relation components partitioned over the ranks, {} pinned sweeps per rank on the '
-                    'owned components, one all_gather of the cumulative scale vectors, engine rebuild of the foreign layers '
-                    '(W = diag(S_out) W0 diag(1/S_in)), bias correction replicated on every rank; plans prebuilt, weights '
-                    'resident'.format(net, sweeps)}
+                    'owned components (on scratch copies), one all_gather of the cumulative scale vectors, ONE batched rebuild launch of every '
+                    'paired tensor on every rank (W = diag(S_out) W0 diag(1/S_in): all ranks end bit-identical), bias correction replicated on '
+                    'every rank; plans prebuilt, weights resident'.format(net, sweeps)}
 
 
 # ---------------------------------------------------------------------------------------------------

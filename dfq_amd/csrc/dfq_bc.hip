@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "dfq_common.hpp"
+#include "dfq_le_shared.hpp"
 
 namespace dfq {
 
@@ -245,7 +246,6 @@ struct BcChainRef {
     int32_t wait_blocks;   // its workgroups
 };
 constexpr int kBcDepStride = 32;        // one counter per 128-byte line
-constexpr long kBcSpinLimit = 20000000;
 
 // values that another workgroup of the SAME launch may have written (a BN's beta~ and its cached ReLU moment):
 // device-scope accesses, see dfq_le.hip / tools/litmus
@@ -272,8 +272,9 @@ struct BcDep {            // null counters: every step is its own launch (depend
     unsigned long long* tags;
     uint32_t epoch;
     int32_t symmetric;    // dfq.py:173 `signed`: the quantiser of the row sums
+    int32_t spin_limit;   // polls after which a wait is abandoned (DFQ_SPIN_LIMIT)
+    int32_t pad3;
 };
-constexpr long kBcTagSpinLimit = 20000000;
 
 template <int kExp>
 __device__ __forceinline__ void bc_step_body(const BcStepDev& st, int blk, const BcSourceDev* __restrict__ sources,
@@ -361,7 +362,7 @@ __device__ __forceinline__ void bc_step_body(const BcStepDev& st, int blk, const
                                      __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)dep.wait_blocks) {
                 __builtin_amdgcn_s_sleep(2);               // few waiters here (one step's workgroups): poll briskly
                 ++spins;
-                if (spins > kBcSpinLimit ||
+                if (spins > dep.spin_limit ||
                     ((spins & 255) == 0 && __hip_atomic_load(dep.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
                     atomicMax(dep.err, 1u);
                     ok = 0;
@@ -391,7 +392,7 @@ __device__ __forceinline__ void bc_step_body(const BcStepDev& st, int blk, const
                 while ((uint32_t)(w >> 32) != dep.epoch) {
                     __builtin_amdgcn_s_sleep(1);
                     ++spins;
-                    if (spins > kBcTagSpinLimit ||
+                    if (spins > dep.spin_limit ||
                         ((spins & 255) == 0 && __hip_atomic_load(dep.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
                         atomicMax(dep.err, 1u);
                         *sh_flag = 0;                      // (every thread that gives up writes the same value)
@@ -533,7 +534,7 @@ __global__ __launch_bounds__(kBlock) void bc_step_kernel(BcStepDev st_inline, co
     if (table) bc_load_step(table + blockIdx.y, desc.u);
     else desc.st = st_inline;
     if ((int)blockIdx.x * desc.st.rows_per_block >= desc.st.out_ch) return;     // grid.x is sized for the largest step of the launch
-    bc_step_body<kExp>(desc.st, blockIdx.x, sources, BcDep{nullptr, nullptr, -1, 0, -1, 0, nullptr, 0u, symmetric}, sh_E, sh_corr, &sh_flag);
+    bc_step_body<kExp>(desc.st, blockIdx.x, sources, BcDep{nullptr, nullptr, -1, 0, -1, 0, nullptr, 0u, symmetric, 0, 0}, sh_E, sh_corr, &sh_flag);
 }
 
 // the whole chain of every network in one launch: 1-D grid over (step, workgroup) in chain order; a workgroup waits
@@ -542,7 +543,7 @@ template <int kExp>
 __global__ __launch_bounds__(kBlock) void bc_chain_kernel(const BcStepDev* __restrict__ table,
                                                           const BcChainRef* __restrict__ refs,
                                                           const BcSourceDev* __restrict__ sources, uint32_t* counters,
-                                                          uint32_t* err, unsigned long long* tags, uint32_t epoch, int symmetric) {
+                                                          uint32_t* err, unsigned long long* tags, uint32_t epoch, int symmetric, int spin_limit) {
     __shared__ float sh_E[kExp];
     __shared__ float sh_corr[kBlock];
     __shared__ int sh_flag;
@@ -554,7 +555,7 @@ __global__ __launch_bounds__(kBlock) void bc_chain_kernel(const BcStepDev* __res
     bc_load_step(table + step, desc.u);
     bc_step_body<kExp>(desc.st, blk, sources,
                        BcDep{counters, err, __builtin_amdgcn_readfirstlane(ref[2]), __builtin_amdgcn_readfirstlane(ref[3]), step, 0,
-                             tags, epoch, symmetric},
+                             tags, epoch, symmetric, spin_limit, 0},
                        sh_E, sh_corr, &sh_flag);
 }
 
@@ -903,12 +904,13 @@ static int bc_run_direct(dfq_bc_plan* p, int32_t symmetric, hipStream_t st) {
         // a recorded graph replays its arguments, so the run epoch of the tagged slots cannot advance: counters there
         unsigned long long* tags = (st != p->capture_stream) ? p->d_tags : nullptr;
         if (tags && ++p->epoch == 0u) p->epoch = 1u;
+        const int spin_limit = spin_limit_from_env(20000000);
         if (p->max_expect <= kExpectSmall)
             hipLaunchKernelGGL(bc_chain_kernel<kExpectSmall>, dim3(p->chain_blocks), dim3(kBlock), 0, st, (const BcStepDev*)p->d_steps,
-                               (const BcChainRef*)p->d_refs, (const BcSourceDev*)p->d_sources, p->d_counters, err, tags, p->epoch, (int)symmetric);
+                               (const BcChainRef*)p->d_refs, (const BcSourceDev*)p->d_sources, p->d_counters, err, tags, p->epoch, (int)symmetric, spin_limit);
         else
             hipLaunchKernelGGL(bc_chain_kernel<kExpectMax>, dim3(p->chain_blocks), dim3(kBlock), 0, st, (const BcStepDev*)p->d_steps,
-                               (const BcChainRef*)p->d_refs, (const BcSourceDev*)p->d_sources, p->d_counters, err, tags, p->epoch, (int)symmetric);
+                               (const BcChainRef*)p->d_refs, (const BcSourceDev*)p->d_sources, p->d_counters, err, tags, p->epoch, (int)symmetric, spin_limit);
         DFQ_CHECK_LAUNCH();
         return DFQ_OK;
     }

@@ -4,7 +4,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string>
+#include <tuple>
 
 #include "../../include/dfq_hip.h"
 
@@ -32,7 +34,7 @@ typedef DFQ_GLOBAL_AS fvec4 gfvec4;
 #define DFQ_LAUNCH_RESIDENT(kernel, grid, block, smem, stream, ...) emu::launch_concurrent_k((grid), (block), (smem), kernel, __VA_ARGS__)
 #else
 #define DFQ_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
-#define DFQ_LAUNCH_RESIDENT(kernel, grid, block, smem, stream, ...) hipLaunchKernelGGL(kernel, grid, block, smem, stream, __VA_ARGS__)
+#define DFQ_LAUNCH_RESIDENT(kernel, grid, block, smem, stream, ...) ::dfq::launch_resident(kernel, grid, block, smem, stream, __VA_ARGS__)
 #endif
 
 // Streaming accesses: the non-temporal hint ("nt" on the global load / store) keeps a line that is touched once per launch
@@ -76,6 +78,27 @@ int fail_hip(hipError_t e, const char* what, const char* file, int line);
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+#ifndef DFQ_EMU
+// Launch of a kernel whose workgroups wait for each other in cycles (all of them must be resident at once): a COOPERATIVE
+// launch -- the runtime itself then guarantees co-residency or refuses the launch (hipErrorCooperativeLaunchTooLarge), instead
+// of the plan's own occupancy arithmetic being the only safeguard.  If the runtime refuses (or does not support cooperative
+// launches), the ordinary launch the plan sized for residency is used, as before round 3; DFQ_COOPERATIVE=0 forces that.
+template <typename... Params, typename... Args>
+inline void launch_resident(void (*kernel)(Params...), dim3 grid, dim3 block, size_t smem, hipStream_t stream, Args... args) {
+    static const bool coop = !(getenv("DFQ_COOPERATIVE") && getenv("DFQ_COOPERATIVE")[0] == '0');
+    if (coop) {
+        std::tuple<Params...> vals{args...};
+        void* ptrs[sizeof...(Params)];
+        int i = 0;
+        std::apply([&](auto&... v) { ((ptrs[i++] = (void*)&v), ...); }, vals);
+        const hipError_t e = hipLaunchCooperativeKernel((const void*)kernel, grid, block, ptrs, (unsigned)smem, stream);
+        if (e == hipSuccess) return;
+        (void)hipGetLastError();                       // refused: fall through to the ordinary launch
+    }
+    hipLaunchKernelGGL(kernel, grid, block, smem, stream, args...);
+}
+#endif
+
 // ---- kernels with in-launch waits never overlap across streams -------------------------------------
 // The one-launch sweep (le_level_kernel), the resident equalisation kernel and the one-launch bias-correction
 // chain contain workgroups that wait for other workgroups of the SAME launch.  That is deadlock-free as long as
@@ -84,7 +107,7 @@ inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s);
 // holding the slots the other's producers need.  So the library serialises them: SpinGuard's
 // constructor makes `stream` wait for the last waiting-kernel batch enqueued on a DIFFERENT stream, its destructor
 // records the end of this batch; host threads enqueue such batches one at a time (a process-wide mutex held between the two).  One event record per enqueue call, nothing per launch; kernels without in-launch
-// waits (per-level launches, bootstrap, quantisers, ...) are not affected.  Process-wide, per device.
+// waits (per-level launches, bootstrap, quantisers, ...) are not affected.  One record per device ordinal, one mutex per process.
 class SpinGuard {
 public:
     explicit SpinGuard(hipStream_t stream);
@@ -93,6 +116,7 @@ public:
     SpinGuard& operator=(const SpinGuard&) = delete;
 private:
     hipStream_t stream_;
+    int device_;
 };
 
 // ---- order-preserving float <-> uint32 encoding for atomic min/max ----------------------------

@@ -30,26 +30,45 @@ int fail_hip(hipError_t e, const char* what, const char* file, int line) {
 }
 
 // ---- SpinGuard (see dfq_common.hpp) ----
+// One {event, stream, pending} record per DEVICE ordinal (an event belongs to the device it was created on: recording an event
+// of device A on a stream of device B fails), one process-wide mutex for all of them.
 namespace {
+constexpr int kMaxDevices = 64;
+struct SpinState {
+    hipEvent_t event = nullptr;
+    hipStream_t stream = nullptr;
+    bool pending = false;
+};
 std::mutex g_spin_mu;
-hipEvent_t g_spin_event = nullptr;
-hipStream_t g_spin_stream = nullptr;
-bool g_spin_pending = false;
+SpinState g_spin[kMaxDevices];
 }  // namespace
 
 // The mutex is held from the constructor to the destructor: a second host thread that enqueued its batch between
 // this thread's wait and this thread's record would wait for the batch BEFORE this one and overlap with this one.
-SpinGuard::SpinGuard(hipStream_t stream) : stream_(stream) {
+SpinGuard::SpinGuard(hipStream_t stream) : stream_(stream), device_(0) {
     g_spin_mu.lock();
-    if (g_spin_pending && g_spin_stream != stream_ && g_spin_event)
-        (void)hipStreamWaitEvent(stream_, g_spin_event, 0);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) { (void)hipGetLastError(); dev = 0; }
+    device_ = dev;
+    SpinState& st = g_spin[device_];
+    if (st.pending && st.stream != stream_ && st.event) {
+        // a failed wait must not linger as the thread's sticky error (the next launch check would report it as a launch
+        // failure): clear it and fall back to the blunt tool
+        if (hipStreamWaitEvent(stream_, st.event, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipStreamSynchronize(st.stream); }
+    }
 }
 
 SpinGuard::~SpinGuard() {
-    if (!g_spin_event && hipEventCreateWithFlags(&g_spin_event, hipEventDisableTiming) != hipSuccess) g_spin_event = nullptr;
-    if (g_spin_event && hipEventRecord(g_spin_event, stream_) == hipSuccess) {
-        g_spin_stream = stream_;
-        g_spin_pending = true;
+    SpinState& st = g_spin[device_];
+    if (!st.event && hipEventCreateWithFlags(&st.event, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); st.event = nullptr; }
+    if (st.event && hipEventRecord(st.event, stream_) == hipSuccess) {
+        st.stream = stream_;
+        st.pending = true;
+    } else {
+        // no event to wait for: make the batch itself finish before anybody else may enqueue one
+        (void)hipGetLastError();
+        (void)hipStreamSynchronize(stream_);
+        st.pending = false;
     }
     g_spin_mu.unlock();
 }

@@ -221,7 +221,6 @@ struct LeDep {
     int32_t sweep;
     int32_t pad;
 };
-constexpr long kSpinLimit = 4000000;    // x (sleep + load) ~ several seconds
 constexpr int kDepStride = 16;          // one 64-bit counter per 128-byte line: hundreds of waiting workgroups poll them
 // Returns false (for the whole workgroup) when the wait was abandoned: the caller then leaves WITHOUT storing anything,
 // so a failed run never rescales weights with stale statistics -- it only stops short, and `err` makes every later
@@ -230,7 +229,7 @@ constexpr int kDepStride = 16;          // one 64-bit counter per 128-byte line:
 // which are performed at the coherence point, and is read with device-scope (sc1) loads, so the counter itself can be
 // relaxed; a release on the add would be a `buffer_wbl2` of every dirty weight line of the XCD per tile.  The producer
 // side orders "statistics performed" before "counter incremented" with s_waitcnt(0) + a workgroup barrier.
-__device__ __forceinline__ bool dep_wait(const LeRelDev& R, const LeDep& dep, int naps, int* sh_flag) {
+__device__ __forceinline__ bool dep_wait(const LeRelDev& R, const LeDep& dep, int naps, int spin_limit, int* sh_flag) {
     if (R.dep_idx < 0) return true;                  // uniform
     if (threadIdx.x == 0) {
         const unsigned long long target = (unsigned long long)R.dep_tiles * (unsigned long long)(dep.sweep + 1);
@@ -239,7 +238,7 @@ __device__ __forceinline__ bool dep_wait(const LeRelDev& R, const LeDep& dep, in
         while (__hip_atomic_load(dep.counters + (int64_t)R.dep_idx * kDepStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
             for (int k = 0; k < naps; ++k) __builtin_amdgcn_s_sleep(8);   // default 2 naps: ~0.5 us between polls
             ++spins;
-            if (spins > kSpinLimit ||
+            if (spins > spin_limit ||
                 ((spins & 255) == 0 && __hip_atomic_load(dep.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull)) {
                 atomicMax(dep.err, 1ull);
                 ok = 0;
@@ -375,7 +374,7 @@ __device__ __forceinline__ double row_tile(const LeRelDev& R, const LeParams& p,
     }
     mid();
     if (waits) {
-        if (!dep_wait(R, dep, p.poll_naps, sh_flag)) return kTileAbandoned;
+        if (!dep_wait(R, dep, p.poll_naps, p.spin_limit, sh_flag)) return kTileAbandoned;
         if (tid < nr) { wa0 = ld_stat(st_a); wa1 = ld_stat(st_a + 1); wb0 = st_b[0]; wb1 = st_b[1]; }
         if (has_sl0) { pa0 = ld_stat(a_base + 2 * c_sl0); pa1 = ld_stat(a_base + 2 * c_sl0 + 1); pb0 = b_base[2 * c_sl0]; pb1 = b_base[2 * c_sl0 + 1]; }
         if (PRE) { landed(wa0, wa1, wb0, wb1); landed(pa0, pa1, pb0, pb1); }
@@ -563,7 +562,7 @@ __device__ __forceinline__ double col_tile(const LeRelDev& R, const LeParams& p,
     }
     mid();
     if (waits) {
-        if (!dep_wait(R, dep, p.poll_naps, sh_flag)) return kTileAbandoned;
+        if (!dep_wait(R, dep, p.poll_naps, p.spin_limit, sh_flag)) return kTileAbandoned;
         if (has_entry) { wa0 = ld_stat(st_a); wa1 = ld_stat(st_a + 1); wb0 = st_b[0]; wb1 = st_b[1]; }
         if (PRE) landed(wa0, wa1, wb0, wb1);
     }
@@ -790,11 +789,11 @@ __global__ __launch_bounds__(kBlock, DFQ_LE_MIN_WAVES) void le_level_kernel(cons
     double acc;
     const bool col_side = tile >= R.n_row_tiles;
     if (!col_side) {
-        if (R.rt_vec == 0) acc = dep_wait(R, dep, p.poll_naps, &sh_flag) ? short_tile<0>(R, p, tile, cur) : kTileAbandoned;
+        if (R.rt_vec == 0) acc = dep_wait(R, dep, p.poll_naps, p.spin_limit, &sh_flag) ? short_tile<0>(R, p, tile, cur) : kTileAbandoned;
         else if (R.rt_vec == 4) { float v[kSlotsVec4][4]; acc = row_tile<4, false>(R, p, tile, cur, dep, false, v, nothing, sh_f, sh_u, sh_g, sh_p, &sh_flag, tr); }
         else { float v[kSlotsVec4][1]; acc = row_tile<1, false>(R, p, tile, cur, dep, false, v, nothing, sh_f, sh_u, sh_g, sh_p, &sh_flag, tr); }
     } else {
-        if (R.ct_vec == 0) acc = dep_wait(R, dep, p.poll_naps, &sh_flag) ? short_tile<1>(R, p, tile - R.n_row_tiles, cur) : kTileAbandoned;
+        if (R.ct_vec == 0) acc = dep_wait(R, dep, p.poll_naps, p.spin_limit, &sh_flag) ? short_tile<1>(R, p, tile - R.n_row_tiles, cur) : kTileAbandoned;
         else if (R.ct_vec == 4) { float v[kSlotsVec4][4]; acc = col_tile<4, false>(R, p, tile - R.n_row_tiles, cur, dep, false, v, nothing, sh_f, sh_u, sh_g, &sh_flag, tr); }
         else { float v[kSlotsVec4][1]; acc = col_tile<1, false>(R, p, tile - R.n_row_tiles, cur, dep, false, v, nothing, sh_f, sh_u, sh_g, &sh_flag, tr); }
     }
@@ -965,7 +964,7 @@ __global__ __launch_bounds__(kBlock, DFQ_LE_SWEEP_MIN_WAVES) void le_sweep_kerne
                 if (R.rt_vec == 4) acc = row_tile<4, true>(R, p, tile, cur, dep, ready, v, ahead, sh_f, sh_u, sh_g, sh_p, &sh_flag, tr);
                 else {
                     ahead();
-                    if (!ready && !dep_wait(R, dep, p.poll_naps, &sh_flag)) acc = kTileAbandoned;
+                    if (!ready && !dep_wait(R, dep, p.poll_naps, p.spin_limit, &sh_flag)) acc = kTileAbandoned;
                     else if (R.rt_vec == 0) acc = short_tile<0>(R, p, tile, cur);
                     else { float v1[kSlotsVec4][1]; acc = row_tile<1, false>(R, p, tile, cur, dep, true, v1, [] {}, sh_f, sh_u, sh_g, sh_p, &sh_flag, tr); }
                 }
@@ -973,7 +972,7 @@ __global__ __launch_bounds__(kBlock, DFQ_LE_SWEEP_MIN_WAVES) void le_sweep_kerne
                 if (R.ct_vec == 4) acc = col_tile<4, true>(R, p, tile - R.n_row_tiles, cur, dep, ready, v, ahead, sh_f, sh_u, sh_g, &sh_flag, tr);
                 else {
                     ahead();
-                    if (!ready && !dep_wait(R, dep, p.poll_naps, &sh_flag)) acc = kTileAbandoned;
+                    if (!ready && !dep_wait(R, dep, p.poll_naps, p.spin_limit, &sh_flag)) acc = kTileAbandoned;
                     else if (R.ct_vec == 0) acc = short_tile<1>(R, p, tile - R.n_row_tiles, cur);
                     else { float v1[kSlotsVec4][1]; acc = col_tile<1, false>(R, p, tile - R.n_row_tiles, cur, dep, true, v1, [] {}, sh_f, sh_u, sh_g, &sh_flag, tr); }
                 }

@@ -47,7 +47,6 @@ constexpr int kResTab = 1024;        // LDS table entries of a tile: (groups x i
 constexpr int kResRows = 512;        // rows of a tile that needs per-row tables (2 owner rows per thread at most)
 constexpr int kResOwn = kResRows / kBlock;
 constexpr int kResStride = 16;       // one 64-bit counter per 128-byte line
-constexpr long kResSpinLimit = 8000000;
 constexpr int kResMaxTiles = 1536;   // partials staged in LDS when the sweep's verdict is drawn
 constexpr int kResMaxLayers = 512;
 #ifndef DFQ_RES_EAGER
@@ -138,7 +137,7 @@ __device__ __forceinline__ void res_stamp(const ResArgs& a, int k, int point) {
 // up to three counters at once (null = not needed): one poll loop by one thread, all loads in flight.  The third one is
 // waited for only if `need3`; returns 0: a wait was abandoned, 1: the first two are there, 2: all three are there.
 __device__ __forceinline__ int res_wait3(const u64* w1, u64 t1, const u64* w2, u64 t2, const u64* w3, u64 t3, bool need3, u64* err,
-                                         int* sh_flag) {
+                                         int* sh_flag, long kResSpinLimit) {
     if (threadIdx.x == 0) {
         long spins = 0;
         int ok = 1;
@@ -163,8 +162,8 @@ __device__ __forceinline__ int res_wait3(const u64* w1, u64 t1, const u64* w2, u
     __syncthreads();                 // sh_flag may be rewritten by the next wait
     return ok;
 }
-__device__ __forceinline__ bool res_wait2(const u64* w1, u64 t1, const u64* w2, u64 t2, u64* err, int* sh_flag) {
-    return res_wait3(w1, t1, w2, t2, nullptr, 0, false, err, sh_flag) != 0;
+__device__ __forceinline__ bool res_wait2(const u64* w1, u64 t1, const u64* w2, u64 t2, u64* err, int* sh_flag, long limit) {
+    return res_wait3(w1, t1, w2, t2, nullptr, 0, false, err, sh_flag, limit) != 0;
 }
 
 __device__ __forceinline__ u64 ld_word(const u64* p) {
@@ -652,7 +651,8 @@ __device__ __forceinline__ double ordered_sum(const double* x, int n) {
 // Done by ONE workgroup (tile 0, a tile of the network's first paired layer: small, early, mostly idle) and published; the
 // others pick the number up a whole sweep later (see the commit logic), so this reduction is on nobody's critical path.
 // `mine` = layer_diff[threadIdx.x], loaded once before the loop.
-__device__ __forceinline__ double reduce_diff(const ResArgs& a, int k, const ResLayerDiff& mine, double* sh_d, double* sh_mean, int* sh_bad) {
+__device__ __forceinline__ double reduce_diff(const ResArgs& a, int k, const ResLayerDiff& mine, double* sh_d, double* sh_mean, int* sh_bad,
+                                              long kResSpinLimit) {
     const int tid = threadIdx.x;
     const auto& c = cold(a);
     const int n_tiles = c.n_tiles, n_layers = c.n_layers;
@@ -702,12 +702,12 @@ __device__ __forceinline__ void advance_state(const ResArgs& a, LoopState& st, d
 // the float64} (one copy per XCD: every tile of the launch polls it); everybody else reads the two words until both carry
 // k + 1 (normally at the first look: the publication is most of a sweep old).  Returns false when a wait was abandoned.
 __device__ __forceinline__ bool verdict(const ResArgs& a, int k, LoopState& st, const ResLayerDiff& mine, double* sh_dec, int* sh_flag, int* sh_bad,
-                                        double* sh_val) {
+                                        double* sh_val, long kResSpinLimit) {
     const auto& c = cold(a);
     const u64 want = (u64)(k + 1);
     double diff_tmp;
     if ((int)blockIdx.x == c.reducer) {
-        diff_tmp = reduce_diff(a, k, mine, sh_dec, sh_dec + kResMaxTiles, sh_bad);
+        diff_tmp = reduce_diff(a, k, mine, sh_dec, sh_dec + kResMaxTiles, sh_bad, kResSpinLimit);
         if (*sh_bad) return false;                                   // (read behind reduce_diff's barriers)
         if (threadIdx.x < 8) {
             u64* copy = cold(a).seq + ((k % 3) * 8 + threadIdx.x) * kResStride;
@@ -758,6 +758,7 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
     // the reducing tile (the smallest one) stages the partial sums in the unused tail of its tile
     double* sh_dec = (double*)(v + kResTileFloats / 2);
     const int tid = threadIdx.x;
+    const long kResSpinLimit = p.spin_limit;
     const bool hasA = T.relA >= 0, hasB = T.relB >= 0;
     const bool chain_start = hasB && !hasA;
     const bool rows_local = T.nc == T.row_len;       // the tile holds complete rows: its row statistics are final
@@ -837,7 +838,7 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
             const u64 t1 = (u64)(hasA ? T.nt_a : T.nt_self) * round;
             const u64* c2 = hasA ? cnt_line(a.cnt_c, T.layer, copy) : nullptr;
             const u64* c3 = hasB ? cnt_line(a.cnt_c, T.b_layer, copy) : nullptr;
-            const int got = res_wait3(c1, t1, c2, (u64)T.nt_self * round, c3, (u64)T.nt_b * round, DFQ_RES_TOPWAIT != 0, a.err, sh_flag);
+            const int got = res_wait3(c1, t1, c2, (u64)T.nt_self * round, c3, (u64)T.nt_b * round, DFQ_RES_TOPWAIT != 0, a.err, sh_flag, kResSpinLimit);
             if (!got) { failed = true; break; }
             have_b = hasB && got == 2;
         }
@@ -917,7 +918,7 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
             if (own_wait || !have_b) {
                 const int copy = blockIdx.x & 7;
                 if (!res_wait2(own_wait ? cnt_line(a.cnt_r, T.layer, copy) : nullptr, (u64)T.nt_self * round,
-                               have_b ? nullptr : cnt_line(a.cnt_c, T.b_layer, copy), (u64)T.nt_b * round, a.err, sh_flag)) { failed = true; break; }
+                               have_b ? nullptr : cnt_line(a.cnt_c, T.b_layer, copy), (u64)T.nt_b * round, a.err, sh_flag, kResSpinLimit)) { failed = true; break; }
             }
             if (!rows_local || !have_b) {
                 long tries = 0;
@@ -959,7 +960,7 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
         __syncthreads();                                          // sh_s complete; sh_row / sh_col free
         if (*sh_bad) { failed = true; break; }                    // a statistics word of phase 2 never showed this sweep's tag
         if (k > 0) {
-            if (!verdict(a, k - 1, st, my_layer, sh_dec, sh_flag, sh_bad, sh_val)) { failed = true; break; }
+            if (!verdict(a, k - 1, st, my_layer, sh_dec, sh_flag, sh_bad, sh_val, kResSpinLimit)) { failed = true; break; }
             if (st.done) break;                                   // sweep k-1 was the last one: sweep k is dropped
         }
         res_stamp<kTrace>(a, k, 6);
@@ -1045,7 +1046,7 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
             }
             res_stamp<kTrace>(a, k, 5);
             if (k > 0) {
-                if (!verdict(a, k - 1, st, my_layer, sh_dec, sh_flag, sh_bad, sh_val)) { failed = true; break; }
+                if (!verdict(a, k - 1, st, my_layer, sh_dec, sh_flag, sh_bad, sh_val, kResSpinLimit)) { failed = true; break; }
                 if (st.done) break;                               // sweep k-1 was the last one: sweep k is dropped
             }
         }
@@ -1066,7 +1067,7 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
             }
         }
         if (k + 1 >= cold(a).n_sweeps) {                          // the launch's last sweep: its verdict closes the state
-            if (!verdict(a, k, st, my_layer, sh_dec, sh_flag, sh_bad, sh_val)) failed = true;
+            if (!verdict(a, k, st, my_layer, sh_dec, sh_flag, sh_bad, sh_val, kResSpinLimit)) failed = true;
             break;
         }
     }

@@ -12,6 +12,7 @@ struct LeParams {
     float s_lo, s_hi, inv_lo, inv_hi, eps;
     int32_t hi_gt_lo, signed_range;
     int32_t poll_naps;      // s_sleep(8) units between two polls of a dependency counter
+    int32_t spin_limit;     // polls after which a workgroup abandons an in-launch wait (DFQ_SPIN_LIMIT; tests force an abandon with 1)
 };
 
 struct LeState {
@@ -22,6 +23,13 @@ struct LeState {
     int32_t done;
     int32_t pad;
 };
+
+// Every in-launch wait is bounded: DFQ_SPIN_LIMIT polls (default: seconds), then the workgroup gives up, raises the plan's
+// error word (every other waiter follows within 256 polls) and the next query / status call returns DFQ_ERR_STATE.
+inline int32_t spin_limit_from_env(int32_t dflt) {
+    const char* e = getenv("DFQ_SPIN_LIMIT");
+    return (e && atoi(e) > 0) ? atoi(e) : dflt;
+}
 
 // a / b for 0 <= a < 2^20, b >= 1 in four instructions: (a + 0.5) / b is at least 0.5/b away from every
 // integer, while v_rcp_f32 (1 ulp) plus the multiply are off by < 2e-7 * a/b < 0.5/b, so truncating
@@ -61,6 +69,7 @@ static inline dfq::LeParams make_params(const dfq_le_config* c) {
     q.hi_gt_lo = c->hi_gt_lo; q.signed_range = c->signed_range;
     const char* pe = getenv("DFQ_LE_POLL_NAPS");
     q.poll_naps = (pe && atoi(pe) > 0) ? atoi(pe) : 2;
+    q.spin_limit = dfq::spin_limit_from_env(4000000);   // x (sleep + load): several seconds
     return q;
 }
 

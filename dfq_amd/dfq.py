@@ -330,10 +330,26 @@ last_equalization = None      # result of the most recent cross_layer_equalizati
 # now hits a small cache keyed on everything the plan depends on: device pointers and shapes of every tensor it binds, the
 # relation structure, the engine-selecting environment.  Only device-resident tensors are cached (CPU tensors go through a
 # per-call shadow copy whose addresses change).
-_PLAN_CACHE_SIZE = 8
+# Thread safety and memory: one lock serialises the cached paths (a plan fetched by one thread must not be closed by another
+# thread's eviction while it runs); a plan whose run raised is dropped (a failed in-launch wait leaves its device-side state
+# and the tensors it binds undefined); every environment switch that shapes a plan is part of the key.  A cached plan pins
+# its small device-side tables (LE: statistics arenas and tile tables, < 1.5 MB for a MobileNetV2; BC: descriptors and a
+# correction vector per layer) until evicted: DFQ_PLAN_CACHE=n sets the number of plans kept per kind (default 8, 0 disables).
+import os as _os
+import threading as _threading
+
+_PLAN_CACHE_SIZE = max(0, int(_os.environ.get('DFQ_PLAN_CACHE', '8') or 0))
 _le_plan_cache = OrderedDict()
 _bc_plan_cache = OrderedDict()
+_cache_lock = _threading.RLock()
 plan_cache_stats = {'le_hits': 0, 'le_misses': 0, 'bc_hits': 0, 'bc_misses': 0}
+_PLAN_ENV = ('DFQ_LE_RESIDENT', 'DFQ_LE_MERGED', 'DFQ_LE_TILE_ELEMS', 'DFQ_LE_ROW_COLS', 'DFQ_LE_PERSIST', 'DFQ_LE_SWEEP_WGS',
+             'DFQ_LE_EMIT_COLS', 'DFQ_LE_NO_SHORT', 'DFQ_LE_CHAIN_FIRST', 'DFQ_LE_POLL_NAPS', 'DFQ_RES_EXACT_GROUPS', 'DFQ_RES_RELAXED',
+             'DFQ_BC_TAGGED', 'DFQ_BC_MERGED', 'DFQ_BC_BLOCKS', 'DFQ_BC_EPS', 'DFQ_GRAPH', 'DFQ_COOPERATIVE', 'DFQ_HIP_LIB')
+
+
+def _env_key():
+    return tuple(_os.environ.get(k, '') for k in _PLAN_ENV)
 
 
 def _tensor_key(t, device):
@@ -367,18 +383,26 @@ def _cache_put(cache, key, value):
         old[0].close()
 
 
+def _cache_drop(cache, key):
+    old = cache.pop(key, None)
+    if old is not None:
+        old[0].close()
+
+
 def clear_plan_cache():
-    for cache in (_le_plan_cache, _bc_plan_cache):
-        while cache:
-            _, old = cache.popitem()
-            old[0].close()
+    with _cache_lock:
+        for cache in (_le_plan_cache, _bc_plan_cache):
+            while cache:
+                _, old = cache.popitem()
+                old[0].close()
 
 
 def _le_cache_key(graph, relations, targ_type):
-    import os
+    if _PLAN_CACHE_SIZE == 0:
+        raise _Uncacheable()
     dev = _ffi.target_device()
     keys = [k for k in graph if type(graph[k]) in targ_type]
-    parts = [os.environ.get('DFQ_LE_RESIDENT', ''), os.environ.get('DFQ_LE_MERGED', ''), os.environ.get('DFQ_LE_TILE_ELEMS', '')]
+    parts = [_env_key()]
     for k in keys:
         m = graph[k]
         parts.append((_tensor_key(m.weight, dev), _tensor_key(m.bias, dev), getattr(m, 'groups', 1)))
@@ -401,7 +425,7 @@ def cross_layer_equalization(graph, relations, targ_type, s_range=[1e-8, 1e8], r
     """
     global last_equalization
     print("Start cross layer equalization")
-    with torch.no_grad():
+    with torch.no_grad(), _cache_lock:
         for rr in relations:                                  # dfq.py:91-92 (before the cache key: biases are part of it)
             _ensure_bias(graph[rr.get_idxs()[0]])
         try:
@@ -439,6 +463,10 @@ def cross_layer_equalization(graph, relations, targ_type, s_range=[1e-8, 1e8], r
         try:
             res = plan.run(s_range=s_range, converge_thres=converge_thres, converge_count=converge_count,
                            signed=signed, eps=eps, max_sweeps=max_sweeps)
+        except Exception:
+            if key is not None:
+                _cache_drop(_le_plan_cache, key)      # an abandoned in-launch wait: the plan's state (and the weights) are undefined
+            raise
         finally:
             if key is None:
                 plan.close()
@@ -677,13 +705,15 @@ def bias_correction(graph, bottoms, targ_type, bits_weight=8, bn_type=torch.nn.B
     ``bits_weight`` is accepted and ignored -- the reference hard-codes 8 bits (dfq.py:218).
     """
     print("Start bias correction")
-    with torch.no_grad():
+    with torch.no_grad(), _cache_lock:
         layers, steps, _ = _bc_tables(graph, bottoms, targ_type, bn_type)
         if not steps:
             return                                       # no layer behind a BN: nothing to correct (dfq.py:197-199)
         dev = _ffi.target_device()
         try:                                             # plan cache, see cross_layer_equalization
-            key = tuple((_tensor_key(w, dev), _tensor_key(b, dev), g) for (w, b, g) in layers) + tuple(
+            if _PLAN_CACHE_SIZE == 0:
+                raise _Uncacheable()
+            key = (_env_key(),) + tuple((_tensor_key(w, dev), _tensor_key(b, dev), g) for (w, b, g) in layers) + tuple(
                 (li, tuple((_tensor_key(fw, dev), _tensor_key(fb, dev), bool(relu), bool(cat)) for (fw, fb, relu, cat) in srcs),
                  _tensor_key(nxt, dev)) for (li, srcs, nxt, _) in steps)
         except _Uncacheable:
@@ -699,6 +729,10 @@ def bias_correction(graph, bottoms, targ_type, bits_weight=8, bn_type=torch.nn.B
                 _cache_put(_bc_plan_cache, key, (plan,))
         try:
             plan.run(signed=signed, check=True)
+        except Exception:
+            if key is not None:
+                _cache_drop(_bc_plan_cache, key)
+            raise
         finally:
             if key is None:
                 plan.close()

@@ -317,9 +317,15 @@ class ShardedEqualizer:
         elif self.rebuild is not None:
             self.rebuild.run()
 
-    def run(self, max_sweeps=None, converge_thres=2e-7, converge_count=20):
+    def run(self, max_sweeps=None, converge_thres=2e-7, converge_count=20, check=True):
         """Returns the number of sweeps.  ``max_sweeps=N`` pins the count (no exchange before the final all_gather);
-        ``None`` keeps the reference's data-dependent loop with one 8-byte all_reduce per sweep."""
+        ``None`` keeps the reference's data-dependent loop with one 8-byte all_reduce per sweep.
+
+        With a pinned count nothing on this path waits for the GPU: snapshot, sweeps, all_gather and rebuild are enqueued back
+        to back and ``check`` (default) synchronises ONCE at the end to surface an abandoned in-launch wait of the sweeps --
+        the rebuilt tensors are undefined then and the caller's weights must be reloaded (errors are never silent,
+        dfq.py:126,276; the collective itself has the usual torch.distributed failure mode).  ``check=False`` leaves that
+        to a later ``check()`` call (bench.py: the bias correction is enqueued right behind)."""
         group, session = self.group, self.session
         with torch.no_grad():
             try:
@@ -345,12 +351,13 @@ class ShardedEqualizer:
                         else:
                             count += 1
                         sweeps += 1
-                if session is not None:
-                    session.finish()
-            finally:
+                if session is not None and self._sgraph_bind:
+                    session.finish()                         # (runner stand-in: copies its scales into the exchange buffer)
+            except Exception:
                 if session is not None:
                     session.close()
                     self.session = None
+                raise
             # ---- exchange: ONE all_gather of the cumulative scale vectors (RCCL over xGMI when the group is 'nccl') ----
             if self.comm_dev == self.dev:
                 dist.all_gather_into_tensor(self.gathered, self.flat, group=group)
@@ -360,12 +367,26 @@ class ShardedEqualizer:
                 self.gathered.copy_(g)
             # ---- every rank rebuilds every paired tensor from its pristine value: identical launch, identical inputs ----
             self._run_rebuild()
+            if self.stage._shadow:
+                self.check()                                 # CPU-resident tensors: the write-back below reads the results
             self.stage.writeback()
             S = self.gathered[self._sel]                    # the owners' segments, relation after relation (one gather)
             for i, rr in enumerate(self.relations):          # Relation.set_scale_vec, cumulative (relation.py:20-24)
                 s = self.stage.out_like(self.graph[rr.get_idxs()[0]].weight, S[self.offsets[i]:self.offsets[i + 1]])
                 rr.S = s if rr.S is None else rr.S.to(s.device) * s
+        if check:
+            self.check()
         return sweeps
+
+    def check(self):
+        """Synchronise and raise if a workgroup of this rank's sweeps abandoned a wait (once; closes the sweep plan)."""
+        session, self.session = self.session, None
+        if session is not None:
+            try:
+                if not self._sgraph_bind:
+                    session.finish()
+            finally:
+                session.close()
 
     def close(self):
         for p in (self.rebuild, self.snapshot):

@@ -149,20 +149,42 @@ class QuantMeasure(nn.Module):
         self.num_bits = num_bits
         self.update_stat = update_stat
 
+    def _packed_range(self, device):
+        """running_min / running_max as the two halves of ONE device float32[2] (what the kernels update and read in place).
+        The buffers are re-packed whenever something (``.to()``, ``load_state_dict`` of a fresh module, a caller assigning a
+        new tensor) has separated them; packed, a forward pass needs no concatenation and no copy back."""
+        mn, mx = self.running_min, self.running_max
+        if (mn.device == device and mx.device == device and mn.dtype == torch.float32 and mx.dtype == torch.float32
+                and mn.numel() == 1 and mx.numel() == 1 and mx.data_ptr() == mn.data_ptr() + 4
+                and mn.untyped_storage().data_ptr() == mx.untyped_storage().data_ptr()):
+            return torch.as_strided(mn, (2,), (1,))
+        if mn.device != device or mx.device != device:
+            return None                                   # a CPU-resident module: per-call shadow copies (below)
+        pair = torch.empty(2, dtype=torch.float32, device=device)
+        pair[0:1].copy_(mn.reshape(1))
+        pair[1:2].copy_(mx.reshape(1))
+        self._buffers['running_min'] = pair[0:1]
+        self._buffers['running_max'] = pair[1:2]
+        return pair
+
     def forward(self, input):
         with torch.no_grad():
             stage = _ffi.Stage()
             x = stage.bind(input)
             n = x.shape[0]
-            running = torch.cat([stage.bind(self.running_min).reshape(1), stage.bind(self.running_max).reshape(1)])
+            running = self._packed_range(stage.device)
+            shadow = running is None
+            if shadow:
+                running = torch.cat([stage.bind(self.running_min).reshape(1), stage.bind(self.running_max).reshape(1)])
             if self.update_stat:
                 sample_minmax_mean(x, n, running=running, stage=stage)       # quantize.py:106-107
             pair = running                                                    # eval: running range
             if self.training:
                 pair = sample_minmax_mean(x, n, stage=stage)                  # quantize.py:109-113
                 running.mul_(1 - self.momentum).add_(pair * self.momentum)
-            self.running_min.copy_(running[0:1])
-            self.running_max.copy_(running[1:2])
+            if shadow:
+                self.running_min.copy_(running[0:1])
+                self.running_max.copy_(running[1:2])
             out = stage.new(x.shape)
             # float(min_value), float(max_value) -> float64 recipe, evaluated on the device
             fake_quant_device(x, out, self.num_bits, False, 1, 0.0, 0.0, pair, None)

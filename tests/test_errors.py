@@ -91,3 +91,54 @@ def test_degenerate_inputs_are_handled(engine):
     assert rels == []
     dfq.cross_layer_equalization(graph, rels, TARG)
     dfq.bias_correction(graph, bottoms, TARG)          # first layer is fed by 'Data': nothing to correct, must not fail
+
+
+@pytest.mark.parametrize('which', ['resident', 'streaming', 'bias_correction'])
+def test_abandoned_in_launch_wait_is_reported_not_silent(engine, monkeypatch, which):
+    """Every wait of a workgroup for another workgroup of the same launch is bounded.  DFQ_SPIN_LIMIT=1 makes the first wait
+    that is not satisfied at its first look give up -- what an oversubscribed or wedged GPU would cause after seconds: the run
+    must come back with DFQ_ERR_STATE ('gave up'), never hang and never report success; the drop-in entry point drops its
+    cached plan; with the limit restored the library works again on reloaded weights (reference behaviour kept: errors are
+    assertions, never silent -- dfq.py:126,276)."""
+    import torch.nn as nn
+    from dfq_amd import synthetic
+    from dfq_amd.utils import layer_transform as lt
+    from dfq_amd.utils import relation as rel
+    TARG = [nn.Conv2d, nn.Linear]
+
+    def fresh():
+        model, graph, bottoms = synthetic.build('tiny_mobile', seed=0)
+        model.to(engine.device)
+        lt.merge_batchnorm(model, graph, bottoms, TARG)
+        return model, graph, bottoms, rel.create_relation(graph, bottoms, TARG)
+
+    if which == 'streaming':
+        monkeypatch.setenv('DFQ_LE_RESIDENT', '0')
+    dfq.clear_plan_cache()
+    monkeypatch.setenv('DFQ_SPIN_LIMIT', '1')
+    model, graph, bottoms, rels = fresh()
+    failed = False
+    for attempt in range(4):          # whether a wait misses its first look is a matter of timing: a few tries make it certain
+        try:
+            if which == 'bias_correction':
+                dfq.bias_correction(graph, bottoms, TARG)
+            else:
+                dfq.cross_layer_equalization(graph, rels, TARG, max_sweeps=6, converge_thres=-1.0, converge_count=10 ** 9)
+        except _ffi.DfqError as e:
+            assert 'gave up' in str(e), str(e)
+            failed = True
+            break
+        model, graph, bottoms, rels = fresh()
+    if engine.kind == 'gpu' or failed:
+        assert failed, 'a spin limit of one poll must make some wait of the launch give up'
+    assert not dfq._le_plan_cache or which == 'bias_correction' or not failed      # the failed plan is not kept
+    # ---- the library is usable afterwards: same passes, default limit, reloaded weights ----
+    monkeypatch.delenv('DFQ_SPIN_LIMIT')
+    model, graph, bottoms, rels = fresh()
+    dfq.cross_layer_equalization(graph, rels, TARG, max_sweeps=6, converge_thres=-1.0, converge_count=10 ** 9)
+    assert dfq.last_equalization['sweeps'] == 6
+    dfq.bias_correction(graph, bottoms, TARG)
+    for m in graph.values():
+        if type(m) in TARG:
+            assert torch.isfinite(m.weight).all() and (m.bias is None or torch.isfinite(m.bias).all())
+    dfq.clear_plan_cache()

@@ -1,7 +1,7 @@
 #!/bin/bash
 tag=${1:-bench}
 mkdir -p gpurun_out/$tag
-/usr/bin/time -f "bench wall %e s" timeout 900 python bench.py > gpurun_out/$tag/bench.json 2> gpurun_out/$tag/bench.err; echo "bench rc=$?"; tail -2 gpurun_out/$tag/bench.err
+SECONDS=0; timeout 900 python bench.py > gpurun_out/$tag/bench.json 2> gpurun_out/$tag/bench.err; echo "bench rc=$? wall ${SECONDS}s"; tail -2 gpurun_out/$tag/bench.err
 python - <<PY
 import json
 d=json.load(open('gpurun_out/$tag/bench.json'))
