@@ -1349,7 +1349,7 @@ struct dfq_le_plan {
     double* d_layer_mean = nullptr;
     LeState* d_state = nullptr;
     uint32_t* d_stats = nullptr;           // R2 arena [2][stat_words], then R1 arena [2][stat_words]
-    // single networks that fit the register files run the whole loop as ONE persistent launch (dfq_le_resident.hip);
+    // single networks that fit the LDS of the chip run the whole loop as ONE persistent launch (dfq_le_resident.hip);
     // null: the streaming one-launch-per-sweep kernel above (batched plans, networks too large, DFQ_LE_RESIDENT=0)
     dfq::LeResident* resident = nullptr;
     std::string resident_why;
@@ -1764,7 +1764,7 @@ int dfq_le_plan_create_batch(const dfq_layer* layers, int32_t n_layers, const in
     return DFQ_OK;
 }
 
-// workgroups (= register-resident tiles) of the persistent whole-loop launch, 0 when the plan streams
+// workgroups (= LDS-resident tiles) of the persistent whole-loop launch, 0 when the plan streams
 int32_t dfq_le_plan_resident_tiles(const dfq_le_plan* p) { return (p && p->resident) ? le_resident_tiles(p->resident) : 0; }
 const char* dfq_le_plan_resident_reason(const dfq_le_plan* p) { return p ? p->resident_why.c_str() : ""; }
 // persistent workgroups of a streaming sweep launch (le_sweep_kernel), 0 when the plan launches one workgroup per tile

@@ -1,36 +1,40 @@
-// Register-resident cross-layer equalisation: the WHOLE data-dependent loop of dfq.py:78-117 for one network as
-// ONE persistent launch (gfx950).
+// LDS-resident cross-layer equalisation: the WHOLE data-dependent loop of dfq.py:78-117 for one network as ONE persistent
+// (cooperative) launch (gfx950).
 //
-// A single network is tiny for this chip: MobileNetV2's paired layers are 13.9 MB, the register files of 256 CUs
-// hold 128 MB.  The streaming kernel of dfq_le.hip re-reads and re-writes every weight every sweep and pays, per
-// sweep, one launch boundary plus a chain of dependent tile latencies (descriptor -> data -> statistics -> store:
-// ~6 us per dependency level, 47 sweeps x 5 levels).  Here every workgroup loads ONE [rows x columns] tile of ONE
-// paired layer into registers once, keeps it there for all sweeps, and only the per-channel statistics travel
-// between workgroups; the weights are written back once, after the loop has stopped.  A sweep then costs the
-// latency of its dependency chain of statistics hand-offs (a few microseconds) and nothing else.
+// A single network is tiny for this chip: MobileNetV2's paired layers are 13.9 MB, the LDS of 256 CUs holds 40 MB.  The
+// streaming kernel of dfq_le.hip re-reads and re-writes every weight every sweep and pays, per sweep, one launch boundary
+// plus a chain of dependent tile latencies.  Here every workgroup loads ONE [rows x columns] tile of ONE paired layer into
+// its LDS once (32 KB; the first version kept it in registers -- see "the tile: three layouts" below for why not), keeps it
+// there for all sweeps, and only the per-channel statistics travel between workgroups; the weights are written back once,
+// after the loop has stopped.  A sweep then costs the latency of its dependency chain of statistics hand-offs.
 //
 // What a tile of layer L does in sweep k (A = the relation whose SECOND layer is L, B = the relation whose FIRST
 // layer is L; either may be absent; dfq.py:85-101 processes A before B):
-//   phase 1 (A): wait for A's row statistics of this sweep and L's column statistics of the previous sweep;
-//                solve s_A per input channel (dfq.py:58-59); the row statistics of t = fl(w / s_A) (dfq.py:73) are
-//                merged over the tiles of the row block and published for B -- no store, t is recomputed below;
-//   phase 2 (B): wait for L's merged row statistics and for the column statistics of B's second layer (previous
-//                sweep); solve s_B per row; the tile that owns the rows updates b, gamma~, beta~, S (dfq.py:62-71);
-//   phase 3    : w <- fl(fl(w / s_A) * s_B) in registers (the reference's two roundings in its order), |dW| summed
-//                in float64, column statistics of the new values published for A of the NEXT sweep (row
-//                statistics for B of the next sweep when L is a chain start).
+//   top      : ONE poll of the counters of everything other tiles produce for this sweep, then every statistics word the
+//              tile needs is requested in one trip through the memory system (words of phase 2 too if they are there);
+//   phase 1 (A): solve s_A per input channel (dfq.py:58-59); the row statistics of t = fl(w / s_A) (dfq.py:73) are
+//                published for B -- no store, t is recomputed below;
+//   phase 2 (B): solve s_B per row (rows complete in the tile: from LDS; else merged over the row block's tiles);
+//   phase 3    : |dW| in float64 and the statistics of the values the sweep WILL produce, from the pending factors;
+//                column statistics published for A of the NEXT sweep (row statistics for a chain start);
+//   commit     : w <- fl(fl(w / s_A) * s_B) in LDS (the reference's two roundings in its order), once the verdict of
+//                sweep k-1 says that sweep k happens at all.
 // Statistics words are 64-bit {sweep tag : order-preserving float bits}, merged with device-scope atomicMax: a newer
 // sweep always wins, so nothing is ever cleared; two parities (tag & 1) keep a sweep's readers and the next sweep's
-// writers apart.  "All tiles of layer X have published" is one monotonic counter per layer and statistic kind.
-// Convergence (dfq.py:105-115): every tile leaves one float64 partial, the LAST tile to arrive (ticket from an
-// atomicAdd) sums them per layer in a fixed order, advances the reference's (diff, count) state machine and
-// publishes the decision; everybody waits for it before the next sweep.
+// writers apart.  "The tiles of layer X have published" is a monotonic counter per layer and statistic kind (eight copies,
+// see `arrive`): strict (all contributions performed) for statistics merged from several tiles, relaxed (issued) for
+// single-producer statistics, whose readers validate the tag of every word they read.
+// Convergence (dfq.py:105-115): every tile leaves its float64 partial as two tagged words; ONE small tile reads them,
+// sums them per layer in a fixed order and publishes diff_tmp as two tagged words; every workgroup advances its own copy
+// of the reference's (diff, count) state machine with it.
 //
-// All workgroups of the launch must be resident at once (they wait for each other in cycles over the sweeps): the
-// plan refuses networks that do not fit (the caller then uses the streaming kernel), the library never runs two
-// kernels with in-launch waits concurrently (SpinGuard), every wait is bounded, and a workgroup that abandons a wait
-// stores NOTHING: a failed launch leaves the weights exactly as they were and is reported by the next query.
-// Results are bit-identical to the streaming kernel and to the oracle (same IEEE operations; min/max are exact).
+// All workgroups of the launch must be resident at once (they wait for each other in cycles over the sweeps): the launch is
+// cooperative (the runtime guarantees co-residency or refuses; the plan additionally refuses networks beyond three quarters
+// of the occupancy limit and the caller then streams), the library never runs two kernels with in-launch waits concurrently
+// (SpinGuard), every wait is bounded (DFQ_SPIN_LIMIT), and a workgroup that abandons a wait stores nothing.  After an
+// abandoned wait the run reports DFQ_ERR_STATE and the network is UNDEFINED as a whole (some tiles may already have stored
+// their result when another one gives up in the last verdict): the caller reloads the weights; the drop-in entry points drop
+// the cached plan.  Results are bit-identical to the streaming kernel and to the oracle (same IEEE operations; min/max exact).
 #include <algorithm>
 #include <cstring>
 #include <string>
@@ -1071,7 +1075,7 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
             break;
         }
     }
-    if (failed) return;                     // nothing is stored: the weights stay as they were before the launch
+    if (failed) return;                     // this tile stores nothing (others may have: the run reports DFQ_ERR_STATE, see the header)
     // ---- write the tile back (once) ----
     lay.store(T, v);
 #pragma unroll

@@ -93,7 +93,7 @@ class LEPlan:
 
     @property
     def resident_tiles(self):
-        """workgroups of the persistent whole-loop launch (weights in registers for all sweeps), 0 if the plan streams"""
+        """workgroups of the persistent whole-loop launch (weights in LDS for all sweeps), 0 if the plan streams"""
         return _ffi.lib().dfq_le_plan_resident_tiles(self._plan)
 
     @property

@@ -131,8 +131,8 @@ int32_t dfq_le_plan_level_launches(const dfq_le_plan* plan, int32_t level, int64
 /* launch geometry of launch `level` of a sweep: grid_x = its workgroups (all of them work), grid_y = 1 */
 int dfq_le_plan_level_grid(const dfq_le_plan* plan, int32_t level, int32_t* grid_x, int32_t* grid_y);
 
-/* Single networks whose paired layers fit the register files run the WHOLE loop as one persistent launch (every
- * workgroup keeps one tile of one layer in registers for all sweeps; dfq_le_resident.hip): the number of its workgroups,
+/* Single networks whose paired layers fit the chip's LDS run the WHOLE loop as one persistent, cooperative launch (every
+ * workgroup keeps one 32 KB tile of one layer in its LDS for all sweeps; dfq_le_resident.hip): the number of its workgroups,
  * or 0 when the plan uses the streaming one-launch-per-sweep kernel (batched plans, networks too large for the
  * chip's resident workgroups, DFQ_LE_RESIDENT=0) -- then dfq_le_plan_resident_reason says why.  Results are
  * bit-identical either way. */
