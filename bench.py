@@ -73,6 +73,7 @@ def parse():
     ap.add_argument('--distill', default='mobilenet_v2:8:64,3,224,224', help='config 5 end to end: net:batches:shape of '
                     'update_quant_range over the distilled batches; "" disables')
     ap.add_argument('--pcie', default='mobilenet_v2', help='CPU-resident model through the drop-in entry points; "" disables')
+    ap.add_argument('--lazy-steps', type=int, default=6, help='timed steps of the opt-in lazy-scale formulation; 0 disables')
     return ap.parse_args()
 
 
@@ -342,6 +343,58 @@ def activation_range_kernels(shape, dev):
         r['frac'] = r['GBps'] / HBM_PEAK_GBS
     return {'config': 'MobileNetV2 --distill_range (configs[4]): activation [{}] float32'.format(', '.join(map(str, shape))),
             'elements': n, 'kernels': rows}
+
+
+# ---------------------------------------------------------------------------------------------------
+# opt-in: the same batch through the lazy-scale formulation (its own byte count, its own roofline entry)
+# ---------------------------------------------------------------------------------------------------
+def lazy_scale_pass(protos, net_sweeps, steps, warm):
+    """SURVEY 7.3 item 9 / 8d "alternative byte count": LE of the batch with every network's sweep count GIVEN (what the
+    reference's loop needs for it), computed from the pristine weights and the cumulative scales -- a sweep reads 4 B per
+    paired element, the tensors are written once (8 B per weight) -- followed by the same bias correction.  Within 1e-5 of the
+    default engine's tensors (tests/test_full_reference.py), not bit-identical: reported next to `value`, never as `value`."""
+    from dfq_amd import dfq
+    units = []
+    for _ in range(steps + warm + 1):
+        nets = [copy.deepcopy(p) for p in protos]
+        units.append(dict(nets=nets, le=dfq.LazyLEPlan([(g, r) for (_, g, _, r) in nets], TARG),
+                          bc=dfq.build_bc_plan_batch([(g, b) for (_, g, b, _) in nets], TARG)))
+
+    def step(u):
+        u['le'].run(net_sweeps)
+        u['bc'].run()
+    for u in units[:warm]:
+        step(u)
+    _sync()
+    t0 = time.perf_counter()
+    for u in units[warm:warm + steps]:
+        step(u)
+    _sync()
+    ms = (time.perf_counter() - t0) * 1e3 / steps
+    le_ms = _gpu_elapsed_ms(lambda: units[-1]['le'].run(net_sweeps))
+    for u in units:
+        u['bc'].status()
+    le = units[0]['le']
+    n_w = sum(m.weight.numel() for m in protos[0][1].values() if type(m) in TARG)
+    paired_per_net = le.paired_elements // len(protos)
+    every_per_net = le.sweep_elements // len(protos)
+    # every network reads all its paired layers in its first sweep and the interior, non-depthwise ones in every later sweep
+    sweep_bytes = 4 * sum(paired_per_net + every_per_net * max(0, n - 1) for n in net_sweeps)
+    final_bytes = 8 * le.weight_elements
+    launches = 2 * le.levels * max(net_sweeps) + 1
+    gbps = (sweep_bytes + final_bytes) / (le_ms * 1e-3) / 1e9
+    return {'ms_per_step': ms, 'value': n_w * len(protos) / (ms * 1e-3), 'unit': 'weights/s', 'equalization_ms': le_ms,
+            'sweeps': net_sweeps, 'sweeps_given': True, 'levels': le.levels, 'launches_per_pass': launches,
+            'roofline': {'bound': 'hbm', 'kernel': 'lz_stats_kernel (+ lz_solve_kernel, rebuild_kernel): the whole lazy pass',
+                         'achieved': gbps, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbps / HBM_PEAK_GBS,
+                         'bytes_per_pass': sweep_bytes + final_bytes, 'bytes_per_network_first_sweep': 4 * paired_per_net,
+                         'bytes_per_network_later_sweep': 4 * every_per_net,
+                         'us_per_sweep': (le_ms * 1e3) / max(1, max(net_sweeps)), 'traffic': None},
+            'what': 'opt-in lazy-scale equalisation (csrc/dfq_le_lazy.hip): {} networks, sweep counts given per network (those of the '
+                    'reference loop), read-only sweeps over W0 with the cumulative scales applied on the fly (4 B per paired element in the first sweep, then only the '
+                    'non-depthwise layers in the interior of a chain: the extrema of the other passes are sweep-invariant and rescaled), '
+                    'one final materialisation (8 B per weight), then the same bias correction; tensors within 1e-5 of the default '
+                    'engine, not bit-identical'.format(len(protos))}
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -724,6 +777,10 @@ def main():
         with _stream_ctx(streams[0]):
             out['config']['activation_ranges'] = activation_range_kernels([int(v) for v in args.act_shape.split(',')], dev)
 
+    if rank == 0 and args.lazy_steps > 0 and args.sweeps == 0:
+        with _stream_ctx(streams[0]):
+            out['lazy_scale'] = lazy_scale_pass(protos, net_sweeps, args.lazy_steps, 2)
+        out['value_lazy_scale'] = out['lazy_scale']['value']
     if rank == 0 and args.distill:
         dnet, dn, dshape = args.distill.split(':')
         with _stream_ctx(streams[0]):

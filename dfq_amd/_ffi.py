@@ -63,7 +63,7 @@ class DfqBcStep(Structure):
 # include/dfq_hip.h and against the symbols the shared object really exports.
 class DfqRebuildItem(Structure):
     _fields_ = [('src', c_void_p), ('dst', c_void_p), ('s_out', c_void_p), ('s_in', c_void_p), ('rows', c_int32),
-                ('cols', c_int32), ('khkw', c_int32), ('groups', c_int32)]
+                ('cols', c_int32), ('khkw', c_int32), ('groups', c_int32), ('in_reciprocal', c_int32), ('reserved', c_int32)]
 
 
 class DfqBnRangeReq(Structure):
@@ -124,6 +124,14 @@ SIGNATURES = {
     'dfq_scale_rows': (c_int32, [c_void_p, c_int32, c_int64, c_void_p, c_int32, c_void_p]),
     'dfq_scale_cols': (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p]),
     'dfq_vec_op': (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
+    'dfq_le_lazy_plan_create': (c_int32, [POINTER(DfqLayer), c_int32, POINTER(c_int32), c_int32, POINTER(DfqRelation), c_int32,
+                                          POINTER(c_void_p)]),
+    'dfq_le_lazy_plan_destroy': (None, [c_void_p]),
+    'dfq_le_lazy_run': (c_int32, [c_void_p, POINTER(DfqLeConfig), POINTER(c_int32), c_void_p]),
+    'dfq_le_lazy_plan_levels': (c_int32, [c_void_p]),
+    'dfq_le_lazy_plan_paired_elements': (c_int64, [c_void_p]),
+    'dfq_le_lazy_plan_weight_elements': (c_int64, [c_void_p]),
+    'dfq_le_lazy_plan_sweep_elements': (c_int64, [c_void_p]),
     'dfq_rebuild_plan_create': (c_int32, [POINTER(DfqRebuildItem), c_int32, POINTER(c_void_p)]),
     'dfq_rebuild_plan_destroy': (None, [c_void_p]),
     'dfq_rebuild_plan_elements': (c_int64, [c_void_p]),

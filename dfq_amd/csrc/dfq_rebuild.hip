@@ -4,7 +4,8 @@
 // This is the replicated write of the sharded equalisation (dfq_amd/sharded.py): after the all_gather of
 // the scale vectors EVERY rank -- the owner of a component included -- runs this one launch on identical inputs
 // (W0, gathered S), so all ranks end with bit-identical tensors, whatever the number of ranks.  Per element two
-// separately rounded float32 operations in a fixed order:  t = fl(w0 * s_out[o]);  w = fl(t / s_in[ch]).
+// separately rounded float32 operations in a fixed order:  t = fl(w0 * s_out[o]);  w = fl(t / s_in[ch])  (or fl(t * r_in[ch])
+// when the caller holds reciprocals: the lazy-scale equalisation, dfq_le_lazy.hip).
 //
 // One launch covers every item of the plan: a workgroup owns a span of kSpan consecutive elements of one item
 // (16-byte vectors when the item's rows allow it); read once, written once -> 8 B per element.
@@ -26,6 +27,8 @@ struct RebuildItemDev {
     int32_t khkw;
     int32_t cols;          // inputs per group
     int32_t out_per_group;
+    int32_t in_mul;        // s_in holds reciprocals: multiply
+    int32_t pad;
 };
 
 struct RebuildBlock {
@@ -41,7 +44,7 @@ __device__ __forceinline__ float rebuild_one(float w, int64_t e, const RebuildIt
         const int r = (int)(e - o * it.row_len);
         const int i = r / it.khkw;
         const int ch = (int)(o / it.out_per_group) * it.cols + i;
-        w = w / it.s_in[ch];
+        w = it.in_mul ? w * it.s_in[ch] : w / it.s_in[ch];
     }
     return w;
 }
@@ -73,12 +76,11 @@ __global__ __launch_bounds__(kBlock) void rebuild_kernel(const RebuildItemDev* _
             }
             if (it.s_in) {
                 const float* sg = it.s_in + (int64_t)(o / it.out_per_group) * it.cols;
-                if (it.khkw == 1) {
-                    x[0] = x[0] / sg[r]; x[1] = x[1] / sg[r + 1]; x[2] = x[2] / sg[r + 2]; x[3] = x[3] / sg[r + 3];
-                } else {
-                    x[0] = x[0] / sg[r / it.khkw]; x[1] = x[1] / sg[(r + 1) / it.khkw];
-                    x[2] = x[2] / sg[(r + 2) / it.khkw]; x[3] = x[3] / sg[(r + 3) / it.khkw];
-                }
+                float f[4];
+                if (it.khkw == 1) { f[0] = sg[r]; f[1] = sg[r + 1]; f[2] = sg[r + 2]; f[3] = sg[r + 3]; }
+                else { f[0] = sg[r / it.khkw]; f[1] = sg[(r + 1) / it.khkw]; f[2] = sg[(r + 2) / it.khkw]; f[3] = sg[(r + 3) / it.khkw]; }
+                if (it.in_mul) { x[0] = x[0] * f[0]; x[1] = x[1] * f[1]; x[2] = x[2] * f[2]; x[3] = x[3] * f[3]; }
+                else { x[0] = x[0] / f[0]; x[1] = x[1] / f[1]; x[2] = x[2] / f[2]; x[3] = x[3] / f[3]; }
             }
             *(fvec4*)(it.dst + e0[k]) = x;
         }
@@ -115,6 +117,7 @@ int dfq_rebuild_plan_create(const dfq_rebuild_item* items, int32_t n_items, dfq_
         d.src = a.src; d.dst = a.dst; d.s_out = a.s_out; d.s_in = a.s_in;
         d.n = (int64_t)a.rows * row_len;
         d.row_len = (int32_t)row_len; d.khkw = a.khkw; d.cols = a.cols; d.out_per_group = a.rows / a.groups;
+        d.in_mul = a.in_reciprocal ? 1 : 0; d.pad = 0;
         for (int64_t f = 0; f < d.n; f += kSpan) blocks.push_back(RebuildBlock{i, 0, f});
         total += d.n;
     }

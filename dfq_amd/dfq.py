@@ -271,6 +271,106 @@ def build_le_plan(graph, relations, targ_type, stage=None):
 
 
 # ------------------------------------------------------------------------------------------------
+# opt-in extension: lazy-scale equalisation (csrc/dfq_le_lazy.hip)
+# ------------------------------------------------------------------------------------------------
+class LazyLEPlan:
+    """The sweeps of dfq.py:83-101 with a GIVEN sweep count per network, from the pristine weights and the cumulative scale
+    vectors: a sweep only reads (4 B per paired element), the tensors are written once at the end.  Within 1e-5 of the
+    sequentially rescaled result of the same number of sweeps, not bit-identical to it (the default engines are)."""
+
+    def __init__(self, items, targ_type, stage=None):
+        """items: list of (graph, relations), one per network (as for ``build_le_plan_batch``)."""
+        self.stage = stage or _ffi.Stage()
+        self._keep = []
+        entries, rels, layer_net = [], [], []
+        self.scale_cum = []
+        for net, (graph, relations) in enumerate(items):
+            keys = [k for k in graph if type(graph[k]) in targ_type]
+            base = len(entries)
+            index = {k: base + i for i, k in enumerate(keys)}
+            for rr in relations:                                  # dfq.py:91-92
+                _ensure_bias(graph[rr.get_idxs()[0]])
+            for k in keys:
+                e, keep = _layer_entry(self.stage, graph[k].weight, graph[k].bias, getattr(graph[k], 'groups', 1))
+                entries.append(e)
+                self._keep.append(keep)
+            layer_net += [net] * len(keys)
+            for rr in relations:
+                kf, ks, kb = rr.get_idxs()
+                if rr.S is None:
+                    rr.S = torch.ones(graph[kf].weight.size(0), dtype=torch.float32, device=self.stage.device)
+                bn = graph[kb] if kb is not None else None
+                bw = self.stage.bind(getattr(bn, 'fake_weight', None))
+                bb = self.stage.bind(getattr(bn, 'fake_bias', None))
+                sc = self.stage.bind(rr.S)
+                self._keep.append((bw, bb, sc))
+                self.scale_cum.append(sc)
+                rels.append(_ffi.DfqRelation(index[kf], index[ks], bw.data_ptr() if bw is not None else None,
+                                             bb.data_ptr() if bb is not None else None, sc.data_ptr()))
+        self.n_nets = len(items)
+        larr = (_ffi.DfqLayer * len(entries))(*entries)
+        rarr = (_ffi.DfqRelation * max(1, len(rels)))(*rels)
+        narr = (ctypes.c_int32 * len(entries))(*layer_net)
+        self._plan = ctypes.c_void_p()
+        _ffi.check(_ffi.lib().dfq_le_lazy_plan_create(larr, len(entries), narr, self.n_nets, rarr, len(rels), ctypes.byref(self._plan)))
+
+    @property
+    def levels(self):
+        return _ffi.lib().dfq_le_lazy_plan_levels(self._plan)
+
+    @property
+    def paired_elements(self):
+        """elements the FIRST sweep reads (4 B each): every paired layer once per role"""
+        return _ffi.lib().dfq_le_lazy_plan_paired_elements(self._plan)
+
+    @property
+    def sweep_elements(self):
+        """elements every later sweep reads (4 B each): the non-depthwise layers in the interior of a chain, once per role
+        (the extrema of the other passes do not change from sweep to sweep and are rescaled, not recomputed)"""
+        return _ffi.lib().dfq_le_lazy_plan_sweep_elements(self._plan)
+
+    @property
+    def weight_elements(self):
+        """elements of the paired tensors, written once at the end (8 B each)"""
+        return _ffi.lib().dfq_le_lazy_plan_weight_elements(self._plan)
+
+    def run(self, sweeps, s_range=(1e-8, 1e8), signed=False, eps=0):
+        """Enqueue ``sweeps`` sweeps (an int, or one count per network) and the final materialisation (asynchronous)."""
+        counts = [int(sweeps)] * self.n_nets if isinstance(sweeps, int) else [int(v) for v in sweeps]
+        assert len(counts) == self.n_nets
+        cfg = _le_config(s_range, -1.0, 10 ** 9, signed, eps, None)
+        arr = (ctypes.c_int32 * self.n_nets)(*counts)
+        _ffi.check(_ffi.lib().dfq_le_lazy_run(self._plan, ctypes.byref(cfg), arr, _ffi.stream_arg()))
+
+    def close(self):
+        if self._plan:
+            _ffi.lib().dfq_le_lazy_plan_destroy(self._plan)
+            self._plan = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def lazy_cross_layer_equalization(graph, relations, targ_type, sweeps, s_range=[1e-8, 1e8], signed=False, eps=0):
+    """``cross_layer_equalization`` for a GIVEN number of sweeps in the lazy-scale formulation (see LazyLEPlan): same in-place
+    update of the caller's tensors and of ``Relation.S``, within 1e-5 of what the sequential loop produces in ``sweeps`` sweeps."""
+    with torch.no_grad():
+        stage = _ffi.Stage()
+        plan = LazyLEPlan([(graph, relations)], targ_type, stage=stage)
+        try:
+            plan.run(int(sweeps), s_range=s_range, signed=signed, eps=eps)
+            _ffi.synchronize()
+        finally:
+            plan.close()
+        stage.writeback()
+        for rr, sc in zip(relations, plan.scale_cum):
+            rr.S = stage.out_like(graph[rr.get_idxs()[0]].weight, sc)
+
+
+# ------------------------------------------------------------------------------------------------
 # dfq.py:8-25
 # ------------------------------------------------------------------------------------------------
 _REDUCTIONS = {None: 0, 'none': 0, 'sum': 1, 'mean': 2, 'channel': 3, 'spatial': 4}

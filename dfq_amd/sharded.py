@@ -99,6 +99,7 @@ class _RebuildPlan:
             a.cols = int(src.shape[1]) if src.dim() > 1 else 1
             a.khkw = _khkw(src)
             a.groups = int(groups)
+            a.in_reciprocal = 0
         self._plan = ctypes.c_void_p()
         _ffi.check(_ffi.lib().dfq_rebuild_plan_create(arr, len(items), ctypes.byref(self._plan)))
 

@@ -249,6 +249,30 @@ int dfq_quant_plan_measure(dfq_quant_plan* plan, void* stream);
 const float* dfq_quant_plan_minmax(const dfq_quant_plan* plan);
 
 /* ------------------------------------------------------------------------------------------
+ * Lazy-scale equalisation (opt-in extension): the sweeps of dfq.py:83-101 with a GIVEN sweep count,
+ * computed from the pristine weights and the cumulative scale vectors of utils/relation.py:20-24 -- a sweep only READS
+ * (4 B per element of the layers it still has to look at, see the byte accounting below), the weights / biases / BN proxies / scale_cum vectors of the relations are written ONCE at the end
+ * (W = diag(S_out) W0 diag(1/S_in); 8 B per weight).  Result: within 1e-5 (relative) of the sequentially rescaled tensors of
+ * the reference loop run for the same number of sweeps -- NOT bit-identical to them (the default engines are).  The
+ * data-dependent exit test of dfq.py:105-115 is not available in this formulation: the caller passes the count (e.g. the one
+ * dfq_le_run reports for the same network).  Same layer / relation tables as dfq_le_plan_create_batch.  Asynchronous run.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct dfq_le_lazy_plan dfq_le_lazy_plan;   /* opaque */
+int dfq_le_lazy_plan_create(const dfq_layer* layers, int32_t n_layers, const int32_t* layer_net, int32_t n_nets,
+                            const dfq_relation* relations, int32_t n_relations, dfq_le_lazy_plan** out_plan);
+void dfq_le_lazy_plan_destroy(dfq_le_lazy_plan* plan);
+/* cfg: s_range / eps / signed_range as for dfq_le_run (the convergence fields are ignored); sweeps_per_net[n] >= 0 */
+int dfq_le_lazy_run(dfq_le_lazy_plan* plan, const dfq_le_config* cfg, const int32_t* sweeps_per_net, void* stream);
+/* byte accounting: passes whose element factors never change run once (chain starts / ends, depthwise layers: their extrema
+ * are kept and rescaled per sweep by the solve launch), so the FIRST sweep reads 4 B x paired_elements, every later sweep
+ * 4 B x sweep_elements (the non-depthwise layers in the interior of a chain, once per role), and the final materialisation
+ * moves 8 B x weight_elements */
+int32_t dfq_le_lazy_plan_levels(const dfq_le_lazy_plan* plan);
+int64_t dfq_le_lazy_plan_paired_elements(const dfq_le_lazy_plan* plan);
+int64_t dfq_le_lazy_plan_sweep_elements(const dfq_le_lazy_plan* plan);
+int64_t dfq_le_lazy_plan_weight_elements(const dfq_le_lazy_plan* plan);
+
+/* ------------------------------------------------------------------------------------------
  * Bias correction -- dfq.py:173-293 (bias_correction), :8-25 (_quantize_error)
  * ---------------------------------------------------------------------------------------- */
 typedef struct dfq_bc_plan dfq_bc_plan;
@@ -341,6 +365,8 @@ typedef struct dfq_rebuild_item {
     int32_t cols;          /* I / groups                                                  */
     int32_t khkw;
     int32_t groups;
+    int32_t in_reciprocal; /* 0: divide by s_in[ch]; 1: s_in holds reciprocals: multiply  */
+    int32_t reserved;
 } dfq_rebuild_item;
 typedef struct dfq_rebuild_plan dfq_rebuild_plan;   /* opaque */
 int dfq_rebuild_plan_create(const dfq_rebuild_item* items, int32_t n_items, dfq_rebuild_plan** out_plan);

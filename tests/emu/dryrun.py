@@ -38,7 +38,7 @@ bench._stream_ctx = lambda s: contextlib.nullcontext()
 world = int(os.environ.get('WORLD_SIZE', '1'))
 sys.argv = ['bench.py', '--net', 'tiny_mobile', '--steps', '2', '--warmup', '1', '--cpu-seconds', '0.2', '--streams', '1', '--batch', '2',
             '--gpus', str(world), '--others', 'tiny_res,tiny_mobile:3', '--act-shape', '4,3,8,8', '--sharded', 'tiny_mobile:4',
-            '--sharded-steps', '2', '--distill', 'tiny_mobile:2:4,3,16,16', '--pcie', 'tiny_mobile']
+            '--sharded-steps', '2', '--distill', 'tiny_mobile:2:4,3,16,16', '--pcie', 'tiny_mobile', '--lazy-steps', '1']
 bench._BACKEND = 'gloo'            # the process group of bench.py over gloo (tests/test_bench_multirank.py)
 if world > 1:
     bench.main()

@@ -79,4 +79,7 @@ def test_bench_line_contract_single_rank():
     assert dr['batches'] == 2 and dr['quant_measures'] > 0 and dr['ms_per_batch'] > 0
     assert dr['quant_measure_bytes_per_batch'] == 12 * dr['elements_per_batch'] and dr['elements_per_batch'] > 0
     assert d['pcie_inclusive_ms'] == d['pcie_inclusive']['le_plus_bc_ms'] > 0
+    lz = d['lazy_scale']            # the opt-in formulation: its own value and its own roofline entry, never `value`
+    assert lz['sweeps'] == d['config']['le_sweeps'] and lz['sweeps_given'] and d['value_lazy_scale'] == lz['value'] > 0
+    assert abs(lz['roofline']['frac'] - lz['roofline']['achieved'] / lz['roofline']['peak']) < 1e-12
     assert 'reference' in c          # the committed reference-CPU record (null for nets it was not measured on)

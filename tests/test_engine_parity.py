@@ -916,3 +916,63 @@ def test_resident_engine_in_chunks(engine):
     assert res[0][0] == res[1][0]
     for k in res[0][1]:
         assert_bitexact(res[0][1][k], res[1][1][k], k)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# opt-in lazy-scale equalisation: read-only sweeps from W0 and the cumulative scales, one final write
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('name,seed,suffix,sweeps', [('tiny_mobile', 0, '', 7), ('tiny_res', 0, '', 3), ('tiny_cat', 0, '', 9),
+                                                     ('tiny_mobile', 2, '_signed', 6), ('tiny_cat', 3, '_abs', 5)])
+def test_lazy_scale_equalization_against_oracle(engine, name, seed, suffix, sweeps):
+    """Same number of sweeps as the sequential loop -> every tensor and every cumulative scale within 1e-5 of the oracle's
+    (the contract of BASELINE.json; the default engines are bit-exact, this formulation rounds its cumulative products
+    differently).  Grouped / depthwise / signed / cat geometries of the fixtures."""
+    gold = net_fixture(name, seed, suffix)
+    model, graph, bottoms = _build(name, seed, gold, engine)
+    lt.merge_batchnorm(model, graph, bottoms, TARG)
+    spec = graphspec.from_torch(graph, bottoms, TARG)
+    rels = rel.create_relation(graph, bottoms, TARG)
+    signed = suffix == '_signed'
+    _, S_ref = orc.cross_layer_equalization(spec, orc.create_relation(spec), max_sweeps=sweeps, converge_thres=-1.0,
+                                            converge_count=10 ** 9, signed=signed)
+    dfq.lazy_cross_layer_equalization(graph, rels, TARG, sweeps, signed=signed)
+    worst = 0.0
+    for i, k in enumerate(graph):
+        n = spec.nodes[k]
+        m = graph[k]
+        if n.kind == 'targ':
+            worst = max(worst, assert_close(npy(m.weight), n.weight, 'lazy w {}'.format(k)))
+            if n.bias is not None and m.bias is not None:
+                assert_close(npy(m.bias), n.bias, 'lazy b {}'.format(k))
+        elif n.kind == 'bn' and n.fake_weight is not None:
+            assert_close(npy(m.fake_weight), n.fake_weight, 'lazy gamma~ {}'.format(k))
+            assert_close(npy(m.fake_bias), n.fake_bias, 'lazy beta~ {}'.format(k))
+    for rr, s in zip(rels, S_ref):
+        assert_close(npy(rr.get_scale_vec()), s, 'lazy S')
+    assert worst <= 1e-5
+
+
+def test_lazy_scale_batch_with_different_sweep_counts(engine):
+    """Two networks in one plan, each with its own sweep count: each equals its own single-network run bit for bit."""
+    outs = []
+    for mode in ('batched', 'single'):
+        nets = []
+        for seed, sweeps in ((0, 3), (1, 6)):
+            model, graph, bottoms = synthetic.build('tiny_mobile', seed=seed)
+            model.to(engine.device)
+            lt.merge_batchnorm(model, graph, bottoms, TARG)
+            nets.append((graph, rel.create_relation(graph, bottoms, TARG), sweeps))
+        if mode == 'batched':
+            plan = dfq.LazyLEPlan([(g, r) for g, r, _ in nets], TARG)
+            assert plan.paired_elements > 0 and plan.weight_elements > 0 and plan.levels >= 2
+            plan.run([s for _, _, s in nets])
+            from dfq_amd import _ffi
+            _ffi.synchronize()
+            plan.close()
+        else:
+            for g, r, s in nets:
+                dfq.lazy_cross_layer_equalization(g, r, TARG, s)
+        outs.append([snapshot(g) for g, _, _ in nets])
+    for a, b in zip(outs[0], outs[1]):
+        for k in a:
+            assert_bitexact(a[k], b[k], 'lazy batched vs single: ' + k)

@@ -333,3 +333,34 @@ def test_bias_correction_stage_wise_against_reference_at_full_size(engine, name,
             seen += 1
     assert seen == len([k for k in gold.files if k.startswith('bc.')])
     assert worst <= 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name,pin,sweeps,n_rel', FULL)
+def test_lazy_scale_engine_at_full_size(name, pin, sweeps, n_rel):
+    """The opt-in lazy-scale formulation at BASELINE size, run for the sweep count the reference's loop
+    needs: every tensor within 1e-5 of the default (bit-exact-to-the-oracle) engine's result and of the reference's records."""
+    from dfq_amd import dfq
+    from dfq_amd.utils import layer_transform as lt
+    from dfq_amd.utils import relation as rel
+    dev = torch.device('cuda', 0)
+    gold = np.load(os.path.join(GOLD, 'full_{}_s0.npz'.format(name)))
+    out = []
+    for lazy in (False, True):
+        model, graph, bottoms = synthetic.build(name, seed=0)
+        model.to(dev)
+        lt.merge_batchnorm(model, graph, bottoms, TARG)
+        rels = rel.create_relation(graph, bottoms, TARG)
+        assert len(rels) == n_rel
+        if lazy:
+            dfq.lazy_cross_layer_equalization(graph, rels, TARG, sweeps)
+        else:
+            dfq.cross_layer_equalization(graph, rels, TARG, max_sweeps=sweeps, converge_thres=-1.0, converge_count=10 ** 9)
+        out.append((snapshot(graph), [npy(r.get_scale_vec()) for r in rels]))
+    worst = 0.0
+    for k in out[0][0]:
+        worst = max(worst, assert_close(out[1][0][k], out[0][0][k], 'lazy vs default engine: {} {}'.format(name, k)))
+    for a, b in zip(out[1][1], out[0][1]):
+        worst = max(worst, assert_close(a, b, 'lazy vs default engine: S'))
+    _check_stage(out[1][0], gold, 'le', 'lazy engine vs reference ' + name)
+    print('{}: lazy vs default engine, worst relative deviation {:.2e}'.format(name, worst))
