@@ -692,6 +692,14 @@ def main():
         },
     }
 
+    # host-inclusive rate: a calibration service that builds a plan per batch pays the table building on the host (Python: one
+    # structure template per architecture, device addresses gathered per network) before it can enqueue -- no overlap assumed
+    pb = out['config']['plan_build_ms_per_unit']
+    out['host_inclusive'] = {'plan_build_ms_per_unit': pb, 'ms_per_step_with_plan_build': ms_per_step + pb,
+                             'value': n_w * batch * world / ((ms_per_step + pb) * 1e-3), 'unit': 'weights/s',
+                             'what': 'tables of the two plans built on the host for every batch, then the timed step; excludes fx tracing, '
+                                     'BN folding and relation pairing (once per architecture / per network, before calibration)'}
+
     # ---- one network alone: the latency a caller of the drop-in API sees (first-class, with its own roofline fraction) ----
     if rank == 0:
         with _stream_ctx(streams[0]):
