@@ -160,7 +160,7 @@ def reference_cpu_record(net):
 def _pmc_traffic(net, batch):
     """HBM bytes per launch of le_level_kernel from the committed PMC summary of a run with exactly this batch
     (rocprofv3 --pmc cannot run inside this process), else null."""
-    for name in ('r02_pmc_summary.json', 'r01_pmc_summary.json'):
+    for name in ('r03_pmc_summary.json', 'r02_pmc_summary.json', 'r01_pmc_summary.json'):
         path = os.path.join(ROOT, 'profiles', name)
         if net != 'mobilenet_v2' or not os.path.exists(path):
             continue

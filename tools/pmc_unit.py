@@ -33,4 +33,10 @@ for _ in range(args.restarts - 1):
 le.enqueue(args.sweeps, restart=True, max_sweeps=args.sweeps, converge_thres=-1.0, converge_count=10 ** 9)
 bc.run()
 torch.cuda.synchronize()
+if args.batch > 1:      # the opt-in lazy-scale engine on a second set of the same networks (its kernels' counters: lz_stats_kernel, rebuild_kernel)
+    import copy
+    nets = [copy.deepcopy(p) for p in protos]
+    lz = dfq.LazyLEPlan([(g, r) for (_, g, _, r) in nets], bench.TARG)
+    lz.run(args.sweeps)
+    torch.cuda.synchronize()
 print('pmc_unit: batch', args.batch, 'sweeps', le.query()['sweeps'], 'workgroups per launch', le.level_info(0)['workgroups'])

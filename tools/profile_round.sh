@@ -7,14 +7,14 @@
 #      single-network latency probe (le_resident_kernel), the other configs and the activation-range kernels;
 #   3. FETCH_SIZE / WRITE_SIZE counter passes (separate --pmc runs) at the bench's own batch size + their digest.
 # Every step runs under `timeout`; nothing here reads stdin.
-R=${ROUND:-r02}
+R=${ROUND:-r03}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 B=${PROFILE_BATCH:-32}
 if [ -z "$SKIP_BENCH" ]; then
-timeout 400 python bench.py > gpurun_out/${R}_bench_default.json 2> gpurun_out/${R}_bench_default.err < /dev/null
+timeout 600 python bench.py > gpurun_out/${R}_bench_default.json 2> gpurun_out/${R}_bench_default.err < /dev/null
 fi
 rm -rf gpurun_out/prof_$R
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$R -o $R -- python bench.py --streams 1 --steps 6 --warmup 2 --cpu-seconds 0 --sharded "" > gpurun_out/${R}_bench_under_rocprof.json 2> gpurun_out/${R}_bench_under_rocprof.err < /dev/null
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$R -o $R -- python bench.py --streams 1 --steps 6 --warmup 2 --cpu-seconds 0 --sharded "" --distill "" --pcie "" > gpurun_out/${R}_bench_under_rocprof.json 2> gpurun_out/${R}_bench_under_rocprof.err < /dev/null
 echo "rocprof rc=$?"
 S=$(find gpurun_out/prof_$R -name "*kernel_stats.csv" | head -1)
 T=$(find gpurun_out/prof_$R -name "*kernel_trace.csv" | head -1)
