@@ -325,7 +325,7 @@ def activation_range_kernels(shape, dev):
     rows.append({'kernel': 'fake_quant_kernel', 'bytes': 8 * n, 'us': ms * 1e3})
     m = q.QuantMeasure(update_stat=True).to(dev).eval()
     ms = timed(lambda: m(x))
-    rows.append({'kernel': 'QuantMeasure.forward (update_stat): 3 launches', 'bytes': 12 * n, 'us': ms * 1e3})
+    rows.append({'kernel': 'QuantMeasure.forward (update_stat): 2 launches (per-sample extrema; mean + running range + quantise)', 'bytes': 12 * n, 'us': ms * 1e3})
     proto = prepare('mobilenet_v2' if n > 10 ** 6 else 'tiny_mobile', 0, dev)
     n_w = sum(m_.weight.numel() + (m_.bias.numel() if m_.bias is not None else 0) for m_ in proto[1].values() if type(m_) in TARG)
     import ctypes

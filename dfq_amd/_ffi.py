@@ -104,6 +104,7 @@ SIGNATURES = {
     'dfq_fake_quant': (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_double, c_double,
                                  c_void_p, c_void_p, c_void_p]),
     'dfq_sample_minmax_mean': (c_int32, [c_void_p, c_int32, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'dfq_quant_measure': (c_int32, [c_void_p, c_void_p, c_int32, c_int64, c_int32, c_void_p, c_void_p, c_int32, c_void_p]),
     'dfq_quant_plan_create': (c_int32, [POINTER(DfqSegment), c_int32, POINTER(c_void_p)]),
     'dfq_quant_plan_destroy': (None, [c_void_p]),
     'dfq_quant_plan_run': (c_int32, [c_void_p, c_void_p]),

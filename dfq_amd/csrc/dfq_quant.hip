@@ -236,10 +236,8 @@ __global__ __launch_bounds__(kBlock) void sample_minmax_kernel(const float* __re
     block_publish_minmax(mn, mx, slots + 2 * smp);
 }
 
-// mean over samples (float64 accumulation, rounded once) + running_min/max update (quantize.py:106-107)
-__global__ __launch_bounds__(kBlock) void sample_mean_kernel(const uint32_t* __restrict__ slots, int n_samples,
-                                                             float* __restrict__ out2, float* __restrict__ running2) {
-    __shared__ double sh[kBlock / kWave];
+// mean over samples of the per-sample extrema (float64 accumulation in a fixed order, rounded once); valid in every thread
+__device__ __forceinline__ void sample_mean(const uint32_t* __restrict__ slots, int n_samples, double* sh, float& mn, float& mx) {
     double smn = 0.0, smx = 0.0;
     for (int i = threadIdx.x; i < n_samples; i += kBlock) {
         smn += (double)slot_min(slots[2 * i + 0]);
@@ -247,10 +245,18 @@ __global__ __launch_bounds__(kBlock) void sample_mean_kernel(const uint32_t* __r
     }
     smn = block_sum(smn, sh);
     smx = block_sum(smx, sh);
+    // one sample: the mean of one element is the element itself
+    mn = (n_samples == 1) ? slot_min(slots[0]) : (float)(smn / (double)n_samples);
+    mx = (n_samples == 1) ? slot_max(slots[1]) : (float)(smx / (double)n_samples);
+}
+
+// mean over samples + running_min/max update (quantize.py:106-107)
+__global__ __launch_bounds__(kBlock) void sample_mean_kernel(const uint32_t* __restrict__ slots, int n_samples,
+                                                             float* __restrict__ out2, float* __restrict__ running2) {
+    __shared__ double sh[kBlock / kWave];
+    float mn, mx;
+    sample_mean(slots, n_samples, sh, mn, mx);
     if (threadIdx.x == 0) {
-        // one sample: the mean of one element is the element itself
-        const float mn = (n_samples == 1) ? slot_min(slots[0]) : (float)(smn / (double)n_samples);
-        const float mx = (n_samples == 1) ? slot_max(slots[1]) : (float)(smx / (double)n_samples);
         out2[0] = mn;
         out2[1] = mx;
         if (running2) {
@@ -258,6 +264,50 @@ __global__ __launch_bounds__(kBlock) void sample_mean_kernel(const uint32_t* __r
             if (mn < running2[0]) running2[0] = mn;
             if (mx > running2[1]) running2[1] = mx;
         }
+    }
+}
+
+// QuantMeasure.forward with update_stat (utils/quantize.py:102-119) behind the per-sample extrema: EVERY workgroup forms the
+// mean of the extrema (the same fixed-order float64 sums -> the same two numbers), folds it into the running range
+// (quantize.py:106-107; min(min(r, m), m) == min(r, m), so it does not matter whether a workgroup reads the running pair
+// before or after workgroup 0 stored the folded one) and quantises its share of x with that range -- the separate one-
+// workgroup launch for the mean and the memset before the extrema launch are gone: workgroup 0 also clears the slots the
+// NEXT call accumulates into (the caller alternates between two slot buffers).
+__global__ __launch_bounds__(kBlock) void measured_fake_quant_kernel(const float* x, float* y, int64_t n, const uint32_t* __restrict__ slots,
+                                                                     int n_samples, float* running2, uint32_t* __restrict__ slots_next,
+                                                                     int num_bits) {
+    __shared__ double sh[kBlock / kWave];
+    float mn, mx;
+    sample_mean(slots, n_samples, sh, mn, mx);
+    const float r0 = running2[0], r1 = running2[1];
+    const float lo = (mn < r0) ? mn : r0;            // Python min(running_min, v): keeps running_min unless v < it (NaN keeps it)
+    const float hi = (mx > r1) ? mx : r1;
+    if (blockIdx.x == 0) {
+        if (threadIdx.x == 0) { running2[0] = lo; running2[1] = hi; }
+        for (int i = threadIdx.x; i < 2 * n_samples; i += kBlock) slots_next[i] = 0u;
+    }
+    const QParams p = qparams_double((double)lo, (double)hi, num_bits, 0);
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    if (((((uintptr_t)x) | ((uintptr_t)y)) & 15u) == 0) {
+        const int64_t n4 = n >> 2;
+        for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += stride) {
+            const fvec4 v = (kQuantNt & 1) ? DFQ_NT_LOAD((const fvec4*)(x + 4 * i)) : *(const fvec4*)(x + 4 * i);
+            fvec4 r;
+            float code;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) r[k] = fake_quant_one(v[k], p, &code);
+            if (kQuantNt & 2) DFQ_NT_STORE(r, (fvec4*)(y + 4 * i));
+            else *(fvec4*)(y + 4 * i) = r;
+        }
+        for (int64_t i = 4 * n4 + (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+            float code;
+            y[i] = fake_quant_one(x[i], p, &code);
+        }
+        return;
+    }
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        float code;
+        y[i] = fake_quant_one(x[i], p, &code);
     }
 }
 
@@ -379,6 +429,28 @@ int dfq_sample_minmax_mean(const float* x, int32_t n_samples, int64_t sample_len
     DFQ_CHECK_LAUNCH();
     hipLaunchKernelGGL(sample_mean_kernel, dim3(1), dim3(kBlock), 0, st, (const uint32_t*)scratch, (int)n_samples,
                        out2, running2);
+    DFQ_CHECK_LAUNCH();
+    return DFQ_OK;
+}
+
+int dfq_quant_measure(const float* x, float* y, int32_t n_samples, int64_t sample_len, int32_t num_bits, float* running2,
+                      uint32_t* scratch, int32_t parity, void* stream) {
+    if (!x || !y || !running2 || !scratch || n_samples <= 0 || sample_len <= 0 || (parity != 0 && parity != 1))
+        return fail_arg("dfq_quant_measure: bad argument");
+    if (n_samples > 65535) return fail_arg("dfq_quant_measure: n_samples=%d > 65535", n_samples);
+    if (num_bits < 1 || num_bits > 30) return fail_arg("dfq_quant_measure: num_bits=%d out of range", num_bits);
+    hipStream_t st = as_stream(stream);
+    uint32_t* cur = scratch + (size_t)parity * 2 * n_samples;
+    uint32_t* nxt = scratch + (size_t)(parity ^ 1) * 2 * n_samples;
+    int64_t gx = std::max<int64_t>(1, 2048 / n_samples);
+    int64_t span = (sample_len + gx - 1) / gx;
+    span = std::max<int64_t>(4096, (span + 1023) / 1024 * 1024);
+    gx = (sample_len + span - 1) / span;
+    hipLaunchKernelGGL(sample_minmax_kernel, dim3((unsigned)gx, n_samples), dim3(kBlock), 0, st, x, sample_len, span, cur);
+    DFQ_CHECK_LAUNCH();
+    const int64_t n = (int64_t)n_samples * sample_len;
+    hipLaunchKernelGGL(measured_fake_quant_kernel, dim3(grid_for(n, kBlock * 8, 4096)), dim3(kBlock), 0, st, x, y, n,
+                       (const uint32_t*)cur, (int)n_samples, running2, nxt, (int)num_bits);
     DFQ_CHECK_LAUNCH();
     return DFQ_OK;
 }

@@ -174,6 +174,19 @@ class QuantMeasure(nn.Module):
             n = x.shape[0]
             running = self._packed_range(stage.device)
             shadow = running is None
+            if self.update_stat and not self.training and not shadow and x.numel() > 0:
+                # the common calibration path (improve_dfq.py:280-297): two launches, no temporaries besides the output
+                sc = getattr(self, '_qm_scratch', None)
+                if sc is None or sc.numel() != 4 * n or sc.device != x.device:
+                    sc = torch.zeros(4 * n, dtype=torch.int32, device=x.device)
+                    self._qm_scratch, self._qm_parity = sc, 0
+                out = stage.new(x.shape)
+                _ffi.check(_ffi.lib().dfq_quant_measure(_ffi.ptr(x), _ffi.ptr(out), n, x.numel() // n, int(self.num_bits),
+                                                        _ffi.ptr(running), _ffi.ptr(sc), self._qm_parity, _ffi.stream_arg()))
+                self._qm_parity ^= 1
+                if input.requires_grad:
+                    return input + (out - input).detach()
+                return out
             if shadow:
                 running = torch.cat([stage.bind(self.running_min).reshape(1), stage.bind(self.running_max).reshape(1)])
             if self.update_stat:

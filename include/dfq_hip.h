@@ -222,6 +222,14 @@ int dfq_fake_quant(const float* x, float* y, int64_t n, int32_t num_bits, int32_
  * running_max = max(running_max, out2[1]).  `scratch` is a device uint32[2*n_samples]. */
 int dfq_sample_minmax_mean(const float* x, int32_t n_samples, int64_t sample_len, float* out2,
                            float* running2, uint32_t* scratch, void* stream);
+/* QuantMeasure.forward with update_stat (utils/quantize.py:102-119; improve_dfq.py:280-297 runs it for every activation of
+ * every distilled batch) in TWO launches: the per-sample extrema, then one kernel in which every workgroup forms their mean
+ * (as dfq_sample_minmax_mean does), folds it into running2 = (running_min, running_max) (quantize.py:106-107) and quantises
+ * x -> y with the folded range (float64 recipe, asymmetric).  scratch: 4 * n_samples uint32 owned by the caller, ZERO before the
+ * first call; parity alternates 0, 1, 0, ... from call to call on the same scratch (each call clears the half the next one
+ * accumulates into).  Same numbers as dfq_sample_minmax_mean(running2) + dfq_fake_quant(range_mode 1). */
+int dfq_quant_measure(const float* x, float* y, int32_t n_samples, int64_t sample_len, int32_t num_bits, float* running2,
+                      uint32_t* scratch, int32_t parity, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Multi-layer weight quantisation -- utils/layer_transform.py:279-296 (quantize_targ_layer)
