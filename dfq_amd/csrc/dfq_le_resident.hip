@@ -77,6 +77,8 @@ struct ResTile {                     // one workgroup
     int32_t layout;                  // kLayGeneral / kLayFixed / kLayShort
     int32_t relax_r;                 // 1: every row of this layer lives in ONE tile -> its row statistics have a single producer
     int32_t relax_c;                 // 1: every input channel of this layer lives in ONE tile -> likewise for its column statistics
+    int32_t slot;                    // logical index of the tile (partial-sum slot, reducer id): the table itself is in LAUNCH order
+    int32_t pad3;
 };
 
 struct ResRel {
@@ -706,11 +708,11 @@ __device__ __forceinline__ void advance_state(const ResArgs& a, LoopState& st, d
 // the float64} (one copy per XCD: every tile of the launch polls it); everybody else reads the two words until both carry
 // k + 1 (normally at the first look: the publication is most of a sweep old).  Returns false when a wait was abandoned.
 __device__ __forceinline__ bool verdict(const ResArgs& a, int k, LoopState& st, const ResLayerDiff& mine, double* sh_dec, int* sh_flag, int* sh_bad,
-                                        double* sh_val, long kResSpinLimit) {
+                                        double* sh_val, long kResSpinLimit, int slot) {
     const auto& c = cold(a);
     const u64 want = (u64)(k + 1);
     double diff_tmp;
-    if ((int)blockIdx.x == c.reducer) {
+    if (slot == c.reducer) {
         diff_tmp = reduce_diff(a, k, mine, sh_dec, sh_dec + kResMaxTiles, sh_bad, kResSpinLimit);
         if (*sh_bad) return false;                                   // (read behind reduce_diff's barriers)
         if (threadIdx.x < 8) {
@@ -964,7 +966,7 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
         __syncthreads();                                          // sh_s complete; sh_row / sh_col free
         if (*sh_bad) { failed = true; break; }                    // a statistics word of phase 2 never showed this sweep's tag
         if (k > 0) {
-            if (!verdict(a, k - 1, st, my_layer, sh_dec, sh_flag, sh_bad, sh_val, kResSpinLimit)) { failed = true; break; }
+            if (!verdict(a, k - 1, st, my_layer, sh_dec, sh_flag, sh_bad, sh_val, kResSpinLimit, T.slot)) { failed = true; break; }
             if (st.done) break;                                   // sweep k-1 was the last one: sweep k is dropped
         }
         res_stamp<kTrace>(a, k, 6);
@@ -997,7 +999,7 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
             const double tsum = block_sum(acc, (double*)sh_col);     // sh_col is free again (statistics published)
             if (tid == 0) {
                 const auto& c = cold(a);            // two tagged words, no counter: the reducer reads them until they carry k + 1
-                u64* dst = (u64*)c.partials + ((int64_t)(k % 3) * c.n_tiles + blockIdx.x) * 2;
+                u64* dst = (u64*)c.partials + ((int64_t)(k % 3) * c.n_tiles + T.slot) * 2;
                 const u64 bits = (u64)__double_as_longlong(tsum), tg = (u64)(k + 1) << 32;
                 __hip_atomic_store(dst, tg | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(dst + 1, tg | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1043,14 +1045,14 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
             const double tsum = block_sum(acc, (double*)sh_col);     // sh_col is free again (statistics published)
             if (tid == 0) {
                 const auto& c = cold(a);            // two tagged words, no counter: the reducer reads them until they carry k + 1
-                u64* dst = (u64*)c.partials + ((int64_t)(k % 3) * c.n_tiles + blockIdx.x) * 2;
+                u64* dst = (u64*)c.partials + ((int64_t)(k % 3) * c.n_tiles + T.slot) * 2;
                 const u64 bits = (u64)__double_as_longlong(tsum), tg = (u64)(k + 1) << 32;
                 __hip_atomic_store(dst, tg | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(dst + 1, tg | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             res_stamp<kTrace>(a, k, 5);
             if (k > 0) {
-                if (!verdict(a, k - 1, st, my_layer, sh_dec, sh_flag, sh_bad, sh_val, kResSpinLimit)) { failed = true; break; }
+                if (!verdict(a, k - 1, st, my_layer, sh_dec, sh_flag, sh_bad, sh_val, kResSpinLimit, T.slot)) { failed = true; break; }
                 if (st.done) break;                               // sweep k-1 was the last one: sweep k is dropped
             }
         }
@@ -1071,7 +1073,7 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
             }
         }
         if (k + 1 >= cold(a).n_sweeps) {                          // the launch's last sweep: its verdict closes the state
-            if (!verdict(a, k, st, my_layer, sh_dec, sh_flag, sh_bad, sh_val, kResSpinLimit)) failed = true;
+            if (!verdict(a, k, st, my_layer, sh_dec, sh_flag, sh_bad, sh_val, kResSpinLimit, T.slot)) failed = true;
             break;
         }
     }
@@ -1090,7 +1092,7 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
             if (RB.b1) RB.b1[c] = o_b1[j];
         }
     }
-    if ((int)blockIdx.x == cold(a).reducer && tid == 0) {
+    if (T.slot == cold(a).reducer && tid == 0) {
         LeState* o = cold(a).state;
         o->diff = st.diff; o->last_diff_tmp = st.last_diff_tmp; o->count = st.count; o->sweeps = st.sweeps; o->done = st.done;
     }
@@ -1327,6 +1329,24 @@ LeResident* le_resident_create(const dfq_layer* layers, int n_layers, const dfq_
             if (pl_of[l] == T.layer) T.nt_self = tile_count[l];
             if (pl_of[l] >= 0 && pl_of[l] == T.a_layer) T.nt_a = tile_count[l];
             if (pl_of[l] >= 0 && pl_of[l] == T.b_layer) T.nt_b = tile_count[l];
+        }
+    }
+    // ---- launch order.  Workgroups are dispatched round-robin over the XCDs and then over the CUs, so workgroups b, b + 256 and
+    //      b + 512 share a CU -- and its instruction issue.  The tiles at the END of the longest chain are the ones whose phases
+    //      sit on the sweep's critical cycle: they go first (one per CU), the tiles of early layers, which mostly
+    //      wait for the verdict, fill the second and third slot.  DFQ_RES_ORDER=0 keeps layer order. ----
+    for (size_t i = 0; i < tiles.size(); ++i) tiles[i].slot = (int32_t)i;
+    {
+        const char* oe = getenv("DFQ_RES_ORDER");
+        if (!(oe && oe[0] == '0')) {
+            // depth of a paired layer in its chain (relations in list order: a second layer is one deeper than its first)
+            std::vector<int> depth(n_pl, 0);
+            for (int q = 0; q < n_relations; ++q)
+                depth[pl_of[relations[q].second]] = std::max(depth[pl_of[relations[q].second]], depth[pl_of[relations[q].first]] + 1);
+            std::stable_sort(tiles.begin(), tiles.end(), [&](const ResTile& x, const ResTile& y) {
+                if (depth[x.layer] != depth[y.layer]) return depth[x.layer] > depth[y.layer];
+                return x.slot < y.slot;
+            });
         }
     }
     LeResident* r = new LeResident();
