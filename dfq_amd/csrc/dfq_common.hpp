@@ -225,6 +225,38 @@ __device__ __forceinline__ float wave_max(float v) {
     wave_minmax(other, v);
     return v;
 }
+// Wave-wide min / max of FOUR independent (mn, mx) pairs at once.  Four full butterflies are 4 x 6 exchange steps; here the
+// first two steps each halve the number of pairs a lane still carries (lanes whose id differs in the step's bit keep
+// different pairs: v_permlane32_swap of pair j against pair j + 2, v_permlane16_swap of the two that are left, move exactly
+// the halves that have to meet), the last four are an ordinary butterfly on the one pair that remains: 2 + 1 + 4 = 7 steps'
+// worth of moves instead of 24.  Lane L ends with the result of pair s(L) = 2 * bit5(L) + bit4(L), the same in the sixteen
+// lanes of its row.  min / max are exact: bit-identical to four separate butterflies (the emulation below does exactly those).
+__device__ __forceinline__ int wave_minmax4_slot(int lane) { return ((lane >> 5) & 1) * 2 + ((lane >> 4) & 1); }
+__device__ __forceinline__ void wave_minmax4(const float (&mn)[4], const float (&mx)[4], float& rmn, float& rmx) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    float n2[2], x2[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {          // bit 5: lanes < 32 keep pairs 0, 1; lanes >= 32 pairs 2, 3
+        const auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(mn[j]), __float_as_uint(mn[j + 2]), false, false);
+        const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx[j]), __float_as_uint(mx[j + 2]), false, false);
+        n2[j] = vmin_raw(__uint_as_float(a[0]), __uint_as_float(a[1]));
+        x2[j] = vmax_raw(__uint_as_float(b[0]), __uint_as_float(b[1]));
+    }
+    // bit 4: even rows of 16 lanes keep pair 0 (of their half), odd rows pair 1
+    const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(n2[0]), __float_as_uint(n2[1]), false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(x2[0]), __float_as_uint(x2[1]), false, false);
+    float kn = vmin_raw(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    float kx = vmax_raw(__uint_as_float(b[0]), __uint_as_float(b[1]));
+    xor_lane_minmax<8>(kn, kx); xor_lane_minmax<4>(kn, kx); xor_lane_minmax<2>(kn, kx); xor_lane_minmax<1>(kn, kx);
+    rmn = kn; rmx = kx;
+#else
+    float an[4], ax[4];
+    for (int j = 0; j < 4; ++j) { an[j] = mn[j]; ax[j] = mx[j]; wave_minmax(an[j], ax[j]); }
+    const int s = wave_minmax4_slot((int)(threadIdx.x % kWave));
+    rmn = an[s]; rmx = ax[s];
+#endif
+}
+
 // v += lane (id ^ M)'s v, with the same register-file moves (both 32-bit halves travel the same way)
 template <int M>
 __device__ __forceinline__ void xor_lane_add(double& v) {

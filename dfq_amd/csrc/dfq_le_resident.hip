@@ -409,6 +409,36 @@ struct LayFixed {
         const int w = tcv < kWave ? tcv : kWave;                    // lanes of a wave that share a row
         float iv[4] = {1.0f, 1.0f, 1.0f, 1.0f};
         if (useA && one_group) inv4(T, G, sh_inv, 0, iv);
+        if (w == kWave) {
+            // a whole wave per row and slot: the rows of four slots are reduced TOGETHER (wave_minmax4: 7 instead of 24 butterfly
+            // steps' worth of moves -- a third of this pass's instructions)
+            const bool wave_on = (((int)threadIdx.x & ~(kWave - 1)) & (tcv - 1)) < (T.nc / 4);   // else: duplicates of the row's last vector only
+            for (int u0 = 0; u0 < n_used; u0 += 4) {
+                float mn4[4], mx4[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    mn4[j] = INFINITY; mx4[j] = -INFINITY;
+                    if (u0 + j < n_used) {                              // uniform
+                        int row = (u0 + j) * rps + rsub;
+                        row = row < T.nr ? row : T.nr - 1;
+                        if (useA && !one_group) inv4(T, G, sh_inv, row, iv);
+                        const float sr = useB ? sh_s[row] : 1.0f;
+                        const fvec4 xv = *(const fvec4*)(tile + ((u0 + j) * kBlock + (int)threadIdx.x) * 4);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const float y = (xv[k] * iv[k]) * sr;        // * 1.0f is exact
+                            mn4[j] = vmin_raw(mn4[j], y); mx4[j] = vmax_raw(mx4[j], y);
+                        }
+                    }
+                }
+                float mn, mx;
+                wave_minmax4(mn4, mx4, mn, mx);
+                const int u = u0 + wave_minmax4_slot(lane);
+                const int row = u * rps + rsub;
+                if ((lane & 15) == 0 && u < n_used && row < T.nr && wave_on) lds_minmax(sh_row + 2 * row, mn, mx);   // one writer per row and wave
+            }
+            return;
+        }
         slots(T, tile, [&](float* x, int row, bool on) {
             if (useA && !one_group) inv4(T, G, sh_inv, row, iv);
             const float sr = useB ? sh_s[row] : 1.0f;
@@ -425,7 +455,6 @@ struct LayFixed {
             if (4 < w) xor_lane_minmax<4>(mn, mx);
             if (8 < w) xor_lane_minmax<8>(mn, mx);
             if (16 < w) xor_lane_minmax<16>(mn, mx);
-            if (32 < w) xor_lane_minmax<32>(mn, mx);
             if ((lane & (w - 1)) == 0 && on) lds_minmax(sh_row + 2 * row, mn, mx);   // one writer per row and wave
         });
     }
