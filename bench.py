@@ -110,9 +110,10 @@ def make_unit(protos):
 
 def pass_bytes(le, bc, sweeps):
     """Algorithmic bytes of one LE(sweeps)+BC pass as executed: per sweep 8 B per element read and written +
-    4 B per interior element only measured; bootstrap 4 B per paired element; BC 8 B per weight (min/max read + the chain's
+    4 B per interior element only measured, less the stores the streaming engine defers (LEPlan.sweep_bytes); bootstrap 4 B
+    per paired element; BC 8 B per weight (min/max read + the chain's
     read: the quant-error row sums are formed in registers)."""
-    return sweeps * (8 * le.rw_elements + 4 * le.ro_elements) + 4 * le.paired_elements + 8 * bc.weight_elements
+    return sweeps * le.sweep_bytes + 4 * le.paired_elements + 8 * bc.weight_elements
 
 
 def cpu_baseline(net, seed, budget_s):
@@ -594,6 +595,7 @@ def main():
     levels = probe['le'].levels
     paired = probe['le'].paired_elements                    # sum over relations of n1 + n2
     rw, ro = probe['le'].rw_elements, probe['le'].ro_elements
+    sweep_bytes, defer_depth, deferred = probe['le'].sweep_bytes, probe['le'].defer_depth, probe['le'].deferred_elements
 
     units = [make_unit(protos) for _ in range(args.steps + args.warmup)]
 
@@ -748,14 +750,16 @@ def main():
         assert wall_rep['le'].query()['sweeps'] == sweeps
         launches = sweeps * levels
         avg_ms = sweep_ms * share_levels / levels
-        bytes_per_sweep = 8 * rw + 4 * ro
+        # bytes as executed: one-way-scaled layers are read every sweep and stored every `defer_depth`-th one (dfq_le.hip,
+        # "Deferred stores"); the timed bracket includes the launch that brings them up to date at the end
+        bytes_per_sweep = sweep_bytes
         avg_bytes = bytes_per_sweep / levels
         achieved = avg_bytes / max(avg_ms * 1e-3, 1e-12) / 1e9
         per_level = []
         for l in range(levels):
             info = prof_rep['le'].level_info(l)
             us = sweep_ms * 1e3 * lvl_corr[l] / max(sum(lvl_corr) + ctl_corr, 1e-12)
-            nbytes = 8 * info['rw_elements'] + 4 * info['ro_elements']
+            nbytes = bytes_per_sweep if levels == 1 else 8 * info['rw_elements'] + 4 * info['ro_elements']
             per_level.append({'level': l, 'relations': info['relations'], 'workgroups': info['workgroups'],
                               'bytes': nbytes, 'us': us, 'GBps': nbytes / max(us, 1e-9) / 1e3})
         # SURVEY.md 8(d)'s eager contract for the same launches: 8 B per paired element + 12 B per weight for a separate
@@ -771,6 +775,9 @@ def main():
             'traffic_source': ('{}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of this command at this batch size; '
                                'a profiler pass cannot run inside this process'.format(traffic_src)) if traffic_src else None,
             'bytes_per_launch': avg_bytes, 'us_per_launch': avg_ms * 1e3, 'launches_timed': launches,
+            'deferred_store_depth': defer_depth, 'deferred_elements_per_launch': deferred / levels,
+            'bytes_per_launch_storing_every_sweep': (8 * rw + 4 * ro) / levels,
+            'equivalent_GBps_storing_every_sweep': (8 * rw + 4 * ro) / levels / max(avg_ms * 1e-3, 1e-12) / 1e9,
             'eager_formulation_bytes_per_launch': survey_bytes,
             'eager_formulation_equivalent_GBps': survey_bytes / max(avg_ms * 1e-3, 1e-12) / 1e9,
             'sweep_wall_us': sweep_ms * 1e3, 'control_us_per_sweep': sweep_ms * 1e3 * (1.0 - share_levels),

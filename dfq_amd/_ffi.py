@@ -89,6 +89,8 @@ SIGNATURES = {
     'dfq_le_plan_depth': (c_int32, [c_void_p]),
     'dfq_le_plan_rw_elements': (c_int64, [c_void_p]),
     'dfq_le_plan_ro_elements': (c_int64, [c_void_p]),
+    'dfq_le_plan_deferred_elements': (c_int64, [c_void_p]),
+    'dfq_le_plan_defer_depth': (c_int32, [c_void_p]),
     'dfq_le_plan_level_launches': (c_int32, [c_void_p, c_int32, POINTER(c_int64), POINTER(c_int64), POINTER(c_int32)]),
     'dfq_le_plan_level_grid': (c_int32, [c_void_p, c_int32, POINTER(c_int32), POINTER(c_int32)]),
     'dfq_le_enqueue': (c_int32, [c_void_p, POINTER(DfqLeConfig), c_int32, c_int32, c_void_p]),

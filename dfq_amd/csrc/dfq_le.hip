@@ -42,6 +42,16 @@
 // emitting the new column statistics (8 B per element).  12 B per interior element and sweep instead
 // of 24 B for two read-write passes plus a pre-sweep snapshot.
 //
+// Deferred stores.  A layer that is only ever scaled one way (chain start: rows by s; chain end: columns by 1/s) is read
+// by nobody but its own tile between two sweeps -- its ranges are forwarded arithmetically -- so its store can wait: with
+// depth D (LeParams::defer, a power of two; DFQ_LE_DEFER, default 2, 1 = off) sweep k with k % D != D-1 only reads the
+// tile, forms nv = fl(t * s_k) for the |dW| sum and remembers s_k per channel (`hold`), where t is the stored value taken
+// through the remembered factors of the skipped sweeps one rounding at a time -- the very float32 operations the
+// reference performs, in its order, so every value and every |dW| term is bit-identical; sweep k % D == D-1 replays the
+// same way and stores.  4 (D + 1) / D bytes per element and sweep instead of 8.  A loop that ends between two stores
+// leaves up to D-1 pending factors: le_flush_kernel applies them (launched at the end of every enqueue call, gated per
+// network on its sweep count) and le_hold_reset_kernel sets the remembered factors back to 1.
+//
 // Convergence (dfq.py:105-115): every element is written exactly once per sweep, by a pass that has
 // its pre-sweep value in a register, so each tile leaves float64 partials of sum|W - W_prev|; they are
 // reduced in a fixed order by a one-workgroup control kernel that also advances the reference's
@@ -61,14 +71,18 @@ namespace dfq {
 
 // register slots (vectors) a thread preloads: 4 x float4 or 8 x float.  Kept small on purpose: every
 // slot is unrolled code, and a cold workgroup pays instruction-fetch latency for every line it walks.
-constexpr int kSlotsVec4 = 8;
-constexpr int kSlotsVec1 = 8;
+#ifndef DFQ_LE_SLOTS
+#define DFQ_LE_SLOTS 8
+#endif
+constexpr int kSlotsVec4 = DFQ_LE_SLOTS;
+constexpr int kSlotsVec1 = DFQ_LE_SLOTS;
 static_assert(kSlotsVec4 == kSlotsVec1, "the tile functions take one register-array shape");
 constexpr int kTileRowsMax = 256;      // rows of a tile (one LDS entry per row)
 constexpr int kRowTileColsMax = 128;   // positions of a row tile (x2 for float4 tiles)
 constexpr int kColTileLanes = 64;      // vector positions of a col tile (one wave per row at most)
 constexpr int kSlotMax = 1024;         // LDS table entries of a tile (stat slots / 1/s table)
 constexpr int kShortChunk = 9;          // taps a thread-per-row tile keeps in flight (one 3x3 kernel)
+constexpr int kHoldMax = 3;             // remembered factors per channel: deferred stores of depth <= 4
 constexpr int kBootTc = 256;           // channels per bootstrap tile (1 KB of a pointwise second layer's row)
 #ifndef DFQ_BOOT_ABLATE
 #define DFQ_BOOT_ABLATE 0
@@ -89,6 +103,7 @@ struct LeRelDev {
     float* bnw;
     float* bnb;
     float* s_cum;
+    float* hold;         // remembered factors of the skipped sweeps (see `defer` below), or null
     uint32_t* prev_r1;   // W1 is interior: row stats (R1) of the relation whose second layer it is, else null
     uint32_t* r1;        // parity 0 of the row stats of W1: [o1][2] = (min slot, max slot); parity 1 is
     uint32_t* r2;        // `stat_stride` words further.  r2: column stats of W2 per paired channel
@@ -112,6 +127,10 @@ struct LeRelDev {
     int32_t dep_idx;        // index of that relation's counter, or -1
     int32_t dep_tiles;      // its column tiles per sweep
     int32_t counter_idx;    // own counter (bumped by this relation's column tiles if somebody waits for them), or -1
+    // deferred stores (see "Deferred stores" in the header comment): bit 0 = W1, bit 1 = W2 is scaled one way only and its
+    // store is skipped in all but every `LeParams::defer`-th sweep; hold[(2 j + side) * o1 + c] = factor of channel c in the
+    // j-th skipped sweep since the last store
+    int32_t defer;
 };
 
 // Tuning builds only (tools/ablate.sh): -DDFQ_LE_ABLATE=bits switches parts of the tile kernels off at compile
@@ -332,6 +351,14 @@ __device__ __forceinline__ double row_tile(const LeRelDev& R, const LeParams& p,
     const int n_max = min(NV, small_div(nr + JL - 1, JL));             // register slots in use (block-uniform)
     gfloat* const w = (gfloat*)R.w1 + ((int64_t)r0 * R.row_len + pos);
     const bool fused = R.w1_interior != 0;     // the column rescale of the previous relation is applied here too
+    // deferred store (plan: never together with `fused` or `emit`): `phase` skipped sweeps precede this one since the
+    // last store; their factors were written by earlier launches and are requested before everything else
+    const bool defer = (R.defer & 1) != 0;
+    const int phase = defer ? (dep.sweep & (p.defer - 1)) : 0;
+    const bool keep = defer && phase != p.defer - 1;           // this sweep does not store either
+    float hv[kHoldMax];
+#pragma unroll
+    for (int j = 0; j < kHoldMax; ++j) hv[j] = (j < phase && tid < nr) ? R.hold[(int64_t)(2 * j) * R.o1 + r0 + tid] : 1.0f;
 
     // ---- load order.  No dependency: the four statistics words of this thread's row go first -- they are back long
     //      before the data and the scale solve then overlaps the data's flight instead of queueing behind it (memory
@@ -415,6 +442,11 @@ __device__ __forceinline__ double row_tile(const LeRelDev& R, const LeParams& p,
         scale_from_words(p, wa0, wa1, wb0, wb1, s, inv, mn1, mx1, mn2, mx2);
         sh_s[tid] = s;
         if (emit) sh_g[tid] = (small_div(c, R.pc_go) - g0) * nci;
+        if (defer) {
+#pragma unroll
+            for (int j = 0; j < kHoldMax; ++j) if (j < phase) sh_pinv[j * kTileRowsMax + tid] = hv[j];
+            if (own && keep) R.hold[(int64_t)(2 * phase) * R.o1 + c] = s;
+        }
         if (own) {
             R.s_cum[c] = o_cum * s;                       // relation.py:20-24
             if (R.bnw) R.bnw[c] = o_bnw * s;              // dfq.py:64-65
@@ -457,13 +489,33 @@ __device__ __forceinline__ double row_tile(const LeRelDev& R, const LeParams& p,
             for (int k = 0; k < VEC; ++k) pin[k] = sh_pinv[g + ci[k]];
         }
         float nv[VEC];
+        if (!defer) {
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) {
-            const float t = v[u][k] * pin[k];               // dfq.py:73 of the previous relation (rounded), then
-            nv[k] = t * s;                                  // dfq.py:62 of this one
+            for (int k = 0; k < VEC; ++k) {
+                const float t = v[u][k] * pin[k];               // dfq.py:73 of the previous relation (rounded), then
+                nv[k] = t * s;                                  // dfq.py:62 of this one
+            }
+            if (ok) vstore<VEC>(w + r * R.row_len, nv);
+            if (!(kAblate & 2)) acc += slot_abs_diff<VEC>(ok, nv, v[u]);
+        } else {
+            // the stored value is `phase` sweeps old: take it through the remembered factors (one rounding each, as the
+            // skipped stores would have), then this sweep's
+            float t[VEC];
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) t[k] = v[u][k];
+#pragma unroll
+            for (int j = 0; j < kHoldMax; ++j) {
+                if (j < phase) {
+                    const float h = sh_pinv[j * kTileRowsMax + r];
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) t[k] = t[k] * h;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) nv[k] = t[k] * s;
+            if (ok && !keep) vstore<VEC>(w + r * R.row_len, nv);
+            if (!(kAblate & 2)) acc += slot_abs_diff<VEC>(ok, nv, t);
         }
-        if (ok) vstore<VEC>(w + r * R.row_len, nv);
-        if (!(kAblate & 2)) acc += slot_abs_diff<VEC>(ok, nv, v[u]);
         if (emit && ok) {
             if (g != cur_g) {
                 if (cur_g >= 0) {
@@ -510,7 +562,7 @@ __device__ __forceinline__ double row_tile(const LeRelDev& R, const LeParams& p,
 template <int VEC, bool PRE, class Mid>
 __device__ __forceinline__ double col_tile(const LeRelDev& R, const LeParams& p, int tile, int cur, const LeDep& dep, bool ready,
                                            float (&v_in)[kSlotsVec4][VEC], Mid mid,
-                                           float* sh_inv, uint32_t* sh_row, int* sh_tab, int* sh_flag, const LeTrace& tr) {
+                                           float* sh_inv, uint32_t* sh_row, int* sh_tab, float* sh_hold, int* sh_flag, const LeTrace& tr) {
     constexpr int NV = (VEC == 4) ? kSlotsVec4 : kSlotsVec1;
     float v_own[NV][VEC];
     float (&v)[NV][VEC] = *(PRE ? &v_in : &v_own);
@@ -550,6 +602,15 @@ __device__ __forceinline__ double col_tile(const LeRelDev& R, const LeParams& p,
     const int e_c = (g_lo + e_gq) * R.gi + i0 + (min(tid, g_n * nci - 1) - e_gq * nci);
     const guint* const st_a = (const guint*)R.r1 + (int64_t)cur * R.stat_stride + 2 * e_c;
     const guint* const st_b = (const guint*)R.r2 + (int64_t)cur * R.stat_stride + 2 * e_c;
+    // deferred store (plan: never with `stat_only` or `emit`), see row_tile: the remembered 1/s of the skipped sweeps, one
+    // table per skipped sweep laid out like sh_inv (the first in sh_hold, the others in the unused row-statistics words)
+    const bool defer = (R.defer & 2) != 0;
+    const int phase = defer ? (dep.sweep & (p.defer - 1)) : 0;
+    const bool keep = defer && phase != p.defer - 1;
+    auto hold_tab = [&](int j) { return j == 0 ? sh_hold : (float*)sh_row + (j - 1) * kSlotMax; };
+    float hv[kHoldMax];
+#pragma unroll
+    for (int j = 0; j < kHoldMax; ++j) hv[j] = (j < phase && has_entry) ? R.hold[(int64_t)(2 * j + 1) * R.o1 + e_c] : 1.0f;
     if (!waits && has_entry) { wa0 = ld_stat(st_a); wa1 = ld_stat(st_a + 1); wb0 = st_b[0]; wb1 = st_b[1]; }
     if (!PRE) {
 #pragma unroll
@@ -575,11 +636,18 @@ __device__ __forceinline__ double col_tile(const LeRelDev& R, const LeParams& p,
         if (idx == tid) scale_from_words(p, wa0, wa1, wb0, wb1, s, inv, mn1, mx1, mn2, mx2);
         else channel_scale(R, p, cur, c, s, inv, mn1, mx1, mn2, mx2);
         sh_inv[idx] = inv;
+        const bool first_row = g * R.go >= r0 && g * R.go < r0 + nr;
         // W2 is never row-scaled: forward its column stats (the tile holding the group's first row does it)
-        if (!emit && g * R.go >= r0 && g * R.go < r0 + nr) {
+        if (!emit && first_row) {
             guint* f = (guint*)R.r2 + (int64_t)nxt * R.stat_stride + 2 * c;
             f[0] = ~enc_ord(mn2 * inv);
             f[1] = enc_ord(mx2 * inv);
+        }
+        if (defer) {
+#pragma unroll
+            for (int j = 0; j < kHoldMax; ++j)
+                if (j < phase) hold_tab(j)[idx] = (idx == tid) ? hv[j] : R.hold[(int64_t)(2 * j + 1) * R.o1 + c];
+            if (keep && first_row) R.hold[(int64_t)(2 * phase + 1) * R.o1 + c] = inv;
         }
     }
     if (tid < nr) sh_tab[tid] = (small_div(r0 + tid, R.go) - g_lo) * nci;
@@ -599,11 +667,29 @@ __device__ __forceinline__ double col_tile(const LeRelDev& R, const LeParams& p,
         const bool ok = lane_on && r_raw < nr;
         const int t0 = sh_tab[r];
         float nv[VEC];
+        if (!defer) {
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) nv[k] = v[u][k] * sh_inv[t0 + ci[k]];      // dfq.py:73
-        if (!stat_only) {
-            if (ok) vstore<VEC>(w + r * row_len2, nv);
-            if (!(kAblate & 2)) acc += slot_abs_diff<VEC>(ok, nv, v[u]);
+            for (int k = 0; k < VEC; ++k) nv[k] = v[u][k] * sh_inv[t0 + ci[k]];      // dfq.py:73
+            if (!stat_only) {
+                if (ok) vstore<VEC>(w + r * row_len2, nv);
+                if (!(kAblate & 2)) acc += slot_abs_diff<VEC>(ok, nv, v[u]);
+            }
+        } else {
+            float t[VEC];
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) t[k] = v[u][k];
+#pragma unroll
+            for (int j = 0; j < kHoldMax; ++j) {
+                if (j < phase) {
+                    const float* tab = hold_tab(j) + t0;
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) t[k] = t[k] * tab[ci[k]];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) nv[k] = t[k] * sh_inv[t0 + ci[k]];
+            if (ok && !keep) vstore<VEC>(w + r * row_len2, nv);
+            if (!(kAblate & 2)) acc += slot_abs_diff<VEC>(ok, nv, t);
         }
         if (emit) {                                        // block-uniform: every lane reaches the shuffles
             float rmn = INFINITY, rmx = -INFINITY;
@@ -794,8 +880,8 @@ __global__ __launch_bounds__(kBlock, DFQ_LE_MIN_WAVES) void le_level_kernel(cons
         else { float v[kSlotsVec4][1]; acc = row_tile<1, false>(R, p, tile, cur, dep, false, v, nothing, sh_f, sh_u, sh_g, sh_p, &sh_flag, tr); }
     } else {
         if (R.ct_vec == 0) acc = dep_wait(R, dep, p.poll_naps, p.spin_limit, &sh_flag) ? short_tile<1>(R, p, tile - R.n_row_tiles, cur) : kTileAbandoned;
-        else if (R.ct_vec == 4) { float v[kSlotsVec4][4]; acc = col_tile<4, false>(R, p, tile - R.n_row_tiles, cur, dep, false, v, nothing, sh_f, sh_u, sh_g, &sh_flag, tr); }
-        else { float v[kSlotsVec4][1]; acc = col_tile<1, false>(R, p, tile - R.n_row_tiles, cur, dep, false, v, nothing, sh_f, sh_u, sh_g, &sh_flag, tr); }
+        else if (R.ct_vec == 4) { float v[kSlotsVec4][4]; acc = col_tile<4, false>(R, p, tile - R.n_row_tiles, cur, dep, false, v, nothing, sh_f, sh_u, sh_g, sh_p, &sh_flag, tr); }
+        else { float v[kSlotsVec4][1]; acc = col_tile<1, false>(R, p, tile - R.n_row_tiles, cur, dep, false, v, nothing, sh_f, sh_u, sh_g, sh_p, &sh_flag, tr); }
     }
     stamp(tr, 6);
     if (acc < 0.0) return;          // abandoned wait (uniform): nothing was stored, the counter is not bumped
@@ -969,12 +1055,12 @@ __global__ __launch_bounds__(kBlock, DFQ_LE_SWEEP_MIN_WAVES) void le_sweep_kerne
                     else { float v1[kSlotsVec4][1]; acc = row_tile<1, false>(R, p, tile, cur, dep, true, v1, [] {}, sh_f, sh_u, sh_g, sh_p, &sh_flag, tr); }
                 }
             } else {
-                if (R.ct_vec == 4) acc = col_tile<4, true>(R, p, tile - R.n_row_tiles, cur, dep, ready, v, ahead, sh_f, sh_u, sh_g, &sh_flag, tr);
+                if (R.ct_vec == 4) acc = col_tile<4, true>(R, p, tile - R.n_row_tiles, cur, dep, ready, v, ahead, sh_f, sh_u, sh_g, sh_p, &sh_flag, tr);
                 else {
                     ahead();
                     if (!ready && !dep_wait(R, dep, p.poll_naps, p.spin_limit, &sh_flag)) acc = kTileAbandoned;
                     else if (R.ct_vec == 0) acc = short_tile<1>(R, p, tile - R.n_row_tiles, cur);
-                    else { float v1[kSlotsVec4][1]; acc = col_tile<1, false>(R, p, tile - R.n_row_tiles, cur, dep, true, v1, [] {}, sh_f, sh_u, sh_g, &sh_flag, tr); }
+                    else { float v1[kSlotsVec4][1]; acc = col_tile<1, false>(R, p, tile - R.n_row_tiles, cur, dep, true, v1, [] {}, sh_f, sh_u, sh_g, sh_p, &sh_flag, tr); }
                 }
             }
             stamp(tr, 6);
@@ -1307,6 +1393,60 @@ __global__ void le_reset_kernel(LeState* states, int n_nets, double converge_thr
     }
 }
 
+// Deferred stores: apply the factors still pending for a network (sweeps % depth of them) to its one-way-scaled layers.
+// One workgroup per span of kFlushSpan elements of one layer; workgroups of networks with nothing pending leave at once.
+constexpr int kFlushSpan = 4096;
+struct LeFlushRef {
+    int32_t rel;       // index into the level-sorted descriptor table
+    int32_t side;      // 0: W1 (rows by s), 1: W2 (columns by 1/s)
+    int64_t first;     // first element of the span
+};
+__global__ __launch_bounds__(kBlock) void le_flush_kernel(const LeRelDev* __restrict__ table, const LeFlushRef* __restrict__ refs,
+                                                          const LeState* __restrict__ state, int depth) {
+    const LeFlushRef ref = refs[blockIdx.x];
+    const LeRelDev& R = table[ref.rel];
+    const int pend = state[R.net].sweeps & (depth - 1);
+    if (pend == 0) return;
+    float* const w = ref.side == 0 ? R.w1 : R.w2;
+    const int row_len = ref.side == 0 ? R.row_len : R.i2g * R.khkw;
+    const int64_t n = (int64_t)(ref.side == 0 ? R.o1 : R.o2) * row_len;
+    const int64_t end = (ref.first + kFlushSpan < n) ? ref.first + kFlushSpan : n;
+    auto factor = [&](int j, int64_t o, int pos) {
+        const int c = ref.side == 0 ? (int)o : (int)(o / R.go) * R.gi + pos / R.khkw;
+        return R.hold[(int64_t)(2 * j + ref.side) * R.o1 + c];
+    };
+    const bool vec = ((row_len & 3) == 0) && (((uintptr_t)w & 15) == 0);
+    if (vec) {
+        for (int64_t e = ref.first + 4 * (int64_t)threadIdx.x; e < end; e += 4 * kBlock) {
+            fvec4 x = *(const fvec4*)(w + e);
+            const int64_t o = e / row_len;
+            const int pos = (int)(e - o * row_len);
+            for (int j = 0; j < pend; ++j) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) x[k] = x[k] * factor(j, o, pos + k);
+            }
+            *(fvec4*)(w + e) = x;
+        }
+    } else {
+        for (int64_t e = ref.first + threadIdx.x; e < end; e += kBlock) {
+            const int64_t o = e / row_len;
+            float x = w[e];
+            for (int j = 0; j < pend; ++j) x = x * factor(j, o, (int)(e - o * row_len));
+            w[e] = x;
+        }
+    }
+}
+
+// remembered factors back to 1 (so that a later sweep that replays them changes nothing): every relation with deferred
+// layers of the networks that had something pending (`force`: all of them, at a restart)
+__global__ __launch_bounds__(kBlock) void le_hold_reset_kernel(const LeRelDev* __restrict__ table, const int32_t* __restrict__ rels,
+                                                               const LeState* __restrict__ state, int depth, int force) {
+    const LeRelDev& R = table[rels[blockIdx.x]];
+    if (!force && (state[R.net].sweeps & (depth - 1)) == 0) return;
+    const int64_t n = (int64_t)2 * (depth - 1) * R.o1;
+    for (int64_t i = threadIdx.x; i < n; i += kBlock) R.hold[i] = 1.0f;
+}
+
 // ---------------------------------------------------------------------------------------------
 // host side: the plan
 // ---------------------------------------------------------------------------------------------
@@ -1330,6 +1470,14 @@ struct dfq_le_plan {
     std::vector<LevelLaunch> levels;
     int64_t paired_total = 0;              // sum over relations of n1 + n2 (SURVEY 8d's Sigma_rel)
     int64_t rw_total = 0, ro_total = 0;    // per sweep: elements read+written / only read
+    // deferred stores: depth (1 = off), elements of the layers concerned (part of rw_total: read every sweep, written every
+    // `defer`-th), the remembered factors, the workgroup tables of the flush / reset launches
+    int defer = 1;
+    int64_t deferred_total = 0;
+    float* d_hold = nullptr;
+    LeFlushRef* d_flush = nullptr;
+    int32_t* d_hold_rels = nullptr;
+    int n_flush = 0, n_hold_rels = 0;
     int total_tiles = 0, boot_blocks = 0;
     int64_t stat_words = 0;                // per parity, per arena
     int64_t r1_zero_words = 0;             // leading part of the R1 arena that is accumulated with atomics
@@ -1423,6 +1571,9 @@ void dfq_le_plan_destroy(dfq_le_plan* p) {
     if (p->d_blocks) (void)hipFree(p->d_blocks);
     if (p->d_dep) (void)hipFree(p->d_dep);
     if (p->d_tiles) (void)hipFree(p->d_tiles);
+    if (p->d_hold) (void)hipFree(p->d_hold);
+    if (p->d_flush) (void)hipFree(p->d_flush);
+    if (p->d_hold_rels) (void)hipFree(p->d_hold_rels);
     for (auto& g : p->graphs) (void)hipGraphExecDestroy(g.exec);
     if (p->capture_stream) (void)hipStreamDestroy(p->capture_stream);
     if (p->resident) le_resident_destroy(p->resident);
@@ -1612,6 +1763,26 @@ int dfq_le_plan_create_batch(const dfq_layer* layers, int32_t n_layers, const in
         p->paired_total += (int64_t)d.o1 * d.row_len + (int64_t)d.o2 * d.i2g * d.khkw;
     }
     p->total_tiles = tile_slot;
+    // ---- deferred stores: layers scaled one way only, handled by the register-tile functions ----
+    {
+        const char* de = getenv("DFQ_LE_DEFER");
+        const int want = de ? atoi(de) : 2;
+        p->defer = (want >= 4) ? 4 : (want >= 2) ? 2 : 1;
+        int64_t hold_floats = 0;
+        std::vector<int64_t> hold_off(n_relations, -1);
+        for (int r = 0; r < n_relations && p->defer > 1; ++r) {
+            LeRelDev& d = h[r];
+            if (!d.w1_interior && d.rt_vec != 0) { d.defer |= 1; p->deferred_total += (int64_t)d.o1 * d.row_len; }
+            if (!d.w2_interior && d.ct_vec != 0) { d.defer |= 2; p->deferred_total += (int64_t)d.o2 * d.i2g * d.khkw; }
+            if (d.defer) { hold_off[r] = hold_floats; hold_floats += (int64_t)2 * (p->defer - 1) * d.o1; }
+        }
+        if (hold_floats > 0) {
+            if ((e = hipMalloc((void**)&p->d_hold, sizeof(float) * hold_floats)) != hipSuccess) return fail_alloc(e);
+            for (int r = 0; r < n_relations; ++r) if (hold_off[r] >= 0) h[r].hold = p->d_hold + hold_off[r];
+        } else {
+            p->defer = 1;
+        }
+    }
     std::vector<LeNetDesc> nets(n_nets);
     for (int n = 0; n < n_nets; ++n) { nets[n].layer_begin = 0; nets[n].n_layers = 0; nets[n].tile_begin = 0; nets[n].n_tiles = 0; }
     for (int l = n_layers - 1; l >= 0; --l) { nets[net_of(l)].layer_begin = l; nets[net_of(l)].n_layers += 1; }
@@ -1712,6 +1883,28 @@ int dfq_le_plan_create_batch(const dfq_layer* layers, int32_t n_layers, const in
             (e = hipMemcpy(p->d_blocks, blocks.data(), sizeof(LeBlockRef) * blocks.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail_alloc(e);
         p->h_rels = sorted;
         p->h_blocks = blocks;
+        if (p->defer > 1) {
+            std::vector<LeFlushRef> refs;
+            std::vector<int32_t> hold_rels;
+            for (int i = 0; i < n_relations; ++i) {
+                const LeRelDev& d = sorted[i];
+                if (!d.defer) continue;
+                hold_rels.push_back(i);
+                for (int side = 0; side < 2; ++side) {
+                    if (!(d.defer & (1 << side))) continue;
+                    const int64_t n = side == 0 ? (int64_t)d.o1 * d.row_len : (int64_t)d.o2 * d.i2g * d.khkw;
+                    for (int64_t f = 0; f < n; f += kFlushSpan) refs.push_back(LeFlushRef{i, side, f});
+                }
+            }
+            p->n_flush = (int)refs.size();
+            p->n_hold_rels = (int)hold_rels.size();
+            if ((e = hipMalloc((void**)&p->d_flush, sizeof(LeFlushRef) * refs.size())) != hipSuccess) return fail_alloc(e);
+            if ((e = hipMalloc((void**)&p->d_hold_rels, sizeof(int32_t) * hold_rels.size())) != hipSuccess) return fail_alloc(e);
+            if ((e = hipMemcpy(p->d_flush, refs.data(), sizeof(LeFlushRef) * refs.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail_alloc(e);
+            if ((e = hipMemcpy(p->d_hold_rels, hold_rels.data(), sizeof(int32_t) * hold_rels.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail_alloc(e);
+            hipLaunchKernelGGL(le_hold_reset_kernel, dim3(p->n_hold_rels), dim3(kBlock), 0, nullptr, (const LeRelDev*)p->d_rels,
+                               (const int32_t*)p->d_hold_rels, (const LeState*)p->d_state, p->defer, 1);
+        }
         if ((e = hipMalloc((void**)&p->d_dep, sizeof(unsigned long long) * ((size_t)n_relations * kDepStride + 1))) != hipSuccess) return fail_alloc(e);
         if ((e = hipMemset(p->d_dep, 0, sizeof(unsigned long long) * ((size_t)n_relations * kDepStride + 1))) != hipSuccess) return fail_alloc(e);
         const char* me = getenv("DFQ_LE_MERGED");
@@ -1802,6 +1995,10 @@ int32_t dfq_le_plan_depth(const dfq_le_plan* p) { return p ? (int32_t)p->levels.
 int64_t dfq_le_plan_paired_elements(const dfq_le_plan* p) { return p ? p->paired_total : 0; }
 int64_t dfq_le_plan_rw_elements(const dfq_le_plan* p) { return p ? p->rw_total : 0; }
 int64_t dfq_le_plan_ro_elements(const dfq_le_plan* p) { return p ? p->ro_total : 0; }
+// deferred stores of the streaming engine: elements (a part of rw_elements) that are read every sweep but written only
+// every `depth`-th; depth 1 = every sweep (resident plans, DFQ_LE_DEFER=1)
+int64_t dfq_le_plan_deferred_elements(const dfq_le_plan* p) { return (p && !p->resident) ? p->deferred_total : 0; }
+int32_t dfq_le_plan_defer_depth(const dfq_le_plan* p) { return (p && !p->resident) ? p->defer : 1; }
 
 // the slice of the sweep's workgroup table that launch `launch` covers
 static bool launch_slice(const dfq_le_plan* p, int launch, int* begin, int* count, int* n_rels, int64_t* rw, int64_t* ro) {
@@ -1865,6 +2062,11 @@ static int le_restart(dfq_le_plan* p, const dfq_le_config* cfg, hipStream_t st) 
                        (int)cfg->converge_count, (int)cfg->max_sweeps);
     DFQ_CHECK_LAUNCH();
     p->sweep_index = 0;
+    if (p->defer > 1) {
+        hipLaunchKernelGGL(le_hold_reset_kernel, dim3(p->n_hold_rels), dim3(kBlock), 0, st, (const LeRelDev*)p->d_rels,
+                           (const int32_t*)p->d_hold_rels, (const LeState*)p->d_state, p->defer, 1);
+        DFQ_CHECK_LAUNCH();
+    }
     DFQ_HIP_TRY(hipMemsetAsync(p->d_dep, 0, sizeof(unsigned long long) * ((size_t)p->n_rels * kDepStride + 1), st));
     if (p->n_rels > 0) {
         DFQ_HIP_TRY(hipMemsetAsync(p->d_stats, 0, sizeof(uint32_t) * 4 * p->stat_words, st));
@@ -1873,6 +2075,24 @@ static int le_restart(dfq_le_plan* p, const dfq_le_config* cfg, hipStream_t st) 
         DFQ_CHECK_LAUNCH();
     }
     return DFQ_OK;
+}
+
+// deferred stores: bring the weights up to date with the sweeps run so far (a no-op for networks whose last sweep stored)
+static int le_flush(dfq_le_plan* p, hipStream_t st) {
+    if (p->defer <= 1 || p->n_flush == 0) return DFQ_OK;
+    hipLaunchKernelGGL(le_flush_kernel, dim3(p->n_flush), dim3(kBlock), 0, st, (const LeRelDev*)p->d_rels,
+                       (const LeFlushRef*)p->d_flush, (const LeState*)p->d_state, p->defer);
+    DFQ_CHECK_LAUNCH();
+    hipLaunchKernelGGL(le_hold_reset_kernel, dim3(p->n_hold_rels), dim3(kBlock), 0, st, (const LeRelDev*)p->d_rels,
+                       (const int32_t*)p->d_hold_rels, (const LeState*)p->d_state, p->defer, 0);
+    DFQ_CHECK_LAUNCH();
+    return DFQ_OK;
+}
+
+static LeParams plan_params(const dfq_le_plan* p, const dfq_le_config* cfg) {
+    LeParams q = make_params(cfg);
+    q.defer = p->defer;
+    return q;
 }
 
 // launch number `launch` of a sweep (see dfq_le_plan_levels)
@@ -1911,7 +2131,7 @@ static int le_launch_control(dfq_le_plan* p, const dfq_le_config* cfg, hipStream
 extern "C" {
 
 static int le_enqueue_direct(dfq_le_plan* p, const dfq_le_config* cfg, int n_sweeps, int restart, hipStream_t st) {
-    const LeParams q = make_params(cfg);
+    const LeParams q = plan_params(p, cfg);
     int rc;
     if (restart && (rc = le_restart(p, cfg, st))) return rc;
     if (n_sweeps <= 0) return DFQ_OK;
@@ -1924,7 +2144,7 @@ static int le_enqueue_direct(dfq_le_plan* p, const dfq_le_config* cfg, int n_swe
             if ((rc = le_launch_level(p, l, q, st))) return rc;
         if ((rc = le_launch_control(p, cfg, st))) return rc;
     }
-    return DFQ_OK;
+    return le_flush(p, st);
 }
 
 // hipGraph replay is opt-in (DFQ_GRAPH=1): on ROCm 7.2 replaying these few-microsecond kernels as graph
@@ -1985,7 +2205,7 @@ int dfq_le_profile(dfq_le_plan* p, const dfq_le_config* cfg, int32_t n_sweeps, v
                    double* control_ms, int32_t* n_level_launches, double* empty_bracket_ms) {
     if (!p || !cfg || n_sweeps <= 0 || !level_ms) return fail_arg("dfq_le_profile: bad argument");
     hipStream_t st = as_stream(stream);
-    const LeParams q = make_params(cfg);
+    const LeParams q = plan_params(p, cfg);
     const int n_levels = dfq_le_plan_levels(p);
     const int per_sweep = n_levels + 1;
     std::vector<hipEvent_t> ev((size_t)2 * per_sweep * n_sweeps);
@@ -2011,6 +2231,7 @@ int dfq_le_profile(dfq_le_plan* p, const dfq_le_config* cfg, int32_t n_sweeps, v
         if ((rc = le_launch_control(p, cfg, st))) return rc;
         DFQ_HIP_TRY(hipEventRecord(ev[k++], st));
     }
+    if ((rc = le_flush(p, st))) return rc;
     DFQ_HIP_TRY(hipStreamSynchronize(st));
     for (int l = 0; l < n_levels; ++l) level_ms[l] = 0.0;
     double ctl = 0.0;
@@ -2041,7 +2262,7 @@ int dfq_le_trace(dfq_le_plan* p, const dfq_le_config* cfg, int32_t launch, int32
                  int64_t* stamps16) {
     if (!p || !cfg || !stamps16 || launch < 0 || launch >= dfq_le_plan_levels(p)) return fail_arg("dfq_le_trace: bad argument");
     hipStream_t st = as_stream(stream);
-    const LeParams q = make_params(cfg);
+    const LeParams q = plan_params(p, cfg);
     long long* d = nullptr;
     DFQ_HIP_TRY(hipMalloc((void**)&d, 16 * sizeof(long long)));
     DFQ_HIP_TRY(hipMemsetAsync(d, 0, 16 * sizeof(long long), st));
@@ -2051,6 +2272,7 @@ int dfq_le_trace(dfq_le_plan* p, const dfq_le_config* cfg, int32_t launch, int32
             rc = le_launch_level(p, l, q, st, (s == 1 && l == launch) ? LeTrace{d, block, 0} : LeTrace{nullptr, 0, 0});
         if (!rc) rc = le_launch_control(p, cfg, st);
     }
+    if (!rc) rc = le_flush(p, st);
     if (!rc) {
         hipError_t e = hipMemcpyAsync(stamps16, d, 16 * sizeof(long long), hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
@@ -2067,16 +2289,21 @@ int dfq_le_trace_blocks(dfq_le_plan* p, const dfq_le_config* cfg, int32_t launch
     const int64_t n_blocks = tc;
     if (capacity_blocks < n_blocks) return fail_arg("dfq_le_trace_blocks: need room for %lld workgroups", (long long)n_blocks);
     hipStream_t st = as_stream(stream);
-    const LeParams q = make_params(cfg);
+    const LeParams q = plan_params(p, cfg);
     long long* d = nullptr;
     DFQ_HIP_TRY(hipMalloc((void**)&d, 3 * n_blocks * sizeof(long long)));
     DFQ_HIP_TRY(hipMemsetAsync(d, 0, 3 * n_blocks * sizeof(long long), st));
     int rc = le_restart(p, cfg, st);
-    for (int s = 0; s < 3 && !rc; ++s) {          // trace the third sweep (steady state, code and tables warm)
+    // trace the third sweep (steady state, code and tables warm); DFQ_TRACE_SWEEP picks another one (with deferred stores
+    // of depth 2 the third sweep does not store, the fourth does)
+    const char* te = getenv("DFQ_TRACE_SWEEP");
+    const int traced = (te && atoi(te) >= 0) ? atoi(te) : 2;
+    for (int s = 0; s <= traced && !rc; ++s) {
         for (int l = 0; l < dfq_le_plan_levels(p) && !rc; ++l)
-            rc = le_launch_level(p, l, q, st, (s == 2 && l == launch) ? LeTrace{d, -1, 0} : LeTrace{nullptr, 0, 0});
+            rc = le_launch_level(p, l, q, st, (s == traced && l == launch) ? LeTrace{d, -1, 0} : LeTrace{nullptr, 0, 0});
         if (!rc) rc = le_launch_control(p, cfg, st);
     }
+    if (!rc) rc = le_flush(p, st);
     if (!rc) {
         hipError_t e = hipMemcpyAsync(out, d, 3 * n_blocks * sizeof(long long), hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);

@@ -13,6 +13,7 @@ struct LeParams {
     int32_t hi_gt_lo, signed_range;
     int32_t poll_naps;      // s_sleep(8) units between two polls of a dependency counter
     int32_t spin_limit;     // polls after which a workgroup abandons an in-launch wait (DFQ_SPIN_LIMIT; tests force an abandon with 1)
+    int32_t defer;          // streaming engine: one-way-scaled layers are stored every `defer`-th sweep (1, 2 or 4; dfq_le.hip)
 };
 
 struct LeState {
@@ -70,6 +71,7 @@ static inline dfq::LeParams make_params(const dfq_le_config* c) {
     const char* pe = getenv("DFQ_LE_POLL_NAPS");
     q.poll_naps = (pe && atoi(pe) > 0) ? atoi(pe) : 2;
     q.spin_limit = dfq::spin_limit_from_env(4000000);   // x (sleep + load): several seconds
+    q.defer = 1;                                        // set by the streaming plan (le_defer_depth)
     return q;
 }
 

@@ -124,6 +124,22 @@ class LEPlan:
         return _ffi.lib().dfq_le_plan_rw_elements(self._plan)
 
     @property
+    def deferred_elements(self):
+        """Elements (a part of rw_elements) of layers that are scaled one way only: the streaming engine reads them every
+        sweep but stores them every `defer_depth`-th one (include/dfq_hip.h)."""
+        return _ffi.lib().dfq_le_plan_deferred_elements(self._plan)
+
+    @property
+    def defer_depth(self):
+        return _ffi.lib().dfq_le_plan_defer_depth(self._plan)
+
+    @property
+    def sweep_bytes(self):
+        """Bytes one sweep moves as executed (averaged over defer_depth sweeps)."""
+        d = self.defer_depth
+        return 8 * self.rw_elements + 4 * self.ro_elements - 4.0 * self.deferred_elements * (d - 1) / d
+
+    @property
     def ro_elements(self):
         """elements only read per sweep: the statistics pass over interior layers (4 B each)"""
         return _ffi.lib().dfq_le_plan_ro_elements(self._plan)
@@ -695,7 +711,7 @@ _bc_plan_cache = OrderedDict()
 _cache_lock = _threading.RLock()
 plan_cache_stats = {'le_hits': 0, 'le_misses': 0, 'bc_hits': 0, 'bc_misses': 0}
 _PLAN_ENV = ('DFQ_LE_RESIDENT', 'DFQ_LE_MERGED', 'DFQ_LE_TILE_ELEMS', 'DFQ_LE_ROW_COLS', 'DFQ_LE_PERSIST', 'DFQ_LE_SWEEP_WGS',
-             'DFQ_LE_EMIT_COLS', 'DFQ_LE_NO_SHORT', 'DFQ_LE_CHAIN_FIRST', 'DFQ_LE_POLL_NAPS', 'DFQ_RES_EXACT_GROUPS', 'DFQ_RES_RELAXED',
+             'DFQ_LE_EMIT_COLS', 'DFQ_LE_NO_SHORT', 'DFQ_LE_CHAIN_FIRST', 'DFQ_LE_POLL_NAPS', 'DFQ_LE_DEFER', 'DFQ_RES_EXACT_GROUPS', 'DFQ_RES_RELAXED',
              'DFQ_BC_TAGGED', 'DFQ_BC_MERGED', 'DFQ_BC_BLOCKS', 'DFQ_BC_EPS', 'DFQ_GRAPH', 'DFQ_COOPERATIVE', 'DFQ_HIP_LIB')
 
 

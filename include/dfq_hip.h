@@ -125,6 +125,13 @@ int64_t dfq_le_plan_paired_elements(const dfq_le_plan* plan);   /* sum over rela
  * interior layers (4 B each); algorithmic bytes of a sweep = 8 * rw + 4 * ro */
 int64_t dfq_le_plan_rw_elements(const dfq_le_plan* plan);
 int64_t dfq_le_plan_ro_elements(const dfq_le_plan* plan);
+/* Deferred stores of the streaming engine (DFQ_LE_DEFER = depth D at plan creation: 2 by default, 1 = off, 4): a layer
+ * that is only ever scaled one way is read every sweep but written every D-th one, the sweeps in between re-derive its
+ * values from the stored ones and the remembered factors -- the same float32 operations, bit-identical results; every
+ * enqueue call ends by bringing the weights up to date.  deferred_elements (a part of rw_elements) are those layers'
+ * elements: bytes per sweep as executed, averaged over D sweeps = 8 * rw + 4 * ro - 4 * deferred * (D - 1) / D. */
+int64_t dfq_le_plan_deferred_elements(const dfq_le_plan* plan);
+int32_t dfq_le_plan_defer_depth(const dfq_le_plan* plan);
 /* the same two counts for one launch level; returns the number of relations in it */
 int32_t dfq_le_plan_level_launches(const dfq_le_plan* plan, int32_t level, int64_t* rw_elems,
                                    int64_t* ro_elems, int32_t* n_workgroups);

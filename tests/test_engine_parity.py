@@ -8,6 +8,7 @@ Contract (BASELINE.json north_star / DESIGN.md):
   * LE / BC float32 weights, biases, BN proxies, S: |err| <= 1e-5 against the reference; against the
     oracle (same IEEE single operations in the same order) LE is bit-exact.
 """
+import copy
 import os
 
 import numpy as np
@@ -868,6 +869,47 @@ def test_resident_and_streaming_engines_agree(engine, monkeypatch, name, seed, s
             assert_bitexact(sa[k], sb[k], '{} {} {}'.format(le_engine, name, k))
         for a, b in zip(ca, cb):
             assert_bitexact(a, b, '{}: cumulative S'.format(le_engine))
+
+
+@pytest.mark.parametrize('depth', ['1', '2', '4'])
+@pytest.mark.parametrize('le_engine', ['streaming', 'streaming-persistent-3wg'])
+@pytest.mark.parametrize('name,seed,signed', [('tiny_mobile', 0, False), ('tiny_res', 0, False), ('tiny_cat', 3, True)])
+def test_deferred_stores_are_invisible(engine, monkeypatch, depth, le_engine, name, seed, signed):
+    """Streaming engine, DFQ_LE_DEFER = depth: layers that are scaled one way only are stored every depth-th sweep and
+    re-derived from the stored values and the remembered factors in between (dfq_le.hip).  Whatever the depth and however
+    the sweeps are cut into enqueue calls, after every call the weights, the [O] vectors, the cumulative scales and the
+    loop state are those of the reference loop stopped at that sweep -- bit for bit."""
+    _select_le_engine(monkeypatch, le_engine)
+    monkeypatch.setenv('DFQ_LE_DEFER', depth)
+    model, graph, bottoms = synthetic.build(name, seed=seed)
+    model.to(engine.device)
+    lt.merge_batchnorm(model, graph, bottoms, TARG)
+    rels = rel.create_relation(graph, bottoms, TARG)
+    spec0 = graphspec.from_torch(graph, bottoms, TARG)
+    plan = dfq.build_le_plan(graph, rels, TARG)
+    assert plan.resident_tiles == 0 and plan.defer_depth == int(depth)
+    if depth == '1':
+        assert plan.deferred_elements == 0
+    else:
+        assert 0 < plan.deferred_elements <= plan.rw_elements
+        assert plan.sweep_bytes < 8 * plan.rw_elements + 4 * plan.ro_elements
+    plan.enqueue(0, restart=True, signed=signed)
+    total = 0
+    for n in (1, 1, 1, 2, 3, 5, 1, 1000):
+        plan.enqueue(n, restart=False, signed=signed)
+        total += n
+        r = plan.query()
+        plan.stage.writeback()
+        spec = copy.deepcopy(spec0)
+        n_o, S_o = orc.cross_layer_equalization(spec, orc.create_relation(spec), max_sweeps=total, signed=signed)
+        assert r['sweeps'] == n_o, (total, r)
+        osnap, esnap = _spec_snapshot(spec), snapshot(graph)
+        for k in osnap:
+            assert_bitexact(esnap[k], osnap[k], '{} after {} sweeps (depth {})'.format(k, total, depth))
+        for a, b in zip(plan.scale_cum, S_o):
+            assert_bitexact(npy(a), b, 'cumulative S after {} sweeps'.format(total))
+    assert r['done']
+    plan.close()
 
 
 def test_block_info_accounts_for_every_element(engine, monkeypatch):
