@@ -894,7 +894,11 @@ int dfq_bc_plan_run(dfq_bc_plan* p, int32_t symmetric, void* stream) {
 }
 
 static int bc_run_direct(dfq_bc_plan* p, int32_t symmetric, hipStream_t st) {
-    DFQ_HIP_TRY(hipMemsetAsync(p->d_slots, 0, sizeof(uint32_t) * 2 * p->n_steps, st));
+    // min/max slots and (one-launch chain) the hand-over counters + error word: one clear launch
+    const bool chain = p->merged && p->chain_blocks > 0;
+    clear_buffers(st, p->d_slots, sizeof(uint32_t) * 2 * p->n_steps,
+                  chain ? p->d_counters : nullptr, sizeof(uint32_t) * ((size_t)p->n_steps * kBcDepStride + 1));
+    DFQ_CHECK_LAUNCH();
     hipLaunchKernelGGL(bc_minmax_kernel, dim3(p->minmax_blocks), dim3(kBlock), 0, st, (const BcLayerDev*)p->d_layers,
                        (const int32_t*)p->d_mm_begin, p->n_steps, p->d_slots);
     DFQ_CHECK_LAUNCH();
@@ -908,8 +912,7 @@ static int bc_run_direct(dfq_bc_plan* p, int32_t symmetric, hipStream_t st) {
                            (const BcCacheSeg*)p->d_cache_segs, p->n_cache_segs, p->cache_total);
         DFQ_CHECK_LAUNCH();
     }
-    if (p->merged && p->chain_blocks > 0) {
-        DFQ_HIP_TRY(hipMemsetAsync(p->d_counters, 0, sizeof(uint32_t) * ((size_t)p->n_steps * kBcDepStride + 1), st));
+    if (chain) {
         uint32_t* err = p->d_counters + (size_t)p->n_steps * kBcDepStride;
         // the chain kernel contains in-launch waits: never concurrent with another stream's (dfq_common.hpp)
         std::unique_ptr<SpinGuard> guard;

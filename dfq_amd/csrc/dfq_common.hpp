@@ -99,6 +99,35 @@ inline void launch_resident(void (*kernel)(Params...), dim3 grid, dim3 block, si
 }
 #endif
 
+// ---- several small buffers zeroed by ONE launch -------------------------------------------------------------------
+// (hipMemsetAsync is a launch of its own per buffer -- two when the size is not a multiple of 16 bytes -- with 4-12 us
+// between consecutive ones: the three clears in front of a single-network equalisation cost ~30 us of its ~100.)
+struct ClearArgs {
+    uint32_t* p[4];
+    long long words[4];
+};
+static __global__ void clear_kernel(ClearArgs a) {
+    const long long step = (long long)gridDim.x * blockDim.x;
+    for (int k = 0; k < 4; ++k)
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < a.words[k]; i += step) a.p[k][i] = 0u;
+}
+// up to four (pointer, bytes) pairs; sizes are multiples of 4
+inline void clear_buffers(hipStream_t st, void* p0, size_t b0, void* p1 = nullptr, size_t b1 = 0, void* p2 = nullptr, size_t b2 = 0,
+                          void* p3 = nullptr, size_t b3 = 0) {
+    ClearArgs a;
+    void* ps[4] = {p0, p1, p2, p3};
+    const size_t bs[4] = {b0, b1, b2, b3};
+    long long most = 0;
+    for (int k = 0; k < 4; ++k) {
+        a.p[k] = (uint32_t*)ps[k];
+        a.words[k] = ps[k] ? (long long)(bs[k] / 4) : 0;
+        if (a.words[k] > most) most = a.words[k];
+    }
+    if (most == 0) return;
+    const int grid = (int)((most + 1023) / 1024 < 512 ? (most + 1023) / 1024 : 512);
+    hipLaunchKernelGGL(clear_kernel, dim3(grid > 0 ? grid : 1), dim3(256), 0, st, a);
+}
+
 // ---- kernels with in-launch waits never overlap across streams -------------------------------------
 // The one-launch sweep (le_level_kernel), the resident equalisation kernel and the one-launch bias-correction
 // chain contain workgroups that wait for other workgroups of the SAME launch.  That is deadlock-free as long as

@@ -44,7 +44,7 @@
 //
 // Deferred stores.  A layer that is only ever scaled one way (chain start: rows by s; chain end: columns by 1/s) is read
 // by nobody but its own tile between two sweeps -- its ranges are forwarded arithmetically -- so its store can wait: with
-// depth D (LeParams::defer, a power of two; DFQ_LE_DEFER, default 2, 1 = off) sweep k with k % D != D-1 only reads the
+// depth D (LeParams::defer, a power of two; DFQ_LE_DEFER; default 4 for batched plans, 1 = off for single networks) sweep k with k % D != D-1 only reads the
 // tile, forms nv = fl(t * s_k) for the |dW| sum and remembers s_k per channel (`hold`), where t is the stored value taken
 // through the remembered factors of the skipped sweeps one rounding at a time -- the very float32 operations the
 // reference performs, in its order, so every value and every |dW| term is bit-identical; sweep k % D == D-1 replays the
@@ -1380,8 +1380,10 @@ __global__ __launch_bounds__(kCtlBlock) void le_control_kernel(const LeLayerDiff
     }
 }
 
-__global__ void le_reset_kernel(LeState* states, int n_nets, double converge_thres, int converge_count, int max_sweeps) {
+__global__ void le_reset_kernel(LeState* states, int n_nets, double converge_thres, int converge_count, int max_sweeps,
+                                unsigned long long* err) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0 && err) *err = 0ull;              // the plan's "a wait was abandoned" word
     if (i < n_nets) {
         LeState* state = states + i;
         state->diff = 10.0;          // dfq.py:81
@@ -1765,8 +1767,11 @@ int dfq_le_plan_create_batch(const dfq_layer* layers, int32_t n_layers, const in
     p->total_tiles = tile_slot;
     // ---- deferred stores: layers scaled one way only, handled by the register-tile functions ----
     {
+        // default: 4 for a batched plan (bound by what a sweep moves: 1.22e10 -> 1.35e10 -> 1.40e10 weights/s at depth 1 / 2 / 4
+        // for 32 MobileNetV2), 1 for a single network (bound by launch latencies: ResNet-18's two sweeps 0.113 / 0.123 /
+        // 0.154 ms -- the launches that bring the weights up to date cost more than the skipped stores save)
         const char* de = getenv("DFQ_LE_DEFER");
-        const int want = de ? atoi(de) : 2;
+        const int want = de ? atoi(de) : (n_nets > 1 ? 4 : 1);
         p->defer = (want >= 4) ? 4 : (want >= 2) ? 2 : 1;
         int64_t hold_floats = 0;
         std::vector<int64_t> hold_off(n_relations, -1);
@@ -1976,8 +1981,7 @@ int dfq_le_resident_trace(dfq_le_plan* p, const dfq_le_config* cfg, int32_t n_sw
     DFQ_HIP_TRY(hipMemsetAsync(d, 0, words * sizeof(long long), st));
     unsigned long long* err = p->d_dep + (size_t)p->n_rels * kDepStride;
     hipLaunchKernelGGL(le_reset_kernel, dim3(1), dim3(64), 0, st, p->d_state, 1, cfg->converge_thres, (int)cfg->converge_count,
-                       (int)cfg->max_sweeps);
-    DFQ_HIP_TRY(hipMemsetAsync(err, 0, sizeof(unsigned long long), st));
+                       (int)cfg->max_sweeps, err);
     int rc = le_resident_enqueue(p->resident, cfg, p->d_state, err, n_sweeps, st, d);
     if (!rc) {
         hipError_t e = hipMemcpyAsync(out, d, words * sizeof(long long), hipMemcpyDeviceToHost, st);
@@ -2059,7 +2063,7 @@ int32_t dfq_le_plan_level_launches(const dfq_le_plan* p, int32_t level, int64_t*
 // reset the loop state, clear every stat word, recompute the stats of the untouched weights
 static int le_restart(dfq_le_plan* p, const dfq_le_config* cfg, hipStream_t st) {
     hipLaunchKernelGGL(le_reset_kernel, dim3((p->n_nets + 63) / 64), dim3(64), 0, st, p->d_state, p->n_nets, cfg->converge_thres,
-                       (int)cfg->converge_count, (int)cfg->max_sweeps);
+                       (int)cfg->converge_count, (int)cfg->max_sweeps, (unsigned long long*)nullptr);
     DFQ_CHECK_LAUNCH();
     p->sweep_index = 0;
     if (p->defer > 1) {
@@ -2067,9 +2071,10 @@ static int le_restart(dfq_le_plan* p, const dfq_le_config* cfg, hipStream_t st) 
                            (const int32_t*)p->d_hold_rels, (const LeState*)p->d_state, p->defer, 1);
         DFQ_CHECK_LAUNCH();
     }
-    DFQ_HIP_TRY(hipMemsetAsync(p->d_dep, 0, sizeof(unsigned long long) * ((size_t)p->n_rels * kDepStride + 1), st));
+    clear_buffers(st, p->d_dep, sizeof(unsigned long long) * ((size_t)p->n_rels * kDepStride + 1),
+                  p->n_rels > 0 ? p->d_stats : nullptr, sizeof(uint32_t) * 4 * p->stat_words);
+    DFQ_CHECK_LAUNCH();
     if (p->n_rels > 0) {
-        DFQ_HIP_TRY(hipMemsetAsync(p->d_stats, 0, sizeof(uint32_t) * 4 * p->stat_words, st));
         hipLaunchKernelGGL(le_bootstrap_kernel, dim3(p->boot_blocks), dim3(kBlock), 0, st,
                            (const LeRelDev*)p->d_rels, (const int32_t*)p->d_boot_map);
         DFQ_CHECK_LAUNCH();
@@ -2164,9 +2169,8 @@ int dfq_le_enqueue(dfq_le_plan* p, const dfq_le_config* cfg, int32_t n_sweeps, i
         unsigned long long* err = p->d_dep + (size_t)p->n_rels * kDepStride;
         if (restart) {
             hipLaunchKernelGGL(le_reset_kernel, dim3(1), dim3(64), 0, st, p->d_state, 1, cfg->converge_thres,
-                               (int)cfg->converge_count, (int)cfg->max_sweeps);
+                               (int)cfg->converge_count, (int)cfg->max_sweeps, err);
             DFQ_CHECK_LAUNCH();
-            DFQ_HIP_TRY(hipMemsetAsync(err, 0, sizeof(unsigned long long), st));
         }
         return le_resident_enqueue(p->resident, cfg, p->d_state, err, n_sweeps, st);
     }

@@ -1421,9 +1421,9 @@ int le_resident_enqueue(LeResident* r, const dfq_le_config* cfg, LeState* d_stat
     if (!r || !cfg || !d_state || !d_err) return fail_arg("le_resident_enqueue: bad argument");
     if (n_sweeps <= 0) return DFQ_OK;
     // every launch is self-contained: statistics are re-derived from the weights it loads, tags and counters start at zero
-    DFQ_HIP_TRY(hipMemsetAsync(r->d_stats, 0, sizeof(u64) * (size_t)r->stat_words, st));
-    DFQ_HIP_TRY(hipMemsetAsync(r->d_sync, 0, sizeof(u64) * r->sync_words, st));
-    DFQ_HIP_TRY(hipMemsetAsync(r->d_partials, 0, sizeof(double) * 6 * (size_t)r->n_tiles, st));
+    clear_buffers(st, r->d_stats, sizeof(u64) * (size_t)r->stat_words, r->d_sync, sizeof(u64) * r->sync_words,
+                  r->d_partials, sizeof(double) * 6 * (size_t)r->n_tiles);
+    DFQ_CHECK_LAUNCH();
     ResArgs a;
     memset(&a, 0, sizeof(a));
     a.tiles = r->d_tiles; a.rels = r->d_rels; a.layer_diff = r->d_layer_diff;

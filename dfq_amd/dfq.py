@@ -306,6 +306,22 @@ def _dev_ptr(t, dev):
     return t.data_ptr()
 
 
+_t_dev, _t_contig, _t_ptr = torch.Tensor.get_device, torch.Tensor.is_contiguous, torch.Tensor.data_ptr
+
+
+def _dev_ptrs(tensors, dev):
+    """_dev_ptr of a whole list (a batch of 32 MobileNetV2 has some 7 000 tensors: one pass per check, no Python per tensor
+    beyond the method calls themselves) as a uint64 array, or None if one of them cannot be used in place"""
+    if dev.type == 'cuda':
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    else:
+        idx = -1
+    f32 = torch.float32
+    if not all(map(_t_contig, tensors)) or any(t.dtype is not f32 for t in tensors) or set(map(_t_dev, tensors)) - {idx}:
+        return None
+    return _np.fromiter(map(_t_ptr, tensors), dtype=_np.uint64, count=len(tensors))
+
+
 def _le_template(graph, relations, targ_type):
     tt = tuple(targ_type)
     mods = [(k, m) for k, m in graph.items() if type(m) in tt]
@@ -322,39 +338,52 @@ def _le_template(graph, relations, targ_type):
             for d in w.shape[2:]:
                 khkw *= int(d)
             geo.append((int(w.shape[0]), int(w.shape[1]), khkw, int(getattr(graph[k], 'groups', 1))))
-        t = dict(keys=keys, geo=_np.array(geo, dtype=_np.int32).reshape(len(keys), 4),
-                 rel=[(index[a], index[b], c) for (a, b, c) in (rr.get_idxs() for rr in relations)],
+        rel = [(index[a], index[b], c) for (a, b, c) in (rr.get_idxs() for rr in relations)]
+        t = dict(keys=keys, geo=_np.array(geo, dtype=_np.int32).reshape(len(keys), 4), rel=rel,
+                 rel_idx=_np.array([(a, b) for (a, b, _) in rel], dtype=_np.int32).reshape(len(rel), 2),
                  firsts=sorted({index[rr.get_idxs()[0]] for rr in relations}),
                  o1=[int(graph[rr.get_idxs()[0]].weight.shape[0]) for rr in relations])
         _structure_cache[sig] = t
     return t
 
 
+def _attr(mod, name):
+    """getattr(mod, name, None) for an nn.Module without the detour through Module.__getattr__ (table building reads some
+    ten thousand attributes per batch)"""
+    d = mod.__dict__
+    v = d.get(name)
+    if v is None:
+        v = d['_parameters'].get(name)
+        if v is None:
+            v = d['_buffers'].get(name)
+    return v
+
+
 def _fast_le_tables(items, targ_type, dev):
-    """struct arrays for a batched LE plan, or None if some tensor needs the general (shadow-copy) path"""
+    """struct arrays for a batched LE plan, or None if some tensor needs the general (shadow-copy) path.  The structure of a
+    network (geometry, relation indices) comes from a template shared by every network with the same graph; only the
+    tensors' addresses are gathered per network, and those in one pass over the whole batch."""
     T = _Tables()
-    lay, rel, net_of = [], [], []
+    geo, net_of, first, second = [], [], [], []
+    tens = []                                     # every tensor whose address goes into a table ...
+    w_pos, b_row, b_pos, s_pos, fw_row, fw_pos, fb_row, fb_pos = [], [], [], [], [], [], [], []   # ... and where it goes
+    n_lay = n_rel = 0
     for net, (graph, relations) in enumerate(items):
         t = _le_template(graph, relations, targ_type)
         mods = [graph[k] for k in t['keys']]
         for i in t['firsts']:                                 # dfq.py:91-92
             _ensure_bias(mods[i])
         n = len(mods)
-        arr = _np.zeros(n, dtype=_LAYER_DT)
         for i, m in enumerate(mods):
-            pw = _dev_ptr(m.weight, dev)
-            if pw is None:
-                return None
-            arr['weight'][i] = pw
-            b = m.bias
+            prm = m.__dict__['_parameters']
+            w_pos.append(len(tens))
+            tens.append(prm['weight'])
+            b = prm.get('bias')
             if b is not None:
-                pb = _dev_ptr(b, dev)
-                if pb is None:
-                    return None
-                arr['bias'][i] = pb
-        arr['out_ch'], arr['in_per_group'], arr['khkw'], arr['groups'] = t['geo'][:, 0], t['geo'][:, 1], t['geo'][:, 2], t['geo'][:, 3]
-        base = sum(len(a) for a in lay)
-        lay.append(arr)
+                b_row.append(n_lay + i)
+                b_pos.append(len(tens))
+                tens.append(b)
+        geo.append(t['geo'])
         net_of.append(_np.full(n, net, dtype=_np.int32))
         # cumulative scale vectors: relations that have none yet share one flat allocation (one launch instead of one per relation)
         missing = [j for j, rr in enumerate(relations) if rr.S is None]
@@ -362,32 +391,44 @@ def _fast_le_tables(items, targ_type, dev):
             flat = torch.ones(sum(t['o1'][j] for j in missing), dtype=torch.float32, device=dev)
             for j, v in zip(missing, flat.split([t['o1'][j] for j in missing])):
                 relations[j].S = v
-        ra = _np.zeros(len(relations), dtype=_REL_DT)
         for j, (rr, (i1, i2, kb)) in enumerate(zip(relations, t['rel'])):
-            ps = _dev_ptr(rr.S, dev)
-            if ps is None:
-                return None
-            ra['first'][j], ra['second'][j], ra['scale_cum'][j] = base + i1, base + i2, ps
+            s_pos.append(len(tens))
+            tens.append(rr.S)
             if kb is not None:
                 bn = graph[kb]
-                fw, fb = getattr(bn, 'fake_weight', None), getattr(bn, 'fake_bias', None)
+                fw, fb = _attr(bn, 'fake_weight'), _attr(bn, 'fake_bias')
                 if fw is not None:
-                    pf = _dev_ptr(fw, dev)
-                    if pf is None:
-                        return None
-                    ra['bn_weight'][j] = pf
+                    fw_row.append(n_rel + j)
+                    fw_pos.append(len(tens))
+                    tens.append(fw)
                 if fb is not None:
-                    pf = _dev_ptr(fb, dev)
-                    if pf is None:
-                        return None
-                    ra['bn_bias'][j] = pf
+                    fb_row.append(n_rel + j)
+                    fb_pos.append(len(tens))
+                    tens.append(fb)
             T.scale_cum.append(rr.S)
-        rel.append(ra)
+        if t['rel']:
+            ri = t['rel_idx']
+            first.append(ri[:, 0] + n_lay)
+            second.append(ri[:, 1] + n_lay)
+        n_lay += n
+        n_rel += len(relations)
         T.keep.append((mods, relations))
-    T.arrays['layers'] = _cat(lay, _LAYER_DT)
-    T.arrays['relations'] = _cat(rel, _REL_DT) if rel else _np.zeros(1, dtype=_REL_DT)
-    T.arrays['layer_net'] = _np.concatenate(net_of)
-    T.n_layers, T.n_relations, T.n_nets = len(T.arrays['layers']), sum(len(a) for a in rel), len(items)
+    ptr = _dev_ptrs(tens, dev)
+    if ptr is None:
+        return None
+    lay = _np.zeros(n_lay, dtype=_LAYER_DT)
+    g = _np.concatenate(geo)
+    lay['out_ch'], lay['in_per_group'], lay['khkw'], lay['groups'] = g[:, 0], g[:, 1], g[:, 2], g[:, 3]
+    lay['weight'] = ptr[w_pos]
+    lay['bias'][b_row] = ptr[b_pos]
+    rel = _np.zeros(max(1, n_rel), dtype=_REL_DT)
+    if n_rel:
+        rel['first'][:n_rel], rel['second'][:n_rel] = _np.concatenate(first), _np.concatenate(second)
+        rel['scale_cum'][:n_rel] = ptr[s_pos]
+        rel['bn_weight'][fw_row] = ptr[fw_pos]
+        rel['bn_bias'][fb_row] = ptr[fb_pos]
+    T.arrays['layers'], T.arrays['relations'], T.arrays['layer_net'] = lay, rel, _np.concatenate(net_of)
+    T.n_layers, T.n_relations, T.n_nets = n_lay, n_rel, len(items)
     return T
 
 
@@ -395,7 +436,8 @@ def _bc_template(graph, bottoms, targ_type, bn_type):
     tt = tuple(targ_type)
     mods = [(k, m) for k, m in graph.items() if type(m) in tt]
     keys = [k for k, _ in mods]
-    sig = ('bc', tuple(graph.keys()), tuple(map(type, graph.values())), str(list(bottoms.values())),
+    sig = ('bc', tuple(graph.keys()), tuple(map(type, graph.values())),
+           tuple([tuple(b) if isinstance(b, (list, tuple)) else b for b in bottoms.values()]),
            tuple(m._parameters['weight'].shape for _, m in mods), tuple(getattr(m, 'groups', 1) for _, m in mods))
     t = _structure_cache.get(sig)
     if t is None:
@@ -419,74 +461,96 @@ def _bc_template(graph, bottoms, targ_type, bn_type):
             for d in w.shape[2:]:
                 khkw *= int(d)
             geo.append((int(w.shape[0]), int(w.shape[1]), khkw, int(getattr(graph[k], 'groups', 1))))
-        t = dict(keys=keys, geo=_np.array(geo, dtype=_np.int32).reshape(len(keys), 4), steps=tsteps,
-                 bias_layers=sorted({li for (li, _, _) in tsteps}))
+        geo = _np.array(geo, dtype=_np.int32).reshape(len(keys), 4)
+        # everything but the addresses: the step / source rows with network-relative indices, and which (graph key, attribute)
+        # goes where
+        step_arr = _np.zeros(len(tsteps), dtype=_STEP_DT)
+        step_next, src_fw, src_fb, rows = [], [], [], []
+        for j, (li, srcs, nxt) in enumerate(tsteps):
+            step_arr['layer'][j], step_arr['source_begin'][j], step_arr['source_count'][j] = li, len(rows), len(srcs)
+            if nxt is not None:
+                step_next.append((j, nxt))
+            for (fw, fb, ch, relu, cat) in srcs:
+                if fw is not None:
+                    src_fw.append((len(rows), fw))
+                src_fb.append((len(rows), fb))
+                rows.append((ch, int(relu), int(cat)))
+        src_arr = _np.zeros(len(rows), dtype=_SRC_DT)
+        if rows:
+            cols = list(zip(*rows))
+            src_arr['channels'], src_arr['relu'], src_arr['concat'] = cols[0], cols[1], cols[2]
+        t = dict(keys=keys, geo=geo, steps=tsteps, bias_layers=sorted({li for (li, _, _) in tsteps}),
+                 step_arr=step_arr, src_arr=src_arr, step_next=step_next, src_fw=src_fw, src_fb=src_fb,
+                 step_out_ch=[int(geo[li, 0]) for (li, _, _) in tsteps], step_in=[int(geo[li, 1]) for (li, _, _) in tsteps])
         _structure_cache[sig] = t
     return t
 
 
 def _fast_bc_tables(items, targ_type, bn_type, dev):
     T = _Tables()
-    lay, stp, src = [], [], []
+    geo, steps, srcs = [], [], []
     T.step_out_ch, T.step_in = [], []
-    n_src = 0
+    tens = []
+    w_pos, b_row, b_pos, nx_row, nx_pos, sw_row, sw_pos, sb_row, sb_pos = [], [], [], [], [], [], [], [], []
+    n_lay = n_stp = n_src = 0
     for net, (graph, bottoms) in enumerate(items):
         t = _bc_template(graph, bottoms, targ_type, bn_type)
         mods = [graph[k] for k in t['keys']]
         for li in t['bias_layers']:
             _ensure_bias(mods[li])
-        n = len(mods)
-        base = sum(len(a) for a in lay)
-        arr = _np.zeros(n, dtype=_LAYER_DT)
         for i, m in enumerate(mods):
-            pw = _dev_ptr(m.weight, dev)
-            if pw is None:
-                return None
-            arr['weight'][i] = pw
-            if m.bias is not None:
-                pb = _dev_ptr(m.bias, dev)
-                if pb is None:
-                    return None
-                arr['bias'][i] = pb
-        arr['out_ch'], arr['in_per_group'], arr['khkw'], arr['groups'] = t['geo'][:, 0], t['geo'][:, 1], t['geo'][:, 2], t['geo'][:, 3]
-        lay.append(arr)
-        ptr_of = {}
+            prm = m.__dict__['_parameters']
+            w_pos.append(len(tens))
+            tens.append(prm['weight'])
+            b = prm.get('bias')
+            if b is not None:
+                b_row.append(n_lay + i)
+                b_pos.append(len(tens))
+                tens.append(b)
+        geo.append(t['geo'])
+        pos_of = {}
 
-        def addr(ref):
-            if ref is None:
-                return 0
-            p = ptr_of.get(ref)
-            if p is None:
-                p = _dev_ptr(getattr(graph[ref[0]], ref[1]), dev)
-                ptr_of[ref] = p if p is not None else -1
-            return ptr_of[ref]
-        sa = _np.zeros(len(t['steps']), dtype=_STEP_DT)
-        rows = []
-        for j, (li, srcs, nxt) in enumerate(t['steps']):
-            sa['layer'][j], sa['source_begin'][j], sa['source_count'][j], sa['net'][j] = base + li, n_src + len(rows), len(srcs), net
-            p = addr(nxt)
-            if p == -1:
-                return None
-            sa['next_bn_bias'][j] = p
-            for (fw, fb, ch, relu, cat) in srcs:
-                a, b = addr(fw), addr(fb)
-                if a == -1 or b == -1:
-                    return None
-                rows.append((a, b, ch, int(relu), int(cat)))
-            T.step_out_ch.append(int(t['geo'][li, 0]))
-            T.step_in.append(int(t['geo'][li, 1]))
-        ra = _np.zeros(len(rows), dtype=_SRC_DT)
-        if rows:
-            cols = list(zip(*rows))
-            ra['fake_weight'], ra['fake_bias'], ra['channels'], ra['relu'], ra['concat'] = cols[0], cols[1], cols[2], cols[3], cols[4]
-        n_src += len(rows)
-        stp.append(sa)
-        src.append(ra)
+        def pos(ref):
+            q = pos_of.get(ref)
+            if q is None:
+                q = pos_of[ref] = len(tens)
+                tens.append(_attr(graph[ref[0]], ref[1]))
+            return q
+        for j, ref in t['step_next']:
+            nx_row.append(n_stp + j)
+            nx_pos.append(pos(ref))
+        for r, ref in t['src_fw']:
+            sw_row.append(n_src + r)
+            sw_pos.append(pos(ref))
+        for r, ref in t['src_fb']:
+            sb_row.append(n_src + r)
+            sb_pos.append(pos(ref))
+        sa = t['step_arr'].copy()
+        sa['layer'] += n_lay
+        sa['source_begin'] += n_src
+        sa['net'] = net
+        steps.append(sa)
+        srcs.append(t['src_arr'])
+        T.step_out_ch.extend(t['step_out_ch'])
+        T.step_in.extend(t['step_in'])
+        n_lay += len(mods)
+        n_stp += len(sa)
+        n_src += len(t['src_arr'])
         T.keep.append((mods, graph))
-    T.arrays['layers'] = _cat(lay, _LAYER_DT)
-    T.arrays['steps'] = _cat(stp, _STEP_DT)
-    T.arrays['sources'] = _cat(src, _SRC_DT)
-    T.n_layers, T.n_steps, T.n_sources = len(T.arrays['layers']), len(T.arrays['steps']), n_src
+    ptr = _dev_ptrs(tens, dev)
+    if ptr is None:
+        return None
+    lay = _np.zeros(n_lay, dtype=_LAYER_DT)
+    g = _np.concatenate(geo)
+    lay['out_ch'], lay['in_per_group'], lay['khkw'], lay['groups'] = g[:, 0], g[:, 1], g[:, 2], g[:, 3]
+    lay['weight'] = ptr[w_pos]
+    lay['bias'][b_row] = ptr[b_pos]
+    stp, src = _cat(steps, _STEP_DT), _cat(srcs, _SRC_DT)
+    stp['next_bn_bias'][nx_row] = ptr[nx_pos]
+    src['fake_weight'][sw_row] = ptr[sw_pos]
+    src['fake_bias'][sb_row] = ptr[sb_pos]
+    T.arrays['layers'], T.arrays['steps'], T.arrays['sources'] = lay, stp, src
+    T.n_layers, T.n_steps, T.n_sources = n_lay, n_stp, n_src
     return T
 
 

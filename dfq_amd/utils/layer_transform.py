@@ -25,6 +25,9 @@ _LINEAR_TYPES = (nn.Linear, QLinear, QuantLinear, QuantNLinear)
 
 def _ensure_bias(layer):
     """The reference adds a zero bias Parameter when a layer has none (layer_transform.py:253-254)."""
+    b = layer.__dict__['_parameters'].get('bias')        # (not layer.bias: Module.__getattr__ is the slow path, and table
+    if b is not None:                                     # building asks thousands of layers)
+        return b
     if layer.bias is None:
         layer.bias = nn.Parameter(torch.zeros(layer.weight.size(0), dtype=torch.float32,
                                               device=layer.weight.device), requires_grad=False)

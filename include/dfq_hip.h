@@ -125,7 +125,8 @@ int64_t dfq_le_plan_paired_elements(const dfq_le_plan* plan);   /* sum over rela
  * interior layers (4 B each); algorithmic bytes of a sweep = 8 * rw + 4 * ro */
 int64_t dfq_le_plan_rw_elements(const dfq_le_plan* plan);
 int64_t dfq_le_plan_ro_elements(const dfq_le_plan* plan);
-/* Deferred stores of the streaming engine (DFQ_LE_DEFER = depth D at plan creation: 2 by default, 1 = off, 4): a layer
+/* Deferred stores of the streaming engine (DFQ_LE_DEFER = depth D at plan creation: 1 = off, 2 or 4; default 4 for batched
+ * plans, 1 for a single network): a layer
  * that is only ever scaled one way is read every sweep but written every D-th one, the sweeps in between re-derive its
  * values from the stored ones and the remembered factors -- the same float32 operations, bit-identical results; every
  * enqueue call ends by bringing the weights up to date.  deferred_elements (a part of rw_elements) are those layers'
