@@ -1720,7 +1720,9 @@ int dfq_le_plan_create_batch(const dfq_layer* layers, int32_t n_layers, const in
             const int64_t rows_work = (as_second[rr.first] < 0) ? (int64_t)nc * d.row_len : 0;
             const int64_t cols_work = (int64_t)nc * d.khkw * d.go;
             const char* be = getenv("DFQ_LE_BOOT_WORK");          // tests: split small layers too
-            const int64_t unit = (be && atoi(be) > 0) ? atoi(be) : kBootWork;
+            // (a single network is bound by the number of workgroups in flight: half the span -- ResNet-18's restart + two
+            // sweeps 0.119 -> 0.105 ms)
+            const int64_t unit = (be && atoi(be) > 0) ? atoi(be) : (n_nets == 1 ? kBootWork / 2 : kBootWork);
             const int64_t want = (std::max(rows_work, cols_work) + unit - 1) / unit;
             d.boot_split = (int)std::max<int64_t>(1, std::min<int64_t>(want, std::min<int64_t>(64, std::max(1, be ? d.go : d.go / 8))));
         }
@@ -2271,9 +2273,11 @@ int dfq_le_trace(dfq_le_plan* p, const dfq_le_config* cfg, int32_t launch, int32
     DFQ_HIP_TRY(hipMalloc((void**)&d, 16 * sizeof(long long)));
     DFQ_HIP_TRY(hipMemsetAsync(d, 0, 16 * sizeof(long long), st));
     int rc = le_restart(p, cfg, st);
-    for (int s = 0; s < 2 && !rc; ++s) {          // trace the second sweep (steady-state stat flow)
+    const char* te = getenv("DFQ_TRACE_SWEEP");    // default: the second sweep (steady-state stat flow)
+    const int traced = (te && atoi(te) >= 0) ? atoi(te) : 1;
+    for (int s = 0; s <= traced && !rc; ++s) {
         for (int l = 0; l < dfq_le_plan_levels(p) && !rc; ++l)
-            rc = le_launch_level(p, l, q, st, (s == 1 && l == launch) ? LeTrace{d, block, 0} : LeTrace{nullptr, 0, 0});
+            rc = le_launch_level(p, l, q, st, (s == traced && l == launch) ? LeTrace{d, block, 0} : LeTrace{nullptr, 0, 0});
         if (!rc) rc = le_launch_control(p, cfg, st);
     }
     if (!rc) rc = le_flush(p, st);

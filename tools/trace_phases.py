@@ -10,7 +10,8 @@ import bench
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 dev = torch.device('cuda', 0)
 protos = [bench.prepare('mobilenet_v2', seed=i, dev=dev) for i in range(batch)]
-for launch in (2, 3):
+unit = bench.make_unit(protos)
+for launch in range(unit['le'].levels):
     unit = bench.make_unit(protos)
     info = unit['le'].level_info(launch)
     n = info['grid'][0] * info['grid'][1]
@@ -18,4 +19,5 @@ for launch in (2, 3):
         unit = bench.make_unit(protos)
         st = unit['le'].trace(launch, block)
         d = [round((st[i] - st[0]) / 2.1) if st[i] else -1 for i in range(1, 8)]   # ~2.1 GHz shader clock -> ns
-        print('launch %d block %5d of %5d: ns since entry %s' % (launch, block, n, d))
+        bi = unit['le'].block_info(launch, block)
+        print('launch %d block %5d of %5d kind %d %4dx%-4d rw %6d ro %6d: ns since entry %s' % (launch, block, n, bi['kind'], bi['rows'], bi['cols'], bi['rw_elements'], bi['ro_elements'], d))
