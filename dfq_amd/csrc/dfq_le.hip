@@ -1539,6 +1539,16 @@ static int plain_row_cols_max(int vec) {
     if (v > 0) return std::min(v, vec == 4 ? 1024 : 256);
     return kRowTileColsMax * (vec == 4 ? 2 : 1);
 }
+// columns of a col tile: every column costs the tile four statistics words (and the remembered factors of deferred stores)
+// whatever its height, so narrow tall tiles read fewer of them per element; DFQ_LE_COL_COLS overrides (tuning)
+// (batch of 32 MobileNetV2: 256 / 128 / 64 / 32 floats -> 175 / 174 / 168 / 177 us per forced sweep; a 32 x 240 tile reads
+// 6.7 KB of statistics and factors for 30 KB of elements, a 128 x 64 tile 1.8 KB)
+static int col_cols_max(int vec, bool batched) {
+    const char* e = getenv("DFQ_LE_COL_COLS");
+    const int v = e ? atoi(e) : 0;
+    if (v > 0) return std::min(v, kColTileLanes * vec);
+    return (batched && vec == 4) ? 64 : kColTileLanes * vec;
+}
 static int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
 // [rows x cols] tiling of a [n_rows, row_len] matrix whose tiles move `vec`-wide vectors:
@@ -1702,7 +1712,7 @@ int dfq_le_plan_create_batch(const dfq_layer* layers, int32_t n_layers, const in
         tile_shape(d.o1, d.row_len, d.rt_vec,
                    emits_cols ? emit_cols_max(d.rt_vec) : plain_row_cols_max(d.rt_vec), false, target,
                    &d.rt_rows, &d.rt_cols, &d.rt_slabs);
-        tile_shape(d.o2, row_len2, d.ct_vec, kColTileLanes * d.ct_vec, true, target,
+        tile_shape(d.o2, row_len2, d.ct_vec, col_cols_max(d.ct_vec, n_nets > 1), true, target,
                    &d.ct_rows, &d.ct_cols, &d.ct_slabs);
         const bool allow_short = getenv("DFQ_LE_NO_SHORT") == nullptr;
         if (allow_short && d.i2g == 1 && d.khkw <= 32 && d.khkw != 1) {     // depthwise second layer: one thread per row
