@@ -860,9 +860,16 @@ __global__ __launch_bounds__(kBlock, DFQ_LE_MIN_WAVES) void le_level_kernel(cons
         const guint* src = (lane < kDescWords) ? (const guint*)(table + rel) + lane : (const guint*)&state[net].done;
         if (lane <= kDescWords) word = *src;
     }
+    // Only the fields the tile's side reads are broadcast into scalar registers (the others stay zero constants): the whole
+    // descriptor is 57 of the ~100 scalar registers a wave has, and every field beyond the budget costs a spill move per use.
     union { LeRelDev R; uint32_t u[kDescWords]; } desc;
 #pragma unroll
-    for (int i = 0; i < kDescWords; ++i) desc.u[i] = __builtin_amdgcn_readlane(word, i);
+    for (int i = 0; i < kDescWords; ++i) desc.u[i] = 0u;
+#define DFQ_TAKE(f)                                                                                                          \
+    _Pragma("unroll") for (int i_ = 0; i_ < (int)(sizeof(desc.R.f) / 4); ++i_)                                               \
+        desc.u[offsetof(LeRelDev, f) / 4 + i_] = __builtin_amdgcn_readlane(word, (int)(offsetof(LeRelDev, f) / 4) + i_)
+    DFQ_TAKE(n_row_tiles); DFQ_TAKE(n_col_tiles); DFQ_TAKE(partial_base); DFQ_TAKE(counter_idx);
+    DFQ_TAKE(dep_idx); DFQ_TAKE(dep_tiles); DFQ_TAKE(r1); DFQ_TAKE(r2); DFQ_TAKE(stat_stride); DFQ_TAKE(hold); DFQ_TAKE(defer); DFQ_TAKE(o1);
     const uint32_t done = __builtin_amdgcn_readlane(word, kDescWords);
     const LeRelDev& R = desc.R;
     const int cur = sweep & 1;
@@ -874,6 +881,15 @@ __global__ __launch_bounds__(kBlock, DFQ_LE_MIN_WAVES) void le_level_kernel(cons
 
     double acc;
     const bool col_side = tile >= R.n_row_tiles;
+    if (!col_side) {
+        DFQ_TAKE(w1); DFQ_TAKE(b1); DFQ_TAKE(bnw); DFQ_TAKE(bnb); DFQ_TAKE(s_cum); DFQ_TAKE(prev_r1); DFQ_TAKE(out_cols);
+        DFQ_TAKE(row_len); DFQ_TAKE(khkw1); DFQ_TAKE(pc_go); DFQ_TAKE(pc_gi);
+        DFQ_TAKE(rt_rows); DFQ_TAKE(rt_cols); DFQ_TAKE(rt_slabs); DFQ_TAKE(rt_vec); DFQ_TAKE(w1_interior);
+    } else {
+        DFQ_TAKE(w2); DFQ_TAKE(out_rows); DFQ_TAKE(o2); DFQ_TAKE(gi); DFQ_TAKE(go); DFQ_TAKE(i2g); DFQ_TAKE(khkw);
+        DFQ_TAKE(ct_rows); DFQ_TAKE(ct_cols); DFQ_TAKE(ct_slabs); DFQ_TAKE(ct_vec); DFQ_TAKE(w2_interior);
+    }
+#undef DFQ_TAKE
     if (!col_side) {
         if (R.rt_vec == 0) acc = dep_wait(R, dep, p.poll_naps, p.spin_limit, &sh_flag) ? short_tile<0>(R, p, tile, cur) : kTileAbandoned;
         else if (R.rt_vec == 4) { float v[kSlotsVec4][4]; acc = row_tile<4, false>(R, p, tile, cur, dep, false, v, nothing, sh_f, sh_u, sh_g, sh_p, &sh_flag, tr); }
