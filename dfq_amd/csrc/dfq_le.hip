@@ -833,11 +833,15 @@ static_assert(sizeof(LeRelDev) % 4 == 0 && kDescWords + 1 <= kWave, "descriptor 
 #ifndef DFQ_LE_MIN_WAVES
 #define DFQ_LE_MIN_WAVES 1
 #endif
+// kTrace: the tuning instantiation that honours `tr_arg` (dfq_le_trace*); the production one sees a constant null trace, so the
+// eight stamp sites and the four scalar registers of the argument vanish.
+template <bool kTrace>
 __global__ __launch_bounds__(kBlock, DFQ_LE_MIN_WAVES) void le_level_kernel(const LeRelDev* __restrict__ table,
                                                           const LeBlockRef* __restrict__ blocks, LeParams p, int sweep,
                                                           const LeState* __restrict__ state,
                                                           double* __restrict__ partials, unsigned long long* dep_counters,
-                                                          unsigned long long* err, LeTrace tr) {
+                                                          unsigned long long* err, LeTrace tr_arg) {
+    LeTrace tr = kTrace ? tr_arg : LeTrace{nullptr, 0, 0};
     tr.flat = (int)blockIdx.x;
     stamp(tr, 0);
     __shared__ float sh_f[kSlotMax];                // row tile: scales; col tile: 1/s table
@@ -2141,9 +2145,14 @@ static int le_launch_level(dfq_le_plan* p, int launch, const LeParams& q, hipStr
         DFQ_CHECK_LAUNCH();
         return DFQ_OK;
     }
-    hipLaunchKernelGGL(le_level_kernel, dim3(count), dim3(kBlock), 0, st, (const LeRelDev*)p->d_rels,
-                       (const LeBlockRef*)(p->d_blocks + begin), q, (int)p->sweep_index, (const LeState*)p->d_state,
-                       p->d_partials, p->d_dep, p->d_dep + (size_t)p->n_rels * kDepStride, tr);
+    if (tr.out)
+        hipLaunchKernelGGL(le_level_kernel<true>, dim3(count), dim3(kBlock), 0, st, (const LeRelDev*)p->d_rels,
+                           (const LeBlockRef*)(p->d_blocks + begin), q, (int)p->sweep_index, (const LeState*)p->d_state,
+                           p->d_partials, p->d_dep, p->d_dep + (size_t)p->n_rels * kDepStride, tr);
+    else
+        hipLaunchKernelGGL(le_level_kernel<false>, dim3(count), dim3(kBlock), 0, st, (const LeRelDev*)p->d_rels,
+                           (const LeBlockRef*)(p->d_blocks + begin), q, (int)p->sweep_index, (const LeState*)p->d_state,
+                           p->d_partials, p->d_dep, p->d_dep + (size_t)p->n_rels * kDepStride, tr);
     DFQ_CHECK_LAUNCH();
     return DFQ_OK;
 }
