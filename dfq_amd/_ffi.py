@@ -11,6 +11,7 @@ import os
 from ctypes import (POINTER, Structure, c_char_p, c_double, c_float, c_int32, c_int64,
                     c_size_t, c_void_p)
 
+import numpy as np
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -227,6 +228,51 @@ def ptr(t):
     return None if t is None else c_void_p(t.data_ptr())
 
 
+def _pinned(n):
+    """float32 host buffer for a packed transfer: page-locked when the target is a GPU (torch's host allocator caches the
+    blocks).  A synchronous copy between the device and PAGEABLE memory -- what `.to()` does -- stalled for 60-90 ms every
+    few calls on the MI355X boxes, whatever its size (even the 64 KB of the scale vectors); copies through page-locked
+    memory that are enqueued on the stream and waited for with a stream synchronisation do not."""
+    return torch.empty(n, dtype=torch.float32, pin_memory=(target_device().type == 'cuda'))
+
+
+_NP_OK = (torch.float32, torch.float64, torch.float16)
+
+
+def _host_copy(pack_np, pack_t, t, to_pack):
+    """One host-side copy between a caller's CPU tensor `t` and its slot of a packed buffer (converts dtype, follows strides).
+    Through numpy where it can: torch's copy_ of a large tensor is an OpenMP parallel-for, and on a host whose cores are not
+    all available at once (the GPU boxes are VMs) the team's barrier stalled for 60-280 ms every few calls; a plain
+    single-threaded memcpy of a network's 14 MB is 2-3 ms."""
+    if t.dtype in _NP_OK:
+        a = t.numpy()
+        if to_pack:
+            np.copyto(pack_np, a, casting='same_kind')
+        else:
+            np.copyto(a, pack_np, casting='same_kind')
+    elif to_pack:
+        pack_t.copy_(t)
+    else:
+        t.copy_(pack_t)
+
+
+def _to_device(host, device):
+    if device.type != 'cuda':
+        return host.to(device)
+    flat = torch.empty(host.numel(), dtype=torch.float32, device=device)
+    flat.copy_(host, non_blocking=True)          # ordered on the current stream before every kernel that reads it
+    return flat
+
+
+def _to_host(flat):
+    if flat.device.type != 'cuda':
+        return flat.to('cpu')
+    host = _pinned(flat.numel())
+    host.copy_(flat.reshape(-1), non_blocking=True)
+    torch.cuda.current_stream().synchronize()
+    return host
+
+
 class Stage:
     """Binds torch tensors to float32 contiguous device buffers for one engine call.
 
@@ -240,6 +286,45 @@ class Stage:
         self.device = target_device()
         self._bound = {}
         self._shadow = []
+        self._packs = []          # (flat device buffer, [(caller's tensor, offset, numel)]) of prefetch()
+        self._hosts = []
+
+    _ALIGN = 64                   # floats: every packed tensor starts on a 256-byte boundary (the kernels' 16-byte vectors)
+
+    def prefetch(self, tensors):
+        """Shadow every tensor of `tensors` that is not usable in place with ONE host-to-device copy: the tensors are packed
+        into one host buffer (float32, contiguous), copied once, and bound to views of one flat device buffer.  A CPU-resident
+        MobileNetV2 is ~250 tensors; one synchronous copy each way per tensor was 40-150 ms per entry point, packed it is the
+        14 MB over PCIe plus two host memcpys.  Later bind() calls find the tensors bound."""
+        todo, seen = [], set()
+        for t in tensors:
+            if t is None or id(t) in self._bound or id(t) in seen:
+                continue
+            if t.device == self.device and t.dtype == torch.float32 and t.is_contiguous():
+                continue
+            if t.device.type != 'cpu' or t.numel() == 0:
+                continue                                  # another device / empty: bind() handles it one by one
+            seen.add(id(t))
+            todo.append(t)
+        if len(todo) < 2:
+            return
+        offs, total = [], 0
+        for t in todo:
+            offs.append(total)
+            total += -(-t.numel() // self._ALIGN) * self._ALIGN
+        host = _pinned(total)
+        hn = host.numpy()
+        with torch.no_grad():
+            for t, o in zip(todo, offs):
+                _host_copy(hn[o:o + t.numel()].reshape(t.shape), host[o:o + t.numel()].view(t.shape), t.detach(), to_pack=True)
+        flat = _to_device(host, self.device)
+        self._hosts.append(host)                  # alive until the stage goes (the copy may still be in flight)
+        items = []
+        for t, o in zip(todo, offs):
+            buf = flat[o:o + t.numel()].view(t.shape)
+            self._bound[id(t)] = (t, buf)
+            items.append((t, o, t.numel()))
+        self._packs.append((flat, items))
 
     def bind(self, t):
         if t is None:
@@ -268,8 +353,25 @@ class Stage:
 
     def writeback(self):
         with torch.no_grad():
+            for flat, items in self._packs:               # one device-to-host copy per pack, then host-side copies
+                host = _to_host(flat)
+                hn = host.numpy()
+                for t, o, n in items:
+                    _host_copy(hn[o:o + n].reshape(t.shape), host[o:o + n].view(t.shape), t.detach(), to_pack=False)
             for t, buf in self._shadow:
                 t.data.copy_(buf.to(t.device, t.dtype) if (buf.device != t.device or buf.dtype != t.dtype) else buf)
+
+    def out_like_many(self, t, bufs):
+        """out_like for a list of device tensors with ONE transfer (independent tensors on the caller's device)."""
+        if not bufs or bufs[0].device == t.device:
+            return list(bufs)
+        flat = torch.cat([b.reshape(-1) for b in bufs])
+        flat = _to_host(flat) if t.device.type == 'cpu' else flat.to(t.device)
+        outs, at = [], 0
+        for b in bufs:
+            outs.append(flat[at:at + b.numel()].view(b.shape).clone())
+            at += b.numel()
+        return outs
 
     def out_like(self, t, buf):
         """Return `buf` on the device/dtype the caller's tensor `t` lives on."""

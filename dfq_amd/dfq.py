@@ -68,6 +68,8 @@ class LEPlan:
                                                            t.n_nets, t.ptr('relations', _ffi.DfqRelation), t.n_relations,
                                                            ctypes.byref(self._plan)))
             return
+        self.stage.prefetch([x for (w, b, g) in layers for x in (w, b)] +
+                            [x for (i1, i2, bnw, bnb, scum) in relations for x in (bnw, bnb, scum)])
         entries = []
         for (w, b, g) in layers:
             e, keep = _layer_entry(self.stage, w, b, g)
@@ -589,11 +591,17 @@ def build_le_plan(graph, relations, targ_type, stage=None):
         _ensure_bias(graph[rr.get_idxs()[0]])
     layers = [(graph[k].weight, graph[k].bias, getattr(graph[k], 'groups', 1)) for k in keys]
     rels = []
+    missing = [rr for rr in relations if rr.S is None]        # one allocation (one fill launch) for all new scale vectors
+    fresh = {}
+    if missing:
+        sizes = [int(graph[rr.get_idxs()[0]].weight.size(0)) for rr in missing]
+        for rr, v in zip(missing, torch.ones(sum(sizes), dtype=torch.float32, device=stage.device).split(sizes)):
+            fresh[id(rr)] = v
     for rr in relations:
         kf, ks, kb = rr.get_idxs()
         o1 = graph[kf].weight.size(0)
         if rr.S is None:
-            scum = torch.ones(o1, dtype=torch.float32, device=stage.device)
+            scum = fresh[id(rr)]
         else:
             scum = rr.S
         bn = graph[kb] if kb is not None else None
@@ -902,10 +910,11 @@ def cross_layer_equalization(graph, relations, targ_type, s_range=[1e-8, 1e8], r
             if key is None:
                 plan.close()
         stage.writeback()
-        for rr, sc in zip(relations, plan.scale_cum):
-            first = graph[rr.get_idxs()[0]].weight
-            out = stage.out_like(first, sc)
-            rr.S = out.clone() if key is not None else out    # Relation.set_scale_vec, cumulative
+        if relations:
+            first = graph[relations[0].get_idxs()[0]].weight
+            outs = stage.out_like_many(first, plan.scale_cum)                    # one transfer for a host-resident model
+            for rr, sc, out in zip(relations, plan.scale_cum, outs):
+                rr.S = out.clone() if (key is not None and out is sc) else out    # Relation.set_scale_vec, cumulative
     last_equalization = res
 
 
@@ -982,6 +991,8 @@ class BCPlan:
             _ffi.check(_ffi.lib().dfq_bc_plan_create(t.ptr('layers', _ffi.DfqLayer), t.n_layers, t.ptr('steps', _ffi.DfqBcStep), t.n_steps,
                                                      t.ptr('sources', _ffi.DfqBcSource), t.n_sources, ctypes.byref(self._plan)))
             return
+        self.stage.prefetch([x for (w, b, g) in layers for x in (w, b)] +
+                            [x for st in steps for (fw, fb, relu, concat) in st[1] for x in (fw, fb)] + [st[2] for st in steps])
         entries = []
         for (w, b, g) in layers:
             e, keep = _layer_entry(self.stage, w, b, g)

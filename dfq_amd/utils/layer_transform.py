@@ -44,6 +44,7 @@ def merge_batchnorm(model, graph, bottoms, targ_type=[QConv2d]):
     lib = _ffi.lib()
     with torch.no_grad():
         stage = _ffi.Stage()
+        pairs = []
         for key in graph:
             bots = bottoms[key]
             if bots is None:
@@ -56,23 +57,36 @@ def merge_batchnorm(model, graph, bottoms, targ_type=[QConv2d]):
                 if type(layer) not in targ_type:
                     continue
                 _ensure_bias(layer)
-                w = stage.bind(layer.weight)
-                b = stage.bind(layer.bias)
-                gamma, beta = stage.bind(bn.weight), stage.bind(bn.bias)
-                mean, var = stage.bind(bn.running_mean), stage.bind(bn.running_var)
-                fw = torch.empty_like(gamma)
-                fb = torch.empty_like(gamma)
-                _ffi.check(lib.dfq_fold_batchnorm(_ffi.ptr(w), _ffi.ptr(b), w.shape[0], w[0].numel(), _ffi.ptr(gamma),
-                                                  _ffi.ptr(beta), _ffi.ptr(mean), _ffi.ptr(var),
-                                                  ctypes.c_float(bn.eps), _ffi.ptr(fw), _ffi.ptr(fb),
-                                                  _ffi.stream_arg()))
-                bn.register_buffer('fake_weight', stage.out_like(bn.weight, fw))
-                bn.register_buffer('fake_bias', stage.out_like(bn.weight, fb))
-                # The reference sets eps = 0 (layer_transform.py:272); current PyTorch rejects eps <= 0 in
-                # F.batch_norm.  1e-12 is absorbed by float32 rounding (1 + 1e-12 == 1): the folded BN is still an
-                # exact identity and the model still runs.
-                bn.eps = 1e-12
+                pairs.append((layer, bn))
                 break
+        # a model that lives on the host crosses PCIe once each way: every tensor of every pair in one packed copy, the new
+        # per-channel vectors of all BatchNorms in one flat buffer that comes back in one copy
+        stage.prefetch([t for layer, bn in pairs for t in (layer.weight, layer.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var)])
+        fake = stage.new((2 * sum(bn.weight.numel() for _, bn in pairs),)) if pairs else None
+        outs, at = [], 0
+        for layer, bn in pairs:
+            w = stage.bind(layer.weight)
+            b = stage.bind(layer.bias)
+            gamma, beta = stage.bind(bn.weight), stage.bind(bn.bias)
+            mean, var = stage.bind(bn.running_mean), stage.bind(bn.running_var)
+            n = gamma.numel()
+            fw, fb = fake[at:at + n], fake[at + n:at + 2 * n]
+            _ffi.check(lib.dfq_fold_batchnorm(_ffi.ptr(w), _ffi.ptr(b), w.shape[0], w[0].numel(), _ffi.ptr(gamma),
+                                              _ffi.ptr(beta), _ffi.ptr(mean), _ffi.ptr(var),
+                                              ctypes.c_float(bn.eps), _ffi.ptr(fw), _ffi.ptr(fb),
+                                              _ffi.stream_arg()))
+            outs.append((bn, at, n))
+            at += 2 * n
+            # The reference sets eps = 0 (layer_transform.py:272); current PyTorch rejects eps <= 0 in
+            # F.batch_norm.  1e-12 is absorbed by float32 rounding (1 + 1e-12 == 1): the folded BN is still an
+            # exact identity and the model still runs.
+            bn.eps = 1e-12
+        host = {}
+        for bn, o, n in outs:
+            dev = bn.weight.device
+            src = fake if dev == fake.device else host.setdefault(dev, fake.to(dev))
+            bn.register_buffer('fake_weight', src[o:o + n].clone())
+            bn.register_buffer('fake_bias', src[o + n:o + 2 * n].clone())
         stage.writeback()
     return model
 
@@ -91,6 +105,7 @@ def quantize_targ_layer(graph, bit_weight=8, bits_bias=16, targ_type=None, retur
     with torch.no_grad():
         stage = _ffi.Stage()
         segs, keep, codes = [], [], {}
+        stage.prefetch([t for layer in graph.values() if type(layer) in targ_type for t in (layer.weight, layer.bias)])
         for key in graph:
             layer = graph[key]
             if type(layer) not in targ_type:

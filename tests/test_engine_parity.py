@@ -652,6 +652,45 @@ def test_host_resident_model_is_staged_and_written_back(engine):
         assert_bitexact(npy(r.get_scale_vec()), s)
 
 
+def test_packed_staging_of_foreign_tensors(engine):
+    """Tensors the kernels cannot use in place (here: a float64 model on the host -- on the GPU engine also simply a host
+    model) are shadowed through ONE packed copy each way (`Stage.prefetch`): same results as the float32 model, written back
+    into the caller's own tensors in their own dtype, weights of different layers not overlapping in the packed buffer."""
+    from dfq_amd import _ffi
+    gold = net_fixture('tiny_mobile', 0, '')
+    model32, graph32, bottoms32 = _build('tiny_mobile', 0, gold, Engine_cpu())
+    model64, graph64, bottoms64 = _build('tiny_mobile', 0, gold, Engine_cpu())
+    model64.double()
+    res = []
+    for model, graph, bottoms in ((model32, graph32, bottoms32), (model64, graph64, bottoms64)):
+        ids = {k: id(m.weight) for k, m in graph.items() if type(m) in TARG}
+        lt.merge_batchnorm(model, graph, bottoms, TARG)
+        rels = rel.create_relation(graph, bottoms, TARG)
+        dfq.cross_layer_equalization(graph, rels, TARG)
+        dfq.bias_correction(graph, bottoms, TARG)
+        lt.quantize_targ_layer(graph, 8, 16, TARG)
+        for k, m in graph.items():
+            if type(m) in TARG:
+                assert id(m.weight) == ids[k] and m.weight.device.type == 'cpu'
+        res.append((dfq.last_equalization['sweeps'], snapshot(graph)))
+    assert all(m.weight.dtype == torch.float64 for m in graph64.values() if type(m) in TARG)
+    assert res[0][0] == res[1][0]
+    for k in res[0][1]:
+        assert_bitexact(np.asarray(res[1][1][k], dtype=F32), res[0][1][k], 'float64 host model: {}'.format(k))
+    # the packing itself: one flat buffer, 256-byte aligned segments, views of the right shape, one copy back
+    st = _ffi.Stage()
+    a, b, c = torch.arange(5, dtype=torch.float64), torch.ones(3, 7, dtype=torch.float64)[:, ::2], torch.zeros(0, dtype=torch.float64)
+    st.prefetch([a, b, None, c, a])
+    assert len(st._packs) == 1 and len(st._packs[0][1]) == 2
+    da, db = st.bind(a), st.bind(b)
+    assert da.dtype == torch.float32 and tuple(db.shape) == (3, 4) and db.is_contiguous()
+    assert (db.data_ptr() - da.data_ptr()) == 4 * _ffi.Stage._ALIGN
+    da += 1
+    db *= 3
+    st.writeback()
+    assert a.tolist() == [1, 2, 3, 4, 5] and b.tolist() == [[3.0] * 4] * 3
+
+
 @pytest.mark.gpu
 def test_one_launch_sweep_is_stable_against_per_level_launches(monkeypatch):
     """Stress for the in-launch dependency protocol (device-scope atomics + sc1 loads across XCDs): a batch of
