@@ -1422,6 +1422,8 @@ struct LeFlushRef {
     int32_t rel;       // index into the level-sorted descriptor table
     int32_t side;      // 0: W1 (rows by s), 1: W2 (columns by 1/s)
     int64_t first;     // first element of the span
+    int32_t row0;      // its row and its position in that row (first = row0 * row_len + pos0)
+    int32_t pos0;
 };
 __global__ __launch_bounds__(kBlock) void le_flush_kernel(const LeRelDev* __restrict__ table, const LeFlushRef* __restrict__ refs,
                                                           const LeState* __restrict__ state, int depth) {
@@ -1429,32 +1431,48 @@ __global__ __launch_bounds__(kBlock) void le_flush_kernel(const LeRelDev* __rest
     const LeRelDev& R = table[ref.rel];
     const int pend = state[R.net].sweeps & (depth - 1);
     if (pend == 0) return;
-    float* const w = ref.side == 0 ? R.w1 : R.w2;
-    const int row_len = ref.side == 0 ? R.row_len : R.i2g * R.khkw;
-    const int64_t n = (int64_t)(ref.side == 0 ? R.o1 : R.o2) * row_len;
-    const int64_t end = (ref.first + kFlushSpan < n) ? ref.first + kFlushSpan : n;
-    auto factor = [&](int j, int64_t o, int pos) {
-        const int c = ref.side == 0 ? (int)o : (int)(o / R.go) * R.gi + pos / R.khkw;
-        return R.hold[(int64_t)(2 * j + ref.side) * R.o1 + c];
+    const int side = ref.side;
+    gfloat* const w = (gfloat*)(side == 0 ? R.w1 : R.w2) + ref.first;
+    const int row_len = side == 0 ? R.row_len : R.i2g * R.khkw;
+    const int64_t n = (int64_t)(side == 0 ? R.o1 : R.o2) * row_len;
+    const int span = (int)((ref.first + kFlushSpan < n) ? kFlushSpan : n - ref.first);
+    const float* const hold = R.hold + (int64_t)side * R.o1;          // factor j of channel c: hold[2 j o1 + c]
+    // channel of the element `off` floats into the span (off < kFlushSpan, positions < 2^20: small_div is exact)
+    auto channel = [&](int off) {
+        const int p = ref.pos0 + off;
+        const int dr = small_div(p, row_len);
+        const int o = ref.row0 + dr;
+        return side == 0 ? o : small_div(o, R.go) * R.gi + small_div(p - dr * row_len, R.khkw);
     };
     const bool vec = ((row_len & 3) == 0) && (((uintptr_t)w & 15) == 0);
     if (vec) {
-        for (int64_t e = ref.first + 4 * (int64_t)threadIdx.x; e < end; e += 4 * kBlock) {
-            fvec4 x = *(const fvec4*)(w + e);
-            const int64_t o = e / row_len;
-            const int pos = (int)(e - o * row_len);
-            for (int j = 0; j < pend; ++j) {
+        constexpr int NV = kFlushSpan / (4 * kBlock);                 // vectors per thread, all requested before the first use
+        fvec4 x[NV];
+        int off[NV];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) x[k] = x[k] * factor(j, o, pos + k);
+        for (int k = 0; k < NV; ++k) {
+            off[k] = 4 * (k * kBlock + (int)threadIdx.x);
+            if (off[k] < span) x[k] = DFQ_NT_LOAD((const gfvec4*)(w + off[k]));
+        }
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            if (off[k] >= span) continue;
+            int c[4];
+            if (side == 0) { c[0] = c[1] = c[2] = c[3] = channel(off[k]); }     // a vector never crosses a row
+            else { c[0] = channel(off[k]); c[1] = channel(off[k] + 1); c[2] = channel(off[k] + 2); c[3] = channel(off[k] + 3); }
+            for (int j = 0; j < pend; ++j) {
+                const float* h = hold + (int64_t)(2 * j) * R.o1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[k][e] = x[k][e] * h[c[e]];
             }
-            *(fvec4*)(w + e) = x;
+            DFQ_NT_STORE(x[k], (gfvec4*)(w + off[k]));
         }
     } else {
-        for (int64_t e = ref.first + threadIdx.x; e < end; e += kBlock) {
-            const int64_t o = e / row_len;
-            float x = w[e];
-            for (int j = 0; j < pend; ++j) x = x * factor(j, o, (int)(e - o * row_len));
-            w[e] = x;
+        for (int off = (int)threadIdx.x; off < span; off += kBlock) {
+            const int c = channel(off);
+            float x = w[off];
+            for (int j = 0; j < pend; ++j) x = x * hold[(int64_t)(2 * j) * R.o1 + c];
+            w[off] = x;
         }
     }
 }
@@ -1930,7 +1948,8 @@ int dfq_le_plan_create_batch(const dfq_layer* layers, int32_t n_layers, const in
                 for (int side = 0; side < 2; ++side) {
                     if (!(d.defer & (1 << side))) continue;
                     const int64_t n = side == 0 ? (int64_t)d.o1 * d.row_len : (int64_t)d.o2 * d.i2g * d.khkw;
-                    for (int64_t f = 0; f < n; f += kFlushSpan) refs.push_back(LeFlushRef{i, side, f});
+                    const int64_t rl = side == 0 ? d.row_len : (int64_t)d.i2g * d.khkw;
+                    for (int64_t f = 0; f < n; f += kFlushSpan) refs.push_back(LeFlushRef{i, side, f, (int32_t)(f / rl), (int32_t)(f % rl)});
                 }
             }
             p->n_flush = (int)refs.size();
