@@ -138,14 +138,29 @@ def cpu_baseline(net, seed, budget_s):
     out = dict(value=n_w * reps / spent, unit='weights/s', cores=1, kind='port',
                sample='{} full LE({} sweeps)+BC passes of the numpy oracle over the same synthetic {} '
                       '({} weights), {:.1f} s of CPU time'.format(reps, sweeps, net, n_w, spent))
-    out['reference'] = reference_cpu_record(net)
+    out['reference'] = reference_cpu_record(net, full_sweeps=sweeps)
     return out, sweeps
 
 
-def reference_cpu_record(net):
-    """The UNMODIFIED reference's CPU path (dfq.py:78-117 + :173-293) on the same synthetic network.  It can only be
-    timed where /root/reference exists -- the build container (tools/time_reference.py writes
-    profiles/r02_reference_cpu.json) -- never on the GPU box, so the committed record is carried, labelled as such."""
+def reference_cpu_record(net, full_sweeps=0, timed_sweeps=2):
+    """The UNMODIFIED reference's CPU path (dfq.py:78-117 + :173-293) on the same synthetic network, timed on THIS box's
+    host cores: oracle/time_ref.py (a subprocess, so the reference's top-level `utils` package stays out of this process)
+    drives the byte-compiled reference of oracle/_ref (oracle/build_ref.py, built by __graft_entry__.build() where
+    /root/reference exists; git-ignored, travels with the snapshot) for `timed_sweeps` sweeps + one bias correction and
+    extrapolates to the `full_sweeps` of a whole pass ("time k sweeps ... report s/sweep").  Only when oracle/_ref
+    is absent the committed build-container figure (profiles/r02_reference_cpu.json) is carried instead, labelled as such."""
+    import subprocess
+    script = os.path.join(ROOT, 'oracle', 'time_ref.py')
+    if os.path.isfile(os.path.join(ROOT, 'oracle', '_ref', 'dfq.pyc')):
+        try:
+            res = subprocess.run([sys.executable, script, '--net', net, '--sweeps', str(timed_sweeps),
+                                  '--full-sweeps', str(full_sweeps)], capture_output=True, text=True, timeout=600)
+            rec = json.loads(res.stdout.strip().splitlines()[-1])
+            if 'error' not in rec:
+                rec['measured_by_this_run'] = True
+                return rec
+        except Exception as e:                                  # fall through to the committed figure, say why
+            print('reference timing failed: {!r}'.format(e), file=sys.stderr)
     path = os.path.join(ROOT, 'profiles', 'r02_reference_cpu.json')
     try:
         rec = json.load(open(path)).get(net)
@@ -155,6 +170,7 @@ def reference_cpu_record(net):
         return None
     return {'value': rec['value'], 'unit': rec['unit'], 'cores': rec['cores'], 'kind': 'reference',
             'sweeps': rec['sweeps'], 'equalization_s': rec['equalization_s'], 'bias_correction_s': rec['bias_correction_s'],
+            'measured_by_this_run': False,
             'what': rec['what'], 'where': rec['where'] + ' -- committed figure (profiles/r02_reference_cpu.json), not measured by this run'}
 
 

@@ -10,9 +10,12 @@ to the calibration passes, and it is fixed by their call sites:
   * tensor ops are string-valued entries whose key *contains* 'add', 'cat', 'F.pad',
     'torch.mean', 'F.interpolate' (layer_transform.py:316-326, relation.py:42-43).
 
-Shape-only ops (view/size/flatten/getitem/contiguous/dropout-in-eval...) are transparent: their
+Shape-only ops (view/size/flatten/getitem/contiguous/functional dropout in eval...) are transparent: their
 consumers are wired to their producer, which is how the reference graphs look
-(images/graph_cls.png ends ... ReLU -> torch.mean -> Linear).  Only a WHITELIST is transparent.  Functional
+(images/graph_cls.png ends ... ReLU -> torch.mean -> Linear).  Only a WHITELIST is transparent.
+``nn.Dropout`` MODULES are nodes, as in the reference's graphs (images/graph_deeplab.png: Dropout_185,
+Dropout_194, Dropout_198): relation.py:36-46 does not walk through them, so the layers either side of
+a Dropout are never paired, and find_prev_bn's depth strings (layer_transform.py:337) count them.  Functional
 activations the passes must see become module nodes (F.relu -> nn.ReLU(), F.relu6 -> nn.ReLU6(): relation.py:36-41
 walks through ReLU but stops at ReLU6, dfq.py:209-211 and layer_transform.py:373-380 look for them behind a BN);
 every other function or method (sigmoid, hardswish, mul, chunk, ...) is kept as an opaque string node, as the
@@ -108,7 +111,7 @@ def _trace(model, key_style='name'):
         ins = [i for i in _tensor_inputs(n) if i in alias]
         if n.op == 'call_module':
             m = modules[n.target]
-            if isinstance(m, (nn.Dropout, nn.Dropout2d, nn.Identity)):
+            if isinstance(m, nn.Identity):
                 alias[n] = key_of(ins[0])
                 continue
             key = '{}_{}'.format(type(m).__name__, counter) if key_style == 'name' else m

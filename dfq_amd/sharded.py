@@ -198,7 +198,12 @@ class ShardedEqualizer:
     graph and builds the tables: the engine plan of the owned components over scratch tensors, the flat exchange
     buffer the plan accumulates its scales into, the snapshot and rebuild launches.  ``run`` is the data path:
     snapshot of the owned tensors (1 launch) -> local sweeps -> ONE all_gather -> rebuild of every paired tensor on
-    every rank (1 launch)."""
+    every rank (1 launch).
+
+    SINGLE USE: ``run`` may be called once.  The rebuild is in place (the pristine tensors are its source AND its
+    destination), the exchange buffer starts at 1 and the sweeps accumulate into it, and ``check`` closes the sweep plan --
+    a second ``run`` would apply the first run's scales again.  It raises instead; build a new equalizer for another pass
+    (bench.py does, untimed)."""
 
     def __init__(self, graph, relations, targ_type, group=None, s_range=(1e-8, 1e8), signed=False, eps=0,
                  le_runner=None, use_torch_rebuild=False):
@@ -210,6 +215,7 @@ class ShardedEqualizer:
         dev = self.dev = self.stage.device
         self.comm_dev = dev if dist.get_backend(group) == 'nccl' else torch.device('cpu')
         self._torch_rebuild = use_torch_rebuild
+        self._ran = False
         first_of, second_of = {}, {}
         with torch.no_grad():
             for i, rr in enumerate(relations):
@@ -327,6 +333,10 @@ class ShardedEqualizer:
         the rebuilt tensors are undefined then and the caller's weights must be reloaded (errors are never silent,
         dfq.py:126,276; the collective itself has the usual torch.distributed failure mode).  ``check=False`` leaves that
         to a later ``check()`` call (bench.py: the bias correction is enqueued right behind)."""
+        if self._ran:
+            raise RuntimeError('ShardedEqualizer.run() is single-use: the in-place rebuild has consumed the pristine tensors '
+                               'and the accumulated scales; construct a new ShardedEqualizer for another pass')
+        self._ran = True
         group, session = self.group, self.session
         with torch.no_grad():
             try:

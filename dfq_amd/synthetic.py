@@ -132,29 +132,27 @@ class ResNet18(nn.Module):
 # DeepLab-v3+ (MobileNetV2 backbone)
 # ------------------------------------------------------------------------------------------
 class _PadConvBlock(nn.Module):
-    """MobileNetV2 block of the segmentation backbone: explicit F.pad before the depthwise conv
-    (modeling/segmentation/backbone/mobilenet.py:16-22, 61-67)."""
+    """MobileNetV2 block of the segmentation backbone (modeling/segmentation/backbone/mobilenet.py:25-67): the explicit
+    F.pad sits at the block's INPUT -- in front of the 1x1 expansion when there is one -- the depthwise conv has no padding
+    of its own, and the residual is ``x + conv(pad(x))`` (images/graph_deeplab.png: BatchNorm2d_9 -> F.pad_10 -> Conv2d_11)."""
 
     def __init__(self, inp, oup, stride, dilation, expand_ratio):
         super().__init__()
         hidden = int(round(inp * expand_ratio))
         self.use_res_connect = stride == 1 and inp == oup
-        self.pad = dilation
-        pre = []
+        self.pad = dilation                      # fixed_padding of a 3x3 kernel: (3 + 2 (d - 1) - 1) // 2 = d either side
+        layers = []
         if expand_ratio != 1:
-            pre += _conv_bn_relu(inp, hidden, 1, 1, 0)
-        self.pre = nn.Sequential(*pre)
-        self.dw = nn.Sequential(*_conv_bn_relu(hidden, hidden, 3, stride, 0, groups=hidden,
-                                               dilation=dilation))
-        self.pw = nn.Sequential(*_conv_bn_relu(hidden, oup, 1, 1, 0, relu=False))
+            layers += _conv_bn_relu(inp, hidden, 1, 1, 0)
+        layers += _conv_bn_relu(hidden, hidden, 3, stride, 0, groups=hidden, dilation=dilation)
+        layers += _conv_bn_relu(hidden, oup, 1, 1, 0, relu=False)
+        self.conv = nn.Sequential(*layers)
 
     def forward(self, x):
-        y = self.pre(x)
-        y = F.pad(y, (self.pad, self.pad, self.pad, self.pad))
-        y = self.pw(self.dw(y))
+        x_pad = F.pad(x, (self.pad, self.pad, self.pad, self.pad))
         if self.use_res_connect:
-            return x + y
-        return y
+            return x + self.conv(x_pad)
+        return self.conv(x_pad)
 
 
 class _ASPP(nn.Module):

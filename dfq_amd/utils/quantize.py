@@ -184,26 +184,24 @@ class QuantMeasure(nn.Module):
                 _ffi.check(_ffi.lib().dfq_quant_measure(_ffi.ptr(x), _ffi.ptr(out), n, x.numel() // n, int(self.num_bits),
                                                         _ffi.ptr(running), _ffi.ptr(sc), self._qm_parity, _ffi.stream_arg()))
                 self._qm_parity ^= 1
-                if input.requires_grad:
-                    return input + (out - input).detach()
-                return out
-            if shadow:
-                running = torch.cat([stage.bind(self.running_min).reshape(1), stage.bind(self.running_max).reshape(1)])
-            if self.update_stat:
-                sample_minmax_mean(x, n, running=running, stage=stage)       # quantize.py:106-107
-            pair = running                                                    # eval: running range
-            if self.training:
-                pair = sample_minmax_mean(x, n, stage=stage)                  # quantize.py:109-113
-                running.mul_(1 - self.momentum).add_(pair * self.momentum)
-            if shadow:
-                self.running_min.copy_(running[0:1])
-                self.running_max.copy_(running[1:2])
-            out = stage.new(x.shape)
-            # float(min_value), float(max_value) -> float64 recipe, evaluated on the device
-            fake_quant_device(x, out, self.num_bits, False, 1, 0.0, 0.0, pair, None)
-            out = stage.out_like(input, out)
+            else:
+                if shadow:
+                    running = torch.cat([stage.bind(self.running_min).reshape(1), stage.bind(self.running_max).reshape(1)])
+                if self.update_stat:
+                    sample_minmax_mean(x, n, running=running, stage=stage)       # quantize.py:106-107
+                pair = running                                                    # eval: running range
+                if self.training:
+                    pair = sample_minmax_mean(x, n, stage=stage)                  # quantize.py:109-113
+                    running.mul_(1 - self.momentum).add_(pair * self.momentum)
+                if shadow:
+                    self.running_min.copy_(running[0:1])
+                    self.running_max.copy_(running[1:2])
+                out = stage.new(x.shape)
+                # float(min_value), float(max_value) -> float64 recipe, evaluated on the device
+                fake_quant_device(x, out, self.num_bits, False, 1, 0.0, 0.0, pair, None)
+            out = stage.out_like(input, out)              # a CPU input gets a CPU result, whichever path ran
         if input.requires_grad:
-            out = input + (out - input).detach()      # straight-through estimator
+            out = input + (out - input).detach()          # straight-through estimator (quantize.py:79-83), OUTSIDE no_grad
         return out
 
     def set_update_stat(self, update_stat):

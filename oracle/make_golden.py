@@ -12,6 +12,8 @@ GPU parity tests can check against them without the reference being present.
 
   tests/golden/kat_fake_quant.npz     UniformQuantize known-answer vectors (bit-exact contract)
   tests/golden/kat_le_pairs.npz       _layer_equalization on every pairing case (incl. dead channels)
+  tests/golden/kat_merge_scale.npz    QConv2d / QLinear.merge_scale_to_weight (row a11), bit-exact contract
+  tests/golden/kat_quant_error.npz    _quantize_error with its four reductions + elementwise (row a3)
   tests/golden/net_<name>_s<seed>.npz full pipeline on the tiny nets: inputs + per-stage outputs
   tests/golden/full_<name>.npz        (--full) MobileNetV2 / ResNet-18 / DeepLab summaries
 """
@@ -118,6 +120,102 @@ def kat_fake_quant():
     out['cases'] = np.array(cases, dtype=np.float64)
     np.savez_compressed(os.path.join(GOLD, 'kat_fake_quant.npz'), **out)
     print('kat_fake_quant: {} cases bit-exact'.format(i))
+
+
+# ------------------------------------------------------------------------------------------
+def kat_merge_scale():
+    """Row a11: the reference's OWN QConv2d / QLinear .set_scale + .merge_scale_to_weight (utils/quantize.py:136-174,
+    262-289) -- grouped conv (the per-group column slices of merge_scale_prev), depthwise, plain, bias / no bias, scale only,
+    scale_prev only; QLinear (whose merge_scale_prev MULTIPLIES, quantize.py:283)."""
+    rng = np.random.default_rng(4242)
+    out = {}
+    names = []
+    cases = [
+        # name, kind, (cin, cout, k, groups), bias, use scale, use scale_prev
+        ('conv_g2', 'conv', (8, 12, 3, 2), True, True, True),
+        ('conv_g1', 'conv', (6, 10, 1, 1), True, True, True),
+        ('conv_dw', 'conv', (16, 16, 3, 16), False, True, True),
+        ('conv_g4_prev_only', 'conv', (16, 8, 3, 4), True, False, True),
+        ('conv_scale_only_nobias', 'conv', (5, 7, 3, 1), False, True, False),
+        ('lin', 'linear', (12, 5), True, True, True),
+        ('lin_prev_only', 'linear', (9, 4), True, False, True),
+        ('lin_nobias', 'linear', (7, 3), False, True, False),
+    ]
+    for name, kind, geom, bias, use_s, use_p in cases:
+        if kind == 'conv':
+            cin, cout, k, g = geom
+            layer = ref_q.QConv2d(cin, cout, k, groups=g, bias=bias)
+            n_prev = cin
+        else:
+            cin, cout = geom
+            g = 1
+            layer = ref_q.QLinear(cin, cout, bias=bias)
+            n_prev = cin
+        w = rng.standard_normal(tuple(layer.weight.shape)).astype(F32)
+        b = rng.standard_normal(cout).astype(F32) if bias else None
+        sc = rng.uniform(0.25, 4, cout).astype(F32) if use_s else None
+        sp = rng.uniform(0.25, 4, n_prev).astype(F32) if use_p else None
+        with torch.no_grad():
+            layer.weight.copy_(torch.from_numpy(w))
+            if bias:
+                layer.bias.copy_(torch.from_numpy(b))
+        # as improve_dfq.py's set_scale installs them: `scale` of the layer itself, `scale_prev` = the previous layer's
+        # `scale` PARAMETER ([C,1,1,1] for a conv, [C,1] for a linear layer)
+        prev = None
+        if use_p:
+            prev = torch.from_numpy(sp.copy()).view(-1, 1, 1, 1) if kind == 'conv' else torch.from_numpy(sp.copy()).view(-1, 1)
+        layer.set_scale(scale=torch.from_numpy(sc.copy()) if use_s else None, scale_prev=prev)
+        with torch.no_grad():
+            layer.merge_scale_to_weight()
+        w_ref = layer.weight.detach().numpy().copy()
+        b_ref = layer.bias.detach().numpy().copy() if bias else None
+        w_o, b_o = orc.merge_scale_to_weight(w, b, sc, sp, groups=g, linear=(kind == 'linear'))
+        assert_bitexact(w_o, w_ref, 'merge_scale {} weight'.format(name))
+        if bias:
+            assert_bitexact(b_o, b_ref, 'merge_scale {} bias'.format(name))
+        out[name + '.w'] = w
+        out[name + '.w_out'] = w_ref
+        if bias:
+            out[name + '.b'] = b
+            out[name + '.b_out'] = b_ref
+        if use_s:
+            out[name + '.scale'] = sc
+        if use_p:
+            out[name + '.scale_prev'] = sp
+        out[name + '.cfg'] = np.array([int(kind == 'linear'), g], dtype=np.int64)
+        names.append(name)
+    out['names'] = np.array(names)
+    np.savez_compressed(os.path.join(GOLD, 'kat_merge_scale.npz'), **out)
+    print('kat_merge_scale: {} cases bit-exact (reference QConv2d / QLinear.merge_scale_to_weight)'.format(len(names)))
+
+
+def kat_quant_error():
+    """Row a3: dfq._quantize_error (dfq.py:8-25) with every reduction it knows, unsigned and signed.  The elementwise
+    result (reduction not in the list, what bias_correction passes) is bit-exact; the reduced scalars are float32 torch
+    sums of unspecified order: 1e-5 relative."""
+    rng = np.random.default_rng(808)
+    out = {}
+    names = []
+    for name, shape, scale in [('conv3', (12, 5, 3, 3), 1.0), ('pw', (40, 24, 1, 1), 0.2), ('dw', (32, 1, 3, 3), 3.0),
+                               ('fc', (10, 64), 0.05)]:
+        w = (rng.standard_normal(shape) * scale).astype(F32)
+        for signed in (False, True):
+            tag = '{}_{}'.format(name, 's' if signed else 'u')
+            out[tag + '.w'] = w
+            for red in ('sum', 'mean', 'channel', 'spatial', 'none'):
+                if red == 'spatial' and len(shape) == 2:
+                    pass                                     # eps.view(O, I, -1) works for a linear layer too
+                got = ref_dfq._quantize_error(torch.from_numpy(w.copy()), 8, red, signed).numpy()
+                mine = orc.quantize_error(w, 8, None if red == 'none' else red, signed)
+                if red == 'none':
+                    assert_bitexact(mine, got, 'quant_error {} none'.format(tag))
+                else:
+                    assert_close(mine, got, 'quant_error {} {}'.format(tag, red), tol=1e-5)
+                out['{}.{}'.format(tag, red)] = got
+            names.append(tag)
+    out['names'] = np.array(names)
+    np.savez_compressed(os.path.join(GOLD, 'kat_quant_error.npz'), **out)
+    print('kat_quant_error: {} tensors x 5 reductions (reference _quantize_error)'.format(len(names)))
 
 
 # ------------------------------------------------------------------------------------------
@@ -379,6 +477,8 @@ def main():
     torch.set_num_threads(os.cpu_count())
     kat_fake_quant()
     kat_le_pairs()
+    kat_merge_scale()
+    kat_quant_error()
     run_net('tiny_mobile', 0)
     run_net('tiny_mobile', 1, absorption=True)
     run_net('tiny_mobile', 2, signed=True)

@@ -45,6 +45,51 @@ def test_merge_scale_to_weight_conv_and_linear(engine):
     assert_bitexact(npy(lin.bias), b_o, 'linear bias')
 
 
+def _kat_merge_names():
+    import os
+    from common import GOLD
+    return [str(n) for n in np.load(os.path.join(GOLD, 'kat_merge_scale.npz'))['names']]
+
+
+@pytest.mark.parametrize('name', _kat_merge_names())
+def test_merge_scale_to_weight_against_reference(engine, name):
+    """Row a11 pinned: tests/golden/kat_merge_scale.npz holds what the REFERENCE's QConv2d / QLinear
+    .set_scale + .merge_scale_to_weight (utils/quantize.py:136-174, 262-289) leave in weight and bias
+    (oracle/make_golden.py:kat_merge_scale) -- grouped, depthwise, scale only, scale_prev only, no bias; QLinear's
+    merge_scale_prev multiplies.  Contract: bit-exact (one IEEE divide, one multiply per element, in that order)."""
+    import os
+    from common import GOLD
+    g = np.load(os.path.join(GOLD, 'kat_merge_scale.npz'))
+    linear, groups = [int(v) for v in g[name + '.cfg']]
+    w = g[name + '.w']
+    has_b = (name + '.b') in g.files
+    if linear:
+        layer = q.QLinear(w.shape[1], w.shape[0], bias=has_b)
+    else:
+        layer = q.QConv2d(w.shape[1] * groups, w.shape[0], w.shape[2], groups=groups, bias=has_b)
+    layer = layer.to(engine.device)
+    with torch.no_grad():
+        layer.weight.copy_(torch.from_numpy(w))
+        if has_b:
+            layer.bias.copy_(torch.from_numpy(g[name + '.b']))
+    sc = engine.to(torch.from_numpy(g[name + '.scale'].copy())) if (name + '.scale') in g.files else None
+    sp = None
+    if (name + '.scale_prev') in g.files:
+        sp = torch.from_numpy(g[name + '.scale_prev'].copy())
+        sp = engine.to(sp.view(-1, 1) if linear else sp.view(-1, 1, 1, 1))
+    layer.set_scale(scale=sc, scale_prev=sp)
+    layer.merge_scale_to_weight()
+    assert_bitexact(npy(layer.weight), g[name + '.w_out'], name + ' weight')
+    if has_b:
+        assert_bitexact(npy(layer.bias), g[name + '.b_out'], name + ' bias')
+    assert getattr(layer, 'scale', None) is None and getattr(layer, 'scale_prev', None) is None
+    # and the oracle agrees with the reference on the same inputs (the oracle is what other tests use)
+    w_o, b_o = orc.merge_scale_to_weight(w, g[name + '.b'] if has_b else None,
+                                         g[name + '.scale'] if sc is not None else None,
+                                         g[name + '.scale_prev'] if sp is not None else None, groups=groups, linear=bool(linear))
+    assert_bitexact(w_o, g[name + '.w_out'], name + ' oracle weight')
+
+
 def test_transform_quant_layer_swaps_and_folds(engine):
     class Net(nn.Module):
         def __init__(self):

@@ -115,6 +115,31 @@ def test_quant_measure(engine):
     assert_bitexact(npy(y2), y2_o)
 
 
+@pytest.mark.parametrize('update_stat', [True, False])
+def test_quant_measure_straight_through_gradient(engine, update_stat):
+    """UniformQuantize.backward passes the gradient through (quantize.py:79-83); QuantMeasure in eval mode must do so on
+    BOTH of its paths -- the fused range-tracking launch (update_stat) and the plain quantiser (the fused
+    path returned from inside no_grad and dropped the gradient).  A CPU input to a device-resident module comes back on
+    the CPU."""
+    rng = np.random.default_rng(12)
+    x = rng.standard_normal((4, 3, 5, 5)).astype(F32)
+    m = q.QuantMeasure(update_stat=True).to(engine.device).eval()
+    m(engine.to(torch.from_numpy(x.copy())))                        # fix a range first
+    m.set_update_stat(update_stat)
+    xin = engine.to(torch.from_numpy(x.copy())).requires_grad_(True)
+    y = m(xin)
+    assert y.requires_grad and y.grad_fn is not None
+    wgt = engine.to(torch.from_numpy(rng.standard_normal(x.shape).astype(F32)))
+    (y * wgt).sum().backward()
+    assert_bitexact(npy(xin.grad), npy(wgt), 'straight-through gradient')
+    # forward value is still the quantised one
+    y_o, _, _ = orc.quant_measure_forward(x, float(npy(m.running_min)[0]), float(npy(m.running_max)[0]), update_stat=False)
+    if not update_stat:
+        assert_close(npy(y), y_o, 'forward value', tol=1e-6)
+    cpu_in = torch.from_numpy(x.copy())
+    assert m(cpu_in).device == cpu_in.device
+
+
 @pytest.mark.gpu
 def test_quant_measure_at_config5_size():
     """BASELINE.json config 5 (--distill_range): one of MobileNetV2's largest activation tensors at batch 64
@@ -149,6 +174,33 @@ def test_quantize_error(engine, reduction):
         assert_bitexact(got, want)
     else:
         assert_close(got, np.asarray(want, dtype=F32), 'reduction {}'.format(reduction), tol=1e-6)
+
+
+def _kat_qe_names():
+    return [str(n) for n in np.load(os.path.join(GOLD, 'kat_quant_error.npz'))['names']]
+
+
+@pytest.mark.parametrize('name', _kat_qe_names())
+def test_quantize_error_against_reference(engine, name):
+    """Row a3 pinned for EVERY reduction: tests/golden/kat_quant_error.npz = the reference's dfq._quantize_error
+    (dfq.py:8-25; oracle/make_golden.py:kat_quant_error) on conv / pointwise / depthwise / linear tensors, unsigned and
+    signed.  Elementwise result bit-exact; the reduced scalars are float32 torch sums of unspecified order in the
+    reference (float64 accumulation here): 1e-5 relative."""
+    g = np.load(os.path.join(GOLD, 'kat_quant_error.npz'))
+    w = g[name + '.w']
+    signed = name.endswith('_s')
+    for red in ('sum', 'mean', 'channel', 'spatial', 'none'):
+        want = g['{}.{}'.format(name, red)]
+        got = npy(dfq._quantize_error(engine.to(torch.from_numpy(w.copy())), 8, red, signed))
+        mine = orc.quantize_error(w, 8, None if red == 'none' else red, signed)
+        if red == 'none':
+            assert_bitexact(got, want, '{} elementwise'.format(name))
+            assert_bitexact(mine, want, '{} oracle elementwise'.format(name))
+        else:
+            assert got.shape == ()
+            scale = max(1.0, abs(float(want)))
+            assert abs(float(got) - float(want)) <= 1e-5 * scale, (name, red, float(got), float(want))
+            assert abs(float(mine) - float(want)) <= 1e-5 * scale, (name, red, float(mine), float(want))
 
 
 # ---------------------------------------------------------------------------------------------
@@ -878,7 +930,7 @@ def test_full_size_networks_against_oracle(net, max_sweeps):
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize('name,seed,signed', [('tiny_mobile', 0, False), ('tiny_res', 0, False), ('tiny_cat', 3, False), ('tiny_mobile', 2, True)])
 def test_resident_and_streaming_engines_agree(engine, monkeypatch, name, seed, signed):
-    """A single network runs the whole loop as ONE persistent launch with its weights in registers
+    """A single network runs the whole loop as ONE persistent launch with its weights in LDS
     (dfq_le_resident.hip); DFQ_LE_RESIDENT=0 forces the streaming kernel.  Same IEEE operations -> the weights, the
     [O] vectors, the cumulative scales, the sweep count and the loop state must be identical bit for bit, and both
     equal the oracle."""

@@ -250,7 +250,7 @@ def test_sharded_deeplab_two_ranks_product_path(tmp_path, emu_lib_path):
     mp.spawn(_worker, args=(world, _free_port(), name, seed, sweeps, str(tmp_path), emu_lib_path), nprocs=world, join=True)
     model, graph, bottoms, spec = _prepare(name, seed)
     orels = orc.create_relation(spec)
-    assert len(orels) == 37          # this synthetic DeepLab (reference run: tests/golden/full_deeplab_mnv2_s0.npz)
+    assert len(orels) == 35          # the reference's DeepLab graph (tests/golden/graph_deeplab_mnv2_relu.json, full_deeplab_mnv2_s0.npz)
     n_ref, S_ref = orc.cross_layer_equalization(spec, orels, max_sweeps=sweeps, converge_thres=-1.0, converge_count=10 ** 9)
     r0 = np.load(os.path.join(str(tmp_path), 'rank0.npz'))
     r1 = np.load(os.path.join(str(tmp_path), 'rank1.npz'))
@@ -276,6 +276,38 @@ def test_components_and_assignment():
         assert len(owner) == len(rels) and all(0 <= o < world for o in owner)
         for c in comps:
             assert len({owner[i] for i in c}) == 1, 'a component stays on one rank'
+
+
+def test_sharded_equalizer_is_single_use(emu_lib_path):
+    """a second run() would rebuild from already-rescaled tensors with scales accumulated over both runs
+    (W0.S1.(S1.S2)).  The object is single-use and says so."""
+    import ctypes
+    from dfq_amd import _ffi
+    saved = (_ffi._lib, _ffi.target_device, _ffi.current_stream, _ffi.synchronize)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(_free_port())
+    dist.init_process_group('gloo', rank=0, world_size=1)
+    try:
+        _use_emulated_engine(emu_lib_path)
+        model, graph, bottoms, spec = _prepare('tiny_mobile', 0)
+        rels = rel.create_relation(graph, bottoms, TARG)
+        eq = sharded.ShardedEqualizer(graph, rels, TARG)
+        try:
+            assert eq.run(max_sweeps=3) == 3
+            first = {k: npy(graph[k].weight).copy() for k in graph if type(graph[k]) in TARG}
+            with pytest.raises(RuntimeError, match='single-use'):
+                eq.run(max_sweeps=3)
+            for k, v in first.items():                       # the refused call touched nothing
+                assert_bitexact(npy(graph[k].weight), v, k)
+        finally:
+            eq.close()
+        orels = orc.create_relation(spec)
+        _, S_ref = orc.cross_layer_equalization(spec, orels, max_sweeps=3, converge_thres=-1.0, converge_count=10 ** 9)
+        for rr, s in zip(rels, S_ref):
+            assert_bitexact(npy(rr.get_scale_vec()), s, 'S')
+    finally:
+        dist.destroy_process_group()
+        _ffi._lib, _ffi.target_device, _ffi.current_stream, _ffi.synchronize = saved
 
 
 @pytest.mark.gpu
@@ -337,3 +369,83 @@ def test_sharded_path_over_rccl_single_rank():
                 assert_bitexact(out[0][1][k], want[k], 'canonical ' + k)
     finally:
         dist.destroy_process_group()
+
+
+def _rccl_worker(rank, world, port, name, seed, sweeps, out_dir):
+    """One rank of the REAL multi-GPU path: its own device, RCCL ('nccl') process group, product library."""
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    from dfq_amd import dfq
+    from dfq_amd.utils import layer_transform as lt
+    dev = torch.device('cuda', rank)
+    torch.cuda.set_device(dev)
+    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    try:
+        model, graph, bottoms = synthetic.build(name, seed=seed)
+        model.to(dev)
+        lt.merge_batchnorm(model, graph, bottoms, TARG)
+        rels = rel.create_relation(graph, bottoms, TARG)
+        n = sharded.sharded_cross_layer_equalization(graph, rels, TARG, max_sweeps=sweeps)
+        snap = {'sweeps': np.array(n), 'owner': np.array(sharded.assign_components(graph, rels, world))}
+        for i, k in enumerate(graph):
+            m = graph[k]
+            if type(m) in TARG:
+                snap['L{}.w'.format(i)] = npy(m.weight)
+                if m.bias is not None:
+                    snap['L{}.b'.format(i)] = npy(m.bias)
+            elif type(m) == nn.BatchNorm2d and hasattr(m, 'fake_weight'):
+                snap['L{}.fw'.format(i)] = npy(m.fake_weight)
+                snap['L{}.fb'.format(i)] = npy(m.fake_bias)
+        for i, rr in enumerate(rels):
+            snap['S{}'.format(i)] = npy(rr.get_scale_vec())
+        dfq.bias_correction(graph, bottoms, TARG)
+        for i, k in enumerate(graph):
+            m = graph[k]
+            if type(m) in TARG and m.bias is not None:
+                snap['C{}.b'.format(i)] = npy(m.bias)
+            elif type(m) == nn.BatchNorm2d and hasattr(m, 'fake_weight'):
+                snap['C{}.fb'.format(i)] = npy(m.fake_bias)
+        _, codes = lt.quantize_targ_layer(graph, 8, 16, TARG, return_codes=True)
+        for j, k in enumerate(codes):
+            snap['Q{}'.format(j)] = npy(codes[k])
+        torch.cuda.synchronize()
+        np.savez(os.path.join(out_dir, 'rank{}.npz'.format(rank)), **snap)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_sharded_deeplab_over_rccl_all_ranks(tmp_path):
+    """BASELINE.json config 4 on the hardware it names: DeepLab (35 relations, pinned to 12 sweeps) sharded over
+    min(device_count, 8) ranks, one process per GPU, RCCL all_gather of the cumulative scale vectors over xGMI, then the
+    replicated bias correction and int8 quantisation.  Every rank must hold the SAME BITS in every tensor, corrected bias
+    and int8 code, and they must equal the world-size-1 result (spawned the same way).  On a 1-GPU box only the
+    world-size-1 leg runs (the spawn / device binding / RCCL init code of the N > 1 leg is the same code)."""
+    n_dev = torch.cuda.device_count()
+    name, seed, sweeps = 'deeplab_mnv2', 0, 12
+    worlds = [1] if n_dev < 2 else [1, min(n_dev, 8)]
+    res = {}
+    for world in worlds:
+        d = tmp_path / 'w{}'.format(world)
+        d.mkdir()
+        mp.spawn(_rccl_worker, args=(world, _free_port(), name, seed, sweeps, str(d)), nprocs=world, join=True)
+        res[world] = [np.load(os.path.join(str(d), 'rank{}.npz'.format(r))) for r in range(world)]
+        assert all(int(r['sweeps']) == sweeps for r in res[world])
+        for r in res[world][1:]:
+            _check_ranks_identical(res[world][0], r, need_tail=True)
+        if world > 1:
+            assert len(set(res[world][0]['owner'].tolist())) > 1, 'more than one rank must own work'
+    base = res[1][0]
+    # the single-process oracle: cumulative scales bit-identical, tensors within 1e-5 (and the canonical rebuild bit for bit)
+    model, graph, bottoms, spec = _prepare(name, seed)
+    orels = orc.create_relation(spec)
+    assert len(orels) == 35
+    _, S_ref = orc.cross_layer_equalization(spec, orels, max_sweeps=sweeps, converge_thres=-1.0, converge_count=10 ** 9)
+    for i, s in enumerate(S_ref):
+        assert_bitexact(base['S{}'.format(i)], s, 'S{}'.format(i))
+    for world in worlds[1:]:
+        for k in base.files:
+            if k[0] in 'LCQS':
+                assert_bitexact(res[world][0][k], base[k], 'world {} vs world 1: {}'.format(world, k))
