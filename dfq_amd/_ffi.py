@@ -123,6 +123,8 @@ SIGNATURES = {
     'dfq_bc_plan_weight_elements': (c_int64, [c_void_p]),
     'dfq_bc_plan_tagged': (c_int32, [c_void_p]),
     'dfq_bc_plan_eps_elements': (c_int64, [c_void_p]),
+    'dfq_bc_plan_folded': (c_int32, [c_void_p]),
+    'dfq_bc_plan_chain_steps': (c_int32, [c_void_p]),
     'dfq_quant_error_scratch_bytes': (c_size_t, [c_int64, c_int64]),
     'dfq_quant_error': (c_int32, [c_void_p, c_int64, c_int64, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     'dfq_scale_rows': (c_int32, [c_void_p, c_int32, c_int64, c_void_p, c_int32, c_void_p]),

@@ -56,7 +56,8 @@ struct BcSourceDev {
 struct BcStepDev {
     const float* w;          // the layer's weights [O, I/g, khkw]
     const uint32_t* mm;      // its (min, max) slots, filled by bc_minmax_kernel
-    int32_t khkw, pad0;
+    int32_t khkw;
+    int32_t fold;            // index of the depthwise step folded into this step's per-row tail (BcFoldDev table), or -1
     const float* eps;        // debug copy of the row sums (DFQ_BC_EPS=1: written by bc_quant_error_kernel, read by nobody)
     float* bias;             // layer bias [O], in/out
     float* next_bn_bias;     // [O] or null
@@ -67,6 +68,28 @@ struct BcStepDev {
     int32_t lg_lanes, chunks, rows_per_block;          // work split, see bc_step_kernel
     int32_t next_tag_off;    // tagged-value slots of the next BN, or -1
     BcSourceDev src[kStepSources];   // copy of sources[source_begin ...] when source_count <= kStepSources
+};
+
+// A depthwise step folded into the per-row tail of the step that produces its only source (round 4).  A layer with ONE input
+// channel per group and as many groups as outputs corrects output channel o with eps[o] * E[o] alone (dfq.py:281-287 with
+// I/g = 1), and E[o] is the beta~ / ReLU moment of channel o of the BN the previous step has just rewritten -- a value the
+// thread that owns row o of THAT step holds in a register.  So that thread also performs the depthwise layer's correction of
+// channel o: its nine taps and per-row operands are requested with the step's own, the row sum of the quantisation error is
+// formed while the expectation is assembled, and after the step's own update the thread does the one multiplication, the
+// two updates of dfq.py:290-293 and the next BN's ReLU moment.  A hand-over through the memory system (3.8 us for a single
+// network, 7.5 us in a batch of 32) per depthwise layer disappears: MobileNetV2's chain has 35 dependent steps instead of 52.
+// Same operations in the same order as the step would perform: bit-identical (DFQ_BC_FOLD=0 keeps the step).
+constexpr int kFoldTaps = 9;            // taps of a folded layer a thread preloads (3 x 3 depthwise kernels)
+struct BcFoldDev {
+    const float* w;              // [O, 1, khkw]
+    const uint32_t* mm;          // (min, max) slots of the folded layer
+    float* bias;                 // [O] in/out
+    float* next_bn_bias;         // [O] or null
+    const float* next_bn_weight; // gamma~ of that BN (null if nobody reads its ReLU moment)
+    float* next_cache;
+    float* corr;                 // [O] out
+    float* eps;                  // debug copy target is written by bc_quant_error_kernel; unused here
+    int32_t khkw, next_tag_off, src_relu, pad;
 };
 
 struct BcCacheSeg {          // one BN whose ReLU moment is cached
@@ -291,7 +314,7 @@ struct BcDep {            // null counters: every step is its own launch (depend
 
 template <int kExp>
 __device__ __forceinline__ void bc_step_body(const BcStepDev& st, int blk, const BcSourceDev* __restrict__ sources,
-                                             const BcDep& dep, float* sh_E, float* sh_corr, int* sh_flag) {
+                                             const BcFoldDev* __restrict__ folds, const BcDep& dep, float* sh_E, float* sh_corr, int* sh_flag) {
     const int tid = threadIdx.x;
     const int lane = tid % kWave;
     const int wave = tid / kWave;
@@ -359,6 +382,25 @@ __device__ __forceinline__ void bc_step_body(const BcStepDev& st, int blk, const
         pre_bias = st.bias[o_tail];
         if (st.next_bn_bias) pre_nb = st.next_bn_bias[o_tail];
         if (st.next_cache) pre_nw = st.next_bn_weight[o_tail];
+    }
+    // the folded depthwise layer (BcFoldDev): this thread's row of it -- taps, bias, the BN behind it -- is requested now too,
+    // and the row sum of its quantisation error (sequential float32 sum from 0.0f, like a step's) is ready before the tail
+    const bool fold_on = st.fold >= 0 && tail_on;
+    float f_eps = 0.0f, f_bias = 0.0f, f_nb = 0.0f, f_nw = 0.0f;
+    if (fold_on) {
+        const BcFoldDev F = folds[st.fold];
+        float taps[kFoldTaps];
+#pragma unroll
+        for (int k = 0; k < kFoldTaps; ++k) taps[k] = F.w[(int64_t)o_tail * F.khkw + min(k, F.khkw - 1)];
+        f_bias = F.bias[o_tail];
+        if (F.next_bn_bias) f_nb = F.next_bn_bias[o_tail];
+        if (F.next_cache) f_nw = F.next_bn_weight[o_tail];
+        const QParams fq = qparams_double((double)slot_min(F.mm[0]), (double)slot_max(F.mm[1]), 8, dep.symmetric);
+        float acc = 0.0f, code;
+#pragma unroll
+        for (int k = 0; k < kFoldTaps; ++k)
+            if (k < F.khkw) acc = acc + (fake_quant_one(taps[k], fq, &code) - taps[k]);
+        f_eps = acc;
     }
     const bool tagged = chained && dep.tags != nullptr;
     if (tagged) {
@@ -491,30 +533,50 @@ __device__ __forceinline__ void bc_step_body(const BcStepDev& st, int blk, const
     __syncthreads();
     // ---- one row per thread: dfq.py:290-293 and the refreshed ReLU moment of the next BN ----
     const int o = o_tail;
+    // publication of one row's update (this step's, then the folded step's): the three hand-over protocols
+    auto publish = [&](float* bn_bias, float* cache, int tag_off, float nb, float moment) {
+        if (tagged) {
+            bn_bias[o] = nb;                                      // the final state; consumers inside the launch read the slots
+            if (cache) cache[o] = moment;
+            if (tag_off >= 0) {
+                unsigned long long* slot = dep.tags + 2 * ((int64_t)tag_off + o);
+                const unsigned long long hi = (unsigned long long)dep.epoch << 32;
+                __hip_atomic_store(slot + 0, hi | __float_as_uint(nb), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (cache)
+                    __hip_atomic_store(slot + 1, hi | __float_as_uint(moment), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        } else if (chained) {
+            st_shared_f32(bn_bias + o, nb);
+            if (cache) st_shared_f32(cache + o, moment);
+        } else {
+            bn_bias[o] = nb;
+            if (cache) cache[o] = moment;
+        }
+    };
     if (tail_on) {
         const float corr = sh_corr[tid];
         const float neg = -corr;
         st.corr[o] = corr;
         st.bias[o] = pre_bias + neg;                              // dfq.py:292
+        float nb = 0.0f, moment = 0.0f;
         if (st.next_bn_bias) {
-            const float nb = pre_nb + neg;                        // dfq.py:204-206, 293 (a BN's beta~ changes once)
-            const float moment = st.next_cache ? relu_mean(pre_nw, nb) : 0.0f;
-            if (tagged) {
-                st.next_bn_bias[o] = nb;                          // the final state; consumers inside the launch read the slots
-                if (st.next_cache) st.next_cache[o] = moment;
-                if (st.next_tag_off >= 0) {
-                    unsigned long long* slot = dep.tags + 2 * ((int64_t)st.next_tag_off + o);
-                    const unsigned long long hi = (unsigned long long)dep.epoch << 32;
-                    __hip_atomic_store(slot + 0, hi | __float_as_uint(nb), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (st.next_cache)
-                        __hip_atomic_store(slot + 1, hi | __float_as_uint(moment), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            } else if (chained) {
-                st_shared_f32(st.next_bn_bias + o, nb);
-                if (st.next_cache) st_shared_f32(st.next_cache + o, moment);
-            } else {
-                st.next_bn_bias[o] = nb;
-                if (st.next_cache) st.next_cache[o] = moment;
+            nb = pre_nb + neg;                                    // dfq.py:204-206, 293 (a BN's beta~ changes once)
+            moment = st.next_cache ? relu_mean(pre_nw, nb) : 0.0f;
+            publish(st.next_bn_bias, st.next_cache, st.next_tag_off, nb, moment);
+        }
+        if (fold_on) {
+            // the folded depthwise step, channel o: E[o] is what this thread has just produced; one input per group, so the
+            // "matvec" of dfq.py:281-287 is one product, accumulated in float64 and rounded once like a step's row
+            const BcFoldDev F = folds[st.fold];
+            const float e = F.src_relu ? moment : nb;
+            const float fcorr = (float)((double)f_eps * (double)e);
+            const float fneg = -fcorr;
+            F.corr[o] = fcorr;
+            F.bias[o] = f_bias + fneg;
+            if (F.next_bn_bias) {
+                const float fnb = f_nb + fneg;
+                const float fmoment = F.next_cache ? relu_mean(f_nw, fnb) : 0.0f;
+                publish(F.next_bn_bias, F.next_cache, F.next_tag_off, fnb, fmoment);
             }
         }
     }
@@ -539,7 +601,7 @@ __device__ __forceinline__ void bc_load_step(const BcStepDev* __restrict__ entry
 // one launch per chain position (DFQ_BC_MERGED=0): grid (workgroups of the largest step, networks)
 template <int kExp>
 __global__ __launch_bounds__(kBlock) void bc_step_kernel(BcStepDev st_inline, const BcStepDev* __restrict__ table,
-                                                         const BcSourceDev* __restrict__ sources, int symmetric) {
+                                                         const BcSourceDev* __restrict__ sources, const BcFoldDev* __restrict__ folds, int symmetric) {
     __shared__ float sh_E[kExp];
     __shared__ float sh_corr[kBlock];
     __shared__ int sh_flag;
@@ -547,7 +609,7 @@ __global__ __launch_bounds__(kBlock) void bc_step_kernel(BcStepDev st_inline, co
     if (table) bc_load_step(table + blockIdx.y, desc.u);
     else desc.st = st_inline;
     if ((int)blockIdx.x * desc.st.rows_per_block >= desc.st.out_ch) return;     // grid.x is sized for the largest step of the launch
-    bc_step_body<kExp>(desc.st, blockIdx.x, sources, BcDep{nullptr, nullptr, -1, 0, -1, 0, nullptr, 0u, symmetric, 0, 0}, sh_E, sh_corr, &sh_flag);
+    bc_step_body<kExp>(desc.st, blockIdx.x, sources, folds, BcDep{nullptr, nullptr, -1, 0, -1, 0, nullptr, 0u, symmetric, 0, 0}, sh_E, sh_corr, &sh_flag);
 }
 
 // the whole chain of every network in one launch: 1-D grid over (step, workgroup) in chain order; a workgroup waits
@@ -555,8 +617,9 @@ __global__ __launch_bounds__(kBlock) void bc_step_kernel(BcStepDev st_inline, co
 template <int kExp>
 __global__ __launch_bounds__(kBlock) void bc_chain_kernel(const BcStepDev* __restrict__ table,
                                                           const BcChainRef* __restrict__ refs,
-                                                          const BcSourceDev* __restrict__ sources, uint32_t* counters,
-                                                          uint32_t* err, unsigned long long* tags, uint32_t epoch, int symmetric, int spin_limit) {
+                                                          const BcSourceDev* __restrict__ sources, const BcFoldDev* __restrict__ folds,
+                                                          uint32_t* counters, uint32_t* err, unsigned long long* tags, uint32_t epoch,
+                                                          int symmetric, int spin_limit) {
     __shared__ float sh_E[kExp];
     __shared__ float sh_corr[kBlock];
     __shared__ int sh_flag;
@@ -566,7 +629,7 @@ __global__ __launch_bounds__(kBlock) void bc_chain_kernel(const BcStepDev* __res
     const int blk = __builtin_amdgcn_readfirstlane(ref[1]);
     union { BcStepDev st; uint32_t u[kStepWords]; } desc;
     bc_load_step(table + step, desc.u);
-    bc_step_body<kExp>(desc.st, blk, sources,
+    bc_step_body<kExp>(desc.st, blk, sources, folds,
                        BcDep{counters, err, __builtin_amdgcn_readfirstlane(ref[2]), __builtin_amdgcn_readfirstlane(ref[3]), step, 0,
                              tags, epoch, symmetric, spin_limit, 0},
                        sh_E, sh_corr, &sh_flag);
@@ -596,6 +659,8 @@ struct dfq_bc_plan {
     int32_t* d_mm_begin = nullptr;
     int32_t* d_qe_begin = nullptr;
     BcSourceDev* d_sources = nullptr;
+    BcFoldDev* d_folds = nullptr;          // depthwise steps folded into their predecessor's tail (see BcFoldDev)
+    int n_folds = 0;
     uint32_t* d_slots = nullptr;
     float* d_eps = nullptr;                // debug (DFQ_BC_EPS=1): all eps matrices, back to back
     bool keep_eps = false;
@@ -615,6 +680,7 @@ void dfq_bc_plan_destroy(dfq_bc_plan* p) {
     if (p->d_mm_begin) (void)hipFree(p->d_mm_begin);
     if (p->d_qe_begin) (void)hipFree(p->d_qe_begin);
     if (p->d_sources) (void)hipFree(p->d_sources);
+    if (p->d_folds) (void)hipFree(p->d_folds);
     if (p->d_slots) (void)hipFree(p->d_slots);
     if (p->d_eps) (void)hipFree(p->d_eps);
     if (p->d_corr) (void)hipFree(p->d_corr);
@@ -756,7 +822,7 @@ int dfq_bc_plan_create(const dfq_layer* layers, int32_t n_layers, const dfq_bc_s
         mb += (hl[s].n + kMmChunk - 1) / kMmChunk;
         qb += (L.khkw == 1) ? (pairs + kBlock * kQePairs - 1) / (kBlock * kQePairs) : (pairs + kBlock - 1) / kBlock;
         BcStepDev& d = p->steps[s];
-        d.w = L.weight; d.mm = p->d_slots + 2 * s; d.khkw = L.khkw; d.pad0 = 0;
+        d.w = L.weight; d.mm = p->d_slots + 2 * s; d.khkw = L.khkw; d.fold = -1;
         d.eps = p->keep_eps ? p->d_eps + eps_off : nullptr; d.bias = L.bias; d.next_bn_bias = steps[s].next_bn_bias; d.corr = p->d_corr + corr_off;
         d.out_ch = L.out_ch; d.in_per_group = L.in_per_group; d.source_begin = steps[s].source_begin;
         d.source_count = steps[s].source_count; d.expect_len = expect_len[s];
@@ -793,20 +859,57 @@ int dfq_bc_plan_create(const dfq_layer* layers, int32_t n_layers, const dfq_bc_s
         eps_off += (pairs + 3) & ~(int64_t)3; corr_off += L.out_ch;
     }
     mmb[n_steps] = (int32_t)mb; qeb[n_steps] = (int32_t)qb;
-    // launch j = the j-th step of every network (steps arrive network by network, in graph order)
+    // ---- depthwise steps folded into the tail of the step in front of them (BcFoldDev).  Step D folds into P = D - 1 (same
+    //      network) when D has one input channel per group and as many groups as outputs (every output o needs E[o] only), at
+    //      most kFoldTaps taps, and its ONLY source is the BN that P rewrites, channel for channel; P must launch itself (a
+    //      folded step has no tail to host another one).  Nothing lies between P and D in the sequential order of
+    //      dfq.py:197-293, so every later step sees the same state as without the fold. ----
+    std::vector<int> folded_into(n_steps, -1);
+    std::vector<BcFoldDev> folds;
     {
-        std::vector<int> ordinal(n_steps, 0);
+        const char* fe = getenv("DFQ_BC_FOLD");
+        const bool fold_on = !(fe && fe[0] == '0');
+        for (int D = 1; D < n_steps && fold_on; ++D) {
+            const int P = D - 1;
+            if (steps[P].net != steps[D].net || folded_into[P] >= 0) continue;
+            const dfq_layer& LD = layers[steps[D].layer];
+            const dfq_layer& LP = layers[steps[P].layer];
+            const dfq_bc_source& src = sources[steps[D].source_begin];
+            if (LD.in_per_group != 1 || expect_len[D] != LD.out_ch || LD.khkw > kFoldTaps || steps[D].source_count != 1) continue;
+            if (!steps[P].next_bn_bias || src.fake_bias != steps[P].next_bn_bias || src.channels != LD.out_ch || LP.out_ch != LD.out_ch) continue;
+            if (steps[D].next_bn_bias == steps[P].next_bn_bias || LD.bias == LP.bias) continue;
+            if (src.relu && !p->steps[P].next_cache) continue;           // (cannot happen: a source read through a ReLU has a cache)
+            BcFoldDev F;
+            const BcStepDev& d = p->steps[D];
+            F.w = d.w; F.mm = d.mm; F.bias = d.bias; F.next_bn_bias = d.next_bn_bias; F.next_bn_weight = d.next_bn_weight;
+            F.next_cache = d.next_cache; F.corr = d.corr; F.eps = nullptr; F.khkw = d.khkw; F.next_tag_off = d.next_tag_off;
+            F.src_relu = src.relu ? 1 : 0; F.pad = 0;
+            p->steps[P].fold = (int)folds.size();
+            folds.push_back(F);
+            folded_into[D] = P;
+        }
+        p->n_folds = (int)folds.size();
+        if (!folds.empty()) {
+            if ((e = hipMalloc((void**)&p->d_folds, sizeof(BcFoldDev) * folds.size())) != hipSuccess) return fail_alloc(e);
+            if ((e = hipMemcpy(p->d_folds, folds.data(), sizeof(BcFoldDev) * folds.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail_alloc(e);
+        }
+    }
+    const int n_live = n_steps - p->n_folds;       // steps that are launched
+    // launch j = the j-th LIVE step of every network (steps arrive network by network, in graph order)
+    {
+        std::vector<int> ordinal(n_steps, -1);
         int n_launch = 0;
         for (int s2 = 0, cur_net = -1, k = 0; s2 < n_steps; ++s2) {
             if (steps[s2].net != cur_net) { cur_net = steps[s2].net; k = 0; }
+            if (folded_into[s2] >= 0) continue;
             ordinal[s2] = k++;
             n_launch = std::max(n_launch, k);
         }
         p->launches.assign(n_launch, dfq_bc_plan::Launch{0, 0, 0, 0});
-        for (int s2 = 0; s2 < n_steps; ++s2) p->launches[ordinal[s2]].n += 1;
+        for (int s2 = 0; s2 < n_steps; ++s2) if (ordinal[s2] >= 0) p->launches[ordinal[s2]].n += 1;
         int off = 0;
         for (auto& L : p->launches) { L.begin = off; off += L.n; L.n = 0; }
-        p->launch_steps.resize(n_steps);
+        p->launch_steps.resize(n_live);
         // A launch wants enough workgroups to occupy the chip (a single network is latency-bound: one
         // row per wave, every row in flight at once) but no more than that (each workgroup rebuilds the
         // expectation vector and pays the descriptor round trip): rows per wave shrink until the launch
@@ -814,8 +917,9 @@ int dfq_bc_plan_create(const dfq_layer* layers, int32_t n_layers, const dfq_bc_s
         const char* te = getenv("DFQ_BC_BLOCKS");
         const int target = (te && atoi(te) > 0) ? atoi(te) : 512;
         std::vector<int> n_in_launch(n_launch, 0);
-        for (int s2 = 0; s2 < n_steps; ++s2) n_in_launch[ordinal[s2]] += 1;
+        for (int s2 = 0; s2 < n_steps; ++s2) if (ordinal[s2] >= 0) n_in_launch[ordinal[s2]] += 1;
         for (int s2 = 0; s2 < n_steps; ++s2) {
+            if (ordinal[s2] < 0) continue;
             BcStepDev& d = p->steps[s2];
             const int rps = kWave >> d.lg_lanes;
             int rw = d.rows_per_block / kRowsPerBlock;
@@ -825,24 +929,28 @@ int dfq_bc_plan_create(const dfq_layer* layers, int32_t n_layers, const dfq_bc_s
             d.rows_per_block = rw * kRowsPerBlock;
         }
         for (int s2 = 0; s2 < n_steps; ++s2) {
+            if (ordinal[s2] < 0) continue;
             auto& L = p->launches[ordinal[s2]];
             p->launch_steps[L.begin + L.n++] = p->steps[s2];
             L.max_blocks = std::max(L.max_blocks, (p->steps[s2].out_ch + p->steps[s2].rows_per_block - 1) / p->steps[s2].rows_per_block);
             L.max_expect = std::max(L.max_expect, p->steps[s2].expect_len);
         }
-        if ((e = hipMalloc((void**)&p->d_steps, sizeof(BcStepDev) * n_steps)) != hipSuccess) return fail_alloc(e);
-        if ((e = hipMemcpy(p->d_steps, p->launch_steps.data(), sizeof(BcStepDev) * n_steps, hipMemcpyHostToDevice)) != hipSuccess) return fail_alloc(e);
-        // workgroup table of the one-launch chain: chain position after chain position; step s2 waits for the previous
-        // step of its network (steps arrive network by network in graph order, so that is s2 - 1)
-        std::vector<int> pos(n_steps, 0), fill(n_launch, 0);
-        for (int s2 = 0; s2 < n_steps; ++s2) pos[s2] = p->launches[ordinal[s2]].begin + fill[ordinal[s2]]++;
-        std::vector<int> wait_of(n_steps, -1), blocks_of(n_steps, 0);
-        for (int s2 = 0; s2 < n_steps; ++s2) {
+        if ((e = hipMalloc((void**)&p->d_steps, sizeof(BcStepDev) * n_live)) != hipSuccess) return fail_alloc(e);
+        if ((e = hipMemcpy(p->d_steps, p->launch_steps.data(), sizeof(BcStepDev) * n_live, hipMemcpyHostToDevice)) != hipSuccess) return fail_alloc(e);
+        // workgroup table of the one-launch chain: chain position after chain position; a step waits for the previous LIVE
+        // step of its network (steps arrive network by network in graph order)
+        std::vector<int> pos(n_steps, -1), fill(n_launch, 0);
+        for (int s2 = 0; s2 < n_steps; ++s2) if (ordinal[s2] >= 0) pos[s2] = p->launches[ordinal[s2]].begin + fill[ordinal[s2]]++;
+        std::vector<int> wait_of(n_live, -1), blocks_of(n_live, 0);
+        for (int s2 = 0, prev_live = -1, cur_net = -1; s2 < n_steps; ++s2) {
+            if (steps[s2].net != cur_net) { cur_net = steps[s2].net; prev_live = -1; }
+            if (ordinal[s2] < 0) continue;
             blocks_of[pos[s2]] = (p->steps[s2].out_ch + p->steps[s2].rows_per_block - 1) / p->steps[s2].rows_per_block;
-            if (ordinal[s2] > 0) wait_of[pos[s2]] = pos[s2 - 1];
+            if (prev_live >= 0) wait_of[pos[s2]] = pos[prev_live];
+            prev_live = s2;
         }
         std::vector<BcChainRef> refs;
-        for (int q = 0; q < n_steps; ++q) {
+        for (int q = 0; q < n_live; ++q) {
             p->max_expect = std::max(p->max_expect, p->launch_steps[q].expect_len);
             for (int b = 0; b < blocks_of[q]; ++b)
                 refs.push_back(BcChainRef{q, b, wait_of[q], wait_of[q] >= 0 ? blocks_of[wait_of[q]] : 0});
@@ -923,10 +1031,10 @@ static int bc_run_direct(dfq_bc_plan* p, int32_t symmetric, hipStream_t st) {
         const int spin_limit = spin_limit_from_env(20000000);
         if (p->max_expect <= kExpectSmall)
             hipLaunchKernelGGL(bc_chain_kernel<kExpectSmall>, dim3(p->chain_blocks), dim3(kBlock), 0, st, (const BcStepDev*)p->d_steps,
-                               (const BcChainRef*)p->d_refs, (const BcSourceDev*)p->d_sources, p->d_counters, err, tags, p->epoch, (int)symmetric, spin_limit);
+                               (const BcChainRef*)p->d_refs, (const BcSourceDev*)p->d_sources, (const BcFoldDev*)p->d_folds, p->d_counters, err, tags, p->epoch, (int)symmetric, spin_limit);
         else
             hipLaunchKernelGGL(bc_chain_kernel<kExpectMax>, dim3(p->chain_blocks), dim3(kBlock), 0, st, (const BcStepDev*)p->d_steps,
-                               (const BcChainRef*)p->d_refs, (const BcSourceDev*)p->d_sources, p->d_counters, err, tags, p->epoch, (int)symmetric, spin_limit);
+                               (const BcChainRef*)p->d_refs, (const BcSourceDev*)p->d_sources, (const BcFoldDev*)p->d_folds, p->d_counters, err, tags, p->epoch, (int)symmetric, spin_limit);
         DFQ_CHECK_LAUNCH();
         return DFQ_OK;
     }
@@ -934,10 +1042,10 @@ static int bc_run_direct(dfq_bc_plan* p, int32_t symmetric, hipStream_t st) {
         const BcStepDev* table = (L.n == 1) ? nullptr : p->d_steps + L.begin;
         if (L.max_expect <= kExpectSmall)
             hipLaunchKernelGGL(bc_step_kernel<kExpectSmall>, dim3(L.max_blocks, L.n), dim3(kBlock), 0, st,
-                               p->launch_steps[L.begin], table, (const BcSourceDev*)p->d_sources, (int)symmetric);
+                               p->launch_steps[L.begin], table, (const BcSourceDev*)p->d_sources, (const BcFoldDev*)p->d_folds, (int)symmetric);
         else
             hipLaunchKernelGGL(bc_step_kernel<kExpectMax>, dim3(L.max_blocks, L.n), dim3(kBlock), 0, st,
-                               p->launch_steps[L.begin], table, (const BcSourceDev*)p->d_sources, (int)symmetric);
+                               p->launch_steps[L.begin], table, (const BcSourceDev*)p->d_sources, (const BcFoldDev*)p->d_folds, (int)symmetric);
         DFQ_CHECK_LAUNCH();
     }
     return DFQ_OK;
@@ -967,5 +1075,7 @@ const float* dfq_bc_plan_correction(const dfq_bc_plan* p, int32_t step) {
 int64_t dfq_bc_plan_weight_elements(const dfq_bc_plan* p) { return p ? p->weight_elems : 0; }
 int32_t dfq_bc_plan_tagged(const dfq_bc_plan* p) { return (p && p->merged && p->d_tags) ? 1 : 0; }
 int64_t dfq_bc_plan_eps_elements(const dfq_bc_plan* p) { return p ? p->eps_elems : 0; }
+int32_t dfq_bc_plan_folded(const dfq_bc_plan* p) { return p ? p->n_folds : 0; }
+int32_t dfq_bc_plan_chain_steps(const dfq_bc_plan* p) { return p ? (int32_t)p->launches.size() : 0; }
 
 }  // extern "C"

@@ -1041,6 +1041,16 @@ class BCPlan:
         """True when the one-launch chain hands values over as tagged 64-bit slots (see dfq_bc_plan_tagged)."""
         return bool(_ffi.lib().dfq_bc_plan_tagged(self._plan))
 
+    @property
+    def folded_steps(self):
+        """Depthwise steps performed by the tail of the step in front of them (dfq_bc_plan_folded)."""
+        return int(_ffi.lib().dfq_bc_plan_folded(self._plan))
+
+    @property
+    def chain_steps(self):
+        """Dependent positions of the correction chain (dfq_bc_plan_chain_steps)."""
+        return int(_ffi.lib().dfq_bc_plan_chain_steps(self._plan))
+
     def status(self):
         """Synchronise and raise if a workgroup of the one-launch chain abandoned its wait (nothing was stored by it)."""
         _ffi.check(_ffi.lib().dfq_bc_plan_status(self._plan, _ffi.stream_arg()))

@@ -339,6 +339,14 @@ int64_t dfq_bc_plan_weight_elements(const dfq_bc_plan* plan);
  * counters (DFQ_BC_TAGGED=0, or a graph the tagged scheme does not cover) or one launch per chain position. */
 int32_t dfq_bc_plan_tagged(const dfq_bc_plan* plan);
 int64_t dfq_bc_plan_eps_elements(const dfq_bc_plan* plan);
+/* Depthwise steps folded into the per-row tail of the step in front of them, and the dependent positions the chain is left
+ * with (MobileNetV2: 17 of 52 steps folded -> 35 positions).  A layer with one input channel per group and as many groups as
+ * outputs corrects channel o with eps[o] * E[o] alone (dfq.py:281-287 with I/g = 1), and E[o] is what the thread owning row o
+ * of the previous step has just produced (dfq.py:204-206, 238-242): that thread performs the depthwise layer's update too --
+ * the same operations in the same order, bit-identical -- and one hand-over through the memory system per depthwise layer
+ * disappears.  DFQ_BC_FOLD=0 in the environment at plan creation keeps every step. */
+int32_t dfq_bc_plan_folded(const dfq_bc_plan* plan);
+int32_t dfq_bc_plan_chain_steps(const dfq_bc_plan* plan);
 
 /* _quantize_error (dfq.py:8-25) on one tensor: q(x) - x with per-tensor min/max, 5 reductions:
  *   reduction 0: none   -> out[n]

@@ -31,7 +31,8 @@ def main():
     ap.add_argument('--seed', type=int, default=0)
     ap.add_argument('--sweeps', type=int, default=2)
     ap.add_argument('--full-sweeps', type=int, default=0, help='sweeps of a whole pass (for the extrapolated weights/s)')
-    ap.add_argument('--threads', type=int, default=0)
+    ap.add_argument('--threads', type=int, default=0, help='torch intra-op threads (default min(8, cores): the reference\'s path is a Python loop of '
+                    'tiny per-channel ops; on the 256-thread GPU box torch.set_num_threads(256) was measured 4-5x SLOWER than 8)')
     args = ap.parse_args()
     if not os.path.isfile(os.path.join(REFDIR, 'dfq.pyc')):
         print(json.dumps({'error': 'oracle/_ref is not built (oracle/build_ref.py needs /root/reference)'}))
@@ -48,7 +49,7 @@ def main():
     from dfq_amd import synthetic
 
     targ = [nn.Conv2d, nn.Linear]
-    cores = args.threads or os.cpu_count()
+    cores = args.threads or min(8, os.cpu_count())
     torch.set_num_threads(cores)
     _stdout = sys.stdout
     sys.stdout = open(os.devnull, 'w')                      # the reference prints progress lines

@@ -551,6 +551,53 @@ def test_bias_correction_hand_over_protocols_agree(engine, monkeypatch, mode):
         plan.close()
 
 
+@pytest.mark.parametrize('mode', ['tagged', 'counters', 'per-position'])
+def test_folded_depthwise_steps_are_invisible(engine, monkeypatch, mode):
+    """Round 4: a depthwise correction step (one input per group: channel o needs E[o] only) is performed by the per-row tail
+    of the step that produces its source BN (dfq_bc.hip: BcFoldDev) -- one hand-over through the memory system less per
+    depthwise layer.  Same operations in the same order: corrected biases, BN proxies and correction vectors are
+    BIT-IDENTICAL to the plan that keeps every step (DFQ_BC_FOLD=0), under all three hand-over protocols, and a second run
+    of the plan repeats the first."""
+    for k in ('DFQ_BC_TAGGED', 'DFQ_BC_MERGED', 'DFQ_BC_FOLD'):
+        monkeypatch.delenv(k, raising=False)
+    if mode == 'counters':
+        monkeypatch.setenv('DFQ_BC_TAGGED', '0')
+    if mode == 'per-position':
+        monkeypatch.setenv('DFQ_BC_MERGED', '0')
+    seen_fold = 0
+    for name, seed, suffix in [('tiny_mobile', 0, ''), ('tiny_mobile', 2, '_signed'), ('tiny_cat', 0, ''), ('tiny_res', 0, '')]:
+        gold = net_fixture(name, seed, suffix)
+        signed = suffix == '_signed'
+        results = {}
+        for fold in ('1', '0'):
+            monkeypatch.setenv('DFQ_BC_FOLD', fold)
+            model, graph, bottoms = _build(name, seed, gold, engine)
+            lt.merge_batchnorm(model, graph, bottoms, TARG)
+            load_stage(graph, gold, 'abs')
+            plan, keys = dfq.build_bc_plan(graph, bottoms, TARG)
+            n_steps = len(keys)
+            if fold == '0':
+                assert plan.folded_steps == 0 and plan.chain_steps == n_steps
+            else:
+                assert plan.chain_steps == n_steps - plan.folded_steps
+                seen_fold += plan.folded_steps
+            plan.run(signed=signed)
+            snap = snapshot(graph)
+            corr = [npy(plan.correction(i)) for i in range(n_steps)]
+            load_stage(graph, gold, 'abs')
+            plan.run(signed=signed)                              # second run of the same plan
+            for k, v in snapshot(graph).items():
+                assert_bitexact(v, snap[k], '{} second run {}'.format(name, k))
+            plan.close()
+            results[fold] = (snap, corr)
+            compare_stage(snap, gold, 'bc', what='{} fold={} {}'.format(name, fold, mode))
+        for k in results['1'][0]:
+            assert_bitexact(results['1'][0][k], results['0'][0][k], '{} folded vs unfolded {}'.format(name, k))
+        for i, (a, b) in enumerate(zip(results['1'][1], results['0'][1])):
+            assert_bitexact(a, b, '{} correction vector of step {}'.format(name, i))
+    assert seen_fold > 0, 'no fixture exercised a folded step'
+
+
 def test_bias_correction_intermediates_against_oracle(engine, monkeypatch):
     """eps (quant-error row sums, dfq.py:216-219) and the correction vectors (dfq.py:281-287) read back from
     the plan: eps is float32 elementwise work in the oracle's order (bit-exact), the matvec is 1e-5.  The chain forms the
