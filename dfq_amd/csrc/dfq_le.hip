@@ -2016,6 +2016,10 @@ int dfq_le_plan_create_batch(const dfq_layer* layers, int32_t n_layers, const in
 // workgroups (= LDS-resident tiles) of the persistent whole-loop launch, 0 when the plan streams
 int32_t dfq_le_plan_resident_tiles(const dfq_le_plan* p) { return (p && p->resident) ? le_resident_tiles(p->resident) : 0; }
 const char* dfq_le_plan_resident_reason(const dfq_le_plan* p) { return p ? p->resident_why.c_str() : ""; }
+int dfq_le_resident_stats(dfq_le_plan* p, void* stream, int64_t* out5) {
+    if (!p || !p->resident) return fail_arg("dfq_le_resident_stats: not a resident plan");
+    return le_resident_stats(p->resident, as_stream(stream), out5);
+}
 // persistent workgroups of a streaming sweep launch (le_sweep_kernel), 0 when the plan launches one workgroup per tile
 int32_t dfq_le_plan_sweep_workgroups(const dfq_le_plan* p) { return (p && !p->resident) ? p->sweep_grid : 0; }
 

@@ -53,10 +53,6 @@ constexpr int kResOwn = kResRows / kBlock;
 constexpr int kResStride = 16;       // one 64-bit counter per 128-byte line
 constexpr int kResMaxTiles = 1536;   // partials staged in LDS when the sweep's verdict is drawn
 constexpr int kResMaxLayers = 512;
-#ifndef DFQ_RES_EAGER
-#define DFQ_RES_EAGER 0              // 1: a sweep is applied in phase 3 itself (verdict of the previous sweep taken BEFORE it: measured
-                                     // slower, 24.6 vs 21.6 us per sweep -- the verdict then sits on the chain's critical path); 0: lazily
-#endif
 #ifndef DFQ_RES_TOPWAIT
 #define DFQ_RES_TOPWAIT 0            // 1: the sweep's first poll also WAITS for phase 2's counter (A/B; slower: see the loop)
 #endif
@@ -77,8 +73,8 @@ struct ResTile {                     // one workgroup
     int32_t layout;                  // kLayGeneral / kLayFixed / kLayShort
     int32_t relax_r;                 // 1: every row of this layer lives in ONE tile -> its row statistics have a single producer
     int32_t relax_c;                 // 1: every input channel of this layer lives in ONE tile -> likewise for its column statistics
-    int32_t slot;                    // logical index of the tile (partial-sum slot, reducer id): the table itself is in LAUNCH order
-    int32_t pad3;
+    int32_t slot;                    // logical index of the tile (partial-sum slot, checkpoint slot): the table itself is in LAUNCH order
+    int32_t log_off;                 // first float of this tile inside an entry of the factor log: 1/s_A per table entry, then s_B per row
 };
 
 struct ResRel {
@@ -104,18 +100,23 @@ struct ResArgs {
     int64_t parity_stride;           // u64 words between the parities of an arena
     u64* cnt_r;                      // [paired layer][8 copies] (x kResStride): tiles that published row statistics (see arrive)
     u64* cnt_c;                      //   "   column statistics
-    u64* seq;                        // [3][8 copies] (x kResStride): two words {sweep + 1 : half of diff_tmp}, by sweep % 3
+    u64* prog;                       // [8 copies] (x kResStride): {sweeps that happen, once the loop has stopped : verdicts drawn}
     u64* err;
-    double* partials;                // [3 parities][tiles][2]: {sweep + 1 : half of the tile's float64 sum of |dW|}
+    double* partials;                // [part_ring][tiles][2]: {sweep + 1 : half of the tile's float64 sum of |dW|}
+    float* log;                      // [log_ring][log_total]: the factors of the latest sweeps (see "speculation past the verdict")
+    float* ckpt;                     // [2][tiles][kCkptFloats]: alternating checkpoints of the LDS tiles
+    int64_t log_total;               // floats of one log entry (all tiles)
     LeState* state;
     int32_t n_tiles, n_layers;       // n_layers: targ layers of the network (layer_diff entries)
-    int32_t reducer;                 // the tile that sums the partials of a sweep and publishes the result
     int32_t n_sweeps;                // sweeps this launch may run
     int32_t max_sweeps;              // cfg: total cap (< 0: none)
     int32_t converge_count;
+    int32_t spec;                    // sweeps a tile may run ahead of the verdicts (0: none)
+    int32_t ckpt_every;              // sweeps between two checkpoints (>= spec)
+    int32_t log_ring, part_ring;     // ckpt_every + spec; spec + 2
     int32_t pad;
     double converge_thres;
-    long long* trace;                // tuning aid (null in production): [tile][kTraceSweeps][8] wall-clock stamps
+    long long* trace;                // tuning aid (null in production): [tile][kTraceSweeps][kTracePoints] wall-clock stamps
 };
 
 constexpr int kTraceSweeps = 6;
@@ -137,39 +138,6 @@ template <bool kTrace>
 __device__ __forceinline__ void res_stamp(const ResArgs& a, int k, int point) {
     if (kTrace && threadIdx.x == 0 && k < kTraceSweeps)
         cold(a).trace[((int64_t)blockIdx.x * kTraceSweeps + k) * kTracePoints + point] = wall_clock64();
-}
-
-// ---- waits ---------------------------------------------------------------------------------------------
-// up to three counters at once (null = not needed): one poll loop by one thread, all loads in flight.  The third one is
-// waited for only if `need3`; returns 0: a wait was abandoned, 1: the first two are there, 2: all three are there.
-__device__ __forceinline__ int res_wait3(const u64* w1, u64 t1, const u64* w2, u64 t2, const u64* w3, u64 t3, bool need3, u64* err,
-                                         int* sh_flag, long kResSpinLimit) {
-    if (threadIdx.x == 0) {
-        long spins = 0;
-        int ok = 1;
-        for (;;) {
-            const u64 a1 = w1 ? __hip_atomic_load(w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : t1;
-            const u64 a2 = w2 ? __hip_atomic_load(w2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : t2;
-            const u64 a3 = w3 ? __hip_atomic_load(w3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : t3;
-            if (a1 >= t1 && a2 >= t2 && (a3 >= t3 || !need3)) { ok = (a3 >= t3) ? 2 : 1; break; }
-            __builtin_amdgcn_s_sleep(1);
-            ++spins;
-            if (spins > kResSpinLimit ||
-                ((spins & 255) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull)) {
-                atomicMax(err, 1ull);
-                ok = 0;
-                break;
-            }
-        }
-        *sh_flag = ok;
-    }
-    __syncthreads();
-    const int ok = *sh_flag;
-    __syncthreads();                 // sh_flag may be rewritten by the next wait
-    return ok;
-}
-__device__ __forceinline__ bool res_wait2(const u64* w1, u64 t1, const u64* w2, u64 t2, u64* err, int* sh_flag, long limit) {
-    return res_wait3(w1, t1, w2, t2, nullptr, 0, false, err, sh_flag, limit) != 0;
 }
 
 __device__ __forceinline__ u64 ld_word(const u64* p) {
@@ -336,17 +304,18 @@ struct LayGeneral {
         });
     }
     __device__ __forceinline__ double diff_and_cols(const ResTile&, const TileGeo&, float*, bool, bool, const float*, const float*, uint32_t*, bool = false) const { return 0.0; }
-    // the thread's sum of |new - old| in float64; `commit`: w <- new
+    // w <- new; kDiff: returns the thread's sum of |new - old| in float64 (else 0: the replay of a rollback)
+    template <bool kDiff>
     __device__ __forceinline__ double update(const ResTile& T, const TileGeo& G, float* tile, bool useA, bool useB,
-                                             const float* sh_inv, const float* sh_s, bool commit) const {
+                                             const float* sh_inv, const float* sh_s) const {
         double acc = 0.0;
         slots(T, tile, [&](float* x, int row, int pos, bool on) {
             double part = 0.0;
 #pragma unroll
             for (int k = 0; k < VEC; ++k) {
                 const float nv = val(T, G, x[k], useA, useB, sh_inv, sh_s, row, pos + k);
-                part += (double)abs_f32(nv - x[k]);
-                if (commit && on) x[k] = nv;
+                if (kDiff) part += (double)abs_f32(nv - x[k]);
+                if (on) x[k] = nv;
             }
             acc += on ? part : 0.0;
         });
@@ -507,8 +476,9 @@ struct LayFixed {
                                               const float* sh_inv, const float* sh_s, uint32_t* sh_col) const {
         (void)diff_and_cols(T, G, tile, useA, useB, sh_inv, sh_s, sh_col);
     }
+    template <bool kDiff>
     __device__ __forceinline__ double update(const ResTile& T, const TileGeo& G, float* tile, bool useA, bool useB,
-                                             const float* sh_inv, const float* sh_s, bool commit) const {
+                                             const float* sh_inv, const float* sh_s) const {
         double acc = 0.0;
         float iv[4] = {1.0f, 1.0f, 1.0f, 1.0f};
         if (useA && one_group) inv4(T, G, sh_inv, 0, iv);
@@ -521,9 +491,9 @@ struct LayFixed {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 nv[k] = (xv[k] * iv[k]) * s;                      // dfq.py:73 (rounded), then dfq.py:62
-                if (!commit || DFQ_RES_EAGER) part += (double)abs_f32(nv[k] - xv[k]);
+                if (kDiff) part += (double)abs_f32(nv[k] - xv[k]);
             }
-            if (commit) *(fvec4*)x = nv;                          // the thread's own slot (padded lanes hold private duplicates)
+            *(fvec4*)x = nv;                                      // the thread's own slot (padded lanes hold private duplicates)
             acc += on ? part : 0.0;
         });
         return acc;
@@ -623,16 +593,17 @@ struct LayShort {
         });
     }
     __device__ __forceinline__ double diff_and_cols(const ResTile&, const TileGeo&, float*, bool, bool, const float*, const float*, uint32_t*, bool = false) const { return 0.0; }
+    template <bool kDiff>
     __device__ __forceinline__ double update(const ResTile& T, const TileGeo& G, float* tile, bool useA, bool useB,
-                                             const float* sh_inv, const float* sh_s, bool commit) const {
+                                             const float* sh_inv, const float* sh_s) const {
         double acc = 0.0;
         rows(T, tile, [&](int j, int row, bool on, float* base) {
             const float fa = fa_of(j, useA, sh_inv), fb = useB ? sh_s[row] : 1.0f;
             double part = 0.0;
             elems(base, [&](int e, float x) {
                 const float nv = val(x, j, e, useA, fa, fb, sh_inv);
-                part += (double)abs_f32(nv - x);
-                if (commit) base[e * kBlock] = nv;
+                if (kDiff) part += (double)abs_f32(nv - x);
+                base[e * kBlock] = nv;
             });
             acc += on ? part : 0.0;
         });
@@ -662,8 +633,8 @@ __device__ __forceinline__ void publish_cols(const ResArgs& a, const ResTile& T,
     }
 }
 
-// The loop state of dfq.py:81-83,110-115.  EVERY workgroup advances its own copy from the same partial sums in the same
-// order (identical everywhere), so no workgroup has to wait for another one's verdict.
+// The loop state of dfq.py:81-83,110-115: advanced by ONE workgroup, the reducer (res_reducer_body), which publishes what the
+// tiles need to know of it in a single 64-bit progress word {number of sweeps that HAPPEN, once known : verdicts drawn}.
 struct LoopState {
     double diff, last_diff_tmp;
     int count, sweeps, done;
@@ -682,105 +653,92 @@ __device__ __forceinline__ double ordered_sum(const double* x, int n) {
     return s;
 }
 
-// dfq.py:105-108 after sweep k: sum over the layers (graph order) of mean |dW|, from the tiles' partial sums (fixed order).
-// Done by ONE workgroup (tile 0, a tile of the network's first paired layer: small, early, mostly idle) and published; the
-// others pick the number up a whole sweep later (see the commit logic), so this reduction is on nobody's critical path.
-// `mine` = layer_diff[threadIdx.x], loaded once before the loop.
-__device__ __forceinline__ double reduce_diff(const ResArgs& a, int k, const ResLayerDiff& mine, double* sh_d, double* sh_mean, int* sh_bad,
-                                              long kResSpinLimit) {
-    const int tid = threadIdx.x;
-    const auto& c = cold(a);
-    const int n_tiles = c.n_tiles, n_layers = c.n_layers;
-    // a tile's partial sum is two words {sweep tag : half of the float64}: the reducer reads the words themselves until they
-    // carry this sweep's tag -- no arrival counter between the tile's store and this load
-    const u64* part = (const u64*)c.partials + (int64_t)(k % 3) * 2 * n_tiles;
-    const u64 want = (u64)(k + 1);
-    for (int i = tid; i < n_tiles; i += kBlock) {
-        long tries = 0;
-        u64 hi, lo;
+// ---- speculation past the verdict (round 4) -----------------------------------------------------------------------
+// dfq.py:105-115 decides after sweep k whether sweep k + 1 happens, from the sum over ALL layers of mean |dW|: a global
+// reduction behind every sweep.  Until round 3 a tile applied sweep k to its weights only once the verdict of sweep k - 1 had
+// arrived (speculation depth one), and the builder's own trace showed nearly every tile idle 10-20 us of every 18 us sweep
+// waiting for exactly that.  Now a sweep is applied AT ONCE (one pass forms the new values, |dW| and the statistics, and writes
+// them to the LDS tile) and a tile may run up to `spec` sweeps ahead of the verdicts; nothing on a chain's dependency cycle
+// waits for the reduction any more.  The price is a rollback when the verdict finally says "the loop stopped after sweep j"
+// and the tile has already applied sweeps j + 1 .. k:
+//   * every sweep's factors (1/s_A per input channel of the tile, s_B per row: <= 6 KB) go to a ring in global memory with
+//     fire-and-forget stores from the threads that solved them (phases 1 and 2);
+//   * every `ckpt` sweeps the LDS tile (raw, 32 KB) and the thread's [O] vector entries go to one of two alternating
+//     checkpoint buffers, fire-and-forget as well (checkpoint 0 is the untouched tensor in place: nothing is stored into the
+//     caller's weights before the loop has stopped);
+//   * rollback = reload the newest checkpoint at or before sweep j + 1 and replay the logged factors: the same two rounded
+//     multiplications per element and sweep in the same order, so the result is bit-identical to never having speculated.
+// Ring sizes: a tile starts sweep k only when the verdicts of sweeps < k - spec are out, so it is at most `spec` sweeps past
+// the stopping point: partial sums spec + 2 deep, factor log ckpt + spec deep, two checkpoints (spec <= ckpt).
+// Stopping: the reducer publishes the stop in the progress word; every spin loop of a tile looks at that word too, so a
+// tile waiting for statistics of a sweep that will never be produced (its producer has left) leaves as well.
+constexpr int kCkptFloats = kResTileFloats + 4 * kResOwn * kBlock;      // raw tile + (s_cum, bn_w, bn_b, b1) x owned rows per thread
+
+__device__ __forceinline__ u64* prog_line(u64* base, int copy) { return base + (int64_t)copy * kResStride; }
+
+// One poll loop by one thread for everything a sweep's start depends on: up to three statistics counters (null = not needed;
+// the third one is only looked at unless `need3`), the speculation bound (verdicts out >= need_v) and the stop.
+// Returns 0: a wait was abandoned, 1: go (the first two counters are there), 2: go (all three are there), 3: the loop has stopped.
+__device__ __forceinline__ int res_wait(const u64* w1, u64 t1, const u64* w2, u64 t2, const u64* w3, u64 t3, bool need3,
+                                        const u64* prog, uint32_t need_v, u64* err, int* sh_flag, long kResSpinLimit) {
+    if (threadIdx.x == 0) {
+        long spins = 0;
+        int ok = 1;
         for (;;) {
-            hi = ld_word(part + 2 * i); lo = ld_word(part + 2 * i + 1);
-            if ((hi >> 32) == want && (lo >> 32) == want) break;
+            const u64 a1 = w1 ? __hip_atomic_load(w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : t1;
+            const u64 a2 = w2 ? __hip_atomic_load(w2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : t2;
+            const u64 a3 = w3 ? __hip_atomic_load(w3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : t3;
+            const u64 pg = __hip_atomic_load(prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((uint32_t)(pg >> 32) != 0u) { ok = 3; break; }
+            if (a1 >= t1 && a2 >= t2 && (a3 >= t3 || !need3) && (uint32_t)pg >= need_v) { ok = (a3 >= t3) ? 2 : 1; break; }
             __builtin_amdgcn_s_sleep(1);
-            if (++tries > kResSpinLimit ||
-                ((tries & 255) == 0 && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull)) {
-                atomicMax(a.err, 1ull); *sh_bad = 1; break;
+            ++spins;
+            if (spins > kResSpinLimit ||
+                ((spins & 255) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull)) {
+                atomicMax(err, 1ull);
+                ok = 0;
+                break;
             }
         }
-        sh_d[i] = __longlong_as_double((long long)((hi << 32) | (lo & 0xffffffffull)));
+        *sh_flag = ok;
     }
     __syncthreads();
-    for (int l = tid; l < n_layers; l += kBlock) {
-        const ResLayerDiff L = (l == tid) ? mine : c.layer_diff[l];
-        const double s = ordered_sum(sh_d + L.tile_begin, L.n_tiles);              // fixed order
-        // float(torch.mean(torch.abs(W - W_prev))): float32 mean, widened to double (dfq.py:108)
-        sh_mean[l] = (L.n_tiles > 0) ? (double)(float)(s / L.n_elems) : 0.0;
-    }
-    __syncthreads();
-    const double diff_tmp = ordered_sum(sh_mean, n_layers);                        // graph order, like Python's sum
-    __syncthreads();                 // sh_d / sh_mean are reused
-    return diff_tmp;
+    const int ok = *sh_flag;
+    __syncthreads();                 // sh_flag may be rewritten by the next wait
+    return ok;
 }
 
-// dfq.py:110-115: every workgroup advances its own copy of the loop state with the published diff_tmp
-__device__ __forceinline__ void advance_state(const ResArgs& a, LoopState& st, double diff_tmp) {
-    if (fabs(st.diff - diff_tmp) > 1e-9) { st.count = 0; st.diff = diff_tmp; }
-    else { st.count += 1; }
-    st.sweeps += 1;
-    st.last_diff_tmp = diff_tmp;
-    const auto& c = cold(a);
-    const bool go_on = (st.diff > c.converge_thres) && (st.count < c.converge_count) && (c.max_sweeps < 0 || st.sweeps < c.max_sweeps);
-    st.done = go_on ? 0 : 1;
-}
-
-// The verdict of sweep k: the reducing tile collects all partials, reduces and publishes diff_tmp as two words {k + 1 : half of
-// the float64} (one copy per XCD: every tile of the launch polls it); everybody else reads the two words until both carry
-// k + 1 (normally at the first look: the publication is most of a sweep old).  Returns false when a wait was abandoned.
-__device__ __forceinline__ bool verdict(const ResArgs& a, int k, LoopState& st, const ResLayerDiff& mine, double* sh_dec, int* sh_flag, int* sh_bad,
-                                        double* sh_val, long kResSpinLimit, int slot) {
-    const auto& c = cold(a);
-    const u64 want = (u64)(k + 1);
-    double diff_tmp;
-    if (slot == c.reducer) {
-        diff_tmp = reduce_diff(a, k, mine, sh_dec, sh_dec + kResMaxTiles, sh_bad, kResSpinLimit);
-        if (*sh_bad) return false;                                   // (read behind reduce_diff's barriers)
-        if (threadIdx.x < 8) {
-            u64* copy = cold(a).seq + ((k % 3) * 8 + threadIdx.x) * kResStride;
-            const u64 bits = (u64)__double_as_longlong(diff_tmp);
-            __hip_atomic_store(copy, (want << 32) | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(copy + 1, (want << 32) | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    } else {
-        const u64* slot = c.seq + ((k % 3) * 8 + (blockIdx.x & 7)) * kResStride;
-        if (threadIdx.x == 0) {
-            long spins = 0;
-            int ok = 1;
-            u64 hi, lo;
-            for (;;) {
-                hi = ld_word(slot); lo = ld_word(slot + 1);
-                if ((hi >> 32) == want && (lo >> 32) == want) break;
-                __builtin_amdgcn_s_sleep(1);
-                if (++spins > kResSpinLimit ||
-                    ((spins & 255) == 0 && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull)) {
-                    atomicMax(a.err, 1ull); ok = 0; break;
-                }
+// The end of a tile's loop: wait until the verdict of every sweep this tile has applied is out (or the stop is).  Returns the
+// number of sweeps to keep, or -1 when the wait was abandoned.
+__device__ __forceinline__ int res_final(const u64* prog, int applied, u64* err, int* sh_flag, long kResSpinLimit) {
+    if (threadIdx.x == 0) {
+        long spins = 0;
+        int keep = -1;
+        for (;;) {
+            const u64 pg = __hip_atomic_load(prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((uint32_t)(pg >> 32) != 0u) { keep = min((int)(uint32_t)(pg >> 32), applied); break; }
+            if ((uint32_t)pg >= (uint32_t)applied) { keep = applied; break; }
+            __builtin_amdgcn_s_sleep(1);
+            ++spins;
+            if (spins > kResSpinLimit ||
+                ((spins & 255) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull)) {
+                atomicMax(err, 1ull);
+                break;
             }
-            *sh_val = __longlong_as_double((long long)((hi << 32) | (lo & 0xffffffffull)));
-            *sh_flag = ok;
         }
-        __syncthreads();
-        const bool ok = *sh_flag != 0;
-        diff_tmp = *sh_val;
-        __syncthreads();
-        if (!ok) return false;
+        *sh_flag = keep;
     }
-    advance_state(a, st, diff_tmp);
-    return true;
+    __syncthreads();
+    const int keep = *sh_flag;
+    __syncthreads();
+    return keep;
 }
 
 template <typename Lay, bool kTrace>
 __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& p, const ResTile& T, unsigned char* smem) {
-    // LDS: [tile: kResTileFloats f32][inv: kResTab f32][s: kResRows f32][row stats: 2 * kResRows u32][col stats: 2 * kResTab u32][flag]
+    // LDS: [tile: kResTileFloats f32][inv: kResTab f32][s: kResRows f32][row stats: 2 * kResRows u32][col stats: 2 * kResTab u32][flags: 16 words]
+    //      [b1 of the owned rows: kResRows f32 -- one of the four [O] vectors lives here instead of in registers: the kernel runs AT its
+    //       register limit (168 for three workgroups per CU) and the LDS has 2 KB to spare per workgroup]
     float* v = (float*)smem;                       // the tile
     float* sh_inv = v + kResTileFloats;
     float* sh_s = sh_inv + kResTab;
@@ -788,10 +746,8 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
     uint32_t* sh_col = sh_row + 2 * kResRows;
     int* sh_flag = (int*)(sh_col + 2 * kResTab);
     int* sh_bad = sh_flag + 1;                     // set by a thread whose statistics words never showed this sweep's tag
-    double* sh_val = (double*)(sh_flag + 2);       // the verdict's diff_tmp, broadcast by the polling thread
+    float* sh_ob1 = (float*)(sh_flag + 16);
     if (threadIdx.x == 0) *sh_bad = 0;
-    // the reducing tile (the smallest one) stages the partial sums in the unused tail of its tile
-    double* sh_dec = (double*)(v + kResTileFloats / 2);
     const int tid = threadIdx.x;
     const long kResSpinLimit = p.spin_limit;
     const bool hasA = T.relA >= 0, hasB = T.relB >= 0;
@@ -802,70 +758,106 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
     const int64_t ra_r1 = cold(a).rels[hasA ? T.relA : 0].r1_off, ra_r2 = cold(a).rels[hasA ? T.relA : 0].r2_off;
     const int64_t rb_r1 = cold(a).rels[hasB ? T.relB : 0].r1_off, rb_r2 = cold(a).rels[hasB ? T.relB : 0].r2_off;
     const TileGeo G = tile_geo(T);
+    const int n_ch = hasA ? G.g_n * G.nci : 0;
     Lay lay;
     lay.init(T, G);
-    LoopState st;
+    // sweeps this launch may run: its own budget and what the loop's cap leaves (the state carries the sweeps of earlier launches)
+    int cap;
     {
-        const LeState* s0 = cold(a).state;
-        st.diff = s0->diff; st.last_diff_tmp = s0->last_diff_tmp;
-        st.count = s0->count; st.sweeps = s0->sweeps; st.done = 0;
+        const auto& c = cold(a);
+        cap = c.n_sweeps;
+        if (c.max_sweeps >= 0) cap = min(cap, c.max_sweeps - c.state->sweeps);
     }
-    ResLayerDiff my_layer;
-    my_layer.tile_begin = 0; my_layer.n_tiles = 0; my_layer.n_elems = 1.0;
-    if (tid < cold(a).n_layers) my_layer = cold(a).layer_diff[tid];
-
-    // ---- load the tile (once) ----
-    lay.load(T, v);
-    // the [O] vectors of relation B for the rows this thread owns
-    float o_cum[kResOwn], o_bnw[kResOwn], o_bnb[kResOwn], o_b1[kResOwn];
     const bool owner = hasB && T.owner != 0;
+    float o_cum[kResOwn], o_bnw[kResOwn], o_bnb[kResOwn];      // (b1: sh_ob1[tid + j * kBlock], touched by its own thread only)
+    // ---- load the tile and the [O] vectors of relation B for the rows this thread owns (also: checkpoint 0 of a rollback) ----
+    auto load_pristine = [&]() {
+        lay.load(T, v);
 #pragma unroll
-    for (int j = 0; j < kResOwn; ++j) {
-        const int i = tid + j * kBlock;
-        o_cum[j] = 1.0f; o_bnw[j] = 0.0f; o_bnb[j] = 0.0f; o_b1[j] = 0.0f;
-        if (owner && i < T.nr) {
-            const ResRel RB = cold(a).rels[T.relB];
-            const int c = T.r0 + i;
-            o_cum[j] = RB.s_cum[c];
-            if (RB.bnw) o_bnw[j] = RB.bnw[c];
-            if (RB.bnb) o_bnb[j] = RB.bnb[c];
-            if (RB.b1) o_b1[j] = RB.b1[c];
+        for (int j = 0; j < kResOwn; ++j) {
+            const int i = tid + j * kBlock;
+            o_cum[j] = 1.0f; o_bnw[j] = 0.0f; o_bnb[j] = 0.0f;
+            float b1 = 0.0f;
+            if (owner && i < T.nr) {
+                const ResRel RB = cold(a).rels[T.relB];
+                const int c = T.r0 + i;
+                o_cum[j] = RB.s_cum[c];
+                if (RB.bnw) o_bnw[j] = RB.bnw[c];
+                if (RB.bnb) o_bnb[j] = RB.bnb[c];
+                if (RB.b1) b1 = RB.b1[c];
+            }
+            sh_ob1[i] = b1;
+        }
+    };
+    load_pristine();
+
+    // ---- statistics of the untouched weights: consumption tag 1 (sweep 0) ----
+    if (cap > 0) {
+        if (hasA) {
+            for (int i = tid; i < 2 * G.g_n * G.nci; i += kBlock) sh_col[i] = 0u;
+            __syncthreads();
+            lay.col_stats(T, G, v, false, false, sh_inv, sh_s, sh_col);
+            __syncthreads();
+            publish_cols(a, T, G, ra_r2, sh_col, 1u);
+            arrive(a.cnt_c, T.layer, !T.relax_c);
+        }
+        if (chain_start) {
+            for (int i = tid; i < 2 * T.nr; i += kBlock) sh_row[i] = 0u;
+            __syncthreads();
+            lay.row_stats(T, G, v, false, false, sh_inv, sh_s, sh_row);
+            __syncthreads();
+            publish_rows(a, T, rb_r1, sh_row, 1u);
+            arrive(a.cnt_r, T.layer, !T.relax_r);
         }
     }
 
-    // ---- statistics of the untouched weights: consumption tag 1 (sweep 0) ----
-    if (hasA) {
-        for (int i = tid; i < 2 * G.g_n * G.nci; i += kBlock) sh_col[i] = 0u;
-        __syncthreads();
-        lay.col_stats(T, G, v, false, false, sh_inv, sh_s, sh_col);
-        __syncthreads();
-        publish_cols(a, T, G, ra_r2, sh_col, 1u);
-        arrive(a.cnt_c, T.layer, !T.relax_c);
-    }
-    if (chain_start) {
-        for (int i = tid; i < 2 * T.nr; i += kBlock) sh_row[i] = 0u;
-        __syncthreads();
-        lay.row_stats(T, G, v, false, false, sh_inv, sh_s, sh_row);
-        __syncthreads();
-        publish_rows(a, T, rb_r1, sh_row, 1u);
-        arrive(a.cnt_r, T.layer, !T.relax_r);
-    }
+    // this tile's entry of the factor log / its checkpoint slot (see "speculation past the verdict")
+    auto log_entry = [&](int sweep) -> float* {
+        const auto& c = cold(a);
+        return c.log + (int64_t)(sweep % c.log_ring) * c.log_total + T.log_off;
+    };
+    auto ckpt_slot = [&](int which) -> float* {
+        const auto& c = cold(a);
+        return c.ckpt + ((int64_t)(which & 1) * c.n_tiles + T.slot) * kCkptFloats;
+    };
 
-    int k = 0;
-    bool failed = false;
-    for (;; ++k) {
+    int k = 0;                       // sweeps applied to the LDS tile so far == the sweep about to run
+    bool failed = false, stopped = false;
+    for (; k < cap; ++k) {
+        // ---- checkpoint after every `ckpt_every`-th sweep (here, at the start of the next one): the raw LDS tile (each thread its
+        //      own 16-byte words, whatever the layout) and the thread's [O] entries, fire-and-forget.  Everything is formed from an
+        //      index the compiler cannot see through: nothing of this cold block is precomputed and kept in registers across the
+        //      sweep loop (the kernel runs AT its register limit) ----
+        if (k > 0 && k % cold(a).ckpt_every == 0) {
+            float* ck = ckpt_slot(k / cold(a).ckpt_every);
+            int ti = tid;
+            opaque(ti);
+            const unsigned tt = (unsigned)ti;
+            gfvec4* gk = (gfvec4*)ck;
+#pragma unroll 1
+            for (unsigned u = 0; u < (unsigned)(kResTileFloats / (4 * kBlock)); ++u)
+                gk[u * kBlock + tt] = *(const fvec4*)(v + (u * kBlock + tt) * 4);
+            if (owner) {
+                gfloat* go = (gfloat*)ck + kResTileFloats;
+#pragma unroll
+                for (int j = 0; j < kResOwn; ++j) {
+                    go[(4 * j + 0) * kBlock + tt] = o_cum[j]; go[(4 * j + 1) * kBlock + tt] = o_bnw[j];
+                    go[(4 * j + 2) * kBlock + tt] = o_bnb[j]; go[(4 * j + 3) * kBlock + tt] = sh_ob1[tt + j * kBlock];
+                }
+            }
+        }
         const uint32_t tag = (uint32_t)k + 1u;                  // what this sweep consumes
         const u64 round = (u64)k + 1ull;
         res_stamp<kTrace>(a, k, 0);
         // ---- what this sweep consumes.  Phase 1 (s_A) needs the row statistics of A's first layer (this sweep: the chain's
         //      hand-off) and this layer's own column statistics (previous sweep); phase 2 (s_B) needs the column statistics of
-        //      B's second layer (previous sweep).  ONE poll looks at all three counters; it waits only for phase 1's.  If phase
-        //      2's are there as well (the usual case: they are a sweep old), every statistics word of the tile is requested in
-        //      the same trip through the memory system and phase 2 never waits; otherwise phase 2 polls and reads later -- the
-        //      row statistics this tile publishes in phase 1 must not wait for that (the tiles of B's second layer overlap
-        //      their own work with it).  A chain start paces itself on its own layer's row counter (its tiles do not otherwise
-        //      wait for each other, and a tile two publications ahead of a sibling would make the monotonic counter lie to the
-        //      layer's consumers). ----
+        //      B's second layer (previous sweep).  ONE poll looks at all three counters, at the speculation bound and at the
+        //      stop; it waits only for phase 1's counters and the bound.  If phase 2's are there as well (the usual case: they
+        //      are a sweep old), every statistics word of the tile is requested in the same trip through the memory system and
+        //      phase 2 never waits; otherwise phase 2 polls and reads later -- the row statistics this tile publishes in phase
+        //      1 must not wait for that (the tiles of B's second layer overlap their own work with it).  A chain start paces
+        //      itself on its own layer's row counter (its tiles do not otherwise wait for each other, and a tile two
+        //      publications ahead of a sibling would make the monotonic counter lie to the layer's consumers). ----
         bool have_b = false;
         {
             const int copy = blockIdx.x & 7;
@@ -873,12 +865,13 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
             const u64 t1 = (u64)(hasA ? T.nt_a : T.nt_self) * round;
             const u64* c2 = hasA ? cnt_line(a.cnt_c, T.layer, copy) : nullptr;
             const u64* c3 = hasB ? cnt_line(a.cnt_c, T.b_layer, copy) : nullptr;
-            const int got = res_wait3(c1, t1, c2, (u64)T.nt_self * round, c3, (u64)T.nt_b * round, DFQ_RES_TOPWAIT != 0, a.err, sh_flag, kResSpinLimit);
+            const int got = res_wait(c1, t1, c2, (u64)T.nt_self * round, c3, (u64)T.nt_b * round, DFQ_RES_TOPWAIT != 0,
+                                     prog_line(cold(a).prog, blockIdx.x & 7), (uint32_t)max(k - cold(a).spec, 0), a.err, sh_flag, kResSpinLimit);
             if (!got) { failed = true; break; }
+            if (got == 3) { stopped = true; break; }
             have_b = hasB && got == 2;
         }
         res_stamp<kTrace>(a, k, 15);
-        const int n_ch = hasA ? G.g_n * G.nci : 0;
         RangeWords w1[kResTab / kBlock], w2[kResTab / kBlock], v1[kResOwn], v2[kResOwn];
         {
             // A word whose producer arrived "relaxed" (see arrive) may still show the previous sweep's tag: read again.  Words
@@ -915,6 +908,11 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
                 if (++tries > kResSpinLimit / 16) { atomicMax(a.err, 1ull); *sh_bad = 1; break; }
             }
         }
+        // (the factor log: uniform base + an index the compiler cannot hoist -- see the checkpoint block)
+        gfloat* const lg = (gfloat*)log_entry(k);
+        int lt_i = tid;
+        opaque(lt_i);
+        const unsigned lt = (unsigned)lt_i;
         // ---- phase 1: s_A per (group, input channel) of the tile ----
         if (hasA) {
 #pragma unroll
@@ -925,7 +923,7 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
                     decode_range(w1[j], tag, mn1, mx1);
                     decode_range(w2[j], tag, mn2, mx2);
                     le_solve(range_of(mn1, mx1, p.signed_range), range_of(mn2, mx2, p.signed_range), p, s, inv);
-                    if (idx < n_ch) sh_inv[idx] = inv;
+                    if (idx < n_ch) { sh_inv[idx] = inv; lg[lt + (unsigned)(j * kBlock)] = inv; }       // (the log: fire-and-forget)
                 }
             }
             res_stamp<kTrace>(a, k, 1);
@@ -952,8 +950,11 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
             const bool own_wait = !rows_local && !chain_start;
             if (own_wait || !have_b) {
                 const int copy = blockIdx.x & 7;
-                if (!res_wait2(own_wait ? cnt_line(a.cnt_r, T.layer, copy) : nullptr, (u64)T.nt_self * round,
-                               have_b ? nullptr : cnt_line(a.cnt_c, T.b_layer, copy), (u64)T.nt_b * round, a.err, sh_flag, kResSpinLimit)) { failed = true; break; }
+                const int got = res_wait(own_wait ? cnt_line(a.cnt_r, T.layer, copy) : nullptr, (u64)T.nt_self * round,
+                                         have_b ? nullptr : cnt_line(a.cnt_c, T.b_layer, copy), (u64)T.nt_b * round, nullptr, 0, false,
+                                         prog_line(cold(a).prog, blockIdx.x & 7), 0u, a.err, sh_flag, kResSpinLimit);
+                if (!got) { failed = true; break; }
+                if (got == 3) { stopped = true; break; }          // (nothing of sweep k has been applied)
             }
             if (!rows_local || !have_b) {
                 long tries = 0;
@@ -981,24 +982,17 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
                     else decode_range(v1[j], tag, mn1, mx1);
                     decode_range(v2[j], tag, mn2, mx2);
                     le_solve(range_of(mn1, mx1, p.signed_range), range_of(mn2, mx2, p.signed_range), p, s, inv);
-                    sh_s[i] = s;                                  // also applied to the [O] vectors when the sweep is committed
+                    sh_s[i] = s;                                  // also applied to the [O] vectors below
+                    lg[(unsigned)n_ch + lt + (unsigned)(j * kBlock)] = s;     // (the log: fire-and-forget)
                 }
             }
         }
         res_stamp<kTrace>(a, k, 3);
-#if DFQ_RES_EAGER
-        // ---- phase 3: w <- fl(fl(w / s_A) * s_B), |dW| and the statistics of the new values in ONE pass over the tile.  It needs
-        //      to know that sweep k-1 was not the last one (then sweep k must not happen): the verdict of sweep k-1 is taken HERE,
-        //      most of a sweep after this tile left its partial sum -- for all but the tiles at the end of the longest chain it
-        //      has long been published.  (Until round 3 the sweep was applied lazily: statistics and |dW| from pending factors in
-        //      one pass, the multiplication again in a second pass after the verdict -- a third of a tile's instructions.) ----
+        // ---- phase 3: w <- fl(fl(w / s_A) * s_B) (dfq.py:73 then :62, both rounded), |dW| and the statistics of the new values
+        //      in ONE pass over the tile.  Applied at once: whether sweep k happens at all is found out later (see
+        //      "speculation past the verdict"). ----
         __syncthreads();                                          // sh_s complete; sh_row / sh_col free
         if (*sh_bad) { failed = true; break; }                    // a statistics word of phase 2 never showed this sweep's tag
-        if (k > 0) {
-            if (!verdict(a, k - 1, st, my_layer, sh_dec, sh_flag, sh_bad, sh_val, kResSpinLimit, T.slot)) { failed = true; break; }
-            if (st.done) break;                                   // sweep k-1 was the last one: sweep k is dropped
-        }
-        res_stamp<kTrace>(a, k, 6);
         if (hasA) for (int i = tid; i < 2 * G.g_n * G.nci; i += kBlock) sh_col[i] = 0u;
         if (chain_start) for (int i = tid; i < 2 * T.nr; i += kBlock) sh_row[i] = 0u;
         __syncthreads();
@@ -1007,7 +1001,7 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
         if (Lay::kFusedCols && hasA) {
             acc = lay.diff_and_cols(T, G, v, hasA, hasB, sh_inv, sh_s, sh_col, true);
         } else {
-            acc = lay.update(T, G, v, hasA, hasB, sh_inv, sh_s, true);
+            acc = lay.template update<true>(T, G, v, hasA, hasB, sh_inv, sh_s);
             if (hasA) lay.col_stats(T, G, v, false, false, sh_inv, sh_s, sh_col);      // of the values just written
         }
         if (chain_start) lay.row_stats(T, G, v, false, false, sh_inv, sh_s, sh_row);
@@ -1023,12 +1017,13 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
             arrive(a.cnt_r, T.layer, !T.relax_r);
         }
         res_stamp<kTrace>(a, k, 4);
-        // ---- convergence: one partial per tile (fixed butterfly + fixed wave order); the reducing tile sums them per layer ----
+        // ---- convergence: one partial per tile (fixed butterfly + fixed wave order) as two tagged words; the reducer workgroup
+        //      reads them until they carry k + 1, sums them per layer and draws the verdict -- off every tile's path ----
         {
             const double tsum = block_sum(acc, (double*)sh_col);     // sh_col is free again (statistics published)
             if (tid == 0) {
-                const auto& c = cold(a);            // two tagged words, no counter: the reducer reads them until they carry k + 1
-                u64* dst = (u64*)c.partials + ((int64_t)(k % 3) * c.n_tiles + T.slot) * 2;
+                const auto& c = cold(a);
+                u64* dst = (u64*)c.partials + ((int64_t)(k % c.part_ring) * c.n_tiles + T.slot) * 2;
                 const u64 bits = (u64)__double_as_longlong(tsum), tg = (u64)(k + 1) << 32;
                 __hip_atomic_store(dst, tg | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(dst + 1, tg | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1036,61 +1031,6 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
             res_stamp<kTrace>(a, k, 5);
         }
         if (kTrace && tid == 0 && k == 0) cold(a).trace[((int64_t)blockIdx.x * kTraceSweeps) * kTracePoints + 7] = ((long long)T.layer << 32) | (unsigned)T.nr << 16 | (unsigned)(T.nc & 0xffff);
-        res_stamp<kTrace>(a, k, 11);
-#else
-        // ---- phase 3: |dW| and the statistics of the values this sweep WILL produce (w itself is not touched yet) ----
-        __syncthreads();                                          // sh_s complete; sh_row / sh_col free
-        if (*sh_bad) { failed = true; break; }                    // a statistics word of phase 2 never showed this sweep's tag
-        if (hasA) for (int i = tid; i < 2 * G.g_n * G.nci; i += kBlock) sh_col[i] = 0u;
-        if (chain_start) for (int i = tid; i < 2 * T.nr; i += kBlock) sh_row[i] = 0u;
-        __syncthreads();
-        res_stamp<kTrace>(a, k, 8);
-        double acc;
-        if (Lay::kFusedCols && hasA) {
-            acc = lay.diff_and_cols(T, G, v, hasA, hasB, sh_inv, sh_s, sh_col);
-        } else {
-            acc = lay.update(T, G, v, hasA, hasB, sh_inv, sh_s, false);
-            if (hasA) lay.col_stats(T, G, v, hasA, hasB, sh_inv, sh_s, sh_col);
-        }
-        if (chain_start) lay.row_stats(T, G, v, hasA, hasB, sh_inv, sh_s, sh_row);
-        res_stamp<kTrace>(a, k, 9);
-        __syncthreads();
-        res_stamp<kTrace>(a, k, 10);
-        if (hasA) {
-            publish_cols(a, T, G, ra_r2, sh_col, tag + 1u);
-            arrive(a.cnt_c, T.layer, !T.relax_c);
-        }
-        if (chain_start) {
-            publish_rows(a, T, rb_r1, sh_row, tag + 1u);
-            arrive(a.cnt_r, T.layer, !T.relax_r);
-        }
-        res_stamp<kTrace>(a, k, 4);
-        // ---- convergence.  One partial per tile (fixed butterfly + fixed wave order); when the partials of a sweep are all
-        //      in, every workgroup draws the same verdict from them.  The verdict of sweep k-1 is needed only HERE, a whole
-        //      sweep after its partials were written: sweep k is applied to the registers ("committed") only once sweep k-1 is
-        //      known not to have been the last one, so nobody ever waits for a verdict in the middle of the dependency chain
-        //      and a workgroup of a short chain may already work on sweep k+1 while a long chain finishes sweep k. ----
-        {
-            const double tsum = block_sum(acc, (double*)sh_col);     // sh_col is free again (statistics published)
-            if (tid == 0) {
-                const auto& c = cold(a);            // two tagged words, no counter: the reducer reads them until they carry k + 1
-                u64* dst = (u64*)c.partials + ((int64_t)(k % 3) * c.n_tiles + T.slot) * 2;
-                const u64 bits = (u64)__double_as_longlong(tsum), tg = (u64)(k + 1) << 32;
-                __hip_atomic_store(dst, tg | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(dst + 1, tg | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            res_stamp<kTrace>(a, k, 5);
-            if (k > 0) {
-                if (!verdict(a, k - 1, st, my_layer, sh_dec, sh_flag, sh_bad, sh_val, kResSpinLimit, T.slot)) { failed = true; break; }
-                if (st.done) break;                               // sweep k-1 was the last one: sweep k is dropped
-            }
-        }
-        res_stamp<kTrace>(a, k, 6);
-        if (kTrace && tid == 0 && k == 0) cold(a).trace[((int64_t)blockIdx.x * kTraceSweeps) * kTracePoints + 7] = ((long long)T.layer << 32) | (unsigned)T.nr << 16 | (unsigned)(T.nc & 0xffff);
-        // ---- commit sweep k ----
-        (void)lay.update(T, G, v, hasA, hasB, sh_inv, sh_s, true);
-        res_stamp<kTrace>(a, k, 11);
-#endif
         if (hasB) {
 #pragma unroll
             for (int j = 0; j < kResOwn; ++j) {
@@ -1098,15 +1038,63 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
                 o_cum[j] = o_cum[j] * sj;                         // relation.py:20-24
                 o_bnw[j] = o_bnw[j] * sj;                         // dfq.py:64-65
                 o_bnb[j] = o_bnb[j] * sj;                         // dfq.py:67-68
-                o_b1[j] = o_b1[j] * sj;                           // dfq.py:70-71
+                sh_ob1[tid + j * kBlock] = sh_ob1[tid + j * kBlock] * sj;   // dfq.py:70-71
             }
         }
-        if (k + 1 >= cold(a).n_sweeps) {                          // the launch's last sweep: its verdict closes the state
-            if (!verdict(a, k, st, my_layer, sh_dec, sh_flag, sh_bad, sh_val, kResSpinLimit, T.slot)) failed = true;
-            break;
-        }
+        res_stamp<kTrace>(a, k, 6);
+        res_stamp<kTrace>(a, k, 11);
     }
     if (failed) return;                     // this tile stores nothing (others may have: the run reports DFQ_ERR_STATE, see the header)
+    // ---- how many of the k applied sweeps happen ----
+    (void)stopped;
+    const int keep = res_final(prog_line(cold(a).prog, blockIdx.x & 7), k, a.err, sh_flag, kResSpinLimit);
+    if (keep < 0) return;
+    if (keep < k) {
+        // rollback: newest checkpoint at or before `keep` sweeps, then the logged factors of the sweeps up to `keep`
+        __builtin_amdgcn_s_waitcnt(0);      // this workgroup's own log / checkpoint stores have been performed
+        __syncthreads();
+        if (tid == 0) {                     // statistics of the launch (tests, tuning): tiles that rolled back, sweeps undone
+            u64* sts = prog_line(cold(a).prog, 8);
+            atomicAdd(sts, 1ull);
+            atomicAdd(sts + 1, (u64)(k - keep));
+            atomicMax(sts + 2, (u64)(k - keep));
+        }
+        const int ckpt_every = cold(a).ckpt_every;
+        const int c0 = (keep / ckpt_every) * ckpt_every;
+        if (c0 == 0) {
+            load_pristine();
+        } else {
+            const float* ck = ckpt_slot(c0 / ckpt_every);
+#pragma unroll 1
+            for (int u = 0; u < kResTileFloats / (4 * kBlock); ++u)
+                *(fvec4*)(v + (u * kBlock + tid) * 4) = *(const gfvec4*)(ck + (u * kBlock + tid) * 4);
+            if (owner) {
+#pragma unroll
+                for (int j = 0; j < kResOwn; ++j) {
+                    const float* o = ck + kResTileFloats + (4 * j) * kBlock + tid;
+                    o_cum[j] = o[0]; o_bnw[j] = o[kBlock]; o_bnb[j] = o[2 * kBlock]; sh_ob1[tid + j * kBlock] = o[3 * kBlock];
+                }
+            }
+        }
+        for (int q = c0; q < keep; ++q) {
+            const float* lq = log_entry(q);
+            __syncthreads();                                      // the previous replay step has read the tables
+            for (int idx = tid; idx < n_ch; idx += kBlock) sh_inv[idx] = lq[idx];
+            if (hasB) for (int i = tid; i < T.nr; i += kBlock) sh_s[i] = lq[n_ch + i];
+            __syncthreads();
+            (void)lay.template update<false>(T, G, v, hasA, hasB, sh_inv, sh_s);
+            if (hasB) {
+#pragma unroll
+                for (int j = 0; j < kResOwn; ++j) {
+                    const float sj = sh_s[min(tid + j * kBlock, T.nr - 1)];
+                    o_cum[j] = o_cum[j] * sj; o_bnw[j] = o_bnw[j] * sj; o_bnb[j] = o_bnb[j] * sj;
+                    sh_ob1[tid + j * kBlock] = sh_ob1[tid + j * kBlock] * sj;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (keep == 0) return;                  // nothing happened: the tensors stay as they are
     // ---- write the tile back (once) ----
     lay.store(T, v);
 #pragma unroll
@@ -1118,17 +1106,85 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
             RB.s_cum[c] = o_cum[j];
             if (RB.bnw) RB.bnw[c] = o_bnw[j];
             if (RB.bnb) RB.bnb[c] = o_bnb[j];
-            if (RB.b1) RB.b1[c] = o_b1[j];
+            if (RB.b1) RB.b1[c] = sh_ob1[i];
         }
     }
-    if (T.slot == cold(a).reducer && tid == 0) {
-        LeState* o = cold(a).state;
+}
+
+// ---- the reducer: one extra workgroup (the launch's last) that holds no tile.  For sweep j = 0, 1, ... it reads the tiles'
+//      partial sums until all carry j + 1, forms dfq.py:105-108 -- per layer float(mean |dW|) from the tiles' float64 partials
+//      in a fixed order, summed over the layers in graph order like Python's sum -- advances the reference's (diff, count)
+//      state machine (dfq.py:110-115) and publishes {sweeps that happen, once the loop has stopped : verdicts drawn} in eight
+//      copies of the progress word.  Nobody waits for it inside a dependency chain. ----
+__device__ __forceinline__ void res_reducer_body(const ResArgs& a, const LeParams& p, unsigned char* smem) {
+    double* sh_d = (double*)smem;                                  // [kResMaxTiles] partial sums of one sweep
+    double* sh_mean = sh_d + kResMaxTiles;                         // [kResMaxLayers]
+    int* sh_bad = (int*)(sh_mean + kResMaxLayers);
+    const int tid = threadIdx.x;
+    const long kResSpinLimit = p.spin_limit;
+    const auto& c = cold(a);
+    const int n_tiles = c.n_tiles, n_layers = c.n_layers;
+    LoopState st;
+    {
+        const LeState* s0 = c.state;
+        st.diff = s0->diff; st.last_diff_tmp = s0->last_diff_tmp;
+        st.count = s0->count; st.sweeps = s0->sweeps; st.done = 0;
+    }
+    int cap = c.n_sweeps;
+    if (c.max_sweeps >= 0) cap = min(cap, c.max_sweeps - st.sweeps);
+    if (tid == 0) *sh_bad = 0;
+    __syncthreads();
+    for (int j = 0; j < cap; ++j) {
+        const u64* part = (const u64*)c.partials + (int64_t)(j % c.part_ring) * 2 * n_tiles;
+        const u64 want = (u64)(j + 1);
+        for (int i = tid; i < n_tiles; i += kBlock) {
+            long tries = 0;
+            u64 hi, lo;
+            for (;;) {
+                hi = ld_word(part + 2 * i); lo = ld_word(part + 2 * i + 1);
+                if ((hi >> 32) == want && (lo >> 32) == want) break;
+                __builtin_amdgcn_s_sleep(1);
+                if (++tries > kResSpinLimit ||
+                    ((tries & 255) == 0 && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull)) {
+                    atomicMax(a.err, 1ull); *sh_bad = 1; break;
+                }
+            }
+            sh_d[i] = __longlong_as_double((long long)((hi << 32) | (lo & 0xffffffffull)));
+        }
+        __syncthreads();
+        if (*sh_bad) return;                                        // abandoned: the tiles give up through the error word
+        for (int l = tid; l < n_layers; l += kBlock) {
+            const ResLayerDiff L = c.layer_diff[l];
+            const double s = ordered_sum(sh_d + L.tile_begin, L.n_tiles);              // fixed order
+            // float(torch.mean(torch.abs(W - W_prev))): float32 mean, widened to double (dfq.py:108)
+            sh_mean[l] = (L.n_tiles > 0) ? (double)(float)(s / L.n_elems) : 0.0;
+        }
+        __syncthreads();
+        const double diff_tmp = ordered_sum(sh_mean, n_layers);                        // graph order, like Python's sum
+        __syncthreads();                 // sh_d / sh_mean are reused
+        // dfq.py:110-115
+        if (fabs(st.diff - diff_tmp) > 1e-9) { st.count = 0; st.diff = diff_tmp; }
+        else { st.count += 1; }
+        st.sweeps += 1;
+        st.last_diff_tmp = diff_tmp;
+        const bool go_on = (st.diff > c.converge_thres) && (st.count < c.converge_count) && (c.max_sweeps < 0 || st.sweeps < c.max_sweeps);
+        st.done = go_on ? 0 : 1;
+        if (tid < 8) {
+            const u64 word = ((u64)(st.done ? (uint32_t)(j + 1) : 0u) << 32) | (u64)(uint32_t)(j + 1);
+            __hip_atomic_store(prog_line(a.prog, tid), word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (st.done) break;
+    }
+    if (tid == 0) {
+        LeState* o = c.state;
         o->diff = st.diff; o->last_diff_tmp = st.last_diff_tmp; o->count = st.count; o->sweeps = st.sweeps; o->done = st.done;
     }
 }
 
-constexpr size_t kResSmemBytes = sizeof(float) * (kResTileFloats + kResTab + kResRows) + sizeof(uint32_t) * 2 * (kResRows + kResTab) + 64;
-static_assert(sizeof(double) * (kResMaxTiles + kResMaxLayers) <= sizeof(float) * kResTileFloats / 2, "partials are staged in half a tile");
+constexpr size_t kResSmemBytes = sizeof(float) * (kResTileFloats + kResTab + kResRows) + sizeof(uint32_t) * 2 * (kResRows + kResTab) + 64 +
+                                 sizeof(float) * kResRows;
+static_assert(3 * kResSmemBytes <= 160 * 1024, "three workgroups per CU");
+static_assert(sizeof(double) * (kResMaxTiles + kResMaxLayers) + 64 <= kResSmemBytes, "the reducer stages a sweep's partial sums in its LDS");
 
 enum { kLayGeneral = 0, kLayFixed = 1, kLayShort = 2 };
 
@@ -1136,6 +1192,7 @@ template <bool kTrace>      // 3 waves per SIMD: at most 168 registers (three wo
 __global__ __launch_bounds__(kBlock, 3) void le_resident_kernel(ResArgs a, LeParams p) {
     DFQ_DYN_SMEM(smem);
     if (a.state->done) return;              // already stopped (uniform over the launch: written before it started)
+    if ((int)blockIdx.x == a.n_tiles) { res_reducer_body(a, p, smem); return; }
     const ResTile T = a.tiles[blockIdx.x];
     if (T.layout == kLayFixed) res_tile_body<LayFixed, kTrace>(a, p, T, smem);
     else if (T.layout == kLayShort) res_tile_body<LayShort, kTrace>(a, p, T, smem);
@@ -1151,7 +1208,11 @@ using namespace dfq;
 // host side
 // ---------------------------------------------------------------------------------------------
 struct dfq::LeResident {
-    int n_tiles = 0, n_pl = 0, n_rels = 0, n_layers = 0, reducer = 0;
+    int n_tiles = 0, n_pl = 0, n_rels = 0, n_layers = 0;
+    int spec = 2, ckpt_every = 8;    // speculation depth and checkpoint period of the launch (DFQ_RES_SPEC, DFQ_RES_CKPT)
+    float* d_log = nullptr;          // [ckpt_every + spec][log_total]
+    float* d_ckpt = nullptr;         // [2][n_tiles][kCkptFloats]
+    int64_t log_total = 0;
     ResTile* d_tiles = nullptr;
     ResRel* d_rels = nullptr;
     ResLayerDiff* d_layer_diff = nullptr;
@@ -1161,7 +1222,7 @@ struct dfq::LeResident {
     u64* d_sync = nullptr;           // cnt_r | cnt_c | done | seq
     size_t sync_words = 0;
     double* d_partials = nullptr;
-    int64_t elements = 0;            // floats held in registers
+    int64_t elements = 0;            // floats held in LDS
 };
 
 namespace {
@@ -1249,10 +1310,22 @@ void le_resident_destroy(LeResident* r) {
     if (r->d_stats) (void)hipFree(r->d_stats);
     if (r->d_sync) (void)hipFree(r->d_sync);
     if (r->d_partials) (void)hipFree(r->d_partials);
+    if (r->d_log) (void)hipFree(r->d_log);
+    if (r->d_ckpt) (void)hipFree(r->d_ckpt);
     delete r;
 }
 
 int le_resident_tiles(const LeResident* r) { return r ? r->n_tiles : 0; }
+// of the LAST launch: out[0] tiles that rolled back, out[1] sweeps undone in total, out[2] most sweeps undone by one tile,
+// out[3] speculation depth, out[4] checkpoint period.  Synchronises `st`.
+int le_resident_stats(const LeResident* r, hipStream_t st, int64_t* out5) {
+    if (!r || !out5) return fail_arg("le_resident_stats: bad argument");
+    u64 w[3] = {0, 0, 0};
+    DFQ_HIP_TRY(hipMemcpyAsync(w, r->d_sync + (size_t)(16 * r->n_pl + 8) * kResStride, sizeof(w), hipMemcpyDeviceToHost, st));
+    DFQ_HIP_TRY(hipStreamSynchronize(st));
+    out5[0] = (int64_t)w[0]; out5[1] = (int64_t)w[1]; out5[2] = (int64_t)w[2]; out5[3] = r->spec; out5[4] = r->ckpt_every;
+    return DFQ_OK;
+}
 int le_resident_trace_words(const LeResident* r) { return r ? r->n_tiles * kTraceSweeps * kTracePoints : 0; }
 int64_t le_resident_elements(const LeResident* r) { return r ? r->elements : 0; }
 
@@ -1331,12 +1404,9 @@ LeResident* le_resident_create(const dfq_layer* layers, int n_layers, const dfq_
             }
         tile_count[l] = n_rb * n_cb;
     }
-    if ((int)tiles.size() > cap_tiles || (int)tiles.size() > kResMaxTiles)
+    if ((int)tiles.size() + 1 > cap_tiles || (int)tiles.size() > kResMaxTiles)       // + 1: the reducer workgroup
         return refuse("the network does not fit the chip's LDS: " + std::to_string(tiles.size()) + " tiles > " +
-                      std::to_string(std::min(cap_tiles, kResMaxTiles)) + " resident workgroups");
-    // the reducing tile stages the partial sums in the upper half of its own tile: the smallest tile, and it must fit
-    int reducer = -1;
-    int64_t best_fp = (int64_t)1 << 60;
+                      std::to_string(std::min(cap_tiles - 1, kResMaxTiles)) + " resident workgroups");
     for (size_t i = 0; i < tiles.size(); ++i) {
         const ResTile& T = tiles[i];
         int64_t fp;
@@ -1349,9 +1419,7 @@ LeResident* le_resident_create(const dfq_layer* layers, int n_layers, const dfq_
             fp = (int64_t)ceil_div_i(T.nr * (T.nc / T.vec), kBlock) * kBlock * T.vec;
         }
         if (fp > kResTileFloats) return refuse("internal: a tile exceeds the LDS tile");
-        if (fp < best_fp) { best_fp = fp; reducer = (int)i; }
     }
-    if (reducer < 0 || best_fp > kResTileFloats / 2) return refuse("no tile small enough to stage the partial sums");
     for (ResTile& T : tiles) {
         // tiles per layer (by paired-layer index)
         for (int l = 0; l < n_layers; ++l) {
@@ -1364,7 +1432,21 @@ LeResident* le_resident_create(const dfq_layer* layers, int n_layers, const dfq_
     //      b + 512 share a CU -- and its instruction issue.  The tiles at the END of the longest chain are the ones whose phases
     //      sit on the sweep's critical cycle: they go first (one per CU), the tiles of early layers, which mostly
     //      wait for the verdict, fill the second and third slot.  DFQ_RES_ORDER=0 keeps layer order. ----
-    for (size_t i = 0; i < tiles.size(); ++i) tiles[i].slot = (int32_t)i;
+    // a tile's share of one entry of the factor log: 1/s_A per (group, input channel) it spans, then s_B per row
+    int64_t log_total = 0;
+    for (size_t i = 0; i < tiles.size(); ++i) {
+        ResTile& T = tiles[i];
+        T.slot = (int32_t)i;
+        int n_ch = 0;
+        if (T.relA >= 0) {
+            const int i0 = T.c0 / T.khkw, nci = (T.c0 + T.nc - 1) / T.khkw - i0 + 1;
+            const int g_lo = T.r0 / T.go, g_n = (T.r0 + T.nr - 1) / T.go - g_lo + 1;
+            n_ch = g_n * nci;
+            if (n_ch > kResTab) return refuse("internal: a tile's factor table exceeds the LDS table");
+        }
+        T.log_off = (int32_t)log_total;
+        log_total += (n_ch + (T.relB >= 0 ? T.nr : 0) + 63) / 64 * 64;
+    }
     {
         const char* oe = getenv("DFQ_RES_ORDER");
         if (!(oe && oe[0] == '0')) {
@@ -1379,7 +1461,7 @@ LeResident* le_resident_create(const dfq_layer* layers, int n_layers, const dfq_
         }
     }
     LeResident* r = new LeResident();
-    r->n_tiles = (int)tiles.size(); r->n_pl = n_pl; r->n_rels = n_relations; r->n_layers = n_layers; r->reducer = reducer; r->elements = total;
+    r->n_tiles = (int)tiles.size(); r->n_pl = n_pl; r->n_rels = n_relations; r->n_layers = n_layers; r->elements = total;
     // statistics arenas: per relation `channels` = O1 entries of 2 words, two parities; r1 arena then r2 arena
     std::vector<ResRel> hr(n_relations);
     int64_t ch_total = 0;
@@ -1402,13 +1484,24 @@ LeResident* le_resident_create(const dfq_layer* layers, int n_layers, const dfq_
         ld[l].n_tiles = tile_count[l];
         ld[l].n_elems = (double)((int64_t)layers[l].out_ch * layers[l].in_per_group * layers[l].khkw);
     }
-    r->sync_words = (size_t)(16 * n_pl + 24) * kResStride;                  // counters [2][n_pl][8] | verdict[3][8]
+    r->sync_words = (size_t)(16 * n_pl + 9) * kResStride;                   // counters [2][n_pl][8] | progress word [8] | rollback statistics
+    {   // speculation depth / checkpoint period (A/B switches)
+        const char* se = getenv("DFQ_RES_SPEC");
+        const char* ce = getenv("DFQ_RES_CKPT");
+        if (se && atoi(se) >= 0) r->spec = atoi(se);
+        if (ce && atoi(ce) > 0) r->ckpt_every = atoi(ce);
+        r->spec = std::min(r->spec, 64);
+        r->ckpt_every = std::min(std::max(r->ckpt_every, std::max(1, r->spec)), 64);   // spec <= ckpt_every: two checkpoint buffers suffice
+    }
+    r->log_total = std::max<int64_t>(log_total, 64);
     bool ok = hipMalloc((void**)&r->d_tiles, sizeof(ResTile) * tiles.size()) == hipSuccess &&
               hipMalloc((void**)&r->d_rels, sizeof(ResRel) * n_relations) == hipSuccess &&
               hipMalloc((void**)&r->d_layer_diff, sizeof(ResLayerDiff) * n_layers) == hipSuccess &&
               hipMalloc((void**)&r->d_stats, sizeof(u64) * (size_t)r->stat_words) == hipSuccess &&
               hipMalloc((void**)&r->d_sync, sizeof(u64) * r->sync_words) == hipSuccess &&
-              hipMalloc((void**)&r->d_partials, sizeof(double) * 6 * tiles.size()) == hipSuccess &&
+              hipMalloc((void**)&r->d_partials, sizeof(double) * 2 * (size_t)(r->spec + 2) * tiles.size()) == hipSuccess &&
+              hipMalloc((void**)&r->d_log, sizeof(float) * (size_t)(r->ckpt_every + r->spec) * (size_t)r->log_total) == hipSuccess &&
+              hipMalloc((void**)&r->d_ckpt, sizeof(float) * 2 * tiles.size() * (size_t)kCkptFloats) == hipSuccess &&
               hipMemcpy(r->d_tiles, tiles.data(), sizeof(ResTile) * tiles.size(), hipMemcpyHostToDevice) == hipSuccess &&
               hipMemcpy(r->d_rels, hr.data(), sizeof(ResRel) * n_relations, hipMemcpyHostToDevice) == hipSuccess &&
               hipMemcpy(r->d_layer_diff, ld.data(), sizeof(ResLayerDiff) * n_layers, hipMemcpyHostToDevice) == hipSuccess;
@@ -1422,7 +1515,7 @@ int le_resident_enqueue(LeResident* r, const dfq_le_config* cfg, LeState* d_stat
     if (n_sweeps <= 0) return DFQ_OK;
     // every launch is self-contained: statistics are re-derived from the weights it loads, tags and counters start at zero
     clear_buffers(st, r->d_stats, sizeof(u64) * (size_t)r->stat_words, r->d_sync, sizeof(u64) * r->sync_words,
-                  r->d_partials, sizeof(double) * 6 * (size_t)r->n_tiles);
+                  r->d_partials, sizeof(double) * 2 * (size_t)(r->spec + 2) * (size_t)r->n_tiles);
     DFQ_CHECK_LAUNCH();
     ResArgs a;
     memset(&a, 0, sizeof(a));
@@ -1430,12 +1523,13 @@ int le_resident_enqueue(LeResident* r, const dfq_le_config* cfg, LeState* d_stat
     a.stats = r->d_stats; a.parity_stride = r->parity_stride;
     a.cnt_r = r->d_sync;
     a.cnt_c = r->d_sync + (size_t)8 * r->n_pl * kResStride;
-    a.seq = r->d_sync + (size_t)16 * r->n_pl * kResStride;
+    a.prog = r->d_sync + (size_t)16 * r->n_pl * kResStride;
+    a.log = r->d_log; a.ckpt = r->d_ckpt; a.log_total = r->log_total;
+    a.spec = r->spec; a.ckpt_every = r->ckpt_every; a.log_ring = r->ckpt_every + r->spec; a.part_ring = r->spec + 2;
     a.err = d_err;
     a.partials = r->d_partials;
     a.state = d_state;
     a.n_tiles = r->n_tiles; a.n_layers = r->n_layers;
-    a.reducer = r->reducer;
     a.n_sweeps = n_sweeps;
     a.max_sweeps = cfg->max_sweeps;
     a.converge_count = cfg->converge_count;
@@ -1446,9 +1540,9 @@ int le_resident_enqueue(LeResident* r, const dfq_le_config* cfg, LeState* d_stat
     if (d_trace) {
         if (kResSmemBytes > 48 * 1024)
             DFQ_HIP_TRY(hipFuncSetAttribute((const void*)le_resident_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kResSmemBytes));
-        DFQ_LAUNCH_RESIDENT(le_resident_kernel<true>, dim3(r->n_tiles), dim3(kBlock), kResSmemBytes, st, a, q);
+        DFQ_LAUNCH_RESIDENT(le_resident_kernel<true>, dim3(r->n_tiles + 1), dim3(kBlock), kResSmemBytes, st, a, q);
     } else {
-        DFQ_LAUNCH_RESIDENT(le_resident_kernel<false>, dim3(r->n_tiles), dim3(kBlock), kResSmemBytes, st, a, q);
+        DFQ_LAUNCH_RESIDENT(le_resident_kernel<false>, dim3(r->n_tiles + 1), dim3(kBlock), kResSmemBytes, st, a, q);
     }
     DFQ_CHECK_LAUNCH();
     return DFQ_OK;

@@ -210,6 +210,12 @@ class LEPlan:
         _ffi.check(_ffi.lib().dfq_le_trace_blocks(self._plan, ctypes.byref(cfg), int(launch), _ffi.stream_arg(), out, n))
         return [(int(out[3 * b]), int(out[3 * b + 1]), int(out[3 * b + 2])) for b in range(n)]
 
+    def resident_stats(self):
+        """Rollbacks of the last resident launch (dfq_le_resident_stats): dict(tiles_rolled_back, sweeps_undone, max_undone, spec, ckpt)."""
+        out = (ctypes.c_int64 * 5)()
+        _ffi.check(_ffi.lib().dfq_le_resident_stats(self._plan, _ffi.stream_arg(), out))
+        return dict(tiles_rolled_back=int(out[0]), sweeps_undone=int(out[1]), max_undone=int(out[2]), spec=int(out[3]), ckpt=int(out[4]))
+
     def resident_trace(self, n_sweeps, **kw):
         """Per-workgroup phase stamps of the persistent launch (tuning aid, see dfq_le_resident_trace): list over tiles of
         dict(layer, rows, cols, stamps=[sweep][8])."""

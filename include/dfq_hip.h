@@ -146,6 +146,13 @@ int dfq_le_plan_level_grid(const dfq_le_plan* plan, int32_t level, int32_t* grid
  * bit-identical either way. */
 int32_t dfq_le_plan_resident_tiles(const dfq_le_plan* plan);
 const char* dfq_le_plan_resident_reason(const dfq_le_plan* plan);
+/* The resident launch applies every sweep to its LDS tiles AT ONCE and learns only later (from a reducer workgroup, off every
+ * dependency chain) whether dfq.py:105-115 let that sweep happen: a tile may be up to `spec` sweeps past the stopping point
+ * and then restores the newest of its checkpoints and replays the logged per-channel factors (bit-identical: the same two
+ * rounded multiplications per element and sweep).  Statistics of the LAST launch (tests, tuning; synchronises `stream`):
+ * out5 = {tiles that rolled back, sweeps undone in total, most sweeps undone by one tile, speculation depth (DFQ_RES_SPEC,
+ * default 2), sweeps between checkpoints (DFQ_RES_CKPT, default 8)}. */
+int dfq_le_resident_stats(dfq_le_plan* plan, void* stream, int64_t* out5);
 /* Streaming plans built with DFQ_LE_PERSIST=1 (an experiment, off by default): persistent workgroups of a sweep launch
  * (each walks its share of the sweep's tiles with the next tile's data in flight); 0 when a sweep launches one workgroup
  * per tile or the plan is resident.  DFQ_LE_SWEEP_WGS caps the number. */

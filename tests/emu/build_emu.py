@@ -28,19 +28,36 @@ def deps():
     return d
 
 
+def _fresh():
+    if not os.path.exists(OUT):
+        return False
+    t = os.path.getmtime(OUT)
+    return all(os.path.getmtime(f) <= t for f in deps())
+
+
 def build(force=False):
+    """Builds at most once even when several pytest-xdist workers ask at the same time: an exclusive lock around the check and
+    the build, the library written under a temporary name and renamed into place (a worker never maps a half-written file)."""
+    import fcntl
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    if not force and os.path.exists(OUT):
-        t = os.path.getmtime(OUT)
-        if all(os.path.getmtime(f) <= t for f in deps()):
+    if not force and _fresh():
+        return OUT
+    with open(OUT + '.lock', 'w') as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and _fresh():
             return OUT
+        _compile(OUT + '.tmp.{}'.format(os.getpid()))
+        os.replace(OUT + '.tmp.{}'.format(os.getpid()), OUT)
+    return OUT
+
+
+def _compile(out):
     cmd = ['g++', '-O2', '-g', '-std=c++17', '-fPIC', '-shared', '-ffp-contract=off', '-fno-fast-math', '-fno-strict-aliasing',
            '-DDFQ_GLOBAL_AS=', '-DDFQ_CONSTANT_AS=', '-Wall', '-Wno-unknown-pragmas', '-Wno-unused-function', '-Wno-unused-variable',
-           '-I', os.path.join(HERE, 'include'), '-I', os.path.join(ROOT, 'include'), '-o', OUT]
+           '-I', os.path.join(HERE, 'include'), '-I', os.path.join(ROOT, 'include'), '-o', out]
     for s in sources():
         cmd += ['-x', 'c++', s]
     subprocess.run(cmd, check=True)
-    return OUT
 
 
 if __name__ == '__main__':

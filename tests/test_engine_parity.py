@@ -1009,6 +1009,79 @@ def test_resident_and_streaming_engines_agree(engine, monkeypatch, name, seed, s
             assert_bitexact(a, b, '{}: cumulative S'.format(le_engine))
 
 
+@pytest.mark.parametrize('spec,ckpt', [('0', '4'), ('1', '1'), ('2', '2'), ('2', '4'), ('3', '3'), ('4', '8'), ('6', '6')])
+@pytest.mark.parametrize('name,seed,signed', [('tiny_mobile', 0, False), ('tiny_res', 0, False), ('tiny_cat', 3, True)])
+def test_speculation_past_the_verdict_is_invisible(engine, monkeypatch, name, seed, signed, spec, ckpt):
+    """Round 4 (dfq_le_resident.hip, "speculation past the verdict"): the resident launch applies every sweep to its LDS
+    tiles at once and may run DFQ_RES_SPEC sweeps ahead of the reducer's verdicts; when the loop stops it restores the
+    newest checkpoint (every DFQ_RES_CKPT sweeps; checkpoint 0 = the untouched tensors) and replays the logged factors.
+    Whatever the depth and the period -- no speculation at all, a checkpoint every sweep (no replay), a stop before the first
+    checkpoint, a replay across several sweeps -- and however the sweeps are cut into launches, weights, [O] vectors,
+    cumulative scales, sweep count and loop state are those of the oracle's sequential loop, bit for bit."""
+    _select_le_engine(monkeypatch, 'resident')
+    monkeypatch.setenv('DFQ_RES_SPEC', spec)
+    monkeypatch.setenv('DFQ_RES_CKPT', ckpt)
+    model, graph, bottoms = synthetic.build(name, seed=seed)
+    model.to(engine.device)
+    lt.merge_batchnorm(model, graph, bottoms, TARG)
+    rels = rel.create_relation(graph, bottoms, TARG)
+    spec0 = graphspec.from_torch(graph, bottoms, TARG)
+    orels = orc.create_relation(spec0)
+    # (1) the data-dependent loop in ONE launch
+    plan = dfq.build_le_plan(graph, rels, TARG)
+    assert plan.resident_tiles > 0, plan.resident_reason
+    res = plan.run(signed=signed)
+    st = plan.resident_stats()
+    assert st['spec'] == int(spec) and st['ckpt'] == max(int(ckpt), int(spec), 1)
+    assert st['max_undone'] <= int(spec), st
+    if spec == '0':
+        assert st['tiles_rolled_back'] == 0, st
+    plan.stage.writeback()
+    sp = spec0.clone()
+    n_o, S_o = orc.cross_layer_equalization(sp, orels, signed=signed)
+    assert res['sweeps'] == n_o, (res, n_o)
+    snap = snapshot(graph)
+    for i, k in enumerate(graph):
+        n = sp.nodes[k]
+        if n.kind == 'targ':
+            assert_bitexact(snap['L{}.w'.format(i)], n.weight, 'w {}'.format(k))
+            if n.bias is not None and 'L{}.b'.format(i) in snap:
+                assert_bitexact(snap['L{}.b'.format(i)], n.bias, 'b {}'.format(k))
+        elif n.kind == 'bn' and n.fake_weight is not None:
+            assert_bitexact(snap['L{}.fw'.format(i)], n.fake_weight, 'fw {}'.format(k))
+            assert_bitexact(snap['L{}.fb'.format(i)], n.fake_bias, 'fb {}'.format(k))
+    for a, b in zip(plan.scale_cum, S_o):
+        assert_bitexact(npy(a), b, 'cumulative S')
+    plan.close()
+    # (2) the same loop cut into launches of 1, 2, 3, ... sweeps (each launch reloads the tensors the previous one stored; the
+    #     stop may fall anywhere inside a launch): after every launch the state is the oracle's after that many sweeps
+    model, graph, bottoms = synthetic.build(name, seed=seed)
+    model.to(engine.device)
+    lt.merge_batchnorm(model, graph, bottoms, TARG)
+    rels = rel.create_relation(graph, bottoms, TARG)
+    plan = dfq.build_le_plan(graph, rels, TARG)
+    plan.enqueue(0, restart=True, signed=signed)
+    total, undone = 0, 0
+    for n in (1, 2, 3, 1, 5, 1000):
+        plan.enqueue(n, restart=False, signed=signed)
+        r = plan.query()
+        undone += plan.resident_stats()['sweeps_undone']
+        total = min(total + n, n_o)
+        assert r['sweeps'] == total, (r, total)
+        sp = spec0.clone()
+        orc.cross_layer_equalization(sp, orels, signed=signed, max_sweeps=total, converge_thres=-1.0, converge_count=10 ** 9)
+        plan.stage.writeback()
+        snap = snapshot(graph)
+        for i, k in enumerate(graph):
+            n_ = sp.nodes[k]
+            if n_.kind == 'targ':
+                assert_bitexact(snap['L{}.w'.format(i)], n_.weight, 'after {} sweeps: w {}'.format(total, k))
+        if r['done']:
+            break
+    assert r['done'] and total == n_o
+    plan.close()
+
+
 @pytest.mark.parametrize('depth', ['1', '2', '4'])
 @pytest.mark.parametrize('le_engine', ['streaming', 'streaming-persistent-3wg'])
 @pytest.mark.parametrize('name,seed,signed', [('tiny_mobile', 0, False), ('tiny_res', 0, False), ('tiny_cat', 3, True)])

@@ -28,7 +28,7 @@ SCRATCH_ALLOWED = {'le_sweep_kernel': (128, 110)}          # opt-in persistent-w
 # ceilings for scalar-register spills of the kernels that have any (everything else: 0)
 SGPR_SPILL_CEILING = {
     'le_resident_kernel': 600, 'le_level_kernel': 120, 'le_sweep_kernel': 120,
-    'bc_chain_kernel': 90, 'bc_step_kernel': 45,
+    'bc_chain_kernel': 95, 'bc_step_kernel': 60,
 }
 
 

@@ -26,7 +26,7 @@ print('tiles', plan.resident_tiles, plan.resident_reason)
 plan.resident_trace(sweeps)                      # warm
 tiles = plan.resident_trace(sweeps)
 t0 = min(t['stamps'][0][0] for t in tiles if t['stamps'][0][0])
-names = ['start', 'sA', 'rowpub', 'sB', 'newvals', 'ticket', 'decision', 'p3a', 'p3b', 'p3c', 'commit']
+names = ['start', 'sA', 'rowpub', 'sB', 'newvals', 'partial', 'end', 'p3a', 'p3b', 'p3c', 'end2']
 by_layer = {}
 for t in tiles:
     by_layer.setdefault(t['layer'], []).append(t)
@@ -42,13 +42,9 @@ for k in (1, 3, 5):
               ' '.join('{}={:7.2f}'.format(n, v) for n, v in zip(names, row)))
 # per-tile phase DURATIONS (median / max over the layer's tiles), sweeps 2..5 pooled: where a tile's own time goes
 import statistics
-if os.environ.get('DFQ_TRACE_LAZY', '1') == '1':      # library built with -DDFQ_RES_EAGER=0 (the default)
-    # stamp slots in program order (index = point, minus one past 7): start waited sA pre-rowstats rowstats published rowpub sB p3a p3b p3c newvals ticket decision commit
-    order = [0, 14, 1, 11, 12, 13, 2, 3, 7, 8, 9, 4, 5, 6, 10]
-    labels = ['wait', 'read+solveA', 'sync', 'rowstats', 'sync+publish', 'arrive', 'wait+solveB', 'zero', 'p3 compute', 'sync', 'pub cols', 'partial', 'verdict', 'commit']
-else:
-    order = [0, 1, 2, 3, 6, 7, 8, 9, 4, 5, 10]      # start sA rowpub sB decision p3a p3b p3c newvals ticket end
-    labels = ['wait+solveA', 'rowstats+pub', 'wait+solveB', 'verdict', 'zero', 'p3 compute+commit', 'sync', 'pub cols', 'partial', 'tail']
+# stamp slots in program order (index = point, minus one past 7): start waited sA pre-rowstats rowstats published rowpub sB p3a p3b p3c newvals partial end
+order = [0, 14, 1, 11, 12, 13, 2, 3, 7, 8, 9, 4, 5, 10]
+labels = ['wait', 'read+solveA', 'sync', 'rowstats', 'sync+publish', 'arrive', 'wait+solveB', 'zero', 'p3 compute+commit', 'sync', 'pub cols', 'partial', 'o-vec']
 print('---- per-tile phase durations, us (median | max over tiles and sweeps 2-5) ----')
 for layer in sorted(by_layer):
     ts = by_layer[layer]
@@ -67,3 +63,4 @@ for layer in sorted(by_layer):
     print('layer {:3d} x{:3d} [{:4d}x{:4d}] sweep={:5.2f} '.format(layer, len(ts), ts[0]['rows'], ts[0]['cols'], statistics.median(tot) if tot else 0.0) + ' '.join(cells))
 dec = sorted(max(t['stamps'][k][6] for t in tiles) for k in range(6))
 print('sweep boundaries (us):', [round((d - t0) / 100.0, 2) for d in dec])
+print('rollbacks of the traced launch:', plan.resident_stats())
