@@ -71,7 +71,9 @@ struct ResTile {                     // one workgroup
     int32_t nt_self, nt_a, nt_b;     // tiles of this layer / of those two
     int32_t owner;                   // holds column block 0: updates the [O] vectors of relation B
     int32_t layout;                  // kLayGeneral / kLayFixed / kLayShort
-    int32_t relax_r;                 // 1: every row of this layer lives in ONE tile -> its row statistics have a single producer
+    int32_t relax_r;                 // bit 0: every row of this layer lives in ONE tile -> its row statistics have a single producer;
+                                     // bit 1: the same holds for relation A's FIRST layer (this tile reads THOSE row statistics: it polls the tagged
+                                     // words themselves instead of that layer's counter -- one trip through the memory system less per hand-off)
     int32_t relax_c;                 // 1: every input channel of this layer lives in ONE tile -> likewise for its column statistics
     int32_t slot;                    // logical index of the tile (partial-sum slot, checkpoint slot): the table itself is in LAUNCH order
     int32_t log_off;                 // first float of this tile inside an entry of the factor log: 1/s_A per table entry, then s_B per row
@@ -460,8 +462,10 @@ struct LayFixed {
                 nw[k] = nv;
                 part += (double)abs_f32(nv - xv[k]);
                 if (one_group) {
-                    cmn[k] = vmin_raw(cmn[k], on ? nv : INFINITY);
-                    cmx[k] = vmax_raw(cmx[k], on ? nv : -INFINITY);
+                    // (no `on` select: the slots of padded lanes / rows hold exact DUPLICATES of valid elements -- loaded as such,
+                    // updated with the same factors, checkpointed raw -- and a duplicate changes no minimum or maximum)
+                    cmn[k] = vmin_raw(cmn[k], nv);
+                    cmx[k] = vmax_raw(cmx[k], nv);
                 } else if (on) {
                     lds_minmax(sh_col + 2 * (gr + tabk[k]), nv, nv);
                 }
@@ -507,7 +511,7 @@ struct LayFixed {
 // element, 2.2 us to multiply the 18 elements a thread holds).
 struct LayShort {
     static constexpr int VEC = 1;
-    static constexpr bool kFusedCols = false;
+    static constexpr bool kFusedCols = true;
     int L, rpt, nci, khkw;
     int rt[kResOwn];                   // table offset of the row's group: (group - g_lo) * nci
     __device__ __forceinline__ void init(const ResTile& T, const TileGeo& G) {
@@ -573,26 +577,39 @@ struct LayShort {
             if (on) { sh_row[2 * row] = ~enc_ord(mn); sh_row[2 * row + 1] = enc_ord(mx); }    // the row's only owner
         });
     }
-    __device__ __forceinline__ void col_stats(const ResTile& T, const TileGeo& G, float* tile, bool useA, bool useB,
-                                              const float* sh_inv, const float* sh_s, uint32_t* sh_col) const {
+    // one pass: |dW| and the column statistics of the new values; `commit`: w <- new in the same pass (round 4: the depthwise tile
+    // of the longest chain sits on the sweep's critical cycle and used to walk its rows twice here)
+    __device__ __forceinline__ double diff_and_cols(const ResTile& T, const TileGeo& G, float* tile, bool useA, bool useB,
+                                                    const float* sh_inv, const float* sh_s, uint32_t* sh_col, bool commit = false) const {
+        double acc = 0.0;
         rows(T, tile, [&](int j, int row, bool on, float* base) {
             const float fa = fa_of(j, useA, sh_inv), fb = useB ? sh_s[row] : 1.0f;
+            double part = 0.0;
             if (nci == 1) {          // one input channel per group (depthwise): the row's range goes to its group's channel
                 float mn = INFINITY, mx = -INFINITY;
                 elems(base, [&](int e, float x) {
-                    const float y = val(x, j, e, useA, fa, fb, sh_inv);
-                    mn = vmin_raw(mn, y); mx = vmax_raw(mx, y);
+                    const float nv = val(x, j, e, useA, fa, fb, sh_inv);
+                    part += (double)abs_f32(nv - x);
+                    if (commit) base[e * kBlock] = nv;
+                    mn = vmin_raw(mn, nv); mx = vmax_raw(mx, nv);
                 });
                 if (on) lds_minmax(sh_col + 2 * rt[j], mn, mx);
             } else {
                 elems(base, [&](int e, float x) {
-                    const float y = val(x, j, e, useA, fa, fb, sh_inv);
-                    if (on) lds_minmax(sh_col + 2 * (rt[j] + small_div(e, khkw)), y, y);
+                    const float nv = val(x, j, e, useA, fa, fb, sh_inv);
+                    part += (double)abs_f32(nv - x);
+                    if (commit) base[e * kBlock] = nv;
+                    if (on) lds_minmax(sh_col + 2 * (rt[j] + small_div(e, khkw)), nv, nv);
                 });
             }
+            acc += on ? part : 0.0;
         });
+        return acc;
     }
-    __device__ __forceinline__ double diff_and_cols(const ResTile&, const TileGeo&, float*, bool, bool, const float*, const float*, uint32_t*, bool = false) const { return 0.0; }
+    __device__ __forceinline__ void col_stats(const ResTile& T, const TileGeo& G, float* tile, bool useA, bool useB,
+                                              const float* sh_inv, const float* sh_s, uint32_t* sh_col) const {
+        (void)diff_and_cols(T, G, tile, useA, useB, sh_inv, sh_s, sh_col);
+    }
     template <bool kDiff>
     __device__ __forceinline__ double update(const ResTile& T, const TileGeo& G, float* tile, bool useA, bool useB,
                                              const float* sh_inv, const float* sh_s) const {
@@ -807,7 +824,7 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
             lay.row_stats(T, G, v, false, false, sh_inv, sh_s, sh_row);
             __syncthreads();
             publish_rows(a, T, rb_r1, sh_row, 1u);
-            arrive(a.cnt_r, T.layer, !T.relax_r);
+            arrive(a.cnt_r, T.layer, !(T.relax_r & 1));
         }
     }
 
@@ -861,7 +878,8 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
         bool have_b = false;
         {
             const int copy = blockIdx.x & 7;
-            const u64* c1 = hasA ? cnt_line(a.cnt_r, T.a_layer, copy) : (chain_start ? cnt_line(a.cnt_r, T.layer, copy) : nullptr);
+            // (row statistics with a single producer per word are polled directly below: no counter)
+            const u64* c1 = hasA ? ((T.relax_r & 2) ? nullptr : cnt_line(a.cnt_r, T.a_layer, copy)) : (chain_start ? cnt_line(a.cnt_r, T.layer, copy) : nullptr);
             const u64 t1 = (u64)(hasA ? T.nt_a : T.nt_self) * round;
             const u64* c2 = hasA ? cnt_line(a.cnt_c, T.layer, copy) : nullptr;
             const u64* c3 = hasB ? cnt_line(a.cnt_c, T.b_layer, copy) : nullptr;
@@ -905,7 +923,10 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
                 }
                 if (ok) break;
                 __builtin_amdgcn_s_sleep(1);
-                if (++tries > kResSpinLimit / 16) { atomicMax(a.err, 1ull); *sh_bad = 1; break; }
+                ++tries;
+                // the producer may have left: the loop has stopped (sweep k does not happen then, whatever this tile makes of it)
+                if ((tries & 7) == 0 && (uint32_t)(ld_word(prog_line(cold(a).prog, blockIdx.x & 7)) >> 32) != 0u) { *sh_bad = 2; break; }
+                if (tries > kResSpinLimit / 16) { atomicMax(a.err, 1ull); *sh_bad = 1; break; }
             }
         }
         // (the factor log: uniform base + an index the compiler cannot hoist -- see the checkpoint block)
@@ -929,6 +950,7 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
             res_stamp<kTrace>(a, k, 1);
             if (hasB) for (int i = tid; i < 2 * T.nr; i += kBlock) sh_row[i] = 0u;
             __syncthreads();
+            if (*sh_bad) break;                                   // (uniform; sorted out behind the loop) nothing is published from stale words
             if (hasB) {
                 // row statistics of t = fl(w * 1/s_A) for relation B of this same sweep (t is not kept: phase 3 recomputes it)
                 res_stamp<kTrace>(a, k, 12);
@@ -937,11 +959,11 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
                 __syncthreads();
                 publish_rows(a, T, rb_r1, sh_row, tag);
                 res_stamp<kTrace>(a, k, 14);
-                arrive(a.cnt_r, T.layer, !T.relax_r);
+                arrive(a.cnt_r, T.layer, !(T.relax_r & 1));
             }
         }
         if (!hasA) __syncthreads();                               // (phase 1 has its own barriers)
-        if (*sh_bad) { failed = true; break; }
+        if (*sh_bad) break;
         res_stamp<kTrace>(a, k, 2);
         // ---- phase 2: s_B per row ----
         if (hasB) {
@@ -970,7 +992,9 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
                     for (int j = 0; j < kResOwn; ++j) ok = ok && (rows_local || tagged(v1[j], tag)) && (have_b || tagged(v2[j], tag));
                     if (ok) break;
                     __builtin_amdgcn_s_sleep(1);
-                    if (++tries > kResSpinLimit / 16) { atomicMax(a.err, 1ull); *sh_bad = 1; break; }
+                    ++tries;
+                    if ((tries & 7) == 0 && (uint32_t)(ld_word(prog_line(cold(a).prog, blockIdx.x & 7)) >> 32) != 0u) { *sh_bad = 2; break; }
+                    if (tries > kResSpinLimit / 16) { atomicMax(a.err, 1ull); *sh_bad = 1; break; }
                 }
             }
 #pragma unroll
@@ -992,7 +1016,7 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
         //      in ONE pass over the tile.  Applied at once: whether sweep k happens at all is found out later (see
         //      "speculation past the verdict"). ----
         __syncthreads();                                          // sh_s complete; sh_row / sh_col free
-        if (*sh_bad) { failed = true; break; }                    // a statistics word of phase 2 never showed this sweep's tag
+        if (*sh_bad) break;                                       // a statistics word of phase 2 never showed this sweep's tag (or the loop stopped)
         if (hasA) for (int i = tid; i < 2 * G.g_n * G.nci; i += kBlock) sh_col[i] = 0u;
         if (chain_start) for (int i = tid; i < 2 * T.nr; i += kBlock) sh_row[i] = 0u;
         __syncthreads();
@@ -1014,7 +1038,7 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
         }
         if (chain_start) {
             publish_rows(a, T, rb_r1, sh_row, tag + 1u);
-            arrive(a.cnt_r, T.layer, !T.relax_r);
+            arrive(a.cnt_r, T.layer, !(T.relax_r & 1));
         }
         res_stamp<kTrace>(a, k, 4);
         // ---- convergence: one partial per tile (fixed butterfly + fixed wave order) as two tagged words; the reducer workgroup
@@ -1044,6 +1068,9 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
         res_stamp<kTrace>(a, k, 6);
         res_stamp<kTrace>(a, k, 11);
     }
+    // a statistics spin left the loop through *sh_bad: 1 = abandoned, 2 = the loop has stopped (sweep k was not applied)
+    __syncthreads();
+    if (*sh_bad == 1) failed = true;
     if (failed) return;                     // this tile stores nothing (others may have: the run reports DFQ_ERR_STATE, see the header)
     // ---- how many of the k applied sweeps happen ----
     (void)stopped;
@@ -1255,10 +1282,10 @@ int layout_of(int vec, int row_len, int nc) {
 // statistics are merged over the column blocks, column statistics over the row blocks) -- complete rows are favoured
 // for layers with row duty: no merge, and the tile does not wait for its own publication -- with a heavy penalty for
 // tiles that fall back to the general layout (LDS atomics per element).
-Shape pick_shape(int R, int C, int vec, int khkw, int go, int i2g, bool need_row, bool need_col) {
+Shape pick_shape(int R, int C, int vec, int khkw, int go, int i2g, bool need_row, bool need_col, int short_rpt) {
     const int ns4 = kResTileFloats / (4 * kBlock);          // float4 slots per thread
-    if (vec == 1 && C <= 32) {               // thread-per-row tiles: complete rows, two rows per thread if they are <= 16 floats
-        int tr = std::min(R, kBlock * (C <= 16 ? 2 : 1));
+    if (vec == 1 && C <= 32) {               // thread-per-row tiles: complete rows; `short_rpt` rows per thread if they are <= 16 floats
+        int tr = std::min(R, kBlock * (C <= 16 ? short_rpt : 1));
         if (need_row) tr = std::min(tr, kResRows);
         if (need_col) while (tr > 1 && max_groups(R, tr, go) * std::min((C + khkw - 1) / khkw + 1, i2g) > kResTab) tr = (tr + 1) / 2;
         return Shape{tr, C};
@@ -1364,6 +1391,12 @@ LeResident* le_resident_create(const dfq_layer* layers, int n_layers, const dfq_
     // the slots stays free: a launch sized to exactly the occupancy limit (le_sweep_kernel, dfq_le.hip) never became fully
     // resident while a second stream kept the chip busy.
     const int cap_tiles = std::min(occ, 3) * cus * 3 / 4;
+    // Thread-per-row tiles (depthwise layers) hold one row per thread when the chip has workgroups to spare, else two: the
+    // depthwise layer of the longest chain sits on the sweep's critical cycle, and with one row per thread each of its
+    // phases takes half as long (MobileNetV2: 571 instead of 559 workgroups).
+    const char* spe = getenv("DFQ_RES_SHORT_RPT");
+    for (int short_rpt = (spe && atoi(spe) == 2) ? 2 : 1; short_rpt <= 2; ++short_rpt) {
+    tiles.clear();
     for (int l = 0; l < n_layers; ++l) {
         tile_begin[l] = (int)tiles.size();
         tile_count[l] = 0;
@@ -1378,7 +1411,7 @@ LeResident* le_resident_create(const dfq_layer* layers, int n_layers, const dfq_
             go = R / Gp;
         }
         const int vec = (C % 4 == 0 && ((uintptr_t)L.weight & 15u) == 0) ? 4 : 1;
-        const Shape sh = pick_shape(R, C, vec, L.khkw, go, i2g, relB >= 0, relA >= 0);
+        const Shape sh = pick_shape(R, C, vec, L.khkw, go, i2g, relB >= 0, relA >= 0, short_rpt);
         if (sh.tr < 1) return refuse("a layer does not tile");
         const int n_rb = ceil_div_i(R, sh.tr), n_cb = ceil_div_i(C, sh.tc);
         for (int rb = 0; rb < n_rb; ++rb)
@@ -1404,6 +1437,8 @@ LeResident* le_resident_create(const dfq_layer* layers, int n_layers, const dfq_
             }
         tile_count[l] = n_rb * n_cb;
     }
+    if ((int)tiles.size() + 1 <= cap_tiles && (int)tiles.size() <= kResMaxTiles) break;
+    }
     if ((int)tiles.size() + 1 > cap_tiles || (int)tiles.size() > kResMaxTiles)       // + 1: the reducer workgroup
         return refuse("the network does not fit the chip's LDS: " + std::to_string(tiles.size()) + " tiles > " +
                       std::to_string(std::min(cap_tiles - 1, kResMaxTiles)) + " resident workgroups");
@@ -1419,6 +1454,13 @@ LeResident* le_resident_create(const dfq_layer* layers, int n_layers, const dfq_
             fp = (int64_t)ceil_div_i(T.nr * (T.nc / T.vec), kBlock) * kBlock * T.vec;
         }
         if (fp > kResTileFloats) return refuse("internal: a tile exceeds the LDS tile");
+    }
+    {   // bit 1 of relax_r: relation A's first layer publishes single-producer row statistics
+        std::vector<int> rel_r(n_pl, 0);
+        for (const ResTile& T : tiles) rel_r[T.layer] = T.relax_r & 1;
+        const char* de = getenv("DFQ_RES_DIRECT");                     // A/B switch: 0 = always wait for the counter first
+        const bool direct = !(de && de[0] == '0');
+        for (ResTile& T : tiles) if (direct && T.a_layer >= 0 && rel_r[T.a_layer]) T.relax_r |= 2;
     }
     for (ResTile& T : tiles) {
         // tiles per layer (by paired-layer index)

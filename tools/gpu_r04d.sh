@@ -1,0 +1,10 @@
+#!/bin/bash
+# round 4: resident engine -- direct polling of single-producer row statistics (A/B), parity, trace
+tag=r04d
+mkdir -p gpurun_out/$tag
+timeout 900 python -m pytest tests/test_engine_parity.py tests/test_full_reference.py tests/test_errors.py -m gpu -x -q > gpurun_out/$tag/pytest.log 2>&1; echo "pytest rc=$?"; tail -1 gpurun_out/$tag/pytest.log
+for rep in 1 2; do
+for d in 1 0; do
+  echo "direct=$d"; DFQ_RES_DIRECT=$d timeout 300 python tools/lat.py mobilenet_v2 deeplab_mnv2:60 2>/dev/null | tee -a gpurun_out/$tag/lat_direct$d.json
+done; done
+timeout 300 python tools/trace_resident.py mobilenet_v2 8 > gpurun_out/$tag/trace.txt 2>&1; tail -2 gpurun_out/$tag/trace.txt
