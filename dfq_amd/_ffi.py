@@ -109,6 +109,9 @@ SIGNATURES = {
                                  c_void_p, c_void_p, c_void_p]),
     'dfq_sample_minmax_mean': (c_int32, [c_void_p, c_int32, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     'dfq_quant_measure': (c_int32, [c_void_p, c_void_p, c_int32, c_int64, c_int32, c_void_p, c_void_p, c_int32, c_void_p]),
+    'dfq_quant_measure_fused_grid': (c_int32, [c_int32, c_int64]),
+    'dfq_quant_measure_fused': (c_int32, [c_void_p, c_void_p, c_int32, c_int64, c_int32, c_void_p, c_void_p, c_int32, c_int64, c_void_p]),
+    'dfq_quant_measure_fused_status': (c_int32, [c_void_p, c_int32, c_void_p]),
     'dfq_quant_plan_create': (c_int32, [POINTER(DfqSegment), c_int32, POINTER(c_void_p)]),
     'dfq_quant_plan_destroy': (None, [c_void_p]),
     'dfq_quant_plan_run': (c_int32, [c_void_p, c_void_p]),

@@ -10,6 +10,7 @@
 #include <algorithm>
 
 #include "dfq_common.hpp"
+#include "dfq_le_shared.hpp"   // spin_limit_from_env
 
 namespace dfq {
 
@@ -311,6 +312,131 @@ __global__ __launch_bounds__(kBlock) void measured_fake_quant_kernel(const float
     }
 }
 
+
+// QuantMeasure.forward with update_stat in ONE launch (round 4).  config 5 runs 74 of these per distilled batch, most of them on
+// small activations: two launches each meant 148 launch boundaries per batch, and the quantise pass of a mid-sized activation
+// re-read from HBM what the extrema pass had just streamed.  Here a grid of persistent workgroups (sized to be co-resident:
+// <= 4 per CU of a kernel that could run 8) does both: phase A, the per-sample extrema of its spans (device-scope atomicMax
+// into the per-sample slots), an arrival on a monotonic counter, a bounded wait until the whole grid has arrived; phase B, the
+// mean of the extrema read back with device-scope loads (the same fixed-order float64 sums in every workgroup), the running
+// range, and the quantisation of its share of x -- which, up to the size of the L2s and the 256 MB Infinity Cache, is still
+// on the chip.  Same numbers as the two-launch form (dfq_quant_measure), bit for bit.  All shared memory is dynamic (the
+// kernel's workgroups wait for each other).
+struct QmArgs {
+    const float* x;
+    float* y;
+    int64_t n, sample_len, span;
+    uint32_t* slots_cur;
+    uint32_t* slots_next;
+    float* running2;
+    unsigned long long* sync;        // [0] arrivals (monotonic over the calls on this scratch), [1] error word
+    unsigned long long target;       // arrivals when the whole grid of THIS call has arrived
+    int32_t n_samples, spans_per_sample, num_bits, spin_limit;
+};
+constexpr size_t kQmSmem = 128;
+
+__global__ __launch_bounds__(kBlock) void quant_measure_fused_kernel(QmArgs a) {
+    DFQ_DYN_SMEM(smem);
+    float* sh_mn = (float*)smem;                         // [kBlock / kWave]
+    float* sh_mx = sh_mn + kBlock / kWave;
+    double* sh_d = (double*)(smem + 32);                 // [kBlock / kWave]
+    int* sh_ok = (int*)(smem + 96);
+    const int tid = threadIdx.x, lane = tid % kWave, wave = tid / kWave;
+    // ---- phase A: extrema of this workgroup's spans ----
+    const int items = a.n_samples * a.spans_per_sample;
+    for (int it = blockIdx.x; it < items; it += gridDim.x) {
+        const int smp = it / a.spans_per_sample;
+        const int64_t b = (int64_t)(it - smp * a.spans_per_sample) * a.span;
+        const int64_t e = (b + a.span < a.sample_len) ? b + a.span : a.sample_len;
+        float mn = INFINITY, mx = -INFINITY;
+        if (b < e) thread_minmax_range(a.x + (int64_t)smp * a.sample_len, b, e, mn, mx);
+        mn = wave_min(mn);
+        mx = wave_max(mx);
+        if (lane == 0) { sh_mn[wave] = mn; sh_mx[wave] = mx; }
+        __syncthreads();
+        if (tid == 0) {
+            float lo = sh_mn[0], hi = sh_mx[0];
+#pragma unroll
+            for (int w = 1; w < kBlock / kWave; ++w) { lo = fminf(lo, sh_mn[w]); hi = fmaxf(hi, sh_mx[w]); }
+            if (lo <= hi) {   // false only if the range was empty
+                atomicMax(a.slots_cur + 2 * smp + 0, ~enc_ord(lo));
+                atomicMax(a.slots_cur + 2 * smp + 1, enc_ord(hi));
+            }
+        }
+        __syncthreads();                                  // sh_mn / sh_mx are rewritten by the next item
+    }
+    // ---- the whole grid has published: arrival (after this workgroup's atomics have been performed), bounded wait ----
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (tid == 0) {
+        atomicAdd(a.sync, 1ull);
+        long spins = 0;
+        int ok = 1;
+        while (__hip_atomic_load(a.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a.target) {
+            __builtin_amdgcn_s_sleep(2);
+            ++spins;
+            if (spins > a.spin_limit ||
+                ((spins & 255) == 0 && __hip_atomic_load(a.sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull)) {
+                atomicMax(a.sync + 1, 1ull);
+                ok = 0;
+                break;
+            }
+        }
+        *sh_ok = ok;
+    }
+    __syncthreads();
+    if (*sh_ok == 0) return;                             // abandoned: nothing is quantised, the status call reports it
+    // ---- phase B: mean over samples of the per-sample extrema (float64, fixed order, rounded once: sample_mean) ----
+    double smn = 0.0, smx = 0.0;
+    for (int i = tid; i < a.n_samples; i += kBlock) {
+        smn += (double)slot_min(__hip_atomic_load(a.slots_cur + 2 * i + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        smx += (double)slot_max(__hip_atomic_load(a.slots_cur + 2 * i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    }
+    smn = block_sum(smn, sh_d);
+    smx = block_sum(smx, sh_d);
+    float mn, mx;
+    if (a.n_samples == 1) {
+        mn = slot_min(__hip_atomic_load(a.slots_cur + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        mx = slot_max(__hip_atomic_load(a.slots_cur + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    } else {
+        mn = (float)(smn / (double)a.n_samples);
+        mx = (float)(smx / (double)a.n_samples);
+    }
+    const float r0 = a.running2[0], r1 = a.running2[1];
+    const float lo = (mn < r0) ? mn : r0;            // Python min(running_min, v): keeps running_min unless v < it (NaN keeps it)
+    const float hi = (mx > r1) ? mx : r1;
+    if (blockIdx.x == 0) {
+        if (tid == 0) { a.running2[0] = lo; a.running2[1] = hi; }
+        for (int i = tid; i < 2 * a.n_samples; i += kBlock) a.slots_next[i] = 0u;
+    }
+    const QParams p = qparams_double((double)lo, (double)hi, a.num_bits, 0);
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    const float* x = a.x;
+    float* y = a.y;
+    const int64_t n = a.n;
+    if (((((uintptr_t)x) | ((uintptr_t)y)) & 15u) == 0) {
+        const int64_t n4 = n >> 2;
+        for (int64_t i = (int64_t)blockIdx.x * kBlock + tid; i < n4; i += stride) {
+            const fvec4 v = *(const fvec4*)(x + 4 * i);   // (plain load: this is the second read, from the caches where it fits)
+            fvec4 r;
+            float code;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) r[k] = fake_quant_one(v[k], p, &code);
+            if (kQuantNt & 2) DFQ_NT_STORE(r, (fvec4*)(y + 4 * i));
+            else *(fvec4*)(y + 4 * i) = r;
+        }
+        for (int64_t i = 4 * n4 + (int64_t)blockIdx.x * kBlock + tid; i < n; i += stride) {
+            float code;
+            y[i] = fake_quant_one(x[i], p, &code);
+        }
+        return;
+    }
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + tid; i < n; i += stride) {
+        float code;
+        y[i] = fake_quant_one(x[i], p, &code);
+    }
+}
+
 // ---- _quantize_error (dfq.py:8-25) ----------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void quant_error_kernel(const float* __restrict__ x, float* __restrict__ out,
                                                              int64_t n, int num_bits, int symmetric,
@@ -452,6 +578,68 @@ int dfq_quant_measure(const float* x, float* y, int32_t n_samples, int64_t sampl
     hipLaunchKernelGGL(measured_fake_quant_kernel, dim3(grid_for(n, kBlock * 8, 4096)), dim3(kBlock), 0, st, x, y, n,
                        (const uint32_t*)cur, (int)n_samples, running2, nxt, (int)num_bits);
     DFQ_CHECK_LAUNCH();
+    return DFQ_OK;
+}
+
+
+static void qm_split(int32_t n_samples, int64_t sample_len, int64_t* span_out, int64_t* spans_out) {
+    int64_t gx = std::max<int64_t>(1, 2048 / n_samples);
+    int64_t span = (sample_len + gx - 1) / gx;
+    span = std::max<int64_t>(4096, (span + 1023) / 1024 * 1024);
+    *span_out = span;
+    *spans_out = (sample_len + span - 1) / span;
+}
+
+int32_t dfq_quant_measure_fused_grid(int32_t n_samples, int64_t sample_len) {
+    if (n_samples <= 0 || sample_len <= 0) return 0;
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                  ? prop.multiProcessorCount : 256;
+    }
+    int64_t span, spans;
+    qm_split(n_samples, sample_len, &span, &spans);
+    const int64_t n = (int64_t)n_samples * sample_len;
+    const int64_t want = std::max<int64_t>(spans * n_samples, grid_for(n, kBlock * 8, 4096));
+    return (int32_t)std::min<int64_t>(want, 4 * (int64_t)cus);     // co-resident: the kernel's occupancy limit is 8 workgroups per CU
+}
+
+int dfq_quant_measure_fused(const float* x, float* y, int32_t n_samples, int64_t sample_len, int32_t num_bits, float* running2,
+                            uint32_t* scratch, int32_t parity, int64_t arrivals_before, void* stream) {
+    if (!x || !y || !running2 || !scratch || n_samples <= 0 || sample_len <= 0 || (parity != 0 && parity != 1) || arrivals_before < 0)
+        return fail_arg("dfq_quant_measure_fused: bad argument");
+    if (n_samples > 65535) return fail_arg("dfq_quant_measure_fused: n_samples=%d > 65535", n_samples);
+    if (num_bits < 1 || num_bits > 30) return fail_arg("dfq_quant_measure_fused: num_bits=%d out of range", num_bits);
+    if ((uintptr_t)(scratch + 4 * (size_t)n_samples) & 7u) return fail_arg("dfq_quant_measure_fused: scratch must be 8-byte aligned");
+    hipStream_t st = as_stream(stream);
+    QmArgs a;
+    a.x = x; a.y = y; a.n = (int64_t)n_samples * sample_len; a.sample_len = sample_len;
+    int64_t spans;
+    qm_split(n_samples, sample_len, &a.span, &spans);
+    a.spans_per_sample = (int32_t)spans;
+    a.slots_cur = scratch + (size_t)parity * 2 * n_samples;
+    a.slots_next = scratch + (size_t)(parity ^ 1) * 2 * n_samples;
+    a.running2 = running2;
+    a.sync = (unsigned long long*)(scratch + 4 * (size_t)n_samples);
+    const int grid = dfq_quant_measure_fused_grid(n_samples, sample_len);
+    a.target = (unsigned long long)arrivals_before + (unsigned long long)grid;
+    a.n_samples = n_samples; a.num_bits = num_bits;
+    a.spin_limit = dfq::spin_limit_from_env(4000000);
+    SpinGuard guard(st);             // workgroups of this launch wait for each other: never next to another such kernel
+    DFQ_LAUNCH_SPINNING(quant_measure_fused_kernel, dim3(grid), dim3(kBlock), kQmSmem, st, a);
+    DFQ_CHECK_LAUNCH();
+    return DFQ_OK;
+}
+
+int dfq_quant_measure_fused_status(const uint32_t* scratch, int32_t n_samples, void* stream) {
+    if (!scratch || n_samples <= 0) return fail_arg("dfq_quant_measure_fused_status: bad argument");
+    hipStream_t st = as_stream(stream);
+    unsigned long long err = 0;
+    DFQ_HIP_TRY(hipMemcpyAsync(&err, (const unsigned long long*)(scratch + 4 * (size_t)n_samples) + 1, sizeof(err), hipMemcpyDeviceToHost, st));
+    DFQ_HIP_TRY(hipStreamSynchronize(st));
+    if (err) { set_error("dfq_quant_measure_fused: a workgroup gave up waiting for the rest of its grid (the output is invalid)"); return DFQ_ERR_STATE; }
     return DFQ_OK;
 }
 

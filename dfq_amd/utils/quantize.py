@@ -12,6 +12,8 @@ and feed the float64 scale recipe there, so there is no host round trip per call
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -133,6 +135,13 @@ def quantize(x, num_bits=8, min_value=None, max_value=None, inplace=False, symme
 # ------------------------------------------------------------------------------------------------
 # QuantMeasure
 # ------------------------------------------------------------------------------------------------
+# QuantMeasure.forward with range tracking as ONE launch of persistent workgroups (dfq_quant_measure_fused) instead of two
+# launches.  Opt-in: measured SLOWER on the MI355X (config 5: 3.73 vs 1.71 ms of QuantMeasure time per distilled batch; the largest
+# activation 189 vs 148 us) -- the grid-wide meeting and the serialisation against other waiting kernels cost more than the
+# launch boundary they replace.
+_QM_FUSED = os.environ.get('DFQ_QM_FUSED', '0') == '1'
+
+
 class QuantMeasure(nn.Module):
     """Activation range tracker + fake quantiser (quantize.py:90-122).
 
@@ -176,13 +185,23 @@ class QuantMeasure(nn.Module):
             shadow = running is None
             if self.update_stat and not self.training and not shadow and x.numel() > 0:
                 # the common calibration path (improve_dfq.py:280-297): two launches, no temporaries besides the output
+                # (DFQ_QM_FUSED=1: one launch of persistent workgroups -- measured slower, see _QM_FUSED)
+                lib = _ffi.lib()
+                fused = _QM_FUSED
+                words = 4 * n + (4 if fused else 0)
                 sc = getattr(self, '_qm_scratch', None)
-                if sc is None or sc.numel() != 4 * n or sc.device != x.device:
-                    sc = torch.zeros(4 * n, dtype=torch.int32, device=x.device)
-                    self._qm_scratch, self._qm_parity = sc, 0
+                if sc is None or sc.numel() != words or sc.device != x.device:
+                    sc = torch.zeros(words, dtype=torch.int32, device=x.device)
+                    self._qm_scratch, self._qm_parity, self._qm_arrivals = sc, 0, 0
                 out = stage.new(x.shape)
-                _ffi.check(_ffi.lib().dfq_quant_measure(_ffi.ptr(x), _ffi.ptr(out), n, x.numel() // n, int(self.num_bits),
-                                                        _ffi.ptr(running), _ffi.ptr(sc), self._qm_parity, _ffi.stream_arg()))
+                if fused:
+                    _ffi.check(lib.dfq_quant_measure_fused(_ffi.ptr(x), _ffi.ptr(out), n, x.numel() // n, int(self.num_bits),
+                                                           _ffi.ptr(running), _ffi.ptr(sc), self._qm_parity, self._qm_arrivals,
+                                                           _ffi.stream_arg()))
+                    self._qm_arrivals += int(lib.dfq_quant_measure_fused_grid(n, x.numel() // n))
+                else:
+                    _ffi.check(lib.dfq_quant_measure(_ffi.ptr(x), _ffi.ptr(out), n, x.numel() // n, int(self.num_bits),
+                                                     _ffi.ptr(running), _ffi.ptr(sc), self._qm_parity, _ffi.stream_arg()))
                 self._qm_parity ^= 1
             else:
                 if shadow:

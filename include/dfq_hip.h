@@ -245,6 +245,20 @@ int dfq_sample_minmax_mean(const float* x, int32_t n_samples, int64_t sample_len
  * accumulates into).  Same numbers as dfq_sample_minmax_mean(running2) + dfq_fake_quant(range_mode 1). */
 int dfq_quant_measure(const float* x, float* y, int32_t n_samples, int64_t sample_len, int32_t num_bits, float* running2,
                       uint32_t* scratch, int32_t parity, void* stream);
+/* The same in ONE launch (round 4 experiment, OPT-IN through DFQ_QM_FUSED=1 in the Python layer: measured slower than the two
+ * launches on the MI355X -- 189 vs 148 us on a [64, 96, 112, 112] activation, 3.73 vs 1.71 ms of QuantMeasure time per distilled
+ * batch of config 5 -- the grid-wide meeting costs more than the launch boundary it replaces): a
+ * grid of persistent workgroups -- dfq_quant_measure_fused_grid(n_samples, sample_len) of them, sized to be co-resident --
+ * takes the per-sample extrema, waits (bounded) until the whole grid has arrived, then every workgroup forms the mean, folds
+ * the running range and quantises its share of x, which up to the size of the chip's caches has not left them.  Bit-identical
+ * to dfq_quant_measure.  scratch: 4 * n_samples + 4 uint32, 8-byte aligned, ZERO before the first call (the last four words
+ * hold a monotonic arrival counter and an error word); parity alternates as above; `arrivals_before` = the sum of
+ * dfq_quant_measure_fused_grid over all earlier calls on this scratch.  dfq_quant_measure_fused_status synchronises and
+ * returns DFQ_ERR_STATE if a workgroup of an earlier call gave up waiting (DFQ_SPIN_LIMIT). */
+int32_t dfq_quant_measure_fused_grid(int32_t n_samples, int64_t sample_len);
+int dfq_quant_measure_fused(const float* x, float* y, int32_t n_samples, int64_t sample_len, int32_t num_bits, float* running2,
+                            uint32_t* scratch, int32_t parity, int64_t arrivals_before, void* stream);
+int dfq_quant_measure_fused_status(const uint32_t* scratch, int32_t n_samples, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Multi-layer weight quantisation -- utils/layer_transform.py:279-296 (quantize_targ_layer)

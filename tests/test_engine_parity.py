@@ -115,6 +115,39 @@ def test_quant_measure(engine):
     assert_bitexact(npy(y2), y2_o)
 
 
+def test_quant_measure_one_launch_equals_two_launches(engine, monkeypatch):
+    """Round 4: QuantMeasure.forward with range tracking is ONE launch (dfq_quant_measure_fused: persistent workgroups take the
+    per-sample extrema, meet on a monotonic arrival counter, then quantise).  Against the two-launch form (DFQ_QM_FUSED=0) on a
+    sequence of calls -- the counter and the slot parity carry over from call to call, shapes of one sample, of spans that do
+    not divide, of a tail that is no multiple of four -- outputs and running ranges must be bit-identical, and equal the
+    oracle's."""
+    from dfq_amd import _ffi
+    rng = np.random.default_rng(21)
+    shapes = [(8, 4, 6, 6), (8, 4, 6, 6), (1, 3, 5, 7), (3, 5, 33, 31), (5, 2, 70, 71), (8, 4, 6, 6)]
+    xs = [rng.standard_normal(sh).astype(F32) * (1.0 + i) for i, sh in enumerate(shapes)]
+    outs = {}
+    for fused in (True, False):
+        monkeypatch.setattr(q, '_QM_FUSED', fused)
+        m = q.QuantMeasure(update_stat=True).to(engine.device).eval()
+        res = []
+        for x in xs:
+            y = m(engine.to(torch.from_numpy(x.copy())))
+            res.append((npy(y), npy(m.running_min).copy(), npy(m.running_max).copy()))
+        if fused:
+            n = xs[-1].shape[0]
+            _ffi.check(_ffi.lib().dfq_quant_measure_fused_status(_ffi.ptr(m._qm_scratch), n, _ffi.stream_arg()))
+            assert m._qm_arrivals > 0
+        outs[fused] = res
+    rmin, rmax = 0.0, 0.0
+    for i, (a, b) in enumerate(zip(outs[True], outs[False])):
+        for u, v, what in zip(a, b, ('output', 'running_min', 'running_max')):
+            assert_bitexact(u, v, 'call {}: {}'.format(i, what))
+        y_o, rmin, rmax = orc.quant_measure_forward(xs[i], rmin, rmax, update_stat=True)
+        assert_bitexact(a[0], y_o, 'call {}: oracle output'.format(i))
+        assert_bitexact(a[1], np.array([rmin], dtype=F32), 'call {}: oracle running_min'.format(i))
+        assert_bitexact(a[2], np.array([rmax], dtype=F32), 'call {}: oracle running_max'.format(i))
+
+
 @pytest.mark.parametrize('update_stat', [True, False])
 def test_quant_measure_straight_through_gradient(engine, update_stat):
     """UniformQuantize.backward passes the gradient through (quantize.py:79-83); QuantMeasure in eval mode must do so on

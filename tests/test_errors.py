@@ -142,3 +142,31 @@ def test_abandoned_in_launch_wait_is_reported_not_silent(engine, monkeypatch, wh
         if type(m) in TARG:
             assert torch.isfinite(m.weight).all() and (m.bias is None or torch.isfinite(m.bias).all())
     dfq.clear_plan_cache()
+
+
+def test_abandoned_quant_measure_grid_is_reported(engine, monkeypatch):
+    """The one-launch QuantMeasure (dfq_quant_measure_fused) lets its workgroups wait for each other; with DFQ_SPIN_LIMIT=1 a
+    workgroup that does not see the whole grid at its first look gives up: the status call reports DFQ_ERR_STATE instead of a
+    hang or a silent wrong output, and a fresh module works again."""
+    import numpy as np
+    from dfq_amd.utils import quantize as q
+    x = torch.from_numpy(np.random.default_rng(5).standard_normal((16, 8, 40, 40)).astype(np.float32)).to(engine.device)
+    monkeypatch.setattr(q, '_QM_FUSED', True)
+    monkeypatch.setenv('DFQ_SPIN_LIMIT', '1')
+    failed = False
+    for attempt in range(4):
+        m = q.QuantMeasure(update_stat=True).to(engine.device).eval()
+        m(x)
+        try:
+            _ffi.check(_ffi.lib().dfq_quant_measure_fused_status(_ffi.ptr(m._qm_scratch), x.shape[0], _ffi.stream_arg()))
+        except _ffi.DfqError as e:
+            assert 'gave up' in str(e), str(e)
+            failed = True
+            break
+    if engine.kind == 'gpu':
+        assert failed, 'a spin limit of one poll must make some workgroup of a multi-workgroup grid give up'
+    monkeypatch.delenv('DFQ_SPIN_LIMIT')
+    m = q.QuantMeasure(update_stat=True).to(engine.device).eval()
+    y = m(x)
+    _ffi.check(_ffi.lib().dfq_quant_measure_fused_status(_ffi.ptr(m._qm_scratch), x.shape[0], _ffi.stream_arg()))
+    assert torch.isfinite(y).all() and float(m.running_max) > 0 > float(m.running_min)
