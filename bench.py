@@ -25,8 +25,10 @@ Next to it, measured by the same run and reported in the same line:
             of the foreign layers, replicated bias correction -> strong scaling (total work fixed); runs at every
             N (at N = 1 it is the degenerate one-rank group), so a driver run at N = 8 puts 8 ranks on the data path;
   roofline  dominant kernel le_level_kernel: algorithmic bytes per launch / HIP-event duration per launch;
-  cpu_baseline   the numpy oracle (a vectorised CPU port) timed live on this host + the unmodified reference's own
-            CPU path as measured in the build container (the GPU box has no /root/reference).
+  cpu_baseline   the numpy oracle (a vectorised CPU port) timed live on this host + `reference`: the UNMODIFIED reference's own
+            CPU path timed on THIS box's host cores (oracle/time_ref.py drives the byte-compiled reference of oracle/_ref for
+            two sweeps + one bias correction and scales to the sweeps of a full pass; the committed build-container figure
+            is carried only when oracle/_ref is absent).
 """
 from __future__ import annotations
 
@@ -177,7 +179,7 @@ def reference_cpu_record(net, full_sweeps=0, timed_sweeps=2):
 def _pmc_traffic(net, batch):
     """HBM bytes per launch of le_level_kernel from the committed PMC summary of a run with exactly this batch
     (rocprofv3 --pmc cannot run inside this process), else null."""
-    for name in ('r03_pmc_summary.json', 'r02_pmc_summary.json', 'r01_pmc_summary.json'):
+    for name in ('r04_pmc_summary.json', 'r03_pmc_summary.json', 'r02_pmc_summary.json', 'r01_pmc_summary.json'):
         path = os.path.join(ROOT, 'profiles', name)
         if net != 'mobilenet_v2' or not os.path.exists(path):
             continue

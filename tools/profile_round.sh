@@ -7,7 +7,7 @@
 #      single-network latency probe (le_resident_kernel), the other configs and the activation-range kernels;
 #   3. FETCH_SIZE / WRITE_SIZE counter passes (separate --pmc runs) at the bench's own batch size + their digest.
 # Every step runs under `timeout`; nothing here reads stdin.
-R=${ROUND:-r03}
+R=${ROUND:-r04}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 B=${PROFILE_BATCH:-32}
 if [ -z "$SKIP_BENCH" ]; then
