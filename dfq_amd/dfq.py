@@ -373,6 +373,7 @@ def _fast_le_tables(items, targ_type, dev):
     tensors' addresses are gathered per network, and those in one pass over the whole batch."""
     T = _Tables()
     geo, net_of, first, second = [], [], [], []
+    fresh_scales = []                             # relations whose cumulative scale vector was created here
     tens = []                                     # every tensor whose address goes into a table ...
     w_pos, b_row, b_pos, s_pos, fw_row, fw_pos, fb_row, fb_pos = [], [], [], [], [], [], [], []   # ... and where it goes
     n_lay = n_rel = 0
@@ -399,6 +400,7 @@ def _fast_le_tables(items, targ_type, dev):
             flat = torch.ones(sum(t['o1'][j] for j in missing), dtype=torch.float32, device=dev)
             for j, v in zip(missing, flat.split([t['o1'][j] for j in missing])):
                 relations[j].S = v
+                fresh_scales.append(relations[j])
         for j, (rr, (i1, i2, kb)) in enumerate(zip(relations, t['rel'])):
             s_pos.append(len(tens))
             tens.append(rr.S)
@@ -423,6 +425,8 @@ def _fast_le_tables(items, targ_type, dev):
         T.keep.append((mods, relations))
     ptr = _dev_ptrs(tens, dev)
     if ptr is None:
+        for rr in fresh_scales:                   # the general path decides about these itself: leave no trace
+            rr.S = None
         return None
     lay = _np.zeros(n_lay, dtype=_LAYER_DT)
     g = _np.concatenate(geo)
@@ -788,9 +792,14 @@ _le_plan_cache = OrderedDict()
 _bc_plan_cache = OrderedDict()
 _cache_lock = _threading.RLock()
 plan_cache_stats = {'le_hits': 0, 'le_misses': 0, 'bc_hits': 0, 'bc_misses': 0}
-_PLAN_ENV = ('DFQ_LE_RESIDENT', 'DFQ_LE_MERGED', 'DFQ_LE_TILE_ELEMS', 'DFQ_LE_ROW_COLS', 'DFQ_LE_PERSIST', 'DFQ_LE_SWEEP_WGS',
-             'DFQ_LE_EMIT_COLS', 'DFQ_LE_NO_SHORT', 'DFQ_LE_CHAIN_FIRST', 'DFQ_LE_POLL_NAPS', 'DFQ_LE_DEFER', 'DFQ_RES_EXACT_GROUPS', 'DFQ_RES_RELAXED',
-             'DFQ_BC_TAGGED', 'DFQ_BC_MERGED', 'DFQ_BC_BLOCKS', 'DFQ_BC_EPS', 'DFQ_GRAPH', 'DFQ_COOPERATIVE', 'DFQ_HIP_LIB')
+# every environment switch the library reads while it CREATES a plan (tests/test_errors.py checks this list against the sources)
+_PLAN_ENV = ('DFQ_LE_RESIDENT', 'DFQ_LE_MERGED', 'DFQ_LE_TILE_ELEMS', 'DFQ_LE_ROW_COLS', 'DFQ_LE_COL_COLS', 'DFQ_LE_BOOT_WORK',
+             'DFQ_LE_PERSIST', 'DFQ_LE_SWEEP_WGS', 'DFQ_LE_EMIT_COLS', 'DFQ_LE_NO_SHORT', 'DFQ_LE_CHAIN_FIRST', 'DFQ_LE_POLL_NAPS',
+             'DFQ_LE_DEFER', 'DFQ_RES_EXACT_GROUPS', 'DFQ_RES_RELAXED', 'DFQ_RES_ORDER', 'DFQ_RES_SPEC', 'DFQ_RES_CKPT',
+             'DFQ_RES_DIRECT', 'DFQ_RES_SHORT_RPT', 'DFQ_BC_TAGGED', 'DFQ_BC_MERGED', 'DFQ_BC_BLOCKS', 'DFQ_BC_EPS', 'DFQ_BC_FOLD',
+             'DFQ_GRAPH', 'DFQ_COOPERATIVE', 'DFQ_HIP_LIB')
+# ... and the ones it reads on every RUN (they change no plan)
+_RUN_ENV = ('DFQ_SPIN_LIMIT', 'DFQ_TRACE_SWEEP')
 
 
 def _env_key():

@@ -84,7 +84,12 @@ def merge_batchnorm(model, graph, bottoms, targ_type=[QConv2d]):
         host = {}
         for bn, o, n in outs:
             dev = bn.weight.device
-            src = fake if dev == fake.device else host.setdefault(dev, fake.to(dev))
+            if dev == fake.device:
+                src = fake
+            else:                                 # ONE copy of the flat buffer per foreign device (a CPU-resident model: one D2H)
+                src = host.get(dev)
+                if src is None:
+                    src = host[dev] = _ffi._to_host(fake) if dev.type == 'cpu' else fake.to(dev)
             bn.register_buffer('fake_weight', src[o:o + n].clone())
             bn.register_buffer('fake_bias', src[o + n:o + 2 * n].clone())
         stage.writeback()

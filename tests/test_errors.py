@@ -170,3 +170,20 @@ def test_abandoned_quant_measure_grid_is_reported(engine, monkeypatch):
     y = m(x)
     _ffi.check(_ffi.lib().dfq_quant_measure_fused_status(_ffi.ptr(m._qm_scratch), x.shape[0], _ffi.stream_arg()))
     assert torch.isfinite(y).all() and float(m.running_max) > 0 > float(m.running_min)
+
+
+def test_plan_cache_key_covers_every_plan_time_switch():
+    """the plan cache of the drop-in entry points is keyed on the environment switches that shape a plan at
+    creation.  Every `getenv("DFQ_...")` in the library's sources must be listed either there (dfq._PLAN_ENV) or among the
+    switches read on every run (dfq._RUN_ENV) -- a new tuning switch that is forgotten would let a stale cached plan through."""
+    import glob
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    seen = set()
+    for path in glob.glob(os.path.join(root, 'dfq_amd', 'csrc', '*')):
+        if path.endswith(('.hip', '.hpp', '.cpp')):
+            seen |= set(re.findall(r'getenv\("(DFQ_[A-Z0-9_]+)"\)', open(path).read()))
+    assert len(seen) >= 25
+    missing = seen - set(dfq._PLAN_ENV) - set(dfq._RUN_ENV)
+    assert not missing, 'switches read by the library but unknown to the plan cache: {}'.format(sorted(missing))
