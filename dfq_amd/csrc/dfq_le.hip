@@ -131,6 +131,14 @@ struct LeRelDev {
     // store is skipped in all but every `LeParams::defer`-th sweep; hold[(2 j + side) * o1 + c] = factor of channel c in the
     // j-th skipped sweep since the last store
     int32_t defer;
+    // thread-per-row W1 that is interior: the thread holds its whole row, so it takes the row range of t = fl(w / s_prev) itself
+    // instead of reading the row statistics a read-only pass of the previous relation would have published -- that pass (one
+    // workgroup per 256 rows, a wait inside the launch, 4 B per element) is then not launched at all (round 4)
+    // The row statistics such a relation's COLUMN tiles solve their 1/s from are then published by its own row tiles (device-scope
+    // atomics into r1, like the pass they replace) and the column tiles wait for THEM: cdep_idx / cdep_tiles replace dep_idx /
+    // dep_tiles on the column side, rcounter_idx is the counter the row tiles bump (-1 everywhere else: both sides share dep_idx).
+    int32_t local_r1;
+    int32_t cdep_idx, cdep_tiles, rcounter_idx;
 };
 
 // Tuning builds only (tools/ablate.sh): -DDFQ_LE_ABLATE=bits switches parts of the tile kernels off at compile
@@ -760,7 +768,31 @@ __device__ __forceinline__ double short_tile(const LeRelDev& R, const LeParams& 
                  p, ps, pinv);
     }
     float s, inv, mn1, mx1, mn2, mx2;
-    channel_scale(R, p, cur, c, s, inv, mn1, mx1, mn2, mx2);
+    const bool local = side == 0 && R.local_r1 != 0;          // (plan: fused, len <= kShortChunk)
+    float x0[kShortChunk];
+    if (local) {
+        // the row's own statistics: range of t = fl(w * 1/s_prev) over its taps (what the previous relation's read-only pass
+        // over this layer computed with the same multiplication), then the scale from them and the stored column statistics
+#pragma unroll
+        for (int k = 0; k < kShortChunk; ++k) x0[k] = w[min(k, len - 1)];
+        const guint* b = (const guint*)R.r2 + (int64_t)cur * R.stat_stride + 2 * c;
+        const uint32_t b0 = b[0], b1 = b[1];
+        mn1 = INFINITY; mx1 = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < kShortChunk; ++k) {
+            const float t = x0[k] * pinv;                          // clamped duplicates of the last tap are harmless
+            mn1 = vmin_raw(mn1, t); mx1 = vmax_raw(mx1, t);
+        }
+        mn2 = slot_min(b0); mx2 = slot_max(b1);
+        le_solve(range_of(mn1, mx1, p.signed_range), range_of(mn2, mx2, p.signed_range), p, s, inv);
+        if (ok) {            // for this relation's column tiles (same launch, other XCDs: atomics, see ld_stat)
+            uint32_t* dst = R.r1 + (int64_t)cur * R.stat_stride + 2 * c;
+            atomicMax(dst + 0, ~enc_ord(mn1));
+            atomicMax(dst + 1, enc_ord(mx1));
+        }
+    } else {
+        channel_scale(R, p, cur, c, s, inv, mn1, mx1, mn2, mx2);
+    }
     const float f = side == 0 ? s : inv;
     if (side == 0 && ok) {
         R.s_cum[c] = o_cum * s;                       // relation.py:20-24
@@ -775,7 +807,7 @@ __device__ __forceinline__ double short_tile(const LeRelDev& R, const LeParams& 
     for (int k0 = 0; k0 < len; k0 += kShortChunk) {
         float x[kShortChunk];
 #pragma unroll
-        for (int k = 0; k < kShortChunk; ++k) x[k] = w[min(k0 + k, len - 1)];
+        for (int k = 0; k < kShortChunk; ++k) x[k] = local ? x0[k] : w[min(k0 + k, len - 1)];
 #pragma unroll
         for (int k = 0; k < kShortChunk; ++k) {
             const bool in = k0 + k < len;                          // uniform
@@ -888,10 +920,12 @@ __global__ __launch_bounds__(kBlock, DFQ_LE_MIN_WAVES) void le_level_kernel(cons
     if (!col_side) {
         DFQ_TAKE(w1); DFQ_TAKE(b1); DFQ_TAKE(bnw); DFQ_TAKE(bnb); DFQ_TAKE(s_cum); DFQ_TAKE(prev_r1); DFQ_TAKE(out_cols);
         DFQ_TAKE(row_len); DFQ_TAKE(khkw1); DFQ_TAKE(pc_go); DFQ_TAKE(pc_gi);
-        DFQ_TAKE(rt_rows); DFQ_TAKE(rt_cols); DFQ_TAKE(rt_slabs); DFQ_TAKE(rt_vec); DFQ_TAKE(w1_interior);
+        DFQ_TAKE(rt_rows); DFQ_TAKE(rt_cols); DFQ_TAKE(rt_slabs); DFQ_TAKE(rt_vec); DFQ_TAKE(w1_interior); DFQ_TAKE(local_r1); DFQ_TAKE(rcounter_idx);
     } else {
         DFQ_TAKE(w2); DFQ_TAKE(out_rows); DFQ_TAKE(o2); DFQ_TAKE(gi); DFQ_TAKE(go); DFQ_TAKE(i2g); DFQ_TAKE(khkw);
         DFQ_TAKE(ct_rows); DFQ_TAKE(ct_cols); DFQ_TAKE(ct_slabs); DFQ_TAKE(ct_vec); DFQ_TAKE(w2_interior);
+        DFQ_TAKE(cdep_idx); DFQ_TAKE(cdep_tiles);
+        if ((int)desc.R.cdep_idx >= 0) { desc.R.dep_idx = desc.R.cdep_idx; desc.R.dep_tiles = desc.R.cdep_tiles; }   // (see LeRelDev::local_r1)
     }
 #undef DFQ_TAKE
     if (!col_side) {
@@ -910,6 +944,11 @@ __global__ __launch_bounds__(kBlock, DFQ_LE_MIN_WAVES) void le_level_kernel(cons
         __builtin_amdgcn_s_waitcnt(0);
         __syncthreads();
         if (threadIdx.x == 0) atomicAdd(dep_counters + (int64_t)R.counter_idx * kDepStride, 1ull);
+    }
+    if (!col_side && R.rcounter_idx >= 0) {                      // row tiles that published their rows' statistics (local_r1)
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(dep_counters + (int64_t)R.rcounter_idx * kDepStride, 1ull);
     }
     // one partial per wave (fixed butterfly order -> deterministic), no workgroup barrier
     const double t = wave_sum(acc);
@@ -1059,6 +1098,9 @@ __global__ __launch_bounds__(kBlock, DFQ_LE_SWEEP_MIN_WAVES) void le_sweep_kerne
             union { LeRelDev R; uint32_t u[kDescWords]; } desc;
 #pragma unroll
             for (int i = 0; i < kDescWords; ++i) desc.u[i] = __builtin_amdgcn_readlane(rel_word, i);
+            // column tiles of a relation whose row tiles publish their rows' statistics wait for THOSE (LeRelDev::local_r1; the
+            // tile reference already carries that counter for the look-ahead)
+            if (T.tile >= desc.R.n_row_tiles && desc.R.cdep_idx >= 0) { desc.R.dep_idx = desc.R.cdep_idx; desc.R.dep_tiles = desc.R.cdep_tiles; }
             const LeRelDev& R = desc.R;
             stamp(tr, 1);
             // the counter was read one tile ago: if it had already reached its target the producers are done
@@ -1089,6 +1131,11 @@ __global__ __launch_bounds__(kBlock, DFQ_LE_SWEEP_MIN_WAVES) void le_sweep_kerne
                 __builtin_amdgcn_s_waitcnt(0);
                 __syncthreads();
                 if (tid == 0) atomicAdd(dep_counters + (int64_t)R.counter_idx * kDepStride, 1ull);
+            }
+            if (!col_side && R.rcounter_idx >= 0) {
+                __builtin_amdgcn_s_waitcnt(0);
+                __syncthreads();
+                if (tid == 0) atomicAdd(dep_counters + (int64_t)R.rcounter_idx * kDepStride, 1ull);
             }
             const double ts = wave_sum(acc);
             if (lane == 0) partials[(int64_t)(R.partial_base + tile) * (kBlock / kWave) + tid / kWave] = ts;
@@ -1779,6 +1826,20 @@ int dfq_le_plan_create_batch(const dfq_layer* layers, int32_t n_layers, const in
     }
     // producer links + slot limits need every relation's geometry, so a second pass
     int tile_slot = 0;
+    // Thread-per-row W1 that is interior (a depthwise layer inside a chain): its threads take the row range of t = fl(w / s_prev)
+    // themselves (LeRelDev::local_r1), so the read-only pass of the previous relation over this layer is not launched at all --
+    // that relation keeps its row tiles only (DFQ_LE_LOCAL_R1=0 keeps the pass).
+    std::vector<int> skip_cols(n_relations, 0), local_r1(n_relations, 0);
+    {
+        const bool on = !(getenv("DFQ_LE_LOCAL_R1") && getenv("DFQ_LE_LOCAL_R1")[0] == '0') && getenv("DFQ_LE_NO_SHORT") == nullptr;
+        for (int r = 0; r < n_relations && on; ++r) {
+            const LeRelDev& d = h[r];
+            const int j_prev = as_second[relations[r].first];
+            if (j_prev < 0 || as_first[relations[j_prev].second] != r) continue;
+            const bool short_rows = d.khkw1 == d.row_len && d.row_len <= kShortChunk && d.row_len != 1 && h[j_prev].go == 1;
+            if (short_rows && h[j_prev].ct_vec == 0) { local_r1[r] = 1; skip_cols[j_prev] = 1; }
+        }
+    }
     for (int r = 0; r < n_relations; ++r) {
         const dfq_relation& rr = relations[r];
         LeRelDev& d = h[r];
@@ -1803,7 +1864,8 @@ int dfq_le_plan_create_batch(const dfq_layer* layers, int32_t n_layers, const in
             d.rt_vec = 0; d.rt_rows = kBlock; d.rt_cols = d.row_len; d.rt_slabs = 1;
         }
         d.n_row_tiles = ceil_div(d.o1, d.rt_rows) * d.rt_slabs;
-        d.n_col_tiles = ceil_div(d.o2, d.ct_rows) * d.ct_slabs;
+        d.n_col_tiles = skip_cols[r] ? 0 : ceil_div(d.o2, d.ct_rows) * d.ct_slabs;
+        d.local_r1 = local_r1[r];
         d.partial_base = tile_slot;
         ld[rr.first].partial_begin = d.partial_base;
         ld[rr.first].n_partials = d.n_row_tiles;                       // last touch of W1 this sweep
@@ -1886,7 +1948,28 @@ int dfq_le_plan_create_batch(const dfq_layer* layers, int32_t n_layers, const in
         const int64_t n1 = (int64_t)h[r].o1 * h[r].row_len;
         const int64_t n2 = (int64_t)h[r].o2 * h[r].i2g * h[r].khkw;
         L.rw_elems += n1 + (h[r].w2_interior ? 0 : n2);
-        L.ro_elems += h[r].w2_interior ? n2 : 0;
+        L.ro_elems += (h[r].w2_interior && h[r].n_col_tiles > 0) ? n2 : 0;      // (no read-only pass where the next relation's rows are local)
+    }
+    // local_r1: the row tiles of such a relation depend on nothing its own level produces and nobody else touches their layer, so
+    // they are listed (and counted) with the PREVIOUS relation of the chain, a level earlier -- right where that relation's read-
+    // only pass used to be; the relation's column tiles, which wait for them, then find them long finished (listed in the same
+    // level they waited for the workgroups just in front of them: 178 instead of 168 us per sweep at batch 32)
+    std::vector<int> lvl_index(n_relations, 0);
+    {
+        int li = -1, pl = -1;
+        for (int i = 0; i < n_relations; ++i) {
+            if (level[order[i]] != pl) { ++li; pl = level[order[i]]; }
+            lvl_index[order[i]] = li;
+        }
+        for (int r = 0; r < n_relations; ++r) {
+            if (!h[r].local_r1) continue;
+            const int j_prev = as_second[relations[r].first];
+            const int64_t n1 = (int64_t)h[r].o1 * h[r].row_len;
+            p->levels[lvl_index[r]].n_blocks -= h[r].n_row_tiles;
+            p->levels[lvl_index[r]].rw_elems -= n1;
+            p->levels[lvl_index[j_prev]].n_blocks += h[r].n_row_tiles;
+            p->levels[lvl_index[j_prev]].rw_elems += n1;
+        }
     }
     for (const LevelLaunch& L : p->levels) { p->rw_total += L.rw_elems; p->ro_total += L.ro_elems; }
     p->boot_blocks = boot;
@@ -1915,10 +1998,23 @@ int dfq_le_plan_create_batch(const dfq_layer* layers, int32_t n_layers, const in
             const int r = order[i];
             const int j_prev = as_second[relations[r].first];
             const int j_next = as_first[relations[r].second];
-            sorted[i].dep_idx = (j_prev >= 0) ? pos[j_prev] : -1;
-            sorted[i].dep_tiles = (j_prev >= 0) ? h[j_prev].n_col_tiles : 0;
+            // the relation whose column tiles produce what this relation's tiles need inside the launch: its predecessor in the
+            // chain -- or, where that one's read-only pass is not launched (local_r1), the predecessor's own predecessor, whose
+            // column tiles publish the row statistics this relation's 1/s_prev is solved from
+            int j_dep = j_prev;
+            if (j_dep >= 0 && h[j_dep].n_col_tiles == 0) j_dep = as_second[relations[j_dep].first];
+            if (j_dep >= 0 && h[j_dep].n_col_tiles == 0) j_dep = -1;       // (two in a row cannot happen: a thread-per-row layer between two such)
+            sorted[i].dep_idx = (j_dep >= 0) ? pos[j_dep] : -1;
+            sorted[i].dep_tiles = (j_dep >= 0) ? h[j_dep].n_col_tiles : 0;
+            // local_r1: the column tiles of the relation wait for its own row tiles (their counter sits behind the error word)
+            sorted[i].cdep_idx = -1; sorted[i].cdep_tiles = 0; sorted[i].rcounter_idx = -1;
+            if (h[r].local_r1) {
+                sorted[i].rcounter_idx = n_relations + 1 + i;
+                sorted[i].cdep_idx = n_relations + 1 + i;
+                sorted[i].cdep_tiles = h[r].n_row_tiles;
+            }
             sorted[i].counter_idx = (j_next >= 0) ? i : -1;
-            if (j_prev >= 0 && pos[j_prev] >= i)
+            if (j_dep >= 0 && pos[j_dep] >= i)
                 return (dfq_le_plan_destroy(p), fail_arg("dfq_le_plan_create: relation %d precedes the relation it depends on", r));
         }
         if (n_relations > 0 &&
@@ -1930,8 +2026,16 @@ int dfq_le_plan_create_batch(const dfq_layer* layers, int32_t n_layers, const in
             L.block_begin = (int)blocks.size();
             for (int i = 0; i < L.n_rels; ++i) {
                 const LeRelDev& d = sorted[L.rel_begin + i];
-                for (int t = 0; t < d.n_row_tiles + d.n_col_tiles; ++t) blocks.push_back(LeBlockRef{L.rel_begin + i, t, d.net, 0});
+                for (int t = d.local_r1 ? d.n_row_tiles : 0; t < d.n_row_tiles + d.n_col_tiles; ++t) blocks.push_back(LeBlockRef{L.rel_begin + i, t, d.net, 0});
+                // ... followed by the row tiles of the next relation of the chain where those take their rows' statistics themselves
+                const int j_next = as_first[relations[order[L.rel_begin + i]].second];
+                if (j_next >= 0 && h[j_next].local_r1) {
+                    const int q = pos[j_next];
+                    for (int t = 0; t < sorted[q].n_row_tiles; ++t) blocks.push_back(LeBlockRef{q, t, sorted[q].net, 0});
+                }
             }
+            if ((int)blocks.size() - L.block_begin != L.n_blocks)
+                return (dfq_le_plan_destroy(p), fail_arg("dfq_le_plan_create: internal: level of %d workgroups listed as %d", L.n_blocks, (int)blocks.size() - L.block_begin));
         }
         if ((e = hipMalloc((void**)&p->d_blocks, sizeof(LeBlockRef) * std::max<size_t>(1, blocks.size()))) != hipSuccess) return fail_alloc(e);
         if (!blocks.empty() &&
@@ -1961,8 +2065,9 @@ int dfq_le_plan_create_batch(const dfq_layer* layers, int32_t n_layers, const in
             hipLaunchKernelGGL(le_hold_reset_kernel, dim3(p->n_hold_rels), dim3(kBlock), 0, nullptr, (const LeRelDev*)p->d_rels,
                                (const int32_t*)p->d_hold_rels, (const LeState*)p->d_state, p->defer, 1);
         }
-        if ((e = hipMalloc((void**)&p->d_dep, sizeof(unsigned long long) * ((size_t)n_relations * kDepStride + 1))) != hipSuccess) return fail_alloc(e);
-        if ((e = hipMemset(p->d_dep, 0, sizeof(unsigned long long) * ((size_t)n_relations * kDepStride + 1))) != hipSuccess) return fail_alloc(e);
+        // counters: [relation: its column tiles][error word + padding][relation: its row tiles (local_r1)]
+        if ((e = hipMalloc((void**)&p->d_dep, sizeof(unsigned long long) * ((size_t)(2 * n_relations + 1) * kDepStride + 1))) != hipSuccess) return fail_alloc(e);
+        if ((e = hipMemset(p->d_dep, 0, sizeof(unsigned long long) * ((size_t)(2 * n_relations + 1) * kDepStride + 1))) != hipSuccess) return fail_alloc(e);
         const char* me = getenv("DFQ_LE_MERGED");
         p->merged = !(me && me[0] == '0');
         const char* pe = getenv("DFQ_LE_PERSIST");
@@ -1986,7 +2091,8 @@ int dfq_le_plan_create_batch(const dfq_layer* layers, int32_t n_layers, const in
                 t.lanes = std::max(1, t.npv);
                 if (col) { int g = 1; while (g < t.npv) g <<= 1; t.lanes = g; }
                 t.rel = blocks[i].rel; t.tile = blocks[i].tile; t.net = blocks[i].net;
-                t.dep_idx = d.dep_idx; t.dep_tiles = d.dep_tiles;
+                t.dep_idx = (col && d.cdep_idx >= 0) ? d.cdep_idx : d.dep_idx;
+                t.dep_tiles = (col && d.cdep_idx >= 0) ? d.cdep_tiles : d.dep_tiles;
             }
             if ((e = hipMalloc((void**)&p->d_tiles, sizeof(LeTileRef) * refs.size())) != hipSuccess) return fail_alloc(e);
             if ((e = hipMemcpy(p->d_tiles, refs.data(), sizeof(LeTileRef) * refs.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail_alloc(e);
@@ -2126,7 +2232,7 @@ static int le_restart(dfq_le_plan* p, const dfq_le_config* cfg, hipStream_t st) 
                            (const int32_t*)p->d_hold_rels, (const LeState*)p->d_state, p->defer, 1);
         DFQ_CHECK_LAUNCH();
     }
-    clear_buffers(st, p->d_dep, sizeof(unsigned long long) * ((size_t)p->n_rels * kDepStride + 1),
+    clear_buffers(st, p->d_dep, sizeof(unsigned long long) * ((size_t)(2 * p->n_rels + 1) * kDepStride + 1),
                   p->n_rels > 0 ? p->d_stats : nullptr, sizeof(uint32_t) * 4 * p->stat_words);
     DFQ_CHECK_LAUNCH();
     if (p->n_rels > 0) {

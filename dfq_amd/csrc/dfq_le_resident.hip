@@ -1032,13 +1032,17 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
         res_stamp<kTrace>(a, k, 9);
         __syncthreads();
         res_stamp<kTrace>(a, k, 10);
+        // A STRICT arrival (statistics merged from several tiles: the counter may move only once this tile's atomics have been
+        // performed, a trip through the memory system) is made after the sweep's tail -- the partial sum, the [O] vectors --
+        // which then runs while the atomics are in flight; a relaxed one (barrier + counter) at once.
+        const bool strict_c = hasA && !T.relax_c, strict_r = chain_start && !(T.relax_r & 1);
         if (hasA) {
             publish_cols(a, T, G, ra_r2, sh_col, tag + 1u);
-            arrive(a.cnt_c, T.layer, !T.relax_c);
+            if (!strict_c) arrive(a.cnt_c, T.layer, false);
         }
         if (chain_start) {
             publish_rows(a, T, rb_r1, sh_row, tag + 1u);
-            arrive(a.cnt_r, T.layer, !(T.relax_r & 1));
+            if (!strict_r) arrive(a.cnt_r, T.layer, false);
         }
         res_stamp<kTrace>(a, k, 4);
         // ---- convergence: one partial per tile (fixed butterfly + fixed wave order) as two tagged words; the reducer workgroup
@@ -1066,6 +1070,8 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
             }
         }
         res_stamp<kTrace>(a, k, 6);
+        if (strict_c) arrive(a.cnt_c, T.layer, true);
+        if (strict_r) arrive(a.cnt_r, T.layer, true);
         res_stamp<kTrace>(a, k, 11);
     }
     // a statistics spin left the loop through *sh_bad: 1 = abandoned, 2 = the loop has stopped (sweep k was not applied)

@@ -502,6 +502,45 @@ def test_launch_modes_give_identical_results(engine, monkeypatch, merged, chain_
             assert_bitexact(esnap[k], osnap[k], '{} {} (merged={}, chain_first={})'.format(name, k, merged, chain_first))
 
 
+@pytest.mark.parametrize('merged', ['1', '0'])
+@pytest.mark.parametrize('tile_elems', [None, 48])
+def test_depthwise_rows_take_their_own_statistics(engine, monkeypatch, merged, tile_elems):
+    """Round 4 (streaming engine): a depthwise layer inside a chain is walked by one thread per row, so the thread takes the
+    row range of t = fl(w / s_prev) itself, publishes it for its relation's column tiles (which wait for it inside the launch)
+    and the previous relation's read-only pass over the layer is not launched (LeRelDev::local_r1).  Fewer workgroups, the same
+    bits: against the oracle and against the plan that keeps the pass (DFQ_LE_LOCAL_R1=0), data-dependent sweep count included."""
+    monkeypatch.setenv('DFQ_LE_RESIDENT', '0')
+    monkeypatch.setenv('DFQ_LE_MERGED', merged)
+    if tile_elems:
+        monkeypatch.setenv('DFQ_LE_TILE_ELEMS', str(tile_elems))
+    for name, seed, suffix in (('tiny_mobile', 0, ''), ('tiny_mobile', 2, '_signed')):
+        gold = net_fixture(name, seed, suffix)
+        signed = bool(gold['cfg'][1])
+        out, groups = {}, {}
+        for local in ('1', '0'):
+            monkeypatch.setenv('DFQ_LE_LOCAL_R1', local)
+            model, graph, bottoms = _build(name, seed, gold, engine)
+            spec = graphspec.from_torch(graph, bottoms, TARG)
+            lt.merge_batchnorm(model, graph, bottoms, TARG)
+            orc.merge_batchnorm(spec)
+            rels = rel.create_relation(graph, bottoms, TARG)
+            plan = dfq.build_le_plan(graph, rels, TARG)
+            groups[local] = sum(plan.level_info(l)['workgroups'] for l in range(plan.levels))
+            res = plan.run(signed=signed)
+            n_o, S_o = orc.cross_layer_equalization(spec, orc.create_relation(spec), signed=signed)
+            assert res['sweeps'] == n_o
+            osnap, esnap = _spec_snapshot(spec), snapshot(graph)
+            for k in osnap:
+                assert_bitexact(esnap[k], osnap[k], '{} {} local_r1={}'.format(name, k, local))
+            for a, b in zip(plan.scale_cum, S_o):
+                assert_bitexact(npy(a), b, 'cumulative S')
+            out[local] = esnap
+            plan.close()
+        assert groups['1'] < groups['0'], groups          # the read-only passes over the depthwise layers are gone
+        for k in out['1']:
+            assert_bitexact(out['1'][k], out['0'][k], '{} {}'.format(name, k))
+
+
 def test_batched_plan_matches_separate_runs(engine):
     """Several networks in one plan (every launch covers the batch): each network must end exactly
     where a plan of its own ends, including its own sweep count."""
