@@ -337,7 +337,7 @@ __device__ __forceinline__ void vstore(gfloat* p, const float (&x)[VEC]) {
 template <int VEC, bool PRE, class Mid>
 __device__ __forceinline__ double row_tile(const LeRelDev& R, const LeParams& p, int tile, int cur, const LeDep& dep, bool ready,
                                            float (&v_in)[kSlotsVec4][VEC], Mid mid,
-                                           float* sh_s, uint32_t* sh_slot, int* sh_g, float* sh_pinv, int* sh_flag, const LeTrace& tr) {
+                                           float* sh_s, uint32_t* sh_slot, int* sh_g, float* sh_pinv, uint32_t* sh_rs, int* sh_flag, const LeTrace& tr) {
     constexpr int NV = (VEC == 4) ? kSlotsVec4 : kSlotsVec1;   // vectors per thread
     float v_own[NV][VEC];                                      // (an array of the caller used here when !PRE tripled the registers)
     float (&v)[NV][VEC] = *(PRE ? &v_in : &v_own);
@@ -359,6 +359,11 @@ __device__ __forceinline__ double row_tile(const LeRelDev& R, const LeParams& p,
     const int n_max = min(NV, small_div(nr + JL - 1, JL));             // register slots in use (block-uniform)
     gfloat* const w = (gfloat*)R.w1 + ((int64_t)r0 * R.row_len + pos);
     const bool fused = R.w1_interior != 0;     // the column rescale of the previous relation is applied here too
+    // local_r1 (plan: VEC == 4, fused, the tile spans FULL rows): the tile takes the row ranges of t = fl(w / s_prev) itself -- a
+    // pass over its registers, a reduction per row through LDS -- instead of reading the statistics a read-only pass of the
+    // previous relation over this layer would have published (that pass is not launched: 4 B per element and a workgroup per
+    // 8192 elements less), and publishes them for its relation's column tiles
+    const bool local = VEC == 4 && R.local_r1 != 0;
     // deferred store (plan: never together with `fused` or `emit`): `phase` skipped sweeps precede this one since the
     // last store; their factors were written by earlier launches and are requested before everything else
     const bool defer = (R.defer & 1) != 0;
@@ -395,7 +400,7 @@ __device__ __forceinline__ double row_tile(const LeRelDev& R, const LeParams& p,
     if (has_sl0) { const int gq = small_div(sl0, nci); c_sl0 = (g0 + gq) * R.pc_gi + i0 + (sl0 - gq * nci); }
     uint32_t pa0 = 0u, pa1 = 0u, pb0 = 0u, pb1 = 0u;
     if (!waits) {
-        if (tid < nr) { wa0 = ld_stat(st_a); wa1 = ld_stat(st_a + 1); wb0 = st_b[0]; wb1 = st_b[1]; }
+        if (tid < nr) { if (!local) { wa0 = ld_stat(st_a); wa1 = ld_stat(st_a + 1); } wb0 = st_b[0]; wb1 = st_b[1]; }
         if (has_sl0) { pa0 = ld_stat(a_base + 2 * c_sl0); pa1 = ld_stat(a_base + 2 * c_sl0 + 1); pb0 = b_base[2 * c_sl0]; pb1 = b_base[2 * c_sl0 + 1]; }
     }
     if (!PRE) {
@@ -410,7 +415,7 @@ __device__ __forceinline__ double row_tile(const LeRelDev& R, const LeParams& p,
     mid();
     if (waits) {
         if (!dep_wait(R, dep, p.poll_naps, p.spin_limit, sh_flag)) return kTileAbandoned;
-        if (tid < nr) { wa0 = ld_stat(st_a); wa1 = ld_stat(st_a + 1); wb0 = st_b[0]; wb1 = st_b[1]; }
+        if (tid < nr) { if (!local) { wa0 = ld_stat(st_a); wa1 = ld_stat(st_a + 1); } wb0 = st_b[0]; wb1 = st_b[1]; }
         if (has_sl0) { pa0 = ld_stat(a_base + 2 * c_sl0); pa1 = ld_stat(a_base + 2 * c_sl0 + 1); pb0 = b_base[2 * c_sl0]; pb1 = b_base[2 * c_sl0 + 1]; }
         if (PRE) { landed(wa0, wa1, wb0, wb1); landed(pa0, pa1, pb0, pb1); }
     }
@@ -433,6 +438,36 @@ __device__ __forceinline__ double row_tile(const LeRelDev& R, const LeParams& p,
             le_solve(range_of(slot_min(a0), slot_max(a1), p.signed_range), range_of(slot_min(b0), slot_max(b1), p.signed_range),
                      p, s, inv);
             sh_pinv[sl] = inv;
+        }
+    }
+    if (local) {
+        // the rows' statistics of t: every thread folds its slots' four values into its row's pair (LDS atomics: the lanes of a
+        // row may sit in different waves)
+        if (tid < nr) { sh_rs[2 * tid] = 0u; sh_rs[2 * tid + 1] = 0u; sh_g[tid] = (small_div(r0 + tid, R.pc_go) - g0) * nci; }
+        __syncthreads();                                   // sh_pinv, sh_g, the cleared pairs
+        int ci0[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) ci0[k] = small_div(pos + k, R.khkw1) - i0;
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            if (u >= n_max) continue;
+            const int r = min(jl + u * JL, nr - 1);
+            const int g = sh_g[r];
+            float mn = INFINITY, mx = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                const float t = v[u][k] * sh_pinv[g + ci0[k]];     // dfq.py:73 of the previous relation (rounded)
+                mn = vmin_raw(mn, t); mx = vmax_raw(mx, t);
+            }
+            if (u < n_own) { atomicMax(&sh_rs[2 * r], ~enc_ord(mn)); atomicMax(&sh_rs[2 * r + 1], enc_ord(mx)); }
+        }
+        __syncthreads();
+        if (tid < nr) {
+            wa0 = sh_rs[2 * tid]; wa1 = sh_rs[2 * tid + 1];
+            // for this relation's column tiles (same launch, other XCDs: atomics, see ld_stat)
+            uint32_t* dst = R.r1 + (int64_t)cur * R.stat_stride + 2 * (r0 + tid);
+            atomicMax(dst + 0, wa0);
+            atomicMax(dst + 1, wa1);
         }
     }
     stamp(tr, 2);
@@ -880,6 +915,7 @@ __global__ __launch_bounds__(kBlock, DFQ_LE_MIN_WAVES) void le_level_kernel(cons
     __shared__ uint32_t sh_u[2 * kSlotMax];         // row tile: column-stat slots; col tile: row stats
     __shared__ int sh_g[kTileRowsMax];              // per-row table offsets
     __shared__ float sh_p[kSlotMax];                // row tile of an interior layer: 1/s of the previous relation
+    __shared__ uint32_t sh_rs[2 * kTileRowsMax];    // row tile that takes its rows' statistics itself (local_r1)
     __shared__ int sh_flag;                         // outcome of the dependency wait
     const int lane = threadIdx.x % kWave;
     // one 16-byte load of the workgroup's entry, then ONE wave-wide load that fetches the descriptor
@@ -930,8 +966,8 @@ __global__ __launch_bounds__(kBlock, DFQ_LE_MIN_WAVES) void le_level_kernel(cons
 #undef DFQ_TAKE
     if (!col_side) {
         if (R.rt_vec == 0) acc = dep_wait(R, dep, p.poll_naps, p.spin_limit, &sh_flag) ? short_tile<0>(R, p, tile, cur) : kTileAbandoned;
-        else if (R.rt_vec == 4) { float v[kSlotsVec4][4]; acc = row_tile<4, false>(R, p, tile, cur, dep, false, v, nothing, sh_f, sh_u, sh_g, sh_p, &sh_flag, tr); }
-        else { float v[kSlotsVec4][1]; acc = row_tile<1, false>(R, p, tile, cur, dep, false, v, nothing, sh_f, sh_u, sh_g, sh_p, &sh_flag, tr); }
+        else if (R.rt_vec == 4) { float v[kSlotsVec4][4]; acc = row_tile<4, false>(R, p, tile, cur, dep, false, v, nothing, sh_f, sh_u, sh_g, sh_p, sh_rs, &sh_flag, tr); }
+        else { float v[kSlotsVec4][1]; acc = row_tile<1, false>(R, p, tile, cur, dep, false, v, nothing, sh_f, sh_u, sh_g, sh_p, sh_rs, &sh_flag, tr); }
     } else {
         if (R.ct_vec == 0) acc = dep_wait(R, dep, p.poll_naps, p.spin_limit, &sh_flag) ? short_tile<1>(R, p, tile - R.n_row_tiles, cur) : kTileAbandoned;
         else if (R.ct_vec == 4) { float v[kSlotsVec4][4]; acc = col_tile<4, false>(R, p, tile - R.n_row_tiles, cur, dep, false, v, nothing, sh_f, sh_u, sh_g, sh_p, &sh_flag, tr); }
@@ -1035,6 +1071,7 @@ __global__ __launch_bounds__(kBlock, DFQ_LE_SWEEP_MIN_WAVES) void le_sweep_kerne
     __shared__ uint32_t sh_u[2 * kSlotMax];
     __shared__ int sh_g[kTileRowsMax];
     __shared__ float sh_p[kSlotMax];
+    __shared__ uint32_t sh_rs[2 * kTileRowsMax];
     __shared__ int sh_flag;
     __shared__ unsigned char sh_done[kSweepMaxNets];
     __shared__ int sh_ready[2];                     // is the dependency of the tile of an even / odd iteration satisfied already?
@@ -1109,12 +1146,12 @@ __global__ __launch_bounds__(kBlock, DFQ_LE_SWEEP_MIN_WAVES) void le_sweep_kerne
             const bool col_side = tile >= R.n_row_tiles;
             double acc;
             if (!col_side) {
-                if (R.rt_vec == 4) acc = row_tile<4, true>(R, p, tile, cur, dep, ready, v, ahead, sh_f, sh_u, sh_g, sh_p, &sh_flag, tr);
+                if (R.rt_vec == 4) acc = row_tile<4, true>(R, p, tile, cur, dep, ready, v, ahead, sh_f, sh_u, sh_g, sh_p, sh_rs, &sh_flag, tr);
                 else {
                     ahead();
                     if (!ready && !dep_wait(R, dep, p.poll_naps, p.spin_limit, &sh_flag)) acc = kTileAbandoned;
                     else if (R.rt_vec == 0) acc = short_tile<0>(R, p, tile, cur);
-                    else { float v1[kSlotsVec4][1]; acc = row_tile<1, false>(R, p, tile, cur, dep, true, v1, [] {}, sh_f, sh_u, sh_g, sh_p, &sh_flag, tr); }
+                    else { float v1[kSlotsVec4][1]; acc = row_tile<1, false>(R, p, tile, cur, dep, true, v1, [] {}, sh_f, sh_u, sh_g, sh_p, sh_rs, &sh_flag, tr); }
                 }
             } else {
                 if (R.ct_vec == 4) acc = col_tile<4, true>(R, p, tile - R.n_row_tiles, cur, dep, ready, v, ahead, sh_f, sh_u, sh_g, sh_p, &sh_flag, tr);
@@ -1635,6 +1672,11 @@ static int col_cols_max(int vec, bool batched) {
     return (batched && vec == 4) ? 64 : kColTileLanes * vec;
 }
 static int ceil_div(int a, int b) { return (a + b - 1) / b; }
+// rows of a full-row tile (row_tile's local mode): what the register slots hold, at most the tile target
+static int local_rows(int n_rows, int row_len, int target) {
+    const int cap = kSlotsVec4 * (kBlock / (row_len / 4));
+    return std::max(1, std::min(std::min(std::min(kTileRowsMax, n_rows), cap), std::max(1, target / row_len)));
+}
 
 // [rows x cols] tiling of a [n_rows, row_len] matrix whose tiles move `vec`-wide vectors:
 // cols = slab width (multiple of vec, <= cols_max), rows so that a thread holds <= its register slots.
@@ -1832,12 +1874,26 @@ int dfq_le_plan_create_batch(const dfq_layer* layers, int32_t n_layers, const in
     std::vector<int> skip_cols(n_relations, 0), local_r1(n_relations, 0);
     {
         const bool on = !(getenv("DFQ_LE_LOCAL_R1") && getenv("DFQ_LE_LOCAL_R1")[0] == '0') && getenv("DFQ_LE_NO_SHORT") == nullptr;
+        const char* lre = getenv("DFQ_LE_LOCAL_ROW");
+        const int local_row_max = lre ? atoi(lre) : 0;
         for (int r = 0; r < n_relations && on; ++r) {
             const LeRelDev& d = h[r];
             const int j_prev = as_second[relations[r].first];
             if (j_prev < 0 || as_first[relations[j_prev].second] != r) continue;
             const bool short_rows = d.khkw1 == d.row_len && d.row_len <= kShortChunk && d.row_len != 1 && h[j_prev].go == 1;
-            if (short_rows && h[j_prev].ct_vec == 0) { local_r1[r] = 1; skip_cols[j_prev] = 1; }
+            if (short_rows && h[j_prev].ct_vec == 0) { local_r1[r] = 1; skip_cols[j_prev] = 1; continue; }
+            // ... and, OPT-IN (DFQ_LE_LOCAL_ROW = longest row in floats, e.g. 512; default 0 = off), a layer of 16-byte-vector rows
+            // tiled in FULL rows: row_tile's local mode.  Built for VERDICT round 3 item 4 and measured at batch 32 (MobileNetV2:
+            // the 1280 x 320 layer in [24 x 320] tiles; with 1024 also the 320 x 960 layer in [8 x 960] tiles): 7 % fewer bytes per
+            // sweep, but 162-164 us per forced sweep against 159-160 us without it -- a full-row tile solves five times as many
+            // column scales and issues five times as many column-statistics atomics as a [128 x 64] one, and this kernel is bound
+            // by instruction issue and workgroup residency as much as by bytes.  Its tile shape is fixed below.
+            const bool short_kind = d.khkw1 == d.row_len && d.row_len <= 32 && d.row_len != 1 && h[j_prev].go == 1;   // (thread-per-row, > 9 taps)
+            if (!short_kind && d.rt_vec == 4 && d.row_len <= local_row_max && d.row_len / 4 <= kBlock) {
+                const int nci = ceil_div(d.row_len, d.khkw1) + 1;
+                const int rows = local_rows(d.o1, d.row_len, target);
+                if ((ceil_div(rows, h[j_prev].go) + 1) * nci <= kSlotMax) { local_r1[r] = 2; skip_cols[j_prev] = 1; }
+            }
         }
     }
     for (int r = 0; r < n_relations; ++r) {
@@ -1863,9 +1919,13 @@ int dfq_le_plan_create_batch(const dfq_layer* layers, int32_t n_layers, const in
         if (getenv("DFQ_LE_NO_SHORT") == nullptr && d.khkw1 == d.row_len && d.row_len <= 32 && d.row_len != 1 && (j_prev < 0 || d.pc_go == 1)) {
             d.rt_vec = 0; d.rt_rows = kBlock; d.rt_cols = d.row_len; d.rt_slabs = 1;
         }
+        if (local_r1[r] == 2) {                       // full rows: row_len / 4 lanes per row, as many rows as the register slots hold
+            d.rt_cols = d.row_len; d.rt_slabs = 1;
+            d.rt_rows = local_rows(d.o1, d.row_len, target);
+        }
         d.n_row_tiles = ceil_div(d.o1, d.rt_rows) * d.rt_slabs;
         d.n_col_tiles = skip_cols[r] ? 0 : ceil_div(d.o2, d.ct_rows) * d.ct_slabs;
-        d.local_r1 = local_r1[r];
+        d.local_r1 = local_r1[r] ? 1 : 0;
         d.partial_base = tile_slot;
         ld[rr.first].partial_begin = d.partial_base;
         ld[rr.first].n_partials = d.n_row_tiles;                       // last touch of W1 this sweep
@@ -2001,11 +2061,21 @@ int dfq_le_plan_create_batch(const dfq_layer* layers, int32_t n_layers, const in
             // the relation whose column tiles produce what this relation's tiles need inside the launch: its predecessor in the
             // chain -- or, where that one's read-only pass is not launched (local_r1), the predecessor's own predecessor, whose
             // column tiles publish the row statistics this relation's 1/s_prev is solved from
-            int j_dep = j_prev;
-            if (j_dep >= 0 && h[j_dep].n_col_tiles == 0) j_dep = as_second[relations[j_dep].first];
-            if (j_dep >= 0 && h[j_dep].n_col_tiles == 0) j_dep = -1;       // (two in a row cannot happen: a thread-per-row layer between two such)
-            sorted[i].dep_idx = (j_dep >= 0) ? pos[j_dep] : -1;
-            sorted[i].dep_tiles = (j_dep >= 0) ? h[j_dep].n_col_tiles : 0;
+            // ... inside the launch: its predecessor in the chain.  Where that one's read-only pass is not launched (this relation
+            // is local_r1) what remains to wait for is whoever publishes the predecessor's ROW statistics (this relation's
+            // 1/s_prev is solved from them): the predecessor's own row tiles if it is local_r1 too, else the column tiles of the
+            // relation before it.
+            int j_dep = j_prev, dep_counter = -1, dep_tiles = 0;
+            if (j_dep >= 0 && h[j_dep].n_col_tiles > 0) {
+                dep_counter = pos[j_dep]; dep_tiles = h[j_dep].n_col_tiles;
+            } else if (j_dep >= 0 && h[j_dep].local_r1) {
+                dep_counter = n_relations + 1 + pos[j_dep]; dep_tiles = h[j_dep].n_row_tiles;
+            } else if (j_dep >= 0) {
+                j_dep = as_second[relations[j_dep].first];
+                if (j_dep >= 0) { dep_counter = pos[j_dep]; dep_tiles = h[j_dep].n_col_tiles; }
+            }
+            sorted[i].dep_idx = dep_counter;
+            sorted[i].dep_tiles = dep_tiles;
             // local_r1: the column tiles of the relation wait for its own row tiles (their counter sits behind the error word)
             sorted[i].cdep_idx = -1; sorted[i].cdep_tiles = 0; sorted[i].rcounter_idx = -1;
             if (h[r].local_r1) {

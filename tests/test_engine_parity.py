@@ -250,12 +250,13 @@ LE_ENGINES = ['resident', 'streaming', 'streaming-persistent', 'streaming-persis
 
 
 def _select_le_engine(monkeypatch, le_engine):
-    for k in ('DFQ_LE_RESIDENT', 'DFQ_LE_PERSIST', 'DFQ_LE_SWEEP_WGS'):
+    for k in ('DFQ_LE_RESIDENT', 'DFQ_LE_PERSIST', 'DFQ_LE_SWEEP_WGS', 'DFQ_LE_TILE_ELEMS'):
         monkeypatch.delenv(k, raising=False)
     if le_engine != 'resident':
         monkeypatch.setenv('DFQ_LE_RESIDENT', '0')
     if le_engine.startswith('streaming-persistent'):
         monkeypatch.setenv('DFQ_LE_PERSIST', '1')
+        monkeypatch.setenv('DFQ_LE_TILE_ELEMS', '256')      # enough tiles for workgroups to walk several (the result does not depend on it)
     if le_engine == 'streaming-persistent-3wg':
         monkeypatch.setenv('DFQ_LE_SWEEP_WGS', '3')
 
@@ -539,6 +540,80 @@ def test_depthwise_rows_take_their_own_statistics(engine, monkeypatch, merged, t
         assert groups['1'] < groups['0'], groups          # the read-only passes over the depthwise layers are gone
         for k in out['1']:
             assert_bitexact(out['1'][k], out['0'][k], '{} {}'.format(name, k))
+
+
+class _PointwiseChain(nn.Module):
+    """conv1x1 chains with interior layers whose rows are 16-byte vectors: c0 -> c1 -> c2 -> c3 (two consecutive interior layers),
+    and a second chain behind a ReLU6 with a grouped interior layer"""
+
+    def __init__(self):
+        super().__init__()
+        self.c0 = nn.Conv2d(3, 16, 1)
+        self.b0 = nn.BatchNorm2d(16)
+        self.c1 = nn.Conv2d(16, 40, 1)
+        self.b1 = nn.BatchNorm2d(40)
+        self.c2 = nn.Conv2d(40, 24, 1)
+        self.b2 = nn.BatchNorm2d(24)
+        self.c3 = nn.Conv2d(24, 12, 1)
+        self.b3 = nn.BatchNorm2d(12)
+        self.r6 = nn.ReLU6()
+        self.d0 = nn.Conv2d(12, 32, 1)
+        self.e0 = nn.BatchNorm2d(32)
+        self.d1 = nn.Conv2d(32, 32, 1, groups=4)          # rows of 8 floats, four groups
+        self.e1 = nn.BatchNorm2d(32)
+        self.d2 = nn.Conv2d(32, 6, 1)
+
+    def forward(self, x):
+        x = torch.relu(self.b0(self.c0(x)))
+        x = torch.relu(self.b1(self.c1(x)))
+        x = torch.relu(self.b2(self.c2(x)))
+        x = self.r6(self.b3(self.c3(x)))
+        x = torch.relu(self.e0(self.d0(x)))
+        x = torch.relu(self.e1(self.d1(x)))
+        return self.d2(x)
+
+
+@pytest.mark.parametrize('merged', ['1', '0'])
+@pytest.mark.parametrize('signed', [False, True])
+def test_full_row_tiles_take_their_own_statistics(engine, monkeypatch, merged, signed):
+    """Round 4 (streaming engine, opt-in DFQ_LE_LOCAL_ROW): an interior layer whose rows are 16-byte vectors is tiled in FULL rows; the
+    tile takes the row ranges of t = fl(w / s_prev) itself (a pass over its registers, a reduction per row through LDS),
+    publishes them for its relation's column tiles, and the previous relation's read-only pass over the layer is not
+    launched.  Two consecutive such layers, a grouped one, several row blocks: bit-identical to the oracle and to the plan
+    that keeps the passes (DFQ_LE_LOCAL_R1=0), data-dependent sweep count included."""
+    from dfq_amd import fxgraph
+    monkeypatch.setenv('DFQ_LE_RESIDENT', '0')
+    monkeypatch.setenv('DFQ_LE_MERGED', merged)
+    monkeypatch.setenv('DFQ_LE_LOCAL_ROW', '512')            # opt-in (measured no faster at batch 32: dfq_le.hip, DESIGN.md 4.1)
+    out, groups = {}, {}
+    for local in ('1', '0'):
+        monkeypatch.setenv('DFQ_LE_LOCAL_R1', local)
+        torch.manual_seed(5)
+        model = _PointwiseChain().eval()
+        gen = torch.Generator().manual_seed(9)
+        synthetic.init_weights(model, gen)
+        graph, bottoms = fxgraph.trace(model)
+        spec = graphspec.from_torch(graph, bottoms, TARG)
+        model.to(engine.device)
+        lt.merge_batchnorm(model, graph, bottoms, TARG)
+        orc.merge_batchnorm(spec)
+        rels = rel.create_relation(graph, bottoms, TARG)
+        assert len(rels) == 5
+        plan = dfq.build_le_plan(graph, rels, TARG)
+        groups[local] = sum(plan.level_info(l)['workgroups'] for l in range(plan.levels))
+        res = plan.run(signed=signed)
+        n_o, S_o = orc.cross_layer_equalization(spec, orc.create_relation(spec), signed=signed)
+        assert res['sweeps'] == n_o
+        osnap, esnap = _spec_snapshot(spec), snapshot(graph)
+        for k in osnap:
+            assert_bitexact(esnap[k], osnap[k], '{} local_r1={}'.format(k, local))
+        for a, b in zip(plan.scale_cum, S_o):
+            assert_bitexact(npy(a), b, 'cumulative S')
+        out[local] = esnap
+        plan.close()
+    assert groups['1'] < groups['0'], groups
+    for k in out['1']:
+        assert_bitexact(out['1'][k], out['0'][k], k)
 
 
 def test_batched_plan_matches_separate_runs(engine):
