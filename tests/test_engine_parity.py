@@ -256,7 +256,7 @@ def _select_le_engine(monkeypatch, le_engine):
         monkeypatch.setenv('DFQ_LE_RESIDENT', '0')
     if le_engine.startswith('streaming-persistent'):
         monkeypatch.setenv('DFQ_LE_PERSIST', '1')
-        monkeypatch.setenv('DFQ_LE_TILE_ELEMS', '256')      # enough tiles for workgroups to walk several (the result does not depend on it)
+        monkeypatch.setenv('DFQ_LE_TILE_ELEMS', '1024')     # enough tiles for workgroups to walk several (the result does not depend on it)
     if le_engine == 'streaming-persistent-3wg':
         monkeypatch.setenv('DFQ_LE_SWEEP_WGS', '3')
 
@@ -503,8 +503,7 @@ def test_launch_modes_give_identical_results(engine, monkeypatch, merged, chain_
             assert_bitexact(esnap[k], osnap[k], '{} {} (merged={}, chain_first={})'.format(name, k, merged, chain_first))
 
 
-@pytest.mark.parametrize('merged', ['1', '0'])
-@pytest.mark.parametrize('tile_elems', [None, 48])
+@pytest.mark.parametrize('merged,tile_elems', [('1', None), ('0', None), ('1', 48)])
 def test_depthwise_rows_take_their_own_statistics(engine, monkeypatch, merged, tile_elems):
     """Round 4 (streaming engine): a depthwise layer inside a chain is walked by one thread per row, so the thread takes the
     row range of t = fl(w / s_prev) itself, publishes it for its relation's column tiles (which wait for it inside the launch)
@@ -1229,8 +1228,8 @@ def test_speculation_past_the_verdict_is_invisible(engine, monkeypatch, name, se
     plan.close()
 
 
-@pytest.mark.parametrize('depth', ['1', '2', '4'])
-@pytest.mark.parametrize('le_engine', ['streaming', 'streaming-persistent-3wg'])
+# (the persistent-workgroup variant is slow on the CPU emulation: it runs at the default depth of batched plans only)
+@pytest.mark.parametrize('depth,le_engine', [('1', 'streaming'), ('2', 'streaming'), ('4', 'streaming'), ('4', 'streaming-persistent-3wg')])
 @pytest.mark.parametrize('name,seed,signed', [('tiny_mobile', 0, False), ('tiny_res', 0, False), ('tiny_cat', 3, True)])
 def test_deferred_stores_are_invisible(engine, monkeypatch, depth, le_engine, name, seed, signed):
     """Streaming engine, DFQ_LE_DEFER = depth: layers that are scaled one way only are stored every depth-th sweep and
