@@ -108,11 +108,19 @@ __device__ __forceinline__ int bc_find(const int32_t* __restrict__ begin, int n,
     return lo;
 }
 
+__device__ __forceinline__ float relu_mean(float w, float b);
+struct BcCacheSeg;
+__device__ __forceinline__ void bc_cache_init_block(const BcCacheSeg* __restrict__ segs, int n_segs, int total, int block);
+
+// (the workgroups behind the `n_mm_blocks` min/max ones refresh the cached ReLU moments of every BN that a step reads through a
+// ReLU from the current proxies -- bc_cache_init_block: until round 4 a launch of its own)
 __global__ __launch_bounds__(kBlock) void bc_minmax_kernel(const BcLayerDev* __restrict__ layers,
                                                            const int32_t* __restrict__ block_begin, int n_layers,
-                                                           uint32_t* __restrict__ slots) {
+                                                           uint32_t* __restrict__ slots, int n_mm_blocks,
+                                                           const BcCacheSeg* __restrict__ segs, int n_segs, int cache_total) {
     __shared__ float sh_mn[kBlock / kWave];
     __shared__ float sh_mx[kBlock / kWave];
+    if ((int)blockIdx.x >= n_mm_blocks) { bc_cache_init_block(segs, n_segs, cache_total, (int)blockIdx.x - n_mm_blocks); return; }
     const int l = bc_find(block_begin, n_layers, blockIdx.x);
     const BcLayerDev L = layers[l];
     const int64_t b = (int64_t)(blockIdx.x - block_begin[l]) * kMmChunk;
@@ -241,9 +249,9 @@ __device__ __forceinline__ float relu_mean(float w, float b) {
     return e;
 }
 
-// ReLU moments of every cached BN from the current beta~ (once per run, all BNs in one launch)
-__global__ __launch_bounds__(kBlock) void bc_cache_init_kernel(const BcCacheSeg* __restrict__ segs, int n_segs, int total) {
-    const int i = blockIdx.x * kBlock + threadIdx.x;
+// ReLU moments of every cached BN from the current beta~ (once per run, all BNs: the trailing workgroups of the min/max launch)
+__device__ __forceinline__ void bc_cache_init_block(const BcCacheSeg* __restrict__ segs, int n_segs, int total, int block) {
+    const int i = block * kBlock + threadIdx.x;
     if (i >= total) return;
     int lo = 0, hi = n_segs - 1;
     while (lo < hi) {
@@ -309,8 +317,16 @@ struct BcDep {            // null counters: every step is its own launch (depend
     uint32_t epoch;
     int32_t symmetric;    // dfq.py:173 `signed`: the quantiser of the row sums
     int32_t spin_limit;   // polls after which a wait is abandoned (DFQ_SPIN_LIMIT)
-    int32_t pad3;
+    int32_t mm_off;       // words from a step's `mm` to the (min, max) slots of THIS run (the slots exist in two parities, below)
 };
+// The error word.  Counter protocol: cleared by the run's clear launch, any non-zero value = a wait of this run was abandoned.
+// Tagged protocol (no clear launch): it holds the EPOCH of the latest run in which a wait was abandoned (atomicMax: epochs
+// only grow), so an old failure is no failure of this run.
+__device__ __forceinline__ bool bc_err_raised(const BcDep& dep) {
+    const uint32_t e = __hip_atomic_load(dep.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return dep.tags ? (e == dep.epoch) : (e != 0u);
+}
+__device__ __forceinline__ void bc_raise_err(const BcDep& dep) { atomicMax(dep.err, dep.tags ? dep.epoch : 1u); }
 
 template <int kExp>
 __device__ __forceinline__ void bc_step_body(const BcStepDev& st, int blk, const BcSourceDev* __restrict__ sources,
@@ -348,7 +364,7 @@ __device__ __forceinline__ void bc_step_body(const BcStepDev& st, int blk, const
             }
         }
     }
-    const QParams qp = qparams_double((double)slot_min(st.mm[0]), (double)slot_max(st.mm[1]), 8, dep.symmetric);
+    const QParams qp = qparams_double((double)slot_min(st.mm[dep.mm_off + 0]), (double)slot_max(st.mm[dep.mm_off + 1]), 8, dep.symmetric);
     {
         int rg = 0, c = 0;
 #pragma unroll
@@ -395,7 +411,7 @@ __device__ __forceinline__ void bc_step_body(const BcStepDev& st, int blk, const
         f_bias = F.bias[o_tail];
         if (F.next_bn_bias) f_nb = F.next_bn_bias[o_tail];
         if (F.next_cache) f_nw = F.next_bn_weight[o_tail];
-        const QParams fq = qparams_double((double)slot_min(F.mm[0]), (double)slot_max(F.mm[1]), 8, dep.symmetric);
+        const QParams fq = qparams_double((double)slot_min(F.mm[dep.mm_off + 0]), (double)slot_max(F.mm[dep.mm_off + 1]), 8, dep.symmetric);
         float acc = 0.0f, code;
 #pragma unroll
         for (int k = 0; k < kFoldTaps; ++k)
@@ -418,8 +434,8 @@ __device__ __forceinline__ void bc_step_body(const BcStepDev& st, int blk, const
                 __builtin_amdgcn_s_sleep(2);               // few waiters here (one step's workgroups): poll briskly
                 ++spins;
                 if (spins > dep.spin_limit ||
-                    ((spins & 255) == 0 && __hip_atomic_load(dep.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
-                    atomicMax(dep.err, 1u);
+                    ((spins & 255) == 0 && bc_err_raised(dep))) {
+                    bc_raise_err(dep);
                     ok = 0;
                     break;
                 }
@@ -448,8 +464,8 @@ __device__ __forceinline__ void bc_step_body(const BcStepDev& st, int blk, const
                     __builtin_amdgcn_s_sleep(1);
                     ++spins;
                     if (spins > dep.spin_limit ||
-                        ((spins & 255) == 0 && __hip_atomic_load(dep.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
-                        atomicMax(dep.err, 1u);
+                        ((spins & 255) == 0 && bc_err_raised(dep))) {
+                        bc_raise_err(dep);
                         *sh_flag = 0;                      // (every thread that gives up writes the same value)
                         break;
                     }
@@ -619,11 +635,15 @@ __global__ __launch_bounds__(kBlock) void bc_chain_kernel(const BcStepDev* __res
                                                           const BcChainRef* __restrict__ refs,
                                                           const BcSourceDev* __restrict__ sources, const BcFoldDev* __restrict__ folds,
                                                           uint32_t* counters, uint32_t* err, unsigned long long* tags, uint32_t epoch,
-                                                          int symmetric, int spin_limit) {
+                                                          int symmetric, int spin_limit, int mm_off, uint32_t* slots_clear, int n_slots_clear) {
     __shared__ float sh_E[kExp];
     __shared__ float sh_corr[kBlock];
     __shared__ int sh_flag;
     typedef int ivec4 __attribute__((vector_size(16)));
+    // the tagged chain has no clear launch in front of it: its first workgroup clears the (min, max) slots the NEXT run's
+    // min/max launch accumulates into (the other parity: nobody touches it in this run)
+    if (blockIdx.x == 0 && slots_clear)
+        for (int i = threadIdx.x; i < n_slots_clear; i += kBlock) slots_clear[i] = 0u;
     const ivec4 ref = *(const DFQ_GLOBAL_AS ivec4*)(refs + blockIdx.x);
     const int step = __builtin_amdgcn_readfirstlane(ref[0]);
     const int blk = __builtin_amdgcn_readfirstlane(ref[1]);
@@ -631,7 +651,7 @@ __global__ __launch_bounds__(kBlock) void bc_chain_kernel(const BcStepDev* __res
     bc_load_step(table + step, desc.u);
     bc_step_body<kExp>(desc.st, blk, sources, folds,
                        BcDep{counters, err, __builtin_amdgcn_readfirstlane(ref[2]), __builtin_amdgcn_readfirstlane(ref[3]), step, 0,
-                             tags, epoch, symmetric, spin_limit, 0},
+                             tags, epoch, symmetric, spin_limit, mm_off},
                        sh_E, sh_corr, &sh_flag);
 }
 
@@ -652,6 +672,8 @@ struct dfq_bc_plan {
     uint32_t* d_counters = nullptr;        // per step: finished workgroups (padded), + error flag
     unsigned long long* d_tags = nullptr;  // tagged-value slots {epoch : float} x 2 per rewritten BN channel; null: counter protocol
     uint32_t epoch = 0;                    // run counter carried by the slots
+    int slot_parity = 0;                   // which half of d_slots the next tagged run's min/max launch accumulates into (it is zero)
+    bool last_tagged = false;              // the last run used the tagged protocol (how dfq_bc_plan_status reads the error word)
     int chain_blocks = 0, max_expect = 0;
     bool merged = true;                    // one launch for the whole chain (false: one per chain position, DFQ_BC_MERGED=0)
     std::vector<const float*> eps_ptr;
@@ -752,7 +774,8 @@ int dfq_bc_plan_create(const dfq_layer* layers, int32_t n_layers, const dfq_bc_s
     if ((e = hipMalloc((void**)&p->d_mm_begin, sizeof(int32_t) * (n_steps + 1))) != hipSuccess) return fail_alloc(e);
     if ((e = hipMalloc((void**)&p->d_qe_begin, sizeof(int32_t) * (n_steps + 1))) != hipSuccess) return fail_alloc(e);
     if ((e = hipMalloc((void**)&p->d_sources, sizeof(BcSourceDev) * n_sources)) != hipSuccess) return fail_alloc(e);
-    if ((e = hipMalloc((void**)&p->d_slots, sizeof(uint32_t) * 2 * n_steps)) != hipSuccess) return fail_alloc(e);
+    if ((e = hipMalloc((void**)&p->d_slots, sizeof(uint32_t) * 4 * n_steps)) != hipSuccess) return fail_alloc(e);      // two parities
+    if ((e = hipMemset(p->d_slots, 0, sizeof(uint32_t) * 4 * n_steps)) != hipSuccess) return fail_alloc(e);
 
     std::vector<BcLayerDev> hl(n_steps);
     std::vector<int32_t> mmb(n_steps + 1), qeb(n_steps + 1);
@@ -1002,22 +1025,32 @@ int dfq_bc_plan_run(dfq_bc_plan* p, int32_t symmetric, void* stream) {
 }
 
 static int bc_run_direct(dfq_bc_plan* p, int32_t symmetric, hipStream_t st) {
-    // min/max slots and (one-launch chain) the hand-over counters + error word: one clear launch
     const bool chain = p->merged && p->chain_blocks > 0;
-    clear_buffers(st, p->d_slots, sizeof(uint32_t) * 2 * p->n_steps,
-                  chain ? p->d_counters : nullptr, sizeof(uint32_t) * ((size_t)p->n_steps * kBcDepStride + 1));
-    DFQ_CHECK_LAUNCH();
-    hipLaunchKernelGGL(bc_minmax_kernel, dim3(p->minmax_blocks), dim3(kBlock), 0, st, (const BcLayerDev*)p->d_layers,
-                       (const int32_t*)p->d_mm_begin, p->n_steps, p->d_slots);
+    const bool tagged_run = chain && p->d_tags != nullptr && st != p->capture_stream;
+    // (min, max) slots: two parities.  A tagged run accumulates into parity `slot_parity` (zero: cleared by the previous tagged
+    // run's chain launch, or at creation) and has NO clear launch; any other run clears both parities and its counters + error
+    // word with one launch and uses parity 0.
+    int parity = 0;
+    if (tagged_run) {
+        parity = p->slot_parity;
+        p->slot_parity ^= 1;
+    } else {
+        clear_buffers(st, p->d_slots, sizeof(uint32_t) * 4 * p->n_steps,
+                      chain ? p->d_counters : nullptr, sizeof(uint32_t) * ((size_t)p->n_steps * kBcDepStride + 1));
+        DFQ_CHECK_LAUNCH();
+        p->slot_parity = 1;                 // parity 0 is dirty after this run, parity 1 clean
+    }
+    p->last_tagged = tagged_run;
+    const int mm_off = parity * 2 * p->n_steps;
+    uint32_t* slots = p->d_slots + mm_off;
+    const int cache_blocks = (p->cache_total + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL(bc_minmax_kernel, dim3(p->minmax_blocks + cache_blocks), dim3(kBlock), 0, st, (const BcLayerDev*)p->d_layers,
+                       (const int32_t*)p->d_mm_begin, p->n_steps, slots, p->minmax_blocks,
+                       (const BcCacheSeg*)p->d_cache_segs, p->n_cache_segs, p->cache_total);
     DFQ_CHECK_LAUNCH();
     if (p->keep_eps) {
         hipLaunchKernelGGL(bc_quant_error_kernel, dim3(p->qerr_blocks), dim3(kBlock), 0, st, (const BcLayerDev*)p->d_layers,
-                           (const int32_t*)p->d_qe_begin, p->n_steps, (const uint32_t*)p->d_slots, 8, (int)symmetric);
-        DFQ_CHECK_LAUNCH();
-    }
-    if (p->cache_total > 0) {
-        hipLaunchKernelGGL(bc_cache_init_kernel, dim3((p->cache_total + kBlock - 1) / kBlock), dim3(kBlock), 0, st,
-                           (const BcCacheSeg*)p->d_cache_segs, p->n_cache_segs, p->cache_total);
+                           (const int32_t*)p->d_qe_begin, p->n_steps, (const uint32_t*)slots, 8, (int)symmetric);
         DFQ_CHECK_LAUNCH();
     }
     if (chain) {
@@ -1031,10 +1064,12 @@ static int bc_run_direct(dfq_bc_plan* p, int32_t symmetric, hipStream_t st) {
         const int spin_limit = spin_limit_from_env(20000000);
         if (p->max_expect <= kExpectSmall)
             hipLaunchKernelGGL(bc_chain_kernel<kExpectSmall>, dim3(p->chain_blocks), dim3(kBlock), 0, st, (const BcStepDev*)p->d_steps,
-                               (const BcChainRef*)p->d_refs, (const BcSourceDev*)p->d_sources, (const BcFoldDev*)p->d_folds, p->d_counters, err, tags, p->epoch, (int)symmetric, spin_limit);
+                               (const BcChainRef*)p->d_refs, (const BcSourceDev*)p->d_sources, (const BcFoldDev*)p->d_folds, p->d_counters, err, tags, p->epoch, (int)symmetric, spin_limit, mm_off,
+                               tagged_run ? p->d_slots + (parity ^ 1) * 2 * p->n_steps : nullptr, 2 * p->n_steps);
         else
             hipLaunchKernelGGL(bc_chain_kernel<kExpectMax>, dim3(p->chain_blocks), dim3(kBlock), 0, st, (const BcStepDev*)p->d_steps,
-                               (const BcChainRef*)p->d_refs, (const BcSourceDev*)p->d_sources, (const BcFoldDev*)p->d_folds, p->d_counters, err, tags, p->epoch, (int)symmetric, spin_limit);
+                               (const BcChainRef*)p->d_refs, (const BcSourceDev*)p->d_sources, (const BcFoldDev*)p->d_folds, p->d_counters, err, tags, p->epoch, (int)symmetric, spin_limit, mm_off,
+                               tagged_run ? p->d_slots + (parity ^ 1) * 2 * p->n_steps : nullptr, 2 * p->n_steps);
         DFQ_CHECK_LAUNCH();
         return DFQ_OK;
     }
@@ -1059,7 +1094,8 @@ int dfq_bc_plan_status(dfq_bc_plan* p, void* stream) {
     uint32_t gave_up = 0;
     DFQ_HIP_TRY(hipMemcpyAsync(&gave_up, p->d_counters + (size_t)p->n_steps * kBcDepStride, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     DFQ_HIP_TRY(hipStreamSynchronize(st));
-    if (gave_up) {
+    // (tagged protocol: the word holds the epoch of the latest failed run, an older failure is none of this run's)
+    if (p->last_tagged ? (gave_up == p->epoch) : (gave_up != 0u)) {
         set_error("dfq_bc_plan_status: a workgroup gave up waiting for the previous correction step (results are invalid)");
         return DFQ_ERR_STATE;
     }
