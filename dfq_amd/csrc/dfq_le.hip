@@ -1499,6 +1499,24 @@ __global__ void le_reset_kernel(LeState* states, int n_nets, double converge_thr
     }
 }
 
+// restart of a streaming plan in ONE launch: the loop state of every network (dfq.py:81-82) and the clearing of the dependency
+// counters + error word and of every statistics word (until round 4: le_reset_kernel + clear_kernel)
+__global__ void le_prepare_kernel(ClearArgs a, LeState* states, int n_nets, double converge_thres, int converge_count, int max_sweeps) {
+    const long long step = (long long)gridDim.x * blockDim.x;
+    const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int k = 0; k < 4; ++k)
+        for (long long i = i0; i < a.words[k]; i += step) a.p[k][i] = 0u;
+    for (long long i = i0; i < n_nets; i += step) {
+        LeState* state = states + i;
+        state->diff = 10.0;          // dfq.py:81
+        state->count = 0;            // dfq.py:82
+        state->sweeps = 0;
+        state->last_diff_tmp = 0.0;
+        const bool go_on = (10.0 > converge_thres) && (0 < converge_count) && (max_sweeps != 0);
+        state->done = go_on ? 0 : 1;
+    }
+}
+
 // Deferred stores: apply the factors still pending for a network (sweeps % depth of them) to its one-way-scaled layers.
 // One workgroup per span of kFlushSpan elements of one layer; workgroups of networks with nothing pending leave at once.
 constexpr int kFlushSpan = 4096;
@@ -2293,18 +2311,23 @@ int32_t dfq_le_plan_level_launches(const dfq_le_plan* p, int32_t level, int64_t*
 
 // reset the loop state, clear every stat word, recompute the stats of the untouched weights
 static int le_restart(dfq_le_plan* p, const dfq_le_config* cfg, hipStream_t st) {
-    hipLaunchKernelGGL(le_reset_kernel, dim3((p->n_nets + 63) / 64), dim3(64), 0, st, p->d_state, p->n_nets, cfg->converge_thres,
-                       (int)cfg->converge_count, (int)cfg->max_sweeps, (unsigned long long*)nullptr);
-    DFQ_CHECK_LAUNCH();
+    {
+        ClearArgs ca;
+        ca.p[0] = (uint32_t*)p->d_dep; ca.words[0] = (long long)(2 * ((size_t)(2 * p->n_rels + 1) * kDepStride + 1));
+        ca.p[1] = p->n_rels > 0 ? p->d_stats : nullptr; ca.words[1] = p->n_rels > 0 ? (long long)(4 * p->stat_words) : 0;
+        ca.p[2] = nullptr; ca.words[2] = 0; ca.p[3] = nullptr; ca.words[3] = 0;
+        const long long most = std::max(ca.words[0], std::max(ca.words[1], (long long)p->n_nets));
+        const int grid = (int)std::max<long long>(1, std::min<long long>((most + 1023) / 1024, 512));
+        hipLaunchKernelGGL(le_prepare_kernel, dim3(grid), dim3(256), 0, st, ca, p->d_state, p->n_nets, cfg->converge_thres,
+                           (int)cfg->converge_count, (int)cfg->max_sweeps);
+        DFQ_CHECK_LAUNCH();
+    }
     p->sweep_index = 0;
     if (p->defer > 1) {
         hipLaunchKernelGGL(le_hold_reset_kernel, dim3(p->n_hold_rels), dim3(kBlock), 0, st, (const LeRelDev*)p->d_rels,
                            (const int32_t*)p->d_hold_rels, (const LeState*)p->d_state, p->defer, 1);
         DFQ_CHECK_LAUNCH();
     }
-    clear_buffers(st, p->d_dep, sizeof(unsigned long long) * ((size_t)(2 * p->n_rels + 1) * kDepStride + 1),
-                  p->n_rels > 0 ? p->d_stats : nullptr, sizeof(uint32_t) * 4 * p->stat_words);
-    DFQ_CHECK_LAUNCH();
     if (p->n_rels > 0) {
         hipLaunchKernelGGL(le_bootstrap_kernel, dim3(p->boot_blocks), dim3(kBlock), 0, st,
                            (const LeRelDev*)p->d_rels, (const int32_t*)p->d_boot_map);
@@ -2403,12 +2426,7 @@ int dfq_le_enqueue(dfq_le_plan* p, const dfq_le_config* cfg, int32_t n_sweeps, i
         // one persistent launch runs up to n_sweeps sweeps from the state in d_state (it re-derives the statistics from
         // the weights it loads, so there is nothing to bootstrap and nothing to carry between calls)
         unsigned long long* err = p->d_dep + (size_t)p->n_rels * kDepStride;
-        if (restart) {
-            hipLaunchKernelGGL(le_reset_kernel, dim3(1), dim3(64), 0, st, p->d_state, 1, cfg->converge_thres,
-                               (int)cfg->converge_count, (int)cfg->max_sweeps, err);
-            DFQ_CHECK_LAUNCH();
-        }
-        return le_resident_enqueue(p->resident, cfg, p->d_state, err, n_sweeps, st);
+        return le_resident_enqueue(p->resident, cfg, p->d_state, err, n_sweeps, st, nullptr, restart ? 1 : 0);
     }
     if (!graphs_enabled() || n_sweeps < 2) return le_enqueue_direct(p, cfg, n_sweeps, restart, st);
     // A whole run of sweeps is a few hundred dependent launches with arguments that only depend on
@@ -2594,17 +2612,18 @@ int32_t dfq_le_plan_nets(const dfq_le_plan* p) { return p ? p->n_nets : 0; }
 
 int dfq_le_run(dfq_le_plan* p, const dfq_le_config* cfg, void* stream, dfq_le_result* out) {
     if (!p || !cfg) return fail_arg("dfq_le_run: bad argument");
-    int rc = dfq_le_enqueue(p, cfg, 0, 1, stream);
-    if (rc) return rc;
+    int rc;
     int32_t done = 0;
     dfq_le_result res;
     int chunk = 8;
     if (p->resident) {
-        // the kernel stops by itself where the reference's loop stops
-        rc = dfq_le_enqueue(p, cfg, cfg->max_sweeps >= 0 ? cfg->max_sweeps : (1 << 30), 0, stream);
+        // the kernel stops by itself where the reference's loop stops; the reset of the loop state rides on the launch in front of it
+        rc = dfq_le_enqueue(p, cfg, cfg->max_sweeps >= 0 ? cfg->max_sweeps : (1 << 30), 1, stream);
         if (rc) return rc;
         rc = dfq_le_query(p, stream, &res, &done);
         if (rc) return rc;
+    } else if ((rc = dfq_le_enqueue(p, cfg, 0, 1, stream)) != 0) {
+        return rc;
     } else if (cfg->max_sweeps >= 0) {
         // the sweep count is known: enqueue all of it, one synchronisation at the end
         rc = dfq_le_enqueue(p, cfg, cfg->max_sweeps, 0, stream);

@@ -1214,6 +1214,25 @@ __device__ __forceinline__ void res_reducer_body(const ResArgs& a, const LeParam
     }
 }
 
+// Everything a resident launch needs zeroed -- statistics words, counters, the progress word, the partial-sum ring -- and, for a
+// run that starts a new loop, the loop state of dfq.py:81-82 and the plan's error word: ONE launch in front of the cooperative
+// one (until round 4: a reset launch and a clear launch).
+__global__ void res_prepare_kernel(ClearArgs a, LeState* state, int restart, double converge_thres, int converge_count, int max_sweeps,
+                                   unsigned long long* err) {
+    const long long step = (long long)gridDim.x * blockDim.x;
+    for (int k = 0; k < 4; ++k)
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < a.words[k]; i += step) a.p[k][i] = 0u;
+    if (restart && blockIdx.x == 0 && threadIdx.x == 0) {
+        *err = 0ull;
+        state->diff = 10.0;          // dfq.py:81
+        state->count = 0;            // dfq.py:82
+        state->sweeps = 0;
+        state->last_diff_tmp = 0.0;
+        const bool go_on = (10.0 > converge_thres) && (0 < converge_count) && (max_sweeps != 0);
+        state->done = go_on ? 0 : 1;
+    }
+}
+
 constexpr size_t kResSmemBytes = sizeof(float) * (kResTileFloats + kResTab + kResRows) + sizeof(uint32_t) * 2 * (kResRows + kResTab) + 64 +
                                  sizeof(float) * kResRows;
 static_assert(3 * kResSmemBytes <= 160 * 1024, "three workgroups per CU");
@@ -1558,13 +1577,27 @@ LeResident* le_resident_create(const dfq_layer* layers, int n_layers, const dfq_
 }
 
 int le_resident_enqueue(LeResident* r, const dfq_le_config* cfg, LeState* d_state, unsigned long long* d_err, int n_sweeps,
-                        hipStream_t st, long long* d_trace) {
+                        hipStream_t st, long long* d_trace, int restart) {
     if (!r || !cfg || !d_state || !d_err) return fail_arg("le_resident_enqueue: bad argument");
-    if (n_sweeps <= 0) return DFQ_OK;
+    if (n_sweeps <= 0 && !restart) return DFQ_OK;
     // every launch is self-contained: statistics are re-derived from the weights it loads, tags and counters start at zero
-    clear_buffers(st, r->d_stats, sizeof(u64) * (size_t)r->stat_words, r->d_sync, sizeof(u64) * r->sync_words,
-                  r->d_partials, sizeof(double) * 2 * (size_t)(r->spec + 2) * (size_t)r->n_tiles);
-    DFQ_CHECK_LAUNCH();
+    {
+        ClearArgs ca;
+        void* ps[4] = {r->d_stats, r->d_sync, r->d_partials, nullptr};
+        const size_t bs[4] = {sizeof(u64) * (size_t)r->stat_words, sizeof(u64) * r->sync_words,
+                              sizeof(double) * 2 * (size_t)(r->spec + 2) * (size_t)r->n_tiles, 0};
+        long long most = 0;
+        for (int k = 0; k < 4; ++k) {
+            ca.p[k] = (uint32_t*)ps[k];
+            ca.words[k] = (ps[k] && n_sweeps > 0) ? (long long)(bs[k] / 4) : 0;
+            most = std::max(most, ca.words[k]);
+        }
+        const int grid = (int)std::max<long long>(1, std::min<long long>((most + 1023) / 1024, 512));
+        hipLaunchKernelGGL(res_prepare_kernel, dim3(grid), dim3(256), 0, st, ca, d_state, restart, cfg->converge_thres,
+                           (int)cfg->converge_count, (int)cfg->max_sweeps, d_err);
+        DFQ_CHECK_LAUNCH();
+    }
+    if (n_sweeps <= 0) return DFQ_OK;
     ResArgs a;
     memset(&a, 0, sizeof(a));
     a.tiles = r->d_tiles; a.rels = r->d_rels; a.layer_diff = r->d_layer_diff;

@@ -19,8 +19,9 @@ int le_resident_stats(const LeResident* r, hipStream_t st, int64_t* out5);   // 
 int64_t le_resident_elements(const LeResident* r);
 // ONE launch: load, run up to n_sweeps sweeps of the loop whose state is *d_state (stops early when the reference's
 // exit test fires), store.  Asynchronous on `st`.
+// `restart`: the launch in front of the cooperative one also resets the loop state and the error word (dfq.py:81-82)
 int le_resident_enqueue(LeResident* r, const dfq_le_config* cfg, LeState* d_state, unsigned long long* d_err, int n_sweeps,
-                        hipStream_t st, long long* d_trace = nullptr);
+                        hipStream_t st, long long* d_trace = nullptr, int restart = 0);
 int le_resident_trace_words(const LeResident* r);   // tuning aid: int64 words of the per-tile phase stamps
 
 }  // namespace dfq
