@@ -89,14 +89,18 @@ def test_no_mfma_anywhere(kernels):
 
 
 def test_occupancy_the_plans_count_on(kernels):
-    """le_resident_kernel is planned at three workgroups of four waves per CU (<= 168 vector registers), le_level_kernel at
-    five to six (<= 80)."""
+    """le_resident_kernel is planned at three workgroups of four waves per CU (<= 168 vector registers), le_level_kernel and
+    bc_chain_kernel at five to six (<= 80)."""
     by = {}
     for k in kernels:
         if k['name'] != '__asm__':
             by.setdefault(k['name'], k)
     res = [k for n, k in by.items() if 'le_resident_kernel' in n]
     lev = [k for n, k in by.items() if 'le_level_kernel' in n]
-    assert res and lev
+    chain = [k for n, k in by.items() if 'bc_chain_kernel' in n]
+    assert res and lev and chain
     assert all(k['vgpr'] <= 168 for k in res), [k['vgpr'] for k in res]
     assert all(k['vgpr'] <= 80 for k in lev), [k['vgpr'] for k in lev]
+    # (round 4: float64 pdf / cdf code inlined into the chain's source-merge loop doubled its registers and cost 28 % of a batch's
+    # correction time before anybody looked)
+    assert all(k['vgpr'] <= 80 for k in chain), [k['vgpr'] for k in chain]
