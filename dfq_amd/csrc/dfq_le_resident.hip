@@ -53,6 +53,11 @@ constexpr int kResOwn = kResRows / kBlock;
 constexpr int kResStride = 16;       // one 64-bit counter per 128-byte line
 constexpr int kResMaxTiles = 1536;   // partials staged in LDS when the sweep's verdict is drawn
 constexpr int kResMaxLayers = 512;
+#ifndef DFQ_RES_LATE_ARRIVE
+#define DFQ_RES_LATE_ARRIVE 0         // 1: a strict arrival is made after the sweep's tail instead of right behind the publication (A/B on one
+                                     // box, three runs each: 0.759-0.80 vs 0.729-0.766 ms for MobileNetV2, 0.474-0.491 vs 0.457-0.470 ms for
+                                     // DeepLab -- the counter moves later than it could and every consumer of the layer with it)
+#endif
 #ifndef DFQ_RES_TOPWAIT
 #define DFQ_RES_TOPWAIT 0            // 1: the sweep's first poll also WAITS for phase 2's counter (A/B; slower: see the loop)
 #endif
@@ -1032,17 +1037,17 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
         res_stamp<kTrace>(a, k, 9);
         __syncthreads();
         res_stamp<kTrace>(a, k, 10);
-        // A STRICT arrival (statistics merged from several tiles: the counter may move only once this tile's atomics have been
-        // performed, a trip through the memory system) is made after the sweep's tail -- the partial sum, the [O] vectors --
-        // which then runs while the atomics are in flight; a relaxed one (barrier + counter) at once.
-        const bool strict_c = hasA && !T.relax_c, strict_r = chain_start && !(T.relax_r & 1);
+        // (DFQ_RES_LATE_ARRIVE: a STRICT arrival -- statistics merged from several tiles: the counter may move only once this tile's
+        // atomics have been performed, a trip through the memory system -- could be made after the sweep's tail, which would then
+        // run while the atomics are in flight.  Measured slower: see the switch.)
+        const bool strict_c = DFQ_RES_LATE_ARRIVE && hasA && !T.relax_c, strict_r = DFQ_RES_LATE_ARRIVE && chain_start && !(T.relax_r & 1);
         if (hasA) {
             publish_cols(a, T, G, ra_r2, sh_col, tag + 1u);
-            if (!strict_c) arrive(a.cnt_c, T.layer, false);
+            if (!strict_c) arrive(a.cnt_c, T.layer, !T.relax_c);
         }
         if (chain_start) {
             publish_rows(a, T, rb_r1, sh_row, tag + 1u);
-            if (!strict_r) arrive(a.cnt_r, T.layer, false);
+            if (!strict_r) arrive(a.cnt_r, T.layer, !(T.relax_r & 1));
         }
         res_stamp<kTrace>(a, k, 4);
         // ---- convergence: one partial per tile (fixed butterfly + fixed wave order) as two tagged words; the reducer workgroup
