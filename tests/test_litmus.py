@@ -37,3 +37,18 @@ def test_register_file_butterfly_steps_match_shfl_xor():
         pytest.skip('tools/litmus/lane_xor not built (python -c "import __graft_entry__ as g; g.build()")')
     out = subprocess.run([binary], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and '0 mismatches' in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.gpu
+def test_grid_is_dispatched_in_index_order_within_the_resident_window():
+    """le_level_kernel (20 000 workgroups, far more than the chip holds) and bc_chain_kernel let a workgroup wait for workgroups
+    with LOWER indices only; that cannot deadlock as long as a 1-D grid is dispatched in index order -- which HIP does not
+    promise.  tools/litmus/dispatch_order.hip measures it on the hardware: every workgroup takes a
+    ticket when it starts; replaying the tickets, no workgroup ever started while a predecessor further back than the number
+    of workgroups resident at once had not.  (The waits are bounded and report DFQ_ERR_STATE anyway: tests/test_errors.py.)"""
+    binary = os.path.join(ROOT, 'tools', 'litmus', 'dispatch_order')
+    if not os.path.exists(binary):
+        pytest.skip('tools/litmus/dispatch_order not built (python -c "import __graft_entry__ as g; g.build()")')
+    for grid, threads in ((21280, 256), (100000, 256), (4096, 1024)):
+        out = subprocess.run([binary, str(grid), str(threads), '200'], capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0 and 'index-ordered' in out.stdout, out.stdout + out.stderr
