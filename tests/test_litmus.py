@@ -40,15 +40,19 @@ def test_register_file_butterfly_steps_match_shfl_xor():
 
 
 @pytest.mark.gpu
-def test_grid_is_dispatched_in_index_order_within_the_resident_window():
+def test_every_xcd_dispatches_its_share_of_a_grid_in_index_order():
     """le_level_kernel (20 000 workgroups, far more than the chip holds) and bc_chain_kernel let a workgroup wait for workgroups
-    with LOWER indices only; that cannot deadlock as long as a 1-D grid is dispatched in index order -- which HIP does not
-    promise.  tools/litmus/dispatch_order.hip measures it on the hardware: every workgroup takes a
-    ticket when it starts; replaying the tickets, no workgroup ever started while a predecessor further back than the number
-    of workgroups resident at once had not.  (The waits are bounded and report DFQ_ERR_STATE anyway: tests/test_errors.py.)"""
+    with LOWER indices only; that cannot deadlock as long as every XCD dispatches its share of a 1-D grid in index order (the
+    argument is in the header of tools/litmus/dispatch_order.hip) -- which HIP does not promise.  The
+    program measures it on the hardware: every workgroup takes a ticket when it starts and notes its XCD; replaying the
+    tickets XCD by XCD, no workgroup ever started while a predecessor further back than what one XCD holds at once had not,
+    while the XCDs drift thousands of workgroups apart; and a chain -- every workgroup waiting for the one before it, the
+    deepest dependency such waits allow -- runs through without a stall at up to 100 000 workgroups (200 000 by hand).  (The engine's waits are
+    bounded and report DFQ_ERR_STATE anyway: tests/test_errors.py.)"""
     binary = os.path.join(ROOT, 'tools', 'litmus', 'dispatch_order')
     if not os.path.exists(binary):
         pytest.skip('tools/litmus/dispatch_order not built (python -c "import __graft_entry__ as g; g.build()")')
-    for grid, threads in ((21280, 256), (100000, 256), (4096, 1024)):
-        out = subprocess.run([binary, str(grid), str(threads), '200'], capture_output=True, text=True, timeout=120)
-        assert out.returncode == 0 and 'index-ordered' in out.stdout, out.stdout + out.stderr
+    for grid, threads, spin in ((21280, 256, 200), (100000, 256, 200), (4096, 1024, 200), (21280, 256, 0), (50000, 64, 50)):
+        out = subprocess.run([binary, str(grid), str(threads), str(spin)], capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0 and ' 0 stalled' in out.stdout and 'i mod n' in out.stdout, out.stdout + out.stderr
+        assert spin == 0 or 'in index order' in out.stdout, out.stdout
