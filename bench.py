@@ -94,19 +94,31 @@ def prepare(net, seed, dev):
     return model, graph, bottoms, rels
 
 
+ARENA = os.environ.get('DFQ_BENCH_ARENA', '1') != '0'      # batches as one allocation (dfq_amd/arena.py); 0: tensors where torch put them
+
+
 def make_unit(protos):
     """One unit of work = a batch of networks calibrated together: deep copies of the prototypes plus
     one LE plan and one BC plan over the whole batch (a batch of 1 is an ordinary single-network plan)."""
-    from dfq_amd import dfq
+    from dfq_amd import arena, dfq
     nets = [copy.deepcopy(p) for p in protos]
-    t0 = time.perf_counter()
     if len(nets) == 1:
+        t0 = time.perf_counter()
         model, graph, bottoms, rels = nets[0]
         le = dfq.build_le_plan(graph, rels, TARG)
         bc, _ = dfq.build_bc_plan(graph, bottoms, TARG)
-    else:
-        le = dfq.build_le_plan_batch([(g, r) for (_, g, _, r) in nets], TARG)
-        bc = dfq.build_bc_plan_batch([(g, b) for (_, g, b, _) in nets], TARG)
+        return dict(nets=nets, le=le, bc=bc, plan_build_ms=(time.perf_counter() - t0) * 1e3)
+    if ARENA:
+        # the batch is put together ONCE as one allocation with a fixed stride per network (part of loading the models, like
+        # the deep copy above); a plan is then one network's tables + a base address per network
+        t0 = time.perf_counter()
+        batch = arena.NetworkBatch([(g, b, r) for (_, g, b, r) in nets], TARG)
+        t1 = time.perf_counter()
+        le, bc = batch.le_plan(), batch.bc_plan()
+        return dict(nets=nets, le=le, bc=bc, batch=batch, layout_ms=(t1 - t0) * 1e3, plan_build_ms=(time.perf_counter() - t1) * 1e3)
+    t0 = time.perf_counter()
+    le = dfq.build_le_plan_batch([(g, r) for (_, g, _, r) in nets], TARG)
+    bc = dfq.build_bc_plan_batch([(g, b) for (_, g, b, _) in nets], TARG)
     return dict(nets=nets, le=le, bc=bc, plan_build_ms=(time.perf_counter() - t0) * 1e3)
 
 
@@ -709,6 +721,9 @@ def main():
             # host-side, once per batch, outside the timed region (like graph tracing / BN folding): descriptor and
             # launch tables of the two plans, small device allocations, one synchronisation
             'plan_build_ms_per_unit': sum(u['plan_build_ms'] for u in units) / len(units),
+            'batch_layout': ('one allocation, fixed stride per network (dfq_amd/arena.py NetworkBatch); a plan = the first network\'s '
+                             'tables + {} base addresses'.format(batch)) if ARENA and batch > 1 else 'tensors where torch allocated them',
+            'batch_layout_ms_per_unit': sum(u.get('layout_ms', 0.0) for u in units) / len(units),
         },
     }
 
@@ -717,8 +732,21 @@ def main():
     pb = out['config']['plan_build_ms_per_unit']
     out['host_inclusive'] = {'plan_build_ms_per_unit': pb, 'ms_per_step_with_plan_build': ms_per_step + pb,
                              'value': n_w * batch * world / ((ms_per_step + pb) * 1e-3), 'unit': 'weights/s',
-                             'what': 'tables of the two plans built on the host for every batch, then the timed step; excludes fx tracing, '
-                                     'BN folding and relation pairing (once per architecture / per network, before calibration)'}
+                             'what': 'the two plans of a batch created on the host for every batch (one network\'s tables + a base address per '
+                                     'network; device tables from a free list), then the timed step; excludes fx tracing, BN folding, relation '
+                                     'pairing and laying the batch out as one allocation (once per architecture / per network / per batch, '
+                                     'when the models are loaded: batch_layout_ms_per_unit)'}
+    if ARENA and batch > 1 and rank == 0:
+        # the same plans over tensors left where torch allocated them: 7 000 addresses gathered in Python per batch
+        from dfq_amd import dfq
+        nets = [copy.deepcopy(p) for p in protos]
+        _sync()
+        t0 = time.perf_counter()
+        le_g = dfq.build_le_plan_batch([(g, r) for (_, g, _, r) in nets], TARG)
+        bc_g = dfq.build_bc_plan_batch([(g, b) for (_, g, b, _) in nets], TARG)
+        out['host_inclusive']['plan_build_ms_per_unit_scattered_tensors'] = (time.perf_counter() - t0) * 1e3
+        le_g.close()
+        bc_g.close()
 
     # ---- one network alone: the latency a caller of the drop-in API sees (first-class, with its own roofline fraction) ----
     if rank == 0:

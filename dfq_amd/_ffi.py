@@ -78,6 +78,8 @@ SIGNATURES = {
     'dfq_le_plan_create': (c_int32, [POINTER(DfqLayer), c_int32, POINTER(DfqRelation), c_int32, POINTER(c_void_p)]),
     'dfq_le_plan_create_batch': (c_int32, [POINTER(DfqLayer), c_int32, POINTER(c_int32), c_int32, POINTER(DfqRelation), c_int32,
                                            POINTER(c_void_p)]),
+    'dfq_le_plan_create_replicated': (c_int32, [POINTER(DfqLayer), c_int32, POINTER(DfqRelation), c_int32, POINTER(c_void_p), c_int32,
+                                                POINTER(c_void_p)]),
     'dfq_le_plan_destroy': (None, [c_void_p]),
     'dfq_le_plan_nets': (c_int32, [c_void_p]),
     'dfq_le_query_all': (c_int32, [c_void_p, c_void_p, POINTER(DfqLeResult), POINTER(c_int32)]),
@@ -119,6 +121,8 @@ SIGNATURES = {
     'dfq_quant_plan_minmax': (c_void_p, [c_void_p]),
     'dfq_bc_plan_create': (c_int32, [POINTER(DfqLayer), c_int32, POINTER(DfqBcStep), c_int32,
                                      POINTER(DfqBcSource), c_int32, POINTER(c_void_p)]),
+    'dfq_bc_plan_create_replicated': (c_int32, [POINTER(DfqLayer), c_int32, POINTER(DfqBcStep), c_int32, POINTER(DfqBcSource), c_int32,
+                                                POINTER(c_void_p), c_int32, POINTER(c_void_p)]),
     'dfq_bc_plan_destroy': (None, [c_void_p]),
     'dfq_bc_plan_run': (c_int32, [c_void_p, c_int32, c_void_p]),
     'dfq_bc_plan_status': (c_int32, [c_void_p, c_void_p]),

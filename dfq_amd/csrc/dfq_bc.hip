@@ -19,6 +19,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <map>
+#include <unordered_map>
 #include <memory>
 #include <vector>
 
@@ -660,6 +661,8 @@ __global__ __launch_bounds__(kBlock) void bc_chain_kernel(const BcStepDev* __res
 using namespace dfq;
 
 struct dfq_bc_plan {
+    dfq::DevSlab mem;                 // every device table below lives in here
+
     int n_steps = 0;
     int minmax_blocks = 0, qerr_blocks = 0;
     int64_t weight_elems = 0, eps_elems = 0;
@@ -698,29 +701,58 @@ extern "C" {
 
 void dfq_bc_plan_destroy(dfq_bc_plan* p) {
     if (!p) return;
-    if (p->d_layers) (void)hipFree(p->d_layers);
-    if (p->d_mm_begin) (void)hipFree(p->d_mm_begin);
-    if (p->d_qe_begin) (void)hipFree(p->d_qe_begin);
-    if (p->d_sources) (void)hipFree(p->d_sources);
-    if (p->d_folds) (void)hipFree(p->d_folds);
-    if (p->d_slots) (void)hipFree(p->d_slots);
-    if (p->d_eps) (void)hipFree(p->d_eps);
-    if (p->d_corr) (void)hipFree(p->d_corr);
-    if (p->d_cache) (void)hipFree(p->d_cache);
-    if (p->d_cache_segs) (void)hipFree(p->d_cache_segs);
-    if (p->d_steps) (void)hipFree(p->d_steps);
-    if (p->d_refs) (void)hipFree(p->d_refs);
-    if (p->d_counters) (void)hipFree(p->d_counters);
-    if (p->d_tags) (void)hipFree(p->d_tags);
+    dfq::dev_quiesce();                                  // nothing in flight may still use the blocks released below
+    p->mem.release();
     for (auto& e : p->exec) if (e) (void)hipGraphExecDestroy(e);
     if (p->capture_stream) (void)hipStreamDestroy(p->capture_stream);
     delete p;
+}
+
+int dfq_bc_plan_create_replicated(const dfq_layer* layers, int32_t n_layers, const dfq_bc_step* steps, int32_t n_steps,
+                                  const dfq_bc_source* sources, int32_t n_sources, const void* const* bases, int32_t n_nets,
+                                  dfq_bc_plan** out_plan) {
+    if (!layers || n_layers <= 0 || !steps || n_steps <= 0 || !sources || n_sources <= 0 || !bases || n_nets < 1 || !out_plan)
+        return fail_arg("dfq_bc_plan_create_replicated: bad argument");
+    if ((int64_t)n_layers * n_nets > INT32_MAX || (int64_t)n_steps * n_nets > INT32_MAX || (int64_t)n_sources * n_nets > INT32_MAX)
+        return fail_arg("dfq_bc_plan_create_replicated: too many layers");
+    std::vector<dfq_layer> L((size_t)n_layers * n_nets);
+    std::vector<dfq_bc_step> S((size_t)n_steps * n_nets);
+    std::vector<dfq_bc_source> C((size_t)n_sources * n_nets);
+    const intptr_t b0 = (intptr_t)bases[0];
+    auto moved = [](const float* p, intptr_t by) { return p ? (const float*)((const char*)p + by) : nullptr; };
+    for (int n = 0; n < n_nets; ++n) {
+        if (!bases[n]) return fail_arg("dfq_bc_plan_create_replicated: network %d has no base address", n);
+        const intptr_t by = (intptr_t)bases[n] - b0;
+        for (int l = 0; l < n_layers; ++l) {
+            dfq_layer& d = L[(size_t)n * n_layers + l];
+            d = layers[l];
+            d.weight = (float*)moved(d.weight, by);
+            d.bias = (float*)moved(d.bias, by);
+        }
+        for (int k = 0; k < n_steps; ++k) {
+            dfq_bc_step& d = S[(size_t)n * n_steps + k];
+            d = steps[k];
+            if (d.net != 0) return fail_arg("dfq_bc_plan_create_replicated: the step table must describe ONE network (step %d)", k);
+            d.layer += n * n_layers;
+            d.source_begin += n * n_sources;
+            d.next_bn_bias = (float*)moved(d.next_bn_bias, by);
+            d.net = n;
+        }
+        for (int k = 0; k < n_sources; ++k) {
+            dfq_bc_source& d = C[(size_t)n * n_sources + k];
+            d = sources[k];
+            d.fake_weight = moved(d.fake_weight, by);
+            d.fake_bias = moved(d.fake_bias, by);
+        }
+    }
+    return dfq_bc_plan_create(L.data(), n_layers * n_nets, S.data(), n_steps * n_nets, C.data(), n_sources * n_nets, out_plan);
 }
 
 int dfq_bc_plan_create(const dfq_layer* layers, int32_t n_layers, const dfq_bc_step* steps, int32_t n_steps,
                        const dfq_bc_source* sources, int32_t n_sources, dfq_bc_plan** out_plan) {
     if (!layers || n_layers <= 0 || !steps || n_steps <= 0 || !sources || n_sources <= 0 || !out_plan)
         return fail_arg("dfq_bc_plan_create: bad argument");
+    PlanTimer timer("dfq_bc_plan_create");
     // ---- validate & size ----
     int64_t eps_total = 0, eps_true = 0, corr_total = 0, mm_blocks = 0, qe_blocks = 0;
     std::vector<int> expect_len(n_steps, 0);
@@ -768,19 +800,21 @@ int dfq_bc_plan_create(const dfq_layer* layers, int32_t n_layers, const dfq_bc_s
         const char* de = getenv("DFQ_BC_EPS");
         p->keep_eps = de && de[0] == '1';
     }
-    if (p->keep_eps && (e = hipMalloc((void**)&p->d_eps, sizeof(float) * eps_total)) != hipSuccess) return fail_alloc(e);
-    if ((e = hipMalloc((void**)&p->d_corr, sizeof(float) * corr_total)) != hipSuccess) return fail_alloc(e);
-    if ((e = hipMalloc((void**)&p->d_layers, sizeof(BcLayerDev) * n_steps)) != hipSuccess) return fail_alloc(e);
-    if ((e = hipMalloc((void**)&p->d_mm_begin, sizeof(int32_t) * (n_steps + 1))) != hipSuccess) return fail_alloc(e);
-    if ((e = hipMalloc((void**)&p->d_qe_begin, sizeof(int32_t) * (n_steps + 1))) != hipSuccess) return fail_alloc(e);
-    if ((e = hipMalloc((void**)&p->d_sources, sizeof(BcSourceDev) * n_sources)) != hipSuccess) return fail_alloc(e);
-    if ((e = hipMalloc((void**)&p->d_slots, sizeof(uint32_t) * 4 * n_steps)) != hipSuccess) return fail_alloc(e);      // two parities
+    timer.tick("validate");
+    if (p->keep_eps && (e = p->mem.alloc((void**)&p->d_eps, sizeof(float) * eps_total)) != hipSuccess) return fail_alloc(e);
+    if ((e = p->mem.alloc((void**)&p->d_corr, sizeof(float) * corr_total)) != hipSuccess) return fail_alloc(e);
+    if ((e = p->mem.alloc((void**)&p->d_layers, sizeof(BcLayerDev) * n_steps)) != hipSuccess) return fail_alloc(e);
+    if ((e = p->mem.alloc((void**)&p->d_mm_begin, sizeof(int32_t) * (n_steps + 1))) != hipSuccess) return fail_alloc(e);
+    if ((e = p->mem.alloc((void**)&p->d_qe_begin, sizeof(int32_t) * (n_steps + 1))) != hipSuccess) return fail_alloc(e);
+    if ((e = p->mem.alloc((void**)&p->d_sources, sizeof(BcSourceDev) * n_sources)) != hipSuccess) return fail_alloc(e);
+    if ((e = p->mem.alloc((void**)&p->d_slots, sizeof(uint32_t) * 4 * n_steps)) != hipSuccess) return fail_alloc(e);      // two parities
     if ((e = hipMemset(p->d_slots, 0, sizeof(uint32_t) * 4 * n_steps)) != hipSuccess) return fail_alloc(e);
 
     std::vector<BcLayerDev> hl(n_steps);
     std::vector<int32_t> mmb(n_steps + 1), qeb(n_steps + 1);
     // BNs read through a ReLU get a cache of their moment E[ReLU(N(beta~, gamma~^2))], keyed by beta~
-    std::map<const float*, int> cache_of;
+    std::unordered_map<const float*, int> cache_of;
+    cache_of.reserve(2 * (size_t)n_sources);
     std::vector<BcCacheSeg> segs;
     int cache_total = 0;
     for (int i = 0; i < n_sources; ++i) {
@@ -793,8 +827,8 @@ int dfq_bc_plan_create(const dfq_layer* layers, int32_t n_layers, const dfq_bc_s
         cache_total += sources[i].channels;
     }
     if (cache_total > 0) {
-        if ((e = hipMalloc((void**)&p->d_cache, sizeof(float) * cache_total)) != hipSuccess) return fail_alloc(e);
-        if ((e = hipMalloc((void**)&p->d_cache_segs, sizeof(BcCacheSeg) * segs.size())) != hipSuccess) return fail_alloc(e);
+        if ((e = p->mem.alloc((void**)&p->d_cache, sizeof(float) * cache_total)) != hipSuccess) return fail_alloc(e);
+        if ((e = p->mem.alloc((void**)&p->d_cache_segs, sizeof(BcCacheSeg) * segs.size())) != hipSuccess) return fail_alloc(e);
         for (BcCacheSeg& sg : segs) sg.cache = p->d_cache + sg.begin;
         if ((e = hipMemcpy(p->d_cache_segs, segs.data(), sizeof(BcCacheSeg) * segs.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail_alloc(e);
     }
@@ -803,8 +837,9 @@ int dfq_bc_plan_create(const dfq_layer* layers, int32_t n_layers, const dfq_bc_s
     // tagged-value slots (see BcDep): one pair per channel of every BN that a step rewrites.  Only if every source of every step
     // is either never rewritten or rewritten by an EARLIER step (the reference's sequential loop reads the old value otherwise)
     // and no BN is rewritten twice; else the counter protocol, which orders whole steps, stays.
-    std::map<const float*, int> tag_of;
-    std::map<const float*, int> writer_of;
+    std::unordered_map<const float*, int> tag_of, writer_of;
+    tag_of.reserve(2 * (size_t)n_steps);
+    writer_of.reserve(2 * (size_t)n_steps);
     int tag_total = 0;
     bool tagged_ok = true;
     {
@@ -882,6 +917,7 @@ int dfq_bc_plan_create(const dfq_layer* layers, int32_t n_layers, const dfq_bc_s
         eps_off += (pairs + 3) & ~(int64_t)3; corr_off += L.out_ch;
     }
     mmb[n_steps] = (int32_t)mb; qeb[n_steps] = (int32_t)qb;
+    timer.tick("tables");
     // ---- depthwise steps folded into the tail of the step in front of them (BcFoldDev).  Step D folds into P = D - 1 (same
     //      network) when D has one input channel per group and as many groups as outputs (every output o needs E[o] only), at
     //      most kFoldTaps taps, and its ONLY source is the BN that P rewrites, channel for channel; P must launch itself (a
@@ -913,7 +949,7 @@ int dfq_bc_plan_create(const dfq_layer* layers, int32_t n_layers, const dfq_bc_s
         }
         p->n_folds = (int)folds.size();
         if (!folds.empty()) {
-            if ((e = hipMalloc((void**)&p->d_folds, sizeof(BcFoldDev) * folds.size())) != hipSuccess) return fail_alloc(e);
+            if ((e = p->mem.alloc((void**)&p->d_folds, sizeof(BcFoldDev) * folds.size())) != hipSuccess) return fail_alloc(e);
             if ((e = hipMemcpy(p->d_folds, folds.data(), sizeof(BcFoldDev) * folds.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail_alloc(e);
         }
     }
@@ -958,7 +994,7 @@ int dfq_bc_plan_create(const dfq_layer* layers, int32_t n_layers, const dfq_bc_s
             L.max_blocks = std::max(L.max_blocks, (p->steps[s2].out_ch + p->steps[s2].rows_per_block - 1) / p->steps[s2].rows_per_block);
             L.max_expect = std::max(L.max_expect, p->steps[s2].expect_len);
         }
-        if ((e = hipMalloc((void**)&p->d_steps, sizeof(BcStepDev) * n_live)) != hipSuccess) return fail_alloc(e);
+        if ((e = p->mem.alloc((void**)&p->d_steps, sizeof(BcStepDev) * n_live)) != hipSuccess) return fail_alloc(e);
         if ((e = hipMemcpy(p->d_steps, p->launch_steps.data(), sizeof(BcStepDev) * n_live, hipMemcpyHostToDevice)) != hipSuccess) return fail_alloc(e);
         // workgroup table of the one-launch chain: chain position after chain position; a step waits for the previous LIVE
         // step of its network (steps arrive network by network in graph order)
@@ -979,22 +1015,24 @@ int dfq_bc_plan_create(const dfq_layer* layers, int32_t n_layers, const dfq_bc_s
                 refs.push_back(BcChainRef{q, b, wait_of[q], wait_of[q] >= 0 ? blocks_of[wait_of[q]] : 0});
         }
         p->chain_blocks = (int)refs.size();
-        if ((e = hipMalloc((void**)&p->d_refs, sizeof(BcChainRef) * std::max<size_t>(1, refs.size()))) != hipSuccess) return fail_alloc(e);
+        if ((e = p->mem.alloc((void**)&p->d_refs, sizeof(BcChainRef) * std::max<size_t>(1, refs.size()))) != hipSuccess) return fail_alloc(e);
         if ((e = hipMemcpy(p->d_refs, refs.data(), sizeof(BcChainRef) * refs.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail_alloc(e);
-        if ((e = hipMalloc((void**)&p->d_counters, sizeof(uint32_t) * ((size_t)n_steps * kBcDepStride + 1))) != hipSuccess) return fail_alloc(e);
+        if ((e = p->mem.alloc((void**)&p->d_counters, sizeof(uint32_t) * ((size_t)n_steps * kBcDepStride + 1))) != hipSuccess) return fail_alloc(e);
         if ((e = hipMemset(p->d_counters, 0, sizeof(uint32_t) * ((size_t)n_steps * kBcDepStride + 1))) != hipSuccess) return fail_alloc(e);
         if (tag_total > 0) {
-            if ((e = hipMalloc((void**)&p->d_tags, sizeof(unsigned long long) * 2 * (size_t)tag_total)) != hipSuccess) return fail_alloc(e);
+            if ((e = p->mem.alloc((void**)&p->d_tags, sizeof(unsigned long long) * 2 * (size_t)tag_total)) != hipSuccess) return fail_alloc(e);
             if ((e = hipMemset(p->d_tags, 0, sizeof(unsigned long long) * 2 * (size_t)tag_total)) != hipSuccess) return fail_alloc(e);
         }
         const char* me = getenv("DFQ_BC_MERGED");
         p->merged = !(me && me[0] == '0');
     }
     p->minmax_blocks = (int)mb; p->qerr_blocks = (int)qb;
+    timer.tick("launches");
     if ((e = hipMemcpy(p->d_layers, hl.data(), sizeof(BcLayerDev) * n_steps, hipMemcpyHostToDevice)) != hipSuccess) return fail_alloc(e);
     if ((e = hipMemcpy(p->d_mm_begin, mmb.data(), sizeof(int32_t) * (n_steps + 1), hipMemcpyHostToDevice)) != hipSuccess) return fail_alloc(e);
     if ((e = hipMemcpy(p->d_qe_begin, qeb.data(), sizeof(int32_t) * (n_steps + 1), hipMemcpyHostToDevice)) != hipSuccess) return fail_alloc(e);
     if ((e = hipMemcpy(p->d_sources, hs.data(), sizeof(BcSourceDev) * n_sources, hipMemcpyHostToDevice)) != hipSuccess) return fail_alloc(e);
+    timer.tick("uploads");
     if ((e = hipDeviceSynchronize()) != hipSuccess) return fail_alloc(e);
     *out_plan = p;
     return DFQ_OK;

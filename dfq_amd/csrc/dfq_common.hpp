@@ -5,8 +5,11 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <time.h>
 #include <string>
 #include <tuple>
+#include <vector>
+#include <algorithm>
 
 #include "../../include/dfq_hip.h"
 
@@ -81,6 +84,67 @@ int fail_hip(hipError_t e, const char* what, const char* file, int line);
     } while (0)
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+// ---- device memory of plans (dfq_core.cpp) ---------------------------------------------------
+// A plan owns some thirty small device tables; a service that calibrates batch after batch creates and destroys plans of the
+// same shapes over and over, and hipMalloc / hipFree (30 us each, hipFree synchronising the device every time) were a third
+// of what creating a plan costs.  Blocks released by a plan go to a per-device free list keyed on their (256-byte rounded)
+// size and are handed out again as they are -- nothing is assumed about their contents, exactly like hipMalloc.  A plan's
+// destroy synchronises the device ONCE (dev_quiesce) before it releases its blocks, which is what the first hipFree used to do.
+// DFQ_POOL_MB caps what the free lists hold (default 512; 0 = every release is a hipFree); blocks above 64 MB bypass the lists.
+// DFQ_PLAN_TIMING=1: where creating a plan spends its host time (stderr, one line per plan)
+struct PlanTimer {
+    const char* name;
+    bool on;
+    double t0, last;
+    std::string line;
+    static double now() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
+    explicit PlanTimer(const char* n) : name(n) { const char* e = getenv("DFQ_PLAN_TIMING"); on = e && *e == '1'; t0 = last = on ? now() : 0; }
+    void tick(const char* label) {
+        if (!on) return;
+        const double t = now();
+        char buf[96];
+        snprintf(buf, sizeof(buf), " %s %.3f", label, t - last);
+        line += buf;
+        last = t;
+    }
+    ~PlanTimer() { if (on) fprintf(stderr, "[dfq] %s: total %.3f ms:%s\n", name, now() - t0, line.c_str()); }
+};
+
+hipError_t dev_malloc(void** out, size_t bytes);
+void dev_free(void* p);
+void dev_quiesce();
+// The tables of ONE plan, carved out of a few 4 MB blocks (a table larger than that gets a block of its own): two or three
+// dev_malloc calls per plan instead of thirty, also when no block of a destroyed plan is waiting in the free lists (a service
+// that keeps several batches in flight).  Tables start on 256-byte boundaries; release() returns every block.
+struct DevSlab {
+    static constexpr size_t kSlab = 4u << 20;
+    std::vector<void*> blocks;
+    char* cur = nullptr;
+    size_t left = 0;
+    hipError_t alloc(void** out, size_t bytes) {
+        const size_t need = (std::max<size_t>(bytes, 1) + 255) & ~(size_t)255;
+        if (need > left) {
+            void* b = nullptr;
+            const hipError_t e = dev_malloc(&b, std::max(need, kSlab));
+            if (e != hipSuccess) return e;
+            blocks.push_back(b);
+            if (need >= kSlab) { *out = b; return hipSuccess; }          // its own block; the current one keeps its rest
+            cur = (char*)b;
+            left = kSlab;
+        }
+        *out = cur;
+        cur += need;
+        left -= need;
+        return hipSuccess;
+    }
+    void release() {
+        for (void* b : blocks) dev_free(b);
+        blocks.clear();
+        cur = nullptr;
+        left = 0;
+    }
+};
 
 #ifndef DFQ_EMU
 // Launch of a kernel whose workgroups wait for each other in cycles (all of them must be resident at once): a COOPERATIVE

@@ -1,7 +1,10 @@
 // Error plumbing and version entry points of libdfq_hip.
 #include <stdarg.h>
 
+#include <algorithm>
 #include <mutex>
+#include <unordered_map>
+#include <vector>
 
 #include "dfq_common.hpp"
 
@@ -28,6 +31,81 @@ int fail_hip(hipError_t e, const char* what, const char* file, int line) {
     g_last_error = buf;
     return DFQ_ERR_HIP;
 }
+
+// ---- device memory of plans (see dfq_common.hpp) ----
+namespace {
+struct DevPool {
+    std::mutex m;
+    std::unordered_map<unsigned long long, std::vector<void*>> free_lists;   // key: device << 48 | rounded size / 256
+    std::unordered_map<void*, unsigned long long> live;                      // block -> key, for blocks that may return to a list
+    size_t cached = 0, cap = 512u << 20;
+    DevPool() {
+        const char* e = getenv("DFQ_POOL_MB");
+        if (e && *e) cap = (size_t)std::max(0, atoi(e)) << 20;
+    }
+};
+DevPool& dev_pool() { static DevPool* p = new DevPool(); return *p; }         // never destroyed: blocks may outlive static teardown
+constexpr size_t kPoolMaxBlock = 64u << 20;
+}  // namespace
+
+hipError_t dev_malloc(void** out, size_t bytes) {
+    const size_t rounded = (std::max<size_t>(bytes, 1) + 255) & ~(size_t)255;
+    DevPool& P = dev_pool();
+    if (P.cap == 0 || rounded > kPoolMaxBlock) return hipMalloc(out, rounded);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long key = ((unsigned long long)dev << 48) | (rounded >> 8);
+    {
+        std::lock_guard<std::mutex> g(P.m);
+        auto it = P.free_lists.find(key);
+        if (it != P.free_lists.end() && !it->second.empty()) {
+            *out = it->second.back();
+            it->second.pop_back();
+            P.cached -= rounded;
+            P.live[*out] = key;
+            return hipSuccess;
+        }
+    }
+    hipError_t e = hipMalloc(out, rounded);
+    if (e != hipSuccess) {                                // out of memory with blocks parked in the lists: give them back, try again
+        std::vector<void*> all;
+        {
+            std::lock_guard<std::mutex> g(P.m);
+            for (auto& kv : P.free_lists) { all.insert(all.end(), kv.second.begin(), kv.second.end()); kv.second.clear(); }
+            P.cached = 0;
+        }
+        if (all.empty()) return e;
+        (void)hipGetLastError();
+        for (void* b : all) (void)hipFree(b);
+        e = hipMalloc(out, rounded);
+        if (e != hipSuccess) return e;
+    }
+    std::lock_guard<std::mutex> g(P.m);
+    P.live[*out] = key;
+    return hipSuccess;
+}
+
+void dev_free(void* p) {
+    if (!p) return;
+    DevPool& P = dev_pool();
+    {
+        std::lock_guard<std::mutex> g(P.m);
+        auto it = P.live.find(p);
+        if (it != P.live.end()) {
+            const unsigned long long key = it->second;
+            const size_t rounded = (size_t)(key & ((1ull << 48) - 1)) << 8;
+            P.live.erase(it);
+            if (P.cached + rounded <= P.cap) {
+                P.free_lists[key].push_back(p);
+                P.cached += rounded;
+                return;
+            }
+        }
+    }
+    (void)hipFree(p);
+}
+
+void dev_quiesce() { (void)hipDeviceSynchronize(); }
 
 // ---- SpinGuard (see dfq_common.hpp) ----
 // One {event, stream, pending} record per DEVICE ordinal (an event belongs to the device it was created on: recording an event

@@ -1606,6 +1606,8 @@ struct LevelLaunch {
 using namespace dfq;
 
 struct dfq_le_plan {
+    dfq::DevSlab mem;                 // every device table below lives in here
+
     int n_layers = 0, n_rels = 0, n_nets = 1;
     LeNetDesc* d_nets = nullptr;
     int32_t* d_boot_map = nullptr;         // bootstrap workgroup -> relation
@@ -1717,20 +1719,8 @@ extern "C" {
 
 void dfq_le_plan_destroy(dfq_le_plan* p) {
     if (!p) return;
-    if (p->d_rels) (void)hipFree(p->d_rels);
-    if (p->d_layer_diff) (void)hipFree(p->d_layer_diff);
-    if (p->d_partials) (void)hipFree(p->d_partials);
-    if (p->d_layer_mean) (void)hipFree(p->d_layer_mean);
-    if (p->d_state) (void)hipFree(p->d_state);
-    if (p->d_stats) (void)hipFree(p->d_stats);
-    if (p->d_nets) (void)hipFree(p->d_nets);
-    if (p->d_boot_map) (void)hipFree(p->d_boot_map);
-    if (p->d_blocks) (void)hipFree(p->d_blocks);
-    if (p->d_dep) (void)hipFree(p->d_dep);
-    if (p->d_tiles) (void)hipFree(p->d_tiles);
-    if (p->d_hold) (void)hipFree(p->d_hold);
-    if (p->d_flush) (void)hipFree(p->d_flush);
-    if (p->d_hold_rels) (void)hipFree(p->d_hold_rels);
+    dfq::dev_quiesce();                                  // nothing in flight may still use the blocks released below
+    p->mem.release();
     for (auto& g : p->graphs) (void)hipGraphExecDestroy(g.exec);
     if (p->capture_stream) (void)hipStreamDestroy(p->capture_stream);
     if (p->resident) le_resident_destroy(p->resident);
@@ -1742,11 +1732,46 @@ int dfq_le_plan_create(const dfq_layer* layers, int32_t n_layers, const dfq_rela
     return dfq_le_plan_create_batch(layers, n_layers, nullptr, 1, relations, n_relations, out_plan);
 }
 
+int dfq_le_plan_create_replicated(const dfq_layer* layers, int32_t n_layers, const dfq_relation* relations, int32_t n_relations,
+                                  const void* const* bases, int32_t n_nets, dfq_le_plan** out_plan) {
+    if (!layers || n_layers <= 0 || n_relations < 0 || (n_relations > 0 && !relations) || !bases || n_nets < 1 || !out_plan)
+        return fail_arg("dfq_le_plan_create_replicated: bad argument");
+    if ((int64_t)n_layers * n_nets > INT32_MAX || (int64_t)n_relations * n_nets > INT32_MAX)
+        return fail_arg("dfq_le_plan_create_replicated: too many layers");
+    std::vector<dfq_layer> L((size_t)n_layers * n_nets);
+    std::vector<dfq_relation> R((size_t)std::max(1, n_relations) * n_nets);
+    std::vector<int32_t> net((size_t)n_layers * n_nets);
+    const intptr_t b0 = (intptr_t)bases[0];
+    auto moved = [](const float* p, intptr_t by) { return p ? (const float*)((const char*)p + by) : nullptr; };
+    for (int n = 0; n < n_nets; ++n) {
+        if (!bases[n]) return fail_arg("dfq_le_plan_create_replicated: network %d has no base address", n);
+        const intptr_t by = (intptr_t)bases[n] - b0;
+        for (int l = 0; l < n_layers; ++l) {
+            dfq_layer& d = L[(size_t)n * n_layers + l];
+            d = layers[l];
+            d.weight = (float*)moved(d.weight, by);
+            d.bias = (float*)moved(d.bias, by);
+            net[(size_t)n * n_layers + l] = n;
+        }
+        for (int r = 0; r < n_relations; ++r) {
+            dfq_relation& d = R[(size_t)n * n_relations + r];
+            d = relations[r];
+            d.first += n * n_layers;
+            d.second += n * n_layers;
+            d.bn_weight = (float*)moved(d.bn_weight, by);
+            d.bn_bias = (float*)moved(d.bn_bias, by);
+            d.scale_cum = (float*)moved(d.scale_cum, by);
+        }
+    }
+    return dfq_le_plan_create_batch(L.data(), n_layers * n_nets, net.data(), n_nets, R.data(), n_relations * n_nets, out_plan);
+}
+
 int dfq_le_plan_create_batch(const dfq_layer* layers, int32_t n_layers, const int32_t* layer_net, int32_t n_nets,
                              const dfq_relation* relations, int32_t n_relations, dfq_le_plan** out_plan) {
     if (!layers || n_layers <= 0 || !out_plan || n_relations < 0 || (n_relations > 0 && !relations) || n_nets < 1 ||
         (n_nets > 1 && !layer_net))
         return fail_arg("dfq_le_plan_create: bad argument");
+    PlanTimer timer("dfq_le_plan_create");
     auto net_of = [&](int l) { return layer_net ? layer_net[l] : 0; };
     for (int l = 0; l < n_layers; ++l) {
         if (net_of(l) < 0 || net_of(l) >= n_nets || (l > 0 && net_of(l) < net_of(l - 1)))
@@ -1795,6 +1820,7 @@ int dfq_le_plan_create_batch(const dfq_layer* layers, int32_t n_layers, const in
     p->n_nets = n_nets;
     auto fail_alloc = [&](hipError_t e) { dfq_le_plan_destroy(p); return fail_hip(e, "le plan allocation", __FILE__, __LINE__); };
 
+    timer.tick("validate");
     // ---- dependency levels: relations sharing a layer keep their list order ----
     std::vector<int> level(n_relations, 0), last_level(n_layers, -1);
     for (int r = 0; r < n_relations; ++r) {
@@ -1804,6 +1830,7 @@ int dfq_le_plan_create_batch(const dfq_layer* layers, int32_t n_layers, const in
         last_level[relations[r].second] = lv;
     }
 
+    timer.tick("levels");
     // ---- stat arenas.  R2 (column stats) of every relation; R1 (row stats) with the relations whose
     //      R1 is accumulated in-sweep (their first layer is someone's second layer) laid out first so
     //      the control kernel can clear exactly that part. ----
@@ -1820,10 +1847,11 @@ int dfq_le_plan_create_batch(const dfq_layer* layers, int32_t n_layers, const in
         if (pass == 0) p->r1_zero_words = w1;
     }
     hipError_t e;
-    if ((e = hipMalloc((void**)&p->d_stats, sizeof(uint32_t) * std::max<int64_t>(1, 4 * words))) != hipSuccess) return fail_alloc(e);
+    if ((e = p->mem.alloc((void**)&p->d_stats, sizeof(uint32_t) * std::max<int64_t>(1, 4 * words))) != hipSuccess) return fail_alloc(e);
     uint32_t* r2_base = p->d_stats;
     uint32_t* r1_base = p->d_stats + 2 * words;
 
+    timer.tick("arenas");
     // ---- per-relation device descriptors ----
     std::vector<LeRelDev> h(n_relations);
     std::vector<LeLayerDiff> ld(n_layers);
@@ -1955,6 +1983,7 @@ int dfq_le_plan_create_batch(const dfq_layer* layers, int32_t n_layers, const in
         p->paired_total += (int64_t)d.o1 * d.row_len + (int64_t)d.o2 * d.i2g * d.khkw;
     }
     p->total_tiles = tile_slot;
+    timer.tick("descriptors");
     // ---- deferred stores: layers scaled one way only, handled by the register-tile functions ----
     {
         // default: 4 for a batched plan (bound by what a sweep moves: 1.22e10 -> 1.35e10 -> 1.40e10 weights/s at depth 1 / 2 / 4
@@ -1972,7 +2001,7 @@ int dfq_le_plan_create_batch(const dfq_layer* layers, int32_t n_layers, const in
             if (d.defer) { hold_off[r] = hold_floats; hold_floats += (int64_t)2 * (p->defer - 1) * d.o1; }
         }
         if (hold_floats > 0) {
-            if ((e = hipMalloc((void**)&p->d_hold, sizeof(float) * hold_floats)) != hipSuccess) return fail_alloc(e);
+            if ((e = p->mem.alloc((void**)&p->d_hold, sizeof(float) * hold_floats)) != hipSuccess) return fail_alloc(e);
             for (int r = 0; r < n_relations; ++r) if (hold_off[r] >= 0) h[r].hold = p->d_hold + hold_off[r];
         } else {
             p->defer = 1;
@@ -1987,6 +2016,7 @@ int dfq_le_plan_create_batch(const dfq_layer* layers, int32_t n_layers, const in
         nd.n_tiles += h[r].n_row_tiles + h[r].n_col_tiles;
     }
 
+    timer.tick("deferred");
     // ---- sort relations by level (stable) and lay out the launches ----
     std::vector<int> order(n_relations);
     for (int r = 0; r < n_relations; ++r) order[r] = r;
@@ -2056,13 +2086,14 @@ int dfq_le_plan_create_batch(const dfq_layer* layers, int32_t n_layers, const in
         for (int b = 0; b < sorted[i].boot_tiles; ++b) boot_map[sorted[i].boot_begin + b] = i;
 
     const size_t n_part = (size_t)std::max(1, p->total_tiles) * (kBlock / kWave);
-    if ((e = hipMalloc((void**)&p->d_rels, sizeof(LeRelDev) * std::max(1, n_relations))) != hipSuccess) return fail_alloc(e);
-    if ((e = hipMalloc((void**)&p->d_layer_diff, sizeof(LeLayerDiff) * n_layers)) != hipSuccess) return fail_alloc(e);
-    if ((e = hipMalloc((void**)&p->d_partials, sizeof(double) * n_part)) != hipSuccess) return fail_alloc(e);
-    if ((e = hipMalloc((void**)&p->d_layer_mean, sizeof(double) * n_layers)) != hipSuccess) return fail_alloc(e);
-    if ((e = hipMalloc((void**)&p->d_state, sizeof(LeState) * n_nets)) != hipSuccess) return fail_alloc(e);
-    if ((e = hipMalloc((void**)&p->d_nets, sizeof(LeNetDesc) * n_nets)) != hipSuccess) return fail_alloc(e);
-    if ((e = hipMalloc((void**)&p->d_boot_map, sizeof(int32_t) * boot_map.size())) != hipSuccess) return fail_alloc(e);
+    timer.tick("layout");
+    if ((e = p->mem.alloc((void**)&p->d_rels, sizeof(LeRelDev) * std::max(1, n_relations))) != hipSuccess) return fail_alloc(e);
+    if ((e = p->mem.alloc((void**)&p->d_layer_diff, sizeof(LeLayerDiff) * n_layers)) != hipSuccess) return fail_alloc(e);
+    if ((e = p->mem.alloc((void**)&p->d_partials, sizeof(double) * n_part)) != hipSuccess) return fail_alloc(e);
+    if ((e = p->mem.alloc((void**)&p->d_layer_mean, sizeof(double) * n_layers)) != hipSuccess) return fail_alloc(e);
+    if ((e = p->mem.alloc((void**)&p->d_state, sizeof(LeState) * n_nets)) != hipSuccess) return fail_alloc(e);
+    if ((e = p->mem.alloc((void**)&p->d_nets, sizeof(LeNetDesc) * n_nets)) != hipSuccess) return fail_alloc(e);
+    if ((e = p->mem.alloc((void**)&p->d_boot_map, sizeof(int32_t) * boot_map.size())) != hipSuccess) return fail_alloc(e);
     if ((e = hipMemcpy(p->d_nets, nets.data(), sizeof(LeNetDesc) * n_nets, hipMemcpyHostToDevice)) != hipSuccess) return fail_alloc(e);
     if ((e = hipMemcpy(p->d_boot_map, boot_map.data(), sizeof(int32_t) * boot_map.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail_alloc(e);
     if ((e = hipMemcpy(p->d_layer_diff, ld.data(), sizeof(LeLayerDiff) * n_layers, hipMemcpyHostToDevice)) != hipSuccess) return fail_alloc(e);
@@ -2125,7 +2156,7 @@ int dfq_le_plan_create_batch(const dfq_layer* layers, int32_t n_layers, const in
             if ((int)blocks.size() - L.block_begin != L.n_blocks)
                 return (dfq_le_plan_destroy(p), fail_arg("dfq_le_plan_create: internal: level of %d workgroups listed as %d", L.n_blocks, (int)blocks.size() - L.block_begin));
         }
-        if ((e = hipMalloc((void**)&p->d_blocks, sizeof(LeBlockRef) * std::max<size_t>(1, blocks.size()))) != hipSuccess) return fail_alloc(e);
+        if ((e = p->mem.alloc((void**)&p->d_blocks, sizeof(LeBlockRef) * std::max<size_t>(1, blocks.size()))) != hipSuccess) return fail_alloc(e);
         if (!blocks.empty() &&
             (e = hipMemcpy(p->d_blocks, blocks.data(), sizeof(LeBlockRef) * blocks.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail_alloc(e);
         p->h_rels = sorted;
@@ -2146,15 +2177,15 @@ int dfq_le_plan_create_batch(const dfq_layer* layers, int32_t n_layers, const in
             }
             p->n_flush = (int)refs.size();
             p->n_hold_rels = (int)hold_rels.size();
-            if ((e = hipMalloc((void**)&p->d_flush, sizeof(LeFlushRef) * refs.size())) != hipSuccess) return fail_alloc(e);
-            if ((e = hipMalloc((void**)&p->d_hold_rels, sizeof(int32_t) * hold_rels.size())) != hipSuccess) return fail_alloc(e);
+            if ((e = p->mem.alloc((void**)&p->d_flush, sizeof(LeFlushRef) * refs.size())) != hipSuccess) return fail_alloc(e);
+            if ((e = p->mem.alloc((void**)&p->d_hold_rels, sizeof(int32_t) * hold_rels.size())) != hipSuccess) return fail_alloc(e);
             if ((e = hipMemcpy(p->d_flush, refs.data(), sizeof(LeFlushRef) * refs.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail_alloc(e);
             if ((e = hipMemcpy(p->d_hold_rels, hold_rels.data(), sizeof(int32_t) * hold_rels.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail_alloc(e);
             hipLaunchKernelGGL(le_hold_reset_kernel, dim3(p->n_hold_rels), dim3(kBlock), 0, nullptr, (const LeRelDev*)p->d_rels,
                                (const int32_t*)p->d_hold_rels, (const LeState*)p->d_state, p->defer, 1);
         }
         // counters: [relation: its column tiles][error word + padding][relation: its row tiles (local_r1)]
-        if ((e = hipMalloc((void**)&p->d_dep, sizeof(unsigned long long) * ((size_t)(2 * n_relations + 1) * kDepStride + 1))) != hipSuccess) return fail_alloc(e);
+        if ((e = p->mem.alloc((void**)&p->d_dep, sizeof(unsigned long long) * ((size_t)(2 * n_relations + 1) * kDepStride + 1))) != hipSuccess) return fail_alloc(e);
         if ((e = hipMemset(p->d_dep, 0, sizeof(unsigned long long) * ((size_t)(2 * n_relations + 1) * kDepStride + 1))) != hipSuccess) return fail_alloc(e);
         const char* me = getenv("DFQ_LE_MERGED");
         p->merged = !(me && me[0] == '0');
@@ -2182,7 +2213,7 @@ int dfq_le_plan_create_batch(const dfq_layer* layers, int32_t n_layers, const in
                 t.dep_idx = (col && d.cdep_idx >= 0) ? d.cdep_idx : d.dep_idx;
                 t.dep_tiles = (col && d.cdep_idx >= 0) ? d.cdep_tiles : d.dep_tiles;
             }
-            if ((e = hipMalloc((void**)&p->d_tiles, sizeof(LeTileRef) * refs.size())) != hipSuccess) return fail_alloc(e);
+            if ((e = p->mem.alloc((void**)&p->d_tiles, sizeof(LeTileRef) * refs.size())) != hipSuccess) return fail_alloc(e);
             if ((e = hipMemcpy(p->d_tiles, refs.data(), sizeof(LeTileRef) * refs.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail_alloc(e);
             // every workgroup must be resident at once (a tile may wait for a tile another workgroup holds)
             int dev = 0, occ = 0;
@@ -2200,9 +2231,12 @@ int dfq_le_plan_create_batch(const dfq_layer* layers, int32_t n_layers, const in
             p->sweep_grid = (int)std::min<int64_t>(cap, (int64_t)blocks.size());
         }
     }
+    timer.tick("uploads");
     if (n_nets == 1 && n_relations > 0) p->resident = le_resident_create(layers, n_layers, relations, n_relations, &p->resident_why);
     else p->resident_why = n_nets > 1 ? "batched plan" : "no relations";
+    timer.tick("resident");
     if ((e = hipDeviceSynchronize()) != hipSuccess) return fail_alloc(e);
+    timer.tick("sync");
     *out_plan = p;
     return DFQ_OK;
 }
@@ -2226,7 +2260,7 @@ int dfq_le_resident_trace(dfq_le_plan* p, const dfq_le_config* cfg, int32_t n_sw
     if (capacity < words) return fail_arg("dfq_le_resident_trace: need room for %lld words", (long long)words);
     hipStream_t st = as_stream(stream);
     long long* d = nullptr;
-    DFQ_HIP_TRY(hipMalloc((void**)&d, words * sizeof(long long)));
+    DFQ_HIP_TRY(dfq::dev_malloc((void**)&d, words * sizeof(long long)));
     DFQ_HIP_TRY(hipMemsetAsync(d, 0, words * sizeof(long long), st));
     unsigned long long* err = p->d_dep + (size_t)p->n_rels * kDepStride;
     hipLaunchKernelGGL(le_reset_kernel, dim3(1), dim3(64), 0, st, p->d_state, 1, cfg->converge_thres, (int)cfg->converge_count,
@@ -2237,7 +2271,7 @@ int dfq_le_resident_trace(dfq_le_plan* p, const dfq_le_config* cfg, int32_t n_sw
         if (e == hipSuccess) e = hipStreamSynchronize(st);
         if (e != hipSuccess) rc = fail_hip(e, "trace copy", __FILE__, __LINE__);
     }
-    (void)hipFree(d);
+    dfq::dev_free(d);
     return rc;
 }
 int64_t dfq_le_resident_trace_words(const dfq_le_plan* p) { return (p && p->resident) ? le_resident_trace_words(p->resident) : 0; }
@@ -2522,7 +2556,7 @@ int dfq_le_trace(dfq_le_plan* p, const dfq_le_config* cfg, int32_t launch, int32
     hipStream_t st = as_stream(stream);
     const LeParams q = plan_params(p, cfg);
     long long* d = nullptr;
-    DFQ_HIP_TRY(hipMalloc((void**)&d, 16 * sizeof(long long)));
+    DFQ_HIP_TRY(dfq::dev_malloc((void**)&d, 16 * sizeof(long long)));
     DFQ_HIP_TRY(hipMemsetAsync(d, 0, 16 * sizeof(long long), st));
     int rc = le_restart(p, cfg, st);
     const char* te = getenv("DFQ_TRACE_SWEEP");    // default: the second sweep (steady-state stat flow)
@@ -2538,7 +2572,7 @@ int dfq_le_trace(dfq_le_plan* p, const dfq_le_config* cfg, int32_t launch, int32
         if (e == hipSuccess) e = hipStreamSynchronize(st);
         if (e != hipSuccess) rc = fail_hip(e, "trace copy", __FILE__, __LINE__);
     }
-    (void)hipFree(d);
+    dfq::dev_free(d);
     return rc;
 }
 
@@ -2551,7 +2585,7 @@ int dfq_le_trace_blocks(dfq_le_plan* p, const dfq_le_config* cfg, int32_t launch
     hipStream_t st = as_stream(stream);
     const LeParams q = plan_params(p, cfg);
     long long* d = nullptr;
-    DFQ_HIP_TRY(hipMalloc((void**)&d, 3 * n_blocks * sizeof(long long)));
+    DFQ_HIP_TRY(dfq::dev_malloc((void**)&d, 3 * n_blocks * sizeof(long long)));
     DFQ_HIP_TRY(hipMemsetAsync(d, 0, 3 * n_blocks * sizeof(long long), st));
     int rc = le_restart(p, cfg, st);
     // trace the third sweep (steady state, code and tables warm); DFQ_TRACE_SWEEP picks another one (with deferred stores
@@ -2569,7 +2603,7 @@ int dfq_le_trace_blocks(dfq_le_plan* p, const dfq_le_config* cfg, int32_t launch
         if (e == hipSuccess) e = hipStreamSynchronize(st);
         if (e != hipSuccess) rc = fail_hip(e, "trace copy", __FILE__, __LINE__);
     }
-    (void)hipFree(d);
+    dfq::dev_free(d);
     return rc;
 }
 

@@ -343,13 +343,14 @@ extern "C" {
 
 void dfq_le_lazy_plan_destroy(dfq_le_lazy_plan* p) {
     if (!p) return;
-    if (p->d_rels) (void)hipFree(p->d_rels);
-    if (p->d_tiles) (void)hipFree(p->d_tiles);
-    if (p->d_lvl_rel) (void)hipFree(p->d_lvl_rel);
-    if (p->d_lvl_begin) (void)hipFree(p->d_lvl_begin);
-    if (p->d_sweeps) (void)hipFree(p->d_sweeps);
-    if (p->d_S) (void)hipFree(p->d_S);
-    if (p->d_stats) (void)hipFree(p->d_stats);
+    dfq::dev_quiesce();                                  // nothing in flight may still use the blocks released below
+    if (p->d_rels) dfq::dev_free(p->d_rels);
+    if (p->d_tiles) dfq::dev_free(p->d_tiles);
+    if (p->d_lvl_rel) dfq::dev_free(p->d_lvl_rel);
+    if (p->d_lvl_begin) dfq::dev_free(p->d_lvl_begin);
+    if (p->d_sweeps) dfq::dev_free(p->d_sweeps);
+    if (p->d_S) dfq::dev_free(p->d_S);
+    if (p->d_stats) dfq::dev_free(p->d_stats);
     if (p->rebuild) dfq_rebuild_plan_destroy(p->rebuild);
     delete p;
 }
@@ -489,8 +490,8 @@ int dfq_le_lazy_plan_create(const dfq_layer* layers, int32_t n_layers, const int
     std::vector<dfq_rebuild_item> items;
     hipError_t e;
     auto fail_alloc = [&](hipError_t err) { dfq_le_lazy_plan_destroy(p); return fail_hip(err, "lazy le plan allocation", __FILE__, __LINE__); };
-    if ((e = hipMalloc((void**)&p->d_S, sizeof(float) * 2 * (size_t)ch)) != hipSuccess) return fail_alloc(e);
-    if ((e = hipMalloc((void**)&p->d_stats, sizeof(uint32_t) * 4 * (size_t)ch)) != hipSuccess) return fail_alloc(e);
+    if ((e = dfq::dev_malloc((void**)&p->d_S, sizeof(float) * 2 * (size_t)ch)) != hipSuccess) return fail_alloc(e);
+    if ((e = dfq::dev_malloc((void**)&p->d_stats, sizeof(uint32_t) * 4 * (size_t)ch)) != hipSuccess) return fail_alloc(e);
     float* dS = p->d_S;
     float* dInv = p->d_S + ch;
     for (int l = 0; l < n_layers; ++l) {
@@ -520,11 +521,11 @@ int dfq_le_lazy_plan_create(const dfq_layer* layers, int32_t n_layers, const int
     }
     int rc = dfq_rebuild_plan_create(items.data(), (int32_t)items.size(), &p->rebuild);
     if (rc) { dfq_le_lazy_plan_destroy(p); return rc; }
-    if ((e = hipMalloc((void**)&p->d_rels, sizeof(LzRel) * n_relations)) != hipSuccess) return fail_alloc(e);
-    if ((e = hipMalloc((void**)&p->d_tiles, sizeof(LzTile) * std::max<size_t>(1, tiles.size()))) != hipSuccess) return fail_alloc(e);
-    if ((e = hipMalloc((void**)&p->d_lvl_rel, sizeof(int32_t) * std::max<size_t>(1, lvl_rel.size()))) != hipSuccess) return fail_alloc(e);
-    if ((e = hipMalloc((void**)&p->d_lvl_begin, sizeof(int32_t) * std::max<size_t>(1, lvl_begin.size()))) != hipSuccess) return fail_alloc(e);
-    if ((e = hipMalloc((void**)&p->d_sweeps, sizeof(int32_t) * n_nets)) != hipSuccess) return fail_alloc(e);
+    if ((e = dfq::dev_malloc((void**)&p->d_rels, sizeof(LzRel) * n_relations)) != hipSuccess) return fail_alloc(e);
+    if ((e = dfq::dev_malloc((void**)&p->d_tiles, sizeof(LzTile) * std::max<size_t>(1, tiles.size()))) != hipSuccess) return fail_alloc(e);
+    if ((e = dfq::dev_malloc((void**)&p->d_lvl_rel, sizeof(int32_t) * std::max<size_t>(1, lvl_rel.size()))) != hipSuccess) return fail_alloc(e);
+    if ((e = dfq::dev_malloc((void**)&p->d_lvl_begin, sizeof(int32_t) * std::max<size_t>(1, lvl_begin.size()))) != hipSuccess) return fail_alloc(e);
+    if ((e = dfq::dev_malloc((void**)&p->d_sweeps, sizeof(int32_t) * n_nets)) != hipSuccess) return fail_alloc(e);
     if ((e = hipMemcpy(p->d_rels, h.data(), sizeof(LzRel) * n_relations, hipMemcpyHostToDevice)) != hipSuccess) return fail_alloc(e);
     if ((e = hipMemcpy(p->d_tiles, tiles.data(), sizeof(LzTile) * tiles.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail_alloc(e);
     if ((e = hipMemcpy(p->d_lvl_rel, lvl_rel.data(), sizeof(int32_t) * lvl_rel.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail_alloc(e);

@@ -1361,14 +1361,14 @@ namespace dfq {
 
 void le_resident_destroy(LeResident* r) {
     if (!r) return;
-    if (r->d_tiles) (void)hipFree(r->d_tiles);
-    if (r->d_rels) (void)hipFree(r->d_rels);
-    if (r->d_layer_diff) (void)hipFree(r->d_layer_diff);
-    if (r->d_stats) (void)hipFree(r->d_stats);
-    if (r->d_sync) (void)hipFree(r->d_sync);
-    if (r->d_partials) (void)hipFree(r->d_partials);
-    if (r->d_log) (void)hipFree(r->d_log);
-    if (r->d_ckpt) (void)hipFree(r->d_ckpt);
+    if (r->d_tiles) dfq::dev_free(r->d_tiles);
+    if (r->d_rels) dfq::dev_free(r->d_rels);
+    if (r->d_layer_diff) dfq::dev_free(r->d_layer_diff);
+    if (r->d_stats) dfq::dev_free(r->d_stats);
+    if (r->d_sync) dfq::dev_free(r->d_sync);
+    if (r->d_partials) dfq::dev_free(r->d_partials);
+    if (r->d_log) dfq::dev_free(r->d_log);
+    if (r->d_ckpt) dfq::dev_free(r->d_ckpt);
     delete r;
 }
 
@@ -1566,14 +1566,14 @@ LeResident* le_resident_create(const dfq_layer* layers, int n_layers, const dfq_
         r->ckpt_every = std::min(std::max(r->ckpt_every, std::max(1, r->spec)), 64);   // spec <= ckpt_every: two checkpoint buffers suffice
     }
     r->log_total = std::max<int64_t>(log_total, 64);
-    bool ok = hipMalloc((void**)&r->d_tiles, sizeof(ResTile) * tiles.size()) == hipSuccess &&
-              hipMalloc((void**)&r->d_rels, sizeof(ResRel) * n_relations) == hipSuccess &&
-              hipMalloc((void**)&r->d_layer_diff, sizeof(ResLayerDiff) * n_layers) == hipSuccess &&
-              hipMalloc((void**)&r->d_stats, sizeof(u64) * (size_t)r->stat_words) == hipSuccess &&
-              hipMalloc((void**)&r->d_sync, sizeof(u64) * r->sync_words) == hipSuccess &&
-              hipMalloc((void**)&r->d_partials, sizeof(double) * 2 * (size_t)(r->spec + 2) * tiles.size()) == hipSuccess &&
-              hipMalloc((void**)&r->d_log, sizeof(float) * (size_t)(r->ckpt_every + r->spec) * (size_t)r->log_total) == hipSuccess &&
-              hipMalloc((void**)&r->d_ckpt, sizeof(float) * 2 * tiles.size() * (size_t)kCkptFloats) == hipSuccess &&
+    bool ok = dfq::dev_malloc((void**)&r->d_tiles, sizeof(ResTile) * tiles.size()) == hipSuccess &&
+              dfq::dev_malloc((void**)&r->d_rels, sizeof(ResRel) * n_relations) == hipSuccess &&
+              dfq::dev_malloc((void**)&r->d_layer_diff, sizeof(ResLayerDiff) * n_layers) == hipSuccess &&
+              dfq::dev_malloc((void**)&r->d_stats, sizeof(u64) * (size_t)r->stat_words) == hipSuccess &&
+              dfq::dev_malloc((void**)&r->d_sync, sizeof(u64) * r->sync_words) == hipSuccess &&
+              dfq::dev_malloc((void**)&r->d_partials, sizeof(double) * 2 * (size_t)(r->spec + 2) * tiles.size()) == hipSuccess &&
+              dfq::dev_malloc((void**)&r->d_log, sizeof(float) * (size_t)(r->ckpt_every + r->spec) * (size_t)r->log_total) == hipSuccess &&
+              dfq::dev_malloc((void**)&r->d_ckpt, sizeof(float) * 2 * tiles.size() * (size_t)kCkptFloats) == hipSuccess &&
               hipMemcpy(r->d_tiles, tiles.data(), sizeof(ResTile) * tiles.size(), hipMemcpyHostToDevice) == hipSuccess &&
               hipMemcpy(r->d_rels, hr.data(), sizeof(ResRel) * n_relations, hipMemcpyHostToDevice) == hipSuccess &&
               hipMemcpy(r->d_layer_diff, ld.data(), sizeof(ResLayerDiff) * n_layers, hipMemcpyHostToDevice) == hipSuccess;

@@ -675,10 +675,10 @@ int dfq_quant_plan_create(const dfq_segment* segs, int32_t n_segs, dfq_quant_pla
     p->n_segs = n_segs;
     p->n_blocks = (int)blocks;
     hipError_t e;
-    if ((e = hipMalloc((void**)&p->d_segs, sizeof(SegDev) * n_segs)) != hipSuccess ||
-        (e = hipMalloc((void**)&p->d_block_begin, sizeof(int32_t) * (n_segs + 1))) != hipSuccess ||
-        (e = hipMalloc((void**)&p->d_slots, sizeof(uint32_t) * 2 * n_segs)) != hipSuccess ||
-        (e = hipMalloc((void**)&p->d_minmax, sizeof(float) * 2 * n_segs)) != hipSuccess ||
+    if ((e = dfq::dev_malloc((void**)&p->d_segs, sizeof(SegDev) * n_segs)) != hipSuccess ||
+        (e = dfq::dev_malloc((void**)&p->d_block_begin, sizeof(int32_t) * (n_segs + 1))) != hipSuccess ||
+        (e = dfq::dev_malloc((void**)&p->d_slots, sizeof(uint32_t) * 2 * n_segs)) != hipSuccess ||
+        (e = dfq::dev_malloc((void**)&p->d_minmax, sizeof(float) * 2 * n_segs)) != hipSuccess ||
         (e = hipMemcpy(p->d_segs, h.data(), sizeof(SegDev) * n_segs, hipMemcpyHostToDevice)) != hipSuccess ||
         (e = hipMemcpy(p->d_block_begin, bb.data(), sizeof(int32_t) * (n_segs + 1), hipMemcpyHostToDevice)) != hipSuccess) {
         dfq_quant_plan_destroy(p);
@@ -690,10 +690,11 @@ int dfq_quant_plan_create(const dfq_segment* segs, int32_t n_segs, dfq_quant_pla
 
 void dfq_quant_plan_destroy(dfq_quant_plan* p) {
     if (!p) return;
-    if (p->d_segs) (void)hipFree(p->d_segs);
-    if (p->d_block_begin) (void)hipFree(p->d_block_begin);
-    if (p->d_slots) (void)hipFree(p->d_slots);
-    if (p->d_minmax) (void)hipFree(p->d_minmax);
+    dfq::dev_quiesce();                                  // nothing in flight may still use the blocks released below
+    if (p->d_segs) dfq::dev_free(p->d_segs);
+    if (p->d_block_begin) dfq::dev_free(p->d_block_begin);
+    if (p->d_slots) dfq::dev_free(p->d_slots);
+    if (p->d_minmax) dfq::dev_free(p->d_minmax);
     delete p;
 }
 

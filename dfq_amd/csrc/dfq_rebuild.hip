@@ -125,8 +125,8 @@ int dfq_rebuild_plan_create(const dfq_rebuild_item* items, int32_t n_items, dfq_
     RebuildPlan* p = new RebuildPlan();
     p->n_blocks = (int)blocks.size();
     p->elements = total;
-    hipError_t e = hipMalloc((void**)&p->d_items, dev.size() * sizeof(RebuildItemDev));
-    if (e == hipSuccess) e = hipMalloc((void**)&p->d_blocks, blocks.size() * sizeof(RebuildBlock));
+    hipError_t e = dfq::dev_malloc((void**)&p->d_items, dev.size() * sizeof(RebuildItemDev));
+    if (e == hipSuccess) e = dfq::dev_malloc((void**)&p->d_blocks, blocks.size() * sizeof(RebuildBlock));
     if (e == hipSuccess) e = hipMemcpy(p->d_items, dev.data(), dev.size() * sizeof(RebuildItemDev), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(p->d_blocks, blocks.data(), blocks.size() * sizeof(RebuildBlock), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
@@ -140,8 +140,9 @@ int dfq_rebuild_plan_create(const dfq_rebuild_item* items, int32_t n_items, dfq_
 void dfq_rebuild_plan_destroy(dfq_rebuild_plan* plan) {
     RebuildPlan* p = (RebuildPlan*)plan;
     if (!p) return;
-    if (p->d_items) (void)hipFree(p->d_items);
-    if (p->d_blocks) (void)hipFree(p->d_blocks);
+    dfq::dev_quiesce();                                  // nothing in flight may still use the blocks released below
+    if (p->d_items) dfq::dev_free(p->d_items);
+    if (p->d_blocks) dfq::dev_free(p->d_blocks);
     delete p;
 }
 

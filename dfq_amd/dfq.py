@@ -62,8 +62,14 @@ class LEPlan:
         if isinstance(layers, _Tables):                     # prebuilt struct arrays (build_le_plan_batch's fast path)
             t = layers
             self._keep, self.scale_cum = t.keep, t.scale_cum
-            self.n_layers, self.n_relations, self.n_nets = t.n_layers, t.n_relations, t.n_nets
             self._plan = ctypes.c_void_p()
+            if t.bases is not None:                         # one network's tables + a base address per network (arena.py)
+                self.n_layers, self.n_relations, self.n_nets = t.n_layers * len(t.bases), t.n_relations * len(t.bases), len(t.bases)
+                _ffi.check(_ffi.lib().dfq_le_plan_create_replicated(
+                    t.ptr('layers', _ffi.DfqLayer), t.n_layers, t.ptr('relations', _ffi.DfqRelation), t.n_relations,
+                    t.bases.ctypes.data_as(ctypes.POINTER(ctypes.c_void_p)), len(t.bases), ctypes.byref(self._plan)))
+                return
+            self.n_layers, self.n_relations, self.n_nets = t.n_layers, t.n_relations, t.n_nets
             _ffi.check(_ffi.lib().dfq_le_plan_create_batch(t.ptr('layers', _ffi.DfqLayer), t.n_layers, t.ptr('layer_net', ctypes.c_int32),
                                                            t.n_nets, t.ptr('relations', _ffi.DfqRelation), t.n_relations,
                                                            ctypes.byref(self._plan)))
@@ -297,6 +303,7 @@ class _Tables:
         self.arrays = {}
         self.keep = []
         self.scale_cum = []
+        self.bases = None           # uint64 array: the tables describe the first of len(bases) networks (arena.py)
 
     def ptr(self, name, ctype):
         a = self.arrays[name]
@@ -799,7 +806,7 @@ _PLAN_ENV = ('DFQ_LE_RESIDENT', 'DFQ_LE_MERGED', 'DFQ_LE_TILE_ELEMS', 'DFQ_LE_RO
              'DFQ_RES_DIRECT', 'DFQ_RES_SHORT_RPT', 'DFQ_BC_TAGGED', 'DFQ_BC_MERGED', 'DFQ_BC_BLOCKS', 'DFQ_BC_EPS', 'DFQ_BC_FOLD',
              'DFQ_GRAPH', 'DFQ_COOPERATIVE', 'DFQ_HIP_LIB')
 # ... and the ones it reads on every RUN (they change no plan)
-_RUN_ENV = ('DFQ_SPIN_LIMIT', 'DFQ_TRACE_SWEEP')
+_RUN_ENV = ('DFQ_SPIN_LIMIT', 'DFQ_TRACE_SWEEP', 'DFQ_PLAN_TIMING', 'DFQ_POOL_MB')     # the last two: diagnostics / where a plan's tables are allocated
 
 
 def _env_key():
@@ -1003,6 +1010,14 @@ class BCPlan:
             self.n_steps = t.n_steps
             self.step_out_ch, self.step_in = t.step_out_ch, t.step_in
             self._plan = ctypes.c_void_p()
+            if t.bases is not None:                         # one network's tables + a base address per network (arena.py)
+                n = len(t.bases)
+                self.n_steps, self.step_out_ch, self.step_in = t.n_steps * n, t.step_out_ch * n, t.step_in * n
+                _ffi.check(_ffi.lib().dfq_bc_plan_create_replicated(
+                    t.ptr('layers', _ffi.DfqLayer), t.n_layers, t.ptr('steps', _ffi.DfqBcStep), t.n_steps,
+                    t.ptr('sources', _ffi.DfqBcSource), t.n_sources,
+                    t.bases.ctypes.data_as(ctypes.POINTER(ctypes.c_void_p)), n, ctypes.byref(self._plan)))
+                return
             _ffi.check(_ffi.lib().dfq_bc_plan_create(t.ptr('layers', _ffi.DfqLayer), t.n_layers, t.ptr('steps', _ffi.DfqBcStep), t.n_steps,
                                                      t.ptr('sources', _ffi.DfqBcSource), t.n_sources, ctypes.byref(self._plan)))
             return

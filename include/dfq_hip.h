@@ -112,6 +112,13 @@ int dfq_le_plan_create(const dfq_layer* layers, int32_t n_layers,
  * loop of the batch runs until every network has stopped. */
 int dfq_le_plan_create_batch(const dfq_layer* layers, int32_t n_layers, const int32_t* layer_net, int32_t n_nets,
                              const dfq_relation* relations, int32_t n_relations, dfq_le_plan** out_plan);
+/* Replicated form: `n_nets` networks of ONE architecture whose tensors lie at the same offsets from a per-network base
+ * address (a batch allocated as one arena with a fixed stride per network -- dfq_amd/arena.py).  `layers` / `relations`
+ * describe the FIRST network (its own addresses, indices relative to it); network n's tensors are those addresses moved by
+ * bases[n] - bases[0] bytes.  The host then builds one network's tables however large the batch is; everything else is as
+ * dfq_le_plan_create_batch.  (Replaces, for a batch, the per-network graph walk of dfq.py:78-82.) */
+int dfq_le_plan_create_replicated(const dfq_layer* layers, int32_t n_layers, const dfq_relation* relations, int32_t n_relations,
+                                  const void* const* bases, int32_t n_nets, dfq_le_plan** out_plan);
 void dfq_le_plan_destroy(dfq_le_plan* plan);
 int32_t dfq_le_plan_nets(const dfq_le_plan* plan);
 
@@ -341,6 +348,12 @@ int dfq_bc_plan_create(const dfq_layer* layers, int32_t n_layers,
                        const dfq_bc_step* steps, int32_t n_steps,
                        const dfq_bc_source* sources, int32_t n_sources,
                        dfq_bc_plan** out_plan);
+/* Replicated form (see dfq_le_plan_create_replicated): the three tables describe the FIRST of `n_nets` networks of one
+ * architecture (step.net = 0, indices relative to that network), network n's tensors lie bases[n] - bases[0] bytes further.
+ * (Replaces, for a batch, the per-network graph walk of dfq.py:194-270.) */
+int dfq_bc_plan_create_replicated(const dfq_layer* layers, int32_t n_layers, const dfq_bc_step* steps, int32_t n_steps,
+                                  const dfq_bc_source* sources, int32_t n_sources, const void* const* bases, int32_t n_nets,
+                                  dfq_bc_plan** out_plan);
 void dfq_bc_plan_destroy(dfq_bc_plan* plan);
 /* per-tensor min/max of all step layers (one launch) -> the sequential per-layer chain (one launch); a step forms
  * the quant-error row sums eps[o, i] = sum_k (Q(w) - w) of its rows (8 bit, dfq.py:216-219) in registers, straight from

@@ -1,0 +1,162 @@
+"""dfq_amd/arena.py: a batch of same-architecture networks in one allocation, plans from one network's tables + base addresses.
+
+The plans must be the plans the ordinary batched builders create over the same tensors: every network ends bit-identical to
+a plan of its own (sweep count included) and to the numpy oracle, and the models keep working on the re-pointed tensors."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from oracle import dfq_oracle as orc
+from oracle import graphspec
+from dfq_amd import arena, dfq, synthetic
+from dfq_amd.utils import layer_transform as lt
+from dfq_amd.utils import relation as rel
+
+DFQ_ERR_ARG = -1     # include/dfq_hip.h
+
+from common import TARG, assert_bitexact, npy, snapshot
+
+
+def _prepared(name, seed, device):
+    model, graph, bottoms = synthetic.build(name, seed=seed)
+    model.to(device)
+    lt.merge_batchnorm(model, graph, bottoms, TARG)
+    rels = rel.create_relation(graph, bottoms, TARG, delete_single=False)
+    return model, graph, bottoms, rels
+
+
+def _spec_state(spec):
+    out = {}
+    for i, node in enumerate(spec.nodes):
+        if getattr(node, 'weight', None) is not None and node.kind in ('conv', 'linear'):
+            out[i] = (node.weight.copy(), None if node.bias is None else node.bias.copy())
+    return out
+
+
+@pytest.mark.parametrize('name', ['tiny_mobile', 'tiny_res'])
+def test_batch_in_one_allocation_equals_separate_plans(engine, name):
+    seeds = [0, 1, 2, 3, 4]
+    nets = [_prepared(name, s, engine.device) for s in seeds]
+    twins = [_prepared(name, s, engine.device) for s in seeds]
+    x = torch.randn(2, 3, 32, 32, device=engine.device)
+    with torch.no_grad():
+        before = [m(x) for (m, _, _, _) in nets]
+    batch = arena.NetworkBatch([(g, b, r) for (_, g, b, r) in nets], TARG)
+    batch.check(thorough=True)
+    # the models run on the re-pointed tensors and give what they gave
+    with torch.no_grad():
+        for (m, _, _, _), y in zip(nets, before):
+            assert torch.equal(m(x), y)
+    lo = batch.storage.data_ptr()
+    for (_, g, _, rels) in nets:
+        for k, m in g.items():
+            if type(m) in TARG:
+                assert lo <= m.weight.data_ptr() < lo + 4 * batch.storage.numel()
+        for rr in rels:
+            assert lo <= rr.S.data_ptr() < lo + 4 * batch.storage.numel()
+    le = batch.le_plan()
+    assert le.n_nets == len(nets)
+    le.run()
+    results, done = le.query_all()
+    assert done
+    bc = batch.bc_plan()
+    bc.run(check=True)
+    for (m, g, b, rels), (m1, g1, b1, r1), res in zip(nets, twins, results):
+        p1 = dfq.build_le_plan(g1, r1, TARG)
+        res1 = p1.run()
+        assert res['sweeps'] == res1['sweeps']
+        for ra, sb in zip(rels, p1.scale_cum):
+            assert_bitexact(npy(ra.S), npy(sb), 'cumulative S')
+        p1.close()
+        dfq.bias_correction(g1, b1, TARG)
+        a, c = snapshot(g), snapshot(g1)
+        for k in c:
+            assert_bitexact(a[k], c[k], '{} {}'.format(name, k))
+    assert len(le.scale_cum) == sum(len(r) for (_, _, _, r) in nets)
+    le.close()
+    bc.close()
+    # a second pair of plans over the same batch (a later calibration pass) needs no new tables
+    le2, bc2 = batch.le_plan(), batch.bc_plan()
+    assert le2.n_nets == len(nets) and bc2.n_steps == bc.n_steps
+    le2.close()
+    bc2.close()
+
+
+def test_batch_against_the_oracle(engine):
+    nets, specs = [], []
+    for s in (0, 1, 2):
+        model, graph, bottoms = synthetic.build('tiny_mobile', seed=s)
+        model.to(engine.device)
+        spec = graphspec.from_torch(graph, bottoms, TARG)
+        lt.merge_batchnorm(model, graph, bottoms, TARG)
+        orc.merge_batchnorm(spec)
+        nets.append((graph, bottoms, rel.create_relation(graph, bottoms, TARG, delete_single=False)))
+        specs.append(spec)
+    batch = arena.NetworkBatch(nets, TARG)
+    le = batch.le_plan()
+    le.run()
+    results, _ = le.query_all()
+    for (graph, bottoms, rels), spec, res in zip(nets, specs, results):
+        n_o, S_o = orc.cross_layer_equalization(spec, orc.create_relation(spec))
+        assert res['sweeps'] == n_o
+        for r, s in zip(rels, S_o):
+            assert_bitexact(npy(r.get_scale_vec()), s)
+    le.close()
+
+
+def test_batch_refuses_what_it_cannot_lay_out(engine):
+    a = _prepared('tiny_mobile', 0, engine.device)
+    b = _prepared('tiny_res', 0, engine.device)
+    with pytest.raises(ValueError, match='one architecture'):
+        arena.NetworkBatch([a[1:], b[1:]], TARG)
+    with pytest.raises(ValueError, match='no networks'):
+        arena.NetworkBatch([], TARG)
+    c = _prepared('tiny_mobile', 1, engine.device)
+    first = next(m for m in c[1].values() if type(m) in TARG)
+    first.weight.data = first.weight.data.double()
+    with pytest.raises(ValueError, match='float32'):
+        arena.NetworkBatch([a[1:], c[1:]], TARG)
+
+
+def test_tensor_that_left_the_batch_is_noticed(engine):
+    nets = [_prepared('tiny_mobile', s, engine.device) for s in (0, 1)]
+    batch = arena.NetworkBatch([(g, b, r) for (_, g, b, r) in nets], TARG)
+    first = next(m for m in nets[1][1].values() if type(m) in TARG)
+    first.weight.data = first.weight.data.clone()
+    with pytest.raises(RuntimeError, match='no longer lives'):
+        batch.le_plan()
+    # a tensor in the middle: only the thorough check sees it
+    nets = [_prepared('tiny_mobile', s, engine.device) for s in (0, 1)]
+    batch = arena.NetworkBatch([(g, b, r) for (_, g, b, r) in nets], TARG)
+    mods = [m for m in nets[1][1].values() if type(m) in TARG]
+    mods[2].weight.data = mods[2].weight.data.clone()
+    batch.check()
+    with pytest.raises(RuntimeError, match='not where the batch put it'):
+        batch.check(thorough=True)
+
+
+def test_replicated_entry_points_reject_bad_arguments(engine):
+    import ctypes
+    from dfq_amd import _ffi
+    nets = [_prepared('tiny_mobile', s, engine.device) for s in (0, 1)]
+    batch = arena.NetworkBatch([(g, b, r) for (_, g, b, r) in nets], TARG)
+    t = batch._le
+    plan = ctypes.c_void_p()
+    bases = batch.bases.copy()
+    bases[1] = 0
+    rc = _ffi.lib().dfq_le_plan_create_replicated(t.ptr('layers', _ffi.DfqLayer), t.n_layers, t.ptr('relations', _ffi.DfqRelation),
+                                                 t.n_relations, bases.ctypes.data_as(ctypes.POINTER(ctypes.c_void_p)), 2, ctypes.byref(plan))
+    assert rc == DFQ_ERR_ARG and b'no base address' in _ffi.lib().dfq_last_error()
+    rc = _ffi.lib().dfq_le_plan_create_replicated(t.ptr('layers', _ffi.DfqLayer), t.n_layers, t.ptr('relations', _ffi.DfqRelation),
+                                                 t.n_relations, None, 2, ctypes.byref(plan))
+    assert rc == DFQ_ERR_ARG
+    b = batch._bc
+    steps = b.arrays['steps'].copy()
+    steps['net'][-1] = 1
+    rc = _ffi.lib().dfq_bc_plan_create_replicated(b.ptr('layers', _ffi.DfqLayer), b.n_layers, steps.ctypes.data_as(ctypes.POINTER(_ffi.DfqBcStep)),
+                                                 b.n_steps, b.ptr('sources', _ffi.DfqBcSource), b.n_sources,
+                                                 batch.bases.ctypes.data_as(ctypes.POINTER(ctypes.c_void_p)), 2, ctypes.byref(plan))
+    assert rc == DFQ_ERR_ARG and b'ONE network' in _ffi.lib().dfq_last_error()

@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 
 import bench
-from dfq_amd import _ffi, dfq
+from dfq_amd import _ffi, arena, dfq
 
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 dev = torch.device('cuda', 0)
@@ -32,4 +32,20 @@ for rep in range(5):
     t4 = time.perf_counter()
     print('LE tables %.2f ms, LE plan (C) %.2f ms, BC tables %.2f ms, BC plan (C) %.2f ms, total %.2f ms' %
           ((t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (t4 - t3) * 1e3, (t4 - t0) * 1e3))
+    le.close(); bc.close()
+
+# the same batch as ONE allocation (dfq_amd/arena.py): layout once, then plans from one network's tables + base addresses
+for rep in range(5):
+    nets = [copy.deepcopy(p) for p in protos]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    nb = arena.NetworkBatch([(g, b, r) for (_, g, b, r) in nets], bench.TARG)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    le = nb.le_plan()
+    t2 = time.perf_counter()
+    bc = nb.bc_plan()
+    t3 = time.perf_counter()
+    print('one allocation: layout %.2f ms (once per batch), LE plan %.2f ms, BC plan %.2f ms, plans %.2f ms' %
+          ((t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (t3 - t1) * 1e3))
     le.close(); bc.close()
