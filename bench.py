@@ -498,7 +498,8 @@ def pcie_inclusive_pass(net, reps=3):
     from dfq_amd import dfq, synthetic
     from dfq_amd.utils import layer_transform as lt
     from dfq_amd.utils import relation as rel
-    best = None
+    import dfq_amd
+    best, scoped = None, None
     for _ in range(reps):
         model, graph, bottoms = synthetic.build(net, seed=0)             # stays on the CPU
         with _stdout_to_stderr():
@@ -517,10 +518,27 @@ def pcie_inclusive_pass(net, reps=3):
                'bias_correction_ms': (t4 - t3) * 1e3, 'le_plus_bc_ms': (t4 - t2) * 1e3}
         if best is None or rec['le_plus_bc_ms'] < best['le_plus_bc_ms']:
             best = rec
+    # the same two calls inside `with dfq_amd.staging():` -- one transfer each way for the sequence, plans keyed on the scope's
+    # device copies (a service calibrating model after model of one architecture finds them in the plan cache)
+    for _ in range(reps + 1):
+        model, graph, bottoms = synthetic.build(net, seed=0)
+        with _stdout_to_stderr():
+            lt.merge_batchnorm(model, graph, bottoms, TARG)
+            rels = rel.create_relation(graph, bottoms, TARG, delete_single=False)
+            t2 = time.perf_counter()
+            with dfq_amd.staging():
+                dfq.cross_layer_equalization(graph, rels, TARG)
+                dfq.bias_correction(graph, bottoms, TARG)
+            _sync()
+            t4 = time.perf_counter()
+        scoped = (t4 - t2) * 1e3 if scoped is None else min(scoped, (t4 - t2) * 1e3)
     n_w = sum(m.weight.numel() for m in graph.values() if type(m) in TARG)
     best.update({'net': net, 'weights': n_w, 'weights_per_s': n_w / (best['le_plus_bc_ms'] * 1e-3),
+                 'le_plus_bc_in_one_staging_scope_ms': scoped,
                  'what': 'CPU-resident {}: cross_layer_equalization + bias_correction through the drop-in entry points, wall time '
-                         'incl. H2D / D2H of every tensor, plan building and synchronisation (best of {})'.format(net, reps)})
+                         'incl. H2D / D2H of every tensor, plan building and synchronisation (best of {}); '
+                         'le_plus_bc_in_one_staging_scope_ms: the same two calls inside `with dfq_amd.staging():` (one transfer each '
+                         'way, plans from the cache after the first model)'.format(net, reps)})
     return best
 
 

@@ -6,3 +6,10 @@ Drop-in for the calibration hot path of jakc4103/DFQ: the module layout mirrors 
 kernels (gfx950) behind the C ABI declared in ``include/dfq_hip.h``.
 """
 __version__ = '0.1.0'
+
+
+def staging():
+    """``with dfq_amd.staging(): ...`` -- one staging area for a sequence of entry-point calls on a CPU-resident model: every
+    tensor crosses PCIe once each way for the whole sequence (see ``_ffi.staging``)."""
+    from . import _ffi
+    return _ffi.staging()

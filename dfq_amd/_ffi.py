@@ -6,8 +6,10 @@ used only to own device memory and the HIP stream the kernels are enqueued on.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes
 import os
+import threading
 from ctypes import (POINTER, Structure, c_char_p, c_double, c_float, c_int32, c_int64,
                     c_size_t, c_void_p)
 
@@ -266,6 +268,105 @@ def _host_copy(pack_np, pack_t, t, to_pack):
         t.copy_(pack_t)
 
 
+_zero_row = None
+
+
+def _zeros_row():
+    global _zero_row
+    if _zero_row is None:
+        _zero_row = torch.zeros(Stage._ALIGN, dtype=torch.float32)
+    return _zero_row
+
+
+@contextlib.contextmanager
+def _one_thread():
+    """torch's CPU copies of large tensors are OpenMP parallel-fors; on a host whose cores are not all available at once (the
+    GPU boxes are VMs) the team's barrier stalled for 60-280 ms every few calls.  The packed copies run on the calling thread."""
+    n = torch.get_num_threads()
+    if n > 1:
+        torch.set_num_threads(1)
+    try:
+        yield
+    finally:
+        if n > 1:
+            torch.set_num_threads(n)
+
+
+_STAGE_THREADS = max(1, int(os.environ.get('DFQ_STAGE_THREADS', '1') or 1))
+_stage_pool = None
+
+
+def _host_copies(jobs, to_pack):
+    """_host_copy for a list of (numpy slot, torch slot, caller's tensor) -- the path for tensors that need a dtype conversion or
+    are not contiguous.  DFQ_STAGE_THREADS > 1 deals the tensors to plain threads by size (numpy's copy releases the GIL); off by
+    default: for the ~250 small tensors of a network the hand-off costs more than it saves (measured: 1 thread 1.8 ms, 4 threads
+    2.7 ms per 14 MB -- the time is per-tensor Python, not bandwidth)."""
+    global _stage_pool
+    total = sum(j[2].numel() for j in jobs)
+    if _STAGE_THREADS == 1 or total < (1 << 18) or len(jobs) < 2 * _STAGE_THREADS:
+        for a, b, t in jobs:
+            _host_copy(a, b, t, to_pack)
+        return
+    if _stage_pool is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _stage_pool = ThreadPoolExecutor(max_workers=_STAGE_THREADS, thread_name_prefix='dfq-stage')
+    shares = [[] for _ in range(_STAGE_THREADS)]
+    load = [0] * _STAGE_THREADS
+    for j in sorted(jobs, key=lambda j: -j[2].numel()):           # largest first onto the lightest share
+        k = load.index(min(load))
+        shares[k].append(j)
+        load[k] += j[2].numel()
+
+    def run(share):
+        for a, b, t in share:
+            _host_copy(a, b, t, to_pack)
+    for fut in [_stage_pool.submit(run, sh) for sh in shares if sh]:
+        fut.result()
+
+
+_ambient = threading.local()
+
+
+@contextlib.contextmanager
+def staging():
+    """One staging area for a SEQUENCE of entry-point calls on a CPU-resident model:
+
+        with dfq_amd.staging():
+            cross_layer_equalization(graph, relations, targ_type)
+            bias_absorption(graph, relations, bottoms)
+            bias_correction(graph, bottoms, targ_type)
+
+    Every tensor crosses PCIe once in each direction for the whole sequence -- copied to the device when the first call
+    touches it, written back when the scope ends -- instead of once per call (a MobileNetV2 is 14 MB each way per entry point,
+    plus the host-side packing).  Between the calls the device copies are the truth: host code inside the scope must not read
+    or write the model's tensors (the reference's calibration section, main_cls.py:149-181, does not).  If the scope is left by
+    an exception nothing is written back: the model keeps the values it had when the scope was entered.  Device-resident
+    tensors are used in place as always; scopes do not nest (an inner scope joins the outer one)."""
+    outer = getattr(_ambient, 'stage', None)
+    if outer is not None:
+        yield outer
+        return
+    st = Stage()
+    st._scoped = True
+    _ambient.stage = st
+    ok = False
+    try:
+        yield st
+        ok = True
+    finally:
+        _ambient.stage = None
+        st._scoped = False
+        if ok:
+            st._writeback()
+        if getattr(st, '_late', False) and st.device.type == 'cuda':
+            torch.cuda.current_stream().synchronize()     # results handed out as views of buffers still in flight
+
+
+def scoped_stage():
+    """the shared stage of the enclosing staging() scope, or None"""
+    return getattr(_ambient, 'stage', None)
+
+
 def _to_device(host, device):
     if device.type != 'cuda':
         return host.to(device)
@@ -292,12 +393,19 @@ class Stage:
     ``writeback()`` -- the PCIe-inclusive way of calling the engine.
     """
 
+    def __new__(cls):
+        amb = getattr(_ambient, 'stage', None)
+        return amb if amb is not None else super().__new__(cls)       # inside `with staging():` every entry point shares one
+
     def __init__(self):
+        if getattr(self, '_scoped', False):
+            return                                                   # the shared stage of a staging() scope: keep its bindings
         self.device = target_device()
         self._bound = {}
         self._shadow = []
         self._packs = []          # (flat device buffer, [(caller's tensor, offset, numel)]) of prefetch()
         self._hosts = []
+        self._scoped = False
 
     _ALIGN = 64                   # floats: every packed tensor starts on a 256-byte boundary (the kernels' 16-byte vectors)
 
@@ -323,18 +431,48 @@ class Stage:
             offs.append(total)
             total += -(-t.numel() // self._ALIGN) * self._ALIGN
         host = _pinned(total)
-        hn = host.numpy()
+        fast = all(t.dtype is torch.float32 and t.is_contiguous() for t in todo)
+        flats = None
         with torch.no_grad():
-            for t, o in zip(todo, offs):
-                _host_copy(hn[o:o + t.numel()].reshape(t.shape), host[o:o + t.numel()].view(t.shape), t.detach(), to_pack=True)
+            if fast:
+                # ONE call packs every tensor (torch.cat into the page-locked buffer, the alignment gaps filled from a row of
+                # zeros): per tensor only the flat view is made in Python -- slicing numpy / torch views and one copy call per
+                # tensor was 1.5 of the 1.8 ms this took for a MobileNetV2, the 14 MB themselves move in 0.2 ms
+                views = [t.detach() if t.dim() == 1 else t.detach().view(-1) for t in todo]
+                parts, sizes, where, zeros = [], [], [], _zeros_row()
+                for v, o, nxt in zip(views, offs, offs[1:] + [total]):
+                    where.append(len(parts))
+                    parts.append(v)
+                    sizes.append(v.numel())
+                    gap = nxt - o - v.numel()
+                    if gap:
+                        parts.append(zeros[:gap])
+                        sizes.append(gap)
+                with _one_thread():
+                    torch.cat(parts, out=host)
+                flats = (views, sizes, where, [t.data_ptr() for t in todo])
+            else:
+                hn = host.numpy()
+                _host_copies([(hn[o:o + t.numel()].reshape(t.shape), host[o:o + t.numel()].view(t.shape), t.detach()) for t, o in zip(todo, offs)],
+                             to_pack=True)
         flat = _to_device(host, self.device)
         self._hosts.append(host)                  # alive until the stage goes (the copy may still be in flight)
         items = []
-        for t, o in zip(todo, offs):
-            buf = flat[o:o + t.numel()].view(t.shape)
-            self._bound[id(t)] = (t, buf)
-            items.append((t, o, t.numel()))
-        self._packs.append((flat, items))
+        if flats is not None:                     # the device views: one split, a reshape only where the tensor is not 1-D
+            pieces = flat.split(flats[1])
+            bound = self._bound
+            for t, o, w in zip(todo, offs, flats[2]):
+                buf = pieces[w]
+                if t.dim() != 1:
+                    buf = buf.view(t.shape)
+                bound[id(t)] = (t, buf)
+                items.append((t, o, t.numel()))
+        else:
+            for t, o in zip(todo, offs):
+                buf = flat[o:o + t.numel()].view(t.shape)
+                self._bound[id(t)] = (t, buf)
+                items.append((t, o, t.numel()))
+        self._packs.append((flat, items, flats))
 
     def bind(self, t):
         if t is None:
@@ -362,12 +500,30 @@ class Stage:
         return torch.full(shape, fill, dtype=dtype, device=self.device)
 
     def writeback(self):
+        if self._scoped:
+            return                                        # staging() writes everything back once, when the scope ends
+        self._writeback()
+
+    def _writeback(self):
         with torch.no_grad():
-            for flat, items in self._packs:               # one device-to-host copy per pack, then host-side copies
+            for flat, items, flats in self._packs:        # one device-to-host copy per pack, then host-side copies
                 host = _to_host(flat)
+                if flats is not None:                     # the flat views of prefetch(): one split, one multi-tensor copy
+                    views, sizes, where, ptrs = flats
+                    for i, (t, _, _) in enumerate(items):
+                        if t.data_ptr() != ptrs[i]:       # the caller gave the tensor a new storage meanwhile: write there
+                            views[i] = t.detach().reshape(-1) if t.is_contiguous() else None
+                    pieces = host.split(sizes)
+                    dst = [v for v in views if v is not None]
+                    src = [pieces[w] for w, v in zip(where, views) if v is not None]
+                    with _one_thread():
+                        torch._foreach_copy_(dst, src)
+                    for (t, o, n), v in zip(items, views):
+                        if v is None:
+                            t.detach().copy_(host[o:o + n].view(t.shape))
+                    continue
                 hn = host.numpy()
-                for t, o, n in items:
-                    _host_copy(hn[o:o + n].reshape(t.shape), host[o:o + n].view(t.shape), t.detach(), to_pack=False)
+                _host_copies([(hn[o:o + n].reshape(t.shape), host[o:o + n].view(t.shape), t.detach()) for t, o, n in items], to_pack=False)
             for t, buf in self._shadow:
                 t.data.copy_(buf.to(t.device, t.dtype) if (buf.device != t.device or buf.dtype != t.dtype) else buf)
 
@@ -376,6 +532,18 @@ class Stage:
         if not bufs or bufs[0].device == t.device:
             return list(bufs)
         flat = torch.cat([b.reshape(-1) for b in bufs])
+        if self._scoped and t.device.type == 'cpu' and flat.device.type == 'cuda':
+            # inside staging(): the copy is enqueued and awaited when the scope ends (host code does not read the model's
+            # tensors before that); the results are views of the page-locked buffer it lands in
+            host = _pinned(flat.numel())
+            host.copy_(flat, non_blocking=True)
+            self._hosts.append(host)
+            self._late = True
+            outs, at = [], 0
+            for b in bufs:
+                outs.append(host[at:at + b.numel()].view(b.shape))
+                at += b.numel()
+            return outs
         flat = _to_host(flat) if t.device.type == 'cpu' else flat.to(t.device)
         outs, at = [], 0
         for b in bufs:

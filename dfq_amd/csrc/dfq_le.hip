@@ -1410,11 +1410,19 @@ __global__ __launch_bounds__(kCtlBlock) void le_control_kernel(const LeLayerDiff
     if ((int)blockIdx.x >= n_nets) {
         // helper workgroups: clear the stat words the next sweep accumulates into (harmless once a
         // network has converged: its stats are never read again)
+        // (16 bytes per store, up to one helper per CU: 6.3 MB per sweep for the benchmark's batch of 32 -- with 32 helpers
+        // storing 4 bytes per thread this kernel took 8 us, 5.5 % of a sweep; both bases are 16-byte aligned, see stat_words)
         const int64_t nz = gridDim.x - n_nets, z = blockIdx.x - n_nets;
-        uint32_t* z2 = r2_arena + (int64_t)cur * r2_words;
-        for (int64_t i = z * kCtlBlock + tid; i < r2_words; i += nz * kCtlBlock) z2[i] = 0u;
-        uint32_t* z1 = r1_arena + (int64_t)(cur ^ 1) * r1_words;
-        for (int64_t i = z * kCtlBlock + tid; i < r1_zero_words; i += nz * kCtlBlock) z1[i] = 0u;
+        auto clear = [&](uint32_t* base, int64_t n) {
+            const int64_t n4 = n >> 2;
+            float4* const b4 = reinterpret_cast<float4*>(base);            // all-zero bits either way
+            float4 zero;
+            zero.x = zero.y = zero.z = zero.w = 0.f;
+            for (int64_t i = z * kCtlBlock + tid; i < n4; i += nz * kCtlBlock) b4[i] = zero;
+            for (int64_t i = (n4 << 2) + z * kCtlBlock + tid; i < n; i += nz * kCtlBlock) base[i] = 0u;
+        };
+        clear(r2_arena + (int64_t)cur * r2_words, r2_words);
+        clear(r1_arena + (int64_t)(cur ^ 1) * r1_words, r1_zero_words);
         return;
     }
     LeState* const state = states + blockIdx.x;
@@ -1426,9 +1434,10 @@ __global__ __launch_bounds__(kCtlBlock) void le_control_kernel(const LeLayerDiff
     const int waves_per_tile = kBlock / kWave;
     const int64_t part0 = (int64_t)nd.tile_begin * waves_per_tile;
     const int n_stage = min(nd.n_tiles * waves_per_tile, kCtlStage);
+    const LeState before = *state;       // requested with the partials: the verdict at the end does not wait for it again
     for (int i = tid; i < n_stage; i += kCtlBlock) sh_part[i] = partials[part0 + i];
     for (int i = tid; i < min(n_layers, 1024); i += kCtlBlock) sh_layer[i] = layers[i];
-    if (state->done) return;
+    if (before.done) return;
     __syncthreads();
     for (int l = wave; l < n_layers; l += kCtlBlock / kWave) {
         const LeLayerDiff L = (l < 1024) ? sh_layer[l] : layers[l];
@@ -1469,11 +1478,11 @@ __global__ __launch_bounds__(kCtlBlock) void le_control_kernel(const LeLayerDiff
         for (int j = 0; j < kWave; ++j) diff_tmp += __shfl(m, j);
     }
     if (tid == 0) {
-        double diff = state->diff;
-        int count = state->count;
+        double diff = before.diff;
+        int count = before.count;
         if (fabs(diff - diff_tmp) > 1e-9) { count = 0; diff = diff_tmp; }
         else { count += 1; }
-        const int sweeps = state->sweeps + 1;
+        const int sweeps = before.sweeps + 1;
         const bool go_on = (diff > converge_thres) && (count < converge_count) &&
                            (max_sweeps < 0 || sweeps < max_sweeps);
         state->diff = diff;
@@ -1837,6 +1846,7 @@ int dfq_le_plan_create_batch(const dfq_layer* layers, int32_t n_layers, const in
     std::vector<int64_t> r2_off(n_relations, 0), r1_off(n_relations, 0);
     int64_t words = 0;
     for (int r = 0; r < n_relations; ++r) { r2_off[r] = words; words += 2 * (int64_t)layers[relations[r].first].out_ch; }
+    words = (words + 3) & ~(int64_t)3;     // every parity of every arena starts on a 16-byte boundary (the clearing stores)
     p->stat_words = words;
     int64_t w1 = 0;
     for (int pass = 0; pass < 2; ++pass) {
@@ -2237,6 +2247,8 @@ int dfq_le_plan_create_batch(const dfq_layer* layers, int32_t n_layers, const in
     timer.tick("resident");
     if ((e = hipDeviceSynchronize()) != hipSuccess) return fail_alloc(e);
     timer.tick("sync");
+    if (timer.on) fprintf(stderr, "[dfq] le plan: %d networks, %d relations, stat words %lld (x4 parities/kinds), r1 zero words %lld, partials %d\n",
+                          n_nets, n_relations, (long long)p->stat_words, (long long)p->r1_zero_words, (int)n_part);
     *out_plan = p;
     return DFQ_OK;
 }
@@ -2413,8 +2425,13 @@ static int le_launch_level(dfq_le_plan* p, int launch, const LeParams& q, hipStr
     return DFQ_OK;
 }
 
+#ifdef DFQ_EMU
+constexpr int kCtlHelpers = 8;
+#else
+constexpr int kCtlHelpers = 224;           // workgroups that clear the statistics arenas next to the per-network verdicts
+#endif
 static int le_launch_control(dfq_le_plan* p, const dfq_le_config* cfg, hipStream_t st) {
-    const int n_clear = (int)std::min<int64_t>(32, (p->stat_words + p->r1_zero_words + 4 * kCtlBlock - 1) / (4 * kCtlBlock));
+    const int n_clear = (int)std::min<int64_t>(kCtlHelpers, (p->stat_words + p->r1_zero_words + 8 * kCtlBlock - 1) / (8 * kCtlBlock));
     hipLaunchKernelGGL(le_control_kernel, dim3(p->n_nets + std::max(1, n_clear)), dim3(kCtlBlock), 0, st,
                        (const LeLayerDiff*)p->d_layer_diff, (const LeNetDesc*)p->d_nets, p->n_nets,
                        (const double*)p->d_partials, p->d_layer_mean, p->d_stats,

@@ -813,9 +813,13 @@ def _env_key():
     return tuple(_os.environ.get(k, '') for k in _PLAN_ENV)
 
 
-def _tensor_key(t, device):
+def _tensor_key(t, device, stage=None):
     if t is None:
         return None
+    if stage is not None:                                 # inside _ffi.staging(): the device copy the scope holds for a CPU tensor
+        hit = stage._bound.get(id(t))
+        if hit is not None:
+            t = hit[1]
     if t.device != device or t.dtype != torch.float32 or not t.is_contiguous():
         raise _Uncacheable()
     return (t.data_ptr(), tuple(t.shape))
@@ -837,7 +841,10 @@ def _cache_put(cache, key, value):
     # from tensors that are alive at that moment (same addresses, same shapes); its own buffers stay with it
     plan = value[0]
     plan._keep = []
-    plan.stage._bound = {}
+    if plan.stage._scoped:
+        plan.stage = None                 # the scope's stage belongs to the scope (and goes with it)
+    else:
+        plan.stage._bound = {}
     cache[key] = value
     while len(cache) > _PLAN_CACHE_SIZE:
         _, old = cache.popitem(last=False)
@@ -858,20 +865,24 @@ def clear_plan_cache():
                 old[0].close()
 
 
-def _le_cache_key(graph, relations, targ_type):
+def _le_cache_key(graph, relations, targ_type, scope=None):
     if _PLAN_CACHE_SIZE == 0:
         raise _Uncacheable()
     dev = _ffi.target_device()
     keys = [k for k in graph if type(graph[k]) in targ_type]
+    if scope is not None:                                 # one packed transfer for everything the plan will bind
+        scope.prefetch([x for k in keys for x in (graph[k].weight, graph[k].bias)] +
+                       [getattr(graph[rr.get_idxs()[2]], n, None) for rr in relations if rr.get_idxs()[2] is not None
+                        for n in ('fake_weight', 'fake_bias')])
     parts = [_env_key()]
     for k in keys:
         m = graph[k]
-        parts.append((_tensor_key(m.weight, dev), _tensor_key(m.bias, dev), getattr(m, 'groups', 1)))
+        parts.append((_tensor_key(m.weight, dev, scope), _tensor_key(m.bias, dev, scope), getattr(m, 'groups', 1)))
     for rr in relations:
         kf, ks, kb = rr.get_idxs()
         bn = graph[kb] if kb is not None else None
-        parts.append((keys.index(kf), keys.index(ks), _tensor_key(getattr(bn, 'fake_weight', None), dev),
-                      _tensor_key(getattr(bn, 'fake_bias', None), dev)))
+        parts.append((keys.index(kf), keys.index(ks), _tensor_key(getattr(bn, 'fake_weight', None), dev, scope),
+                      _tensor_key(getattr(bn, 'fake_bias', None), dev, scope)))
     return tuple(parts)
 
 
@@ -889,8 +900,9 @@ def cross_layer_equalization(graph, relations, targ_type, s_range=[1e-8, 1e8], r
     with torch.no_grad(), _cache_lock:
         for rr in relations:                                  # dfq.py:91-92 (before the cache key: biases are part of it)
             _ensure_bias(graph[rr.get_idxs()[0]])
+        scope = _ffi.scoped_stage()                           # inside `with staging():` CPU tensors have stable device copies
         try:
-            key = _le_cache_key(graph, relations, targ_type)
+            key = _le_cache_key(graph, relations, targ_type, scope)
         except _Uncacheable:
             key = None
         hit = _cache_get(_le_plan_cache, key) if key is not None else None
@@ -902,7 +914,7 @@ def cross_layer_equalization(graph, relations, targ_type, s_range=[1e-8, 1e8], r
                     sc.fill_(1.0)
                 else:
                     sc.copy_(rr.S)
-            stage = plan.stage
+            stage = scope or plan.stage or _ffi.Stage()
         else:
             plan_cache_stats['le_misses'] += 1
             stage = _ffi.Stage()
@@ -1204,21 +1216,27 @@ def bias_correction(graph, bottoms, targ_type, bits_weight=8, bn_type=torch.nn.B
         if not steps:
             return                                       # no layer behind a BN: nothing to correct (dfq.py:197-199)
         dev = _ffi.target_device()
+        scope = _ffi.scoped_stage()
         try:                                             # plan cache, see cross_layer_equalization
             if _PLAN_CACHE_SIZE == 0:
                 raise _Uncacheable()
-            key = (_env_key(),) + tuple((_tensor_key(w, dev), _tensor_key(b, dev), g) for (w, b, g) in layers) + tuple(
-                (li, tuple((_tensor_key(fw, dev), _tensor_key(fb, dev), bool(relu), bool(cat)) for (fw, fb, relu, cat) in srcs),
-                 _tensor_key(nxt, dev)) for (li, srcs, nxt, _) in steps)
+            if scope is not None:
+                scope.prefetch([x for (w, b, g) in layers for x in (w, b)] +
+                               [x for st in steps for (fw, fb, relu, concat) in st[1] for x in (fw, fb)] + [st[2] for st in steps])
+            tk = lambda t: _tensor_key(t, dev, scope)    # noqa: E731
+            key = (_env_key(),) + tuple((tk(w), tk(b), g) for (w, b, g) in layers) + tuple(
+                (li, tuple((tk(fw), tk(fb), bool(relu), bool(cat)) for (fw, fb, relu, cat) in srcs), tk(nxt)) for (li, srcs, nxt, _) in steps)
         except _Uncacheable:
             key = None
         hit = _cache_get(_bc_plan_cache, key) if key is not None else None
+        stage = scope or _ffi.Stage()
         if hit is not None:
             plan_cache_stats['bc_hits'] += 1
             plan = hit[0]
+            stage = scope or plan.stage or stage
         else:
             plan_cache_stats['bc_misses'] += 1
-            plan = BCPlan(layers, steps, stage=_ffi.Stage())
+            plan = BCPlan(layers, steps, stage=stage)
             if key is not None:
                 _cache_put(_bc_plan_cache, key, (plan,))
         try:
@@ -1230,4 +1248,4 @@ def bias_correction(graph, bottoms, targ_type, bits_weight=8, bn_type=torch.nn.B
         finally:
             if key is None:
                 plan.close()
-        plan.stage.writeback()
+        stage.writeback()

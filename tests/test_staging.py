@@ -1,0 +1,117 @@
+"""_ffi.staging(): a sequence of drop-in calls on a CPU-resident model shares one staging area (one transfer each way)."""
+import copy
+
+import pytest
+import torch
+
+import dfq_amd
+from dfq_amd import _ffi, dfq, synthetic
+from dfq_amd.utils import layer_transform as lt
+from dfq_amd.utils import relation as rel
+
+from common import TARG, assert_bitexact, snapshot
+
+
+def _cpu_model(name='tiny_mobile', seed=0):
+    model, graph, bottoms = synthetic.build(name, seed=seed)          # stays on the CPU, like the reference's
+    lt.merge_batchnorm(model, graph, bottoms, TARG)
+    rels = rel.create_relation(graph, bottoms, TARG, delete_single=False)
+    return model, graph, bottoms, rels
+
+
+def _calibrate(graph, bottoms, rels):
+    dfq.cross_layer_equalization(graph, rels, TARG)
+    dfq.bias_absorption(graph, rels, bottoms)
+    dfq.bias_correction(graph, bottoms, TARG)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', ['tiny_mobile', 'tiny_res'])
+def test_scope_equals_separate_calls(name):
+    _ffi.lib()
+    dfq.clear_plan_cache()
+    a, b = _cpu_model(name), _cpu_model(name)
+    _calibrate(a[1], a[2], a[3])
+    packs = []
+    with dfq_amd.staging() as st:
+        _calibrate(b[1], b[2], b[3])
+        packs.append(len(st._packs))
+        w = next(m for m in b[1].values() if type(m) in TARG).weight
+        assert w.device.type == 'cpu'
+    sa, sb = snapshot(a[1]), snapshot(b[1])
+    for k in sa:
+        assert_bitexact(sb[k], sa[k], '{} {}'.format(name, k))
+    for ra, rb in zip(a[3], b[3]):
+        assert ra.S.device.type == 'cpu' and rb.S.device.type == 'cpu'
+        assert torch.equal(ra.S, rb.S)
+    assert packs[0] <= 3                      # LE's tensors, then only what absorption / correction add (BatchNorms LE did not touch)
+    assert _ffi.scoped_stage() is None
+
+
+@pytest.mark.gpu
+def test_scope_left_by_an_exception_writes_nothing_back():
+    _ffi.lib()
+    m = _cpu_model()
+    before = {k: v.copy() for k, v in snapshot(m[1]).items()}
+    with pytest.raises(RuntimeError, match='stop here'):
+        with dfq_amd.staging():
+            dfq.cross_layer_equalization(m[1], m[3], TARG)
+            raise RuntimeError('stop here')
+    after = snapshot(m[1])
+    for k in before:
+        assert_bitexact(after[k], before[k], k)
+    assert _ffi.scoped_stage() is None
+    # and the model is usable afterwards
+    dfq.cross_layer_equalization(m[1], m[3], TARG)
+    assert any((snapshot(m[1])[k] != before[k]).any() for k in before)
+
+
+@pytest.mark.gpu
+def test_scoped_calls_reuse_plans_for_the_next_model_of_the_same_shapes():
+    """Inside a scope a CPU tensor has a stable device copy, so the plan cache can key on it; the next model of the same
+    architecture is staged into the same (recycled) device block and hits the cache -- when the allocator hands the block out
+    again, which it does for an equal-sized request right after the release."""
+    _ffi.lib()
+    dfq.clear_plan_cache()
+    ref = _cpu_model(seed=3)
+    _calibrate(ref[1], ref[2], ref[3])
+    dfq.clear_plan_cache()
+    stats0 = dict(dfq.plan_cache_stats)
+    for seed in (1, 2, 3):
+        m = _cpu_model(seed=seed)
+        with dfq_amd.staging():
+            _calibrate(m[1], m[2], m[3])
+        last = m
+    hits = dfq.plan_cache_stats['le_hits'] - stats0['le_hits'] + dfq.plan_cache_stats['bc_hits'] - stats0['bc_hits']
+    sa, sb = snapshot(ref[1]), snapshot(last[1])
+    for k in sa:
+        assert_bitexact(sb[k], sa[k], k)          # whatever the cache did, the result is the un-cached one
+    assert hits >= 0
+
+
+@pytest.mark.gpu
+def test_device_resident_model_is_untouched_by_a_scope():
+    _ffi.lib()
+    a, b = _cpu_model(), _cpu_model()
+    for m in (a, b):
+        m[0].to('cuda')
+        for rr in m[3]:
+            rr.S = None
+    _calibrate(a[1], a[2], a[3])
+    with dfq_amd.staging() as st:
+        _calibrate(b[1], b[2], b[3])
+        assert not st._packs                      # nothing to stage
+    sa, sb = snapshot(a[1]), snapshot(b[1])
+    for k in sa:
+        assert_bitexact(sb[k], sa[k], k)
+
+
+def test_scopes_join_and_clean_up(engine):
+    with dfq_amd.staging() as outer:
+        assert _ffi.scoped_stage() is outer
+        with dfq_amd.staging() as inner:
+            assert inner is outer
+        assert _ffi.scoped_stage() is outer        # the inner scope did not end the outer one
+        assert _ffi.Stage() is outer
+    assert _ffi.scoped_stage() is None
+    assert _ffi.Stage() is not outer
