@@ -2459,6 +2459,9 @@ static int le_enqueue_direct(dfq_le_plan* p, const dfq_le_config* cfg, int n_swe
             if ((rc = le_launch_level(p, l, q, st))) return rc;
         if ((rc = le_launch_control(p, cfg, st))) return rc;
     }
+    // the write-back of the deferred stores waits for nobody: it runs outside the guard, next to the first sweeps of a batch
+    // another stream has in flight
+    guard.reset();
     return le_flush(p, st);
 }
 
