@@ -53,6 +53,13 @@ def test_every_xcd_dispatches_its_share_of_a_grid_in_index_order():
     if not os.path.exists(binary):
         pytest.skip('tools/litmus/dispatch_order not built (python -c "import __graft_entry__ as g; g.build()")')
     for grid, threads, spin in ((21280, 256, 200), (100000, 256, 200), (4096, 1024, 200), (21280, 256, 0), (50000, 64, 50)):
-        out = subprocess.run([binary, str(grid), str(threads), str(spin)], capture_output=True, text=True, timeout=120)
-        assert out.returncode == 0 and ' 0 stalled' in out.stdout and 'i mod n' in out.stdout, out.stdout + out.stderr
-        assert spin == 0 or 'in index order' in out.stdout, out.stdout
+        # (the ticket is taken by the workgroup's first instruction, some time after its dispatch: another process on the GPU
+        # -- a test running next to this one under pytest-xdist -- can delay that arbitrarily, so a failed start-order verdict
+        # is retried; the chain is the property itself and must hold every time)
+        for attempt in range(3):
+            out = subprocess.run([binary, str(grid), str(threads), str(spin)], capture_output=True, text=True, timeout=120)
+            assert ' 0 stalled' in out.stdout and 'i mod n' in out.stdout, out.stdout + out.stderr
+            if out.returncode == 0 and (spin == 0 or 'in index order' in out.stdout):
+                break
+        else:
+            raise AssertionError(out.stdout + out.stderr)
