@@ -354,14 +354,14 @@ def _random_pair(rng):
 
 @pytest.mark.parametrize('le_engine,boot_work', [('resident', None), ('streaming', None), ('streaming', 50)])
 def test_layer_equalization_random_geometries(engine, monkeypatch, le_engine, boot_work):
-    """Random pairings (60 per engine on the GPU; 10, or 4 for the resident launch, on the CPU emulation, which is slow) -- odd sizes, rows shorter than a vector and longer than a wave of vectors, fewer
+    """Random pairings (60 per engine on the GPU; 10, or 2 for the resident launch, on the CPU emulation, which is slow) -- odd sizes, rows shorter than a vector and longer than a wave of vectors, fewer
     channels than a bootstrap block and several blocks, slices of a block shared by several workgroups -- bit-exact against
     the oracle, three sweeps each (the second and third use the statistics the first one forwarded)."""
     _select_le_engine(monkeypatch, le_engine)
     if boot_work:
         monkeypatch.setenv('DFQ_LE_BOOT_WORK', str(boot_work))
     rng = np.random.default_rng(20260926)
-    for case in range(60 if engine.device.type == 'cuda' else (4 if le_engine == 'resident' else 10)):
+    for case in range(60 if engine.device.type == 'cuda' else (2 if le_engine == 'resident' else 10)):
         s1, s2 = _random_pair(rng)
         signed = bool(rng.integers(0, 2))
         w1 = rng.standard_normal(s1).astype(F32)
