@@ -1528,35 +1528,53 @@ __global__ void le_prepare_kernel(ClearArgs a, LeState* states, int n_nets, doub
 
 // Deferred stores: apply the factors still pending for a network (sweeps % depth of them) to its one-way-scaled layers.
 // One workgroup per span of kFlushSpan elements of one layer; workgroups of networks with nothing pending leave at once.
-constexpr int kFlushSpan = 4096;
-struct LeFlushRef {
-    int32_t rel;       // index into the level-sorted descriptor table
-    int32_t side;      // 0: W1 (rows by s), 1: W2 (columns by 1/s)
-    int64_t first;     // first element of the span
-    int32_t row0;      // its row and its position in that row (first = row0 * row_len + pos0)
+// A span's reference is self-contained (64 bytes, fetched with ONE wave-wide load and broadcast with v_readlane): the first
+// version went span -> relation descriptor (fields fetched piecemeal) -> loop state -> data, three dependent round trips before
+// the first element was requested, with four vectors per thread in flight: 258 us for the 516 MB of a batch of 32 (2 TB/s).
+constexpr int kFlushSpan = 8192;
+struct alignas(64) LeFlushRef {
+    float* w;            // first element of the span
+    const float* hold;   // remembered factors of this side: factor j of channel c is hold[2 j o1 + c]
+    int32_t span;        // elements
+    int32_t row_len;     // of the layer
+    int32_t row0;        // row and position in that row of the first element
     int32_t pos0;
+    int32_t side;        // 0: W1 (rows by s), 1: W2 (columns by 1/s)
+    int32_t net;
+    int32_t go, gi, khkw, o1;
+    int32_t vec;         // 1: the span is made of aligned 16-byte vectors that never cross a row
+    int32_t pad;
 };
-__global__ __launch_bounds__(kBlock) void le_flush_kernel(const LeRelDev* __restrict__ table, const LeFlushRef* __restrict__ refs,
-                                                          const LeState* __restrict__ state, int depth) {
-    const LeFlushRef ref = refs[blockIdx.x];
-    const LeRelDev& R = table[ref.rel];
-    const int pend = state[R.net].sweeps & (depth - 1);
+static_assert(sizeof(LeFlushRef) == 64, "one span reference per 64-byte line");
+__global__ __launch_bounds__(kBlock) void le_flush_kernel(const LeFlushRef* __restrict__ refs, const LeState* __restrict__ state, int depth) {
+    const int lane = threadIdx.x % kWave;
+    const uint32_t word = fetch_words(refs + blockIdx.x, 16, lane);
+    LeFlushRef ref;
+    {
+        const uint64_t w_lo = (uint32_t)__builtin_amdgcn_readlane(word, 0), w_hi = (uint32_t)__builtin_amdgcn_readlane(word, 1);
+        const uint64_t h_lo = (uint32_t)__builtin_amdgcn_readlane(word, 2), h_hi = (uint32_t)__builtin_amdgcn_readlane(word, 3);
+        ref.w = (float*)(uintptr_t)(w_lo | (w_hi << 32));
+        ref.hold = (const float*)(uintptr_t)(h_lo | (h_hi << 32));
+        ref.span = __builtin_amdgcn_readlane(word, 4); ref.row_len = __builtin_amdgcn_readlane(word, 5);
+        ref.row0 = __builtin_amdgcn_readlane(word, 6); ref.pos0 = __builtin_amdgcn_readlane(word, 7);
+        ref.side = __builtin_amdgcn_readlane(word, 8); ref.net = __builtin_amdgcn_readlane(word, 9);
+        ref.go = __builtin_amdgcn_readlane(word, 10); ref.gi = __builtin_amdgcn_readlane(word, 11);
+        ref.khkw = __builtin_amdgcn_readlane(word, 12); ref.o1 = __builtin_amdgcn_readlane(word, 13);
+        ref.vec = __builtin_amdgcn_readlane(word, 14);
+    }
+    const int pend = state[ref.net].sweeps & (depth - 1);
     if (pend == 0) return;
-    const int side = ref.side;
-    gfloat* const w = (gfloat*)(side == 0 ? R.w1 : R.w2) + ref.first;
-    const int row_len = side == 0 ? R.row_len : R.i2g * R.khkw;
-    const int64_t n = (int64_t)(side == 0 ? R.o1 : R.o2) * row_len;
-    const int span = (int)((ref.first + kFlushSpan < n) ? kFlushSpan : n - ref.first);
-    const float* const hold = R.hold + (int64_t)side * R.o1;          // factor j of channel c: hold[2 j o1 + c]
+    const int side = ref.side, row_len = ref.row_len, span = ref.span;
+    gfloat* const w = (gfloat*)ref.w;
+    const float* const hold = ref.hold;
     // channel of the element `off` floats into the span (off < kFlushSpan, positions < 2^20: small_div is exact)
     auto channel = [&](int off) {
         const int p = ref.pos0 + off;
         const int dr = small_div(p, row_len);
         const int o = ref.row0 + dr;
-        return side == 0 ? o : small_div(o, R.go) * R.gi + small_div(p - dr * row_len, R.khkw);
+        return side == 0 ? o : small_div(o, ref.go) * ref.gi + small_div(p - dr * row_len, ref.khkw);
     };
-    const bool vec = ((row_len & 3) == 0) && (((uintptr_t)w & 15) == 0);
-    if (vec) {
+    if (ref.vec) {
         constexpr int NV = kFlushSpan / (4 * kBlock);                 // vectors per thread, all requested before the first use
         fvec4 x[NV];
         int off[NV];
@@ -1568,13 +1586,28 @@ __global__ __launch_bounds__(kBlock) void le_flush_kernel(const LeRelDev* __rest
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
             if (off[k] >= span) continue;
-            int c[4];
-            if (side == 0) { c[0] = c[1] = c[2] = c[3] = channel(off[k]); }     // a vector never crosses a row
-            else { c[0] = channel(off[k]); c[1] = channel(off[k] + 1); c[2] = channel(off[k] + 2); c[3] = channel(off[k] + 3); }
-            for (int j = 0; j < pend; ++j) {
-                const float* h = hold + (int64_t)(2 * j) * R.o1;
+            // the factors of a vector's four elements: ONE load per pending sweep when they share a channel (rows by s: a
+            // vector never crosses a row) or sit on consecutive channels (columns of a 1x1 layer, 16-byte aligned), four
+            // otherwise -- as four gathers per vector and sweep this loop kept the address units busier than the data did
+            const int c0 = channel(off[k]);
+            if (side == 0) {
+                for (int j = 0; j < pend; ++j) {
+                    const float hj = hold[(int64_t)(2 * j) * ref.o1 + c0];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) x[k][e] = x[k][e] * h[c[e]];
+                    for (int e = 0; e < 4; ++e) x[k][e] = x[k][e] * hj;
+                }
+            } else if (ref.khkw == 1 && (((uintptr_t)(hold + c0)) & 15) == 0 && ((2 * ref.o1) & 3) == 0) {
+                for (int j = 0; j < pend; ++j) {
+                    const fvec4 hj = *(const fvec4*)(hold + (int64_t)(2 * j) * ref.o1 + c0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) x[k][e] = x[k][e] * hj[e];
+                }
+            } else {
+                const int c1 = channel(off[k] + 1), c2 = channel(off[k] + 2), c3 = channel(off[k] + 3);
+                for (int j = 0; j < pend; ++j) {
+                    const float* h = hold + (int64_t)(2 * j) * ref.o1;
+                    x[k][0] = x[k][0] * h[c0]; x[k][1] = x[k][1] * h[c1]; x[k][2] = x[k][2] * h[c2]; x[k][3] = x[k][3] * h[c3];
+                }
             }
             DFQ_NT_STORE(x[k], (gfvec4*)(w + off[k]));
         }
@@ -1582,7 +1615,7 @@ __global__ __launch_bounds__(kBlock) void le_flush_kernel(const LeRelDev* __rest
         for (int off = (int)threadIdx.x; off < span; off += kBlock) {
             const int c = channel(off);
             float x = w[off];
-            for (int j = 0; j < pend; ++j) x = x * hold[(int64_t)(2 * j) * R.o1 + c];
+            for (int j = 0; j < pend; ++j) x = x * hold[(int64_t)(2 * j) * ref.o1 + c];
             w[off] = x;
         }
     }
@@ -2182,7 +2215,20 @@ int dfq_le_plan_create_batch(const dfq_layer* layers, int32_t n_layers, const in
                     if (!(d.defer & (1 << side))) continue;
                     const int64_t n = side == 0 ? (int64_t)d.o1 * d.row_len : (int64_t)d.o2 * d.i2g * d.khkw;
                     const int64_t rl = side == 0 ? d.row_len : (int64_t)d.i2g * d.khkw;
-                    for (int64_t f = 0; f < n; f += kFlushSpan) refs.push_back(LeFlushRef{i, side, f, (int32_t)(f / rl), (int32_t)(f % rl)});
+                    float* const base = side == 0 ? d.w1 : d.w2;
+                    for (int64_t f = 0; f < n; f += kFlushSpan) {
+                        LeFlushRef fr;
+                        memset(&fr, 0, sizeof(fr));
+                        fr.w = base + f;
+                        fr.hold = d.hold + (int64_t)side * d.o1;
+                        fr.span = (int32_t)std::min<int64_t>(kFlushSpan, n - f);
+                        fr.row_len = (int32_t)rl;
+                        fr.row0 = (int32_t)(f / rl); fr.pos0 = (int32_t)(f % rl);
+                        fr.side = side; fr.net = d.net;
+                        fr.go = d.go; fr.gi = d.gi; fr.khkw = d.khkw; fr.o1 = d.o1;
+                        fr.vec = ((rl & 3) == 0 && (((uintptr_t)fr.w) & 15) == 0) ? 1 : 0;
+                        refs.push_back(fr);
+                    }
                 }
             }
             p->n_flush = (int)refs.size();
@@ -2385,8 +2431,8 @@ static int le_restart(dfq_le_plan* p, const dfq_le_config* cfg, hipStream_t st) 
 // deferred stores: bring the weights up to date with the sweeps run so far (a no-op for networks whose last sweep stored)
 static int le_flush(dfq_le_plan* p, hipStream_t st) {
     if (p->defer <= 1 || p->n_flush == 0) return DFQ_OK;
-    hipLaunchKernelGGL(le_flush_kernel, dim3(p->n_flush), dim3(kBlock), 0, st, (const LeRelDev*)p->d_rels,
-                       (const LeFlushRef*)p->d_flush, (const LeState*)p->d_state, p->defer);
+    hipLaunchKernelGGL(le_flush_kernel, dim3(p->n_flush), dim3(kBlock), 0, st, (const LeFlushRef*)p->d_flush, (const LeState*)p->d_state,
+                       p->defer);
     DFQ_CHECK_LAUNCH();
     hipLaunchKernelGGL(le_hold_reset_kernel, dim3(p->n_hold_rels), dim3(kBlock), 0, st, (const LeRelDev*)p->d_rels,
                        (const int32_t*)p->d_hold_rels, (const LeState*)p->d_state, p->defer, 0);
