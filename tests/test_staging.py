@@ -115,3 +115,24 @@ def test_scopes_join_and_clean_up(engine):
         assert _ffi.Stage() is outer
     assert _ffi.scoped_stage() is None
     assert _ffi.Stage() is not outer
+
+
+@pytest.mark.gpu
+def test_whole_calibration_section_inside_one_scope():
+    """main_cls.py:149-181 from BN folding to the int8 weights, every call inside one scope: what the separate calls give."""
+    _ffi.lib()
+
+    def run(scoped):
+        import contextlib
+        model, graph, bottoms = synthetic.build('tiny_mobile', seed=0)
+        with (dfq_amd.staging() if scoped else contextlib.nullcontext()):
+            lt.merge_batchnorm(model, graph, bottoms, TARG)
+            rels = rel.create_relation(graph, bottoms, TARG, delete_single=False)
+            dfq.cross_layer_equalization(graph, rels, TARG)
+            dfq.bias_absorption(graph, rels, bottoms)
+            dfq.bias_correction(graph, bottoms, TARG)
+            lt.quantize_targ_layer(graph, 8, 8, TARG)
+        return snapshot(graph)
+    a, b = run(False), run(True)
+    for k in a:
+        assert_bitexact(b[k], a[k], k)
