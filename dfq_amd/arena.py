@@ -6,7 +6,8 @@ fake_bias, the cumulative scale vectors): 7 000 addresses for the benchmark's ba
 batch cost, against 7.6 ms of GPU work for the whole calibration.  ``NetworkBatch`` moves the tensors ONCE, when the batch
 is put together (model loading, not calibration), into one allocation in which network n's tensors sit at the same offsets
 from ``base + n * stride``; the modules' parameters and buffers are re-pointed at those slots (views, so the models keep
-working as before).  A plan over the batch is then the tables of the FIRST network plus one base address per network
+working as before; ``release()`` gives them storages of their own again -- do that before saving or deep-copying a packed
+model, because torch pickles and copies a view together with its whole storage).  A plan over the batch is then the tables of the FIRST network plus one base address per network
 (``dfq_le_plan_create_replicated`` / ``dfq_bc_plan_create_replicated``, include/dfq_hip.h): no per-tensor host work at all.
 
 This is the host side of the reference's per-network graph walks (dfq.py:78-82, :194-270) for a batch; the arithmetic is the
@@ -145,6 +146,37 @@ class NetworkBatch:
         self._scale_cum = [rr.S for (_, _, rels) in self.nets for rr in rels]
         self._probe = [(slots[0][2], slots[-1][0]) for slots in per_net]       # first weight, last relation of every network
 
+    def release(self):
+        """Give every tensor a storage of its own again (a copy of its slot) and drop the batch allocation.  The models' tensors
+        are VIEWS of ``self.storage`` while the batch exists, and torch treats a view as its whole storage when it pickles or
+        deep-copies one: ``torch.save(model.state_dict())`` / ``copy.deepcopy(model)`` of a packed model would carry all the
+        batch's networks.  Call this when the calibration is done and the models go their own ways; plans created from the batch
+        must not be run afterwards."""
+        home = self.storage.untyped_storage().data_ptr()
+
+        def mine(t):
+            return torch.is_tensor(t) and t.untyped_storage().data_ptr() == home
+        with torch.no_grad():
+            for (graph, bottoms, relations) in self.nets:
+                for m in graph.values():
+                    if not isinstance(m, torch.nn.Module):
+                        continue                                    # functional nodes of the graph are recorded by name
+                    for name, t in m.__dict__['_parameters'].items():
+                        if mine(t):
+                            t.data = t.data.clone()
+                    bufs = m.__dict__['_buffers']
+                    for name in list(bufs):
+                        if mine(bufs[name]):
+                            bufs[name] = bufs[name].clone()
+                    for name, t in list(m.__dict__.items()):
+                        if mine(t):
+                            m.__dict__[name] = t.clone()
+                for rr in relations:
+                    if mine(rr.S):
+                        rr.S = rr.S.clone()
+        self._probe, self._scale_cum = [], []
+        self.storage = None
+
     # -- plans ---------------------------------------------------------------------------------------------------------
     def _tables(self, T):
         out = _dfq._Tables()
@@ -157,6 +189,8 @@ class NetworkBatch:
     def check(self, thorough=False):
         """Raise if a tensor has left its slot (someone assigned a new tensor to ``weight.data`` or ``Relation.S`` after the
         batch was put together).  The quick form looks at the first and the last slot of every network."""
+        if self.storage is None:
+            raise RuntimeError('NetworkBatch: the batch has been released')
         span = 4 * self.stride
         for n, ((w, rr), base) in enumerate(zip(self._probe, self._base_ints)):
             if w.data_ptr() != base or rr.S is None or not (base <= rr.S.data_ptr() < base + span):

@@ -203,3 +203,31 @@ def test_full_size_batch_in_one_allocation_equals_single_network_plans():
                                                                     # runs one sweep longer (torch's CPU sqrt)
     le.close()
     bc.close()
+
+
+def test_released_batch_gives_the_models_their_own_storages(engine):
+    nets = [_prepared('tiny_mobile', s, engine.device) for s in (0, 1, 2)]
+    batch = arena.NetworkBatch([(g, b, r) for (_, g, b, r) in nets], TARG)
+    le = batch.le_plan()
+    le.run()
+    le.close()
+    want = [snapshot(g) for (_, g, _, _) in nets]
+    scales = [[npy(rr.S).copy() for rr in r] for (_, _, _, r) in nets]
+    base = batch.storage.untyped_storage().data_ptr()
+    batch.release()
+    for (m, g, b, rels), snap, sc in zip(nets, want, scales):
+        for k, mod in g.items():
+            if not isinstance(mod, nn.Module):
+                continue
+            for t in list(mod.parameters(recurse=False)) + list(mod.buffers(recurse=False)):
+                assert t.untyped_storage().data_ptr() != base
+                assert t.untyped_storage().nbytes() <= 4 * max(t.numel(), 1) + 64          # its own, not the batch's
+        got = snapshot(g)
+        for k in snap:
+            assert_bitexact(got[k], snap[k], k)
+        for rr, s0 in zip(rels, sc):
+            assert_bitexact(npy(rr.S), s0)
+        clone = copy.deepcopy(m)                                       # now an ordinary, small copy
+        assert sum(p.untyped_storage().nbytes() for p in clone.parameters()) < 4 * 4 * sum(p.numel() for p in clone.parameters()) + 4096
+    with pytest.raises(RuntimeError, match='released'):
+        batch.le_plan()
