@@ -2,6 +2,7 @@
 """Where building the two plans of a batch goes (GPU box): table building in Python vs the C-side plan creation.
    python tools/plan_cost.py [batch]"""
 import copy
+import gc
 import os
 import sys
 import time
@@ -33,6 +34,8 @@ for rep in range(5):
     print('LE tables %.2f ms, LE plan (C) %.2f ms, BC tables %.2f ms, BC plan (C) %.2f ms, total %.2f ms' %
           ((t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (t4 - t3) * 1e3, (t4 - t0) * 1e3))
     le.close(); bc.close()
+    del le, bc, lt, bt, nets          # the previous repetition's 32 models go NOW, not inside the next repetition's timed lines
+    gc.collect()
 
 # the same batch as ONE allocation (dfq_amd/arena.py): layout once, then plans from one network's tables + base addresses
 for rep in range(5):
@@ -49,3 +52,5 @@ for rep in range(5):
     print('one allocation: layout %.2f ms (once per batch), LE plan %.2f ms, BC plan %.2f ms, plans %.2f ms' %
           ((t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (t3 - t1) * 1e3))
     le.close(); bc.close()
+    del le, bc, nb, nets
+    gc.collect()
