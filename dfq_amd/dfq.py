@@ -1205,6 +1205,22 @@ def _bc_tables(graph, bottoms, targ_type, bn_type, base=0, net=0):
     return layers, [tuple(s) for s in steps], [keys[s[0] - base] for s in steps]
 
 
+def _bc_tables_cached(graph, bottoms, targ_type, bn_type):
+    """``_bc_tables`` of one network from the structure template of its architecture (``_bc_template``: the graph walk of
+    dfq.py:194-270 done once per distinct graph, the tensors looked up by (graph key, attribute)): what a second call on the
+    same architecture -- the next checkpoint, the next model of a service -- pays is the signature and ~250 attribute reads."""
+    t = _bc_template(graph, bottoms, targ_type, bn_type)
+    mods = [graph[k] for k in t['keys']]
+    for li in t['bias_layers']:
+        _ensure_bias(mods[li])
+    layers = [(m.__dict__['_parameters']['weight'], m.__dict__['_parameters'].get('bias'), getattr(m, 'groups', 1)) for m in mods]
+
+    def at(ref):
+        return None if ref is None else _attr(graph[ref[0]], ref[1])
+    steps = [(li, [(at(fw), at(fb), relu, cat) for (fw, fb, _, relu, cat) in srcs], at(nxt), 0) for (li, srcs, nxt) in t['steps']]
+    return layers, steps, [t['keys'][li] for (li, _, _) in t['steps']]
+
+
 def bias_correction(graph, bottoms, targ_type, bits_weight=8, bn_type=torch.nn.BatchNorm2d, signed=False):
     """Analytic bias correction: b -= eps . E[x], propagated into the next BN's beta~.
 
@@ -1212,7 +1228,7 @@ def bias_correction(graph, bottoms, targ_type, bits_weight=8, bn_type=torch.nn.B
     """
     print("Start bias correction")
     with torch.no_grad(), _cache_lock:
-        layers, steps, _ = _bc_tables(graph, bottoms, targ_type, bn_type)
+        layers, steps, _ = _bc_tables_cached(graph, bottoms, targ_type, bn_type)
         if not steps:
             return                                       # no layer behind a BN: nothing to correct (dfq.py:197-199)
         dev = _ffi.target_device()
