@@ -907,13 +907,16 @@ def cross_layer_equalization(graph, relations, targ_type, s_range=[1e-8, 1e8], r
             key = None
         hit = _cache_get(_le_plan_cache, key) if key is not None else None
         if hit is not None:
-            plan, scum = hit
+            plan, scum, scum_flat = hit
             plan_cache_stats['le_hits'] += 1
-            for rr, sc in zip(relations, scum):               # the plan accumulates into ITS buffers: start from S (or 1)
-                if rr.S is None:
-                    sc.fill_(1.0)
-                else:
-                    sc.copy_(rr.S)
+            if all(rr.S is None for rr in relations):         # the plan accumulates into ITS buffers: start from 1 ...
+                scum_flat.fill_(1.0)                          # (one launch for all of them)
+            else:
+                for rr, sc in zip(relations, scum):           # ... or from the caller's S
+                    if rr.S is None:
+                        sc.fill_(1.0)
+                    else:
+                        sc.copy_(rr.S)
             stage = scope or plan.stage or _ffi.Stage()
         else:
             plan_cache_stats['le_misses'] += 1
@@ -921,16 +924,17 @@ def cross_layer_equalization(graph, relations, targ_type, s_range=[1e-8, 1e8], r
             if key is not None:
                 # cached plans own their cumulative-scale buffers (a Relation's S tensor is replaced on every call)
                 saved = [rr.S for rr in relations]
-                scum = []
-                for rr in relations:
-                    o1 = graph[rr.get_idxs()[0]].weight.size(0)
-                    sc = torch.ones(o1, dtype=torch.float32, device=stage.device) if rr.S is None else rr.S.detach().clone().to(stage.device)
-                    scum.append(sc)
+                sizes = [int(graph[rr.get_idxs()[0]].weight.size(0)) for rr in relations]
+                scum_flat = torch.ones(sum(sizes), dtype=torch.float32, device=stage.device)
+                scum = list(scum_flat.split(sizes)) if sizes else []
+                for rr, sc in zip(relations, scum):
+                    if rr.S is not None:
+                        sc.copy_(rr.S.detach())
                     rr.S = sc
                 plan = build_le_plan(graph, relations, targ_type, stage=stage)
                 for rr, s0 in zip(relations, saved):
                     rr.S = s0
-                _cache_put(_le_plan_cache, key, (plan, scum))
+                _cache_put(_le_plan_cache, key, (plan, scum, scum_flat))
             else:
                 plan = build_le_plan(graph, relations, targ_type, stage=stage)
         try:
