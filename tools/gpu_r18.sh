@@ -6,7 +6,7 @@ python - "$t" <<'PY'
 import csv, sys
 rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r['Start_Timestamp']))
 # last occurrence of the reset kernel starts the last LE pass
-idx = [i for i, r in enumerate(rows) if 'le_reset' in r['Kernel_Name']]
+idx = [i for i, r in enumerate(rows) if 'le_prepare' in r['Kernel_Name'] or 'le_reset' in r['Kernel_Name']]
 start = idx[-1]
 t0 = int(rows[start]['Start_Timestamp'])
 prev_end = t0
