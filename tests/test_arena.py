@@ -231,3 +231,43 @@ def test_released_batch_gives_the_models_their_own_storages(engine):
         assert sum(p.untyped_storage().nbytes() for p in clone.parameters()) < 4 * 4 * sum(p.numel() for p in clone.parameters()) + 4096
     with pytest.raises(RuntimeError, match='released'):
         batch.le_plan()
+
+
+def _restore(graph, snap, device):
+    """put a snapshot()'s values back IN PLACE (the tensors stay in their slots)"""
+    with torch.no_grad():
+        for i, (k, mod) in enumerate(graph.items()):
+            for name, attr in (('w', 'weight'), ('b', 'bias'), ('fw', 'fake_weight'), ('fb', 'fake_bias')):
+                key = 'L{}.{}'.format(i, name)
+                if key in snap:
+                    getattr(mod, attr).copy_(torch.from_numpy(snap[key]).to(device))
+
+
+def test_plans_created_and_destroyed_over_and_over_reuse_their_tables(engine):
+    """A service creates and destroys plans of the same shapes batch after batch: the tables come from per-plan slabs whose
+    blocks go back to a free list (dfq_core.cpp); twenty rounds give twenty times the same result."""
+    nets = [_prepared('tiny_mobile', s, engine.device) for s in (0, 1)]
+    batch = arena.NetworkBatch([(g, b, r) for (_, g, b, r) in nets], TARG)
+    start = [snapshot(g) for (_, g, _, _) in nets]                  # (after the layout: zero biases exist now)
+    first = None
+    for rep in range(20):
+        for (m, g, b, rels), snap in zip(nets, start):
+            _restore(g, snap, engine.device)
+            with torch.no_grad():
+                for rr in rels:
+                    rr.S.fill_(1.0)
+        le, bc = batch.le_plan(), batch.bc_plan()
+        le.enqueue(3, restart=True, max_sweeps=3)
+        bc.run(check=True)
+        if engine.device.type == 'cuda':
+            torch.cuda.synchronize()
+        got = [snapshot(g) for (_, g, _, _) in nets]
+        le.close()
+        bc.close()
+        if first is None:
+            first = got
+            assert any((first[0][k] != start[0][k]).any() for k in first[0])
+        else:
+            for a, b in zip(got, first):
+                for k in a:
+                    assert_bitexact(a[k], b[k], 'round {} {}'.format(rep, k))

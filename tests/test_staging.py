@@ -136,3 +136,28 @@ def test_whole_calibration_section_inside_one_scope():
     a, b = run(False), run(True)
     for k in a:
         assert_bitexact(b[k], a[k], k)
+
+
+@pytest.mark.gpu
+def test_full_size_cpu_resident_model_in_a_scope_equals_the_device_resident_pass():
+    """MobileNetV2 at full size: the CPU-resident model calibrated inside a scope ends bit-identical to the same model
+    calibrated on the device (same plans, same kernels -- the scope only moves the bytes), sweep count included."""
+    _ffi.lib()
+    dfq.clear_plan_cache()
+    a = _cpu_model('mobilenet_v2', seed=0)
+    b = _cpu_model('mobilenet_v2', seed=0)
+    b[0].to('cuda')
+    with dfq_amd.staging():
+        dfq.cross_layer_equalization(a[1], a[3], TARG)
+        sweeps_a = dfq.last_equalization['sweeps']
+        dfq.bias_correction(a[1], a[2], TARG)
+    dfq.cross_layer_equalization(b[1], b[3], TARG)
+    sweeps_b = dfq.last_equalization['sweeps']
+    dfq.bias_correction(b[1], b[2], TARG)
+    assert sweeps_a == sweeps_b == 47
+    sa, sb = snapshot(a[1]), snapshot(b[1])
+    for k in sb:
+        assert_bitexact(sa[k], sb[k], k)
+    for ra, rb in zip(a[3], b[3]):
+        assert ra.S.device.type == 'cpu'
+        assert torch.equal(ra.S, rb.S.cpu())
