@@ -52,12 +52,24 @@ def build(force=False):
 
 
 def _compile(out):
-    cmd = ['g++', '-O2', '-g', '-std=c++17', '-fPIC', '-shared', '-ffp-contract=off', '-fno-fast-math', '-fno-strict-aliasing',
-           '-DDFQ_GLOBAL_AS=', '-DDFQ_CONSTANT_AS=', '-Wall', '-Wno-unknown-pragmas', '-Wno-unused-function', '-Wno-unused-variable',
-           '-I', os.path.join(HERE, 'include'), '-I', os.path.join(ROOT, 'include'), '-o', out]
-    for s in sources():
-        cmd += ['-x', 'c++', s]
-    subprocess.run(cmd, check=True)
+    """every source to an object file of its own, in parallel (one g++ over all sources took 28 s), then one link"""
+    from concurrent.futures import ThreadPoolExecutor
+    flags = ['-O2', '-g', '-std=c++17', '-fPIC', '-ffp-contract=off', '-fno-fast-math', '-fno-strict-aliasing',
+             '-DDFQ_GLOBAL_AS=', '-DDFQ_CONSTANT_AS=', '-Wall', '-Wno-unknown-pragmas', '-Wno-unused-function', '-Wno-unused-variable',
+             '-I', os.path.join(HERE, 'include'), '-I', os.path.join(ROOT, 'include')]
+    objdir = out + '.objs'
+    os.makedirs(objdir, exist_ok=True)
+    objs = [os.path.join(objdir, os.path.basename(s) + '.o') for s in sources()]
+
+    def one(job):
+        src, obj = job
+        subprocess.run(['g++'] + flags + ['-c', '-x', 'c++', src, '-o', obj], check=True)
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
+        list(pool.map(one, zip(sources(), objs)))
+    subprocess.run(['g++', '-shared', '-fPIC', '-o', out] + objs, check=True)
+    for o in objs:
+        os.remove(o)
+    os.rmdir(objdir)
 
 
 if __name__ == '__main__':
