@@ -18,12 +18,16 @@ calibrates its own replicas, `value` = weights calibrated by all ranks / max-ove
 Next to it, measured by the same run and reported in the same line:
   latency   one single-network pass with nothing else in flight (what main_cls.py would feel), with its own
             roofline fraction;
-  config.others   configs[2] ResNet-18, configs[3] DeepLab on one GPU (pinned 60 sweeps), configs[4]
-            the activation-range kernels at MobileNetV2's largest activation (12 B per element);
-  sharded   configs[3] as `north_star` splits it: ONE DeepLab network, relation components partitioned over the
+  config.others   configs[2] ResNet-18, configs[3] DeepLab on one GPU -- through the reference's own data-dependent loop (46
+            sweeps: on its 35-relation graph the reference terminates, tests/golden/fullconv_deeplab_mnv2_s0.npz) and
+            through the 60 pinned sweeps SURVEY 8d names --, configs[4] the activation-range kernels at MobileNetV2's
+            largest activation (12 B per element);
+  sharded   a LIST: `north_star`'s own graph (the 53-layer MobileNetV2, 47 pinned sweeps) and configs[3] (DeepLab, 60
+            pinned sweeps), each as ONE network whose relation components are partitioned over the
             ranks, pinned sweeps, ONE all_gather of the cumulative scale vectors (RCCL over xGMI), engine rebuild
-            of the foreign layers, replicated bias correction -> strong scaling (total work fixed); runs at every
+            of every paired layer, replicated bias correction -> strong scaling (total work fixed); runs at every
             N (at N = 1 it is the degenerate one-rank group), so a driver run at N = 8 puts 8 ranks on the data path;
+            `data_dependent_ms`: the same pass with the reference's stopping rule (one 8-byte all_reduce per sweep);
   roofline  dominant kernel le_level_kernel: algorithmic bytes per launch / HIP-event duration per launch;
   cpu_baseline   the numpy oracle (a vectorised CPU port) timed live on this host + `reference`: the UNMODIFIED reference's own
             CPU path timed on THIS box's host cores (oracle/time_ref.py drives the byte-compiled reference of oracle/_ref for
@@ -66,10 +70,10 @@ def parse():
                     'kernels with in-launch waits are serialised across streams by the library, the others overlap')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--force-sweeps', action='store_true', help='tuning: run --sweeps sweeps regardless of convergence')
-    ap.add_argument('--others', default='resnet18,deeplab_mnv2:60', help='other BASELINE configs measured on one GPU: '
+    ap.add_argument('--others', default='resnet18,deeplab_mnv2,deeplab_mnv2:60', help='other BASELINE configs measured on one GPU: '
                     'comma list of net[:pinned sweeps]; "" disables')
     ap.add_argument('--act-shape', default='64,96,112,112', help='config 5: activation tensor for the range kernels; "" disables')
-    ap.add_argument('--sharded', default='deeplab_mnv2:60', help='config 4: net:pinned sweeps for the sharded single-network '
+    ap.add_argument('--sharded', default='mobilenet_v2:47,deeplab_mnv2:60', help='config 4: net:pinned sweeps for the sharded single-network '
                     'pass; "" disables')
     ap.add_argument('--sharded-steps', type=int, default=6)
     ap.add_argument('--distill', default='mobilenet_v2:8:64,3,224,224', help='config 5 end to end: net:batches:shape of '
@@ -546,49 +550,87 @@ def pcie_inclusive_pass(net, reps=3):
 # config 4: one network sharded over the ranks (north_star's split)
 # ---------------------------------------------------------------------------------------------------
 def sharded_single_network(spec, steps, dev, dist, rank, world):
+    """One entry of `sharded`: `net[:pinned sweeps]` -- the pinned pass (no exchange before the final all_gather) timed over
+    `steps` passes, then the SAME network through the data-dependent mode (the reference's own loop, dfq.py:83-115: one 8-byte
+    all_reduce of sum mean|dW| per sweep, the host in the loop) over min(steps, 3) passes."""
     from dfq_amd import dfq, sharded
     net, _, pin = spec.partition(':')
     sweeps = int(pin or 60)
     proto = prepare(net, 0, dev)                       # the SAME network on every rank (seed 0)
     n_w = sum(m.weight.numel() for m in proto[1].values() if type(m) in TARG)
-    reps = []
-    for _ in range(steps + 2):
-        model, graph, bottoms, rels = copy.deepcopy(proto)
-        eq = sharded.ShardedEqualizer(graph, rels, TARG)            # partition + the owned components' plan (untimed)
-        bc, _ = dfq.build_bc_plan(graph, bottoms, TARG)
-        reps.append((eq, bc, graph))
+    dd_steps = min(steps, 3)
 
-    def one(r):
-        r[0].run(max_sweeps=sweeps, check=False)   # snapshot -> local sweeps -> ONE all_gather -> rebuild of every paired tensor
-        r[1].run()                           # the correction chain is sequential over layers: replicated on every rank
+    def fresh(n):
+        reps = []
+        for _ in range(n):
+            model, graph, bottoms, rels = copy.deepcopy(proto)
+            eq = sharded.ShardedEqualizer(graph, rels, TARG)            # partition + the owned components' plan (untimed)
+            bc, _ = dfq.build_bc_plan(graph, bottoms, TARG)
+            reps.append((eq, bc, graph))
+        return reps
 
     def fence():
         _sync()
         dist.barrier()
         _sync()
-    for r in reps[:2]:
-        one(r)
-    fence()
-    t0 = time.perf_counter()
-    for r in reps[2:]:
-        one(r)
-    fence()
-    elapsed = time.perf_counter() - t0
+
+    def timed(reps, warm, one):
+        for r in reps[:warm]:
+            one(r)
+        fence()
+        t0 = time.perf_counter()
+        for r in reps[warm:]:
+            one(r)
+        fence()
+        elapsed = time.perf_counter() - t0
+        for r in reps:
+            r[0].check()                         # an abandoned in-launch wait of any pass raises here
+            r[1].status()
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == 'nccl' else 'cpu')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item()) * 1e3 / (len(reps) - warm)
+
+    def pinned(r):
+        r[0].run(max_sweeps=sweeps, check=False)   # snapshot -> local sweeps -> ONE all_gather -> rebuild of every paired tensor
+        r[1].run()                           # the correction chain is sequential over layers: replicated on every rank
+
+    dd_sweeps = []
+
+    def data_dependent(r):
+        dd_sweeps.append(r[0].run(max_sweeps=None, check=False))       # one all_reduce per sweep decides whether the next one happens
+        r[1].run()
+
+    reps = fresh(steps + 2)
+    ms = timed(reps, 2, pinned)
+    eq0 = reps[0][0]
+    owner = list(eq0.owner)
+    comps = sharded.relation_components(proto[3])
+    per_rank = [0] * world
+    for i, rr in enumerate(proto[3]):
+        a, b, _ = rr.get_idxs()
+        per_rank[owner[i]] += proto[1][a].weight.numel() + proto[1][b].weight.numel()
+    exchange = eq0.exchange_bytes
     for r in reps:
-        r[0].check()                         # an abandoned in-launch wait of any pass raises here
-        r[1].status()
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == 'nccl' else 'cpu')
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    ms = float(t.item()) * 1e3 / steps
-    owned = sorted(set(reps[0][0].owner))
-    return {'net': net, 'weights': n_w, 'relations': len(proto[3]), 'sweeps': sweeps, 'sweeps_pinned': True, 'world': world,
-            'ranks_owning_components': len(owned), 'ms_per_pass': ms, 'value': n_w / (ms * 1e-3), 'unit': 'weights/s',
-            'scaling': 'strong', 'collectives_per_pass': 1, 'exchange_bytes_per_rank': reps[0][0].exchange_bytes,
+        r[0].close()
+    del reps
+    reps = fresh(dd_steps + 1)
+    dd_ms = timed(reps, 1, data_dependent)
+    for r in reps:
+        r[0].close()
+    del reps
+    return {'net': net, 'weights': n_w, 'relations': len(proto[3]), 'components': len(comps), 'sweeps': sweeps, 'sweeps_pinned': True,
+            'world': world, 'ranks_owning_components': len(set(owner)), 'paired_elements_per_rank': per_rank,
+            'ms_per_pass': ms, 'value': n_w / (ms * 1e-3), 'unit': 'weights/s',
+            'scaling': 'strong', 'collectives_per_pass': 1, 'exchange_bytes_per_rank': exchange,
+            'data_dependent_ms': dd_ms, 'data_dependent_sweeps': dd_sweeps[-1], 'data_dependent_collectives_per_pass': dd_sweeps[-1] + 1,
             'backend': dist.get_backend(),
-            'what': 'ONE {} network per pass: relation components partitioned over the ranks, {} pinned sweeps per rank on the '
+            'what': 'ONE {} network per pass: relation components partitioned over the ranks (greedy by paired elements: '
+                    'paired_elements_per_rank), {} pinned sweeps per rank on the '
                     'owned components (on scratch copies), one all_gather of the cumulative scale vectors, ONE batched rebuild launch of every '
                     'paired tensor on every rank (W = diag(S_out) W0 diag(1/S_in): all ranks end bit-identical), bias correction replicated on '
-                    'every rank; plans prebuilt, weights resident'.format(net, sweeps)}
+                    'every rank; plans prebuilt, weights resident.  data_dependent_ms: the same pass with the reference\'s own stopping '
+                    'rule (dfq.py:83-115) -- every sweep ends with an 8-byte all_reduce of sum mean|dW| that the host reads before it enqueues '
+                    'the next sweep'.format(net, sweeps)}
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -887,7 +929,7 @@ def main():
     # ---- config 4 as north_star splits it (every rank takes part) ----
     if args.sharded and dist is not None:
         with _stream_ctx(streams[0]):
-            sh = sharded_single_network(args.sharded, args.sharded_steps, dev, dist, rank, world)
+            sh = [sharded_single_network(item, args.sharded_steps, dev, dist, rank, world) for item in args.sharded.split(',') if item]
         if rank == 0:
             out['sharded'] = sh
 

@@ -13,3 +13,10 @@ def staging():
     tensor crosses PCIe once each way for the whole sequence (see ``_ffi.staging``)."""
     from . import _ffi
     return _ffi.staging()
+
+
+def pool_trim():
+    """Return the device blocks that destroyed plans parked in the library's free lists to the driver (``dfq_pool_trim``);
+    the number of bytes released.  For a process that needs the memory for something else: torch's allocator cannot see them."""
+    from . import _ffi
+    return int(_ffi.lib().dfq_pool_trim())

@@ -76,6 +76,7 @@ class DfqBnRangeReq(Structure):
 SIGNATURES = {
     'dfq_version': (c_int32, []),
     'dfq_last_error': (c_char_p, []),
+    'dfq_pool_trim': (ctypes.c_longlong, []),
     'dfq_device_count': (c_int32, []),
     'dfq_le_plan_create': (c_int32, [POINTER(DfqLayer), c_int32, POINTER(DfqRelation), c_int32, POINTER(c_void_p)]),
     'dfq_le_plan_create_batch': (c_int32, [POINTER(DfqLayer), c_int32, POINTER(c_int32), c_int32, POINTER(DfqRelation), c_int32,
@@ -341,7 +342,9 @@ def staging():
     plus the host-side packing).  Between the calls the device copies are the truth: host code inside the scope must not read
     or write the model's tensors (the reference's calibration section, main_cls.py:149-181, does not).  If the scope is left by
     an exception nothing is written back: the model keeps the values it had when the scope was entered.  Device-resident
-    tensors are used in place as always; scopes do not nest (an inner scope joins the outer one)."""
+    tensors are used in place as always; scopes do not nest (an inner scope joins the outer one).  Only the calibration
+    entry points join the scope (entry_stage()); QuantMeasure / quantize() / the single-step primitives called inside it
+    keep their one-call staging (their inputs change between calls)."""
     outer = getattr(_ambient, 'stage', None)
     if outer is not None:
         yield outer
@@ -365,6 +368,15 @@ def staging():
 def scoped_stage():
     """the shared stage of the enclosing staging() scope, or None"""
     return getattr(_ambient, 'stage', None)
+
+
+def entry_stage():
+    """The stage of a CALIBRATION entry point (merge_batchnorm, cross_layer_equalization, bias_absorption, clip_weight,
+    bias_correction, quantize_targ_layer, set_quant_minmax): the enclosing staging() scope's, else a private one.  Nothing
+    else shares the scope's stage: a per-call user -- QuantMeasure.forward, quantize(), the single-step primitives -- binds
+    tensors whose host values change between calls (running ranges, activations), and a scope-long binding would hand every
+    later call the first call's device copy and write that stale copy back when the scope ends."""
+    return scoped_stage() or Stage()
 
 
 def _to_device(host, device):
@@ -393,13 +405,7 @@ class Stage:
     ``writeback()`` -- the PCIe-inclusive way of calling the engine.
     """
 
-    def __new__(cls):
-        amb = getattr(_ambient, 'stage', None)
-        return amb if amb is not None else super().__new__(cls)       # inside `with staging():` every entry point shares one
-
     def __init__(self):
-        if getattr(self, '_scoped', False):
-            return                                                   # the shared stage of a staging() scope: keep its bindings
         self.device = target_device()
         self._bound = {}
         self._shadow = []

@@ -114,6 +114,7 @@ struct PlanTimer {
 hipError_t dev_malloc(void** out, size_t bytes);
 void dev_free(void* p);
 void dev_quiesce();
+size_t dev_pool_trim();
 // The tables of ONE plan, carved out of a few 4 MB blocks (a table larger than that gets a block of its own): two or three
 // dev_malloc calls per plan instead of thirty, also when no block of a destroyed plan is waiting in the free lists (a service
 // that keeps several batches in flight).  Tables start on 256-byte boundaries; release() returns every block.

@@ -39,6 +39,7 @@ struct DevPool {
     std::unordered_map<unsigned long long, std::vector<void*>> free_lists;   // key: device << 48 | rounded size / 256
     std::unordered_map<void*, unsigned long long> live;                      // block -> key, for blocks that may return to a list
     size_t cached = 0, cap = 512u << 20;
+    unsigned long long devices = 0;                                           // bit d: a block of device d was ever handed out
     DevPool() {
         const char* e = getenv("DFQ_POOL_MB");
         if (e && *e) cap = (size_t)std::max(0, atoi(e)) << 20;
@@ -57,6 +58,7 @@ hipError_t dev_malloc(void** out, size_t bytes) {
     const unsigned long long key = ((unsigned long long)dev << 48) | (rounded >> 8);
     {
         std::lock_guard<std::mutex> g(P.m);
+        if (dev >= 0 && dev < 64) P.devices |= 1ull << dev;
         auto it = P.free_lists.find(key);
         if (it != P.free_lists.end() && !it->second.empty()) {
             *out = it->second.back();
@@ -105,7 +107,41 @@ void dev_free(void* p) {
     (void)hipFree(p);
 }
 
-void dev_quiesce() { (void)hipDeviceSynchronize(); }
+// A destroyed plan's blocks go back to the free list of THEIR device, and the next plan of that device may take them at once:
+// nothing of the destroyed plan may still be in flight there.  The caller's current device need not be the plan's (several
+// GPUs driven from one process), so every device this library ever allocated on is synchronised -- one, in the usual
+// one-process-per-GPU arrangement: the same single hipDeviceSynchronize the first hipFree of a plan used to be.
+void dev_quiesce() {
+    unsigned long long devices;
+    {
+        DevPool& P = dev_pool();
+        std::lock_guard<std::mutex> g(P.m);
+        devices = P.devices;
+    }
+    int cur = 0;
+    if (hipGetDevice(&cur) != hipSuccess) { (void)hipGetLastError(); return; }
+    (void)hipDeviceSynchronize();
+    bool moved = false;
+    for (int d = 0; d < 64; ++d) {
+        if (d == cur || !((devices >> d) & 1)) continue;
+        if (hipSetDevice(d) == hipSuccess) { (void)hipDeviceSynchronize(); moved = true; } else (void)hipGetLastError();
+    }
+    if (moved) (void)hipSetDevice(cur);
+}
+
+size_t dev_pool_trim() {
+    DevPool& P = dev_pool();
+    std::vector<void*> all;
+    size_t bytes;
+    {
+        std::lock_guard<std::mutex> g(P.m);
+        for (auto& kv : P.free_lists) { all.insert(all.end(), kv.second.begin(), kv.second.end()); kv.second.clear(); }
+        bytes = P.cached;
+        P.cached = 0;
+    }
+    for (void* b : all) (void)hipFree(b);       // hipFree takes any device's pointer
+    return bytes;
+}
 
 // ---- SpinGuard (see dfq_common.hpp) ----
 // One {event, stream, pending} record per DEVICE ordinal (an event belongs to the device it was created on: recording an event
@@ -158,6 +194,8 @@ extern "C" {
 int dfq_version(void) { return DFQ_HIP_VERSION; }
 
 const char* dfq_last_error(void) { return dfq::g_last_error.c_str(); }
+
+long long dfq_pool_trim(void) { return (long long)dfq::dev_pool_trim(); }
 
 int dfq_device_count(void) {
     int n = 0;

@@ -714,7 +714,7 @@ def lazy_cross_layer_equalization(graph, relations, targ_type, sweeps, s_range=[
     """``cross_layer_equalization`` for a GIVEN number of sweeps in the lazy-scale formulation (see LazyLEPlan): same in-place
     update of the caller's tensors and of ``Relation.S``, within 1e-5 of what the sequential loop produces in ``sweeps`` sweeps."""
     with torch.no_grad():
-        stage = _ffi.Stage()
+        stage = _ffi.entry_stage()
         plan = LazyLEPlan([(graph, relations)], targ_type, stage=stage)
         try:
             plan.run(int(sweeps), s_range=s_range, signed=signed, eps=eps)
@@ -842,7 +842,7 @@ def _cache_put(cache, key, value):
     plan = value[0]
     plan._keep = []
     if plan.stage._scoped:
-        plan.stage = None                 # the scope's stage belongs to the scope (and goes with it)
+        plan.stage = _ffi.Stage()         # the scope's stage belongs to the scope (and goes with it): a private one for the helpers
     else:
         plan.stage._bound = {}
     cache[key] = value
@@ -920,7 +920,7 @@ def cross_layer_equalization(graph, relations, targ_type, s_range=[1e-8, 1e8], r
             stage = scope or plan.stage or _ffi.Stage()
         else:
             plan_cache_stats['le_misses'] += 1
-            stage = _ffi.Stage()
+            stage = scope or _ffi.Stage()
             if key is not None:
                 # cached plans own their cumulative-scale buffers (a Relation's S tensor is replaced on every call)
                 saved = [rr.S for rr in relations]
@@ -975,7 +975,7 @@ def bias_absorption(graph, relations, bottoms, N=3):
     print("Absorbing bias")
     lib = _ffi.lib()
     with torch.no_grad():
-        stage = _ffi.Stage()
+        stage = _ffi.entry_stage()
         for rr in relations:
             kf, ks, kb = rr.get_idxs()
             if not _relu_between(graph, bottoms, ks, kf):
@@ -999,7 +999,7 @@ def bias_absorption(graph, relations, bottoms, N=3):
 def clip_weight(graph, range_clip=[-15, 15], targ_type=[nn.Conv2d, nn.Linear]):
     lib = _ffi.lib()
     with torch.no_grad():
-        stage = _ffi.Stage()
+        stage = _ffi.entry_stage()
         for key in graph:
             if type(graph[key]) in targ_type:
                 w = stage.bind(graph[key].weight)

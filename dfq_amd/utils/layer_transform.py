@@ -43,7 +43,7 @@ def merge_batchnorm(model, graph, bottoms, targ_type=[QConv2d]):
     """
     lib = _ffi.lib()
     with torch.no_grad():
-        stage = _ffi.Stage()
+        stage = _ffi.entry_stage()
         pairs = []
         for key in graph:
             bots = bottoms[key]
@@ -108,7 +108,7 @@ def quantize_targ_layer(graph, bit_weight=8, bits_bias=16, targ_type=None, retur
     assert targ_type != None, "targ_type cannot be None!"
     lib = _ffi.lib()
     with torch.no_grad():
-        stage = _ffi.Stage()
+        stage = _ffi.entry_stage()
         segs, keep, codes = [], [], {}
         stage.prefetch([t for layer in graph.values() if type(layer) in targ_type for t in (layer.weight, layer.bias)])
         for key in graph:
@@ -257,7 +257,7 @@ def set_quant_minmax(graph, bottoms, is_detection=False, bn_type=torch.nn.BatchN
         print("SET QUANT MIN MAX")
     eps = 1e-6
     bn_module, relu_attached = {}, {}
-    stage = _ffi.Stage()
+    stage = _ffi.entry_stage()
     one_to_one = []          # (quantiser, fake_weight, fake_bias, relu) resolved with one launch at the end
     with torch.no_grad():
         for key in graph:

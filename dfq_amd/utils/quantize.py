@@ -129,7 +129,7 @@ class UniformQuantize(InplaceFunction):
 
 
 def quantize(x, num_bits=8, min_value=None, max_value=None, inplace=False, symmetric=False, num_chunks=None):
-    return UniformQuantize().apply(x, num_bits, min_value, max_value, inplace, symmetric, num_chunks)
+    return UniformQuantize.apply(x, num_bits, min_value, max_value, inplace, symmetric, num_chunks)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -224,7 +224,22 @@ class QuantMeasure(nn.Module):
         return out
 
     def set_update_stat(self, update_stat):
+        self.check_fused_status()
         self.update_stat = update_stat
+
+    def check_fused_status(self):
+        """DFQ_QM_FUSED=1 only: the one-launch variant cannot report an abandoned grid-wide wait from inside forward() without a
+        synchronisation per call, so the calibration loop's own boundary does it -- `set_update_stat` (improve_dfq.py:299-309 calls
+        it before and after `update_quant_range`).  After an abandon the outputs and the range of the failed call are undefined:
+        raises, and the scratch (whose error word is sticky) is dropped so that the module can be used again."""
+        sc = getattr(self, '_qm_scratch', None)
+        if not _QM_FUSED or sc is None or sc.device.type != 'cuda':
+            return
+        n = (sc.numel() - 4) // 4
+        rc = _ffi.lib().dfq_quant_measure_fused_status(_ffi.ptr(sc), n, _ffi.stream_arg())
+        if rc != 0:
+            self._qm_scratch = None
+            _ffi.check(rc)
 
 
 # ------------------------------------------------------------------------------------------------

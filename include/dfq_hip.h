@@ -47,6 +47,11 @@ int dfq_version(void);
 const char* dfq_last_error(void);
 /* number of visible HIP devices, or a negative error */
 int dfq_device_count(void);
+/* Destroyed plans park their small device blocks (descriptor tables, statistics arenas: <= DFQ_POOL_MB, default 512 MB per
+ * process) in per-device free lists OUTSIDE the caller's allocator so that the next plan costs no hipMalloc.  This returns
+ * them to the driver (hipFree) and reports how many bytes that was -- for a host that is about to need the memory itself
+ * (torch's caching allocator cannot see these blocks).  No reference counterpart (the reference allocates nothing). */
+long long dfq_pool_trim(void);
 
 /* ------------------------------------------------------------------------------------------
  * Layer / relation tables shared by the plans

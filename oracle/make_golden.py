@@ -16,6 +16,8 @@ GPU parity tests can check against them without the reference being present.
   tests/golden/kat_quant_error.npz    _quantize_error with its four reductions + elementwise (row a3)
   tests/golden/net_<name>_s<seed>.npz full pipeline on the tiny nets: inputs + per-stage outputs
   tests/golden/full_<name>.npz        (--full) MobileNetV2 / ResNet-18 / DeepLab summaries
+  tests/golden/fullconv_deeplab_mnv2_s0.npz, full60_deeplab_mnv2_s0.npz   (--deeplab) DeepLab through the reference's own
+                                      data-dependent loop (46 sweeps) and through 60 pinned sweeps (bench.py's count)
 """
 from __future__ import annotations
 
@@ -472,9 +474,16 @@ def spec_from_snapshot(spec, snap):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--full', action='store_true', help='also MobileNetV2 / ResNet-18 / DeepLab (minutes)')
+    ap.add_argument('--deeplab', action='store_true', help='ONLY the two DeepLab records of round 5: the reference\'s own '
+                    'data-dependent loop (it terminates, after 46 sweeps, on the 35-relation graph) and 60 pinned sweeps '
+                    '(the count SURVEY 8d / bench.py time)')
     args = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(os.cpu_count())
+    if args.deeplab:
+        run_net('deeplab_mnv2', 0, save_inputs=False, prefix='fullconv')
+        run_net('deeplab_mnv2', 0, fixed_sweeps=60, save_inputs=False, prefix='full60')
+        return
     kat_fake_quant()
     kat_le_pairs()
     kat_merge_scale()

@@ -37,14 +37,14 @@ bench._bind_thread = lambda dev: None
 bench._stream_ctx = lambda s: contextlib.nullcontext()
 world = int(os.environ.get('WORLD_SIZE', '1'))
 sys.argv = ['bench.py', '--net', 'tiny_mobile', '--steps', '2', '--warmup', '1', '--cpu-seconds', '0.2', '--streams', '1', '--batch', '2',
-            '--gpus', str(world), '--others', 'tiny_res,tiny_mobile:3', '--act-shape', '4,3,8,8', '--sharded', 'tiny_mobile:4',
+            '--gpus', str(world), '--others', 'tiny_res,tiny_mobile:3', '--act-shape', '4,3,8,8', '--sharded', 'tiny_mobile:4,tiny_res:3',
             '--sharded-steps', '2', '--distill', 'tiny_mobile:2:4,3,16,16', '--pcie', 'tiny_mobile', '--lazy-steps', '1']
 bench._BACKEND = 'gloo'            # the process group of bench.py over gloo (tests/test_bench_multirank.py)
 if world > 1:
     # the multi-rank run checks the rank protocol (barrier, MAX over ranks, one line from rank 0) and the sharded pass; the
     # single-network legs are the single-rank run's business
     sys.argv = ['bench.py', '--net', 'tiny_mobile', '--steps', '2', '--warmup', '1', '--cpu-seconds', '0', '--streams', '1', '--batch', '2',
-                '--gpus', str(world), '--others', '', '--act-shape', '', '--sharded', 'tiny_mobile:4', '--sharded-steps', '2',
+                '--gpus', str(world), '--others', '', '--act-shape', '', '--sharded', 'tiny_mobile:4,tiny_res:3', '--sharded-steps', '2',
                 '--distill', '', '--pcie', '', '--lazy-steps', '0']
     bench.main()
     sys.exit(0)

@@ -253,6 +253,7 @@ inline void launch_concurrent_k(dim3 grid, dim3 block, size_t smem, K kernel, A0
 inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, const void*, int, size_t) { *n = 8; return hipSuccess; }
 struct hipDeviceProp_t { int multiProcessorCount; };
 inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+inline hipError_t hipSetDevice(int d) { return d == 0 ? hipSuccess : hipErrorUnknown; }
 inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) { p->multiProcessorCount = 256; return hipSuccess; }
 #define hipFuncAttributeMaxDynamicSharedMemorySize 8
 inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }

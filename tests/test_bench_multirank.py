@@ -33,9 +33,16 @@ def test_two_ranks_weak_scaling_line():
     assert d['n_gpus'] == 2 and d['scaling'] == 'weak' and d['config']['networks_per_step'] == 4
     assert d['value'] > 0 and d['vs_baseline'] is None and 'cpu_baseline' not in d     # CPU baseline: N=1 only
     # config 4 as north_star splits it: both ranks on the data path, one collective per pass, strong scaling
-    sh = d['sharded']
-    assert sh['world'] == 2 and sh['ranks_owning_components'] == 2 and sh['collectives_per_pass'] == 1
-    assert sh['scaling'] == 'strong' and sh['sweeps_pinned'] and sh['value'] > 0 and sh['exchange_bytes_per_rank'] > 0
+    assert [e['net'] for e in d['sharded']] == ['tiny_mobile', 'tiny_res']
+    for sh in d['sharded']:
+        assert sh['world'] == 2 and sh['ranks_owning_components'] == 2 and sh['collectives_per_pass'] == 1
+        assert sh['scaling'] == 'strong' and sh['sweeps_pinned'] and sh['value'] > 0 and sh['exchange_bytes_per_rank'] > 0
+        # who holds what: greedy split of the components by paired elements
+        assert len(sh['paired_elements_per_rank']) == 2 and all(n > 0 for n in sh['paired_elements_per_rank'])
+        assert sh['components'] >= 2
+        # the reference's own stopping rule across ranks: one all_reduce per sweep + the final all_gather
+        assert sh['data_dependent_ms'] > 0 and sh['data_dependent_sweeps'] >= 1
+        assert sh['data_dependent_collectives_per_pass'] == sh['data_dependent_sweeps'] + 1
 
 
 def test_bench_line_contract_single_rank():
@@ -72,7 +79,10 @@ def test_bench_line_contract_single_rank():
     assert all(o['ms'] > 0 and o['roofline_frac'] > 0 for o in others)
     act = d['config']['activation_ranges']
     assert [k['bytes'] for k in act['kernels'][:3]] == [4 * act['elements'], 8 * act['elements'], 12 * act['elements']]
-    assert d['sharded']['world'] == 1 and d['sharded']['scaling'] == 'strong'
+    assert [e['net'] for e in d['sharded']] == ['tiny_mobile', 'tiny_res']
+    assert all(e['world'] == 1 and e['scaling'] == 'strong' and e['data_dependent_ms'] > 0 for e in d['sharded'])
+    # one rank, same network: the data-dependent sharded loop stops where the plain entry point's loop stops
+    assert d['sharded'][0]['data_dependent_sweeps'] == d['config']['le_sweeps'][0]
     # like-for-like figure, config 5 end to end, the PCIe-inclusive drop-in pass
     assert abs(d['value_single_network'] - lat['weights_per_s']) < 1e-6 * lat['weights_per_s']
     dr = d['config']['distill_range']

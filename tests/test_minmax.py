@@ -17,7 +17,7 @@ import torch.nn as nn
 
 from dfq_amd import synthetic
 from dfq_amd.utils import layer_transform as lt
-from dfq_amd.utils.quantize import QConv2d, QLinear
+from dfq_amd.utils.quantize import QConv2d, QLinear, QuantMeasure
 from oracle import dfq_oracle as orc
 from oracle import graphspec
 
@@ -192,3 +192,40 @@ def test_ncnn_calibration_table_matches_oracle(engine, tmp_path):
     k0 = spec.targ_keys()[0]
     w0 = spec.nodes[k0].weight.reshape(spec.nodes[k0].weight.shape[0], -1)
     assert pc[0].split(' ')[1:] == [str(128. / float(np.abs(w0[r]).max())) for r in range(w0.shape[0])]
+
+
+def test_ncnn_calibration_table_against_the_reference(engine, tmp_path):
+    """Row f3 pinned to the REFERENCE (tests/golden/ncnn_table.json, oracle/make_golden_ncnn.py): the lines are what the
+    reference's own inline block convert_ncnn.py:180-197 -- executed by the generator -- wrote for the bench's synthetic
+    MobileNetV2, with the line names (column 1) of the table the reference holds,
+    modeling/ncnn/model_quant_relu_equal.table.  106 lines; a weight line repeats ONE `str(float)` scale once per output
+    channel (token counts 32, 32, 16, 96, 96, 24, 144 ... 1280, 1000: the held table's), an activation line has one."""
+    import json
+    from dfq_amd import ncnn_table
+    gold = json.load(open(os.path.join(GOLD, 'ncnn_table.json')))
+    names, held_counts = gold['names'], gold['held_token_counts']
+    want = [' '.join([n] + [s] * c) for n, s, c in gold['lines']]
+    assert len(want) == 106 and len(names) == 106
+    assert held_counts[:7] == [32, 32, 16, 96, 96, 24, 144] and held_counts[51:53] == [1280, 1000] and held_counts[53:] == [1] * 53
+    assert [c for _, _, c in gold['lines']] == held_counts           # the held table's structure, line by line
+
+    model, graph, bottoms = synthetic.build('mobilenet_v2', seed=0)
+    model.to(engine.device)
+    keys = [k for k in graph if type(graph[k]) in TARG]
+    assert len(keys) == 53
+    for i, k in enumerate(keys):
+        q = QuantMeasure()
+        q.running_min.fill_(gold['act_min'][i])
+        q.running_max.fill_(gold['act_max'][i])
+        graph[k].quant = q.to(engine.device)
+    path = str(tmp_path / 'model_int8_tensor.table')
+    lines = ncnn_table.write_calibration_table(path, graph, targ_type=TARG, names=names)
+    assert lines == want
+    assert open(path).read() == '\n'.join(want) + '\n'
+    for line, count in zip(lines, held_counts):
+        toks = line.split(' ')
+        assert len(toks) == 1 + count and len(set(toks[1:])) == 1
+        assert str(float(toks[1])) == toks[1]                         # Python's repr of a double: round-trips
+    # without `names` the graph keys stand in for ncnn's blob names: same scales
+    plain = ncnn_table.calibration_table(graph, targ_type=TARG)
+    assert [l.split(' ')[1:] for l in plain] == [l.split(' ')[1:] for l in want]

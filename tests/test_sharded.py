@@ -241,7 +241,7 @@ def test_sharded_result_does_not_depend_on_world_size(tmp_path, emu_lib_path):
 
 def test_sharded_deeplab_two_ranks_product_path(tmp_path, emu_lib_path):
     """BASELINE.json config 4: DeepLab-v3+ (MobileNetV2 backbone, 61 convs, 35 relations) sharded over ranks, pinned to
-    4 sweeps here (the CPU emulation is slow; 12 and 60 on the GPU: test_sharded_deeplab_over_rccl_all_ranks, bench.py -- the
+    4 sweeps here (the CPU emulation is slow; 60 on the GPU: test_sharded_network_over_rccl_all_ranks, bench.py -- the
     reference's loop does not terminate on this network) -- the product code path
     (per-rank engine plan over scratch copies, ONE all_gather of the cumulative scale vectors, ONE batched rebuild launch on
     every rank, then the replicated bias correction and int8 quantisation) on the CPU emulation of the kernels, world size 2
@@ -327,7 +327,7 @@ def test_sharded_path_over_rccl_single_rank():
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
     try:
-        for name, sweeps_pin in (('tiny_mobile', 5), ('deeplab_mnv2', 12)):
+        for name, sweeps_pin in (('tiny_mobile', 5), ('deeplab_mnv2', 60)):
             out = []
             for use_sharded in (True, False):
                 model, graph, bottoms = synthetic.build(name, seed=0)
@@ -418,14 +418,16 @@ def _rccl_worker(rank, world, port, name, seed, sweeps, out_dir):
 
 
 @pytest.mark.gpu
-def test_sharded_deeplab_over_rccl_all_ranks(tmp_path):
-    """BASELINE.json config 4 on the hardware it names: DeepLab (35 relations, pinned to 12 sweeps) sharded over
-    min(device_count, 8) ranks, one process per GPU, RCCL all_gather of the cumulative scale vectors over xGMI, then the
-    replicated bias correction and int8 quantisation.  Every rank must hold the SAME BITS in every tensor, corrected bias
-    and int8 code, and they must equal the world-size-1 result (spawned the same way).  On a 1-GPU box only the
+@pytest.mark.parametrize('name,sweeps,n_rel', [('deeplab_mnv2', 60, 35), ('mobilenet_v2', 47, 37)])
+def test_sharded_network_over_rccl_all_ranks(tmp_path, name, sweeps, n_rel):
+    """BASELINE.json config 4 on the hardware it names, in the two configurations bench.py times (`sharded`): DeepLab (35
+    relations, 60 pinned sweeps) and north_star's own graph, the 53-layer MobileNetV2 (37 relations in 16 components, 47 pinned
+    sweeps), sharded over min(device_count, 8) ranks, one process per GPU, RCCL all_gather of the cumulative scale vectors over
+    xGMI, then the replicated bias correction and int8 quantisation.  Every rank must hold the SAME BITS in every tensor,
+    corrected bias and int8 code, and they must equal the world-size-1 result (spawned the same way).  On a 1-GPU box only the
     world-size-1 leg runs (the spawn / device binding / RCCL init code of the N > 1 leg is the same code)."""
     n_dev = torch.cuda.device_count()
-    name, seed, sweeps = 'deeplab_mnv2', 0, 12
+    seed = 0
     worlds = [1] if n_dev < 2 else [1, min(n_dev, 8)]
     res = {}
     for world in worlds:
@@ -442,7 +444,7 @@ def test_sharded_deeplab_over_rccl_all_ranks(tmp_path):
     # the single-process oracle: cumulative scales bit-identical, tensors within 1e-5 (and the canonical rebuild bit for bit)
     model, graph, bottoms, spec = _prepare(name, seed)
     orels = orc.create_relation(spec)
-    assert len(orels) == 35
+    assert len(orels) == n_rel
     _, S_ref = orc.cross_layer_equalization(spec, orels, max_sweeps=sweeps, converge_thres=-1.0, converge_count=10 ** 9)
     for i, s in enumerate(S_ref):
         assert_bitexact(base['S{}'.format(i)], s, 'S{}'.format(i))

@@ -112,9 +112,10 @@ def test_scopes_join_and_clean_up(engine):
         with dfq_amd.staging() as inner:
             assert inner is outer
         assert _ffi.scoped_stage() is outer        # the inner scope did not end the outer one
-        assert _ffi.Stage() is outer
+        assert _ffi.entry_stage() is outer         # what a calibration entry point takes ...
+        assert _ffi.Stage() is not outer           # ... and what a per-call user (QuantMeasure, quantize, prims) takes
     assert _ffi.scoped_stage() is None
-    assert _ffi.Stage() is not outer
+    assert _ffi.entry_stage() is not outer
 
 
 @pytest.mark.gpu
@@ -161,3 +162,46 @@ def test_full_size_cpu_resident_model_in_a_scope_equals_the_device_resident_pass
     for ra, rb in zip(a[3], b[3]):
         assert ra.S.device.type == 'cpu'
         assert torch.equal(ra.S, rb.S.cpu())
+
+
+@pytest.mark.gpu
+def test_per_call_users_do_not_join_the_scope():
+    """a CPU-resident QuantMeasure called inside `with staging():` must keep tracking its range from call to
+    call (its running range and its input change between calls: a scope-long binding would hand every later call the first
+    call's device copy and write the stale copy back when the scope ends), and the scope must not adopt -- or write back over --
+    the activations.  Only the calibration entry points share the scope's stage (_ffi.entry_stage)."""
+    from dfq_amd.utils.quantize import QuantMeasure, quantize
+    _ffi.lib()
+    g = torch.Generator().manual_seed(3)
+    xs = [torch.randn(4, 3, 8, 8, generator=g) * (i + 1) for i in range(3)]
+
+    def run(scoped):
+        qm = QuantMeasure()                                       # CPU-resident module, CPU inputs
+        qm.set_update_stat(True)
+        qm.eval()
+        ins = [x.clone() for x in xs]
+        outs, ranges = [], []
+        ctx = dfq_amd.staging() if scoped else _null()
+        with ctx as st:
+            for x in ins:
+                outs.append(qm(x).clone())
+                ranges.append((float(qm.running_min), float(qm.running_max)))
+            q = quantize(ins[0], 8, -1.0, 1.0)
+            if scoped:
+                assert not st._bound and not st._shadow and not st._packs      # nothing of a per-call user stayed with the scope
+        return outs, ranges, ins, q, (float(qm.running_min), float(qm.running_max))
+
+    import contextlib
+
+    @contextlib.contextmanager
+    def _null():
+        yield None
+
+    a, b = run(False), run(True)
+    assert a[1] == b[1] and a[4] == b[4]
+    assert a[1][0] != a[1][2]                                     # the range did move from call to call
+    for x, y in zip(a[0], b[0]):
+        assert torch.equal(x, y)
+    for x, y in zip(xs, b[2]):
+        assert torch.equal(x, y)                                  # inputs untouched when the scope ended
+    assert torch.equal(a[3], b[3])
