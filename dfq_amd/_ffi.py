@@ -88,6 +88,7 @@ SIGNATURES = {
     'dfq_le_query_all': (c_int32, [c_void_p, c_void_p, POINTER(DfqLeResult), POINTER(c_int32)]),
     'dfq_le_plan_resident_tiles': (c_int32, [c_void_p]),
     'dfq_le_plan_resident_reason': (ctypes.c_char_p, [c_void_p]),
+    'dfq_le_plan_degraded': (c_int32, [c_void_p]),
     'dfq_le_resident_stats': (c_int32, [c_void_p, c_void_p, POINTER(c_int64)]),
     'dfq_le_resident_trace_words': (c_int64, [c_void_p]),
     'dfq_le_resident_trace': (c_int32, [c_void_p, POINTER(DfqLeConfig), c_int32, c_void_p, c_void_p, c_int64]),

@@ -35,10 +35,12 @@ typedef DFQ_GLOBAL_AS fvec4 gfvec4;
 #ifdef DFQ_EMU
 #define DFQ_DYN_SMEM(name) unsigned char* name = emu::cur->smem
 #define DFQ_LAUNCH_RESIDENT(kernel, grid, block, smem, stream, ...) emu::launch_concurrent_k((grid), (block), (smem), kernel, __VA_ARGS__)
+#define DFQ_LAUNCH_RESIDENT_PLAIN(kernel, grid, block, smem, stream, ...) emu::launch_concurrent_k((grid), (block), (smem), kernel, __VA_ARGS__)
 #define DFQ_LAUNCH_SPINNING(kernel, grid, block, smem, stream, ...) emu::launch_concurrent_k((grid), (block), (smem), kernel, __VA_ARGS__)
 #else
 #define DFQ_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
 #define DFQ_LAUNCH_RESIDENT(kernel, grid, block, smem, stream, ...) ::dfq::launch_resident(kernel, grid, block, smem, stream, __VA_ARGS__)
+#define DFQ_LAUNCH_RESIDENT_PLAIN(kernel, grid, block, smem, stream, ...) ::dfq::launch_resident_opt(false, kernel, grid, block, smem, stream, __VA_ARGS__)
 // an ORDINARY launch of a grid whose workgroups wait for each other: the caller sizes it to be co-resident (well below the
 // kernel's occupancy limit) and holds a SpinGuard; cheaper than the cooperative launch (~40 us), for small kernels launched often
 #define DFQ_LAUNCH_SPINNING(kernel, grid, block, smem, stream, ...) hipLaunchKernelGGL(kernel, grid, block, smem, stream, __VA_ARGS__)
@@ -152,9 +154,14 @@ struct DevSlab {
 // launch -- the runtime itself then guarantees co-residency or refuses the launch (hipErrorCooperativeLaunchTooLarge), instead
 // of the plan's own occupancy arithmetic being the only safeguard.  If the runtime refuses (or does not support cooperative
 // launches), the ordinary launch the plan sized for residency is used, as before round 3; DFQ_COOPERATIVE=0 forces that.
+// `coop_default`: what happens without DFQ_COOPERATIVE in the environment (1 / 0 there force either).  The persistent
+// equalisation launch (dfq_le_resident.hip) passes false since round 5: a cooperative launch costs 20-40 us of a 0.65 ms pass
+// (measured: tools/gpu_r05_ab.sh), its plan admits only three quarters of the occupancy limit anyway, and that launch stores ALL
+// OR NOTHING -- an abandoned wait leaves the network untouched and the pass is repeated on per-level launches (dfq_le_run).
 template <typename... Params, typename... Args>
-inline void launch_resident(void (*kernel)(Params...), dim3 grid, dim3 block, size_t smem, hipStream_t stream, Args... args) {
-    static const bool coop = !(getenv("DFQ_COOPERATIVE") && getenv("DFQ_COOPERATIVE")[0] == '0');
+inline void launch_resident_opt(bool coop_default, void (*kernel)(Params...), dim3 grid, dim3 block, size_t smem, hipStream_t stream, Args... args) {
+    static const char* env = getenv("DFQ_COOPERATIVE");
+    const bool coop = (env && (env[0] == '0' || env[0] == '1')) ? env[0] == '1' : coop_default;
     if (coop) {
         std::tuple<Params...> vals{args...};
         void* ptrs[sizeof...(Params)];
@@ -165,6 +172,10 @@ inline void launch_resident(void (*kernel)(Params...), dim3 grid, dim3 block, si
         (void)hipGetLastError();                       // refused: fall through to the ordinary launch
     }
     hipLaunchKernelGGL(kernel, grid, block, smem, stream, args...);
+}
+template <typename... Params, typename... Args>
+inline void launch_resident(void (*kernel)(Params...), dim3 grid, dim3 block, size_t smem, hipStream_t stream, Args... args) {
+    launch_resident_opt(true, kernel, grid, block, smem, stream, args...);
 }
 #endif
 

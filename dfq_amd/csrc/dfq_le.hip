@@ -1678,6 +1678,8 @@ struct dfq_le_plan {
     LeBlockRef* d_blocks = nullptr;        // workgroup table of a sweep: level after level
     unsigned long long* d_dep = nullptr;   // per-relation counters of finished column tiles (padded) + error flag
     bool merged = true;                    // one launch per sweep (false: one per level, DFQ_LE_MERGED=0)
+    bool resident_off = false;             // the resident engine abandoned a wait once (nothing stored): this plan streams from now on
+    int degraded = 0;                      // runs that were repeated on the per-level launches after such an abandon (dfq_le_plan_degraded)
     LeLayerDiff* d_layer_diff = nullptr;
     double* d_partials = nullptr;
     double* d_layer_mean = nullptr;
@@ -2300,20 +2302,22 @@ int dfq_le_plan_create_batch(const dfq_layer* layers, int32_t n_layers, const in
 }
 
 // workgroups (= LDS-resident tiles) of the persistent whole-loop launch, 0 when the plan streams
-int32_t dfq_le_plan_resident_tiles(const dfq_le_plan* p) { return (p && p->resident) ? le_resident_tiles(p->resident) : 0; }
+static inline bool res_on(const dfq_le_plan* p) { return p && p->resident && !p->resident_off; }
+int32_t dfq_le_plan_resident_tiles(const dfq_le_plan* p) { return res_on(p) ? le_resident_tiles(p->resident) : 0; }
+int32_t dfq_le_plan_degraded(const dfq_le_plan* p) { return p ? p->degraded : 0; }
 const char* dfq_le_plan_resident_reason(const dfq_le_plan* p) { return p ? p->resident_why.c_str() : ""; }
 int dfq_le_resident_stats(dfq_le_plan* p, void* stream, int64_t* out5) {
-    if (!p || !p->resident) return fail_arg("dfq_le_resident_stats: not a resident plan");
+    if (!res_on(p)) return fail_arg("dfq_le_resident_stats: not a resident plan");
     return le_resident_stats(p->resident, as_stream(stream), out5);
 }
 // persistent workgroups of a streaming sweep launch (le_sweep_kernel), 0 when the plan launches one workgroup per tile
-int32_t dfq_le_plan_sweep_workgroups(const dfq_le_plan* p) { return (p && !p->resident) ? p->sweep_grid : 0; }
+int32_t dfq_le_plan_sweep_workgroups(const dfq_le_plan* p) { return (p && !res_on(p)) ? p->sweep_grid : 0; }
 
 // Tuning aid: restart, run `n_sweeps` sweeps of the persistent launch with per-tile phase stamps (100 MHz wall clock;
 // [tile][6 sweeps][8 points]: 0 sweep start, 1 s_A solved, 2 row statistics published, 3 s_B solved, 4 new values +
 // statistics published, 5 ticket taken, 6 decision seen; [7] of sweep 0 = layer << 32 | rows << 16 | columns).  Synchronises.
 int dfq_le_resident_trace(dfq_le_plan* p, const dfq_le_config* cfg, int32_t n_sweeps, void* stream, int64_t* out, int64_t capacity) {
-    if (!p || !cfg || !out || !p->resident) return fail_arg("dfq_le_resident_trace: not a resident plan");
+    if (!p || !cfg || !out || !res_on(p)) return fail_arg("dfq_le_resident_trace: not a resident plan");
     const int64_t words = le_resident_trace_words(p->resident);
     if (capacity < words) return fail_arg("dfq_le_resident_trace: need room for %lld words", (long long)words);
     hipStream_t st = as_stream(stream);
@@ -2342,8 +2346,8 @@ int64_t dfq_le_plan_rw_elements(const dfq_le_plan* p) { return p ? p->rw_total :
 int64_t dfq_le_plan_ro_elements(const dfq_le_plan* p) { return p ? p->ro_total : 0; }
 // deferred stores of the streaming engine: elements (a part of rw_elements) that are read every sweep but written only
 // every `depth`-th; depth 1 = every sweep (resident plans, DFQ_LE_DEFER=1)
-int64_t dfq_le_plan_deferred_elements(const dfq_le_plan* p) { return (p && !p->resident) ? p->deferred_total : 0; }
-int32_t dfq_le_plan_defer_depth(const dfq_le_plan* p) { return (p && !p->resident) ? p->defer : 1; }
+int64_t dfq_le_plan_deferred_elements(const dfq_le_plan* p) { return (p && !res_on(p)) ? p->deferred_total : 0; }
+int32_t dfq_le_plan_defer_depth(const dfq_le_plan* p) { return (p && !res_on(p)) ? p->defer : 1; }
 
 // the slice of the sweep's workgroup table that launch `launch` covers
 static bool launch_slice(const dfq_le_plan* p, int launch, int* begin, int* count, int* n_rels, int64_t* rw, int64_t* ro) {
@@ -2522,7 +2526,7 @@ static bool graphs_enabled() {
 int dfq_le_enqueue(dfq_le_plan* p, const dfq_le_config* cfg, int32_t n_sweeps, int32_t restart, void* stream) {
     if (!p || !cfg || n_sweeps < 0) return fail_arg("dfq_le_enqueue: bad argument");
     hipStream_t st = as_stream(stream);
-    if (p->resident) {
+    if (res_on(p)) {
         // one persistent launch runs up to n_sweeps sweeps from the state in d_state (it re-derives the statistics from
         // the weights it loads, so there is nothing to bootstrap and nothing to carry between calls)
         unsigned long long* err = p->d_dep + (size_t)p->n_rels * kDepStride;
@@ -2716,12 +2720,31 @@ int dfq_le_run(dfq_le_plan* p, const dfq_le_config* cfg, void* stream, dfq_le_re
     int32_t done = 0;
     dfq_le_result res;
     int chunk = 8;
-    if (p->resident) {
+    bool streamed = !res_on(p);
+    if (!streamed) {
         // the kernel stops by itself where the reference's loop stops; the reset of the loop state rides on the launch in front of it
         rc = dfq_le_enqueue(p, cfg, cfg->max_sweeps >= 0 ? cfg->max_sweeps : (1 << 30), 1, stream);
         if (rc) return rc;
         rc = dfq_le_query(p, stream, &res, &done);
-        if (rc) return rc;
+        if (rc == DFQ_ERR_STATE) {
+            // A workgroup of the persistent launch gave up a wait (DFQ_SPIN_LIMIT: the chip was not the library's alone for seconds,
+            // or the dispatch the in-launch waits count on did not happen).  The launch stores all or nothing (dfq_le_resident.hip,
+            // "all or nothing"): if no tile stored, the network is exactly as the caller passed it, and the pass is simply run
+            // again -- on ONE LAUNCH PER LEVEL, which waits for nothing inside a launch -- instead of failing.  The plan stays
+            // on that engine (dfq_le_plan_degraded counts the repeats; dfq_le_plan_resident_reason says why).
+            int64_t stored = -1;
+            if (le_resident_stored_tiles(p->resident, as_stream(stream), &stored) != DFQ_OK || stored != 0) return rc;
+            p->resident_off = true;
+            p->merged = false;
+            p->degraded += 1;
+            p->resident_why = "an in-launch wait of the persistent launch was abandoned (nothing had been stored): this plan now runs one launch per level";
+            streamed = true;
+        } else if (rc) {
+            return rc;
+        }
+    }
+    if (!streamed) {
+        // (done above)
     } else if ((rc = dfq_le_enqueue(p, cfg, 0, 1, stream)) != 0) {
         return rc;
     } else if (cfg->max_sweeps >= 0) {

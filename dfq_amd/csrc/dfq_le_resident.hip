@@ -48,7 +48,8 @@ namespace dfq {
 
 constexpr int kResTileFloats = 8192;  // the tile in LDS (32 KB)
 constexpr int kResTab = 1024;        // LDS table entries of a tile: (groups x input channels) it spans
-constexpr int kResRows = 512;        // rows of a tile that needs per-row tables (2 owner rows per thread at most)
+constexpr int kResRows = 256;        // rows of a tile that needs per-row tables: one per thread (512 until round 4: the second row per thread cost eleven vector registers
+                                     // the kernel does not have -- three workgroups per CU -- and no tile of the BASELINE networks used it)
 constexpr int kResOwn = kResRows / kBlock;
 constexpr int kResStride = 16;       // one 64-bit counter per 128-byte line
 constexpr int kResMaxTiles = 1536;   // partials staged in LDS when the sweep's verdict is drawn
@@ -57,6 +58,27 @@ constexpr int kResMaxLayers = 512;
 #define DFQ_RES_LATE_ARRIVE 0         // 1: a strict arrival is made after the sweep's tail instead of right behind the publication (A/B on one
                                      // box, three runs each: 0.759-0.80 vs 0.729-0.766 ms for MobileNetV2, 0.474-0.491 vs 0.457-0.470 ms for
                                      // DeepLab -- the counter moves later than it could and every consumer of the layer with it)
+#endif
+#ifndef DFQ_RES_ABLATE
+#define DFQ_RES_ABLATE 0             // tuning aid, NEVER in the product build: compile work OUT of a sweep to see what its time is made of
+                                     // (tools/gpu_r05_ablate.sh; results are wrong, run with a pinned sweep count).  1: no float64 |dW| chain,
+                                     // 2: no scale solves (s = 1), 4: no row-statistics pass, 8: no phase-3 pass, 16: no statistics fetch,
+                                     // 32: no factor log, 64: no statistics publication (use with 16), 128: no checkpoints
+#endif
+// Round 5, built, parity-green and measured NO faster (tools/gpu_r05_ab.sh, MobileNetV2 47 sweeps / DeepLab 60, two rounds on one box:
+// both on 0.72-0.75 / 0.48 ms, prefetch off 0.69-0.71 / 0.48, both off 0.675-0.69 / 0.48): (1) single-producer COLUMN statistics
+// validated by their tags alone, no poll of the layer's counter (relax_c bits 1, 2); (2) a thread's first statistics words requested
+// BEFORE the sweep's first poll, so that poll and fetch are one trip.  256 threads re-reading tagged words are a heavier poll than one
+// thread on a counter line, and the trips were never what paces a sweep (profiles/r05_resident_ablation.txt).  Opt-in switches:
+#ifndef DFQ_RES_PIPE
+#define DFQ_RES_PIPE 2               // slots of a [256 x float4] tile pass whose LDS reads are in flight together (1: the rolled loop of round 4; measured on one box,
+                                     // two rounds, MobileNetV2 47 sweeps / DeepLab 60: 1 -> 0.69 / 0.48 ms, 2 -> 0.65 / 0.453, 4 -> 0.68 / 0.46)
+#endif
+#ifndef DFQ_RES_PREFETCH
+#define DFQ_RES_PREFETCH 0
+#endif
+#ifndef DFQ_RES_DIRECT_COLS
+#define DFQ_RES_DIRECT_COLS 0
 #endif
 #ifndef DFQ_RES_TOPWAIT
 #define DFQ_RES_TOPWAIT 0            // 1: the sweep's first poll also WAITS for phase 2's counter (A/B; slower: see the loop)
@@ -79,7 +101,9 @@ struct ResTile {                     // one workgroup
     int32_t relax_r;                 // bit 0: every row of this layer lives in ONE tile -> its row statistics have a single producer;
                                      // bit 1: the same holds for relation A's FIRST layer (this tile reads THOSE row statistics: it polls the tagged
                                      // words themselves instead of that layer's counter -- one trip through the memory system less per hand-off)
-    int32_t relax_c;                 // 1: every input channel of this layer lives in ONE tile -> likewise for its column statistics
+    int32_t relax_c;                 // bit 0: every input channel of this layer lives in ONE tile -> likewise for its column statistics;
+                                     // bit 1: the same holds for relation B's SECOND layer (this tile reads THOSE column statistics in phase 2);
+                                     // bit 2: bit 0 and the tile may poll its own column words' tags instead of the layer's counter (DFQ_RES_DIRECT)
     int32_t slot;                    // logical index of the tile (partial-sum slot, checkpoint slot): the table itself is in LAUNCH order
     int32_t log_off;                 // first float of this tile inside an entry of the factor log: 1/s_A per table entry, then s_B per row
 };
@@ -366,6 +390,33 @@ struct LayFixed {
             f(tile + (u * kBlock + (int)threadIdx.x) * 4, row, on);
         }
     }
+    // The element passes of a sweep, kPipe slots at a time: the LDS reads of all of them (tile vectors and per-row factors) are
+    // issued BEFORE the first is used.  (Round 5: a rolled loop with one ds_read_b128 -> s_waitcnt -> arithmetic -> ds_write per slot
+    // paid the LDS latency eight times per pass, and a wave of this kernel has nothing else to issue meanwhile: 71 % of its cycles
+    // were spent parked -- profiles/r05_resident_pmc.txt.)  f(x, xv, sr, row, on) per slot in use, in slot order.
+    static constexpr int kPipe = DFQ_RES_PIPE;
+    template <typename F>
+    __device__ __forceinline__ void slots_piped(const ResTile& T, float* tile, bool useB, const float* sh_s, F f) const {
+        for (int u0 = 0; u0 < n_used; u0 += kPipe) {
+            fvec4 xv[kPipe];
+            float sr[kPipe];
+            int rowj[kPipe];
+            bool onj[kPipe];
+#pragma unroll
+            for (int j = 0; j < kPipe; ++j) {
+                const int u = min(u0 + j, n_used - 1);                 // past the end: the last slot again (read, not used)
+                int row = u * rps + rsub;
+                const bool row_ok = row < T.nr;
+                onj[j] = row_ok && lane_on;
+                rowj[j] = row_ok ? row : T.nr - 1;
+                xv[j] = *(const fvec4*)(tile + (u * kBlock + (int)threadIdx.x) * 4);
+                sr[j] = useB ? sh_s[rowj[j]] : 1.0f;
+            }
+#pragma unroll
+            for (int j = 0; j < kPipe; ++j)
+                if (u0 + j < n_used) f(tile + ((u0 + j) * kBlock + (int)threadIdx.x) * 4, xv[j], sr[j], rowj[j], onj[j]);     // (uniform)
+        }
+    }
     __device__ __forceinline__ void load(const ResTile& T, float* tile) const {
         const gfloat* wt = (const gfloat*)T.w;
         slots(T, tile, [&](float* x, int row, bool) { *(fvec4*)x = *(const gfvec4*)(wt + ((int64_t)(T.r0 + row) * T.row_len + pos)); });
@@ -391,15 +442,24 @@ struct LayFixed {
             const bool wave_on = (((int)threadIdx.x & ~(kWave - 1)) & (tcv - 1)) < (T.nc / 4);   // else: duplicates of the row's last vector only
             for (int u0 = 0; u0 < n_used; u0 += 4) {
                 float mn4[4], mx4[4];
+                fvec4 xv4[4];
+                float sr4[4];
+                int row4[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {                           // all four slots' LDS reads in flight (see slots_piped)
+                    const int u = min(u0 + j, n_used - 1);
+                    int row = u * rps + rsub;
+                    row4[j] = row < T.nr ? row : T.nr - 1;
+                    xv4[j] = *(const fvec4*)(tile + (u * kBlock + (int)threadIdx.x) * 4);
+                    sr4[j] = useB ? sh_s[row4[j]] : 1.0f;
+                }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     mn4[j] = INFINITY; mx4[j] = -INFINITY;
                     if (u0 + j < n_used) {                              // uniform
-                        int row = (u0 + j) * rps + rsub;
-                        row = row < T.nr ? row : T.nr - 1;
-                        if (useA && !one_group) inv4(T, G, sh_inv, row, iv);
-                        const float sr = useB ? sh_s[row] : 1.0f;
-                        const fvec4 xv = *(const fvec4*)(tile + ((u0 + j) * kBlock + (int)threadIdx.x) * 4);
+                        if (useA && !one_group) inv4(T, G, sh_inv, row4[j], iv);
+                        const float sr = sr4[j];
+                        const fvec4 xv = xv4[j];
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
                             const float y = (xv[k] * iv[k]) * sr;        // * 1.0f is exact
@@ -415,10 +475,8 @@ struct LayFixed {
             }
             return;
         }
-        slots(T, tile, [&](float* x, int row, bool on) {
+        slots_piped(T, tile, useB, sh_s, [&](float*, const fvec4& xv, float sr, int row, bool on) {
             if (useA && !one_group) inv4(T, G, sh_inv, row, iv);
-            const float sr = useB ? sh_s[row] : 1.0f;
-            const fvec4 xv = *(const fvec4*)x;
             float mn = INFINITY, mx = -INFINITY;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -454,18 +512,16 @@ struct LayFixed {
         float cmn[4], cmx[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) { cmn[k] = INFINITY; cmx[k] = -INFINITY; }
-        slots(T, tile, [&](float* x, int row, bool on) {
+        slots_piped(T, tile, useB, sh_s, [&](float* x, const fvec4& xv, float sr, int row, bool on) {
             if (useA && !one_group) inv4(T, G, sh_inv, row, iv);
-            const float sr = useB ? sh_s[row] : 1.0f;
             const int gr = one_group ? 0 : group_row(T, G, row);
-            const fvec4 xv = *(const fvec4*)x;
             fvec4 nw;
             double part = 0.0;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const float nv = (xv[k] * iv[k]) * sr;            // dfq.py:73 then :62, both rounded
                 nw[k] = nv;
-                part += (double)abs_f32(nv - xv[k]);
+                if (!(DFQ_RES_ABLATE & 1)) part += (double)abs_f32(nv - xv[k]);
                 if (one_group) {
                     // (no `on` select: the slots of padded lanes / rows hold exact DUPLICATES of valid elements -- loaded as such,
                     // updated with the same factors, checkpointed raw -- and a duplicate changes no minimum or maximum)
@@ -491,10 +547,8 @@ struct LayFixed {
         double acc = 0.0;
         float iv[4] = {1.0f, 1.0f, 1.0f, 1.0f};
         if (useA && one_group) inv4(T, G, sh_inv, 0, iv);
-        slots(T, tile, [&](float* x, int row, bool on) {
+        slots_piped(T, tile, useB, sh_s, [&](float* x, const fvec4& xv, float s, int row, bool on) {
             if (useA && !one_group) inv4(T, G, sh_inv, row, iv);
-            const float s = useB ? sh_s[row] : 1.0f;
-            const fvec4 xv = *(const fvec4*)x;
             fvec4 nv;
             double part = 0.0;
 #pragma unroll
@@ -594,7 +648,7 @@ struct LayShort {
                 float mn = INFINITY, mx = -INFINITY;
                 elems(base, [&](int e, float x) {
                     const float nv = val(x, j, e, useA, fa, fb, sh_inv);
-                    part += (double)abs_f32(nv - x);
+                    if (!(DFQ_RES_ABLATE & 1)) part += (double)abs_f32(nv - x);
                     if (commit) base[e * kBlock] = nv;
                     mn = vmin_raw(mn, nv); mx = vmax_raw(mx, nv);
                 });
@@ -636,6 +690,7 @@ struct LayShort {
 // sh_row -> global row statistics of relation B (rows r0 .. r0 + nr), tagged
 __device__ __forceinline__ void publish_rows(const ResArgs& a, const ResTile& T, int64_t r1_off, const uint32_t* sh_row, uint32_t tag) {
     u64* dst = a.stats + r1_off + (int64_t)(tag & 1u) * a.parity_stride;
+    if (DFQ_RES_ABLATE & 64) return;
     for (int i = threadIdx.x; i < T.nr; i += kBlock) {
         publish_max(dst + 2 * (int64_t)(T.r0 + i), tag, sh_row[2 * i]);
         publish_max(dst + 2 * (int64_t)(T.r0 + i) + 1, tag, sh_row[2 * i + 1]);
@@ -645,10 +700,11 @@ __device__ __forceinline__ void publish_rows(const ResArgs& a, const ResTile& T,
 __device__ __forceinline__ void publish_cols(const ResArgs& a, const ResTile& T, const TileGeo& G, int64_t r2_off,
                                              const uint32_t* sh_col, uint32_t tag) {
     u64* dst = a.stats + r2_off + (int64_t)(tag & 1u) * a.parity_stride;
+    if (DFQ_RES_ABLATE & 64) return;
     for (int idx = threadIdx.x; idx < G.g_n * G.nci; idx += kBlock) {
         const int gq = small_div(idx, G.nci);
         const int c = (G.g_lo + gq) * T.i2g + G.i0 + (idx - gq * G.nci);
-        if (sh_col[2 * idx + 1] != 0u) {              // a channel no element of this tile belongs to stays untouched
+        if ((DFQ_RES_ABLATE & 8) || sh_col[2 * idx + 1] != 0u) {              // a channel no element of this tile belongs to stays untouched
             publish_max(dst + 2 * (int64_t)c, tag, sh_col[2 * idx]);
             publish_max(dst + 2 * (int64_t)c + 1, tag, sh_col[2 * idx + 1]);
         }
@@ -821,7 +877,7 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
             lay.col_stats(T, G, v, false, false, sh_inv, sh_s, sh_col);
             __syncthreads();
             publish_cols(a, T, G, ra_r2, sh_col, 1u);
-            arrive(a.cnt_c, T.layer, !T.relax_c);
+            arrive(a.cnt_c, T.layer, !(T.relax_c & 1));
         }
         if (chain_start) {
             for (int i = tid; i < 2 * T.nr; i += kBlock) sh_row[i] = 0u;
@@ -850,7 +906,7 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
         //      own 16-byte words, whatever the layout) and the thread's [O] entries, fire-and-forget.  Everything is formed from an
         //      index the compiler cannot see through: nothing of this cold block is precomputed and kept in registers across the
         //      sweep loop (the kernel runs AT its register limit) ----
-        if (k > 0 && k % cold(a).ckpt_every == 0) {
+        if (!(DFQ_RES_ABLATE & 128) && k > 0 && k % cold(a).ckpt_every == 0) {
             float* ck = ckpt_slot(k / cold(a).ckpt_every);
             int ti = tid;
             opaque(ti);
@@ -880,45 +936,79 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
         //      1 must not wait for that (the tiles of B's second layer overlap their own work with it).  A chain start paces
         //      itself on its own layer's row counter (its tiles do not otherwise wait for each other, and a tile two
         //      publications ahead of a sibling would make the monotonic counter lie to the layer's consumers). ----
+        // Round 5 experiment, OFF by default (see DFQ_RES_PREFETCH / DFQ_RES_DIRECT_COLS at the top: measured no faster).  The idea
+        // (tools/litmus/handoff_latency.hip: one dependent trip through the memory system is ~0.4 us on an idle chip and
+        // ~1 us inside this kernel, and a sweep of a tile makes two before it can compute anything -- poll, THEN fetch):
+        //   * statistics words with a single producer are validated by their sweep tags, so they need no counter at all: the
+        //     tile's OWN column statistics when every input channel lives in one tile (relax_c bit 0: no poll of the layer's
+        //     counter), those of B's second layer likewise (bit 1), A's row statistics as before (relax_r bit 1);
+        //   * and they are REQUESTED BEFORE the poll (of the speculation bound, the stop and whatever counters are left): when
+        //     they are there -- the usual case behind a busy neighbour -- the poll and the fetch are ONE trip.  A word that is not
+        //     there yet shows an older tag and is read again below, exactly as a relaxed word always was.
+        //   Words merged from several tiles (strict) keep counter -> fetch: their tags cannot tell a complete merge from a partial one.
+        const bool direct_r = hasA && (T.relax_r & 2) != 0, direct_c = hasA && (T.relax_c & 4) != 0 && DFQ_RES_DIRECT_COLS;
+        const bool direct_b = hasB && (T.relax_c & 2) != 0 && DFQ_RES_DIRECT_COLS;
+        RangeWords w1[kResTab / kBlock], w2[kResTab / kBlock], v1[kResOwn], v2[kResOwn];
+        // (only the words of a thread's first kPreJ channels are requested ahead of the poll: the kernel runs AT its register limit --
+        // three workgroups per CU -- and sixteen 64-bit words in flight across the poll spilled; tiles with more than kPreJ * 256 table
+        // entries -- complete rows of 960 floats -- request the rest behind the poll, in the same trip as a retry would make)
+        constexpr int kPreJ = 2;
+        auto fetch_top = [&](int j_lo, int j_hi, bool want1, bool want2, bool wantb) {
+#pragma unroll
+            for (int j = 0; j < kResTab / kBlock; ++j) {
+                if (j >= j_lo && j < j_hi && j * kBlock < n_ch) {     // uniform over the workgroup
+                    const int idx = min(tid + j * kBlock, n_ch - 1);
+                    const int gq = small_div(idx, G.nci);
+                    const int c = (G.g_lo + gq) * T.i2g + G.i0 + (idx - gq * G.nci);
+                    if (DFQ_RES_ABLATE & 16) { w1[j].a = w1[j].b = w2[j].a = w2[j].b = ((u64)tag << 32) | (u64)(uint32_t)c; }
+                    else {
+                    if (want1) w1[j] = load_range(a.stats, ra_r1, a.parity_stride, tag, c);
+                    if (want2) w2[j] = load_range(a.stats, ra_r2, a.parity_stride, tag, c);
+                    }
+                }
+            }
+            if (wantb) {
+#pragma unroll
+                for (int j = 0; j < kResOwn; ++j) {
+                    const int c = T.r0 + min(tid + j * kBlock, T.nr - 1);
+                    if (DFQ_RES_ABLATE & 16) v2[j].a = v2[j].b = ((u64)tag << 32) | (u64)(uint32_t)c;
+                    else v2[j] = load_range(a.stats, rb_r2, a.parity_stride, tag, c);
+                }
+            }
+        };
+        const bool pre = DFQ_RES_PREFETCH != 0;
+        if (pre && (direct_r || direct_c)) fetch_top(0, kPreJ, direct_r, direct_c, false);
         bool have_b = false;
         {
             const int copy = blockIdx.x & 7;
             // (row statistics with a single producer per word are polled directly below: no counter)
-            const u64* c1 = hasA ? ((T.relax_r & 2) ? nullptr : cnt_line(a.cnt_r, T.a_layer, copy)) : (chain_start ? cnt_line(a.cnt_r, T.layer, copy) : nullptr);
+            const u64* c1 = hasA ? (direct_r ? nullptr : cnt_line(a.cnt_r, T.a_layer, copy)) : (chain_start ? cnt_line(a.cnt_r, T.layer, copy) : nullptr);
             const u64 t1 = (u64)(hasA ? T.nt_a : T.nt_self) * round;
-            const u64* c2 = hasA ? cnt_line(a.cnt_c, T.layer, copy) : nullptr;
-            const u64* c3 = hasB ? cnt_line(a.cnt_c, T.b_layer, copy) : nullptr;
+            const u64* c2 = (hasA && !direct_c) ? cnt_line(a.cnt_c, T.layer, copy) : nullptr;
+            const u64* c3 = (hasB && !direct_b) ? cnt_line(a.cnt_c, T.b_layer, copy) : nullptr;
             const int got = res_wait(c1, t1, c2, (u64)T.nt_self * round, c3, (u64)T.nt_b * round, DFQ_RES_TOPWAIT != 0,
                                      prog_line(cold(a).prog, blockIdx.x & 7), (uint32_t)max(k - cold(a).spec, 0), a.err, sh_flag, kResSpinLimit);
             if (!got) { failed = true; break; }
             if (got == 3) { stopped = true; break; }
-            have_b = hasB && got == 2;
+            have_b = hasB && !direct_b && got == 2;          // counter-guarded words of phase 2 are complete: fetched with phase 1's
         }
         res_stamp<kTrace>(a, k, 15);
-        RangeWords w1[kResTab / kBlock], w2[kResTab / kBlock], v1[kResOwn], v2[kResOwn];
         {
             // A word whose producer arrived "relaxed" (see arrive) may still show the previous sweep's tag: read again.  Words
             // merged from several tiles were complete before their counter moved.  Each thread looks after its own words.
+            // Phase 2's single-producer words (direct_b) ride along but are NOT waited for here: the row statistics this tile
+            // publishes in phase 1 must not wait for them (phase 2 polls them itself).
             long tries = 0;
+            bool first = true;
             for (;;) {
                 bool ok = true;
-#pragma unroll
-                for (int j = 0; j < kResTab / kBlock; ++j) {
-                    if (j * kBlock < n_ch) {                              // uniform over the workgroup
-                        const int idx = min(tid + j * kBlock, n_ch - 1);
-                        const int gq = small_div(idx, G.nci);
-                        const int c = (G.g_lo + gq) * T.i2g + G.i0 + (idx - gq * G.nci);
-                        w1[j] = load_range(a.stats, ra_r1, a.parity_stride, tag, c);
-                        w2[j] = load_range(a.stats, ra_r2, a.parity_stride, tag, c);
-                    }
+                if (first) {
+                    fetch_top(0, kPreJ, !(pre && direct_r), !(pre && direct_c), have_b || direct_b);
+                    fetch_top(kPreJ, kResTab / kBlock, true, true, false);
+                } else {
+                    fetch_top(0, kResTab / kBlock, true, true, have_b || direct_b);
                 }
-                if (have_b) {
-#pragma unroll
-                    for (int j = 0; j < kResOwn; ++j) {
-                        const int c = T.r0 + min(tid + j * kBlock, T.nr - 1);
-                        v2[j] = load_range(a.stats, rb_r2, a.parity_stride, tag, c);
-                    }
-                }
+                first = false;
 #pragma unroll
                 for (int j = 0; j < kResTab / kBlock; ++j)
                     if (j * kBlock < n_ch) ok = ok && tagged(w1[j], tag) && tagged(w2[j], tag);
@@ -948,8 +1038,9 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
                     float mn1, mx1, mn2, mx2, s, inv;
                     decode_range(w1[j], tag, mn1, mx1);
                     decode_range(w2[j], tag, mn2, mx2);
-                    le_solve(range_of(mn1, mx1, p.signed_range), range_of(mn2, mx2, p.signed_range), p, s, inv);
-                    if (idx < n_ch) { sh_inv[idx] = inv; lg[lt + (unsigned)(j * kBlock)] = inv; }       // (the log: fire-and-forget)
+                    if (DFQ_RES_ABLATE & 2) { s = 1.0f; inv = 1.0f + 0.0f * (mn1 + mx1 + mn2 + mx2); }
+                    else le_solve(range_of(mn1, mx1, p.signed_range), range_of(mn2, mx2, p.signed_range), p, s, inv);
+                    if (idx < n_ch) { sh_inv[idx] = inv; if (!(DFQ_RES_ABLATE & 32)) lg[lt + (unsigned)(j * kBlock)] = inv; }       // (the log: fire-and-forget)
                 }
             }
             res_stamp<kTrace>(a, k, 1);
@@ -959,7 +1050,7 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
             if (hasB) {
                 // row statistics of t = fl(w * 1/s_A) for relation B of this same sweep (t is not kept: phase 3 recomputes it)
                 res_stamp<kTrace>(a, k, 12);
-                lay.row_stats(T, G, v, true, false, sh_inv, sh_s, sh_row);
+                if (!(DFQ_RES_ABLATE & 4)) lay.row_stats(T, G, v, true, false, sh_inv, sh_s, sh_row);
                 res_stamp<kTrace>(a, k, 13);
                 __syncthreads();
                 publish_rows(a, T, rb_r1, sh_row, tag);
@@ -975,23 +1066,27 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
             // a tile of complete rows already has its rows' statistics (sh_row: this sweep's phase 1, or the previous
             // sweep's phase 3 for a chain start); otherwise they are merged over the row block's tiles in global memory
             const bool own_wait = !rows_local && !chain_start;
-            if (own_wait || !have_b) {
+            const bool cnt_b = !have_b && !direct_b;              // counter-guarded column statistics that were not there at the top
+            if (own_wait || cnt_b) {
                 const int copy = blockIdx.x & 7;
                 const int got = res_wait(own_wait ? cnt_line(a.cnt_r, T.layer, copy) : nullptr, (u64)T.nt_self * round,
-                                         have_b ? nullptr : cnt_line(a.cnt_c, T.b_layer, copy), (u64)T.nt_b * round, nullptr, 0, false,
+                                         cnt_b ? cnt_line(a.cnt_c, T.b_layer, copy) : nullptr, (u64)T.nt_b * round, nullptr, 0, false,
                                          prog_line(cold(a).prog, blockIdx.x & 7), 0u, a.err, sh_flag, kResSpinLimit);
                 if (!got) { failed = true; break; }
                 if (got == 3) { stopped = true; break; }          // (nothing of sweep k has been applied)
             }
             if (!rows_local || !have_b) {
+                // (direct_b: the words requested at the sweep's top are looked at first; only a thread whose words are not there
+                // yet reads again)
                 long tries = 0;
                 for (;;) {
                     bool ok = true;
 #pragma unroll
                     for (int j = 0; j < kResOwn; ++j) {
                         const int c = T.r0 + min(tid + j * kBlock, T.nr - 1);
+                        if (DFQ_RES_ABLATE & 16) { v1[j].a = v1[j].b = v2[j].a = v2[j].b = ((u64)tag << 32) | (u64)(uint32_t)c; continue; }
                         if (!rows_local) v1[j] = load_range(a.stats, rb_r1, a.parity_stride, tag, c);
-                        if (!have_b) v2[j] = load_range(a.stats, rb_r2, a.parity_stride, tag, c);
+                        if (!have_b && !(direct_b && tries == 0 && tagged(v2[j], tag))) v2[j] = load_range(a.stats, rb_r2, a.parity_stride, tag, c);
                     }
 #pragma unroll
                     for (int j = 0; j < kResOwn; ++j) ok = ok && (rows_local || tagged(v1[j], tag)) && (have_b || tagged(v2[j], tag));
@@ -1010,9 +1105,10 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
                     if (rows_local) { mn1 = slot_min(sh_row[2 * i]); mx1 = slot_max(sh_row[2 * i + 1]); }
                     else decode_range(v1[j], tag, mn1, mx1);
                     decode_range(v2[j], tag, mn2, mx2);
-                    le_solve(range_of(mn1, mx1, p.signed_range), range_of(mn2, mx2, p.signed_range), p, s, inv);
+                    if (DFQ_RES_ABLATE & 2) { inv = 1.0f; s = 1.0f + 0.0f * (mn1 + mx1 + mn2 + mx2); }
+                    else le_solve(range_of(mn1, mx1, p.signed_range), range_of(mn2, mx2, p.signed_range), p, s, inv);
                     sh_s[i] = s;                                  // also applied to the [O] vectors below
-                    lg[(unsigned)n_ch + lt + (unsigned)(j * kBlock)] = s;     // (the log: fire-and-forget)
+                    if (!(DFQ_RES_ABLATE & 32)) lg[(unsigned)n_ch + lt + (unsigned)(j * kBlock)] = s;     // (the log: fire-and-forget)
                 }
             }
         }
@@ -1027,7 +1123,9 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
         __syncthreads();
         res_stamp<kTrace>(a, k, 8);
         double acc;
-        if (Lay::kFusedCols && hasA) {
+        if (DFQ_RES_ABLATE & 8) {
+            acc = 0.0;
+        } else if (Lay::kFusedCols && hasA) {
             acc = lay.diff_and_cols(T, G, v, hasA, hasB, sh_inv, sh_s, sh_col, true);
         } else {
             acc = lay.template update<true>(T, G, v, hasA, hasB, sh_inv, sh_s);
@@ -1040,10 +1138,10 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
         // (DFQ_RES_LATE_ARRIVE: a STRICT arrival -- statistics merged from several tiles: the counter may move only once this tile's
         // atomics have been performed, a trip through the memory system -- could be made after the sweep's tail, which would then
         // run while the atomics are in flight.  Measured slower: see the switch.)
-        const bool strict_c = DFQ_RES_LATE_ARRIVE && hasA && !T.relax_c, strict_r = DFQ_RES_LATE_ARRIVE && chain_start && !(T.relax_r & 1);
+        const bool strict_c = DFQ_RES_LATE_ARRIVE && hasA && !(T.relax_c & 1), strict_r = DFQ_RES_LATE_ARRIVE && chain_start && !(T.relax_r & 1);
         if (hasA) {
             publish_cols(a, T, G, ra_r2, sh_col, tag + 1u);
-            if (!strict_c) arrive(a.cnt_c, T.layer, !T.relax_c);
+            if (!strict_c) arrive(a.cnt_c, T.layer, !(T.relax_c & 1));
         }
         if (chain_start) {
             publish_rows(a, T, rb_r1, sh_row, tag + 1u);
@@ -1133,6 +1231,39 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
         __syncthreads();
     }
     if (keep == 0) return;                  // nothing happened: the tensors stay as they are
+    // ---- all or nothing (round 5).  Nothing has been stored into the caller's tensors so far.  A tile stores only once EVERY
+    //      tile of the launch has got this far (one arrival per tile, one more bounded wait): a tile that abandoned a wait never
+    //      arrives, the others give up here in turn, and the launch leaves the network exactly as it found it -- which is what
+    //      lets the host run the pass again on the streaming engine instead of reporting an undefined network (dfq_le_run).
+    //      Tiles that do store count themselves, so the host can tell "nothing was stored" from "the last wait itself timed out
+    //      in some tiles" (then, and only then, the network is undefined as before). ----
+    {
+        u64* commit = prog_line(cold(a).prog, 9);
+        if (tid == 0) {
+            atomicAdd(commit, 1ull);
+            const u64 want = (u64)cold(a).n_tiles;
+            // (this wait is at least 200 000 polls patient whatever DFQ_SPIN_LIMIT says: the tiles reach it up to `spec` sweeps
+            // apart, and a tile that gave up here while the others go on to store is the one case that still leaves an undefined
+            // network behind -- the tests' limit of ONE poll is meant for the waits of the loop)
+            const long patience = kResSpinLimit > 200000 ? kResSpinLimit : 200000;
+            long spins = 0;
+            int ok = 1;
+            while (__hip_atomic_load(commit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+                __builtin_amdgcn_s_sleep(1);
+                ++spins;
+                if (spins > patience ||
+                    ((spins & 255) == 0 && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull)) {
+                    atomicMax(a.err, 1ull);
+                    ok = 0;
+                    break;
+                }
+            }
+            if (ok) atomicAdd(prog_line(cold(a).prog, 10), 1ull);     // this tile stores
+            *sh_flag = ok;
+        }
+        __syncthreads();
+        if (!*sh_flag) return;
+    }
     // ---- write the tile back (once) ----
     lay.store(T, v);
 #pragma unroll
@@ -1315,7 +1446,7 @@ int layout_of(int vec, int row_len, int nc) {
 Shape pick_shape(int R, int C, int vec, int khkw, int go, int i2g, bool need_row, bool need_col, int short_rpt) {
     const int ns4 = kResTileFloats / (4 * kBlock);          // float4 slots per thread
     if (vec == 1 && C <= 32) {               // thread-per-row tiles: complete rows; `short_rpt` rows per thread if they are <= 16 floats
-        int tr = std::min(R, kBlock * (C <= 16 ? short_rpt : 1));
+        int tr = std::min(R, kBlock * (C <= 16 ? std::min(short_rpt, kResOwn) : 1));
         if (need_row) tr = std::min(tr, kResRows);
         if (need_col) while (tr > 1 && max_groups(R, tr, go) * std::min((C + khkw - 1) / khkw + 1, i2g) > kResTab) tr = (tr + 1) / 2;
         return Shape{tr, C};
@@ -1381,6 +1512,16 @@ int le_resident_stats(const LeResident* r, hipStream_t st, int64_t* out5) {
     DFQ_HIP_TRY(hipMemcpyAsync(w, r->d_sync + (size_t)(16 * r->n_pl + 8) * kResStride, sizeof(w), hipMemcpyDeviceToHost, st));
     DFQ_HIP_TRY(hipStreamSynchronize(st));
     out5[0] = (int64_t)w[0]; out5[1] = (int64_t)w[1]; out5[2] = (int64_t)w[2]; out5[3] = r->spec; out5[4] = r->ckpt_every;
+    return DFQ_OK;
+}
+// tiles of the LAST launch that stored their result (0 after an abandoned wait in front of the commit: the network is untouched).
+// Synchronises `st`.
+int le_resident_stored_tiles(const LeResident* r, hipStream_t st, int64_t* out) {
+    if (!r || !out) return fail_arg("le_resident_stored_tiles: bad argument");
+    u64 w = 0;
+    DFQ_HIP_TRY(hipMemcpyAsync(&w, r->d_sync + (size_t)(16 * r->n_pl + 10) * kResStride, sizeof(w), hipMemcpyDeviceToHost, st));
+    DFQ_HIP_TRY(hipStreamSynchronize(st));
+    *out = (int64_t)w;
     return DFQ_OK;
 }
 int le_resident_trace_words(const LeResident* r) { return r ? r->n_tiles * kTraceSweeps * kTracePoints : 0; }
@@ -1491,6 +1632,13 @@ LeResident* le_resident_create(const dfq_layer* layers, int n_layers, const dfq_
         const char* de = getenv("DFQ_RES_DIRECT");                     // A/B switch: 0 = always wait for the counter first
         const bool direct = !(de && de[0] == '0');
         for (ResTile& T : tiles) if (direct && T.a_layer >= 0 && rel_r[T.a_layer]) T.relax_r |= 2;
+        // bit 1 of relax_c: relation B's second layer publishes single-producer column statistics
+        std::vector<int> rel_c(n_pl, 0);
+        for (const ResTile& T : tiles) rel_c[T.layer] = T.relax_c & 1;
+        for (ResTile& T : tiles) {
+            if (direct && T.b_layer >= 0 && rel_c[T.b_layer]) T.relax_c |= 2;
+            if (direct && (T.relax_c & 1)) T.relax_c |= 4;
+        }
     }
     for (ResTile& T : tiles) {
         // tiles per layer (by paired-layer index)
@@ -1556,7 +1704,7 @@ LeResident* le_resident_create(const dfq_layer* layers, int n_layers, const dfq_
         ld[l].n_tiles = tile_count[l];
         ld[l].n_elems = (double)((int64_t)layers[l].out_ch * layers[l].in_per_group * layers[l].khkw);
     }
-    r->sync_words = (size_t)(16 * n_pl + 9) * kResStride;                   // counters [2][n_pl][8] | progress word [8] | rollback statistics
+    r->sync_words = (size_t)(16 * n_pl + 11) * kResStride;                  // counters [2][n_pl][8] | progress word [8] | rollback statistics | commit arrivals | tiles that stored
     {   // speculation depth / checkpoint period (A/B switches)
         const char* se = getenv("DFQ_RES_SPEC");
         const char* ce = getenv("DFQ_RES_CKPT");
@@ -1626,9 +1774,9 @@ int le_resident_enqueue(LeResident* r, const dfq_le_config* cfg, LeState* d_stat
     if (d_trace) {
         if (kResSmemBytes > 48 * 1024)
             DFQ_HIP_TRY(hipFuncSetAttribute((const void*)le_resident_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kResSmemBytes));
-        DFQ_LAUNCH_RESIDENT(le_resident_kernel<true>, dim3(r->n_tiles + 1), dim3(kBlock), kResSmemBytes, st, a, q);
+        DFQ_LAUNCH_RESIDENT_PLAIN(le_resident_kernel<true>, dim3(r->n_tiles + 1), dim3(kBlock), kResSmemBytes, st, a, q);
     } else {
-        DFQ_LAUNCH_RESIDENT(le_resident_kernel<false>, dim3(r->n_tiles + 1), dim3(kBlock), kResSmemBytes, st, a, q);
+        DFQ_LAUNCH_RESIDENT_PLAIN(le_resident_kernel<false>, dim3(r->n_tiles + 1), dim3(kBlock), kResSmemBytes, st, a, q);
     }
     DFQ_CHECK_LAUNCH();
     return DFQ_OK;

@@ -16,6 +16,7 @@ LeResident* le_resident_create(const dfq_layer* layers, int n_layers, const dfq_
 void le_resident_destroy(LeResident* r);
 int le_resident_tiles(const LeResident* r);
 int le_resident_stats(const LeResident* r, hipStream_t st, int64_t* out5);   // rollbacks of the last launch (tests, tuning)
+int le_resident_stored_tiles(const LeResident* r, hipStream_t st, int64_t* out);   // tiles of the last launch that stored (0: network untouched)
 int64_t le_resident_elements(const LeResident* r);
 // ONE launch: load, run up to n_sweeps sweeps of the loop whose state is *d_state (stops early when the reference's
 // exit test fires), store.  Asynchronous on `st`.

@@ -118,6 +118,12 @@ class LEPlan:
         return (_ffi.lib().dfq_le_plan_resident_reason(self._plan) or b'').decode()
 
     @property
+    def degraded(self):
+        """runs of this plan that were repeated on per-level launches after the persistent launch abandoned a wait with
+        nothing stored (dfq_le_plan_degraded); 0 in normal operation"""
+        return _ffi.lib().dfq_le_plan_degraded(self._plan)
+
+    @property
     def depth(self):
         """dependency levels of the relation list (levels = equalisation launches per sweep: 1 unless DFQ_LE_MERGED=0)"""
         return _ffi.lib().dfq_le_plan_depth(self._plan)

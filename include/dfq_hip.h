@@ -158,6 +158,13 @@ int dfq_le_plan_level_grid(const dfq_le_plan* plan, int32_t level, int32_t* grid
  * bit-identical either way. */
 int32_t dfq_le_plan_resident_tiles(const dfq_le_plan* plan);
 const char* dfq_le_plan_resident_reason(const dfq_le_plan* plan);
+/* The persistent launch stores ALL OR NOTHING (round 5): its tiles write their result back only once every tile has finished
+ * the loop.  If a workgroup abandons an in-launch wait (DFQ_SPIN_LIMIT), no tile stores, the caller's tensors are exactly as
+ * they were passed, and dfq_le_run repeats the pass on one launch per level -- which waits for nothing inside a launch --
+ * instead of returning DFQ_ERR_STATE; the plan then stays on that engine (dfq_le_plan_resident_tiles becomes 0,
+ * dfq_le_plan_resident_reason says why).  Number of runs of this plan that were repeated that way (0 in normal operation).
+ * The reference's loop (dfq.py:78-117) has no counterpart: it cannot fail half way. */
+int32_t dfq_le_plan_degraded(const dfq_le_plan* plan);
 /* The resident launch applies every sweep to its LDS tiles AT ONCE and learns only later (from a reducer workgroup, off every
  * dependency chain) whether dfq.py:105-115 let that sweep happen: a tile may be up to `spec` sweeps past the stopping point
  * and then restores the newest of its checkpoints and replays the logged per-channel factors (bit-identical: the same two

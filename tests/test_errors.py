@@ -2,10 +2,13 @@
 message in dfq_last_error(); geometry the reference would mis-handle silently is rejected; nothing aborts."""
 import ctypes
 
+import numpy as np
 import pytest
 import torch
 
 from dfq_amd import _ffi, dfq, prims
+
+from common import npy
 
 
 def _w(engine, *shape):
@@ -117,6 +120,33 @@ def test_abandoned_in_launch_wait_is_reported_not_silent(engine, monkeypatch, wh
     dfq.clear_plan_cache()
     monkeypatch.setenv('DFQ_SPIN_LIMIT', '1')
     model, graph, bottoms, rels = fresh()
+    if which == 'resident':
+        # Round 5: the persistent launch stores ALL OR NOTHING, so an abandoned wait is no longer an error of the drop-in call:
+        # nothing was stored, the pass is repeated on one launch per level (test_abandoned_resident_launch_degrades below).
+        # The report itself is still there one level down: the plan's enqueue / query pair.
+        plan = dfq.build_le_plan(graph, rels, TARG)
+        assert plan.resident_tiles > 0, plan.resident_reason
+        before = {k: npy(m.weight).copy() for k, m in graph.items() if type(m) in TARG}
+        gave_up = False
+        for attempt in range(4):
+            plan.enqueue(6, restart=True, converge_thres=-1.0, converge_count=10 ** 9)
+            try:
+                plan.query()
+            except _ffi.DfqError as e:
+                assert 'gave up' in str(e), str(e)
+                gave_up = True
+                break
+        if engine.kind == 'gpu' or gave_up:
+            assert gave_up, 'a spin limit of one poll must make some wait of the launch give up'
+            for k, w in before.items():                         # ... and the abandoned launch stored NOTHING
+                assert np.array_equal(npy(graph[k].weight).view(np.int32), w.view(np.int32)), k
+        plan.close()
+        monkeypatch.delenv('DFQ_SPIN_LIMIT')
+        model, graph, bottoms, rels = fresh()
+        dfq.cross_layer_equalization(graph, rels, TARG, max_sweeps=6, converge_thres=-1.0, converge_count=10 ** 9)
+        assert dfq.last_equalization['sweeps'] == 6
+        dfq.clear_plan_cache()
+        return
     failed = False
     for attempt in range(4):          # whether a wait misses its first look is a matter of timing: a few tries make it certain
         try:
@@ -141,6 +171,63 @@ def test_abandoned_in_launch_wait_is_reported_not_silent(engine, monkeypatch, wh
     for m in graph.values():
         if type(m) in TARG:
             assert torch.isfinite(m.weight).all() and (m.bias is None or torch.isfinite(m.bias).all())
+    dfq.clear_plan_cache()
+
+
+def test_abandoned_resident_launch_degrades_to_per_level_launches(engine, monkeypatch):
+    """VERDICT r4 item 7.  DFQ_SPIN_LIMIT=1 makes a wait of the persistent equalisation launch give up.  The launch stores all or
+    nothing (its tiles write back only once every tile has finished the loop), so the caller's tensors are untouched, and
+    `dfq_le_run` -- the drop-in `cross_layer_equalization` -- repeats the pass on one launch per level (no wait inside a launch)
+    instead of raising: same sweep count, tensors, [O] vectors and cumulative scales as an undisturbed run, bit for bit; the plan
+    says that it degraded and stays on the per-level engine."""
+    import torch.nn as nn
+    from dfq_amd import synthetic
+    from dfq_amd.utils import layer_transform as lt
+    from dfq_amd.utils import relation as rel
+    from common import snapshot
+    TARG = [nn.Conv2d, nn.Linear]
+
+    def fresh():
+        model, graph, bottoms = synthetic.build('tiny_mobile', seed=0)
+        model.to(engine.device)
+        lt.merge_batchnorm(model, graph, bottoms, TARG)
+        return model, graph, bottoms, rel.create_relation(graph, bottoms, TARG)
+
+    dfq.clear_plan_cache()
+    model, graph, bottoms, rels = fresh()
+    dfq.cross_layer_equalization(graph, rels, TARG)
+    want, want_sweeps, want_S = snapshot(graph), dfq.last_equalization['sweeps'], [npy(r.get_scale_vec()) for r in rels]
+    dfq.clear_plan_cache()
+
+    monkeypatch.setenv('DFQ_SPIN_LIMIT', '1')
+    degraded = 0
+    for attempt in range(4):          # whether a wait misses its first look is a matter of timing
+        model, graph, bottoms, rels = fresh()
+        plan = dfq.build_le_plan(graph, rels, TARG)
+        assert plan.resident_tiles > 0, plan.resident_reason
+        res = plan.run()                                        # dfq_le_run: what the drop-in entry point calls
+        degraded = plan.degraded
+        assert res['sweeps'] == want_sweeps
+        got = snapshot(graph)
+        for k in want:
+            assert np.array_equal(got[k].view(np.int32), want[k].view(np.int32)), k
+        for sc, s in zip(plan.scale_cum, want_S):
+            assert np.array_equal(npy(sc).view(np.int32), s.view(np.int32))
+        if degraded:
+            assert plan.resident_tiles == 0 and 'abandoned' in plan.resident_reason and plan.levels > 1
+            assert plan.run.__self__ is plan
+            plan.close()
+            break
+        plan.close()
+    if engine.kind == 'gpu':
+        assert degraded == 1, 'a spin limit of one poll must make some wait of the persistent launch give up'
+    # the drop-in entry point: no exception, the reference's answer
+    model, graph, bottoms, rels = fresh()
+    dfq.cross_layer_equalization(graph, rels, TARG)
+    assert dfq.last_equalization['sweeps'] == want_sweeps
+    got = snapshot(graph)
+    for k in want:
+        assert np.array_equal(got[k].view(np.int32), want[k].view(np.int32)), k
     dfq.clear_plan_cache()
 
 
