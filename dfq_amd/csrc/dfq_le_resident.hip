@@ -70,6 +70,22 @@ constexpr int kResMaxLayers = 512;
 // validated by their tags alone, no poll of the layer's counter (relax_c bits 1, 2); (2) a thread's first statistics words requested
 // BEFORE the sweep's first poll, so that poll and fetch are one trip.  256 threads re-reading tagged words are a heavier poll than one
 // thread on a counter line, and the trips were never what paces a sweep (profiles/r05_resident_ablation.txt).  Opt-in switches:
+#ifndef DFQ_RES_NAP
+#define DFQ_RES_NAP 1                // s_sleep units (64 clocks) between two looks of a waiting wave
+#endif
+#ifndef DFQ_RES_PRIO
+#define DFQ_RES_PRIO 1               // 1: a wave raises its issue priority for the element passes (the waves it shares a SIMD with mostly poll)
+#endif
+#ifndef DFQ_RES_SPLIT_AB
+#define DFQ_RES_SPLIT_AB 0             // 1: the tile body compiled per (A, B) case (measured: MobileNetV2 -2 %, DeepLab +2 % -- noise; three times the code)
+#endif
+#ifndef DFQ_RES_HOT
+#define DFQ_RES_HOT 1                // 0: every [256 x float4] tile runs the generic phase-3 loop (round 4)
+#endif
+#ifndef DFQ_RES_COMMIT
+#define DFQ_RES_COMMIT 1             // 0 (A/B only): tiles store as soon as they have finished themselves, as until round 4 (an abandoned wait then leaves
+                                     // an undefined network behind and dfq_le_run must not repeat the pass)
+#endif
 #ifndef DFQ_RES_PIPE
 #define DFQ_RES_PIPE 2               // slots of a [256 x float4] tile pass whose LDS reads are in flight together (1: the rolled loop of round 4; measured on one box,
                                      // two rounds, MobileNetV2 47 sweeps / DeepLab 60: 1 -> 0.69 / 0.48 ms, 2 -> 0.65 / 0.453, 4 -> 0.68 / 0.46)
@@ -503,9 +519,56 @@ struct LayFixed {
             for (int k = 0; k < 4; ++k) lds_minmax(sh_col + 2 * tabk[k], cmn[k], cmx[k]);
         }
     }
+    // The hot form of the phase-3 pass, compiled for its case (round 5): ONE group (the thread's four 1/s_A stay in registers, the
+    // column statistics too), relation A present, w <- new in the same pass, and `UB` (relation B present) a template switch --
+    // every tile of a pointwise layer behind a depthwise or a pointwise one.  The generic loop below decides all of that per
+    // slot with uniform branches and keeps both arms in the loop body: ~90 issued instructions per float4 slot where this
+    // needs ~40, and a pass of a [8 x 960] tile took 3.0 us where the bare loop takes 0.7 (tools/litmus/lds_pass.hip).
+    template <bool UB>
+    __device__ __forceinline__ double diff_and_cols_hot(const ResTile& T, const TileGeo& G, float* tile, const float* sh_inv,
+                                                        const float* sh_s, uint32_t* sh_col) const {
+        double acc = 0.0;
+        float iv[4];
+        inv4(T, G, sh_inv, 0, iv);
+        float cmn[4], cmx[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { cmn[k] = INFINITY; cmx[k] = -INFINITY; }
+        const int tid4 = (int)threadIdx.x * 4;
+        const int nr_last = T.nr - 1;
+        for (int u0 = 0; u0 < n_used; u0 += 2) {
+            const int u1 = min(u0 + 1, n_used - 1);                        // an odd count: the last slot twice (second copy unused)
+            const int ra = u0 * rps + rsub, rb = u1 * rps + rsub;
+            float* xa = tile + u0 * (kBlock * 4) + tid4;
+            float* xb = tile + u1 * (kBlock * 4) + tid4;
+            const fvec4 va = *(const fvec4*)xa, vb = *(const fvec4*)xb;
+            float sa = 1.0f, sb = 1.0f;
+            if (UB) { sa = sh_s[min(ra, nr_last)]; sb = sh_s[min(rb, nr_last)]; }
+            const bool on_a = ra < T.nr && lane_on, on_b = rb < T.nr && lane_on && (u0 + 1 < n_used);
+            fvec4 na, nb;
+            double pa = 0.0, pb = 0.0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                na[k] = UB ? (va[k] * iv[k]) * sa : va[k] * iv[k];        // dfq.py:73 then :62, both rounded
+                nb[k] = UB ? (vb[k] * iv[k]) * sb : vb[k] * iv[k];
+                if (!(DFQ_RES_ABLATE & 1)) { pa += (double)abs_f32(na[k] - va[k]); pb += (double)abs_f32(nb[k] - vb[k]); }
+                // (no `on` select: padded lanes / rows hold exact duplicates of valid elements; the unused second copy of an odd
+                // count's last slot is such a duplicate too)
+                cmn[k] = vmin_raw(vmin_raw(cmn[k], na[k]), nb[k]);
+                cmx[k] = vmax_raw(vmax_raw(cmx[k], na[k]), nb[k]);
+            }
+            *(fvec4*)xa = na;
+            if (u0 + 1 < n_used) *(fvec4*)xb = nb;                         // (uniform)
+            acc += on_a ? pa : 0.0;                                        // slot order, as the generic loop sums
+            acc += on_b ? pb : 0.0;
+        }
+        cols_finish(cmn, cmx, sh_col);
+        return acc;
+    }
     // one pass: |dW| and the column statistics of the new values; `commit`: w <- new in the same pass
     __device__ __forceinline__ double diff_and_cols(const ResTile& T, const TileGeo& G, float* tile, bool useA, bool useB,
                                                     const float* sh_inv, const float* sh_s, uint32_t* sh_col, bool commit = false) const {
+        if (DFQ_RES_HOT && one_group && useA && commit)
+            return useB ? diff_and_cols_hot<true>(T, G, tile, sh_inv, sh_s, sh_col) : diff_and_cols_hot<false>(T, G, tile, sh_inv, sh_s, sh_col);
         double acc = 0.0;
         float iv[4] = {1.0f, 1.0f, 1.0f, 1.0f};
         if (useA && one_group) inv4(T, G, sh_inv, 0, iv);
@@ -697,16 +760,20 @@ __device__ __forceinline__ void publish_rows(const ResArgs& a, const ResTile& T,
     }
 }
 // sh_col -> global column statistics of relation A, tagged
+// (and the table entry goes back to the identity 0 behind the read: the next sweep's pass accumulates into it without a clearing
+// loop and a barrier of its own in front of it -- round 5)
 __device__ __forceinline__ void publish_cols(const ResArgs& a, const ResTile& T, const TileGeo& G, int64_t r2_off,
-                                             const uint32_t* sh_col, uint32_t tag) {
+                                             uint32_t* sh_col, uint32_t tag) {
     u64* dst = a.stats + r2_off + (int64_t)(tag & 1u) * a.parity_stride;
-    if (DFQ_RES_ABLATE & 64) return;
     for (int idx = threadIdx.x; idx < G.g_n * G.nci; idx += kBlock) {
+        if (DFQ_RES_ABLATE & 64) { sh_col[2 * idx] = 0u; sh_col[2 * idx + 1] = 0u; continue; }
         const int gq = small_div(idx, G.nci);
         const int c = (G.g_lo + gq) * T.i2g + G.i0 + (idx - gq * G.nci);
-        if ((DFQ_RES_ABLATE & 8) || sh_col[2 * idx + 1] != 0u) {              // a channel no element of this tile belongs to stays untouched
-            publish_max(dst + 2 * (int64_t)c, tag, sh_col[2 * idx]);
-            publish_max(dst + 2 * (int64_t)c + 1, tag, sh_col[2 * idx + 1]);
+        const uint32_t lo = sh_col[2 * idx], hi = sh_col[2 * idx + 1];
+        if ((DFQ_RES_ABLATE & 8) || hi != 0u) {                               // a channel no element of this tile belongs to stays untouched
+            publish_max(dst + 2 * (int64_t)c, tag, lo);
+            publish_max(dst + 2 * (int64_t)c + 1, tag, hi);
+            sh_col[2 * idx] = 0u; sh_col[2 * idx + 1] = 0u;
         }
     }
 }
@@ -769,7 +836,7 @@ __device__ __forceinline__ int res_wait(const u64* w1, u64 t1, const u64* w2, u6
             const u64 pg = __hip_atomic_load(prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if ((uint32_t)(pg >> 32) != 0u) { ok = 3; break; }
             if (a1 >= t1 && a2 >= t2 && (a3 >= t3 || !need3) && (uint32_t)pg >= need_v) { ok = (a3 >= t3) ? 2 : 1; break; }
-            __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_s_sleep(DFQ_RES_NAP);
             ++spins;
             if (spins > kResSpinLimit ||
                 ((spins & 255) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull)) {
@@ -796,7 +863,7 @@ __device__ __forceinline__ int res_final(const u64* prog, int applied, u64* err,
             const u64 pg = __hip_atomic_load(prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if ((uint32_t)(pg >> 32) != 0u) { keep = min((int)(uint32_t)(pg >> 32), applied); break; }
             if ((uint32_t)pg >= (uint32_t)applied) { keep = applied; break; }
-            __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_s_sleep(DFQ_RES_NAP);
             ++spins;
             if (spins > kResSpinLimit ||
                 ((spins & 255) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull)) {
@@ -812,7 +879,9 @@ __device__ __forceinline__ int res_final(const u64* prog, int applied, u64* err,
     return keep;
 }
 
-template <typename Lay, bool kTrace>
+// kAB: bit 0 -- the layer is the SECOND layer of a relation (A), bit 1 -- the FIRST layer of one (B).  Template switches (round 5: as
+// run-time flags both arms of every `if (hasA)` / `if (hasB)` sat in the sweep loop and were branched around; DFQ_RES_SPLIT_AB=0)
+template <typename Lay, bool kTrace, int kAB>
 __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& p, const ResTile& T, unsigned char* smem) {
     // LDS: [tile: kResTileFloats f32][inv: kResTab f32][s: kResRows f32][row stats: 2 * kResRows u32][col stats: 2 * kResTab u32][flags: 16 words]
     //      [b1 of the owned rows: kResRows f32 -- one of the four [O] vectors lives here instead of in registers: the kernel runs AT its
@@ -828,7 +897,7 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
     if (threadIdx.x == 0) *sh_bad = 0;
     const int tid = threadIdx.x;
     const long kResSpinLimit = p.spin_limit;
-    const bool hasA = T.relA >= 0, hasB = T.relB >= 0;
+    const bool hasA = kAB < 0 ? T.relA >= 0 : (kAB & 1) != 0, hasB = kAB < 0 ? T.relB >= 0 : (kAB & 2) != 0;
     const bool chain_start = hasB && !hasA;
     const bool rows_local = T.nc == T.row_len;       // the tile holds complete rows: its row statistics are final
     // only the statistics offsets of the two relations stay live through the loop (scalar registers are the scarce resource
@@ -1017,7 +1086,7 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
                     for (int j = 0; j < kResOwn; ++j) ok = ok && tagged(v2[j], tag);
                 }
                 if (ok) break;
-                __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_s_sleep(DFQ_RES_NAP);
                 ++tries;
                 // the producer may have left: the loop has stopped (sweep k does not happen then, whatever this tile makes of it)
                 if ((tries & 7) == 0 && (uint32_t)(ld_word(prog_line(cold(a).prog, blockIdx.x & 7)) >> 32) != 0u) { *sh_bad = 2; break; }
@@ -1050,7 +1119,9 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
             if (hasB) {
                 // row statistics of t = fl(w * 1/s_A) for relation B of this same sweep (t is not kept: phase 3 recomputes it)
                 res_stamp<kTrace>(a, k, 12);
+                if (DFQ_RES_PRIO) __builtin_amdgcn_s_setprio(3);
                 if (!(DFQ_RES_ABLATE & 4)) lay.row_stats(T, G, v, true, false, sh_inv, sh_s, sh_row);
+                if (DFQ_RES_PRIO) __builtin_amdgcn_s_setprio(0);
                 res_stamp<kTrace>(a, k, 13);
                 __syncthreads();
                 publish_rows(a, T, rb_r1, sh_row, tag);
@@ -1091,7 +1162,7 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
 #pragma unroll
                     for (int j = 0; j < kResOwn; ++j) ok = ok && (rows_local || tagged(v1[j], tag)) && (have_b || tagged(v2[j], tag));
                     if (ok) break;
-                    __builtin_amdgcn_s_sleep(1);
+                    __builtin_amdgcn_s_sleep(DFQ_RES_NAP);
                     ++tries;
                     if ((tries & 7) == 0 && (uint32_t)(ld_word(prog_line(cold(a).prog, blockIdx.x & 7)) >> 32) != 0u) { *sh_bad = 2; break; }
                     if (tries > kResSpinLimit / 16) { atomicMax(a.err, 1ull); *sh_bad = 1; break; }
@@ -1102,7 +1173,10 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
                 const int i = tid + j * kBlock;
                 if (i < T.nr) {
                     float mn1, mx1, mn2, mx2, s, inv;
-                    if (rows_local) { mn1 = slot_min(sh_row[2 * i]); mx1 = slot_max(sh_row[2 * i + 1]); }
+                    if (rows_local) {
+                        mn1 = slot_min(sh_row[2 * i]); mx1 = slot_max(sh_row[2 * i + 1]);
+                        if (chain_start) { sh_row[2 * i] = 0u; sh_row[2 * i + 1] = 0u; }     // phase 3 accumulates the next sweep's into it
+                    }
                     else decode_range(v1[j], tag, mn1, mx1);
                     decode_range(v2[j], tag, mn2, mx2);
                     if (DFQ_RES_ABLATE & 2) { inv = 1.0f; s = 1.0f + 0.0f * (mn1 + mx1 + mn2 + mx2); }
@@ -1116,22 +1190,27 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
         // ---- phase 3: w <- fl(fl(w / s_A) * s_B) (dfq.py:73 then :62, both rounded), |dW| and the statistics of the new values
         //      in ONE pass over the tile.  Applied at once: whether sweep k happens at all is found out later (see
         //      "speculation past the verdict"). ----
-        __syncthreads();                                          // sh_s complete; sh_row / sh_col free
+        __syncthreads();                                          // sh_s complete; sh_col is all zero since its publication, a chain start's sh_row since phase 2
         if (*sh_bad) break;                                       // a statistics word of phase 2 never showed this sweep's tag (or the loop stopped)
-        if (hasA) for (int i = tid; i < 2 * G.g_n * G.nci; i += kBlock) sh_col[i] = 0u;
-        if (chain_start) for (int i = tid; i < 2 * T.nr; i += kBlock) sh_row[i] = 0u;
-        __syncthreads();
+        if (chain_start && !rows_local) {                         // (never with the shapes pick_shape chooses: a chain start whose rows are cut)
+            for (int i = tid; i < 2 * T.nr; i += kBlock) sh_row[i] = 0u;
+            __syncthreads();
+        }
         res_stamp<kTrace>(a, k, 8);
         double acc;
+        if (DFQ_RES_PRIO) __builtin_amdgcn_s_setprio(3);
         if (DFQ_RES_ABLATE & 8) {
             acc = 0.0;
         } else if (Lay::kFusedCols && hasA) {
+            if (DFQ_RES_ABLATE & 256) { double junk = lay.diff_and_cols(T, G, v, hasA, hasB, sh_inv, sh_s, sh_col, false); if (junk == -1.0) sh_s[0] = 0.0f; }   // the pass TWICE: its marginal cost
+            if (DFQ_RES_ABLATE & 512) { lay.row_stats(T, G, v, hasA, hasB, sh_inv, sh_s, sh_row); }                  // + a read-only statistics pass
             acc = lay.diff_and_cols(T, G, v, hasA, hasB, sh_inv, sh_s, sh_col, true);
         } else {
             acc = lay.template update<true>(T, G, v, hasA, hasB, sh_inv, sh_s);
             if (hasA) lay.col_stats(T, G, v, false, false, sh_inv, sh_s, sh_col);      // of the values just written
         }
         if (chain_start) lay.row_stats(T, G, v, false, false, sh_inv, sh_s, sh_row);
+        if (DFQ_RES_PRIO) __builtin_amdgcn_s_setprio(0);
         res_stamp<kTrace>(a, k, 9);
         __syncthreads();
         res_stamp<kTrace>(a, k, 10);
@@ -1151,7 +1230,7 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
         // ---- convergence: one partial per tile (fixed butterfly + fixed wave order) as two tagged words; the reducer workgroup
         //      reads them until they carry k + 1, sums them per layer and draws the verdict -- off every tile's path ----
         {
-            const double tsum = block_sum(acc, (double*)sh_col);     // sh_col is free again (statistics published)
+            const double tsum = block_sum(acc, (double*)(sh_flag + 4));   // (four doubles in the flag block; sh_col stays all zero for the next pass)
             if (tid == 0) {
                 const auto& c = cold(a);
                 u64* dst = (u64*)c.partials + ((int64_t)(k % c.part_ring) * c.n_tiles + T.slot) * 2;
@@ -1162,6 +1241,12 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
             res_stamp<kTrace>(a, k, 5);
         }
         if (kTrace && tid == 0 && k == 0) cold(a).trace[((int64_t)blockIdx.x * kTraceSweeps) * kTracePoints + 7] = ((long long)T.layer << 32) | (unsigned)T.nr << 16 | (unsigned)(T.nc & 0xffff);
+#if defined(__HIP_DEVICE_COMPILE__)
+        // where the workgroup runs (tuning aid): XCC_ID (hwreg 20) and HW_ID (hwreg 4: cu_id [11:8], sh_id [12], se_id [15:13])
+        if (kTrace && tid == 0 && k == 1)
+            cold(a).trace[((int64_t)blockIdx.x * kTraceSweeps + 1) * kTracePoints + 7] =
+                ((long long)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 15u) << 32) | (long long)(__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)));
+#endif
         if (hasB) {
 #pragma unroll
             for (int j = 0; j < kResOwn; ++j) {
@@ -1237,7 +1322,7 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
     //      lets the host run the pass again on the streaming engine instead of reporting an undefined network (dfq_le_run).
     //      Tiles that do store count themselves, so the host can tell "nothing was stored" from "the last wait itself timed out
     //      in some tiles" (then, and only then, the network is undefined as before). ----
-    {
+    if (DFQ_RES_COMMIT) {
         u64* commit = prog_line(cold(a).prog, 9);
         if (tid == 0) {
             atomicAdd(commit, 1ull);
@@ -1249,7 +1334,7 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
             long spins = 0;
             int ok = 1;
             while (__hip_atomic_load(commit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
-                __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_s_sleep(DFQ_RES_NAP);
                 ++spins;
                 if (spins > patience ||
                     ((spins & 255) == 0 && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull)) {
@@ -1312,7 +1397,7 @@ __device__ __forceinline__ void res_reducer_body(const ResArgs& a, const LeParam
             for (;;) {
                 hi = ld_word(part + 2 * i); lo = ld_word(part + 2 * i + 1);
                 if ((hi >> 32) == want && (lo >> 32) == want) break;
-                __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_s_sleep(DFQ_RES_NAP);
                 if (++tries > kResSpinLimit ||
                     ((tries & 255) == 0 && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull)) {
                     atomicMax(a.err, 1ull); *sh_bad = 1; break;
@@ -1382,10 +1467,21 @@ __global__ __launch_bounds__(kBlock, 3) void le_resident_kernel(ResArgs a, LePar
     if (a.state->done) return;              // already stopped (uniform over the launch: written before it started)
     if ((int)blockIdx.x == a.n_tiles) { res_reducer_body(a, p, smem); return; }
     const ResTile T = a.tiles[blockIdx.x];
-    if (T.layout == kLayFixed) res_tile_body<LayFixed, kTrace>(a, p, T, smem);
-    else if (T.layout == kLayShort) res_tile_body<LayShort, kTrace>(a, p, T, smem);
-    else if (T.vec == 4) res_tile_body<LayGeneral<4>, kTrace>(a, p, T, smem);
-    else res_tile_body<LayGeneral<1>, kTrace>(a, p, T, smem);
+#if DFQ_RES_SPLIT_AB
+#define DFQ_RES_BODY(LAY)                                                                     \
+    do {                                                                                      \
+        if (T.relA >= 0 && T.relB >= 0) res_tile_body<LAY, kTrace, 3>(a, p, T, smem);         \
+        else if (T.relA >= 0) res_tile_body<LAY, kTrace, 1>(a, p, T, smem);                   \
+        else res_tile_body<LAY, kTrace, 2>(a, p, T, smem);                                    \
+    } while (0)
+#else
+#define DFQ_RES_BODY(LAY) res_tile_body<LAY, kTrace, -1>(a, p, T, smem)
+#endif
+    if (T.layout == kLayFixed) DFQ_RES_BODY(LayFixed);
+    else if (T.layout == kLayShort) DFQ_RES_BODY(LayShort);
+    else if (T.vec == 4) res_tile_body<LayGeneral<4>, kTrace, -1>(a, p, T, smem);       // (the slow fallback layouts stay generic)
+    else res_tile_body<LayGeneral<1>, kTrace, -1>(a, p, T, smem);
+#undef DFQ_RES_BODY
 }
 
 }  // namespace dfq

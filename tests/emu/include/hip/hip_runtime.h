@@ -162,6 +162,7 @@ inline void __builtin_amdgcn_s_waitcnt(int) {}
 inline long long clock64() { return 0; }
 inline long long wall_clock64() { return 0; }
 inline unsigned __builtin_amdgcn_s_getreg(int) { return 0u; }
+inline void __builtin_amdgcn_s_setprio(int) {}
 inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
 
 using std::max;
