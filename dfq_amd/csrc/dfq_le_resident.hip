@@ -149,7 +149,7 @@ struct ResArgs {
     u64* cnt_c;                      //   "   column statistics
     u64* prog;                       // [8 copies] (x kResStride): {sweeps that happen, once the loop has stopped : verdicts drawn}
     u64* err;
-    double* partials;                // [part_ring][tiles][2]: {sweep + 1 : half of the tile's float64 sum of |dW|}
+    double* partials;                // [part_ring][tiles][4 waves][2]: {sweep + 1 : half of the wave's float64 sum of |dW|}
     float* log;                      // [log_ring][log_total]: the factors of the latest sweeps (see "speculation past the verdict")
     float* ckpt;                     // [2][tiles][kCkptFloats]: alternating checkpoints of the LDS tiles
     int64_t log_total;               // floats of one log entry (all tiles)
@@ -848,9 +848,7 @@ __device__ __forceinline__ int res_wait(const u64* w1, u64 t1, const u64* w2, u6
         *sh_flag = ok;
     }
     __syncthreads();
-    const int ok = *sh_flag;
-    __syncthreads();                 // sh_flag may be rewritten by the next wait
-    return ok;
+    return *sh_flag;                 // (no second barrier: consecutive waits of a tile alternate between two flag words -- the callers' `wflag`)
 }
 
 // The end of a tile's loop: wait until the verdict of every sweep this tile has applied is out (or the stop is).  Returns the
@@ -1056,7 +1054,7 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
             const u64* c2 = (hasA && !direct_c) ? cnt_line(a.cnt_c, T.layer, copy) : nullptr;
             const u64* c3 = (hasB && !direct_b) ? cnt_line(a.cnt_c, T.b_layer, copy) : nullptr;
             const int got = res_wait(c1, t1, c2, (u64)T.nt_self * round, c3, (u64)T.nt_b * round, DFQ_RES_TOPWAIT != 0,
-                                     prog_line(cold(a).prog, blockIdx.x & 7), (uint32_t)max(k - cold(a).spec, 0), a.err, sh_flag, kResSpinLimit);
+                                     prog_line(cold(a).prog, blockIdx.x & 7), (uint32_t)max(k - cold(a).spec, 0), a.err, sh_flag + 2, kResSpinLimit);
             if (!got) { failed = true; break; }
             if (got == 3) { stopped = true; break; }
             have_b = hasB && !direct_b && got == 2;          // counter-guarded words of phase 2 are complete: fetched with phase 1's
@@ -1142,7 +1140,7 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
                 const int copy = blockIdx.x & 7;
                 const int got = res_wait(own_wait ? cnt_line(a.cnt_r, T.layer, copy) : nullptr, (u64)T.nt_self * round,
                                          cnt_b ? cnt_line(a.cnt_c, T.b_layer, copy) : nullptr, (u64)T.nt_b * round, nullptr, 0, false,
-                                         prog_line(cold(a).prog, blockIdx.x & 7), 0u, a.err, sh_flag, kResSpinLimit);
+                                         prog_line(cold(a).prog, blockIdx.x & 7), 0u, a.err, sh_flag + 3, kResSpinLimit);
                 if (!got) { failed = true; break; }
                 if (got == 3) { stopped = true; break; }          // (nothing of sweep k has been applied)
             }
@@ -1230,11 +1228,13 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
         // ---- convergence: one partial per tile (fixed butterfly + fixed wave order) as two tagged words; the reducer workgroup
         //      reads them until they carry k + 1, sums them per layer and draws the verdict -- off every tile's path ----
         {
-            const double tsum = block_sum(acc, (double*)(sh_flag + 4));   // (four doubles in the flag block; sh_col stays all zero for the next pass)
-            if (tid == 0) {
+            // (round 5: one partial per WAVE -- the fixed butterfly -- instead of one per tile: the four are added by the reducer in
+            // wave order from 0.0, exactly what block_sum did here behind two barriers and a trip through the LDS)
+            const double wsum = wave_sum(acc);
+            if ((tid % kWave) == 0) {
                 const auto& c = cold(a);
-                u64* dst = (u64*)c.partials + ((int64_t)(k % c.part_ring) * c.n_tiles + T.slot) * 2;
-                const u64 bits = (u64)__double_as_longlong(tsum), tg = (u64)(k + 1) << 32;
+                u64* dst = (u64*)c.partials + (((int64_t)(k % c.part_ring) * c.n_tiles + T.slot) * (kBlock / kWave) + tid / kWave) * 2;
+                const u64 bits = (u64)__double_as_longlong(wsum), tg = (u64)(k + 1) << 32;
                 __hip_atomic_store(dst, tg | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(dst + 1, tg | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
@@ -1389,21 +1389,29 @@ __device__ __forceinline__ void res_reducer_body(const ResArgs& a, const LeParam
     if (tid == 0) *sh_bad = 0;
     __syncthreads();
     for (int j = 0; j < cap; ++j) {
-        const u64* part = (const u64*)c.partials + (int64_t)(j % c.part_ring) * 2 * n_tiles;
+        constexpr int kW = kBlock / kWave;                           // partials per tile: one per wave
+        const u64* part = (const u64*)c.partials + (int64_t)(j % c.part_ring) * 2 * kW * n_tiles;
         const u64 want = (u64)(j + 1);
         for (int i = tid; i < n_tiles; i += kBlock) {
             long tries = 0;
-            u64 hi, lo;
+            u64 hi[kW], lo[kW];
             for (;;) {
-                hi = ld_word(part + 2 * i); lo = ld_word(part + 2 * i + 1);
-                if ((hi >> 32) == want && (lo >> 32) == want) break;
+                bool ok = true;
+#pragma unroll
+                for (int w = 0; w < kW; ++w) { hi[w] = ld_word(part + 2 * (kW * i + w)); lo[w] = ld_word(part + 2 * (kW * i + w) + 1); }
+#pragma unroll
+                for (int w = 0; w < kW; ++w) ok = ok && (hi[w] >> 32) == want && (lo[w] >> 32) == want;
+                if (ok) break;
                 __builtin_amdgcn_s_sleep(DFQ_RES_NAP);
                 if (++tries > kResSpinLimit ||
                     ((tries & 255) == 0 && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull)) {
                     atomicMax(a.err, 1ull); *sh_bad = 1; break;
                 }
             }
-            sh_d[i] = __longlong_as_double((long long)((hi << 32) | (lo & 0xffffffffull)));
+            double t = 0.0;                                           // wave order, from 0.0: block_sum's
+#pragma unroll
+            for (int w = 0; w < kW; ++w) t += __longlong_as_double((long long)((hi[w] << 32) | (lo[w] & 0xffffffffull)));
+            sh_d[i] = t;
         }
         __syncthreads();
         if (*sh_bad) return;                                        // abandoned: the tiles give up through the error word
@@ -1815,7 +1823,7 @@ LeResident* le_resident_create(const dfq_layer* layers, int n_layers, const dfq_
               dfq::dev_malloc((void**)&r->d_layer_diff, sizeof(ResLayerDiff) * n_layers) == hipSuccess &&
               dfq::dev_malloc((void**)&r->d_stats, sizeof(u64) * (size_t)r->stat_words) == hipSuccess &&
               dfq::dev_malloc((void**)&r->d_sync, sizeof(u64) * r->sync_words) == hipSuccess &&
-              dfq::dev_malloc((void**)&r->d_partials, sizeof(double) * 2 * (size_t)(r->spec + 2) * tiles.size()) == hipSuccess &&
+              dfq::dev_malloc((void**)&r->d_partials, sizeof(double) * 2 * (kBlock / kWave) * (size_t)(r->spec + 2) * tiles.size()) == hipSuccess &&
               dfq::dev_malloc((void**)&r->d_log, sizeof(float) * (size_t)(r->ckpt_every + r->spec) * (size_t)r->log_total) == hipSuccess &&
               dfq::dev_malloc((void**)&r->d_ckpt, sizeof(float) * 2 * tiles.size() * (size_t)kCkptFloats) == hipSuccess &&
               hipMemcpy(r->d_tiles, tiles.data(), sizeof(ResTile) * tiles.size(), hipMemcpyHostToDevice) == hipSuccess &&
@@ -1834,7 +1842,7 @@ int le_resident_enqueue(LeResident* r, const dfq_le_config* cfg, LeState* d_stat
         ClearArgs ca;
         void* ps[4] = {r->d_stats, r->d_sync, r->d_partials, nullptr};
         const size_t bs[4] = {sizeof(u64) * (size_t)r->stat_words, sizeof(u64) * r->sync_words,
-                              sizeof(double) * 2 * (size_t)(r->spec + 2) * (size_t)r->n_tiles, 0};
+                              sizeof(double) * 2 * (kBlock / kWave) * (size_t)(r->spec + 2) * (size_t)r->n_tiles, 0};
         long long most = 0;
         for (int k = 0; k < 4; ++k) {
             ca.p[k] = (uint32_t*)ps[k];
