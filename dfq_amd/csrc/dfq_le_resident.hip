@@ -275,6 +275,8 @@ template <int VEC_>
 struct LayGeneral {
     static constexpr int VEC = VEC_;
     static constexpr bool kFusedCols = false;
+    static constexpr bool kFusedRows = false;
+    __device__ __forceinline__ double update_rows(const ResTile&, const TileGeo&, float*, bool, bool, const float*, const float*, uint32_t*) const { return 0.0; }
     int tcv, n_vec, n_slots;
     __device__ __forceinline__ void init(const ResTile& T, const TileGeo&) {
         tcv = T.nc / VEC; n_vec = T.nr * tcv; n_slots = (n_vec + kBlock - 1) / kBlock;
@@ -446,8 +448,13 @@ struct LayFixed {
 #pragma unroll
         for (int k = 0; k < 4; ++k) iv[k] = sh_inv[gr + tabk[k]];
     }
-    __device__ __forceinline__ void row_stats(const ResTile& T, const TileGeo& G, float* tile, bool useA, bool useB,
-                                              const float* sh_inv, const float* sh_s, uint32_t* sh_row) const {
+    // kCommit (round 5, a chain start's phase 3): the pass also WRITES the values it takes the statistics of and returns the thread's
+    // float64 sum of |new - old| -- w <- new, |dW| and the row statistics of the new values in ONE pass over the tile instead of
+    // update<true> followed by row_stats (two generic passes: 3.4 us of a [64 x 96] tile's ~10 us sweep)
+    template <bool kCommit>
+    __device__ __forceinline__ double row_stats_t(const ResTile& T, const TileGeo& G, float* tile, bool useA, bool useB,
+                                                  const float* sh_inv, const float* sh_s, uint32_t* sh_row) const {
+        double acc = 0.0;
         const int lane = threadIdx.x % kWave;
         const int w = tcv < kWave ? tcv : kWave;                    // lanes of a wave that share a row
         float iv[4] = {1.0f, 1.0f, 1.0f, 1.0f};
@@ -476,10 +483,18 @@ struct LayFixed {
                         if (useA && !one_group) inv4(T, G, sh_inv, row4[j], iv);
                         const float sr = sr4[j];
                         const fvec4 xv = xv4[j];
+                        fvec4 yv;
+                        double part = 0.0;
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
                             const float y = (xv[k] * iv[k]) * sr;        // * 1.0f is exact
+                            yv[k] = y;
+                            if (kCommit) part += (double)abs_f32(y - xv[k]);
                             mn4[j] = vmin_raw(mn4[j], y); mx4[j] = vmax_raw(mx4[j], y);
+                        }
+                        if (kCommit) {
+                            *(fvec4*)(tile + ((u0 + j) * kBlock + (int)threadIdx.x) * 4) = yv;       // the thread's own slot
+                            acc += ((u0 + j) * rps + rsub < T.nr && lane_on) ? part : 0.0;           // slot order
                         }
                     }
                 }
@@ -489,16 +504,21 @@ struct LayFixed {
                 const int row = u * rps + rsub;
                 if ((lane & 15) == 0 && u < n_used && row < T.nr && wave_on) lds_minmax(sh_row + 2 * row, mn, mx);   // one writer per row and wave
             }
-            return;
+            return acc;
         }
-        slots_piped(T, tile, useB, sh_s, [&](float*, const fvec4& xv, float sr, int row, bool on) {
+        slots_piped(T, tile, useB, sh_s, [&](float* x, const fvec4& xv, float sr, int row, bool on) {
             if (useA && !one_group) inv4(T, G, sh_inv, row, iv);
             float mn = INFINITY, mx = -INFINITY;
+            fvec4 yv;
+            double part = 0.0;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const float y = (xv[k] * iv[k]) * sr;                // * 1.0f is exact
+                yv[k] = y;
+                if (kCommit) part += (double)abs_f32(y - xv[k]);
                 mn = vmin_raw(mn, y); mx = vmax_raw(mx, y);
             }
+            if (kCommit) { *(fvec4*)x = yv; acc += on ? part : 0.0; }
             // register-file butterflies (xor_lane_minmax, dfq_common.hpp) behind uniform guards
             if (1 < w) xor_lane_minmax<1>(mn, mx);
             if (2 < w) xor_lane_minmax<2>(mn, mx);
@@ -507,6 +527,16 @@ struct LayFixed {
             if (16 < w) xor_lane_minmax<16>(mn, mx);
             if ((lane & (w - 1)) == 0 && on) lds_minmax(sh_row + 2 * row, mn, mx);   // one writer per row and wave
         });
+        return acc;
+    }
+    __device__ __forceinline__ void row_stats(const ResTile& T, const TileGeo& G, float* tile, bool useA, bool useB,
+                                              const float* sh_inv, const float* sh_s, uint32_t* sh_row) const {
+        (void)row_stats_t<false>(T, G, tile, useA, useB, sh_inv, sh_s, sh_row);
+    }
+    static constexpr bool kFusedRows = true;
+    __device__ __forceinline__ double update_rows(const ResTile& T, const TileGeo& G, float* tile, bool useA, bool useB,
+                                                  const float* sh_inv, const float* sh_s, uint32_t* sh_row) const {
+        return row_stats_t<true>(T, G, tile, useA, useB, sh_inv, sh_s, sh_row);
     }
     // cross-lane part of the column statistics: lanes of the wave that hold the same columns (ids differing in bits >= lg tcv)
     __device__ __forceinline__ void cols_finish(float (&cmn)[4], float (&cmx)[4], uint32_t* sh_col) const {
@@ -634,6 +664,8 @@ struct LayFixed {
 struct LayShort {
     static constexpr int VEC = 1;
     static constexpr bool kFusedCols = true;
+    static constexpr bool kFusedRows = false;
+    __device__ __forceinline__ double update_rows(const ResTile&, const TileGeo&, float*, bool, bool, const float*, const float*, uint32_t*) const { return 0.0; }
     int L, rpt, nci, khkw;
     int rt[kResOwn];                   // table offset of the row's group: (group - g_lo) * nci
     __device__ __forceinline__ void init(const ResTile& T, const TileGeo& G) {
@@ -1203,11 +1235,13 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
             if (DFQ_RES_ABLATE & 256) { double junk = lay.diff_and_cols(T, G, v, hasA, hasB, sh_inv, sh_s, sh_col, false); if (junk == -1.0) sh_s[0] = 0.0f; }   // the pass TWICE: its marginal cost
             if (DFQ_RES_ABLATE & 512) { lay.row_stats(T, G, v, hasA, hasB, sh_inv, sh_s, sh_row); }                  // + a read-only statistics pass
             acc = lay.diff_and_cols(T, G, v, hasA, hasB, sh_inv, sh_s, sh_col, true);
+        } else if (DFQ_RES_HOT && Lay::kFusedRows && chain_start) {
+            acc = lay.update_rows(T, G, v, false, true, sh_inv, sh_s, sh_row);         // w <- w * s_B, |dW| and the new rows' statistics: one pass
         } else {
             acc = lay.template update<true>(T, G, v, hasA, hasB, sh_inv, sh_s);
             if (hasA) lay.col_stats(T, G, v, false, false, sh_inv, sh_s, sh_col);      // of the values just written
+            if (chain_start) lay.row_stats(T, G, v, false, false, sh_inv, sh_s, sh_row);
         }
-        if (chain_start) lay.row_stats(T, G, v, false, false, sh_inv, sh_s, sh_row);
         if (DFQ_RES_PRIO) __builtin_amdgcn_s_setprio(0);
         res_stamp<kTrace>(a, k, 9);
         __syncthreads();
