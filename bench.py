@@ -195,7 +195,7 @@ def reference_cpu_record(net, full_sweeps=0, timed_sweeps=2):
 def _pmc_traffic(net, batch):
     """HBM bytes per launch of le_level_kernel from the committed PMC summary of a run with exactly this batch
     (rocprofv3 --pmc cannot run inside this process), else null."""
-    for name in ('r04_pmc_summary.json', 'r03_pmc_summary.json', 'r02_pmc_summary.json', 'r01_pmc_summary.json'):
+    for name in ('r05_pmc_summary.json', 'r04_pmc_summary.json', 'r03_pmc_summary.json', 'r02_pmc_summary.json', 'r01_pmc_summary.json'):
         path = os.path.join(ROOT, 'profiles', name)
         if net != 'mobilenet_v2' or not os.path.exists(path):
             continue
