@@ -1581,8 +1581,16 @@ int layout_of(int vec, int row_len, int nc) {
 // statistics are merged over the column blocks, column statistics over the row blocks) -- complete rows are favoured
 // for layers with row duty: no merge, and the tile does not wait for its own publication -- with a heavy penalty for
 // tiles that fall back to the general layout (LDS atomics per element).
+// elements a tile may hold: kResTileFloats, or fewer with DFQ_RES_TILE_FLOATS (TESTS: small networks then get layers of several
+// tiles -- statistics merged over row blocks, strict arrivals -- on the CPU emulation; multiples of 1024)
+int tile_capacity() {
+    const char* e = getenv("DFQ_RES_TILE_FLOATS");                          // (read per plan: tests switch it between plans)
+    const int v = (e && atoi(e) > 0) ? atoi(e) : kResTileFloats;
+    return std::max(4 * kBlock, std::min(kResTileFloats, v / (4 * kBlock) * (4 * kBlock)));
+}
+
 Shape pick_shape(int R, int C, int vec, int khkw, int go, int i2g, bool need_row, bool need_col, int short_rpt) {
-    const int ns4 = kResTileFloats / (4 * kBlock);          // float4 slots per thread
+    const int ns4 = tile_capacity() / (4 * kBlock);         // float4 slots per thread
     if (vec == 1 && C <= 32) {               // thread-per-row tiles: complete rows; `short_rpt` rows per thread if they are <= 16 floats
         int tr = std::min(R, kBlock * (C <= 16 ? std::min(short_rpt, kResOwn) : 1));
         if (need_row) tr = std::min(tr, kResRows);
@@ -1599,7 +1607,7 @@ Shape pick_shape(int R, int C, int vec, int khkw, int go, int i2g, bool need_row
         const int lay = layout_of(vec, C, tc);
         int tr;
         if (lay == kLayFixed) tr = ns4 * (kBlock / pow2_ceil(tc / 4));      // rows per slot x slots
-        else tr = kResTileFloats / tc;
+        else tr = tile_capacity() / tc;
         tr = std::min(R, tr);
         if (tr < 1) continue;
         if (need_row) tr = std::min(tr, kResRows);

@@ -243,6 +243,25 @@ class TinyMobile(nn.Module):
         return self.fc(x)
 
 
+class TinyTail(nn.Module):
+    """MobileNetV2's tail in miniature -- depthwise -> 1x1 -> 1x1 -> mean -> fc, one chain of five paired layers -- with a 1x1
+    layer of 200 x 48 = 9600 weights in its middle: more than one LDS tile of the resident equalisation engine (8192 floats), so
+    its column statistics are merged over several row blocks (the slot all-reduce of dfq_le_resident.hip) even on the CPU emulation."""
+
+    def __init__(self, n_class=10):
+        super().__init__()
+        self.stem = nn.Sequential(*_conv_bn_relu(3, 16, 3, 2, 1))
+        self.dw = nn.Sequential(*_conv_bn_relu(16, 16, 3, 1, 1, groups=16))
+        self.pw1 = nn.Sequential(*_conv_bn_relu(16, 48, 1, 1, 0))
+        self.pw2 = nn.Sequential(*_conv_bn_relu(48, 200, 1, 1, 0))
+        self.fc = nn.Linear(200, n_class)
+
+    def forward(self, x):
+        x = self.pw2(self.pw1(self.dw(self.stem(x))))
+        x = torch.mean(x.view(x.size(0), x.size(1), -1), -1)
+        return self.fc(x)
+
+
 class TinyRes(nn.Module):
     def __init__(self, n_class=7):
         super().__init__()
@@ -389,7 +408,7 @@ def relu6_to_relu(model):
 
 _FACTORY = {
     'mobilenet_v2': MobileNetV2, 'resnet18': ResNet18, 'deeplab_mnv2': DeepLabMNV2,
-    'tiny_mobile': TinyMobile, 'tiny_res': TinyRes, 'tiny_cat': TinyCat, 'tiny_wide': TinyWide, 'tiny_head': TinyHead, 'tiny_seg': TinySeg,
+    'tiny_mobile': TinyMobile, 'tiny_res': TinyRes, 'tiny_cat': TinyCat, 'tiny_wide': TinyWide, 'tiny_head': TinyHead, 'tiny_seg': TinySeg, 'tiny_tail': TinyTail,
 }
 
 

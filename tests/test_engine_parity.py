@@ -1380,3 +1380,69 @@ def test_lazy_scale_batch_with_different_sweep_counts(engine):
     for a, b in zip(outs[0], outs[1]):
         for k in a:
             assert_bitexact(a[k], b[k], 'lazy batched vs single: ' + k)
+
+
+# ---------------------------------------------------------------------------------------------
+# round 5: layers of SEVERAL tiles on the CPU emulation (statistics merged over row blocks: strict arrivals)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('tile_floats,spec', [('8192', '2'), ('1024', '2'), ('2048', '0'), ('1024', '4')])
+def test_column_statistics_merged_over_row_blocks(engine, monkeypatch, tile_floats, spec):
+    """A layer cut into several row blocks merges its per-input-channel (min, max) over them every sweep (atomicMax into shared
+    tagged words, a strict arrival on the layer's counter).  Until round 5 only the full-size networks had such layers, i.e. only the
+    GPU ran that code.  `tiny_tail` has one at the default tile size (2 row blocks of its 200 x 48 layer); DFQ_RES_TILE_FLOATS (a test
+    knob) shrinks the tiles so that it is cut into 13 / 7 row blocks and the classifier into 3 / 2.  Whatever the cut, the speculation
+    depth and the chunking of the loop into launches: weights, [O] vectors, cumulative scales and the sweep count are the oracle's,
+    bit for bit.  (The same merge through per-tile slots -- plain stores, every tile reduces its slice, tagged polls -- was built,
+    passed this test and was measured SLOWER on the MI355X: 0.73 vs 0.61 ms for MobileNetV2)"""
+    _select_le_engine(monkeypatch, 'resident')
+    monkeypatch.setenv('DFQ_RES_TILE_FLOATS', tile_floats)
+    monkeypatch.setenv('DFQ_RES_SPEC', spec)
+
+    def fresh():
+        model, graph, bottoms = synthetic.build('tiny_tail', seed=0)
+        model.to(engine.device)
+        lt.merge_batchnorm(model, graph, bottoms, TARG)
+        return model, graph, bottoms, rel.create_relation(graph, bottoms, TARG)
+
+    def check(graph, plan, sp, S_o):
+        snap = snapshot(graph)
+        for i, k in enumerate(graph):
+            n = sp.nodes[k]
+            if n.kind == 'targ':
+                assert_bitexact(snap['L{}.w'.format(i)], n.weight, 'w {}'.format(k))
+                if n.bias is not None and 'L{}.b'.format(i) in snap:
+                    assert_bitexact(snap['L{}.b'.format(i)], n.bias, 'b {}'.format(k))
+            elif n.kind == 'bn' and n.fake_weight is not None:
+                assert_bitexact(snap['L{}.fw'.format(i)], n.fake_weight, 'fw {}'.format(k))
+                assert_bitexact(snap['L{}.fb'.format(i)], n.fake_bias, 'fb {}'.format(k))
+        for a, b in zip(plan.scale_cum, S_o):
+            assert_bitexact(npy(a), b, 'cumulative S')
+
+    model, graph, bottoms, rels = fresh()
+    spec0 = graphspec.from_torch(graph, bottoms, TARG)
+    orels = orc.create_relation(spec0)
+    assert len(rels) == 4
+    plan = dfq.build_le_plan(graph, rels, TARG)
+    assert plan.resident_tiles >= {'8192': 6, '2048': 11, '1024': 18}[tile_floats], (plan.resident_tiles, plan.resident_reason)
+    # (1) the data-dependent loop in one launch
+    res = plan.run()
+    plan.stage.writeback()
+    sp = spec0.clone()
+    n_o, S_o = orc.cross_layer_equalization(sp, orels)
+    assert res['sweeps'] == n_o == 34
+    check(graph, plan, sp, S_o)
+    plan.close()
+    # (2) cut into launches of 1, 3, 5, ... sweeps
+    model, graph, bottoms, rels = fresh()
+    plan = dfq.build_le_plan(graph, rels, TARG)
+    plan.enqueue(0, restart=True)
+    total, step = 0, 1
+    while total < n_o:
+        plan.enqueue(step, restart=False)
+        total = min(n_o, total + step)
+        q = plan.query()
+        assert q['sweeps'] == total
+        step += 2
+    plan.stage.writeback()
+    check(graph, plan, sp, S_o)
+    plan.close()
