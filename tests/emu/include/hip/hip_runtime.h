@@ -34,6 +34,7 @@ struct dim3 {
     dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
 };
 
+struct int2 { int x, y; };
 struct float4 {
     float x, y, z, w;
 };
