@@ -208,6 +208,27 @@ def _pmc_traffic(net, batch):
     return None, None
 
 
+def _pmc_kernel_traffic(kernel, net, batch):
+    """Mean HBM bytes per DISPATCH of `kernel` from the committed PMC summary of a run at this batch size: FETCH_SIZE (KB,
+    doubled as MI355X_MICROARCH.md prescribes) + WRITE_SIZE (KB), separate --pmc passes of tools/pmc_unit.py; else null."""
+    for name in ('r05_pmc_summary.json', 'r04_pmc_summary.json', 'r03_pmc_summary.json'):
+        path = os.path.join(ROOT, 'profiles', name)
+        if net != 'mobilenet_v2' or not os.path.exists(path):
+            continue
+        try:
+            summary = json.load(open(path))
+            if int(summary['batch']) != int(batch):
+                continue
+            key = next(k for k in summary['FETCH_SIZE']['per_kernel_mean_KB'] if kernel in k)
+            fetch = 2.0 * 1024.0 * float(summary['FETCH_SIZE']['per_kernel_mean_KB'][key])
+            write = 1024.0 * float(summary['WRITE_SIZE']['per_kernel_mean_KB'][key])
+            return {'kernel': kernel, 'bytes_per_dispatch': fetch + write, 'fetch_bytes_corrected': fetch, 'write_bytes': write,
+                    'dispatches_in_pmc_run': int(summary['FETCH_SIZE']['per_kernel_dispatches'][key]), 'source': 'profiles/' + name}
+        except Exception:
+            pass
+    return None
+
+
 _BACKEND = 'nccl'
 
 
@@ -383,7 +404,7 @@ def activation_range_kernels(shape, dev):
 # ---------------------------------------------------------------------------------------------------
 # opt-in: the same batch through the lazy-scale formulation (its own byte count, its own roofline entry)
 # ---------------------------------------------------------------------------------------------------
-def lazy_scale_pass(protos, net_sweeps, steps, warm):
+def lazy_scale_pass(protos, net_sweeps, steps, warm, net='mobilenet_v2'):
     """SURVEY 7.3 item 9 / 8d "alternative byte count": LE of the batch with every network's sweep count GIVEN (what the
     reference's loop needs for it), computed from the pristine weights and the cumulative scales -- a sweep reads 4 B per
     paired element, the tensors are written once (8 B per weight) -- followed by the same bias correction.  Within 1e-5 of the
@@ -424,7 +445,8 @@ def lazy_scale_pass(protos, net_sweeps, steps, warm):
                          'achieved': gbps, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbps / HBM_PEAK_GBS,
                          'bytes_per_pass': sweep_bytes + final_bytes, 'bytes_per_network_first_sweep': 4 * paired_per_net,
                          'bytes_per_network_later_sweep': 4 * every_per_net,
-                         'us_per_sweep': (le_ms * 1e3) / max(1, max(net_sweeps)), 'traffic': None},
+                         'us_per_sweep': (le_ms * 1e3) / max(1, max(net_sweeps)),
+                         'traffic': _pmc_kernel_traffic('lz_stats_kernel', net, len(protos))},
             'what': 'opt-in lazy-scale equalisation (csrc/dfq_le_lazy.hip): {} networks, sweep counts given per network (those of the '
                     'reference loop), read-only sweeps over W0 with the cumulative scales applied on the fly (4 B per paired element in the first sweep, then only the '
                     'non-depthwise layers in the interior of a chain: the extrema of the other passes are sweep-invariant and rescaled), '
@@ -911,7 +933,7 @@ def main():
             out['config']['activation_ranges'] = res
 
     if rank == 0 and args.lazy_steps > 0 and args.sweeps == 0:
-        res = side_leg('lazy_scale', lambda: lazy_scale_pass(protos, net_sweeps, args.lazy_steps, 2))
+        res = side_leg('lazy_scale', lambda: lazy_scale_pass(protos, net_sweeps, args.lazy_steps, 2, net=args.net))
         if res is not None:
             out['lazy_scale'] = res
             out['value_lazy_scale'] = res['value']
