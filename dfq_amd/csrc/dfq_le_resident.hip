@@ -114,7 +114,8 @@ struct ResTile {                     // one workgroup
     int32_t nt_self, nt_a, nt_b;     // tiles of this layer / of those two
     int32_t owner;                   // holds column block 0: updates the [O] vectors of relation B
     int32_t layout;                  // kLayGeneral / kLayFixed / kLayShort
-    int32_t relax_r;                 // bit 0: every row of this layer lives in ONE tile -> its row statistics have a single producer;
+    int32_t relax_r;                 // (bit 2: see le_resident_create -- the layer's row counter has no reader)
+                                     // bit 0: every row of this layer lives in ONE tile -> its row statistics have a single producer;
                                      // bit 1: the same holds for relation A's FIRST layer (this tile reads THOSE row statistics: it polls the tagged
                                      // words themselves instead of that layer's counter -- one trip through the memory system less per hand-off)
     int32_t relax_c;                 // bit 0: every input channel of this layer lives in ONE tile -> likewise for its column statistics;
@@ -1156,7 +1157,9 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
                 __syncthreads();
                 publish_rows(a, T, rb_r1, sh_row, tag);
                 res_stamp<kTrace>(a, k, 14);
-                arrive(a.cnt_r, T.layer, !(T.relax_r & 1));
+                // (bit 2 of relax_r: every reader of these rows polls the tagged words themselves and no tile of the layer waits for
+                // its siblings' rows -- nobody ever looks at the layer's row counter: no barrier, no arrival)
+                if (!(T.relax_r & 4)) arrive(a.cnt_r, T.layer, !(T.relax_r & 1));
             }
         }
         if (!hasA) __syncthreads();                               // (phase 1 has its own barriers)
@@ -1778,6 +1781,15 @@ LeResident* le_resident_create(const dfq_layer* layers, int n_layers, const dfq_
         const char* de = getenv("DFQ_RES_DIRECT");                     // A/B switch: 0 = always wait for the counter first
         const bool direct = !(de && de[0] == '0');
         for (ResTile& T : tiles) if (direct && T.a_layer >= 0 && rel_r[T.a_layer]) T.relax_r |= 2;
+        // bit 2 of relax_r: the layer's row counter has no reader -- its rows have one producer each (bit 0: so no tile waits for
+        // siblings' rows either), every consumer polls the words directly (bit 1 on ALL tiles of relation B's second layer), and the
+        // layer is not a chain start (those pace themselves on their own row counter)
+        {
+            std::vector<int> all_direct(n_pl, 1);
+            for (const ResTile& T : tiles) if (T.a_layer >= 0 && !(T.relax_r & 2)) all_direct[T.a_layer] = 0;
+            for (ResTile& T : tiles)
+                if (direct && (T.relax_r & 1) && T.relA >= 0 && T.relB >= 0 && all_direct[T.layer]) T.relax_r |= 4;
+        }
         // bit 1 of relax_c: relation B's second layer publishes single-producer column statistics
         std::vector<int> rel_c(n_pl, 0);
         for (const ResTile& T : tiles) rel_c[T.layer] = T.relax_c & 1;
