@@ -2502,11 +2502,21 @@ static int le_enqueue_direct(dfq_le_plan* p, const dfq_le_config* cfg, int n_swe
     if (n_sweeps <= 0) return DFQ_OK;
     // one-launch sweeps contain in-launch waits: never concurrent with another stream's (dfq_common.hpp); not while
     // the stream is being captured (the graph launch is guarded instead)
+    // The guard is taken around the whole loop of sweeps.  Round 5 tried it PER SWEEP LAUNCH (DFQ_LE_GUARD_PER_LAUNCH=1): only the
+    // sweep kernel waits inside a launch, so with two batches in flight the sweep launches of the two streams could alternate and
+    // one batch's control launch, launch gap and ramp would run next to the other batch's sweep kernel.  Measured (batch of 32, two
+    // streams, two rounds): 1.437e10 weights/s against 1.472e10 -- an event record and a cross-stream wait per launch cost more than
+    // the overlap returns.  Kept as a switch.
+    static const bool guard_loop = !(getenv("DFQ_LE_GUARD_PER_LAUNCH") && getenv("DFQ_LE_GUARD_PER_LAUNCH")[0] == '1');
+    const bool guarded = p->merged && st != p->capture_stream;
     std::unique_ptr<SpinGuard> guard;
-    if (p->merged && st != p->capture_stream) guard.reset(new SpinGuard(st));
+    if (guarded && guard_loop) guard.reset(new SpinGuard(st));
     for (int s = 0; s < n_sweeps; ++s) {
-        for (int l = 0; l < dfq_le_plan_levels(p); ++l)
+        for (int l = 0; l < dfq_le_plan_levels(p); ++l) {
+            std::unique_ptr<SpinGuard> g1;
+            if (guarded && !guard_loop) g1.reset(new SpinGuard(st));
             if ((rc = le_launch_level(p, l, q, st))) return rc;
+        }
         if ((rc = le_launch_control(p, cfg, st))) return rc;
     }
     // the write-back of the deferred stores waits for nobody: it runs outside the guard, next to the first sweeps of a batch

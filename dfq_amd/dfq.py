@@ -846,7 +846,7 @@ _PLAN_ENV = ('DFQ_LE_RESIDENT', 'DFQ_LE_MERGED', 'DFQ_LE_TILE_ELEMS', 'DFQ_LE_RO
              'DFQ_RES_DIRECT', 'DFQ_RES_SHORT_RPT', 'DFQ_RES_TILE_FLOATS', 'DFQ_BC_TAGGED', 'DFQ_BC_MERGED', 'DFQ_BC_BLOCKS', 'DFQ_BC_EPS', 'DFQ_BC_FOLD',
              'DFQ_GRAPH', 'DFQ_COOPERATIVE', 'DFQ_HIP_LIB')
 # ... and the ones it reads on every RUN (they change no plan)
-_RUN_ENV = ('DFQ_SPIN_LIMIT', 'DFQ_TRACE_SWEEP', 'DFQ_PLAN_TIMING', 'DFQ_POOL_MB')     # the last two: diagnostics / where a plan's tables are allocated
+_RUN_ENV = ('DFQ_SPIN_LIMIT', 'DFQ_TRACE_SWEEP', 'DFQ_PLAN_TIMING', 'DFQ_POOL_MB', 'DFQ_LE_GUARD_PER_LAUNCH')     # the last two: diagnostics / where a plan's tables are allocated
 
 
 def _env_key():
