@@ -674,7 +674,8 @@ struct dfq_bc_plan {
     BcChainRef* d_refs = nullptr;          // workgroup table of the one-launch chain
     uint32_t* d_counters = nullptr;        // per step: finished workgroups (padded), + error flag
     unsigned long long* d_tags = nullptr;  // tagged-value slots {epoch : float} x 2 per rewritten BN channel; null: counter protocol
-    uint32_t epoch = 0;                    // run counter carried by the slots
+    uint32_t epoch = 1;                    // run counter carried by the slots; the first tagged run has epoch 2: the error word of a failed
+                                           // COUNTER-protocol run is 1 and must not read as "this tagged run failed" 
     int slot_parity = 0;                   // which half of d_slots the next tagged run's min/max launch accumulates into (it is zero)
     bool last_tagged = false;              // the last run used the tagged protocol (how dfq_bc_plan_status reads the error word)
     int chain_blocks = 0, max_expect = 0;
@@ -1098,7 +1099,7 @@ static int bc_run_direct(dfq_bc_plan* p, int32_t symmetric, hipStream_t st) {
         if (st != p->capture_stream) guard.reset(new SpinGuard(st));
         // a recorded graph replays its arguments, so the run epoch of the tagged slots cannot advance: counters there
         unsigned long long* tags = (st != p->capture_stream) ? p->d_tags : nullptr;
-        if (tags && ++p->epoch == 0u) p->epoch = 1u;
+        if (tags && ++p->epoch < 2u) p->epoch = 2u;
         const int spin_limit = spin_limit_from_env(20000000);
         if (p->max_expect <= kExpectSmall)
             hipLaunchKernelGGL(bc_chain_kernel<kExpectSmall>, dim3(p->chain_blocks), dim3(kBlock), 0, st, (const BcStepDev*)p->d_steps,
