@@ -2508,7 +2508,7 @@ static int le_enqueue_direct(dfq_le_plan* p, const dfq_le_config* cfg, int n_swe
     // streams, two rounds): 1.437e10 weights/s against 1.472e10 -- an event record and a cross-stream wait per launch cost more than
     // the overlap returns.  Kept as a switch.
     static const bool guard_loop = !(getenv("DFQ_LE_GUARD_PER_LAUNCH") && getenv("DFQ_LE_GUARD_PER_LAUNCH")[0] == '1');
-    const bool guarded = p->merged && st != p->capture_stream;
+    const bool guarded = p->merged && !(p->capture_stream != nullptr && st == p->capture_stream);      // the NULL stream is a caller's stream too
     std::unique_ptr<SpinGuard> guard;
     if (guarded && guard_loop) guard.reset(new SpinGuard(st));
     for (int s = 0; s < n_sweeps; ++s) {

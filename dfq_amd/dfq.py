@@ -1146,6 +1146,11 @@ class BCPlan:
         return bool(_ffi.lib().dfq_bc_plan_tagged(self._plan))
 
     @property
+    def last_run_tagged(self):
+        """True when the latest run used the tagged slots (False: counters -- a recorded graph -- or no run yet)."""
+        return bool(_ffi.lib().dfq_bc_plan_last_run_tagged(self._plan))
+
+    @property
     def folded_steps(self):
         """Depthwise steps performed by the tail of the step in front of them (dfq_bc_plan_folded)."""
         return int(_ffi.lib().dfq_bc_plan_folded(self._plan))

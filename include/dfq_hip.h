@@ -384,6 +384,9 @@ int64_t dfq_bc_plan_weight_elements(const dfq_bc_plan* plan);
 /* 1 when the one-launch chain hands values from step to step as tagged 64-bit slots (the default), 0 when it uses per-step
  * counters (DFQ_BC_TAGGED=0, or a graph the tagged scheme does not cover) or one launch per chain position. */
 int32_t dfq_bc_plan_tagged(const dfq_bc_plan* plan);
+/* 1 when the LATEST run of the plan used the tagged slots, 0 when it used counters (a run recorded into a graph) or has not run.
+ * A run on the NULL stream is an ordinary run (until round 5 it was mistaken for a recording: counters, no guard). */
+int32_t dfq_bc_plan_last_run_tagged(const dfq_bc_plan* plan);
 int64_t dfq_bc_plan_eps_elements(const dfq_bc_plan* plan);
 /* Depthwise steps folded into the per-row tail of the step in front of them, and the dependent positions the chain is left
  * with (MobileNetV2: 17 of 52 steps folded -> 35 positions).  A layer with one input channel per group and as many groups as

@@ -683,8 +683,11 @@ def test_bias_correction_hand_over_protocols_agree(engine, monkeypatch, mode):
         load_stage(graph, gold, 'abs')
         start = {k: v.copy() for k, v in snapshot(graph).items()}
         plan, _ = dfq.build_bc_plan(graph, bottoms, TARG)
-        assert plan.tagged == (mode == 'tagged')
+        assert plan.tagged == (mode == 'tagged') and not plan.last_run_tagged
         plan.run()
+        # the run itself, on the stream the tests run on -- the NULL stream, which until round 5 was mistaken for the plan's
+        # (not yet created) graph-recording stream and got the counters
+        assert plan.last_run_tagged == (mode == 'tagged')
         first = snapshot(graph)
         compare_stage(first, gold, 'bc', what='{} {}'.format(name, mode))
         # second run of the SAME plan from the same start: bit-identical to the first
@@ -1446,3 +1449,27 @@ def test_column_statistics_merged_over_row_blocks(engine, monkeypatch, tile_floa
     plan.stage.writeback()
     check(graph, plan, sp, S_o)
     plan.close()
+
+
+@pytest.mark.gpu
+def test_default_stream_is_an_ordinary_stream(engine):
+    """The drop-in entry points run on torch's current stream, for most callers the NULL stream.  It gets the same protocol
+    (tagged slots, guarded against another stream's in-launch waits) and the same result as a side stream."""
+    import torch
+    gold = net_fixture('tiny_mobile', 0, '')
+    results = []
+    for side in (False, True):
+        model, graph, bottoms = _build('tiny_mobile', 0, gold, engine)
+        lt.merge_batchnorm(model, graph, bottoms, TARG)
+        load_stage(graph, gold, 'abs')
+        stream = torch.cuda.Stream() if side else torch.cuda.default_stream()
+        torch.cuda.synchronize()
+        with torch.cuda.stream(stream):
+            plan, _ = dfq.build_bc_plan(graph, bottoms, TARG)
+            plan.run(check=True)
+            assert plan.tagged and plan.last_run_tagged, 'side' if side else 'default'
+            plan.close()
+        torch.cuda.synchronize()
+        results.append(snapshot(graph))
+    for k in results[0]:
+        assert_bitexact(results[0][k], results[1][k], k)
