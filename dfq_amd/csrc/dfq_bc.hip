@@ -28,6 +28,16 @@
 
 namespace dfq {
 
+#if DFQ_BC_TRACE
+constexpr int kBcTraceWgs = 8192, kBcTraceWords = 8;
+__device__ long long g_bc_trace[kBcTraceWgs * kBcTraceWords];
+#define BC_STAMP(k) do { if (chained && threadIdx.x == 0 && blockIdx.x < kBcTraceWgs) g_bc_trace[blockIdx.x * kBcTraceWords + (k)] = (long long)wall_clock64(); } while (0)
+#define BC_STAMP_VAL(k, v) do { if (chained && threadIdx.x == 0 && blockIdx.x < kBcTraceWgs) g_bc_trace[blockIdx.x * kBcTraceWords + (k)] = (long long)(v); } while (0)
+#else
+#define BC_STAMP(k) do { } while (0)
+#define BC_STAMP_VAL(k, v) do { } while (0)
+#endif
+
 constexpr int kMmChunk = kBlock * 64;   // floats per workgroup of the min/max pass: a read-only stream wants long runs (4 trips of 4 loads)
 constexpr int kQePairs = 4;            // (o, i) pairs per thread of the quant-error kernel for khkw == 1 layers
 constexpr int kExpectMax = 8192;       // floats of E[x] kept in LDS (32 KiB)
@@ -233,7 +243,20 @@ __global__ __launch_bounds__(kBlock) void bc_quant_error_kernel(const BcLayerDev
 #ifndef DFQ_BC_F32_MOMENT
 #define DFQ_BC_F32_MOMENT 0
 #endif
+// Measurement builds only (results wrong by construction; tools/gpu_r05_bc_ablate.sh): what a chain position's ~3.6 us are made
+// of.  1: no ReLU moment (pdf / cdf), 2: no matvec, 4: polls take whatever the slot holds (no dependency: the chain's
+// positions run side by side -- what is left is launch, weight stream and quantiser), 8: no quantiser, 16: no second barrier pair
+#ifndef DFQ_BC_ABLATE
+#define DFQ_BC_ABLATE 0
+#endif
+// -DDFQ_BC_TRACE=1 (measurement builds; tools/bc_trace.py): thread 0 of every workgroup of the one-launch chain leaves five
+// timestamps (wall_clock64: 100 MHz) -- entry, weights quantised (in front of the wait), expectation assembled, matvec done,
+// tail done -- and its step index; dfq_bc_debug_trace copies them out.
+#ifndef DFQ_BC_TRACE
+#define DFQ_BC_TRACE 0
+#endif
 __device__ __forceinline__ float relu_mean(float w, float b) {
+    if (DFQ_BC_ABLATE & 1) return b + w;
     const float t = (-b) / w;
     float pdf, cdf;
     if (DFQ_BC_F32_MOMENT) {
@@ -346,6 +369,8 @@ __device__ __forceinline__ void bc_step_body(const BcStepDev& st, int blk, const
     const int ln = lane & (lanes - 1);
     const int row0 = blk * rpb + wave * rw;
     const int n_slots = min(kBcRegs, ((rw + rps - 1) >> (6 - st.lg_lanes)) * chunks);
+    BC_STAMP(0);
+    BC_STAMP_VAL(7, ((long long)dep.bump_idx << 32) | (uint32_t)blk);
     // ---- this wave's quant-error row sums go into registers first: eps[o, i] = sum_k (Q(w) - w) (dfq.py:216-219, 8 bit,
     //      per-tensor range from the min/max launch; sequential float32 sum over k from 0.0f like the reference's .sum(-1)).
     //      The weights are requested before anything else and the quantiser runs while the expectation's sources arrive ----
@@ -366,27 +391,55 @@ __device__ __forceinline__ void bc_step_body(const BcStepDev& st, int blk, const
         }
     }
     const QParams qp = qparams_double((double)slot_min(st.mm[dep.mm_off + 0]), (double)slot_max(st.mm[dep.mm_off + 1]), 8, dep.symmetric);
+    // Everything of the matvec that does not depend on the expectation is settled here, before the wait: where in sh_E each
+    // slot's factor will lie (a byte offset < 64 Ki, two per register) and which slots take part at all (a slot outside the
+    // row or the layer holds eps = 0: its product is a zero of either sign, and adding one to a sum that started at +0.0
+    // changes no bit -- the row it would poison with 0 x inf is a row that is discarded, or one the clamped element belongs to).
+    // Until round 5 the index arithmetic, the predicate and the LDS read of every slot sat between the arrival of the
+    // expectation and the row's sum, one slot after the other: 53 of the 113 us of a MobileNetV2's dependent chain
+    // (profiles/r05_bc_ablation.txt).
+    const int num_group = st.expect_len / in;
+    const int step_o = st.out_ch / num_group;
+    uint32_t eo[kBcRegs / 2];
+#pragma unroll
+    for (int u = 0; u < kBcRegs / 2; ++u) eo[u] = 0u;
     {
         int rg = 0, c = 0;
+        uint32_t off0 = 0u;
 #pragma unroll
         for (int u = 0; u < kBcRegs; ++u) {
             if (u < n_slots) {
                 float code;
+                const int r_local = rg * rps + sub;
+                const int row_u = row0 + r_local;
+                const int col_u = c * lanes + ln;
+                const bool ok = r_local < rw && row_u < st.out_ch && col_u < in;
+                const int g = (num_group == 1) ? 0 : bc_small_div(min(row_u, st.out_ch - 1), step_o);
+                const uint32_t off = (uint32_t)(g * in + min(col_u, in - 1)) * 4u;
+                if (u == 0) off0 = off;
+                eo[u >> 1] |= off << (16 * (u & 1));
                 if (khkw == 1) {
                     const float v = ev[u];
-                    ev[u] = 0.0f + (fake_quant_one(v, qp, &code) - v);
+                    ev[u] = (DFQ_BC_ABLATE & 8) ? v : 0.0f + (fake_quant_one(v, qp, &code) - v);
                 } else {
-                    const int row = min(row0 + rg * rps + sub, st.out_ch - 1);
-                    const int col = min(c * lanes + ln, in - 1);
+                    const int row = min(row_u, st.out_ch - 1);
+                    const int col = min(col_u, in - 1);
                     const float* wp = st.w + ((int64_t)row * in + col) * khkw;
                     float acc = 0.0f;
                     for (int k = 0; k < khkw; ++k) {
                         const float v = wp[k];
-                        acc = acc + (fake_quant_one(v, qp, &code) - v);
+                        acc = (DFQ_BC_ABLATE & 8) ? acc + v : acc + (fake_quant_one(v, qp, &code) - v);
                     }
                     ev[u] = acc;
-                    if (++c == chunks) { c = 0; ++rg; }
                 }
+                if (chunks <= kBcRegs && !ok) ev[u] = 0.0f;
+                // the quantiser's arithmetic belongs in FRONT of the wait: without this the compiler sinks it to the first use
+                // of ev[u] -- the matvec, behind the arrival of the expectation, on the chain's critical path
+                asm volatile("" : "+v"(ev[u]));
+                if (++c == chunks) { c = 0; ++rg; }
+            } else {
+                ev[u] = 0.0f;                                    // a slot nobody owns: factor = this lane's first one
+                eo[u >> 1] |= off0 << (16 * (u & 1));
             }
         }
     }
@@ -418,8 +471,10 @@ __device__ __forceinline__ void bc_step_body(const BcStepDev& st, int blk, const
         for (int k = 0; k < kFoldTaps; ++k)
             if (k < F.khkw) acc = acc + (fake_quant_one(taps[k], fq, &code) - taps[k]);
         f_eps = acc;
+        asm volatile("" : "+v"(f_eps));                           // (in front of the wait, like ev[])
     }
     const bool tagged = chained && dep.tags != nullptr;
+    BC_STAMP(1);
     if (tagged) {
         if (tid == 0) *sh_flag = 1;
         __syncthreads();
@@ -461,7 +516,7 @@ __device__ __forceinline__ void bc_step_body(const BcStepDev& st, int blk, const
             if (poll) {
                 unsigned long long w = __hip_atomic_load(slot + 2 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 long spins = 0;
-                while ((uint32_t)(w >> 32) != dep.epoch) {
+                while (!(DFQ_BC_ABLATE & 4) && (uint32_t)(w >> 32) != dep.epoch) {
                     __builtin_amdgcn_s_sleep(1);
                     ++spins;
                     if (spins > dep.spin_limit ||
@@ -496,9 +551,8 @@ __device__ __forceinline__ void bc_step_body(const BcStepDev& st, int blk, const
     }
     // (every merge ends with a barrier) an abandoned poll: leave before anything is stored, like an abandoned counter wait
     if (tagged && *sh_flag == 0) return;
+    BC_STAMP(2);
     // ---- grouped matvec (dfq.py:281-287), float64 accumulation rounded once per row ----
-    const int num_group = st.expect_len / in;
-    const int step_o = st.out_ch / num_group;
     if (chunks > kBcRegs) {
         // very long rows (> 1536 inputs): one row per wave, the tail streams from memory
         const int o = min(row0, st.out_ch - 1);
@@ -520,19 +574,52 @@ __device__ __forceinline__ void bc_step_body(const BcStepDev& st, int blk, const
         }
         acc = wave_sum(acc);
         if (lane == 0) sh_corr[wave * rw] = (float)acc;
+    } else if (DFQ_BC_ABLATE & 2) {
+        if (tid < rpb) sh_corr[tid] = ev[0] * sh_E[0];
     } else {
+        // the factors of all slots are requested at once (eight, sixteen or all twenty-four), then summed in slot order
+        float e[kBcRegs];
+        auto factor = [&](int u) { return *(const float*)((const char*)sh_E + ((eo[u >> 1] >> (16 * (u & 1))) & 0xffffu)); };
+#pragma unroll
+        for (int u = 0; u < 8; ++u) e[u] = factor(u);
+        if (n_slots > 8) {
+#pragma unroll
+            for (int u = 8; u < 16; ++u) e[u] = factor(u);
+        }
+        if (n_slots > 16) {
+#pragma unroll
+            for (int u = 16; u < kBcRegs; ++u) e[u] = factor(u);
+        }
         int rg = 0, c = 0;
         double acc = 0.0;
+        BC_STAMP(5);
+        if (n_slots == chunks) {
+            // ONE group of rows per wave -- the split of a single network, where this sum lies on the chain's critical path.
+            // Slots in groups of eight without a decision per slot (a slot nobody owns adds a zero, above), one butterfly, one
+            // store: 0.2 us where the general loop below, which asks of each of its 24 slots whether it exists and whether
+            // it ends a group, took 0.8 us even for a single slot (profiles/r05_bc_trace.txt).  Same additions, same order.
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += (double)ev[u] * (double)e[u];
+            if (n_slots > 8) {
+#pragma unroll
+                for (int u = 8; u < 16; ++u) acc += (double)ev[u] * (double)e[u];
+            }
+            if (n_slots > 16) {
+#pragma unroll
+                for (int u = 16; u < kBcRegs; ++u) acc += (double)ev[u] * (double)e[u];
+            }
+            if (lanes > 32) xor_lane_add<32>(acc);
+            if (lanes > 16) xor_lane_add<16>(acc);
+            if (lanes > 8) xor_lane_add<8>(acc);
+            if (lanes > 4) xor_lane_add<4>(acc);
+            if (lanes > 2) xor_lane_add<2>(acc);
+            if (lanes > 1) xor_lane_add<1>(acc);
+            if (ln == 0 && sub < rw) sh_corr[wave * rw + sub] = (float)acc;
+        } else
 #pragma unroll
         for (int u = 0; u < kBcRegs; ++u) {
             if (u < n_slots) {
-                const int r_local = rg * rps + sub;
-                const int row = row0 + r_local;
-                const int col = c * lanes + ln;
-                const bool ok = r_local < rw && row < st.out_ch && col < in;
-                const int g = bc_small_div(min(row, st.out_ch - 1), step_o);
-                const float e = sh_E[g * in + min(col, in - 1)];
-                acc += ok ? (double)ev[u] * (double)e : 0.0;
+                acc += (double)ev[u] * (double)e[u];
                 if (++c == chunks) {                                   // the rows of this slot group are complete
                     // segmented butterfly over the `lanes` lanes of a row, high mask first (register-file moves, dfq_common.hpp)
                     if (lanes > 32) xor_lane_add<32>(acc);
@@ -541,13 +628,16 @@ __device__ __forceinline__ void bc_step_body(const BcStepDev& st, int blk, const
                     if (lanes > 4) xor_lane_add<4>(acc);
                     if (lanes > 2) xor_lane_add<2>(acc);
                     if (lanes > 1) xor_lane_add<1>(acc);
+                    const int r_local = rg * rps + sub;
                     if (ln == 0 && r_local < rw) sh_corr[wave * rw + r_local] = (float)acc;
                     acc = 0.0; c = 0; ++rg;
                 }
             }
         }
     }
+    BC_STAMP(6);
     __syncthreads();
+    BC_STAMP(3);
     // ---- one row per thread: dfq.py:290-293 and the refreshed ReLU moment of the next BN ----
     const int o = o_tail;
     // publication of one row's update (this step's, then the folded step's): the three hand-over protocols
@@ -597,6 +687,7 @@ __device__ __forceinline__ void bc_step_body(const BcStepDev& st, int blk, const
             }
         }
     }
+    BC_STAMP(4);
     if (chained && !tagged) {
         __builtin_amdgcn_s_waitcnt(0);                            // the stores above have been performed
         __syncthreads();
@@ -1153,6 +1244,20 @@ const float* dfq_bc_plan_correction(const dfq_bc_plan* p, int32_t step) {
 int64_t dfq_bc_plan_weight_elements(const dfq_bc_plan* p) { return p ? p->weight_elems : 0; }
 int32_t dfq_bc_plan_tagged(const dfq_bc_plan* p) { return (p && p->merged && p->d_tags) ? 1 : 0; }
 int32_t dfq_bc_plan_last_run_tagged(const dfq_bc_plan* p) { return (p && p->last_tagged) ? 1 : 0; }
+
+// measurement builds (-DDFQ_BC_TRACE=1): the timestamps of the latest chain launch, 8 words per workgroup; 0 words otherwise
+int64_t dfq_bc_debug_trace(long long* out, int64_t words) {
+#if DFQ_BC_TRACE
+    if (!out || words <= 0) return 0;
+    const int64_t n = std::min<int64_t>(words, (int64_t)kBcTraceWgs * kBcTraceWords);
+    if (hipDeviceSynchronize() != hipSuccess) return 0;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bc_trace), sizeof(long long) * n, 0, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    return n;
+#else
+    (void)out; (void)words;
+    return 0;
+#endif
+}
 int64_t dfq_bc_plan_eps_elements(const dfq_bc_plan* p) { return p ? p->eps_elems : 0; }
 int32_t dfq_bc_plan_folded(const dfq_bc_plan* p) { return p ? p->n_folds : 0; }
 int32_t dfq_bc_plan_chain_steps(const dfq_bc_plan* p) { return p ? (int32_t)p->launches.size() : 0; }

@@ -387,6 +387,9 @@ int32_t dfq_bc_plan_tagged(const dfq_bc_plan* plan);
 /* 1 when the LATEST run of the plan used the tagged slots, 0 when it used counters (a run recorded into a graph) or has not run.
  * A run on the NULL stream is an ordinary run (until round 5 it was mistaken for a recording: counters, no guard). */
 int32_t dfq_bc_plan_last_run_tagged(const dfq_bc_plan* plan);
+/* Diagnostics.  A library built with -DDFQ_BC_TRACE=1 (tools/bc_trace.py) records five timestamps per workgroup of the one-launch
+ * chain; this copies up to `words` 64-bit words of them to `out` and returns the number copied -- 0 from the shipped library. */
+int64_t dfq_bc_debug_trace(long long* out, int64_t words);
 int64_t dfq_bc_plan_eps_elements(const dfq_bc_plan* plan);
 /* Depthwise steps folded into the per-row tail of the step in front of them, and the dependent positions the chain is left
  * with (MobileNetV2: 17 of 52 steps folded -> 35 positions).  A layer with one input channel per group and as many groups as
