@@ -128,14 +128,14 @@ __device__ __forceinline__ void bc_cache_init_block(const BcCacheSeg* __restrict
 __global__ __launch_bounds__(kBlock) void bc_minmax_kernel(const BcLayerDev* __restrict__ layers,
                                                            const int32_t* __restrict__ block_begin, int n_layers,
                                                            uint32_t* __restrict__ slots, int n_mm_blocks,
-                                                           const BcCacheSeg* __restrict__ segs, int n_segs, int cache_total) {
+                                                           const BcCacheSeg* __restrict__ segs, int n_segs, int cache_total, int mm_chunk) {
     __shared__ float sh_mn[kBlock / kWave];
     __shared__ float sh_mx[kBlock / kWave];
     if ((int)blockIdx.x >= n_mm_blocks) { bc_cache_init_block(segs, n_segs, cache_total, (int)blockIdx.x - n_mm_blocks); return; }
     const int l = bc_find(block_begin, n_layers, blockIdx.x);
     const BcLayerDev L = layers[l];
-    const int64_t b = (int64_t)(blockIdx.x - block_begin[l]) * kMmChunk;
-    const int64_t e = (b + kMmChunk < L.n) ? b + kMmChunk : L.n;
+    const int64_t b = (int64_t)(blockIdx.x - block_begin[l]) * mm_chunk;
+    const int64_t e = (b + mm_chunk < L.n) ? b + mm_chunk : L.n;
     float mn = INFINITY, mx = -INFINITY;
     if ((((uintptr_t)L.w) & 15u) == 0) {
         // 16-byte vectors over the aligned body of the chunk (chunk starts are multiples of 4 floats)
@@ -352,7 +352,11 @@ __device__ __forceinline__ bool bc_err_raised(const BcDep& dep) {
 }
 __device__ __forceinline__ void bc_raise_err(const BcDep& dep) { atomicMax(dep.err, dep.tags ? dep.epoch : 1u); }
 
-template <int kExp>
+// kOneGroup: every step of the launch gives a wave ONE group of rows (n_slots == chunks: the split of a single network, where
+// the chain is latency and nothing else) -- the body then spends two dozen registers more on settling the row sum's operands
+// before the wait.  A batch keeps the leaner body: its chain is bound by how many workgroups are resident ahead of the front
+// (80 against 119 VGPRs: the batch of 32 measured 0.46 against 0.49 ms).
+template <int kExp, bool kOneGroup>
 __device__ __forceinline__ void bc_step_body(const BcStepDev& st, int blk, const BcSourceDev* __restrict__ sources,
                                              const BcFoldDev* __restrict__ folds, const BcDep& dep, float* sh_E, float* sh_corr, int* sh_flag) {
     const int tid = threadIdx.x;
@@ -396,8 +400,8 @@ __device__ __forceinline__ void bc_step_body(const BcStepDev& st, int blk, const
     // row or the layer holds eps = 0: its product is a zero of either sign, and adding one to a sum that started at +0.0
     // changes no bit -- the row it would poison with 0 x inf is a row that is discarded, or one the clamped element belongs to).
     // Until round 5 the index arithmetic, the predicate and the LDS read of every slot sat between the arrival of the
-    // expectation and the row's sum, one slot after the other: 53 of the 113 us of a MobileNetV2's dependent chain
-    // (profiles/r05_bc_ablation.txt).
+    // expectation and the row's sum, one slot after the other, and the compiler had sunk the quantiser there too: a third
+    // of a MobileNetV2's dependent chain (profiles/r05_bc_chain.txt).
     const int num_group = st.expect_len / in;
     const int step_o = st.out_ch / num_group;
     uint32_t eo[kBcRegs / 2];
@@ -414,10 +418,12 @@ __device__ __forceinline__ void bc_step_body(const BcStepDev& st, int blk, const
                 const int row_u = row0 + r_local;
                 const int col_u = c * lanes + ln;
                 const bool ok = r_local < rw && row_u < st.out_ch && col_u < in;
-                const int g = (num_group == 1) ? 0 : bc_small_div(min(row_u, st.out_ch - 1), step_o);
-                const uint32_t off = (uint32_t)(g * in + min(col_u, in - 1)) * 4u;
-                if (u == 0) off0 = off;
-                eo[u >> 1] |= off << (16 * (u & 1));
+                if (kOneGroup) {
+                    const int g = (num_group == 1) ? 0 : bc_small_div(min(row_u, st.out_ch - 1), step_o);
+                    const uint32_t off = (uint32_t)(g * in + min(col_u, in - 1)) * 4u;
+                    if (u == 0) off0 = off;
+                    eo[u >> 1] |= off << (16 * (u & 1));
+                }
                 if (khkw == 1) {
                     const float v = ev[u];
                     ev[u] = (DFQ_BC_ABLATE & 8) ? v : 0.0f + (fake_quant_one(v, qp, &code) - v);
@@ -432,12 +438,12 @@ __device__ __forceinline__ void bc_step_body(const BcStepDev& st, int blk, const
                     }
                     ev[u] = acc;
                 }
-                if (chunks <= kBcRegs && !ok) ev[u] = 0.0f;
+                if (kOneGroup && chunks <= kBcRegs && !ok) ev[u] = 0.0f;
                 // the quantiser's arithmetic belongs in FRONT of the wait: without this the compiler sinks it to the first use
                 // of ev[u] -- the matvec, behind the arrival of the expectation, on the chain's critical path
                 asm volatile("" : "+v"(ev[u]));
                 if (++c == chunks) { c = 0; ++rg; }
-            } else {
+            } else if (kOneGroup) {
                 ev[u] = 0.0f;                                    // a slot nobody owns: factor = this lane's first one
                 eo[u >> 1] |= off0 << (16 * (u & 1));
             }
@@ -577,27 +583,26 @@ __device__ __forceinline__ void bc_step_body(const BcStepDev& st, int blk, const
     } else if (DFQ_BC_ABLATE & 2) {
         if (tid < rpb) sh_corr[tid] = ev[0] * sh_E[0];
     } else {
-        // the factors of all slots are requested at once (eight, sixteen or all twenty-four), then summed in slot order
-        float e[kBcRegs];
-        auto factor = [&](int u) { return *(const float*)((const char*)sh_E + ((eo[u >> 1] >> (16 * (u & 1))) & 0xffffu)); };
+        if (kOneGroup) {
+            // the factors of all slots are requested at once (eight, sixteen or all twenty-four), then summed in slot order, in
+            // groups of eight without a decision per slot (a slot nobody owns adds a zero, above), one butterfly, one store:
+            // 0.35 us where the general loop below -- which computes each slot's place, asks whether the slot exists and
+            // whether it ends a group, 24 times -- took 1.0 us even for a single slot (profiles/r05_bc_trace.txt).  Same
+            // additions in the same order.
+            float e[kBcRegs];
+            auto factor = [&](int u) { return *(const float*)((const char*)sh_E + ((eo[u >> 1] >> (16 * (u & 1))) & 0xffffu)); };
 #pragma unroll
-        for (int u = 0; u < 8; ++u) e[u] = factor(u);
-        if (n_slots > 8) {
+            for (int u = 0; u < 8; ++u) e[u] = factor(u);
+            if (n_slots > 8) {
 #pragma unroll
-            for (int u = 8; u < 16; ++u) e[u] = factor(u);
-        }
-        if (n_slots > 16) {
+                for (int u = 8; u < 16; ++u) e[u] = factor(u);
+            }
+            if (n_slots > 16) {
 #pragma unroll
-            for (int u = 16; u < kBcRegs; ++u) e[u] = factor(u);
-        }
-        int rg = 0, c = 0;
-        double acc = 0.0;
-        BC_STAMP(5);
-        if (n_slots == chunks) {
-            // ONE group of rows per wave -- the split of a single network, where this sum lies on the chain's critical path.
-            // Slots in groups of eight without a decision per slot (a slot nobody owns adds a zero, above), one butterfly, one
-            // store: 0.2 us where the general loop below, which asks of each of its 24 slots whether it exists and whether
-            // it ends a group, took 0.8 us even for a single slot (profiles/r05_bc_trace.txt).  Same additions, same order.
+                for (int u = 16; u < kBcRegs; ++u) e[u] = factor(u);
+            }
+            double acc = 0.0;
+            BC_STAMP(5);
 #pragma unroll
             for (int u = 0; u < 8; ++u) acc += (double)ev[u] * (double)e[u];
             if (n_slots > 8) {
@@ -608,6 +613,7 @@ __device__ __forceinline__ void bc_step_body(const BcStepDev& st, int blk, const
 #pragma unroll
                 for (int u = 16; u < kBcRegs; ++u) acc += (double)ev[u] * (double)e[u];
             }
+            // segmented butterfly over the `lanes` lanes of a row, high mask first (register-file moves, dfq_common.hpp)
             if (lanes > 32) xor_lane_add<32>(acc);
             if (lanes > 16) xor_lane_add<16>(acc);
             if (lanes > 8) xor_lane_add<8>(acc);
@@ -615,22 +621,29 @@ __device__ __forceinline__ void bc_step_body(const BcStepDev& st, int blk, const
             if (lanes > 2) xor_lane_add<2>(acc);
             if (lanes > 1) xor_lane_add<1>(acc);
             if (ln == 0 && sub < rw) sh_corr[wave * rw + sub] = (float)acc;
-        } else
+        } else {
+            int rg = 0, c = 0;
+            double acc = 0.0;
 #pragma unroll
-        for (int u = 0; u < kBcRegs; ++u) {
-            if (u < n_slots) {
-                acc += (double)ev[u] * (double)e[u];
-                if (++c == chunks) {                                   // the rows of this slot group are complete
-                    // segmented butterfly over the `lanes` lanes of a row, high mask first (register-file moves, dfq_common.hpp)
-                    if (lanes > 32) xor_lane_add<32>(acc);
-                    if (lanes > 16) xor_lane_add<16>(acc);
-                    if (lanes > 8) xor_lane_add<8>(acc);
-                    if (lanes > 4) xor_lane_add<4>(acc);
-                    if (lanes > 2) xor_lane_add<2>(acc);
-                    if (lanes > 1) xor_lane_add<1>(acc);
+            for (int u = 0; u < kBcRegs; ++u) {
+                if (u < n_slots) {
                     const int r_local = rg * rps + sub;
-                    if (ln == 0 && r_local < rw) sh_corr[wave * rw + r_local] = (float)acc;
-                    acc = 0.0; c = 0; ++rg;
+                    const int row = row0 + r_local;
+                    const int col = c * lanes + ln;
+                    const bool ok = r_local < rw && row < st.out_ch && col < in;
+                    const int g = bc_small_div(min(row, st.out_ch - 1), step_o);
+                    const float e = sh_E[g * in + min(col, in - 1)];
+                    acc += ok ? (double)ev[u] * (double)e : 0.0;
+                    if (++c == chunks) {                                   // the rows of this slot group are complete
+                        if (lanes > 32) xor_lane_add<32>(acc);
+                        if (lanes > 16) xor_lane_add<16>(acc);
+                        if (lanes > 8) xor_lane_add<8>(acc);
+                        if (lanes > 4) xor_lane_add<4>(acc);
+                        if (lanes > 2) xor_lane_add<2>(acc);
+                        if (lanes > 1) xor_lane_add<1>(acc);
+                        if (ln == 0 && r_local < rw) sh_corr[wave * rw + r_local] = (float)acc;
+                        acc = 0.0; c = 0; ++rg;
+                    }
                 }
             }
         }
@@ -717,12 +730,12 @@ __global__ __launch_bounds__(kBlock) void bc_step_kernel(BcStepDev st_inline, co
     if (table) bc_load_step(table + blockIdx.y, desc.u);
     else desc.st = st_inline;
     if ((int)blockIdx.x * desc.st.rows_per_block >= desc.st.out_ch) return;     // grid.x is sized for the largest step of the launch
-    bc_step_body<kExp>(desc.st, blockIdx.x, sources, folds, BcDep{nullptr, nullptr, -1, 0, -1, 0, nullptr, 0u, symmetric, 0, 0}, sh_E, sh_corr, &sh_flag);
+    bc_step_body<kExp, false>(desc.st, blockIdx.x, sources, folds, BcDep{nullptr, nullptr, -1, 0, -1, 0, nullptr, 0u, symmetric, 0, 0}, sh_E, sh_corr, &sh_flag);
 }
 
 // the whole chain of every network in one launch: 1-D grid over (step, workgroup) in chain order; a workgroup waits
 // for the previous step of its network (lower indices only -> no deadlock, see dfq_le.hip)
-template <int kExp>
+template <int kExp, bool kOneGroup>
 __global__ __launch_bounds__(kBlock) void bc_chain_kernel(const BcStepDev* __restrict__ table,
                                                           const BcChainRef* __restrict__ refs,
                                                           const BcSourceDev* __restrict__ sources, const BcFoldDev* __restrict__ folds,
@@ -741,7 +754,7 @@ __global__ __launch_bounds__(kBlock) void bc_chain_kernel(const BcStepDev* __res
     const int blk = __builtin_amdgcn_readfirstlane(ref[1]);
     union { BcStepDev st; uint32_t u[kStepWords]; } desc;
     bc_load_step(table + step, desc.u);
-    bc_step_body<kExp>(desc.st, blk, sources, folds,
+    bc_step_body<kExp, kOneGroup>(desc.st, blk, sources, folds,
                        BcDep{counters, err, __builtin_amdgcn_readfirstlane(ref[2]), __builtin_amdgcn_readfirstlane(ref[3]), step, 0,
                              tags, epoch, symmetric, spin_limit, mm_off},
                        sh_E, sh_corr, &sh_flag);
@@ -756,6 +769,8 @@ struct dfq_bc_plan {
 
     int n_steps = 0;
     int minmax_blocks = 0, qerr_blocks = 0;
+    int mm_chunk = kMmChunk;               // floats per workgroup of the min/max launch
+    bool one_group = false;                // every live step gives a wave one group of rows: the chain kernel's latency variant
     int64_t weight_elems = 0, eps_elems = 0;
     std::vector<BcStepDev> steps;          // host copies in the caller's order
     struct Launch { int begin, n, max_blocks, max_expect; };
@@ -847,6 +862,9 @@ int dfq_bc_plan_create(const dfq_layer* layers, int32_t n_layers, const dfq_bc_s
     PlanTimer timer("dfq_bc_plan_create");
     // ---- validate & size ----
     int64_t eps_total = 0, eps_true = 0, corr_total = 0, mm_blocks = 0, qe_blocks = 0;
+    // floats per workgroup of the min/max launch (a multiple of 4 * kBlock): DFQ_BC_MM_CHUNK, tuning
+    int mm_chunk = kMmChunk;
+    if (const char* ce = getenv("DFQ_BC_MM_CHUNK")) { const int v = atoi(ce); if (v >= 4 * kBlock && v % (4 * kBlock) == 0) mm_chunk = v; }
     std::vector<int> expect_len(n_steps, 0);
     for (int s = 0; s < n_steps; ++s) {
         const dfq_bc_step& st = steps[s];
@@ -878,13 +896,14 @@ int dfq_bc_plan_create(const dfq_layer* layers, int32_t n_layers, const dfq_bc_s
         eps_total += (pairs + 3) & ~(int64_t)3;      // every eps matrix starts 16-byte aligned
         eps_true += pairs;
         corr_total += L.out_ch;
-        mm_blocks += (pairs * L.khkw + kMmChunk - 1) / kMmChunk;
+        mm_blocks += (pairs * L.khkw + mm_chunk - 1) / mm_chunk;
         qe_blocks += (L.khkw == 1) ? (pairs + kBlock * kQePairs - 1) / (kBlock * kQePairs) : (pairs + kBlock - 1) / kBlock;
     }
     if (mm_blocks > 0x7fffffff || qe_blocks > 0x7fffffff) return fail_arg("dfq_bc_plan_create: too large");
 
     dfq_bc_plan* p = new dfq_bc_plan();
     p->n_steps = n_steps;
+    p->mm_chunk = mm_chunk;
     p->eps_elems = eps_true;
     hipError_t e;
     auto fail_alloc = [&](hipError_t err) { dfq_bc_plan_destroy(p); return fail_hip(err, "bc plan allocation", __FILE__, __LINE__); };
@@ -969,7 +988,7 @@ int dfq_bc_plan_create(const dfq_layer* layers, int32_t n_layers, const dfq_bc_s
         hl[s].w = L.weight; hl[s].eps = p->keep_eps ? p->d_eps + eps_off : nullptr; hl[s].n = pairs * L.khkw; hl[s].pairs = pairs;
         hl[s].khkw = L.khkw; hl[s].pad = 0;
         mmb[s] = (int32_t)mb; qeb[s] = (int32_t)qb;
-        mb += (hl[s].n + kMmChunk - 1) / kMmChunk;
+        mb += (hl[s].n + mm_chunk - 1) / mm_chunk;
         qb += (L.khkw == 1) ? (pairs + kBlock * kQePairs - 1) / (kBlock * kQePairs) : (pairs + kBlock - 1) / kBlock;
         BcStepDev& d = p->steps[s];
         d.w = L.weight; d.mm = p->d_slots + 2 * s; d.khkw = L.khkw; d.fold = -1;
@@ -1079,6 +1098,11 @@ int dfq_bc_plan_create(const dfq_layer* layers, int32_t n_layers, const dfq_bc_s
             rw = std::min(rw, std::max(want, std::min(rps, rw)));            // never below one full register slot of rows
             d.rows_per_block = rw * kRowsPerBlock;
         }
+        p->one_group = !(getenv("DFQ_BC_ONE_GROUP") && getenv("DFQ_BC_ONE_GROUP")[0] == '0');
+        for (int s2 = 0; s2 < n_steps; ++s2) {
+            if (ordinal[s2] < 0) continue;
+            if (p->steps[s2].rows_per_block / kRowsPerBlock > (kWave >> p->steps[s2].lg_lanes)) p->one_group = false;
+        }
         for (int s2 = 0; s2 < n_steps; ++s2) {
             if (ordinal[s2] < 0) continue;
             auto& L = p->launches[ordinal[s2]];
@@ -1179,7 +1203,7 @@ static int bc_run_direct(dfq_bc_plan* p, int32_t symmetric, hipStream_t st) {
     const int cache_blocks = (p->cache_total + kBlock - 1) / kBlock;
     hipLaunchKernelGGL(bc_minmax_kernel, dim3(p->minmax_blocks + cache_blocks), dim3(kBlock), 0, st, (const BcLayerDev*)p->d_layers,
                        (const int32_t*)p->d_mm_begin, p->n_steps, slots, p->minmax_blocks,
-                       (const BcCacheSeg*)p->d_cache_segs, p->n_cache_segs, p->cache_total);
+                       (const BcCacheSeg*)p->d_cache_segs, p->n_cache_segs, p->cache_total, p->mm_chunk);
     DFQ_CHECK_LAUNCH();
     if (p->keep_eps) {
         hipLaunchKernelGGL(bc_quant_error_kernel, dim3(p->qerr_blocks), dim3(kBlock), 0, st, (const BcLayerDev*)p->d_layers,
@@ -1195,14 +1219,14 @@ static int bc_run_direct(dfq_bc_plan* p, int32_t symmetric, hipStream_t st) {
         unsigned long long* tags = capturing ? nullptr : p->d_tags;
         if (tags && ++p->epoch < 2u) p->epoch = 2u;
         const int spin_limit = spin_limit_from_env(20000000);
-        if (p->max_expect <= kExpectSmall)
-            hipLaunchKernelGGL(bc_chain_kernel<kExpectSmall>, dim3(p->chain_blocks), dim3(kBlock), 0, st, (const BcStepDev*)p->d_steps,
-                               (const BcChainRef*)p->d_refs, (const BcSourceDev*)p->d_sources, (const BcFoldDev*)p->d_folds, p->d_counters, err, tags, p->epoch, (int)symmetric, spin_limit, mm_off,
-                               tagged_run ? p->d_slots + (parity ^ 1) * 2 * p->n_steps : nullptr, 2 * p->n_steps);
-        else
-            hipLaunchKernelGGL(bc_chain_kernel<kExpectMax>, dim3(p->chain_blocks), dim3(kBlock), 0, st, (const BcStepDev*)p->d_steps,
-                               (const BcChainRef*)p->d_refs, (const BcSourceDev*)p->d_sources, (const BcFoldDev*)p->d_folds, p->d_counters, err, tags, p->epoch, (int)symmetric, spin_limit, mm_off,
-                               tagged_run ? p->d_slots + (parity ^ 1) * 2 * p->n_steps : nullptr, 2 * p->n_steps);
+#define DFQ_BC_CHAIN_LAUNCH(EXP, ONE)                                                                                                  \
+        hipLaunchKernelGGL((bc_chain_kernel<EXP, ONE>), dim3(p->chain_blocks), dim3(kBlock), 0, st, (const BcStepDev*)p->d_steps,         \
+                           (const BcChainRef*)p->d_refs, (const BcSourceDev*)p->d_sources, (const BcFoldDev*)p->d_folds, p->d_counters,  \
+                           err, tags, p->epoch, (int)symmetric, spin_limit, mm_off,                                                     \
+                           tagged_run ? p->d_slots + (parity ^ 1) * 2 * p->n_steps : nullptr, 2 * p->n_steps)
+        if (p->max_expect <= kExpectSmall) { if (p->one_group) DFQ_BC_CHAIN_LAUNCH(kExpectSmall, true); else DFQ_BC_CHAIN_LAUNCH(kExpectSmall, false); }
+        else { if (p->one_group) DFQ_BC_CHAIN_LAUNCH(kExpectMax, true); else DFQ_BC_CHAIN_LAUNCH(kExpectMax, false); }
+#undef DFQ_BC_CHAIN_LAUNCH
         DFQ_CHECK_LAUNCH();
         return DFQ_OK;
     }
