@@ -255,6 +255,12 @@ __global__ __launch_bounds__(kBlock) void bc_quant_error_kernel(const BcLayerDev
 #ifndef DFQ_BC_TRACE
 #define DFQ_BC_TRACE 0
 #endif
+// 1: the batch body also settles each slot's place in sh_E and its predicate before the wait (81 instead of 72 VGPRs: the batch of
+// 32 measured 0.416 against 0.400 ms over three alternating rounds, tools/gpu_r05_bench_ab.sh -- residency ahead of the chain's
+// front is worth more to a batch than a shorter row sum)
+#ifndef DFQ_BC_BATCH_HOIST
+#define DFQ_BC_BATCH_HOIST 0
+#endif
 __device__ __forceinline__ float relu_mean(float w, float b) {
     if (DFQ_BC_ABLATE & 1) return b + w;
     const float t = (-b) / w;
@@ -418,7 +424,7 @@ __device__ __forceinline__ void bc_step_body(const BcStepDev& st, int blk, const
                 const int row_u = row0 + r_local;
                 const int col_u = c * lanes + ln;
                 const bool ok = r_local < rw && row_u < st.out_ch && col_u < in;
-                if (kOneGroup) {
+                if (kOneGroup || DFQ_BC_BATCH_HOIST) {
                     const int g = (num_group == 1) ? 0 : bc_small_div(min(row_u, st.out_ch - 1), step_o);
                     const uint32_t off = (uint32_t)(g * in + min(col_u, in - 1)) * 4u;
                     if (u == 0) off0 = off;
@@ -438,7 +444,7 @@ __device__ __forceinline__ void bc_step_body(const BcStepDev& st, int blk, const
                     }
                     ev[u] = acc;
                 }
-                if (kOneGroup && chunks <= kBcRegs && !ok) ev[u] = 0.0f;
+                if ((kOneGroup || DFQ_BC_BATCH_HOIST) && chunks <= kBcRegs && !ok) ev[u] = 0.0f;
                 // the quantiser's arithmetic belongs in FRONT of the wait: without this the compiler sinks it to the first use
                 // of ev[u] -- the matvec, behind the arrival of the expectation, on the chain's critical path
                 asm volatile("" : "+v"(ev[u]));
@@ -628,12 +634,17 @@ __device__ __forceinline__ void bc_step_body(const BcStepDev& st, int blk, const
             for (int u = 0; u < kBcRegs; ++u) {
                 if (u < n_slots) {
                     const int r_local = rg * rps + sub;
-                    const int row = row0 + r_local;
-                    const int col = c * lanes + ln;
-                    const bool ok = r_local < rw && row < st.out_ch && col < in;
-                    const int g = bc_small_div(min(row, st.out_ch - 1), step_o);
-                    const float e = sh_E[g * in + min(col, in - 1)];
-                    acc += ok ? (double)ev[u] * (double)e : 0.0;
+                    if (DFQ_BC_BATCH_HOIST) {
+                        const float e = *(const float*)((const char*)sh_E + ((eo[u >> 1] >> (16 * (u & 1))) & 0xffffu));
+                        acc += (double)ev[u] * (double)e;
+                    } else {
+                        const int row = row0 + r_local;
+                        const int col = c * lanes + ln;
+                        const bool ok = r_local < rw && row < st.out_ch && col < in;
+                        const int g = bc_small_div(min(row, st.out_ch - 1), step_o);
+                        const float e = sh_E[g * in + min(col, in - 1)];
+                        acc += ok ? (double)ev[u] * (double)e : 0.0;
+                    }
                     if (++c == chunks) {                                   // the rows of this slot group are complete
                         if (lanes > 32) xor_lane_add<32>(acc);
                         if (lanes > 16) xor_lane_add<16>(acc);
@@ -735,6 +746,7 @@ __global__ __launch_bounds__(kBlock) void bc_step_kernel(BcStepDev st_inline, co
 
 // the whole chain of every network in one launch: 1-D grid over (step, workgroup) in chain order; a workgroup waits
 // for the previous step of its network (lower indices only -> no deadlock, see dfq_le.hip)
+// (the batch body at 64 VGPRs -- amdgpu_waves_per_eu(8, 8): 17 registers spilled to scratch -- measured 0.44 against 0.40 ms)
 template <int kExp, bool kOneGroup>
 __global__ __launch_bounds__(kBlock) void bc_chain_kernel(const BcStepDev* __restrict__ table,
                                                           const BcChainRef* __restrict__ refs,
