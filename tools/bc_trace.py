@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Where a position of the one-launch correction chain spends its time (GPU box, a library built with -DDFQ_BC_TRACE=1):
-   DFQ_HIP_LIB=$PWD/variants/libdfq_hip_bctrace.so python tools/bc_trace.py mobilenet_v2
+   DFQ_HIP_LIB=$PWD/variants/libdfq_hip_bctrace.so python tools/bc_trace.py [--batch=32] mobilenet_v2
 Per chain position (max / min over its workgroups, us since the launch's first stamp): entry, weights quantised, expectation
 assembled, matvec done, tail done; and the deltas along the critical path."""
 import ctypes
@@ -16,15 +16,16 @@ import bench
 from dfq_amd import _ffi
 
 dev = torch.device('cuda', 0)
-for net in sys.argv[1:] or ['mobilenet_v2']:
-    proto = bench.prepare(net, 0, dev)
-    unit = bench.make_unit([proto])
+args = [a for a in sys.argv[1:] if not a.startswith('--batch=')]
+batch = max([int(a.split('=')[1]) for a in sys.argv[1:] if a.startswith('--batch=')] + [1])
+for net in args or ['mobilenet_v2']:
+    unit = bench.make_unit([bench.prepare(net, seed, dev) for seed in range(batch)])
     unit['le'].enqueue(3, restart=True, max_sweeps=3, converge_thres=-1.0, converge_count=10 ** 9)
     unit['le'].query()
     for _ in range(3):
         unit['bc'].run()
         unit['bc'].status()
-    buf = np.zeros(8192 * 8, dtype=np.int64)
+    buf = np.zeros(32768 * 8, dtype=np.int64)
     n_wg = unit['bc'].chain_workgroups if hasattr(unit['bc'], 'chain_workgroups') else None
     n = _ffi.lib().dfq_bc_debug_trace(buf.ctypes.data_as(ctypes.c_void_p), buf.size)
     if n == 0:
@@ -32,7 +33,7 @@ for net in sys.argv[1:] or ['mobilenet_v2']:
     t = buf.reshape(-1, 8)
     t = t[t[:, 0] != 0]
     t = t[t[:, 0] >= t[:, 0].max() - 100 * 2000]          # (rows of an earlier, larger launch: older than 2 ms)
-    step = (t[:, 7] >> 32).astype(int)
+    step = (t[:, 7] >> 32).astype(int) // batch           # launch-major step table: position x network
     t0 = t[:, 0].min()
     us = (t[:, :5] - t0) / 100.0
     print('# {}: {} workgroups, {} positions; us since the first workgroup entered'.format(net, len(t), step.max() + 1))
