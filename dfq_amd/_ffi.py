@@ -92,6 +92,7 @@ SIGNATURES = {
     'dfq_le_resident_stats': (c_int32, [c_void_p, c_void_p, POINTER(c_int64)]),
     'dfq_le_resident_trace_words': (c_int64, [c_void_p]),
     'dfq_le_resident_trace': (c_int32, [c_void_p, POINTER(DfqLeConfig), c_int32, c_void_p, c_void_p, c_int64]),
+    'dfq_le_plan_uniform': (c_int32, [c_void_p]),
     'dfq_le_plan_levels': (c_int32, [c_void_p]),
     'dfq_le_plan_paired_elements': (c_int64, [c_void_p]),
     'dfq_le_plan_depth': (c_int32, [c_void_p]),

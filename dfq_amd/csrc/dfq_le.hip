@@ -1399,7 +1399,7 @@ __global__ __launch_bounds__(kCtlBlock) void le_control_kernel(const LeLayerDiff
                                                                uint32_t* __restrict__ r1_arena, int64_t r1_words,
                                                                int64_t r1_zero_words, int parity,
                                                                LeState* __restrict__ states, double converge_thres,
-                                                               int converge_count, int max_sweeps) {
+                                                               int converge_count, int max_sweeps, int uni_layers, int uni_tiles) {
     __shared__ double sh_part[kCtlStage];
     __shared__ double sh_mean[1024];
     __shared__ LeLayerDiff sh_layer[1024];
@@ -1426,7 +1426,15 @@ __global__ __launch_bounds__(kCtlBlock) void le_control_kernel(const LeLayerDiff
         return;
     }
     LeState* const state = states + blockIdx.x;
-    const LeNetDesc nd = nets[blockIdx.x];
+    // a batch of like networks (uni_layers > 0): the descriptor is arithmetic, and the partials, the layer table and the state are
+    // requested at once instead of behind the descriptor's round trip through the memory system
+    LeNetDesc nd;
+    if (uni_layers > 0) {
+        nd.layer_begin = (int)blockIdx.x * uni_layers; nd.n_layers = uni_layers;
+        nd.tile_begin = (int)blockIdx.x * uni_tiles; nd.n_tiles = uni_tiles;
+    } else {
+        nd = nets[blockIdx.x];
+    }
     layers += nd.layer_begin;
     layer_mean += nd.layer_begin;
     const int n_layers = nd.n_layers;
@@ -1445,18 +1453,18 @@ __global__ __launch_bounds__(kCtlBlock) void le_control_kernel(const LeLayerDiff
         if (L.partial_begin >= 0) {
             // every tile left one partial per wave
             const int rel0 = (L.partial_begin - nd.tile_begin) * waves_per_tile;     // offset inside the staged range
-            // (same order of additions as one value per trip; four loads in flight for the part of a large network that
+            // (same order of additions as one value per trip; eight loads in flight for the part of a large network that
             // did not fit the staging buffer -- ResNet-18's 10 868 partials made this kernel 14.7 us instead of 6)
             const int n_l = L.n_partials * waves_per_tile;
-            for (int i = lane; i < n_l; i += 4 * kWave) {
-                double x[4];
+            for (int i = lane; i < n_l; i += 8 * kWave) {
+                double x[8];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < 8; ++u) {
                     const int idx = rel0 + i + u * kWave;
                     x[u] = (i + u * kWave < n_l) ? ((idx < n_stage) ? sh_part[idx] : partials[part0 + idx]) : 0.0;
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) s += x[u];
+                for (int u = 0; u < 8; ++u) s += x[u];
             }
             s = wave_sum(s);
         }
@@ -1471,11 +1479,21 @@ __global__ __launch_bounds__(kCtlBlock) void le_control_kernel(const LeLayerDiff
     // diff_tmp = sum of the layer means IN GRAPH ORDER (Python's left-to-right float64 sum).  Lane l
     // fetches mean[l] with one LDS instruction per 64 layers; the values then travel lane by lane
     // through a shuffle so that lane 0 adds them in order (adding +0.0 for missing layers is exact).
+    // (every lane reads the same word: a broadcast; until round 5 lane l fetched mean[l] and the values travelled to lane 0 through
+    // 64 shuffles per 64 layers -- same additions in the same order, a third of the instructions)
     double diff_tmp = 0.0;
-    for (int base = 0; base < n_layers; base += kWave) {
-        const int l = base + lane;
-        const double m = (l < n_layers) ? ((l < 1024) ? sh_mean[l] : layer_mean[l]) : 0.0;
-        for (int j = 0; j < kWave; ++j) diff_tmp += __shfl(m, j);
+    {
+        const int n_lds = min(n_layers, 1024);
+        int l = 0;
+        for (; l + 8 <= n_lds; l += 8) {
+            double m[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) m[u] = sh_mean[l + u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) diff_tmp += m[u];
+        }
+        for (; l < n_lds; ++l) diff_tmp += sh_mean[l];
+        for (; l < n_layers; ++l) diff_tmp += layer_mean[l];
     }
     if (tid == 0) {
         double diff = before.diff;
@@ -1652,6 +1670,7 @@ struct dfq_le_plan {
 
     int n_layers = 0, n_rels = 0, n_nets = 1;
     LeNetDesc* d_nets = nullptr;
+    int uni_layers = 0, uni_tiles = 0;       // > 0: every network of the plan has this many layers / tiles, laid out back to back
     int32_t* d_boot_map = nullptr;         // bootstrap workgroup -> relation
     std::vector<LevelLaunch> levels;
     int64_t paired_total = 0;              // sum over relations of n1 + n2 (SURVEY 8d's Sigma_rel)
@@ -2061,6 +2080,14 @@ int dfq_le_plan_create_batch(const dfq_layer* layers, int32_t n_layers, const in
         nd.n_tiles += h[r].n_row_tiles + h[r].n_col_tiles;
     }
 
+    {
+        bool uni = n_nets > 1 && nets[0].n_layers > 0 && nets[0].n_tiles > 0 && !(getenv("DFQ_LE_UNIFORM") && getenv("DFQ_LE_UNIFORM")[0] == '0');
+        for (int n = 0; n < n_nets && uni; ++n)
+            uni = nets[n].n_layers == nets[0].n_layers && nets[n].n_tiles == nets[0].n_tiles &&
+                  nets[n].layer_begin == n * nets[0].n_layers && nets[n].tile_begin == n * nets[0].n_tiles;
+        p->uni_layers = uni ? nets[0].n_layers : 0;
+        p->uni_tiles = uni ? nets[0].n_tiles : 0;
+    }
     timer.tick("deferred");
     // ---- sort relations by level (stable) and lay out the launches ----
     std::vector<int> order(n_relations);
@@ -2305,6 +2332,7 @@ int dfq_le_plan_create_batch(const dfq_layer* layers, int32_t n_layers, const in
 static inline bool res_on(const dfq_le_plan* p) { return p && p->resident && !p->resident_off; }
 int32_t dfq_le_plan_resident_tiles(const dfq_le_plan* p) { return res_on(p) ? le_resident_tiles(p->resident) : 0; }
 int32_t dfq_le_plan_degraded(const dfq_le_plan* p) { return p ? p->degraded : 0; }
+int32_t dfq_le_plan_uniform(const dfq_le_plan* p) { return (p && p->uni_layers > 0) ? 1 : 0; }
 const char* dfq_le_plan_resident_reason(const dfq_le_plan* p) { return p ? p->resident_why.c_str() : ""; }
 int dfq_le_resident_stats(dfq_le_plan* p, void* stream, int64_t* out5) {
     if (!res_on(p)) return fail_arg("dfq_le_resident_stats: not a resident plan");
@@ -2487,7 +2515,7 @@ static int le_launch_control(dfq_le_plan* p, const dfq_le_config* cfg, hipStream
                        (const double*)p->d_partials, p->d_layer_mean, p->d_stats,
                        (int64_t)p->stat_words, p->d_stats + 2 * p->stat_words, (int64_t)p->stat_words,
                        (int64_t)p->r1_zero_words, (int)(p->sweep_index & 1),
-                       p->d_state, cfg->converge_thres, (int)cfg->converge_count, (int)cfg->max_sweeps);
+                       p->d_state, cfg->converge_thres, (int)cfg->converge_count, (int)cfg->max_sweeps, p->uni_layers, p->uni_tiles);
     DFQ_CHECK_LAUNCH();
     p->sweep_index += 1;             // the control launch closes a sweep
     return DFQ_OK;

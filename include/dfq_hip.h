@@ -130,6 +130,9 @@ int32_t dfq_le_plan_nets(const dfq_le_plan* plan);
 /* introspection (tests, bench byte accounting).  levels: equalisation launches per sweep -- 1 (the whole sweep is one
  * launch whose workgroups wait for the tiles they depend on) or, with DFQ_LE_MERGED=0 in the environment at plan
  * creation, one per dependency level; depth: number of dependency levels of the relation list */
+/* 1 when the plan's networks are alike and laid out back to back (a batch from one template): the convergence launch then derives
+ * a network's descriptor from its workgroup index instead of fetching it. */
+int32_t dfq_le_plan_uniform(const dfq_le_plan* plan);
 int32_t dfq_le_plan_levels(const dfq_le_plan* plan);
 int32_t dfq_le_plan_depth(const dfq_le_plan* plan);
 int64_t dfq_le_plan_paired_elements(const dfq_le_plan* plan);   /* sum over relations of n1+n2  */

@@ -59,6 +59,8 @@ def test_batch_in_one_allocation_equals_separate_plans(engine, name):
             assert lo <= rr.S.data_ptr() < lo + 4 * batch.storage.numel()
     le = batch.le_plan()
     assert le.n_nets == len(nets)
+    # like networks back to back: the convergence launch derives a network's descriptor from its workgroup index
+    assert le.uniform
     le.run()
     results, done = le.query_all()
     assert done
@@ -66,6 +68,7 @@ def test_batch_in_one_allocation_equals_separate_plans(engine, name):
     bc.run(check=True)
     for (m, g, b, rels), (m1, g1, b1, r1), res in zip(nets, twins, results):
         p1 = dfq.build_le_plan(g1, r1, TARG)
+        assert not p1.uniform                       # (a single network fetches its descriptor: nothing to derive it from)
         res1 = p1.run()
         assert res['sweeps'] == res1['sweeps']
         for ra, sb in zip(rels, p1.scale_cum):
@@ -185,6 +188,7 @@ def test_full_size_batch_in_one_allocation_equals_single_network_plans():
     sweeps = []
     for (m, g, b, rels), (m1, g1, b1, r1), res in zip(nets, twins, results):
         p1 = dfq.build_le_plan(g1, r1, TARG)
+        assert not p1.uniform                       # (a single network fetches its descriptor: nothing to derive it from)
         res1 = p1.run()
         assert res['sweeps'] == res1['sweeps']
         sweeps.append(res['sweeps'])
