@@ -642,7 +642,7 @@ __device__ __forceinline__ void bc_step_body(const BcStepDev& st, int blk, const
             // the factors of all slots are requested at once (eight, sixteen or all twenty-four), then summed in slot order, in
             // groups of eight without a decision per slot (a slot nobody owns adds a zero, above), one butterfly, one store:
             // 0.35 us where the general loop below -- which computes each slot's place, asks whether the slot exists and
-            // whether it ends a group, 24 times -- took 1.0 us even for a single slot (profiles/r05_bc_trace.txt).  Same
+            // whether it ends a group, 24 times -- took 1.0 us even for a single slot (profiles/r05_bc_chain.txt).  Same
             // additions in the same order.
             float e[kBcRegs];
             auto factor = [&](int u) { return *(const float*)((const char*)sh_E + ((eo[u >> 1] >> (16 * (u & 1))) & 0xffffu)); };
