@@ -136,6 +136,7 @@ SIGNATURES = {
     'dfq_bc_plan_weight_elements': (c_int64, [c_void_p]),
     'dfq_bc_plan_tagged': (c_int32, [c_void_p]),
     'dfq_bc_plan_last_run_tagged': (c_int32, [c_void_p]),
+    'dfq_bc_plan_one_launch': (c_int32, [c_void_p]),
     'dfq_bc_debug_trace': (c_int64, [c_void_p, c_int64]),
     'dfq_bc_plan_eps_elements': (c_int64, [c_void_p]),
     'dfq_bc_plan_folded': (c_int32, [c_void_p]),

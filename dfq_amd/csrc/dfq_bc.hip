@@ -78,6 +78,8 @@ struct BcStepDev {
     int32_t out_ch, in_per_group, source_begin, source_count, expect_len, inline_sources;
     int32_t lg_lanes, chunks, rows_per_block;          // work split, see bc_step_kernel
     int32_t next_tag_off;    // tagged-value slots of the next BN, or -1
+    int32_t mm_index, mm_blocks, wait_cache;   // one-launch correction: the layer's arrival counter, how many min/max blocks feed it; 1: a
+                                               // source is a never-rewritten BN read through a ReLU (its moment is refreshed by blocks of the launch)
     BcSourceDev src[kStepSources];   // copy of sources[source_begin ...] when source_count <= kStepSources
 };
 
@@ -101,6 +103,7 @@ struct BcFoldDev {
     float* corr;                 // [O] out
     float* eps;                  // debug copy target is written by bc_quant_error_kernel; unused here
     int32_t khkw, next_tag_off, src_relu, pad;
+    int32_t mm_index, mm_blocks;           // (as in BcStepDev)
 };
 
 struct BcCacheSeg {          // one BN whose ReLU moment is cached
@@ -121,20 +124,16 @@ __device__ __forceinline__ int bc_find(const int32_t* __restrict__ begin, int n,
 
 __device__ __forceinline__ float relu_mean(float w, float b);
 struct BcCacheSeg;
-__device__ __forceinline__ void bc_cache_init_block(const BcCacheSeg* __restrict__ segs, int n_segs, int total, int block);
+__device__ __forceinline__ void bc_cache_init_block(const BcCacheSeg* __restrict__ segs, int n_segs, int total, int block, bool device_scope);
 
-// (the workgroups behind the `n_mm_blocks` min/max ones refresh the cached ReLU moments of every BN that a step reads through a
-// ReLU from the current proxies -- bc_cache_init_block: until round 4 a launch of its own)
-__global__ __launch_bounds__(kBlock) void bc_minmax_kernel(const BcLayerDev* __restrict__ layers,
-                                                           const int32_t* __restrict__ block_begin, int n_layers,
-                                                           uint32_t* __restrict__ slots, int n_mm_blocks,
-                                                           const BcCacheSeg* __restrict__ segs, int n_segs, int cache_total, int mm_chunk) {
+// per-tensor (min, max): one block of `mm_chunk` floats of one layer, merged into the layer's two slots
+__device__ __forceinline__ void bc_minmax_block(const BcLayerDev* __restrict__ layers, const int32_t* __restrict__ block_begin, int n_layers,
+                                                uint32_t* __restrict__ slots, int mm_chunk, int block, uint32_t* arrive) {
     __shared__ float sh_mn[kBlock / kWave];
     __shared__ float sh_mx[kBlock / kWave];
-    if ((int)blockIdx.x >= n_mm_blocks) { bc_cache_init_block(segs, n_segs, cache_total, (int)blockIdx.x - n_mm_blocks); return; }
-    const int l = bc_find(block_begin, n_layers, blockIdx.x);
+    const int l = bc_find(block_begin, n_layers, block);
     const BcLayerDev L = layers[l];
-    const int64_t b = (int64_t)(blockIdx.x - block_begin[l]) * mm_chunk;
+    const int64_t b = (int64_t)(block - block_begin[l]) * mm_chunk;
     const int64_t e = (b + mm_chunk < L.n) ? b + mm_chunk : L.n;
     float mn = INFINITY, mx = -INFINITY;
     if ((((uintptr_t)L.w) & 15u) == 0) {
@@ -181,7 +180,24 @@ __global__ __launch_bounds__(kBlock) void bc_minmax_kernel(const BcLayerDev* __r
             atomicMax(slots + 2 * l + 0, ~enc_ord(a));
             atomicMax(slots + 2 * l + 1, enc_ord(c));
         }
+        // one-launch correction: the steps of THIS launch wait for their layer's blocks.  The two merges above are performed (s_waitcnt)
+        // before the counter moves -- plain device-scope atomics: a RELEASE here is a write-back of the whole L2 per block, an ACQUIRE
+        // in the waiters' polls an invalidation per poll, and the correction of a batch took 0.98 instead of 0.41 ms with them.
+        if (arrive) {
+            __builtin_amdgcn_s_waitcnt(0);
+            atomicAdd(arrive + l, 1u);
+        }
     }
+}
+
+// (the workgroups behind the `n_mm_blocks` min/max ones refresh the cached ReLU moments of every BN that a step reads through a
+// ReLU from the current proxies -- bc_cache_init_block: until round 4 a launch of its own)
+__global__ __launch_bounds__(kBlock) void bc_minmax_kernel(const BcLayerDev* __restrict__ layers,
+                                                           const int32_t* __restrict__ block_begin, int n_layers,
+                                                           uint32_t* __restrict__ slots, int n_mm_blocks,
+                                                           const BcCacheSeg* __restrict__ segs, int n_segs, int cache_total, int mm_chunk) {
+    if ((int)blockIdx.x >= n_mm_blocks) { bc_cache_init_block(segs, n_segs, cache_total, (int)blockIdx.x - n_mm_blocks, false); return; }
+    bc_minmax_block(layers, block_begin, n_layers, slots, mm_chunk, (int)blockIdx.x, nullptr);
 }
 
 // non-temporal hint on the 16-byte loads (1) / stores (2) of bc_quant_error_kernel (stores only: -1.5 % of a batch's
@@ -280,7 +296,7 @@ __device__ __forceinline__ float relu_mean(float w, float b) {
 }
 
 // ReLU moments of every cached BN from the current beta~ (once per run, all BNs: the trailing workgroups of the min/max launch)
-__device__ __forceinline__ void bc_cache_init_block(const BcCacheSeg* __restrict__ segs, int n_segs, int total, int block) {
+__device__ __forceinline__ void bc_cache_init_block(const BcCacheSeg* __restrict__ segs, int n_segs, int total, int block, bool device_scope) {
     const int i = block * kBlock + threadIdx.x;
     if (i >= total) return;
     int lo = 0, hi = n_segs - 1;
@@ -290,7 +306,9 @@ __device__ __forceinline__ void bc_cache_init_block(const BcCacheSeg* __restrict
     }
     const BcCacheSeg sg = segs[lo];
     const int c = i - sg.begin;
-    sg.cache[c] = relu_mean(sg.fw[c], sg.fb[c]);
+    const float m = relu_mean(sg.fw[c], sg.fb[c]);
+    if (device_scope) __hip_atomic_store((uint32_t*)(sg.cache + c), __float_as_uint(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // read by workgroups of the same launch
+    else sg.cache[c] = m;
 }
 
 constexpr int kStepWords = (int)(sizeof(BcStepDev) / 4);
@@ -348,6 +366,9 @@ struct BcDep {            // null counters: every step is its own launch (depend
     int32_t symmetric;    // dfq.py:173 `signed`: the quantiser of the row sums
     int32_t spin_limit;   // polls after which a wait is abandoned (DFQ_SPIN_LIMIT)
     int32_t mm_off;       // words from a step's `mm` to the (min, max) slots of THIS run (the slots exist in two parities, below)
+    const uint32_t* mm_arrive;   // one-launch correction: per layer, the min/max blocks of THIS launch that have merged; else null
+    const uint32_t* cache_arrive;   // ... and the blocks that have refreshed the cached moments of the never-rewritten BNs
+    int32_t cache_blocks;
 };
 // The error word.  Counter protocol: cleared by the run's clear launch, any non-zero value = a wait of this run was abandoned.
 // Tagged protocol (no clear launch): it holds the EPOCH of the latest run in which a wait was abandoned (atomicMax: epochs
@@ -400,7 +421,38 @@ __device__ __forceinline__ void bc_step_body(const BcStepDev& st, int blk, const
             }
         }
     }
-    const QParams qp = qparams_double((double)slot_min(st.mm[dep.mm_off + 0]), (double)slot_max(st.mm[dep.mm_off + 1]), 8, dep.symmetric);
+    const bool tagged = chained && dep.tags != nullptr;
+    if (tagged) {
+        if (tid == 0) *sh_flag = 1;
+        __syncthreads();
+    }
+    // One-launch correction (dep.mm_arrive): the layer's (min, max) are formed by min/max blocks of THIS launch, which lie in
+    // front of this workgroup in the grid; wait until all of them have merged (the weights requested above arrive meanwhile)
+    // and read the slots past the caches of this XCD.
+    auto mm_wait = [&](const uint32_t* counter, int blocks) {
+        long spins = 0;
+        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)blocks) {
+            __builtin_amdgcn_s_sleep(2);
+            ++spins;
+            if (spins > dep.spin_limit || ((spins & 255) == 0 && bc_err_raised(dep))) {
+                bc_raise_err(dep);
+                *sh_flag = 0;
+                break;
+            }
+        }
+    };
+    auto mm_slot = [&](const uint32_t* q) {
+        return dep.mm_arrive ? __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *q;
+    };
+    if (dep.mm_arrive) {
+        if (tid == 0) {
+            mm_wait(dep.mm_arrive + st.mm_index, st.mm_blocks);
+            if (st.wait_cache) mm_wait(dep.cache_arrive, dep.cache_blocks);
+        }
+        __syncthreads();
+        if (*sh_flag == 0) return;           // abandoned: nothing has been stored
+    }
+    const QParams qp = qparams_double((double)slot_min(mm_slot(st.mm + dep.mm_off + 0)), (double)slot_max(mm_slot(st.mm + dep.mm_off + 1)), 8, dep.symmetric);
     // Everything of the matvec that does not depend on the expectation is settled here, before the wait: where in sh_E each
     // slot's factor will lie (a byte offset < 64 Ki, two per register) and which slots take part at all (a slot outside the
     // row or the layer holds eps = 0: its product is a zero of either sign, and adding one to a sum that started at +0.0
@@ -477,7 +529,8 @@ __device__ __forceinline__ void bc_step_body(const BcStepDev& st, int blk, const
         f_bias = F.bias[o_tail];
         if (F.next_bn_bias) f_nb = F.next_bn_bias[o_tail];
         if (F.next_cache) f_nw = F.next_bn_weight[o_tail];
-        const QParams fq = qparams_double((double)slot_min(F.mm[dep.mm_off + 0]), (double)slot_max(F.mm[dep.mm_off + 1]), 8, dep.symmetric);
+        if (dep.mm_arrive) mm_wait(dep.mm_arrive + F.mm_index, F.mm_blocks);      // (the few threads that own a row of it; an abandoned wait is noticed behind the merges)
+        const QParams fq = qparams_double((double)slot_min(mm_slot(F.mm + dep.mm_off + 0)), (double)slot_max(mm_slot(F.mm + dep.mm_off + 1)), 8, dep.symmetric);
         float acc = 0.0f, code;
 #pragma unroll
         for (int k = 0; k < kFoldTaps; ++k)
@@ -485,12 +538,7 @@ __device__ __forceinline__ void bc_step_body(const BcStepDev& st, int blk, const
         f_eps = acc;
         asm volatile("" : "+v"(f_eps));                           // (in front of the wait, like ev[])
     }
-    const bool tagged = chained && dep.tags != nullptr;
     BC_STAMP(1);
-    if (tagged) {
-        if (tid == 0) *sh_flag = 1;
-        __syncthreads();
-    }
     if (chained && !tagged && dep.wait_idx >= 0) {
         // the previous layer's correction feeds this expectation: wait for all its workgroups (the eps values
         // requested above arrive meanwhile)
@@ -590,7 +638,7 @@ __device__ __forceinline__ void bc_step_body(const BcStepDev& st, int blk, const
                 }
                 e = __uint_as_float((uint32_t)w);
             } else {
-                e = (chained && !tagged) ? ld_shared_f32(val + i) : val[i];
+                e = (chained && (!tagged || dep.mm_arrive)) ? ld_shared_f32(val + i) : val[i];
             }
             if (assign) sh_E[base + i] = e;
             else sh_E[i] = sh_E[i] + e;
@@ -790,18 +838,34 @@ __global__ __launch_bounds__(kBlock) void bc_step_kernel(BcStepDev st_inline, co
     if (table) bc_load_step(table + blockIdx.y, desc.u);
     else desc.st = st_inline;
     if ((int)blockIdx.x * desc.st.rows_per_block >= desc.st.out_ch) return;     // grid.x is sized for the largest step of the launch
-    bc_step_body<kExp, false>(desc.st, blockIdx.x, sources, folds, BcDep{nullptr, nullptr, -1, 0, -1, 0, nullptr, 0u, symmetric, 0, 0}, sh_E, sh_corr, &sh_flag);
+    bc_step_body<kExp, false>(desc.st, blockIdx.x, sources, folds, BcDep{nullptr, nullptr, -1, 0, -1, 0, nullptr, 0u, symmetric, 0, 0, nullptr, nullptr, 0}, sh_E, sh_corr, &sh_flag);
 }
 
 // the whole chain of every network in one launch: 1-D grid over (step, workgroup) in chain order; a workgroup waits
 // for the previous step of its network (lower indices only -> no deadlock, see dfq_le.hip)
+// One-launch correction (round 5): the per-tensor min/max blocks are workgroups of the chain launch.  The plan interleaves them with
+// the chain's positions -- the blocks of the layers a position needs lie a few positions in front of it in the grid -- so a step
+// waits only for blocks with lower indices (no deadlock), the large late layers are reduced while the chain's early positions
+// hand over (a phase that leaves the memory system idle), and the launch boundary between the two kernels is gone.
+struct BcFusedMm {
+    const BcLayerDev* layers;
+    const int32_t* block_begin;
+    uint32_t* slots;        // this run's parity
+    uint32_t* arrive;       // per layer: merged blocks of this run (same parity region, zero at the start); null: min/max was its own launch
+    int32_t n_layers, mm_chunk;
+    const BcCacheSeg* segs; // the never-rewritten BNs read through a ReLU: their cached moments are refreshed by the launch's first blocks
+    uint32_t* cache_arrive;
+    int32_t n_segs, cache_total, cache_blocks, pad;
+};
+
 // (the batch body at 64 VGPRs -- amdgpu_waves_per_eu(8, 8): 17 registers spilled to scratch -- measured 0.44 against 0.40 ms)
 template <int kExp, bool kOneGroup>
 __global__ __launch_bounds__(kBlock) void bc_chain_kernel(const BcStepDev* __restrict__ table,
                                                           const BcChainRef* __restrict__ refs,
                                                           const BcSourceDev* __restrict__ sources, const BcFoldDev* __restrict__ folds,
                                                           uint32_t* counters, uint32_t* err, unsigned long long* tags, uint32_t epoch,
-                                                          int symmetric, int spin_limit, int mm_off, uint32_t* slots_clear, int n_slots_clear) {
+                                                          int symmetric, int spin_limit, int mm_off, uint32_t* slots_clear, int n_slots_clear,
+                                                          BcFusedMm fm) {
     __shared__ float sh_E[kExp];
     __shared__ float sh_corr[kBlock];
     __shared__ int sh_flag;
@@ -813,11 +877,22 @@ __global__ __launch_bounds__(kBlock) void bc_chain_kernel(const BcStepDev* __res
     const ivec4 ref = *(const DFQ_GLOBAL_AS ivec4*)(refs + blockIdx.x);
     const int step = __builtin_amdgcn_readfirstlane(ref[0]);
     const int blk = __builtin_amdgcn_readfirstlane(ref[1]);
+    if (step == -1) {                // a min/max block of the one-launch correction
+        bc_minmax_block(fm.layers, fm.block_begin, fm.n_layers, fm.slots, fm.mm_chunk, blk, fm.arrive);
+        return;
+    }
+    if (step == -2) {                // ... a block of cached ReLU moments
+        bc_cache_init_block(fm.segs, fm.n_segs, fm.cache_total, blk, true);
+        __builtin_amdgcn_s_waitcnt(0);              // the device-scope stores have been performed
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(fm.cache_arrive, 1u);
+        return;
+    }
     union { BcStepDev st; uint32_t u[kStepWords]; } desc;
     bc_load_step(table + step, desc.u);
     bc_step_body<kExp, kOneGroup>(desc.st, blk, sources, folds,
                        BcDep{counters, err, __builtin_amdgcn_readfirstlane(ref[2]), __builtin_amdgcn_readfirstlane(ref[3]), step, 0,
-                             tags, epoch, symmetric, spin_limit, mm_off},
+                             tags, epoch, symmetric, spin_limit, mm_off, fm.arrive, fm.cache_arrive, fm.cache_blocks},
                        sh_E, sh_corr, &sh_flag);
 }
 
@@ -832,6 +907,11 @@ struct dfq_bc_plan {
     int minmax_blocks = 0, qerr_blocks = 0;
     int mm_chunk = kMmChunk;               // floats per workgroup of the min/max launch
     bool one_group = false;                // every live step gives a wave one group of rows: the chain kernel's latency variant
+    bool fused_mm = false;                 // tagged runs are ONE launch: the min/max blocks are workgroups of the chain launch
+    BcChainRef* d_refs_fused = nullptr;    // its workgroup table (min/max blocks a few positions in front of the steps that need them)
+    int chain_blocks_fused = 0;
+    BcCacheSeg* d_cache_segs_launch = nullptr;   // the never-rewritten BNs among the cached ones (refreshed by blocks of the one launch)
+    int n_cache_segs_launch = 0, cache_total_launch = 0;
     int64_t weight_elems = 0, eps_elems = 0;
     std::vector<BcStepDev> steps;          // host copies in the caller's order
     struct Launch { int begin, n, max_blocks, max_expect; };
@@ -979,8 +1059,10 @@ int dfq_bc_plan_create(const dfq_layer* layers, int32_t n_layers, const dfq_bc_s
     if ((e = p->mem.alloc((void**)&p->d_mm_begin, sizeof(int32_t) * (n_steps + 1))) != hipSuccess) return fail_alloc(e);
     if ((e = p->mem.alloc((void**)&p->d_qe_begin, sizeof(int32_t) * (n_steps + 1))) != hipSuccess) return fail_alloc(e);
     if ((e = p->mem.alloc((void**)&p->d_sources, sizeof(BcSourceDev) * n_sources)) != hipSuccess) return fail_alloc(e);
-    if ((e = p->mem.alloc((void**)&p->d_slots, sizeof(uint32_t) * 4 * n_steps)) != hipSuccess) return fail_alloc(e);      // two parities
-    if ((e = hipMemset(p->d_slots, 0, sizeof(uint32_t) * 4 * n_steps)) != hipSuccess) return fail_alloc(e);
+    // per parity: (min, max) of every step's layer, then one arrival counter per layer (one-launch correction)
+    // (+ one counter for the blocks that refresh cached moments inside the launch)
+    if ((e = p->mem.alloc((void**)&p->d_slots, sizeof(uint32_t) * 2 * (3 * (size_t)n_steps + 1))) != hipSuccess) return fail_alloc(e);      // two parities
+    if ((e = hipMemset(p->d_slots, 0, sizeof(uint32_t) * 2 * (3 * (size_t)n_steps + 1))) != hipSuccess) return fail_alloc(e);
 
     std::vector<BcLayerDev> hl(n_steps);
     std::vector<int32_t> mmb(n_steps + 1), qeb(n_steps + 1);
@@ -1053,6 +1135,7 @@ int dfq_bc_plan_create(const dfq_layer* layers, int32_t n_layers, const dfq_bc_s
         qb += (L.khkw == 1) ? (pairs + kBlock * kQePairs - 1) / (kBlock * kQePairs) : (pairs + kBlock - 1) / kBlock;
         BcStepDev& d = p->steps[s];
         d.w = L.weight; d.mm = p->d_slots + 2 * s; d.khkw = L.khkw; d.fold = -1;
+        d.mm_index = s; d.mm_blocks = (int32_t)((hl[s].n + mm_chunk - 1) / mm_chunk); d.wait_cache = 0;
         d.eps = p->keep_eps ? p->d_eps + eps_off : nullptr; d.bias = L.bias; d.next_bn_bias = steps[s].next_bn_bias; d.corr = p->d_corr + corr_off;
         d.out_ch = L.out_ch; d.in_per_group = L.in_per_group; d.source_begin = steps[s].source_begin;
         d.source_count = steps[s].source_count; d.expect_len = expect_len[s];
@@ -1114,7 +1197,7 @@ int dfq_bc_plan_create(const dfq_layer* layers, int32_t n_layers, const dfq_bc_s
             const BcStepDev& d = p->steps[D];
             F.w = d.w; F.mm = d.mm; F.bias = d.bias; F.next_bn_bias = d.next_bn_bias; F.next_bn_weight = d.next_bn_weight;
             F.next_cache = d.next_cache; F.corr = d.corr; F.eps = nullptr; F.khkw = d.khkw; F.next_tag_off = d.next_tag_off;
-            F.src_relu = src.relu ? 1 : 0; F.pad = 0;
+            F.src_relu = src.relu ? 1 : 0; F.pad = 0; F.mm_index = d.mm_index; F.mm_blocks = d.mm_blocks;
             p->steps[P].fold = (int)folds.size();
             folds.push_back(F);
             folded_into[D] = P;
@@ -1194,6 +1277,84 @@ int dfq_bc_plan_create(const dfq_layer* layers, int32_t n_layers, const dfq_bc_s
         p->chain_blocks = (int)refs.size();
         if ((e = p->mem.alloc((void**)&p->d_refs, sizeof(BcChainRef) * std::max<size_t>(1, refs.size()))) != hipSuccess) return fail_alloc(e);
         if ((e = hipMemcpy(p->d_refs, refs.data(), sizeof(BcChainRef) * refs.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail_alloc(e);
+        // ---- one-launch correction: the same table with the min/max blocks woven in.  The blocks of the layers that chain position
+        //      P needs (its steps' own layers and the depthwise layers folded into them) lie `ahead` positions in front of P's
+        //      workgroups; the first `ahead` positions' blocks open the grid.  Not for plans that read a never-rewritten BN through
+        //      a ReLU (its cached moment is refreshed by the min/max LAUNCH's trailing workgroups) or keep the eps matrices. ----
+        {
+            // Default: for a BATCH only.  Measured (tools/gpu_r05_bench_env_ab.sh, two alternating rounds): the batch of 32 0.410-0.415 ->
+            // 0.375-0.379 ms -- its large late layers are reduced while the early positions hand over -- but ONE network 0.1265 -> 0.131-
+            // 0.136 ms, ResNet-18 0.082 -> 0.112-0.117: every workgroup of a single network's chain is resident from the first
+            // microsecond and polls its sources' slots (180 000 threads, a device-scope load each every 64 clocks), and min/max blocks
+            // that stream next to that finish at 40 us instead of 5 (tools/bc_trace.py: `quantised` of position 0).  DFQ_BC_ONE_LAUNCH=1 / 0
+            // forces it on / off.
+            const char* fe = getenv("DFQ_BC_ONE_LAUNCH");
+            const bool want = fe ? (fe[0] != '0') : !p->one_group;
+            bool ok = tagged_ok && tag_total > 0 && !p->keep_eps && want;
+            std::vector<int> wait_cache(n_steps, 0);
+            for (int s2 = 0; s2 < n_steps && ok; ++s2) {
+                if (p->steps[s2].chunks > kBcRegs) ok = false;      // (nothing in the way; its rows stream from memory behind the wait: keep the plain pair of launches)
+                for (int m = 0; m < steps[s2].source_count; ++m) {
+                    const BcSourceDev& src = hs[steps[s2].source_begin + m];
+                    if (src.relu && src.tag_off < 0) wait_cache[s2] = 1;          // a never-rewritten BN read through a ReLU
+                }
+            }
+            // the cached moments of never-rewritten BNs are refreshed by the first blocks of the launch (the rewritten BNs' are
+            // produced by the steps themselves and read through the tagged slots)
+            std::vector<BcCacheSeg> segs_launch;
+            int cache_total_launch = 0;
+            for (const BcCacheSeg& sg : segs) {
+                if (tag_of.count(sg.fb)) continue;
+                BcCacheSeg c = sg;
+                c.begin = cache_total_launch;
+                cache_total_launch += sg.channels;
+                segs_launch.push_back(c);
+            }
+            const int cache_blocks_launch = (cache_total_launch + kBlock - 1) / kBlock;
+            if (ok) {
+                const char* ae = getenv("DFQ_BC_MM_AHEAD");
+                const int ahead = (ae && atoi(ae) >= 0) ? atoi(ae) : 2;
+                // min/max blocks per chain position (launch), in step order
+                std::vector<std::vector<int>> mm_of(n_launch);
+                for (int s2 = 0; s2 < n_steps; ++s2) {
+                    const int host = ordinal[s2] >= 0 ? s2 : folded_into[s2];     // a folded step's layer is needed where its host runs
+                    if (host < 0 || ordinal[host] < 0) { ok = false; break; }
+                    for (int b = mmb[s2]; b < mmb[s2 + 1]; ++b) mm_of[ordinal[host]].push_back(b);
+                }
+                if (ok) {
+                    std::vector<BcChainRef> fused;
+                    fused.reserve(refs.size() + (size_t)mmb[n_steps] + cache_blocks_launch);
+                    auto emit_mm = [&](int P) { if (P < n_launch) for (int b : mm_of[P]) fused.push_back(BcChainRef{-1, b, -1, 0}); };
+                    for (int b = 0; b < cache_blocks_launch; ++b) fused.push_back(BcChainRef{-2, b, -1, 0});
+                    for (int P = 0; P < std::min(ahead, n_launch); ++P) emit_mm(P);
+                    size_t r = 0;
+                    for (int P = 0; P < n_launch; ++P) {
+                        emit_mm(P + ahead);
+                        const int q_end = p->launches[P].begin + p->launches[P].n;
+                        for (; r < refs.size() && refs[r].step < q_end; ++r) fused.push_back(refs[r]);
+                    }
+                    if (r == refs.size() && fused.size() == refs.size() + (size_t)mmb[n_steps] + cache_blocks_launch) {
+                        p->chain_blocks_fused = (int)fused.size();
+                        if (!segs_launch.empty()) {
+                            if ((e = p->mem.alloc((void**)&p->d_cache_segs_launch, sizeof(BcCacheSeg) * segs_launch.size())) != hipSuccess) return fail_alloc(e);
+                            if ((e = hipMemcpy(p->d_cache_segs_launch, segs_launch.data(), sizeof(BcCacheSeg) * segs_launch.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail_alloc(e);
+                        }
+                        p->n_cache_segs_launch = (int)segs_launch.size();
+                        p->cache_total_launch = cache_total_launch;
+                        // (the step table is on the device already: the flag goes into both copies)
+                        for (int s2 = 0; s2 < n_steps; ++s2) {
+                            if (!wait_cache[s2] || ordinal[s2] < 0) continue;
+                            p->steps[s2].wait_cache = 1;
+                            p->launch_steps[pos[s2]].wait_cache = 1;
+                        }
+                        if ((e = hipMemcpy(p->d_steps, p->launch_steps.data(), sizeof(BcStepDev) * n_live, hipMemcpyHostToDevice)) != hipSuccess) return fail_alloc(e);
+                        if ((e = p->mem.alloc((void**)&p->d_refs_fused, sizeof(BcChainRef) * fused.size())) != hipSuccess) return fail_alloc(e);
+                        if ((e = hipMemcpy(p->d_refs_fused, fused.data(), sizeof(BcChainRef) * fused.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail_alloc(e);
+                        p->fused_mm = true;
+                    }
+                }
+            }
+        }
         if ((e = p->mem.alloc((void**)&p->d_counters, sizeof(uint32_t) * ((size_t)n_steps * kBcDepStride + 1))) != hipSuccess) return fail_alloc(e);
         if ((e = hipMemset(p->d_counters, 0, sizeof(uint32_t) * ((size_t)n_steps * kBcDepStride + 1))) != hipSuccess) return fail_alloc(e);
         if (tag_total > 0) {
@@ -1253,19 +1414,23 @@ static int bc_run_direct(dfq_bc_plan* p, int32_t symmetric, hipStream_t st) {
         parity = p->slot_parity;
         p->slot_parity ^= 1;
     } else {
-        clear_buffers(st, p->d_slots, sizeof(uint32_t) * 4 * p->n_steps,
+        clear_buffers(st, p->d_slots, sizeof(uint32_t) * 2 * (3 * (size_t)p->n_steps + 1),
                       chain ? p->d_counters : nullptr, sizeof(uint32_t) * ((size_t)p->n_steps * kBcDepStride + 1));
         DFQ_CHECK_LAUNCH();
         p->slot_parity = 1;                 // parity 0 is dirty after this run, parity 1 clean
     }
     p->last_tagged = tagged_run;
-    const int mm_off = parity * 2 * p->n_steps;
+    const int mm_off = parity * (3 * p->n_steps + 1);
     uint32_t* slots = p->d_slots + mm_off;
     const int cache_blocks = (p->cache_total + kBlock - 1) / kBlock;
-    hipLaunchKernelGGL(bc_minmax_kernel, dim3(p->minmax_blocks + cache_blocks), dim3(kBlock), 0, st, (const BcLayerDev*)p->d_layers,
-                       (const int32_t*)p->d_mm_begin, p->n_steps, slots, p->minmax_blocks,
-                       (const BcCacheSeg*)p->d_cache_segs, p->n_cache_segs, p->cache_total, p->mm_chunk);
-    DFQ_CHECK_LAUNCH();
+    // one-launch correction: the min/max blocks are workgroups of the tagged chain launch below
+    const bool one_launch = tagged_run && p->fused_mm;
+    if (!one_launch) {
+        hipLaunchKernelGGL(bc_minmax_kernel, dim3(p->minmax_blocks + cache_blocks), dim3(kBlock), 0, st, (const BcLayerDev*)p->d_layers,
+                           (const int32_t*)p->d_mm_begin, p->n_steps, slots, p->minmax_blocks,
+                           (const BcCacheSeg*)p->d_cache_segs, p->n_cache_segs, p->cache_total, p->mm_chunk);
+        DFQ_CHECK_LAUNCH();
+    }
     if (p->keep_eps) {
         hipLaunchKernelGGL(bc_quant_error_kernel, dim3(p->qerr_blocks), dim3(kBlock), 0, st, (const BcLayerDev*)p->d_layers,
                            (const int32_t*)p->d_qe_begin, p->n_steps, (const uint32_t*)slots, 8, (int)symmetric);
@@ -1280,11 +1445,18 @@ static int bc_run_direct(dfq_bc_plan* p, int32_t symmetric, hipStream_t st) {
         unsigned long long* tags = capturing ? nullptr : p->d_tags;
         if (tags && ++p->epoch < 2u) p->epoch = 2u;
         const int spin_limit = spin_limit_from_env(20000000);
+        BcFusedMm fm;
+        fm.layers = (const BcLayerDev*)p->d_layers; fm.block_begin = (const int32_t*)p->d_mm_begin; fm.slots = slots;
+        fm.arrive = one_launch ? slots + 2 * p->n_steps : nullptr; fm.n_layers = p->n_steps; fm.mm_chunk = p->mm_chunk;
+        fm.segs = (const BcCacheSeg*)p->d_cache_segs_launch; fm.cache_arrive = one_launch ? slots + 3 * p->n_steps : nullptr;
+        fm.n_segs = p->n_cache_segs_launch; fm.cache_total = p->cache_total_launch; fm.cache_blocks = (p->cache_total_launch + kBlock - 1) / kBlock; fm.pad = 0;
+        const int grid_blocks = one_launch ? p->chain_blocks_fused : p->chain_blocks;
+        const BcChainRef* ref_table = one_launch ? p->d_refs_fused : p->d_refs;
 #define DFQ_BC_CHAIN_LAUNCH(EXP, ONE)                                                                                                  \
-        hipLaunchKernelGGL((bc_chain_kernel<EXP, ONE>), dim3(p->chain_blocks), dim3(kBlock), 0, st, (const BcStepDev*)p->d_steps,         \
-                           (const BcChainRef*)p->d_refs, (const BcSourceDev*)p->d_sources, (const BcFoldDev*)p->d_folds, p->d_counters,  \
+        hipLaunchKernelGGL((bc_chain_kernel<EXP, ONE>), dim3(grid_blocks), dim3(kBlock), 0, st, (const BcStepDev*)p->d_steps,             \
+                           ref_table, (const BcSourceDev*)p->d_sources, (const BcFoldDev*)p->d_folds, p->d_counters,                    \
                            err, tags, p->epoch, (int)symmetric, spin_limit, mm_off,                                                     \
-                           tagged_run ? p->d_slots + (parity ^ 1) * 2 * p->n_steps : nullptr, 2 * p->n_steps)
+                           tagged_run ? p->d_slots + (parity ^ 1) * (3 * p->n_steps + 1) : nullptr, 3 * p->n_steps + 1, fm)
         if (p->max_expect <= kExpectSmall) { if (p->one_group) DFQ_BC_CHAIN_LAUNCH(kExpectSmall, true); else DFQ_BC_CHAIN_LAUNCH(kExpectSmall, false); }
         else { if (p->one_group) DFQ_BC_CHAIN_LAUNCH(kExpectMax, true); else DFQ_BC_CHAIN_LAUNCH(kExpectMax, false); }
 #undef DFQ_BC_CHAIN_LAUNCH
@@ -1329,6 +1501,7 @@ const float* dfq_bc_plan_correction(const dfq_bc_plan* p, int32_t step) {
 int64_t dfq_bc_plan_weight_elements(const dfq_bc_plan* p) { return p ? p->weight_elems : 0; }
 int32_t dfq_bc_plan_tagged(const dfq_bc_plan* p) { return (p && p->merged && p->d_tags) ? 1 : 0; }
 int32_t dfq_bc_plan_last_run_tagged(const dfq_bc_plan* p) { return (p && p->last_tagged) ? 1 : 0; }
+int32_t dfq_bc_plan_one_launch(const dfq_bc_plan* p) { return (p && p->merged && p->fused_mm) ? 1 : 0; }
 
 // measurement builds (-DDFQ_BC_TRACE=1): the timestamps of the latest chain launch, 8 words per workgroup; 0 words otherwise
 int64_t dfq_bc_debug_trace(long long* out, int64_t words) {

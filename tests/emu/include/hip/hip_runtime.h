@@ -158,6 +158,7 @@ inline double atomicAdd(double* p, double v) { double o = *p; *p = o + v; return
 // decide "is the counter there yet?" for itself passed every emulated test and mismatched its barriers on the GPU.)
 #define __hip_atomic_load(ptr, order, scope) (emu::visibility_point(), *(ptr))
 #define __hip_atomic_store(ptr, val, order, scope) (*(ptr) = (val))
+#define __hip_atomic_fetch_add(ptr, val, order, scope) __atomic_fetch_add((ptr), (val), __ATOMIC_SEQ_CST)
 inline void __builtin_amdgcn_s_sleep(int) { emu::poll_yield(); }
 inline void __builtin_amdgcn_s_waitcnt(int) {}
 inline long long clock64() { return 0; }

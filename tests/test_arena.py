@@ -37,7 +37,10 @@ def _spec_state(spec):
 
 
 @pytest.mark.parametrize('name', ['tiny_mobile', 'tiny_res'])
-def test_batch_in_one_allocation_equals_separate_plans(engine, name):
+def test_batch_in_one_allocation_equals_separate_plans(engine, name, monkeypatch):
+    # the one-launch correction (min/max blocks woven into the chain launch) is the default where a wave owns several groups of
+    # rows -- the bench's batch of 32; forced here so that five small networks take that path too
+    monkeypatch.setenv('DFQ_BC_ONE_LAUNCH', '1')
     seeds = [0, 1, 2, 3, 4]
     nets = [_prepared(name, s, engine.device) for s in seeds]
     twins = [_prepared(name, s, engine.device) for s in seeds]
@@ -65,6 +68,7 @@ def test_batch_in_one_allocation_equals_separate_plans(engine, name):
     results, done = le.query_all()
     assert done
     bc = batch.bc_plan()
+    assert bc.one_launch                            # a batch's correction: min/max blocks woven into the chain launch
     bc.run(check=True)
     for (m, g, b, rels), (m1, g1, b1, r1), res in zip(nets, twins, results):
         p1 = dfq.build_le_plan(g1, r1, TARG)
@@ -166,7 +170,7 @@ def test_replicated_entry_points_reject_bad_arguments(engine):
 
 
 @pytest.mark.gpu
-def test_full_size_batch_in_one_allocation_equals_single_network_plans():
+def test_full_size_batch_in_one_allocation_equals_single_network_plans(monkeypatch):
     """bench.py's default layout at the benchmark's size: MobileNetV2 (53 layers, 3.47 M weights) x 4 seeds as one allocation,
     one LE plan and one BC plan over the batch (streaming engine, deferred stores, the write-back kernel at the end) against a
     plan of its own for every network (the resident engine): every tensor, every cumulative scale and every sweep count
@@ -174,6 +178,9 @@ def test_full_size_batch_in_one_allocation_equals_single_network_plans():
     from dfq_amd import _ffi
     _ffi.lib()
     dev = torch.device('cuda', 0)
+    # the batch's correction as ONE launch (min/max blocks woven into the chain launch: the default from the batch size on at which a
+    # wave owns several groups of rows, forced for these four) against the single networks' pair of launches
+    monkeypatch.setenv('DFQ_BC_ONE_LAUNCH', '1')
     seeds = [0, 1, 2, 3]
     nets = [_prepared('mobilenet_v2', s, dev) for s in seeds]
     twins = [_prepared('mobilenet_v2', s, dev) for s in seeds]
@@ -181,6 +188,8 @@ def test_full_size_batch_in_one_allocation_equals_single_network_plans():
     batch.check(thorough=True)
     le, bc = batch.le_plan(), batch.bc_plan()
     assert le.resident_tiles == 0 and le.defer_depth == 4          # the batched, streaming path
+    assert bc.one_launch
+    monkeypatch.setenv('DFQ_BC_ONE_LAUNCH', '0')                   # (the twins below)
     le.run()
     results, done = le.query_all()
     assert done

@@ -684,6 +684,7 @@ def test_bias_correction_hand_over_protocols_agree(engine, monkeypatch, mode):
         start = {k: v.copy() for k, v in snapshot(graph).items()}
         plan, _ = dfq.build_bc_plan(graph, bottoms, TARG)
         assert plan.tagged == (mode == 'tagged') and not plan.last_run_tagged
+        assert not plan.one_launch                                # (a single network keeps min/max as its own launch: measured slower woven in)
         plan.run()
         # the run itself, on the stream the tests run on -- the NULL stream, which until round 5 was mistaken for the plan's
         # (not yet created) graph-recording stream and got the counters
@@ -1473,3 +1474,41 @@ def test_default_stream_is_an_ordinary_stream(engine):
         results.append(snapshot(graph))
     for k in results[0]:
         assert_bitexact(results[0][k], results[1][k], k)
+
+
+@pytest.mark.parametrize('setting', ['two-launches', 'ahead-0', 'ahead-1', 'ahead-100'])
+def test_one_launch_correction_is_invisible(engine, monkeypatch, setting):
+    """Round 5: a tagged correction can be ONE launch (the default for a batch) -- the per-tensor min/max blocks are workgroups of the chain launch, woven in
+    `DFQ_BC_MM_AHEAD` (default 2) chain positions in front of the steps that need them; a step waits for its layer's blocks
+    through a per-layer arrival counter.  Min and max do not care who forms them: results BIT-IDENTICAL to the pair of launches
+    (DFQ_BC_ONE_LAUNCH=0), for every look-ahead (0: right in front of the position; 100: all of them first), signed and unsigned,
+    and a second run of the plan (the other parity of the slots and counters) repeats the first."""
+    for k in ('DFQ_BC_TAGGED', 'DFQ_BC_MERGED', 'DFQ_BC_FOLD', 'DFQ_BC_ONE_LAUNCH', 'DFQ_BC_MM_AHEAD'):
+        monkeypatch.delenv(k, raising=False)
+    for name, seed, suffix in [('tiny_mobile', 0, ''), ('tiny_mobile', 2, '_signed'), ('tiny_cat', 0, ''), ('tiny_res', 0, '')]:
+        gold = net_fixture(name, seed, suffix)
+        signed = suffix == '_signed'
+        results = {}
+        for variant in ('default', setting):
+            monkeypatch.setenv('DFQ_BC_ONE_LAUNCH', '1')          # (the default for batches only; forced for these single networks)
+            monkeypatch.delenv('DFQ_BC_MM_AHEAD', raising=False)
+            if variant == 'two-launches':
+                monkeypatch.setenv('DFQ_BC_ONE_LAUNCH', '0')
+            elif variant.startswith('ahead-'):
+                monkeypatch.setenv('DFQ_BC_MM_AHEAD', variant.split('-')[1])
+            model, graph, bottoms = _build(name, seed, gold, engine)
+            lt.merge_batchnorm(model, graph, bottoms, TARG)
+            load_stage(graph, gold, 'abs')
+            plan, _ = dfq.build_bc_plan(graph, bottoms, TARG)
+            assert plan.one_launch == (variant != 'two-launches'), (name, variant)
+            plan.run(signed=signed, check=True)
+            first = snapshot(graph)
+            compare_stage(first, gold, 'bc', what='{} {}'.format(name, variant))
+            load_stage(graph, gold, 'abs')
+            plan.run(signed=signed, check=True)
+            for k, v in snapshot(graph).items():
+                assert_bitexact(v, first[k], '{} second run {} ({})'.format(name, k, variant))
+            plan.close()
+            results[variant] = first
+        for k, v in results['default'].items():
+            assert_bitexact(v, results[setting][k], '{} {} ({} vs default)'.format(name, k, setting))

@@ -28,7 +28,7 @@ SCRATCH_ALLOWED = {'le_sweep_kernel': (128, 110)}          # opt-in persistent-w
 # ceilings for scalar-register spills of the kernels that have any (everything else: 0)
 SGPR_SPILL_CEILING = {                                      # (ILb0 = the production instantiation, ILb1 = the tuning one with trace stamps)
     'le_resident_kernel': 600, 'le_level_kernelILb0': 100, 'le_level_kernelILb1': 150, 'le_sweep_kernel': 120,
-    'bc_chain_kernel': 95, 'bc_step_kernel': 60,
+    'bc_chain_kernel': 115, 'bc_step_kernel': 60,
 }
 
 
