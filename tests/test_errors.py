@@ -96,7 +96,7 @@ def test_degenerate_inputs_are_handled(engine):
     dfq.bias_correction(graph, bottoms, TARG)          # first layer is fed by 'Data': nothing to correct, must not fail
 
 
-@pytest.mark.parametrize('which', ['resident', 'streaming', 'bias_correction'])
+@pytest.mark.parametrize('which', ['resident', 'streaming', 'bias_correction', 'bias_correction_one_launch'])
 def test_abandoned_in_launch_wait_is_reported_not_silent(engine, monkeypatch, which):
     """Every wait of a workgroup for another workgroup of the same launch is bounded.  DFQ_SPIN_LIMIT=1 makes the first wait
     that is not satisfied at its first look give up -- what an oversubscribed or wedged GPU would cause after seconds: the run
@@ -117,6 +117,11 @@ def test_abandoned_in_launch_wait_is_reported_not_silent(engine, monkeypatch, wh
 
     if which == 'streaming':
         monkeypatch.setenv('DFQ_LE_RESIDENT', '0')
+    if which == 'bias_correction_one_launch':
+        # (a batch's default: the per-tensor min/max blocks are workgroups of the chain launch and the steps wait for their
+        # layer's blocks -- one more kind of in-launch wait, bounded like the others)
+        monkeypatch.setenv('DFQ_BC_ONE_LAUNCH', '1')
+        which = 'bias_correction'
     dfq.clear_plan_cache()
     monkeypatch.setenv('DFQ_SPIN_LIMIT', '1')
     model, graph, bottoms, rels = fresh()
