@@ -80,3 +80,66 @@ def test_a_layer_scaled_along_both_axes_has_no_closed_form():
     scaled = (w * inv[None, :]).astype(F32)
     ratios = scaled.max(-1) / w.max(-1)
     assert ratios.max() / ratios.min() > 1.5
+
+
+# ---- ... and against the unmodified reference (oracle/_ref: dfq.py byte-compiled from /root/reference by oracle/build_ref.py) ----
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REFDIR = os.path.join(ROOT, 'oracle', '_ref')
+
+
+@pytest.mark.skipif(not os.path.isfile(os.path.join(REFDIR, 'dfq.pyc')),
+                    reason='oracle/_ref is not built (oracle/build_ref.py needs /root/reference)')
+@pytest.mark.parametrize('signed', [False, True])
+def test_block_recurrence_against_the_reference_itself(signed):
+    """The same recurrence against the REFERENCE's `_layer_equalization` (dfq.py:29-75, torch on the CPU): the scale vectors of
+    both relations over 30 sweeps.  torch's CPU sqrt is not correctly rounded, so scale factors may differ from numpy's in the
+    last place -- the recurrence is therefore fed the reference's OWN solve, one channel at a time as the reference
+    does it: what is checked is that ranges taken from six scalars equal ranges taken from the weights, sweep after sweep."""
+    import torch
+    before = set(sys.modules)
+    sys.path.insert(0, REFDIR)
+    old = sys.dont_write_bytecode
+    sys.dont_write_bytecode = True
+    try:
+        import dfq as ref_dfq
+        assert os.path.dirname(os.path.abspath(ref_dfq.__file__)) == REFDIR
+        a, b, c = (torch.from_numpy(x.copy()) for x in _block(4))
+        ch = a.shape[0]
+
+        def stats(x2d):
+            if signed:
+                return torch.zeros(x2d.shape[0]), x2d.abs().max(-1)[0]
+            return x2d.min(-1)[0], x2d.max(-1)[0]
+
+        def rng(lo, hi):
+            return hi.clone() if signed else hi - lo
+
+        def solve(r1, r2):                      # dfq.py:56-59, element by element like the reference's loop
+            s = torch.empty(ch)
+            inv = torch.empty(ch)
+            for k in range(ch):
+                v = (1 / (r1[k] + 0)) * torch.sqrt(r1[k] * r2[k] + 0)
+                v = max(1e-8, min(1e8, v))
+                s[k] = v
+                inv[k] = 1 / v
+            return s, inv
+
+        lo_a, hi_a = stats(a.reshape(ch, -1))
+        lo_b, hi_b = stats(b.reshape(ch, -1))
+        lo_c, hi_c = stats(c.reshape(c.shape[0], ch).t())
+        with torch.no_grad():
+            for sweep in range(30):
+                _, _, _, s1 = ref_dfq._layer_equalization(a, b, None, signed=signed)
+                _, _, _, s2 = ref_dfq._layer_equalization(b, c, None, signed=signed)
+                q1, inv1 = solve(rng(lo_a, hi_a), rng(lo_b, hi_b))
+                lo_a, hi_a, lo_b, hi_b = lo_a * q1, hi_a * q1, lo_b * inv1, hi_b * inv1
+                q2, inv2 = solve(rng(lo_b, hi_b), rng(lo_c, hi_c))
+                lo_b, hi_b, lo_c, hi_c = lo_b * q2, hi_b * q2, lo_c * inv2, hi_c * inv2
+                assert torch.equal(s1, q1), (sweep, 'relation (a, b)')
+                assert torch.equal(s2, q2), (sweep, 'relation (b, c)')
+    finally:
+        sys.dont_write_bytecode = old
+        sys.path.remove(REFDIR)
+        for name in set(sys.modules) - before:
+            if name == 'dfq' or name == 'utils' or name.startswith('utils.'):
+                del sys.modules[name]
