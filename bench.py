@@ -708,6 +708,7 @@ def main():
     paired = probe['le'].paired_elements                    # sum over relations of n1 + n2
     rw, ro = probe['le'].rw_elements, probe['le'].ro_elements
     sweep_bytes, defer_depth, deferred = probe['le'].sweep_bytes, probe['le'].defer_depth, probe['le'].deferred_elements
+    fr_elems, fr_group = probe['le'].free_running_elements, probe['le'].free_running_group     # (dfq_le_cf.hpp)
 
     units = [make_unit(protos) for _ in range(args.steps + args.warmup)]
 
@@ -868,7 +869,12 @@ def main():
         empty = prof['empty_bracket_ms']
         lvl_corr = [max(ms / sweeps - empty, 0.0) for ms in prof['level_ms']]          # per launch, ms
         ctl_corr = max(prof['control_ms'] / sweeps - empty, 0.0)
-        share_levels = sum(lvl_corr) / max(sum(lvl_corr) + ctl_corr, 1e-12)
+        # the lean launch of the free-running layers runs once per group of sweeps: its time per launch and per sweep
+        n_lean = prof.get('lean_launches', 0)
+        lean_launch_corr = max(prof['lean_ms'] / n_lean - empty, 0.0) if n_lean else 0.0
+        lean_corr = lean_launch_corr * n_lean / sweeps
+        total_corr = max(sum(lvl_corr) + ctl_corr + lean_corr, 1e-12)
+        share_levels = sum(lvl_corr) / total_corr
         # every sweep must do real work here, so the convergence exit is disabled for this run
         always = dict(converge_thres=-1.0, converge_count=10 ** 9)
         wall_rep = make_unit(protos)
@@ -880,13 +886,14 @@ def main():
         avg_ms = sweep_ms * share_levels / levels
         # bytes as executed: one-way-scaled layers are read every sweep and stored every `defer_depth`-th one (dfq_le.hip,
         # "Deferred stores"); the timed bracket includes the launch that brings them up to date at the end
-        bytes_per_sweep = sweep_bytes
+        # ... and the free-running layers (8 B per element once per group of sweeps) are le_lean_kernel's bytes, not this kernel's
+        bytes_per_sweep = sweep_bytes - 8.0 * fr_elems / fr_group
         avg_bytes = bytes_per_sweep / levels
         achieved = avg_bytes / max(avg_ms * 1e-3, 1e-12) / 1e9
         per_level = []
         for l in range(levels):
             info = prof_rep['le'].level_info(l)
-            us = sweep_ms * 1e3 * lvl_corr[l] / max(sum(lvl_corr) + ctl_corr, 1e-12)
+            us = sweep_ms * 1e3 * lvl_corr[l] / total_corr
             nbytes = bytes_per_sweep if levels == 1 else 8 * info['rw_elements'] + 4 * info['ro_elements']
             per_level.append({'level': l, 'relations': info['relations'], 'workgroups': info['workgroups'],
                               'bytes': nbytes, 'us': us, 'GBps': nbytes / max(us, 1e-9) / 1e3})
@@ -908,9 +915,21 @@ def main():
             'equivalent_GBps_storing_every_sweep': (8 * rw + 4 * ro) / levels / max(avg_ms * 1e-3, 1e-12) / 1e9,
             'eager_formulation_bytes_per_launch': survey_bytes,
             'eager_formulation_equivalent_GBps': survey_bytes / max(avg_ms * 1e-3, 1e-12) / 1e9,
-            'sweep_wall_us': sweep_ms * 1e3, 'control_us_per_sweep': sweep_ms * 1e3 * (1.0 - share_levels),
+            'sweep_wall_us': sweep_ms * 1e3, 'control_us_per_sweep': sweep_ms * 1e3 * ctl_corr / total_corr,
             'event_pair_overhead_us': empty * 1e3, 'levels': per_level,
+            'bytes_per_sweep_all_kernels': sweep_bytes,
+            'GBps_per_sweep_all_kernels': sweep_bytes / max(sweep_ms * 1e-3, 1e-12) / 1e9,
         }
+        if n_lean:
+            # the second streaming kernel of a sweep: one launch per `fr_group` sweeps over the layers whose statistics are
+            # closed-form (read once, written once, |dW| of the whole group formed on the way)
+            lean_us = sweep_ms * 1e3 * (lean_corr / total_corr) * sweeps / n_lean
+            out['roofline']['free_running'] = {
+                'kernel': 'le_lean_kernel', 'sweeps_per_launch': fr_group, 'launches_timed': n_lean,
+                'bytes_per_launch': 8.0 * fr_elems, 'us_per_launch': lean_us, 'us_per_sweep': lean_us / fr_group,
+                'achieved': 8.0 * fr_elems / max(lean_us * 1e-6, 1e-12) / 1e9, 'unit': 'GB/s',
+                'frac': 8.0 * fr_elems / max(lean_us * 1e-6, 1e-12) / 1e9 / HBM_PEAK_GBS,
+            }
 
     # ---- the other BASELINE configurations, each with ms and roofline fraction.  These legs come after the headline has been
     #      measured: one of them failing is recorded in the line (`<name>_error`) instead of costing the whole line ----

@@ -100,13 +100,17 @@ SIGNATURES = {
     'dfq_le_plan_ro_elements': (c_int64, [c_void_p]),
     'dfq_le_plan_deferred_elements': (c_int64, [c_void_p]),
     'dfq_le_plan_defer_depth': (c_int32, [c_void_p]),
+    'dfq_le_plan_free_running_elements': (c_int64, [c_void_p]),
+    'dfq_le_plan_free_running_group': (c_int32, [c_void_p]),
+    'dfq_le_plan_lean_tiles': (c_int32, [c_void_p]),
+    'dfq_le_plan_lean_info': (c_int32, [c_void_p, c_int32, POINTER(c_int64)]),
     'dfq_le_plan_level_launches': (c_int32, [c_void_p, c_int32, POINTER(c_int64), POINTER(c_int64), POINTER(c_int32)]),
     'dfq_le_plan_level_grid': (c_int32, [c_void_p, c_int32, POINTER(c_int32), POINTER(c_int32)]),
     'dfq_le_enqueue': (c_int32, [c_void_p, POINTER(DfqLeConfig), c_int32, c_int32, c_void_p]),
     'dfq_le_query': (c_int32, [c_void_p, c_void_p, POINTER(DfqLeResult), POINTER(c_int32)]),
     'dfq_le_run': (c_int32, [c_void_p, POINTER(DfqLeConfig), c_void_p, POINTER(DfqLeResult)]),
     'dfq_le_profile': (c_int32, [c_void_p, POINTER(DfqLeConfig), c_int32, c_void_p, POINTER(c_double), POINTER(c_double),
-                                 POINTER(c_int32), POINTER(c_double)]),
+                                 POINTER(c_int32), POINTER(c_double), POINTER(c_double), POINTER(c_int32)]),
     'dfq_le_trace': (c_int32, [c_void_p, POINTER(DfqLeConfig), c_int32, c_int32, c_void_p, POINTER(c_int64)]),
     'dfq_le_plan_sweep_workgroups': (c_int32, [c_void_p]),
     'dfq_le_plan_block_info': (c_int32, [c_void_p, c_int32, c_int32, POINTER(c_int64)]),

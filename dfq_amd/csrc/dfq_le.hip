@@ -1196,6 +1196,8 @@ __global__ __launch_bounds__(kBlock, DFQ_LE_SWEEP_MIN_WAVES) void le_sweep_kerne
     }
 }
 
+#include "dfq_le_cf.hpp"
+
 // Stats of the untouched weights, once per run: R1 (rows of W1) for chain-start relations and R2
 // (columns of W2) for every relation, parity 0.  One workgroup per `kBootTc` paired channels.
 __global__ __launch_bounds__(kBlock) void le_bootstrap_kernel(const LeRelDev* __restrict__ rels,
@@ -1399,7 +1401,10 @@ __global__ __launch_bounds__(kCtlBlock) void le_control_kernel(const LeLayerDiff
                                                                uint32_t* __restrict__ r1_arena, int64_t r1_words,
                                                                int64_t r1_zero_words, int parity,
                                                                LeState* __restrict__ states, double converge_thres,
-                                                               int converge_count, int max_sweeps, int uni_layers, int uni_tiles) {
+                                                               int converge_count, int max_sweeps, int uni_layers, int uni_tiles,
+                                                               int n_clear, const LeCfSeg* __restrict__ cf_segs,
+                                                               const LeCfRel* __restrict__ cf_rels, const int32_t* __restrict__ cf_map,
+                                                               LeParams cf_p, int cf_k0, int cf_group) {
     __shared__ double sh_part[kCtlStage];
     __shared__ double sh_mean[1024];
     __shared__ LeLayerDiff sh_layer[1024];
@@ -1407,12 +1412,18 @@ __global__ __launch_bounds__(kCtlBlock) void le_control_kernel(const LeLayerDiff
     const int lane = tid % kWave;
     const int wave = tid / kWave;
     const int cur = parity;          // sweep index & 1, from the host
+    if ((int)blockIdx.x >= n_nets + n_clear) {
+        // free-running segments (dfq_le_cf.hpp): at the last sweep of a group these workgroups advance the recurrence by the next
+        // group's sweeps -- a thread per channel, no weight is read -- next to the verdicts and the clearing
+        cf_solve_block(cf_segs, cf_rels, cf_map, (int)blockIdx.x - n_nets - n_clear, cf_p, cf_k0, cf_group, cf_group, false, states);
+        return;
+    }
     if ((int)blockIdx.x >= n_nets) {
         // helper workgroups: clear the stat words the next sweep accumulates into (harmless once a
         // network has converged: its stats are never read again)
         // (16 bytes per store, up to one helper per CU: 6.3 MB per sweep for the benchmark's batch of 32 -- with 32 helpers
         // storing 4 bytes per thread this kernel took 8 us, 5.5 % of a sweep; both bases are 16-byte aligned, see stat_words)
-        const int64_t nz = gridDim.x - n_nets, z = blockIdx.x - n_nets;
+        const int64_t nz = n_clear, z = blockIdx.x - n_nets;
         auto clear = [&](uint32_t* base, int64_t n) {
             const int64_t n4 = n >> 2;
             float4* const b4 = reinterpret_cast<float4*>(base);            // all-zero bits either way
@@ -1550,23 +1561,30 @@ __global__ void le_prepare_kernel(ClearArgs a, LeState* states, int n_nets, doub
 // version went span -> relation descriptor (fields fetched piecemeal) -> loop state -> data, three dependent round trips before
 // the first element was requested, with four vectors per thread in flight: 258 us for the 516 MB of a batch of 32 (2 TB/s).
 constexpr int kFlushSpan = 8192;
-struct alignas(64) LeFlushRef {
+struct alignas(128) LeFlushRef {
     float* w;            // first element of the span
     const float* hold;   // remembered factors of this side: factor j of channel c is hold[2 j o1 + c]
     int32_t span;        // elements
     int32_t row_len;     // of the layer
     int32_t row0;        // row and position in that row of the first element
     int32_t pos0;
-    int32_t side;        // 0: W1 (rows by s), 1: W2 (columns by 1/s)
+    int32_t side;        // 0: W1 (rows by s), 1: W2 (columns by 1/s), 2: a depthwise layer between two free-running relations
+                         //    (row o by 1/s of the relation in front -- hold2 -- and then by s of its own -- hold --, sweep by sweep)
     int32_t net;
     int32_t go, gi, khkw, o1;
     int32_t vec;         // 1: the span is made of aligned 16-byte vectors that never cross a row
-    int32_t pad;
+    int32_t fr;          // layer of a free-running segment (dfq_le_cf.hpp): `hold` is the relation's factor ring, the pending
+                         //    sweeps are the ones after the group's first (cf_pending)
+    const float* hold2;  // side 2: the ring of the relation in front, at its 1/s
+    int32_t o1_2;        // channels of that relation
+    int32_t pc_gi;       // side 2: row o is channel o * pc_gi of it
+    int32_t pad[12];
 };
-static_assert(sizeof(LeFlushRef) == 64, "one span reference per 64-byte line");
-__global__ __launch_bounds__(kBlock) void le_flush_kernel(const LeFlushRef* __restrict__ refs, const LeState* __restrict__ state, int depth) {
+static_assert(sizeof(LeFlushRef) == 128, "one span reference per 128-byte line");
+__global__ __launch_bounds__(kBlock) void le_flush_kernel(const LeFlushRef* __restrict__ refs, const LeState* __restrict__ state, int depth,
+                                                          int cf_group) {
     const int lane = threadIdx.x % kWave;
-    const uint32_t word = fetch_words(refs + blockIdx.x, 16, lane);
+    const uint32_t word = fetch_words(refs + blockIdx.x, 20, lane);
     LeFlushRef ref;
     {
         const uint64_t w_lo = (uint32_t)__builtin_amdgcn_readlane(word, 0), w_hi = (uint32_t)__builtin_amdgcn_readlane(word, 1);
@@ -1578,10 +1596,30 @@ __global__ __launch_bounds__(kBlock) void le_flush_kernel(const LeFlushRef* __re
         ref.side = __builtin_amdgcn_readlane(word, 8); ref.net = __builtin_amdgcn_readlane(word, 9);
         ref.go = __builtin_amdgcn_readlane(word, 10); ref.gi = __builtin_amdgcn_readlane(word, 11);
         ref.khkw = __builtin_amdgcn_readlane(word, 12); ref.o1 = __builtin_amdgcn_readlane(word, 13);
-        ref.vec = __builtin_amdgcn_readlane(word, 14);
+        ref.vec = __builtin_amdgcn_readlane(word, 14); ref.fr = __builtin_amdgcn_readlane(word, 15);
+        const uint64_t g_lo = (uint32_t)__builtin_amdgcn_readlane(word, 16), g_hi = (uint32_t)__builtin_amdgcn_readlane(word, 17);
+        ref.hold2 = (const float*)(uintptr_t)(g_lo | (g_hi << 32));
+        ref.o1_2 = __builtin_amdgcn_readlane(word, 18); ref.pc_gi = __builtin_amdgcn_readlane(word, 19);
     }
-    const int pend = state[ref.net].sweeps & (depth - 1);
+    int slot0 = 0;
+    const int pend = ref.fr ? cf_pending(state[ref.net].sweeps, cf_group, &slot0) : (state[ref.net].sweeps & (depth - 1));
     if (pend == 0) return;
+    if (ref.side == 2) {
+        // depthwise layer between two free-running relations (a few thousand floats): per sweep dfq.py:73 of the relation in
+        // front, then dfq.py:62 of its own -- the two roundings the lean tile would have performed
+        const int row_len = ref.row_len;
+        gfloat* const w2 = (gfloat*)ref.w;
+        for (int off = (int)threadIdx.x; off < ref.span; off += kBlock) {
+            const int o = ref.row0 + small_div(ref.pos0 + off, row_len);
+            float x = w2[off];
+            for (int j = 0; j < pend; ++j) {
+                x = x * ref.hold2[(int64_t)(2 * (slot0 + j)) * ref.o1_2 + o * ref.pc_gi];
+                x = x * ref.hold[(int64_t)(2 * (slot0 + j)) * ref.o1 + o];
+            }
+            w2[off] = x;
+        }
+        return;
+    }
     const int side = ref.side, row_len = ref.row_len, span = ref.span;
     gfloat* const w = (gfloat*)ref.w;
     const float* const hold = ref.hold;
@@ -1610,20 +1648,20 @@ __global__ __launch_bounds__(kBlock) void le_flush_kernel(const LeFlushRef* __re
             const int c0 = channel(off[k]);
             if (side == 0) {
                 for (int j = 0; j < pend; ++j) {
-                    const float hj = hold[(int64_t)(2 * j) * ref.o1 + c0];
+                    const float hj = hold[(int64_t)(2 * (slot0 + j)) * ref.o1 + c0];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) x[k][e] = x[k][e] * hj;
                 }
             } else if (ref.khkw == 1 && (((uintptr_t)(hold + c0)) & 15) == 0 && ((2 * ref.o1) & 3) == 0) {
                 for (int j = 0; j < pend; ++j) {
-                    const fvec4 hj = *(const fvec4*)(hold + (int64_t)(2 * j) * ref.o1 + c0);
+                    const fvec4 hj = *(const fvec4*)(hold + (int64_t)(2 * (slot0 + j)) * ref.o1 + c0);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) x[k][e] = x[k][e] * hj[e];
                 }
             } else {
                 const int c1 = channel(off[k] + 1), c2 = channel(off[k] + 2), c3 = channel(off[k] + 3);
                 for (int j = 0; j < pend; ++j) {
-                    const float* h = hold + (int64_t)(2 * j) * ref.o1;
+                    const float* h = hold + (int64_t)(2 * (slot0 + j)) * ref.o1;
                     x[k][0] = x[k][0] * h[c0]; x[k][1] = x[k][1] * h[c1]; x[k][2] = x[k][2] * h[c2]; x[k][3] = x[k][3] * h[c3];
                 }
             }
@@ -1633,7 +1671,7 @@ __global__ __launch_bounds__(kBlock) void le_flush_kernel(const LeFlushRef* __re
         for (int off = (int)threadIdx.x; off < span; off += kBlock) {
             const int c = channel(off);
             float x = w[off];
-            for (int j = 0; j < pend; ++j) x = x * hold[(int64_t)(2 * j) * ref.o1 + c];
+            for (int j = 0; j < pend; ++j) x = x * hold[(int64_t)(2 * (slot0 + j)) * ref.o1 + c];
             w[off] = x;
         }
     }
@@ -1714,6 +1752,17 @@ struct dfq_le_plan {
     // (le_sweep_kernel; an experiment that measured slower than one workgroup per tile)
     LeTileRef* d_tiles = nullptr;
     int sweep_grid = 0;                    // workgroups of le_sweep_kernel; 0: le_level_kernel
+    // free-running segments (dfq_le_cf.hpp): their layers are not in the sweep's workgroup table -- le_lean_kernel handles a
+    // group of cf_group sweeps at the group's first sweep, the solver workgroups of the convergence launch keep the factor rings
+    int cf_group = 1;                      // G; 1: no free-running segments in this plan
+    int n_cf_rels = 0, n_cf_segs = 0, n_cf_blocks = 0, n_lean = 0;
+    LeCfRel* d_cf_rels = nullptr;
+    LeCfSeg* d_cf_segs = nullptr;
+    int32_t* d_cf_map = nullptr;           // solver workgroup -> (segment, block of kCtlBlock channels)
+    LeLeanRef* d_lean = nullptr;
+    int64_t fr_total = 0;                  // elements of free-running layers: read and written once per cf_group sweeps
+    int64_t part_stride = 0;               // doubles of one sweep's partial sums (the array exists cf_group times)
+    std::vector<int> lean_info;            // per lean tile: kind, rows, floats per row (dfq_le_plan_lean_info)
 };
 
 // elements per tile; DFQ_LE_TILE_ELEMS overrides (tuning / tests).  A workgroup's fixed cost (workgroup table ->
@@ -1755,6 +1804,15 @@ static int col_cols_max(int vec, bool batched) {
     return (batched && vec == 4) ? 64 : kColTileLanes * vec;
 }
 static int ceil_div(int a, int b) { return (a + b - 1) / b; }
+// group depth of the free-running segments (dfq_le_cf.hpp): DFQ_LE_CF=0 or DFQ_LE_CF_GROUP=1 keep every layer on the general
+// tiles; 2 / 4 / 8 sweeps per pass over a free-running layer (default 4)
+static int cf_group_from_env() {
+    const char* off = getenv("DFQ_LE_CF");
+    if (off && off[0] == '0') return 1;
+    const char* e = getenv("DFQ_LE_CF_GROUP");
+    const int v = e ? atoi(e) : 4;
+    return v >= 8 ? 8 : v >= 4 ? 4 : v >= 2 ? 2 : 1;
+}
 // rows of a full-row tile (row_tile's local mode): what the register slots hold, at most the tile target
 static int local_rows(int n_rows, int row_len, int target) {
     const int cap = kSlotsVec4 * (kBlock / (row_len / 4));
@@ -1984,6 +2042,45 @@ int dfq_le_plan_create_batch(const dfq_layer* layers, int32_t n_layers, const in
         d.boot_tiles = ceil_div(d.o1, kBootTc) * d.boot_split;
         d.net = net_of(rr.first);
     }
+    // ---- free-running segments (dfq_le_cf.hpp): a chain start, relations linked through depthwise layers, a chain end ----
+    std::vector<int> fr(n_relations, 0);            // 1 + position in its segment
+    std::vector<int> fr_last(n_relations, 0);       // last relation of its segment (its second layer is the chain's end)
+    std::vector<std::vector<int>> segments;
+    p->cf_group = cf_group_from_env();
+    {
+        const bool no_short = getenv("DFQ_LE_NO_SHORT") != nullptr;
+        // first layer handled by one thread per row (the rule of the second pass below)
+        auto short_first = [&](int r, int j_prev) {
+            const LeRelDev& d = h[r];
+            return !no_short && d.khkw1 == d.row_len && d.row_len <= 32 && d.row_len != 1 && (j_prev < 0 || h[j_prev].go == 1);
+        };
+        for (int r0 = 0; r0 < n_relations && p->cf_group > 1; ++r0) {
+            if (as_second[relations[r0].first] >= 0) continue;              // not a chain start
+            std::vector<int> seg{r0};
+            bool ok = true;
+            for (int cur = r0;;) {
+                const int nx = as_first[relations[cur].second];
+                if (nx < 0) break;                                          // the chain ends here: every statistic is closed-form
+                // the layer in between must be scaled uniformly along BOTH statistics' axes: one thread-per-row channel per paired channel
+                const bool diag = short_first(nx, cur) && h[cur].go == 1 && h[cur].gi == 1 && h[nx].o1 == h[cur].o1 && (int)seg.size() < kCfMaxRel;
+                if (!diag) { ok = false; break; }
+                seg.push_back(nx);
+                cur = nx;
+            }
+            if (!ok) continue;
+            // the last layer's column tiles keep one table entry per (group, input channel) they span and sweep
+            LeRelDev& last = h[seg.back()];
+            if (last.ct_vec != 0) {
+                const int nci2 = ceil_div(last.ct_cols, last.khkw) + 1;
+                while (last.ct_rows > 1 && (ceil_div(last.ct_rows, last.go) + 1) * nci2 > kCfTab) last.ct_rows = (last.ct_rows + 1) / 2;
+                if ((ceil_div(last.ct_rows, last.go) + 1) * nci2 > kCfTab) continue;
+            }
+            for (size_t i = 0; i < seg.size(); ++i) fr[seg[i]] = 1 + (int)i;
+            fr_last[seg.back()] = 1;
+            segments.push_back(seg);
+        }
+        if (segments.empty()) p->cf_group = 1;
+    }
     // producer links + slot limits need every relation's geometry, so a second pass
     int tile_slot = 0;
     // Thread-per-row W1 that is interior (a depthwise layer inside a chain): its threads take the row range of t = fl(w / s_prev)
@@ -1997,6 +2094,7 @@ int dfq_le_plan_create_batch(const dfq_layer* layers, int32_t n_layers, const in
         for (int r = 0; r < n_relations && on; ++r) {
             const LeRelDev& d = h[r];
             const int j_prev = as_second[relations[r].first];
+            if (fr[r]) continue;                      // free-running: its tiles are le_lean_kernel's
             if (j_prev < 0 || as_first[relations[j_prev].second] != r) continue;
             const bool short_rows = d.khkw1 == d.row_len && d.row_len <= kShortChunk && d.row_len != 1 && h[j_prev].go == 1;
             if (short_rows && h[j_prev].ct_vec == 0) { local_r1[r] = 1; skip_cols[j_prev] = 1; continue; }
@@ -2042,7 +2140,7 @@ int dfq_le_plan_create_batch(const dfq_layer* layers, int32_t n_layers, const in
             d.rt_rows = local_rows(d.o1, d.row_len, target);
         }
         d.n_row_tiles = ceil_div(d.o1, d.rt_rows) * d.rt_slabs;
-        d.n_col_tiles = skip_cols[r] ? 0 : ceil_div(d.o2, d.ct_rows) * d.ct_slabs;
+        d.n_col_tiles = (skip_cols[r] || (fr[r] && !fr_last[r])) ? 0 : ceil_div(d.o2, d.ct_rows) * d.ct_slabs;   // (no pass over a depthwise layer inside a free-running segment)
         d.local_r1 = local_r1[r] ? 1 : 0;
         d.partial_base = tile_slot;
         ld[rr.first].partial_begin = d.partial_base;
@@ -2068,6 +2166,7 @@ int dfq_le_plan_create_batch(const dfq_layer* layers, int32_t n_layers, const in
         std::vector<int64_t> hold_off(n_relations, -1);
         for (int r = 0; r < n_relations && p->defer > 1; ++r) {
             LeRelDev& d = h[r];
+            if (fr[r]) continue;
             if (!d.w1_interior && d.rt_vec != 0) { d.defer |= 1; p->deferred_total += (int64_t)d.o1 * d.row_len; }
             if (!d.w2_interior && d.ct_vec != 0) { d.defer |= 2; p->deferred_total += (int64_t)d.o2 * d.i2g * d.khkw; }
             if (d.defer) { hold_off[r] = hold_floats; hold_floats += (int64_t)2 * (p->defer - 1) * d.o1; }
@@ -2131,10 +2230,14 @@ int dfq_le_plan_create_batch(const dfq_layer* layers, int32_t n_layers, const in
         sorted[i] = h[r];
         sorted[i].boot_begin = boot;              // bootstrap launch walks the same (sorted) table
         boot += h[r].boot_tiles;
-        L.n_blocks += h[r].n_row_tiles + h[r].n_col_tiles;
         L.n_rels += 1;
         const int64_t n1 = (int64_t)h[r].o1 * h[r].row_len;
         const int64_t n2 = (int64_t)h[r].o2 * h[r].i2g * h[r].khkw;
+        if (fr[r]) {                              // free-running: not in the sweep's workgroup table (le_lean_kernel)
+            p->fr_total += n1 + (fr_last[r] ? n2 : 0);
+            continue;
+        }
+        L.n_blocks += h[r].n_row_tiles + h[r].n_col_tiles;
         L.rw_elems += n1 + (h[r].w2_interior ? 0 : n2);
         L.ro_elems += (h[r].w2_interior && h[r].n_col_tiles > 0) ? n2 : 0;      // (no read-only pass where the next relation's rows are local)
     }
@@ -2169,7 +2272,8 @@ int dfq_le_plan_create_batch(const dfq_layer* layers, int32_t n_layers, const in
     timer.tick("layout");
     if ((e = p->mem.alloc((void**)&p->d_rels, sizeof(LeRelDev) * std::max(1, n_relations))) != hipSuccess) return fail_alloc(e);
     if ((e = p->mem.alloc((void**)&p->d_layer_diff, sizeof(LeLayerDiff) * n_layers)) != hipSuccess) return fail_alloc(e);
-    if ((e = p->mem.alloc((void**)&p->d_partials, sizeof(double) * n_part)) != hipSuccess) return fail_alloc(e);
+    p->part_stride = (int64_t)n_part;                // one array of partial sums per sweep of a group (dfq_le_cf.hpp)
+    if ((e = p->mem.alloc((void**)&p->d_partials, sizeof(double) * n_part * p->cf_group)) != hipSuccess) return fail_alloc(e);
     if ((e = p->mem.alloc((void**)&p->d_layer_mean, sizeof(double) * n_layers)) != hipSuccess) return fail_alloc(e);
     if ((e = p->mem.alloc((void**)&p->d_state, sizeof(LeState) * n_nets)) != hipSuccess) return fail_alloc(e);
     if ((e = p->mem.alloc((void**)&p->d_nets, sizeof(LeNetDesc) * n_nets)) != hipSuccess) return fail_alloc(e);
@@ -2177,7 +2281,7 @@ int dfq_le_plan_create_batch(const dfq_layer* layers, int32_t n_layers, const in
     if ((e = hipMemcpy(p->d_nets, nets.data(), sizeof(LeNetDesc) * n_nets, hipMemcpyHostToDevice)) != hipSuccess) return fail_alloc(e);
     if ((e = hipMemcpy(p->d_boot_map, boot_map.data(), sizeof(int32_t) * boot_map.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail_alloc(e);
     if ((e = hipMemcpy(p->d_layer_diff, ld.data(), sizeof(LeLayerDiff) * n_layers, hipMemcpyHostToDevice)) != hipSuccess) return fail_alloc(e);
-    if ((e = hipMemset(p->d_partials, 0, sizeof(double) * n_part)) != hipSuccess) return fail_alloc(e);
+    if ((e = hipMemset(p->d_partials, 0, sizeof(double) * n_part * p->cf_group)) != hipSuccess) return fail_alloc(e);
     if ((e = hipMemset(p->d_state, 0, sizeof(LeState) * n_nets)) != hipSuccess) return fail_alloc(e);
     {
         // dependency links (see le_level_kernel): position of every relation in the level-sorted table
@@ -2225,6 +2329,7 @@ int dfq_le_plan_create_batch(const dfq_layer* layers, int32_t n_layers, const in
             L.block_begin = (int)blocks.size();
             for (int i = 0; i < L.n_rels; ++i) {
                 const LeRelDev& d = sorted[L.rel_begin + i];
+                if (fr[order[L.rel_begin + i]]) continue;
                 for (int t = d.local_r1 ? d.n_row_tiles : 0; t < d.n_row_tiles + d.n_col_tiles; ++t) blocks.push_back(LeBlockRef{L.rel_begin + i, t, d.net, 0});
                 // ... followed by the row tiles of the next relation of the chain where those take their rows' statistics themselves
                 const int j_next = as_first[relations[order[L.rel_begin + i]].second];
@@ -2241,10 +2346,28 @@ int dfq_le_plan_create_batch(const dfq_layer* layers, int32_t n_layers, const in
             (e = hipMemcpy(p->d_blocks, blocks.data(), sizeof(LeBlockRef) * blocks.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail_alloc(e);
         p->h_rels = sorted;
         p->h_blocks = blocks;
-        if (p->defer > 1) {
+        {
             std::vector<LeFlushRef> refs;
             std::vector<int32_t> hold_rels;
-            for (int i = 0; i < n_relations; ++i) {
+            auto add_spans = [&](float* base, int64_t n, int64_t rl, const float* hold, int side, const LeRelDev& d, int is_fr,
+                                 const float* hold2, int o1_2) {
+                for (int64_t f = 0; f < n; f += kFlushSpan) {
+                    LeFlushRef fr_;
+                    memset(&fr_, 0, sizeof(fr_));
+                    fr_.w = base + f;
+                    fr_.hold = hold;
+                    fr_.span = (int32_t)std::min<int64_t>(kFlushSpan, n - f);
+                    fr_.row_len = (int32_t)rl;
+                    fr_.row0 = (int32_t)(f / rl); fr_.pos0 = (int32_t)(f % rl);
+                    fr_.side = side; fr_.net = d.net;
+                    fr_.go = d.go; fr_.gi = d.gi; fr_.khkw = d.khkw; fr_.o1 = d.o1;
+                    fr_.vec = ((rl & 3) == 0 && (((uintptr_t)fr_.w) & 15) == 0) ? 1 : 0;
+                    fr_.fr = is_fr;
+                    fr_.hold2 = hold2; fr_.o1_2 = o1_2; fr_.pc_gi = d.pc_gi;
+                    refs.push_back(fr_);
+                }
+            };
+            for (int i = 0; i < n_relations && p->defer > 1; ++i) {
                 const LeRelDev& d = sorted[i];
                 if (!d.defer) continue;
                 hold_rels.push_back(i);
@@ -2252,30 +2375,132 @@ int dfq_le_plan_create_batch(const dfq_layer* layers, int32_t n_layers, const in
                     if (!(d.defer & (1 << side))) continue;
                     const int64_t n = side == 0 ? (int64_t)d.o1 * d.row_len : (int64_t)d.o2 * d.i2g * d.khkw;
                     const int64_t rl = side == 0 ? d.row_len : (int64_t)d.i2g * d.khkw;
-                    float* const base = side == 0 ? d.w1 : d.w2;
-                    for (int64_t f = 0; f < n; f += kFlushSpan) {
-                        LeFlushRef fr;
-                        memset(&fr, 0, sizeof(fr));
-                        fr.w = base + f;
-                        fr.hold = d.hold + (int64_t)side * d.o1;
-                        fr.span = (int32_t)std::min<int64_t>(kFlushSpan, n - f);
-                        fr.row_len = (int32_t)rl;
-                        fr.row0 = (int32_t)(f / rl); fr.pos0 = (int32_t)(f % rl);
-                        fr.side = side; fr.net = d.net;
-                        fr.go = d.go; fr.gi = d.gi; fr.khkw = d.khkw; fr.o1 = d.o1;
-                        fr.vec = ((rl & 3) == 0 && (((uintptr_t)fr.w) & 15) == 0) ? 1 : 0;
-                        refs.push_back(fr);
-                    }
+                    add_spans(side == 0 ? d.w1 : d.w2, n, rl, d.hold + (int64_t)side * d.o1, side, d, 0, nullptr, 0);
                 }
+            }
+            // ---- free-running segments: factor rings + recurrence state, the solver's tables, the lean tiles, their flush spans ----
+            if (p->cf_group > 1) {
+                const int G = p->cf_group;
+                std::vector<int> cf_index(n_relations, -1);          // original relation -> LeCfRel
+                std::vector<LeCfRel> cf_rels;
+                std::vector<LeCfSeg> cf_segs;
+                std::vector<int32_t> cf_map;
+                int64_t ring_floats = 0, state_floats = 0;
+                for (const auto& seg : segments)
+                    for (int r : seg) { ring_floats += (int64_t)4 * G * h[r].o1; state_floats += (int64_t)4 * h[r].o1; }
+                float* d_ring = nullptr;
+                float* d_state = nullptr;
+                if ((e = p->mem.alloc((void**)&d_ring, sizeof(float) * ring_floats)) != hipSuccess) return fail_alloc(e);
+                if ((e = p->mem.alloc((void**)&d_state, sizeof(float) * state_floats)) != hipSuccess) return fail_alloc(e);
+                int64_t ring_off = 0, state_off = 0;
+                for (const auto& seg : segments) {
+                    LeCfSeg S;
+                    memset(&S, 0, sizeof(S));
+                    S.n_rel = (int)seg.size(); S.o1 = h[seg[0]].o1; S.net = h[seg[0]].net;
+                    for (size_t i = 0; i < seg.size(); ++i) {
+                        const int r = seg[i];
+                        const LeRelDev& d = sorted[pos[r]];
+                        LeCfRel c;
+                        memset(&c, 0, sizeof(c));
+                        c.ring = d_ring + ring_off; ring_off += (int64_t)4 * G * d.o1;
+                        c.state = d_state + state_off; state_off += (int64_t)4 * d.o1;
+                        c.boot_r1 = i == 0 ? d.r1 : nullptr;             // (parity 0: what the bootstrap launch writes)
+                        c.boot_r2 = d.r2;
+                        c.s_cum = d.s_cum; c.bnw = d.bnw; c.bnb = d.bnb; c.b1 = d.b1;
+                        c.o1 = d.o1; c.net = d.net;
+                        cf_index[r] = (int)cf_rels.size();
+                        S.rel[i] = (int)cf_rels.size();
+                        cf_rels.push_back(c);
+                    }
+                    for (int ch = 0; ch < ceil_div(S.o1, kCtlBlock); ++ch) { cf_map.push_back((int32_t)cf_segs.size()); cf_map.push_back(ch); }
+                    cf_segs.push_back(S);
+                }
+                // the lean tiles: the same shapes the general tiles of these layers would have had, listed network after network
+                std::vector<LeLeanRef> lean;
+                auto lean_base = [&](const LeRelDev& d, int r) {
+                    LeLeanRef t;
+                    memset(&t, 0, sizeof(t));
+                    t.ring = cf_rels[cf_index[r]].ring;
+                    t.net = d.net; t.o1 = d.o1; t.go = d.go; t.gi = d.gi; t.khkw = d.khkw; t.pc_gi = 1; t.o1_prev = 1;
+                    return t;
+                };
+                for (int i = 0; i < n_relations; ++i) {
+                    const int r = order[i];
+                    if (!fr[r]) continue;
+                    const LeRelDev& d = sorted[i];
+                    const int j_prev = as_second[relations[r].first];
+                    // first layer: rows * s
+                    for (int tile = 0; tile < d.n_row_tiles; ++tile) {
+                        LeLeanRef t = lean_base(d, r);
+                        t.slot = d.partial_base + tile;
+                        if (d.rt_vec == 0) {
+                            t.kind = kLeanShort0;
+                            t.r0 = tile * kBlock; t.nr = std::min(kBlock, d.o1 - t.r0); t.np = d.row_len; t.stride = d.row_len; t.p0 = 0;
+                            t.w = d.w1 + (int64_t)t.r0 * d.row_len;
+                            if (j_prev >= 0) { t.ring_prev = cf_rels[cf_index[j_prev]].ring; t.o1_prev = h[j_prev].o1; t.pc_gi = d.pc_gi; }
+                            t.s_cum = d.s_cum; t.bnw = d.bnw; t.bnb = d.bnb; t.b1 = d.b1;
+                        } else {
+                            const int rblk = tile / d.rt_slabs, slab = tile - rblk * d.rt_slabs;
+                            t.kind = d.rt_vec == 4 ? kLeanRow4 : kLeanRow1;
+                            t.r0 = rblk * d.rt_rows; t.nr = std::min(d.rt_rows, d.o1 - t.r0);
+                            t.p0 = slab * d.rt_cols; t.np = std::min(d.rt_cols, d.row_len - t.p0); t.stride = d.row_len;
+                            t.w = d.w1 + ((int64_t)t.r0 * d.row_len + t.p0);
+                            if (slab == 0) { t.s_cum = d.s_cum; t.bnw = d.bnw; t.bnb = d.bnb; t.b1 = d.b1; }
+                        }
+                        lean.push_back(t);
+                        p->lean_info.push_back(t.kind); p->lean_info.push_back(t.nr); p->lean_info.push_back(t.np);
+                    }
+                    // the chain's last layer: columns * 1/s
+                    const int row_len2 = d.i2g * d.khkw;
+                    for (int tile = 0; tile < d.n_col_tiles; ++tile) {
+                        LeLeanRef t = lean_base(d, r);
+                        t.slot = d.partial_base + d.n_row_tiles + tile;
+                        if (d.ct_vec == 0) {
+                            t.kind = kLeanShort1;
+                            t.r0 = tile * kBlock; t.nr = std::min(kBlock, d.o2 - t.r0); t.np = row_len2; t.stride = row_len2; t.p0 = 0;
+                            t.w = d.w2 + (int64_t)t.r0 * row_len2;
+                        } else {
+                            const int rblk = tile / d.ct_slabs, slab = tile - rblk * d.ct_slabs;
+                            t.kind = d.ct_vec == 4 ? kLeanCol4 : kLeanCol1;
+                            t.r0 = rblk * d.ct_rows; t.nr = std::min(d.ct_rows, d.o2 - t.r0);
+                            t.p0 = slab * d.ct_cols; t.np = std::min(d.ct_cols, row_len2 - t.p0); t.stride = row_len2;
+                            t.w = d.w2 + ((int64_t)t.r0 * row_len2 + t.p0);
+                        }
+                        lean.push_back(t);
+                        p->lean_info.push_back(t.kind); p->lean_info.push_back(t.nr); p->lean_info.push_back(t.np);
+                    }
+                    // what a loop that stops inside a group leaves pending
+                    const float* ring = cf_rels[cf_index[r]].ring;
+                    if (j_prev >= 0)
+                        add_spans(d.w1, (int64_t)d.o1 * d.row_len, d.row_len, ring, 2, d, 1, cf_rels[cf_index[j_prev]].ring + h[j_prev].o1, h[j_prev].o1);
+                    else
+                        add_spans(d.w1, (int64_t)d.o1 * d.row_len, d.row_len, ring, 0, d, 1, nullptr, 0);
+                    if (fr_last[r]) add_spans(d.w2, (int64_t)d.o2 * row_len2, row_len2, ring + d.o1, 1, d, 1, nullptr, 0);
+                }
+                p->n_cf_rels = (int)cf_rels.size(); p->n_cf_segs = (int)cf_segs.size(); p->n_cf_blocks = (int)cf_map.size() / 2;
+                p->n_lean = (int)lean.size();
+                if ((e = p->mem.alloc((void**)&p->d_cf_rels, sizeof(LeCfRel) * cf_rels.size())) != hipSuccess) return fail_alloc(e);
+                if ((e = p->mem.alloc((void**)&p->d_cf_segs, sizeof(LeCfSeg) * cf_segs.size())) != hipSuccess) return fail_alloc(e);
+                if ((e = p->mem.alloc((void**)&p->d_cf_map, sizeof(int32_t) * cf_map.size())) != hipSuccess) return fail_alloc(e);
+                if ((e = p->mem.alloc((void**)&p->d_lean, sizeof(LeLeanRef) * lean.size())) != hipSuccess) return fail_alloc(e);
+                if ((e = hipMemcpy(p->d_cf_rels, cf_rels.data(), sizeof(LeCfRel) * cf_rels.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail_alloc(e);
+                if ((e = hipMemcpy(p->d_cf_segs, cf_segs.data(), sizeof(LeCfSeg) * cf_segs.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail_alloc(e);
+                if ((e = hipMemcpy(p->d_cf_map, cf_map.data(), sizeof(int32_t) * cf_map.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail_alloc(e);
+                if ((e = hipMemcpy(p->d_lean, lean.data(), sizeof(LeLeanRef) * lean.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail_alloc(e);
+                hipLaunchKernelGGL(le_cf_ring_reset_kernel, dim3(p->n_cf_rels), dim3(kBlock), 0, nullptr, (const LeCfRel*)p->d_cf_rels, G);
             }
             p->n_flush = (int)refs.size();
             p->n_hold_rels = (int)hold_rels.size();
-            if ((e = p->mem.alloc((void**)&p->d_flush, sizeof(LeFlushRef) * refs.size())) != hipSuccess) return fail_alloc(e);
-            if ((e = p->mem.alloc((void**)&p->d_hold_rels, sizeof(int32_t) * hold_rels.size())) != hipSuccess) return fail_alloc(e);
-            if ((e = hipMemcpy(p->d_flush, refs.data(), sizeof(LeFlushRef) * refs.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail_alloc(e);
-            if ((e = hipMemcpy(p->d_hold_rels, hold_rels.data(), sizeof(int32_t) * hold_rels.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail_alloc(e);
-            hipLaunchKernelGGL(le_hold_reset_kernel, dim3(p->n_hold_rels), dim3(kBlock), 0, nullptr, (const LeRelDev*)p->d_rels,
-                               (const int32_t*)p->d_hold_rels, (const LeState*)p->d_state, p->defer, 1);
+            if (!refs.empty()) {
+                if ((e = p->mem.alloc((void**)&p->d_flush, sizeof(LeFlushRef) * refs.size())) != hipSuccess) return fail_alloc(e);
+                if ((e = hipMemcpy(p->d_flush, refs.data(), sizeof(LeFlushRef) * refs.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail_alloc(e);
+            }
+            if (!hold_rels.empty()) {
+                if ((e = p->mem.alloc((void**)&p->d_hold_rels, sizeof(int32_t) * hold_rels.size())) != hipSuccess) return fail_alloc(e);
+                if ((e = hipMemcpy(p->d_hold_rels, hold_rels.data(), sizeof(int32_t) * hold_rels.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail_alloc(e);
+                hipLaunchKernelGGL(le_hold_reset_kernel, dim3(p->n_hold_rels), dim3(kBlock), 0, nullptr, (const LeRelDev*)p->d_rels,
+                                   (const int32_t*)p->d_hold_rels, (const LeState*)p->d_state, p->defer, 1);
+            }
         }
         // counters: [relation: its column tiles][error word + padding][relation: its row tiles (local_r1)]
         if ((e = p->mem.alloc((void**)&p->d_dep, sizeof(unsigned long long) * ((size_t)(2 * n_relations + 1) * kDepStride + 1))) != hipSuccess) return fail_alloc(e);
@@ -2378,18 +2603,30 @@ int64_t dfq_le_resident_trace_words(const dfq_le_plan* p) { return (p && p->resi
 int32_t dfq_le_plan_levels(const dfq_le_plan* p) { return p ? (p->merged ? (p->levels.empty() ? 0 : 1) : (int32_t)p->levels.size()) : 0; }
 int32_t dfq_le_plan_depth(const dfq_le_plan* p) { return p ? (int32_t)p->levels.size() : 0; }
 int64_t dfq_le_plan_paired_elements(const dfq_le_plan* p) { return p ? p->paired_total : 0; }
-int64_t dfq_le_plan_rw_elements(const dfq_le_plan* p) { return p ? p->rw_total : 0; }
+int64_t dfq_le_plan_rw_elements(const dfq_le_plan* p) { return p ? p->rw_total + (res_on(p) ? p->fr_total : 0) : 0; }   // (the persistent launch holds every paired layer)
 int64_t dfq_le_plan_ro_elements(const dfq_le_plan* p) { return p ? p->ro_total : 0; }
 // deferred stores of the streaming engine: elements (a part of rw_elements) that are read every sweep but written only
 // every `depth`-th; depth 1 = every sweep (resident plans, DFQ_LE_DEFER=1)
 int64_t dfq_le_plan_deferred_elements(const dfq_le_plan* p) { return (p && !res_on(p)) ? p->deferred_total : 0; }
 int32_t dfq_le_plan_defer_depth(const dfq_le_plan* p) { return (p && !res_on(p)) ? p->defer : 1; }
+// free-running segments of the streaming engine (dfq_le_cf.hpp): elements (NOT part of rw_elements) of layers whose every
+// statistic is closed-form -- read and written once per `group` sweeps by le_lean_kernel; group 1 = none
+int64_t dfq_le_plan_free_running_elements(const dfq_le_plan* p) { return (p && !res_on(p)) ? p->fr_total : 0; }
+int32_t dfq_le_plan_free_running_group(const dfq_le_plan* p) { return (p && !res_on(p)) ? p->cf_group : 1; }
+int32_t dfq_le_plan_lean_tiles(const dfq_le_plan* p) { return (p && !res_on(p)) ? p->n_lean : 0; }
+// tile `tile` of the lean launch: out3 = kind (0/1 rows of 16-byte vectors / floats, 2 thread per row, 3/4 columns, 5 thread per
+// row of a chain's last layer), rows, floats per row
+int dfq_le_plan_lean_info(const dfq_le_plan* p, int32_t tile, int64_t* out3) {
+    if (!p || !out3 || tile < 0 || tile >= p->n_lean) return fail_arg("dfq_le_plan_lean_info: bad argument");
+    for (int i = 0; i < 3; ++i) out3[i] = p->lean_info[(size_t)3 * tile + i];
+    return DFQ_OK;
+}
 
 // the slice of the sweep's workgroup table that launch `launch` covers
 static bool launch_slice(const dfq_le_plan* p, int launch, int* begin, int* count, int* n_rels, int64_t* rw, int64_t* ro) {
     if (!p || launch < 0 || launch >= dfq_le_plan_levels(p)) return false;
     if (p->merged) {
-        *begin = 0; *count = p->total_tiles; *n_rels = p->n_rels; *rw = p->rw_total; *ro = p->ro_total;
+        *begin = 0; *count = (int)p->h_blocks.size(); *n_rels = p->n_rels; *rw = p->rw_total; *ro = p->ro_total;
     } else {
         const LevelLaunch& L = p->levels[launch];
         *begin = L.block_begin; *count = L.n_blocks; *n_rels = L.n_rels; *rw = L.rw_elems; *ro = L.ro_elems;
@@ -2441,6 +2678,12 @@ int32_t dfq_le_plan_level_launches(const dfq_le_plan* p, int32_t level, int64_t*
 
 }  // extern "C"
 
+static LeParams plan_params(const dfq_le_plan* p, const dfq_le_config* cfg) {
+    LeParams q = make_params(cfg);
+    q.defer = p->defer;
+    return q;
+}
+
 // reset the loop state, clear every stat word, recompute the stats of the untouched weights
 static int le_restart(dfq_le_plan* p, const dfq_le_config* cfg, hipStream_t st) {
     {
@@ -2455,9 +2698,13 @@ static int le_restart(dfq_le_plan* p, const dfq_le_config* cfg, hipStream_t st) 
         DFQ_CHECK_LAUNCH();
     }
     p->sweep_index = 0;
-    if (p->defer > 1) {
+    if (p->defer > 1 && p->n_hold_rels > 0) {
         hipLaunchKernelGGL(le_hold_reset_kernel, dim3(p->n_hold_rels), dim3(kBlock), 0, st, (const LeRelDev*)p->d_rels,
                            (const int32_t*)p->d_hold_rels, (const LeState*)p->d_state, p->defer, 1);
+        DFQ_CHECK_LAUNCH();
+    }
+    if (p->cf_group > 1) {
+        hipLaunchKernelGGL(le_cf_ring_reset_kernel, dim3(p->n_cf_rels), dim3(kBlock), 0, st, (const LeCfRel*)p->d_cf_rels, p->cf_group);
         DFQ_CHECK_LAUNCH();
     }
     if (p->n_rels > 0) {
@@ -2465,25 +2712,53 @@ static int le_restart(dfq_le_plan* p, const dfq_le_config* cfg, hipStream_t st) 
                            (const LeRelDev*)p->d_rels, (const int32_t*)p->d_boot_map);
         DFQ_CHECK_LAUNCH();
     }
+    if (p->cf_group > 1) {
+        // the factors of the first group's sweeps, from the scalars the bootstrap launch has just taken
+        hipLaunchKernelGGL(le_cf_solve_kernel, dim3(p->n_cf_blocks), dim3(kCtlBlock), 0, st, (const LeCfSeg*)p->d_cf_segs,
+                           (const LeCfRel*)p->d_cf_rels, (const int32_t*)p->d_cf_map, plan_params(p, cfg), 0, p->cf_group, p->cf_group, 1,
+                           (const LeState*)p->d_state);
+        DFQ_CHECK_LAUNCH();
+    }
     return DFQ_OK;
 }
 
 // deferred stores: bring the weights up to date with the sweeps run so far (a no-op for networks whose last sweep stored)
 static int le_flush(dfq_le_plan* p, hipStream_t st) {
-    if (p->defer <= 1 || p->n_flush == 0) return DFQ_OK;
+    if (p->n_flush == 0) return DFQ_OK;
     hipLaunchKernelGGL(le_flush_kernel, dim3(p->n_flush), dim3(kBlock), 0, st, (const LeFlushRef*)p->d_flush, (const LeState*)p->d_state,
-                       p->defer);
+                       p->defer, p->cf_group);
     DFQ_CHECK_LAUNCH();
-    hipLaunchKernelGGL(le_hold_reset_kernel, dim3(p->n_hold_rels), dim3(kBlock), 0, st, (const LeRelDev*)p->d_rels,
-                       (const int32_t*)p->d_hold_rels, (const LeState*)p->d_state, p->defer, 0);
-    DFQ_CHECK_LAUNCH();
+    if (p->n_hold_rels > 0) {
+        hipLaunchKernelGGL(le_hold_reset_kernel, dim3(p->n_hold_rels), dim3(kBlock), 0, st, (const LeRelDev*)p->d_rels,
+                           (const int32_t*)p->d_hold_rels, (const LeState*)p->d_state, p->defer, 0);
+        DFQ_CHECK_LAUNCH();
+    }
+    if (p->cf_group > 1) {
+        // free-running segments: the pending sweeps into the [O1] vectors, their ring entries back to 1
+        hipLaunchKernelGGL(le_cf_settle_kernel, dim3(p->n_cf_rels), dim3(kBlock), 0, st, (const LeCfRel*)p->d_cf_rels,
+                           (const LeState*)p->d_state, p->cf_group);
+        DFQ_CHECK_LAUNCH();
+    }
     return DFQ_OK;
 }
 
-static LeParams plan_params(const dfq_le_plan* p, const dfq_le_config* cfg) {
-    LeParams q = make_params(cfg);
-    q.defer = p->defer;
-    return q;
+// partial sums of the sweep being enqueued (one array per sweep of a group: the lean tiles of a group's first sweep leave the
+// later sweeps' sums in theirs, dfq_le_cf.hpp)
+static double* sweep_partials(const dfq_le_plan* p) { return p->d_partials + (p->sweep_index & (p->cf_group - 1)) * p->part_stride; }
+
+// the lean tiles of the free-running layers: at the first sweep of a group only
+static int le_launch_lean(dfq_le_plan* p, hipStream_t st) {
+    if (p->cf_group <= 1 || p->n_lean == 0 || (p->sweep_index & (p->cf_group - 1)) != 0) return DFQ_OK;
+    LeanArgs a;
+    a.k = (int32_t)p->sweep_index; a.pad = 0; a.part_stride = p->part_stride;
+    if (p->cf_group == 2)
+        hipLaunchKernelGGL(le_lean_kernel<2>, dim3(p->n_lean), dim3(kBlock), 0, st, (const LeLeanRef*)p->d_lean, a, (const LeState*)p->d_state, p->d_partials);
+    else if (p->cf_group == 4)
+        hipLaunchKernelGGL(le_lean_kernel<4>, dim3(p->n_lean), dim3(kBlock), 0, st, (const LeLeanRef*)p->d_lean, a, (const LeState*)p->d_state, p->d_partials);
+    else
+        hipLaunchKernelGGL(le_lean_kernel<8>, dim3(p->n_lean), dim3(kBlock), 0, st, (const LeLeanRef*)p->d_lean, a, (const LeState*)p->d_state, p->d_partials);
+    DFQ_CHECK_LAUNCH();
+    return DFQ_OK;
 }
 
 // launch number `launch` of a sweep (see dfq_le_plan_levels)
@@ -2495,18 +2770,18 @@ static int le_launch_level(dfq_le_plan* p, int launch, const LeParams& q, hipStr
     if (p->sweep_grid > 0) {
         DFQ_LAUNCH_RESIDENT(le_sweep_kernel, dim3(p->sweep_grid), dim3(kBlock), 0, st, (const LeRelDev*)p->d_rels,
                             (const LeTileRef*)p->d_tiles, count, q, (int)p->sweep_index, (const LeState*)p->d_state, p->n_nets,
-                            p->d_partials, p->d_dep, p->d_dep + (size_t)p->n_rels * kDepStride, tr);
+                            sweep_partials(p), p->d_dep, p->d_dep + (size_t)p->n_rels * kDepStride, tr);
         DFQ_CHECK_LAUNCH();
         return DFQ_OK;
     }
     if (tr.out)
         hipLaunchKernelGGL(le_level_kernel<true>, dim3(count), dim3(kBlock), 0, st, (const LeRelDev*)p->d_rels,
                            (const LeBlockRef*)(p->d_blocks + begin), q, (int)p->sweep_index, (const LeState*)p->d_state,
-                           p->d_partials, p->d_dep, p->d_dep + (size_t)p->n_rels * kDepStride, tr);
+                           sweep_partials(p), p->d_dep, p->d_dep + (size_t)p->n_rels * kDepStride, tr);
     else
         hipLaunchKernelGGL(le_level_kernel<false>, dim3(count), dim3(kBlock), 0, st, (const LeRelDev*)p->d_rels,
                            (const LeBlockRef*)(p->d_blocks + begin), q, (int)p->sweep_index, (const LeState*)p->d_state,
-                           p->d_partials, p->d_dep, p->d_dep + (size_t)p->n_rels * kDepStride, tr);
+                           sweep_partials(p), p->d_dep, p->d_dep + (size_t)p->n_rels * kDepStride, tr);
     DFQ_CHECK_LAUNCH();
     return DFQ_OK;
 }
@@ -2518,12 +2793,17 @@ constexpr int kCtlHelpers = 224;           // workgroups that clear the statisti
 #endif
 static int le_launch_control(dfq_le_plan* p, const dfq_le_config* cfg, hipStream_t st) {
     const int n_clear = (int)std::min<int64_t>(kCtlHelpers, (p->stat_words + p->r1_zero_words + 8 * kCtlBlock - 1) / (8 * kCtlBlock));
-    hipLaunchKernelGGL(le_control_kernel, dim3(p->n_nets + std::max(1, n_clear)), dim3(kCtlBlock), 0, st,
+    // at the last sweep of a group: the solver workgroups of the free-running segments leave the next group's factors (dfq_le_cf.hpp)
+    const bool solve = p->cf_group > 1 && ((p->sweep_index + 1) & (p->cf_group - 1)) == 0;
+    const int n_helpers = std::max(1, n_clear);
+    hipLaunchKernelGGL(le_control_kernel, dim3(p->n_nets + n_helpers + (solve ? p->n_cf_blocks : 0)), dim3(kCtlBlock), 0, st,
                        (const LeLayerDiff*)p->d_layer_diff, (const LeNetDesc*)p->d_nets, p->n_nets,
-                       (const double*)p->d_partials, p->d_layer_mean, p->d_stats,
+                       (const double*)sweep_partials(p), p->d_layer_mean, p->d_stats,
                        (int64_t)p->stat_words, p->d_stats + 2 * p->stat_words, (int64_t)p->stat_words,
                        (int64_t)p->r1_zero_words, (int)(p->sweep_index & 1),
-                       p->d_state, cfg->converge_thres, (int)cfg->converge_count, (int)cfg->max_sweeps, p->uni_layers, p->uni_tiles);
+                       p->d_state, cfg->converge_thres, (int)cfg->converge_count, (int)cfg->max_sweeps, p->uni_layers, p->uni_tiles,
+                       n_helpers, (const LeCfSeg*)p->d_cf_segs, (const LeCfRel*)p->d_cf_rels, (const int32_t*)p->d_cf_map,
+                       plan_params(p, cfg), (int)(p->sweep_index + 1), p->cf_group);
     DFQ_CHECK_LAUNCH();
     p->sweep_index += 1;             // the control launch closes a sweep
     return DFQ_OK;
@@ -2548,6 +2828,7 @@ static int le_enqueue_direct(dfq_le_plan* p, const dfq_le_config* cfg, int n_swe
     std::unique_ptr<SpinGuard> guard;
     if (guarded && guard_loop) guard.reset(new SpinGuard(st));
     for (int s = 0; s < n_sweeps; ++s) {
+        if ((rc = le_launch_lean(p, st))) return rc;
         for (int l = 0; l < dfq_le_plan_levels(p); ++l) {
             std::unique_ptr<SpinGuard> g1;
             if (guarded && !guard_loop) g1.reset(new SpinGuard(st));
@@ -2610,12 +2891,12 @@ int dfq_le_enqueue(dfq_le_plan* p, const dfq_le_config* cfg, int32_t n_sweeps, i
 }
 
 int dfq_le_profile(dfq_le_plan* p, const dfq_le_config* cfg, int32_t n_sweeps, void* stream, double* level_ms,
-                   double* control_ms, int32_t* n_level_launches, double* empty_bracket_ms) {
+                   double* control_ms, int32_t* n_level_launches, double* empty_bracket_ms, double* lean_ms, int32_t* n_lean_launches) {
     if (!p || !cfg || n_sweeps <= 0 || !level_ms) return fail_arg("dfq_le_profile: bad argument");
     hipStream_t st = as_stream(stream);
     const LeParams q = plan_params(p, cfg);
     const int n_levels = dfq_le_plan_levels(p);
-    const int per_sweep = n_levels + 1;
+    const int per_sweep = n_levels + 2;
     std::vector<hipEvent_t> ev((size_t)2 * per_sweep * n_sweeps);
     for (auto& e : ev) DFQ_HIP_TRY(hipEventCreate(&e));
     int rc = le_restart(p, cfg, st);
@@ -2629,7 +2910,13 @@ int dfq_le_profile(dfq_le_plan* p, const dfq_le_config* cfg, int32_t n_sweeps, v
         DFQ_HIP_TRY(hipEventRecord(cal[2 * i + 1], st));
     }
     size_t k = 0;
+    std::vector<char> had_lean(n_sweeps, 0);
     for (int s = 0; s < n_sweeps; ++s) {
+        // the lean tiles of the free-running layers (first sweep of a group only, dfq_le_cf.hpp): a bracket of their own
+        had_lean[s] = p->cf_group > 1 && p->n_lean > 0 && (p->sweep_index & (p->cf_group - 1)) == 0;
+        DFQ_HIP_TRY(hipEventRecord(ev[k++], st));
+        if ((rc = le_launch_lean(p, st))) return rc;
+        DFQ_HIP_TRY(hipEventRecord(ev[k++], st));
         for (int l = 0; l < n_levels; ++l) {
             DFQ_HIP_TRY(hipEventRecord(ev[k++], st));
             if ((rc = le_launch_level(p, l, q, st))) return rc;
@@ -2642,18 +2929,23 @@ int dfq_le_profile(dfq_le_plan* p, const dfq_le_config* cfg, int32_t n_sweeps, v
     if ((rc = le_flush(p, st))) return rc;
     DFQ_HIP_TRY(hipStreamSynchronize(st));
     for (int l = 0; l < n_levels; ++l) level_ms[l] = 0.0;
-    double ctl = 0.0;
+    double ctl = 0.0, lean = 0.0;
+    int n_lean = 0;
     k = 0;
     for (int s = 0; s < n_sweeps; ++s) {
-        for (int l = 0; l <= n_levels; ++l) {
+        for (int l = -1; l <= n_levels; ++l) {
             float ms = 0.0f;
             DFQ_HIP_TRY(hipEventElapsedTime(&ms, ev[k], ev[k + 1]));
             k += 2;
-            if (l < n_levels) level_ms[l] += ms; else ctl += ms;
+            if (l < 0) { if (had_lean[s]) { lean += ms; n_lean += 1; } }
+            else if (l < n_levels) level_ms[l] += ms;
+            else ctl += ms;
         }
     }
     if (control_ms) *control_ms = ctl;
     if (n_level_launches) *n_level_launches = n_levels * n_sweeps;
+    if (lean_ms) *lean_ms = lean;
+    if (n_lean_launches) *n_lean_launches = n_lean;
     double cal_ms = 0.0;
     for (int i = 0; i < n_cal; ++i) {
         float ms = 0.0f;
@@ -2678,6 +2970,7 @@ int dfq_le_trace(dfq_le_plan* p, const dfq_le_config* cfg, int32_t launch, int32
     const char* te = getenv("DFQ_TRACE_SWEEP");    // default: the second sweep (steady-state stat flow)
     const int traced = (te && atoi(te) >= 0) ? atoi(te) : 1;
     for (int s = 0; s <= traced && !rc; ++s) {
+        rc = le_launch_lean(p, st);
         for (int l = 0; l < dfq_le_plan_levels(p) && !rc; ++l)
             rc = le_launch_level(p, l, q, st, (s == traced && l == launch) ? LeTrace{d, block, 0} : LeTrace{nullptr, 0, 0});
         if (!rc) rc = le_launch_control(p, cfg, st);
@@ -2709,6 +3002,7 @@ int dfq_le_trace_blocks(dfq_le_plan* p, const dfq_le_config* cfg, int32_t launch
     const char* te = getenv("DFQ_TRACE_SWEEP");
     const int traced = (te && atoi(te) >= 0) ? atoi(te) : 2;
     for (int s = 0; s <= traced && !rc; ++s) {
+        rc = le_launch_lean(p, st);
         for (int l = 0; l < dfq_le_plan_levels(p) && !rc; ++l)
             rc = le_launch_level(p, l, q, st, (s == traced && l == launch) ? LeTrace{d, -1, 0} : LeTrace{nullptr, 0, 0});
         if (!rc) rc = le_launch_control(p, cfg, st);

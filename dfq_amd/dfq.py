@@ -153,10 +153,30 @@ class LEPlan:
         return _ffi.lib().dfq_le_plan_defer_depth(self._plan)
 
     @property
+    def free_running_elements(self):
+        """Elements (NOT part of rw_elements) of layers whose every statistic is closed-form: the streaming engine reads and
+        writes them once per `free_running_group` sweeps, in a lean launch of its own (dfq_le_cf.hpp, include/dfq_hip.h)."""
+        return _ffi.lib().dfq_le_plan_free_running_elements(self._plan)
+
+    @property
+    def free_running_group(self):
+        return _ffi.lib().dfq_le_plan_free_running_group(self._plan)
+
+    @property
+    def lean_tiles(self):
+        return _ffi.lib().dfq_le_plan_lean_tiles(self._plan)
+
+    def lean_info(self, tile):
+        out = (ctypes.c_int64 * 3)()
+        _ffi.check(_ffi.lib().dfq_le_plan_lean_info(self._plan, int(tile), out))
+        return dict(kind=int(out[0]), rows=int(out[1]), cols=int(out[2]))
+
+    @property
     def sweep_bytes(self):
-        """Bytes one sweep moves as executed (averaged over defer_depth sweeps)."""
+        """Bytes one sweep moves as executed (averaged over defer_depth sweeps and over a group of the free-running layers)."""
         d = self.defer_depth
-        return 8 * self.rw_elements + 4 * self.ro_elements - 4.0 * self.deferred_elements * (d - 1) / d
+        return (8 * self.rw_elements + 4 * self.ro_elements - 4.0 * self.deferred_elements * (d - 1) / d
+                + 8.0 * self.free_running_elements / self.free_running_group)
 
     @property
     def ro_elements(self):
@@ -199,10 +219,13 @@ class LEPlan:
         ctl = ctypes.c_double()
         nlaunch = ctypes.c_int32()
         empty = ctypes.c_double()
+        lean = ctypes.c_double()
+        nlean = ctypes.c_int32()
         _ffi.check(_ffi.lib().dfq_le_profile(self._plan, ctypes.byref(cfg), int(n_sweeps), _ffi.stream_arg(), level_ms,
-                                             ctypes.byref(ctl), ctypes.byref(nlaunch), ctypes.byref(empty)))
+                                             ctypes.byref(ctl), ctypes.byref(nlaunch), ctypes.byref(empty), ctypes.byref(lean),
+                                             ctypes.byref(nlean)))
         return dict(level_ms=[level_ms[i] for i in range(nl)], control_ms=ctl.value, level_launches=nlaunch.value,
-                    empty_bracket_ms=empty.value)
+                    empty_bracket_ms=empty.value, lean_ms=lean.value, lean_launches=nlean.value)
 
     def trace(self, launch, block, **kw):
         """Shader-clock stamps of one workgroup's tile phases (tuning aid, see dfq_le_trace)."""
@@ -847,7 +870,7 @@ class _no_in_launch_waits:
 # every environment switch the library reads while it CREATES a plan (tests/test_errors.py checks this list against the sources)
 _PLAN_ENV = ('DFQ_LE_RESIDENT', 'DFQ_LE_MERGED', 'DFQ_LE_TILE_ELEMS', 'DFQ_LE_ROW_COLS', 'DFQ_LE_COL_COLS', 'DFQ_LE_BOOT_WORK',
              'DFQ_LE_PERSIST', 'DFQ_LE_SWEEP_WGS', 'DFQ_LE_EMIT_COLS', 'DFQ_LE_NO_SHORT', 'DFQ_LE_CHAIN_FIRST', 'DFQ_LE_POLL_NAPS',
-             'DFQ_LE_DEFER', 'DFQ_LE_UNIFORM', 'DFQ_LE_LOCAL_R1', 'DFQ_LE_LOCAL_ROW', 'DFQ_RES_EXACT_GROUPS', 'DFQ_RES_RELAXED', 'DFQ_RES_ORDER', 'DFQ_RES_SPEC', 'DFQ_RES_CKPT',
+             'DFQ_LE_DEFER', 'DFQ_LE_CF', 'DFQ_LE_CF_GROUP', 'DFQ_LE_UNIFORM', 'DFQ_LE_LOCAL_R1', 'DFQ_LE_LOCAL_ROW', 'DFQ_RES_EXACT_GROUPS', 'DFQ_RES_RELAXED', 'DFQ_RES_ORDER', 'DFQ_RES_SPEC', 'DFQ_RES_CKPT',
              'DFQ_RES_DIRECT', 'DFQ_RES_SHORT_RPT', 'DFQ_RES_TILE_FLOATS', 'DFQ_BC_TAGGED', 'DFQ_BC_MERGED', 'DFQ_BC_BLOCKS', 'DFQ_BC_EPS', 'DFQ_BC_FOLD', 'DFQ_BC_MM_CHUNK', 'DFQ_BC_ONE_GROUP', 'DFQ_BC_ONE_LAUNCH', 'DFQ_BC_MM_AHEAD',
              'DFQ_GRAPH', 'DFQ_COOPERATIVE', 'DFQ_HIP_LIB')
 # ... and the ones it reads on every RUN (they change no plan)

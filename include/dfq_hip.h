@@ -148,6 +148,20 @@ int64_t dfq_le_plan_ro_elements(const dfq_le_plan* plan);
  * elements: bytes per sweep as executed, averaged over D sweeps = 8 * rw + 4 * ro - 4 * deferred * (D - 1) / D. */
 int64_t dfq_le_plan_deferred_elements(const dfq_le_plan* plan);
 int32_t dfq_le_plan_defer_depth(const dfq_le_plan* plan);
+/* Free-running segments of the streaming engine (dfq_le_cf.hpp; DFQ_LE_CF=0 switches them off, DFQ_LE_CF_GROUP = G in
+ * {2, 4, 8}, default 4).  A chain of relations whose every consumed range is closed-form -- a chain's first layer (rows * s,
+ * dfq.py:62), depthwise layers in between, its last layer (columns * 1/s, dfq.py:73): max_i fl(w_i * s) == fl(max_i w_i * s)
+ * -- has the scale factors of ALL its sweeps follow from a few scalars per channel (dfq.py:39-59 without reading a weight).
+ * Its layers are not part of a sweep's launch: at the first sweep of every group of G sweeps ONE lean launch reads them, brings
+ * them up to date, stores them and leaves sum |W - W_prev| (dfq.py:105-108) of the group's G sweeps; every enqueue call ends by
+ * bringing them up to date like the deferred stores.  free_running_elements are NOT part of rw_elements: bytes per sweep as
+ * executed = 8 * rw + 4 * ro - 4 * deferred * (D - 1) / D + 8 * free_running / G.  Bit-identical values and sweep counts. */
+int64_t dfq_le_plan_free_running_elements(const dfq_le_plan* plan);
+int32_t dfq_le_plan_free_running_group(const dfq_le_plan* plan);
+int32_t dfq_le_plan_lean_tiles(const dfq_le_plan* plan);
+/* Tuning aid: tile `tile` of the lean launch.  out3 = { kind (0 / 1: rows * s in 16-byte vectors / floats, 2: one thread per
+ * row, 3 / 4: columns * 1/s, 5: one thread per row of a chain's last layer), rows, floats per row }. */
+int dfq_le_plan_lean_info(const dfq_le_plan* plan, int32_t tile, int64_t* out3);
 /* the same two counts for one launch level; returns the number of relations in it */
 int32_t dfq_le_plan_level_launches(const dfq_le_plan* plan, int32_t level, int64_t* rw_elems,
                                    int64_t* ro_elems, int32_t* n_workgroups);
@@ -205,11 +219,12 @@ int dfq_le_run(dfq_le_plan* plan, const dfq_le_config* cfg, void* stream, dfq_le
  * launch is bracketed by a pair of HIP events recorded on `stream`.  level_ms[l] receives the summed
  * duration of the launches of level l (array of dfq_le_plan_levels() doubles), *control_ms the summed
  * duration of the convergence kernel, *n_level_launches the number of level launches timed,
- * *empty_bracket_ms what a pair of event records measures with nothing between them (to subtract).
- * Synchronises. */
+ * *empty_bracket_ms what a pair of event records measures with nothing between them (to subtract),
+ * *lean_ms / *n_lean_launches (either may be NULL) the summed duration and number of the lean launches of the
+ * free-running layers (one per group of sweeps).  Synchronises. */
 int dfq_le_profile(dfq_le_plan* plan, const dfq_le_config* cfg, int32_t n_sweeps, void* stream,
                    double* level_ms, double* control_ms, int32_t* n_level_launches,
-                   double* empty_bracket_ms);
+                   double* empty_bracket_ms, double* lean_ms, int32_t* n_lean_launches);
 
 /* Tuning aid: run two sweeps and return the shader-clock stamps (s_memtime) that thread 0 of
  * workgroup `block` (= blockIdx.y * grid_x + blockIdx.x) of launch `launch` took at the phase boundaries of its tile during the second

@@ -246,14 +246,21 @@ def _kat_names():
 # the equalisation engines a single network can run on: the resident whole-loop launch; the streaming launch of one
 # workgroup per tile (what batched plans use); the opt-in streaming launch of persistent workgroups (DFQ_LE_PERSIST=1;
 # with 3 workgroups every workgroup walks several tiles and tiles wait for tiles of other workgroups)
-LE_ENGINES = ['resident', 'streaming', 'streaming-persistent', 'streaming-persistent-3wg']
+# 'streaming': the default streaming engine -- free-running segments on lean tiles, four sweeps per pass (dfq_le_cf.hpp), the other
+# layers on the general tiles; '-cf2' / '-cf8': other group depths; 'streaming-general': every layer on the general tiles
+# (DFQ_LE_CF=0); the persistent-workgroup variants of the general tiles run without free-running segments as well
+LE_ENGINES = ['resident', 'streaming', 'streaming-cf2', 'streaming-cf8', 'streaming-general', 'streaming-persistent', 'streaming-persistent-3wg']
 
 
 def _select_le_engine(monkeypatch, le_engine):
-    for k in ('DFQ_LE_RESIDENT', 'DFQ_LE_PERSIST', 'DFQ_LE_SWEEP_WGS', 'DFQ_LE_TILE_ELEMS'):
+    for k in ('DFQ_LE_RESIDENT', 'DFQ_LE_PERSIST', 'DFQ_LE_SWEEP_WGS', 'DFQ_LE_TILE_ELEMS', 'DFQ_LE_CF', 'DFQ_LE_CF_GROUP'):
         monkeypatch.delenv(k, raising=False)
     if le_engine != 'resident':
         monkeypatch.setenv('DFQ_LE_RESIDENT', '0')
+    if le_engine.startswith('streaming-cf'):
+        monkeypatch.setenv('DFQ_LE_CF_GROUP', le_engine[len('streaming-cf'):])
+    if le_engine == 'streaming-general' or le_engine.startswith('streaming-persistent'):
+        monkeypatch.setenv('DFQ_LE_CF', '0')
     if le_engine.startswith('streaming-persistent'):
         monkeypatch.setenv('DFQ_LE_PERSIST', '1')
         monkeypatch.setenv('DFQ_LE_TILE_ELEMS', '1024')     # enough tiles for workgroups to walk several (the result does not depend on it)
@@ -508,8 +515,10 @@ def test_depthwise_rows_take_their_own_statistics(engine, monkeypatch, merged, t
     """Round 4 (streaming engine): a depthwise layer inside a chain is walked by one thread per row, so the thread takes the
     row range of t = fl(w / s_prev) itself, publishes it for its relation's column tiles (which wait for it inside the launch)
     and the previous relation's read-only pass over the layer is not launched (LeRelDev::local_r1).  Fewer workgroups, the same
-    bits: against the oracle and against the plan that keeps the pass (DFQ_LE_LOCAL_R1=0), data-dependent sweep count included."""
+    bits: against the oracle and against the plan that keeps the pass (DFQ_LE_LOCAL_R1=0), data-dependent sweep count included.
+    (General tiles only, DFQ_LE_CF=0: with free-running segments the blocks of this network are not on these tiles at all.)"""
     monkeypatch.setenv('DFQ_LE_RESIDENT', '0')
+    monkeypatch.setenv('DFQ_LE_CF', '0')
     monkeypatch.setenv('DFQ_LE_MERGED', merged)
     if tile_elems:
         monkeypatch.setenv('DFQ_LE_TILE_ELEMS', str(tile_elems))
@@ -1238,8 +1247,9 @@ def test_speculation_past_the_verdict_is_invisible(engine, monkeypatch, name, se
 
 
 # (the persistent-workgroup variant is slow on the CPU emulation: it runs at the default depth of batched plans only)
-@pytest.mark.parametrize('depth,le_engine', [('1', 'streaming'), ('2', 'streaming'), ('4', 'streaming'), ('4', 'streaming-persistent-3wg')])
-@pytest.mark.parametrize('name,seed,signed', [('tiny_mobile', 0, False), ('tiny_res', 0, False), ('tiny_cat', 3, True)])
+@pytest.mark.parametrize('depth,le_engine', [('1', 'streaming-general'), ('2', 'streaming-general'), ('4', 'streaming-general'), ('4', 'streaming-persistent-3wg'),
+                                             ('1', 'streaming'), ('4', 'streaming'), ('2', 'streaming-cf2'), ('4', 'streaming-cf8')])
+@pytest.mark.parametrize('name,seed,signed', [('tiny_mobile', 0, False), ('tiny_res', 0, False), ('tiny_cat', 3, True), ('tiny_tail', 1, False)])
 def test_deferred_stores_are_invisible(engine, monkeypatch, depth, le_engine, name, seed, signed):
     """Streaming engine, DFQ_LE_DEFER = depth: layers that are scaled one way only are stored every depth-th sweep and
     re-derived from the stored values and the remembered factors in between (dfq_le.hip).  Whatever the depth and however
@@ -1253,12 +1263,22 @@ def test_deferred_stores_are_invisible(engine, monkeypatch, depth, le_engine, na
     rels = rel.create_relation(graph, bottoms, TARG)
     spec0 = graphspec.from_torch(graph, bottoms, TARG)
     plan = dfq.build_le_plan(graph, rels, TARG)
-    assert plan.resident_tiles == 0 and plan.defer_depth == int(depth)
-    if depth == '1':
-        assert plan.deferred_elements == 0
+    assert plan.resident_tiles == 0
+    if le_engine in ('streaming-general', 'streaming-persistent-3wg'):
+        assert plan.defer_depth == int(depth) and plan.free_running_elements == 0 and plan.free_running_group == 1 and plan.lean_tiles == 0
+        if depth == '1':
+            assert plan.deferred_elements == 0
+        else:
+            assert 0 < plan.deferred_elements <= plan.rw_elements
+            assert plan.sweep_bytes < 8 * plan.rw_elements + 4 * plan.ro_elements
     else:
-        assert 0 < plan.deferred_elements <= plan.rw_elements
-        assert plan.sweep_bytes < 8 * plan.rw_elements + 4 * plan.ro_elements
+        # the free-running segments (dfq_le_cf.hpp): layers whose every statistic is closed-form leave the sweep's launch
+        group = {'streaming': 4, 'streaming-cf2': 2, 'streaming-cf8': 8}[le_engine]
+        if name in ('tiny_cat', 'tiny_tail'):   # (their chains run through dense layers scaled along both axes: nothing is free-running)
+            assert plan.free_running_group == 1 and plan.free_running_elements == 0
+        else:
+            assert plan.free_running_group == group and plan.free_running_elements > 0 and plan.lean_tiles > 0
+        assert plan.rw_elements + plan.free_running_elements <= plan.paired_elements
     plan.enqueue(0, restart=True, signed=signed)
     total = 0
     for n in (1, 1, 1, 2, 3, 5, 1, 1000):
