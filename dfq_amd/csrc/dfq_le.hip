@@ -241,14 +241,23 @@ __device__ __forceinline__ void landed(uint32_t& a, uint32_t& b, uint32_t& c, ui
 #endif
 }
 
-// dependency of a workgroup inside a one-launch sweep (see le_level_kernel)
+// dependency of a workgroup inside a one-launch sweep (see le_level_kernel): where the counters and the error word are, how
+// patient a wait is.  Two carriers with one interface: LeDep holds the values (le_sweep_kernel); LeDepCold (below, behind
+// LevelArgs) re-reads them from the kernel's argument block where a wait uses them -- they are touched by one thread of a
+// workgroup, once or twice in its life, and six scalar registers that stay live across a whole tile function are six more values
+// the compiler parks in vector-register lanes and moves back and forth (`cold`, dfq_le_resident.hip).
 struct LeDep {
-    const unsigned long long* counters;   // 64-bit: tiles x sweeps outgrows 32 bits on runs with a large sweep cap
-    unsigned long long* err;
+    const unsigned long long* counters_;   // 64-bit: tiles x sweeps outgrows 32 bits on runs with a large sweep cap
+    unsigned long long* err_;
     int32_t sweep;
-    int32_t pad;
+    int32_t naps_, limit_;
+    __device__ __forceinline__ unsigned long long* counters() const { return (unsigned long long*)counters_; }
+    __device__ __forceinline__ unsigned long long* err() const { return err_; }
+    __device__ __forceinline__ int naps() const { return naps_; }
+    __device__ __forceinline__ int limit() const { return limit_; }
 };
 constexpr int kDepStride = 16;          // one 64-bit counter per 128-byte line: hundreds of waiting workgroups poll them
+constexpr int kLocalSlabs = 3;          // LeRelDev::local_r1: row tiles that merge their rows' statistics over the slabs of a row block inside the launch
 // Returns false (for the whole workgroup) when the wait was abandoned: the caller then leaves WITHOUT storing anything,
 // so a failed run never rescales weights with stale statistics -- it only stops short, and `err` makes every later
 // waiter of the plan give up at once (they poll it every 256 spins) and the next query / run report DFQ_ERR_STATE.
@@ -256,18 +265,22 @@ constexpr int kDepStride = 16;          // one 64-bit counter per 128-byte line:
 // which are performed at the coherence point, and is read with device-scope (sc1) loads, so the counter itself can be
 // relaxed; a release on the add would be a `buffer_wbl2` of every dirty weight line of the XCD per tile.  The producer
 // side orders "statistics performed" before "counter incremented" with s_waitcnt(0) + a workgroup barrier.
-__device__ __forceinline__ bool dep_wait(const LeRelDev& R, const LeDep& dep, int naps, int spin_limit, int* sh_flag) {
-    if (R.dep_idx < 0) return true;                  // uniform
+template <class Dep>
+__device__ __forceinline__ bool counter_wait(const Dep& dep, int idx, int tiles, int* sh_flag) {
+    if (idx < 0) return true;                        // uniform
     if (threadIdx.x == 0) {
-        const unsigned long long target = (unsigned long long)R.dep_tiles * (unsigned long long)(dep.sweep + 1);
+        const unsigned long long target = (unsigned long long)tiles * (unsigned long long)(dep.sweep + 1);
+        const unsigned long long* const counter = dep.counters() + (int64_t)idx * kDepStride;
+        unsigned long long* const err = dep.err();
+        const int naps = dep.naps(), spin_limit = dep.limit();
         long spins = 0;
         int ok = 1;
-        while (__hip_atomic_load(dep.counters + (int64_t)R.dep_idx * kDepStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
             for (int k = 0; k < naps; ++k) __builtin_amdgcn_s_sleep(8);   // default 2 naps: ~0.5 us between polls
             ++spins;
             if (spins > spin_limit ||
-                ((spins & 255) == 0 && __hip_atomic_load(dep.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull)) {
-                atomicMax(dep.err, 1ull);
+                ((spins & 255) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull)) {
+                atomicMax(err, 1ull);
                 ok = 0;
                 break;
             }
@@ -276,6 +289,10 @@ __device__ __forceinline__ bool dep_wait(const LeRelDev& R, const LeDep& dep, in
     }
     __syncthreads();
     return *sh_flag != 0;
+}
+template <class Dep>
+__device__ __forceinline__ bool dep_wait(const LeRelDev& R, const Dep& dep, int* sh_flag) {
+    return counter_wait(dep, R.dep_idx, R.dep_tiles, sh_flag);
 }
 constexpr double kTileAbandoned = -1.0;   // a tile function's return value after a failed wait (sums of |dW| are >= 0)
 
@@ -334,8 +351,8 @@ __device__ __forceinline__ void vstore(gfloat* p, const float (&x)[VEC]) {
 // is known to be satisfied; `mid()` is called right after the tile's own statistics requests have been issued -- the
 // sweep kernel requests the NEXT tile's data there, so that waiting for the statistics does not wait for that data
 // (vector memory returns in order).
-template <int VEC, bool PRE, class Mid>
-__device__ __forceinline__ double row_tile(const LeRelDev& R, const LeParams& p, int tile, int cur, const LeDep& dep, bool ready,
+template <int VEC, bool PRE, class Mid, class Dep>
+__device__ __forceinline__ double row_tile(const LeRelDev& R, const LeParams& p, int tile, int cur, const Dep& dep, bool ready,
                                            float (&v_in)[kSlotsVec4][VEC], Mid mid,
                                            float* sh_s, uint32_t* sh_slot, int* sh_g, float* sh_pinv, uint32_t* sh_rs, int* sh_flag, const LeTrace& tr) {
     constexpr int NV = (VEC == 4) ? kSlotsVec4 : kSlotsVec1;   // vectors per thread
@@ -414,7 +431,7 @@ __device__ __forceinline__ double row_tile(const LeRelDev& R, const LeParams& p,
     }
     mid();
     if (waits) {
-        if (!dep_wait(R, dep, p.poll_naps, p.spin_limit, sh_flag)) return kTileAbandoned;
+        if (!dep_wait(R, dep, sh_flag)) return kTileAbandoned;
         if (tid < nr) { if (!local) { wa0 = ld_stat(st_a); wa1 = ld_stat(st_a + 1); } wb0 = st_b[0]; wb1 = st_b[1]; }
         if (has_sl0) { pa0 = ld_stat(a_base + 2 * c_sl0); pa1 = ld_stat(a_base + 2 * c_sl0 + 1); pb0 = b_base[2 * c_sl0]; pb1 = b_base[2 * c_sl0 + 1]; }
         if (PRE) { landed(wa0, wa1, wb0, wb1); landed(pa0, pa1, pb0, pb1); }
@@ -468,6 +485,23 @@ __device__ __forceinline__ double row_tile(const LeRelDev& R, const LeParams& p,
             uint32_t* dst = R.r1 + (int64_t)cur * R.stat_stride + 2 * (r0 + tid);
             atomicMax(dst + 0, wa0);
             atomicMax(dst + 1, wa1);
+        }
+        if (R.local_r1 == kLocalSlabs) {
+            // The tile holds a SLAB of its rows; the rest of them sits in the row block's other slabs, whose workgroups are doing
+            // exactly this.  So: the partial ranges above merge in the relation's statistics words, the tile arrives on the
+            // relation's row-tile counter (statistics performed -> s_waitcnt 0 -> barrier -> one atomicAdd), waits until EVERY row
+            // tile of the relation has arrived -- with its elements in registers -- and reads its rows' merged ranges back.  The
+            // layer is then read ONCE per sweep: no read-only pass of the relation in front over it (8 instead of 12 B per element).
+            // Row tiles of one relation and network are adjacent in the launch's table and dispatched in index order, so the ones
+            // a tile waits for are resident or the next to become resident (le_level_kernel, "Dependencies inside a launch").
+            __builtin_amdgcn_s_waitcnt(0);
+            __syncthreads();
+            if (tid == 0) atomicAdd(dep.counters() + (int64_t)R.rcounter_idx * kDepStride, 1ull);
+            if (!counter_wait(dep, R.rcounter_idx, R.n_row_tiles, sh_flag)) return kTileAbandoned;
+            if (tid < nr) {
+                const guint* src = (const guint*)R.r1 + (int64_t)cur * R.stat_stride + 2 * (r0 + tid);
+                wa0 = ld_stat(src); wa1 = ld_stat(src + 1);
+            }
         }
     }
     stamp(tr, 2);
@@ -602,8 +636,8 @@ __device__ __forceinline__ double row_tile(const LeRelDev& R, const LeParams& p,
 
 // col tile: W2[r0:r0+nr, p0:p0+np] *= 1/s[input channel]   (+ row stats of the new values)
 // G = pow2 >= np/VEC lanes share a row; 256/G rows are in flight per register slot.
-template <int VEC, bool PRE, class Mid>
-__device__ __forceinline__ double col_tile(const LeRelDev& R, const LeParams& p, int tile, int cur, const LeDep& dep, bool ready,
+template <int VEC, bool PRE, class Mid, class Dep>
+__device__ __forceinline__ double col_tile(const LeRelDev& R, const LeParams& p, int tile, int cur, const Dep& dep, bool ready,
                                            float (&v_in)[kSlotsVec4][VEC], Mid mid,
                                            float* sh_inv, uint32_t* sh_row, int* sh_tab, float* sh_hold, int* sh_flag, const LeTrace& tr) {
     constexpr int NV = (VEC == 4) ? kSlotsVec4 : kSlotsVec1;
@@ -666,7 +700,7 @@ __device__ __forceinline__ double col_tile(const LeRelDev& R, const LeParams& p,
     }
     mid();
     if (waits) {
-        if (!dep_wait(R, dep, p.poll_naps, p.spin_limit, sh_flag)) return kTileAbandoned;
+        if (!dep_wait(R, dep, sh_flag)) return kTileAbandoned;
         if (has_entry) { wa0 = ld_stat(st_a); wa1 = ld_stat(st_a + 1); wb0 = st_b[0]; wb1 = st_b[1]; }
         if (PRE) landed(wa0, wa1, wb0, wb1);
     }
@@ -883,6 +917,14 @@ __device__ __forceinline__ double short_tile(const LeRelDev& R, const LeParams& 
     return acc;
 }
 
+// lanes 0..n_words-1 fetch one word each (the others repeat the last one: no predicate, so the request is unconditional
+// for the compiler's bookkeeping of outstanding loads, see le_sweep_kernel)
+__device__ __forceinline__ uint32_t fetch_words(const void* base, int n_words, int lane) {
+    return ((const guint*)base)[min(lane, n_words - 1)];
+}
+#include "dfq_le_cf.hpp"
+
+constexpr size_t kLevelSmem = sizeof(float) * (2 * kSlotMax + 2 * kSlotMax + kTileRowsMax + 2 * kTileRowsMax + 1);   // le_level_kernel's shared memory
 constexpr int kDescWords = (int)(sizeof(LeRelDev) / 4);
 static_assert(sizeof(LeRelDev) % 4 == 0 && kDescWords + 1 <= kWave, "descriptor must fit one wave-wide load");
 
@@ -902,21 +944,72 @@ static_assert(sizeof(LeRelDev) % 4 == 0 && kDescWords + 1 <= kWave, "descriptor 
 #endif
 // kTrace: the tuning instantiation that honours `tr_arg` (dfq_le_trace*); the production one sees a constant null trace, so the
 // eight stamp sites and the four scalar registers of the argument vanish.
+// -DDFQ_LE_WEAVE=1 (opt-in build): the lean tiles of the free-running layers ride in the sweep's own launch at a group's first
+// sweep, listed evenly among the general tiles, instead of in a launch of their own.  Built and measured in round 6 (batch of 32
+// MobileNetV2, two alternating rounds, tools/gpu_r06_weave.sh): 1.701 / 1.705e10 weights/s woven against 1.688 / 1.690e10 with
+// le_lean_kernel's own launch -- the sweep's wall time is the same (141.5-143.6 against 139.9-140.8 us): the lean tiles' arithmetic
+// does not hide behind the general tiles' memory traffic, it queues for the same issue slots -- and the woven body takes
+// le_level_kernel from 78 to 86 vector registers (six -> five workgroups per CU) and from 94 to 127 scalar spills, which costs the
+// launches WITHOUT lean tiles 2 % (1.66e10 with the lean launch on the 86-register build).  Not the default.
+#ifndef DFQ_LE_WEAVE
+#define DFQ_LE_WEAVE 0
+#endif
+constexpr bool kWeave = DFQ_LE_WEAVE != 0;
+constexpr int kWeaveGroup = 4;          // the group depth whose lean tiles ride in the sweep's launch (the default depth)
+static_assert((2 * kWeaveGroup - 1) * kCfTab <= 2 * kSlotMax, "the woven lean tile's factor tables live in the column-statistics slots");
+// The kernel's ONE argument: what a tile needs all the time is read through `a`, what it needs once or twice in its life (the
+// wait's counters, error word and patience) through cold(a) at the point of use.
+struct LevelArgs {
+    const LeRelDev* table;
+    const LeBlockRef* blocks;
+    LeParams p;
+    int32_t sweep;
+    int32_t pad;
+    const LeState* state;
+    double* partials;
+    unsigned long long* dep_counters;
+    unsigned long long* err;
+    LeTrace tr;
+    const LeLeanRef* lean;
+    int64_t part_stride;
+};
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ const LevelArgs DFQ_CONSTANT_AS& cold(const LevelArgs&) {
+    auto p = __builtin_amdgcn_kernarg_segment_ptr();      // LevelArgs is the kernel's first (and only) argument
+    asm volatile("" : "+s"(p));
+    return *(const LevelArgs DFQ_CONSTANT_AS*)p;
+}
+#else
+__device__ __forceinline__ const LevelArgs& cold(const LevelArgs& a) { return a; }
+#endif
+struct LeDepCold {
+    const LevelArgs& a;
+    int32_t sweep;
+    __device__ __forceinline__ unsigned long long* counters() const { return cold(a).dep_counters; }
+    __device__ __forceinline__ unsigned long long* err() const { return cold(a).err; }
+    __device__ __forceinline__ int naps() const { return cold(a).p.poll_naps; }
+    __device__ __forceinline__ int limit() const { return cold(a).p.spin_limit; }
+};
 template <bool kTrace>
-__global__ __launch_bounds__(kBlock, DFQ_LE_MIN_WAVES) void le_level_kernel(const LeRelDev* __restrict__ table,
-                                                          const LeBlockRef* __restrict__ blocks, LeParams p, int sweep,
-                                                          const LeState* __restrict__ state,
-                                                          double* __restrict__ partials, unsigned long long* dep_counters,
-                                                          unsigned long long* err, LeTrace tr_arg) {
-    LeTrace tr = kTrace ? tr_arg : LeTrace{nullptr, 0, 0};
+__global__ __launch_bounds__(kBlock, DFQ_LE_MIN_WAVES) void le_level_kernel(LevelArgs a) {
+    const LeRelDev* const table = a.table;
+    const LeBlockRef* const blocks = a.blocks;
+    const LeParams& p = a.p;
+    const int sweep = a.sweep;
+    const LeState* const state = a.state;
+    double* const partials = a.partials;
+    LeTrace tr = kTrace ? a.tr : LeTrace{nullptr, 0, 0};
     tr.flat = (int)blockIdx.x;
     stamp(tr, 0);
-    __shared__ float sh_f[kSlotMax];                // row tile: scales; col tile: 1/s table
-    __shared__ uint32_t sh_u[2 * kSlotMax];         // row tile: column-stat slots; col tile: row stats
-    __shared__ int sh_g[kTileRowsMax];              // per-row table offsets
-    __shared__ float sh_p[kSlotMax];                // row tile of an interior layer: 1/s of the previous relation
-    __shared__ uint32_t sh_rs[2 * kTileRowsMax];    // row tile that takes its rows' statistics itself (local_r1)
-    __shared__ int sh_flag;                         // outcome of the dependency wait
+    // (dynamic shared memory, carved by hand: the slab tiles keep their tables across an in-launch wait, and the CPU emulation
+    // gives every workgroup of a concurrent launch a buffer of its own only for dynamic shared memory)
+    DFQ_DYN_SMEM(smem);
+    float* const sh_f = (float*)smem;                           // [kSlotMax] row tile: scales; col tile: 1/s table
+    uint32_t* const sh_u = (uint32_t*)(sh_f + kSlotMax);        // [2 kSlotMax] row tile: column-stat slots; col tile: row stats
+    int* const sh_g = (int*)(sh_u + 2 * kSlotMax);              // [kTileRowsMax] per-row table offsets
+    float* const sh_p = (float*)(sh_g + kTileRowsMax);          // [kSlotMax] row tile of an interior layer: 1/s of the previous relation
+    uint32_t* const sh_rs = (uint32_t*)(sh_p + kSlotMax);       // [2 kTileRowsMax] row tile that takes its rows' statistics itself (local_r1)
+    int& sh_flag = *(int*)(sh_rs + 2 * kTileRowsMax);           // outcome of the dependency wait
     const int lane = threadIdx.x % kWave;
     // one 16-byte load of the workgroup's entry, then ONE wave-wide load that fetches the descriptor
     // (lanes 0..kDescWords-1) and the loop state of the network (lane kDescWords) together; v_readlane
@@ -927,6 +1020,12 @@ __global__ __launch_bounds__(kBlock, DFQ_LE_MIN_WAVES) void le_level_kernel(cons
     const int rel = __builtin_amdgcn_readfirstlane(ref[0]);
     const int net = __builtin_amdgcn_readfirstlane(ref[2]);
     const int tile = __builtin_amdgcn_readfirstlane(ref[1]);
+    if (kWeave && rel < 0) {
+        // a lean tile of a free-running layer (dfq_le_cf.hpp), woven into the launch of its group's first sweep: multiplies and
+        // |dW| chains for kWeaveGroup sweeps per element loaded -- arithmetic that overlaps the general tiles' memory traffic
+        lean_tile_run<kWeaveGroup>(a.lean, tile, LeanArgs{sweep, 0, a.part_stride}, state, partials, (float*)sh_u, sh_g);
+        return;
+    }
     uint32_t word = 0u;
     {
         const guint* src = (lane < kDescWords) ? (const guint*)(table + rel) + lane : (const guint*)&state[net].done;
@@ -948,7 +1047,7 @@ __global__ __launch_bounds__(kBlock, DFQ_LE_MIN_WAVES) void le_level_kernel(cons
     if (done || tile >= R.n_row_tiles + R.n_col_tiles) return;   // uniform
     stamp(tr, 1);
 
-    const LeDep dep{dep_counters, err, sweep, 0};
+    const LeDepCold dep{a, sweep};
     auto nothing = [] {};
 
     double acc;
@@ -965,11 +1064,11 @@ __global__ __launch_bounds__(kBlock, DFQ_LE_MIN_WAVES) void le_level_kernel(cons
     }
 #undef DFQ_TAKE
     if (!col_side) {
-        if (R.rt_vec == 0) acc = dep_wait(R, dep, p.poll_naps, p.spin_limit, &sh_flag) ? short_tile<0>(R, p, tile, cur) : kTileAbandoned;
+        if (R.rt_vec == 0) acc = dep_wait(R, dep, &sh_flag) ? short_tile<0>(R, p, tile, cur) : kTileAbandoned;
         else if (R.rt_vec == 4) { float v[kSlotsVec4][4]; acc = row_tile<4, false>(R, p, tile, cur, dep, false, v, nothing, sh_f, sh_u, sh_g, sh_p, sh_rs, &sh_flag, tr); }
         else { float v[kSlotsVec4][1]; acc = row_tile<1, false>(R, p, tile, cur, dep, false, v, nothing, sh_f, sh_u, sh_g, sh_p, sh_rs, &sh_flag, tr); }
     } else {
-        if (R.ct_vec == 0) acc = dep_wait(R, dep, p.poll_naps, p.spin_limit, &sh_flag) ? short_tile<1>(R, p, tile - R.n_row_tiles, cur) : kTileAbandoned;
+        if (R.ct_vec == 0) acc = dep_wait(R, dep, &sh_flag) ? short_tile<1>(R, p, tile - R.n_row_tiles, cur) : kTileAbandoned;
         else if (R.ct_vec == 4) { float v[kSlotsVec4][4]; acc = col_tile<4, false>(R, p, tile - R.n_row_tiles, cur, dep, false, v, nothing, sh_f, sh_u, sh_g, sh_p, &sh_flag, tr); }
         else { float v[kSlotsVec4][1]; acc = col_tile<1, false>(R, p, tile - R.n_row_tiles, cur, dep, false, v, nothing, sh_f, sh_u, sh_g, sh_p, &sh_flag, tr); }
     }
@@ -979,12 +1078,12 @@ __global__ __launch_bounds__(kBlock, DFQ_LE_MIN_WAVES) void le_level_kernel(cons
         // every statistics atomic of this workgroup has been performed before the counter moves
         __builtin_amdgcn_s_waitcnt(0);
         __syncthreads();
-        if (threadIdx.x == 0) atomicAdd(dep_counters + (int64_t)R.counter_idx * kDepStride, 1ull);
+        if (threadIdx.x == 0) atomicAdd(dep.counters() + (int64_t)R.counter_idx * kDepStride, 1ull);
     }
-    if (!col_side && R.rcounter_idx >= 0) {                      // row tiles that published their rows' statistics (local_r1)
+    if (!col_side && R.rcounter_idx >= 0 && R.local_r1 != kLocalSlabs) {   // row tiles that published their rows' statistics (local_r1; the slab kind arrived long ago)
         __builtin_amdgcn_s_waitcnt(0);
         __syncthreads();
-        if (threadIdx.x == 0) atomicAdd(dep_counters + (int64_t)R.rcounter_idx * kDepStride, 1ull);
+        if (threadIdx.x == 0) atomicAdd(dep.counters() + (int64_t)R.rcounter_idx * kDepStride, 1ull);
     }
     // one partial per wave (fixed butterfly order -> deterministic), no workgroup barrier
     const double t = wave_sum(acc);
@@ -1025,11 +1124,6 @@ static_assert(sizeof(LeTileRef) == 64, "one tile reference per 64-byte line");
 constexpr int kRefWords = 11;
 constexpr int kSweepMaxNets = 4096;     // done flags of a launch's networks, one LDS byte each
 
-// lanes 0..n_words-1 fetch one word each (the others repeat the last one: no predicate, so the request is unconditional
-// for the compiler's bookkeeping of outstanding loads, see le_sweep_kernel)
-__device__ __forceinline__ uint32_t fetch_words(const void* base, int n_words, int lane) {
-    return ((const guint*)base)[min(lane, n_words - 1)];
-}
 __device__ __forceinline__ void ref_from_word(uint32_t word, LeTileRef& T) {
     const uint64_t lo = (uint32_t)__builtin_amdgcn_readlane(word, 0), hi = (uint32_t)__builtin_amdgcn_readlane(word, 1);
     T.w = (float*)(uintptr_t)(lo | (hi << 32));
@@ -1079,7 +1173,7 @@ __global__ __launch_bounds__(kBlock, DFQ_LE_SWEEP_MIN_WAVES) void le_sweep_kerne
     const int lane = tid % kWave;
     const int G = (int)gridDim.x;
     const int cur = sweep & 1;
-    const LeDep dep{dep_counters, err, sweep, 0};
+    const LeDep dep{dep_counters, err, sweep, p.poll_naps, p.spin_limit};
 
     // which networks have stopped (the flags only change between launches)
     for (int n = tid; n < n_nets; n += kBlock) sh_done[n] = state[n].done != 0;
@@ -1149,7 +1243,7 @@ __global__ __launch_bounds__(kBlock, DFQ_LE_SWEEP_MIN_WAVES) void le_sweep_kerne
                 if (R.rt_vec == 4) acc = row_tile<4, true>(R, p, tile, cur, dep, ready, v, ahead, sh_f, sh_u, sh_g, sh_p, sh_rs, &sh_flag, tr);
                 else {
                     ahead();
-                    if (!ready && !dep_wait(R, dep, p.poll_naps, p.spin_limit, &sh_flag)) acc = kTileAbandoned;
+                    if (!ready && !dep_wait(R, dep, &sh_flag)) acc = kTileAbandoned;
                     else if (R.rt_vec == 0) acc = short_tile<0>(R, p, tile, cur);
                     else { float v1[kSlotsVec4][1]; acc = row_tile<1, false>(R, p, tile, cur, dep, true, v1, [] {}, sh_f, sh_u, sh_g, sh_p, sh_rs, &sh_flag, tr); }
                 }
@@ -1157,7 +1251,7 @@ __global__ __launch_bounds__(kBlock, DFQ_LE_SWEEP_MIN_WAVES) void le_sweep_kerne
                 if (R.ct_vec == 4) acc = col_tile<4, true>(R, p, tile - R.n_row_tiles, cur, dep, ready, v, ahead, sh_f, sh_u, sh_g, sh_p, &sh_flag, tr);
                 else {
                     ahead();
-                    if (!ready && !dep_wait(R, dep, p.poll_naps, p.spin_limit, &sh_flag)) acc = kTileAbandoned;
+                    if (!ready && !dep_wait(R, dep, &sh_flag)) acc = kTileAbandoned;
                     else if (R.ct_vec == 0) acc = short_tile<1>(R, p, tile - R.n_row_tiles, cur);
                     else { float v1[kSlotsVec4][1]; acc = col_tile<1, false>(R, p, tile - R.n_row_tiles, cur, dep, true, v1, [] {}, sh_f, sh_u, sh_g, sh_p, &sh_flag, tr); }
                 }
@@ -1195,8 +1289,6 @@ __global__ __launch_bounds__(kBlock, DFQ_LE_SWEEP_MIN_WAVES) void le_sweep_kerne
         __syncthreads();               // the LDS tables of this tile are dead before the next one fills them
     }
 }
-
-#include "dfq_le_cf.hpp"
 
 // Stats of the untouched weights, once per run: R1 (rows of W1) for chain-start relations and R2
 // (columns of W2) for every relation, parity 0.  One workgroup per `kBootTc` paired channels.
@@ -1539,11 +1631,14 @@ __global__ void le_reset_kernel(LeState* states, int n_nets, double converge_thr
 
 // restart of a streaming plan in ONE launch: the loop state of every network (dfq.py:81-82) and the clearing of the dependency
 // counters + error word and of every statistics word (until round 4: le_reset_kernel + clear_kernel)
-__global__ void le_prepare_kernel(ClearArgs a, LeState* states, int n_nets, double converge_thres, int converge_count, int max_sweeps) {
+__global__ void le_prepare_kernel(ClearArgs a, LeState* states, int n_nets, double converge_thres, int converge_count, int max_sweeps,
+                                  float* ones, long long n_ones) {
     const long long step = (long long)gridDim.x * blockDim.x;
     const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     for (int k = 0; k < 4; ++k)
         for (long long i = i0; i < a.words[k]; i += step) a.p[k][i] = 0u;
+    // the factor rings of the free-running segments (dfq_le_cf.hpp): every entry 1, so that the first group's replay changes nothing
+    for (long long i = i0; i < n_ones; i += step) ones[i] = 1.0f;
     for (long long i = i0; i < n_nets; i += step) {
         LeState* state = states + i;
         state->diff = 10.0;          // dfq.py:81
@@ -1760,9 +1855,16 @@ struct dfq_le_plan {
     LeCfSeg* d_cf_segs = nullptr;
     int32_t* d_cf_map = nullptr;           // solver workgroup -> (segment, block of kCtlBlock channels)
     LeLeanRef* d_lean = nullptr;
+    float* d_cf_ring = nullptr;            // every relation's ring, back to back (set to 1 by the restart's first launch)
+    int64_t cf_ring_floats = 0;
     int64_t fr_total = 0;                  // elements of free-running layers: read and written once per cf_group sweeps
     int64_t part_stride = 0;               // doubles of one sweep's partial sums (the array exists cf_group times)
     std::vector<int> lean_info;            // per lean tile: kind, rows, floats per row (dfq_le_plan_lean_info)
+    // the sweep's workgroup table with the lean tiles woven in evenly (group depth kWeaveGroup, one launch per sweep): the launch
+    // of a group's first sweep; null: the lean tiles get a launch of their own (le_lean_kernel)
+    LeBlockRef* d_blocks_woven = nullptr;
+    int n_woven = 0;
+    bool has_slab_tiles = false;           // some row tiles wait for their row block's other slabs (kLocalSlabs): also a per-level launch contains in-launch waits
 };
 
 // elements per tile; DFQ_LE_TILE_ELEMS overrides (tuning / tests).  A workgroup's fixed cost (workgroup table ->
@@ -2091,6 +2193,9 @@ int dfq_le_plan_create_batch(const dfq_layer* layers, int32_t n_layers, const in
         const bool on = !(getenv("DFQ_LE_LOCAL_R1") && getenv("DFQ_LE_LOCAL_R1")[0] == '0') && getenv("DFQ_LE_NO_SHORT") == nullptr;
         const char* lre = getenv("DFQ_LE_LOCAL_ROW");
         const int local_row_max = lre ? atoi(lre) : 0;
+        const char* fe = getenv("DFQ_LE_FUSE");
+        const char* pe0 = getenv("DFQ_LE_PERSIST");           // (persistent workgroups walk the table one tile at a time: no tile may wait for a later one)
+        const bool fuse_slabs = (fe && fe[0] == '1') && !(pe0 && pe0[0] == '1');
         for (int r = 0; r < n_relations && on; ++r) {
             const LeRelDev& d = h[r];
             const int j_prev = as_second[relations[r].first];
@@ -2110,6 +2215,16 @@ int dfq_le_plan_create_batch(const dfq_layer* layers, int32_t n_layers, const in
                 const int rows = local_rows(d.o1, d.row_len, target);
                 if ((ceil_div(rows, h[j_prev].go) + 1) * nci <= kSlotMax) { local_r1[r] = 2; skip_cols[j_prev] = 1; }
             }
+            // ... and the same without full rows (round 6; OPT-IN, DFQ_LE_FUSE=1): the tiles keep their tall narrow shape -- few
+            // column-statistics atomics per word -- and merge their rows' ranges over the slabs of the row block INSIDE the launch
+            // (kLocalSlabs, row_tile): 12 -> 8 B per element of a layer scaled along both axes and no read-only workgroups, at the
+            // price of a second in-launch wait with the tile's elements in registers.  Bit-identical (test_deferred_stores_are_
+            // invisible[...streaming-fused], the GPU suite) and measured NO FASTER at batch 32 (tools/gpu_r06_fuse.sh, two alternating
+            // rounds: 1.725 / 1.723e10 weights/s against 1.732 / 1.730e10, 416 instead of 508 MB per launch in the same 99 us): a slab
+            // tile lives 26 us where the read-only pass and the rescaling pass lived 11 + 10 -- it holds its slot and its registers
+            // while the relation's other row tiles trickle in, and the layer behind it waits for all of them in turn; the launch is
+            // bound by that chain and by workgroup residency, not by the bytes saved (profiles/r06_level_kernel_by_kind_fused.txt).
+            if (local_r1[r] == 0 && fuse_slabs && !short_kind && d.rt_vec == 4) { local_r1[r] = kLocalSlabs; skip_cols[j_prev] = 1; p->has_slab_tiles = true; }
         }
     }
     for (int r = 0; r < n_relations; ++r) {
@@ -2141,7 +2256,7 @@ int dfq_le_plan_create_batch(const dfq_layer* layers, int32_t n_layers, const in
         }
         d.n_row_tiles = ceil_div(d.o1, d.rt_rows) * d.rt_slabs;
         d.n_col_tiles = (skip_cols[r] || (fr[r] && !fr_last[r])) ? 0 : ceil_div(d.o2, d.ct_rows) * d.ct_slabs;   // (no pass over a depthwise layer inside a free-running segment)
-        d.local_r1 = local_r1[r] ? 1 : 0;
+        d.local_r1 = local_r1[r] == kLocalSlabs ? kLocalSlabs : (local_r1[r] ? 1 : 0);
         d.partial_base = tile_slot;
         ld[rr.first].partial_begin = d.partial_base;
         ld[rr.first].n_partials = d.n_row_tiles;                       // last touch of W1 this sweep
@@ -2392,6 +2507,7 @@ int dfq_le_plan_create_batch(const dfq_layer* layers, int32_t n_layers, const in
                 float* d_state = nullptr;
                 if ((e = p->mem.alloc((void**)&d_ring, sizeof(float) * ring_floats)) != hipSuccess) return fail_alloc(e);
                 if ((e = p->mem.alloc((void**)&d_state, sizeof(float) * state_floats)) != hipSuccess) return fail_alloc(e);
+                p->d_cf_ring = d_ring; p->cf_ring_floats = ring_floats;
                 int64_t ring_off = 0, state_off = 0;
                 for (const auto& seg : segments) {
                     LeCfSeg S;
@@ -2488,6 +2604,27 @@ int dfq_le_plan_create_batch(const dfq_layer* layers, int32_t n_layers, const in
                 if ((e = hipMemcpy(p->d_cf_map, cf_map.data(), sizeof(int32_t) * cf_map.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail_alloc(e);
                 if ((e = hipMemcpy(p->d_lean, lean.data(), sizeof(LeLeanRef) * lean.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail_alloc(e);
                 hipLaunchKernelGGL(le_cf_ring_reset_kernel, dim3(p->n_cf_rels), dim3(kBlock), 0, nullptr, (const LeCfRel*)p->d_cf_rels, G);
+                // the lean tiles woven evenly into the sweep's workgroup table (they wait for nobody and nobody waits for them, so
+                // the order among the general tiles -- which only ever wait for lower indices -- is kept); DFQ_LE_CF_WEAVE=0: own launch
+                const char* we = getenv("DFQ_LE_CF_WEAVE");
+                if (kWeave && G == kWeaveGroup && !(we && we[0] == '0') && !lean.empty()) {
+                    std::vector<LeBlockRef> woven;
+                    woven.reserve(blocks.size() + lean.size());
+                    const size_t n_g = blocks.size(), n_l = lean.size();
+                    size_t gi = 0, li = 0;
+                    while (gi < n_g || li < n_l) {
+                        // next lean tile whenever the lean share of what has been listed falls behind its share of the whole
+                        if (li < n_l && (gi >= n_g || li * (n_g + n_l) <= (gi + li) * n_l)) {
+                            woven.push_back(LeBlockRef{-1, (int32_t)li, lean[li].net, 0});
+                            ++li;
+                        } else {
+                            woven.push_back(blocks[gi++]);
+                        }
+                    }
+                    p->n_woven = (int)woven.size();
+                    if ((e = p->mem.alloc((void**)&p->d_blocks_woven, sizeof(LeBlockRef) * woven.size())) != hipSuccess) return fail_alloc(e);
+                    if ((e = hipMemcpy(p->d_blocks_woven, woven.data(), sizeof(LeBlockRef) * woven.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail_alloc(e);
+                }
             }
             p->n_flush = (int)refs.size();
             p->n_hold_rels = (int)hold_rels.size();
@@ -2691,20 +2828,16 @@ static int le_restart(dfq_le_plan* p, const dfq_le_config* cfg, hipStream_t st) 
         ca.p[0] = (uint32_t*)p->d_dep; ca.words[0] = (long long)(2 * ((size_t)(2 * p->n_rels + 1) * kDepStride + 1));
         ca.p[1] = p->n_rels > 0 ? p->d_stats : nullptr; ca.words[1] = p->n_rels > 0 ? (long long)(4 * p->stat_words) : 0;
         ca.p[2] = nullptr; ca.words[2] = 0; ca.p[3] = nullptr; ca.words[3] = 0;
-        const long long most = std::max(ca.words[0], std::max(ca.words[1], (long long)p->n_nets));
+        const long long most = std::max(std::max(ca.words[0], (long long)p->cf_ring_floats), std::max(ca.words[1], (long long)p->n_nets));
         const int grid = (int)std::max<long long>(1, std::min<long long>((most + 1023) / 1024, 512));
         hipLaunchKernelGGL(le_prepare_kernel, dim3(grid), dim3(256), 0, st, ca, p->d_state, p->n_nets, cfg->converge_thres,
-                           (int)cfg->converge_count, (int)cfg->max_sweeps);
+                           (int)cfg->converge_count, (int)cfg->max_sweeps, p->d_cf_ring, (long long)p->cf_ring_floats);
         DFQ_CHECK_LAUNCH();
     }
     p->sweep_index = 0;
     if (p->defer > 1 && p->n_hold_rels > 0) {
         hipLaunchKernelGGL(le_hold_reset_kernel, dim3(p->n_hold_rels), dim3(kBlock), 0, st, (const LeRelDev*)p->d_rels,
                            (const int32_t*)p->d_hold_rels, (const LeState*)p->d_state, p->defer, 1);
-        DFQ_CHECK_LAUNCH();
-    }
-    if (p->cf_group > 1) {
-        hipLaunchKernelGGL(le_cf_ring_reset_kernel, dim3(p->n_cf_rels), dim3(kBlock), 0, st, (const LeCfRel*)p->d_cf_rels, p->cf_group);
         DFQ_CHECK_LAUNCH();
     }
     if (p->n_rels > 0) {
@@ -2747,8 +2880,10 @@ static int le_flush(dfq_le_plan* p, hipStream_t st) {
 static double* sweep_partials(const dfq_le_plan* p) { return p->d_partials + (p->sweep_index & (p->cf_group - 1)) * p->part_stride; }
 
 // the lean tiles of the free-running layers: at the first sweep of a group only
+// are the lean tiles part of the sweep's own launch?  (one launch per sweep on le_level_kernel only)
+static bool lean_woven(const dfq_le_plan* p) { return p->d_blocks_woven != nullptr && p->merged && p->sweep_grid == 0; }
 static int le_launch_lean(dfq_le_plan* p, hipStream_t st) {
-    if (p->cf_group <= 1 || p->n_lean == 0 || (p->sweep_index & (p->cf_group - 1)) != 0) return DFQ_OK;
+    if (p->cf_group <= 1 || p->n_lean == 0 || (p->sweep_index & (p->cf_group - 1)) != 0 || lean_woven(p)) return DFQ_OK;
     LeanArgs a;
     a.k = (int32_t)p->sweep_index; a.pad = 0; a.part_stride = p->part_stride;
     if (p->cf_group == 2)
@@ -2766,6 +2901,8 @@ static int le_launch_level(dfq_le_plan* p, int launch, const LeParams& q, hipStr
                            LeTrace tr = LeTrace{nullptr, 0, 0}) {
     int begin, count, n; int64_t rw, ro;
     if (!launch_slice(p, launch, &begin, &count, &n, &rw, &ro)) return fail_arg("le_launch_level: bad launch");
+    const LeBlockRef* table = p->d_blocks + begin;
+    if (lean_woven(p) && (p->sweep_index & (p->cf_group - 1)) == 0) { table = p->d_blocks_woven; count = p->n_woven; }   // a group's first sweep
     if (count == 0) return DFQ_OK;
     if (p->sweep_grid > 0) {
         DFQ_LAUNCH_RESIDENT(le_sweep_kernel, dim3(p->sweep_grid), dim3(kBlock), 0, st, (const LeRelDev*)p->d_rels,
@@ -2774,14 +2911,18 @@ static int le_launch_level(dfq_le_plan* p, int launch, const LeParams& q, hipStr
         DFQ_CHECK_LAUNCH();
         return DFQ_OK;
     }
-    if (tr.out)
-        hipLaunchKernelGGL(le_level_kernel<true>, dim3(count), dim3(kBlock), 0, st, (const LeRelDev*)p->d_rels,
-                           (const LeBlockRef*)(p->d_blocks + begin), q, (int)p->sweep_index, (const LeState*)p->d_state,
-                           sweep_partials(p), p->d_dep, p->d_dep + (size_t)p->n_rels * kDepStride, tr);
-    else
-        hipLaunchKernelGGL(le_level_kernel<false>, dim3(count), dim3(kBlock), 0, st, (const LeRelDev*)p->d_rels,
-                           (const LeBlockRef*)(p->d_blocks + begin), q, (int)p->sweep_index, (const LeState*)p->d_state,
-                           sweep_partials(p), p->d_dep, p->d_dep + (size_t)p->n_rels * kDepStride, tr);
+    LevelArgs la;
+    la.table = (const LeRelDev*)p->d_rels; la.blocks = table; la.p = q; la.sweep = (int32_t)p->sweep_index; la.pad = 0;
+    la.state = (const LeState*)p->d_state; la.partials = sweep_partials(p); la.dep_counters = p->d_dep;
+    la.err = p->d_dep + (size_t)p->n_rels * kDepStride; la.tr = tr; la.lean = (const LeLeanRef*)p->d_lean; la.part_stride = p->part_stride;
+#ifdef DFQ_EMU
+    if (p->has_slab_tiles) {           // tiles wait for LATER tiles of their row block: the CPU emulation must keep the launch's workgroups alive together
+        DFQ_LAUNCH_SPINNING(le_level_kernel<false>, dim3(count), dim3(kBlock), kLevelSmem, st, la);
+        return DFQ_OK;
+    }
+#endif
+    if (tr.out) hipLaunchKernelGGL(le_level_kernel<true>, dim3(count), dim3(kBlock), kLevelSmem, st, la);
+    else hipLaunchKernelGGL(le_level_kernel<false>, dim3(count), dim3(kBlock), kLevelSmem, st, la);
     DFQ_CHECK_LAUNCH();
     return DFQ_OK;
 }
@@ -2824,7 +2965,7 @@ static int le_enqueue_direct(dfq_le_plan* p, const dfq_le_config* cfg, int n_swe
     // streams, two rounds): 1.437e10 weights/s against 1.472e10 -- an event record and a cross-stream wait per launch cost more than
     // the overlap returns.  Kept as a switch.
     static const bool guard_loop = !(getenv("DFQ_LE_GUARD_PER_LAUNCH") && getenv("DFQ_LE_GUARD_PER_LAUNCH")[0] == '1');
-    const bool guarded = p->merged && !(p->capture_stream != nullptr && st == p->capture_stream);      // the NULL stream is a caller's stream too
+    const bool guarded = (p->merged || p->has_slab_tiles) && !(p->capture_stream != nullptr && st == p->capture_stream);      // the NULL stream is a caller's stream too
     std::unique_ptr<SpinGuard> guard;
     if (guarded && guard_loop) guard.reset(new SpinGuard(st));
     for (int s = 0; s < n_sweeps; ++s) {
@@ -2913,7 +3054,7 @@ int dfq_le_profile(dfq_le_plan* p, const dfq_le_config* cfg, int32_t n_sweeps, v
     std::vector<char> had_lean(n_sweeps, 0);
     for (int s = 0; s < n_sweeps; ++s) {
         // the lean tiles of the free-running layers (first sweep of a group only, dfq_le_cf.hpp): a bracket of their own
-        had_lean[s] = p->cf_group > 1 && p->n_lean > 0 && (p->sweep_index & (p->cf_group - 1)) == 0;
+        had_lean[s] = p->cf_group > 1 && p->n_lean > 0 && (p->sweep_index & (p->cf_group - 1)) == 0 && !lean_woven(p);
         DFQ_HIP_TRY(hipEventRecord(ev[k++], st));
         if ((rc = le_launch_lean(p, st))) return rc;
         DFQ_HIP_TRY(hipEventRecord(ev[k++], st));

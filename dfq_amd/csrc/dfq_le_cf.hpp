@@ -33,6 +33,7 @@
 
 constexpr int kCfGroupMax = 8;                  // largest group depth G (a power of two)
 constexpr int kCfTab = 256;                     // entries per table (rows of a row tile / (groups x channels) of a column tile)
+static_assert(kCfTab <= kBlock, "a lean column tile fills its tables with one entry per thread");
 constexpr int kCfMaxRel = 4;                    // relations per segment (longer chains of depthwise layers stay on the general path)
 
 // one relation of a free-running segment
@@ -210,17 +211,23 @@ struct LeanArgs {
 };
 
 // the [O1] entries of channel c for the sweeps up to and including k (the later ones are not known to happen):
-// relation.py:20-24, dfq.py:64-71; f[0 .. G-2] = the previous group's pending sweeps, f[G-1] = sweep k
+// relation.py:20-24, dfq.py:64-71; f[0 .. G-2] = the previous group's pending sweeps, f[G-1] = sweep k.  Requested early
+// (lean_vectors_load, in front of the tile's elements: memory returns in order), finished when the factors are there.
+struct LeanVec { float cum, bnw, bnb, b1; };
+__device__ __forceinline__ LeanVec lean_vectors_load(const LeLeanRef& T, int c) {
+    LeanVec v;
+    v.cum = T.s_cum[c];
+    v.bnw = T.bnw ? T.bnw[c] : 0.f; v.bnb = T.bnb ? T.bnb[c] : 0.f; v.b1 = T.b1 ? T.b1[c] : 0.f;
+    return v;
+}
 template <int G>
-__device__ __forceinline__ void lean_vectors(const LeLeanRef& T, int c, const float (&f)[2 * G - 1]) {
-    float v_cum = T.s_cum[c];
-    float v_bnw = T.bnw ? T.bnw[c] : 0.f, v_bnb = T.bnb ? T.bnb[c] : 0.f, v_b1 = T.b1 ? T.b1[c] : 0.f;
+__device__ __forceinline__ void lean_vectors_finish(const LeLeanRef& T, int c, LeanVec v, const float (&f)[2 * G - 1]) {
 #pragma unroll
-    for (int j = 0; j < G; ++j) { v_cum = v_cum * f[j]; v_bnw = v_bnw * f[j]; v_bnb = v_bnb * f[j]; v_b1 = v_b1 * f[j]; }
-    T.s_cum[c] = v_cum;
-    if (T.bnw) T.bnw[c] = v_bnw;
-    if (T.bnb) T.bnb[c] = v_bnb;
-    if (T.b1) T.b1[c] = v_b1;
+    for (int j = 0; j < G; ++j) { v.cum = v.cum * f[j]; v.bnw = v.bnw * f[j]; v.bnb = v.bnb * f[j]; v.b1 = v.b1 * f[j]; }
+    T.s_cum[c] = v.cum;
+    if (T.bnw) T.bnw[c] = v.bnw;
+    if (T.bnb) T.bnb[c] = v.bnb;
+    if (T.b1) T.b1[c] = v.b1;
 }
 
 // rows * s: [nr x np] block, lanes along the row, a thread walks down the rows (as row_tile)
@@ -239,20 +246,26 @@ __device__ __forceinline__ void lean_row(const LeLeanRef& T, const LeanArgs& A, 
     const int n_own = lane_on ? small_div(nr - jl + JL - 1, JL) : 0;
     const int n_max = min(NV, small_div(nr + JL - 1, JL));
     gfloat* const w = (gfloat*)T.w + pos;
+    // the rows' factors are requested IN FRONT of the elements (memory returns in order: behind them, the table could only be
+    // filled once the whole tile had arrived)
+    const int c = T.r0 + min(tid, nr - 1);
+    float f[NT];
+    LeanVec vec{0.f, 0.f, 0.f, 0.f};
+    if (tid < nr) {
+        const gfloat* const ring = (const gfloat*)T.ring + c;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) f[j] = ring[(int64_t)(2 * cf_slot(A.k - G + 1 + j, G)) * T.o1];
+        if (T.s_cum) vec = lean_vectors_load(T, c);
+    }
     float v[NV][VEC];
 #pragma unroll
     for (int u = 0; u < NV; ++u) {
         if (u < n_max) vload<VEC>(w + min(jl + u * JL, nr - 1) * T.stride, v[u]);
     }
     if (tid < nr) {
-        const int c = T.r0 + tid;
-        const gfloat* const ring = (const gfloat*)T.ring + c;
-        float f[NT];
-#pragma unroll
-        for (int j = 0; j < NT; ++j) f[j] = ring[(int64_t)(2 * cf_slot(A.k - G + 1 + j, G)) * T.o1];
-        if (T.s_cum) lean_vectors<G>(T, c, f);
 #pragma unroll
         for (int j = 0; j < NT; ++j) sh_f[j * kCfTab + tid] = f[j];
+        if (T.s_cum) lean_vectors_finish<G>(T, c, vec, f);
     }
     __syncthreads();
 #pragma unroll
@@ -305,10 +318,6 @@ __device__ __forceinline__ void lean_col(const LeLeanRef& T, const LeanArgs& A, 
     const int n_max = min(NV, (nr + n_rowslots - 1) >> (8 - lg));
     gfloat* const w = (gfloat*)T.w + pos;
     float v[NV][VEC];
-#pragma unroll
-    for (int u = 0; u < NV; ++u) {
-        if (u < n_max) vload<VEC>(w + min(grp + u * n_rowslots, nr - 1) * T.stride, v[u]);
-    }
     // 1/s tables: (groups spanned by the rows) x (input channels spanned by the columns), one table per sweep
     const int i0 = small_div(T.p0, T.khkw);
     const int nci = small_div(T.p0 + np - 1, T.khkw) - i0 + 1;
@@ -319,14 +328,26 @@ __device__ __forceinline__ void lean_col(const LeLeanRef& T, const LeanArgs& A, 
     for (int e = 0; e < VEC; ++e) ci[e] = small_div(T.p0 + pos + e, T.khkw) - i0;
     if (g_n == 1) {
         // one group (every ungrouped layer): a thread's columns are the same in all of its rows -- their factors come straight
-        // from the ring into registers, no table, no barrier
+        // from the ring into registers, no table, no barrier; requested in front of the elements (memory returns in order)
         const int c0 = g_lo * T.gi + i0;
         float h[NT][VEC];
+        // a pointwise layer's four columns are four consecutive channels: one 16-byte request per sweep
+        const bool wide = VEC == 4 && T.khkw == 1 && (T.o1 & 3) == 0 && ((c0 + ci[0]) & 3) == 0 && (((uintptr_t)T.ring) & 15u) == 0;
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const gfloat* const ring = (const gfloat*)T.ring + (int64_t)(2 * cf_slot(A.k - G + 1 + j, G) + 1) * T.o1 + c0;
+            if (wide) {
+                const fvec4 t = *(const gfvec4*)(ring + ci[0]);
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) h[j][e] = ring[ci[e]];
+                for (int e = 0; e < VEC; ++e) h[j][e] = t[e % 4];
+            } else {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) h[j][e] = ring[ci[e]];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            if (u < n_max) vload<VEC>(w + min(grp + u * n_rowslots, nr - 1) * T.stride, v[u]);
         }
 #pragma unroll
         for (int u = 0; u < NV; ++u) {
@@ -358,7 +379,9 @@ __device__ __forceinline__ void lean_col(const LeLeanRef& T, const LeanArgs& A, 
         }
         return;
     }
-    for (int idx = tid; idx < g_n * nci; idx += kBlock) {      // (<= kCfTab entries by plan: one trip)
+    {
+        // (<= kCfTab = kBlock entries by plan: one per thread; requested in front of the elements)
+        const int idx = min(tid, g_n * nci - 1);
         const int gq = small_div(idx, nci);
         const int c = (g_lo + gq) * T.gi + i0 + (idx - gq * nci);
         const gfloat* const ring = (const gfloat*)T.ring + T.o1 + c;
@@ -366,7 +389,13 @@ __device__ __forceinline__ void lean_col(const LeLeanRef& T, const LeanArgs& A, 
 #pragma unroll
         for (int j = 0; j < NT; ++j) f[j] = ring[(int64_t)(2 * cf_slot(A.k - G + 1 + j, G)) * T.o1];
 #pragma unroll
-        for (int j = 0; j < NT; ++j) sh_f[j * kCfTab + idx] = f[j];
+        for (int u = 0; u < NV; ++u) {
+            if (u < n_max) vload<VEC>(w + min(grp + u * n_rowslots, nr - 1) * T.stride, v[u]);
+        }
+        if (tid < g_n * nci) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) sh_f[j * kCfTab + idx] = f[j];
+        }
     }
     if (tid < nr) sh_tab[tid] = (small_div(T.r0 + tid, T.go) - g_lo) * nci;
     __syncthreads();
@@ -429,7 +458,7 @@ __device__ __forceinline__ void lean_short(const LeLeanRef& T, const LeanArgs& A
             pf[j] = fused ? prev[(int64_t)(2 * slot) * T.o1_prev] : 1.0f;                      // (* 1.0f is exact)
         }
     }
-    if (side == 0 && ok && T.s_cum) lean_vectors<G>(T, c, f);
+    if (side == 0 && ok && T.s_cum) lean_vectors_finish<G>(T, c, lean_vectors_load(T, c), f);
     for (int k0 = 0; k0 < len; k0 += kShortChunk) {
         float x[kShortChunk];
 #pragma unroll
@@ -451,14 +480,12 @@ __device__ __forceinline__ void lean_short(const LeLeanRef& T, const LeanArgs& A
     }
 }
 
-// One launch per group of G sweeps: grid = the lean tiles of every free-running layer of the plan.
+// tile `idx` of the lean table.  sh_f: (2G - 1) * kCfTab floats, sh_tab: kTileRowsMax ints of LDS.
 template <int G>
-__global__ __launch_bounds__(kBlock) void le_lean_kernel(const LeLeanRef* __restrict__ refs, LeanArgs A, const LeState* __restrict__ state,
-                                                         double* __restrict__ partials) {
-    __shared__ float sh_f[(2 * G - 1) * kCfTab];
-    __shared__ int sh_tab[kTileRowsMax];
+__device__ __forceinline__ void lean_tile_run(const LeLeanRef* __restrict__ refs, int idx, const LeanArgs& A, const LeState* __restrict__ state,
+                                              double* __restrict__ partials, float* sh_f, int* sh_tab) {
     const int lane = threadIdx.x % kWave;
-    const uint32_t word = fetch_words(refs + blockIdx.x, kLeanWords, lane);
+    const uint32_t word = fetch_words(refs + idx, kLeanWords, lane);
     LeLeanRef T;
     {
         auto ptr = [&](int i) {
@@ -494,4 +521,15 @@ __global__ __launch_bounds__(kBlock) void le_lean_kernel(const LeLeanRef* __rest
         if (lane == 0)
             partials[(int64_t)((A.k + i) & (G - 1)) * A.part_stride + (int64_t)T.slot * (kBlock / kWave) + threadIdx.x / kWave] = t;
     }
+}
+
+// One launch per group of G sweeps: grid = the lean tiles of every free-running layer of the plan.  (With the default depth the
+// lean tiles are instead woven into the sweep's own launch at the group's first sweep -- le_level_kernel -- where their
+// arithmetic overlaps the general tiles' memory traffic; this kernel serves the other depths and the per-level launches.)
+template <int G>
+__global__ __launch_bounds__(kBlock) void le_lean_kernel(const LeLeanRef* __restrict__ refs, LeanArgs A, const LeState* __restrict__ state,
+                                                         double* __restrict__ partials) {
+    __shared__ float sh_f[(2 * G - 1) * kCfTab];
+    __shared__ int sh_tab[kTileRowsMax];
+    lean_tile_run<G>(refs, (int)blockIdx.x, A, state, partials, sh_f, sh_tab);
 }

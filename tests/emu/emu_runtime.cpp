@@ -93,6 +93,8 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
         for (size_t i = old; i < fibers.size(); ++i) fibers[i].stack = (char*)malloc(kStack);
     }
     body_ptr = &body;
+    // dynamic shared memory of a sequential launch: one buffer serves every workgroup in turn (an LDS's worth)
+    static unsigned char* seq_smem = (unsigned char*)aligned_alloc(256, 160 * 1024);
     for (unsigned bz = 0; bz < grid.z; ++bz)
     for (unsigned by = 0; by < grid.y; ++by)
     for (unsigned bx = 0; bx < grid.x; ++bx) {
@@ -102,6 +104,7 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
             f.tc.bid = dim3(bx, by, bz);
             f.tc.bdim = block;
             f.tc.gdim = grid;
+            f.tc.smem = seq_smem;
             f.tc.slot = 0;
             f.tc.rl_valid = false;
             f.state = READY;

@@ -249,12 +249,16 @@ def _kat_names():
 # 'streaming': the default streaming engine -- free-running segments on lean tiles, four sweeps per pass (dfq_le_cf.hpp), the other
 # layers on the general tiles; '-cf2' / '-cf8': other group depths; 'streaming-general': every layer on the general tiles
 # (DFQ_LE_CF=0); the persistent-workgroup variants of the general tiles run without free-running segments as well
-LE_ENGINES = ['resident', 'streaming', 'streaming-cf2', 'streaming-cf8', 'streaming-general', 'streaming-persistent', 'streaming-persistent-3wg']
+# 'streaming-fused': layers scaled along both axes are read once per sweep -- their row tiles merge the rows' statistics over the slabs
+# of a row block inside the launch (DFQ_LE_FUSE=1: the default of batched plans)
+LE_ENGINES = ['resident', 'streaming', 'streaming-cf2', 'streaming-cf8', 'streaming-general', 'streaming-fused', 'streaming-persistent', 'streaming-persistent-3wg']
 
 
 def _select_le_engine(monkeypatch, le_engine):
-    for k in ('DFQ_LE_RESIDENT', 'DFQ_LE_PERSIST', 'DFQ_LE_SWEEP_WGS', 'DFQ_LE_TILE_ELEMS', 'DFQ_LE_CF', 'DFQ_LE_CF_GROUP'):
+    for k in ('DFQ_LE_RESIDENT', 'DFQ_LE_PERSIST', 'DFQ_LE_SWEEP_WGS', 'DFQ_LE_TILE_ELEMS', 'DFQ_LE_CF', 'DFQ_LE_CF_GROUP', 'DFQ_LE_FUSE'):
         monkeypatch.delenv(k, raising=False)
+    if le_engine == 'streaming-fused':
+        monkeypatch.setenv('DFQ_LE_FUSE', '1')
     if le_engine != 'resident':
         monkeypatch.setenv('DFQ_LE_RESIDENT', '0')
     if le_engine.startswith('streaming-cf'):
@@ -1248,7 +1252,8 @@ def test_speculation_past_the_verdict_is_invisible(engine, monkeypatch, name, se
 
 # (the persistent-workgroup variant is slow on the CPU emulation: it runs at the default depth of batched plans only)
 @pytest.mark.parametrize('depth,le_engine', [('1', 'streaming-general'), ('2', 'streaming-general'), ('4', 'streaming-general'), ('4', 'streaming-persistent-3wg'),
-                                             ('1', 'streaming'), ('4', 'streaming'), ('2', 'streaming-cf2'), ('4', 'streaming-cf8')])
+                                             ('1', 'streaming'), ('4', 'streaming'), ('2', 'streaming-cf2'), ('4', 'streaming-cf8'),
+                                             ('1', 'streaming-fused'), ('4', 'streaming-fused')])
 @pytest.mark.parametrize('name,seed,signed', [('tiny_mobile', 0, False), ('tiny_res', 0, False), ('tiny_cat', 3, True), ('tiny_tail', 1, False)])
 def test_deferred_stores_are_invisible(engine, monkeypatch, depth, le_engine, name, seed, signed):
     """Streaming engine, DFQ_LE_DEFER = depth: layers that are scaled one way only are stored every depth-th sweep and
@@ -1273,7 +1278,7 @@ def test_deferred_stores_are_invisible(engine, monkeypatch, depth, le_engine, na
             assert plan.sweep_bytes < 8 * plan.rw_elements + 4 * plan.ro_elements
     else:
         # the free-running segments (dfq_le_cf.hpp): layers whose every statistic is closed-form leave the sweep's launch
-        group = {'streaming': 4, 'streaming-cf2': 2, 'streaming-cf8': 8}[le_engine]
+        group = {'streaming': 4, 'streaming-cf2': 2, 'streaming-cf8': 8, 'streaming-fused': 4}[le_engine]
         if name in ('tiny_cat', 'tiny_tail'):   # (their chains run through dense layers scaled along both axes: nothing is free-running)
             assert plan.free_running_group == 1 and plan.free_running_elements == 0
         else:

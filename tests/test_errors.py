@@ -117,6 +117,7 @@ def test_abandoned_in_launch_wait_is_reported_not_silent(engine, monkeypatch, wh
 
     if which == 'streaming':
         monkeypatch.setenv('DFQ_LE_RESIDENT', '0')
+        monkeypatch.setenv('DFQ_LE_CF', '0')      # every layer on the general tiles: the launch with the most in-launch waits
     if which == 'bias_correction_one_launch':
         # (a batch's default: the per-tensor min/max blocks are workgroups of the chain launch and the steps wait for their
         # layer's blocks -- one more kind of in-launch wait, bounded like the others)
@@ -253,6 +254,7 @@ def test_host_resident_model_survives_an_abandoned_wait(monkeypatch, which):
     TARG = [nn.Conv2d, nn.Linear]
     _ffi.lib()
     monkeypatch.setenv('DFQ_LE_RESIDENT', '0')
+    monkeypatch.setenv('DFQ_LE_CF', '0')           # every layer on the general tiles: the launch with the most in-launch waits
 
     def fresh():
         model, graph, bottoms = synthetic.build('tiny_mobile', seed=0)          # stays on the CPU
