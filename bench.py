@@ -27,7 +27,7 @@ Next to it, measured by the same run and reported in the same line:
             ranks, pinned sweeps, ONE all_gather of the cumulative scale vectors (RCCL over xGMI), engine rebuild
             of every paired layer, replicated bias correction -> strong scaling (total work fixed); runs at every
             N (at N = 1 it is the degenerate one-rank group), so a driver run at N = 8 puts 8 ranks on the data path;
-            `data_dependent_ms`: the same pass with the reference's stopping rule (one 8-byte all_reduce per sweep);
+            `data_dependent_ms`: the same pass with the reference's stopping rule (one all_reduce per chunk of sweeps);
   roofline  dominant kernel le_level_kernel: algorithmic bytes per launch / HIP-event duration per launch;
   cpu_baseline   the numpy oracle (a vectorised CPU port) timed live on this host + `reference`: the UNMODIFIED reference's own
             CPU path timed on THIS box's host cores (oracle/time_ref.py drives the byte-compiled reference of oracle/_ref for
@@ -619,7 +619,7 @@ def sharded_single_network(spec, steps, dev, dist, rank, world):
     dd_sweeps = []
 
     def data_dependent(r):
-        dd_sweeps.append(r[0].run(max_sweeps=None, check=False))       # one all_reduce per sweep decides whether the next one happens
+        dd_sweeps.append(r[0].run(max_sweeps=None, check=False))       # chunks of sweeps, one all_reduce + one host read per chunk (sharded.py)
         r[1].run()
 
     reps = fresh(steps + 2)
@@ -644,15 +644,17 @@ def sharded_single_network(spec, steps, dev, dist, rank, world):
             'world': world, 'ranks_owning_components': len(set(owner)), 'paired_elements_per_rank': per_rank,
             'ms_per_pass': ms, 'value': n_w / (ms * 1e-3), 'unit': 'weights/s',
             'scaling': 'strong', 'collectives_per_pass': 1, 'exchange_bytes_per_rank': exchange,
-            'data_dependent_ms': dd_ms, 'data_dependent_sweeps': dd_sweeps[-1], 'data_dependent_collectives_per_pass': dd_sweeps[-1] + 1,
+            'data_dependent_ms': dd_ms, 'data_dependent_sweeps': dd_sweeps[-1], 'data_dependent_chunk': sharded.ShardedEqualizer.CHUNK,
+            'data_dependent_collectives_per_pass': -(-dd_sweeps[-1] // sharded.ShardedEqualizer.CHUNK) + 1,
             'backend': dist.get_backend(),
             'what': 'ONE {} network per pass: relation components partitioned over the ranks (greedy by paired elements: '
                     'paired_elements_per_rank), {} pinned sweeps per rank on the '
                     'owned components (on scratch copies), one all_gather of the cumulative scale vectors, ONE batched rebuild launch of every '
                     'paired tensor on every rank (W = diag(S_out) W0 diag(1/S_in): all ranks end bit-identical), bias correction replicated on '
                     'every rank; plans prebuilt, weights resident.  data_dependent_ms: the same pass with the reference\'s own stopping '
-                    'rule (dfq.py:83-115) -- every sweep ends with an 8-byte all_reduce of sum mean|dW| that the host reads before it enqueues '
-                    'the next sweep'.format(net, sweeps)}
+                    'rule (dfq.py:83-115) -- chunks of data_dependent_chunk sweeps on the device, ONE all_reduce of a chunk\'s per-sweep '
+                    'sums of mean|dW|, the verdicts drawn on the device, one host read per chunk; a loop that stops inside a chunk goes back to '
+                    'the chunk\'s start (scratch copies) and runs exactly the sweeps that happen'.format(net, sweeps)}
 
 
 # ---------------------------------------------------------------------------------------------------

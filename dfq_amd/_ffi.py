@@ -109,6 +109,8 @@ SIGNATURES = {
     'dfq_le_enqueue': (c_int32, [c_void_p, POINTER(DfqLeConfig), c_int32, c_int32, c_void_p]),
     'dfq_le_query': (c_int32, [c_void_p, c_void_p, POINTER(DfqLeResult), POINTER(c_int32)]),
     'dfq_le_run': (c_int32, [c_void_p, POINTER(DfqLeConfig), c_void_p, POINTER(DfqLeResult)]),
+    'dfq_le_set_diff_log': (c_int32, [c_void_p, c_void_p, c_int32]),
+    'dfq_le_shared_verdict': (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_double, c_int32, c_int32, c_void_p]),
     'dfq_le_profile': (c_int32, [c_void_p, POINTER(DfqLeConfig), c_int32, c_void_p, POINTER(c_double), POINTER(c_double),
                                  POINTER(c_int32), POINTER(c_double), POINTER(c_double), POINTER(c_int32)]),
     'dfq_le_trace': (c_int32, [c_void_p, POINTER(DfqLeConfig), c_int32, c_int32, c_void_p, POINTER(c_int64)]),

@@ -1611,6 +1611,7 @@ __global__ __launch_bounds__(kCtlBlock) void le_control_kernel(const LeLayerDiff
         state->sweeps = sweeps;
         state->last_diff_tmp = diff_tmp;
         state->done = go_on ? 0 : 1;
+        if (before.log && before.sweeps < before.log_cap) before.log[before.sweeps] = diff_tmp;
     }
 }
 
@@ -3194,6 +3195,49 @@ int dfq_le_query(dfq_le_plan* p, void* stream, dfq_le_result* out, int32_t* done
 }
 
 int32_t dfq_le_plan_nets(const dfq_le_plan* p) { return p ? p->n_nets : 0; }
+
+// ---- a stopping rule that spans several plans (the sharded pass, dfq_amd/sharded.py) ----
+int dfq_le_set_diff_log(dfq_le_plan* p, double* log_device, int32_t capacity) {
+    if (!p || capacity < 0 || (capacity > 0 && !log_device)) return fail_arg("dfq_le_set_diff_log: bad argument");
+    if (p->n_nets != 1) return fail_arg("dfq_le_set_diff_log: single-network plans only");
+    LeState h;
+    DFQ_HIP_TRY(hipMemcpy(&h, p->d_state, sizeof(LeState), hipMemcpyDeviceToHost));
+    h.log = capacity > 0 ? log_device : nullptr;
+    h.log_cap = capacity;
+    DFQ_HIP_TRY(hipMemcpy(p->d_state, &h, sizeof(LeState), hipMemcpyHostToDevice));
+    return DFQ_OK;
+}
+
+}  // extern "C"
+
+// dfq.py:110-115 over `n` values of diff_tmp that are sums over ALL participants: ext = { diff, count, sweeps, done } as doubles
+__global__ void le_shared_verdict_kernel(const double* __restrict__ reduced, int n, double* __restrict__ ext, dfq::LeState* states,
+                                         int n_nets, double converge_thres, int converge_count, int max_sweeps) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    double diff = ext[0];
+    int count = (int)ext[1], sweeps = (int)ext[2];
+    bool done = ext[3] != 0.0;
+    for (int i = 0; i < n && !done; ++i) {
+        const double diff_tmp = reduced[i];
+        if (fabs(diff - diff_tmp) > 1e-9) { count = 0; diff = diff_tmp; }
+        else { count += 1; }
+        sweeps += 1;
+        done = !((diff > converge_thres) && (count < converge_count) && (max_sweeps < 0 || sweeps < max_sweeps));
+    }
+    ext[0] = diff; ext[1] = (double)count; ext[2] = (double)sweeps; ext[3] = done ? 1.0 : 0.0;
+    if (done) for (int k = 0; k < n_nets; ++k) states[k].done = 1;        // sweeps already enqueued behind this become no-ops
+}
+
+extern "C" {
+
+int dfq_le_shared_verdict(dfq_le_plan* p, const double* reduced_device, int32_t n, double* ext4_device, double converge_thres,
+                          int32_t converge_count, int32_t max_sweeps, void* stream) {
+    if (!reduced_device || !ext4_device || n < 0) return fail_arg("dfq_le_shared_verdict: bad argument");
+    hipLaunchKernelGGL(le_shared_verdict_kernel, dim3(1), dim3(64), 0, as_stream(stream), reduced_device, (int)n, ext4_device,
+                       p ? p->d_state : nullptr, p ? p->n_nets : 0, converge_thres, (int)converge_count, (int)max_sweeps);
+    DFQ_CHECK_LAUNCH();
+    return DFQ_OK;
+}
 
 int dfq_le_run(dfq_le_plan* p, const dfq_le_config* cfg, void* stream, dfq_le_result* out) {
     if (!p || !cfg) return fail_arg("dfq_le_run: bad argument");

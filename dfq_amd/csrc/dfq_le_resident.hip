@@ -1464,6 +1464,10 @@ __device__ __forceinline__ void res_reducer_body(const ResArgs& a, const LeParam
         // dfq.py:110-115
         if (fabs(st.diff - diff_tmp) > 1e-9) { st.count = 0; st.diff = diff_tmp; }
         else { st.count += 1; }
+        if (tid == 0) {                         // (optional per-sweep record for a stopping rule that spans several plans, LeState::log)
+            const LeState* s0 = c.state;
+            if (s0->log && st.sweeps < s0->log_cap) s0->log[st.sweeps] = diff_tmp;
+        }
         st.sweeps += 1;
         st.last_diff_tmp = diff_tmp;
         const bool go_on = (st.diff > c.converge_thres) && (st.count < c.converge_count) && (c.max_sweeps < 0 || st.sweeps < c.max_sweeps);

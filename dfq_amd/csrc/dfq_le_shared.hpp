@@ -22,7 +22,11 @@ struct LeState {
     int32_t count;
     int32_t sweeps;
     int32_t done;
-    int32_t pad;
+    int32_t log_cap;        // entries of `log` (0: none)
+    // optional: diff_tmp of sweep j (sweeps since the last restart) is also left in log[j] -- a sharded pass (dfq_amd/sharded.py)
+    // runs chunks of sweeps without the reference's exit test and all-reduces a chunk's values in ONE collective
+    // (dfq_le_set_diff_log; untouched by restarts)
+    double* log;
 };
 
 // Every in-launch wait is bounded: DFQ_SPIN_LIMIT polls (default: seconds), then the workgroup gives up, raises the plan's

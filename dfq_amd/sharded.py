@@ -23,7 +23,8 @@ BASELINE.json (DeepLab sharded over 8 GPUs) and for networks too large for one p
 for the headline MobileNetV2 number (bench.py shards whole networks over ranks instead).
 
 The data-dependent convergence test of dfq.py:83-115 needs the sum of all layers' mean |dW|: with
-``max_sweeps=None`` the ranks run sweep by sweep and all-reduce that one float64 per sweep.
+``max_sweeps=None`` the ranks run CHUNKS of sweeps, all-reduce a chunk's per-sweep sums in one collective and
+draw the verdicts on the device (``ShardedEqualizer._run_data_dependent``): one host read per chunk.
 """
 from __future__ import annotations
 
@@ -153,6 +154,11 @@ class _EngineSession:
     def last_diff(self):
         """sum over the owned layers of mean|W - W_prev| of the latest sweep (one small device-to-host copy)."""
         return self.plan.query()['last_diff_tmp']
+
+    def set_log(self, log):
+        """From now on diff_tmp of sweep j (since the last restart) is also left in log[j] (dfq_le_set_diff_log)."""
+        _ffi.check(_ffi.lib().dfq_le_set_diff_log(self.plan._plan, log.data_ptr() if log is not None else None,
+                                                  int(log.numel()) if log is not None else 0))
 
     def finish(self):
         self.plan.query()                                    # synchronises and surfaces a failed in-launch wait
@@ -347,6 +353,8 @@ class ShardedEqualizer:
                     if session is not None and max_sweeps > 0:
                         session.sweeps(max_sweeps)
                     sweeps = max_sweeps
+                elif session is None or isinstance(session, _EngineSession):
+                    sweeps = self._run_data_dependent(session, converge_thres, converge_count)
                 else:
                     diff, count, sweeps = 10.0, 0, 0
                     while diff > converge_thres and count < converge_count:       # dfq.py:83
@@ -388,6 +396,69 @@ class ShardedEqualizer:
         if check:
             self.check()
         return sweeps
+
+    #: sweeps per chunk of the data-dependent mode: one collective and one host read per chunk (DFQ_SHARD_CHUNK)
+    CHUNK = 8
+
+    def _run_data_dependent(self, session, converge_thres, converge_count):
+        """The reference's own stopping rule (dfq.py:83-115) over the ranks' summed mean|dW| WITHOUT a host round trip per sweep.
+        A rank runs a chunk of sweeps with its plan's exit test disabled; the plan leaves diff_tmp of every sweep in a device
+        log; ONE all_reduce per chunk sums the ranks' logs; the (diff, count) state machine runs over the chunk's sums on the
+        device (dfq_le_shared_verdict) and the host reads four numbers per chunk.  A loop that stops INSIDE a chunk has run a few
+        sweeps too many on this rank's SCRATCH copies (all a rank keeps of them are the cumulative scales): scratch tensors and
+        scales go back to the chunk's start (two device copies taken there) and exactly the sweeps that happen are run again.
+        Every rank sees the same sums, draws the same verdicts and enqueues the same collectives."""
+        import os
+        chunk = max(1, int(os.environ.get('DFQ_SHARD_CHUNK', self.CHUNK)))
+        dev, cdev, group = self.dev, self.comm_dev, self.group
+        log_cap = 64 * chunk
+        log = torch.zeros(log_cap, dtype=torch.float64, device=dev)
+        ext = torch.tensor([10.0, 0.0, 0.0, 0.0], dtype=torch.float64, device=dev)      # dfq.py:81-82
+        keep_scratch = torch.empty_like(self.scratch) if session is not None else None
+        keep_flat = torch.empty_like(self.flat)
+        if session is not None:
+            session.set_log(log)
+        plan = session.plan._plan if session is not None else None
+        engine_sweep, total = 0, 0            # sweeps since the plan's last restart / since the start of the pass
+        try:
+            while True:
+                if engine_sweep + chunk > log_cap:                # (a loop of thousands of sweeps: the log starts over)
+                    session is not None and session.start()
+                    engine_sweep = 0
+                if session is not None:
+                    keep_scratch.copy_(self.scratch)
+                keep_flat.copy_(self.flat)
+                if session is not None:
+                    session.sweeps(chunk)
+                piece = log[engine_sweep:engine_sweep + chunk]
+                if cdev == dev:
+                    dist.all_reduce(piece, op=dist.ReduceOp.SUM, group=group)
+                else:
+                    t = piece.to(cdev)
+                    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+                    piece.copy_(t)
+                _ffi.check(_ffi.lib().dfq_le_shared_verdict(plan, piece.data_ptr(), chunk, ext.data_ptr(), float(converge_thres),
+                                                            int(converge_count), -1, _ffi.stream_arg()))
+                state = ext.tolist()                              # the ONE host read of the chunk
+                engine_sweep += chunk
+                if state[3] != 0.0:
+                    n_keep = int(state[2]) - total
+                    total = int(state[2])
+                    if n_keep < chunk:
+                        # the loop stopped inside the chunk: back to the chunk's start, then exactly the sweeps that happen
+                        if session is not None:
+                            self.scratch.copy_(keep_scratch)
+                        self.flat.copy_(keep_flat)
+                        if session is not None:
+                            session.set_log(None)
+                            session.start()                       # (statistics of the restored tensors; the loop state starts over)
+                            if n_keep > 0:
+                                session.sweeps(n_keep)
+                    return total
+                total += chunk
+        finally:
+            if session is not None and session.plan._plan:
+                session.set_log(None)
 
     def check(self):
         """Synchronise and raise if a workgroup of this rank's sweeps abandoned a wait (once; closes the sweep plan)."""

@@ -212,6 +212,17 @@ int dfq_le_enqueue(dfq_le_plan* plan, const dfq_le_config* cfg, int32_t n_sweeps
  * plan has stopped; dfq_le_query_all: `out` has dfq_le_plan_nets() entries. */
 int dfq_le_query(dfq_le_plan* plan, void* stream, dfq_le_result* out, int32_t* done);
 int dfq_le_query_all(dfq_le_plan* plan, void* stream, dfq_le_result* out, int32_t* all_done);
+/* A stopping rule that spans several plans -- the sharded pass (dfq_amd/sharded.py), where dfq.py:105-108's sum runs over the
+ * layers of ALL ranks.  dfq_le_set_diff_log (single-network plans; synchronises): from now on the plan also leaves diff_tmp of
+ * sweep j (sweeps since the last restart) in log_device[j], j < capacity; capacity 0 switches it off.  The caller runs a chunk of
+ * sweeps with the plan's own exit test disabled (converge_thres < 0), all-reduces the chunk's log entries in ONE collective and
+ * hands the sums to dfq_le_shared_verdict: the (diff, count) state machine of dfq.py:110-115 over `n` values on the device,
+ * ext4_device = { diff, count, sweeps, done } as float64 (initialise to { 10, 0, 0, 0 }: dfq.py:81-82); once `done`, the plan's
+ * loop state (plan may be NULL for a rank that owns nothing) is stopped so that sweeps enqueued behind it are no-ops.
+ * Asynchronous; nothing is read back. */
+int dfq_le_set_diff_log(dfq_le_plan* plan, double* log_device, int32_t capacity);
+int dfq_le_shared_verdict(dfq_le_plan* plan, const double* reduced_device, int32_t n, double* ext4_device, double converge_thres,
+                          int32_t converge_count, int32_t max_sweeps, void* stream);
 /* The whole dfq.py:83-115 loop: enqueue in chunks, poll, stop when the device says so.
  * Synchronises. */
 int dfq_le_run(dfq_le_plan* plan, const dfq_le_config* cfg, void* stream, dfq_le_result* out);

@@ -226,6 +226,25 @@ def test_sharded_equalization_two_ranks(tmp_path, emu_lib_path, name, seed, max_
         assert_bitexact(r0[k], v, 'canonical ' + k)
 
 
+@pytest.mark.parametrize('chunk', ['1', '3', '16'])
+def test_sharded_data_dependent_loop_in_chunks(tmp_path, emu_lib_path, monkeypatch, chunk):
+    """the reference's own stopping rule (dfq.py:83-115) over the ranks' summed mean|dW| without a host round
+    trip per sweep -- chunks of sweeps, ONE all_reduce of a chunk's per-sweep sums, the verdicts drawn on the device
+    (dfq_le_shared_verdict), scratch tensors and scales taken back to the chunk's start when the loop stops inside a chunk.
+    Whatever the chunk size: the oracle's sweep count, bit-exact cumulative scales, bit-equal ranks."""
+    monkeypatch.setenv('DFQ_SHARD_CHUNK', chunk)
+    world, name, seed = 2, 'tiny_mobile', 0
+    mp.spawn(_worker, args=(world, _free_port(), name, seed, None, str(tmp_path), emu_lib_path, False, False), nprocs=world, join=True)
+    model, graph, bottoms, spec = _prepare(name, seed)
+    n_ref, S_ref = orc.cross_layer_equalization(spec, orc.create_relation(spec))
+    r0 = np.load(os.path.join(str(tmp_path), 'rank0.npz'))
+    r1 = np.load(os.path.join(str(tmp_path), 'rank1.npz'))
+    assert int(r0['sweeps']) == int(r1['sweeps']) == n_ref
+    assert n_ref % 16 != 0                                       # (the loop does stop inside a chunk of 3 or 16)
+    _check_against_oracle((r0, r1), graph, spec, S_ref)
+    _check_ranks_identical(r0, r1, need_tail=False)
+
+
 def test_sharded_result_does_not_depend_on_world_size(tmp_path, emu_lib_path):
     """One rank and two ranks end with the same bits (the rebuild is a function of W0 and the cumulative scales only)."""
     outs = []
@@ -418,7 +437,7 @@ def _rccl_worker(rank, world, port, name, seed, sweeps, out_dir):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('name,sweeps,n_rel', [('deeplab_mnv2', 60, 35), ('mobilenet_v2', 47, 37)])
+@pytest.mark.parametrize('name,sweeps,n_rel', [('deeplab_mnv2', 60, 35), ('mobilenet_v2', 47, 37), ('mobilenet_v2', None, 37)])
 def test_sharded_network_over_rccl_all_ranks(tmp_path, name, sweeps, n_rel):
     """BASELINE.json config 4 on the hardware it names, in the two configurations bench.py times (`sharded`): DeepLab (35
     relations, 60 pinned sweeps) and north_star's own graph, the 53-layer MobileNetV2 (37 relations in 16 components, 47 pinned
@@ -430,10 +449,20 @@ def test_sharded_network_over_rccl_all_ranks(tmp_path, name, sweeps, n_rel):
     seed = 0
     worlds = [1] if n_dev < 2 else [1, min(n_dev, 8)]
     res = {}
+    # (sweeps None: the reference's own stopping rule over the ranks' summed mean|dW| -- chunks of sweeps, one all_reduce per chunk,
+    # verdicts on the device, sharded.py; the oracle's data-dependent loop says where it must stop)
+    model, graph, bottoms, spec = _prepare(name, seed)
+    orels = orc.create_relation(spec)
+    assert len(orels) == n_rel
+    if sweeps is None:
+        pinned, (sweeps, S_ref) = None, orc.cross_layer_equalization(spec, orels)
+    else:
+        pinned = sweeps
+        _, S_ref = orc.cross_layer_equalization(spec, orels, max_sweeps=sweeps, converge_thres=-1.0, converge_count=10 ** 9)
     for world in worlds:
         d = tmp_path / 'w{}'.format(world)
         d.mkdir()
-        mp.spawn(_rccl_worker, args=(world, _free_port(), name, seed, sweeps, str(d)), nprocs=world, join=True)
+        mp.spawn(_rccl_worker, args=(world, _free_port(), name, seed, pinned, str(d)), nprocs=world, join=True)
         res[world] = [np.load(os.path.join(str(d), 'rank{}.npz'.format(r))) for r in range(world)]
         assert all(int(r['sweeps']) == sweeps for r in res[world])
         for r in res[world][1:]:
@@ -442,10 +471,6 @@ def test_sharded_network_over_rccl_all_ranks(tmp_path, name, sweeps, n_rel):
             assert len(set(res[world][0]['owner'].tolist())) > 1, 'more than one rank must own work'
     base = res[1][0]
     # the single-process oracle: cumulative scales bit-identical, tensors within 1e-5 (and the canonical rebuild bit for bit)
-    model, graph, bottoms, spec = _prepare(name, seed)
-    orels = orc.create_relation(spec)
-    assert len(orels) == n_rel
-    _, S_ref = orc.cross_layer_equalization(spec, orels, max_sweeps=sweeps, converge_thres=-1.0, converge_count=10 ** 9)
     for i, s in enumerate(S_ref):
         assert_bitexact(base['S{}'.format(i)], s, 'S{}'.format(i))
     for world in worlds[1:]:
