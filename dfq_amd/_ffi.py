@@ -109,6 +109,10 @@ SIGNATURES = {
     'dfq_le_enqueue': (c_int32, [c_void_p, POINTER(DfqLeConfig), c_int32, c_int32, c_void_p]),
     'dfq_le_query': (c_int32, [c_void_p, c_void_p, POINTER(DfqLeResult), POINTER(c_int32)]),
     'dfq_le_run': (c_int32, [c_void_p, POINTER(DfqLeConfig), c_void_p, POINTER(DfqLeResult)]),
+    'dfq_le_plan_has_waits': (c_int32, [c_void_p]),
+    'dfq_le_plan_set_safe_mode': (c_int32, [c_void_p]),
+    'dfq_bc_plan_has_waits': (c_int32, [c_void_p]),
+    'dfq_bc_plan_set_safe_mode': (c_int32, [c_void_p]),
     'dfq_le_set_diff_log': (c_int32, [c_void_p, c_void_p, c_int32]),
     'dfq_le_shared_verdict': (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_double, c_int32, c_int32, c_void_p]),
     'dfq_le_profile': (c_int32, [c_void_p, POINTER(DfqLeConfig), c_int32, c_void_p, POINTER(c_double), POINTER(c_double),
@@ -223,13 +227,18 @@ def lib():
 
 
 class DfqError(RuntimeError):
-    pass
+    code = 0
+
+
+ERR_ABANDONED = -4          # DFQ_ERR_ABANDONED: a workgroup gave up a bounded in-launch wait (include/dfq_hip.h)
 
 
 def check(rc):
     if rc != 0:
         msg = lib().dfq_last_error()
-        raise DfqError('libdfq_hip error {}: {}'.format(rc, msg.decode() if msg else '?'))
+        err = DfqError('libdfq_hip error {}: {}'.format(rc, msg.decode() if msg else '?'))
+        err.code = int(rc)
+        raise err
 
 
 def target_device():
@@ -498,6 +507,15 @@ class Stage:
         hit = self._bound.get(key)
         if hit is not None:
             return hit[1]
+        amb = getattr(_ambient, 'stage', None)
+        if amb is not None and amb is not self:
+            # a private stage INSIDE a staging() scope (merge_scale_into_layer, _layer_equalization, the single-step primitives):
+            # a tensor the scope has already shadowed is bound to the SCOPE's device copy -- between the calls of a scope that
+            # copy is the truth (the host value is stale), and what this call writes must not be overwritten by the scope's
+            # write-back when it ends
+            shared = amb._bound.get(key)
+            if shared is not None and shared[1] is not t:
+                return shared[1]
         if t.device == self.device and t.dtype == torch.float32 and t.is_contiguous():
             # already where the kernels want it: the engine only takes its address (no torch op ever writes through this
             # handle), so the tensor itself will do -- no detach(), whose cost adds up over the ~250 tensors of a network

@@ -184,6 +184,7 @@ class NetworkBatch:
         out.n_layers = T.n_layers
         out.keep = [self]
         out.bases = self.bases
+        out.mutable = [self.storage]          # one allocation holds every tensor the plans rewrite: a snapshot is ONE copy
         return out
 
     def check(self, thorough=False):

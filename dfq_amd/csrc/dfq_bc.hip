@@ -1487,7 +1487,7 @@ int dfq_bc_plan_status(dfq_bc_plan* p, void* stream) {
     // (tagged protocol: the word holds the epoch of the latest failed run, an older failure is none of this run's)
     if (p->last_tagged ? (gave_up == p->epoch) : (gave_up != 0u)) {
         set_error("dfq_bc_plan_status: a workgroup gave up waiting for the previous correction step (results are invalid)");
-        return DFQ_ERR_STATE;
+        return DFQ_ERR_ABANDONED;
     }
     return DFQ_OK;
 }
@@ -1500,6 +1500,14 @@ const float* dfq_bc_plan_correction(const dfq_bc_plan* p, int32_t step) {
 }
 int64_t dfq_bc_plan_weight_elements(const dfq_bc_plan* p) { return p ? p->weight_elems : 0; }
 int32_t dfq_bc_plan_tagged(const dfq_bc_plan* p) { return (p && p->merged && p->d_tags) ? 1 : 0; }
+// the chain as one launch contains in-launch waits (dfq_bc_plan_status can report DFQ_ERR_ABANDONED); safe mode: one launch per
+// chain position from now on -- nothing waits, nothing can be abandoned
+int32_t dfq_bc_plan_has_waits(const dfq_bc_plan* p) { return (p && p->merged && p->chain_blocks > 0) ? 1 : 0; }
+int dfq_bc_plan_set_safe_mode(dfq_bc_plan* p) {
+    if (!p) return fail_arg("dfq_bc_plan_set_safe_mode: null plan");
+    p->merged = false;
+    return DFQ_OK;
+}
 int32_t dfq_bc_plan_last_run_tagged(const dfq_bc_plan* p) { return (p && p->last_tagged) ? 1 : 0; }
 int32_t dfq_bc_plan_one_launch(const dfq_bc_plan* p) { return (p && p->merged && p->fused_mm) ? 1 : 0; }
 

@@ -2704,6 +2704,18 @@ static inline bool res_on(const dfq_le_plan* p) { return p && p->resident && !p-
 int32_t dfq_le_plan_resident_tiles(const dfq_le_plan* p) { return res_on(p) ? le_resident_tiles(p->resident) : 0; }
 int32_t dfq_le_plan_degraded(const dfq_le_plan* p) { return p ? p->degraded : 0; }
 int32_t dfq_le_plan_uniform(const dfq_le_plan* p) { return (p && p->uni_layers > 0) ? 1 : 0; }
+int32_t dfq_le_plan_has_waits(const dfq_le_plan* p) {
+    return (p && !res_on(p) && p->n_rels > 0 && ((p->merged && p->levels.size() > 1) || p->has_slab_tiles)) ? 1 : 0;
+}
+int dfq_le_plan_set_safe_mode(dfq_le_plan* p) {
+    if (!p) return fail_arg("dfq_le_plan_set_safe_mode: null plan");
+    if (p->has_slab_tiles) { set_error("dfq_le_plan_set_safe_mode: a plan with slab tiles (DFQ_LE_FUSE=1) waits inside every launch"); return DFQ_ERR_STATE; }
+    p->resident_off = true;
+    p->merged = false;
+    p->sweep_grid = 0;
+    if (p->resident_why.empty() || p->resident) p->resident_why = "safe mode: one launch per dependency level, no in-launch waits";
+    return DFQ_OK;
+}
 const char* dfq_le_plan_resident_reason(const dfq_le_plan* p) { return p ? p->resident_why.c_str() : ""; }
 int dfq_le_resident_stats(dfq_le_plan* p, void* stream, int64_t* out5) {
     if (!res_on(p)) return fail_arg("dfq_le_resident_stats: not a resident plan");
@@ -3169,7 +3181,7 @@ int dfq_le_query_all(dfq_le_plan* p, void* stream, dfq_le_result* out, int32_t* 
     DFQ_HIP_TRY(hipStreamSynchronize(st));
     if (gave_up) {
         set_error("dfq_le_query: a workgroup gave up waiting for the tiles it depends on (results are invalid)");
-        return DFQ_ERR_STATE;
+        return DFQ_ERR_ABANDONED;
     }
     int32_t done = 1;
     for (int n = 0; n < p->n_nets; ++n) {
@@ -3251,7 +3263,7 @@ int dfq_le_run(dfq_le_plan* p, const dfq_le_config* cfg, void* stream, dfq_le_re
         rc = dfq_le_enqueue(p, cfg, cfg->max_sweeps >= 0 ? cfg->max_sweeps : (1 << 30), 1, stream);
         if (rc) return rc;
         rc = dfq_le_query(p, stream, &res, &done);
-        if (rc == DFQ_ERR_STATE) {
+        if (rc == DFQ_ERR_ABANDONED) {
             // A workgroup of the persistent launch gave up a wait (DFQ_SPIN_LIMIT: the chip was not the library's alone for seconds,
             // or the dispatch the in-launch waits count on did not happen).  The launch stores all or nothing (dfq_le_resident.hip,
             // "all or nothing"): if no tile stored, the network is exactly as the caller passed it, and the pass is simply run
@@ -3261,6 +3273,7 @@ int dfq_le_run(dfq_le_plan* p, const dfq_le_config* cfg, void* stream, dfq_le_re
             if (le_resident_stored_tiles(p->resident, as_stream(stream), &stored) != DFQ_OK || stored != 0) return rc;
             p->resident_off = true;
             p->merged = false;
+            p->sweep_grid = 0;                   // (the persistent-workgroup variant of the sweep walks the WHOLE table: per-level launches are le_level_kernel's)
             p->degraded += 1;
             p->resident_why = "an in-launch wait of the persistent launch was abandoned (nothing had been stored): this plan now runs one launch per level";
             streamed = true;

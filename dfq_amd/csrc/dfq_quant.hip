@@ -639,7 +639,7 @@ int dfq_quant_measure_fused_status(const uint32_t* scratch, int32_t n_samples, v
     unsigned long long err = 0;
     DFQ_HIP_TRY(hipMemcpyAsync(&err, (const unsigned long long*)(scratch + 4 * (size_t)n_samples) + 1, sizeof(err), hipMemcpyDeviceToHost, st));
     DFQ_HIP_TRY(hipStreamSynchronize(st));
-    if (err) { set_error("dfq_quant_measure_fused: a workgroup gave up waiting for the rest of its grid (the output is invalid)"); return DFQ_ERR_STATE; }
+    if (err) { set_error("dfq_quant_measure_fused: a workgroup gave up waiting for the rest of its grid (the output is invalid)"); return DFQ_ERR_ABANDONED; }
     return DFQ_OK;
 }
 

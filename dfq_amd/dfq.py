@@ -45,6 +45,37 @@ def _le_config(s_range, converge_thres, converge_count, signed, eps, max_sweeps)
                             -1 if max_sweeps is None else int(max_sweeps))
 
 
+class _Snapshot:
+    """A device-side copy of the tensors a plan rewrites: taken in front of a run whose launches contain in-launch waits, put
+    back if a workgroup abandoned one (DFQ_ERR_ABANDONED) -- the pass is then repeated on launches that wait for nothing
+    (``*_set_safe_mode``).  One flat buffer per plan, allocated at the first run; two multi-tensor copies."""
+
+    def __init__(self, tensors):
+        seen, self.src = set(), []
+        for t in tensors:
+            if t is not None and t.numel() > 0 and t.data_ptr() not in seen:
+                seen.add(t.data_ptr())
+                self.src.append(t)
+        self.dst = None
+
+    def take(self):
+        if not self.src:
+            return
+        with torch.no_grad():
+            if self.dst is None:
+                flat = torch.empty(sum(t.numel() for t in self.src), dtype=self.src[0].dtype, device=self.src[0].device)
+                self.dst, off = [], 0
+                for t in self.src:
+                    self.dst.append(flat[off:off + t.numel()].view(t.shape))
+                    off += t.numel()
+            torch._foreach_copy_(self.dst, self.src)
+
+    def restore(self):
+        if self.src and self.dst is not None:
+            with torch.no_grad():
+                torch._foreach_copy_(self.src, self.dst)
+
+
 class LEPlan:
     """Device-side work list for cross-layer equalisation over a fixed set of layers/relations.
 
@@ -59,9 +90,11 @@ class LEPlan:
         independent networks: every launch then covers all of them, each with its own loop state."""
         self.stage = stage or _ffi.Stage()
         self._keep = []
+        self._mutable, self._snapshot, self.repeated = [], None, 0      # see run(): an abandoned in-launch wait is repeated, not raised
         if isinstance(layers, _Tables):                     # prebuilt struct arrays (build_le_plan_batch's fast path)
             t = layers
             self._keep, self.scale_cum = t.keep, t.scale_cum
+            self._mutable = list(t.mutable)
             self._plan = ctypes.c_void_p()
             if t.bases is not None:                         # one network's tables + a base address per network (arena.py)
                 self.n_layers, self.n_relations, self.n_nets = t.n_layers * len(t.bases), t.n_relations * len(t.bases), len(t.bases)
@@ -81,12 +114,14 @@ class LEPlan:
             e, keep = _layer_entry(self.stage, w, b, g)
             entries.append(e)
             self._keep.append(keep)
+            self._mutable.extend(keep)
         rels = []
         self.scale_cum = []
         for (i1, i2, bnw, bnb, scum) in relations:
             bw, bb = self.stage.bind(bnw), self.stage.bind(bnb)
             sc = self.stage.bind(scum)
             self._keep.append((bw, bb, sc))
+            self._mutable.extend((bw, bb, sc))
             self.scale_cum.append(sc)
             rels.append(_ffi.DfqRelation(int(i1), int(i2), bw.data_ptr() if bw is not None else None,
                                          bb.data_ptr() if bb is not None else None, sc.data_ptr()))
@@ -197,11 +232,44 @@ class LEPlan:
                     grid=(gx.value, gy.value))
 
     # -- execution -----------------------------------------------------------------------------
+    @property
+    def has_waits(self):
+        """True when a run of this plan can end abandoned AFTER tensors were rewritten: the streaming engine's one-launch sweep
+        (dfq_le_plan_has_waits; the persistent launch of a single network stores all or nothing and repeats itself)."""
+        return bool(_ffi.lib().dfq_le_plan_has_waits(self._plan))
+
+    def set_safe_mode(self):
+        """From now on one launch per dependency level: no workgroup waits for another one (dfq_le_plan_set_safe_mode)."""
+        _ffi.check(_ffi.lib().dfq_le_plan_set_safe_mode(self._plan))
+
     def run(self, s_range=(1e-8, 1e8), converge_thres=2e-7, converge_count=20, signed=False, eps=0,
-            max_sweeps=None):
+            max_sweeps=None, recover=True):
+        """The whole loop of dfq.py:83-115; synchronises once.
+
+        ``recover`` (default): a run that comes back with DFQ_ERR_ABANDONED -- a workgroup gave up a bounded in-launch wait
+        (DFQ_SPIN_LIMIT: the chip was not the library's for seconds, or the dispatch order the waits count on did not hold) --
+        is REPEATED instead of raised: the tensors the plan rewrites (weights, biases, BN proxies, cumulative scales: the
+        caller's own tensors when they live on the device, the stage's shadows otherwise) are put back from a device-side copy
+        taken in front of the run, the plan switches to one launch per dependency level for good (``set_safe_mode``: nothing
+        waits, nothing can be abandoned) and the pass runs again.  ``repeated`` counts it.  The copy is only taken for plans
+        whose launches contain in-launch waits and store as they go (``has_waits``); ``enqueue`` never takes one."""
         cfg = _le_config(s_range, converge_thres, converge_count, signed, eps, max_sweeps)
         res = _ffi.DfqLeResult()
-        _ffi.check(_ffi.lib().dfq_le_run(self._plan, ctypes.byref(cfg), _ffi.stream_arg(), ctypes.byref(res)))
+        guard = recover and self.has_waits
+        if guard:
+            if self._snapshot is None:
+                self._snapshot = _Snapshot(self._mutable)
+            self._snapshot.take()
+        try:
+            _ffi.check(_ffi.lib().dfq_le_run(self._plan, ctypes.byref(cfg), _ffi.stream_arg(), ctypes.byref(res)))
+        except _ffi.DfqError as exc:
+            if not (guard and exc.code == _ffi.ERR_ABANDONED):
+                raise
+            self._snapshot.restore()
+            self.set_safe_mode()
+            self.repeated += 1
+            degraded_runs['le'] += 1
+            _ffi.check(_ffi.lib().dfq_le_run(self._plan, ctypes.byref(cfg), _ffi.stream_arg(), ctypes.byref(res)))
         return dict(sweeps=res.sweeps, stall_count=res.stall_count, diff=res.diff, last_diff_tmp=res.last_diff_tmp)
 
     def enqueue(self, n_sweeps, restart=True, s_range=(1e-8, 1e8), converge_thres=2e-7, converge_count=20,
@@ -337,6 +405,7 @@ class _Tables:
         self.arrays = {}
         self.keep = []
         self.scale_cum = []
+        self.mutable = []           # every tensor a run of the plan may rewrite (LEPlan / BCPlan snapshots)
         self.bases = None           # uint64 array: the tables describe the first of len(bases) networks (arena.py)
 
     def ptr(self, name, ctype):
@@ -482,6 +551,7 @@ def _fast_le_tables(items, targ_type, dev):
         rel['bn_bias'][fb_row] = ptr[fb_pos]
     T.arrays['layers'], T.arrays['relations'], T.arrays['layer_net'] = lay, rel, _np.concatenate(net_of)
     T.n_layers, T.n_relations, T.n_nets = n_lay, n_rel, len(items)
+    T.mutable = tens
     return T
 
 
@@ -604,6 +674,8 @@ def _fast_bc_tables(items, targ_type, bn_type, dev):
     src['fake_bias'][sb_row] = ptr[sb_pos]
     T.arrays['layers'], T.arrays['steps'], T.arrays['sources'] = lay, stp, src
     T.n_layers, T.n_steps, T.n_sources = n_lay, n_stp, n_src
+    weights = set(w_pos)
+    T.mutable = [t for i, t in enumerate(tens) if i not in weights]      # the correction rewrites biases and BN proxies, never a weight
     return T
 
 
@@ -833,40 +905,12 @@ _le_plan_cache = OrderedDict()
 _bc_plan_cache = OrderedDict()
 _cache_lock = _threading.RLock()
 plan_cache_stats = {'le_hits': 0, 'le_misses': 0, 'bc_hits': 0, 'bc_misses': 0}
-# Drop-in calls that were REPEATED on launches without in-launch waits after a workgroup of the one-launch kernels gave up a wait
-# (DFQ_SPIN_LIMIT): see _pristine_on_host / _no_in_launch_waits.  0 in normal operation.
+# Runs that were REPEATED on launches without in-launch waits after a workgroup of the one-launch kernels gave up a wait
+# (DFQ_SPIN_LIMIT): LEPlan.run / BCPlan.run put the tensors back from their device-side snapshot, switch the plan to its safe mode
+# (an explicit plan flag, dfq_*_plan_set_safe_mode) and run again.  0 in normal operation.
 degraded_runs = {'le': 0, 'bc': 0}
 
 
-def _pristine_on_host(stage, tensors):
-    """After an abandoned in-launch wait the device copies of a network are undefined.  The caller's OWN tensors are a pristine
-    copy exactly when they live on the host (the reference's default flow, main_cls.py:149-181 on a CPU model): the engine worked
-    on shadows, and nothing is written back before a run has succeeded.  Not inside a staging() scope -- there the device copies
-    are the truth between calls and the host values are stale."""
-    if stage._scoped:
-        return False
-    dev = _ffi.target_device()
-    ts = [t for t in tensors if t is not None]
-    return bool(ts) and all(t.device != dev for t in ts)
-
-
-class _no_in_launch_waits:
-    """Plans built inside this block use one launch per level / per chain position (DFQ_LE_RESIDENT=0, DFQ_LE_MERGED=0,
-    DFQ_BC_MERGED=0: read by the library when a plan is created; modes that are parity-tested since round 1): no workgroup waits
-    for another one, so there is nothing to abandon.  Entered under _cache_lock."""
-    _KEYS = {'DFQ_LE_RESIDENT': '0', 'DFQ_LE_MERGED': '0', 'DFQ_BC_MERGED': '0'}
-
-    def __enter__(self):
-        self._old = {k: _os.environ.get(k) for k in self._KEYS}
-        _os.environ.update(self._KEYS)
-
-    def __exit__(self, *exc):
-        for k, v in self._old.items():
-            if v is None:
-                _os.environ.pop(k, None)
-            else:
-                _os.environ[k] = v
-        return False
 # every environment switch the library reads while it CREATES a plan (tests/test_errors.py checks this list against the sources)
 _PLAN_ENV = ('DFQ_LE_RESIDENT', 'DFQ_LE_MERGED', 'DFQ_LE_TILE_ELEMS', 'DFQ_LE_ROW_COLS', 'DFQ_LE_COL_COLS', 'DFQ_LE_BOOT_WORK',
              'DFQ_LE_PERSIST', 'DFQ_LE_SWEEP_WGS', 'DFQ_LE_EMIT_COLS', 'DFQ_LE_NO_SHORT', 'DFQ_LE_CHAIN_FIRST', 'DFQ_LE_POLL_NAPS',
@@ -1013,23 +1057,9 @@ def cross_layer_equalization(graph, relations, targ_type, s_range=[1e-8, 1e8], r
                 _cache_drop(_le_plan_cache, key)      # an abandoned in-launch wait: the plan's state (and the device copies) are undefined
             else:
                 plan.close()
-            touched = [x for k in graph if type(graph[k]) in targ_type for x in (graph[k].weight, graph[k].bias)]
-            touched += [getattr(graph[rr.get_idxs()[2]], n, None) for rr in relations if rr.get_idxs()[2] is not None
-                        for n in ('fake_weight', 'fake_bias')]
-            if not (isinstance(exc, _ffi.DfqError) and 'gave up' in str(exc) and _pristine_on_host(stage, touched)):
-                raise
-            # (the persistent launch of a network that fits the chip never gets here: it stores all or nothing and dfq_le_run
-            # repeats the pass itself.  This is the streaming engine's one-launch-per-sweep mode on a host-resident model.)
-            with _no_in_launch_waits():
-                stage = _ffi.Stage()                  # fresh device copies of the caller's untouched tensors
-                plan = build_le_plan(graph, relations, targ_type, stage=stage)
-            key = None
-            degraded_runs['le'] += 1
-            try:
-                res = plan.run(s_range=s_range, converge_thres=converge_thres, converge_count=converge_count,
-                               signed=signed, eps=eps, max_sweeps=max_sweeps)
-            finally:
-                plan.close()
+            # (an abandoned in-launch wait never gets here: the persistent launch stores all or nothing and dfq_le_run repeats the
+            # pass itself; the streaming engine's one-launch sweeps are repeated by LEPlan.run from its device-side snapshot)
+            raise
         else:
             if key is None:
                 plan.close()
@@ -1106,9 +1136,11 @@ class BCPlan:
         (network by network) the j-th steps of all networks share one launch."""
         self.stage = stage or _ffi.Stage()
         self._keep = []
+        self._mutable, self._snapshot, self.repeated = [], None, 0      # see run(check=True)
         if isinstance(layers, _Tables):                     # prebuilt struct arrays (build_bc_plan_batch's fast path)
             t = layers
             self._keep = t.keep
+            self._mutable = list(t.mutable)
             self.n_steps = t.n_steps
             self.step_out_ch, self.step_in = t.step_out_ch, t.step_in
             self._plan = ctypes.c_void_p()
@@ -1130,6 +1162,7 @@ class BCPlan:
             e, keep = _layer_entry(self.stage, w, b, g)
             entries.append(e)
             self._keep.append(keep)
+            self._mutable.append(keep[1])
         src_arr, step_arr = [], []
         steps = [tuple(st) + (0,) if len(st) == 3 else tuple(st) for st in steps]
         for (li, srcs, nxt, net) in steps:
@@ -1141,6 +1174,7 @@ class BCPlan:
                                                 int(dfb.numel()), int(bool(relu)), int(bool(concat))))
             dn = self.stage.bind(nxt)
             self._keep.append(dn)
+            self._mutable.append(dn)
             step_arr.append(_ffi.DfqBcStep(int(li), begin, len(srcs), dn.data_ptr() if dn is not None else None,
                                            int(net), 0))
         self.n_steps = len(step_arr)
@@ -1161,12 +1195,39 @@ class BCPlan:
     def eps_elements(self):
         return _ffi.lib().dfq_bc_plan_eps_elements(self._plan)
 
-    def run(self, signed=False, check=False):
-        """Enqueue the whole correction (asynchronous).  ``check`` synchronises and raises if a workgroup of the
-        one-launch chain gave up waiting for the step it depends on."""
+    @property
+    def has_waits(self):
+        """True when the chain runs as one launch whose workgroups wait for each other (dfq_bc_plan_has_waits)."""
+        return bool(_ffi.lib().dfq_bc_plan_has_waits(self._plan))
+
+    def set_safe_mode(self):
+        """From now on one launch per chain position: nothing waits, nothing can be abandoned (dfq_bc_plan_set_safe_mode)."""
+        _ffi.check(_ffi.lib().dfq_bc_plan_set_safe_mode(self._plan))
+
+    def run(self, signed=False, check=False, recover=True):
+        """Enqueue the whole correction (asynchronous).  ``check`` synchronises; with ``recover`` (default) a run in which a
+        workgroup of the one-launch chain gave up its wait (DFQ_ERR_ABANDONED) is then REPEATED instead of raised: biases and BN
+        proxies go back to a device-side copy taken in front of the run, the plan switches to one launch per chain position for
+        good (``set_safe_mode``) and the correction runs again (``repeated`` counts it).  Without ``check`` nothing is copied
+        and an abandoned run surfaces at the next ``status()``."""
+        guard = check and recover and self.has_waits
+        if guard:
+            if self._snapshot is None:
+                self._snapshot = _Snapshot(self._mutable)
+            self._snapshot.take()
         _ffi.check(_ffi.lib().dfq_bc_plan_run(self._plan, int(bool(signed)), _ffi.stream_arg()))
         if check:
-            self.status()
+            try:
+                self.status()
+            except _ffi.DfqError as exc:
+                if not (guard and exc.code == _ffi.ERR_ABANDONED):
+                    raise
+                self._snapshot.restore()
+                self.set_safe_mode()
+                self.repeated += 1
+                degraded_runs['bc'] += 1
+                _ffi.check(_ffi.lib().dfq_bc_plan_run(self._plan, int(bool(signed)), _ffi.stream_arg()))
+                self.status()
 
     @property
     def tagged(self):
@@ -1362,19 +1423,7 @@ def bias_correction(graph, bottoms, targ_type, bits_weight=8, bn_type=torch.nn.B
                 _cache_drop(_bc_plan_cache, key)
             else:
                 plan.close()
-            touched = [x for (w, b, g) in layers for x in (w, b)] + [x for st in steps for (fw, fb, relu, concat) in st[1] for x in (fw, fb)] + \
-                      [st[2] for st in steps]
-            if not (isinstance(exc, _ffi.DfqError) and 'gave up' in str(exc) and _pristine_on_host(stage, touched)):
-                raise
-            with _no_in_launch_waits():               # one launch per chain position, from the caller's untouched (host) tensors
-                stage = _ffi.Stage()
-                plan = BCPlan(layers, steps, stage=stage)
-            key = None
-            degraded_runs['bc'] += 1
-            try:
-                plan.run(signed=signed, check=True)
-            finally:
-                plan.close()
+            raise                                     # (an abandoned wait of the one-launch chain was already repeated by BCPlan.run)
         else:
             if key is None:
                 plan.close()

@@ -42,6 +42,8 @@ extern "C" {
 #define DFQ_ERR_ARG (-1)     /* invalid argument / unsupported geometry            */
 #define DFQ_ERR_HIP (-2)     /* a HIP runtime call failed (message has the details) */
 #define DFQ_ERR_STATE (-3)   /* object used in the wrong state                      */
+#define DFQ_ERR_ABANDONED (-4) /* a workgroup gave up a bounded in-launch wait (DFQ_SPIN_LIMIT): the tensors the run
+                                  rewrites are undefined unless the entry point says otherwise; see *_set_safe_mode */
 
 int dfq_version(void);
 const char* dfq_last_error(void);
@@ -182,6 +184,13 @@ const char* dfq_le_plan_resident_reason(const dfq_le_plan* plan);
  * dfq_le_plan_resident_reason says why).  Number of runs of this plan that were repeated that way (0 in normal operation).
  * The reference's loop (dfq.py:78-117) has no counterpart: it cannot fail half way. */
 int32_t dfq_le_plan_degraded(const dfq_le_plan* plan);
+/* Launches of the streaming engine in which workgroups wait for other workgroups (the one-launch sweep): 1 if a run of this
+ * plan can end with DFQ_ERR_ABANDONED after having rewritten tensors (the persistent launch stores all or nothing and is not
+ * counted).  dfq_le_plan_set_safe_mode: from now on the plan runs one launch per dependency level -- no workgroup waits for
+ * another one, nothing can be abandoned (parity-tested since round 1, slower) -- and never the persistent launch.  The Python
+ * binding's LEPlan.run() uses the pair to repeat an abandoned pass from a device-side snapshot of the tensors (dfq_amd/dfq.py). */
+int32_t dfq_le_plan_has_waits(const dfq_le_plan* plan);
+int dfq_le_plan_set_safe_mode(dfq_le_plan* plan);
 /* The resident launch applies every sweep to its LDS tiles AT ONCE and learns only later (from a reducer workgroup, off every
  * dependency chain) whether dfq.py:105-115 let that sweep happen: a tile may be up to `spec` sweeps past the stopping point
  * and then restores the newest of its checkpoints and replays the logged per-channel factors (bit-identical: the same two
@@ -413,6 +422,12 @@ int64_t dfq_bc_plan_weight_elements(const dfq_bc_plan* plan);
 /* 1 when the one-launch chain hands values from step to step as tagged 64-bit slots (the default), 0 when it uses per-step
  * counters (DFQ_BC_TAGGED=0, or a graph the tagged scheme does not cover) or one launch per chain position. */
 int32_t dfq_bc_plan_tagged(const dfq_bc_plan* plan);
+/* 1 if the correction chain runs as ONE launch whose workgroups wait for each other (dfq_bc_plan_status can then report
+ * DFQ_ERR_ABANDONED after biases / BN proxies have been rewritten).  dfq_bc_plan_set_safe_mode: one launch per chain position
+ * from now on -- nothing waits, nothing can be abandoned (the parity-tested DFQ_BC_MERGED=0 path).  BCPlan.run() of the Python
+ * binding uses the pair to repeat an abandoned pass from a device-side snapshot. */
+int32_t dfq_bc_plan_has_waits(const dfq_bc_plan* plan);
+int dfq_bc_plan_set_safe_mode(dfq_bc_plan* plan);
 /* 1 when the LATEST run of the plan used the tagged slots, 0 when it used counters (a run recorded into a graph) or has not run.
  * A run on the NULL stream is an ordinary run (until round 5 it was mistaken for a recording: counters, no guard). */
 int32_t dfq_bc_plan_last_run_tagged(const dfq_bc_plan* plan);

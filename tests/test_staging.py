@@ -205,3 +205,24 @@ def test_per_call_users_do_not_join_the_scope():
     for x, y in zip(xs, b[2]):
         assert torch.equal(x, y)                                  # inputs untouched when the scope ended
     assert torch.equal(a[3], b[3])
+
+
+@pytest.mark.gpu
+def test_weight_mutating_helpers_inside_a_scope_work_on_the_scope_copy():
+    """`_layer_equalization` (and the other helpers with a private stage: merge_scale_into_layer, the single-step
+    primitives) called INSIDE `with staging():` on tensors an entry point of the scope has already shadowed must read the
+    scope's device copy -- the truth between the calls of a scope -- and what they write must survive the scope's write-back.
+    Equal, bit for bit, to the same sequence of calls without a scope."""
+    def run(scoped):
+        model, graph, bottoms, rels = _cpu_model()
+        a, b, kb = rels[0].get_idxs()
+        import contextlib
+        with (dfq_amd.staging() if scoped else contextlib.nullcontext()):
+            dfq.cross_layer_equalization(graph, rels, TARG, max_sweeps=2, converge_thres=-1.0, converge_count=10 ** 9)
+            # a helper with a stage of its own, on tensors the entry point above has shadowed (and rewritten on the device)
+            dfq._layer_equalization(graph[a].weight, graph[b].weight, graph[a].bias)
+            dfq.bias_correction(graph, bottoms, TARG)
+        return snapshot(graph)
+    want, got = run(False), run(True)
+    for k in want:
+        assert_bitexact(got[k], want[k], k)
