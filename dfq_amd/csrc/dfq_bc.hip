@@ -847,6 +847,13 @@ __global__ __launch_bounds__(kBlock) void bc_step_kernel(BcStepDev st_inline, co
 // the chain's positions -- the blocks of the layers a position needs lie a few positions in front of it in the grid -- so a step
 // waits only for blocks with lower indices (no deadlock), the large late layers are reduced while the chain's early positions
 // hand over (a phase that leaves the memory system idle), and the launch boundary between the two kernels is gone.
+// INVARIANT of everything that is handed over behind these arrival counters (and behind the chain's own step counters, BcDep): the
+// producer writes it with device-scope atomics (the min / max merges, the cached moments) or sc1 stores and orders it before its
+// arrival with s_waitcnt(0) only; the consumer polls with relaxed device-scope loads and reads the payload through mm_slot /
+// ld_shared_f32 (device-scope loads).  There is NO release / acquire pair: a release would write back the XCD's whole L2 per block and
+// an acquire invalidate it per poll (0.98 instead of 0.41 ms for a batch).  A PLAIN load or store added on this path would be wrong
+// across XCDs -- silently, and invisibly to the CPU emulation (its atomics are sequentially consistent): keep every access on these
+// helpers.  tests/test_engine_parity.py::test_one_launch_correction_under_stress repeats one-launch runs with the look-ahead at 0.
 struct BcFusedMm {
     const BcLayerDev* layers;
     const int32_t* block_begin;
@@ -1279,8 +1286,9 @@ int dfq_bc_plan_create(const dfq_layer* layers, int32_t n_layers, const dfq_bc_s
         if ((e = hipMemcpy(p->d_refs, refs.data(), sizeof(BcChainRef) * refs.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail_alloc(e);
         // ---- one-launch correction: the same table with the min/max blocks woven in.  The blocks of the layers that chain position
         //      P needs (its steps' own layers and the depthwise layers folded into them) lie `ahead` positions in front of P's
-        //      workgroups; the first `ahead` positions' blocks open the grid.  Not for plans that read a never-rewritten BN through
-        //      a ReLU (its cached moment is refreshed by the min/max LAUNCH's trailing workgroups) or keep the eps matrices. ----
+        //      workgroups; the first `ahead` positions' blocks open the grid.  A never-rewritten BN read through a ReLU is covered
+        //      too: its cached moment is refreshed by the launch's first blocks and its readers wait for them (wait_cache /
+        //      cache_arrive, the step == -2 blocks below).  Not for plans that keep the eps matrices. ----
         {
             // Default: for a BATCH only.  Measured (tools/gpu_r05_bench_env_ab.sh, two alternating rounds): the batch of 32 0.410-0.415 ->
             // 0.375-0.379 ms -- its large late layers are reduced while the early positions hand over -- but ONE network 0.1265 -> 0.131-

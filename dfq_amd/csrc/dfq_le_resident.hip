@@ -31,10 +31,14 @@
 // All workgroups of the launch must be resident at once (they wait for each other in cycles over the sweeps): the launch is
 // cooperative (the runtime guarantees co-residency or refuses; the plan additionally refuses networks beyond three quarters
 // of the occupancy limit and the caller then streams), the library never runs two kernels with in-launch waits concurrently
-// (SpinGuard), every wait is bounded (DFQ_SPIN_LIMIT), and a workgroup that abandons a wait stores nothing.  After an
-// abandoned wait the run reports DFQ_ERR_STATE and the network is UNDEFINED as a whole (some tiles may already have stored
-// their result when another one gives up in the last verdict): the caller reloads the weights; the drop-in entry points drop
-// the cached plan.  Results are bit-identical to the streaming kernel and to the oracle (same IEEE operations; min/max exact).
+// (SpinGuard), every wait is bounded (DFQ_SPIN_LIMIT), and the launch stores ALL OR NOTHING: a tile writes its result back only
+// once every tile has finished the loop, so after an abandoned wait (reported as DFQ_ERR_ABANDONED by the query) the network is
+// exactly as the caller passed it -- le_resident_stored_tiles == 0 -- and dfq_le_run repeats the pass at once on one launch per
+// level (dfq_le.hip; the plan stays there, dfq_le_plan_degraded).  The one case that still leaves an undefined network is a
+// give-up inside that last "every tile has finished" wait itself (some tiles stored, others did not: DFQ_ERR_STATE; that wait is
+// at least 200 000 polls patient whatever the limit says).  Since round 5 the launch is an ordinary one by default
+// (DFQ_COOPERATIVE=1 restores the cooperative launch).  Results are bit-identical to the streaming kernel and to the oracle
+// (same IEEE operations; min/max exact).
 #include <algorithm>
 #include <cstring>
 #include <string>

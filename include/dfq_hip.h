@@ -432,8 +432,9 @@ int dfq_bc_plan_set_safe_mode(dfq_bc_plan* plan);
  * A run on the NULL stream is an ordinary run (until round 5 it was mistaken for a recording: counters, no guard). */
 int32_t dfq_bc_plan_last_run_tagged(const dfq_bc_plan* plan);
 /* 1 when a tagged run of the plan is ONE launch: the per-tensor min/max blocks are workgroups of the chain launch, woven in a few chain
- * positions in front of the steps that need them (DFQ_BC_ONE_LAUNCH=0, a kept eps matrix, rows too long for the registers or a
- * never-rewritten BN read through a ReLU: min/max launch + chain launch). */
+ * positions in front of the steps that need them (DFQ_BC_ONE_LAUNCH=0, a kept eps matrix or rows too long for the registers:
+ * min/max launch + chain launch).  A never-rewritten BN read through a ReLU does NOT prevent it: the cached moments of such BNs are
+ * refreshed by the launch's first blocks and their readers wait for those blocks (cache_arrive). */
 int32_t dfq_bc_plan_one_launch(const dfq_bc_plan* plan);
 /* Diagnostics.  A library built with -DDFQ_BC_TRACE=1 (tools/bc_trace.py) records five timestamps per workgroup of the one-launch
  * chain; this copies up to `words` 64-bit words of them to `out` and returns the number copied -- 0 from the shipped library. */

@@ -1537,3 +1537,55 @@ def test_one_launch_correction_is_invisible(engine, monkeypatch, setting):
             results[variant] = first
         for k, v in results['default'].items():
             assert_bitexact(v, results[setting][k], '{} {} ({} vs default)'.format(name, k, setting))
+
+
+@pytest.mark.gpu
+def test_one_launch_correction_under_stress(monkeypatch):
+    """everything handed over behind the arrival counters of the one-launch correction is written with
+    device-scope atomics / sc1 stores and read with device-scope loads -- no release / acquire pair (BcFusedMm, dfq_bc.hip) -- an
+    invariant only the hardware can check (the CPU emulation's atomics are sequentially consistent).  A full-size batch, the
+    look-ahead at 0 (the steps find their layer's min/max blocks directly in front of them: every hand-over is as late as it can be),
+    forty runs: every run must leave the bits of the two-launch correction."""
+    from dfq_amd import synthetic
+    dev = torch.device('cuda', 0)
+
+    def batch():
+        nets = []
+        for seed in range(4):
+            model, graph, bottoms = synthetic.build('mobilenet_v2', seed=seed)
+            synthetic.relu6_to_relu(model)
+            model.to(dev)
+            lt.merge_batchnorm(model, graph, bottoms, TARG)
+            nets.append((model, graph, bottoms))
+        return nets
+
+    def run(nets, reps):
+        bc = dfq.build_bc_plan_batch([(g, b) for (_, g, b) in nets], TARG)
+        saved = [[(m.bias.clone() if getattr(m, 'bias', None) is not None else None, getattr(m, 'fake_bias', None).clone() if hasattr(m, 'fake_bias') else None)
+                  for m in g.values() if not isinstance(m, str)] for (_, g, _) in nets]
+        outs = []
+        for _ in range(reps):
+            with torch.no_grad():
+                for (_, g, _), sv in zip(nets, saved):
+                    for m, (b, fb) in zip([m for m in g.values() if not isinstance(m, str)], sv):
+                        if b is not None:
+                            m.bias.copy_(b)
+                        if fb is not None:
+                            m.fake_bias.copy_(fb)
+            bc.run(check=True, recover=False)
+            outs.append([snapshot(g) for (_, g, _) in nets])
+        one = bc.one_launch
+        bc.close()
+        return outs, one
+
+    monkeypatch.setenv('DFQ_BC_ONE_LAUNCH', '0')
+    (want,), one = run(batch(), 1)
+    assert not one
+    monkeypatch.delenv('DFQ_BC_ONE_LAUNCH')
+    monkeypatch.setenv('DFQ_BC_MM_AHEAD', '0')
+    outs, one = run(batch(), 40)
+    assert one
+    for rep, got in enumerate(outs):
+        for a, b in zip(got, want):
+            for k in b:
+                assert_bitexact(a[k], b[k], 'run {}: {}'.format(rep, k))
