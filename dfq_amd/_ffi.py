@@ -441,8 +441,10 @@ class Stage:
         MobileNetV2 is ~250 tensors; one synchronous copy each way per tensor was 40-150 ms per entry point, packed it is the
         14 MB over PCIe plus two host memcpys.  Later bind() calls find the tensors bound."""
         todo, seen = [], set()
+        amb = getattr(_ambient, 'stage', None)
+        amb_bound = amb._bound if (amb is not None and amb is not self) else {}
         for t in tensors:
-            if t is None or id(t) in self._bound or id(t) in seen:
+            if t is None or id(t) in self._bound or id(t) in seen or id(t) in amb_bound:      # (the scope's copy is the truth: bind())
                 continue
             if t.device == self.device and t.dtype == torch.float32 and t.is_contiguous():
                 continue

@@ -1514,6 +1514,9 @@ int32_t dfq_bc_plan_has_waits(const dfq_bc_plan* p) { return (p && p->merged && 
 int dfq_bc_plan_set_safe_mode(dfq_bc_plan* p) {
     if (!p) return fail_arg("dfq_bc_plan_set_safe_mode: null plan");
     p->merged = false;
+    // the error word of an abandoned chain launch is none of the per-position launches' (they have no waits and do not clear it)
+    DFQ_HIP_TRY(hipMemset(p->d_counters + (size_t)p->n_steps * kBcDepStride, 0, sizeof(uint32_t)));
+    p->last_tagged = false;
     return DFQ_OK;
 }
 int32_t dfq_bc_plan_last_run_tagged(const dfq_bc_plan* p) { return (p && p->last_tagged) ? 1 : 0; }

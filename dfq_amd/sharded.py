@@ -398,7 +398,7 @@ class ShardedEqualizer:
         return sweeps
 
     #: sweeps per chunk of the data-dependent mode: one collective and one host read per chunk (DFQ_SHARD_CHUNK)
-    CHUNK = 8
+    CHUNK = 12
 
     def _run_data_dependent(self, session, converge_thres, converge_count):
         """The reference's own stopping rule (dfq.py:83-115) over the ranks' summed mean|dW| WITHOUT a host round trip per sweep.
