@@ -15,6 +15,13 @@ def staging():
     return _ffi.staging()
 
 
+def release_staging():
+    """Drop the device copies (and the references to the caller's tensors) that the drop-in entry points keep of the last
+    CPU-resident model they calibrated, so that consecutive plain calls transfer it once (``_ffi.persistent_stage``)."""
+    from . import _ffi
+    _ffi.release_staging()
+
+
 def pool_trim():
     """Return the device blocks that destroyed plans parked in the library's free lists to the driver (``dfq_pool_trim``);
     the number of bytes released.  For a process that needs the memory for something else: torch's allocator cannot see them."""

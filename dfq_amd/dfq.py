@@ -953,8 +953,8 @@ def _cache_put(cache, key, value):
     # from tensors that are alive at that moment (same addresses, same shapes); its own buffers stay with it
     plan = value[0]
     plan._keep = []
-    if plan.stage._scoped:
-        plan.stage = _ffi.Stage()         # the scope's stage belongs to the scope (and goes with it): a private one for the helpers
+    if plan.stage._scoped or plan.stage._persistent:
+        plan.stage = _ffi.Stage()         # the scope's (or the thread's persistent) stage is not the plan's: a private one for the helpers
     else:
         plan.stage._bound = {}
     cache[key] = value
@@ -1427,4 +1427,4 @@ def bias_correction(graph, bottoms, targ_type, bits_weight=8, bn_type=torch.nn.B
         else:
             if key is None:
                 plan.close()
-        stage.writeback()
+        stage.writeback(unchanged=[w for (w, b, g) in layers])      # the correction rewrites biases and BN proxies, never a weight

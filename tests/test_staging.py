@@ -114,7 +114,7 @@ def test_scopes_join_and_clean_up(engine):
         assert _ffi.scoped_stage() is outer        # the inner scope did not end the outer one
         assert _ffi.entry_stage() is outer         # what a calibration entry point takes ...
         assert _ffi.Stage() is not outer           # ... and what a per-call user (QuantMeasure, quantize, prims) takes
-    assert _ffi.scoped_stage() is None
+    assert _ffi.scoped_stage() is _ffi.persistent_stage()      # outside a scope: the thread's persistent stage (round 6), or None
     assert _ffi.entry_stage() is not outer
 
 
@@ -226,3 +226,46 @@ def test_weight_mutating_helpers_inside_a_scope_work_on_the_scope_copy():
     want, got = run(False), run(True)
     for k in want:
         assert_bitexact(got[k], want[k], k)
+
+
+@pytest.mark.gpu
+def test_plain_calls_share_device_copies_and_see_host_side_writes():
+    """the reference's own sequence of plain calls on a CPU-resident model (main_cls.py:149-188:
+    merge_batchnorm -> cross_layer_equalization -> bias_correction -> quantize_targ_layer) transfers the network ONCE -- the
+    thread's persistent stage keeps the device shadows of the previous call, keyed on every tensor's (_version, data_ptr) -- while
+    every call still leaves its results in the caller's tensors.  A host-side write between two calls (an in-place op, a new
+    storage) must be seen by the next call; the result equals the same calls with the persistent stage switched off."""
+    def run(persist, mutate):
+        _ffi.release_staging()
+        old = _ffi._PERSIST
+        _ffi._PERSIST = persist
+        try:
+            model, graph, bottoms = synthetic.build('tiny_mobile', seed=0)
+            lt.merge_batchnorm(model, graph, bottoms, TARG)
+            rels = rel.create_relation(graph, bottoms, TARG, delete_single=False)
+            uploads = []
+            st = _ffi.persistent_stage()
+            n0 = len(st._packs) if st is not None else 0
+            dfq.cross_layer_equalization(graph, rels, TARG)
+            first = next(m for m in graph.values() if type(m) in TARG)
+            after_le = first.weight.detach().clone()                      # the call left its result on the host
+            if mutate:
+                with torch.no_grad():
+                    first.weight.mul_(1.5)                                 # an in-place write: _version moves
+                    last = [m for m in graph.values() if type(m) in TARG][-1]
+                    last.bias.data = last.bias.data.clone() + 0.25        # a new storage: data_ptr moves
+            dfq.bias_correction(graph, bottoms, TARG)
+            if st is not None:
+                uploads = len(st._packs) - n0
+            lt.quantize_targ_layer(graph, 8, 16, TARG)
+            return snapshot(graph), after_le, uploads
+        finally:
+            _ffi._PERSIST = old
+            _ffi.release_staging()
+    for mutate in (False, True):
+        want, le_w, _ = run(False, mutate)
+        got, le_g, uploads = run(True, mutate)
+        assert torch.equal(le_w, le_g)
+        for k in want:
+            assert_bitexact(got[k], want[k], '{} (mutate={})'.format(k, mutate))
+        assert uploads == 0, 'the equalisation and the correction found the shadows merge_batchnorm had made: no new pack'
