@@ -42,7 +42,7 @@ def test_two_ranks_weak_scaling_line():
         assert sh['components'] >= 2
         # the reference's own stopping rule across ranks: one all_reduce per sweep + the final all_gather
         assert sh['data_dependent_ms'] > 0 and sh['data_dependent_sweeps'] >= 1
-        assert sh['data_dependent_collectives_per_pass'] == sh['data_dependent_sweeps'] + 1
+        assert sh['data_dependent_collectives_per_pass'] == -(-sh['data_dependent_sweeps'] // sh['data_dependent_chunk']) + 1   # one all_reduce per chunk of sweeps (sharded.py) + the all_gather
 
 
 def test_bench_line_contract_single_rank():
