@@ -519,8 +519,10 @@ def distill_range_pass(net, shape, n_batches, dev):
 # ---------------------------------------------------------------------------------------------------
 def pcie_inclusive_pass(net, reps=3):
     """main_cls.py:149-181 with the model where the reference keeps it -- on the CPU: every entry point shadows the tensors it
-    touches with device copies and writes them back (dfq_amd._ffi.Stage), and builds its plan per call (CPU tensors are not
-    cached).  Wall time of cross_layer_equalization + bias_correction, H2D / D2H and host work included.  Never `value`."""
+    touches with device copies and writes its results back (dfq_amd._ffi.Stage).  Since round 6 the shadows outlive the call
+    (the thread's persistent stage: consecutive plain calls transfer the network once, find their plans in the cache and bring
+    back only what they rewrote).  Wall time of cross_layer_equalization + bias_correction, transfers and host work included.
+    Never `value`."""
     from dfq_amd import dfq, synthetic
     from dfq_amd.utils import layer_transform as lt
     from dfq_amd.utils import relation as rel
@@ -561,8 +563,10 @@ def pcie_inclusive_pass(net, reps=3):
     n_w = sum(m.weight.numel() for m in graph.values() if type(m) in TARG)
     best.update({'net': net, 'weights': n_w, 'weights_per_s': n_w / (best['le_plus_bc_ms'] * 1e-3),
                  'le_plus_bc_in_one_staging_scope_ms': scoped,
-                 'what': 'CPU-resident {}: cross_layer_equalization + bias_correction through the drop-in entry points, wall time '
-                         'incl. H2D / D2H of every tensor, plan building and synchronisation (best of {}); '
+                 'what': 'CPU-resident {}: cross_layer_equalization + bias_correction through PLAIN calls of the drop-in entry points '
+                         '(no staging() scope), wall time incl. transfers, host work and synchronisation (best of {}); the device copies '
+                         'merge_batchnorm made are found again by the two calls (persistent stage, keyed on every tensor\'s _version / '
+                         'data_ptr), each call writes back what it rewrote; '
                          'le_plus_bc_in_one_staging_scope_ms: the same two calls inside `with dfq_amd.staging():` (one transfer each '
                          'way, plans from the cache after the first model)'.format(net, reps)})
     return best

@@ -407,7 +407,7 @@ def release_staging():
     """Drop the persistent stage's device copies (and its references to the caller's tensors)."""
     st = getattr(_ambient, 'persist', None)
     if st is not None:
-        st.reset()
+        st.reset(keep_buffers=False)
 
 
 def scoped_stage():
@@ -465,6 +465,9 @@ class Stage:
         # moment the shadow and the caller's tensor last held the same values
         self._persistent = False
         self._seen = {}
+        self._touched = set()
+        self._spare = {}
+        self._whole = []          # (device buffer, layout key) of every transfer: what reset() keeps aside
 
     def _note(self, t):
         self._seen[id(t)] = (t._version, t.data_ptr())
@@ -473,6 +476,7 @@ class Stage:
         """Persistent stage, at the start of an entry point: a shadow whose tensor the caller has written since (torch bumps
         ``_version`` on every in-place write; a new storage shows in ``data_ptr``) is refreshed from the host, in place -- the
         device address stays, cached plans stay valid."""
+        self._touched = set()                            # what THIS call binds: all its write-back has to bring home
         stale = [(t, buf) for (t, buf) in self._bound.values() if buf is not t and self._seen.get(id(t)) != (t._version, t.data_ptr())]
         if stale:
             with torch.no_grad():
@@ -481,9 +485,17 @@ class Stage:
                     self._note(t)
         return self
 
-    def reset(self):
-        """Drop every shadow (a new model arrives, or release_staging())."""
-        self._bound, self._shadow, self._packs, self._hosts, self._seen = {}, [], [], [], {}
+    def reset(self, keep_buffers=True):
+        """Drop every shadow (a new model arrives, or release_staging()).  The packs' device buffers are kept aside by layout
+        (the sizes of the tensors packed into them): the next model of the same architecture is uploaded INTO them, so its shadows
+        have the addresses the previous model's had and the plans built on those come back from the plan cache."""
+        spare = {}
+        if keep_buffers:
+            for flat, layout in self._whole:
+                spare.setdefault(layout, flat)
+        self._bound, self._shadow, self._packs, self._hosts, self._seen, self._whole = {}, [], [], [], {}, []
+        self._spare = spare
+        self._touched = set()
 
     _ALIGN = 64                   # floats: every packed tensor starts on a 256-byte boundary (the kernels' 16-byte vectors)
     _BIG = 4096                   # floats: tensors of at least this size go into the persistent stage's "large" pack
@@ -501,6 +513,8 @@ class Stage:
         todo, seen = [], set()
         amb = getattr(_ambient, 'stage', None)
         amb_bound = amb._bound if (amb is not None and amb is not self) else {}
+        if self._persistent:
+            self._touched.update(id(t) for t in tensors if t is not None)
         for t in tensors:
             if t is None or id(t) in self._bound or id(t) in seen or id(t) in amb_bound:      # (the scope's copy is the truth: bind())
                 continue
@@ -512,19 +526,15 @@ class Stage:
             todo.append(t)
         if len(todo) < 2:
             return
-        if self._persistent and not getattr(self, '_splitting', False):
-            # two packs: the large tensors (weights) and the small ones (biases, BN proxies, scales) -- an entry point that
-            # rewrites only vectors (bias_correction) then brings back a few dozen KB instead of the whole network (writeback)
+        n_big = 0
+        if self._persistent:
+            # the large tensors (weights) first, then the small ones (biases, BN proxies, scales): ONE transfer, registered as TWO
+            # packs over the two regions of the buffer -- an entry point that rewrites only vectors (bias_correction) then brings
+            # back a few dozen KB instead of the whole network (writeback)
             big = [t for t in todo if t.numel() >= self._BIG]
-            small = [t for t in todo if t.numel() < self._BIG]
-            if len(big) >= 2 and len(small) >= 2:
-                self._splitting = True
-                try:
-                    self.prefetch(big)
-                    self.prefetch(small)
-                finally:
-                    self._splitting = False
-                return
+            if len(big) >= 2 and len(todo) - len(big) >= 2:
+                todo = big + [t for t in todo if t.numel() < self._BIG]
+                n_big = len(big)
         offs, total = [], 0
         for t in todo:
             offs.append(total)
@@ -554,7 +564,12 @@ class Stage:
                 hn = host.numpy()
                 _host_copies([(hn[o:o + t.numel()].reshape(t.shape), host[o:o + t.numel()].view(t.shape), t.detach()) for t, o in zip(todo, offs)],
                              to_pack=True)
-        flat = _to_device(host, self.device)
+        spare = getattr(self, '_spare', None)
+        flat = spare.pop(tuple(t.numel() for t in todo), None) if (spare and flats is not None) else None
+        if flat is not None and flat.numel() == total and flat.device == self.device:
+            flat.copy_(host, non_blocking=True)   # the previous model's buffer of the same layout: same device addresses (see reset)
+        else:
+            flat = _to_device(host, self.device)
         self._hosts.append(host)                  # alive until the stage goes (the copy may still be in flight)
         items = []
         if flats is not None:                     # the device views: one split, a reshape only where the tensor is not 1-D
@@ -571,15 +586,65 @@ class Stage:
                 buf = flat[o:o + t.numel()].view(t.shape)
                 self._bound[id(t)] = (t, buf)
                 items.append((t, o, t.numel()))
-        self._packs.append((flat, items, flats))
+        if n_big and flats is not None:
+            # the two regions as packs of their own (views of the one buffer; the pieces' order is the tensors' order)
+            a = offs[n_big]
+            views, sizes, where, ptrs = flats
+            k = where[n_big]                          # first piece of the small region
+            self._packs.append((flat[:a], items[:n_big], (views[:n_big], sizes[:k], where[:n_big], ptrs[:n_big])))
+            self._packs.append((flat[a:], [(t, o - a, n) for (t, o, n) in items[n_big:]],
+                                (views[n_big:], sizes[k:], [w - k for w in where[n_big:]], ptrs[n_big:])))
+            self._whole.append((flat, tuple(t.numel() for t in todo)))
+        else:
+            self._packs.append((flat, items, flats))
+            self._whole.append((flat, tuple(t.numel() for t in todo)))
         if self._persistent:
             for t in todo:
                 self._note(t)
+
+    def new_flat(self, n):
+        """A flat float32 device buffer that adopt() may be given later: the persistent stage hands out the previous model's
+        buffer of the same size (same address: cached plans stay valid, see reset)."""
+        flat = self._spare.pop(('flat', int(n)), None) if self._persistent else None
+        return flat if flat is not None else torch.empty((int(n),), dtype=torch.float32, device=self.device)
+
+    def adopt(self, flat, items):
+        """A flat device buffer whose slices ARE the device values of host tensors that were just created from it (the BN proxies
+        merge_batchnorm computes on the device and registers on the host): the stage takes it as one more pack, so the next entry
+        point finds those tensors shadowed instead of uploading them.  items: [(host tensor, offset, numel)].  Stages whose
+        shadows outlive the call only (a scope or the persistent stage)."""
+        if not (self._scoped or self._persistent) or flat.device != self.device:
+            return
+        kept = []
+        for t, o, n in sorted(items, key=lambda it: it[1]):
+            if id(t) in self._bound or t.device.type != 'cpu' or t.dtype != torch.float32 or not t.is_contiguous():
+                continue
+            self._bound[id(t)] = (t, flat[o:o + n].view(t.shape))
+            kept.append((t, o, n))
+            if self._persistent:
+                self._note(t)
+        if kept:
+            # the same description prefetch() makes of a pack (flat views of the caller's tensors, the sizes the host copy of the
+            # buffer is split into, which piece is whose): the write-back is then one split and one multi-tensor copy
+            views, sizes, where, at = [], [], [], 0
+            for t, o, n in kept:
+                if o > at:
+                    sizes.append(o - at)
+                where.append(len(sizes))
+                sizes.append(n)
+                views.append(t.view(-1))
+                at = o + n
+            if at < flat.numel():
+                sizes.append(flat.numel() - at)
+            self._packs.append((flat, kept, (views, sizes, where, [t.data_ptr() for t, _, _ in kept])))
+            self._whole.append((flat, ('flat', flat.numel())))
 
     def bind(self, t):
         if t is None:
             return None
         key = id(t)
+        if self._persistent:
+            self._touched.add(key)
         hit = self._bound.get(key)
         if hit is not None:
             return hit[1]
@@ -620,9 +685,12 @@ class Stage:
         self._writeback(frozenset(id(t) for t in unchanged if t is not None) if unchanged else frozenset())
 
     def _writeback(self, skip=frozenset()):
+        touched = self._touched if self._persistent else None      # persistent stage: only what this call has bound can have changed
         with torch.no_grad():
             for flat, items, flats in self._packs:        # one device-to-host copy per pack, then host-side copies
                 if skip and all(id(t) in skip for (t, _, _) in items):
+                    continue
+                if touched is not None and not any(id(t) in touched for (t, _, _) in items):
                     continue
                 host = _to_host(flat)
                 if flats is not None:                     # the flat views of prefetch(): one split, one multi-tensor copy
@@ -642,7 +710,7 @@ class Stage:
                 hn = host.numpy()
                 _host_copies([(hn[o:o + n].reshape(t.shape), host[o:o + n].view(t.shape), t.detach()) for t, o, n in items], to_pack=False)
             for t, buf in self._shadow:
-                if id(t) in skip:
+                if id(t) in skip or (touched is not None and id(t) not in touched):
                     continue
                 t.data.copy_(buf.to(t.device, t.dtype) if (buf.device != t.device or buf.dtype != t.dtype) else buf)
             if self._persistent:                          # shadow and tensor hold the same values again: remember the versions

@@ -62,7 +62,7 @@ def merge_batchnorm(model, graph, bottoms, targ_type=[QConv2d]):
         # a model that lives on the host crosses PCIe once each way: every tensor of every pair in one packed copy, the new
         # per-channel vectors of all BatchNorms in one flat buffer that comes back in one copy
         stage.prefetch([t for layer, bn in pairs for t in (layer.weight, layer.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var)])
-        fake = stage.new((2 * sum(bn.weight.numel() for _, bn in pairs),)) if pairs else None
+        fake = stage.new_flat(2 * sum(bn.weight.numel() for _, bn in pairs)) if pairs else None
         outs, at = [], 0
         for layer, bn in pairs:
             w = stage.bind(layer.weight)
@@ -92,6 +92,10 @@ def merge_batchnorm(model, graph, bottoms, targ_type=[QConv2d]):
                     src = host[dev] = _ffi._to_host(fake) if dev.type == 'cpu' else fake.to(dev)
             bn.register_buffer('fake_weight', src[o:o + n].clone())
             bn.register_buffer('fake_bias', src[o + n:o + 2 * n].clone())
+        if fake is not None and any(bn.weight.device != fake.device for bn, _, _ in outs):
+            # the proxies were computed on the device: a stage whose shadows outlive the call keeps `fake` as their device copy
+            stage.adopt(fake, [(t, at, t.numel()) for bn, o, n in outs
+                               for t, at in ((bn.fake_weight, o), (bn.fake_bias, o + n)) if t.device.type == 'cpu'])
         stage.writeback()
     return model
 

@@ -45,7 +45,7 @@ def test_scope_equals_separate_calls(name):
         assert ra.S.device.type == 'cpu' and rb.S.device.type == 'cpu'
         assert torch.equal(ra.S, rb.S)
     assert packs[0] <= 3                      # LE's tensors, then only what absorption / correction add (BatchNorms LE did not touch)
-    assert _ffi.scoped_stage() is None
+    assert getattr(_ffi._ambient, 'stage', None) is None      # (no explicit scope is open; the thread's persistent stage is another matter)
 
 
 @pytest.mark.gpu
@@ -60,7 +60,7 @@ def test_scope_left_by_an_exception_writes_nothing_back():
     after = snapshot(m[1])
     for k in before:
         assert_bitexact(after[k], before[k], k)
-    assert _ffi.scoped_stage() is None
+    assert getattr(_ffi._ambient, 'stage', None) is None      # (no explicit scope is open; the thread's persistent stage is another matter)
     # and the model is usable afterwards
     dfq.cross_layer_equalization(m[1], m[3], TARG)
     assert any((snapshot(m[1])[k] != before[k]).any() for k in before)
@@ -268,4 +268,6 @@ def test_plain_calls_share_device_copies_and_see_host_side_writes():
         assert torch.equal(le_w, le_g)
         for k in want:
             assert_bitexact(got[k], want[k], '{} (mutate={})'.format(k, mutate))
-        assert uploads == 0, 'the equalisation and the correction found the shadows merge_batchnorm had made: no new pack'
+        # the equalisation and the correction found the shadows merge_batchnorm had made: what they add are the BN proxies that
+        # merge_batchnorm has just CREATED on the host (fake_weight / fake_bias: new tensors), nothing else
+        assert uploads <= 2, uploads
