@@ -457,7 +457,7 @@ def lazy_scale_pass(protos, net_sweeps, steps, warm, net='mobilenet_v2'):
 # ---------------------------------------------------------------------------------------------------
 # config 5 end to end: update_quant_range over the distilled batches through the whole quantised network
 # ---------------------------------------------------------------------------------------------------
-def distill_range_pass(net, shape, n_batches, dev):
+def distill_range_pass(net, shape, n_batches, dev, group=None, world=1):
     """configs[4] as improve_dfq.py:280-297 runs it: `n_batches` batches of `shape` through the whole quantised network with
     every QuantMeasure recording its range (set_update_stat -> update_quant_range), the data resident on the GPU.  The
     convolutions are MIOpen's (the inference path, out of scope); the QuantMeasure kernels' share is the difference to the same
@@ -487,7 +487,8 @@ def distill_range_pass(net, shape, n_batches, dev):
     _sync()
 
     def run_all():
-        improve_dfq.update_quant_range(qmodel, data, graph, bottoms)
+        # world > 1: the batches are split over the ranks and ONE all_reduce merges the [modules, 2] range table
+        improve_dfq.update_quant_range(qmodel, data, graph, bottoms, group=group if world > 1 else None)
     with_q = min(_gpu_elapsed_ms(run_all) for _ in range(2))
     t0 = time.perf_counter()
     run_all()
@@ -503,7 +504,8 @@ def distill_range_pass(net, shape, n_batches, dev):
     improve_dfq.set_update_stat(qmodel, [q.QuantMeasure], False)
     qm_ms = max(with_q - without_q, 1e-9)
     nbytes = 12 * elements_per_batch * n_batches
-    return {'net': net, 'batches': n_batches, 'batch_shape': list(shape), 'quant_measures': len(measures),
+    return {'net': net, 'batches': n_batches, 'batch_shape': list(shape), 'quant_measures': len(measures), 'world': world,
+            'batches_per_rank': -(-n_batches // world), 'collectives_per_pass': 1 if world > 1 else 0,
             'elements_per_batch': elements_per_batch, 'ms_per_batch': with_q / n_batches, 'ms_total': with_q, 'wall_ms_total': wall,
             'convolutions_only_ms_per_batch': without_q / n_batches,
             'quant_measure_ms_per_batch': qm_ms / n_batches, 'quant_measure_share': qm_ms / with_q,
@@ -962,10 +964,15 @@ def main():
         if res is not None:
             out['lazy_scale'] = res
             out['value_lazy_scale'] = res['value']
-    if rank == 0 and args.distill:
+    if args.distill and (rank == 0 or world > 1):
+        # every rank takes part at N > 1: data-parallel over the distilled batches, one all_reduce of the range table
         dnet, dn, dshape = args.distill.split(':')
-        res = side_leg('distill_range', lambda: distill_range_pass(dnet, [int(v) for v in dshape.split(',')], int(dn), dev))
-        if res is not None:
+        if world > 1:
+            with _stream_ctx(streams[0]):
+                res = distill_range_pass(dnet, [int(v) for v in dshape.split(',')], int(dn), dev, group=dist.group.WORLD, world=world)
+        else:
+            res = side_leg('distill_range', lambda: distill_range_pass(dnet, [int(v) for v in dshape.split(',')], int(dn), dev))
+        if res is not None and rank == 0:
             out['config']['distill_range'] = res
     if rank == 0 and world == 1 and args.pcie:
         rec = side_leg('pcie_inclusive', lambda: pcie_inclusive_pass(args.pcie))

