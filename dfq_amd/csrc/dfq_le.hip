@@ -684,6 +684,28 @@ __device__ __forceinline__ double col_tile(const LeRelDev& R, const LeParams& p,
     const bool defer = (R.defer & 2) != 0;
     const int phase = defer ? (dep.sweep & (p.defer - 1)) : 0;
     const bool keep = defer && phase != p.defer - 1;
+    if ((kAblate & 16) && defer) {
+        // tuning builds only: what a deferred chain-end column tile would cost with its factors handed to it (no wait, no
+        // statistics words, no solve, no table, no barrier) -- results WRONG by construction
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            if (u < n_max) vload<VEC>(w + min(grp + u * n_rowslots, nr - 1) * row_len2, v[u], false);
+        }
+        const float f = 1.0f + 1e-7f * (float)(dep.sweep & 3);
+        double a = 0.0;
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            if (u >= n_max) continue;
+            const int r_raw = grp + u * n_rowslots;
+            const bool ok = lane_on && r_raw < nr;
+            float nv[VEC];
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) nv[k] = v[u][k] * f;
+            if (ok && !keep) vstore<VEC>(w + min(r_raw, nr - 1) * row_len2, nv);
+            a += slot_abs_diff<VEC>(ok, nv, v[u]);
+        }
+        return a;
+    }
     auto hold_tab = [&](int j) { return j == 0 ? sh_hold : (float*)sh_row + (j - 1) * kSlotMax; };
     float hv[kHoldMax];
 #pragma unroll
@@ -1908,12 +1930,15 @@ static int col_cols_max(int vec, bool batched) {
 }
 static int ceil_div(int a, int b) { return (a + b - 1) / b; }
 // group depth of the free-running segments (dfq_le_cf.hpp): DFQ_LE_CF=0 or DFQ_LE_CF_GROUP=1 keep every layer on the general
-// tiles; 2 / 4 / 8 sweeps per pass over a free-running layer (default 4)
-static int cf_group_from_env() {
+// tiles; 2 / 4 / 8 sweeps per pass over a free-running layer
+// Default: 8 for a batched plan (batch of 32 MobileNetV2, two alternating rounds, tools/gpu_r06_g8.sh: 1.741 / 1.743e10 weights/s at
+// depth 4, 1.788 / 1.801e10 at depth 8 -- the lean launch 73 us per 4 sweeps against 104 us per 8), 4 for a single network (a
+// ResNet-18 stops after two sweeps: every sweep a lean tile looks ahead beyond the loop's end is arithmetic for nothing).
+static int cf_group_from_env(bool batched) {
     const char* off = getenv("DFQ_LE_CF");
     if (off && off[0] == '0') return 1;
     const char* e = getenv("DFQ_LE_CF_GROUP");
-    const int v = e ? atoi(e) : 4;
+    const int v = e ? atoi(e) : (batched ? 8 : 4);
     return v >= 8 ? 8 : v >= 4 ? 4 : v >= 2 ? 2 : 1;
 }
 // rows of a full-row tile (row_tile's local mode): what the register slots hold, at most the tile target
@@ -2149,7 +2174,7 @@ int dfq_le_plan_create_batch(const dfq_layer* layers, int32_t n_layers, const in
     std::vector<int> fr(n_relations, 0);            // 1 + position in its segment
     std::vector<int> fr_last(n_relations, 0);       // last relation of its segment (its second layer is the chain's end)
     std::vector<std::vector<int>> segments;
-    p->cf_group = cf_group_from_env();
+    p->cf_group = cf_group_from_env(n_nets > 1);
     {
         const bool no_short = getenv("DFQ_LE_NO_SHORT") != nullptr;
         // first layer handled by one thread per row (the rule of the second pass below)

@@ -66,8 +66,24 @@ def main():
                 'doubled per MI355X_MICROARCH.md; per-launch figures are the mean over the %d launch levels of a sweep, like '
                 'bench.py roofline.bytes_per_launch' % (batch, n_levels),
     }
+    # the second streaming kernel of a sweep (round 6): le_lean_kernel, one launch per group of sweeps over the free-running layers
+    fr = bench['roofline'].get('free_running')
+    if fr:
+        lean = {}
+        for c in ('FETCH_SIZE', 'WRITE_SIZE'):
+            v = [float(r['Counter_Value']) for r in load(c, root) if 'le_lean_kernel' in r['Kernel_Name'] and float(r['Counter_Value']) > 64.0]
+            if v:
+                lean[c] = (sum(v) / len(v), len(v))
+        if len(lean) == 2:
+            fetch, write = lean['FETCH_SIZE'][0] * 1024 * 2.0, lean['WRITE_SIZE'][0] * 1024
+            out['le_lean_kernel'] = {'launches_counted': lean['FETCH_SIZE'][1], 'fetch_bytes_corrected': fetch, 'write_bytes': write,
+                                     'traffic_bytes_per_launch': fetch + write, 'algorithmic_bytes_per_launch': fr['bytes_per_launch'],
+                                     'traffic_over_algorithmic': (fetch + write) / fr['bytes_per_launch'],
+                                     'sweeps_per_launch': fr['sweeps_per_launch']}
     json.dump(out, open(dest, 'w'), indent=1)
     print(json.dumps(out['le_level_kernel'], indent=1))
+    if 'le_lean_kernel' in out:
+        print(json.dumps(out['le_lean_kernel'], indent=1))
 
 
 if __name__ == '__main__':

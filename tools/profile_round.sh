@@ -7,7 +7,7 @@
 #      single-network latency probe (le_resident_kernel), the other configs and the activation-range kernels;
 #   3. FETCH_SIZE / WRITE_SIZE counter passes (separate --pmc runs) at the bench's own batch size + their digest.
 # Every step runs under `timeout`; nothing here reads stdin.
-R=${ROUND:-r04}
+R=${ROUND:-r06}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 B=${PROFILE_BATCH:-32}
 if [ -z "$SKIP_BENCH" ]; then
@@ -23,7 +23,7 @@ D=$(find gpurun_out/prof_$R -name "*domain_stats.csv" | head -1)
 [ -n "$D" ] && cp "$D" gpurun_out/${R}_bench_domain_stats.csv
 [ -n "$T" ] && timeout 120 python tools/rocprof_digest.py "$T" gpurun_out/${R}_bench_under_rocprof.json > gpurun_out/${R}_level_kernel_by_launch.csv < /dev/null
 [ -n "$T" ] && rm -f "$T"
-PMC_TIMEOUT=400 bash tools/pmc_level.sh --batch $B --sweeps 4 < /dev/null
+PMC_TIMEOUT=400 bash tools/pmc_level.sh --batch $B --sweeps 8 < /dev/null     # (8: one whole group of the free-running layers)
 timeout 120 python tools/pmc_digest.py gpurun_out gpurun_out/${R}_bench_under_rocprof.json gpurun_out/${R}_pmc_summary.json < /dev/null | tail -12
 timeout 60 python tools/bench_line.py gpurun_out/${R}_bench_default.json gpurun_out/${R}_bench_under_rocprof.json < /dev/null
 tail -3 gpurun_out/pmc_FETCH_SIZE.log | cut -c1-300

@@ -12,7 +12,8 @@ import csv
 import json
 import sys
 
-rows = [r for r in csv.DictReader(open(sys.argv[1])) if 'le_level_kernel' in r['Kernel_Name']]
+all_rows = list(csv.DictReader(open(sys.argv[1])))
+rows = [r for r in all_rows if 'le_level_kernel' in r['Kernel_Name']]
 groups = collections.OrderedDict()
 for r in rows:
     wgs = (int(r['Grid_Size_X']) // int(r['Workgroup_Size_X'])) * int(r['Grid_Size_Y'])
@@ -32,3 +33,11 @@ if len(sys.argv) > 2:
     sel = [x for (flat, wgs), d in groups.items() if flat and wgs in want for x in d]
     print('# launches of the timed batch (%s workgroups): %d dispatches, average %.2f us; bench.py roofline.us_per_launch = %.2f us'
           % (sorted(want), len(sel), sum(sel) / max(len(sel), 1) / 1e3, b['roofline']['us_per_launch']))
+
+# round 6: the lean launches of the free-running layers (one per group of sweeps), by grid size
+lean = collections.OrderedDict()
+for r in all_rows:
+    if 'le_lean_kernel' in r['Kernel_Name']:
+        lean.setdefault(int(r['Grid_Size_X']) // int(r['Workgroup_Size_X']), []).append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
+for wgs, d in sorted(lean.items()):
+    print('# le_lean_kernel, %d workgroups: %d dispatches, average %.2f us (min %.2f, max %.2f)' % (wgs, len(d), sum(d) / len(d) / 1e3, min(d) / 1e3, max(d) / 1e3))
