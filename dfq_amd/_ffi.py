@@ -369,8 +369,11 @@ def staging():
     if outer is not None:
         yield outer
         return
-    st = Stage()
+    # the scope works on the thread's persistent stage when there is one: what earlier plain calls (merge_batchnorm) have
+    # uploaded is found again, and the plans keyed on those device copies come back from the cache
+    st = persistent_stage() or Stage()
     st._scoped = True
+    st._touched = set()
     _ambient.stage = st
     ok = False
     try:
@@ -381,6 +384,8 @@ def staging():
         st._scoped = False
         if ok:
             st._writeback()
+        elif st._persistent:
+            st.reset()                                    # the device copies are ahead of the caller's tensors: they go
         if getattr(st, '_late', False) and st.device.type == 'cuda':
             torch.cuda.current_stream().synchronize()     # results handed out as views of buffers still in flight
 
@@ -476,7 +481,8 @@ class Stage:
         """Persistent stage, at the start of an entry point: a shadow whose tensor the caller has written since (torch bumps
         ``_version`` on every in-place write; a new storage shows in ``data_ptr``) is refreshed from the host, in place -- the
         device address stays, cached plans stay valid."""
-        self._touched = set()                            # what THIS call binds: all its write-back has to bring home
+        if not self._scoped:
+            self._touched = set()                        # what THIS call binds: all its write-back has to bring home
         stale = [(t, buf) for (t, buf) in self._bound.values() if buf is not t and self._seen.get(id(t)) != (t._version, t.data_ptr())]
         if stale:
             with torch.no_grad():

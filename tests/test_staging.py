@@ -92,6 +92,7 @@ def test_scoped_calls_reuse_plans_for_the_next_model_of_the_same_shapes():
 @pytest.mark.gpu
 def test_device_resident_model_is_untouched_by_a_scope():
     _ffi.lib()
+    _ffi.release_staging()                        # (the scope works on the thread's persistent stage: start from an empty one)
     a, b = _cpu_model(), _cpu_model()
     for m in (a, b):
         m[0].to('cuda')
@@ -115,7 +116,7 @@ def test_scopes_join_and_clean_up(engine):
         assert _ffi.entry_stage() is outer         # what a calibration entry point takes ...
         assert _ffi.Stage() is not outer           # ... and what a per-call user (QuantMeasure, quantize, prims) takes
     assert _ffi.scoped_stage() is _ffi.persistent_stage()      # outside a scope: the thread's persistent stage (round 6), or None
-    assert _ffi.entry_stage() is not outer
+    assert getattr(_ffi._ambient, 'stage', None) is None and not outer._scoped      # (the scope worked ON the persistent stage)
 
 
 @pytest.mark.gpu
@@ -172,6 +173,7 @@ def test_per_call_users_do_not_join_the_scope():
     the activations.  Only the calibration entry points share the scope's stage (_ffi.entry_stage)."""
     from dfq_amd.utils.quantize import QuantMeasure, quantize
     _ffi.lib()
+    _ffi.release_staging()                        # (the scope works on the thread's persistent stage: start from an empty one)
     g = torch.Generator().manual_seed(3)
     xs = [torch.randn(4, 3, 8, 8, generator=g) * (i + 1) for i in range(3)]
 
