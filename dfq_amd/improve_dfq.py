@@ -144,8 +144,11 @@ def update_quant_range(model, data, graph, bottoms, is_detection=False, group=No
                     m.running_min.copy_((-row[1:2]).to(m.running_min.device))
     for key in graph:
         bot = bottoms[key]
-        if bot is not None and bot[0] == 'Data' and hasattr(graph[key], 'quant'):
-            q = graph[key].quant
+        # (the graph fxgraph.quantize_tensor_ops returns lists a layer's input quantiser as a node of its own: there the node fed
+        # by 'Data' IS the QuantMeasure of the first layer)
+        first = graph[key].quant if hasattr(graph[key], 'quant') else (graph[key] if isinstance(graph[key], QuantMeasure) else None)
+        if bot is not None and bot[0] == 'Data' and first is not None:
+            q = first
             if is_detection:
                 q.running_max.fill_(1.0)
                 q.running_min.fill_(-1.0)

@@ -169,7 +169,8 @@ def test_update_quant_range_at_the_bench_configuration():
     for h in hooks:
         h.remove()
     assert seen[0] > 4.6e8                                       # the bench line's elements_per_batch
-    pinned = [graph[k].quant for k in graph if bottoms[k] is not None and bottoms[k][0] == 'Data' and hasattr(graph[k], 'quant')]
+    # (in the graph quantize_tensor_ops returns, the first layer's input quantiser is the node fed by 'Data': it is pinned)
+    pinned = [graph[k] for k in graph if bottoms[k] is not None and bottoms[k][0] == 'Data' and isinstance(graph[k], q.QuantMeasure)]
     assert len(pinned) == 1
     for n, m in measures:
         got = np.array([float(m.running_min), float(m.running_max)], dtype=F32)
