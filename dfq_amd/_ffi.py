@@ -699,30 +699,43 @@ class Stage:
                 if touched is not None and not any(id(t) in touched for (t, _, _) in items):
                     continue
                 host = _to_host(flat)
+                # (persistent stage: of a pack that comes back, only the tensors this call has bound are copied into the caller's
+                # tensors -- the others hold on the host what they hold on the device)
+                want = (lambda t: id(t) in touched) if touched is not None else (lambda t: True)
                 if flats is not None:                     # the flat views of prefetch(): one split, one multi-tensor copy
                     views, sizes, where, ptrs = flats
                     for i, (t, _, _) in enumerate(items):
                         if t.data_ptr() != ptrs[i]:       # the caller gave the tensor a new storage meanwhile: write there
                             views[i] = t.detach().reshape(-1) if t.is_contiguous() else None
                     pieces = host.split(sizes)
-                    dst = [v for v in views if v is not None]
-                    src = [pieces[w] for w, v in zip(where, views) if v is not None]
-                    with _one_thread():
-                        torch._foreach_copy_(dst, src)
+                    dst, src = [], []
+                    for (t, _, _), w, v in zip(items, where, views):
+                        if v is not None and want(t):
+                            dst.append(v)
+                            src.append(pieces[w])
+                    if dst:
+                        with _one_thread():
+                            torch._foreach_copy_(dst, src)
                     for (t, o, n), v in zip(items, views):
-                        if v is None:
+                        if v is None and want(t):
                             t.detach().copy_(host[o:o + n].view(t.shape))
+                    if self._persistent:                  # shadow and tensor hold the same values again: remember the versions
+                        for (t, _, _) in items:
+                            if want(t):
+                                self._note(t)
                     continue
                 hn = host.numpy()
-                _host_copies([(hn[o:o + n].reshape(t.shape), host[o:o + n].view(t.shape), t.detach()) for t, o, n in items], to_pack=False)
+                _host_copies([(hn[o:o + n].reshape(t.shape), host[o:o + n].view(t.shape), t.detach()) for t, o, n in items if want(t)], to_pack=False)
+                if self._persistent:
+                    for (t, _, _) in items:
+                        if want(t):
+                            self._note(t)
             for t, buf in self._shadow:
                 if id(t) in skip or (touched is not None and id(t) not in touched):
                     continue
                 t.data.copy_(buf.to(t.device, t.dtype) if (buf.device != t.device or buf.dtype != t.dtype) else buf)
-            if self._persistent:                          # shadow and tensor hold the same values again: remember the versions
-                for t, buf in self._bound.values():
-                    if buf is not t:
-                        self._note(t)
+                if self._persistent:
+                    self._note(t)
 
     def out_like_many(self, t, bufs):
         """out_like for a list of device tensors with ONE transfer (independent tensors on the caller's device)."""

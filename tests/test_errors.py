@@ -189,7 +189,8 @@ def test_abandoned_in_launch_wait_is_reported_not_silent(engine, monkeypatch, wh
     dfq.clear_plan_cache()
 
 
-def test_abandoned_resident_launch_degrades_to_per_level_launches(engine, monkeypatch):
+@pytest.mark.parametrize('persist', ['0', '1'])
+def test_abandoned_resident_launch_degrades_to_per_level_launches(engine, monkeypatch, persist):
     """VERDICT r4 item 7.  DFQ_SPIN_LIMIT=1 makes a wait of the persistent equalisation launch give up.  The launch stores all or
     nothing (its tiles write back only once every tile has finished the loop), so the caller's tensors are untouched, and
     `dfq_le_run` -- the drop-in `cross_layer_equalization` -- repeats the pass on one launch per level (no wait inside a launch)
@@ -208,6 +209,11 @@ def test_abandoned_resident_launch_degrades_to_per_level_launches(engine, monkey
         lt.merge_batchnorm(model, graph, bottoms, TARG)
         return model, graph, bottoms, rel.create_relation(graph, bottoms, TARG)
 
+    # (persist: the plan was built with the persistent-workgroup variant of the streaming sweep, DFQ_LE_PERSIST=1 -- ADVICE round 5:
+    # a degraded plan must run its per-level launches on le_level_kernel, not on that variant, which walks the WHOLE table)
+    monkeypatch.setenv('DFQ_LE_PERSIST', persist)
+    if persist == '1':
+        monkeypatch.setenv('DFQ_LE_CF', '0')
     dfq.clear_plan_cache()
     model, graph, bottoms, rels = fresh()
     dfq.cross_layer_equalization(graph, rels, TARG)
@@ -229,7 +235,7 @@ def test_abandoned_resident_launch_degrades_to_per_level_launches(engine, monkey
         for sc, s in zip(plan.scale_cum, want_S):
             assert np.array_equal(npy(sc).view(np.int32), s.view(np.int32))
         if degraded:
-            assert plan.resident_tiles == 0 and 'abandoned' in plan.resident_reason and plan.levels > 1
+            assert plan.resident_tiles == 0 and 'abandoned' in plan.resident_reason and plan.levels > 1 and plan.sweep_workgroups == 0
             assert plan.run.__self__ is plan
             plan.close()
             break

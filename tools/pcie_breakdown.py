@@ -20,7 +20,7 @@ def wrap(obj, name, label):
 wrap(dfq, '_le_cache_key', 'le key'); wrap(dfq, '_bc_cache_key', 'bc key') if hasattr(dfq, '_bc_cache_key') else None
 wrap(dfq.LEPlan, 'run', 'le run'); wrap(dfq.BCPlan, 'run', 'bc run')
 wrap(_ffi.Stage, '_writeback', 'writeback'); wrap(_ffi.Stage, 'prefetch', 'prefetch'); wrap(_ffi.Stage, 'out_like_many', 'S out')
-wrap(_ffi.Stage, 'begin_call', 'begin_call'); wrap(_ffi, '_to_host', 'd2h')
+wrap(_ffi.Stage, 'begin_call', 'begin_call'); wrap(_ffi, '_to_host', 'd2h'); wrap(_ffi, '_pinned', 'pinned alloc'); wrap(_ffi, '_to_device', 'h2d'); wrap(_ffi.Stage, 'reset', 'reset'); wrap(_ffi.Stage, 'adopt', 'adopt'); wrap(torch, 'cat', 'torch.cat')
 wrap(dfq, '_bc_tables_cached', 'bc tables') if hasattr(dfq, '_bc_tables_cached') else None
 net = sys.argv[1] if len(sys.argv) > 1 else 'mobilenet_v2'
 for rep in range(4):
