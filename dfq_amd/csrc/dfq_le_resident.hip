@@ -125,6 +125,8 @@ struct ResTile {                     // one workgroup
     int32_t relax_c;                 // bit 0: every input channel of this layer lives in ONE tile -> likewise for its column statistics;
                                      // bit 1: the same holds for relation B's SECOND layer (this tile reads THOSE column statistics in phase 2);
                                      // bit 2: bit 0 and the tile may poll its own column words' tags instead of the layer's counter (DFQ_RES_DIRECT)
+                                     // bit 3: a chain END (relation A only): the next sweep's column statistics follow from this sweep's in closed
+                                     // form -- see "closed-form column statistics" in res_tile_body (round 6)
     int32_t slot;                    // logical index of the tile (partial-sum slot, checkpoint slot): the table itself is in LAUNCH order
     int32_t log_off;                 // first float of this tile inside an entry of the factor log: 1/s_A per table entry, then s_B per row
 };
@@ -357,7 +359,7 @@ struct LayGeneral {
             }
         });
     }
-    __device__ __forceinline__ double diff_and_cols(const ResTile&, const TileGeo&, float*, bool, bool, const float*, const float*, uint32_t*, bool = false) const { return 0.0; }
+    __device__ __forceinline__ double diff_and_cols(const ResTile&, const TileGeo&, float*, bool, bool, const float*, const float*, uint32_t*, bool = false, bool = true) const { return 0.0; }
     // w <- new; kDiff: returns the thread's sum of |new - old| in float64 (else 0: the replay of a rollback)
     template <bool kDiff>
     __device__ __forceinline__ double update(const ResTile& T, const TileGeo& G, float* tile, bool useA, bool useB,
@@ -559,9 +561,10 @@ struct LayFixed {
     // every tile of a pointwise layer behind a depthwise or a pointwise one.  The generic loop below decides all of that per
     // slot with uniform branches and keeps both arms in the loop body: ~90 issued instructions per float4 slot where this
     // needs ~40, and a pass of a [8 x 960] tile took 3.0 us where the bare loop takes 0.7 (tools/litmus/lds_pass.hip).
+    // (`cols` false -- a chain end with closed-form column statistics, round 6: w <- new and |dW| only; a uniform branch)
     template <bool UB>
     __device__ __forceinline__ double diff_and_cols_hot(const ResTile& T, const TileGeo& G, float* tile, const float* sh_inv,
-                                                        const float* sh_s, uint32_t* sh_col) const {
+                                                        const float* sh_s, uint32_t* sh_col, bool cols) const {
         double acc = 0.0;
         float iv[4];
         inv4(T, G, sh_inv, 0, iv);
@@ -588,22 +591,24 @@ struct LayFixed {
                 if (!(DFQ_RES_ABLATE & 1)) { pa += (double)abs_f32(na[k] - va[k]); pb += (double)abs_f32(nb[k] - vb[k]); }
                 // (no `on` select: padded lanes / rows hold exact duplicates of valid elements; the unused second copy of an odd
                 // count's last slot is such a duplicate too)
-                cmn[k] = vmin_raw(vmin_raw(cmn[k], na[k]), nb[k]);
-                cmx[k] = vmax_raw(vmax_raw(cmx[k], na[k]), nb[k]);
+                if (UB || cols) {
+                    cmn[k] = vmin_raw(vmin_raw(cmn[k], na[k]), nb[k]);
+                    cmx[k] = vmax_raw(vmax_raw(cmx[k], na[k]), nb[k]);
+                }
             }
             *(fvec4*)xa = na;
             if (u0 + 1 < n_used) *(fvec4*)xb = nb;                         // (uniform)
             acc += on_a ? pa : 0.0;                                        // slot order, as the generic loop sums
             acc += on_b ? pb : 0.0;
         }
-        cols_finish(cmn, cmx, sh_col);
+        if (UB || cols) cols_finish(cmn, cmx, sh_col);
         return acc;
     }
     // one pass: |dW| and the column statistics of the new values; `commit`: w <- new in the same pass
     __device__ __forceinline__ double diff_and_cols(const ResTile& T, const TileGeo& G, float* tile, bool useA, bool useB,
-                                                    const float* sh_inv, const float* sh_s, uint32_t* sh_col, bool commit = false) const {
+                                                    const float* sh_inv, const float* sh_s, uint32_t* sh_col, bool commit = false, bool cols = true) const {
         if (DFQ_RES_HOT && one_group && useA && commit)
-            return useB ? diff_and_cols_hot<true>(T, G, tile, sh_inv, sh_s, sh_col) : diff_and_cols_hot<false>(T, G, tile, sh_inv, sh_s, sh_col);
+            return useB ? diff_and_cols_hot<true>(T, G, tile, sh_inv, sh_s, sh_col, true) : diff_and_cols_hot<false>(T, G, tile, sh_inv, sh_s, sh_col, cols);
         double acc = 0.0;
         float iv[4] = {1.0f, 1.0f, 1.0f, 1.0f};
         if (useA && one_group) inv4(T, G, sh_inv, 0, iv);
@@ -620,7 +625,8 @@ struct LayFixed {
                 const float nv = (xv[k] * iv[k]) * sr;            // dfq.py:73 then :62, both rounded
                 nw[k] = nv;
                 if (!(DFQ_RES_ABLATE & 1)) part += (double)abs_f32(nv - xv[k]);
-                if (one_group) {
+                if (!cols) {
+                } else if (one_group) {
                     // (no `on` select: the slots of padded lanes / rows hold exact DUPLICATES of valid elements -- loaded as such,
                     // updated with the same factors, checkpointed raw -- and a duplicate changes no minimum or maximum)
                     cmn[k] = vmin_raw(cmn[k], nv);
@@ -632,7 +638,7 @@ struct LayFixed {
             if (commit) *(fvec4*)x = nw;                          // the thread's own slot (padded lanes hold private duplicates)
             acc += on ? part : 0.0;
         });
-        if (one_group) cols_finish(cmn, cmx, sh_col);
+        if (one_group && cols) cols_finish(cmn, cmx, sh_col);
         return acc;
     }
     __device__ __forceinline__ void col_stats(const ResTile& T, const TileGeo& G, float* tile, bool useA, bool useB,
@@ -739,7 +745,7 @@ struct LayShort {
     // one pass: |dW| and the column statistics of the new values; `commit`: w <- new in the same pass (round 4: the depthwise tile
     // of the longest chain sits on the sweep's critical cycle and used to walk its rows twice here)
     __device__ __forceinline__ double diff_and_cols(const ResTile& T, const TileGeo& G, float* tile, bool useA, bool useB,
-                                                    const float* sh_inv, const float* sh_s, uint32_t* sh_col, bool commit = false) const {
+                                                    const float* sh_inv, const float* sh_s, uint32_t* sh_col, bool commit = false, bool cols = true) const {
         double acc = 0.0;
         rows(T, tile, [&](int j, int row, bool on, float* base) {
             const float fa = fa_of(j, useA, sh_inv), fb = useB ? sh_s[row] : 1.0f;
@@ -752,13 +758,13 @@ struct LayShort {
                     if (commit) base[e * kBlock] = nv;
                     mn = vmin_raw(mn, nv); mx = vmax_raw(mx, nv);
                 });
-                if (on) lds_minmax(sh_col + 2 * rt[j], mn, mx);
+                if (on && cols) lds_minmax(sh_col + 2 * rt[j], mn, mx);
             } else {
                 elems(base, [&](int e, float x) {
                     const float nv = val(x, j, e, useA, fa, fb, sh_inv);
                     part += (double)abs_f32(nv - x);
                     if (commit) base[e * kBlock] = nv;
-                    if (on) lds_minmax(sh_col + 2 * (rt[j] + small_div(e, khkw)), nv, nv);
+                    if (on && cols) lds_minmax(sh_col + 2 * (rt[j] + small_div(e, khkw)), nv, nv);
                 });
             }
             acc += on ? part : 0.0;
@@ -812,6 +818,25 @@ __device__ __forceinline__ void publish_cols(const ResArgs& a, const ResTile& T,
             publish_max(dst + 2 * (int64_t)c + 1, tag, hi);
             sh_col[2 * idx] = 0u; sh_col[2 * idx + 1] = 0u;
         }
+    }
+}
+// closed-form column statistics (see res_tile_body): sh_col holds the extrema this sweep CONSUMED (raw floats, from phase 1), the
+// next sweep's are fl(extremum * 1/s_A) -- published by the tile that holds the first row of the channel's group only (every
+// tile of the channel holds the same pair: one producer per word), and the table goes back to zero
+__device__ __forceinline__ void publish_cols_cf(const ResArgs& a, const ResTile& T, const TileGeo& G, int64_t r2_off,
+                                                uint32_t* sh_col, const float* sh_inv, uint32_t tag) {
+    u64* dst = a.stats + r2_off + (int64_t)(tag & 1u) * a.parity_stride;
+#pragma unroll 1
+    for (int idx = threadIdx.x; idx < G.g_n * G.nci; idx += kBlock) {
+        const int gq = small_div(idx, G.nci);
+        const int first = (G.g_lo + gq) * T.go - T.r0;
+        if (first >= 0 && first < T.nr && !(DFQ_RES_ABLATE & 64)) {
+            const int c = (G.g_lo + gq) * T.i2g + G.i0 + (idx - gq * G.nci);
+            const float inv = sh_inv[idx];
+            publish_max(dst + 2 * (int64_t)c, tag, ~enc_ord(__uint_as_float(sh_col[2 * idx]) * inv));
+            publish_max(dst + 2 * (int64_t)c + 1, tag, enc_ord(__uint_as_float(sh_col[2 * idx + 1]) * inv));
+        }
+        sh_col[2 * idx] = 0u; sh_col[2 * idx + 1] = 0u;
     }
 }
 
@@ -935,6 +960,17 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
     const bool hasA = kAB < 0 ? T.relA >= 0 : (kAB & 1) != 0, hasB = kAB < 0 ? T.relB >= 0 : (kAB & 2) != 0;
     const bool chain_start = hasB && !hasA;
     const bool rows_local = T.nc == T.row_len;       // the tile holds complete rows: its row statistics are final
+    // Closed-form column statistics (round 6, bit 3 of relax_c).  A chain END's sweep is w <- fl(w * 1/s_A[c]) and nothing else
+    // (dfq.py:73), a positive factor per input channel: rounding is monotonic, so the minimum (maximum) of the channel's new values
+    // is fl(old minimum (maximum) * 1/s_A[c]) -- exactly, whichever element attains it.  Every tile of the channel holds both
+    // operands after phase 1 (the merged statistics it has just consumed, the factor it has just solved), so the next sweep's
+    // statistics are two multiplications per channel instead of a min/max over the tile, a merge of the tiles' results through
+    // atomics (1000 x 1280 classifier: 160 tiles x 2048 atomics per sweep) and an arrival that waits for them.  ONE tile per
+    // channel publishes (the tile holding the first row of the channel's group): the words have a single producer, readers
+    // validate them by their tags as they do all relaxed words, and the arrival need not wait for the atomics.  The FIRST
+    // publication (the untouched weights) is still taken from the elements and merged strictly.  Opt-in: see le_resident_create.
+    auto cf_cols_f = [&]() -> bool { return hasA && !hasB && (T.relax_c & 8) != 0; };      // (re-derived at each use: scalar registers)
+#define cf_cols (cf_cols_f())
     // only the statistics offsets of the two relations stay live through the loop (scalar registers are the scarce resource
     // of this kernel); the [O] vector pointers are re-read where the vectors are loaded and stored
     const int64_t ra_r1 = cold(a).rels[hasA ? T.relA : 0].r1_off, ra_r2 = cold(a).rels[hasA ? T.relA : 0].r2_off;
@@ -1145,6 +1181,8 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
                     if (DFQ_RES_ABLATE & 2) { s = 1.0f; inv = 1.0f + 0.0f * (mn1 + mx1 + mn2 + mx2); }
                     else le_solve(range_of(mn1, mx1, p.signed_range), range_of(mn2, mx2, p.signed_range), p, s, inv);
                     if (idx < n_ch) { sh_inv[idx] = inv; if (!(DFQ_RES_ABLATE & 32)) lg[lt + (unsigned)(j * kBlock)] = inv; }       // (the log: fire-and-forget)
+                    // closed-form column statistics: this sweep's extrema stay in the table (raw floats) for publish_cols_cf
+                    if (cf_cols && idx < n_ch) { sh_col[2 * idx] = __float_as_uint(mn2); sh_col[2 * idx + 1] = __float_as_uint(mx2); }
                 }
             }
             res_stamp<kTrace>(a, k, 1);
@@ -1241,12 +1279,12 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
         } else if (Lay::kFusedCols && hasA) {
             if (DFQ_RES_ABLATE & 256) { double junk = lay.diff_and_cols(T, G, v, hasA, hasB, sh_inv, sh_s, sh_col, false); if (junk == -1.0) sh_s[0] = 0.0f; }   // the pass TWICE: its marginal cost
             if (DFQ_RES_ABLATE & 512) { lay.row_stats(T, G, v, hasA, hasB, sh_inv, sh_s, sh_row); }                  // + a read-only statistics pass
-            acc = lay.diff_and_cols(T, G, v, hasA, hasB, sh_inv, sh_s, sh_col, true);
+            acc = lay.diff_and_cols(T, G, v, hasA, hasB, sh_inv, sh_s, sh_col, true, !cf_cols);   // (closed form: the statistics were formed in phase 1)
         } else if (DFQ_RES_HOT && Lay::kFusedRows && chain_start) {
             acc = lay.update_rows(T, G, v, false, true, sh_inv, sh_s, sh_row);         // w <- w * s_B, |dW| and the new rows' statistics: one pass
         } else {
             acc = lay.template update<true>(T, G, v, hasA, hasB, sh_inv, sh_s);
-            if (hasA) lay.col_stats(T, G, v, false, false, sh_inv, sh_s, sh_col);      // of the values just written
+            if (hasA && !cf_cols) lay.col_stats(T, G, v, false, false, sh_inv, sh_s, sh_col);      // of the values just written
             if (chain_start) lay.row_stats(T, G, v, false, false, sh_inv, sh_s, sh_row);
         }
         if (DFQ_RES_PRIO) __builtin_amdgcn_s_setprio(0);
@@ -1256,10 +1294,11 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
         // (DFQ_RES_LATE_ARRIVE: a STRICT arrival -- statistics merged from several tiles: the counter may move only once this tile's
         // atomics have been performed, a trip through the memory system -- could be made after the sweep's tail, which would then
         // run while the atomics are in flight.  Measured slower: see the switch.)
-        const bool strict_c = DFQ_RES_LATE_ARRIVE && hasA && !(T.relax_c & 1), strict_r = DFQ_RES_LATE_ARRIVE && chain_start && !(T.relax_r & 1);
+        const bool strict_c = DFQ_RES_LATE_ARRIVE && hasA && !(T.relax_c & 1) && !cf_cols, strict_r = DFQ_RES_LATE_ARRIVE && chain_start && !(T.relax_r & 1);
         if (hasA) {
-            publish_cols(a, T, G, ra_r2, sh_col, tag + 1u);
-            if (!strict_c) arrive(a.cnt_c, T.layer, !(T.relax_c & 1));
+            if (cf_cols) publish_cols_cf(a, T, G, ra_r2, sh_col, sh_inv, tag + 1u);
+            else publish_cols(a, T, G, ra_r2, sh_col, tag + 1u);
+            if (!strict_c) arrive(a.cnt_c, T.layer, !(T.relax_c & 1) && !cf_cols);
         }
         if (chain_start) {
             publish_rows(a, T, rb_r1, sh_row, tag + 1u);
@@ -1303,6 +1342,7 @@ __device__ __forceinline__ void res_tile_body(const ResArgs& a, const LeParams& 
         if (strict_r) arrive(a.cnt_r, T.layer, true);
         res_stamp<kTrace>(a, k, 11);
     }
+#undef cf_cols
     // a statistics spin left the loop through *sh_bad: 1 = abandoned, 2 = the loop has stopped (sweep k was not applied)
     __syncthreads();
     if (*sh_bad == 1) failed = true;
@@ -1805,6 +1845,13 @@ LeResident* le_resident_create(const dfq_layer* layers, int n_layers, const dfq_
             if (direct && T.b_layer >= 0 && rel_c[T.b_layer]) T.relax_c |= 2;
             if (direct && (T.relax_c & 1)) T.relax_c |= 4;
         }
+        // bit 3 of relax_c: closed-form column statistics for the chain ends.  OPT-IN (DFQ_RES_CF=1): bit-exact (tests: the
+        // 'resident-cf' engine), and measured no faster on the MI355X -- MobileNetV2 0.585-0.593 ms with, 0.580-0.589 without,
+        // DeepLab 0.343-0.348 vs 0.344-0.361 (profiles/r06_experiments.txt): the classifier's 160 tiles are not on the sweep's
+        // critical cycle, which runs through the chains' hand-offs
+        const char* ce = getenv("DFQ_RES_CF");
+        if (relaxed_ok && ce && ce[0] == '1')
+            for (ResTile& T : tiles) if (T.relA >= 0 && T.relB < 0) T.relax_c |= 8;
     }
     for (ResTile& T : tiles) {
         // tiles per layer (by paired-layer index)

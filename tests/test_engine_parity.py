@@ -251,15 +251,17 @@ def _kat_names():
 # (DFQ_LE_CF=0); the persistent-workgroup variants of the general tiles run without free-running segments as well
 # 'streaming-fused': layers scaled along both axes are read once per sweep -- their row tiles merge the rows' statistics over the slabs
 # of a row block inside the launch (DFQ_LE_FUSE=1: the default of batched plans)
-LE_ENGINES = ['resident', 'streaming', 'streaming-cf2', 'streaming-cf8', 'streaming-general', 'streaming-fused', 'streaming-persistent', 'streaming-persistent-3wg']
+LE_ENGINES = ['resident', 'resident-cf', 'streaming', 'streaming-cf2', 'streaming-cf8', 'streaming-general', 'streaming-fused', 'streaming-persistent', 'streaming-persistent-3wg']
 
 
 def _select_le_engine(monkeypatch, le_engine):
-    for k in ('DFQ_LE_RESIDENT', 'DFQ_LE_PERSIST', 'DFQ_LE_SWEEP_WGS', 'DFQ_LE_TILE_ELEMS', 'DFQ_LE_CF', 'DFQ_LE_CF_GROUP', 'DFQ_LE_FUSE'):
+    for k in ('DFQ_LE_RESIDENT', 'DFQ_LE_PERSIST', 'DFQ_LE_SWEEP_WGS', 'DFQ_LE_TILE_ELEMS', 'DFQ_LE_CF', 'DFQ_LE_CF_GROUP', 'DFQ_LE_FUSE', 'DFQ_RES_CF'):
         monkeypatch.delenv(k, raising=False)
+    if le_engine == 'resident-cf':              # closed-form column statistics of the chain ends (opt-in, dfq_le_resident.hip)
+        monkeypatch.setenv('DFQ_RES_CF', '1')
     if le_engine == 'streaming-fused':
         monkeypatch.setenv('DFQ_LE_FUSE', '1')
-    if le_engine != 'resident':
+    if not le_engine.startswith('resident'):
         monkeypatch.setenv('DFQ_LE_RESIDENT', '0')
     if le_engine.startswith('streaming-cf'):
         monkeypatch.setenv('DFQ_LE_CF_GROUP', le_engine[len('streaming-cf'):])
@@ -1157,7 +1159,7 @@ def test_resident_and_streaming_engines_agree(engine, monkeypatch, name, seed, s
         lt.merge_batchnorm(model, graph, bottoms, TARG)
         rels = rel.create_relation(graph, bottoms, TARG)
         plan = dfq.build_le_plan(graph, rels, TARG)
-        assert (plan.resident_tiles > 0) == (le_engine == 'resident'), plan.resident_reason
+        assert (plan.resident_tiles > 0) == le_engine.startswith('resident'), plan.resident_reason
         if le_engine == 'streaming-persistent':
             assert plan.sweep_workgroups > 3
         elif le_engine == 'streaming-persistent-3wg':
@@ -1414,8 +1416,9 @@ def test_lazy_scale_batch_with_different_sweep_counts(engine):
 # ---------------------------------------------------------------------------------------------
 # round 5: layers of SEVERAL tiles on the CPU emulation (statistics merged over row blocks: strict arrivals)
 # ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('closed_form', [False, True])
 @pytest.mark.parametrize('tile_floats,spec', [('8192', '2'), ('2048', '0'), ('1024', '4')])
-def test_column_statistics_merged_over_row_blocks(engine, monkeypatch, tile_floats, spec):
+def test_column_statistics_merged_over_row_blocks(engine, monkeypatch, tile_floats, spec, closed_form):
     """A layer cut into several row blocks merges its per-input-channel (min, max) over them every sweep (atomicMax into shared
     tagged words, a strict arrival on the layer's counter).  Until round 5 only the full-size networks had such layers, i.e. only the
     GPU ran that code.  `tiny_tail` has one at the default tile size (2 row blocks of its 200 x 48 layer); DFQ_RES_TILE_FLOATS (a test
@@ -1423,7 +1426,7 @@ def test_column_statistics_merged_over_row_blocks(engine, monkeypatch, tile_floa
     depth and the chunking of the loop into launches: weights, [O] vectors, cumulative scales and the sweep count are the oracle's,
     bit for bit.  (The same merge through per-tile slots -- plain stores, every tile reduces its slice, tagged polls -- was built,
     passed this test and was measured SLOWER on the MI355X: 0.73 vs 0.61 ms for MobileNetV2)"""
-    _select_le_engine(monkeypatch, 'resident')
+    _select_le_engine(monkeypatch, 'resident-cf' if closed_form else 'resident')   # (closed form: one tile per channel publishes)
     monkeypatch.setenv('DFQ_RES_TILE_FLOATS', tile_floats)
     monkeypatch.setenv('DFQ_RES_SPEC', spec)
 

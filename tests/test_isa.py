@@ -24,7 +24,8 @@ FLAGS = ['-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '--offload-arch=gfx9
          '-Wno-unused-command-line-argument', '-o', '-']
 
 # kernels allowed to use scratch: name fragment -> (max scratch bytes, max vgpr spills)
-SCRATCH_ALLOWED = {'le_sweep_kernel': (128, 110)}          # opt-in persistent-workgroup variant (slower, kept for A/B)
+SCRATCH_ALLOWED = {'le_sweep_kernel': (128, 110),          # opt-in persistent-workgroup variant (slower, kept for A/B)
+                   'le_resident_kernelILb1': (32, 6)}       # the TUNING instantiation (trace stamps; tools/trace_*.py only) of a kernel at its register limit
 # ceilings for scalar-register spills of the kernels that have any (everything else: 0)
 SGPR_SPILL_CEILING = {                                      # (ILb0 = the production instantiation, ILb1 = the tuning one with trace stamps)
     'le_resident_kernel': 600, 'le_level_kernelILb0': 100, 'le_level_kernelILb1': 150, 'le_sweep_kernel': 120,
