@@ -1934,11 +1934,15 @@ static int ceil_div(int a, int b) { return (a + b - 1) / b; }
 // Default: 8 for a batched plan (batch of 32 MobileNetV2, two alternating rounds, tools/gpu_r06_g8.sh: 1.741 / 1.743e10 weights/s at
 // depth 4, 1.788 / 1.801e10 at depth 8 -- the lean launch 73 us per 4 sweeps against 104 us per 8), 4 for a single network (a
 // ResNet-18 stops after two sweeps: every sweep a lean tile looks ahead beyond the loop's end is arithmetic for nothing).
-static int cf_group_from_env(bool batched) {
+// A single network SMALL enough for the chip's caches (MobileNetV2, DeepLab: the sharded pass, the repeat of an abandoned resident
+// launch) keeps every layer on the general tiles unless DFQ_LE_CF_GROUP asks: its sweep is two launch latencies, not bandwidth,
+// and the lean launches only add to them (tools/lat.py, DFQ_LE_RESIDENT=0, two alternating rounds: MobileNetV2 1.87 ms with
+// segments of depth 4 against 1.82 without, DeepLab 1.22 against 1.14 -- profiles/r06_experiments.txt 8).
+static int cf_group_from_env(bool batched, bool large) {
     const char* off = getenv("DFQ_LE_CF");
     if (off && off[0] == '0') return 1;
     const char* e = getenv("DFQ_LE_CF_GROUP");
-    const int v = e ? atoi(e) : (batched ? 8 : 4);
+    const int v = e ? atoi(e) : (batched ? 8 : large ? 4 : 1);
     return v >= 8 ? 8 : v >= 4 ? 4 : v >= 2 ? 2 : 1;
 }
 // rows of a full-row tile (row_tile's local mode): what the register slots hold, at most the tile target
@@ -2174,7 +2178,7 @@ int dfq_le_plan_create_batch(const dfq_layer* layers, int32_t n_layers, const in
     std::vector<int> fr(n_relations, 0);            // 1 + position in its segment
     std::vector<int> fr_last(n_relations, 0);       // last relation of its segment (its second layer is the chain's end)
     std::vector<std::vector<int>> segments;
-    p->cf_group = cf_group_from_env(n_nets > 1);
+    p->cf_group = cf_group_from_env(n_nets > 1, paired_elems >= (int64_t)6 << 20);
     {
         const bool no_short = getenv("DFQ_LE_NO_SHORT") != nullptr;
         // first layer handled by one thread per row (the rule of the second pass below)
@@ -2198,8 +2202,12 @@ int dfq_le_plan_create_batch(const dfq_layer* layers, int32_t n_layers, const in
             if (!ok) continue;
             // the last layer's column tiles keep one table entry per (group, input channel) they span and sweep
             LeRelDev& last = h[seg.back()];
-            if (last.ct_vec != 0) {
-                const int nci2 = ceil_div(last.ct_cols, last.khkw) + 1;
+            // (an UNGROUPED layer -- every row in the one group -- needs no table at all: lean_col keeps a thread's factors in
+            // registers.  Until late in round 6 the bound was applied to those too and refused every chain end whose column tile
+            // is wider than 127 channels: a single MobileNetV2 on the streaming engine -- the sharded pass, the repeat of an
+            // abandoned resident launch -- had no free-running segment at all.)
+            if (last.ct_vec != 0 && last.go < last.o2) {
+                const int nci2 = last.khkw == 1 ? last.ct_cols : ceil_div(last.ct_cols, last.khkw) + 1;
                 while (last.ct_rows > 1 && (ceil_div(last.ct_rows, last.go) + 1) * nci2 > kCfTab) last.ct_rows = (last.ct_rows + 1) / 2;
                 if ((ceil_div(last.ct_rows, last.go) + 1) * nci2 > kCfTab) continue;
             }

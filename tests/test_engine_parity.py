@@ -265,6 +265,8 @@ def _select_le_engine(monkeypatch, le_engine):
         monkeypatch.setenv('DFQ_LE_RESIDENT', '0')
     if le_engine.startswith('streaming-cf'):
         monkeypatch.setenv('DFQ_LE_CF_GROUP', le_engine[len('streaming-cf'):])
+    if le_engine in ('streaming', 'streaming-fused'):
+        monkeypatch.setenv('DFQ_LE_CF_GROUP', '4')    # (the default of a LARGE single network; a small one keeps the general tiles)
     if le_engine == 'streaming-general' or le_engine.startswith('streaming-persistent'):
         monkeypatch.setenv('DFQ_LE_CF', '0')
     if le_engine.startswith('streaming-persistent'):
@@ -1140,6 +1142,38 @@ def test_full_size_networks_against_oracle(net, max_sweeps, pinned):
     for k in codes:
         assert np.array_equal(codes[k].cpu().numpy(), ocodes[k].astype(np.int32)), 'int8 codes of {}'.format(k)
         assert len(np.unique(npy(graph[k].weight))) <= 256
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('net,max_sweeps,pinned', [('mobilenet_v2', None, False), ('deeplab_mnv2', 12, True)])
+def test_full_size_single_network_on_the_streaming_engine(monkeypatch, net, max_sweeps, pinned):
+    """ONE full-size network on the streaming engine with free-running segments (DFQ_LE_CF_GROUP=4: by default a single network
+    of this size keeps the general tiles, measured faster -- cf_group_from_env).  Its chains expand -> depthwise -> project are
+    segments like the batch's, with column tiles as wide as the layer (until late in round 6 the plan refused every chain end
+    whose column tile spans more than 127 channels: a bound meant for grouped layers' factor tables), and the result is the
+    oracle's, bit for bit, sweep count included."""
+    monkeypatch.setenv('DFQ_LE_RESIDENT', '0')
+    monkeypatch.setenv('DFQ_LE_CF_GROUP', '4')
+    pin = dict(converge_thres=-1.0, converge_count=10 ** 9) if pinned else {}
+    dev = torch.device('cuda', 0)
+    model, graph, bottoms = synthetic.build(net, seed=0)
+    spec = graphspec.from_torch(graph, bottoms, TARG)
+    model.to(dev)
+    lt.merge_batchnorm(model, graph, bottoms, TARG)
+    orc.merge_batchnorm(spec)
+    rels = rel.create_relation(graph, bottoms, TARG)
+    orels = orc.create_relation(spec)
+    plan = dfq.build_le_plan(graph, rels, TARG)
+    assert plan.resident_tiles == 0 and plan.free_running_elements > 1000000 and plan.free_running_group == 4
+    out = plan.run(max_sweeps=max_sweeps, **pin)
+    n_o, S_o = orc.cross_layer_equalization(spec, orels, max_sweeps=max_sweeps, **pin)
+    assert out['sweeps'] == n_o
+    osnap, esnap = _spec_snapshot(spec), snapshot(graph)
+    for k in osnap:
+        assert_bitexact(esnap[k], osnap[k], '{} LE {}'.format(net, k))
+    for a, s in zip(plan.scale_cum, S_o):
+        assert_bitexact(npy(a), s, 'cumulative S')
+    plan.close()
 
 
 # ---------------------------------------------------------------------------------------------

@@ -226,13 +226,14 @@ def test_sharded_equalization_two_ranks(tmp_path, emu_lib_path, name, seed, max_
         assert_bitexact(r0[k], v, 'canonical ' + k)
 
 
-@pytest.mark.parametrize('chunk', ['1', '3', '16'])
-def test_sharded_data_dependent_loop_in_chunks(tmp_path, emu_lib_path, monkeypatch, chunk):
+@pytest.mark.parametrize('chunk,cf_group', [('1', '4'), ('3', '4'), ('16', '4'), ('3', '1')])
+def test_sharded_data_dependent_loop_in_chunks(tmp_path, emu_lib_path, monkeypatch, chunk, cf_group):
     """the reference's own stopping rule (dfq.py:83-115) over the ranks' summed mean|dW| without a host round
     trip per sweep -- chunks of sweeps, ONE all_reduce of a chunk's per-sweep sums, the verdicts drawn on the device
     (dfq_le_shared_verdict), scratch tensors and scales taken back to the chunk's start when the loop stops inside a chunk.
     Whatever the chunk size: the oracle's sweep count, bit-exact cumulative scales, bit-equal ranks."""
     monkeypatch.setenv('DFQ_SHARD_CHUNK', chunk)
+    monkeypatch.setenv('DFQ_LE_CF_GROUP', cf_group)             # free-running segments of depth 4 / every layer on the general tiles (a small network's default)
     world, name, seed = 2, 'tiny_mobile', 0
     mp.spawn(_worker, args=(world, _free_port(), name, seed, None, str(tmp_path), emu_lib_path, False, False), nprocs=world, join=True)
     model, graph, bottoms, spec = _prepare(name, seed)
