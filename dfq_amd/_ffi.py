@@ -102,6 +102,7 @@ SIGNATURES = {
     'dfq_le_plan_defer_depth': (c_int32, [c_void_p]),
     'dfq_le_plan_free_running_elements': (c_int64, [c_void_p]),
     'dfq_le_plan_free_running_group': (c_int32, [c_void_p]),
+    'dfq_le_plan_lean_background': (c_int32, [c_void_p]),
     'dfq_le_plan_lean_tiles': (c_int32, [c_void_p]),
     'dfq_le_plan_lean_info': (c_int32, [c_void_p, c_int32, POINTER(c_int64)]),
     'dfq_le_plan_level_launches': (c_int32, [c_void_p, c_int32, POINTER(c_int64), POINTER(c_int64), POINTER(c_int32)]),

@@ -1633,6 +1633,7 @@ __global__ __launch_bounds__(kCtlBlock) void le_control_kernel(const LeLayerDiff
         state->sweeps = sweeps;
         state->last_diff_tmp = diff_tmp;
         state->done = go_on ? 0 : 1;
+        if (go_on) state->happen = sweeps;                   // sweep `sweeps` (the next one) happens
         if (before.log && before.sweeps < before.log_cap) before.log[before.sweeps] = diff_tmp;
     }
 }
@@ -1649,6 +1650,7 @@ __global__ void le_reset_kernel(LeState* states, int n_nets, double converge_thr
         state->last_diff_tmp = 0.0;
         const bool go_on = (10.0 > converge_thres) && (0 < converge_count) && (max_sweeps != 0);
         state->done = go_on ? 0 : 1;
+        state->happen = go_on ? 0 : -1;
     }
 }
 
@@ -1670,6 +1672,7 @@ __global__ void le_prepare_kernel(ClearArgs a, LeState* states, int n_nets, doub
         state->last_diff_tmp = 0.0;
         const bool go_on = (10.0 > converge_thres) && (0 < converge_count) && (max_sweeps != 0);
         state->done = go_on ? 0 : 1;
+        state->happen = go_on ? 0 : -1;
     }
 }
 
@@ -1881,7 +1884,13 @@ struct dfq_le_plan {
     float* d_cf_ring = nullptr;            // every relation's ring, back to back (set to 1 by the restart's first launch)
     int64_t cf_ring_floats = 0;
     int64_t fr_total = 0;                  // elements of free-running layers: read and written once per cf_group sweeps
-    int64_t part_stride = 0;               // doubles of one sweep's partial sums (the array exists cf_group times)
+    int64_t part_stride = 0;               // doubles of one sweep's partial sums (the array exists 2 * cf_group times: sweep j uses array j mod 2G)
+    // background mode of the lean launches (dfq_le_cf.hpp): a second, low-priority stream next to the group's sweep launches
+    bool cf_bg = false;
+    hipStream_t bg_stream = nullptr;
+    hipEvent_t bg_fork = nullptr;          // recorded on the caller's stream where a background launch may begin
+    hipEvent_t bg_done[2] = {nullptr, nullptr};   // recorded behind the background launch of group g in bg_done[g & 1] ...
+    int64_t bg_wait_at[2] = {-1, -1};      // ... which the convergence launch of THIS sweep (and nothing earlier) has to wait for; -1: none
     std::vector<int> lean_info;            // per lean tile: kind, rows, floats per row (dfq_le_plan_lean_info)
     // the sweep's workgroup table with the lean tiles woven in evenly (group depth kWeaveGroup, one launch per sweep): the launch
     // of a group's first sweep; null: the lean tiles get a launch of their own (le_lean_kernel)
@@ -1976,6 +1985,9 @@ void dfq_le_plan_destroy(dfq_le_plan* p) {
     p->mem.release();
     for (auto& g : p->graphs) (void)hipGraphExecDestroy(g.exec);
     if (p->capture_stream) (void)hipStreamDestroy(p->capture_stream);
+    if (p->bg_stream) (void)hipStreamDestroy(p->bg_stream);
+    if (p->bg_fork) (void)hipEventDestroy(p->bg_fork);
+    for (auto& e : p->bg_done) if (e) (void)hipEventDestroy(e);
     if (p->resident) le_resident_destroy(p->resident);
     delete p;
 }
@@ -2216,6 +2228,11 @@ int dfq_le_plan_create_batch(const dfq_layer* layers, int32_t n_layers, const in
             segments.push_back(seg);
         }
         if (segments.empty()) p->cf_group = 1;
+        // background mode of the lean launches (dfq_le_cf.hpp): OPT-IN, DFQ_LE_CF_BG=1 -- bit-identical and measured no faster
+        // (profiles/r06_experiments.txt 9); not with recorded graphs (a second stream inside a capture) and not with the woven build
+        const char* be = getenv("DFQ_LE_CF_BG");
+        const char* ge = getenv("DFQ_GRAPH");
+        p->cf_bg = p->cf_group > 1 && be && be[0] == '1' && !(ge && ge[0] == '1') && !kWeave;
     }
     // producer links + slot limits need every relation's geometry, so a second pass
     int tile_slot = 0;
@@ -2422,7 +2439,8 @@ int dfq_le_plan_create_batch(const dfq_layer* layers, int32_t n_layers, const in
     if ((e = p->mem.alloc((void**)&p->d_rels, sizeof(LeRelDev) * std::max(1, n_relations))) != hipSuccess) return fail_alloc(e);
     if ((e = p->mem.alloc((void**)&p->d_layer_diff, sizeof(LeLayerDiff) * n_layers)) != hipSuccess) return fail_alloc(e);
     p->part_stride = (int64_t)n_part;                // one array of partial sums per sweep of a group (dfq_le_cf.hpp)
-    if ((e = p->mem.alloc((void**)&p->d_partials, sizeof(double) * n_part * p->cf_group)) != hipSuccess) return fail_alloc(e);
+    const size_t part_ring = p->cf_group > 1 ? (size_t)2 * p->cf_group : 1;
+    if ((e = p->mem.alloc((void**)&p->d_partials, sizeof(double) * n_part * part_ring)) != hipSuccess) return fail_alloc(e);
     if ((e = p->mem.alloc((void**)&p->d_layer_mean, sizeof(double) * n_layers)) != hipSuccess) return fail_alloc(e);
     if ((e = p->mem.alloc((void**)&p->d_state, sizeof(LeState) * n_nets)) != hipSuccess) return fail_alloc(e);
     if ((e = p->mem.alloc((void**)&p->d_nets, sizeof(LeNetDesc) * n_nets)) != hipSuccess) return fail_alloc(e);
@@ -2430,7 +2448,7 @@ int dfq_le_plan_create_batch(const dfq_layer* layers, int32_t n_layers, const in
     if ((e = hipMemcpy(p->d_nets, nets.data(), sizeof(LeNetDesc) * n_nets, hipMemcpyHostToDevice)) != hipSuccess) return fail_alloc(e);
     if ((e = hipMemcpy(p->d_boot_map, boot_map.data(), sizeof(int32_t) * boot_map.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail_alloc(e);
     if ((e = hipMemcpy(p->d_layer_diff, ld.data(), sizeof(LeLayerDiff) * n_layers, hipMemcpyHostToDevice)) != hipSuccess) return fail_alloc(e);
-    if ((e = hipMemset(p->d_partials, 0, sizeof(double) * n_part * p->cf_group)) != hipSuccess) return fail_alloc(e);
+    if ((e = hipMemset(p->d_partials, 0, sizeof(double) * n_part * part_ring)) != hipSuccess) return fail_alloc(e);
     if ((e = hipMemset(p->d_state, 0, sizeof(LeState) * n_nets)) != hipSuccess) return fail_alloc(e);
     {
         // dependency links (see le_level_kernel): position of every relation in the level-sorted table
@@ -2536,7 +2554,7 @@ int dfq_le_plan_create_batch(const dfq_layer* layers, int32_t n_layers, const in
                 std::vector<int32_t> cf_map;
                 int64_t ring_floats = 0, state_floats = 0;
                 for (const auto& seg : segments)
-                    for (int r : seg) { ring_floats += (int64_t)4 * G * h[r].o1; state_floats += (int64_t)4 * h[r].o1; }
+                    for (int r : seg) { ring_floats += (int64_t)8 * G * h[r].o1; state_floats += (int64_t)4 * h[r].o1; }   // (ring: 4G sweeps x {s, 1/s})
                 float* d_ring = nullptr;
                 float* d_state = nullptr;
                 if ((e = p->mem.alloc((void**)&d_ring, sizeof(float) * ring_floats)) != hipSuccess) return fail_alloc(e);
@@ -2552,7 +2570,7 @@ int dfq_le_plan_create_batch(const dfq_layer* layers, int32_t n_layers, const in
                         const LeRelDev& d = sorted[pos[r]];
                         LeCfRel c;
                         memset(&c, 0, sizeof(c));
-                        c.ring = d_ring + ring_off; ring_off += (int64_t)4 * G * d.o1;
+                        c.ring = d_ring + ring_off; ring_off += (int64_t)8 * G * d.o1;
                         c.state = d_state + state_off; state_off += (int64_t)4 * d.o1;
                         c.boot_r1 = i == 0 ? d.r1 : nullptr;             // (parity 0: what the bootstrap launch writes)
                         c.boot_r2 = d.r2;
@@ -2796,6 +2814,8 @@ int32_t dfq_le_plan_defer_depth(const dfq_le_plan* p) { return (p && !res_on(p))
 // statistic is closed-form -- read and written once per `group` sweeps by le_lean_kernel; group 1 = none
 int64_t dfq_le_plan_free_running_elements(const dfq_le_plan* p) { return (p && !res_on(p)) ? p->fr_total : 0; }
 int32_t dfq_le_plan_free_running_group(const dfq_le_plan* p) { return (p && !res_on(p)) ? p->cf_group : 1; }
+// 1: the lean launches of the free-running layers run in the background (a second stream, two groups of look-ahead: dfq_le_cf.hpp)
+int32_t dfq_le_plan_lean_background(const dfq_le_plan* p) { return (p && !res_on(p) && p->cf_bg) ? 1 : 0; }
 int32_t dfq_le_plan_lean_tiles(const dfq_le_plan* p) { return (p && !res_on(p)) ? p->n_lean : 0; }
 // tile `tile` of the lean launch: out3 = kind (0/1 rows of 16-byte vectors / floats, 2 thread per row, 3/4 columns, 5 thread per
 // row of a chain's last layer), rows, floats per row
@@ -2867,8 +2887,11 @@ static LeParams plan_params(const dfq_le_plan* p, const dfq_le_config* cfg) {
     return q;
 }
 
+static int le_bg_join(dfq_le_plan* p, hipStream_t st);
 // reset the loop state, clear every stat word, recompute the stats of the untouched weights
 static int le_restart(dfq_le_plan* p, const dfq_le_config* cfg, hipStream_t st) {
+    int rcj = le_bg_join(p, st);
+    if (rcj) return rcj;
     {
         ClearArgs ca;
         ca.p[0] = (uint32_t*)p->d_dep; ca.words[0] = (long long)(2 * ((size_t)(2 * p->n_rels + 1) * kDepStride + 1));
@@ -2892,9 +2915,9 @@ static int le_restart(dfq_le_plan* p, const dfq_le_config* cfg, hipStream_t st) 
         DFQ_CHECK_LAUNCH();
     }
     if (p->cf_group > 1) {
-        // the factors of the first group's sweeps, from the scalars the bootstrap launch has just taken
+        // the factors of the first group's sweeps (background mode: of the first TWO groups'), from the scalars the bootstrap launch has just taken
         hipLaunchKernelGGL(le_cf_solve_kernel, dim3(p->n_cf_blocks), dim3(kCtlBlock), 0, st, (const LeCfSeg*)p->d_cf_segs,
-                           (const LeCfRel*)p->d_cf_rels, (const int32_t*)p->d_cf_map, plan_params(p, cfg), 0, p->cf_group, p->cf_group, 1,
+                           (const LeCfRel*)p->d_cf_rels, (const int32_t*)p->d_cf_map, plan_params(p, cfg), 0, (p->cf_bg ? 2 : 1) * p->cf_group, p->cf_group, 1,
                            (const LeState*)p->d_state);
         DFQ_CHECK_LAUNCH();
     }
@@ -2903,6 +2926,8 @@ static int le_restart(dfq_le_plan* p, const dfq_le_config* cfg, hipStream_t st) 
 
 // deferred stores: bring the weights up to date with the sweeps run so far (a no-op for networks whose last sweep stored)
 static int le_flush(dfq_le_plan* p, hipStream_t st) {
+    int rcj = le_bg_join(p, st);                     // (a background lean launch stores the values the write-back starts from)
+    if (rcj) return rcj;
     if (p->n_flush == 0) return DFQ_OK;
     hipLaunchKernelGGL(le_flush_kernel, dim3(p->n_flush), dim3(kBlock), 0, st, (const LeFlushRef*)p->d_flush, (const LeState*)p->d_state,
                        p->defer, p->cf_group);
@@ -2923,22 +2948,71 @@ static int le_flush(dfq_le_plan* p, hipStream_t st) {
 
 // partial sums of the sweep being enqueued (one array per sweep of a group: the lean tiles of a group's first sweep leave the
 // later sweeps' sums in theirs, dfq_le_cf.hpp)
-static double* sweep_partials(const dfq_le_plan* p) { return p->d_partials + (p->sweep_index & (p->cf_group - 1)) * p->part_stride; }
+static double* sweep_partials(const dfq_le_plan* p) { return p->d_partials + (p->cf_group > 1 ? (p->sweep_index & (2 * p->cf_group - 1)) : 0) * p->part_stride; }
 
 // the lean tiles of the free-running layers: at the first sweep of a group only
 // are the lean tiles part of the sweep's own launch?  (one launch per sweep on le_level_kernel only)
 static bool lean_woven(const dfq_le_plan* p) { return p->d_blocks_woven != nullptr && p->merged && p->sweep_grid == 0; }
-static int le_launch_lean(dfq_le_plan* p, hipStream_t st) {
+template <int MODE>
+static void le_lean_dispatch(const dfq_le_plan* p, const LeanArgs& a, hipStream_t st) {
+    if (p->cf_group == 2)
+        hipLaunchKernelGGL((le_lean_kernel<2, MODE>), dim3(p->n_lean), dim3(kBlock), 0, st, (const LeLeanRef*)p->d_lean, a, (const LeState*)p->d_state, p->d_partials);
+    else if (p->cf_group == 4)
+        hipLaunchKernelGGL((le_lean_kernel<4, MODE>), dim3(p->n_lean), dim3(kBlock), 0, st, (const LeLeanRef*)p->d_lean, a, (const LeState*)p->d_state, p->d_partials);
+    else
+        hipLaunchKernelGGL((le_lean_kernel<8, MODE>), dim3(p->n_lean), dim3(kBlock), 0, st, (const LeLeanRef*)p->d_lean, a, (const LeState*)p->d_state, p->d_partials);
+}
+// `in_line`: a background plan's launch on the caller's stream after all (the profiling entry points bracket every launch with
+// events; an in-order stream meets every deadline by itself)
+static int le_launch_lean(dfq_le_plan* p, hipStream_t st, bool in_line = false) {
     if (p->cf_group <= 1 || p->n_lean == 0 || (p->sweep_index & (p->cf_group - 1)) != 0 || lean_woven(p)) return DFQ_OK;
     LeanArgs a;
     a.k = (int32_t)p->sweep_index; a.pad = 0; a.part_stride = p->part_stride;
-    if (p->cf_group == 2)
-        hipLaunchKernelGGL(le_lean_kernel<2>, dim3(p->n_lean), dim3(kBlock), 0, st, (const LeLeanRef*)p->d_lean, a, (const LeState*)p->d_state, p->d_partials);
-    else if (p->cf_group == 4)
-        hipLaunchKernelGGL(le_lean_kernel<4>, dim3(p->n_lean), dim3(kBlock), 0, st, (const LeLeanRef*)p->d_lean, a, (const LeState*)p->d_state, p->d_partials);
-    else
-        hipLaunchKernelGGL(le_lean_kernel<8>, dim3(p->n_lean), dim3(kBlock), 0, st, (const LeLeanRef*)p->d_lean, a, (const LeState*)p->d_state, p->d_partials);
+    if (!p->cf_bg) {
+        le_lean_dispatch<kLeanInline>(p, a, st);
+    } else if (p->sweep_index == 0) {
+        le_lean_dispatch<kLeanFirst>(p, a, st);                 // the |dW| sums of the first two groups: nothing to overlap with yet
+    } else if (in_line) {
+        le_lean_dispatch<kLeanBg>(p, a, st);
+    } else {
+        // next to the sweep launches of this group, on the plan's own stream: it may begin where the caller's stream stands now
+        // (the verdict of sweep k-1, the factors, an earlier call's write-back), and the convergence launch of sweep k+G waits
+        // for it (le_bg_deadline) -- as does everything that touches the free-running layers or the rings (le_bg_join)
+        if (!p->bg_stream) {
+            int lo = 0, hi = 0;
+            DFQ_HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));        // (lo: the numerically largest = the lowest priority)
+            const char* pe = getenv("DFQ_LE_CF_BG_PRIO");
+            const int prio = (pe && pe[0] == 'h') ? hi : (pe && pe[0] == 'n') ? (lo + hi) / 2 : lo;     // (A/B: high / normal / low, the default)
+            DFQ_HIP_TRY(hipStreamCreateWithPriority(&p->bg_stream, hipStreamNonBlocking, prio));
+            DFQ_HIP_TRY(hipEventCreateWithFlags(&p->bg_fork, hipEventDisableTiming));
+            for (auto& e : p->bg_done) DFQ_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        }
+        const int which = (int)((p->sweep_index / p->cf_group) & 1);
+        DFQ_HIP_TRY(hipEventRecord(p->bg_fork, st));
+        DFQ_HIP_TRY(hipStreamWaitEvent(p->bg_stream, p->bg_fork, 0));
+        le_lean_dispatch<kLeanBg>(p, a, p->bg_stream);
+        DFQ_HIP_TRY(hipEventRecord(p->bg_done[which], p->bg_stream));
+        p->bg_wait_at[which] = p->sweep_index + p->cf_group;
+    }
     DFQ_CHECK_LAUNCH();
+    return DFQ_OK;
+}
+// the convergence launch of the sweep being enqueued reads |dW| sums a background launch leaves: wait for that one
+static int le_bg_deadline(dfq_le_plan* p, hipStream_t st) {
+    for (int i = 0; i < 2; ++i)
+        if (p->bg_wait_at[i] >= 0 && p->bg_wait_at[i] <= p->sweep_index) {
+            DFQ_HIP_TRY(hipStreamWaitEvent(st, p->bg_done[i], 0));
+            p->bg_wait_at[i] = -1;
+        }
+    return DFQ_OK;
+}
+// ... and so does whatever touches the free-running layers, the rings or the [O1] vectors next (write-back, restart)
+static int le_bg_join(dfq_le_plan* p, hipStream_t st) {
+    for (int i = 0; i < 2; ++i)
+        if (p->bg_wait_at[i] >= 0) {
+            DFQ_HIP_TRY(hipStreamWaitEvent(st, p->bg_done[i], 0));
+            p->bg_wait_at[i] = -1;
+        }
     return DFQ_OK;
 }
 
@@ -2980,9 +3054,12 @@ constexpr int kCtlHelpers = 224;           // workgroups that clear the statisti
 #endif
 static int le_launch_control(dfq_le_plan* p, const dfq_le_config* cfg, hipStream_t st) {
     const int n_clear = (int)std::min<int64_t>(kCtlHelpers, (p->stat_words + p->r1_zero_words + 8 * kCtlBlock - 1) / (8 * kCtlBlock));
-    // at the last sweep of a group: the solver workgroups of the free-running segments leave the next group's factors (dfq_le_cf.hpp)
+    // at the last sweep of a group: the solver workgroups of the free-running segments leave the next group's factors -- in
+    // background mode those of the group after the next (dfq_le_cf.hpp)
     const bool solve = p->cf_group > 1 && ((p->sweep_index + 1) & (p->cf_group - 1)) == 0;
     const int n_helpers = std::max(1, n_clear);
+    int rcb = le_bg_deadline(p, st);
+    if (rcb) return rcb;
     hipLaunchKernelGGL(le_control_kernel, dim3(p->n_nets + n_helpers + (solve ? p->n_cf_blocks : 0)), dim3(kCtlBlock), 0, st,
                        (const LeLayerDiff*)p->d_layer_diff, (const LeNetDesc*)p->d_nets, p->n_nets,
                        (const double*)sweep_partials(p), p->d_layer_mean, p->d_stats,
@@ -2990,7 +3067,7 @@ static int le_launch_control(dfq_le_plan* p, const dfq_le_config* cfg, hipStream
                        (int64_t)p->r1_zero_words, (int)(p->sweep_index & 1),
                        p->d_state, cfg->converge_thres, (int)cfg->converge_count, (int)cfg->max_sweeps, p->uni_layers, p->uni_tiles,
                        n_helpers, (const LeCfSeg*)p->d_cf_segs, (const LeCfRel*)p->d_cf_rels, (const int32_t*)p->d_cf_map,
-                       plan_params(p, cfg), (int)(p->sweep_index + 1), p->cf_group);
+                       plan_params(p, cfg), (int)(p->sweep_index + 1 + (p->cf_bg ? p->cf_group : 0)), p->cf_group);
     DFQ_CHECK_LAUNCH();
     p->sweep_index += 1;             // the control launch closes a sweep
     return DFQ_OK;
@@ -3102,7 +3179,7 @@ int dfq_le_profile(dfq_le_plan* p, const dfq_le_config* cfg, int32_t n_sweeps, v
         // the lean tiles of the free-running layers (first sweep of a group only, dfq_le_cf.hpp): a bracket of their own
         had_lean[s] = p->cf_group > 1 && p->n_lean > 0 && (p->sweep_index & (p->cf_group - 1)) == 0 && !lean_woven(p);
         DFQ_HIP_TRY(hipEventRecord(ev[k++], st));
-        if ((rc = le_launch_lean(p, st))) return rc;
+        if ((rc = le_launch_lean(p, st, true))) return rc;
         DFQ_HIP_TRY(hipEventRecord(ev[k++], st));
         for (int l = 0; l < n_levels; ++l) {
             DFQ_HIP_TRY(hipEventRecord(ev[k++], st));
@@ -3157,7 +3234,7 @@ int dfq_le_trace(dfq_le_plan* p, const dfq_le_config* cfg, int32_t launch, int32
     const char* te = getenv("DFQ_TRACE_SWEEP");    // default: the second sweep (steady-state stat flow)
     const int traced = (te && atoi(te) >= 0) ? atoi(te) : 1;
     for (int s = 0; s <= traced && !rc; ++s) {
-        rc = le_launch_lean(p, st);
+        rc = le_launch_lean(p, st, true);
         for (int l = 0; l < dfq_le_plan_levels(p) && !rc; ++l)
             rc = le_launch_level(p, l, q, st, (s == traced && l == launch) ? LeTrace{d, block, 0} : LeTrace{nullptr, 0, 0});
         if (!rc) rc = le_launch_control(p, cfg, st);
@@ -3189,7 +3266,7 @@ int dfq_le_trace_blocks(dfq_le_plan* p, const dfq_le_config* cfg, int32_t launch
     const char* te = getenv("DFQ_TRACE_SWEEP");
     const int traced = (te && atoi(te) >= 0) ? atoi(te) : 2;
     for (int s = 0; s <= traced && !rc; ++s) {
-        rc = le_launch_lean(p, st);
+        rc = le_launch_lean(p, st, true);
         for (int l = 0; l < dfq_le_plan_levels(p) && !rc; ++l)
             rc = le_launch_level(p, l, q, st, (s == traced && l == launch) ? LeTrace{d, -1, 0} : LeTrace{nullptr, 0, 0});
         if (!rc) rc = le_launch_control(p, cfg, st);

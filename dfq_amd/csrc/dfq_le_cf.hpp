@@ -27,6 +27,21 @@
 //   * a loop that stops inside a group leaves up to G-1 sweeps that are not in the stored values: le_flush_kernel applies them
 //     (as for the deferred stores of the general tiles) and le_cf_settle_kernel does the same for the relation's [O1] vectors
 //     and then sets the applied ring entries to 1, so that the next group's replay changes nothing.
+//   * BACKGROUND mode (late round 6; opt-in, DFQ_LE_CF_BG=1: built, bit-identical, measured NO FASTER -- a batch of 32 on one
+//     stream 1.783-1.786e10 weights/s against 1.777-1.780e10, with two batches in flight 1.62-1.64e10 against 1.80e10: the
+//     second queue's kernel shares the memory system with the sweep launch instead of waiting for its gaps, whatever the
+//     stream's priority, and the cross-queue waits cost the two-stream pipeline more than that returns; profiles/r06_experiments.txt 9).
+//     The lean launch above sits IN the sweep's chain of launches:
+//     ~100 us per 8 sweeps of a batch of 32 during which no general tile runs, while every sweep leaves ~20 us of launch
+//     boundaries (sweep launch -> convergence launch -> next sweep launch) in which the chip idles.  Nothing forces that order
+//     but the |dW| sums: so the tile looks ahead TWO groups.  The launch of group start k (kLeanBg) still stores the values
+//     after sweep k -- known to happen -- but leaves the |dW| sums of sweeps k+G .. k+2G-1; those of k .. k+G-1 were left by
+//     the launch before it (the first launch of a run, kLeanFirst, leaves 2G of them).  Its deadline is therefore the
+//     convergence launch of sweep k+G, a whole group away, and it runs on a second, low-priority stream next to that group's
+//     sweep launches (dfq_le.hip: le_launch_lean, le_bg_deadline, le_bg_join).  The factor ring holds four groups (the
+//     launch reads sweeps k-G+1 .. k+2G-1 while the solver may already be writing k+2G .. k+3G-1), the solver runs one group
+//     further ahead, the partial sums exist 2G times.  Same float32 operations per element in the same order, same float64
+//     partials per wave: bit-identical to the in-line mode, whatever the two streams' interleaving.
 // Every value, every |dW| term and every cumulative scale is bit-identical to the general tiles' (same float32 operations in the
 // same order per element); only the order in which the float64 partial sums are formed differs, as it does between tile shapes.
 #pragma once
@@ -38,7 +53,7 @@ constexpr int kCfMaxRel = 4;                    // relations per segment (longer
 
 // one relation of a free-running segment
 struct LeCfRel {
-    float* ring;               // [2G][2][o1]: s and 1/s of every channel for the sweeps of the current and the previous group
+    float* ring;               // [4G][2][o1]: s and 1/s of every channel for the sweeps of four consecutive groups (cf_slot)
     float* state;              // [4][o1]: (min, max) of the first layer's rows (segment start only), (min, max) of the second layer's columns
     const uint32_t* boot_r1;   // the bootstrap launch's words (parity 0), [o1][2] order-preserving (min, max); null unless segment start
     const uint32_t* boot_r2;
@@ -54,8 +69,21 @@ struct LeCfSeg {
     int32_t rel[kCfMaxRel];    // indices into the LeCfRel table, in sweep order
 };
 
-// slot of sweep `sweep` (may be negative by less than 2G) in a ring of 2G entries
-__device__ __forceinline__ int cf_slot(int sweep, int G) { return (sweep + 2 * G) & (2 * G - 1); }
+// slot of sweep `sweep` (may be negative by less than 4G) in a ring of 4G entries
+__device__ __forceinline__ int cf_slot(int sweep, int G) { return (sweep + 4 * G) & (4 * G - 1); }
+
+// what a lean launch does around its group's first sweep k (the stored values have seen the sweeps up to k-G):
+//   kLeanInline  replay k-G+1 .. k-1, apply k and store, look ahead k+1 .. k+G-1:   |dW| sums of k .. k+G-1
+//   kLeanFirst   (k = 0 of a background plan) ... look ahead 1 .. 2G-1:             |dW| sums of 0 .. 2G-1
+//   kLeanBg      ... look ahead k+1 .. k+2G-1:                                      |dW| sums of k+G .. k+2G-1
+enum { kLeanInline = 0, kLeanFirst = 1, kLeanBg = 2 };
+template <int G, int MODE>
+struct LeanShape {
+    static constexpr int LOOK = MODE == kLeanInline ? G : 2 * G;     // sweeps from k on (k included)
+    static constexpr int ACC0 = MODE == kLeanBg ? G : 0;             // the first of them whose |dW| sum is kept
+    static constexpr int NA = LOOK - ACC0;                           // sums kept
+    static constexpr int NT = G - 1 + LOOK;                          // factor sets: sweeps k-G+1 .. k+LOOK-1
+};
 
 // The recurrence: thread = one channel of one segment, `n_sweeps` sweeps starting at `k0`.  init: the scalars come from the
 // bootstrap launch's statistics words instead of the state arrays.
@@ -131,7 +159,7 @@ __global__ __launch_bounds__(1024) void le_cf_solve_kernel(const LeCfSeg* __rest
 // every ring entry 1 (a restart: the first group's replay must change nothing)
 __global__ __launch_bounds__(kBlock) void le_cf_ring_reset_kernel(const LeCfRel* __restrict__ rels, int G) {
     const LeCfRel& R = rels[blockIdx.x];
-    const int64_t n = (int64_t)4 * G * R.o1;
+    const int64_t n = (int64_t)8 * G * R.o1;
     for (int64_t i = threadIdx.x; i < n; i += kBlock) R.ring[i] = 1.0f;
 }
 
@@ -207,7 +235,7 @@ constexpr int kLeanWords = 28;
 struct LeanArgs {
     int32_t k;               // the group's first sweep (sweeps since the last restart)
     int32_t pad;
-    int64_t part_stride;     // doubles between the partial arrays of two sweeps of a group
+    int64_t part_stride;     // doubles between the partial arrays of two sweeps (2G arrays: sweep j uses array j mod 2G)
 };
 
 // the [O1] entries of channel c for the sweeps up to and including k (the later ones are not known to happen):
@@ -220,8 +248,8 @@ __device__ __forceinline__ LeanVec lean_vectors_load(const LeLeanRef& T, int c) 
     v.bnw = T.bnw ? T.bnw[c] : 0.f; v.bnb = T.bnb ? T.bnb[c] : 0.f; v.b1 = T.b1 ? T.b1[c] : 0.f;
     return v;
 }
-template <int G>
-__device__ __forceinline__ void lean_vectors_finish(const LeLeanRef& T, int c, LeanVec v, const float (&f)[2 * G - 1]) {
+template <int G, int NT>
+__device__ __forceinline__ void lean_vectors_finish(const LeLeanRef& T, int c, LeanVec v, const float (&f)[NT]) {
 #pragma unroll
     for (int j = 0; j < G; ++j) { v.cum = v.cum * f[j]; v.bnw = v.bnw * f[j]; v.bnb = v.bnb * f[j]; v.b1 = v.b1 * f[j]; }
     T.s_cum[c] = v.cum;
@@ -231,10 +259,11 @@ __device__ __forceinline__ void lean_vectors_finish(const LeLeanRef& T, int c, L
 }
 
 // rows * s: [nr x np] block, lanes along the row, a thread walks down the rows (as row_tile)
-template <int VEC, int G>
-__device__ __forceinline__ void lean_row(const LeLeanRef& T, const LeanArgs& A, float* sh_f, double (&acc)[G]) {
+template <int VEC, int G, int MODE>
+__device__ __forceinline__ void lean_row(const LeLeanRef& T, const LeanArgs& A, float* sh_f, double (&acc)[LeanShape<G, MODE>::NA]) {
+    typedef LeanShape<G, MODE> SH;
     constexpr int NV = kSlotsVec4;
-    constexpr int NT = 2 * G - 1;
+    constexpr int NT = SH::NT;
     const int tid = threadIdx.x;
     const int nr = T.nr;
     const int npv = T.np / VEC;
@@ -265,7 +294,7 @@ __device__ __forceinline__ void lean_row(const LeLeanRef& T, const LeanArgs& A, 
     if (tid < nr) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) sh_f[j * kCfTab + tid] = f[j];
-        if (T.s_cum) lean_vectors_finish<G>(T, c, vec, f);
+        if (T.s_cum) lean_vectors_finish<G, NT>(T, c, vec, f);
     }
     __syncthreads();
 #pragma unroll
@@ -287,13 +316,13 @@ __device__ __forceinline__ void lean_row(const LeLeanRef& T, const LeanArgs& A, 
 #pragma unroll
         for (int e = 0; e < VEC; ++e) nv[e] = x[e] * h[G - 1];  // sweep k: dfq.py:62
         if (ok) vstore<VEC>(w + r * T.stride, nv);
-        acc[0] += slot_abs_diff<VEC>(ok, nv, x);
+        if (SH::ACC0 == 0) acc[0] += slot_abs_diff<VEC>(ok, nv, x);
 #pragma unroll
-        for (int i = 1; i < G; ++i) {                          // sweeps k+1 .. k+G-1: their |dW| only
+        for (int i = 1; i < SH::LOOK; ++i) {                   // the sweeps behind k: their |dW| only (from ACC0 on)
             float y[VEC];
 #pragma unroll
             for (int e = 0; e < VEC; ++e) y[e] = nv[e] * h[G - 1 + i];
-            acc[i] += slot_abs_diff<VEC>(ok, y, nv);
+            if (i >= SH::ACC0) acc[i - SH::ACC0] += slot_abs_diff<VEC>(ok, y, nv);
 #pragma unroll
             for (int e = 0; e < VEC; ++e) nv[e] = y[e];
         }
@@ -301,10 +330,11 @@ __device__ __forceinline__ void lean_row(const LeLeanRef& T, const LeanArgs& A, 
 }
 
 // columns * 1/s: [nr x np] block, G2 = pow2 >= np / VEC lanes share a row (as col_tile)
-template <int VEC, int G>
-__device__ __forceinline__ void lean_col(const LeLeanRef& T, const LeanArgs& A, float* sh_f, int* sh_tab, double (&acc)[G]) {
+template <int VEC, int G, int MODE>
+__device__ __forceinline__ void lean_col(const LeLeanRef& T, const LeanArgs& A, float* sh_f, int* sh_tab, double (&acc)[LeanShape<G, MODE>::NA]) {
+    typedef LeanShape<G, MODE> SH;
     constexpr int NV = kSlotsVec4;
-    constexpr int NT = 2 * G - 1;
+    constexpr int NT = SH::NT;
     const int tid = threadIdx.x;
     const int nr = T.nr, np = T.np;
     const int npv = np / VEC;
@@ -366,13 +396,13 @@ __device__ __forceinline__ void lean_col(const LeLeanRef& T, const LeanArgs& A, 
 #pragma unroll
             for (int e = 0; e < VEC; ++e) nv[e] = x[e] * h[G - 1][e];       // sweep k: dfq.py:73
             if (ok) vstore<VEC>(w + r * T.stride, nv);
-            acc[0] += slot_abs_diff<VEC>(ok, nv, x);
+            if (SH::ACC0 == 0) acc[0] += slot_abs_diff<VEC>(ok, nv, x);
 #pragma unroll
-            for (int i = 1; i < G; ++i) {
+            for (int i = 1; i < SH::LOOK; ++i) {
                 float y[VEC];
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) y[e] = nv[e] * h[G - 1 + i][e];
-                acc[i] += slot_abs_diff<VEC>(ok, y, nv);
+                if (i >= SH::ACC0) acc[i - SH::ACC0] += slot_abs_diff<VEC>(ok, y, nv);
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) nv[e] = y[e];
             }
@@ -420,15 +450,15 @@ __device__ __forceinline__ void lean_col(const LeLeanRef& T, const LeanArgs& A, 
 #pragma unroll
             for (int e = 0; e < VEC; ++e) nv[e] = x[e] * tab[ci[e]];
             if (ok) vstore<VEC>(w + r * T.stride, nv);
-            acc[0] += slot_abs_diff<VEC>(ok, nv, x);
+            if (SH::ACC0 == 0) acc[0] += slot_abs_diff<VEC>(ok, nv, x);
         }
 #pragma unroll
-        for (int i = 1; i < G; ++i) {
+        for (int i = 1; i < SH::LOOK; ++i) {
             const float* tab = sh_f + (G - 1 + i) * kCfTab + t0;
             float y[VEC];
 #pragma unroll
             for (int e = 0; e < VEC; ++e) y[e] = nv[e] * tab[ci[e]];
-            acc[i] += slot_abs_diff<VEC>(ok, y, nv);
+            if (i >= SH::ACC0) acc[i - SH::ACC0] += slot_abs_diff<VEC>(ok, y, nv);
 #pragma unroll
             for (int e = 0; e < VEC; ++e) nv[e] = y[e];
         }
@@ -437,9 +467,10 @@ __device__ __forceinline__ void lean_col(const LeLeanRef& T, const LeanArgs& A, 
 
 // one THREAD per row (depthwise k x k kernels).  side 0: first layer of the relation (rows * s; behind a relation also * 1/s of
 // that one first: dfq.py:73 then dfq.py:62, two roundings); side 1: depthwise second layer at a chain's end (rows * 1/s).
-template <int side, int G>
-__device__ __forceinline__ void lean_short(const LeLeanRef& T, const LeanArgs& A, double (&acc)[G]) {
-    constexpr int NT = 2 * G - 1;
+template <int side, int G, int MODE>
+__device__ __forceinline__ void lean_short(const LeLeanRef& T, const LeanArgs& A, double (&acc)[LeanShape<G, MODE>::NA]) {
+    typedef LeanShape<G, MODE> SH;
+    constexpr int NT = SH::NT;
     const int tid = threadIdx.x;
     const bool ok = tid < T.nr;
     const int o = T.r0 + min(tid, T.nr - 1);
@@ -458,7 +489,7 @@ __device__ __forceinline__ void lean_short(const LeLeanRef& T, const LeanArgs& A
             pf[j] = fused ? prev[(int64_t)(2 * slot) * T.o1_prev] : 1.0f;                      // (* 1.0f is exact)
         }
     }
-    if (side == 0 && ok && T.s_cum) lean_vectors_finish<G>(T, c, lean_vectors_load(T, c), f);
+    if (side == 0 && ok && T.s_cum) lean_vectors_finish<G, NT>(T, c, lean_vectors_load(T, c), f);
     for (int k0 = 0; k0 < len; k0 += kShortChunk) {
         float x[kShortChunk];
 #pragma unroll
@@ -470,18 +501,18 @@ __device__ __forceinline__ void lean_short(const LeLeanRef& T, const LeanArgs& A
 #pragma unroll
             for (int j = 0; j < G - 1; ++j) { nv = nv * pf[j]; nv = nv * f[j]; }
 #pragma unroll
-            for (int i = 0; i < G; ++i) {
+            for (int i = 0; i < SH::LOOK; ++i) {
                 const float y = (nv * pf[G - 1 + i]) * f[G - 1 + i];
                 if (i == 0 && in) w[k0 + e] = y;
-                acc[i] += (double)abs_diff_if(in, y, nv);
+                if (i >= SH::ACC0) acc[i - SH::ACC0] += (double)abs_diff_if(in, y, nv);
                 nv = y;
             }
         }
     }
 }
 
-// tile `idx` of the lean table.  sh_f: (2G - 1) * kCfTab floats, sh_tab: kTileRowsMax ints of LDS.
-template <int G>
+// tile `idx` of the lean table.  sh_f: LeanShape::NT * kCfTab floats, sh_tab: kTileRowsMax ints of LDS.
+template <int G, int MODE = kLeanInline>
 __device__ __forceinline__ void lean_tile_run(const LeLeanRef* __restrict__ refs, int idx, const LeanArgs& A, const LeState* __restrict__ state,
                                               double* __restrict__ partials, float* sh_f, int* sh_tab) {
     const int lane = threadIdx.x % kWave;
@@ -502,34 +533,39 @@ __device__ __forceinline__ void lean_tile_run(const LeLeanRef* __restrict__ refs
         T.khkw = __builtin_amdgcn_readlane(word, 24); T.o1_prev = __builtin_amdgcn_readlane(word, 25);
         T.slot = __builtin_amdgcn_readlane(word, 26); T.pc_gi = __builtin_amdgcn_readlane(word, 27);
     }
-    if (state[T.net].done) return;                     // uniform
-    double acc[G];
+    typedef LeanShape<G, MODE> SH;
+    // Does sweep k happen?  In line, the launch sits behind the convergence launch of sweep k-1: `done` is what that one left.
+    // A background launch runs next to LATER convergence launches, which may raise `done` while some of its workgroups have
+    // not started yet: it asks for the token the convergence launch of sweep k-1 left instead ("sweep k happens": `happen`
+    // only grows during a run).  (uniform)
+    if (MODE == kLeanBg ? state[T.net].happen < A.k : state[T.net].done != 0) return;
+    double acc[SH::NA];
 #pragma unroll
-    for (int i = 0; i < G; ++i) acc[i] = 0.0;
+    for (int i = 0; i < SH::NA; ++i) acc[i] = 0.0;
     switch (T.kind) {
-        case kLeanRow4: lean_row<4, G>(T, A, sh_f, acc); break;
-        case kLeanRow1: lean_row<1, G>(T, A, sh_f, acc); break;
-        case kLeanShort0: lean_short<0, G>(T, A, acc); break;
-        case kLeanCol4: lean_col<4, G>(T, A, sh_f, sh_tab, acc); break;
-        case kLeanCol1: lean_col<1, G>(T, A, sh_f, sh_tab, acc); break;
-        default: lean_short<1, G>(T, A, acc); break;
+        case kLeanRow4: lean_row<4, G, MODE>(T, A, sh_f, acc); break;
+        case kLeanRow1: lean_row<1, G, MODE>(T, A, sh_f, acc); break;
+        case kLeanShort0: lean_short<0, G, MODE>(T, A, acc); break;
+        case kLeanCol4: lean_col<4, G, MODE>(T, A, sh_f, sh_tab, acc); break;
+        case kLeanCol1: lean_col<1, G, MODE>(T, A, sh_f, sh_tab, acc); break;
+        default: lean_short<1, G, MODE>(T, A, acc); break;
     }
-    // one partial per wave and sweep (fixed butterfly order -> deterministic); sweep k + i is read by ITS convergence launch
+    // one partial per wave and sweep (fixed butterfly order -> deterministic); sweep j is read by ITS convergence launch
 #pragma unroll
-    for (int i = 0; i < G; ++i) {
+    for (int i = 0; i < SH::NA; ++i) {
         const double t = wave_sum(acc[i]);
         if (lane == 0)
-            partials[(int64_t)((A.k + i) & (G - 1)) * A.part_stride + (int64_t)T.slot * (kBlock / kWave) + threadIdx.x / kWave] = t;
+            partials[(int64_t)((A.k + SH::ACC0 + i) & (2 * G - 1)) * A.part_stride + (int64_t)T.slot * (kBlock / kWave) + threadIdx.x / kWave] = t;
     }
 }
 
 // One launch per group of G sweeps: grid = the lean tiles of every free-running layer of the plan.  (With the default depth the
 // lean tiles are instead woven into the sweep's own launch at the group's first sweep -- le_level_kernel -- where their
 // arithmetic overlaps the general tiles' memory traffic; this kernel serves the other depths and the per-level launches.)
-template <int G>
+template <int G, int MODE>
 __global__ __launch_bounds__(kBlock) void le_lean_kernel(const LeLeanRef* __restrict__ refs, LeanArgs A, const LeState* __restrict__ state,
                                                          double* __restrict__ partials) {
-    __shared__ float sh_f[(2 * G - 1) * kCfTab];
+    __shared__ float sh_f[LeanShape<G, MODE>::NT * kCfTab];
     __shared__ int sh_tab[kTileRowsMax];
-    lean_tile_run<G>(refs, (int)blockIdx.x, A, state, partials, sh_f, sh_tab);
+    lean_tile_run<G, MODE>(refs, (int)blockIdx.x, A, state, partials, sh_f, sh_tab);
 }

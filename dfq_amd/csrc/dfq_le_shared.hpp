@@ -23,6 +23,10 @@ struct LeState {
     int32_t sweeps;
     int32_t done;
     int32_t log_cap;        // entries of `log` (0: none)
+    int32_t happen;         // streaming engine: the latest sweep KNOWN to happen (its predecessor's verdict was "go on"; 0 after a restart,
+                            // -1 when the loop is over before it began).  Only grows during a run: what a background lean launch asks
+                            // instead of `done`, which a later convergence launch may raise while it is still running (dfq_le_cf.hpp)
+    int32_t pad_;
     // optional: diff_tmp of sweep j (sweeps since the last restart) is also left in log[j] -- a sharded pass (dfq_amd/sharded.py)
     // runs chunks of sweeps without the reference's exit test and all-reduces a chunk's values in ONE collective
     // (dfq_le_set_diff_log; untouched by restarts)

@@ -198,6 +198,11 @@ class LEPlan:
         return _ffi.lib().dfq_le_plan_free_running_group(self._plan)
 
     @property
+    def lean_background(self):
+        """The lean launches of the free-running layers run on a second stream next to the sweep launches (include/dfq_hip.h)."""
+        return bool(_ffi.lib().dfq_le_plan_lean_background(self._plan))
+
+    @property
     def lean_tiles(self):
         return _ffi.lib().dfq_le_plan_lean_tiles(self._plan)
 
@@ -914,7 +919,7 @@ degraded_runs = {'le': 0, 'bc': 0}
 # every environment switch the library reads while it CREATES a plan (tests/test_errors.py checks this list against the sources)
 _PLAN_ENV = ('DFQ_LE_RESIDENT', 'DFQ_LE_MERGED', 'DFQ_LE_TILE_ELEMS', 'DFQ_LE_ROW_COLS', 'DFQ_LE_COL_COLS', 'DFQ_LE_BOOT_WORK',
              'DFQ_LE_PERSIST', 'DFQ_LE_SWEEP_WGS', 'DFQ_LE_EMIT_COLS', 'DFQ_LE_NO_SHORT', 'DFQ_LE_CHAIN_FIRST', 'DFQ_LE_POLL_NAPS',
-             'DFQ_LE_DEFER', 'DFQ_LE_CF', 'DFQ_LE_CF_GROUP', 'DFQ_LE_CF_WEAVE', 'DFQ_LE_FUSE', 'DFQ_LE_UNIFORM', 'DFQ_LE_LOCAL_R1', 'DFQ_LE_LOCAL_ROW', 'DFQ_RES_EXACT_GROUPS', 'DFQ_RES_RELAXED', 'DFQ_RES_ORDER', 'DFQ_RES_SPEC', 'DFQ_RES_CKPT',
+             'DFQ_LE_DEFER', 'DFQ_LE_CF', 'DFQ_LE_CF_GROUP', 'DFQ_LE_CF_BG', 'DFQ_LE_CF_BG_PRIO', 'DFQ_LE_CF_WEAVE', 'DFQ_LE_FUSE', 'DFQ_LE_UNIFORM', 'DFQ_LE_LOCAL_R1', 'DFQ_LE_LOCAL_ROW', 'DFQ_RES_EXACT_GROUPS', 'DFQ_RES_RELAXED', 'DFQ_RES_ORDER', 'DFQ_RES_SPEC', 'DFQ_RES_CKPT',
              'DFQ_RES_DIRECT', 'DFQ_RES_CF', 'DFQ_RES_SHORT_RPT', 'DFQ_RES_TILE_FLOATS', 'DFQ_BC_TAGGED', 'DFQ_BC_MERGED', 'DFQ_BC_BLOCKS', 'DFQ_BC_EPS', 'DFQ_BC_FOLD', 'DFQ_BC_MM_CHUNK', 'DFQ_BC_ONE_GROUP', 'DFQ_BC_ONE_LAUNCH', 'DFQ_BC_MM_AHEAD',
              'DFQ_GRAPH', 'DFQ_COOPERATIVE', 'DFQ_HIP_LIB')
 # ... and the ones it reads on every RUN (they change no plan)

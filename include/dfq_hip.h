@@ -160,6 +160,12 @@ int32_t dfq_le_plan_defer_depth(const dfq_le_plan* plan);
  * executed = 8 * rw + 4 * ro - 4 * deferred * (D - 1) / D + 8 * free_running / G.  Bit-identical values and sweep counts. */
 int64_t dfq_le_plan_free_running_elements(const dfq_le_plan* plan);
 int32_t dfq_le_plan_free_running_group(const dfq_le_plan* plan);
+/* 1: the lean launches run in the BACKGROUND (opt-in, DFQ_LE_CF_BG=1: bit-identical, measured no faster): a lean launch
+ * looks ahead two groups -- it leaves sum |W - W_prev| of the NEXT group's sweeps, this group's were left by the launch before --
+ * so its deadline is a whole group away and it runs on a second, low-priority stream of the plan next to the group's sweep
+ * launches, in the launch boundaries of the caller's stream (which waits for it where the sums are read and at every
+ * write-back; an enqueue call never returns with one in flight).  Same values, same sums, same sweep counts. */
+int32_t dfq_le_plan_lean_background(const dfq_le_plan* plan);
 int32_t dfq_le_plan_lean_tiles(const dfq_le_plan* plan);
 /* Tuning aid: tile `tile` of the lean launch.  out3 = { kind (0 / 1: rows * s in 16-byte vectors / floats, 2: one thread per
  * row, 3 / 4: columns * 1/s, 5: one thread per row of a chain's last layer), rows, floats per row }. */

@@ -227,6 +227,9 @@ typedef std::vector<std::function<void()>>* hipGraph_t;
 typedef std::vector<std::function<void()>>* hipGraphExec_t;
 enum hipStreamCaptureMode { hipStreamCaptureModeGlobal = 0, hipStreamCaptureModeThreadLocal = 1, hipStreamCaptureModeRelaxed = 2 };
 inline hipError_t hipStreamCreate(hipStream_t* s) { *s = nullptr; return hipSuccess; }
+#define hipStreamNonBlocking 1
+inline hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned, int) { *s = (hipStream_t)8; return hipSuccess; }   // (launches run at once, whatever the stream)
+inline hipError_t hipDeviceGetStreamPriorityRange(int* lo, int* hi) { *lo = 0; *hi = -1; return hipSuccess; }
 inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 inline hipError_t hipStreamBeginCapture(hipStream_t, hipStreamCaptureMode) {
     emu::capture = new std::vector<std::function<void()>>();

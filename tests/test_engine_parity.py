@@ -251,12 +251,15 @@ def _kat_names():
 # (DFQ_LE_CF=0); the persistent-workgroup variants of the general tiles run without free-running segments as well
 # 'streaming-fused': layers scaled along both axes are read once per sweep -- their row tiles merge the rows' statistics over the slabs
 # of a row block inside the launch (DFQ_LE_FUSE=1: the default of batched plans)
-LE_ENGINES = ['resident', 'resident-cf', 'streaming', 'streaming-cf2', 'streaming-cf8', 'streaming-general', 'streaming-fused', 'streaming-persistent', 'streaming-persistent-3wg']
+LE_ENGINES = ['resident', 'resident-cf', 'streaming', 'streaming-cf2', 'streaming-cf8', 'streaming-bg2', 'streaming-bg4', 'streaming-bg8', 'streaming-general', 'streaming-fused', 'streaming-persistent', 'streaming-persistent-3wg']
 
 
 def _select_le_engine(monkeypatch, le_engine):
-    for k in ('DFQ_LE_RESIDENT', 'DFQ_LE_PERSIST', 'DFQ_LE_SWEEP_WGS', 'DFQ_LE_TILE_ELEMS', 'DFQ_LE_CF', 'DFQ_LE_CF_GROUP', 'DFQ_LE_FUSE', 'DFQ_RES_CF'):
+    for k in ('DFQ_LE_RESIDENT', 'DFQ_LE_PERSIST', 'DFQ_LE_SWEEP_WGS', 'DFQ_LE_TILE_ELEMS', 'DFQ_LE_CF', 'DFQ_LE_CF_GROUP', 'DFQ_LE_CF_BG', 'DFQ_LE_FUSE', 'DFQ_RES_CF'):
         monkeypatch.delenv(k, raising=False)
+    if le_engine.startswith('streaming-bg'):     # the lean launches in the background: two groups of look-ahead, a second stream (dfq_le_cf.hpp)
+        monkeypatch.setenv('DFQ_LE_CF_GROUP', le_engine[len('streaming-bg'):])
+        monkeypatch.setenv('DFQ_LE_CF_BG', '1')
     if le_engine == 'resident-cf':              # closed-form column statistics of the chain ends (opt-in, dfq_le_resident.hip)
         monkeypatch.setenv('DFQ_RES_CF', '1')
     if le_engine == 'streaming-fused':
@@ -632,9 +635,15 @@ def test_full_row_tiles_take_their_own_statistics(engine, monkeypatch, merged, s
         assert_bitexact(out['1'][k], out['0'][k], k)
 
 
-def test_batched_plan_matches_separate_runs(engine):
+@pytest.mark.parametrize('background', [False, True])
+def test_batched_plan_matches_separate_runs(engine, monkeypatch, background):
     """Several networks in one plan (every launch covers the batch): each network must end exactly
-    where a plan of its own ends, including its own sweep count."""
+    where a plan of its own ends, including its own sweep count.  `background`: the lean launches of the free-running layers on
+    the plan's second stream, two groups of look-ahead (DFQ_LE_CF_BG=1, dfq_le_cf.hpp) -- networks of one batch stop at
+    different sweeps, i.e. inside different groups."""
+    monkeypatch.delenv('DFQ_LE_CF_BG', raising=False)
+    if background:
+        monkeypatch.setenv('DFQ_LE_CF_BG', '1')
     cases = [('tiny_mobile', 0, ''), ('tiny_cat', 0, ''), ('tiny_mobile', 1, '_abs'), ('tiny_res', 0, '')]
     items, specs = [], []
     for name, seed, suffix in cases:
@@ -646,7 +655,7 @@ def test_batched_plan_matches_separate_runs(engine):
         items.append((graph, rel.create_relation(graph, bottoms, TARG)))
         specs.append(spec)
     plan = dfq.build_le_plan_batch(items, TARG)
-    assert plan.n_nets == len(cases)
+    assert plan.n_nets == len(cases) and plan.lean_background == background and plan.free_running_group == 8
     plan.run()
     results, all_done = plan.query_all()
     assert all_done
@@ -1289,6 +1298,7 @@ def test_speculation_past_the_verdict_is_invisible(engine, monkeypatch, name, se
 # (the persistent-workgroup variant is slow on the CPU emulation: it runs at the default depth of batched plans only)
 @pytest.mark.parametrize('depth,le_engine', [('1', 'streaming-general'), ('2', 'streaming-general'), ('4', 'streaming-general'), ('4', 'streaming-persistent-3wg'),
                                              ('1', 'streaming'), ('4', 'streaming'), ('2', 'streaming-cf2'), ('4', 'streaming-cf8'),
+                                             ('4', 'streaming-bg2'), ('1', 'streaming-bg4'), ('4', 'streaming-bg8'),
                                              ('1', 'streaming-fused'), ('4', 'streaming-fused')])
 @pytest.mark.parametrize('name,seed,signed', [('tiny_mobile', 0, False), ('tiny_res', 0, False), ('tiny_cat', 3, True), ('tiny_tail', 1, False)])
 def test_deferred_stores_are_invisible(engine, monkeypatch, depth, le_engine, name, seed, signed):
@@ -1314,11 +1324,13 @@ def test_deferred_stores_are_invisible(engine, monkeypatch, depth, le_engine, na
             assert plan.sweep_bytes < 8 * plan.rw_elements + 4 * plan.ro_elements
     else:
         # the free-running segments (dfq_le_cf.hpp): layers whose every statistic is closed-form leave the sweep's launch
-        group = {'streaming': 4, 'streaming-cf2': 2, 'streaming-cf8': 8, 'streaming-fused': 4}[le_engine]
+        group = {'streaming': 4, 'streaming-cf2': 2, 'streaming-cf8': 8, 'streaming-fused': 4, 'streaming-bg2': 2, 'streaming-bg4': 4,
+                 'streaming-bg8': 8}[le_engine]
         if name in ('tiny_cat', 'tiny_tail'):   # (their chains run through dense layers scaled along both axes: nothing is free-running)
-            assert plan.free_running_group == 1 and plan.free_running_elements == 0
+            assert plan.free_running_group == 1 and plan.free_running_elements == 0 and not plan.lean_background
         else:
             assert plan.free_running_group == group and plan.free_running_elements > 0 and plan.lean_tiles > 0
+            assert plan.lean_background == le_engine.startswith('streaming-bg')
         assert plan.rw_elements + plan.free_running_elements <= plan.paired_elements
     plan.enqueue(0, restart=True, signed=signed)
     total = 0
