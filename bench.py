@@ -65,7 +65,10 @@ def parse():
     ap.add_argument('--net', default='mobilenet_v2', choices=NETS)
     ap.add_argument('--sweeps', type=int, default=0, help='pin the LE sweep count (0 = what the convergence test needs)')
     ap.add_argument('--cpu-seconds', type=float, default=10.0, help='CPU-baseline budget (0 disables)')
-    ap.add_argument('--batch', type=int, default=32, help='networks calibrated together in one step (one batched plan)')
+    ap.add_argument('--batch', type=int, default=64, help='networks calibrated together in one step (one batched plan).  64 since '
+                    'late round 6 (32 before): a sweep of the batch pays ~27 us of launch boundaries and convergence launch '
+                    'whatever the batch, so a larger batch is a larger share of bytes moved -- one box, full default run: 1.77e10 '
+                    'weights/s at 32, 1.95e10 at 64, 2.01e10 at 128 (119 s of wall time; 70 s at 64); profiles/r06_experiments.txt 10')
     ap.add_argument('--streams', type=int, default=2, help='steps in flight per GPU (one HIP stream + host thread each); '
                     'kernels with in-launch waits are serialised across streams by the library, the others overlap')
     ap.add_argument('--no-roofline', action='store_true')

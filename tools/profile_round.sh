@@ -9,7 +9,7 @@
 # Every step runs under `timeout`; nothing here reads stdin.
 R=${ROUND:-r06}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-B=${PROFILE_BATCH:-32}
+B=${PROFILE_BATCH:-64}
 if [ -z "$SKIP_BENCH" ]; then
 timeout 600 python bench.py > gpurun_out/${R}_bench_default.json 2> gpurun_out/${R}_bench_default.err < /dev/null
 fi
