@@ -198,7 +198,7 @@ def reference_cpu_record(net, full_sweeps=0, timed_sweeps=2):
 def _pmc_traffic(net, batch):
     """HBM bytes per launch of le_level_kernel from the committed PMC summary of a run with exactly this batch
     (rocprofv3 --pmc cannot run inside this process), else null."""
-    for name in ('r06_pmc_summary.json',):      # (older summaries describe a kernel that moved other bytes: not this round's traffic)
+    for name in ('r06_pmc_summary.json', 'r06_pmc_summary_batch32.json'):      # (older summaries describe a kernel that moved other bytes: not this round's traffic)
         path = os.path.join(ROOT, 'profiles', name)
         if net != 'mobilenet_v2' or not os.path.exists(path):
             continue
@@ -214,7 +214,7 @@ def _pmc_traffic(net, batch):
 def _pmc_kernel_traffic(kernel, net, batch):
     """Mean HBM bytes per DISPATCH of `kernel` from the committed PMC summary of a run at this batch size: FETCH_SIZE (KB,
     doubled as MI355X_MICROARCH.md prescribes) + WRITE_SIZE (KB), separate --pmc passes of tools/pmc_unit.py; else null."""
-    for name in ('r06_pmc_summary.json', 'r05_pmc_summary.json'):
+    for name in ('r06_pmc_summary.json', 'r06_pmc_summary_batch32.json', 'r05_pmc_summary.json'):
         path = os.path.join(ROOT, 'profiles', name)
         if net != 'mobilenet_v2' or not os.path.exists(path):
             continue

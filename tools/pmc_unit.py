@@ -18,6 +18,8 @@ ap.add_argument('--batch', type=int, default=32)
 ap.add_argument('--sweeps', type=int, default=4)
 ap.add_argument('--net', default='mobilenet_v2')
 ap.add_argument('--restarts', type=int, default=1, help='repeat the restart (bootstrap launch) this many times')
+ap.add_argument('--no-lazy', action='store_true', help='without the opt-in lazy-scale engine')
+ap.add_argument('--le-only', action='store_true', help='the equalisation launches only (a counter pass over everything aborted inside rocprofv3 at batch 64)')
 args = ap.parse_args()
 dev = torch.device('cuda', 0)
 protos = [bench.prepare(args.net, seed=i, dev=dev) for i in range(args.batch)]
@@ -31,9 +33,10 @@ else:
 for _ in range(args.restarts - 1):
     le.enqueue(0, restart=True, max_sweeps=args.sweeps, converge_thres=-1.0, converge_count=10 ** 9)
 le.enqueue(args.sweeps, restart=True, max_sweeps=args.sweeps, converge_thres=-1.0, converge_count=10 ** 9)
-bc.run()
+if not args.le_only:
+    bc.run()
 torch.cuda.synchronize()
-if args.batch > 1:      # the opt-in lazy-scale engine on a second set of the same networks (its kernels' counters: lz_stats_kernel, rebuild_kernel)
+if args.batch > 1 and not args.le_only and not args.no_lazy:      # the opt-in lazy-scale engine on a second set of the same networks (its kernels' counters: lz_stats_kernel, rebuild_kernel)
     import copy
     nets = [copy.deepcopy(p) for p in protos]
     lz = dfq.LazyLEPlan([(g, r) for (_, g, _, r) in nets], bench.TARG)

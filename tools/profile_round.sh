@@ -23,7 +23,7 @@ D=$(find gpurun_out/prof_$R -name "*domain_stats.csv" | head -1)
 [ -n "$D" ] && cp "$D" gpurun_out/${R}_bench_domain_stats.csv
 [ -n "$T" ] && timeout 120 python tools/rocprof_digest.py "$T" gpurun_out/${R}_bench_under_rocprof.json > gpurun_out/${R}_level_kernel_by_launch.csv < /dev/null
 [ -n "$T" ] && rm -f "$T"
-PMC_TIMEOUT=400 bash tools/pmc_level.sh --batch $B --sweeps 8 < /dev/null     # (8: one whole group of the free-running layers)
+PMC_TIMEOUT=200 bash tools/pmc_level.sh --batch $B --sweeps 8 --no-lazy < /dev/null     # (8: one whole group of the free-running layers; --no-lazy: with the opt-in lazy-scale engine in the process a counter pass at batch 64 aborts inside rocprofv3 -- "AQL packet is malformed")
 timeout 120 python tools/pmc_digest.py gpurun_out gpurun_out/${R}_bench_under_rocprof.json gpurun_out/${R}_pmc_summary.json < /dev/null | tail -12
 timeout 60 python tools/bench_line.py gpurun_out/${R}_bench_default.json gpurun_out/${R}_bench_under_rocprof.json < /dev/null
 tail -3 gpurun_out/pmc_FETCH_SIZE.log | cut -c1-300
