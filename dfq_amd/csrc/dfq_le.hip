@@ -2756,7 +2756,7 @@ int32_t dfq_le_plan_resident_tiles(const dfq_le_plan* p) { return res_on(p) ? le
 int32_t dfq_le_plan_degraded(const dfq_le_plan* p) { return p ? p->degraded : 0; }
 int32_t dfq_le_plan_uniform(const dfq_le_plan* p) { return (p && p->uni_layers > 0) ? 1 : 0; }
 int32_t dfq_le_plan_has_waits(const dfq_le_plan* p) {
-    return (p && !res_on(p) && p->n_rels > 0 && ((p->merged && p->levels.size() > 1) || p->has_slab_tiles)) ? 1 : 0;
+    return (p && !res_on(p) && p->n_rels > 0 && !p->h_blocks.empty() && ((p->merged && p->levels.size() > 1) || p->has_slab_tiles)) ? 1 : 0;
 }
 int dfq_le_plan_set_safe_mode(dfq_le_plan* p) {
     if (!p) return fail_arg("dfq_le_plan_set_safe_mode: null plan");
@@ -3088,7 +3088,10 @@ static int le_enqueue_direct(dfq_le_plan* p, const dfq_le_config* cfg, int n_swe
     // streams, two rounds): 1.437e10 weights/s against 1.472e10 -- an event record and a cross-stream wait per launch cost more than
     // the overlap returns.  Kept as a switch.
     static const bool guard_loop = !(getenv("DFQ_LE_GUARD_PER_LAUNCH") && getenv("DFQ_LE_GUARD_PER_LAUNCH")[0] == '1');
-    const bool guarded = (p->merged || p->has_slab_tiles) && !(p->capture_stream != nullptr && st == p->capture_stream);      // the NULL stream is a caller's stream too
+    // (a plan whose every layer is free-running -- ResNet-18 -- launches no sweep kernel at all: nothing waits, nothing to guard;
+    // the guard's event record showed as 6 us between the last convergence launch and the write-back of its 0.1 ms pass)
+    const bool guarded = (p->merged || p->has_slab_tiles) && !p->h_blocks.empty() &&
+                         !(p->capture_stream != nullptr && st == p->capture_stream);      // the NULL stream is a caller's stream too
     std::unique_ptr<SpinGuard> guard;
     if (guarded && guard_loop) guard.reset(new SpinGuard(st));
     for (int s = 0; s < n_sweeps; ++s) {
