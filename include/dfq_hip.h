@@ -151,7 +151,8 @@ int64_t dfq_le_plan_ro_elements(const dfq_le_plan* plan);
 int64_t dfq_le_plan_deferred_elements(const dfq_le_plan* plan);
 int32_t dfq_le_plan_defer_depth(const dfq_le_plan* plan);
 /* Free-running segments of the streaming engine (dfq_le_cf.hpp; DFQ_LE_CF=0 switches them off, DFQ_LE_CF_GROUP = G in
- * {2, 4, 8}, default 8 for a batched plan, 4 for a single network).  A chain of relations whose every consumed range is closed-form -- a chain's first layer (rows * s,
+ * {2, 4, 8}, default 8 for a batched plan, 4 for a single network of >= 6 M paired elements, none for a smaller one: its
+ * sweep is two launch latencies, and the lean launches only add to them).  A chain of relations whose every consumed range is closed-form -- a chain's first layer (rows * s,
  * dfq.py:62), depthwise layers in between, its last layer (columns * 1/s, dfq.py:73): max_i fl(w_i * s) == fl(max_i w_i * s)
  * -- has the scale factors of ALL its sweeps follow from a few scalars per channel (dfq.py:39-59 without reading a weight).
  * Its layers are not part of a sweep's launch: at the first sweep of every group of G sweeps ONE lean launch reads them, brings
