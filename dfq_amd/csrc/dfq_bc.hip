@@ -44,6 +44,7 @@ constexpr int kExpectMax = 8192;       // floats of E[x] kept in LDS (32 KiB)
 constexpr int kExpectSmall = 2048;     // ... by the kernel variant used when every step of a launch fits (8 KiB)
 constexpr int kRowsPerBlock = kBlock / kWave;   // output rows of the matvec per workgroup: one per wave
 constexpr int kBcRegs = 24;            // eps values a lane preloads (rows up to 1536 inputs per group)
+constexpr double kBcSkewDefault = 0.0; // chain positions a network of a batch runs behind the network in front of it (DFQ_BC_SKEW; see the plan)
 
 struct BcLayerDev {
     const float* w;
@@ -1281,6 +1282,32 @@ int dfq_bc_plan_create(const dfq_layer* layers, int32_t n_layers, const dfq_bc_s
             for (int b = 0; b < blocks_of[q]; ++b)
                 refs.push_back(BcChainRef{q, b, wait_of[q], wait_of[q] >= 0 ? blocks_of[wait_of[q]] : 0});
         }
+        // ---- a batch's networks SKEWED against each other (late round 6).  In position-major order every network of a batch is at
+        //      the same chain position at the same time: ~33 small positions that hand over at latency pace while the memory system
+        //      idles, then the three large ones (84 % of the weights) that stream while nothing hands over (profiles/r05_bc_chain.txt:
+        //      215 + 100 us for a batch of 32).  The workgroups are therefore listed by position + skew x network: network n runs
+        //      `skew` positions behind network n-1, so at any time some networks stream their large layers while others hand over.
+        //      Within a network the order of positions is what it was -- every workgroup's producers still have lower grid indices
+        //      (the in-launch waits stay deadlock-free) -- and a workgroup computes what it computed: results are bit-identical.
+        //      DFQ_BC_SKEW sets the skew (positions per network; 0: position-major). ----
+        std::vector<int> P_of(n_live, 0), net_rank_of(n_live, 0);
+        double skew = 0.0;
+        {
+            std::vector<int> nets_seen;
+            for (int s2 = 0; s2 < n_steps; ++s2) {
+                if (ordinal[s2] < 0) continue;
+                P_of[pos[s2]] = ordinal[s2];
+                auto it = std::find(nets_seen.begin(), nets_seen.end(), (int)steps[s2].net);
+                if (it == nets_seen.end()) { nets_seen.push_back((int)steps[s2].net); it = nets_seen.end() - 1; }
+                net_rank_of[pos[s2]] = (int)(it - nets_seen.begin());
+            }
+            const char* se = getenv("DFQ_BC_SKEW");
+            skew = se ? atof(se) : kBcSkewDefault;
+            if (nets_seen.size() < 2 || !(skew > 0.0)) skew = 0.0;
+        }
+        auto key_of = [&](int q) { return (double)P_of[q] + skew * (double)net_rank_of[q]; };
+        if (skew > 0.0)
+            std::stable_sort(refs.begin(), refs.end(), [&](const BcChainRef& a, const BcChainRef& b) { return key_of(a.step) < key_of(b.step); });
         p->chain_blocks = (int)refs.size();
         if ((e = p->mem.alloc((void**)&p->d_refs, sizeof(BcChainRef) * std::max<size_t>(1, refs.size()))) != hipSuccess) return fail_alloc(e);
         if ((e = hipMemcpy(p->d_refs, refs.data(), sizeof(BcChainRef) * refs.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail_alloc(e);
@@ -1334,12 +1361,32 @@ int dfq_bc_plan_create(const dfq_layer* layers, int32_t n_layers, const dfq_bc_s
                     fused.reserve(refs.size() + (size_t)mmb[n_steps] + cache_blocks_launch);
                     auto emit_mm = [&](int P) { if (P < n_launch) for (int b : mm_of[P]) fused.push_back(BcChainRef{-1, b, -1, 0}); };
                     for (int b = 0; b < cache_blocks_launch; ++b) fused.push_back(BcChainRef{-2, b, -1, 0});
-                    for (int P = 0; P < std::min(ahead, n_launch); ++P) emit_mm(P);
                     size_t r = 0;
-                    for (int P = 0; P < n_launch; ++P) {
-                        emit_mm(P + ahead);
-                        const int q_end = p->launches[P].begin + p->launches[P].n;
-                        for (; r < refs.size() && refs[r].step < q_end; ++r) fused.push_back(refs[r]);
+                    if (skew > 0.0) {
+                        // skewed networks (above): a layer's min/max blocks lie `ahead` positions in front of the workgroups of ITS
+                        // network's step that needs them -- merge the two sorted lists
+                        struct MmItem { double key; int block; };
+                        std::vector<MmItem> mm_items;
+                        for (int s2 = 0; s2 < n_steps; ++s2) {
+                            const int host = ordinal[s2] >= 0 ? s2 : folded_into[s2];
+                            const double k = key_of(pos[host]) - (double)ahead;
+                            for (int b = mmb[s2]; b < mmb[s2 + 1]; ++b) mm_items.push_back(MmItem{k, b});
+                        }
+                        std::stable_sort(mm_items.begin(), mm_items.end(), [](const MmItem& a, const MmItem& b) { return a.key < b.key; });
+                        size_t m = 0;
+                        for (; r < refs.size(); ++r) {
+                            const double k = key_of(refs[r].step);
+                            for (; m < mm_items.size() && mm_items[m].key <= k; ++m) fused.push_back(BcChainRef{-1, mm_items[m].block, -1, 0});
+                            fused.push_back(refs[r]);
+                        }
+                        for (; m < mm_items.size(); ++m) fused.push_back(BcChainRef{-1, mm_items[m].block, -1, 0});
+                    } else {
+                        for (int P = 0; P < std::min(ahead, n_launch); ++P) emit_mm(P);
+                        for (int P = 0; P < n_launch; ++P) {
+                            emit_mm(P + ahead);
+                            const int q_end = p->launches[P].begin + p->launches[P].n;
+                            for (; r < refs.size() && refs[r].step < q_end; ++r) fused.push_back(refs[r]);
+                        }
                     }
                     if (r == refs.size() && fused.size() == refs.size() + (size_t)mmb[n_steps] + cache_blocks_launch) {
                         p->chain_blocks_fused = (int)fused.size();

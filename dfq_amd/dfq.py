@@ -920,7 +920,7 @@ degraded_runs = {'le': 0, 'bc': 0}
 _PLAN_ENV = ('DFQ_LE_RESIDENT', 'DFQ_LE_MERGED', 'DFQ_LE_TILE_ELEMS', 'DFQ_LE_ROW_COLS', 'DFQ_LE_COL_COLS', 'DFQ_LE_BOOT_WORK',
              'DFQ_LE_PERSIST', 'DFQ_LE_SWEEP_WGS', 'DFQ_LE_EMIT_COLS', 'DFQ_LE_NO_SHORT', 'DFQ_LE_CHAIN_FIRST', 'DFQ_LE_POLL_NAPS',
              'DFQ_LE_DEFER', 'DFQ_LE_CF', 'DFQ_LE_CF_GROUP', 'DFQ_LE_CF_BG', 'DFQ_LE_CF_BG_PRIO', 'DFQ_LE_CF_WEAVE', 'DFQ_LE_FUSE', 'DFQ_LE_UNIFORM', 'DFQ_LE_LOCAL_R1', 'DFQ_LE_LOCAL_ROW', 'DFQ_RES_EXACT_GROUPS', 'DFQ_RES_RELAXED', 'DFQ_RES_ORDER', 'DFQ_RES_SPEC', 'DFQ_RES_CKPT',
-             'DFQ_RES_DIRECT', 'DFQ_RES_CF', 'DFQ_RES_SHORT_RPT', 'DFQ_RES_TILE_FLOATS', 'DFQ_BC_TAGGED', 'DFQ_BC_MERGED', 'DFQ_BC_BLOCKS', 'DFQ_BC_EPS', 'DFQ_BC_FOLD', 'DFQ_BC_MM_CHUNK', 'DFQ_BC_ONE_GROUP', 'DFQ_BC_ONE_LAUNCH', 'DFQ_BC_MM_AHEAD',
+             'DFQ_RES_DIRECT', 'DFQ_RES_CF', 'DFQ_RES_SHORT_RPT', 'DFQ_RES_TILE_FLOATS', 'DFQ_BC_TAGGED', 'DFQ_BC_MERGED', 'DFQ_BC_BLOCKS', 'DFQ_BC_EPS', 'DFQ_BC_FOLD', 'DFQ_BC_MM_CHUNK', 'DFQ_BC_ONE_GROUP', 'DFQ_BC_ONE_LAUNCH', 'DFQ_BC_MM_AHEAD', 'DFQ_BC_SKEW',
              'DFQ_GRAPH', 'DFQ_COOPERATIVE', 'DFQ_HIP_LIB')
 # ... and the ones it reads on every RUN (they change no plan)
 _RUN_ENV = ('DFQ_SPIN_LIMIT', 'DFQ_TRACE_SWEEP', 'DFQ_PLAN_TIMING', 'DFQ_POOL_MB', 'DFQ_LE_GUARD_PER_LAUNCH')     # the last two: diagnostics / where a plan's tables are allocated

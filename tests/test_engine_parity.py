@@ -669,9 +669,16 @@ def test_batched_plan_matches_separate_runs(engine, monkeypatch, background):
             assert_bitexact(npy(r.get_scale_vec()), s)
 
 
-def test_batched_bias_correction_matches_separate_runs(engine):
+@pytest.mark.parametrize('skew,one_launch', [('0', None), ('0.5', None), ('3', '1'), ('0.25', '0'), ('40', '1')])
+def test_batched_bias_correction_matches_separate_runs(engine, monkeypatch, skew, one_launch):
     """The j-th correction steps of all networks of a batch share one launch; every network must get
-    exactly what its own plan gives it."""
+    exactly what its own plan gives it.  `skew` (DFQ_BC_SKEW): the networks of the batch run that many chain positions behind
+    each other in the launch's workgroup order (dfq_bc.hip: some stream their large layers while others hand over) -- the order
+    of the workgroups changes, no result does; with and without the min/max blocks woven into the launch."""
+    monkeypatch.setenv('DFQ_BC_SKEW', skew)
+    monkeypatch.delenv('DFQ_BC_ONE_LAUNCH', raising=False)
+    if one_launch is not None:
+        monkeypatch.setenv('DFQ_BC_ONE_LAUNCH', one_launch)
     cases = [('tiny_mobile', 0, ''), ('tiny_cat', 0, ''), ('tiny_res', 0, '')]
     items, singles = [], []
     for name, seed, suffix in cases:
