@@ -320,9 +320,13 @@ _SHAPES = [
 ]
 
 
+# (one pair, one sweep: a group depth or the background mode makes no difference to the tiles that run -- one engine per tile body)
+_SHAPE_ENGINES = [e for e in LE_ENGINES if e not in ('resident-cf', 'streaming-cf2', 'streaming-bg2', 'streaming-bg8')]
+
+
 @pytest.mark.parametrize('s1,s2', _SHAPES)
 @pytest.mark.parametrize('signed', [False, True])
-@pytest.mark.parametrize('le_engine', LE_ENGINES)
+@pytest.mark.parametrize('le_engine', _SHAPE_ENGINES)
 def test_layer_equalization_shapes(engine, monkeypatch, s1, s2, signed, le_engine):
     """One sweep of one pair over the tile kinds of both equalisation engines (a single pair would always take the
     resident launch: DFQ_LE_RESIDENT=0 forces the streaming kernel), bit-exact against the oracle."""
@@ -372,14 +376,14 @@ def _random_pair(rng):
 
 @pytest.mark.parametrize('le_engine,boot_work', [('resident', None), ('streaming', None), ('streaming', 50)])
 def test_layer_equalization_random_geometries(engine, monkeypatch, le_engine, boot_work):
-    """Random pairings (60 per engine on the GPU; 10, or 2 for the resident launch, on the CPU emulation, which is slow) -- odd sizes, rows shorter than a vector and longer than a wave of vectors, fewer
+    """Random pairings (60 per engine on the GPU; 8, or 1 for the resident launch, on the CPU emulation, which is slow) -- odd sizes, rows shorter than a vector and longer than a wave of vectors, fewer
     channels than a bootstrap block and several blocks, slices of a block shared by several workgroups -- bit-exact against
     the oracle, three sweeps each (the second and third use the statistics the first one forwarded)."""
     _select_le_engine(monkeypatch, le_engine)
     if boot_work:
         monkeypatch.setenv('DFQ_LE_BOOT_WORK', str(boot_work))
     rng = np.random.default_rng(20260926)
-    for case in range(60 if engine.device.type == 'cuda' else (2 if le_engine == 'resident' else 10)):
+    for case in range(60 if engine.device.type == 'cuda' else (1 if le_engine == 'resident' else 8)):
         s1, s2 = _random_pair(rng)
         signed = bool(rng.integers(0, 2))
         w1 = rng.standard_normal(s1).astype(F32)
@@ -1303,11 +1307,19 @@ def test_speculation_past_the_verdict_is_invisible(engine, monkeypatch, name, se
 
 
 # (the persistent-workgroup variant is slow on the CPU emulation: it runs at the default depth of batched plans only)
-@pytest.mark.parametrize('depth,le_engine', [('1', 'streaming-general'), ('2', 'streaming-general'), ('4', 'streaming-general'), ('4', 'streaming-persistent-3wg'),
-                                             ('1', 'streaming'), ('4', 'streaming'), ('2', 'streaming-cf2'), ('4', 'streaming-cf8'),
-                                             ('4', 'streaming-bg2'), ('1', 'streaming-bg4'), ('4', 'streaming-bg8'),
-                                             ('1', 'streaming-fused'), ('4', 'streaming-fused')])
-@pytest.mark.parametrize('name,seed,signed', [('tiny_mobile', 0, False), ('tiny_res', 0, False), ('tiny_cat', 3, True), ('tiny_tail', 1, False)])
+# Every (depth, engine) pair on tiny_mobile -- the network with free-running segments AND deferred one-way layers; a cross-section on
+# the others (the whole product was 52 cases and a third of the CPU suite's time).
+_DEFER_ENGINES = [('1', 'streaming-general'), ('2', 'streaming-general'), ('4', 'streaming-general'), ('4', 'streaming-persistent-3wg'),
+                  ('1', 'streaming'), ('4', 'streaming'), ('2', 'streaming-cf2'), ('4', 'streaming-cf8'),
+                  ('4', 'streaming-bg2'), ('1', 'streaming-bg4'), ('4', 'streaming-bg8'),
+                  ('1', 'streaming-fused'), ('4', 'streaming-fused')]
+_DEFER_CASES = ([(d, e, 'tiny_mobile', 0, False) for d, e in _DEFER_ENGINES] +
+                [(d, e, 'tiny_res', 0, False) for d, e in [('1', 'streaming-general'), ('4', 'streaming-cf8'), ('4', 'streaming-bg2')]] +
+                [(d, e, 'tiny_cat', 3, True) for d, e in [('4', 'streaming-general'), ('4', 'streaming'), ('1', 'streaming-fused')]] +
+                [(d, e, 'tiny_tail', 1, False) for d, e in [('4', 'streaming'), ('4', 'streaming-bg8')]])
+
+
+@pytest.mark.parametrize('depth,le_engine,name,seed,signed', _DEFER_CASES)
 def test_deferred_stores_are_invisible(engine, monkeypatch, depth, le_engine, name, seed, signed):
     """Streaming engine, DFQ_LE_DEFER = depth: layers that are scaled one way only are stored every depth-th sweep and
     re-derived from the stored values and the remembered factors in between (dfq_le.hip).  Whatever the depth and however
@@ -1469,8 +1481,8 @@ def test_lazy_scale_batch_with_different_sweep_counts(engine):
 # ---------------------------------------------------------------------------------------------
 # round 5: layers of SEVERAL tiles on the CPU emulation (statistics merged over row blocks: strict arrivals)
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize('closed_form', [False, True])
-@pytest.mark.parametrize('tile_floats,spec', [('8192', '2'), ('2048', '0'), ('1024', '4')])
+@pytest.mark.parametrize('tile_floats,spec,closed_form', [('8192', '2', False), ('2048', '0', False), ('1024', '4', False),
+                                                          ('2048', '0', True)])
 def test_column_statistics_merged_over_row_blocks(engine, monkeypatch, tile_floats, spec, closed_form):
     """A layer cut into several row blocks merges its per-input-channel (min, max) over them every sweep (atomicMax into shared
     tagged words, a strict arrival on the layer's counter).  Until round 5 only the full-size networks had such layers, i.e. only the
